@@ -1,0 +1,206 @@
+/*
+ * vtx.h — C ABI of the MI355X-native VarTrix genotyping hot path.
+ *
+ * This is the drop-in boundary for the reference's per-locus hot path.  The
+ * reference (10XGenomics/vartrix v1.1.22, one Rust file) has no FFI of its own;
+ * the seam this library replaces is the rayon map over chunks of variant loci
+ *
+ *     src/main.rs:279-291   pool.install(|| rec_chunks.par_iter()
+ *                               .map_with(rdr, |r, c| evaluate_chunk(c, r, &args)).collect())
+ *     src/main.rs:596-607   evaluate_chunk -> Vec<(usize, EvaluateAlnResults)>
+ *
+ * plus its consumer, the single-threaded merge loop src/main.rs:320-348 that
+ * turns per-locus Scores into matrix triplets.  The host keeps BAM/VCF/FASTA
+ * ingest, read filtering (src/main.rs:829-895) and haplotype construction
+ * (src/main.rs:958-994) and hands this library *packed batches*:
+ *
+ *   hap arena   : REF and ALT haplotype byte strings of every locus
+ *   read arena  : bases of every read that reached the aligner (src/main.rs:896)
+ *   records     : one per (locus, read) = one `Scores` entry of the reference
+ *                 (src/main.rs:996-1001), carrying cell_index and an interned
+ *                 UMI id instead of the UMI bytes (only UMI equality is used,
+ *                 src/main.rs:1053-1056)
+ *   loci        : matrix row + the record range + hap offsets of each locus
+ *
+ * and receives (a) the two Smith-Waterman scores per record — the inner seam
+ * src/main.rs:898-901/926-927 — and (b) the matrix triplets of
+ * consensus_scoring / alt_frac / coverage (src/main.rs:1111-1164) in the
+ * insertion order of the merge loop (row ascending, then cell_index ascending,
+ * src/main.rs:320-348 + :932).
+ *
+ * Conventions: plain C, no exceptions cross the boundary, every entry point
+ * returns 0 (VTX_OK) or a negative vtx_status; vtx_strerror gives the message.
+ * Inputs are borrowed for the duration of the call only.  Outputs returned by
+ * pointer are owned by the context and stay valid until the next vtx_run /
+ * vtx_destroy on that context.  A context is bound to one HIP device and is
+ * not thread-safe; distinct contexts are independent (one per GPU / per host
+ * thread — the analogue of one rayon worker, src/main.rs:466-473).
+ *
+ * There is NO CPU fallback in this library: every compute entry point needs a
+ * gfx950 device and fails with VTX_E_NODEVICE otherwise.
+ */
+#ifndef VTX_H
+#define VTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VTX_ABI_VERSION 1
+
+typedef enum vtx_status {
+    VTX_OK = 0,
+    VTX_E_INVAL = -1,      /* bad argument / malformed batch                      */
+    VTX_E_NODEVICE = -2,   /* no usable HIP device (the library has no CPU path)  */
+    VTX_E_HIP = -3,        /* a HIP runtime call failed                           */
+    VTX_E_NOMEM = -4,      /* host or device allocation failed                    */
+    VTX_E_UNSUPPORTED = -5,/* valid request this build cannot serve               */
+    VTX_E_STATE = -6       /* call sequence error (e.g. fetch before run)         */
+} vtx_status;
+
+/* Which restatement of bio::alignment::pairwise::banded::Aligner::local
+ * (crate bio 0.30.0, called at src/main.rs:899-901) is computed.            */
+typedef enum vtx_aligner {
+    VTX_ALIGNER_BANDED = 0, /* k-mer seeded band (K=6, W=20, src/main.rs:33-34) */
+    VTX_ALIGNER_FULL = 1    /* full-matrix affine local SW                      */
+} vtx_aligner;
+
+/* --scoring-method, src/main.rs:89-94 / :323-346 */
+typedef enum vtx_scoring_mode {
+    VTX_MODE_CONSENSUS = 0, /* consensus_scoring src/main.rs:1111-1129 */
+    VTX_MODE_ALT_FRAC = 1,  /* alt_frac          src/main.rs:1131-1145 */
+    VTX_MODE_COVERAGE = 2   /* coverage          src/main.rs:1147-1164 */
+} vtx_scoring_mode;
+
+/* Compile-time constants of the reference (src/main.rs:27-38) made explicit.
+ * vtx_config_default() fills the reference's values.                        */
+typedef struct vtx_config {
+    int32_t abi_version;   /* must be VTX_ABI_VERSION                           */
+    int32_t device;        /* HIP device ordinal                                */
+    int32_t aligner;       /* vtx_aligner                                       */
+    int32_t scoring_mode;  /* vtx_scoring_mode                                  */
+    int32_t use_umi;       /* --umi, src/main.rs:121-123                        */
+    int32_t match_score;   /* MATCH      =  1  src/main.rs:35                   */
+    int32_t mismatch_score;/* MISMATCH   = -5  src/main.rs:36                   */
+    int32_t gap_open;      /* GAP_OPEN   = -5  src/main.rs:37                   */
+    int32_t gap_extend;    /* GAP_EXTEND = -1  src/main.rs:38                   */
+    int32_t min_score;     /* MIN_SCORE  = 25  src/main.rs:30                   */
+    int32_t kmer_k;        /* K = 6            src/main.rs:33                   */
+    int32_t band_w;        /* W = 20           src/main.rs:34                   */
+    uint32_t n_barcodes;   /* matrix columns (cell_barcodes.len(), :247)        */
+    uint32_t reserved;
+} vtx_config;
+
+/* One variant locus = one VCF record that reached evaluate_alns
+ * (src/main.rs:686).  Skipped loci (multi-allelic :646-653, invalid ALT
+ * haplotype :675-684) are simply not submitted; their matrix row stays empty. */
+typedef struct vtx_locus {
+    uint32_t row;        /* RecHolder.i — matrix row, src/main.rs:226-228        */
+    uint32_t rec_begin;  /* first record of this locus in records[]             */
+    uint32_t rec_count;  /* number of records (reads that reached the aligner)  */
+    uint32_t ref_off;    /* REF haplotype bytes in hap_arena (src/main.rs:984)  */
+    uint32_t ref_len;
+    uint32_t alt_off;    /* ALT haplotype bytes in hap_arena (src/main.rs:977-981) */
+    uint32_t alt_len;
+    uint32_t reserved;
+} vtx_locus;
+
+/* One scored read at one locus = one `Scores` of the reference
+ * (src/main.rs:923-930) before alignment.  Within a locus, records MUST be
+ * ordered by (cell_index, umi_id) ascending — the reference's stable sort by
+ * cell_index (src/main.rs:932) followed by the per-cell UMI HashMap
+ * (src/main.rs:1047-1057), whose iteration order never reaches the output.   */
+typedef struct vtx_record {
+    uint32_t read_off;   /* read bases in read_arena (rec.seq().as_bytes(), :896) */
+    uint32_t read_len;
+    uint32_t cell_index; /* column, get_cell_barcode src/main.rs:737-750         */
+    uint32_t umi_id;     /* interned UB bytes; any value when !use_umi           */
+} vtx_record;
+
+typedef struct vtx_batch {
+    const vtx_locus* loci;
+    uint32_t n_loci;
+    const vtx_record* records;
+    uint32_t n_records;
+    const uint8_t* hap_arena;   /* ASCII bytes; compared by byte equality (:898)  */
+    uint64_t hap_bytes;
+    const uint8_t* read_arena;  /* ASCII bytes as produced by BAM seq decoding    */
+    uint64_t read_bytes;
+} vtx_batch;
+
+/* Matrix triplets in merge-loop order (src/main.rs:320-348).  `alt`, `ref`,
+ * `unk` are the CellCounts of convert_to_counts (src/main.rs:1032-1039) for the
+ * (row, col) group after optional UMI collapse; `value` is the f64 the
+ * reference adds to `matrix`, `ref_value` the one it adds to `ref_matrix`
+ * (coverage mode only, src/main.rs:336-344; 0 otherwise).                     */
+typedef struct vtx_coo {
+    const uint32_t* row;
+    const uint32_t* col;
+    const uint32_t* alt;
+    const uint32_t* ref;
+    const uint32_t* unk;
+    const double* value;
+    const double* ref_value;
+    uint64_t nnz;
+} vtx_coo;
+
+/* Device-side timing of the last vtx_run, from hipEvents on the context's
+ * stream (ms).  `sw_ms` covers the alignment kernel(s) only.                  */
+typedef struct vtx_timing {
+    float total_ms;
+    float sw_ms;
+    float reduce_ms;
+    uint32_t sw_launches;
+    uint32_t reserved;
+} vtx_timing;
+
+typedef struct vtx_ctx vtx_ctx;
+
+/* Reference constants (src/main.rs:27-38), banded aligner, consensus mode.   */
+void vtx_config_default(vtx_config* cfg);
+
+/* Replaces the per-run setup of src/main.rs:266-283 (Arguments + thread pool). */
+int vtx_create(const vtx_config* cfg, vtx_ctx** out);
+void vtx_destroy(vtx_ctx* ctx);
+
+/* Upload one packed batch into HBM (validates offsets/ordering first).
+ * Replaces handing `rec_chunk` to a worker, src/main.rs:285-289.  The batch
+ * stays resident until the next vtx_submit, so vtx_run may be repeated.      */
+int vtx_submit(vtx_ctx* ctx, const vtx_batch* batch);
+
+/* Run the hot path on the resident batch: Smith-Waterman of every record
+ * against both haplotypes (src/main.rs:898-901), per-read call
+ * (evaluate_scores :1019-1030), UMI collapse (parse_scores :1041-1109) and the
+ * per-(row, cell) count histogram; results stay in HBM.  Synchronous: returns
+ * after the device finished.  Replaces evaluate_chunk + the scoring half of
+ * the merge loop.                                                            */
+int vtx_run(vtx_ctx* ctx);
+
+/* Copy the per-record scores of the last vtx_run to host arrays of n_records
+ * int32 each (Scores.ref_score / alt_score, src/main.rs:926-927).            */
+int vtx_fetch_scores(vtx_ctx* ctx, int32_t* ref_score, int32_t* alt_score);
+
+/* Copy the triplets of the last vtx_run to context-owned host memory.        */
+int vtx_fetch_coo(vtx_ctx* ctx, vtx_coo* out);
+
+/* Device pointers of the last vtx_run's per-record scores (for callers that
+ * keep results on the GPU, e.g. an RCCL gather).  int32[n_records] each.     */
+int vtx_device_scores(vtx_ctx* ctx, const int32_t** d_ref, const int32_t** d_alt);
+
+int vtx_last_timing(vtx_ctx* ctx, vtx_timing* out);
+
+/* Number of DP cells the last vtx_run evaluated (sum over records and both
+ * haplotypes of rows x columns actually computed) — the roofline numerator.  */
+int vtx_last_cells(vtx_ctx* ctx, uint64_t* cells);
+
+/* Message for the last failing call on ctx (ctx may be NULL for create).     */
+const char* vtx_strerror(const vtx_ctx* ctx);
+const char* vtx_status_name(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTX_H */

@@ -1,0 +1,182 @@
+"""ctypes mirror of ``include/vtx.h`` — the C-ABI boundary of the hot path.
+
+Field order and widths must match the header exactly; ``tests/test_abi.py``
+checks the struct sizes against ``vtx_abi_sizes()`` exported by the library.
+The packed batch mirrors what a reference worker receives in
+``evaluate_chunk`` (reference ``src/main.rs:596-607``) after read filtering.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+VTX_ABI_VERSION = 1
+
+VTX_OK = 0
+VTX_E_INVAL = -1
+VTX_E_NODEVICE = -2
+VTX_E_HIP = -3
+VTX_E_NOMEM = -4
+VTX_E_UNSUPPORTED = -5
+VTX_E_STATE = -6
+
+ALIGNER_BANDED = 0
+ALIGNER_FULL = 1
+ALIGNERS = {"banded": ALIGNER_BANDED, "full": ALIGNER_FULL}
+
+MODE_CONSENSUS = 0
+MODE_ALT_FRAC = 1
+MODE_COVERAGE = 2
+# --scoring-method values of the reference CLI, src/main.rs:89-94
+MODES = {"consensus": MODE_CONSENSUS, "alt_frac": MODE_ALT_FRAC, "coverage": MODE_COVERAGE}
+
+
+class VtxConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("device", C.c_int32),
+        ("aligner", C.c_int32),
+        ("scoring_mode", C.c_int32),
+        ("use_umi", C.c_int32),
+        ("match_score", C.c_int32),
+        ("mismatch_score", C.c_int32),
+        ("gap_open", C.c_int32),
+        ("gap_extend", C.c_int32),
+        ("min_score", C.c_int32),
+        ("kmer_k", C.c_int32),
+        ("band_w", C.c_int32),
+        ("n_barcodes", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+def default_config(**overrides) -> VtxConfig:
+    """Reference constants, src/main.rs:27-38 (same as vtx_config_default)."""
+    cfg = VtxConfig(
+        abi_version=VTX_ABI_VERSION, device=0, aligner=ALIGNER_BANDED,
+        scoring_mode=MODE_CONSENSUS, use_umi=0, match_score=1, mismatch_score=-5,
+        gap_open=-5, gap_extend=-1, min_score=25, kmer_k=6, band_w=20,
+        n_barcodes=0, reserved=0)
+    for k, v in overrides.items():
+        if k == "aligner" and isinstance(v, str):
+            v = ALIGNERS[v]
+        if k == "scoring_mode" and isinstance(v, str):
+            v = MODES[v]
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, int(v))
+    return cfg
+
+
+LOCUS_DTYPE = np.dtype([
+    ("row", "<u4"), ("rec_begin", "<u4"), ("rec_count", "<u4"),
+    ("ref_off", "<u4"), ("ref_len", "<u4"), ("alt_off", "<u4"), ("alt_len", "<u4"),
+    ("reserved", "<u4")])
+RECORD_DTYPE = np.dtype([
+    ("read_off", "<u4"), ("read_len", "<u4"), ("cell_index", "<u4"), ("umi_id", "<u4")])
+assert LOCUS_DTYPE.itemsize == 32 and RECORD_DTYPE.itemsize == 16
+
+
+class VtxBatch(C.Structure):
+    _fields_ = [
+        ("loci", C.c_void_p),
+        ("n_loci", C.c_uint32),
+        ("records", C.c_void_p),
+        ("n_records", C.c_uint32),
+        ("hap_arena", C.c_void_p),
+        ("hap_bytes", C.c_uint64),
+        ("read_arena", C.c_void_p),
+        ("read_bytes", C.c_uint64),
+    ]
+
+
+class VtxCoo(C.Structure):
+    _fields_ = [
+        ("row", C.POINTER(C.c_uint32)),
+        ("col", C.POINTER(C.c_uint32)),
+        ("alt", C.POINTER(C.c_uint32)),
+        ("ref", C.POINTER(C.c_uint32)),
+        ("unk", C.POINTER(C.c_uint32)),
+        ("value", C.POINTER(C.c_double)),
+        ("ref_value", C.POINTER(C.c_double)),
+        ("nnz", C.c_uint64),
+    ]
+
+
+class VtxTiming(C.Structure):
+    _fields_ = [
+        ("total_ms", C.c_float),
+        ("sw_ms", C.c_float),
+        ("reduce_ms", C.c_float),
+        ("sw_launches", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+@dataclass
+class PackedBatch:
+    """Host-side packed batch (numpy) — the payload of ``vtx_submit``.
+
+    ``loci``/``records`` use LOCUS_DTYPE / RECORD_DTYPE; arenas are uint8.
+    Records of a locus are contiguous and ordered by (cell_index, umi_id),
+    which is the reference's stable sort by cell (src/main.rs:932) refined by
+    UMI (the per-cell HashMap of src/main.rs:1047-1057 is order-free).
+    """
+    loci: np.ndarray
+    records: np.ndarray
+    hap_arena: np.ndarray
+    read_arena: np.ndarray
+
+    def __post_init__(self):
+        self.loci = np.ascontiguousarray(self.loci, dtype=LOCUS_DTYPE)
+        self.records = np.ascontiguousarray(self.records, dtype=RECORD_DTYPE)
+        self.hap_arena = np.ascontiguousarray(self.hap_arena, dtype=np.uint8)
+        self.read_arena = np.ascontiguousarray(self.read_arena, dtype=np.uint8)
+
+    @property
+    def n_loci(self) -> int:
+        return int(self.loci.shape[0])
+
+    @property
+    def n_records(self) -> int:
+        return int(self.records.shape[0])
+
+    def as_struct(self) -> VtxBatch:
+        def ptr(a):
+            return a.ctypes.data if a.size else None
+        return VtxBatch(
+            loci=ptr(self.loci), n_loci=self.n_loci,
+            records=ptr(self.records), n_records=self.n_records,
+            hap_arena=ptr(self.hap_arena), hap_bytes=int(self.hap_arena.size),
+            read_arena=ptr(self.read_arena), read_bytes=int(self.read_arena.size))
+
+    def slice_loci(self, lo: int, hi: int) -> "PackedBatch":
+        """Contiguous sub-batch [lo, hi) of loci, re-based so it is self-contained.
+
+        This is how loci shard across GPUs (rows are independent,
+        src/main.rs:284-291): each rank receives only its own loci, records,
+        read bases and haplotypes.
+        """
+        loci = self.loci[lo:hi].copy()
+        if loci.shape[0] == 0:
+            return PackedBatch(loci, self.records[:0], self.hap_arena[:0], self.read_arena[:0])
+        r0 = int(loci["rec_begin"][0])
+        r1 = int(loci["rec_begin"][-1] + loci["rec_count"][-1])
+        recs = self.records[r0:r1].copy()
+        loci["rec_begin"] -= r0
+        # haplotypes: contiguous span covering the slice
+        h0 = int(min(loci["ref_off"].min(), loci["alt_off"].min()))
+        h1 = int(max((loci["ref_off"] + loci["ref_len"]).max(), (loci["alt_off"] + loci["alt_len"]).max()))
+        loci["ref_off"] -= h0
+        loci["alt_off"] -= h0
+        haps = self.hap_arena[h0:h1].copy()
+        if recs.shape[0]:
+            a0 = int(recs["read_off"].min())
+            a1 = int((recs["read_off"] + recs["read_len"]).max())
+            recs["read_off"] -= a0
+            reads = self.read_arena[a0:a1].copy()
+        else:
+            reads = self.read_arena[:0]
+        return PackedBatch(loci, recs, haps, reads)
