@@ -190,6 +190,10 @@ int vtx_fetch_coo(vtx_ctx* ctx, vtx_coo* out);
  * keep results on the GPU, e.g. an RCCL gather).  int32[n_records] each.     */
 int vtx_device_scores(vtx_ctx* ctx, const int32_t** d_ref, const int32_t** d_alt);
 
+/* Device pointers of the last vtx_run's triplets (same layout as vtx_coo, all
+ * arrays resident in HBM) — the payload of the multi-GPU row gather.          */
+int vtx_device_coo(vtx_ctx* ctx, vtx_coo* out);
+
 int vtx_last_timing(vtx_ctx* ctx, vtx_timing* out);
 
 /* Number of DP cells the last vtx_run evaluated (sum over records and both
@@ -199,6 +203,11 @@ int vtx_last_cells(vtx_ctx* ctx, uint64_t* cells);
 /* Message for the last failing call on ctx (ctx may be NULL for create).     */
 const char* vtx_strerror(const vtx_ctx* ctx);
 const char* vtx_status_name(int status);
+
+/* sizeof() of {vtx_config, vtx_locus, vtx_record, vtx_batch, vtx_coo,
+ * vtx_timing} as compiled into the library, for binding self-checks.
+ * Writes min(n, 6) entries; returns VTX_ABI_VERSION.                         */
+int vtx_abi_sizes(uint32_t* out, uint32_t n);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,178 @@
+"""GPU parity: the HIP path behind the C-ABI vs the CPU oracle, bit-exact.
+
+Small/medium seeded batches are compared record-by-record (scores) and
+triplet-by-triplet (COO) with the oracle; the golden BAM fixtures go through
+the device too.  Full-size runs are covered by size-independent properties in
+test_gpu_properties.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle, refpipe
+from vartrix_amd import lib, synth
+from vartrix_amd.abi import LOCUS_DTYPE, RECORD_DTYPE, PackedBatch, default_config
+
+pytestmark = pytest.mark.gpu
+
+
+def run_device(batch, cfg):
+    with lib.Context(cfg) as ctx:
+        ctx.submit(batch)
+        ctx.run()
+        ref, alt = ctx.fetch_scores()
+        coo = ctx.fetch_coo()
+        cells = ctx.cells()
+    return ref, alt, coo, cells
+
+
+def assert_same(batch, cfg, threads=8):
+    ref, alt, coo, cells = run_device(batch, cfg)
+    oref, oalt = oracle.batch_scores(batch, cfg, threads=threads)
+    bad = np.nonzero((ref != oref) | (alt != oalt))[0]
+    assert bad.size == 0, "first mismatch at record %d: device (%d,%d) oracle (%d,%d)" % (
+        bad[0], ref[bad[0]], alt[bad[0]], oref[bad[0]], oalt[bad[0]])
+    ocoo = oracle.batch_reduce(batch, cfg, oref, oalt)
+    for k in ("row", "col", "alt", "ref", "unk"):
+        assert np.array_equal(coo[k], ocoo[k]), k
+    # alt_frac may hold NaN (0/0, src/main.rs:1140): compare bit patterns
+    assert np.array_equal(coo["value"].view(np.uint64), ocoo["value"].view(np.uint64))
+    assert np.array_equal(coo["ref_value"], ocoo["ref_value"])
+    assert cells == oracle.batch_cells(batch, cfg)
+    return ref, alt, coo
+
+
+@pytest.mark.parametrize("mode", ["consensus", "alt_frac", "coverage"])
+@pytest.mark.parametrize("umi", [0, 1])
+def test_snv_batch(mode, umi):
+    spec = synth.SynthSpec(n_loci=96, n_barcodes=300, reads_per_locus=48, use_umi=bool(umi), seed=7 + umi)
+    batch = synth.make_batch(spec)
+    cfg = default_config(aligner="full", scoring_mode=mode, use_umi=umi, n_barcodes=spec.n_barcodes)
+    assert_same(batch, cfg)
+
+
+@pytest.mark.parametrize("mode", ["consensus", "alt_frac", "coverage"])
+def test_indel_umi_ragged_batch(mode):
+    """Config-5 shape: SNV + indels <= 20bp, UMIs with disagreeing members, ragged read lengths."""
+    spec = synth.SynthSpec(n_loci=128, n_barcodes=150, reads_per_locus=40, indel_frac=0.5, use_umi=True,
+                           read_len_jitter=120, umi_flip=0.2, seed=11)
+    batch = synth.make_batch(spec)
+    cfg = default_config(aligner="full", scoring_mode=mode, use_umi=1, n_barcodes=spec.n_barcodes)
+    assert_same(batch, cfg)
+
+
+@pytest.mark.parametrize("read_len", [1, 5, 17, 31, 32, 33, 64, 65, 100, 151, 160, 161, 200, 250, 256, 257, 400, 1000])
+def test_read_length_buckets(read_len):
+    """Every kernel shape (rows-per-lane x lanes-per-record) incl. bucket edges."""
+    spec = synth.SynthSpec(n_loci=12, n_barcodes=40, reads_per_locus=12, read_len=read_len,
+                           padding=max(100, read_len // 2 + 20), indel_frac=0.4, seed=read_len)
+    batch = synth.make_batch(spec)
+    cfg = default_config(aligner="full", scoring_mode="coverage", n_barcodes=spec.n_barcodes)
+    assert_same(batch, cfg, threads=8)
+
+
+def _manual_batch(haps, reads_per_locus, n_barcodes):
+    loci, recs, hb, rb = [], [], bytearray(), bytearray()
+    for i, ((ref, alt), reads) in enumerate(zip(haps, reads_per_locus)):
+        begin = len(recs)
+        for cell, umi, seq in sorted(reads, key=lambda t: (t[0], t[1])):
+            recs.append((len(rb), len(seq), cell, umi))
+            rb += seq
+        loci.append((i, begin, len(recs) - begin, len(hb), len(ref), len(hb) + len(ref), len(alt), 0))
+        hb += ref + alt
+    return PackedBatch(np.array(loci, LOCUS_DTYPE).reshape(-1), np.array(recs, RECORD_DTYPE).reshape(-1),
+                       np.frombuffer(bytes(hb), np.uint8), np.frombuffer(bytes(rb), np.uint8))
+
+
+def test_edge_cases():
+    """Empty loci, empty reads, empty ALT haplotype flank, N / lower-case bytes (byte equality,
+    src/main.rs:898), ties (UNKNOWN), sub-threshold reads (None), a cell with only None calls."""
+    rng = np.random.default_rng(3)
+    g = bytes(rng.choice(list(b"ACGT"), 400).tolist())
+    ref = g[100:301]
+    alt = g[100:200] + b"t" + g[201:301]          # lower-case ALT allele never matches upper-case reads
+    altn = g[100:200] + b"N" + g[201:301]
+    haps = [(ref, alt), (ref, altn), (ref, ref), (g[0:50], g[0:20] + g[30:50]), (ref, alt)]
+    reads = [
+        [(0, 0, g[120:270]), (0, 0, g[150:300]), (1, 0, b""), (2, 5, b"ACGT"), (3, 1, g[190:215])],
+        [(0, 0, g[120:200] + b"N" + g[201:270]), (0, 1, g[120:270]), (7, 0, b"N" * 60)],
+        [(4, 0, g[130:280]), (4, 0, g[131:281])],                       # identical haps -> ties -> UNKNOWN
+        [(1, 0, g[0:50]), (2, 0, g[0:20] + g[30:50]), (5, 0, g[5:45])],
+        [],                                                              # locus with no reads
+    ]
+    batch = _manual_batch(haps, reads, 8)
+    for mode in ("consensus", "alt_frac", "coverage"):
+        for umi in (0, 1):
+            cfg = default_config(aligner="full", scoring_mode=mode, use_umi=umi, n_barcodes=8)
+            ref_s, alt_s, coo = assert_same(batch, cfg, threads=1)
+    # identical haplotypes: every read ties
+    l2 = batch.loci[2]
+    sl = slice(int(l2["rec_begin"]), int(l2["rec_begin"] + l2["rec_count"]))
+    assert np.array_equal(ref_s[sl], alt_s[sl])
+
+
+def test_empty_batch():
+    batch = PackedBatch(np.zeros(0, LOCUS_DTYPE), np.zeros(0, RECORD_DTYPE), np.zeros(0, np.uint8), np.zeros(0, np.uint8))
+    cfg = default_config(aligner="full", n_barcodes=4)
+    ref, alt, coo, cells = run_device(batch, cfg)
+    assert ref.size == 0 and coo["row"].size == 0 and cells == 0
+
+
+def test_submit_validation():
+    spec = synth.SynthSpec(n_loci=4, n_barcodes=10, reads_per_locus=8)
+    batch = synth.make_batch(spec)
+    with lib.Context(default_config(aligner="full", n_barcodes=10)) as ctx:
+        bad = PackedBatch(batch.loci.copy(), batch.records.copy(), batch.hap_arena, batch.read_arena)
+        bad.records["cell_index"][0] = 99
+        with pytest.raises(lib.VtxError):
+            ctx.submit(bad)
+        bad = PackedBatch(batch.loci.copy(), batch.records[::-1].copy(), batch.hap_arena, batch.read_arena)
+        with pytest.raises(lib.VtxError):
+            ctx.submit(bad)
+        with pytest.raises(lib.VtxError):
+            ctx.run()          # nothing resident after a failed submit
+        ctx.submit(batch)
+        ctx.run()
+
+
+def test_rerun_is_idempotent():
+    spec = synth.SynthSpec(n_loci=32, n_barcodes=64, reads_per_locus=32, use_umi=True)
+    batch = synth.make_batch(spec)
+    cfg = default_config(aligner="full", scoring_mode="alt_frac", use_umi=1, n_barcodes=64)
+    with lib.Context(cfg) as ctx:
+        ctx.submit(batch)
+        ctx.run()
+        a = ctx.fetch_coo()
+        ctx.run()
+        b = ctx.fetch_coo()
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8))
+
+
+GOLDEN = [
+    ("consensus", False, "barcodes.tsv", "test_consensus.mtx", None),
+    ("alt_frac", False, "barcodes.tsv", "test_frac.mtx", None),
+    ("coverage", False, "barcodes.tsv", "test_coverage.mtx", "test_coverage_ref.mtx"),
+    ("coverage", True, "barcodes.tsv", "test_coverage_umi.mtx", "test_coverage_ref_umi.mtx"),
+    ("coverage", True, "barcodes.tsv.gz", "test_coverage_umi.mtx", "test_coverage_ref_umi.mtx"),
+]
+
+
+@pytest.mark.parametrize("case", GOLDEN, ids=["consensus", "alt_frac", "coverage", "coverage_umi", "coverage_umi_gz"])
+def test_reference_fixtures_on_device(golden_dir, case):
+    """The reference's own regression tests (src/main.rs:1208-1390), device path: CSR-equal .mtx."""
+    mode, umi, bcfile, main_fx, ref_fx = case
+    g = golden_dir
+    bcs = refpipe.load_barcodes(os.path.join(g, bcfile))
+    vcf = refpipe.read_vcf(os.path.join(g, "test.vcf"))
+    batch, _ = refpipe.pack(vcf, refpipe.read_fasta(os.path.join(g, "test.fa")),
+                            refpipe.read_bam(os.path.join(g, "test.bam")), bcs, refpipe.Args(use_umi=umi))
+    cfg = default_config(aligner="full", scoring_mode=mode, use_umi=int(umi), n_barcodes=len(bcs))
+    ref, alt, coo = assert_same(batch, cfg, threads=1)
+    shape, want = refpipe.read_mtx(os.path.join(g, main_fx))
+    assert shape == (len(vcf), len(bcs))
+    assert {(int(r), int(c)): float(v) for r, c, v in zip(coo["row"], coo["col"], coo["value"])} == want
+    if ref_fx:
+        _, want = refpipe.read_mtx(os.path.join(g, ref_fx))
+        assert {(int(r), int(c)): float(v) for r, c, v in zip(coo["row"], coo["col"], coo["ref_value"])} == want

@@ -1,0 +1,427 @@
+// vtx_api.hip — C-ABI layer of libvtx.so (see include/vtx.h for the contract).
+//
+// Owns the HIP context state: device buffers sized for the resident batch, the
+// per-bucket work lists, one stream, hipEvents for timing.  No CPU compute
+// path exists here: without a device every entry point fails.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "vtx_device.h"
+
+extern "C" hipError_t vtxk_inclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, void* temp,
+                                              size_t temp_bytes, hipStream_t s) {
+    if (!n) return hipSuccess;
+    return hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, in, out, (int)n, s);
+}
+extern "C" size_t vtxk_scan_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    hipcub::DeviceScan::InclusiveSum(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)std::max(n, 1u));
+    return bytes;
+}
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+struct Bucket { int R, GL; uint32_t offset, count; };
+
+// (rows per lane, lanes per record) choices; capacity = R * GL read bases.
+const int kShapes[][2] = {{2, 16}, {4, 16}, {6, 16}, {8, 16}, {10, 16}, {12, 16}, {16, 16}, {8, 64}, {16, 64}};
+const int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
+const uint32_t kMaxReadLen = 16 * 64;
+const uint32_t kMaxHapLen = 2400;   // 16 record slots x (len + 35) words must fit 160 KiB of LDS
+
+thread_local std::string g_create_err;
+
+}  // namespace
+
+struct vtx_ctx {
+    vtx_config cfg{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    std::string err;
+    bool submitted = false, ran = false;
+    uint32_t n_loci = 0, n_records = 0, n_cell_groups = 0, n_umi_groups = 0, max_hap_len = 0;
+    uint64_t cells = 0, nnz = 0;
+    std::vector<Bucket> buckets;
+    vtx_timing timing{};
+    DevBuf d_loci, d_records, d_rec_locus, d_hap, d_read, d_work, d_ref, d_alt;
+    DevBuf d_head_cell, d_head_umi, d_cell_scan, d_umi_scan, d_grp_row, d_grp_col, d_umi_cellgrp;
+    DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
+    DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
+    std::vector<uint32_t> h_row, h_col, h_alt, h_ref, h_unk;
+    std::vector<double> h_val, h_refval;
+};
+
+namespace {
+
+int fail(vtx_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail((c), _e == hipErrorOutOfMemory ? VTX_E_NOMEM : VTX_E_HIP, "%s: %s", #expr, \
+                        hipGetErrorString(_e));                                                \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+void vtx_config_default(vtx_config* cfg) {
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->abi_version = VTX_ABI_VERSION;
+    cfg->device = 0;
+    cfg->aligner = VTX_ALIGNER_BANDED;
+    cfg->scoring_mode = VTX_MODE_CONSENSUS;
+    cfg->use_umi = 0;
+    cfg->match_score = 1;
+    cfg->mismatch_score = -5;
+    cfg->gap_open = -5;
+    cfg->gap_extend = -1;
+    cfg->min_score = 25;
+    cfg->kmer_k = 6;
+    cfg->band_w = 20;
+}
+
+int vtx_abi_sizes(uint32_t* out, uint32_t n) {
+    const uint32_t s[6] = {(uint32_t)sizeof(vtx_config), (uint32_t)sizeof(vtx_locus), (uint32_t)sizeof(vtx_record),
+                           (uint32_t)sizeof(vtx_batch), (uint32_t)sizeof(vtx_coo), (uint32_t)sizeof(vtx_timing)};
+    for (uint32_t i = 0; i < n && i < 6; ++i) out[i] = s[i];
+    return VTX_ABI_VERSION;
+}
+
+const char* vtx_status_name(int status) {
+    switch (status) {
+    case VTX_OK: return "VTX_OK";
+    case VTX_E_INVAL: return "VTX_E_INVAL";
+    case VTX_E_NODEVICE: return "VTX_E_NODEVICE";
+    case VTX_E_HIP: return "VTX_E_HIP";
+    case VTX_E_NOMEM: return "VTX_E_NOMEM";
+    case VTX_E_UNSUPPORTED: return "VTX_E_UNSUPPORTED";
+    case VTX_E_STATE: return "VTX_E_STATE";
+    default: return "VTX_E_?";
+    }
+}
+
+const char* vtx_strerror(const vtx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int vtx_create(const vtx_config* cfg, vtx_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, VTX_E_INVAL, "vtx_create: null argument");
+    *out = nullptr;
+    if (cfg->abi_version != VTX_ABI_VERSION)
+        return fail(nullptr, VTX_E_INVAL, "vtx_create: abi_version %d != %d", cfg->abi_version, VTX_ABI_VERSION);
+    if (cfg->aligner != VTX_ALIGNER_BANDED && cfg->aligner != VTX_ALIGNER_FULL)
+        return fail(nullptr, VTX_E_INVAL, "vtx_create: unknown aligner %d", cfg->aligner);
+    if (cfg->scoring_mode < VTX_MODE_CONSENSUS || cfg->scoring_mode > VTX_MODE_COVERAGE)
+        return fail(nullptr, VTX_E_INVAL, "vtx_create: unknown scoring_mode %d", cfg->scoring_mode);
+    // The kernels bake the reference's scoring constants (src/main.rs:33-38) in as immediates.
+    if (cfg->match_score != 1 || cfg->mismatch_score != -5 || cfg->gap_open != -5 || cfg->gap_extend != -1)
+        return fail(nullptr, VTX_E_UNSUPPORTED,
+                    "vtx_create: only the reference scoring (+1/-5, gap -5/-1; src/main.rs:35-38) is built");
+    if (cfg->kmer_k != 6 || cfg->band_w != 20)
+        return fail(nullptr, VTX_E_UNSUPPORTED, "vtx_create: only K=6, W=20 (src/main.rs:33-34) is built");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, VTX_E_NODEVICE, "vtx_create: no HIP device (%s); this library has no CPU path",
+                    e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, VTX_E_INVAL, "vtx_create: device %d out of range (%d devices)", cfg->device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+        return fail(nullptr, VTX_E_HIP, "vtx_create: hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, VTX_E_NODEVICE, "vtx_create: device %d is %s; kernels are built for gfx950 only",
+                    cfg->device, prop.gcnArchName);
+    vtx_ctx* c = new (std::nothrow) vtx_ctx();
+    if (!c) return fail(nullptr, VTX_E_NOMEM, "vtx_create: out of host memory");
+    c->cfg = *cfg;
+    if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(nullptr, VTX_E_HIP, "vtx_create: stream creation failed");
+    }
+    for (auto& ev : c->ev)
+        if (hipEventCreate(&ev) != hipSuccess) { vtx_destroy(c); return fail(nullptr, VTX_E_HIP, "vtx_create: event creation failed"); }
+    *out = c;
+    return VTX_OK;
+}
+
+void vtx_destroy(vtx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->d_loci, &c->d_records, &c->d_rec_locus, &c->d_hap, &c->d_read, &c->d_work, &c->d_ref,
+                      &c->d_alt, &c->d_head_cell, &c->d_head_umi, &c->d_cell_scan, &c->d_umi_scan, &c->d_grp_row,
+                      &c->d_grp_col, &c->d_umi_cellgrp, &c->d_cell_cnt, &c->d_umi_cnt, &c->d_keep, &c->d_keep_scan,
+                      &c->d_scan_tmp, &c->d_o_row, &c->d_o_col, &c->d_o_alt, &c->d_o_ref, &c->d_o_unk, &c->d_o_val,
+                      &c->d_o_refval};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
+    if (!c) return VTX_E_INVAL;
+    if (!b) return fail(c, VTX_E_INVAL, "vtx_submit: null batch");
+    c->submitted = false; c->ran = false;
+    const uint32_t nl = b->n_loci, nr = b->n_records;
+    if ((nl && !b->loci) || (nr && !b->records) || (b->hap_bytes && !b->hap_arena) || (b->read_bytes && !b->read_arena))
+        return fail(c, VTX_E_INVAL, "vtx_submit: null array with non-zero count");
+    if (b->hap_bytes > 0xffffffffull || b->read_bytes > 0xffffffffull)
+        return fail(c, VTX_E_UNSUPPORTED, "vtx_submit: arenas above 4 GiB need more than one batch");
+
+    // ---- validate + derive rec_locus, buckets, cell count (host; O(records)) ----
+    std::vector<uint32_t> rec_locus(nr);
+    uint32_t next_rec = 0, max_hap = 0;
+    uint64_t cells = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+        const vtx_locus& L = b->loci[l];
+        if (L.rec_begin != next_rec) return fail(c, VTX_E_INVAL, "vtx_submit: locus %u: records not contiguous (rec_begin %u, expected %u)", l, L.rec_begin, next_rec);
+        if ((uint64_t)L.rec_begin + L.rec_count > nr) return fail(c, VTX_E_INVAL, "vtx_submit: locus %u: record range exceeds n_records", l);
+        if ((uint64_t)L.ref_off + L.ref_len > b->hap_bytes || (uint64_t)L.alt_off + L.alt_len > b->hap_bytes)
+            return fail(c, VTX_E_INVAL, "vtx_submit: locus %u: haplotype outside hap_arena", l);
+        if (L.ref_len > kMaxHapLen || L.alt_len > kMaxHapLen)
+            return fail(c, VTX_E_UNSUPPORTED, "vtx_submit: locus %u: haplotype longer than %u", l, kMaxHapLen);
+        max_hap = std::max(max_hap, std::max(L.ref_len, L.alt_len));
+        for (uint32_t r = L.rec_begin; r < L.rec_begin + L.rec_count; ++r) {
+            const vtx_record& R = b->records[r];
+            if ((uint64_t)R.read_off + R.read_len > b->read_bytes) return fail(c, VTX_E_INVAL, "vtx_submit: record %u: read outside read_arena", r);
+            if (R.read_len > kMaxReadLen) return fail(c, VTX_E_UNSUPPORTED, "vtx_submit: record %u: read length %u above %u", r, R.read_len, kMaxReadLen);
+            if (R.cell_index >= c->cfg.n_barcodes) return fail(c, VTX_E_INVAL, "vtx_submit: record %u: cell_index %u >= n_barcodes %u", r, R.cell_index, c->cfg.n_barcodes);
+            if (r > L.rec_begin) {
+                const vtx_record& P = b->records[r - 1];
+                if (P.cell_index > R.cell_index || (P.cell_index == R.cell_index && P.umi_id > R.umi_id))
+                    return fail(c, VTX_E_INVAL, "vtx_submit: record %u: not sorted by (cell_index, umi_id) within locus %u", r, l);
+            }
+            rec_locus[r] = l;
+            cells += (uint64_t)R.read_len * ((uint64_t)L.ref_len + L.alt_len);
+        }
+        next_rec = L.rec_begin + L.rec_count;
+    }
+    if (next_rec != nr) return fail(c, VTX_E_INVAL, "vtx_submit: %u records not covered by any locus", nr - next_rec);
+
+    // work lists per kernel shape (smallest R*GL that holds the read)
+    std::vector<std::vector<uint32_t>> lists(kNumShapes);
+    for (uint32_t r = 0; r < nr; ++r) {
+        const uint32_t m = b->records[r].read_len;
+        int s = 0;
+        while ((uint32_t)(kShapes[s][0] * kShapes[s][1]) < m) ++s;
+        lists[s].push_back(r);
+    }
+    std::vector<uint32_t> work;
+    work.reserve(nr);
+    c->buckets.clear();
+    for (int s = 0; s < kNumShapes; ++s) {
+        if (lists[s].empty()) continue;
+        c->buckets.push_back(Bucket{kShapes[s][0], kShapes[s][1], (uint32_t)work.size(), (uint32_t)lists[s].size()});
+        work.insert(work.end(), lists[s].begin(), lists[s].end());
+    }
+
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const size_t u32 = sizeof(uint32_t);
+    HIP_TRY(c, c->d_loci.reserve((size_t)nl * sizeof(vtx_locus)));
+    HIP_TRY(c, c->d_records.reserve((size_t)nr * sizeof(vtx_record)));
+    HIP_TRY(c, c->d_rec_locus.reserve(nr * u32));
+    HIP_TRY(c, c->d_hap.reserve(b->hap_bytes + 16));
+    HIP_TRY(c, c->d_read.reserve(b->read_bytes + 16));
+    HIP_TRY(c, c->d_work.reserve(nr * u32));
+    HIP_TRY(c, c->d_ref.reserve(nr * sizeof(int32_t)));
+    HIP_TRY(c, c->d_alt.reserve(nr * sizeof(int32_t)));
+    DevBuf* per_rec[] = {&c->d_head_cell, &c->d_head_umi, &c->d_cell_scan, &c->d_umi_scan, &c->d_grp_row, &c->d_grp_col,
+                         &c->d_umi_cellgrp, &c->d_keep, &c->d_keep_scan, &c->d_o_row, &c->d_o_col, &c->d_o_alt,
+                         &c->d_o_ref, &c->d_o_unk};
+    for (DevBuf* d : per_rec) HIP_TRY(c, d->reserve(nr * u32));
+    HIP_TRY(c, c->d_cell_cnt.reserve(3 * (size_t)nr * u32));
+    HIP_TRY(c, c->d_umi_cnt.reserve(3 * (size_t)nr * u32));
+    HIP_TRY(c, c->d_o_val.reserve(nr * sizeof(double)));
+    HIP_TRY(c, c->d_o_refval.reserve(nr * sizeof(double)));
+    const size_t tmp_bytes = vtxk_scan_temp_bytes(nr);
+    HIP_TRY(c, c->d_scan_tmp.reserve(tmp_bytes));
+
+    hipStream_t s = c->stream;
+    if (nl) HIP_TRY(c, hipMemcpyAsync(c->d_loci.p, b->loci, (size_t)nl * sizeof(vtx_locus), hipMemcpyHostToDevice, s));
+    if (nr) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_records.p, b->records, (size_t)nr * sizeof(vtx_record), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->d_rec_locus.p, rec_locus.data(), nr * u32, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->d_work.p, work.data(), nr * u32, hipMemcpyHostToDevice, s));
+    }
+    if (b->hap_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_hap.p, b->hap_arena, b->hap_bytes, hipMemcpyHostToDevice, s));
+    if (b->read_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_read.p, b->read_arena, b->read_bytes, hipMemcpyHostToDevice, s));
+
+    // ---- (row, cell) / (row, cell, umi) group structure: depends only on the records ----
+    c->n_cell_groups = c->n_umi_groups = 0;
+    if (nr) {
+        HIP_TRY(c, vtxk_group_heads(c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), nr,
+                                    c->d_head_cell.as<uint32_t>(), c->d_head_umi.as<uint32_t>(), s));
+        HIP_TRY(c, vtxk_inclusive_scan_u32(c->d_head_cell.as<uint32_t>(), c->d_cell_scan.as<uint32_t>(), nr, c->d_scan_tmp.p, tmp_bytes, s));
+        HIP_TRY(c, vtxk_inclusive_scan_u32(c->d_head_umi.as<uint32_t>(), c->d_umi_scan.as<uint32_t>(), nr, c->d_scan_tmp.p, tmp_bytes, s));
+        HIP_TRY(c, vtxk_group_table(c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), nr,
+                                    c->d_head_cell.as<uint32_t>(), c->d_head_umi.as<uint32_t>(), c->d_cell_scan.as<uint32_t>(),
+                                    c->d_umi_scan.as<uint32_t>(), c->d_grp_row.as<uint32_t>(), c->d_grp_col.as<uint32_t>(),
+                                    c->d_umi_cellgrp.as<uint32_t>(), s));
+        HIP_TRY(c, hipMemcpyAsync(&c->n_cell_groups, c->d_cell_scan.as<uint32_t>() + (nr - 1), u32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(&c->n_umi_groups, c->d_umi_scan.as<uint32_t>() + (nr - 1), u32, hipMemcpyDeviceToHost, s));
+    }
+    // rec_locus / work are host vectors: the copies must land before they die
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->n_loci = nl; c->n_records = nr; c->max_hap_len = max_hap; c->cells = cells;
+    c->submitted = true;
+    return VTX_OK;
+}
+
+int vtx_run(vtx_ctx* c) {
+    if (!c) return VTX_E_INVAL;
+    if (!c->submitted) return fail(c, VTX_E_STATE, "vtx_run: no batch submitted");
+    if (c->cfg.aligner != VTX_ALIGNER_FULL)
+        return fail(c, VTX_E_UNSUPPORTED, "vtx_run: the banded aligner is not built on the device yet; use VTX_ALIGNER_FULL");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    const uint32_t nr = c->n_records;
+    c->ran = false;
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    uint32_t launches = 0;
+    for (const Bucket& bk : c->buckets) {
+        HIP_TRY(c, vtxk_launch_sw_full(bk.R, bk.GL, bk.count, c->d_work.as<uint32_t>() + bk.offset,
+                                       c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
+                                       c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(),
+                                       c->d_alt.as<int32_t>(), c->max_hap_len, s));
+        ++launches;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    uint32_t nnz32 = 0;
+    const uint32_t ng = c->n_cell_groups, nu = c->n_umi_groups;
+    if (nr) {
+        const size_t tmp_bytes = vtxk_scan_temp_bytes(nr);
+        HIP_TRY(c, hipMemsetAsync(c->d_cell_cnt.p, 0, 3 * (size_t)ng * sizeof(uint32_t), s));
+        if (c->cfg.use_umi) {
+            HIP_TRY(c, hipMemsetAsync(c->d_umi_cnt.p, 0, 3 * (size_t)nu * sizeof(uint32_t), s));
+            HIP_TRY(c, vtxk_count_calls(c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), nr, c->cfg.min_score,
+                                        c->d_umi_scan.as<uint32_t>(), c->d_umi_cnt.as<uint32_t>(), s));
+            HIP_TRY(c, vtxk_umi_collapse(c->d_umi_cnt.as<uint32_t>(), nu, c->d_umi_cellgrp.as<uint32_t>(), c->d_cell_cnt.as<uint32_t>(), s));
+        } else {
+            HIP_TRY(c, vtxk_count_calls(c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), nr, c->cfg.min_score,
+                                        c->d_cell_scan.as<uint32_t>(), c->d_cell_cnt.as<uint32_t>(), s));
+        }
+        HIP_TRY(c, vtxk_keep_flags(c->d_cell_cnt.as<uint32_t>(), ng, c->cfg.scoring_mode, c->d_keep.as<uint32_t>(), s));
+        HIP_TRY(c, vtxk_inclusive_scan_u32(c->d_keep.as<uint32_t>(), c->d_keep_scan.as<uint32_t>(), ng, c->d_scan_tmp.p, tmp_bytes, s));
+        HIP_TRY(c, vtxk_emit_coo(c->d_cell_cnt.as<uint32_t>(), ng, c->cfg.scoring_mode, c->d_keep.as<uint32_t>(),
+                                 c->d_keep_scan.as<uint32_t>(), c->d_grp_row.as<uint32_t>(), c->d_grp_col.as<uint32_t>(),
+                                 c->d_o_row.as<uint32_t>(), c->d_o_col.as<uint32_t>(), c->d_o_alt.as<uint32_t>(),
+                                 c->d_o_ref.as<uint32_t>(), c->d_o_unk.as<uint32_t>(), c->d_o_val.as<double>(),
+                                 c->d_o_refval.as<double>(), s));
+        if (ng) HIP_TRY(c, hipMemcpyAsync(&nnz32, c->d_keep_scan.as<uint32_t>() + (ng - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->nnz = nnz32;
+    float t01 = 0, t12 = 0;
+    HIP_TRY(c, hipEventElapsedTime(&t01, c->ev[0], c->ev[1]));
+    HIP_TRY(c, hipEventElapsedTime(&t12, c->ev[1], c->ev[2]));
+    c->timing.sw_ms = t01; c->timing.reduce_ms = t12; c->timing.total_ms = t01 + t12;
+    c->timing.sw_launches = launches; c->timing.reserved = 0;
+    c->ran = true;
+    return VTX_OK;
+}
+
+int vtx_fetch_scores(vtx_ctx* c, int32_t* ref_score, int32_t* alt_score) {
+    if (!c) return VTX_E_INVAL;
+    if (!c->ran) return fail(c, VTX_E_STATE, "vtx_fetch_scores: no completed vtx_run");
+    if (c->n_records && (!ref_score || !alt_score)) return fail(c, VTX_E_INVAL, "vtx_fetch_scores: null output");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (c->n_records) {
+        HIP_TRY(c, hipMemcpy(ref_score, c->d_ref.p, (size_t)c->n_records * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(alt_score, c->d_alt.p, (size_t)c->n_records * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    return VTX_OK;
+}
+
+int vtx_device_scores(vtx_ctx* c, const int32_t** d_ref, const int32_t** d_alt) {
+    if (!c) return VTX_E_INVAL;
+    if (!c->ran) return fail(c, VTX_E_STATE, "vtx_device_scores: no completed vtx_run");
+    if (d_ref) *d_ref = c->d_ref.as<int32_t>();
+    if (d_alt) *d_alt = c->d_alt.as<int32_t>();
+    return VTX_OK;
+}
+
+int vtx_fetch_coo(vtx_ctx* c, vtx_coo* out) {
+    if (!c) return VTX_E_INVAL;
+    if (!out) return fail(c, VTX_E_INVAL, "vtx_fetch_coo: null output");
+    if (!c->ran) return fail(c, VTX_E_STATE, "vtx_fetch_coo: no completed vtx_run");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const size_t n = c->nnz;
+    c->h_row.resize(n); c->h_col.resize(n); c->h_alt.resize(n); c->h_ref.resize(n); c->h_unk.resize(n);
+    c->h_val.resize(n); c->h_refval.resize(n);
+    if (n) {
+        HIP_TRY(c, hipMemcpy(c->h_row.data(), c->d_o_row.p, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_col.data(), c->d_o_col.p, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_alt.data(), c->d_o_alt.p, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_ref.data(), c->d_o_ref.p, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_unk.data(), c->d_o_unk.p, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_val.data(), c->d_o_val.p, n * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_refval.data(), c->d_o_refval.p, n * 8, hipMemcpyDeviceToHost));
+    }
+    out->row = c->h_row.data(); out->col = c->h_col.data(); out->alt = c->h_alt.data(); out->ref = c->h_ref.data();
+    out->unk = c->h_unk.data(); out->value = c->h_val.data(); out->ref_value = c->h_refval.data();
+    out->nnz = n;
+    return VTX_OK;
+}
+
+int vtx_device_coo(vtx_ctx* c, vtx_coo* out) {
+    if (!c) return VTX_E_INVAL;
+    if (!out) return fail(c, VTX_E_INVAL, "vtx_device_coo: null output");
+    if (!c->ran) return fail(c, VTX_E_STATE, "vtx_device_coo: no completed vtx_run");
+    out->row = c->d_o_row.as<uint32_t>(); out->col = c->d_o_col.as<uint32_t>(); out->alt = c->d_o_alt.as<uint32_t>();
+    out->ref = c->d_o_ref.as<uint32_t>(); out->unk = c->d_o_unk.as<uint32_t>(); out->value = c->d_o_val.as<double>();
+    out->ref_value = c->d_o_refval.as<double>();
+    out->nnz = c->nnz;
+    return VTX_OK;
+}
+
+int vtx_last_timing(vtx_ctx* c, vtx_timing* out) {
+    if (!c || !out) return VTX_E_INVAL;
+    if (!c->ran) return fail(c, VTX_E_STATE, "vtx_last_timing: no completed vtx_run");
+    *out = c->timing;
+    return VTX_OK;
+}
+
+int vtx_last_cells(vtx_ctx* c, uint64_t* cells) {
+    if (!c || !cells) return VTX_E_INVAL;
+    if (!c->ran) return fail(c, VTX_E_STATE, "vtx_last_cells: no completed vtx_run");
+    *cells = c->cells;
+    return VTX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// vtx_device.h — internal declarations shared by the kernels and the C-ABI layer.
+#ifndef VTX_DEVICE_H
+#define VTX_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vtx.h"
+
+extern "C" {
+hipError_t vtxk_launch_sw_full(int R, int GL, uint32_t n_work, const uint32_t* work, const vtx_record* records,
+                               const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
+                               const uint8_t* hap_arena, int32_t* ref_score, int32_t* alt_score,
+                               uint32_t max_hap_len, hipStream_t stream);
+hipError_t vtxk_group_heads(const vtx_record* records, const uint32_t* rec_locus, uint32_t n, uint32_t* head_cell,
+                            uint32_t* head_umi, hipStream_t s);
+hipError_t vtxk_group_table(const vtx_record* records, const uint32_t* rec_locus, const vtx_locus* loci, uint32_t n,
+                            const uint32_t* head_cell, const uint32_t* head_umi, const uint32_t* cell_scan,
+                            const uint32_t* umi_scan, uint32_t* grp_row, uint32_t* grp_col, uint32_t* umi_cellgrp,
+                            hipStream_t s);
+hipError_t vtxk_count_calls(const int32_t* ref_score, const int32_t* alt_score, uint32_t n, int32_t min_score,
+                            const uint32_t* gscan, uint32_t* cnt, hipStream_t s);
+hipError_t vtxk_umi_collapse(const uint32_t* umi_cnt, uint32_t n_umi, const uint32_t* umi_cellgrp,
+                             uint32_t* cell_cnt, hipStream_t s);
+hipError_t vtxk_keep_flags(const uint32_t* cell_cnt, uint32_t n_grp, int mode, uint32_t* keep, hipStream_t s);
+hipError_t vtxk_emit_coo(const uint32_t* cell_cnt, uint32_t n_grp, int mode, const uint32_t* keep,
+                         const uint32_t* keep_scan, const uint32_t* grp_row, const uint32_t* grp_col, uint32_t* o_row,
+                         uint32_t* o_col, uint32_t* o_alt, uint32_t* o_ref, uint32_t* o_unk, double* o_val,
+                         double* o_refval, hipStream_t s);
+hipError_t vtxk_inclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes,
+                                   hipStream_t s);
+size_t vtxk_scan_temp_bytes(uint32_t n);
+}
+#endif

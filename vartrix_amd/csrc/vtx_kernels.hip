@@ -1,0 +1,352 @@
+// vtx_kernels.hip — hand-written gfx950 (CDNA4) kernels of the VarTrix hot path.
+//
+// What is computed (reference 10XGenomics/vartrix v1.1.22, src/main.rs):
+//   sw_full_kernel      : aligner.local(seq, ref_hap).score and .local(seq, alt_hap).score
+//                         for every record (src/main.rs:898-901, :926-927), full-matrix
+//                         affine local Smith-Waterman, +1/-5, gap -5-L.
+//   group/count/collapse/emit kernels : evaluate_scores (:1019-1030), parse_scores
+//                         (:1041-1109), convert_to_counts (:1032-1039) and the three matrix
+//                         modes (:1111-1164) as a per-(row, cell) histogram + ordered emit.
+//
+// Machine mapping (MI355X: 256 CUs x 4 SIMD, wave64, no MFMA — this is integer
+// DP, VALU-bound; see DESIGN.md for the roofline):
+//   * One 16-lane DPP row = one record.  A wave carries 4 records, a 256-thread
+//     workgroup 16.  Lane l of a row owns read rows [l*R, (l+1)*R) in VGPRs
+//     (R = rows per lane, template parameter chosen per read-length bucket).
+//   * Both haplotypes of the record are aligned at once: every DP quantity is a
+//     packed pair of 16-bit lanes {REF haplotype, ALT haplotype} in one VGPR,
+//     updated with v_pk_* instructions (2 DP cells per VALU op).
+//   * Systolic anti-diagonal wavefront: at step t lane l processes haplotype
+//     column t-l for all its R rows; the bottom-row (H, F) pair moves to lane
+//     l+1 with one DPP row_shr:1 each per step.  No LDS traffic for DP state.
+//   * Haplotype columns are staged once per record into LDS as packed
+//     {ref byte, alt byte} words with never-matching sentinels before column 0
+//     and after the last column; each lane reads its own column with one
+//     ds_read_b32 per step (consecutive lanes -> consecutive banks).
+//   * Arithmetic: H,E,F >= 0 kept with unsigned saturating subtracts
+//     (v_pk_sub_u16 clamp), the diagonal term as a signed v_pk_mad_i16 — 12
+//     packed VALU ops per cell pair.  Scores <= min(read, hap) length < 2^15.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vtx_device.h"
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+
+#define AS_S(x) __builtin_bit_cast(v2s, (x))
+#define AS_U(x) __builtin_bit_cast(v2u, (x))
+#define AS_I(x) __builtin_bit_cast(uint32_t, (x))
+
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {
+    return AS_I(__builtin_elementwise_sub_sat(AS_U(a), AS_U(b)));
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+    return AS_I(__builtin_elementwise_max(AS_S(a), AS_S(b)));
+}
+// The two ops below are pinned with inline asm: written as C++ the compiler
+// canonicalises min(x,1)*-6+g into per-half compare/select/perm chains (6 VALU
+// ops instead of 2).  Pure register ops: no memory, no hazards beyond what the
+// assembler / hardware interlocks handle for VALU->VALU.
+__device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    return AS_I(AS_S(a) + AS_S(b));
+}
+// a * b + c per 16-bit lane
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+#define PK(x) ((uint32_t)(uint16_t)(x) * 0x00010001u)
+
+// DPP controls (GFX9): row_shr:1 shifts within a 16-lane row, wave_shr:1 across the wave.
+#define DPP_ROW_SHR1 0x111
+#define DPP_WAVE_SHR1 0x138
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t lane_shr1(uint32_t old, uint32_t v) {
+    // lanes without a source (lane 0 of the row / wave) keep `old`
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// ---------------------------------------------------------------------------
+// Full-matrix Smith-Waterman, R rows per lane, GL lanes per record (16 or 64).
+// work[] lists the record ids of this read-length bucket.
+// LDS: per record slot (lcols) words of packed haplotype columns.
+// ---------------------------------------------------------------------------
+template <int R, int GL>
+__global__ __launch_bounds__(256) void sw_full_kernel(
+    const uint32_t* __restrict__ work, uint32_t n_work,
+    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus,
+    const vtx_locus* __restrict__ loci,
+    const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
+    int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score, uint32_t lcols) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr int GROUPS_PER_BLOCK = 256 / GL;
+    constexpr int DPP = (GL == 16) ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
+    constexpr int PRE = GL;   // sentinel words before column 0
+
+    const int tid = threadIdx.x;
+    const int grp = tid / GL;            // record slot in the block
+    const int l = tid % GL;              // lane within the record
+    const uint32_t widx = blockIdx.x * GROUPS_PER_BLOCK + grp;
+    const bool active = widx < n_work;
+
+    uint32_t rid = 0, m = 0, nr = 0, na = 0, roff = 0, ref_off = 0, alt_off = 0;
+    if (active) {
+        rid = work[widx];
+        const vtx_record rec = records[rid];
+        const vtx_locus loc = loci[rec_locus[rid]];
+        m = rec.read_len; roff = rec.read_off;
+        nr = loc.ref_len; na = loc.alt_len; ref_off = loc.ref_off; alt_off = loc.alt_off;
+    }
+    const uint32_t n = nr > na ? nr : na;
+    // wave-uniform step count: every record slot of this wave runs the same loop
+    uint32_t nwave = n;
+    if (GL == 16) {
+        nwave = max(nwave, (uint32_t)__shfl_xor((int)nwave, 16));
+        nwave = max(nwave, (uint32_t)__shfl_xor((int)nwave, 32));
+    }
+    // scalar (SGPR) loop bound: uniform by construction
+    const uint32_t steps = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nwave + GL - 1));
+
+    // ---- stage packed haplotype columns into LDS (sentinels never match) ----
+    uint32_t* cols = smem + (size_t)grp * lcols;
+    const uint32_t HAP_PAD = 0x0200u, READ_PAD = 0x0100u;
+    for (uint32_t idx = l; idx < PRE + steps + 1; idx += GL) {   // +1: prefetch of the last step
+        const int j = (int)idx - PRE;
+        uint32_t rc = HAP_PAD, ac = HAP_PAD;
+        if (j >= 0) {
+            if ((uint32_t)j < nr) rc = hap_arena[ref_off + j];
+            if ((uint32_t)j < na) ac = hap_arena[alt_off + j];
+        }
+        cols[idx] = rc | (ac << 16);
+    }
+
+    // ---- this lane's read rows, replicated into both halves ----
+    uint32_t c[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = (uint32_t)(l * R + r);
+        const uint32_t ch = (i < m) ? (uint32_t)read_arena[roff + i] : READ_PAD;
+        c[r] = ch * 0x00010001u;
+    }
+    __syncthreads();
+
+    // DP state per row: G = H+1, Q = max(H-6, 0), E (all of column j-1)
+    uint32_t G[R], Q[R], E[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { G[r] = PK(1); Q[r] = 0; E[r] = 0; }
+    uint32_t best = 0;
+    uint32_t g_last = PK(1), f_last = 0;   // bottom row of this lane, column just finished
+    uint32_t gu_prev = PK(1);              // G of the row above, previous column (diagonal of r = 0)
+
+    const uint32_t* colp = cols + PRE - l;  // column of step t is colp[t]
+    uint32_t hp = colp[0];
+    for (uint32_t t = 0; t < steps; ++t) {
+        const uint32_t hp_next = colp[t + 1];
+        // row above this lane's block, current column (lane 0: H = 0 boundary)
+        const uint32_t gu = lane_shr1<DPP>(PK(1), g_last);
+        const uint32_t fu = lane_shr1<DPP>(0u, f_last);
+        uint32_t gd = gu_prev;                       // H[i-1][j-1] + 1
+        uint32_t qa = pk_sub_sat(gu, PK(7));         // max(H[i-1][j] - 6, 0)
+        uint32_t fa = fu;                            // F[i-1][j]
+        gu_prev = gu;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t ne = pk_min_u(c[r] ^ hp, PK(1));        // 0 = match, 1 = mismatch
+            const uint32_t tt = pk_mad(ne, PK(-6), gd);            // diag + (match ? 1 : -5)
+            gd = G[r];
+            const uint32_t e = pk_max(pk_sub_sat(E[r], PK(1)), Q[r]);   // max(E-1, H-6) >= 0
+            const uint32_t f = pk_max(pk_sub_sat(fa, PK(1)), qa);
+            const uint32_t h = pk_max(pk_max(tt, e), f);                // >= 0
+            best = pk_max(best, tt);    // an optimal local alignment ends on a match
+            E[r] = e;
+            G[r] = pk_add(h, PK(1));
+            Q[r] = pk_sub_sat(h, PK(6));
+            fa = f; qa = Q[r];
+        }
+        g_last = G[R - 1];
+        f_last = fa;
+        hp = hp_next;
+    }
+
+    // max over the record's lanes
+#pragma unroll
+    for (int off = 1; off < GL; off <<= 1) best = pk_max(best, (uint32_t)__shfl_xor((int)best, off));
+    if (active && l == 0) {
+        ref_score[rid] = (int32_t)(int16_t)(best & 0xffffu);
+        alt_score[rid] = (int32_t)(int16_t)(best >> 16);
+    }
+}
+
+#define INST(R, GL) template __global__ void sw_full_kernel<R, GL>(                                     \
+    const uint32_t*, uint32_t, const vtx_record*, const uint32_t*, const vtx_locus*, const uint8_t*,     \
+    const uint8_t*, int32_t*, int32_t*, uint32_t);
+INST(2, 16) INST(4, 16) INST(6, 16) INST(8, 16) INST(10, 16) INST(12, 16) INST(16, 16) INST(8, 64) INST(16, 64)
+
+extern "C" hipError_t vtxk_launch_sw_full(int R, int GL, uint32_t n_work, const uint32_t* work,
+                                          const vtx_record* records, const uint32_t* rec_locus,
+                                          const vtx_locus* loci, const uint8_t* read_arena,
+                                          const uint8_t* hap_arena, int32_t* ref_score, int32_t* alt_score,
+                                          uint32_t max_hap_len, hipStream_t stream) {
+    if (n_work == 0) return hipSuccess;
+    const uint32_t groups = 256 / GL;
+    const uint32_t lcols = ((GL + max_hap_len + GL + 3) + 3u) & ~3u;
+    const size_t shmem = (size_t)groups * lcols * sizeof(uint32_t);
+    const dim3 grid((n_work + groups - 1) / groups), block(256);
+#define CASE(r, gl)                                                                                     \
+    if (R == r && GL == gl) {                                                                           \
+        if (shmem > 48 * 1024) {                                                                        \
+            hipError_t e = hipFuncSetAttribute((const void*)sw_full_kernel<r, gl>,                      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+            if (e != hipSuccess) return e;                                                              \
+        }                                                                                               \
+        hipLaunchKernelGGL((sw_full_kernel<r, gl>), grid, block, shmem, stream, work, n_work, records,  \
+                           rec_locus, loci, read_arena, hap_arena, ref_score, alt_score, lcols);        \
+        return hipGetLastError();                                                                       \
+    }
+    CASE(2, 16) CASE(4, 16) CASE(6, 16) CASE(8, 16) CASE(10, 16) CASE(12, 16) CASE(16, 16) CASE(8, 64) CASE(16, 64)
+#undef CASE
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------
+// Grouping (depends only on the records, computed once per submit).
+// head_cell[r] = 1 iff record r opens a (row, cell) group (itertools group_by
+// over the sorted scores, src/main.rs:1044); head_umi[r] = 1 iff it opens a
+// (row, cell, umi) sub-group (the per-cell HashMap keyed by UMI, :1047-1057).
+// ---------------------------------------------------------------------------
+__global__ void group_heads_kernel(const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus,
+                                   uint32_t n, uint32_t* __restrict__ head_cell, uint32_t* __restrict__ head_umi) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    uint32_t hc = 1, hu = 1;
+    if (r > 0 && rec_locus[r - 1] == rec_locus[r] && records[r - 1].cell_index == records[r].cell_index) {
+        hc = 0;
+        hu = records[r - 1].umi_id != records[r].umi_id;
+    }
+    head_cell[r] = hc;
+    head_umi[r] = hu;
+}
+
+// After the inclusive scans: gid = scan - 1.  Head records publish their group's (row, col).
+__global__ void group_table_kernel(const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus,
+                                   const vtx_locus* __restrict__ loci, uint32_t n,
+                                   const uint32_t* __restrict__ head_cell, const uint32_t* __restrict__ head_umi,
+                                   const uint32_t* __restrict__ cell_scan, const uint32_t* __restrict__ umi_scan,
+                                   uint32_t* __restrict__ grp_row, uint32_t* __restrict__ grp_col,
+                                   uint32_t* __restrict__ umi_cellgrp) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t cg = cell_scan[r] - 1;
+    if (head_cell[r]) { grp_row[cg] = loci[rec_locus[r]].row; grp_col[cg] = records[r].cell_index; }
+    if (head_umi[r]) umi_cellgrp[umi_scan[r] - 1] = cg;
+}
+
+// evaluate_scores (src/main.rs:1019-1030) + histogram.  cnt layout: 3 counters
+// (ref, alt, unk) per group.  Non-UMI mode counts straight into the cell group
+// (:1090-1105); UMI mode counts into the UMI sub-group first (:1048-1057).
+__global__ void count_calls_kernel(const int32_t* __restrict__ ref_score, const int32_t* __restrict__ alt_score,
+                                   uint32_t n, int32_t min_score, const uint32_t* __restrict__ gscan,
+                                   uint32_t* __restrict__ cnt) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int32_t rs = ref_score[r], as = alt_score[r];
+    if ((rs < min_score) & (as < min_score)) return;           // None
+    const uint32_t which = rs > as ? 0u : (as > rs ? 1u : 2u);  // REF / ALT / UNKNOWN
+    atomicAdd(&cnt[3u * (gscan[r] - 1u) + which], 1u);
+}
+
+// UMI collapse (src/main.rs:1058-1082): per UMI sub-group with at least one call,
+// ALT if alt/total >= 0.75, else REF if ref/total >= 0.75, else UNKNOWN.
+// 0.75 is exact in binary and |x/t - 3/4| >= 1/(4t), so 4x >= 3t decides identically.
+__global__ void umi_collapse_kernel(const uint32_t* __restrict__ umi_cnt, uint32_t n_umi,
+                                    const uint32_t* __restrict__ umi_cellgrp, uint32_t* __restrict__ cell_cnt) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_umi) return;
+    const uint32_t r = umi_cnt[3u * u], a = umi_cnt[3u * u + 1], k = umi_cnt[3u * u + 2];
+    const uint32_t t = r + a + k;
+    if (t == 0) return;   // all reads of this UMI were None: no entry (:1050-1052)
+    const uint32_t which = (4u * a >= 3u * t) ? 1u : ((4u * r >= 3u * t) ? 0u : 2u);
+    atomicAdd(&cell_cnt[3u * umi_cellgrp[u] + which], 1u);
+}
+
+// keep flag per cell group: consensus drops groups with no REF and no ALT call
+// (src/main.rs:1120-1126); alt_frac / coverage emit every group (:1140-1142, :1160-1161).
+__global__ void keep_flags_kernel(const uint32_t* __restrict__ cell_cnt, uint32_t n_grp, int mode,
+                                  uint32_t* __restrict__ keep) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_grp) return;
+    keep[g] = (mode != VTX_MODE_CONSENSUS) || (cell_cnt[3u * g] > 0) || (cell_cnt[3u * g + 1] > 0);
+}
+
+__global__ void emit_coo_kernel(const uint32_t* __restrict__ cell_cnt, uint32_t n_grp, int mode,
+                                const uint32_t* __restrict__ keep, const uint32_t* __restrict__ keep_scan,
+                                const uint32_t* __restrict__ grp_row, const uint32_t* __restrict__ grp_col,
+                                uint32_t* __restrict__ o_row, uint32_t* __restrict__ o_col,
+                                uint32_t* __restrict__ o_alt, uint32_t* __restrict__ o_ref,
+                                uint32_t* __restrict__ o_unk, double* __restrict__ o_val,
+                                double* __restrict__ o_refval) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_grp || !keep[g]) return;
+    const uint32_t o = keep_scan[g] - 1u;
+    const uint32_t r = cell_cnt[3u * g], a = cell_cnt[3u * g + 1], k = cell_cnt[3u * g + 2];
+    double v, rv = 0.0;
+    if (mode == VTX_MODE_CONSENSUS) v = (r > 0 && a > 0) ? 3.0 : (a > 0 ? 2.0 : 1.0);
+    else if (mode == VTX_MODE_ALT_FRAC) v = (double)a / ((double)r + (double)a + (double)k);   // NaN for 0/0
+    else { v = (double)a; rv = (double)r; }
+    o_row[o] = grp_row[g]; o_col[o] = grp_col[g];
+    o_alt[o] = a; o_ref[o] = r; o_unk[o] = k;
+    o_val[o] = v; o_refval[o] = rv;
+}
+
+static inline dim3 grid1d(uint32_t n, uint32_t b) { return dim3((n + b - 1) / b); }
+
+extern "C" hipError_t vtxk_group_heads(const vtx_record* records, const uint32_t* rec_locus, uint32_t n,
+                                       uint32_t* head_cell, uint32_t* head_umi, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(group_heads_kernel, grid1d(n, 256), dim3(256), 0, s, records, rec_locus, n, head_cell, head_umi);
+    return hipGetLastError();
+}
+extern "C" hipError_t vtxk_group_table(const vtx_record* records, const uint32_t* rec_locus, const vtx_locus* loci,
+                                       uint32_t n, const uint32_t* head_cell, const uint32_t* head_umi,
+                                       const uint32_t* cell_scan, const uint32_t* umi_scan, uint32_t* grp_row,
+                                       uint32_t* grp_col, uint32_t* umi_cellgrp, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(group_table_kernel, grid1d(n, 256), dim3(256), 0, s, records, rec_locus, loci, n, head_cell,
+                       head_umi, cell_scan, umi_scan, grp_row, grp_col, umi_cellgrp);
+    return hipGetLastError();
+}
+extern "C" hipError_t vtxk_count_calls(const int32_t* ref_score, const int32_t* alt_score, uint32_t n,
+                                       int32_t min_score, const uint32_t* gscan, uint32_t* cnt, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(count_calls_kernel, grid1d(n, 256), dim3(256), 0, s, ref_score, alt_score, n, min_score, gscan, cnt);
+    return hipGetLastError();
+}
+extern "C" hipError_t vtxk_umi_collapse(const uint32_t* umi_cnt, uint32_t n_umi, const uint32_t* umi_cellgrp,
+                                        uint32_t* cell_cnt, hipStream_t s) {
+    if (!n_umi) return hipSuccess;
+    hipLaunchKernelGGL(umi_collapse_kernel, grid1d(n_umi, 256), dim3(256), 0, s, umi_cnt, n_umi, umi_cellgrp, cell_cnt);
+    return hipGetLastError();
+}
+extern "C" hipError_t vtxk_keep_flags(const uint32_t* cell_cnt, uint32_t n_grp, int mode, uint32_t* keep, hipStream_t s) {
+    if (!n_grp) return hipSuccess;
+    hipLaunchKernelGGL(keep_flags_kernel, grid1d(n_grp, 256), dim3(256), 0, s, cell_cnt, n_grp, mode, keep);
+    return hipGetLastError();
+}
+extern "C" hipError_t vtxk_emit_coo(const uint32_t* cell_cnt, uint32_t n_grp, int mode, const uint32_t* keep,
+                                    const uint32_t* keep_scan, const uint32_t* grp_row, const uint32_t* grp_col,
+                                    uint32_t* o_row, uint32_t* o_col, uint32_t* o_alt, uint32_t* o_ref,
+                                    uint32_t* o_unk, double* o_val, double* o_refval, hipStream_t s) {
+    if (!n_grp) return hipSuccess;
+    hipLaunchKernelGGL(emit_coo_kernel, grid1d(n_grp, 256), dim3(256), 0, s, cell_cnt, n_grp, mode, keep, keep_scan,
+                       grp_row, grp_col, o_row, o_col, o_alt, o_ref, o_unk, o_val, o_refval);
+    return hipGetLastError();
+}

@@ -1,0 +1,161 @@
+"""ctypes binding of libvtx.so — the host side of the C-ABI in ``include/vtx.h``.
+
+There is no fallback: if the shared library is missing or no gfx950 device is
+present, the calls raise.  The method names follow the C entry points, which in
+turn name the reference seam they replace (``evaluate_chunk`` +
+the merge loop, reference ``src/main.rs:596-607`` / ``:320-348``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvtx.so")
+
+SYMBOLS = (
+    "vtx_config_default", "vtx_create", "vtx_destroy", "vtx_submit", "vtx_run", "vtx_fetch_scores",
+    "vtx_fetch_coo", "vtx_device_scores", "vtx_device_coo", "vtx_last_timing", "vtx_last_cells", "vtx_strerror",
+    "vtx_status_name", "vtx_abi_sizes",
+)
+
+
+class VtxError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__("%s: %s" % (status_name(status), message))
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """dlopen libvtx.so (built in-tree by ``__graft_entry__.build()``); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C vartrix_amd/csrc). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    ctxp = C.c_void_p
+    L.vtx_config_default.restype = None
+    L.vtx_config_default.argtypes = [C.POINTER(abi.VtxConfig)]
+    L.vtx_create.restype = C.c_int
+    L.vtx_create.argtypes = [C.POINTER(abi.VtxConfig), C.POINTER(ctxp)]
+    L.vtx_destroy.restype = None
+    L.vtx_destroy.argtypes = [ctxp]
+    L.vtx_submit.restype = C.c_int
+    L.vtx_submit.argtypes = [ctxp, C.POINTER(abi.VtxBatch)]
+    L.vtx_run.restype = C.c_int
+    L.vtx_run.argtypes = [ctxp]
+    L.vtx_fetch_scores.restype = C.c_int
+    L.vtx_fetch_scores.argtypes = [ctxp, C.c_void_p, C.c_void_p]
+    L.vtx_fetch_coo.restype = C.c_int
+    L.vtx_fetch_coo.argtypes = [ctxp, C.POINTER(abi.VtxCoo)]
+    L.vtx_device_scores.restype = C.c_int
+    L.vtx_device_scores.argtypes = [ctxp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.vtx_device_coo.restype = C.c_int
+    L.vtx_device_coo.argtypes = [ctxp, C.POINTER(abi.VtxCoo)]
+    L.vtx_last_timing.restype = C.c_int
+    L.vtx_last_timing.argtypes = [ctxp, C.POINTER(abi.VtxTiming)]
+    L.vtx_last_cells.restype = C.c_int
+    L.vtx_last_cells.argtypes = [ctxp, C.POINTER(C.c_uint64)]
+    L.vtx_strerror.restype = C.c_char_p
+    L.vtx_strerror.argtypes = [ctxp]
+    L.vtx_status_name.restype = C.c_char_p
+    L.vtx_status_name.argtypes = [C.c_int]
+    L.vtx_abi_sizes.restype = C.c_int
+    L.vtx_abi_sizes.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
+    _lib = L
+    return L
+
+
+def status_name(status: int) -> str:
+    return load().vtx_status_name(status).decode()
+
+
+class Context:
+    """One vtx_ctx: bound to one GPU, holds one resident batch."""
+
+    def __init__(self, cfg: abi.VtxConfig):
+        self._L = load()
+        self._h = C.c_void_p()
+        self.cfg = cfg
+        rc = self._L.vtx_create(C.byref(cfg), C.byref(self._h))
+        if rc != abi.VTX_OK:
+            raise VtxError(rc, self._L.vtx_strerror(None).decode())
+        self.n_records = 0
+
+    def _check(self, rc: int):
+        if rc != abi.VTX_OK:
+            raise VtxError(rc, self._L.vtx_strerror(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._L.vtx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, batch: abi.PackedBatch):
+        st = batch.as_struct()
+        self._check(self._L.vtx_submit(self._h, C.byref(st)))
+        self.n_records = batch.n_records
+
+    def run(self):
+        self._check(self._L.vtx_run(self._h))
+
+    def fetch_scores(self):
+        ref = np.zeros(self.n_records, np.int32)
+        alt = np.zeros(self.n_records, np.int32)
+        self._check(self._L.vtx_fetch_scores(self._h, ref.ctypes.data, alt.ctypes.data))
+        return ref, alt
+
+    def fetch_coo(self) -> dict:
+        coo = abi.VtxCoo()
+        self._check(self._L.vtx_fetch_coo(self._h, C.byref(coo)))
+        n = int(coo.nnz)
+        out = {}
+        for k, dt in (("row", np.uint32), ("col", np.uint32), ("alt", np.uint32), ("ref", np.uint32),
+                      ("unk", np.uint32), ("value", np.float64), ("ref_value", np.float64)):
+            out[k] = np.ctypeslib.as_array(getattr(coo, k), shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
+        return out
+
+    def device_scores(self):
+        r, a = C.c_void_p(), C.c_void_p()
+        self._check(self._L.vtx_device_scores(self._h, C.byref(r), C.byref(a)))
+        return r.value, a.value
+
+    def device_coo(self) -> dict:
+        """Raw device addresses of the triplet arrays + nnz (for torch/RCCL interop)."""
+        coo = abi.VtxCoo()
+        self._check(self._L.vtx_device_coo(self._h, C.byref(coo)))
+        out = {"nnz": int(coo.nnz)}
+        for k in ("row", "col", "alt", "ref", "unk", "value", "ref_value"):
+            out[k] = C.cast(getattr(coo, k), C.c_void_p).value or 0
+        return out
+
+    def timing(self) -> abi.VtxTiming:
+        t = abi.VtxTiming()
+        self._check(self._L.vtx_last_timing(self._h, C.byref(t)))
+        return t
+
+    def cells(self) -> int:
+        n = C.c_uint64(0)
+        self._check(self._L.vtx_last_cells(self._h, C.byref(n)))
+        return int(n.value)
