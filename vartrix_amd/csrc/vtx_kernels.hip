@@ -139,43 +139,64 @@ __global__ __launch_bounds__(256) void sw_full_kernel(
     }
     __syncthreads();
 
-    // DP state per row: G = H+1, Q = max(H-6, 0), E (all of column j-1)
-    uint32_t G[R], Q[R], E[R];
+    // DP state per row: G = H+1, Q = max(H-6, 0), E (all of column j-1).  Two copies
+    // (ping-pong) so the 2x-unrolled step loop needs no register-rotation moves.
+    uint32_t Ga[R], Qa[R], Ea[R], Gb[R], Qb[R], Eb[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) { G[r] = PK(1); Q[r] = 0; E[r] = 0; }
+    for (int r = 0; r < R; ++r) { Ga[r] = PK(1); Qa[r] = 0; Ea[r] = 0; }
     uint32_t best = 0;
-    uint32_t g_last = PK(1), f_last = 0;   // bottom row of this lane, column just finished
-    uint32_t gu_prev = PK(1);              // G of the row above, previous column (diagonal of r = 0)
+    // Values received from the lane above.  Lane 0 of the record never receives
+    // (row_shr / wave_shr leave lanes without a source untouched), so these
+    // registers keep the matrix boundary there: H = 0 (G = 1, Q = 0), F = 0.
+    uint32_t gu_a = PK(1), gu_b = PK(1), qu = 0, fu = 0;
 
     const uint32_t* colp = cols + PRE - l;  // column of step t is colp[t]
-    uint32_t hp = colp[0];
-    for (uint32_t t = 0; t < steps; ++t) {
-        const uint32_t hp_next = colp[t + 1];
-        // row above this lane's block, current column (lane 0: H = 0 boundary)
-        const uint32_t gu = lane_shr1<DPP>(PK(1), g_last);
-        const uint32_t fu = lane_shr1<DPP>(0u, f_last);
-        uint32_t gd = gu_prev;                       // H[i-1][j-1] + 1
-        uint32_t qa = pk_sub_sat(gu, PK(7));         // max(H[i-1][j] - 6, 0)
-        uint32_t fa = fu;                            // F[i-1][j]
-        gu_prev = gu;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t ne = pk_min_u(c[r] ^ hp, PK(1));        // 0 = match, 1 = mismatch
-            const uint32_t tt = pk_mad(ne, PK(-6), gd);            // diag + (match ? 1 : -5)
-            gd = G[r];
-            const uint32_t e = pk_max(pk_sub_sat(E[r], PK(1)), Q[r]);   // max(E-1, H-6) >= 0
-            const uint32_t f = pk_max(pk_sub_sat(fa, PK(1)), qa);
-            const uint32_t h = pk_max(pk_max(tt, e), f);                // >= 0
-            best = pk_max(best, tt);    // an optimal local alignment ends on a match
-            E[r] = e;
-            G[r] = pk_add(h, PK(1));
-            Q[r] = pk_sub_sat(h, PK(6));
-            fa = f; qa = Q[r];
-        }
-        g_last = G[R - 1];
-        f_last = fa;
-        hp = hp_next;
+
+    // One systolic step: column `hp`; reads state S (column j-1), writes state D (column j).
+    // gprev = G of the row above at column j-1 (diagonal of the lane's first row).
+#define SW_STEP(GS, QS, ES, GD, QD, ED, gprev, gcur, hp)                                        \
+    {                                                                                           \
+        gcur = lane_shr1<DPP>(gcur, GD##_last);                                                 \
+        qu = lane_shr1<DPP>(qu, q_last);                                                        \
+        fu = lane_shr1<DPP>(fu, f_last);                                                        \
+        uint32_t gd = gprev, qa = qu, fa = fu;                                                  \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) {                                         \
+            const uint32_t ne = pk_min_u(c[r] ^ hp, one);          /* 0 match, 1 mismatch */    \
+            const uint32_t tt = pk_mad(ne, neg6, gd);              /* diag + (1 | -5) */        \
+            gd = GS[r];                                                                         \
+            const uint32_t e = pk_max(pk_sub_sat(ES[r], PK(1)), QS[r]);   /* max(E-1, H-6) */    \
+            const uint32_t f = pk_max(pk_sub_sat(fa, PK(1)), qa);                               \
+            const uint32_t h = pk_max(pk_max(tt, e), f);                                        \
+            best = pk_max(best, tt);   /* an optimal local alignment ends on a match */         \
+            ED[r] = e;                                                                          \
+            GD[r] = pk_add(h, PK(1));                                                           \
+            QD[r] = pk_sub_sat(h, PK(6));                                                       \
+            fa = f; qa = QD[r];                                                                 \
+        }                                                                                       \
+        f_last = fa;                                                                            \
     }
+    // bottom row of this lane for the column just finished (what the lane below receives)
+    uint32_t f_last = 0;
+#define Ga_last Gb[R - 1]   /* step A (writes Ga) forwards the bottom row written by step B */
+#define Gb_last Ga[R - 1]
+#define q_last q_bottom
+    uint32_t q_bottom = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { Gb[r] = PK(1); Qb[r] = 0; Eb[r] = 0; }
+    const uint32_t one = PK(1), neg6 = PK(-6);
+    const uint32_t steps2 = (steps + 1) >> 1;
+    for (uint32_t t2 = 0; t2 < steps2; ++t2) {
+        const uint32_t hp0 = colp[2 * t2], hp1 = colp[2 * t2 + 1];
+        // step A: state b (column j-1) -> state a (column j); lane above finished column j in its step B'
+        q_bottom = Qb[R - 1];
+        SW_STEP(Gb, Qb, Eb, Ga, Qa, Ea, gu_b, gu_a, hp0)
+        q_bottom = Qa[R - 1];
+        SW_STEP(Ga, Qa, Ea, Gb, Qb, Eb, gu_a, gu_b, hp1)
+    }
+#undef SW_STEP
+#undef Ga_last
+#undef Gb_last
+#undef q_last
 
     // max over the record's lanes
 #pragma unroll

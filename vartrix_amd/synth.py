@@ -160,7 +160,9 @@ def make_batch(spec: SynthSpec, chunk_loci: int = 2048) -> PackedBatch:
         return _make_batch_snv(spec)
     rng = np.random.default_rng(spec.seed)
     V, B, R, Lr, pad = spec.n_loci, spec.n_barcodes, spec.reads_per_locus, spec.read_len, spec.padding
-    genome_codes = rng.integers(0, 4, size=1000 * V + 1000, dtype=np.uint8)
+    margin = 4 * (Lr + pad + spec.max_indel + 8)
+    lead = max(0, margin - 500)                      # keep windows of the first locus inside the contig
+    genome_codes = rng.integers(0, 4, size=lead + 1000 * V + 1000 + margin, dtype=np.uint8)
     genome = _ACGT[genome_codes]
 
     loci_parts, rec_parts, hap_parts, read_parts = [], [], [], []
@@ -171,7 +173,7 @@ def make_batch(spec: SynthSpec, chunk_loci: int = 2048) -> PackedBatch:
         b = min(a + chunk_loci, V)
         nl = b - a
         li = np.arange(a, b, dtype=np.int64)
-        pos0 = 500 + 1000 * li
+        pos0 = lead + 500 + 1000 * li
         # --- variants -------------------------------------------------------
         kind = np.zeros(nl, np.int64)                      # 0 SNV, 1 INS, 2 DEL
         if spec.indel_frac > 0:
