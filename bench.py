@@ -39,7 +39,8 @@ from vartrix_amd.abi import default_config  # noqa: E402
 # read 150 B bases + 12 B record + 8 B scores out, over 2 alignments, + the locus'
 # haplotypes and descriptor amortised over its reads.
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-VALU_PEAK_TOPS = 78.6          # 256 CU x 4 SIMD-32 x 2.4 GHz lane-ops/s (packed op = 1 lane-op)
+VALU_PEAK_TOPS = 39.3          # packed 16-bit VALU ops issue at 4 cycles / wave64 on gfx950: 256 CU x 4 SIMD x 16
+                               # lanes/clk x 2.4 GHz (measured 38.7, profiles/r01_valu_peak_microbench.txt)
 OPS_PER_CELL_PAIR = 12         # packed VALU ops per DP cell pair
 
 
