@@ -1,0 +1,81 @@
+/*
+ * vtx_host.h — C ABI of the host-side packer (libvtxhost.so): ingest + read
+ * filtering + haplotype construction, i.e. everything of the reference that
+ * sits *above* the hot-path seam and produces the packed batch of vtx.h.
+ *
+ * Restates (reference 10XGenomics/vartrix v1.1.22, src/main.rs):
+ *   load_barcodes :697-718 / open_with_gz :721-735, the VCF loop :221-234,
+ *   validate_inputs :545-594, evaluate_rec :610-695 (multi-allelic skip,
+ *   empty ALT, valid_chars), construct_haplotypes :958-994 + read_locus
+ *   :936-954, evaluate_alns fetch + filters :822-895, useful_alignment
+ *   :790-806, get_cell_barcode :737-750, get_umi :752-757, the stable sort by
+ *   cell :932, Metrics :449-459, write_matrix_market :381-389,
+ *   write_variants :1166-1179, write_barcodes :1181-1195.
+ * Library code replaced: rust-htslib/htslib (BGZF, BAM, text VCF), rust-bio
+ * fasta::IndexedReader, flate2, sprs — re-implemented on zlib only.
+ * Not supported (fails loudly): CRAM, BCF, CSI-only semantics are not needed
+ * (the BAM is swept once in coordinate order instead of one index seek per
+ * locus; the index file must still exist, like check_inputs_exist :513-541).
+ *
+ * Pure CPU code, no GPU needed: `tests/test_host.py` checks it against the
+ * Python restatement on the reference's own fixtures.
+ */
+#ifndef VTX_HOST_H
+#define VTX_HOST_H
+
+#include <stdint.h>
+#include "vtx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Arguments struct src/main.rs:420-427 plus the file paths / --padding. */
+typedef struct vtxh_args {
+    const char* vcf;
+    const char* bam;
+    const char* fasta;
+    const char* cell_barcodes;
+    uint32_t padding;        /* --padding, default 100 (:88)                    */
+    uint32_t mapq;           /* --mapq (:112-116)                               */
+    int32_t primary_only;    /* --primary-alignments (:117-119)                 */
+    int32_t no_duplicates;   /* --no-duplicates (:120-122)                      */
+    int32_t use_umi;         /* --umi (:123-125)                                */
+    const char* bam_tag;     /* --bam-tag, default "CB" (:126-129)              */
+    const char* valid_chars; /* --valid-chars, default "ATGCatgc" (:130-133)    */
+    int32_t threads;         /* BGZF inflate threads (does not affect results)  */
+} vtxh_args;
+
+/* Metrics, src/main.rs:449-459 */
+typedef struct vtxh_metrics {
+    uint64_t num_reads, num_low_mapq, num_non_primary, num_duplicates, num_not_cell_bc,
+             num_not_useful, num_non_umi, num_invalid_recs, num_multiallelic_recs;
+} vtxh_metrics;
+
+typedef struct vtxh_pack vtxh_pack;
+
+/* Ingest + filter + pack.  Returns 0 or a negative vtx_status; *out owns all
+ * arrays until vtxh_free.  On failure vtxh_last_error() has the message.      */
+int vtxh_pack_files(const vtxh_args* args, vtxh_pack** out);
+void vtxh_free(vtxh_pack* p);
+const char* vtxh_last_error(void);
+
+/* The packed batch (pointers valid until vtxh_free). */
+void vtxh_get_batch(const vtxh_pack* p, vtx_batch* out);
+void vtxh_get_metrics(const vtxh_pack* p, vtxh_metrics* out);
+uint32_t vtxh_num_variants(const vtxh_pack* p);   /* matrix rows = VCF records (:237)      */
+uint32_t vtxh_num_barcodes(const vtxh_pack* p);   /* matrix cols = distinct barcodes (:245) */
+/* "{chrom}_{pos0}" of VCF record i (write_variants :1174); barcode of column j. */
+const char* vtxh_variant_name(const vtxh_pack* p, uint32_t i);
+const char* vtxh_barcode(const vtxh_pack* p, uint32_t j);
+
+/* sprs::io::write_matrix_market of a TriMat<f64> (:381): 3 header lines, then
+ * "row+1 col+1 value" in the given order with Rust `{}` float text.           */
+int vtxh_write_mtx(const char* path, uint32_t n_rows, uint32_t n_cols, uint64_t nnz,
+                   const uint32_t* row, const uint32_t* col, const double* value);
+int vtxh_format_f64(double v, char* buf32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,95 @@
+"""End to end on the GPU through the drop-in command line: the reference's own regression tests
+(src/main.rs:1208-1390) re-run against `vartrix_amd/bin/vartrix`, plus an authored indel BAM."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle, refpipe
+from vartrix_amd import hostlib
+from vartrix_amd.abi import default_config
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def run_cli(args, cwd):
+    r = subprocess.run([hostlib.CLI_PATH] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r
+
+
+def csr(path):
+    return refpipe.read_mtx(path)
+
+
+def base_args(bc="barcodes.tsv"):
+    return ["-v", os.path.join(G, "test.vcf"), "-b", os.path.join(G, "test.bam"), "-f", os.path.join(G, "test.fa"),
+            "-c", os.path.join(G, bc)]
+
+
+def test_consensus_matrix(tmp_path):          # src/main.rs:1208-1233
+    out = str(tmp_path / "out.mtx")
+    run_cli(base_args() + ["-o", out], tmp_path)
+    assert csr(out) == csr(os.path.join(G, "test_consensus.mtx"))
+    assert open(out).read() == open(os.path.join(G, "test_consensus.mtx")).read()   # byte-identical too
+
+
+def test_frac_matrix(tmp_path):               # :1236-1263
+    out = str(tmp_path / "out.mtx")
+    run_cli(base_args() + ["-o", out, "-s", "alt_frac"], tmp_path)
+    assert open(out).read() == open(os.path.join(G, "test_frac.mtx")).read()
+
+
+def test_coverage_matrices(tmp_path):         # :1266-1300
+    out, ref = str(tmp_path / "out.mtx"), str(tmp_path / "ref.mtx")
+    run_cli(base_args() + ["-o", out, "-s", "coverage", "--ref-matrix", ref], tmp_path)
+    assert csr(out) == csr(os.path.join(G, "test_coverage.mtx"))
+    assert csr(ref) == csr(os.path.join(G, "test_coverage_ref.mtx"))
+
+
+def test_coverage_matrices_umi(tmp_path):     # :1303-1339
+    out, ref = str(tmp_path / "out.mtx"), str(tmp_path / "ref.mtx")
+    run_cli(base_args() + ["-o", out, "-s", "coverage", "--ref-matrix", ref, "--umi"], tmp_path)
+    assert csr(out) == csr(os.path.join(G, "test_coverage_umi.mtx"))
+    assert csr(ref) == csr(os.path.join(G, "test_coverage_ref_umi.mtx"))
+
+
+def test_coverage_matrices_umi_gzipped_bcs(tmp_path):   # :1342-1390
+    out, ref, obc, ovar = (str(tmp_path / n) for n in ("out.mtx", "ref.mtx", "bcs.tsv", "vars.txt"))
+    run_cli(base_args("barcodes.tsv.gz") + ["-o", out, "-s", "coverage", "--ref-matrix", ref, "--umi",
+                                              "--out-barcodes", obc, "--out-variants", ovar], tmp_path)
+    assert csr(out) == csr(os.path.join(G, "test_coverage_umi.mtx"))
+    assert csr(ref) == csr(os.path.join(G, "test_coverage_ref_umi.mtx"))
+    assert open(obc).read() == open(os.path.join(G, "barcodes.tsv")).read()          # barcode round trip :1387-1389
+    assert open(ovar).read() == "1_199\n17_199\n2_199\n7_199\n"                        # 0-based pos (:1174)
+
+
+def test_coverage_mode_without_ref_matrix_flag_writes_only_main(tmp_path):
+    out = str(tmp_path / "out.mtx")
+    run_cli(base_args() + ["-o", out, "-s", "coverage"], tmp_path)                    # :385 is_present("ref_matrix")
+    assert os.path.exists(out) and not os.path.exists(tmp_path / "ref_matrix.mtx")
+
+
+@pytest.mark.parametrize("mode", ["consensus", "alt_frac", "coverage"])
+@pytest.mark.parametrize("umi", [False, True])
+def test_authored_indel_bam_end_to_end(tmp_path, mode, umi):
+    """test_dna.vcf (SNV + INS + DEL + multi-allelic) over an authored BAM: CLI output is byte-identical to
+    the oracle pipeline (Python ingest restatement + C oracle, full aligner) rendered as .mtx."""
+    from tests.test_host import make_dna_bam
+    bam = make_dna_bam(tmp_path, seed=3, n_reads=1500)
+    vcfp, fap, bcp = (os.path.join(G, n) for n in ("test_dna.vcf", "test_dna.fa", "dna_barcodes.tsv"))
+    out, ref = str(tmp_path / "out.mtx"), str(tmp_path / "ref.mtx")
+    args = ["-v", vcfp, "-b", bam, "-f", fap, "-c", bcp, "-o", out, "-s", mode, "--ref-matrix", ref, "--threads", "4"]
+    run_cli(args + (["--umi"] if umi else []), tmp_path)
+    bcs = refpipe.load_barcodes(bcp)
+    vcf = refpipe.read_vcf(vcfp)
+    batch, _ = refpipe.pack(vcf, refpipe.read_fasta(fap), refpipe.read_bam(bam), bcs, refpipe.Args(use_umi=umi))
+    cfg = default_config(aligner="full", scoring_mode=mode, use_umi=int(umi), n_barcodes=len(bcs))
+    r, a = oracle.batch_scores(batch, cfg, threads=8)
+    coo = oracle.batch_reduce(batch, cfg, r, a)
+    assert open(out).read() == refpipe.mtx_text(len(vcf), len(bcs), coo["row"], coo["col"], coo["value"])
+    if mode == "coverage":
+        assert open(ref).read() == refpipe.mtx_text(len(vcf), len(bcs), coo["row"], coo["col"], coo["ref_value"])
+    assert len(coo["row"]) > 50

@@ -1,0 +1,209 @@
+"""Host logic (C++ packer behind include/vtx_host.h) on CPU: same packed batch as the Python
+restatement on the reference's fixtures, oracle on top reproduces the .mtx fixtures, MTX text,
+CLI argument / output-path behaviour of the reference (src/main.rs:475-542)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle, refpipe
+from vartrix_amd import hostlib
+from vartrix_amd.abi import default_config
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def same_batch(a, b):
+    """Equal as packed batches up to the placement of reads inside the arena."""
+    if not (np.array_equal(a.loci, b.loci) and np.array_equal(a.hap_arena, b.hap_arena)):
+        return False
+    if a.n_records != b.n_records:
+        return False
+    for k in ("read_len", "cell_index", "umi_id"):
+        if not np.array_equal(a.records[k], b.records[k]):
+            return False
+    for ra, rb in zip(a.records, b.records):
+        sa = a.read_arena[int(ra["read_off"]):int(ra["read_off"]) + int(ra["read_len"])]
+        sb = b.read_arena[int(rb["read_off"]):int(rb["read_off"]) + int(rb["read_len"])]
+        if not np.array_equal(sa, sb):
+            return False
+    return True
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not (os.path.exists(hostlib.LIB_PATH) and os.path.exists(hostlib.CLI_PATH)):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+def _inputs(bc="barcodes.tsv"):
+    return dict(vcf=os.path.join(G, "test.vcf"), bam=os.path.join(G, "test.bam"), fasta=os.path.join(G, "test.fa"),
+                cell_barcodes=os.path.join(G, bc))
+
+
+@pytest.mark.parametrize("umi", [False, True])
+@pytest.mark.parametrize("bc", ["barcodes.tsv", "barcodes.tsv.gz"])
+def test_packer_equals_python_restatement(umi, bc):
+    batch, metrics, nv, barcodes, variants = hostlib.pack_files(use_umi=umi, threads=3, **_inputs(bc))
+    bcs = refpipe.load_barcodes(os.path.join(G, bc))
+    want, wmetrics = refpipe.pack(refpipe.read_vcf(os.path.join(G, "test.vcf")), refpipe.read_fasta(os.path.join(G, "test.fa")),
+                                  refpipe.read_bam(os.path.join(G, "test.bam")), bcs, refpipe.Args(use_umi=umi))
+    assert metrics == wmetrics
+    assert nv == 4 and barcodes == list(bcs.keys())
+    assert variants == ["1_199", "17_199", "2_199", "7_199"]          # write_variants prints 0-based pos (:1174)
+    assert same_batch(batch, want)
+
+
+def test_packer_filters():
+    base, m0, *_ = hostlib.pack_files(**_inputs())
+    _, m1, *_ = hostlib.pack_files(mapq=255, **_inputs())
+    assert m1["num_low_mapq"] > 0 and m1["num_reads"] == m0["num_reads"]
+    _, m2, *_ = hostlib.pack_files(primary_only=True, **_inputs())
+    assert m2["num_non_primary"] >= 0
+    b3, m3, *_ = hostlib.pack_files(valid_chars="ATC", **_inputs())   # G not allowed -> every ALT haplotype invalid
+    assert m3["num_invalid_recs"] == 4 and b3.n_loci == 0 and m3["num_reads"] == 0
+    b4, m4, *_ = hostlib.pack_files(bam_tag="XX", **_inputs())
+    assert b4.n_records == 0 and m4["num_not_cell_bc"] > 0
+    # python restatement agrees on each variant
+    for kw, args in (({"mapq": 255}, refpipe.Args(mapq=255)), ({"primary_only": True}, refpipe.Args(primary=True)),
+                     ({"no_duplicates": True}, refpipe.Args(duplicates=True)), ({"padding": 30}, refpipe.Args(padding=30))):
+        b, m, *_ = hostlib.pack_files(**kw, **_inputs())
+        wb, wm = refpipe.pack(refpipe.read_vcf(os.path.join(G, "test.vcf")), refpipe.read_fasta(os.path.join(G, "test.fa")),
+                              refpipe.read_bam(os.path.join(G, "test.bam")), refpipe.load_barcodes(os.path.join(G, "barcodes.tsv")), args)
+        assert m == wm and same_batch(b, wb)
+
+
+def test_validate_inputs_errors():
+    """validate_inputs (:574-591): contig must be in FASTA and BAM; REF end <= chromosome length."""
+    with pytest.raises(hostlib.HostError, match="larger than the chromosome length"):
+        hostlib.pack_files(os.path.join(G, "test_dna.vcf"), os.path.join(G, "test.bam"), os.path.join(G, "test.fa"),
+                           os.path.join(G, "dna_barcodes.tsv"))
+
+
+def test_validate_inputs_unknown_contig(tmp_path):
+    vcf = tmp_path / "x.vcf"
+    vcf.write_text("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\nzz\t10\t.\tA\tC\t.\t.\t.\n")
+    with pytest.raises(hostlib.HostError, match="Sequence zz not seen in FASTA"):
+        hostlib.pack_files(str(vcf), os.path.join(G, "test.bam"), os.path.join(G, "test.fa"), os.path.join(G, "barcodes.tsv"))
+
+
+def make_dna_bam(tmp_path, seed=1, n_reads=600):
+    """Author a coordinate-sorted BAM over test_dna.fa covering the loci of test_dna.vcf (SNV, INS,
+    DEL, one multi-allelic record) with assorted CIGARs, flags, tags and soft clips."""
+    from oracle import bamwriter
+    rng = np.random.default_rng(seed)
+    fa = refpipe.read_fasta(os.path.join(G, "test_dna.fa"))["1"].upper()
+    vcf = refpipe.read_vcf(os.path.join(G, "test_dna.vcf"))
+    bcs = list(refpipe.load_barcodes(os.path.join(G, "dna_barcodes.tsv")).keys())
+    recs = []
+    for k in range(n_reads):
+        v = vcf[int(rng.integers(0, len(vcf)))]
+        start = max(0, v.pos - int(rng.integers(0, 140)))
+        carry_alt = len(v.alleles) >= 2 and rng.random() < 0.5
+        ln = int(rng.integers(60, 151))
+        if carry_alt and start <= v.pos:
+            refa, alta = v.alleles[0], v.alleles[1]
+            hapseq = fa[start:v.pos] + alta.upper() + fa[v.pos + len(refa):v.pos + len(refa) + 200]
+            seq = hapseq[:ln].decode()
+            left = v.pos - start
+            d = len(alta) - len(refa)
+            if d == 0 or left + 1 >= ln:
+                cigar = "%dM" % len(seq)
+            elif d > 0:
+                cigar = "%dM%dI%dM" % (left + 1, min(d, ln - left - 1), max(ln - left - 1 - d, 0)) if ln - left - 1 - d > 0 else "%dM%dS" % (left + 1, ln - left - 1)
+            else:
+                cigar = "%dM%dD%dM" % (left + 1, -d, ln - left - 1)
+        else:
+            seq = fa[start:start + ln].decode()
+            cigar = "%dM" % len(seq)
+        flag = 0
+        u = rng.random()
+        if u < 0.05:
+            flag |= 0x400
+        elif u < 0.10:
+            flag |= 0x100
+        elif u < 0.13:
+            flag |= 0x800
+        if rng.random() < 0.1 and cigar.endswith("M") and cigar.count("M") == 1 and len(seq) > 20:
+            clip = int(rng.integers(1, 15))
+            cigar = "%dS%dM" % (clip, len(seq) - clip)
+        tags = []
+        if rng.random() < 0.9:
+            tags.append(("CB", "Z", bcs[int(rng.integers(0, 40))] if rng.random() < 0.9 else b"NOTLISTED-1"))
+        if rng.random() < 0.85:
+            tags.append(("UB", "Z", "UMI%02d" % int(rng.integers(0, 12))))
+        if rng.random() < 0.05:
+            tags.append(("CB", "i", 7)) if not any(t[0] == "CB" for t in tags) else None
+        tags.append(("NM", "i", 0))
+        mapq = int(rng.choice([0, 3, 30, 60, 255]))
+        recs.append((start, bamwriter.record(0, start, "r%04d" % k, seq, cigar, flag=flag, mapq=mapq, tags=tags)))
+    recs.sort(key=lambda t: t[0])
+    bam = str(tmp_path / "dna.bam")
+    bamwriter.write_bam(bam, [("1", len(fa))], [r for _, r in recs], block=20000)
+    return bam
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(use_umi=True), dict(mapq=30), dict(primary_only=True, no_duplicates=True),
+                                dict(padding=20), dict(use_umi=True, padding=150)])
+def test_packer_on_authored_indel_bam(tmp_path, kw):
+    """C++ packer == Python restatement on a BAM with indel reads over test_dna.vcf (46 records: 37 SNV,
+    5 DEL, 3 INS, 1 multi-allelic -> skipped with its row kept, :646-653)."""
+    bam = make_dna_bam(tmp_path)
+    vcfp, fap, bcp = (os.path.join(G, n) for n in ("test_dna.vcf", "test_dna.fa", "dna_barcodes.tsv"))
+    batch, metrics, nv, barcodes, variants = hostlib.pack_files(vcfp, bam, fap, bcp, threads=2, **kw)
+    args = refpipe.Args(mapq=kw.get("mapq", 0), primary=kw.get("primary_only", False), duplicates=kw.get("no_duplicates", False),
+                        use_umi=kw.get("use_umi", False), padding=kw.get("padding", 100))
+    want, wm = refpipe.pack(refpipe.read_vcf(vcfp), refpipe.read_fasta(fap), refpipe.read_bam(bam),
+                            refpipe.load_barcodes(bcp), args)
+    assert metrics == wm and metrics["num_multiallelic_recs"] == 1
+    assert nv == 46 and len(barcodes) == 1331 and batch.n_loci == 45
+    assert same_batch(batch, want)
+    assert batch.n_records > 100
+
+
+def test_mtx_writer_bytes(tmp_path):
+    for v, s in [(1.0, "1"), (0.0, "0"), (0.5, "0.5"), (1 / 3, "0.3333333333333333"), (float("nan"), "NaN"),
+                 (2 / 3, "0.6666666666666666"), (1 / 30000, "0.000033333333333333335"), (7.0, "7")]:
+        assert hostlib.format_f64(v) == s == oracle.format_f64(v)
+    p = str(tmp_path / "m.mtx")
+    hostlib.write_mtx(p, 4, 20, [0, 1, 1, 2], [19, 14, 19, 17], [1.0, 1.0, 1.0, 2.0])
+    assert open(p).read() == open(os.path.join(G, "test_consensus.mtx")).read()
+
+
+def test_oracle_on_cpp_packed_batch_reproduces_fixtures():
+    for mode, umi, fx, rfx in (("consensus", False, "test_consensus.mtx", None), ("alt_frac", False, "test_frac.mtx", None),
+                               ("coverage", True, "test_coverage_umi.mtx", "test_coverage_ref_umi.mtx")):
+        batch, _, nv, barcodes, _ = hostlib.pack_files(use_umi=umi, **_inputs())
+        cfg = default_config(aligner="banded", scoring_mode=mode, use_umi=int(umi), n_barcodes=len(barcodes))
+        ref, alt = oracle.batch_scores(batch, cfg)
+        coo = oracle.batch_reduce(batch, cfg, ref, alt)
+        _, want = refpipe.read_mtx(os.path.join(G, fx))
+        assert {(int(r), int(c)): float(v) for r, c, v in zip(coo["row"], coo["col"], coo["value"])} == want
+        if rfx:
+            _, want = refpipe.read_mtx(os.path.join(G, rfx))
+            assert {(int(r), int(c)): float(v) for r, c, v in zip(coo["row"], coo["col"], coo["ref_value"])} == want
+
+
+def _cli(args, cwd):
+    return subprocess.run([hostlib.CLI_PATH] + args, cwd=cwd, capture_output=True, text=True, timeout=120)
+
+
+def test_cli_refuses_existing_output_and_missing_input(tmp_path):
+    i = _inputs()
+    base = ["-v", i["vcf"], "-b", i["bam"], "-f", i["fasta"], "-c", i["cell_barcodes"]]
+    out = tmp_path / "o.mtx"
+    out.write_text("x")
+    r = _cli(base + ["-o", str(out)], tmp_path)                       # validate_output_path :477-480
+    assert r.returncode == 1 and "Output path already exists" in r.stderr
+    (tmp_path / "ref_matrix.mtx").write_text("x")                      # default ref matrix is checked too (:509-511)
+    r = _cli(base + ["-o", str(tmp_path / "new.mtx")], tmp_path)
+    assert r.returncode == 1 and "Output path already exists" in r.stderr
+    os.remove(tmp_path / "ref_matrix.mtx")
+    r = _cli(["-v", "/nonexistent.vcf", "-b", i["bam"], "-f", i["fasta"], "-c", i["cell_barcodes"]], tmp_path)
+    assert r.returncode == 1 and "does not exist" in r.stderr
+    r = _cli(base + ["-s", "bogus"], tmp_path)
+    assert r.returncode == 1
+    r = _cli(["-v", i["vcf"]], tmp_path)
+    assert r.returncode == 1 and "required" in r.stderr

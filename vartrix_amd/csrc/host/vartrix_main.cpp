@@ -1,0 +1,278 @@
+// vartrix — drop-in command line of the reference (same flags, same outputs), hot path on MI355X.
+//
+// Restates _main (reference src/main.rs:163-418): argument surface of get_args
+// (:40-135), check_inputs_exist / validate_output_path (:475-542), then
+// ingest + pack (libvtxhost) -> vtx_submit / vtx_run / vtx_fetch_coo (libvtx,
+// replacing the rayon map :279-291 and the merge loop :320-348) -> .mtx and the
+// optional variants / barcodes files.  `--threads` only sizes the BGZF inflate
+// pool here (it never affected results in the reference either, :279-291).
+// New, optional: --devices N (shard loci over N GPUs), --aligner full|banded.
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/vtx.h"
+#include "../../../include/vtx_host.h"
+
+namespace {
+
+int g_log_level = 0;   // 0 error, 1 info, 2 debug  (--log-level, :102-106)
+
+void logmsg(int level, const char* tag, const char* fmt, ...) {
+    if (level > g_log_level) return;
+    char ts[16];
+    time_t t = time(nullptr);
+    strftime(ts, sizeof ts, "%H:%M:%S", gmtime(&t));
+    fprintf(stderr, "%s [%s] ", ts, tag);
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fputc('\n', stderr);
+}
+#define LOG_ERROR(...) logmsg(0, "ERROR", __VA_ARGS__)
+#define LOG_INFO(...) logmsg(1, "INFO", __VA_ARGS__)
+#define LOG_DEBUG(...) logmsg(2, "DEBUG", __VA_ARGS__)
+
+bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+// validate_output_path, :475-491
+void validate_output_path(const std::string& p) {
+    if (exists(p)) { LOG_ERROR("Output path already exists"); exit(1); }
+    size_t slash = p.find_last_of('/');
+    std::string parent = slash == std::string::npos ? "" : p.substr(0, slash);
+    if (!parent.empty() && !exists(parent)) { LOG_ERROR("Output directory \"%s\" does not exist", parent.c_str()); exit(1); }
+}
+
+struct Opt { const char* name; char shrt; bool flag; const char* def; };
+const Opt kOpts[] = {
+    {"vcf", 'v', false, nullptr}, {"bam", 'b', false, nullptr}, {"fasta", 'f', false, nullptr},
+    {"cell-barcodes", 'c', false, nullptr}, {"out-matrix", 'o', false, "out_matrix.mtx"},
+    {"out-variants", 0, false, nullptr}, {"out-barcodes", 0, false, nullptr}, {"padding", 'p', false, "100"},
+    {"scoring-method", 's', false, "consensus"}, {"ref-matrix", 0, false, "ref_matrix.mtx"},
+    {"log-level", 0, false, "error"}, {"threads", 0, false, "1"}, {"mapq", 0, false, "0"},
+    {"primary-alignments", 0, true, nullptr}, {"no-duplicates", 0, true, nullptr}, {"umi", 0, true, nullptr},
+    {"bam-tag", 0, false, "CB"}, {"valid-chars", 0, false, "ATGCatgc"},
+    {"devices", 0, false, "1"}, {"aligner", 0, false, "full"},
+};
+
+void usage() {
+    fprintf(stderr,
+            "vartrix (MI355X-native hot path)\nUSAGE: vartrix --vcf <FILE> --bam <FILE> --fasta <FILE> --cell-barcodes <FILE> [OPTIONS]\n"
+            "  -o, --out-matrix <FILE> [out_matrix.mtx]   --out-variants <FILE>   --out-barcodes <FILE>\n"
+            "  -p, --padding <INT> [100]   -s, --scoring-method consensus|coverage|alt_frac [consensus]\n"
+            "  --ref-matrix <FILE> [ref_matrix.mtx]   --log-level info|debug|error [error]   --threads <INT> [1]\n"
+            "  --mapq <INT> [0]   --primary-alignments   --no-duplicates   --umi   --bam-tag <TAG> [CB]\n"
+            "  --valid-chars <CHARS> [ATGCatgc]   --devices <INT> [1]   --aligner full|banded [full]\n");
+}
+
+struct Shard {
+    std::vector<vtx_locus> loci;
+    std::vector<vtx_record> records;
+    const uint8_t *haps, *reads;
+    uint64_t hap_bytes, read_bytes;
+    std::vector<uint32_t> row, col;
+    std::vector<double> val, refval;
+    std::string err;
+    int rc = 0;
+};
+
+void run_shard(Shard* s, vtx_config cfg) {
+    vtx_ctx* ctx = nullptr;
+    s->rc = vtx_create(&cfg, &ctx);
+    if (s->rc) { s->err = vtx_strerror(nullptr); return; }
+    vtx_batch b{s->loci.data(), (uint32_t)s->loci.size(), s->records.data(), (uint32_t)s->records.size(), s->haps,
+                s->hap_bytes, s->reads, s->read_bytes};
+    vtx_coo coo{};
+    if ((s->rc = vtx_submit(ctx, &b)) || (s->rc = vtx_run(ctx)) || (s->rc = vtx_fetch_coo(ctx, &coo))) {
+        s->err = vtx_strerror(ctx);
+        vtx_destroy(ctx);
+        return;
+    }
+    s->row.assign(coo.row, coo.row + coo.nnz);
+    s->col.assign(coo.col, coo.col + coo.nnz);
+    s->val.assign(coo.value, coo.value + coo.nnz);
+    s->refval.assign(coo.ref_value, coo.ref_value + coo.nnz);
+    vtx_destroy(ctx);
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    std::map<std::string, std::string> val;
+    std::map<std::string, bool> present;
+    for (const Opt& o : kOpts) if (o.def) val[o.name] = o.def;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "-h" || a == "--help") { usage(); return 0; }
+        const Opt* opt = nullptr;
+        std::string inline_val;
+        bool has_inline = false;
+        if (a.rfind("--", 0) == 0) {
+            size_t eq = a.find('=');
+            std::string name = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+            if (eq != std::string::npos) { inline_val = a.substr(eq + 1); has_inline = true; }
+            for (const Opt& o : kOpts) if (name == o.name) opt = &o;
+        } else if (a.size() >= 2 && a[0] == '-') {
+            for (const Opt& o : kOpts) if (o.shrt && a[1] == o.shrt) opt = &o;
+            if (opt && a.size() > 2) { inline_val = a.substr(2); has_inline = true; }
+        }
+        if (!opt) { fprintf(stderr, "error: Found argument '%s' which wasn't expected\n", a.c_str()); usage(); return 1; }
+        present[opt->name] = true;
+        if (opt->flag) continue;
+        if (has_inline) val[opt->name] = inline_val;
+        else if (i + 1 < argc) val[opt->name] = argv[++i];
+        else { fprintf(stderr, "error: The argument '--%s <value>' requires a value\n", opt->name); return 1; }
+    }
+    for (const char* req : {"vcf", "bam", "fasta", "cell-barcodes"})
+        if (!val.count(req)) { fprintf(stderr, "error: The following required arguments were not provided:\n    --%s <FILE>\n", req); usage(); return 1; }
+    const std::string ll = val["log-level"];
+    if (ll == "info") g_log_level = 1; else if (ll == "debug") g_log_level = 2;
+    else if (ll != "error") { printf("Log level not valid\n"); return 1; }                 // :202-205
+    const std::string mode = val["scoring-method"];
+    if (mode != "consensus" && mode != "coverage" && mode != "alt_frac") {
+        fprintf(stderr, "error: '%s' isn't a valid value for '--scoring-method <scoring_method>'\n", mode.c_str());
+        return 1;
+    }
+    const std::string out_matrix = val["out-matrix"], ref_matrix = val["ref-matrix"];
+
+    // check_inputs_exist, :493-542
+    for (const char* k : {"fasta", "vcf", "bam", "cell-barcodes"})
+        if (!exists(val[k])) { LOG_ERROR("Input file %s does not exist", val[k].c_str()); return 1; }
+    validate_output_path(out_matrix);
+    validate_output_path(ref_matrix);     // the default ref_matrix.mtx too, even in consensus mode (:509-511)
+    if (!exists(val["fasta"] + ".fai")) { LOG_ERROR("File %s.fai does not exist", val["fasta"].c_str()); return 1; }
+    {
+        const std::string& bam = val["bam"];
+        size_t dot = bam.find_last_of('.');
+        std::string ext = dot == std::string::npos ? "" : bam.substr(dot + 1);
+        if (ext == "bam") {
+            if (!exists(bam + ".bai") && !exists(bam + ".csi")) { LOG_ERROR("BAM index does not exist. Expecting %s.bai or %s.csi", bam.c_str(), bam.c_str()); return 1; }
+        } else if (ext == "cram") {
+            LOG_ERROR("CRAM input is not supported by this build"); return 1;
+        } else { LOG_ERROR("BAM file did not end in .bam or .cram. Unable to validate"); return 1; }
+    }
+
+    vtxh_args ha{};
+    ha.vcf = val["vcf"].c_str(); ha.bam = val["bam"].c_str(); ha.fasta = val["fasta"].c_str();
+    ha.cell_barcodes = val["cell-barcodes"].c_str();
+    ha.padding = (uint32_t)strtoul(val["padding"].c_str(), nullptr, 10);
+    ha.mapq = (uint32_t)strtoul(val["mapq"].c_str(), nullptr, 10);
+    ha.primary_only = present.count("primary-alignments"); ha.no_duplicates = present.count("no-duplicates");
+    ha.use_umi = present.count("umi");
+    ha.bam_tag = val["bam-tag"].c_str(); ha.valid_chars = val["valid-chars"].c_str();
+    ha.threads = std::max(1, atoi(val["threads"].c_str()));
+    vtxh_pack* pk = nullptr;
+    if (vtxh_pack_files(&ha, &pk) != 0) {
+        printf("Vartrix error.\nError: %s\n", vtxh_last_error());
+        return 1;
+    }
+    const uint32_t n_vars = vtxh_num_variants(pk), n_bcs = vtxh_num_barcodes(pk);
+    LOG_INFO("Loaded %u barcodes", n_bcs);
+    if (n_vars == 0)
+        LOG_ERROR("Warning! Zero variants found in input VCF. Output matrices will be by definition empty but will still be generated.");
+    LOG_INFO("Initialized a %u variants x %u cell barcodes matrix", n_vars, n_bcs);
+
+    // ---- the hot path: loci sharded over --devices GPUs (contiguous row ranges by record count) ----
+    vtx_batch full{};
+    vtxh_get_batch(pk, &full);
+    vtx_config cfg;
+    vtx_config_default(&cfg);
+    cfg.aligner = val["aligner"] == "banded" ? VTX_ALIGNER_BANDED : VTX_ALIGNER_FULL;
+    cfg.scoring_mode = mode == "consensus" ? VTX_MODE_CONSENSUS : (mode == "alt_frac" ? VTX_MODE_ALT_FRAC : VTX_MODE_COVERAGE);
+    cfg.use_umi = ha.use_umi;
+    cfg.n_barcodes = n_bcs;
+    const int ndev = std::max(1, atoi(val["devices"].c_str()));
+    std::vector<Shard> shards((size_t)ndev);
+    {
+        const uint64_t total = full.n_records;
+        std::vector<uint32_t> cuts((size_t)ndev + 1, full.n_loci);
+        cuts[0] = 0;
+        uint64_t acc = 0;
+        uint32_t l = 0;
+        for (int d = 1; d < ndev; ++d) {
+            const uint64_t target = total * (uint64_t)d / (uint64_t)ndev;
+            while (l < full.n_loci && acc < target) acc += full.loci[l++].rec_count;
+            cuts[(size_t)d] = l;
+        }
+        for (int d = 0; d < ndev; ++d) {
+            Shard& s = shards[(size_t)d];
+            s.loci.assign(full.loci + cuts[(size_t)d], full.loci + cuts[(size_t)d + 1]);
+            const uint32_t r0 = s.loci.empty() ? 0 : s.loci.front().rec_begin;
+            const uint32_t r1 = s.loci.empty() ? 0 : s.loci.back().rec_begin + s.loci.back().rec_count;
+            s.records.assign(full.records + r0, full.records + r1);
+            for (auto& L : s.loci) L.rec_begin -= r0;
+            s.haps = full.hap_arena; s.hap_bytes = full.hap_bytes;       // arenas are shared read-only, offsets stay valid
+            s.reads = full.read_arena; s.read_bytes = full.read_bytes;
+        }
+    }
+    std::vector<std::thread> th;
+    for (int d = 0; d < ndev; ++d) {
+        vtx_config c = cfg;
+        c.device = d;
+        th.emplace_back(run_shard, &shards[(size_t)d], c);
+    }
+    for (auto& t : th) t.join();
+    for (auto& s : shards)
+        if (s.rc) { printf("Vartrix error.\nError: %s: %s\n", vtx_status_name(s.rc), s.err.c_str()); return 1; }
+
+    // merge in shard (= row) order: exactly the triplet order of the merge loop :320-348
+    std::vector<uint32_t> row, col;
+    std::vector<double> v, rv;
+    for (auto& s : shards) {
+        row.insert(row.end(), s.row.begin(), s.row.end());
+        col.insert(col.end(), s.col.begin(), s.col.end());
+        v.insert(v.end(), s.val.begin(), s.val.end());
+        rv.insert(rv.end(), s.refval.begin(), s.refval.end());
+    }
+    vtxh_metrics m;
+    vtxh_get_metrics(pk, &m);
+    LOG_INFO("Number of alignments evaluated: %llu", (unsigned long long)m.num_reads);                                        // :350-379
+    LOG_INFO("Number of alignments skipped due to low mapping quality: %llu", (unsigned long long)m.num_low_mapq);
+    LOG_INFO("Number of alignments skipped due to not being primary: %llu", (unsigned long long)m.num_non_primary);
+    LOG_INFO("Number of alignments skipped due to being duplicates: %llu", (unsigned long long)m.num_duplicates);
+    LOG_INFO("Number of alignments skipped due to not being associated with a cell barcode: %llu", (unsigned long long)m.num_not_cell_bc);
+    LOG_INFO("Number of alignments skipped due to not intersecting variant: %llu", (unsigned long long)m.num_not_useful);
+    LOG_INFO("Number of alignments skipped due to not having a UMI: %llu", (unsigned long long)m.num_non_umi);
+    LOG_INFO("Number of VCF records skipped due to having invalid characters in the alternative haplotype: %llu", (unsigned long long)m.num_invalid_recs);
+    LOG_INFO("Number of VCF records skipped due to being multi-allelic: %llu", (unsigned long long)m.num_multiallelic_recs);
+
+    if (vtxh_write_mtx(out_matrix.c_str(), n_vars, n_bcs, row.size(), row.data(), col.data(), v.data()) != 0) {
+        printf("Vartrix error.\nError: Error writing out-matrix\nInfo: caused by %s\n", vtxh_last_error());
+        return 1;
+    }
+    if (mode == "coverage" && present.count("ref-matrix")) {                                                                 // :385-389
+        if (vtxh_write_mtx(ref_matrix.c_str(), n_vars, n_bcs, row.size(), row.data(), col.data(), rv.data()) != 0) {
+            printf("Vartrix error.\nError: Error writing ref-matrix\nInfo: caused by %s\n", vtxh_last_error());
+            return 1;
+        }
+    }
+    if (present.count("out-variants")) {                                                                                     // :391-398
+        validate_output_path(val["out-variants"]);
+        FILE* f = fopen(val["out-variants"].c_str(), "wb");
+        if (!f) { printf("Vartrix error.\nError: error writing variants file\n"); return 1; }
+        for (uint32_t i = 0; i < n_vars; ++i) fprintf(f, "%s\n", vtxh_variant_name(pk, i));
+        fclose(f);
+    }
+    if (present.count("out-barcodes")) {                                                                                     // :400-407
+        validate_output_path(val["out-barcodes"]);
+        FILE* f = fopen(val["out-barcodes"].c_str(), "wb");
+        if (!f) { printf("Vartrix error.\nError: error writing barcodes file\n"); return 1; }
+        for (uint32_t j = 0; j < n_bcs; ++j) fprintf(f, "%s\n", vtxh_barcode(pk, j));
+        fclose(f);
+    }
+    double sum = 0;
+    for (double x : v) sum += x;
+    if (sum == 0.0) LOG_ERROR("The resulting matrix has a sum of 0. Did you use the --umi flag on data without UMIs?");       // :410-415
+    vtxh_free(pk);
+    return 0;
+}

@@ -1,0 +1,113 @@
+"""ctypes binding of libvtxhost.so (include/vtx_host.h): ingest + read filters +
+haplotype construction -> packed batch.  CPU-only code; the packed batch then goes
+to ``vartrix_amd.lib.Context.submit``."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvtxhost.so")
+CLI_PATH = os.path.join(_HERE, "bin", "vartrix")
+
+SYMBOLS = ("vtxh_pack_files", "vtxh_free", "vtxh_last_error", "vtxh_get_batch", "vtxh_get_metrics",
+           "vtxh_num_variants", "vtxh_num_barcodes", "vtxh_variant_name", "vtxh_barcode", "vtxh_write_mtx",
+           "vtxh_format_f64")
+METRIC_NAMES = ("num_reads", "num_low_mapq", "num_non_primary", "num_duplicates", "num_not_cell_bc",
+                "num_not_useful", "num_non_umi", "num_invalid_recs", "num_multiallelic_recs")
+
+
+class VtxhArgs(C.Structure):
+    _fields_ = [("vcf", C.c_char_p), ("bam", C.c_char_p), ("fasta", C.c_char_p), ("cell_barcodes", C.c_char_p),
+                ("padding", C.c_uint32), ("mapq", C.c_uint32), ("primary_only", C.c_int32),
+                ("no_duplicates", C.c_int32), ("use_umi", C.c_int32), ("bam_tag", C.c_char_p),
+                ("valid_chars", C.c_char_p), ("threads", C.c_int32)]
+
+
+class VtxhMetrics(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in METRIC_NAMES]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not built (make -C vartrix_amd/csrc all)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.vtxh_pack_files.restype = C.c_int
+        L.vtxh_pack_files.argtypes = [C.POINTER(VtxhArgs), C.POINTER(C.c_void_p)]
+        L.vtxh_free.argtypes = [C.c_void_p]
+        L.vtxh_last_error.restype = C.c_char_p
+        L.vtxh_get_batch.argtypes = [C.c_void_p, C.POINTER(abi.VtxBatch)]
+        L.vtxh_get_metrics.argtypes = [C.c_void_p, C.POINTER(VtxhMetrics)]
+        L.vtxh_num_variants.restype = C.c_uint32
+        L.vtxh_num_variants.argtypes = [C.c_void_p]
+        L.vtxh_num_barcodes.restype = C.c_uint32
+        L.vtxh_num_barcodes.argtypes = [C.c_void_p]
+        L.vtxh_variant_name.restype = C.c_char_p
+        L.vtxh_variant_name.argtypes = [C.c_void_p, C.c_uint32]
+        L.vtxh_barcode.restype = C.c_char_p
+        L.vtxh_barcode.argtypes = [C.c_void_p, C.c_uint32]
+        L.vtxh_write_mtx.restype = C.c_int
+        L.vtxh_write_mtx.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vtxh_format_f64.restype = C.c_int
+        L.vtxh_format_f64.argtypes = [C.c_double, C.c_char_p]
+        _lib = L
+    return _lib
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def pack_files(vcf, bam, fasta, cell_barcodes, padding=100, mapq=0, primary_only=False, no_duplicates=False,
+               use_umi=False, bam_tag="CB", valid_chars="ATGCatgc", threads=1):
+    """-> (PackedBatch, metrics dict, n_variants, barcodes list, variant names)."""
+    L = load()
+    args = VtxhArgs(vcf.encode(), bam.encode(), fasta.encode(), cell_barcodes.encode(), padding, mapq,
+                    int(primary_only), int(no_duplicates), int(use_umi), bam_tag.encode(), valid_chars.encode(), threads)
+    h = C.c_void_p()
+    rc = L.vtxh_pack_files(C.byref(args), C.byref(h))
+    if rc != 0:
+        raise HostError(L.vtxh_last_error().decode())
+    try:
+        b = abi.VtxBatch()
+        L.vtxh_get_batch(h, C.byref(b))
+
+        def arr(ptr, n, dt):
+            if not n:
+                return np.zeros(0, dt)
+            return np.frombuffer(C.string_at(ptr, n * np.dtype(dt).itemsize), dtype=dt).copy()
+        batch = abi.PackedBatch(arr(b.loci, b.n_loci, abi.LOCUS_DTYPE), arr(b.records, b.n_records, abi.RECORD_DTYPE),
+                                arr(b.hap_arena, b.hap_bytes, np.uint8), arr(b.read_arena, b.read_bytes, np.uint8))
+        m = VtxhMetrics()
+        L.vtxh_get_metrics(h, C.byref(m))
+        metrics = {n: int(getattr(m, n)) for n in METRIC_NAMES}
+        nv, nb = L.vtxh_num_variants(h), L.vtxh_num_barcodes(h)
+        barcodes = [L.vtxh_barcode(h, j) for j in range(nb)]
+        variants = [L.vtxh_variant_name(h, i).decode() for i in range(nv)]
+    finally:
+        L.vtxh_free(h)
+    return batch, metrics, nv, barcodes, variants
+
+
+def write_mtx(path, n_rows, n_cols, row, col, value):
+    row = np.ascontiguousarray(row, np.uint32)
+    col = np.ascontiguousarray(col, np.uint32)
+    value = np.ascontiguousarray(value, np.float64)
+    rc = load().vtxh_write_mtx(path.encode(), n_rows, n_cols, len(row), row.ctypes.data, col.ctypes.data, value.ctypes.data)
+    if rc != 0:
+        raise HostError(load().vtxh_last_error().decode())
+
+
+def format_f64(v: float) -> str:
+    buf = C.create_string_buffer(40)
+    n = load().vtxh_format_f64(v, buf)
+    return buf.raw[:n].decode()

@@ -86,10 +86,33 @@ def tensors_to_coo(t: dict) -> dict:
     return out
 
 
-def gather_coo(local: dict, group=None, dst: int = 0):
-    """Gather every rank's triplet tensors to ``dst`` (rank order = row order).
+def _pack(local: dict, rows: int) -> torch.Tensor:
+    """Triplet arrays -> one int32 payload [rows, 9] (5 x u32, 2 x f64 as int32 pairs), zero padded."""
+    dev = local["row"].device
+    n = local["row"].shape[0]
+    buf = torch.zeros((rows, 9), dtype=torch.int32, device=dev)
+    if n:
+        for c, k in enumerate(("row", "col", "alt", "ref", "unk")):
+            buf[:n, c] = local[k]
+        buf[:n, 5:7] = local["value"].contiguous().view(torch.int32).view(n, 2)
+        buf[:n, 7:9] = local["ref_value"].contiguous().view(torch.int32).view(n, 2)
+    return buf
 
-    Returns the concatenated dict on ``dst`` and ``None`` elsewhere.
+
+def _unpack(buf: torch.Tensor) -> dict:
+    out = {k: buf[:, c].contiguous() for c, k in enumerate(("row", "col", "alt", "ref", "unk"))}
+    out["value"] = buf[:, 5:7].contiguous().view(torch.float64).view(-1)
+    out["ref_value"] = buf[:, 7:9].contiguous().view(torch.float64).view(-1)
+    return out
+
+
+def gather_coo(local: dict, group=None, dst: int = 0):
+    """Gather every rank's triplets to ``dst`` (rank order = row order).
+
+    One tiny all_gather of the counts, then ONE gather of a packed, padded int32
+    payload per rank (RCCL lowers gather to grouped send/recv: each rank's block
+    travels once over its direct xGMI link to ``dst``).  Returns the
+    concatenated dict on ``dst`` and ``None`` elsewhere.
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -98,19 +121,11 @@ def gather_coo(local: dict, group=None, dst: int = 0):
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts, n_local, group=group)
     counts = [int(c.item()) for c in counts]
-    if rank != dst:
-        if counts[rank]:
-            for k, _ in COO_FIELDS:
-                dist.send(local[k].contiguous(), dst=dst, group=group)
-        return None
-    parts = {k: [] for k, _ in COO_FIELDS}
-    for r in range(world):
-        for k, dt in COO_FIELDS:
-            if r == dst:
-                parts[k].append(local[k])
-            elif counts[r]:
-                buf = torch.empty(counts[r], dtype=_TORCH_DT[dt], device=dev)
-                dist.recv(buf, src=r, group=group)
-                parts[k].append(buf)
-    return {k: torch.cat(v) if v else torch.zeros(0, dtype=_TORCH_DT[dt], device=dev)
-            for (k, dt), v in zip(COO_FIELDS, parts.values())}
+    rows = max(max(counts), 1)
+    payload = _pack(local, rows)
+    if rank == dst:
+        bufs = [torch.empty((rows, 9), dtype=torch.int32, device=dev) for _ in range(world)]
+        dist.gather(payload, gather_list=bufs, dst=dst, group=group)
+        return _unpack(torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0))
+    dist.gather(payload, gather_list=None, dst=dst, group=group)
+    return None
