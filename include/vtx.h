@@ -148,13 +148,14 @@ typedef struct vtx_coo {
 } vtx_coo;
 
 /* Device-side timing of the last vtx_run, from hipEvents on the context's
- * stream (ms).  `sw_ms` covers the alignment kernel(s) only.                  */
+ * stream (ms).  `sw_ms` covers the alignment kernels only (full DP, and for
+ * the banded flavour the band kernel + band-masked DP).                      */
 typedef struct vtx_timing {
     float total_ms;
     float sw_ms;
     float reduce_ms;
     uint32_t sw_launches;
-    uint32_t reserved;
+    uint32_t hard_tasks;   /* banded flavour: alignments that needed the band-masked DP */
 } vtx_timing;
 
 typedef struct vtx_ctx vtx_ctx;

@@ -39,27 +39,78 @@ def assert_same(batch, cfg, threads=8):
     # alt_frac may hold NaN (0/0, src/main.rs:1140): compare bit patterns
     assert np.array_equal(coo["value"].view(np.uint64), ocoo["value"].view(np.uint64))
     assert np.array_equal(coo["ref_value"], ocoo["ref_value"])
-    assert cells == oracle.batch_cells(batch, cfg)
+    if cfg.aligner == 1:
+        assert cells == oracle.batch_cells(batch, cfg)
     return ref, alt, coo
 
 
+ALIGNERS = ["full", "banded"]
+
+
+@pytest.mark.parametrize("aligner", ALIGNERS)
 @pytest.mark.parametrize("mode", ["consensus", "alt_frac", "coverage"])
 @pytest.mark.parametrize("umi", [0, 1])
-def test_snv_batch(mode, umi):
+def test_snv_batch(mode, umi, aligner):
     spec = synth.SynthSpec(n_loci=96, n_barcodes=300, reads_per_locus=48, use_umi=bool(umi), seed=7 + umi)
     batch = synth.make_batch(spec)
-    cfg = default_config(aligner="full", scoring_mode=mode, use_umi=umi, n_barcodes=spec.n_barcodes)
+    cfg = default_config(aligner=aligner, scoring_mode=mode, use_umi=umi, n_barcodes=spec.n_barcodes)
     assert_same(batch, cfg)
 
 
+@pytest.mark.parametrize("aligner", ALIGNERS)
 @pytest.mark.parametrize("mode", ["consensus", "alt_frac", "coverage"])
-def test_indel_umi_ragged_batch(mode):
+def test_indel_umi_ragged_batch(mode, aligner):
     """Config-5 shape: SNV + indels <= 20bp, UMIs with disagreeing members, ragged read lengths."""
     spec = synth.SynthSpec(n_loci=128, n_barcodes=150, reads_per_locus=40, indel_frac=0.5, use_umi=True,
                            read_len_jitter=120, umi_flip=0.2, seed=11)
     batch = synth.make_batch(spec)
-    cfg = default_config(aligner="full", scoring_mode=mode, use_umi=1, n_barcodes=spec.n_barcodes)
+    cfg = default_config(aligner=aligner, scoring_mode=mode, use_umi=1, n_barcodes=spec.n_barcodes)
     assert_same(batch, cfg)
+
+
+def test_banded_differs_from_full_and_device_follows_the_band():
+    """On indel batches the band changes some scores; the device must track the banded oracle, and report
+    how many alignments needed the band-masked DP (the certificate handles the rest)."""
+    spec = synth.SynthSpec(n_loci=256, n_barcodes=200, reads_per_locus=48, indel_frac=0.6, read_len_jitter=60, seed=23,
+                           sub_error=0.02)
+    batch = synth.make_batch(spec)
+    cfgb = default_config(aligner="banded", scoring_mode="coverage", n_barcodes=spec.n_barcodes)
+    with lib.Context(cfgb) as ctx:
+        ctx.submit(batch)
+        ctx.run()
+        ref, alt = ctx.fetch_scores()
+        hard = ctx.timing().hard_tasks
+    oref, oalt = oracle.batch_scores(batch, cfgb, threads=8)
+    assert np.array_equal(ref, oref) and np.array_equal(alt, oalt)
+    fref, falt = oracle.batch_scores(batch, default_config(aligner="full", n_barcodes=spec.n_barcodes), threads=8)
+    n_diff = int((fref != oref).sum() + (falt != oalt).sum())
+    assert n_diff > 0, "workload too clean to exercise the band"
+    assert n_diff <= hard <= 2 * batch.n_records
+    print("banded != full on %d of %d alignments; %d took the masked DP" % (n_diff, 2 * batch.n_records, hard))
+
+
+def test_banded_low_complexity_overflow_slabs():
+    """Poly-A / tandem-repeat reads against repeat-rich haplotypes: thousands of k-mer matches per
+    alignment, which overflow the first scratch slab and take the larger-slab rerun."""
+    rng = np.random.default_rng(99)
+    haps, reads = [], []
+    for i in range(6):
+        flank = bytes(rng.choice(list(b"ACGT"), 80).tolist())
+        rep = [b"A" * 60, b"AC" * 30, b"AAAAAT" * 10, b"A" * 25 + b"G" + b"A" * 34, b"ACG" * 20, b"T" * 60][i]
+        ref = flank + rep + flank[::-1]
+        alt = flank + rep[:30] + b"C" + rep[31:] + flank[::-1]
+        haps.append((ref, alt))
+        rl = []
+        for k in range(10):
+            o = int(rng.integers(0, 60))
+            rd = bytearray((flank + rep + flank[::-1])[o:o + 150])
+            if k % 3 == 0:
+                rd = bytearray(b"A" * 150) if i % 2 == 0 else bytearray((b"AC" * 75))
+            rl.append((k % 5, 0, bytes(rd)))
+        reads.append(rl)
+    batch = _manual_batch(haps, reads, 8)
+    cfg = default_config(aligner="banded", scoring_mode="coverage", n_barcodes=8)
+    assert_same(batch, cfg, threads=4)
 
 
 @pytest.mark.parametrize("read_len", [1, 5, 17, 31, 32, 33, 64, 65, 100, 151, 160, 161, 200, 250, 256, 257, 400, 1000])
@@ -68,8 +119,9 @@ def test_read_length_buckets(read_len):
     spec = synth.SynthSpec(n_loci=12, n_barcodes=40, reads_per_locus=12, read_len=read_len,
                            padding=max(100, read_len // 2 + 20), indel_frac=0.4, seed=read_len)
     batch = synth.make_batch(spec)
-    cfg = default_config(aligner="full", scoring_mode="coverage", n_barcodes=spec.n_barcodes)
-    assert_same(batch, cfg, threads=8)
+    for aligner in ALIGNERS:
+        cfg = default_config(aligner=aligner, scoring_mode="coverage", n_barcodes=spec.n_barcodes)
+        assert_same(batch, cfg, threads=8)
 
 
 def _manual_batch(haps, reads_per_locus, n_barcodes):
@@ -102,10 +154,11 @@ def test_edge_cases():
         [],                                                              # locus with no reads
     ]
     batch = _manual_batch(haps, reads, 8)
-    for mode in ("consensus", "alt_frac", "coverage"):
-        for umi in (0, 1):
-            cfg = default_config(aligner="full", scoring_mode=mode, use_umi=umi, n_barcodes=8)
-            ref_s, alt_s, coo = assert_same(batch, cfg, threads=1)
+    for aligner in ALIGNERS:
+        for mode in ("consensus", "alt_frac", "coverage"):
+            for umi in (0, 1):
+                cfg = default_config(aligner=aligner, scoring_mode=mode, use_umi=umi, n_barcodes=8)
+                ref_s, alt_s, coo = assert_same(batch, cfg, threads=1)
     # identical haplotypes: every read ties
     l2 = batch.loci[2]
     sl = slice(int(l2["rec_begin"]), int(l2["rec_begin"] + l2["rec_count"]))
@@ -159,8 +212,9 @@ GOLDEN = [
 ]
 
 
+@pytest.mark.parametrize("aligner", ALIGNERS)
 @pytest.mark.parametrize("case", GOLDEN, ids=["consensus", "alt_frac", "coverage", "coverage_umi", "coverage_umi_gz"])
-def test_reference_fixtures_on_device(golden_dir, case):
+def test_reference_fixtures_on_device(golden_dir, case, aligner):
     """The reference's own regression tests (src/main.rs:1208-1390), device path: CSR-equal .mtx."""
     mode, umi, bcfile, main_fx, ref_fx = case
     g = golden_dir
@@ -168,7 +222,7 @@ def test_reference_fixtures_on_device(golden_dir, case):
     vcf = refpipe.read_vcf(os.path.join(g, "test.vcf"))
     batch, _ = refpipe.pack(vcf, refpipe.read_fasta(os.path.join(g, "test.fa")),
                             refpipe.read_bam(os.path.join(g, "test.bam")), bcs, refpipe.Args(use_umi=umi))
-    cfg = default_config(aligner="full", scoring_mode=mode, use_umi=int(umi), n_barcodes=len(bcs))
+    cfg = default_config(aligner=aligner, scoring_mode=mode, use_umi=int(umi), n_barcodes=len(bcs))
     ref, alt, coo = assert_same(batch, cfg, threads=1)
     shape, want = refpipe.read_mtx(os.path.join(g, main_fx))
     assert shape == (len(vcf), len(bcs))

@@ -111,7 +111,7 @@ class VtxTiming(C.Structure):
         ("sw_ms", C.c_float),
         ("reduce_ms", C.c_float),
         ("sw_launches", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("hard_tasks", C.c_uint32),
     ]
 
 

@@ -448,7 +448,7 @@ int vtxh_pack_files(const vtxh_args* a, vtxh_pack** out) {
         auto ti = tid_of.find(v.chrom);
         if (ti == tid_of.end()) return fail(VTX_E_INVAL, "Sequence %s not seen in BAM", v.chrom.c_str());
         const FaiEntry& fe = fa.seqs[fi->second];
-        const int64_t start = v.pos, end = v.pos + (int64_t)v.alleles[0].size();
+        const int64_t end = v.pos + (int64_t)v.alleles[0].size();
         if ((uint64_t)end > fe.len)
             return fail(VTX_E_INVAL, "Record %s:%lld has end position %lld, which is larger than the chromosome length (%llu). Does your FASTA match your VCF?",
                         v.chrom.c_str(), (long long)v.pos, (long long)end, (unsigned long long)fe.len);

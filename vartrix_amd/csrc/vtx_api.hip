@@ -70,6 +70,8 @@ struct vtx_ctx {
     DevBuf d_head_cell, d_head_umi, d_cell_scan, d_umi_scan, d_grp_row, d_grp_col, d_umi_cellgrp;
     DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
+    DevBuf d_band_ws, d_band_ws2, d_band, d_hard, d_over, d_over2, d_cnt;   // banded flavour
+    uint32_t max_read_len = 0;
     std::vector<uint32_t> h_row, h_col, h_alt, h_ref, h_unk;
     std::vector<double> h_val, h_refval;
 };
@@ -186,7 +188,8 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_alt, &c->d_head_cell, &c->d_head_umi, &c->d_cell_scan, &c->d_umi_scan, &c->d_grp_row,
                       &c->d_grp_col, &c->d_umi_cellgrp, &c->d_cell_cnt, &c->d_umi_cnt, &c->d_keep, &c->d_keep_scan,
                       &c->d_scan_tmp, &c->d_o_row, &c->d_o_col, &c->d_o_alt, &c->d_o_ref, &c->d_o_unk, &c->d_o_val,
-                      &c->d_o_refval};
+                      &c->d_o_refval, &c->d_band_ws, &c->d_band_ws2, &c->d_band, &c->d_hard, &c->d_over, &c->d_over2,
+                      &c->d_cnt};
     for (DevBuf* b : bufs) b->release();
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -205,7 +208,7 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
 
     // ---- validate + derive rec_locus, buckets, cell count (host; O(records)) ----
     std::vector<uint32_t> rec_locus(nr);
-    uint32_t next_rec = 0, max_hap = 0;
+    uint32_t next_rec = 0, max_hap = 0, max_read = 0;
     uint64_t cells = 0;
     for (uint32_t l = 0; l < nl; ++l) {
         const vtx_locus& L = b->loci[l];
@@ -227,6 +230,7 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
                     return fail(c, VTX_E_INVAL, "vtx_submit: record %u: not sorted by (cell_index, umi_id) within locus %u", r, l);
             }
             rec_locus[r] = l;
+            max_read = std::max(max_read, R.read_len);
             cells += (uint64_t)R.read_len * ((uint64_t)L.ref_len + L.alt_len);
         }
         next_rec = L.rec_begin + L.rec_count;
@@ -297,7 +301,7 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
     }
     // rec_locus / work are host vectors: the copies must land before they die
     HIP_TRY(c, hipStreamSynchronize(s));
-    c->n_loci = nl; c->n_records = nr; c->max_hap_len = max_hap; c->cells = cells;
+    c->n_loci = nl; c->n_records = nr; c->max_hap_len = max_hap; c->max_read_len = max_read; c->cells = cells;
     c->submitted = true;
     return VTX_OK;
 }
@@ -305,8 +309,6 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
 int vtx_run(vtx_ctx* c) {
     if (!c) return VTX_E_INVAL;
     if (!c->submitted) return fail(c, VTX_E_STATE, "vtx_run: no batch submitted");
-    if (c->cfg.aligner != VTX_ALIGNER_FULL)
-        return fail(c, VTX_E_UNSUPPORTED, "vtx_run: the banded aligner is not built on the device yet; use VTX_ALIGNER_FULL");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
     const uint32_t nr = c->n_records;
@@ -319,6 +321,62 @@ int vtx_run(vtx_ctx* c) {
                                        c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(),
                                        c->d_alt.as<int32_t>(), c->max_hap_len, s));
         ++launches;
+    }
+    uint32_t hard_total = 0;
+    if (c->cfg.aligner == VTX_ALIGNER_BANDED && nr) {
+        // Banded flavour: d_ref / d_alt hold the full scores.  Per chunk of tasks (task = 2*record + hap):
+        // band kernel (seed, chain, band, certificate) -> hard list -> band-masked DP overwrites hard scores.
+        const uint64_t n_tasks = 2ull * nr;
+        const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_tasks, 1u << 20);
+        const uint32_t band_stride = (c->max_hap_len + 2 + 7) & ~7u;
+        uint32_t m_cap = 512;
+        const size_t stride = vtxk_band_ws_stride(m_cap, c->max_hap_len);
+        HIP_TRY(c, c->d_band_ws.reserve((size_t)chunk * stride));
+        HIP_TRY(c, c->d_band.reserve((size_t)chunk * 2 * band_stride * sizeof(uint16_t)));
+        HIP_TRY(c, c->d_hard.reserve((size_t)chunk * sizeof(uint32_t)));
+        HIP_TRY(c, c->d_over.reserve((size_t)chunk * sizeof(uint32_t)));
+        HIP_TRY(c, c->d_cnt.reserve(2 * sizeof(uint32_t)));
+        int shape = 0;
+        while ((uint32_t)(kShapes[shape][0] * kShapes[shape][1]) < c->max_read_len) ++shape;
+        for (uint64_t base = 0; base < n_tasks; base += chunk) {
+            const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, n_tasks - base);
+            HIP_TRY(c, hipMemsetAsync(c->d_cnt.p, 0, 2 * sizeof(uint32_t), s));
+            HIP_TRY(c, vtxk_launch_band(nullptr, nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                        c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                        c->d_band_ws.as<uint8_t>(), stride, m_cap, c->max_hap_len, c->d_ref.as<int32_t>(),
+                                        c->d_alt.as<int32_t>(), c->d_band.as<uint16_t>(), band_stride, c->d_hard.as<uint32_t>(),
+                                        c->d_over.as<uint32_t>(), c->d_cnt.as<uint32_t>(), s));
+            uint32_t cnt[2] = {0, 0};
+            HIP_TRY(c, hipMemcpyAsync(cnt, c->d_cnt.p, sizeof cnt, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            // tasks whose k-mer matches did not fit the slab: rerun them alone with a larger one
+            uint32_t cap2 = m_cap;
+            while (cnt[1] > 0) {
+                const uint64_t worst = (uint64_t)c->max_read_len * c->max_hap_len;
+                if (cap2 >= worst) return fail(c, VTX_E_STATE, "vtx_run: band kernel overflow with a worst-case slab");
+                cap2 = (uint32_t)std::min<uint64_t>((uint64_t)cap2 * 16, worst);
+                const uint32_t n_over = cnt[1];
+                const size_t stride2 = vtxk_band_ws_stride(cap2, c->max_hap_len);
+                HIP_TRY(c, c->d_band_ws2.reserve((size_t)n_over * stride2));
+                HIP_TRY(c, c->d_over2.reserve((size_t)n_over * sizeof(uint32_t)));
+                HIP_TRY(c, hipMemcpyAsync(c->d_over2.p, c->d_over.p, (size_t)n_over * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+                HIP_TRY(c, hipMemsetAsync(c->d_cnt.as<uint32_t>() + 1, 0, sizeof(uint32_t), s));
+                HIP_TRY(c, vtxk_launch_band(c->d_over2.as<uint32_t>(), n_over, 0, c->d_records.as<vtx_record>(),
+                                            c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                            c->d_hap.as<uint8_t>(), c->d_band_ws2.as<uint8_t>(), stride2, cap2, c->max_hap_len,
+                                            c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_band.as<uint16_t>(), band_stride,
+                                            c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_cnt.as<uint32_t>(), s));
+                HIP_TRY(c, hipMemcpyAsync(cnt, c->d_cnt.p, sizeof cnt, hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipStreamSynchronize(s));
+                ++launches;
+            }
+            HIP_TRY(c, vtxk_launch_sw_banded(kShapes[shape][0], kShapes[shape][1], cnt[0], c->d_hard.as<uint32_t>(),
+                                             c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
+                                             c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_band.as<uint16_t>(), band_stride,
+                                             c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len, s));
+            hard_total += cnt[0];
+            launches += 2;
+        }
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     uint32_t nnz32 = 0;
@@ -351,7 +409,7 @@ int vtx_run(vtx_ctx* c) {
     HIP_TRY(c, hipEventElapsedTime(&t01, c->ev[0], c->ev[1]));
     HIP_TRY(c, hipEventElapsedTime(&t12, c->ev[1], c->ev[2]));
     c->timing.sw_ms = t01; c->timing.reduce_ms = t12; c->timing.total_ms = t01 + t12;
-    c->timing.sw_launches = launches; c->timing.reserved = 0;
+    c->timing.sw_launches = launches; c->timing.hard_tasks = hard_total;
     c->ran = true;
     return VTX_OK;
 }

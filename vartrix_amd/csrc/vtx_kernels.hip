@@ -371,3 +371,183 @@ extern "C" hipError_t vtxk_emit_coo(const uint32_t* cell_cnt, uint32_t n_grp, in
                        grp_row, grp_col, o_row, o_col, o_alt, o_ref, o_unk, o_val, o_refval);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------
+// Band-masked Smith-Waterman for the banded aligner flavour (vtx_band.hip).
+// Same systolic packed-i16 scheme, but the two 16-bit halves are two INDEPENDENT
+// tasks (task = 2 * record + haplotype) taken pairwise from the hard list, each
+// with its own read, haplotype and per-column row ranges [lo, hi) (oracle
+// coordinates: DP row ii = read index + 1, column jj = hap index + 1, row / column
+// 0 = boundary).  Out-of-band cells hold G = H+1 = "-inf" and Q = E = F = 0, so
+// nothing flows through them except the free local restart at 0 that every
+// in-band cell has anyway; `best` only sees in-band cells.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return AS_I(AS_S(a) - AS_S(b)); }
+__device__ __forceinline__ uint32_t pk_sign(uint32_t a) {   // 0xffff per half iff that half is negative
+    const v2s sh = {15, 15};
+    const v2s r = AS_S(a) >> sh;
+    return AS_I(r);
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+#define NEG_G PK(-16000)
+
+template <int R, int GL>
+__global__ __launch_bounds__(256) void sw_banded_kernel(
+    const uint32_t* __restrict__ hard, uint32_t n_hard,
+    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus,
+    const vtx_locus* __restrict__ loci, const uint8_t* __restrict__ read_arena,
+    const uint8_t* __restrict__ hap_arena, const uint16_t* __restrict__ band, uint32_t band_stride,
+    int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score, uint32_t lcols) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr int GROUPS_PER_BLOCK = 256 / GL;
+    constexpr int DPP = (GL == 16) ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
+    // One extra leading column: hap index j = -1 is the oracle's boundary column 0, processed like any
+    // other column (never-matching sentinel base, ranges lo[0], hi[0]), so the boundary state is
+    // produced by the same masked step.  Lane l processes hap index t - l - 1 at step t.
+    constexpr int PRE = GL + 1;
+    const int tid = threadIdx.x;
+    const int grp = tid / GL;
+    const int l = tid % GL;
+    const uint32_t pair = blockIdx.x * GROUPS_PER_BLOCK + grp;
+
+    // the two tasks of this record slot
+    uint32_t task[2], m[2] = {0, 0}, n[2] = {0, 0}, roff[2] = {0, 0}, hoff[2] = {0, 0};
+    bool act[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t s = 2 * pair + k;
+        act[k] = s < n_hard;
+        task[k] = 0;
+        if (act[k]) {
+            task[k] = hard[s];
+            const uint32_t rid = task[k] >> 1;
+            const vtx_record rec = records[rid];
+            const vtx_locus loc = loci[rec_locus[rid]];
+            m[k] = rec.read_len; roff[k] = rec.read_off;
+            n[k] = (task[k] & 1) ? loc.alt_len : loc.ref_len;
+            hoff[k] = (task[k] & 1) ? loc.alt_off : loc.ref_off;
+        }
+    }
+    uint32_t nwave = n[0] > n[1] ? n[0] : n[1];
+    if (GL == 16) {
+        nwave = max(nwave, (uint32_t)__shfl_xor((int)nwave, 16));
+        nwave = max(nwave, (uint32_t)__shfl_xor((int)nwave, 32));
+    }
+    const uint32_t steps = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nwave + GL));
+
+    // LDS per slot: columns, lo pairs, hi pairs (index PRE + j <-> hap index j, oracle column j + 1)
+    uint32_t* cols = smem + (size_t)grp * 3 * lcols;
+    uint32_t* los = cols + lcols;
+    uint32_t* his = los + lcols;
+    const uint32_t HAP_PAD = 0x0200u, READ_PAD = 0x0100u;
+    const uint16_t* bandA = band + (size_t)(2 * pair) * 2 * band_stride;        // lo[0..n], hi at + band_stride
+    const uint16_t* bandB = band + (size_t)(2 * pair + 1) * 2 * band_stride;
+    for (uint32_t idx = l; idx < PRE + steps + 2; idx += GL) {
+        const int j = (int)idx - PRE;
+        uint32_t ca = HAP_PAD, cb = HAP_PAD, la = 0x7fff, lb = 0x7fff, ha = 0, hb = 0;
+        if (j >= -1) {
+            if (act[0] && j < (int)n[0]) { if (j >= 0) ca = hap_arena[hoff[0] + j]; la = bandA[j + 1]; ha = bandA[band_stride + j + 1]; }
+            if (act[1] && j < (int)n[1]) { if (j >= 0) cb = hap_arena[hoff[1] + j]; lb = bandB[j + 1]; hb = bandB[band_stride + j + 1]; }
+        }
+        cols[idx] = ca | (cb << 16);
+        los[idx] = la | (lb << 16);
+        his[idx] = ha | (hb << 16);
+    }
+    uint32_t c[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = (uint32_t)(l * R + r);
+        const uint32_t ca = (act[0] && i < m[0]) ? (uint32_t)read_arena[roff[0] + i] : READ_PAD;
+        const uint32_t cb = (act[1] && i < m[1]) ? (uint32_t)read_arena[roff[1] + i] : READ_PAD;
+        c[r] = ca | (cb << 16);
+    }
+    __syncthreads();
+
+    const uint32_t one = PK(1), neg6 = PK(-6);
+    const uint32_t rowbase = PK(l * R + 1);                 // oracle row of this lane's r = 0
+    // boundary row 0 in band:  lo == 0 && hi > 0
+#define ROW0_MASK(lo2, hi2) (pk_sign(pk_sub(lo2, one)) & pk_sign(pk_sub(0u, hi2)))
+
+    uint32_t Ga[R], Qa[R], Ea[R], Gb[R], Qb[R], Eb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { Ga[r] = NEG_G; Qa[r] = 0; Ea[r] = 0; Gb[r] = NEG_G; Qb[r] = 0; Eb[r] = 0; }   // "column -1": outside
+    uint32_t best = 0;
+    uint32_t gu_a = NEG_G, gu_b = NEG_G, qu = 0, fu = 0, f_last = 0, q_bottom = 0;
+    const uint32_t* colp = cols + PRE - 1 - l;
+    const uint32_t* lop = los + PRE - 1 - l;
+    const uint32_t* hip = his + PRE - 1 - l;
+
+#define SWB_STEP(GS, QS, ES, GD, QD, ED, gprev, gcur, gsrc, t)                                     \
+    {                                                                                              \
+        const uint32_t hp = colp[t], lo2 = lop[t], hi2 = hip[t];                                   \
+        gcur = bfi(ROW0_MASK(lo2, hi2), one, NEG_G);          /* lane 0: boundary row of this column */ \
+        gcur = lane_shr1<DPP>(gcur, gsrc);                                                         \
+        qu = lane_shr1<DPP>(qu, q_bottom);                                                         \
+        fu = lane_shr1<DPP>(fu, f_last);                                                           \
+        const uint32_t am = pk_sub(lo2, rowbase), bm = pk_sub(hi2, rowbase);                       \
+        uint32_t gd = gprev, qa = qu, fa = fu;                                                     \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) {                                            \
+            const uint32_t mk = pk_sign(pk_sub(am, PK(r + 1))) & pk_sign(pk_sub(PK(r), bm));       \
+            const uint32_t ne = pk_min_u(c[r] ^ hp, one);                                          \
+            const uint32_t tt = pk_mad(ne, neg6, gd) & mk;                                         \
+            gd = GS[r];                                                                            \
+            const uint32_t e = pk_max(pk_sub_sat(ES[r], PK(1)), QS[r]) & mk;                       \
+            const uint32_t f = pk_max(pk_sub_sat(fa, PK(1)), qa) & mk;                             \
+            const uint32_t h = pk_max(pk_max(tt, e), f);                                           \
+            best = pk_max(best, tt);                                                               \
+            ED[r] = e;                                                                             \
+            GD[r] = bfi(mk, pk_add(h, PK(1)), NEG_G);                                              \
+            QD[r] = pk_sub_sat(h, PK(6)) & mk;                                                     \
+            fa = f; qa = QD[r];                                                                    \
+        }                                                                                          \
+        f_last = fa;                                                                               \
+    }
+    const uint32_t steps2 = (steps + 1) >> 1;
+    for (uint32_t t2 = 0; t2 < steps2; ++t2) {
+        q_bottom = Qb[R - 1];
+        SWB_STEP(Gb, Qb, Eb, Ga, Qa, Ea, gu_b, gu_a, Gb[R - 1], 2 * t2)
+        q_bottom = Qa[R - 1];
+        SWB_STEP(Ga, Qa, Ea, Gb, Qb, Eb, gu_a, gu_b, Ga[R - 1], 2 * t2 + 1)
+    }
+#undef SWB_STEP
+#undef ROW0_MASK
+
+#pragma unroll
+    for (int off = 1; off < GL; off <<= 1) best = pk_max(best, (uint32_t)__shfl_xor((int)best, off));
+    if (l == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!act[k]) continue;
+            const int32_t sc = (int32_t)(int16_t)((best >> (16 * k)) & 0xffffu);
+            if (task[k] & 1) alt_score[task[k] >> 1] = sc; else ref_score[task[k] >> 1] = sc;
+        }
+    }
+}
+
+extern "C" hipError_t vtxk_launch_sw_banded(int R, int GL, uint32_t n_hard, const uint32_t* hard,
+                                            const vtx_record* records, const uint32_t* rec_locus, const vtx_locus* loci,
+                                            const uint8_t* read_arena, const uint8_t* hap_arena, const uint16_t* band,
+                                            uint32_t band_stride, int32_t* ref_score, int32_t* alt_score,
+                                            uint32_t max_hap_len, hipStream_t stream) {
+    if (n_hard == 0) return hipSuccess;
+    const uint32_t groups = 256 / GL;
+    const uint32_t pairs = (n_hard + 1) / 2;
+    const uint32_t lcols = ((GL + max_hap_len + GL + 8) + 3u) & ~3u;
+    const size_t shmem = (size_t)groups * 3 * lcols * sizeof(uint32_t);
+    const dim3 grid((pairs + groups - 1) / groups), block(256);
+#define CASE(r, gl)                                                                                       \
+    if (R == r && GL == gl) {                                                                             \
+        if (shmem > 48 * 1024) {                                                                          \
+            hipError_t e = hipFuncSetAttribute((const void*)sw_banded_kernel<r, gl>,                      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);   \
+            if (e != hipSuccess) return e;                                                                \
+        }                                                                                                 \
+        hipLaunchKernelGGL((sw_banded_kernel<r, gl>), grid, block, shmem, stream, hard, n_hard, records,  \
+                           rec_locus, loci, read_arena, hap_arena, band, band_stride, ref_score, alt_score, lcols); \
+        return hipGetLastError();                                                                         \
+    }
+    CASE(2, 16) CASE(4, 16) CASE(6, 16) CASE(8, 16) CASE(10, 16) CASE(12, 16) CASE(16, 16) CASE(8, 64) CASE(16, 64)
+#undef CASE
+    return hipErrorInvalidValue;
+}
