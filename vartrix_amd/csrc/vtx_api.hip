@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -71,7 +72,7 @@ struct vtx_ctx {
     DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
     DevBuf d_band_ws, d_band_ws2, d_band, d_hard, d_over, d_over2, d_cnt;   // banded flavour
-    uint32_t max_read_len = 0;
+    uint32_t max_read_len = 0, fast_overflow = 0;
     std::vector<uint32_t> h_row, h_col, h_alt, h_ref, h_unk;
     std::vector<double> h_val, h_refval;
 };
@@ -329,28 +330,36 @@ int vtx_run(vtx_ctx* c) {
         const uint64_t n_tasks = 2ull * nr;
         const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_tasks, 1u << 20);
         const uint32_t band_stride = (c->max_hap_len + 2 + 7) & ~7u;
-        uint32_t m_cap = 512;
-        const size_t stride = vtxk_band_ws_stride(m_cap, c->max_hap_len);
-        HIP_TRY(c, c->d_band_ws.reserve((size_t)chunk * stride));
+        const uint32_t m_cap = 512;
+        uint32_t fast_overflow = 0;
+        HIP_TRY(c, c->d_band_ws.reserve((size_t)chunk * 24 * 2 * sizeof(uint32_t)));   // jump log of the fast kernel
         HIP_TRY(c, c->d_band.reserve((size_t)chunk * 2 * band_stride * sizeof(uint16_t)));
         HIP_TRY(c, c->d_hard.reserve((size_t)chunk * sizeof(uint32_t)));
         HIP_TRY(c, c->d_over.reserve((size_t)chunk * sizeof(uint32_t)));
-        HIP_TRY(c, c->d_cnt.reserve(2 * sizeof(uint32_t)));
+        HIP_TRY(c, c->d_cnt.reserve(8 * sizeof(uint32_t)));
         int shape = 0;
         while ((uint32_t)(kShapes[shape][0] * kShapes[shape][1]) < c->max_read_len) ++shape;
         for (uint64_t base = 0; base < n_tasks; base += chunk) {
             const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, n_tasks - base);
-            HIP_TRY(c, hipMemsetAsync(c->d_cnt.p, 0, 2 * sizeof(uint32_t), s));
-            HIP_TRY(c, vtxk_launch_band(nullptr, nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                        c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
-                                        c->d_band_ws.as<uint8_t>(), stride, m_cap, c->max_hap_len, c->d_ref.as<int32_t>(),
-                                        c->d_alt.as<int32_t>(), c->d_band.as<uint16_t>(), band_stride, c->d_hard.as<uint32_t>(),
-                                        c->d_over.as<uint32_t>(), c->d_cnt.as<uint32_t>(), s));
+            HIP_TRY(c, hipMemsetAsync(c->d_cnt.p, 0, 8 * sizeof(uint32_t), s));
+            // fast streaming band kernel for every task of the chunk; what it cannot hold goes to the general one
+            HIP_TRY(c, vtxk_launch_band_fast(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                             c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                             c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
+                                             c->d_band_ws.as<uint32_t>(), c->d_band.as<uint16_t>(), band_stride,
+                                             c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_cnt.as<uint32_t>(), s));
             uint32_t cnt[2] = {0, 0};
             HIP_TRY(c, hipMemcpyAsync(cnt, c->d_cnt.p, sizeof cnt, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
+            fast_overflow += cnt[1];
+            if (getenv("VTX_DEBUG")) {
+                uint32_t why[8];
+                HIP_TRY(c, hipMemcpy(why, c->d_cnt.p, sizeof why, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[vtx] chunk: overflow reasons inside-run=%u runs-full=%u log-full=%u fifo-full=%u traceback=%u\n", why[3], why[4], why[5], why[6], why[7]);
+            }
+            // general kernel (per-task scratch slab) on the overflow list; slabs grow until every task fits
+            uint32_t cap2 = m_cap / 16;
             // tasks whose k-mer matches did not fit the slab: rerun them alone with a larger one
-            uint32_t cap2 = m_cap;
             while (cnt[1] > 0) {
                 const uint64_t worst = (uint64_t)c->max_read_len * c->max_hap_len;
                 if (cap2 >= worst) return fail(c, VTX_E_STATE, "vtx_run: band kernel overflow with a worst-case slab");
@@ -370,13 +379,18 @@ int vtx_run(vtx_ctx* c) {
                 HIP_TRY(c, hipStreamSynchronize(s));
                 ++launches;
             }
+            HIP_TRY(c, vtxk_launch_band_expand(c->d_hard.as<uint32_t>(), cnt[0], c->d_records.as<vtx_record>(),
+                                               c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_band.as<uint16_t>(),
+                                               band_stride, s));
             HIP_TRY(c, vtxk_launch_sw_banded(kShapes[shape][0], kShapes[shape][1], cnt[0], c->d_hard.as<uint32_t>(),
                                              c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
                                              c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_band.as<uint16_t>(), band_stride,
                                              c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len, s));
             hard_total += cnt[0];
-            launches += 2;
+            launches += 3;
         }
+        c->fast_overflow = fast_overflow;
+        if (getenv("VTX_DEBUG")) fprintf(stderr, "[vtx] banded: %llu tasks, %u overflowed the fast band kernel, %u hard\n", (unsigned long long)n_tasks, fast_overflow, hard_total);
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     uint32_t nnz32 = 0;

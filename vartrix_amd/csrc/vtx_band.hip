@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "vtx_device.h"
 
 #define KMER 6
@@ -275,5 +277,437 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
     hipLaunchKernelGGL(band_kernel, dim3((n_tasks + 63) / 64), dim3(64), 0, s, tasks, n_tasks, task_base, records,
                        rec_locus, loci, read_arena, hap_arena, workspace, ws_stride, m_cap, max_hap, ref_score, alt_score,
                        band, band_stride, hard_list, overflow_list, counters);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// band_fast_kernel — the common-case band kernel: one lane per task, STREAMING over read rows.
+//
+// Same results as band_kernel (sdpkpp chain -> staircase -> certificate), restructured so the
+// per-lane state is a few dozen LDS words instead of a per-task global scratch slab:
+//   * haplotype k-mer tables (48-bit k-mer words, chained hash with ascending-y chains, raw bytes)
+//     are built ONCE per (locus, haplotype) per workgroup in LDS and shared by its tasks;
+//   * sdpkpp needs, at a match (x, y), max (V, idx) over matches that ENDED at (<= x, <= y).  Ended
+//     matches live in a dominance-pruned staircase (ye ascending, V strictly increasing) which stays
+//     tiny because an entry is dead once V + 1 - (x + ye) < K (it can never again beat a fresh
+//     start); matches of the last K rows wait in a FIFO until their end becomes visible, and the
+//     FIFO also answers "does (x-1, y-1) exist and what is its dp" (LCSk++ continuation);
+//   * only non-continuation matches (chain starts and jumps) are logged (global memory) — the
+//     traceback hops through that log, so the chain comes out as a few diagonal segments;
+//   * the certificate walk adds +1 per k-mer cell without touching bytes (k-mer cells are exact
+//     matches), bytes are compared only in gap diagonals and the lazy extensions.
+// Any capacity overflow (staircase, FIFO, log, segments) sends the task to band_kernel via
+// overflow_list: results never depend on which kernel handled a task.
+// Hard tasks get a polyline (vertex list) in their band slot, flagged 0xffff; band_expand_kernel
+// turns it into the lo / hi arrays sw_banded_kernel reads.
+// =============================================================================================
+#define PS 12       // staircase runs per lane
+#define PQ 16       // pending FIFO entries per lane
+#define LG 24       // jump-log entries per task (global)
+#define SG 10       // chain segments per task
+#define TB_HEADS 512
+#define NONE_ID 0xffffffffu
+
+struct hap_table {
+    uint32_t n;
+    const uint32_t* kwlo;   // low 32 bits of the 48-bit k-mer word at y
+    const uint16_t* kwhi;   // high 16 bits
+    const uint16_t* next;   // chain (ascending y), 0xffff ends
+    const uint16_t* head;   // TB_HEADS
+    const uint8_t* bytes;   // raw haplotype bytes
+};
+
+__device__ __forceinline__ uint32_t kw_hash(uint32_t lo, uint32_t hi) {
+    uint32_t h = lo * 0x9E3779B1u ^ (hi + 0x7F4A7C15u) * 0x85EBCA77u;
+    return (h >> 20) & (TB_HEADS - 1);
+}
+
+extern "C" size_t vtxk_band_table_stride(uint32_t max_hap) {
+    size_t o = (size_t)max_hap * 4 + (size_t)max_hap * 2 * 2 + TB_HEADS * 2 + ((size_t)max_hap + 8);
+    return (o + 15) & ~(size_t)15;
+}
+
+__global__ __launch_bounds__(256) void band_fast_kernel(
+    uint32_t n_tasks, uint32_t task_base,
+    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
+    const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
+    uint32_t max_hap, uint32_t tables_per_pass, uint32_t table_stride,
+    const int32_t* __restrict__ ref_score, const int32_t* __restrict__ alt_score,
+    uint32_t* __restrict__ logbuf, uint16_t* __restrict__ band, uint32_t band_stride,
+    uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x;
+    // per-lane LDS arrays, element i of lane tid at [i * 256 + tid]
+    // staircase of ended matches, stored as RUNS: elements (ye0 + t, V0 + 3t, id0 + t*(1,1)), t < len
+    // (a continued k-mer adds +1 to ye and, with dp + 1, +3 to V = dp + xe + ye)
+    uint32_t* pm_a = smem;                     // ye0 << 16 | V0
+    uint32_t* pm_id = pm_a + PS * 256;         // id0
+    uint32_t* pm_l = pm_id + PS * 256;         // len
+    uint32_t* fq_id = pm_l + PS * 256;         // x << 16 | y
+    uint32_t* fq_dp = fq_id + PQ * 256;
+    uint8_t* tables = (uint8_t*)(fq_dp + PQ * 256);
+#define PM_A(i) pm_a[(i) * 256 + tid]
+#define PM_ID(i) pm_id[(i) * 256 + tid]
+#define PM_L(i) pm_l[(i) * 256 + tid]
+#define FQ_ID(i) fq_id[((i) & (PQ - 1)) * 256 + tid]
+#define FQ_DP(i) fq_dp[((i) & (PQ - 1)) * 256 + tid]
+
+    const uint32_t slot = blockIdx.x * 256 + tid;
+    const bool have = slot < n_tasks;
+    const uint32_t task = task_base + slot;
+    uint32_t rid = 0, hap = 0, my_locus = 0, m = 0, n = 0;
+    const uint8_t* x = nullptr;
+    if (have) {
+        rid = task >> 1; hap = task & 1;
+        const vtx_record rec = records[rid];
+        my_locus = rec_locus[rid];
+        m = rec.read_len;
+        x = read_arena + rec.read_off;
+        n = hap ? loci[my_locus].alt_len : loci[my_locus].ref_len;
+    }
+    // locus range of this workgroup (tasks are in record order, records in locus order)
+    const uint32_t first_task = task_base + blockIdx.x * 256;
+    const uint32_t last_task = min(task_base + n_tasks - 1, first_task + 255);
+    const uint32_t l_first = rec_locus[first_task >> 1], l_last = rec_locus[last_task >> 1];
+    const uint32_t loci_per_pass = tables_per_pass / 2;
+    bool done = !have || m == 0 || n == 0;     // empty read / haplotype: score 0 == full
+    uint32_t* mylog = logbuf + (size_t)slot * LG * 2;
+
+    for (uint32_t lbase = l_first; lbase <= l_last; lbase += loci_per_pass) {
+        __syncthreads();
+        // ---- build the haplotype tables of loci [lbase, lbase + loci_per_pass) ----
+        const uint32_t n_tab = min(loci_per_pass, l_last - lbase + 1) * 2;
+        for (uint32_t t = 0; t < n_tab; ++t) {
+            const vtx_locus loc = loci[lbase + (t >> 1)];
+            const uint32_t hn = (t & 1) ? loc.alt_len : loc.ref_len;
+            const uint8_t* hy = hap_arena + ((t & 1) ? loc.alt_off : loc.ref_off);
+            uint8_t* tb = tables + (size_t)t * table_stride;
+            uint32_t* kwlo = (uint32_t*)tb;
+            uint16_t* kwhi = (uint16_t*)(tb + (size_t)max_hap * 4);
+            uint16_t* head = kwhi + 2 * (size_t)max_hap;
+            uint8_t* bytes = (uint8_t*)(head + TB_HEADS);
+            for (uint32_t y = tid; y < hn; y += 256) {
+                bytes[y] = hy[y];
+                if (y + KMER <= hn) {
+                    kwlo[y] = (uint32_t)hy[y] | ((uint32_t)hy[y + 1] << 8) | ((uint32_t)hy[y + 2] << 16) | ((uint32_t)hy[y + 3] << 24);
+                    kwhi[y] = (uint16_t)((uint32_t)hy[y + 4] | ((uint32_t)hy[y + 5] << 8));
+                }
+            }
+            for (uint32_t i = tid; i < TB_HEADS; i += 256) head[i] = 0xffff;
+        }
+        __syncthreads();
+        if ((uint32_t)tid < n_tab) {     // one lane per table: sequential head insertion, descending y => ascending chains
+            const vtx_locus loc = loci[lbase + ((uint32_t)tid >> 1)];
+            const uint32_t hn = (tid & 1) ? loc.alt_len : loc.ref_len;
+            uint8_t* tb = tables + (size_t)tid * table_stride;
+            const uint32_t* kwlo = (const uint32_t*)tb;
+            uint16_t* kwhi = (uint16_t*)(tb + (size_t)max_hap * 4);
+            uint16_t* next = kwhi + max_hap;
+            uint16_t* head = kwhi + 2 * (size_t)max_hap;
+            if (hn >= KMER)
+                for (int y = (int)hn - KMER; y >= 0; --y) {
+                    const uint32_t h = kw_hash(kwlo[y], kwhi[y]);
+                    next[y] = head[h]; head[h] = (uint16_t)y;
+                }
+        }
+        __syncthreads();
+        if (done || my_locus < lbase || my_locus >= lbase + loci_per_pass) continue;
+        done = true;
+        // ---- this lane's table ----
+        const uint8_t* tb = tables + (size_t)((my_locus - lbase) * 2 + hap) * table_stride;
+        const uint32_t* kwlo = (const uint32_t*)tb;
+        const uint16_t* kwhi = (const uint16_t*)(tb + (size_t)max_hap * 4);
+        const uint16_t* next = kwhi + max_hap;
+        const uint16_t* head = kwhi + 2 * (size_t)max_hap;
+        const uint8_t* yb = (const uint8_t*)(head + TB_HEADS);
+        const int32_t full = hap ? alt_score[rid] : ref_score[rid];
+        if (m < KMER || n < KMER) continue;                 // no k-mer: Band::full_matrix, banded == full
+
+        // ---- streaming sdpkpp ----
+        uint32_t pm_n = 0, fq_head = 0, fq_n = 0, lg_n = 0;
+        int32_t best_v = -1; uint32_t best_id = 0;
+        bool overflow = false;
+        uint32_t why = 0;
+        uint32_t wlo = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
+        uint32_t whi = (uint32_t)x[4] | ((uint32_t)x[5] << 8);
+        for (uint32_t xr = 0; xr + KMER <= m && !overflow; ++xr) {
+            // (a) ends that became visible: matches with xq + K <= xr
+            while (fq_n > 0 && (FQ_ID(fq_head) >> 16) + KMER <= xr) {
+                const uint32_t id = FQ_ID(fq_head), dp = FQ_DP(fq_head);
+                ++fq_head; --fq_n;
+                const uint32_t ye = (id & 0xffff) + KMER, xe = (id >> 16) + KMER;
+                const uint32_t V = dp + xe + ye;
+                // j = number of runs starting at or before column ye
+                uint32_t j = 0;
+                while (j < pm_n && (PM_A(j) >> 16) <= ye) ++j;
+                bool placed = false;
+                if (j > 0) {
+                    const uint32_t a = PM_A(j - 1), len = PM_L(j - 1);
+                    const uint32_t y0 = a >> 16, v0 = a & 0xffff;
+                    const uint32_t t = min(len - 1, ye - y0);
+                    if (v0 + 3 * t > V) continue;                       // dominated (ids grow: ties go to the new element)
+                    if (ye <= y0 + len - 1) {
+                        // lands inside run j-1 at element t (same column, V' <= V): elements t .. te-1 go
+                        const uint32_t te = (V - v0) / 3 + 1;
+                        if (t == 0) {
+                            --j;                                        // the run starts at this column: generic trimming below
+                        } else if (te >= len) {
+                            PM_L(j - 1) = t;                            // keep the prefix, nothing of the run survives after it
+                        } else {
+                            // prefix [0, t) stays, then the new element, then the suffix [te, len) as its own run
+                            if (pm_n + 2 > PS) { overflow = true; why = 2; break; }
+                            for (uint32_t i = pm_n; i > j; --i) {
+                                PM_A(i + 1) = PM_A(i - 1); PM_ID(i + 1) = PM_ID(i - 1); PM_L(i + 1) = PM_L(i - 1);
+                            }
+                            PM_L(j - 1) = t;
+                            PM_A(j) = (ye << 16) | V; PM_ID(j) = id; PM_L(j) = 1;
+                            PM_A(j + 1) = ((y0 + te) << 16) | (v0 + 3 * te);
+                            PM_ID(j + 1) = PM_ID(j - 1) + te * 0x10001u;
+                            PM_L(j + 1) = len - te;
+                            pm_n += 2;
+                            placed = true;
+                        }
+                    } else if (j == pm_n && ye == y0 + len && V == v0 + 3 * len && id == PM_ID(j - 1) + len * 0x10001u) {
+                        PM_L(j - 1) = len + 1;                          // typical: continues the last run
+                        placed = true;
+                    }
+                }
+                if (placed) continue;
+                // drop / trim following runs whose elements have V' <= V (they are at columns >= ye)
+                uint32_t last = j;
+                while (last < pm_n) {
+                    const uint32_t a = PM_A(last), len = PM_L(last);
+                    const uint32_t v0 = a & 0xffff;
+                    if (v0 > V) break;
+                    const uint32_t k = (V - v0) / 3 + 1;                // elements 0..k-1 have V' <= V
+                    if (k >= len) { ++last; continue; }
+                    PM_A(last) = (((a >> 16) + k) << 16) | (v0 + 3 * k);
+                    PM_ID(last) = PM_ID(last) + k * 0x10001u;
+                    PM_L(last) = len - k;
+                    break;
+                }
+                if (last == j) {                                        // make room at j
+                    if (pm_n == PS) { overflow = true; why = 2; break; }
+                    for (uint32_t i = pm_n; i > j; --i) { PM_A(i) = PM_A(i - 1); PM_ID(i) = PM_ID(i - 1); PM_L(i) = PM_L(i - 1); }
+                    ++pm_n;
+                } else if (last > j + 1) {
+                    const uint32_t d = last - j - 1;
+                    for (uint32_t i = last; i < pm_n; ++i) { PM_A(i - d) = PM_A(i); PM_ID(i - d) = PM_ID(i); PM_L(i - d) = PM_L(i); }
+                    pm_n -= d;
+                }
+                PM_A(j) = (ye << 16) | V; PM_ID(j) = id; PM_L(j) = 1;
+            }
+            if (overflow) break;
+            // (b) prune dead elements: element t of a run is alive iff V0 + 3t + 1 - (xr + ye0 + t) >= K
+            {
+                uint32_t w = 0;
+                for (uint32_t i = 0; i < pm_n; ++i) {
+                    const uint32_t a = PM_A(i), len = PM_L(i);
+                    const int32_t need = (int32_t)(xr + (a >> 16)) + KMER - 1 - (int32_t)(a & 0xffff);   // 2t >= need
+                    const uint32_t k = need > 0 ? (uint32_t)(need + 1) >> 1 : 0;
+                    if (k >= len) continue;
+                    PM_A(w) = (((a >> 16) + k) << 16) | ((a & 0xffff) + 3 * k);
+                    PM_ID(w) = PM_ID(i) + k * 0x10001u;
+                    PM_L(w) = len - k;
+                    ++w;
+                }
+                pm_n = w;
+            }
+            // (c) matches of this row, ascending y
+            for (uint32_t y = head[kw_hash(wlo, whi)]; y != 0xffff; y = next[y]) {
+                if (kwlo[y] != wlo || kwhi[y] != (uint16_t)whi) continue;
+                const uint32_t id = (xr << 16) | y;
+                // LCSk++ continuation: is (xr-1, y-1) a match?  It would be among the newest FIFO entries.
+                int32_t dpc = -1;
+                if (xr > 0 && y > 0) {
+                    const uint32_t want = ((xr - 1) << 16) | (y - 1);
+                    for (uint32_t i = fq_n; i-- > 0;) {
+                        const uint32_t q = FQ_ID(fq_head + i);
+                        if ((q >> 16) + 1 < xr) break;
+                        if (q == want) { dpc = (int32_t)FQ_DP(fq_head + i); break; }
+                    }
+                }
+                // start candidate: last staircase element with ye <= y
+                int32_t dp = KMER; uint32_t prev = NONE_ID;
+                for (uint32_t i = pm_n; i-- > 0;) {
+                    const uint32_t a = PM_A(i);
+                    if ((a >> 16) <= y) {
+                        const uint32_t t = min(PM_L(i) - 1, y - (a >> 16));
+                        const int32_t cand = (int32_t)((a & 0xffff) + 3 * t) - 5 - (int32_t)(xr + y) + KMER;
+                        if (cand >= dp) { dp = cand; prev = PM_ID(i) + t * 0x10001u; }
+                        break;
+                    }
+                }
+                bool cont = false;
+                if (dpc >= 0 && dpc + 1 >= dp) { dp = dpc + 1; cont = true; }   // ties: continuation has the larger index
+                if (!cont) {
+                    if (lg_n == LG) { overflow = true; why = 3; break; }
+                    mylog[2 * lg_n] = id; mylog[2 * lg_n + 1] = prev; ++lg_n;
+                }
+                if (fq_n == PQ) { overflow = true; why = 4; break; }
+                FQ_ID(fq_head + fq_n) = id; FQ_DP(fq_head + fq_n) = (uint32_t)dp; ++fq_n;
+                if (dp >= best_v) { best_v = dp; best_id = id; }
+            }
+            // (d) slide the 48-bit window
+            if (xr + KMER < m) {
+                wlo = (wlo >> 8) | (whi << 24);
+                whi = ((whi >> 8) & 0xff) | ((uint32_t)x[xr + KMER] << 8);
+            }
+        }
+        if (overflow) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[2 + why], 1u); continue; }
+        if (best_v < 0) continue;                            // no match at all: full matrix
+        // ---- traceback through the jump log: chain = diagonal segments (x0, y0, len), last first ----
+        uint32_t seg_xy[SG], seg_len[SG];
+        uint32_t n_seg = 0;
+        uint32_t cur = best_id;
+        bool bad = false;
+        while (true) {
+            const int32_t cx = (int32_t)(cur >> 16), cy = (int32_t)(cur & 0xffff);
+            int32_t bx = -1; uint32_t bprev = NONE_ID, bid = 0;
+            for (uint32_t i = 0; i < lg_n; ++i) {
+                const uint32_t p = mylog[2 * i];
+                const int32_t px = (int32_t)(p >> 16), py = (int32_t)(p & 0xffff);
+                if (py - px == cy - cx && px <= cx && px > bx) { bx = px; bprev = mylog[2 * i + 1]; bid = p; }
+            }
+            if (bx < 0 || n_seg == SG) { bad = true; break; }
+            seg_xy[n_seg] = bid; seg_len[n_seg] = (uint32_t)(cx - bx + 1); ++n_seg;
+            if (bprev == NONE_ID) break;
+            cur = bprev;
+        }
+        if (bad) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[7], 1u); continue; }
+        // ---- staircase walk: certificate, and the polyline if the task turns out hard ----
+        // One vertex after every non-empty piece (pure diagonal / vertical / horizontal).
+        uint32_t verts[4 * SG + 6];
+        uint32_t nv = 0;
+        const uint32_t fst = seg_xy[n_seg - 1];
+        const int fx = (int)(fst >> 16), fy = (int)(fst & 0xffff);
+        int d0 = fx < fy ? fx : fy; if (d0 > 2 * KMER) d0 = 2 * KMER;
+        int r = fx - d0, c = fy - d0;
+        walk_state w = {0, -100000, 0, 0};
+#define EMIT() verts[nv++] = ((uint32_t)r << 16) | (uint32_t)c
+        EMIT();
+        for (int i = 0; i < d0; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
+        if (d0 > 0) EMIT();
+        for (uint32_t sgi = n_seg; sgi-- > 0;) {
+            const int px = (int)(seg_xy[sgi] >> 16), py = (int)(seg_xy[sgi] & 0xffff);
+            int dr = px - r, dc = py - c;
+            const int dg = dr < dc ? dr : dc;
+            for (int i = 0; i < dg; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
+            if (dg > 0) EMIT();
+            dr = px - r; dc = py - c;
+            for (int i = 0; i < dr; ++i) { ++r; walk_gap(w, 1); }
+            if (dr > 0) EMIT();
+            for (int i = 0; i < dc; ++i) { ++c; walk_gap(w, 2); }
+            if (dc > 0) EMIT();
+            // the segment's k-mer cells: len + K - 1 diagonal steps, every one an exact match
+            const int run = (int)seg_len[sgi] + KMER - 1;
+            const int32_t v = (w.s > w.gap ? w.s : w.gap) + 1;      // s >= 0, so v >= 1
+            w.s = v + (run - 1); w.gap = -100000; w.dir = 0;
+            if (w.s > w.best) w.best = w.s;
+            r += run; c += run;
+            EMIT();
+        }
+        int d1 = ((int)m - r) < ((int)n - c) ? ((int)m - r) : ((int)n - c); if (d1 > 2 * KMER) d1 = 2 * KMER;
+        for (int i = 0; i < d1; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
+        if (d1 > 0) EMIT();
+#undef EMIT
+        if (w.best == full) continue;                        // banded == full
+        const uint32_t h = atomicAdd(&counters[0], 1u);
+        hard_list[h] = task;
+        uint16_t* lo = band + (size_t)h * 2 * band_stride;
+        lo[0] = 0xffff; lo[1] = (uint16_t)nv;
+        uint32_t* vout = (uint32_t*)(lo + 2);
+        for (uint32_t i = 0; i < nv; ++i) vout[i] = verts[i];
+    }
+#undef PM_A
+#undef PM_ID
+#undef PM_L
+#undef FQ_ID
+#undef FQ_DP
+}
+
+// Polyline -> lo / hi arrays, one 16-lane group per hard slot (slots written by band_kernel already
+// hold arrays and are skipped).  Vertices are joined by pure diagonal / vertical / horizontal pieces.
+__global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __restrict__ hard_list, uint32_t n_hard,
+                                                          const vtx_record* __restrict__ records,
+                                                          const uint32_t* __restrict__ rec_locus,
+                                                          const vtx_locus* __restrict__ loci,
+                                                          uint16_t* __restrict__ band, uint32_t band_stride) {
+    __shared__ uint32_t sv[16][4 * SG + 8];
+    const int grp = threadIdx.x / 16, l = threadIdx.x % 16;
+    const uint32_t h = blockIdx.x * 16 + grp;
+    uint16_t* lo = band + (size_t)(h < n_hard ? h : 0) * 2 * band_stride;
+    uint16_t* hi = lo + band_stride;
+    const bool poly = h < n_hard && lo[0] == 0xffff;
+    uint32_t nv = 0;
+    if (poly) {
+        nv = lo[1];
+        const uint32_t* vin = (const uint32_t*)(lo + 2);
+        for (uint32_t i = l; i < nv; i += 16) sv[grp][i] = vin[i];
+    }
+    __syncthreads();
+    if (!poly) return;
+    const uint32_t task = hard_list[h];
+    const vtx_record rec = records[task >> 1];
+    const vtx_locus loc = loci[rec_locus[task >> 1]];
+    const int m = (int)rec.read_len, n = (int)((task & 1) ? loc.alt_len : loc.ref_len);
+    const int rows = m + 1;
+    const uint32_t* v = sv[grp];
+    const int cA = (int)(v[0] & 0xffff), cB = (int)(v[nv - 1] & 0xffff);
+    for (int j = l; j <= n; j += 16) {
+        uint16_t lj = 0x7fff, hj = 0;
+        if (j >= cA - BANDW && j <= cB + BANDW) {
+            const int c0 = j - BANDW > cA ? j - BANDW : cA;
+            const int c1 = j + BANDW < cB ? j + BANDW : cB;
+            // first anchor row in column c0: first piece that covers c0
+            int rmin = 0, rmax = 0;
+            for (uint32_t i = 0; i + 1 < nv; ++i) {
+                const int ra = (int)(v[i] >> 16), ca = (int)(v[i] & 0xffff), cb = (int)(v[i + 1] & 0xffff);
+                if (c0 >= ca && c0 <= cb) { rmin = (ca == cb) ? ra : ((int)(v[i + 1] >> 16) == ra ? ra : ra + (c0 - ca)); break; }
+            }
+            // last anchor row in column c1: last piece that covers c1
+            for (uint32_t i = nv - 1; i-- > 0;) {
+                const int ra = (int)(v[i] >> 16), ca = (int)(v[i] & 0xffff), rb = (int)(v[i + 1] >> 16), cb = (int)(v[i + 1] & 0xffff);
+                if (c1 >= ca && c1 <= cb) { rmax = (ca == cb) ? rb : (rb == ra ? ra : ra + (c1 - ca)); break; }
+            }
+            const int a = rmin - BANDW, b = rmax + BANDW + 1;
+            lj = (uint16_t)(a > 0 ? a : 0);
+            hj = (uint16_t)(b < rows ? b : rows);
+        }
+        lo[j] = lj; hi[j] = hj;     // vertices were copied to LDS above: safe to overwrite in place
+    }
+}
+
+extern "C" hipError_t vtxk_launch_band_fast(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
+                                            const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
+                                            const uint8_t* hap_arena, uint32_t max_hap, const int32_t* ref_score,
+                                            const int32_t* alt_score, uint32_t* logbuf, uint16_t* band,
+                                            uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
+                                            uint32_t* counters, hipStream_t s) {
+    if (!n_tasks) return hipSuccess;
+    const size_t lane_bytes = (size_t)(3 * PS + 2 * PQ) * 256 * 4;
+    const size_t tstride = vtxk_band_table_stride(max_hap);
+    size_t budget = 60 * 1024;
+    uint32_t tables = (uint32_t)((budget - std::min(budget, lane_bytes)) / tstride) & ~1u;
+    if (tables < 2) tables = 2;
+    if (tables > 8) tables = 8;
+    const size_t shmem = lane_bytes + (size_t)tables * tstride;
+    if (shmem > 160 * 1024) return hipErrorInvalidValue;
+    if (shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)band_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(band_fast_kernel, dim3((n_tasks + 255) / 256), dim3(256), shmem, s, n_tasks, task_base, records,
+                       rec_locus, loci, read_arena, hap_arena, max_hap, tables, (uint32_t)tstride, ref_score, alt_score,
+                       logbuf, band, band_stride, hard_list, overflow_list, counters);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t vtxk_launch_band_expand(const uint32_t* hard_list, uint32_t n_hard, const vtx_record* records,
+                                              const uint32_t* rec_locus, const vtx_locus* loci, uint16_t* band,
+                                              uint32_t band_stride, hipStream_t s) {
+    if (!n_hard) return hipSuccess;
+    hipLaunchKernelGGL(band_expand_kernel, dim3((n_hard + 15) / 16), dim3(256), 0, s, hard_list, n_hard, records,
+                       rec_locus, loci, band, band_stride);
     return hipGetLastError();
 }
