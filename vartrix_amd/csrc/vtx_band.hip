@@ -301,8 +301,8 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
 // Hard tasks get a polyline (vertex list) in their band slot, flagged 0xffff; band_expand_kernel
 // turns it into the lo / hi arrays sw_banded_kernel reads.
 // =============================================================================================
-#define PS 12       // staircase runs per lane
-#define PQ 16       // pending FIFO entries per lane
+#define PS 10       // staircase runs per lane (LDS) + the top run in registers
+#define PQ 16       // pending FIFO entries per lane, packed x:10 | y:12 | dp:10
 #define LG 24       // jump-log entries per task (global)
 #define SG 10       // chain segments per task
 #define TB_HEADS 512
@@ -343,14 +343,15 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
     uint32_t* pm_a = smem;                     // ye0 << 16 | V0
     uint32_t* pm_id = pm_a + PS * 256;         // id0
     uint32_t* pm_l = pm_id + PS * 256;         // len
-    uint32_t* fq_id = pm_l + PS * 256;         // x << 16 | y
-    uint32_t* fq_dp = fq_id + PQ * 256;
-    uint8_t* tables = (uint8_t*)(fq_dp + PQ * 256);
+    uint32_t* fq = pm_l + PS * 256;            // x << 22 | y << 10 | dp
+    uint8_t* tables = (uint8_t*)(fq + PQ * 256);
 #define PM_A(i) pm_a[(i) * 256 + tid]
 #define PM_ID(i) pm_id[(i) * 256 + tid]
 #define PM_L(i) pm_l[(i) * 256 + tid]
-#define FQ_ID(i) fq_id[((i) & (PQ - 1)) * 256 + tid]
-#define FQ_DP(i) fq_dp[((i) & (PQ - 1)) * 256 + tid]
+#define FQ(i) fq[((i) & (PQ - 1)) * 256 + tid]
+#define FQ_X(e) ((e) >> 22)
+#define FQ_IDOF(e) ((((e) >> 22) << 16) | (((e) >> 10) & 0xfff))
+#define FQ_DPOF(e) ((e) & 0x3ff)
 
     const uint32_t slot = blockIdx.x * 256 + tid;
     const bool have = slot < n_tasks;
@@ -422,39 +423,75 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
         const uint8_t* yb = (const uint8_t*)(head + TB_HEADS);
         const int32_t full = hap ? alt_score[rid] : ref_score[rid];
         if (m < KMER || n < KMER) continue;                 // no k-mer: Band::full_matrix, banded == full
+        if (m > 1023 || n > 4095) { overflow_list[atomicAdd(&counters[1], 1u)] = task; continue; }   // FIFO packing limits
 
         // ---- streaming sdpkpp ----
+        // The TOP staircase run (largest columns: in practice the main diagonal) lives in registers
+        // (t_y0, t_v0, t_id0, t_len; t_len == 0: none); lower runs live in LDS slots [0, pm_n).
+        // Elements that can no longer win are pruned eagerly from the top run and only every 8 rows
+        // from the LDS runs: a dead element never changes a query's outcome, pruning is for capacity.
         uint32_t pm_n = 0, fq_head = 0, fq_n = 0, lg_n = 0;
+        uint32_t t_y0 = 0, t_v0 = 0, t_id0 = 0, t_len = 0;
+        uint32_t last_id = NONE_ID; int32_t last_dp = 0;       // newest match (for the continuation test)
         int32_t best_v = -1; uint32_t best_id = 0;
         bool overflow = false;
         uint32_t why = 0;
         uint32_t wlo = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
         uint32_t whi = (uint32_t)x[4] | ((uint32_t)x[5] << 8);
+        uint32_t nextb = m > KMER ? x[KMER] : 0;
         for (uint32_t xr = 0; xr + KMER <= m && !overflow; ++xr) {
+            const uint32_t nextb2 = (xr + KMER + 1 < m) ? x[xr + KMER + 1] : 0;   // prefetch one row ahead
             // (a) ends that became visible: matches with xq + K <= xr
-            while (fq_n > 0 && (FQ_ID(fq_head) >> 16) + KMER <= xr) {
-                const uint32_t id = FQ_ID(fq_head), dp = FQ_DP(fq_head);
+            while (fq_n > 0 && FQ_X(FQ(fq_head)) + KMER <= xr) {
+                const uint32_t fe = FQ(fq_head);
+                const uint32_t id = FQ_IDOF(fe), dp = FQ_DPOF(fe);
                 ++fq_head; --fq_n;
                 const uint32_t ye = (id & 0xffff) + KMER, xe = (id >> 16) + KMER;
                 const uint32_t V = dp + xe + ye;
-                // j = number of runs starting at or before column ye
+                if (t_len && ye >= t_y0) {
+                    // in or after the top run
+                    const uint32_t t = min(t_len - 1, ye - t_y0);
+                    if (t_v0 + 3 * t > V) continue;                                  // dominated
+                    if (ye == t_y0 + t_len && V == t_v0 + 3 * t_len && id == t_id0 + t_len * 0x10001u) { ++t_len; continue; }
+                    if (ye >= t_y0 + t_len) {
+                        // after the top run, not continuing it: the old top run moves to LDS, this becomes the top
+                        if (pm_n == PS) { overflow = true; why = 2; break; }
+                        PM_A(pm_n) = (t_y0 << 16) | t_v0; PM_ID(pm_n) = t_id0; PM_L(pm_n) = t_len; ++pm_n;
+                        t_y0 = ye; t_v0 = V; t_id0 = id; t_len = 1;
+                        continue;
+                    }
+                    // inside the top run at element t (V' <= V): elements t .. te-1 go
+                    const uint32_t te = (V - t_v0) / 3 + 1;
+                    if (t > 0) {
+                        if (pm_n == PS) { overflow = true; why = 2; break; }
+                        PM_A(pm_n) = (t_y0 << 16) | t_v0; PM_ID(pm_n) = t_id0; PM_L(pm_n) = t; ++pm_n;     // prefix
+                    }
+                    if (te < t_len) {
+                        if (pm_n == PS) { overflow = true; why = 2; break; }
+                        PM_A(pm_n) = (ye << 16) | V; PM_ID(pm_n) = id; PM_L(pm_n) = 1; ++pm_n;           // the new element
+                        t_id0 += te * 0x10001u; t_y0 += te; t_v0 += 3 * te; t_len -= te;              // suffix stays on top
+                    } else {
+                        t_y0 = ye; t_v0 = V; t_id0 = id; t_len = 1;
+                    }
+                    continue;
+                }
+                if (!t_len) { t_y0 = ye; t_v0 = V; t_id0 = id; t_len = 1; continue; }
+                // before the top run: LDS runs are sorted by column; j = number of runs starting at or before ye
                 uint32_t j = 0;
                 while (j < pm_n && (PM_A(j) >> 16) <= ye) ++j;
-                bool placed = false;
+                bool placed = false, merge = false;
                 if (j > 0) {
                     const uint32_t a = PM_A(j - 1), len = PM_L(j - 1);
                     const uint32_t y0 = a >> 16, v0 = a & 0xffff;
                     const uint32_t t = min(len - 1, ye - y0);
-                    if (v0 + 3 * t > V) continue;                       // dominated (ids grow: ties go to the new element)
+                    if (v0 + 3 * t > V) continue;
                     if (ye <= y0 + len - 1) {
-                        // lands inside run j-1 at element t (same column, V' <= V): elements t .. te-1 go
                         const uint32_t te = (V - v0) / 3 + 1;
                         if (t == 0) {
-                            --j;                                        // the run starts at this column: generic trimming below
+                            --j;
                         } else if (te >= len) {
-                            PM_L(j - 1) = t;                            // keep the prefix, nothing of the run survives after it
+                            PM_L(j - 1) = t;
                         } else {
-                            // prefix [0, t) stays, then the new element, then the suffix [te, len) as its own run
                             if (pm_n + 2 > PS) { overflow = true; why = 2; break; }
                             for (uint32_t i = pm_n; i > j; --i) {
                                 PM_A(i + 1) = PM_A(i - 1); PM_ID(i + 1) = PM_ID(i - 1); PM_L(i + 1) = PM_L(i - 1);
@@ -467,26 +504,52 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
                             pm_n += 2;
                             placed = true;
                         }
-                    } else if (j == pm_n && ye == y0 + len && V == v0 + 3 * len && id == PM_ID(j - 1) + len * 0x10001u) {
-                        PM_L(j - 1) = len + 1;                          // typical: continues the last run
-                        placed = true;
+                    } else if (ye == y0 + len && V == v0 + 3 * len && id == PM_ID(j - 1) + len * 0x10001u) {
+                        merge = true;                                  // continues LDS run j-1
                     }
                 }
                 if (placed) continue;
-                // drop / trim following runs whose elements have V' <= V (they are at columns >= ye)
+                // drop / trim following runs (LDS, then the top run) whose elements have V' <= V
                 uint32_t last = j;
+                bool stop = false;
                 while (last < pm_n) {
                     const uint32_t a = PM_A(last), len = PM_L(last);
                     const uint32_t v0 = a & 0xffff;
-                    if (v0 > V) break;
-                    const uint32_t k = (V - v0) / 3 + 1;                // elements 0..k-1 have V' <= V
+                    if (v0 > V) { stop = true; break; }
+                    const uint32_t k = (V - v0) / 3 + 1;
                     if (k >= len) { ++last; continue; }
                     PM_A(last) = (((a >> 16) + k) << 16) | (v0 + 3 * k);
                     PM_ID(last) = PM_ID(last) + k * 0x10001u;
                     PM_L(last) = len - k;
+                    stop = true;
                     break;
                 }
-                if (last == j) {                                        // make room at j
+                if (!stop && t_v0 <= V) {                          // reaches into the top run
+                    const uint32_t k = (V - t_v0) / 3 + 1;
+                    if (k >= t_len) {
+                        // the whole top run goes, and so did LDS runs [j, pm_n): the new element ends up on top
+                        if (merge) {
+                            const uint32_t a = PM_A(j - 1);
+                            t_y0 = a >> 16; t_v0 = a & 0xffff; t_id0 = PM_ID(j - 1); t_len = PM_L(j - 1) + 1;
+                            pm_n = j - 1;
+                        } else {
+                            pm_n = j;
+                            t_y0 = ye; t_v0 = V; t_id0 = id; t_len = 1;
+                        }
+                        continue;
+                    }
+                    t_id0 += k * 0x10001u; t_y0 += k; t_v0 += 3 * k; t_len -= k;
+                }
+                if (merge) {
+                    PM_L(j - 1) = PM_L(j - 1) + 1;
+                    if (last > j) {
+                        const uint32_t d = last - j;
+                        for (uint32_t i = last; i < pm_n; ++i) { PM_A(i - d) = PM_A(i); PM_ID(i - d) = PM_ID(i); PM_L(i - d) = PM_L(i); }
+                        pm_n -= d;
+                    }
+                    continue;
+                }
+                if (last == j) {
                     if (pm_n == PS) { overflow = true; why = 2; break; }
                     for (uint32_t i = pm_n; i > j; --i) { PM_A(i) = PM_A(i - 1); PM_ID(i) = PM_ID(i - 1); PM_L(i) = PM_L(i - 1); }
                     ++pm_n;
@@ -498,12 +561,20 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
                 PM_A(j) = (ye << 16) | V; PM_ID(j) = id; PM_L(j) = 1;
             }
             if (overflow) break;
-            // (b) prune dead elements: element t of a run is alive iff V0 + 3t + 1 - (xr + ye0 + t) >= K
-            {
+            // (b) prune: element t of a run is alive iff V0 + 3t + 1 - (xr + ye0 + t) >= K  <=>  2t >= need
+            if (t_len) {
+                const int32_t need = (int32_t)(xr + t_y0) + KMER - 1 - (int32_t)t_v0;
+                const uint32_t k = need > 0 ? (uint32_t)(need + 1) >> 1 : 0;
+                if (k >= t_len) {
+                    t_len = 0;
+                    if (pm_n) { --pm_n; const uint32_t a = PM_A(pm_n); t_y0 = a >> 16; t_v0 = a & 0xffff; t_id0 = PM_ID(pm_n); t_len = PM_L(pm_n); }
+                } else if (k) { t_id0 += k * 0x10001u; t_y0 += k; t_v0 += 3 * k; t_len -= k; }
+            }
+            if ((xr & 7) == 7 && pm_n) {
                 uint32_t w = 0;
                 for (uint32_t i = 0; i < pm_n; ++i) {
                     const uint32_t a = PM_A(i), len = PM_L(i);
-                    const int32_t need = (int32_t)(xr + (a >> 16)) + KMER - 1 - (int32_t)(a & 0xffff);   // 2t >= need
+                    const int32_t need = (int32_t)(xr + (a >> 16)) + KMER - 1 - (int32_t)(a & 0xffff);
                     const uint32_t k = need > 0 ? (uint32_t)(need + 1) >> 1 : 0;
                     if (k >= len) continue;
                     PM_A(w) = (((a >> 16) + k) << 16) | ((a & 0xffff) + 3 * k);
@@ -517,25 +588,33 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
             for (uint32_t y = head[kw_hash(wlo, whi)]; y != 0xffff; y = next[y]) {
                 if (kwlo[y] != wlo || kwhi[y] != (uint16_t)whi) continue;
                 const uint32_t id = (xr << 16) | y;
-                // LCSk++ continuation: is (xr-1, y-1) a match?  It would be among the newest FIFO entries.
+                // LCSk++ continuation: is (xr-1, y-1) a match?  Usually it is the newest match.
                 int32_t dpc = -1;
                 if (xr > 0 && y > 0) {
                     const uint32_t want = ((xr - 1) << 16) | (y - 1);
-                    for (uint32_t i = fq_n; i-- > 0;) {
-                        const uint32_t q = FQ_ID(fq_head + i);
-                        if ((q >> 16) + 1 < xr) break;
-                        if (q == want) { dpc = (int32_t)FQ_DP(fq_head + i); break; }
-                    }
+                    if (last_id == want) dpc = last_dp;
+                    else
+                        for (uint32_t i = fq_n; i-- > 0;) {
+                            const uint32_t fe = FQ(fq_head + i);
+                            if (FQ_X(fe) + 1 < xr) break;
+                            if (FQ_IDOF(fe) == want) { dpc = (int32_t)FQ_DPOF(fe); break; }
+                        }
                 }
-                // start candidate: last staircase element with ye <= y
+                // start candidate: last staircase element with ye <= y (top run first)
                 int32_t dp = KMER; uint32_t prev = NONE_ID;
-                for (uint32_t i = pm_n; i-- > 0;) {
-                    const uint32_t a = PM_A(i);
-                    if ((a >> 16) <= y) {
-                        const uint32_t t = min(PM_L(i) - 1, y - (a >> 16));
-                        const int32_t cand = (int32_t)((a & 0xffff) + 3 * t) - 5 - (int32_t)(xr + y) + KMER;
-                        if (cand >= dp) { dp = cand; prev = PM_ID(i) + t * 0x10001u; }
-                        break;
+                if (t_len && t_y0 <= y) {
+                    const uint32_t t = min(t_len - 1, y - t_y0);
+                    const int32_t cand = (int32_t)(t_v0 + 3 * t) - 5 - (int32_t)(xr + y) + KMER;
+                    if (cand >= dp) { dp = cand; prev = t_id0 + t * 0x10001u; }
+                } else {
+                    for (uint32_t i = pm_n; i-- > 0;) {
+                        const uint32_t a = PM_A(i);
+                        if ((a >> 16) <= y) {
+                            const uint32_t t = min(PM_L(i) - 1, y - (a >> 16));
+                            const int32_t cand = (int32_t)((a & 0xffff) + 3 * t) - 5 - (int32_t)(xr + y) + KMER;
+                            if (cand >= dp) { dp = cand; prev = PM_ID(i) + t * 0x10001u; }
+                            break;
+                        }
                     }
                 }
                 bool cont = false;
@@ -544,15 +623,15 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
                     if (lg_n == LG) { overflow = true; why = 3; break; }
                     mylog[2 * lg_n] = id; mylog[2 * lg_n + 1] = prev; ++lg_n;
                 }
-                if (fq_n == PQ) { overflow = true; why = 4; break; }
-                FQ_ID(fq_head + fq_n) = id; FQ_DP(fq_head + fq_n) = (uint32_t)dp; ++fq_n;
+                if (fq_n == PQ || dp > 1022) { overflow = true; why = 4; break; }
+                FQ(fq_head + fq_n) = (xr << 22) | (y << 10) | (uint32_t)dp; ++fq_n;
+                last_id = id; last_dp = dp;
                 if (dp >= best_v) { best_v = dp; best_id = id; }
             }
             // (d) slide the 48-bit window
-            if (xr + KMER < m) {
-                wlo = (wlo >> 8) | (whi << 24);
-                whi = ((whi >> 8) & 0xff) | ((uint32_t)x[xr + KMER] << 8);
-            }
+            wlo = (wlo >> 8) | (whi << 24);
+            whi = ((whi >> 8) & 0xff) | (nextb << 8);
+            nextb = nextb2;
         }
         if (overflow) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[2 + why], 1u); continue; }
         if (best_v < 0) continue;                            // no match at all: full matrix
@@ -622,8 +701,10 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
 #undef PM_A
 #undef PM_ID
 #undef PM_L
-#undef FQ_ID
-#undef FQ_DP
+#undef FQ
+#undef FQ_X
+#undef FQ_IDOF
+#undef FQ_DPOF
 }
 
 // Polyline -> lo / hi arrays, one 16-lane group per hard slot (slots written by band_kernel already
@@ -685,9 +766,9 @@ extern "C" hipError_t vtxk_launch_band_fast(uint32_t n_tasks, uint32_t task_base
                                             uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
                                             uint32_t* counters, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
-    const size_t lane_bytes = (size_t)(3 * PS + 2 * PQ) * 256 * 4;
+    const size_t lane_bytes = (size_t)(3 * PS + PQ) * 256 * 4;
     const size_t tstride = vtxk_band_table_stride(max_hap);
-    size_t budget = 60 * 1024;
+    size_t budget = 52 * 1024;
     uint32_t tables = (uint32_t)((budget - std::min(budget, lane_bytes)) / tstride) & ~1u;
     if (tables < 2) tables = 2;
     if (tables > 8) tables = 8;
