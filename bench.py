@@ -82,9 +82,11 @@ def main():
     ap.add_argument("--barcodes", type=int, default=10_000)
     ap.add_argument("--reads-per-locus", type=int, default=256)
     ap.add_argument("--mode", default="consensus", choices=["consensus", "alt_frac", "coverage"])
-    ap.add_argument("--aligner", default="full", choices=["full", "banded"])
+    ap.add_argument("--aligner", default="banded", choices=["banded", "full"],
+                    help="banded = the reference's banded::Aligner semantics (default); full = unbanded Smith-Waterman")
     ap.add_argument("--umi", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-aligner", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -99,8 +101,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_gather = os.environ.get("VTX_FORCE_GATHER") == "1"     # exercise the RCCL path with one rank
+    if world > 1 or force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     spec = synth.SynthSpec(n_loci=args.loci, n_barcodes=args.barcodes, reads_per_locus=args.reads_per_locus,
@@ -118,7 +122,7 @@ def main():
 
     def step():
         ctx.run()
-        if world > 1:
+        if world > 1 or force_gather:
             local = shard.device_coo_tensors(ctx, device)
             return shard.gather_coo(local)
         return None
@@ -131,7 +135,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    sw_ms, red_ms = [], []
+    sw_ms, red_ms, full_ms, band_ms = [], [], [], []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -139,6 +143,8 @@ def main():
         t = ctx.timing()                                   # hipEvents on the context's own stream
         sw_ms.append(t.sw_ms)
         red_ms.append(t.reduce_ms)
+        full_ms.append(t.full_ms)
+        band_ms.append(t.band_ms)
     fence()
     elapsed = time.perf_counter() - t0
     n_aln = 2 * batch.n_records
@@ -154,6 +160,22 @@ def main():
         total_aln, total_cells, total_nnz = (int(x) for x in tot.tolist())
     else:
         total_aln, total_cells, total_nnz = n_aln, cells, nnz
+
+    # secondary: the other aligner flavour on the same resident-size batch (rank 0 only, single GPU timing)
+    other = None
+    if rank == 0 and not args.no_other_aligner:
+        oname = "full" if args.aligner == "banded" else "banded"
+        ocfg = default_config(aligner=oname, scoring_mode=args.mode, use_umi=args.umi, n_barcodes=args.barcodes, device=local_rank)
+        octx = lib.Context(ocfg)
+        octx.submit(batch)
+        octx.run()
+        t1 = time.perf_counter()
+        for _ in range(max(1, min(args.steps, 3))):
+            octx.run()
+        dt = (time.perf_counter() - t1) / max(1, min(args.steps, 3))
+        other = {"aligner": oname, "value": n_aln / dt, "unit": "read-alignments/s (1 GPU)", "ms_per_step": 1e3 * dt,
+                 "sw_kernel_ms": octx.timing().sw_ms, "hard_tasks": octx.timing().hard_tasks}
+        octx.close()
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -171,7 +193,8 @@ def main():
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        lane_ops = cells / 2 * OPS_PER_CELL_PAIR            # useful packed ops of rank 0's launch(es)
+        lane_ops = cells / 2 * OPS_PER_CELL_PAIR            # useful packed ops of rank 0's sw_full_kernel launch(es)
+        full_avg_ms = float(np.mean(full_ms))
         out = {
             "metric": "read-alignments/sec at 100k loci x 10k cells; bit-exact .mtx vs ref",
             "value": value, "unit": "read-alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -183,21 +206,25 @@ def main():
                        "sharding": "loci (matrix rows) per rank, COO rows gathered to rank 0" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "sw_full_kernel (all read-length buckets, %d launch(es))" % launches,
+                         "kernel": ("sw_full_kernel" if args.aligner == "full" else "sw_full_kernel + band_fast_kernel + band_kernel + sw_banded_kernel") + " (%d launches)" % launches,
                          "kernel_ms": sw_avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "integer DP: the binding roof is VALU, see roofline_valu; HBM fraction is reported as north_star asks"},
-            "roofline_valu": {"bound": "valu", "achieved": lane_ops / (sw_avg_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS,
-                              "unit": "T packed-lane-ops/s", "frac": lane_ops / (sw_avg_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
-                              "gcups": cells / (sw_avg_ms * 1e-3) / 1e9, "ops_per_cell_pair": OPS_PER_CELL_PAIR},
-            "timing": {"sw_kernel_ms": sw_avg_ms, "reduce_ms": float(np.mean(red_ms)), "submit_h2d_s": t_sub,
+            "roofline_valu": {"bound": "valu", "kernel": "sw_full_kernel", "kernel_ms": full_avg_ms,
+                              "achieved": lane_ops / (full_avg_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS,
+                              "unit": "T packed-lane-ops/s", "frac": lane_ops / (full_avg_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                              "gcups": cells / (full_avg_ms * 1e-3) / 1e9, "ops_per_cell_pair": OPS_PER_CELL_PAIR},
+            "timing": {"sw_kernel_ms": sw_avg_ms, "full_kernel_ms": full_avg_ms, "band_kernels_ms": float(np.mean(band_ms)), "reduce_ms": float(np.mean(red_ms)), "submit_h2d_s": t_sub,
                        "generate_s": t_gen,
                        "pcie_inclusive_alignments_per_s": total_aln / world / (t_sub + elapsed / args.steps)},
         }
+        if other is not None:
+            out["other_aligner"] = other
+        out["timing"]["hard_tasks"] = int(ctx.timing().hard_tasks)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch, cfg, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if world > 1 or force_gather:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -156,6 +156,8 @@ typedef struct vtx_timing {
     float reduce_ms;
     uint32_t sw_launches;
     uint32_t hard_tasks;   /* banded flavour: alignments that needed the band-masked DP */
+    float full_ms;         /* sw_full_kernel launches only (part of sw_ms)                */
+    float band_ms;         /* band kernels + band-masked DP (banded flavour; part of sw_ms) */
 } vtx_timing;
 
 typedef struct vtx_ctx vtx_ctx;

@@ -72,21 +72,23 @@ def test_coverage_mode_without_ref_matrix_flag_writes_only_main(tmp_path):
     assert os.path.exists(out) and not os.path.exists(tmp_path / "ref_matrix.mtx")
 
 
+@pytest.mark.parametrize("aligner", ["banded", "full"])
 @pytest.mark.parametrize("mode", ["consensus", "alt_frac", "coverage"])
 @pytest.mark.parametrize("umi", [False, True])
-def test_authored_indel_bam_end_to_end(tmp_path, mode, umi):
+def test_authored_indel_bam_end_to_end(tmp_path, mode, umi, aligner):
     """test_dna.vcf (SNV + INS + DEL + multi-allelic) over an authored BAM: CLI output is byte-identical to
-    the oracle pipeline (Python ingest restatement + C oracle, full aligner) rendered as .mtx."""
+    the oracle pipeline (Python ingest restatement + C oracle, same aligner flavour) rendered as .mtx."""
     from tests.test_host import make_dna_bam
     bam = make_dna_bam(tmp_path, seed=3, n_reads=1500)
     vcfp, fap, bcp = (os.path.join(G, n) for n in ("test_dna.vcf", "test_dna.fa", "dna_barcodes.tsv"))
     out, ref = str(tmp_path / "out.mtx"), str(tmp_path / "ref.mtx")
-    args = ["-v", vcfp, "-b", bam, "-f", fap, "-c", bcp, "-o", out, "-s", mode, "--ref-matrix", ref, "--threads", "4"]
+    args = ["-v", vcfp, "-b", bam, "-f", fap, "-c", bcp, "-o", out, "-s", mode, "--ref-matrix", ref, "--threads", "4",
+            "--aligner", aligner]
     run_cli(args + (["--umi"] if umi else []), tmp_path)
     bcs = refpipe.load_barcodes(bcp)
     vcf = refpipe.read_vcf(vcfp)
     batch, _ = refpipe.pack(vcf, refpipe.read_fasta(fap), refpipe.read_bam(bam), bcs, refpipe.Args(use_umi=umi))
-    cfg = default_config(aligner="full", scoring_mode=mode, use_umi=int(umi), n_barcodes=len(bcs))
+    cfg = default_config(aligner=aligner, scoring_mode=mode, use_umi=int(umi), n_barcodes=len(bcs))
     r, a = oracle.batch_scores(batch, cfg, threads=8)
     coo = oracle.batch_reduce(batch, cfg, r, a)
     assert open(out).read() == refpipe.mtx_text(len(vcf), len(bcs), coo["row"], coo["col"], coo["value"])

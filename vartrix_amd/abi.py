@@ -112,6 +112,8 @@ class VtxTiming(C.Structure):
         ("reduce_ms", C.c_float),
         ("sw_launches", C.c_uint32),
         ("hard_tasks", C.c_uint32),
+        ("full_ms", C.c_float),
+        ("band_ms", C.c_float),
     ]
 
 

@@ -6,7 +6,8 @@
 // replacing the rayon map :279-291 and the merge loop :320-348) -> .mtx and the
 // optional variants / barcodes files.  `--threads` only sizes the BGZF inflate
 // pool here (it never affected results in the reference either, :279-291).
-// New, optional: --devices N (shard loci over N GPUs), --aligner full|banded.
+// New, optional: --devices N (shard loci over N GPUs), --aligner banded|full (default banded = the
+// reference's banded::Aligner, src/main.rs:899; full = unbanded Smith-Waterman).
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -62,7 +63,7 @@ const Opt kOpts[] = {
     {"log-level", 0, false, "error"}, {"threads", 0, false, "1"}, {"mapq", 0, false, "0"},
     {"primary-alignments", 0, true, nullptr}, {"no-duplicates", 0, true, nullptr}, {"umi", 0, true, nullptr},
     {"bam-tag", 0, false, "CB"}, {"valid-chars", 0, false, "ATGCatgc"},
-    {"devices", 0, false, "1"}, {"aligner", 0, false, "full"},
+    {"devices", 0, false, "1"}, {"aligner", 0, false, "banded"},
 };
 
 void usage() {
@@ -72,7 +73,7 @@ void usage() {
             "  -p, --padding <INT> [100]   -s, --scoring-method consensus|coverage|alt_frac [consensus]\n"
             "  --ref-matrix <FILE> [ref_matrix.mtx]   --log-level info|debug|error [error]   --threads <INT> [1]\n"
             "  --mapq <INT> [0]   --primary-alignments   --no-duplicates   --umi   --bam-tag <TAG> [CB]\n"
-            "  --valid-chars <CHARS> [ATGCatgc]   --devices <INT> [1]   --aligner full|banded [full]\n");
+            "  --valid-chars <CHARS> [ATGCatgc]   --devices <INT> [1]   --aligner banded|full [banded]\n");
 }
 
 struct Shard {
@@ -187,6 +188,10 @@ int main(int argc, char** argv) {
     vtxh_get_batch(pk, &full);
     vtx_config cfg;
     vtx_config_default(&cfg);
+    if (val["aligner"] != "banded" && val["aligner"] != "full") {
+        fprintf(stderr, "error: '%s' isn't a valid value for '--aligner <aligner>'\n", val["aligner"].c_str());
+        return 1;
+    }
     cfg.aligner = val["aligner"] == "banded" ? VTX_ALIGNER_BANDED : VTX_ALIGNER_FULL;
     cfg.scoring_mode = mode == "consensus" ? VTX_MODE_CONSENSUS : (mode == "alt_frac" ? VTX_MODE_ALT_FRAC : VTX_MODE_COVERAGE);
     cfg.use_umi = ha.use_umi;

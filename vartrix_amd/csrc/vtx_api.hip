@@ -60,7 +60,7 @@ thread_local std::string g_create_err;
 struct vtx_ctx {
     vtx_config cfg{};
     hipStream_t stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::string err;
     bool submitted = false, ran = false;
     uint32_t n_loci = 0, n_records = 0, n_cell_groups = 0, n_umi_groups = 0, max_hap_len = 0;
@@ -324,6 +324,7 @@ int vtx_run(vtx_ctx* c) {
         ++launches;
     }
     uint32_t hard_total = 0;
+    HIP_TRY(c, hipEventRecord(c->ev[3], s));
     if (c->cfg.aligner == VTX_ALIGNER_BANDED && nr) {
         // Banded flavour: d_ref / d_alt hold the full scores.  Per chunk of tasks (task = 2*record + hap):
         // band kernel (seed, chain, band, certificate) -> hard list -> band-masked DP overwrites hard scores.
@@ -419,8 +420,11 @@ int vtx_run(vtx_ctx* c) {
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
     HIP_TRY(c, hipStreamSynchronize(s));
     c->nnz = nnz32;
-    float t01 = 0, t12 = 0;
+    float t01 = 0, t12 = 0, t03 = 0;
+    HIP_TRY(c, hipEventElapsedTime(&t03, c->ev[0], c->ev[3]));
+    c->timing.full_ms = t03;
     HIP_TRY(c, hipEventElapsedTime(&t01, c->ev[0], c->ev[1]));
+    c->timing.band_ms = t01 - t03;
     HIP_TRY(c, hipEventElapsedTime(&t12, c->ev[1], c->ev[2]));
     c->timing.sw_ms = t01; c->timing.reduce_ms = t12; c->timing.total_ms = t01 + t12;
     c->timing.sw_launches = launches; c->timing.hard_tasks = hard_total;

@@ -219,7 +219,8 @@ extern "C" hipError_t vtxk_launch_sw_full(int R, int GL, uint32_t n_work, const 
                                           uint32_t max_hap_len, hipStream_t stream) {
     if (n_work == 0) return hipSuccess;
     const uint32_t groups = 256 / GL;
-    const uint32_t lcols = ((GL + max_hap_len + GL + 3) + 3u) & ~3u;
+    // slot stride = 16 (mod 32) words: the two 16-lane records of a 32-lane LDS group hit disjoint banks
+    const uint32_t lcols = (((GL + max_hap_len + GL + 3) + 31u) & ~31u) + 16u;
     const size_t shmem = (size_t)groups * lcols * sizeof(uint32_t);
     const dim3 grid((n_work + groups - 1) / groups), block(256);
 #define CASE(r, gl)                                                                                     \
