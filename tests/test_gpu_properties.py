@@ -1,0 +1,90 @@
+"""Full-size runs (BASELINE.json configs[1]: 10k SNV loci x 5k barcodes, coverage) checked through
+size-independent properties, plus an oracle spot-check on a random sample of records."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from vartrix_amd import lib, synth
+from vartrix_amd.abi import PackedBatch, default_config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big():
+    spec = synth.config2()
+    return spec, synth.make_batch(spec)
+
+
+def run(batch, cfg):
+    with lib.Context(cfg) as ctx:
+        ctx.submit(batch)
+        ctx.run()
+        return ctx.fetch_scores() + (ctx.fetch_coo(),)
+
+
+@pytest.mark.parametrize("aligner", ["banded", "full"])
+def test_config2_properties(big, aligner):
+    spec, batch = big
+    cfg = default_config(aligner=aligner, scoring_mode="coverage", n_barcodes=spec.n_barcodes)
+    ref, alt, coo = run(batch, cfg)
+    n = batch.n_records
+    assert ref.shape == (n,) and ref.min() >= 0 and alt.min() >= 0
+    assert ref.max() <= spec.read_len and alt.max() <= spec.read_len          # local score <= read length
+    # SNV haplotypes differ in one base: scores differ by at most match - mismatch = 6
+    assert np.abs(ref - alt).max() <= 6
+    # evaluate_scores (:1019-1030) recomputed on the host from the device scores == the histogram on the device
+    none = (ref < 25) & (alt < 25)
+    calls_ref = int(((ref > alt) & ~none).sum())
+    calls_alt = int(((alt > ref) & ~none).sum())
+    calls_unk = int(((alt == ref) & ~none).sum())
+    assert (int(coo["ref"].sum()), int(coo["alt"].sum()), int(coo["unk"].sum())) == (calls_ref, calls_alt, calls_unk)
+    # one triplet per (locus, cell) group, in merge-loop order (row asc, then col asc)
+    key = coo["row"].astype(np.int64) * spec.n_barcodes + coo["col"]
+    assert np.all(np.diff(key) > 0)
+    rec_key = np.repeat(batch.loci["row"].astype(np.int64), batch.loci["rec_count"]) * spec.n_barcodes + batch.records["cell_index"]
+    assert len(key) == len(np.unique(rec_key))
+    # coverage mode values are the counts (:1160-1161)
+    assert np.array_equal(coo["value"], coo["alt"].astype(np.float64)) and np.array_equal(coo["ref_value"], coo["ref"].astype(np.float64))
+    # oracle spot check: 3000 random records, bit-exact
+    rng = np.random.default_rng(1)
+    pick = np.sort(rng.choice(n, 3000, replace=False))
+    rec_locus = np.repeat(np.arange(batch.n_loci), batch.loci["rec_count"])
+    for r in pick[:3000]:
+        rec = batch.records[r]
+        loc = batch.loci[rec_locus[r]]
+        read = bytes(batch.read_arena[rec["read_off"]:rec["read_off"] + rec["read_len"]])
+        rh = bytes(batch.hap_arena[loc["ref_off"]:loc["ref_off"] + loc["ref_len"]])
+        ah = bytes(batch.hap_arena[loc["alt_off"]:loc["alt_off"] + loc["alt_len"]])
+        f = oracle.sw_banded if aligner == "banded" else oracle.sw_full
+        assert (f(read, rh), f(read, ah)) == (int(ref[r]), int(alt[r])), r
+
+
+def test_shard_invariance_and_determinism(big):
+    """Loci shard independently (src/main.rs:284-291): 3 uneven shards run separately give the same triplets."""
+    spec, batch = big
+    cfg = default_config(aligner="banded", scoring_mode="consensus", n_barcodes=spec.n_barcodes)
+    ref, alt, coo = run(batch, cfg)
+    ref2, alt2, coo2 = run(batch, cfg)
+    assert np.array_equal(ref, ref2) and np.array_equal(alt, alt2)
+    assert all(np.array_equal(coo[k].view(np.uint8), coo2[k].view(np.uint8)) for k in coo)
+    cuts = [0, 1234, 7001, batch.n_loci]
+    parts = [run(batch.slice_loci(a, b), cfg)[2] for a, b in zip(cuts[:-1], cuts[1:])]
+    for k in coo:
+        assert np.array_equal(np.concatenate([p[k] for p in parts]).view(np.uint8), coo[k].view(np.uint8)), k
+
+
+def test_ref_alt_swap_symmetry(big):
+    """Swapping the REF and ALT haplotypes of every locus swaps the two scores of every record."""
+    spec, batch = big
+    sub = batch.slice_loci(0, 1500)
+    loci = sub.loci.copy()
+    loci["ref_off"], loci["alt_off"] = sub.loci["alt_off"], sub.loci["ref_off"]
+    loci["ref_len"], loci["alt_len"] = sub.loci["alt_len"], sub.loci["ref_len"]
+    swapped = PackedBatch(loci, sub.records, sub.hap_arena, sub.read_arena)
+    for aligner in ("banded", "full"):
+        cfg = default_config(aligner=aligner, scoring_mode="coverage", n_barcodes=spec.n_barcodes)
+        ref, alt, coo = run(sub, cfg)
+        sref, salt, scoo = run(swapped, cfg)
+        assert np.array_equal(ref, salt) and np.array_equal(alt, sref)
+        assert np.array_equal(coo["alt"], scoo["ref"]) and np.array_equal(coo["ref"], scoo["alt"])

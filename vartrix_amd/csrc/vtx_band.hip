@@ -301,11 +301,11 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
 // Hard tasks get a polyline (vertex list) in their band slot, flagged 0xffff; band_expand_kernel
 // turns it into the lo / hi arrays sw_banded_kernel reads.
 // =============================================================================================
-#define PS 10       // staircase runs per lane (LDS) + the top run in registers
+#define PS 6        // staircase runs per lane (LDS) + the top run in registers
 #define PQ 16       // pending FIFO entries per lane, packed x:10 | y:12 | dp:10
 #define LG 24       // jump-log entries per task (global)
 #define SG 10       // chain segments per task
-#define TB_HEADS 512
+#define TB_HEADS 2048
 #define NONE_ID 0xffffffffu
 
 struct hap_table {
@@ -319,7 +319,7 @@ struct hap_table {
 
 __device__ __forceinline__ uint32_t kw_hash(uint32_t lo, uint32_t hi) {
     uint32_t h = lo * 0x9E3779B1u ^ (hi + 0x7F4A7C15u) * 0x85EBCA77u;
-    return (h >> 20) & (TB_HEADS - 1);
+    return (h >> 18) & (TB_HEADS - 1);
 }
 
 extern "C" size_t vtxk_band_table_stride(uint32_t max_hap) {
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
                     if (pm_n) { --pm_n; const uint32_t a = PM_A(pm_n); t_y0 = a >> 16; t_v0 = a & 0xffff; t_id0 = PM_ID(pm_n); t_len = PM_L(pm_n); }
                 } else if (k) { t_id0 += k * 0x10001u; t_y0 += k; t_v0 += 3 * k; t_len -= k; }
             }
-            if ((xr & 7) == 7 && pm_n) {
+            if ((xr & 15) == 15 && pm_n) {
                 uint32_t w = 0;
                 for (uint32_t i = 0; i < pm_n; ++i) {
                     const uint32_t a = PM_A(i), len = PM_L(i);
@@ -768,7 +768,7 @@ extern "C" hipError_t vtxk_launch_band_fast(uint32_t n_tasks, uint32_t task_base
     if (!n_tasks) return hipSuccess;
     const size_t lane_bytes = (size_t)(3 * PS + PQ) * 256 * 4;
     const size_t tstride = vtxk_band_table_stride(max_hap);
-    size_t budget = 52 * 1024;
+    size_t budget = 40 * 1024;
     uint32_t tables = (uint32_t)((budget - std::min(budget, lane_bytes)) / tstride) & ~1u;
     if (tables < 2) tables = 2;
     if (tables > 8) tables = 8;
