@@ -31,8 +31,10 @@ def test_config2_properties(big, aligner):
     n = batch.n_records
     assert ref.shape == (n,) and ref.min() >= 0 and alt.min() >= 0
     assert ref.max() <= spec.read_len and alt.max() <= spec.read_len          # local score <= read length
-    # SNV haplotypes differ in one base: scores differ by at most match - mismatch = 6
-    assert np.abs(ref - alt).max() <= 6
+    # SNV haplotypes differ in one base: full-matrix scores differ by at most match - mismatch = 6
+    # (not an invariant of the banded flavour: the two haplotypes get their own seed chains and bands)
+    if aligner == "full":
+        assert np.abs(ref - alt).max() <= 6
     # evaluate_scores (:1019-1030) recomputed on the host from the device scores == the histogram on the device
     none = (ref < 25) & (alt < 25)
     calls_ref = int(((ref > alt) & ~none).sum())
