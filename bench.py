@@ -41,7 +41,8 @@ from vartrix_amd.abi import default_config  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_TOPS = 39.3          # packed 16-bit VALU ops issue at 4 cycles / wave64 on gfx950: 256 CU x 4 SIMD x 16
                                # lanes/clk x 2.4 GHz (measured 38.7, profiles/r01_valu_peak_microbench.txt)
-OPS_PER_CELL_PAIR = 12         # packed VALU ops per DP cell pair
+OPS_PER_CELL_PAIR = 9          # packed VALU ops per DP cell pair of sw_full_lut_kernel; the
+                               # byte-equality fallback sw_full_kernel spends 12
 
 
 def algorithmic_bytes(batch) -> int:
@@ -206,10 +207,10 @@ def main():
                        "sharding": "loci (matrix rows) per rank, COO rows gathered to rank 0" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("sw_full_kernel" if args.aligner == "full" else "sw_full_kernel + band_fast_kernel + band_kernel + sw_banded_kernel") + " (%d launches)" % launches,
+                         "kernel": ("sw_full_lut_kernel" if args.aligner == "full" else "sw_full_lut_kernel + band_fast_kernel + band_kernel + sw_banded_kernel") + " (%d launches)" % launches,
                          "kernel_ms": sw_avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "integer DP: the binding roof is VALU, see roofline_valu; HBM fraction is reported as north_star asks"},
-            "roofline_valu": {"bound": "valu", "kernel": "sw_full_kernel", "kernel_ms": full_avg_ms,
+            "roofline_valu": {"bound": "valu", "kernel": "sw_full_lut_kernel", "kernel_ms": full_avg_ms,
                               "achieved": lane_ops / (full_avg_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS,
                               "unit": "T packed-lane-ops/s", "frac": lane_ops / (full_avg_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
                               "gcups": cells / (full_avg_ms * 1e-3) / 1e9, "ops_per_cell_pair": OPS_PER_CELL_PAIR},

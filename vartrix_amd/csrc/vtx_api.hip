@@ -45,7 +45,8 @@ struct DevBuf {
     template <typename T> T* as() const { return (T*)p; }
 };
 
-struct Bucket { int R, GL; uint32_t offset, count; };
+struct Bucket { int R, GL; uint32_t offset, count; bool lut; };
+const uint32_t kLutLociCap = 4;     // loci tables per workgroup of the LUT kernel (6 KiB each at 257 columns)
 
 // (rows per lane, lanes per record) choices; capacity = R * GL read bases.
 const int kShapes[][2] = {{2, 16}, {4, 16}, {6, 16}, {8, 16}, {10, 16}, {12, 16}, {16, 16}, {8, 64}, {16, 64}};
@@ -72,6 +73,7 @@ struct vtx_ctx {
     DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
     DevBuf d_band_ws, d_band_ws2, d_band, d_hard, d_over, d_over2, d_cnt;   // banded flavour
+    DevBuf d_redo, d_redo_cnt;                                               // LUT kernel: records with non-ACGTN bytes
     uint32_t max_read_len = 0, fast_overflow = 0;
     std::vector<uint32_t> h_row, h_col, h_alt, h_ref, h_unk;
     std::vector<double> h_val, h_refval;
@@ -190,7 +192,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_grp_col, &c->d_umi_cellgrp, &c->d_cell_cnt, &c->d_umi_cnt, &c->d_keep, &c->d_keep_scan,
                       &c->d_scan_tmp, &c->d_o_row, &c->d_o_col, &c->d_o_alt, &c->d_o_ref, &c->d_o_unk, &c->d_o_val,
                       &c->d_o_refval, &c->d_band_ws, &c->d_band_ws2, &c->d_band, &c->d_hard, &c->d_over, &c->d_over2,
-                      &c->d_cnt};
+                      &c->d_cnt, &c->d_redo, &c->d_redo_cnt};
     for (DevBuf* b : bufs) b->release();
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -251,7 +253,13 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
     c->buckets.clear();
     for (int s = 0; s < kNumShapes; ++s) {
         if (lists[s].empty()) continue;
-        c->buckets.push_back(Bucket{kShapes[s][0], kShapes[s][1], (uint32_t)work.size(), (uint32_t)lists[s].size()});
+        // LUT kernel eligibility: every 16-record workgroup must span at most kLutLociCap loci
+        bool lut = kShapes[s][1] == 16 && (size_t)kLutLociCap * (max_hap + 36) * 6 * 4 <= 96 * 1024;
+        for (size_t i = 0; lut && i < lists[s].size(); i += 16) {
+            const size_t j = std::min(lists[s].size(), i + 16) - 1;
+            if (rec_locus[lists[s][j]] - rec_locus[lists[s][i]] + 1 > kLutLociCap) lut = false;
+        }
+        c->buckets.push_back(Bucket{kShapes[s][0], kShapes[s][1], (uint32_t)work.size(), (uint32_t)lists[s].size(), lut});
         work.insert(work.end(), lists[s].begin(), lists[s].end());
     }
 
@@ -263,6 +271,8 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
     HIP_TRY(c, c->d_hap.reserve(b->hap_bytes + 16));
     HIP_TRY(c, c->d_read.reserve(b->read_bytes + 16));
     HIP_TRY(c, c->d_work.reserve(nr * u32));
+    HIP_TRY(c, c->d_redo.reserve(nr * u32));
+    HIP_TRY(c, c->d_redo_cnt.reserve(16 * u32));
     HIP_TRY(c, c->d_ref.reserve(nr * sizeof(int32_t)));
     HIP_TRY(c, c->d_alt.reserve(nr * sizeof(int32_t)));
     DevBuf* per_rec[] = {&c->d_head_cell, &c->d_head_umi, &c->d_cell_scan, &c->d_umi_scan, &c->d_grp_row, &c->d_grp_col,
@@ -316,12 +326,38 @@ int vtx_run(vtx_ctx* c) {
     c->ran = false;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     uint32_t launches = 0;
-    for (const Bucket& bk : c->buckets) {
-        HIP_TRY(c, vtxk_launch_sw_full(bk.R, bk.GL, bk.count, c->d_work.as<uint32_t>() + bk.offset,
-                                       c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
-                                       c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(),
-                                       c->d_alt.as<int32_t>(), c->max_hap_len, s));
+    bool any_lut = false;
+    for (const Bucket& bk : c->buckets) any_lut |= bk.lut;
+    if (any_lut) HIP_TRY(c, hipMemsetAsync(c->d_redo_cnt.p, 0, 16 * sizeof(uint32_t), s));
+    for (size_t b = 0; b < c->buckets.size(); ++b) {
+        const Bucket& bk = c->buckets[b];
+        if (bk.lut) {
+            HIP_TRY(c, vtxk_launch_sw_full_lut(bk.R, bk.count, c->d_work.as<uint32_t>() + bk.offset, c->d_records.as<vtx_record>(),
+                                               c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                               c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
+                                               c->max_hap_len, kLutLociCap, c->d_redo.as<uint32_t>() + bk.offset,
+                                               c->d_redo_cnt.as<uint32_t>() + b, s));
+        } else {
+            HIP_TRY(c, vtxk_launch_sw_full(bk.R, bk.GL, bk.count, c->d_work.as<uint32_t>() + bk.offset,
+                                           c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
+                                           c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(),
+                                           c->d_alt.as<int32_t>(), c->max_hap_len, s));
+        }
         ++launches;
+    }
+    if (any_lut) {
+        // records with bytes outside ACGTN: the generic (byte-equality) kernel scores them
+        uint32_t redo[16] = {0};
+        HIP_TRY(c, hipMemcpyAsync(redo, c->d_redo_cnt.p, sizeof redo, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        for (size_t b = 0; b < c->buckets.size(); ++b) {
+            const Bucket& bk = c->buckets[b];
+            if (!bk.lut || !redo[b]) continue;
+            HIP_TRY(c, vtxk_launch_sw_full(bk.R, bk.GL, redo[b], c->d_redo.as<uint32_t>() + bk.offset, c->d_records.as<vtx_record>(),
+                                           c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                           c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len, s));
+            ++launches;
+        }
     }
     uint32_t hard_total = 0;
     HIP_TRY(c, hipEventRecord(c->ev[3], s));

@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "vtx_device.h"
 
@@ -334,7 +335,8 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
     uint32_t max_hap, uint32_t tables_per_pass, uint32_t table_stride,
     const int32_t* __restrict__ ref_score, const int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ logbuf, uint16_t* __restrict__ band, uint32_t band_stride,
-    uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters) {
+    uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters,
+    uint32_t ablate) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x;
     // per-lane LDS arrays, element i of lane tid at [i * 256 + tid]
@@ -423,6 +425,18 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
         const uint8_t* yb = (const uint8_t*)(head + TB_HEADS);
         const int32_t full = hap ? alt_score[rid] : ref_score[rid];
         if (m < KMER || n < KMER) continue;                 // no k-mer: Band::full_matrix, banded == full
+        if (ablate == 1) continue;                           // (profiling aid) table build only
+        if (ablate == 2) {                                   // (profiling aid) probe loop only
+            uint32_t wl = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
+            uint32_t wh = (uint32_t)x[4] | ((uint32_t)x[5] << 8), cntm = 0;
+            for (uint32_t xr = 0; xr + KMER <= m; ++xr) {
+                for (uint32_t y = head[kw_hash(wl, wh)]; y != 0xffff; y = next[y]) cntm += (kwlo[y] == wl && kwhi[y] == (uint16_t)wh);
+                const uint32_t nb = (xr + KMER < m) ? x[xr + KMER] : 0;
+                wl = (wl >> 8) | (wh << 24); wh = ((wh >> 8) & 0xff) | (nb << 8);
+            }
+            if (cntm == 0xffffffffu) counters[7] = cntm;
+            continue;
+        }
         if (m > 1023 || n > 4095) { overflow_list[atomicAdd(&counters[1], 1u)] = task; continue; }   // FIFO packing limits
 
         // ---- streaming sdpkpp ----
@@ -433,6 +447,9 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
         uint32_t pm_n = 0, fq_head = 0, fq_n = 0, lg_n = 0;
         uint32_t t_y0 = 0, t_v0 = 0, t_id0 = 0, t_len = 0;
         uint32_t last_id = NONE_ID; int32_t last_dp = 0;       // newest match (for the continuation test)
+        // Ended matches with dp == K (isolated k-mers: nearly every off-diagonal match) can only win a query
+        // within L1 distance 1 of their end, i.e. for two rows: they wait in two registers instead of the staircase.
+        uint32_t iso_a = NONE_ID, iso_b = NONE_ID;
         int32_t best_v = -1; uint32_t best_id = 0;
         bool overflow = false;
         uint32_t why = 0;
@@ -448,6 +465,12 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
                 ++fq_head; --fq_n;
                 const uint32_t ye = (id & 0xffff) + KMER, xe = (id >> 16) + KMER;
                 const uint32_t V = dp + xe + ye;
+                if (dp == KMER) {
+                    if (iso_a == NONE_ID || (iso_a >> 16) + KMER + 1 < xr) iso_a = id;
+                    else if (iso_b == NONE_ID || (iso_b >> 16) + KMER + 1 < xr) iso_b = id;
+                    else { overflow = true; why = 1; break; }
+                    continue;
+                }
                 if (t_len && ye >= t_y0) {
                     // in or after the top run
                     const uint32_t t = min(t_len - 1, ye - t_y0);
@@ -600,22 +623,34 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
                             if (FQ_IDOF(fe) == want) { dpc = (int32_t)FQ_DPOF(fe); break; }
                         }
                 }
-                // start candidate: last staircase element with ye <= y (top run first)
-                int32_t dp = KMER; uint32_t prev = NONE_ID;
+                // start candidate: max (V, id) over the last staircase element with ye <= y (top run first)
+                // and the isolated ended matches still in range
+                uint32_t bV = 0, bid = NONE_ID;
                 if (t_len && t_y0 <= y) {
                     const uint32_t t = min(t_len - 1, y - t_y0);
-                    const int32_t cand = (int32_t)(t_v0 + 3 * t) - 5 - (int32_t)(xr + y) + KMER;
-                    if (cand >= dp) { dp = cand; prev = t_id0 + t * 0x10001u; }
+                    bV = t_v0 + 3 * t; bid = t_id0 + t * 0x10001u;
                 } else {
                     for (uint32_t i = pm_n; i-- > 0;) {
                         const uint32_t a = PM_A(i);
                         if ((a >> 16) <= y) {
                             const uint32_t t = min(PM_L(i) - 1, y - (a >> 16));
-                            const int32_t cand = (int32_t)((a & 0xffff) + 3 * t) - 5 - (int32_t)(xr + y) + KMER;
-                            if (cand >= dp) { dp = cand; prev = PM_ID(i) + t * 0x10001u; }
+                            bV = (a & 0xffff) + 3 * t; bid = PM_ID(i) + t * 0x10001u;
                             break;
                         }
                     }
+                }
+                if (iso_a != NONE_ID && (iso_a & 0xffff) + KMER <= y) {
+                    const uint32_t v = KMER + (iso_a >> 16) + KMER + (iso_a & 0xffff) + KMER;
+                    if (v > bV || (v == bV && (bid == NONE_ID || iso_a > bid))) { bV = v; bid = iso_a; }
+                }
+                if (iso_b != NONE_ID && (iso_b & 0xffff) + KMER <= y) {
+                    const uint32_t v = KMER + (iso_b >> 16) + KMER + (iso_b & 0xffff) + KMER;
+                    if (v > bV || (v == bV && (bid == NONE_ID || iso_b > bid))) { bV = v; bid = iso_b; }
+                }
+                int32_t dp = KMER; uint32_t prev = NONE_ID;
+                if (bid != NONE_ID) {
+                    const int32_t cand = (int32_t)bV - 5 - (int32_t)(xr + y) + KMER;
+                    if (cand >= dp) { dp = cand; prev = bid; }
                 }
                 bool cont = false;
                 if (dpc >= 0 && dpc + 1 >= dp) { dp = dpc + 1; cont = true; }   // ties: continuation has the larger index
@@ -780,7 +815,8 @@ extern "C" hipError_t vtxk_launch_band_fast(uint32_t n_tasks, uint32_t task_base
     }
     hipLaunchKernelGGL(band_fast_kernel, dim3((n_tasks + 255) / 256), dim3(256), shmem, s, n_tasks, task_base, records,
                        rec_locus, loci, read_arena, hap_arena, max_hap, tables, (uint32_t)tstride, ref_score, alt_score,
-                       logbuf, band, band_stride, hard_list, overflow_list, counters);
+                       logbuf, band, band_stride, hard_list, overflow_list, counters,
+                       (uint32_t)(getenv("VTX_BAND_ABLATE") ? atoi(getenv("VTX_BAND_ABLATE")) : 0));
     return hipGetLastError();
 }
 

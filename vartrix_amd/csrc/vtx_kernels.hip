@@ -552,3 +552,180 @@ extern "C" hipError_t vtxk_launch_sw_banded(int R, int GL, uint32_t n_hard, cons
 #undef CASE
     return hipErrorInvalidValue;
 }
+
+// ---------------------------------------------------------------------------
+// sw_full_lut_kernel — sw_full_kernel with the substitution term read from LDS.
+//
+// Per locus (shared by every record of the workgroup that aligns to it) a table
+//   lut[idx * 6 + code] = { ref[j] == base(code) ? +1 : -5 , alt[j] == base(code) ? +1 : -5 }   (i16 pair)
+// idx = PRE + j, code 0..4 = A C G T N, code 5 = "row beyond the read" (never matches), sentinel
+// columns never match.  Each lane keeps one LDS byte address per row (table base + its column
+// offset + the row's base code); the per-step column advance is folded into the ds_read
+// immediate offset.  The diagonal term becomes t = H_diag + w (one v_pk_add_i16) and the state is H
+// itself: 9 packed VALU ops per cell pair instead of 12 (no xor / min / mad / H+1).
+// Reads holding a byte outside ACGTN are appended to `redo` and scored by sw_full_kernel.
+// The stride of 6 words per column spreads the 16 lanes of a record over distinct even banks.
+// ---------------------------------------------------------------------------
+#define LUT_CODES 6
+
+__device__ __forceinline__ uint32_t base_code(uint32_t ch) {
+    return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : ch == 'N' ? 4u : 6u;   // 6 = not representable
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void sw_full_lut_kernel(
+    const uint32_t* __restrict__ work, uint32_t n_work,
+    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus,
+    const vtx_locus* __restrict__ loci,
+    const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
+    int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score, uint32_t lcols, uint32_t loci_cap,
+    uint32_t* __restrict__ redo, uint32_t* __restrict__ redo_count) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr int GL = 16;
+    constexpr int GROUPS_PER_BLOCK = 16;
+    constexpr int PRE = GL;
+    const int tid = threadIdx.x;
+    const int grp = tid / GL;
+    const int l = tid % GL;
+    const uint32_t widx = blockIdx.x * GROUPS_PER_BLOCK + grp;
+    const bool active = widx < n_work;
+
+    uint32_t rid = 0, m = 0, nr = 0, na = 0, roff = 0, my_locus = 0;
+    if (active) {
+        rid = work[widx];
+        const vtx_record rec = records[rid];
+        my_locus = rec_locus[rid];
+        const vtx_locus loc = loci[my_locus];
+        m = rec.read_len; roff = rec.read_off;
+        nr = loc.ref_len; na = loc.alt_len;
+    }
+    // locus range of the workgroup (work lists are in record order => loci ascending)
+    const uint32_t w_first = blockIdx.x * GROUPS_PER_BLOCK;
+    const uint32_t w_last = min(n_work - 1, w_first + GROUPS_PER_BLOCK - 1);
+    const uint32_t l_first = rec_locus[work[w_first]], l_last = rec_locus[work[w_last]];
+    const uint32_t n_loc = l_last - l_first + 1;          // <= loci_cap (checked by the host when choosing this kernel)
+    if (!active) my_locus = l_first;                      // idle slots read a valid table
+
+    const uint32_t n = nr > na ? nr : na;
+    uint32_t nwave = n;
+    nwave = max(nwave, (uint32_t)__shfl_xor((int)nwave, 16));
+    nwave = max(nwave, (uint32_t)__shfl_xor((int)nwave, 32));
+    const uint32_t steps = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nwave + GL - 1));
+
+    // ---- build the tables of loci l_first .. l_last: lcols columns x 6 codes each ----
+    const uint32_t tab_words = lcols * LUT_CODES;
+    for (uint32_t t = 0; t < n_loc && t < loci_cap; ++t) {
+        const vtx_locus loc = loci[l_first + t];
+        uint32_t* tab = smem + (size_t)t * tab_words;
+        for (uint32_t idx = tid; idx < lcols; idx += 256) {
+            const int j = (int)idx - PRE;
+            uint32_t rc = 0x200u, ac = 0x200u;            // sentinel: equals no base
+            if (j >= 0) {
+                if ((uint32_t)j < loc.ref_len) rc = hap_arena[loc.ref_off + j];
+                if ((uint32_t)j < loc.alt_len) ac = hap_arena[loc.alt_off + j];
+            }
+            const uint32_t bases[5] = {'A', 'C', 'G', 'T', 'N'};
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const uint32_t wr = (rc == bases[k]) ? 0x0001u : 0xfffbu;
+                const uint32_t wa = (ac == bases[k]) ? 0x0001u : 0xfffbu;
+                tab[idx * LUT_CODES + k] = wr | (wa << 16);
+            }
+            tab[idx * LUT_CODES + 5] = 0xfffbfffbu;
+        }
+    }
+
+    // ---- this lane's rows: LDS byte address of (column of step 0, row's base code) ----
+    const uint32_t tab_base = (uint32_t)(my_locus - l_first) * tab_words;
+    uint32_t addr[R];
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = (uint32_t)(l * R + r);
+        uint32_t code = 5;
+        if (i < m) { code = base_code(read_arena[roff + i]); if (code > 5) { bad = true; code = 5; } }
+        addr[r] = (tab_base + (uint32_t)(PRE - l) * LUT_CODES + code) * 4u;
+    }
+    __syncthreads();
+    // any lane of the record saw a byte outside ACGTN: leave the record to the generic kernel
+    uint32_t badm = bad ? 1u : 0u;
+#pragma unroll
+    for (int off = 1; off < GL; off <<= 1) badm |= (uint32_t)__shfl_xor((int)badm, off);
+
+    uint32_t Ha[R], Hb[R], Q[R], E[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { Ha[r] = 0; Hb[r] = 0; Q[r] = 0; E[r] = 0; }
+    uint32_t best = 0;
+    uint32_t hu_a = 0, hu_b = 0, qu = 0, fu = 0, f_last = 0, q_bottom = 0;
+    const char* lds = (const char*)smem;
+
+    // state S = column j-1 (H only; Q and E are updated in place), D = column j
+#define LUT_STEP(HS, HD, hprev, hcur, hsrc, OFF)                                                   \
+    {                                                                                              \
+        hcur = lane_shr1<DPP_ROW_SHR1>(hcur, hsrc);                                                \
+        qu = lane_shr1<DPP_ROW_SHR1>(qu, q_bottom);                                                \
+        fu = lane_shr1<DPP_ROW_SHR1>(fu, f_last);                                                  \
+        uint32_t hd = hprev, qa = qu, fa = fu;                                                     \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) {                                            \
+            const uint32_t w = *(const uint32_t*)(lds + addr[r] + (OFF));                          \
+            const uint32_t tt = pk_add(hd, w);                                                     \
+            hd = HS[r];                                                                            \
+            const uint32_t e = pk_max(pk_sub_sat(E[r], PK(1)), Q[r]);                              \
+            const uint32_t f = pk_max(pk_sub_sat(fa, PK(1)), qa);                                  \
+            const uint32_t h = pk_max(pk_max(tt, e), f);                                           \
+            best = pk_max(best, tt);                                                               \
+            E[r] = e;                                                                              \
+            HD[r] = h;                                                                             \
+            Q[r] = pk_sub_sat(h, PK(6));                                                           \
+            fa = f; qa = Q[r];                                                                     \
+        }                                                                                          \
+        f_last = fa; q_bottom = Q[R - 1];                                                          \
+    }
+    const uint32_t steps4 = (steps + 3) >> 2;
+    for (uint32_t t4 = 0; t4 < steps4; ++t4) {
+        LUT_STEP(Hb, Ha, hu_b, hu_a, Hb[R - 1], 0 * LUT_CODES * 4)
+        LUT_STEP(Ha, Hb, hu_a, hu_b, Ha[R - 1], 1 * LUT_CODES * 4)
+        LUT_STEP(Hb, Ha, hu_b, hu_a, Hb[R - 1], 2 * LUT_CODES * 4)
+        LUT_STEP(Ha, Hb, hu_a, hu_b, Ha[R - 1], 3 * LUT_CODES * 4)
+#pragma unroll
+        for (int r = 0; r < R; ++r) addr[r] += 4 * LUT_CODES * 4;
+    }
+#undef LUT_STEP
+
+#pragma unroll
+    for (int off = 1; off < GL; off <<= 1) best = pk_max(best, (uint32_t)__shfl_xor((int)best, off));
+    if (active && l == 0) {
+        if (badm) {
+            redo[atomicAdd(redo_count, 1u)] = rid;
+        } else {
+            ref_score[rid] = (int32_t)(int16_t)(best & 0xffffu);
+            alt_score[rid] = (int32_t)(int16_t)(best >> 16);
+        }
+    }
+}
+
+extern "C" hipError_t vtxk_launch_sw_full_lut(int R, uint32_t n_work, const uint32_t* work, const vtx_record* records,
+                                              const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
+                                              const uint8_t* hap_arena, int32_t* ref_score, int32_t* alt_score,
+                                              uint32_t max_hap_len, uint32_t loci_cap, uint32_t* redo, uint32_t* redo_count,
+                                              hipStream_t stream) {
+    if (n_work == 0) return hipSuccess;
+    // columns: PRE sentinels + haplotype + (GL - 1 + 3) trailing steps (4x unrolled loop) + 1
+    const uint32_t lcols = 16 + max_hap_len + 16 + 4;
+    const size_t shmem = (size_t)loci_cap * lcols * LUT_CODES * sizeof(uint32_t);
+    const dim3 grid((n_work + 15) / 16), block(256);
+#define CASE(r)                                                                                          \
+    if (R == r) {                                                                                        \
+        if (shmem > 48 * 1024) {                                                                         \
+            hipError_t e = hipFuncSetAttribute((const void*)sw_full_lut_kernel<r>,                       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  \
+            if (e != hipSuccess) return e;                                                               \
+        }                                                                                                \
+        hipLaunchKernelGGL((sw_full_lut_kernel<r>), grid, block, shmem, stream, work, n_work, records,   \
+                           rec_locus, loci, read_arena, hap_arena, ref_score, alt_score, lcols, loci_cap, redo, redo_count); \
+        return hipGetLastError();                                                                        \
+    }
+    CASE(2) CASE(4) CASE(6) CASE(8) CASE(10) CASE(12) CASE(16)
+#undef CASE
+    return hipErrorInvalidValue;
+}
