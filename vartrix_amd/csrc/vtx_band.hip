@@ -285,25 +285,26 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
 // band_fast_kernel — the common-case band kernel: one lane per task, STREAMING over read rows.
 //
 // Same results as band_kernel (sdpkpp chain -> staircase -> certificate), restructured so the
-// per-lane state is a few dozen LDS words instead of a per-task global scratch slab:
+// per-lane state is a few registers + 24 LDS words instead of a per-task global scratch slab:
 //   * haplotype k-mer tables (48-bit k-mer words, chained hash with ascending-y chains, raw bytes)
 //     are built ONCE per (locus, haplotype) per workgroup in LDS and shared by its tasks;
-//   * sdpkpp needs, at a match (x, y), max (V, idx) over matches that ENDED at (<= x, <= y).  Ended
-//     matches live in a dominance-pruned staircase (ye ascending, V strictly increasing) which stays
-//     tiny because an entry is dead once V + 1 - (x + ye) < K (it can never again beat a fresh
-//     start); matches of the last K rows wait in a FIFO until their end becomes visible, and the
-//     FIFO also answers "does (x-1, y-1) exist and what is its dp" (LCSk++ continuation);
-//   * only non-continuation matches (chain starts and jumps) are logged (global memory) — the
-//     traceback hops through that log, so the chain comes out as a few diagonal segments;
+//   * sdpkpp needs, at a match (x, y), max (V, idx) over matches that ENDED at (<= x, <= y).  Matches
+//     are kept as SEGMENTS — linear pieces of diagonal runs (id0, dp0, len) — whose element u ends
+//     at (x0+u+K, y0+u+K) with V = V0 + 3u, so a segment's best candidate for any query is closed
+//     form, u* = min(len-1, x-x0-K, y-y0-K): descriptors are immutable except `len`, there is no
+//     per-row maintenance, and the LCSk++ continuation is a register compare;
+//   * a continuing k-mer skips the query when an upper bound (largest V of any other segment)
+//     cannot beat the continuation; only segment starts (chain starts, jumps, breakpoints) query
+//     all segments and are logged (global memory) — the traceback hops through that log, so the
+//     chain comes out as a few diagonal segments;
 //   * the certificate walk adds +1 per k-mer cell without touching bytes (k-mer cells are exact
 //     matches), bytes are compared only in gap diagonals and the lazy extensions.
-// Any capacity overflow (staircase, FIFO, log, segments) sends the task to band_kernel via
+// Any capacity overflow (parked segments, log, chain segments) sends the task to band_kernel via
 // overflow_list: results never depend on which kernel handled a task.
 // Hard tasks get a polyline (vertex list) in their band slot, flagged 0xffff; band_expand_kernel
 // turns it into the lo / hi arrays sw_banded_kernel reads.
 // =============================================================================================
-#define PS 6        // staircase runs per lane (LDS) + the top run in registers
-#define PQ 16       // pending FIFO entries per lane, packed x:10 | y:12 | dp:10
+#define PS 12       // parked segments per lane (LDS); two more live in registers
 #define LG 24       // jump-log entries per task (global)
 #define SG 10       // chain segments per task
 #define TB_HEADS 2048
@@ -342,18 +343,11 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
     // per-lane LDS arrays, element i of lane tid at [i * 256 + tid]
     // staircase of ended matches, stored as RUNS: elements (ye0 + t, V0 + 3t, id0 + t*(1,1)), t < len
     // (a continued k-mer adds +1 to ye and, with dp + 1, +3 to V = dp + xe + ye)
-    uint32_t* pm_a = smem;                     // ye0 << 16 | V0
-    uint32_t* pm_id = pm_a + PS * 256;         // id0
-    uint32_t* pm_l = pm_id + PS * 256;         // len
-    uint32_t* fq = pm_l + PS * 256;            // x << 22 | y << 10 | dp
-    uint8_t* tables = (uint8_t*)(fq + PQ * 256);
+    uint32_t* pm_a = smem;                     // parked segments: id0 = x0 << 16 | y0
+    uint32_t* pm_id = pm_a + PS * 256;         //                  dp0 << 16 | len
+    uint8_t* tables = (uint8_t*)(pm_id + PS * 256);
 #define PM_A(i) pm_a[(i) * 256 + tid]
 #define PM_ID(i) pm_id[(i) * 256 + tid]
-#define PM_L(i) pm_l[(i) * 256 + tid]
-#define FQ(i) fq[((i) & (PQ - 1)) * 256 + tid]
-#define FQ_X(e) ((e) >> 22)
-#define FQ_IDOF(e) ((((e) >> 22) << 16) | (((e) >> 10) & 0xfff))
-#define FQ_DPOF(e) ((e) & 0x3ff)
 
     const uint32_t slot = blockIdx.x * 256 + tid;
     const bool have = slot < n_tasks;
@@ -437,239 +431,152 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
             if (cntm == 0xffffffffu) counters[7] = cntm;
             continue;
         }
-        if (m > 1023 || n > 4095) { overflow_list[atomicAdd(&counters[1], 1u)] = task; continue; }   // FIFO packing limits
 
-        // ---- streaming sdpkpp ----
-        // The TOP staircase run (largest columns: in practice the main diagonal) lives in registers
-        // (t_y0, t_v0, t_id0, t_len; t_len == 0: none); lower runs live in LDS slots [0, pm_n).
-        // Elements that can no longer win are pruned eagerly from the top run and only every 8 rows
-        // from the LDS runs: a dead element never changes a query's outcome, pruning is for capacity.
-        uint32_t pm_n = 0, fq_head = 0, fq_n = 0, lg_n = 0;
-        uint32_t t_y0 = 0, t_v0 = 0, t_id0 = 0, t_len = 0;
-        uint32_t last_id = NONE_ID; int32_t last_dp = 0;       // newest match (for the continuation test)
-        // Ended matches with dp == K (isolated k-mers: nearly every off-diagonal match) can only win a query
-        // within L1 distance 1 of their end, i.e. for two rows: they wait in two registers instead of the staircase.
-        uint32_t iso_a = NONE_ID, iso_b = NONE_ID;
+        // ---- streaming sdpkpp at SEGMENT level ----
+        // A segment is a linear piece of a diagonal run: matches id0 + u*(1,1), dp = dp0 + u, u < len.
+        // Its element u ends at (x0+u+K, y0+u+K) with V = dp + xe + ye = V0 + 3u, so for a query at
+        // (x, y) the best candidate of a segment is u* = min(len-1, x-x0-K, y-y0-K) in closed form:
+        // descriptors are immutable except for `len`, no per-row maintenance.  Two segments live in
+        // registers (the two most recently extended ones), the rest in an LDS list; segments none of
+        // whose elements can win any more (V + 1 - (x + ye) < K for all of them) are dropped from the
+        // list when it fills up (they stay in the jump log, which is what the traceback reads).
+#define SEG_NONE 0xffffffffu
+        uint32_t a_id0 = SEG_NONE, a_dp0 = 0, a_len = 0;     // slot A
+        uint32_t b_id0 = SEG_NONE, b_dp0 = 0, b_len = 0;     // slot B
+        uint32_t pm_n = 0, lg_n = 0;
+        int32_t vmax_lds = 0;                                 // max V of any element of an LDS segment (upper bound)
         int32_t best_v = -1; uint32_t best_id = 0;
         bool overflow = false;
         uint32_t why = 0;
         uint32_t wlo = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
         uint32_t whi = (uint32_t)x[4] | ((uint32_t)x[5] << 8);
         uint32_t nextb = m > KMER ? x[KMER] : 0;
+        // candidate of one segment for a query at (qx, qy): updates (bV, bid) by tuple order
+#define SEG_QUERY(id0, dp0, len, qx, qy, bV, bid)                                                          \
+        {                                                                                                   \
+            const int32_t sx = (int32_t)((id0) >> 16), sy = (int32_t)((id0) & 0xffff);                       \
+            int32_t u = (int32_t)(len) - 1;                                                                 \
+            u = min(u, (int32_t)(qx) - sx - KMER);                                                          \
+            u = min(u, (int32_t)(qy) - sy - KMER);                                                          \
+            if (u >= 0) {                                                                                   \
+                const int32_t v = (int32_t)(dp0) + sx + sy + 2 * KMER + 3 * u;                               \
+                const uint32_t qid = (id0) + (uint32_t)u * 0x10001u;                                        \
+                if (v > bV || (v == bV && (bid == NONE_ID || qid > bid))) { bV = v; bid = qid; }             \
+            }                                                                                               \
+        }
         for (uint32_t xr = 0; xr + KMER <= m && !overflow; ++xr) {
             const uint32_t nextb2 = (xr + KMER + 1 < m) ? x[xr + KMER + 1] : 0;   // prefetch one row ahead
-            // (a) ends that became visible: matches with xq + K <= xr
-            while (fq_n > 0 && FQ_X(FQ(fq_head)) + KMER <= xr) {
-                const uint32_t fe = FQ(fq_head);
-                const uint32_t id = FQ_IDOF(fe), dp = FQ_DPOF(fe);
-                ++fq_head; --fq_n;
-                const uint32_t ye = (id & 0xffff) + KMER, xe = (id >> 16) + KMER;
-                const uint32_t V = dp + xe + ye;
-                if (dp == KMER) {
-                    if (iso_a == NONE_ID || (iso_a >> 16) + KMER + 1 < xr) iso_a = id;
-                    else if (iso_b == NONE_ID || (iso_b >> 16) + KMER + 1 < xr) iso_b = id;
-                    else { overflow = true; why = 1; break; }
-                    continue;
-                }
-                if (t_len && ye >= t_y0) {
-                    // in or after the top run
-                    const uint32_t t = min(t_len - 1, ye - t_y0);
-                    if (t_v0 + 3 * t > V) continue;                                  // dominated
-                    if (ye == t_y0 + t_len && V == t_v0 + 3 * t_len && id == t_id0 + t_len * 0x10001u) { ++t_len; continue; }
-                    if (ye >= t_y0 + t_len) {
-                        // after the top run, not continuing it: the old top run moves to LDS, this becomes the top
-                        if (pm_n == PS) { overflow = true; why = 2; break; }
-                        PM_A(pm_n) = (t_y0 << 16) | t_v0; PM_ID(pm_n) = t_id0; PM_L(pm_n) = t_len; ++pm_n;
-                        t_y0 = ye; t_v0 = V; t_id0 = id; t_len = 1;
-                        continue;
-                    }
-                    // inside the top run at element t (V' <= V): elements t .. te-1 go
-                    const uint32_t te = (V - t_v0) / 3 + 1;
-                    if (t > 0) {
-                        if (pm_n == PS) { overflow = true; why = 2; break; }
-                        PM_A(pm_n) = (t_y0 << 16) | t_v0; PM_ID(pm_n) = t_id0; PM_L(pm_n) = t; ++pm_n;     // prefix
-                    }
-                    if (te < t_len) {
-                        if (pm_n == PS) { overflow = true; why = 2; break; }
-                        PM_A(pm_n) = (ye << 16) | V; PM_ID(pm_n) = id; PM_L(pm_n) = 1; ++pm_n;           // the new element
-                        t_id0 += te * 0x10001u; t_y0 += te; t_v0 += 3 * te; t_len -= te;              // suffix stays on top
-                    } else {
-                        t_y0 = ye; t_v0 = V; t_id0 = id; t_len = 1;
-                    }
-                    continue;
-                }
-                if (!t_len) { t_y0 = ye; t_v0 = V; t_id0 = id; t_len = 1; continue; }
-                // before the top run: LDS runs are sorted by column; j = number of runs starting at or before ye
-                uint32_t j = 0;
-                while (j < pm_n && (PM_A(j) >> 16) <= ye) ++j;
-                bool placed = false, merge = false;
-                if (j > 0) {
-                    const uint32_t a = PM_A(j - 1), len = PM_L(j - 1);
-                    const uint32_t y0 = a >> 16, v0 = a & 0xffff;
-                    const uint32_t t = min(len - 1, ye - y0);
-                    if (v0 + 3 * t > V) continue;
-                    if (ye <= y0 + len - 1) {
-                        const uint32_t te = (V - v0) / 3 + 1;
-                        if (t == 0) {
-                            --j;
-                        } else if (te >= len) {
-                            PM_L(j - 1) = t;
-                        } else {
-                            if (pm_n + 2 > PS) { overflow = true; why = 2; break; }
-                            for (uint32_t i = pm_n; i > j; --i) {
-                                PM_A(i + 1) = PM_A(i - 1); PM_ID(i + 1) = PM_ID(i - 1); PM_L(i + 1) = PM_L(i - 1);
-                            }
-                            PM_L(j - 1) = t;
-                            PM_A(j) = (ye << 16) | V; PM_ID(j) = id; PM_L(j) = 1;
-                            PM_A(j + 1) = ((y0 + te) << 16) | (v0 + 3 * te);
-                            PM_ID(j + 1) = PM_ID(j - 1) + te * 0x10001u;
-                            PM_L(j + 1) = len - te;
-                            pm_n += 2;
-                            placed = true;
-                        }
-                    } else if (ye == y0 + len && V == v0 + 3 * len && id == PM_ID(j - 1) + len * 0x10001u) {
-                        merge = true;                                  // continues LDS run j-1
-                    }
-                }
-                if (placed) continue;
-                // drop / trim following runs (LDS, then the top run) whose elements have V' <= V
-                uint32_t last = j;
-                bool stop = false;
-                while (last < pm_n) {
-                    const uint32_t a = PM_A(last), len = PM_L(last);
-                    const uint32_t v0 = a & 0xffff;
-                    if (v0 > V) { stop = true; break; }
-                    const uint32_t k = (V - v0) / 3 + 1;
-                    if (k >= len) { ++last; continue; }
-                    PM_A(last) = (((a >> 16) + k) << 16) | (v0 + 3 * k);
-                    PM_ID(last) = PM_ID(last) + k * 0x10001u;
-                    PM_L(last) = len - k;
-                    stop = true;
-                    break;
-                }
-                if (!stop && t_v0 <= V) {                          // reaches into the top run
-                    const uint32_t k = (V - t_v0) / 3 + 1;
-                    if (k >= t_len) {
-                        // the whole top run goes, and so did LDS runs [j, pm_n): the new element ends up on top
-                        if (merge) {
-                            const uint32_t a = PM_A(j - 1);
-                            t_y0 = a >> 16; t_v0 = a & 0xffff; t_id0 = PM_ID(j - 1); t_len = PM_L(j - 1) + 1;
-                            pm_n = j - 1;
-                        } else {
-                            pm_n = j;
-                            t_y0 = ye; t_v0 = V; t_id0 = id; t_len = 1;
-                        }
-                        continue;
-                    }
-                    t_id0 += k * 0x10001u; t_y0 += k; t_v0 += 3 * k; t_len -= k;
-                }
-                if (merge) {
-                    PM_L(j - 1) = PM_L(j - 1) + 1;
-                    if (last > j) {
-                        const uint32_t d = last - j;
-                        for (uint32_t i = last; i < pm_n; ++i) { PM_A(i - d) = PM_A(i); PM_ID(i - d) = PM_ID(i); PM_L(i - d) = PM_L(i); }
-                        pm_n -= d;
-                    }
-                    continue;
-                }
-                if (last == j) {
-                    if (pm_n == PS) { overflow = true; why = 2; break; }
-                    for (uint32_t i = pm_n; i > j; --i) { PM_A(i) = PM_A(i - 1); PM_ID(i) = PM_ID(i - 1); PM_L(i) = PM_L(i - 1); }
-                    ++pm_n;
-                } else if (last > j + 1) {
-                    const uint32_t d = last - j - 1;
-                    for (uint32_t i = last; i < pm_n; ++i) { PM_A(i - d) = PM_A(i); PM_ID(i - d) = PM_ID(i); PM_L(i - d) = PM_L(i); }
-                    pm_n -= d;
-                }
-                PM_A(j) = (ye << 16) | V; PM_ID(j) = id; PM_L(j) = 1;
-            }
-            if (overflow) break;
-            // (b) prune: element t of a run is alive iff V0 + 3t + 1 - (xr + ye0 + t) >= K  <=>  2t >= need
-            if (t_len) {
-                const int32_t need = (int32_t)(xr + t_y0) + KMER - 1 - (int32_t)t_v0;
-                const uint32_t k = need > 0 ? (uint32_t)(need + 1) >> 1 : 0;
-                if (k >= t_len) {
-                    t_len = 0;
-                    if (pm_n) { --pm_n; const uint32_t a = PM_A(pm_n); t_y0 = a >> 16; t_v0 = a & 0xffff; t_id0 = PM_ID(pm_n); t_len = PM_L(pm_n); }
-                } else if (k) { t_id0 += k * 0x10001u; t_y0 += k; t_v0 += 3 * k; t_len -= k; }
-            }
-            if ((xr & 15) == 15 && pm_n) {
-                uint32_t w = 0;
-                for (uint32_t i = 0; i < pm_n; ++i) {
-                    const uint32_t a = PM_A(i), len = PM_L(i);
-                    const int32_t need = (int32_t)(xr + (a >> 16)) + KMER - 1 - (int32_t)(a & 0xffff);
-                    const uint32_t k = need > 0 ? (uint32_t)(need + 1) >> 1 : 0;
-                    if (k >= len) continue;
-                    PM_A(w) = (((a >> 16) + k) << 16) | ((a & 0xffff) + 3 * k);
-                    PM_ID(w) = PM_ID(i) + k * 0x10001u;
-                    PM_L(w) = len - k;
-                    ++w;
-                }
-                pm_n = w;
-            }
-            // (c) matches of this row, ascending y
             for (uint32_t y = head[kw_hash(wlo, whi)]; y != 0xffff; y = next[y]) {
                 if (kwlo[y] != wlo || kwhi[y] != (uint16_t)whi) continue;
                 const uint32_t id = (xr << 16) | y;
-                // LCSk++ continuation: is (xr-1, y-1) a match?  Usually it is the newest match.
-                int32_t dpc = -1;
-                if (xr > 0 && y > 0) {
-                    const uint32_t want = ((xr - 1) << 16) | (y - 1);
-                    if (last_id == want) dpc = last_dp;
-                    else
-                        for (uint32_t i = fq_n; i-- > 0;) {
-                            const uint32_t fe = FQ(fq_head + i);
-                            if (FQ_X(fe) + 1 < xr) break;
-                            if (FQ_IDOF(fe) == want) { dpc = (int32_t)FQ_DPOF(fe); break; }
-                        }
+                // which segment (if any) does this match continue?
+                int cont = 0;                                   // 1: slot A, 2: slot B
+                if (a_id0 != SEG_NONE && id == a_id0 + a_len * 0x10001u) cont = 1;
+                else if (b_id0 != SEG_NONE && id == b_id0 + b_len * 0x10001u) cont = 2;
+                if (cont == 2) {                                // keep the segment being extended in slot A
+                    uint32_t t;
+                    t = a_id0; a_id0 = b_id0; b_id0 = t;
+                    t = a_dp0; a_dp0 = b_dp0; b_dp0 = t;
+                    t = a_len; a_len = b_len; b_len = t;
+                    cont = 1;
                 }
-                // start candidate: max (V, id) over the last staircase element with ye <= y (top run first)
-                // and the isolated ended matches still in range
-                uint32_t bV = 0, bid = NONE_ID;
-                if (t_len && t_y0 <= y) {
-                    const uint32_t t = min(t_len - 1, y - t_y0);
-                    bV = t_v0 + 3 * t; bid = t_id0 + t * 0x10001u;
-                } else {
-                    for (uint32_t i = pm_n; i-- > 0;) {
-                        const uint32_t a = PM_A(i);
-                        if ((a >> 16) <= y) {
-                            const uint32_t t = min(PM_L(i) - 1, y - (a >> 16));
-                            bV = (a & 0xffff) + 3 * t; bid = PM_ID(i) + t * 0x10001u;
+                int32_t cdp = -1;
+                bool need_query = true;
+                if (cont == 1) {
+                    cdp = (int32_t)(a_dp0 + a_len);              // dp of the previous match + 1
+                    // cheap bound: can any OTHER segment's candidate beat the continuation?
+                    int32_t vb = vmax_lds;
+                    if (b_id0 != SEG_NONE && (b_id0 >> 16) + KMER <= xr) {
+                        const int32_t v = (int32_t)b_dp0 + (int32_t)(b_id0 >> 16) + (int32_t)(b_id0 & 0xffff) + 2 * KMER + 3 * ((int32_t)b_len - 1);
+                        vb = max(vb, v);
+                    }
+                    // (own visible elements give dp(t-K) + 1 < dp(t-1) + 1: never win)
+                    if (vb + 1 - (int32_t)(xr + y) <= cdp) need_query = false;
+                } else if (pm_n) {
+                    // maybe it continues a segment parked in LDS (a third diagonal being extended)
+                    for (uint32_t i = 0; i < pm_n; ++i) {
+                        const uint32_t sid = PM_A(i), sdl = PM_ID(i);
+                        if (id == sid + (sdl & 0xffff) * 0x10001u) {
+                            // bring it into slot A; park A (B stays)
+                            const uint32_t pa = a_id0, pd = a_dp0, pl = a_len;
+                            a_id0 = sid; a_dp0 = sdl >> 16; a_len = sdl & 0xffff;
+                            if (pa != SEG_NONE) { PM_A(i) = pa; PM_ID(i) = (pd << 16) | pl; }
+                            else { PM_A(i) = PM_A(pm_n - 1); PM_ID(i) = PM_ID(pm_n - 1); --pm_n; }
+                            cont = 1; cdp = (int32_t)(a_dp0 + a_len);
                             break;
                         }
                     }
                 }
-                if (iso_a != NONE_ID && (iso_a & 0xffff) + KMER <= y) {
-                    const uint32_t v = KMER + (iso_a >> 16) + KMER + (iso_a & 0xffff) + KMER;
-                    if (v > bV || (v == bV && (bid == NONE_ID || iso_a > bid))) { bV = v; bid = iso_a; }
-                }
-                if (iso_b != NONE_ID && (iso_b & 0xffff) + KMER <= y) {
-                    const uint32_t v = KMER + (iso_b >> 16) + KMER + (iso_b & 0xffff) + KMER;
-                    if (v > bV || (v == bV && (bid == NONE_ID || iso_b > bid))) { bV = v; bid = iso_b; }
-                }
                 int32_t dp = KMER; uint32_t prev = NONE_ID;
-                if (bid != NONE_ID) {
-                    const int32_t cand = (int32_t)bV - 5 - (int32_t)(xr + y) + KMER;
-                    if (cand >= dp) { dp = cand; prev = bid; }
+                if (need_query) {
+                    int32_t bV = INT32_MIN; uint32_t bid = NONE_ID;
+                    if (a_id0 != SEG_NONE) SEG_QUERY(a_id0, a_dp0, a_len, xr, y, bV, bid)
+                    if (b_id0 != SEG_NONE) SEG_QUERY(b_id0, b_dp0, b_len, xr, y, bV, bid)
+                    for (uint32_t i = 0; i < pm_n; ++i) {
+                        const uint32_t sid = PM_A(i), sdl = PM_ID(i);
+                        SEG_QUERY(sid, (sdl >> 16), (sdl & 0xffff), xr, y, bV, bid)
+                    }
+                    if (bid != NONE_ID) {
+                        const int32_t cand = bV - 5 - (int32_t)(xr + y) + KMER;
+                        if (cand >= dp) { dp = cand; prev = bid; }
+                    }
                 }
-                bool cont = false;
-                if (dpc >= 0 && dpc + 1 >= dp) { dp = dpc + 1; cont = true; }   // ties: continuation has the larger index
-                if (!cont) {
+                if (cont == 1 && cdp >= dp) {
+                    ++a_len;                                     // plain continuation (ties: continuation wins)
+                    dp = cdp;
+                } else {
+                    // a new segment starts here (fresh start, jump, or a breakpoint inside a run)
                     if (lg_n == LG) { overflow = true; why = 3; break; }
                     mylog[2 * lg_n] = id; mylog[2 * lg_n + 1] = prev; ++lg_n;
+                    if (cont != 1 && a_id0 != SEG_NONE) {
+                        // slot A keeps the most recently extended segment: move A to B, park B
+                        if (b_id0 != SEG_NONE) {
+                            // park B unless none of its elements can win any more
+                            const int32_t bx = (int32_t)(b_id0 >> 16);
+                            if (2 * ((int32_t)b_len - 1) >= (int32_t)xr - bx - (int32_t)b_dp0 - 1) {
+                                if (pm_n == PS) {           // drop dead parked segments first
+                                    uint32_t w = 0; int32_t vm = 0;
+                                    for (uint32_t i = 0; i < pm_n; ++i) {
+                                        const uint32_t sid = PM_A(i), sdl = PM_ID(i);
+                                        const int32_t sx = (int32_t)(sid >> 16), sl = (int32_t)(sdl & 0xffff), sd = (int32_t)(sdl >> 16);
+                                        if (2 * (sl - 1) < (int32_t)xr - sx - sd - 1) continue;
+                                        PM_A(w) = sid; PM_ID(w) = sdl; ++w;
+                                        vm = max(vm, sd + sx + (int32_t)(sid & 0xffff) + 2 * KMER + 3 * (sl - 1));
+                                    }
+                                    pm_n = w; vmax_lds = vm;
+                                    if (pm_n == PS) { overflow = true; why = 2; break; }
+                                }
+                                PM_A(pm_n) = b_id0; PM_ID(pm_n) = (b_dp0 << 16) | b_len; ++pm_n;
+                                vmax_lds = max(vmax_lds, (int32_t)b_dp0 + bx + (int32_t)(b_id0 & 0xffff) + 2 * KMER + 3 * ((int32_t)b_len - 1));
+                            }
+                        }
+                        b_id0 = a_id0; b_dp0 = a_dp0; b_len = a_len;
+                    } else if (cont == 1) {
+                        // breakpoint inside the run in slot A: the finished piece goes to B's place via the same path
+                        if (b_id0 != SEG_NONE) {
+                            const int32_t bx = (int32_t)(b_id0 >> 16);
+                            if (2 * ((int32_t)b_len - 1) >= (int32_t)xr - bx - (int32_t)b_dp0 - 1) {
+                                if (pm_n == PS) { overflow = true; why = 2; break; }
+                                PM_A(pm_n) = b_id0; PM_ID(pm_n) = (b_dp0 << 16) | b_len; ++pm_n;
+                                vmax_lds = max(vmax_lds, (int32_t)b_dp0 + bx + (int32_t)(b_id0 & 0xffff) + 2 * KMER + 3 * ((int32_t)b_len - 1));
+                            }
+                        }
+                        b_id0 = a_id0; b_dp0 = a_dp0; b_len = a_len;
+                    }
+                    a_id0 = id; a_dp0 = (uint32_t)dp; a_len = 1;
                 }
-                if (fq_n == PQ || dp > 1022) { overflow = true; why = 4; break; }
-                FQ(fq_head + fq_n) = (xr << 22) | (y << 10) | (uint32_t)dp; ++fq_n;
-                last_id = id; last_dp = dp;
                 if (dp >= best_v) { best_v = dp; best_id = id; }
             }
-            // (d) slide the 48-bit window
+            // slide the 48-bit window
             wlo = (wlo >> 8) | (whi << 24);
             whi = ((whi >> 8) & 0xff) | (nextb << 8);
             nextb = nextb2;
         }
+#undef SEG_QUERY
+#undef SEG_NONE
         if (overflow) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[2 + why], 1u); continue; }
         if (best_v < 0) continue;                            // no match at all: full matrix
+        if (ablate == 3) { if (best_id == 0xfffffffeu) counters[7] = best_v; continue; }   // (profiling aid) no traceback / walk
         // ---- traceback through the jump log: chain = diagonal segments (x0, y0, len), last first ----
         uint32_t seg_xy[SG], seg_len[SG];
         uint32_t n_seg = 0;
@@ -735,11 +642,6 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
     }
 #undef PM_A
 #undef PM_ID
-#undef PM_L
-#undef FQ
-#undef FQ_X
-#undef FQ_IDOF
-#undef FQ_DPOF
 }
 
 // Polyline -> lo / hi arrays, one 16-lane group per hard slot (slots written by band_kernel already
@@ -801,9 +703,9 @@ extern "C" hipError_t vtxk_launch_band_fast(uint32_t n_tasks, uint32_t task_base
                                             uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
                                             uint32_t* counters, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
-    const size_t lane_bytes = (size_t)(3 * PS + PQ) * 256 * 4;
+    const size_t lane_bytes = (size_t)(2 * PS) * 256 * 4;
     const size_t tstride = vtxk_band_table_stride(max_hap);
-    size_t budget = 40 * 1024;
+    size_t budget = 40 * 1024;   // lane arrays (24 KiB) + haplotype tables
     uint32_t tables = (uint32_t)((budget - std::min(budget, lane_bytes)) / tstride) & ~1u;
     if (tables < 2) tables = 2;
     if (tables > 8) tables = 8;
