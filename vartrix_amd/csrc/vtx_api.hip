@@ -363,68 +363,83 @@ int vtx_run(vtx_ctx* c) {
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
     if (c->cfg.aligner == VTX_ALIGNER_BANDED && nr) {
         // Banded flavour: d_ref / d_alt hold the full scores.  Per chunk of tasks (task = 2*record + hap):
-        // band kernel (seed, chain, band, certificate) -> hard list -> band-masked DP overwrites hard scores.
+        // fast band kernel (seed, chain, certificate) -> hard list -> expand -> band-masked DP overwrites the
+        // hard scores.  Tasks the fast kernel cannot hold accumulate in ONE overflow list that the general
+        // band kernel processes after the last chunk (a launch of a handful of serial lanes costs ~2 ms).
         const uint64_t n_tasks = 2ull * nr;
         const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_tasks, 1u << 20);
         const uint32_t band_stride = (c->max_hap_len + 2 + 7) & ~7u;
-        const uint32_t m_cap = 512;
         uint32_t fast_overflow = 0;
         HIP_TRY(c, c->d_band_ws.reserve((size_t)chunk * 24 * 2 * sizeof(uint32_t)));   // jump log of the fast kernel
         HIP_TRY(c, c->d_band.reserve((size_t)chunk * 2 * band_stride * sizeof(uint16_t)));
         HIP_TRY(c, c->d_hard.reserve((size_t)chunk * sizeof(uint32_t)));
-        HIP_TRY(c, c->d_over.reserve((size_t)chunk * sizeof(uint32_t)));
-        HIP_TRY(c, c->d_cnt.reserve(8 * sizeof(uint32_t)));
+        HIP_TRY(c, c->d_over.reserve((size_t)n_tasks * sizeof(uint32_t)));
+        HIP_TRY(c, c->d_cnt.reserve(16 * sizeof(uint32_t)));
+        uint32_t* d_cnt = c->d_cnt.as<uint32_t>();        // [0] hard, [1] overflow (fast), [2..7] reasons; [8],[9] general kernel
         int shape = 0;
         while ((uint32_t)(kShapes[shape][0] * kShapes[shape][1]) < c->max_read_len) ++shape;
+        auto masked_dp = [&](uint32_t n_hard) -> int {
+            HIP_TRY(c, vtxk_launch_band_expand(c->d_hard.as<uint32_t>(), n_hard, c->d_records.as<vtx_record>(),
+                                               c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_band.as<uint16_t>(),
+                                               band_stride, s));
+            HIP_TRY(c, vtxk_launch_sw_banded(kShapes[shape][0], kShapes[shape][1], n_hard, c->d_hard.as<uint32_t>(),
+                                             c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
+                                             c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_band.as<uint16_t>(), band_stride,
+                                             c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len, s));
+            return VTX_OK;
+        };
+        HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 16 * sizeof(uint32_t), s));
+        uint32_t cnt[2] = {0, 0};
         for (uint64_t base = 0; base < n_tasks; base += chunk) {
             const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, n_tasks - base);
-            HIP_TRY(c, hipMemsetAsync(c->d_cnt.p, 0, 8 * sizeof(uint32_t), s));
-            // fast streaming band kernel for every task of the chunk; what it cannot hold goes to the general one
+            HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), s));                 // hard count of this chunk
             HIP_TRY(c, vtxk_launch_band_fast(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                              c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                              c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
                                              c->d_band_ws.as<uint32_t>(), c->d_band.as<uint16_t>(), band_stride,
-                                             c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_cnt.as<uint32_t>(), s));
-            uint32_t cnt[2] = {0, 0};
-            HIP_TRY(c, hipMemcpyAsync(cnt, c->d_cnt.p, sizeof cnt, hipMemcpyDeviceToHost, s));
+                                             c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), d_cnt, s));
+            HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
-            fast_overflow += cnt[1];
-            if (getenv("VTX_DEBUG")) {
-                uint32_t why[8];
-                HIP_TRY(c, hipMemcpy(why, c->d_cnt.p, sizeof why, hipMemcpyDeviceToHost));
-                fprintf(stderr, "[vtx] chunk: overflow reasons inside-run=%u runs-full=%u log-full=%u fifo-full=%u traceback=%u\n", why[3], why[4], why[5], why[6], why[7]);
-            }
-            // general kernel (per-task scratch slab) on the overflow list; slabs grow until every task fits
-            uint32_t cap2 = m_cap / 16;
-            // tasks whose k-mer matches did not fit the slab: rerun them alone with a larger one
-            while (cnt[1] > 0) {
-                const uint64_t worst = (uint64_t)c->max_read_len * c->max_hap_len;
-                if (cap2 >= worst) return fail(c, VTX_E_STATE, "vtx_run: band kernel overflow with a worst-case slab");
-                cap2 = (uint32_t)std::min<uint64_t>((uint64_t)cap2 * 16, worst);
-                const uint32_t n_over = cnt[1];
-                const size_t stride2 = vtxk_band_ws_stride(cap2, c->max_hap_len);
-                HIP_TRY(c, c->d_band_ws2.reserve((size_t)n_over * stride2));
-                HIP_TRY(c, c->d_over2.reserve((size_t)n_over * sizeof(uint32_t)));
-                HIP_TRY(c, hipMemcpyAsync(c->d_over2.p, c->d_over.p, (size_t)n_over * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-                HIP_TRY(c, hipMemsetAsync(c->d_cnt.as<uint32_t>() + 1, 0, sizeof(uint32_t), s));
-                HIP_TRY(c, vtxk_launch_band(c->d_over2.as<uint32_t>(), n_over, 0, c->d_records.as<vtx_record>(),
-                                            c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
-                                            c->d_hap.as<uint8_t>(), c->d_band_ws2.as<uint8_t>(), stride2, cap2, c->max_hap_len,
-                                            c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_band.as<uint16_t>(), band_stride,
-                                            c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_cnt.as<uint32_t>(), s));
-                HIP_TRY(c, hipMemcpyAsync(cnt, c->d_cnt.p, sizeof cnt, hipMemcpyDeviceToHost, s));
-                HIP_TRY(c, hipStreamSynchronize(s));
-                ++launches;
-            }
-            HIP_TRY(c, vtxk_launch_band_expand(c->d_hard.as<uint32_t>(), cnt[0], c->d_records.as<vtx_record>(),
-                                               c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_band.as<uint16_t>(),
-                                               band_stride, s));
-            HIP_TRY(c, vtxk_launch_sw_banded(kShapes[shape][0], kShapes[shape][1], cnt[0], c->d_hard.as<uint32_t>(),
-                                             c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
-                                             c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_band.as<uint16_t>(), band_stride,
-                                             c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len, s));
+            if (int rc = masked_dp(cnt[0])) return rc;
             hard_total += cnt[0];
             launches += 3;
+        }
+        fast_overflow = cnt[1];
+        if (getenv("VTX_DEBUG")) {
+            uint32_t why[8];
+            HIP_TRY(c, hipMemcpy(why, d_cnt, sizeof why, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[vtx] fast band kernel overflow reasons: bound=%u parked-full=%u log-full=%u other=%u traceback=%u\n", why[3], why[4], why[5], why[6], why[7]);
+        }
+        // general kernel (per-task scratch slab) on the accumulated overflow list; slabs grow until every task fits
+        for (uint32_t obase = 0; obase < fast_overflow; obase += chunk) {
+            const uint32_t n_over = std::min(chunk, fast_overflow - obase);
+            uint32_t cap2 = 512 / 16, todo = n_over;
+            const uint32_t* tasks = c->d_over.as<uint32_t>() + obase;
+            HIP_TRY(c, hipMemsetAsync(d_cnt + 8, 0, 2 * sizeof(uint32_t), s));
+            uint32_t gcnt[2] = {0, 0};
+            while (todo > 0) {
+                const uint64_t worst = (uint64_t)c->max_read_len * c->max_hap_len;
+                if (cap2 >= worst && cap2 >= 512) return fail(c, VTX_E_STATE, "vtx_run: band kernel overflow with a worst-case slab");
+                cap2 = (uint32_t)std::max<uint64_t>(std::min<uint64_t>((uint64_t)cap2 * 16, worst), 512);
+                const size_t stride2 = vtxk_band_ws_stride(cap2, c->max_hap_len);
+                HIP_TRY(c, c->d_band_ws2.reserve((size_t)todo * stride2));
+                HIP_TRY(c, c->d_over2.reserve(2 * (size_t)n_over * sizeof(uint32_t)));
+                HIP_TRY(c, hipMemsetAsync(d_cnt + 9, 0, sizeof(uint32_t), s));
+                HIP_TRY(c, vtxk_launch_band(tasks, todo, 0, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                            c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                            c->d_band_ws2.as<uint8_t>(), stride2, cap2, c->max_hap_len, c->d_ref.as<int32_t>(),
+                                            c->d_alt.as<int32_t>(), c->d_band.as<uint16_t>(), band_stride, c->d_hard.as<uint32_t>(),
+                                            c->d_over2.as<uint32_t>() + ((tasks == c->d_over2.as<uint32_t>()) ? n_over : 0), d_cnt + 8, s));
+                HIP_TRY(c, hipMemcpyAsync(gcnt, d_cnt + 8, sizeof gcnt, hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipStreamSynchronize(s));
+                // tasks that still do not fit were written to the other half of d_over2: rerun them with a larger slab
+                tasks = c->d_over2.as<uint32_t>() + ((tasks == c->d_over2.as<uint32_t>()) ? n_over : 0);
+                todo = gcnt[1];
+                ++launches;
+            }
+            if (int rc = masked_dp(gcnt[0])) return rc;
+            hard_total += gcnt[0];
+            launches += 2;
         }
         c->fast_overflow = fast_overflow;
         if (getenv("VTX_DEBUG")) fprintf(stderr, "[vtx] banded: %llu tasks, %u overflowed the fast band kernel, %u hard\n", (unsigned long long)n_tasks, fast_overflow, hard_total);
