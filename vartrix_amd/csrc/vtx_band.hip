@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "vtx_device.h"
 
@@ -304,7 +305,7 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
 // Hard tasks get a polyline (vertex list) in their band slot, flagged 0xffff; band_expand_kernel
 // turns it into the lo / hi arrays sw_banded_kernel reads.
 // =============================================================================================
-#define PS 12       // parked segments per lane (LDS); two more live in registers
+#define PS 20       // per-lane LDS entries: parked segments (band_fast_kernel) / pieces + segments (band_run_kernel)
 #define LG 24       // jump-log entries per task (global)
 #define SG 10       // chain segments per task
 #define TB_HEADS 2048
@@ -327,6 +328,72 @@ __device__ __forceinline__ uint32_t kw_hash(uint32_t lo, uint32_t hi) {
 extern "C" size_t vtxk_band_table_stride(uint32_t max_hap) {
     size_t o = (size_t)max_hap * 4 + (size_t)max_hap * 2 * 2 + TB_HEADS * 2 + ((size_t)max_hap + 8);
     return (o + 15) & ~(size_t)15;
+}
+
+// Shared tail of the streaming band kernels: traceback through the jump log (chain = a few diagonal
+// segments), walk of the anchor staircase (certificate), polyline for hard tasks.
+// Returns 0: certified (banded == full); 1: hard (verts / *nv_out filled); 2: capacity exceeded.
+__device__ int band_finish(const uint32_t* mylog, uint32_t lg_n, uint32_t best_id, const uint8_t* x,
+                           const uint8_t* yb, uint32_t m, uint32_t n, int32_t full, uint32_t* verts_out,
+                           uint32_t* nv_out) {
+        // ---- traceback through the jump log: chain = diagonal segments (x0, y0, len), last first ----
+        uint32_t seg_xy[SG], seg_len[SG];
+        uint32_t n_seg = 0;
+        uint32_t cur = best_id;
+        bool bad = false;
+        while (true) {
+            const int32_t cx = (int32_t)(cur >> 16), cy = (int32_t)(cur & 0xffff);
+            int32_t bx = -1; uint32_t bprev = NONE_ID, bid = 0;
+            for (uint32_t i = 0; i < lg_n; ++i) {
+                const uint32_t p = mylog[2 * i];
+                const int32_t px = (int32_t)(p >> 16), py = (int32_t)(p & 0xffff);
+                if (py - px == cy - cx && px <= cx && px > bx) { bx = px; bprev = mylog[2 * i + 1]; bid = p; }
+            }
+            if (bx < 0 || n_seg == SG) { bad = true; break; }
+            seg_xy[n_seg] = bid; seg_len[n_seg] = (uint32_t)(cx - bx + 1); ++n_seg;
+            if (bprev == NONE_ID) break;
+            cur = bprev;
+        }
+        if (bad) return 2;
+        // ---- staircase walk: certificate, and the polyline if the task turns out hard ----
+        // One vertex after every non-empty piece (pure diagonal / vertical / horizontal).
+        uint32_t* verts = verts_out;
+        uint32_t nv = 0;
+        const uint32_t fst = seg_xy[n_seg - 1];
+        const int fx = (int)(fst >> 16), fy = (int)(fst & 0xffff);
+        int d0 = fx < fy ? fx : fy; if (d0 > 2 * KMER) d0 = 2 * KMER;
+        int r = fx - d0, c = fy - d0;
+        walk_state w = {0, -100000, 0, 0};
+#define EMIT() verts[nv++] = ((uint32_t)r << 16) | (uint32_t)c
+        EMIT();
+        for (int i = 0; i < d0; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
+        if (d0 > 0) EMIT();
+        for (uint32_t sgi = n_seg; sgi-- > 0;) {
+            const int px = (int)(seg_xy[sgi] >> 16), py = (int)(seg_xy[sgi] & 0xffff);
+            int dr = px - r, dc = py - c;
+            const int dg = dr < dc ? dr : dc;
+            for (int i = 0; i < dg; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
+            if (dg > 0) EMIT();
+            dr = px - r; dc = py - c;
+            for (int i = 0; i < dr; ++i) { ++r; walk_gap(w, 1); }
+            if (dr > 0) EMIT();
+            for (int i = 0; i < dc; ++i) { ++c; walk_gap(w, 2); }
+            if (dc > 0) EMIT();
+            // the segment's k-mer cells: len + K - 1 diagonal steps, every one an exact match
+            const int run = (int)seg_len[sgi] + KMER - 1;
+            const int32_t v = (w.s > w.gap ? w.s : w.gap) + 1;      // s >= 0, so v >= 1
+            w.s = v + (run - 1); w.gap = -100000; w.dir = 0;
+            if (w.s > w.best) w.best = w.s;
+            r += run; c += run;
+            EMIT();
+        }
+        int d1 = ((int)m - r) < ((int)n - c) ? ((int)m - r) : ((int)n - c); if (d1 > 2 * KMER) d1 = 2 * KMER;
+        for (int i = 0; i < d1; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
+        if (d1 > 0) EMIT();
+#undef EMIT
+        if (w.best == full) return 0;                        // banded == full
+        *nv_out = nv;
+        return 1;
 }
 
 __global__ __launch_bounds__(256) void band_fast_kernel(
@@ -577,62 +644,13 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
         if (overflow) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[2 + why], 1u); continue; }
         if (best_v < 0) continue;                            // no match at all: full matrix
         if (ablate == 3) { if (best_id == 0xfffffffeu) counters[7] = best_v; continue; }   // (profiling aid) no traceback / walk
-        // ---- traceback through the jump log: chain = diagonal segments (x0, y0, len), last first ----
-        uint32_t seg_xy[SG], seg_len[SG];
-        uint32_t n_seg = 0;
-        uint32_t cur = best_id;
-        bool bad = false;
-        while (true) {
-            const int32_t cx = (int32_t)(cur >> 16), cy = (int32_t)(cur & 0xffff);
-            int32_t bx = -1; uint32_t bprev = NONE_ID, bid = 0;
-            for (uint32_t i = 0; i < lg_n; ++i) {
-                const uint32_t p = mylog[2 * i];
-                const int32_t px = (int32_t)(p >> 16), py = (int32_t)(p & 0xffff);
-                if (py - px == cy - cx && px <= cx && px > bx) { bx = px; bprev = mylog[2 * i + 1]; bid = p; }
-            }
-            if (bx < 0 || n_seg == SG) { bad = true; break; }
-            seg_xy[n_seg] = bid; seg_len[n_seg] = (uint32_t)(cx - bx + 1); ++n_seg;
-            if (bprev == NONE_ID) break;
-            cur = bprev;
-        }
-        if (bad) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[7], 1u); continue; }
-        // ---- staircase walk: certificate, and the polyline if the task turns out hard ----
-        // One vertex after every non-empty piece (pure diagonal / vertical / horizontal).
         uint32_t verts[4 * SG + 6];
         uint32_t nv = 0;
-        const uint32_t fst = seg_xy[n_seg - 1];
-        const int fx = (int)(fst >> 16), fy = (int)(fst & 0xffff);
-        int d0 = fx < fy ? fx : fy; if (d0 > 2 * KMER) d0 = 2 * KMER;
-        int r = fx - d0, c = fy - d0;
-        walk_state w = {0, -100000, 0, 0};
-#define EMIT() verts[nv++] = ((uint32_t)r << 16) | (uint32_t)c
-        EMIT();
-        for (int i = 0; i < d0; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
-        if (d0 > 0) EMIT();
-        for (uint32_t sgi = n_seg; sgi-- > 0;) {
-            const int px = (int)(seg_xy[sgi] >> 16), py = (int)(seg_xy[sgi] & 0xffff);
-            int dr = px - r, dc = py - c;
-            const int dg = dr < dc ? dr : dc;
-            for (int i = 0; i < dg; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
-            if (dg > 0) EMIT();
-            dr = px - r; dc = py - c;
-            for (int i = 0; i < dr; ++i) { ++r; walk_gap(w, 1); }
-            if (dr > 0) EMIT();
-            for (int i = 0; i < dc; ++i) { ++c; walk_gap(w, 2); }
-            if (dc > 0) EMIT();
-            // the segment's k-mer cells: len + K - 1 diagonal steps, every one an exact match
-            const int run = (int)seg_len[sgi] + KMER - 1;
-            const int32_t v = (w.s > w.gap ? w.s : w.gap) + 1;      // s >= 0, so v >= 1
-            w.s = v + (run - 1); w.gap = -100000; w.dir = 0;
-            if (w.s > w.best) w.best = w.s;
-            r += run; c += run;
-            EMIT();
+        {
+            const int fr = band_finish(mylog, lg_n, best_id, x, yb, m, n, full, verts, &nv);
+            if (fr == 0) continue;
+            if (fr == 2) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[7], 1u); continue; }
         }
-        int d1 = ((int)m - r) < ((int)n - c) ? ((int)m - r) : ((int)n - c); if (d1 > 2 * KMER) d1 = 2 * KMER;
-        for (int i = 0; i < d1; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
-        if (d1 > 0) EMIT();
-#undef EMIT
-        if (w.best == full) continue;                        // banded == full
         const uint32_t h = atomicAdd(&counters[0], 1u);
         hard_list[h] = task;
         uint16_t* lo = band + (size_t)h * 2 * band_stride;
@@ -643,6 +661,306 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
 #undef PM_A
 #undef PM_ID
 }
+
+__global__ __launch_bounds__(256) void band_run_kernel(
+    uint32_t n_tasks, uint32_t task_base,
+    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
+    const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
+    uint32_t max_hap, uint32_t tables_per_pass, uint32_t table_stride,
+    const int32_t* __restrict__ ref_score, const int32_t* __restrict__ alt_score,
+    uint32_t* __restrict__ logbuf, uint16_t* __restrict__ band, uint32_t band_stride,
+    uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters,
+    uint32_t ablate) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x;
+    // per-lane LDS arrays, element i of lane tid at [i * 256 + tid]
+    // staircase of ended matches, stored as RUNS: elements (ye0 + t, V0 + 3t, id0 + t*(1,1)), t < len
+    // (a continued k-mer adds +1 to ye and, with dp + 1, +3 to V = dp + xe + ye)
+    uint32_t* pm_a = smem;                     // parked segments: id0 = x0 << 16 | y0
+    uint32_t* pm_id = pm_a + PS * 256;         //                  dp0 << 16 | len
+    uint8_t* tables = (uint8_t*)(pm_id + PS * 256);
+#define PM_A(i) pm_a[(i) * 256 + tid]
+#define PM_ID(i) pm_id[(i) * 256 + tid]
+
+    const uint32_t slot = blockIdx.x * 256 + tid;
+    const bool have = slot < n_tasks;
+    const uint32_t task = task_base + slot;
+    uint32_t rid = 0, hap = 0, my_locus = 0, m = 0, n = 0;
+    const uint8_t* x = nullptr;
+    if (have) {
+        rid = task >> 1; hap = task & 1;
+        const vtx_record rec = records[rid];
+        my_locus = rec_locus[rid];
+        m = rec.read_len;
+        x = read_arena + rec.read_off;
+        n = hap ? loci[my_locus].alt_len : loci[my_locus].ref_len;
+    }
+    // locus range of this workgroup (tasks are in record order, records in locus order)
+    const uint32_t first_task = task_base + blockIdx.x * 256;
+    const uint32_t last_task = min(task_base + n_tasks - 1, first_task + 255);
+    const uint32_t l_first = rec_locus[first_task >> 1], l_last = rec_locus[last_task >> 1];
+    const uint32_t loci_per_pass = tables_per_pass / 2;
+    bool done = !have || m == 0 || n == 0;     // empty read / haplotype: score 0 == full
+    uint32_t* mylog = logbuf + (size_t)slot * LG * 2;
+
+    for (uint32_t lbase = l_first; lbase <= l_last; lbase += loci_per_pass) {
+        __syncthreads();
+        // ---- build the haplotype tables of loci [lbase, lbase + loci_per_pass) ----
+        const uint32_t n_tab = min(loci_per_pass, l_last - lbase + 1) * 2;
+        for (uint32_t t = 0; t < n_tab; ++t) {
+            const vtx_locus loc = loci[lbase + (t >> 1)];
+            const uint32_t hn = (t & 1) ? loc.alt_len : loc.ref_len;
+            const uint8_t* hy = hap_arena + ((t & 1) ? loc.alt_off : loc.ref_off);
+            uint8_t* tb = tables + (size_t)t * table_stride;
+            uint32_t* kwlo = (uint32_t*)tb;
+            uint16_t* kwhi = (uint16_t*)(tb + (size_t)max_hap * 4);
+            uint16_t* head = kwhi + 2 * (size_t)max_hap;
+            uint8_t* bytes = (uint8_t*)(head + TB_HEADS);
+            for (uint32_t y = tid; y < hn; y += 256) {
+                bytes[y] = hy[y];
+                if (y + KMER <= hn) {
+                    kwlo[y] = (uint32_t)hy[y] | ((uint32_t)hy[y + 1] << 8) | ((uint32_t)hy[y + 2] << 16) | ((uint32_t)hy[y + 3] << 24);
+                    kwhi[y] = (uint16_t)((uint32_t)hy[y + 4] | ((uint32_t)hy[y + 5] << 8));
+                }
+            }
+            for (uint32_t i = tid; i < TB_HEADS; i += 256) head[i] = 0xffff;
+        }
+        __syncthreads();
+        if ((uint32_t)tid < n_tab) {     // one lane per table: sequential head insertion, descending y => ascending chains
+            const vtx_locus loc = loci[lbase + ((uint32_t)tid >> 1)];
+            const uint32_t hn = (tid & 1) ? loc.alt_len : loc.ref_len;
+            uint8_t* tb = tables + (size_t)tid * table_stride;
+            const uint32_t* kwlo = (const uint32_t*)tb;
+            uint16_t* kwhi = (uint16_t*)(tb + (size_t)max_hap * 4);
+            uint16_t* next = kwhi + max_hap;
+            uint16_t* head = kwhi + 2 * (size_t)max_hap;
+            if (hn >= KMER)
+                for (int y = (int)hn - KMER; y >= 0; --y) {
+                    const uint32_t h = kw_hash(kwlo[y], kwhi[y]);
+                    next[y] = head[h]; head[h] = (uint16_t)y;
+                }
+        }
+        __syncthreads();
+        if (done || my_locus < lbase || my_locus >= lbase + loci_per_pass) continue;
+        done = true;
+        // ---- this lane's table ----
+        const uint8_t* tb = tables + (size_t)((my_locus - lbase) * 2 + hap) * table_stride;
+        const uint32_t* kwlo = (const uint32_t*)tb;
+        const uint16_t* kwhi = (const uint16_t*)(tb + (size_t)max_hap * 4);
+        const uint16_t* next = kwhi + max_hap;
+        const uint16_t* head = kwhi + 2 * (size_t)max_hap;
+        const uint8_t* yb = (const uint8_t*)(head + TB_HEADS);
+        const int32_t full = hap ? alt_score[rid] : ref_score[rid];
+        if (m < KMER || n < KMER) continue;                 // no k-mer: Band::full_matrix, banded == full
+        if (ablate == 1) continue;                           // (profiling aid) table build only
+        if (ablate == 2) {                                   // (profiling aid) probe loop only
+            uint32_t wl = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
+            uint32_t wh = (uint32_t)x[4] | ((uint32_t)x[5] << 8), cntm = 0;
+            for (uint32_t xr = 0; xr + KMER <= m; ++xr) {
+                for (uint32_t y = head[kw_hash(wl, wh)]; y != 0xffff; y = next[y]) cntm += (kwlo[y] == wl && kwhi[y] == (uint16_t)wh);
+                const uint32_t nb = (xr + KMER < m) ? x[xr + KMER] : 0;
+                wl = (wl >> 8) | (wh << 24); wh = ((wh >> 8) & 0xff) | (nb << 8);
+            }
+            if (cntm == 0xffffffffu) counters[7] = cntm;
+            continue;
+        }
+
+        // ================= phase 1: geometric diagonal pieces =================
+        // Every k-mer match either extends one of the two pieces held in registers or opens a new piece
+        // (appended to the LDS list).  A piece that really continues a parked piece is simply a new,
+        // adjacent piece: phase 2 treats adjacency as the LCSk++ continuation.  No queries here.
+#define E_ID(i) pm_a[(i) * 256 + tid]
+#define E_DL(i) pm_id[(i) * 256 + tid]
+        uint32_t n_ent = 0;
+        uint32_t a_idx = NONE_ID, a_id0 = 0, a_len = 0, b_idx = NONE_ID, b_id0 = 0, b_len = 0;
+        bool overflow = false;
+        uint32_t why = 0;
+        {
+            uint32_t wlo = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
+            uint32_t whi = (uint32_t)x[4] | ((uint32_t)x[5] << 8);
+            uint32_t nextb = m > KMER ? x[KMER] : 0;
+            for (uint32_t xr = 0; xr + KMER <= m && !overflow; ++xr) {
+                const uint32_t nextb2 = (xr + KMER + 1 < m) ? x[xr + KMER + 1] : 0;
+                for (uint32_t y = head[kw_hash(wlo, whi)]; y != 0xffff; y = next[y]) {
+                    if (kwlo[y] != wlo || kwhi[y] != (uint16_t)whi) continue;
+                    const uint32_t id = (xr << 16) | y;
+                    if (a_idx != NONE_ID && id == a_id0 + a_len * 0x10001u) { ++a_len; continue; }
+                    if (b_idx != NONE_ID && id == b_id0 + b_len * 0x10001u) {
+                        ++b_len;
+                        uint32_t t;
+                        t = a_idx; a_idx = b_idx; b_idx = t;
+                        t = a_id0; a_id0 = b_id0; b_id0 = t;
+                        t = a_len; a_len = b_len; b_len = t;
+                        continue;
+                    }
+                    if (n_ent == PS) { overflow = true; why = 2; break; }
+                    if (b_idx != NONE_ID) E_DL(b_idx) = b_len;
+                    b_idx = a_idx; b_id0 = a_id0; b_len = a_len;
+                    a_idx = n_ent; a_id0 = id; a_len = 1;
+                    E_ID(n_ent) = id; ++n_ent;
+                }
+                wlo = (wlo >> 8) | (whi << 24);
+                whi = ((whi >> 8) & 0xff) | (nextb << 8);
+                nextb = nextb2;
+            }
+            if (a_idx != NONE_ID) E_DL(a_idx) = a_len;
+            if (b_idx != NONE_ID) E_DL(b_idx) = b_len;
+        }
+        uint32_t lg_n = 0;
+        uint32_t best_id = 0;
+        if (!overflow && n_ent == 0) continue;                // no k-mer match: full matrix, banded == full
+        if (ablate == 3) { if (n_ent == 0xffffu) counters[7] = n_ent; continue; }   // (profiling aid) phase 1 only
+        // ================= phase 2: sdpkpp over the pieces =================
+        // E_DL = dp0 << 16 | len (dp0 == 0: piece not started yet).  A started entry is a SEGMENT: linear
+        // piece with dp = dp0 + u.  Pieces start in list order (= match order); a breakpoint inside a
+        // segment can only happen at the ENTRY row of another segment (after its entry a linear segment's
+        // candidate minus the row index never grows, while the run's own value never shrinks), so every
+        // ordered pair (segment -> segment) yields at most one candidate match, queued as an event and
+        // re-examined with a full query when the sweep reaches it.
+        if (!overflow) {
+            const uint32_t n1 = n_ent;
+            uint32_t ev0 = NONE_ID, ev1 = NONE_ID;
+#define SEGQ(id0, dp0, len, qx, qy, bV, bid)                                                                \
+            {                                                                                               \
+                const int32_t sx = (int32_t)((id0) >> 16), sy = (int32_t)((id0) & 0xffff);                   \
+                int32_t u = (int32_t)(len) - 1;                                                             \
+                u = min(u, (int32_t)(qx) - sx - KMER);                                                      \
+                u = min(u, (int32_t)(qy) - sy - KMER);                                                      \
+                if (u >= 0) {                                                                               \
+                    const int32_t v = (int32_t)(dp0) + sx + sy + 2 * KMER + 3 * u;                           \
+                    const uint32_t qid = (id0) + (uint32_t)u * 0x10001u;                                    \
+                    if (v > bV || (v == bV && (bid == NONE_ID || qid > bid))) { bV = v; bid = qid; }         \
+                }                                                                                           \
+            }
+            // event of segment s entering segment e: first row of e at which an element of s is visible
+#define GEN_EVENT(s_id, s_dp, s_len, e_id, e_dp, e_len)                                                     \
+            {                                                                                               \
+                const int32_t ga = (int32_t)((e_id) >> 16) - (int32_t)((s_id) >> 16) - KMER;                 \
+                const int32_t gb = (int32_t)((e_id) & 0xffff) - (int32_t)((s_id) & 0xffff) - KMER;           \
+                const int32_t ts = max(max(-ga, -gb), 0);                                                   \
+                if (ts >= 1 && ts < (int32_t)(e_len)) {                                                     \
+                    const int32_t gu = min(min(ga + ts, gb + ts), (int32_t)(s_len) - 1);                     \
+                    const int32_t gc = (int32_t)(s_dp) + gu + 1 - ((ga + ts - gu) + (gb + ts - gu));         \
+                    if (gc > (int32_t)(e_dp) + ts) {                                                        \
+                        const uint32_t mid = (e_id) + (uint32_t)ts * 0x10001u;                              \
+                        if (mid != ev0 && mid != ev1) {                                                     \
+                            if (ev0 == NONE_ID) ev0 = mid; else if (ev1 == NONE_ID) ev1 = mid;               \
+                            else { overflow = true; why = 4; }                                              \
+                        }                                                                                   \
+                    }                                                                                       \
+                }                                                                                           \
+            }
+            for (uint32_t i = 0; i <= n1 && !overflow; ++i) {
+                const uint32_t start_id = i < n1 ? E_ID(i) : NONE_ID;
+                // ---- events (possible breakpoints) due before this start, in match order ----
+                while (!overflow) {
+                    uint32_t mid = ev0 < ev1 ? ev0 : ev1;
+                    if (mid == NONE_ID || mid >= start_id) break;
+                    if (mid == ev0) ev0 = NONE_ID; else ev1 = NONE_ID;
+                    const int32_t mx = (int32_t)(mid >> 16), my = (int32_t)(mid & 0xffff);
+                    int32_t bV = INT32_MIN; uint32_t bid = NONE_ID;
+                    uint32_t e = NONE_ID, e_id = 0, e_dp = 0, e_len = 0;
+                    for (uint32_t j = 0; j < n_ent; ++j) {
+                        const uint32_t dl = E_DL(j);
+                        if ((dl >> 16) == 0) continue;
+                        const uint32_t sid = E_ID(j);
+                        const int32_t sx = (int32_t)(sid >> 16);
+                        if ((int32_t)(sid & 0xffff) - sx == my - mx && sx <= mx && mx < sx + (int32_t)(dl & 0xffff)) {
+                            e = j; e_id = sid; e_dp = dl >> 16; e_len = dl & 0xffff;
+                        }
+                        SEGQ(sid, (dl >> 16), (dl & 0xffff), mx, my, bV, bid)
+                    }
+                    if (e == NONE_ID) continue;
+                    const uint32_t t = (uint32_t)(mx - (int32_t)(e_id >> 16));
+                    if (t == 0 || bid == NONE_ID) continue;
+                    const int32_t cand = bV - 5 - (mx + my) + KMER;
+                    if (cand <= (int32_t)(e_dp + t)) continue;              // continuation wins (ties included)
+                    // breakpoint: split segment e at t
+                    if (n_ent == PS || lg_n == LG) { overflow = true; why = 3; break; }
+                    E_DL(e) = (e_dp << 16) | t;
+                    const uint32_t nd = (uint32_t)cand, nl = e_len - t;
+                    E_ID(n_ent) = mid; E_DL(n_ent) = (nd << 16) | nl;
+                    mylog[2 * lg_n] = mid; mylog[2 * lg_n + 1] = bid; ++lg_n;
+                    const uint32_t ni = n_ent++;
+                    for (uint32_t j = 0; j < n_ent && !overflow; ++j) {
+                        if (j == ni) continue;
+                        const uint32_t dl = E_DL(j);
+                        if ((dl >> 16) == 0) continue;
+                        const uint32_t sid = E_ID(j);
+                        if (nl >= 2) GEN_EVENT(sid, (dl >> 16), (dl & 0xffff), mid, nd, nl)
+                        if ((dl & 0xffff) >= 2) GEN_EVENT(mid, nd, nl, sid, (dl >> 16), (dl & 0xffff))
+                    }
+                }
+                if (i == n1 || overflow) break;
+                // ---- start of piece i ----
+                const int32_t px = (int32_t)(start_id >> 16), py = (int32_t)(start_id & 0xffff);
+                const uint32_t plen = E_DL(i) & 0xffff;
+                int32_t bV = INT32_MIN; uint32_t bid = NONE_ID;
+                int32_t cdp = -1;
+                for (uint32_t j = 0; j < n_ent; ++j) {
+                    const uint32_t dl = E_DL(j);
+                    if ((dl >> 16) == 0) continue;
+                    const uint32_t sid = E_ID(j);
+                    if (sid + (dl & 0xffff) * 0x10001u == start_id) cdp = (int32_t)((dl >> 16) + (dl & 0xffff));
+                    SEGQ(sid, (dl >> 16), (dl & 0xffff), px, py, bV, bid)
+                }
+                int32_t dp = KMER; uint32_t prev = NONE_ID;
+                if (bid != NONE_ID) {
+                    const int32_t cand = bV - 5 - (px + py) + KMER;
+                    if (cand >= dp) { dp = cand; prev = bid; }
+                }
+                if (cdp >= dp) {
+                    dp = cdp;                                            // adjacent piece: LCSk++ continuation, no log entry
+                } else {
+                    if (lg_n == LG) { overflow = true; why = 3; break; }
+                    mylog[2 * lg_n] = start_id; mylog[2 * lg_n + 1] = prev; ++lg_n;
+                }
+                E_DL(i) = ((uint32_t)dp << 16) | plen;
+                if (plen >= 2 || dp + (int32_t)plen - 1 > KMER) {
+                    for (uint32_t j = 0; j < n_ent && !overflow; ++j) {
+                        if (j == i) continue;
+                        const uint32_t dl = E_DL(j);
+                        if ((dl >> 16) == 0) continue;
+                        const uint32_t sid = E_ID(j);
+                        if (plen >= 2) GEN_EVENT(sid, (dl >> 16), (dl & 0xffff), start_id, (uint32_t)dp, plen)
+                        if ((dl & 0xffff) >= 2) GEN_EVENT(start_id, (uint32_t)dp, plen, sid, (dl >> 16), (dl & 0xffff))
+                    }
+                }
+            }
+#undef SEGQ
+#undef GEN_EVENT
+            // best match = end of the segment with the largest (dp, index)
+            if (!overflow) {
+                int32_t best_v = -1;
+                for (uint32_t j = 0; j < n_ent; ++j) {
+                    const uint32_t dl = E_DL(j);
+                    const int32_t v = (int32_t)((dl >> 16) + (dl & 0xffff)) - 1;
+                    const uint32_t eid = E_ID(j) + ((dl & 0xffff) - 1) * 0x10001u;
+                    if (v > best_v || (v == best_v && eid > best_id)) { best_v = v; best_id = eid; }
+                }
+            }
+        }
+#undef E_ID
+#undef E_DL
+        if (overflow) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[2 + why], 1u); continue; }
+        uint32_t verts[4 * SG + 6];
+        uint32_t nv = 0;
+        {
+            const int fr = band_finish(mylog, lg_n, best_id, x, yb, m, n, full, verts, &nv);
+            if (fr == 0) continue;
+            if (fr == 2) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[7], 1u); continue; }
+        }
+        const uint32_t h = atomicAdd(&counters[0], 1u);
+        hard_list[h] = task;
+        uint16_t* lo = band + (size_t)h * 2 * band_stride;
+        lo[0] = 0xffff; lo[1] = (uint16_t)nv;
+        uint32_t* vout = (uint32_t*)(lo + 2);
+        for (uint32_t i = 0; i < nv; ++i) vout[i] = verts[i];
+    }
+#undef PM_A
+#undef PM_ID
+}
+
 
 // Polyline -> lo / hi arrays, one 16-lane group per hard slot (slots written by band_kernel already
 // hold arrays and are skipped).  Vertices are joined by pure diagonal / vertical / horizontal pieces.
@@ -705,7 +1023,7 @@ extern "C" hipError_t vtxk_launch_band_fast(uint32_t n_tasks, uint32_t task_base
     if (!n_tasks) return hipSuccess;
     const size_t lane_bytes = (size_t)(2 * PS) * 256 * 4;
     const size_t tstride = vtxk_band_table_stride(max_hap);
-    size_t budget = 40 * 1024;   // lane arrays (24 KiB) + haplotype tables
+    size_t budget = 52 * 1024;   // lane arrays (40 KiB) + haplotype tables
     uint32_t tables = (uint32_t)((budget - std::min(budget, lane_bytes)) / tstride) & ~1u;
     if (tables < 2) tables = 2;
     if (tables > 8) tables = 8;
@@ -715,7 +1033,13 @@ extern "C" hipError_t vtxk_launch_band_fast(uint32_t n_tasks, uint32_t task_base
         hipError_t e = hipFuncSetAttribute((const void*)band_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(band_fast_kernel, dim3((n_tasks + 255) / 256), dim3(256), shmem, s, n_tasks, task_base, records,
+    static const bool use_stream = getenv("VTX_BAND_KERNEL") && !strcmp(getenv("VTX_BAND_KERNEL"), "stream");
+    auto kern = use_stream ? band_fast_kernel : band_run_kernel;
+    if (shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((n_tasks + 255) / 256), dim3(256), shmem, s, n_tasks, task_base, records,
                        rec_locus, loci, read_arena, hap_arena, max_hap, tables, (uint32_t)tstride, ref_score, alt_score,
                        logbuf, band, band_stride, hard_list, overflow_list, counters,
                        (uint32_t)(getenv("VTX_BAND_ABLATE") ? atoi(getenv("VTX_BAND_ABLATE")) : 0));
