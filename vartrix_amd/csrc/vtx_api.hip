@@ -370,7 +370,7 @@ int vtx_run(vtx_ctx* c) {
         const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_tasks, 1u << 20);
         const uint32_t band_stride = (c->max_hap_len + 2 + 7) & ~7u;
         uint32_t fast_overflow = 0;
-        HIP_TRY(c, c->d_band_ws.reserve((size_t)chunk * 24 * 2 * sizeof(uint32_t)));   // jump log of the fast kernel
+        HIP_TRY(c, c->d_band_ws.reserve((size_t)chunk * 64 * 2 * sizeof(uint32_t)));   // jump log of the fast kernel (LG entries per task)
         HIP_TRY(c, c->d_band.reserve((size_t)chunk * 2 * band_stride * sizeof(uint16_t)));
         HIP_TRY(c, c->d_hard.reserve((size_t)chunk * sizeof(uint32_t)));
         HIP_TRY(c, c->d_over.reserve((size_t)n_tasks * sizeof(uint32_t)));

@@ -306,7 +306,7 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
 // turns it into the lo / hi arrays sw_banded_kernel reads.
 // =============================================================================================
 #define PS 20       // per-lane LDS entries: parked segments (band_fast_kernel) / pieces + segments (band_run_kernel)
-#define LG 24       // jump-log entries per task (global)
+#define LG 64       // jump-log entries per task (global)
 #define SG 10       // chain segments per task
 #define TB_HEADS 2048
 #define NONE_ID 0xffffffffu
@@ -662,6 +662,177 @@ __global__ __launch_bounds__(256) void band_fast_kernel(
 #undef PM_ID
 }
 
+// ---- band_run_kernel's chain DP over pieces (see the kernel for the overall scheme) ----------------
+// LDS entry j of lane tid: e_id[j*256+tid] = x0 << 16 | y0, e_dl[j*256+tid] = dp0 << 16 | len
+// (dp0 == 0: piece collected by phase 1 but not started yet).  A started entry is a SEGMENT (linear:
+// dp = dp0 + u).  Pieces start in list order (= match order); a breakpoint inside a segment can only
+// happen at the ENTRY row of another segment (after its entry a linear segment's candidate minus the
+// row index never grows, while the run's own value never shrinks), so every ordered pair
+// (segment -> segment) yields at most one candidate match, queued as an event and re-examined with a
+// full query when the sweep reaches it.
+struct run_state {
+    uint32_t n_ent, i_next, ev0, ev1, lg_n;
+    int32_t best_v; uint32_t best_id;
+    bool overflow; uint32_t why;
+};
+
+__device__ __forceinline__ void run_segq(uint32_t id0, uint32_t dp0, uint32_t len, int32_t qx, int32_t qy, int32_t& bV,
+                                         uint32_t& bid) {
+    const int32_t sx = (int32_t)(id0 >> 16), sy = (int32_t)(id0 & 0xffff);
+    int32_t u = (int32_t)len - 1;
+    u = min(u, qx - sx - KMER);
+    u = min(u, qy - sy - KMER);
+    if (u >= 0) {
+        const int32_t v = (int32_t)dp0 + sx + sy + 2 * KMER + 3 * u;
+        const uint32_t qid = id0 + (uint32_t)u * 0x10001u;
+        if (v > bV || (v == bV && (bid == NONE_ID || qid > bid))) { bV = v; bid = qid; }
+    }
+}
+
+// segment s entering segment e: the first row of e at which an element of s is visible.  e_len is the
+// length to test against (0xffff for a piece that is still growing).
+__device__ __forceinline__ void run_gen_event(run_state& st, uint32_t s_id, uint32_t s_dp, uint32_t s_len, uint32_t e_id,
+                                              uint32_t e_dp, uint32_t e_len) {
+    const int32_t ga = (int32_t)(e_id >> 16) - (int32_t)(s_id >> 16) - KMER;
+    const int32_t gb = (int32_t)(e_id & 0xffff) - (int32_t)(s_id & 0xffff) - KMER;
+    const int32_t ts = max(max(-ga, -gb), 0);
+    if (ts < 1 || ts >= (int32_t)e_len) return;
+    const int32_t gu = min(min(ga + ts, gb + ts), (int32_t)s_len - 1);
+    const int32_t gc = (int32_t)s_dp + gu + 1 - ((ga + ts - gu) + (gb + ts - gu));
+    if (gc <= (int32_t)e_dp + ts) return;
+    const uint32_t mid = e_id + (uint32_t)ts * 0x10001u;
+    if (mid == st.ev0 || mid == st.ev1) return;
+    if (st.ev0 == NONE_ID) st.ev0 = mid;
+    else if (st.ev1 == NONE_ID) st.ev1 = mid;
+    else { st.overflow = true; st.why = 4; }
+}
+
+// events both ways between the (new) segment at index ni and every other started segment
+__device__ void run_pair_events(run_state& st, const uint32_t* e_id, const uint32_t* e_dl, int tid, uint32_t ni,
+                                uint32_t open_a, uint32_t open_b) {
+    const uint32_t nid = e_id[ni * 256 + tid], ndl = e_dl[ni * 256 + tid];
+    const uint32_t nd = ndl >> 16, nl = ndl & 0xffff;
+    const bool n_open = ni == open_a || ni == open_b;
+    if (!(nl >= 2 || n_open || nd + nl - 1 > KMER)) return;     // an isolated k-mer with dp = K: no events either way
+    for (uint32_t j = 0; j < st.n_ent && !st.overflow; ++j) {
+        if (j == ni) continue;
+        const uint32_t dl = e_dl[j * 256 + tid];
+        if ((dl >> 16) == 0) continue;
+        const uint32_t sid = e_id[j * 256 + tid];
+        const bool j_open = j == open_a || j == open_b;
+        if (nl >= 2 || n_open) run_gen_event(st, sid, dl >> 16, dl & 0xffff, nid, nd, n_open ? 0xffffu : nl);
+        if ((dl & 0xffff) >= 2 || j_open) run_gen_event(st, nid, nd, nl, sid, dl >> 16, j_open ? 0xffffu : (dl & 0xffff));
+    }
+}
+
+// Process, in match order, every event and every piece start with id < limit.
+__device__ void run_advance(run_state& st, uint32_t* e_id, uint32_t* e_dl, int tid, uint32_t limit, uint32_t& open_a,
+                            uint32_t& open_b, uint32_t* mylog) {
+    while (!st.overflow) {
+        // next unstarted piece
+        uint32_t i = st.i_next;
+        while (i < st.n_ent && (e_dl[i * 256 + tid] >> 16) != 0) ++i;
+        st.i_next = i;
+        uint32_t start_id = i < st.n_ent ? e_id[i * 256 + tid] : NONE_ID;
+        if (start_id >= limit) start_id = limit;
+        // ---- events (possible breakpoints) due before that, in match order ----
+        while (!st.overflow) {
+            const uint32_t mid = st.ev0 < st.ev1 ? st.ev0 : st.ev1;
+            if (mid == NONE_ID || mid >= start_id) break;
+            if (mid == st.ev0) st.ev0 = NONE_ID; else st.ev1 = NONE_ID;
+            const int32_t mx = (int32_t)(mid >> 16), my = (int32_t)(mid & 0xffff);
+            int32_t bV = INT32_MIN; uint32_t bid = NONE_ID;
+            uint32_t e = NONE_ID, eid = 0, edp = 0, elen = 0;
+            for (uint32_t j = 0; j < st.n_ent; ++j) {
+                const uint32_t dl = e_dl[j * 256 + tid];
+                if ((dl >> 16) == 0) continue;
+                const uint32_t sid = e_id[j * 256 + tid];
+                const int32_t sx = (int32_t)(sid >> 16);
+                if ((int32_t)(sid & 0xffff) - sx == my - mx && sx <= mx && mx < sx + (int32_t)(dl & 0xffff)) {
+                    e = j; eid = sid; edp = dl >> 16; elen = dl & 0xffff;
+                }
+                run_segq(sid, dl >> 16, dl & 0xffff, mx, my, bV, bid);
+            }
+            if (e == NONE_ID) continue;                        // beyond the end of its piece
+            const uint32_t t = (uint32_t)(mx - (int32_t)(eid >> 16));
+            if (t == 0 || bid == NONE_ID) continue;
+            const int32_t cand = bV - 5 - (mx + my) + KMER;
+            if (cand <= (int32_t)(edp + t)) continue;          // continuation wins (ties included)
+            // breakpoint: split segment e at t; the tail becomes a new segment (keeps e's open status if it was open)
+            if (st.n_ent == PS || st.lg_n == LG) { st.overflow = true; st.why = 3; break; }
+            e_dl[e * 256 + tid] = (edp << 16) | t;
+            e_id[st.n_ent * 256 + tid] = mid;
+            e_dl[st.n_ent * 256 + tid] = ((uint32_t)cand << 16) | (elen - t);
+            mylog[2 * st.lg_n] = mid; mylog[2 * st.lg_n + 1] = bid; ++st.lg_n;
+            const uint32_t ni = st.n_ent++;
+            if (open_a == e) open_a = ni;                     // the growing end of an open piece is its tail
+            if (open_b == e) open_b = ni;
+            run_pair_events(st, e_id, e_dl, tid, ni, open_a, open_b);
+        }
+        if (st.overflow || start_id >= limit || i >= st.n_ent) break;
+        // ---- start of piece i ----
+        const int32_t px = (int32_t)(start_id >> 16), py = (int32_t)(start_id & 0xffff);
+        const uint32_t plen = e_dl[i * 256 + tid] & 0xffff;
+        int32_t bV = INT32_MIN; uint32_t bid = NONE_ID;
+        int32_t cdp = -1;
+        for (uint32_t j = 0; j < st.n_ent; ++j) {
+            const uint32_t dl = e_dl[j * 256 + tid];
+            if ((dl >> 16) == 0) continue;
+            const uint32_t sid = e_id[j * 256 + tid];
+            if (sid + (dl & 0xffff) * 0x10001u == start_id) cdp = (int32_t)((dl >> 16) + (dl & 0xffff));
+            run_segq(sid, dl >> 16, dl & 0xffff, px, py, bV, bid);
+        }
+        int32_t dp = KMER; uint32_t prev = NONE_ID;
+        if (bid != NONE_ID) {
+            const int32_t cand = bV - 5 - (px + py) + KMER;
+            if (cand >= dp) { dp = cand; prev = bid; }
+        }
+        if (cdp >= dp) {
+            dp = cdp;                                          // adjacent piece: LCSk++ continuation, no log entry
+        } else {
+            if (st.lg_n == LG) { st.overflow = true; st.why = 3; break; }
+            mylog[2 * st.lg_n] = start_id; mylog[2 * st.lg_n + 1] = prev; ++st.lg_n;
+        }
+        e_dl[i * 256 + tid] = ((uint32_t)dp << 16) | plen;
+        st.i_next = i + 1;
+        run_pair_events(st, e_id, e_dl, tid, i, open_a, open_b);
+    }
+}
+
+// Drop started, closed segments none of whose elements can win a query any more (2*(len-1) < x - x0 - dp0 - 1);
+// their ends are folded into the running best first.  Updates the indices of the two open pieces.
+__device__ void run_compact(run_state& st, uint32_t* e_id, uint32_t* e_dl, int tid, uint32_t xr, uint32_t& a_idx,
+                            uint32_t& b_idx) {
+    uint32_t w = 0, na = NONE_ID, nb = NONE_ID, ni = NONE_ID;
+    for (uint32_t j = 0; j < st.n_ent; ++j) {
+        const uint32_t sid = e_id[j * 256 + tid], dl = e_dl[j * 256 + tid];
+        const int32_t dp0 = (int32_t)(dl >> 16), len = (int32_t)(dl & 0xffff);
+        const bool open = j == a_idx || j == b_idx;
+        // an event still queued for one of its matches keeps a segment
+        bool has_ev = false;
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t mid = k ? st.ev1 : st.ev0;
+            if (mid == NONE_ID) continue;
+            const int32_t mx = (int32_t)(mid >> 16), sx = (int32_t)(sid >> 16);
+            if ((int32_t)(mid & 0xffff) - mx == (int32_t)(sid & 0xffff) - sx && mx >= sx) has_ev = true;
+        }
+        if (dp0 != 0 && !open && !has_ev && 2 * (len - 1) < (int32_t)xr - (int32_t)(sid >> 16) - dp0 - 1) {
+            const int32_t v = dp0 + len - 1;
+            const uint32_t eid = sid + (uint32_t)(len - 1) * 0x10001u;
+            if (v > st.best_v || (v == st.best_v && eid > st.best_id)) { st.best_v = v; st.best_id = eid; }
+            continue;
+        }
+        if (j == a_idx) na = w;
+        if (j == b_idx) nb = w;
+        if (ni == NONE_ID && dp0 == 0) ni = w;
+        if (w != j) { e_id[w * 256 + tid] = sid; e_dl[w * 256 + tid] = dl; }
+        ++w;
+    }
+    st.n_ent = w;
+    st.i_next = ni == NONE_ID ? w : ni;
+    a_idx = na; b_idx = nb;
+}
+
 __global__ __launch_bounds__(256) void band_run_kernel(
     uint32_t n_tasks, uint32_t task_base,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
@@ -765,183 +936,97 @@ __global__ __launch_bounds__(256) void band_run_kernel(
             continue;
         }
 
-        // ================= phase 1: geometric diagonal pieces =================
+        // ================= phase 1: geometric diagonal pieces (+ incremental phase 2 when the list fills) ======
         // Every k-mer match either extends one of the two pieces held in registers or opens a new piece
         // (appended to the LDS list).  A piece that really continues a parked piece is simply a new,
         // adjacent piece: phase 2 treats adjacency as the LCSk++ continuation.  No queries here.
-#define E_ID(i) pm_a[(i) * 256 + tid]
-#define E_DL(i) pm_id[(i) * 256 + tid]
-        uint32_t n_ent = 0;
+        run_state st;
+        st.n_ent = 0; st.i_next = 0; st.ev0 = NONE_ID; st.ev1 = NONE_ID; st.lg_n = 0;
+        st.best_v = -1; st.best_id = 0; st.overflow = false; st.why = 0;
         uint32_t a_idx = NONE_ID, a_id0 = 0, a_len = 0, b_idx = NONE_ID, b_id0 = 0, b_len = 0;
-        bool overflow = false;
-        uint32_t why = 0;
         {
             uint32_t wlo = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
             uint32_t whi = (uint32_t)x[4] | ((uint32_t)x[5] << 8);
             uint32_t nextb = m > KMER ? x[KMER] : 0;
-            for (uint32_t xr = 0; xr + KMER <= m && !overflow; ++xr) {
-                const uint32_t nextb2 = (xr + KMER + 1 < m) ? x[xr + KMER + 1] : 0;
-                for (uint32_t y = head[kw_hash(wlo, whi)]; y != 0xffff; y = next[y]) {
-                    if (kwlo[y] != wlo || kwhi[y] != (uint16_t)whi) continue;
-                    const uint32_t id = (xr << 16) | y;
-                    if (a_idx != NONE_ID && id == a_id0 + a_len * 0x10001u) { ++a_len; continue; }
-                    if (b_idx != NONE_ID && id == b_id0 + b_len * 0x10001u) {
-                        ++b_len;
-                        uint32_t t;
-                        t = a_idx; a_idx = b_idx; b_idx = t;
-                        t = a_id0; a_id0 = b_id0; b_id0 = t;
-                        t = a_len; a_len = b_len; b_len = t;
-                        continue;
-                    }
-                    if (n_ent == PS) { overflow = true; why = 2; break; }
-                    if (b_idx != NONE_ID) E_DL(b_idx) = b_len;
-                    b_idx = a_idx; b_id0 = a_id0; b_len = a_len;
-                    a_idx = n_ent; a_id0 = id; a_len = 1;
-                    E_ID(n_ent) = id; ++n_ent;
-                }
-                wlo = (wlo >> 8) | (whi << 24);
-                whi = ((whi >> 8) & 0xff) | (nextb << 8);
-                nextb = nextb2;
-            }
-            if (a_idx != NONE_ID) E_DL(a_idx) = a_len;
-            if (b_idx != NONE_ID) E_DL(b_idx) = b_len;
-        }
-        uint32_t lg_n = 0;
-        uint32_t best_id = 0;
-        if (!overflow && n_ent == 0) continue;                // no k-mer match: full matrix, banded == full
-        if (ablate == 3) { if (n_ent == 0xffffu) counters[7] = n_ent; continue; }   // (profiling aid) phase 1 only
-        // ================= phase 2: sdpkpp over the pieces =================
-        // E_DL = dp0 << 16 | len (dp0 == 0: piece not started yet).  A started entry is a SEGMENT: linear
-        // piece with dp = dp0 + u.  Pieces start in list order (= match order); a breakpoint inside a
-        // segment can only happen at the ENTRY row of another segment (after its entry a linear segment's
-        // candidate minus the row index never grows, while the run's own value never shrinks), so every
-        // ordered pair (segment -> segment) yields at most one candidate match, queued as an event and
-        // re-examined with a full query when the sweep reaches it.
-        if (!overflow) {
-            const uint32_t n1 = n_ent;
-            uint32_t ev0 = NONE_ID, ev1 = NONE_ID;
-#define SEGQ(id0, dp0, len, qx, qy, bV, bid)                                                                \
-            {                                                                                               \
-                const int32_t sx = (int32_t)((id0) >> 16), sy = (int32_t)((id0) & 0xffff);                   \
-                int32_t u = (int32_t)(len) - 1;                                                             \
-                u = min(u, (int32_t)(qx) - sx - KMER);                                                      \
-                u = min(u, (int32_t)(qy) - sy - KMER);                                                      \
-                if (u >= 0) {                                                                               \
-                    const int32_t v = (int32_t)(dp0) + sx + sy + 2 * KMER + 3 * u;                           \
-                    const uint32_t qid = (id0) + (uint32_t)u * 0x10001u;                                    \
-                    if (v > bV || (v == bV && (bid == NONE_ID || qid > bid))) { bV = v; bid = qid; }         \
-                }                                                                                           \
-            }
-            // event of segment s entering segment e: first row of e at which an element of s is visible
-#define GEN_EVENT(s_id, s_dp, s_len, e_id, e_dp, e_len)                                                     \
-            {                                                                                               \
-                const int32_t ga = (int32_t)((e_id) >> 16) - (int32_t)((s_id) >> 16) - KMER;                 \
-                const int32_t gb = (int32_t)((e_id) & 0xffff) - (int32_t)((s_id) & 0xffff) - KMER;           \
-                const int32_t ts = max(max(-ga, -gb), 0);                                                   \
-                if (ts >= 1 && ts < (int32_t)(e_len)) {                                                     \
-                    const int32_t gu = min(min(ga + ts, gb + ts), (int32_t)(s_len) - 1);                     \
-                    const int32_t gc = (int32_t)(s_dp) + gu + 1 - ((ga + ts - gu) + (gb + ts - gu));         \
-                    if (gc > (int32_t)(e_dp) + ts) {                                                        \
-                        const uint32_t mid = (e_id) + (uint32_t)ts * 0x10001u;                              \
-                        if (mid != ev0 && mid != ev1) {                                                     \
-                            if (ev0 == NONE_ID) ev0 = mid; else if (ev1 == NONE_ID) ev1 = mid;               \
-                            else { overflow = true; why = 4; }                                              \
-                        }                                                                                   \
-                    }                                                                                       \
-                }                                                                                           \
-            }
-            for (uint32_t i = 0; i <= n1 && !overflow; ++i) {
-                const uint32_t start_id = i < n1 ? E_ID(i) : NONE_ID;
-                // ---- events (possible breakpoints) due before this start, in match order ----
-                while (!overflow) {
-                    uint32_t mid = ev0 < ev1 ? ev0 : ev1;
-                    if (mid == NONE_ID || mid >= start_id) break;
-                    if (mid == ev0) ev0 = NONE_ID; else ev1 = NONE_ID;
-                    const int32_t mx = (int32_t)(mid >> 16), my = (int32_t)(mid & 0xffff);
-                    int32_t bV = INT32_MIN; uint32_t bid = NONE_ID;
-                    uint32_t e = NONE_ID, e_id = 0, e_dp = 0, e_len = 0;
-                    for (uint32_t j = 0; j < n_ent; ++j) {
-                        const uint32_t dl = E_DL(j);
-                        if ((dl >> 16) == 0) continue;
-                        const uint32_t sid = E_ID(j);
-                        const int32_t sx = (int32_t)(sid >> 16);
-                        if ((int32_t)(sid & 0xffff) - sx == my - mx && sx <= mx && mx < sx + (int32_t)(dl & 0xffff)) {
-                            e = j; e_id = sid; e_dp = dl >> 16; e_len = dl & 0xffff;
+            uint32_t xr = 0;
+            uint32_t ycur = head[kw_hash(wlo, whi)];          // chain cursor of the current row
+            bool service;
+            do {
+                // ---- hot loops: kept free of the (rare, large) list-full handling, which sits after them ----
+                service = false;
+                uint32_t pend_id = 0;
+                while (xr + KMER <= m) {
+                    while (ycur != 0xffff) {
+                        const uint32_t y = ycur;
+                        ycur = next[y];
+                        if (kwlo[y] != wlo || kwhi[y] != (uint16_t)whi) continue;
+                        const uint32_t id = (xr << 16) | y;
+                        if (a_idx != NONE_ID && id == a_id0 + a_len * 0x10001u) { ++a_len; continue; }
+                        if (b_idx != NONE_ID && id == b_id0 + b_len * 0x10001u) {
+                            ++b_len;
+                            uint32_t t;
+                            t = a_idx; a_idx = b_idx; b_idx = t;
+                            t = a_id0; a_id0 = b_id0; b_id0 = t;
+                            t = a_len; a_len = b_len; b_len = t;
+                            continue;
                         }
-                        SEGQ(sid, (dl >> 16), (dl & 0xffff), mx, my, bV, bid)
+                        if (st.n_ent == PS) { service = true; pend_id = id; break; }
+                        if (b_idx != NONE_ID) pm_id[b_idx * 256 + tid] = (pm_id[b_idx * 256 + tid] & 0xffff0000u) | b_len;
+                        b_idx = a_idx; b_id0 = a_id0; b_len = a_len;
+                        a_idx = st.n_ent; a_id0 = id; a_len = 1;
+                        pm_a[st.n_ent * 256 + tid] = id; pm_id[st.n_ent * 256 + tid] = 1; ++st.n_ent;
                     }
-                    if (e == NONE_ID) continue;
-                    const uint32_t t = (uint32_t)(mx - (int32_t)(e_id >> 16));
-                    if (t == 0 || bid == NONE_ID) continue;
-                    const int32_t cand = bV - 5 - (mx + my) + KMER;
-                    if (cand <= (int32_t)(e_dp + t)) continue;              // continuation wins (ties included)
-                    // breakpoint: split segment e at t
-                    if (n_ent == PS || lg_n == LG) { overflow = true; why = 3; break; }
-                    E_DL(e) = (e_dp << 16) | t;
-                    const uint32_t nd = (uint32_t)cand, nl = e_len - t;
-                    E_ID(n_ent) = mid; E_DL(n_ent) = (nd << 16) | nl;
-                    mylog[2 * lg_n] = mid; mylog[2 * lg_n + 1] = bid; ++lg_n;
-                    const uint32_t ni = n_ent++;
-                    for (uint32_t j = 0; j < n_ent && !overflow; ++j) {
-                        if (j == ni) continue;
-                        const uint32_t dl = E_DL(j);
-                        if ((dl >> 16) == 0) continue;
-                        const uint32_t sid = E_ID(j);
-                        if (nl >= 2) GEN_EVENT(sid, (dl >> 16), (dl & 0xffff), mid, nd, nl)
-                        if ((dl & 0xffff) >= 2) GEN_EVENT(mid, nd, nl, sid, (dl >> 16), (dl & 0xffff))
-                    }
+                    if (service) break;
+                    const uint32_t nb2 = (xr + KMER + 1 < m) ? x[xr + KMER + 1] : 0;
+                    wlo = (wlo >> 8) | (whi << 24);
+                    whi = ((whi >> 8) & 0xff) | (nextb << 8);
+                    nextb = nb2;
+                    ++xr;
+                    ycur = (xr + KMER <= m) ? head[kw_hash(wlo, whi)] : 0xffffu;
                 }
-                if (i == n1 || overflow) break;
-                // ---- start of piece i ----
-                const int32_t px = (int32_t)(start_id >> 16), py = (int32_t)(start_id & 0xffff);
-                const uint32_t plen = E_DL(i) & 0xffff;
-                int32_t bV = INT32_MIN; uint32_t bid = NONE_ID;
-                int32_t cdp = -1;
-                for (uint32_t j = 0; j < n_ent; ++j) {
-                    const uint32_t dl = E_DL(j);
-                    if ((dl >> 16) == 0) continue;
-                    const uint32_t sid = E_ID(j);
-                    if (sid + (dl & 0xffff) * 0x10001u == start_id) cdp = (int32_t)((dl >> 16) + (dl & 0xffff));
-                    SEGQ(sid, (dl >> 16), (dl & 0xffff), px, py, bV, bid)
-                }
-                int32_t dp = KMER; uint32_t prev = NONE_ID;
-                if (bid != NONE_ID) {
-                    const int32_t cand = bV - 5 - (px + py) + KMER;
-                    if (cand >= dp) { dp = cand; prev = bid; }
-                }
-                if (cdp >= dp) {
-                    dp = cdp;                                            // adjacent piece: LCSk++ continuation, no log entry
-                } else {
-                    if (lg_n == LG) { overflow = true; why = 3; break; }
-                    mylog[2 * lg_n] = start_id; mylog[2 * lg_n + 1] = prev; ++lg_n;
-                }
-                E_DL(i) = ((uint32_t)dp << 16) | plen;
-                if (plen >= 2 || dp + (int32_t)plen - 1 > KMER) {
-                    for (uint32_t j = 0; j < n_ent && !overflow; ++j) {
-                        if (j == i) continue;
-                        const uint32_t dl = E_DL(j);
-                        if ((dl >> 16) == 0) continue;
-                        const uint32_t sid = E_ID(j);
-                        if (plen >= 2) GEN_EVENT(sid, (dl >> 16), (dl & 0xffff), start_id, (uint32_t)dp, plen)
-                        if ((dl & 0xffff) >= 2) GEN_EVENT(start_id, (uint32_t)dp, plen, sid, (dl >> 16), (dl & 0xffff))
+                if (service) {
+                    // list full: run the chain DP up to this match, drop segments that cannot matter any more,
+                    // then open the pending piece and resume the probe where it stopped
+                    if (a_idx != NONE_ID) pm_id[a_idx * 256 + tid] = (pm_id[a_idx * 256 + tid] & 0xffff0000u) | a_len;
+                    if (b_idx != NONE_ID) pm_id[b_idx * 256 + tid] = (pm_id[b_idx * 256 + tid] & 0xffff0000u) | b_len;
+                    run_advance(st, pm_a, pm_id, tid, pend_id, a_idx, b_idx, mylog);
+                    if (!st.overflow) run_compact(st, pm_a, pm_id, tid, xr, a_idx, b_idx);
+                    if (st.n_ent == PS && !st.overflow) { st.overflow = true; st.why = 2; }
+                    if (!st.overflow) {
+                        // a breakpoint may have split an open piece and compaction renumbers: reload the register copies
+                        if (a_idx != NONE_ID) { a_id0 = pm_a[a_idx * 256 + tid]; a_len = pm_id[a_idx * 256 + tid] & 0xffff; }
+                        if (b_idx != NONE_ID) {
+                            b_id0 = pm_a[b_idx * 256 + tid]; b_len = pm_id[b_idx * 256 + tid] & 0xffff;
+                            pm_id[b_idx * 256 + tid] = (pm_id[b_idx * 256 + tid] & 0xffff0000u) | b_len;
+                        }
+                        b_idx = a_idx; b_id0 = a_id0; b_len = a_len;
+                        a_idx = st.n_ent; a_id0 = pend_id; a_len = 1;
+                        pm_a[st.n_ent * 256 + tid] = pend_id; pm_id[st.n_ent * 256 + tid] = 1; ++st.n_ent;
                     }
                 }
-            }
-#undef SEGQ
-#undef GEN_EVENT
+            } while (service && !st.overflow);
+            if (a_idx != NONE_ID) pm_id[a_idx * 256 + tid] = (pm_id[a_idx * 256 + tid] & 0xffff0000u) | a_len;
+            if (b_idx != NONE_ID) pm_id[b_idx * 256 + tid] = (pm_id[b_idx * 256 + tid] & 0xffff0000u) | b_len;
+        }
+        bool overflow = st.overflow;
+        uint32_t why = st.why;
+        if (!overflow && st.n_ent == 0 && st.best_v < 0) continue;     // no k-mer match: full matrix, banded == full
+        if (ablate == 3) { if (st.n_ent == 0xffffu) counters[7] = st.n_ent; continue; }   // (profiling aid) phase 1 only
+        // ================= phase 2: the rest of the chain DP =================
+        if (!overflow) {
+            uint32_t no_a = NONE_ID, no_b = NONE_ID;
+            run_advance(st, pm_a, pm_id, tid, NONE_ID, no_a, no_b, mylog);
+            overflow = st.overflow; why = st.why;
             // best match = end of the segment with the largest (dp, index)
-            if (!overflow) {
-                int32_t best_v = -1;
-                for (uint32_t j = 0; j < n_ent; ++j) {
-                    const uint32_t dl = E_DL(j);
-                    const int32_t v = (int32_t)((dl >> 16) + (dl & 0xffff)) - 1;
-                    const uint32_t eid = E_ID(j) + ((dl & 0xffff) - 1) * 0x10001u;
-                    if (v > best_v || (v == best_v && eid > best_id)) { best_v = v; best_id = eid; }
-                }
+            for (uint32_t j = 0; j < st.n_ent && !overflow; ++j) {
+                const uint32_t dl = pm_id[j * 256 + tid];
+                const int32_t v = (int32_t)((dl >> 16) + (dl & 0xffff)) - 1;
+                const uint32_t eid = pm_a[j * 256 + tid] + ((dl & 0xffff) - 1) * 0x10001u;
+                if (v > st.best_v || (v == st.best_v && eid > st.best_id)) { st.best_v = v; st.best_id = eid; }
             }
         }
-#undef E_ID
-#undef E_DL
+        const uint32_t lg_n = st.lg_n;
+        const uint32_t best_id = st.best_id;
         if (overflow) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[2 + why], 1u); continue; }
         uint32_t verts[4 * SG + 6];
         uint32_t nv = 0;
