@@ -230,3 +230,33 @@ def test_reference_fixtures_on_device(golden_dir, case, aligner):
     if ref_fx:
         _, want = refpipe.read_mtx(os.path.join(g, ref_fx))
         assert {(int(r), int(c)): float(v) for r, c, v in zip(coo["row"], coo["col"], coo["ref_value"])} == want
+
+
+def test_alternative_band_kernel_agrees(tmp_path):
+    """The streaming band kernel (VTX_BAND_KERNEL=stream) and the default run-level one are two
+    implementations of the same chain DP: same scores on an indel batch (separate process: the choice
+    is read once per process)."""
+    import subprocess
+    import sys
+    code = '''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from vartrix_amd import lib, synth
+from vartrix_amd.abi import default_config
+spec = synth.SynthSpec(n_loci=200, n_barcodes=100, reads_per_locus=40, indel_frac=0.5, read_len_jitter=50, seed=5, sub_error=0.02)
+b = synth.make_batch(spec)
+with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=100)) as ctx:
+    ctx.submit(b); ctx.run(); r, a = ctx.fetch_scores()
+np.save(sys.argv[1], np.stack([r, a]))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for kern in ("run", "stream"):
+        out = str(tmp_path / (kern + ".npy"))
+        env = dict(os.environ, VTX_BAND_KERNEL=kern)
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0], outs[1])
+    spec = synth.SynthSpec(n_loci=200, n_barcodes=100, reads_per_locus=40, indel_frac=0.5, read_len_jitter=50, seed=5, sub_error=0.02)
+    batch = synth.make_batch(spec)
+    oref, oalt = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=100), threads=8)
+    assert np.array_equal(outs[0][0], oref) and np.array_equal(outs[0][1], oalt)
