@@ -39,7 +39,9 @@ def _worker(rank, world, port, spec_kwargs, mode, umi, out_path):
     mine = batch.slice_loci(lo, hi)
     ref, alt = oracle.batch_scores(mine, cfg)
     coo = oracle.batch_reduce(mine, cfg, ref, alt)
-    got = shard.gather_coo(shard.coo_to_tensors(coo))
+    from vartrix_amd.abi import MODES
+    h = shard.gather_coo_async(shard.coo_to_tensors(coo), MODES[mode])     # overlappable form
+    got = h.wait()
     if rank == 0:
         full_ref, full_alt = oracle.batch_scores(batch, cfg, threads=4)
         want = oracle.batch_reduce(batch, cfg, full_ref, full_alt)

@@ -5,9 +5,11 @@ chunks has no shared mutable state (``src/main.rs:284-291``) and the merge loop
 is a concatenation in chunk order (``src/main.rs:320-348``).  So the multi-GPU
 path is: contiguous row ranges balanced by record count, one process per GPU,
 no collective on the data path, and ONE exchange at the end — every rank's COO
-block goes to rank 0 over its direct xGMI link (point-to-point send/recv, the
-pattern xGMI is built for; counts first with one all_gather).  Rank 0
-concatenates in rank order, which is already (row asc, col asc).
+block (row, col and the three counts; the f64 values are recomputed from the
+counts on rank 0) goes to rank 0 over its direct xGMI link (a gather = grouped
+point-to-point send/recv, the pattern xGMI is built for; counts first with one
+all_gather), asynchronously so it overlaps with the next batch's compute.
+Rank 0 concatenates in rank order, which is already (row asc, col asc).
 
 Works on any ``torch.distributed`` backend: ``nccl`` (= RCCL on ROCm) with GPU
 tensors, ``gloo`` with CPU tensors (the world_size-2 tests).
@@ -86,33 +88,57 @@ def tensors_to_coo(t: dict) -> dict:
     return out
 
 
+def values_from_counts(alt: torch.Tensor, ref: torch.Tensor, unk: torch.Tensor, mode: int):
+    """(value, ref_value) of the matrix modes from the per-group counts — the same arithmetic as the
+    emit kernel / reference ``src/main.rs:1120-1126, 1140-1142, 1160-1161`` (f64, IEEE division)."""
+    a, r, u = alt.to(torch.float64), ref.to(torch.float64), unk.to(torch.float64)
+    if mode == 0:      # consensus
+        v = torch.where((ref > 0) & (alt > 0), 3.0, torch.where(alt > 0, 2.0, 1.0)).to(torch.float64)
+        return v, torch.zeros_like(v)
+    if mode == 1:      # alt_frac (0/0 -> NaN like the reference)
+        return a / (r + a + u), torch.zeros_like(a)
+    return a, r        # coverage
+
+
 def _pack(local: dict, rows: int) -> torch.Tensor:
-    """Triplet arrays -> one int32 payload [rows, 9] (5 x u32, 2 x f64 as int32 pairs), zero padded."""
+    """Triplet arrays -> one int32 payload [rows, 5] (row, col, alt, ref, unk), zero padded.  The f64 values
+    are a function of the counts and the mode, so they are recomputed on the destination instead of sent."""
     dev = local["row"].device
     n = local["row"].shape[0]
-    buf = torch.zeros((rows, 9), dtype=torch.int32, device=dev)
+    buf = torch.zeros((rows, 5), dtype=torch.int32, device=dev)
     if n:
         for c, k in enumerate(("row", "col", "alt", "ref", "unk")):
             buf[:n, c] = local[k]
-        buf[:n, 5:7] = local["value"].contiguous().view(torch.int32).view(n, 2)
-        buf[:n, 7:9] = local["ref_value"].contiguous().view(torch.int32).view(n, 2)
     return buf
 
 
-def _unpack(buf: torch.Tensor) -> dict:
+def _unpack(buf: torch.Tensor, mode: int) -> dict:
     out = {k: buf[:, c].contiguous() for c, k in enumerate(("row", "col", "alt", "ref", "unk"))}
-    out["value"] = buf[:, 5:7].contiguous().view(torch.float64).view(-1)
-    out["ref_value"] = buf[:, 7:9].contiguous().view(torch.float64).view(-1)
+    out["value"], out["ref_value"] = values_from_counts(out["alt"], out["ref"], out["unk"], mode)
     return out
 
 
-def gather_coo(local: dict, group=None, dst: int = 0):
-    """Gather every rank's triplets to ``dst`` (rank order = row order).
+class GatherHandle:
+    """An in-flight gather_coo: ``wait()`` returns the concatenated dict on dst, None elsewhere."""
 
-    One tiny all_gather of the counts, then ONE gather of a packed, padded int32
-    payload per rank (RCCL lowers gather to grouped send/recv: each rank's block
-    travels once over its direct xGMI link to ``dst``).  Returns the
-    concatenated dict on ``dst`` and ``None`` elsewhere.
+    def __init__(self, work, bufs, counts, payload, mode, is_dst):
+        self._work, self._bufs, self._counts, self._payload, self._mode, self._is_dst = work, bufs, counts, payload, mode, is_dst
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+        if not self._is_dst:
+            return None
+        return _unpack(torch.cat([b[:c] for b, c in zip(self._bufs, self._counts)], dim=0), self._mode)
+
+
+def gather_coo_async(local: dict, mode: int, group=None, dst: int = 0) -> GatherHandle:
+    """Start gathering every rank's triplets to ``dst`` (rank order = row order).
+
+    One tiny all_gather of the counts, then ONE asynchronous gather of a packed, padded int32 payload
+    per rank (RCCL lowers gather to grouped send/recv: each rank's block travels once over its direct
+    xGMI link to ``dst``).  The payload is a copy, so the caller may overwrite the source arrays (run
+    the next step) as soon as this returns — the exchange overlaps with compute.
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -123,9 +149,16 @@ def gather_coo(local: dict, group=None, dst: int = 0):
     counts = [int(c.item()) for c in counts]
     rows = max(max(counts), 1)
     payload = _pack(local, rows)
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()      # the copy out of the source arrays is complete
     if rank == dst:
-        bufs = [torch.empty((rows, 9), dtype=torch.int32, device=dev) for _ in range(world)]
-        dist.gather(payload, gather_list=bufs, dst=dst, group=group)
-        return _unpack(torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0))
-    dist.gather(payload, gather_list=None, dst=dst, group=group)
-    return None
+        bufs = [torch.empty((rows, 5), dtype=torch.int32, device=dev) for _ in range(world)]
+        work = dist.gather(payload, gather_list=bufs, dst=dst, group=group, async_op=True)
+        return GatherHandle(work, bufs, counts, payload, mode, True)
+    work = dist.gather(payload, gather_list=None, dst=dst, group=group, async_op=True)
+    return GatherHandle(work, None, counts, payload, mode, False)
+
+
+def gather_coo(local: dict, mode: int = 2, group=None, dst: int = 0):
+    """Blocking form of gather_coo_async."""
+    return gather_coo_async(local, mode, group, dst).wait()
