@@ -11,6 +11,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -172,12 +173,17 @@ int main(int argc, char** argv) {
     ha.use_umi = present.count("umi");
     ha.bam_tag = val["bam-tag"].c_str(); ha.valid_chars = val["valid-chars"].c_str();
     ha.threads = std::max(1, atoi(val["threads"].c_str()));
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
     vtxh_pack* pk = nullptr;
     if (vtxh_pack_files(&ha, &pk) != 0) {
         printf("Vartrix error.\nError: %s\n", vtxh_last_error());
         return 1;
     }
     const uint32_t n_vars = vtxh_num_variants(pk), n_bcs = vtxh_num_barcodes(pk);
+    const double t_ingest = since(t_start);
     LOG_INFO("Loaded %u barcodes", n_bcs);
     if (n_vars == 0)
         LOG_ERROR("Warning! Zero variants found in input VCF. Output matrices will be by definition empty but will still be generated.");
@@ -220,6 +226,8 @@ int main(int argc, char** argv) {
             s.reads = full.read_arena; s.read_bytes = full.read_bytes;
         }
     }
+    LOG_INFO("Ingest + filter + pack: %.3f s (%u loci, %u scored reads)", t_ingest, full.n_loci, full.n_records);
+    const auto t_dev = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
     for (int d = 0; d < ndev; ++d) {
         vtx_config c = cfg;
@@ -230,6 +238,7 @@ int main(int argc, char** argv) {
     for (auto& s : shards)
         if (s.rc) { printf("Vartrix error.\nError: %s: %s\n", vtx_status_name(s.rc), s.err.c_str()); return 1; }
 
+    LOG_INFO("Device (create + submit + run + fetch) on %d GPU(s): %.3f s", ndev, since(t_dev));
     // merge in shard (= row) order: exactly the triplet order of the merge loop :320-348
     std::vector<uint32_t> row, col;
     std::vector<double> v, rv;

@@ -367,7 +367,7 @@ int vtx_run(vtx_ctx* c) {
         // hard scores.  Tasks the fast kernel cannot hold accumulate in ONE overflow list that the general
         // band kernel processes after the last chunk (a launch of a handful of serial lanes costs ~2 ms).
         const uint64_t n_tasks = 2ull * nr;
-        const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_tasks, 1u << 22);
+        const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_tasks, 1u << 24);
         const uint32_t band_stride = (c->max_hap_len + 2 + 7) & ~7u;
         uint32_t fast_overflow = 0;
         HIP_TRY(c, c->d_band_ws.reserve((size_t)chunk * 64 * 2 * sizeof(uint32_t)));   // jump log of the fast kernel (LG entries per task)
