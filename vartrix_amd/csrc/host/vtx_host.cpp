@@ -6,6 +6,10 @@
 // is inflated block-parallel and swept ONCE in file order; every record is
 // joined against the per-contig sorted locus intervals, so each locus receives
 // its reads in exactly the order `bam.fetch(...).records()` yields them.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -67,6 +71,32 @@ bool read_gz(const std::string& path, std::string& out) {   // MultiGzDecoder / 
     return n == 0;
 }
 
+// read-only mapping of a (possibly huge) input file: BAM and FASTA are never copied into host memory
+struct MappedFile {
+    const unsigned char* p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    bool open(const std::string& path) {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) return false;
+        n = (size_t)st.st_size;
+        if (n == 0) return true;
+        void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) return false;
+        p = (const unsigned char*)m;
+        madvise(m, n, MADV_SEQUENTIAL);
+        return true;
+    }
+    ~MappedFile() {
+        if (p) munmap((void*)p, n);
+        if (fd >= 0) ::close(fd);
+    }
+    size_t size() const { return n; }
+    const unsigned char* data() const { return p; }
+};
+
 // BufRead::lines(): split on '\n', drop one trailing '\r'; no empty last line after a final '\n'
 std::vector<std::string> split_lines(const std::string& data) {
     std::vector<std::string> lines;
@@ -85,7 +115,7 @@ std::vector<std::string> split_lines(const std::string& data) {
 // ---- FASTA + .fai (rust-bio fasta::IndexedReader) ------------------------------
 struct FaiEntry { std::string name; uint64_t len, offset, linebases, linewidth; };
 struct Fasta {
-    std::string data;                 // whole file (genomes fit host RAM; mmap is a later refinement)
+    MappedFile data;                  // mapped, random access through the .fai offsets
     std::vector<FaiEntry> seqs;
     std::unordered_map<std::string, size_t> by_name;
     // fetch [start, end) of contig, upper-cased (read_locus :947-952)
@@ -93,7 +123,7 @@ struct Fasta {
         out.clear();
         for (uint64_t p = start; p < end; ++p) {
             uint64_t off = e.offset + (p / e.linebases) * e.linewidth + p % e.linebases;
-            unsigned char c = off < data.size() ? (unsigned char)data[off] : 'N';
+            unsigned char c = off < data.size() ? data.data()[off] : 'N';
             if (c >= 'a' && c <= 'z') c = (unsigned char)(c - 32);
             out.push_back((char)c);
         }
@@ -109,7 +139,7 @@ enum { FLAG_UNMAP = 0x4, FLAG_SECONDARY = 0x100, FLAG_DUP = 0x400, FLAG_SUPP = 0
 
 struct BgzfBlock { size_t coff; uint32_t clen; uint32_t isize; };
 
-bool index_bgzf(const std::string& file, std::vector<BgzfBlock>& blocks) {
+bool index_bgzf(const MappedFile& file, std::vector<BgzfBlock>& blocks) {
     size_t o = 0;
     while (o + 18 <= file.size()) {
         const unsigned char* h = (const unsigned char*)file.data() + o;
@@ -132,7 +162,7 @@ bool index_bgzf(const std::string& file, std::vector<BgzfBlock>& blocks) {
     return o == file.size();
 }
 
-bool inflate_block(const std::string& file, const BgzfBlock& b, unsigned char* dst) {
+bool inflate_block(const MappedFile& file, const BgzfBlock& b, unsigned char* dst) {
     if (b.isize == 0) return true;
     z_stream zs;
     memset(&zs, 0, sizeof zs);
@@ -383,12 +413,12 @@ int vtxh_pack_files(const vtxh_args* a, vtxh_pack** out) {
             fa.by_name.emplace(e.name, fa.seqs.size());
             fa.seqs.push_back(e);
         }
-        if (!read_file(a->fasta, fa.data)) return fail(VTX_E_INVAL, "error opening fasta file %s", a->fasta);
+        if (!fa.data.open(a->fasta)) return fail(VTX_E_INVAL, "error opening fasta file %s", a->fasta);
     }
 
     // ---- BAM: header ----
-    std::string bam_file;
-    if (!read_file(a->bam, bam_file)) return fail(VTX_E_INVAL, "error opening bam file: %s", a->bam);
+    MappedFile bam_file;
+    if (!bam_file.open(a->bam)) return fail(VTX_E_INVAL, "error opening bam file: %s", a->bam);
     if (ends_with(a->bam, ".cram")) return fail(VTX_E_UNSUPPORTED, "CRAM input is not supported");
     std::vector<BgzfBlock> blocks;
     if (!index_bgzf(bam_file, blocks)) return fail(VTX_E_INVAL, "%s is not a valid BGZF/BAM file", a->bam);
