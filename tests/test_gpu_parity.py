@@ -260,3 +260,58 @@ np.save(sys.argv[1], np.stack([r, a]))
     batch = synth.make_batch(spec)
     oref, oalt = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=100), threads=8)
     assert np.array_equal(outs[0][0], oref) and np.array_equal(outs[0][1], oalt)
+
+
+@pytest.mark.parametrize("seed,sub_error,indel_frac,read_len,padding", [
+    (101, 0.03, 0.5, 150, 100), (102, 0.08, 0.3, 100, 60), (103, 0.01, 0.7, 151, 120), (104, 0.15, 0.5, 80, 100)])
+def test_banded_large_random_vs_oracle(seed, sub_error, indel_frac, read_len, padding):
+    """Stress of the band kernels' rare paths (breakpoints, open-piece splits, list compaction, fallback):
+    tens of thousands of noisy, ragged reads over indel loci, every score checked against the oracle."""
+    spec = synth.SynthSpec(n_loci=600, n_barcodes=500, reads_per_locus=80, read_len=read_len, padding=padding,
+                           indel_frac=indel_frac, sub_error=sub_error, read_len_jitter=read_len // 3, seed=seed)
+    batch = synth.make_batch(spec)
+    cfg = default_config(aligner="banded", scoring_mode="coverage", n_barcodes=spec.n_barcodes)
+    with lib.Context(cfg) as ctx:
+        ctx.submit(batch)
+        ctx.run()
+        ref, alt = ctx.fetch_scores()
+        hard = ctx.timing().hard_tasks
+    oref, oalt = oracle.batch_scores(batch, cfg, threads=os.cpu_count() or 8)
+    bad = np.nonzero((ref != oref) | (alt != oalt))[0]
+    assert bad.size == 0, "%d mismatches, first at record %d: device (%d,%d) oracle (%d,%d)" % (
+        bad.size, bad[0], ref[bad[0]], alt[bad[0]], oref[bad[0]], oalt[bad[0]])
+    print("seed %d: %d records ok, %d hard tasks" % (seed, batch.n_records, hard))
+
+
+def test_banded_repeat_rich_genome_vs_oracle():
+    """Haplotypes and reads drawn from a low-entropy genome (tandem repeats, homopolymers): hundreds of
+    k-mer matches per alignment, many concurrent diagonals — exercises piece-list compaction and the
+    general fallback kernel."""
+    rng = np.random.default_rng(77)
+    units = [b"A", b"AC", b"AAT", b"ACGT", b"AAAAC", b"AG", b"T", b"CAG"]
+    g = bytearray()
+    while len(g) < 60000:
+        u = units[int(rng.integers(0, len(units)))]
+        g += u * int(rng.integers(3, 30))
+        g += bytes(rng.choice(list(b"ACGT"), int(rng.integers(5, 40))).tolist())
+    g = bytes(g)
+    haps, reads = [], []
+    for i in range(120):
+        p = int(rng.integers(200, len(g) - 400))
+        ref = g[p - 100:p + 101]
+        alt = ref[:100] + bytes([b"ACGT"[(b"ACGT".index(ref[100:101]) + 1) % 4]]) + ref[101:]
+        haps.append((ref, alt))
+        rl = []
+        for k in range(40):
+            s = p - int(rng.integers(0, 150))
+            rd = bytearray(g[s:s + 150])
+            if k % 2:
+                rd[p - s] = alt[100]
+            for e in np.nonzero(rng.random(len(rd)) < 0.02)[0]:
+                rd[e] = b"ACGT"[int(rng.integers(0, 4))]
+            rl.append((int(rng.integers(0, 30)), 0, bytes(rd)))
+        reads.append(rl)
+    batch = _manual_batch(haps, reads, 30)
+    for aligner in ALIGNERS:
+        cfg = default_config(aligner=aligner, scoring_mode="coverage", n_barcodes=30)
+        assert_same(batch, cfg, threads=os.cpu_count() or 8)
