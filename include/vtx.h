@@ -174,6 +174,60 @@ void vtx_destroy(vtx_ctx* ctx);
  * stays resident until the next vtx_submit, so vtx_run may be repeated.      */
 int vtx_submit(vtx_ctx* ctx, const vtx_batch* batch);
 
+/* ---- raw batches: barcode lookup, UMI grouping and the sort done on the device ----------------
+ * A raw record is a read that passed the alignment-level filters of evaluate_alns
+ * (mapq / flags / useful_alignment, src/main.rs:833-864) but whose cell barcode and UMI are
+ * still the tag BYTES of the BAM record.  The device then does what the reference does per read
+ * on the CPU: `cell_barcodes.get(..)` (get_cell_barcode, src/main.rs:737-750, :867-876), the
+ * UB-present test (:879-888), the grouping of reads by UMI byte string (parse_scores' per-cell
+ * HashMap, :1047-1057) and the sort by cell (:932).                                               */
+#define VTX_TAG_MISSING 0xffffu   /* umi_len of a read without the UB tag */
+
+typedef struct vtx_raw_record {
+    uint32_t read_off;   /* into read_arena */
+    uint32_t read_len;
+    uint32_t bc_off;     /* cell-barcode tag bytes in tag_arena (the whole Z string, e.g. "ACGT...-1") */
+    uint32_t umi_off;    /* UB tag bytes in tag_arena; ignored unless cfg.use_umi                       */
+    uint16_t bc_len;
+    uint16_t umi_len;    /* VTX_TAG_MISSING: no UB tag (dropped and counted when cfg.use_umi)            */
+} vtx_raw_record;
+
+typedef struct vtx_raw_batch {
+    const vtx_locus* loci;          /* rec_begin/rec_count delimit RAW records (any order inside a locus) */
+    uint32_t n_loci;
+    const vtx_raw_record* records;
+    uint32_t n_records;
+    const uint8_t* hap_arena;
+    uint64_t hap_bytes;
+    const uint8_t* read_arena;
+    uint64_t read_bytes;
+    const uint8_t* tag_arena;
+    uint64_t tag_bytes;
+} vtx_raw_batch;
+
+typedef struct vtx_raw_stats {
+    uint64_t num_not_cell_bc;   /* barcode not in the list (Metrics.num_not_cell_bc, src/main.rs:870-876) */
+    uint64_t num_non_umi;       /* use_umi and no UB tag, after the barcode test (:879-888)               */
+    uint64_t kept;              /* records that reach the aligner                                         */
+    float prep_ms;              /* device time of lookup + sort + regrouping                              */
+    uint32_t hash_rounds;       /* UMI hash seeds tried (1 unless two UMIs of one cell collided)          */
+} vtx_raw_stats;
+
+/* Upload the barcode list (load_barcodes, src/main.rs:697-718): barcode j is
+ * bytes[offsets[j] .. offsets[j+1]); j is the matrix column.  A byte string listed twice keeps
+ * its FIRST index (:704-710).  n must equal cfg.n_barcodes.                                       */
+int vtx_set_barcodes(vtx_ctx* ctx, const uint8_t* bytes, const uint64_t* offsets, uint32_t n);
+
+/* vtx_submit for a raw batch: same resident state afterwards (vtx_run / vtx_fetch_* unchanged).
+ * Records are resolved, filtered and ordered by (row, cell_index, UMI) on the device; the order
+ * of reads inside one (row, cell, UMI) group is unspecified (no result depends on it).           */
+int vtx_submit_raw(vtx_ctx* ctx, const vtx_raw_batch* batch, vtx_raw_stats* stats);
+
+/* Parity/debug: the resolved, sorted records of the resident batch and the per-locus record
+ * ranges (n_records entries of vtx_record — umi_id is a dense group number — and n_loci
+ * (rec_begin, rec_count) pairs).  Buffers are caller-allocated; n_records = stats.kept.           */
+int vtx_fetch_records(vtx_ctx* ctx, vtx_record* records, uint32_t* rec_begin, uint32_t* rec_count);
+
 /* Run the hot path on the resident batch: Smith-Waterman of every record
  * against both haplotypes (src/main.rs:898-901), per-read call
  * (evaluate_scores :1019-1030), UMI collapse (parse_scores :1041-1109) and the
@@ -208,8 +262,9 @@ const char* vtx_strerror(const vtx_ctx* ctx);
 const char* vtx_status_name(int status);
 
 /* sizeof() of {vtx_config, vtx_locus, vtx_record, vtx_batch, vtx_coo,
- * vtx_timing} as compiled into the library, for binding self-checks.
- * Writes min(n, 6) entries; returns VTX_ABI_VERSION.                         */
+ * vtx_timing, vtx_raw_record, vtx_raw_batch, vtx_raw_stats} as compiled into
+ * the library, for binding self-checks.
+ * Writes min(n, 9) entries; returns VTX_ABI_VERSION.                         */
 int vtx_abi_sizes(uint32_t* out, uint32_t n);
 
 #ifdef __cplusplus

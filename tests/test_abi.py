@@ -31,10 +31,11 @@ def test_exports_every_declared_symbol(L):
 
 
 def test_struct_sizes_match(L):
-    out = (C.c_uint32 * 6)()
-    assert L.vtx_abi_sizes(out, 6) == abi.VTX_ABI_VERSION
+    out = (C.c_uint32 * 9)()
+    assert L.vtx_abi_sizes(out, 9) == abi.VTX_ABI_VERSION
     assert list(out) == [C.sizeof(abi.VtxConfig), abi.LOCUS_DTYPE.itemsize, abi.RECORD_DTYPE.itemsize,
-                         C.sizeof(abi.VtxBatch), C.sizeof(abi.VtxCoo), C.sizeof(abi.VtxTiming)]
+                         C.sizeof(abi.VtxBatch), C.sizeof(abi.VtxCoo), C.sizeof(abi.VtxTiming),
+                         abi.RAW_RECORD_DTYPE.itemsize, C.sizeof(abi.VtxRawBatch), C.sizeof(abi.VtxRawStats)]
 
 
 def test_config_default_is_reference_constants(L):

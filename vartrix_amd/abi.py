@@ -117,6 +117,73 @@ class VtxTiming(C.Structure):
     ]
 
 
+TAG_MISSING = 0xFFFF
+RAW_RECORD_DTYPE = np.dtype([
+    ("read_off", "<u4"), ("read_len", "<u4"), ("bc_off", "<u4"), ("umi_off", "<u4"),
+    ("bc_len", "<u2"), ("umi_len", "<u2")])
+assert RAW_RECORD_DTYPE.itemsize == 20
+
+
+class VtxRawBatch(C.Structure):
+    _fields_ = [
+        ("loci", C.c_void_p),
+        ("n_loci", C.c_uint32),
+        ("records", C.c_void_p),
+        ("n_records", C.c_uint32),
+        ("hap_arena", C.c_void_p),
+        ("hap_bytes", C.c_uint64),
+        ("read_arena", C.c_void_p),
+        ("read_bytes", C.c_uint64),
+        ("tag_arena", C.c_void_p),
+        ("tag_bytes", C.c_uint64),
+    ]
+
+
+class VtxRawStats(C.Structure):
+    _fields_ = [
+        ("num_not_cell_bc", C.c_uint64),
+        ("num_non_umi", C.c_uint64),
+        ("kept", C.c_uint64),
+        ("prep_ms", C.c_float),
+        ("hash_rounds", C.c_uint32),
+    ]
+
+
+@dataclass
+class RawBatch:
+    """Host-side raw batch — the payload of ``vtx_submit_raw``: reads that passed the alignment-level
+    filters (src/main.rs:833-864), in any order inside a locus, barcode / UMI still as tag bytes."""
+    loci: np.ndarray
+    records: np.ndarray
+    hap_arena: np.ndarray
+    read_arena: np.ndarray
+    tag_arena: np.ndarray
+
+    def __post_init__(self):
+        self.loci = np.ascontiguousarray(self.loci, dtype=LOCUS_DTYPE)
+        self.records = np.ascontiguousarray(self.records, dtype=RAW_RECORD_DTYPE)
+        self.hap_arena = np.ascontiguousarray(self.hap_arena, dtype=np.uint8)
+        self.read_arena = np.ascontiguousarray(self.read_arena, dtype=np.uint8)
+        self.tag_arena = np.ascontiguousarray(self.tag_arena, dtype=np.uint8)
+
+    @property
+    def n_loci(self) -> int:
+        return int(self.loci.shape[0])
+
+    @property
+    def n_records(self) -> int:
+        return int(self.records.shape[0])
+
+    def as_struct(self) -> VtxRawBatch:
+        def ptr(a):
+            return a.ctypes.data if a.size else None
+        return VtxRawBatch(
+            loci=ptr(self.loci), n_loci=self.n_loci, records=ptr(self.records), n_records=self.n_records,
+            hap_arena=ptr(self.hap_arena), hap_bytes=int(self.hap_arena.size),
+            read_arena=ptr(self.read_arena), read_bytes=int(self.read_arena.size),
+            tag_arena=ptr(self.tag_arena), tag_bytes=int(self.tag_arena.size))
+
+
 @dataclass
 class PackedBatch:
     """Host-side packed batch (numpy) — the payload of ``vtx_submit``.

@@ -74,6 +74,12 @@ struct vtx_ctx {
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
     DevBuf d_band_ws, d_band_ws2, d_band, d_hard, d_over, d_over2, d_cnt;   // banded flavour
     DevBuf d_redo, d_redo_cnt;                                               // LUT kernel: records with non-ACGTN bytes
+    // raw batches (vtx_submit_raw): barcode table + preparation scratch
+    DevBuf d_bc_slots, d_bc_hash, d_bc_off, d_bc_bytes;
+    uint32_t bc_mask = 0;
+    bool bc_ready = false;
+    DevBuf d_raw, d_tags, d_raw_locus, d_key_lc, d_key_lc2, d_key_umi, d_key_umi2, d_idx, d_idx2, d_shape, d_shape2, d_seq,
+        d_locus_cnt, d_locus_scan, d_prep_cnt, d_sort_tmp;
     uint32_t max_read_len = 0, fast_overflow = 0;
     std::vector<uint32_t> h_row, h_col, h_alt, h_ref, h_unk;
     std::vector<double> h_val, h_refval;
@@ -99,6 +105,54 @@ int fail(vtx_ctx* c, int code, const char* fmt, ...) {
                         hipGetErrorString(_e));                                                \
     } while (0)
 
+// per-record device buffers of the resident batch (scores, group structure, COO staging)
+int reserve_record_buffers(vtx_ctx* c, uint32_t nr) {
+    const size_t u32 = sizeof(uint32_t);
+    HIP_TRY(c, c->d_records.reserve((size_t)nr * sizeof(vtx_record)));
+    HIP_TRY(c, c->d_rec_locus.reserve(nr * u32));
+    HIP_TRY(c, c->d_work.reserve(nr * u32));
+    HIP_TRY(c, c->d_redo.reserve(nr * u32));
+    HIP_TRY(c, c->d_redo_cnt.reserve(16 * u32));
+    HIP_TRY(c, c->d_ref.reserve(nr * sizeof(int32_t)));
+    HIP_TRY(c, c->d_alt.reserve(nr * sizeof(int32_t)));
+    DevBuf* per_rec[] = {&c->d_head_cell, &c->d_head_umi, &c->d_cell_scan, &c->d_umi_scan, &c->d_grp_row, &c->d_grp_col,
+                         &c->d_umi_cellgrp, &c->d_keep, &c->d_keep_scan, &c->d_o_row, &c->d_o_col, &c->d_o_alt,
+                         &c->d_o_ref, &c->d_o_unk};
+    for (DevBuf* d : per_rec) HIP_TRY(c, d->reserve(nr * u32));
+    HIP_TRY(c, c->d_cell_cnt.reserve(3 * (size_t)nr * u32));
+    HIP_TRY(c, c->d_umi_cnt.reserve(3 * (size_t)nr * u32));
+    HIP_TRY(c, c->d_o_val.reserve(nr * sizeof(double)));
+    HIP_TRY(c, c->d_o_refval.reserve(nr * sizeof(double)));
+    HIP_TRY(c, c->d_scan_tmp.reserve(vtxk_scan_temp_bytes(nr)));
+    return VTX_OK;
+}
+
+// (row, cell) / (row, cell, umi) group structure of the resident records: depends only on the records.
+// Leaves the two group counts in flight on the stream (the caller synchronises).
+int build_groups(vtx_ctx* c, uint32_t nr) {
+    hipStream_t s = c->stream;
+    const size_t tmp_bytes = vtxk_scan_temp_bytes(nr);
+    c->n_cell_groups = c->n_umi_groups = 0;
+    if (!nr) return VTX_OK;
+    HIP_TRY(c, vtxk_group_heads(c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), nr,
+                                c->d_head_cell.as<uint32_t>(), c->d_head_umi.as<uint32_t>(), s));
+    HIP_TRY(c, vtxk_inclusive_scan_u32(c->d_head_cell.as<uint32_t>(), c->d_cell_scan.as<uint32_t>(), nr, c->d_scan_tmp.p, tmp_bytes, s));
+    HIP_TRY(c, vtxk_inclusive_scan_u32(c->d_head_umi.as<uint32_t>(), c->d_umi_scan.as<uint32_t>(), nr, c->d_scan_tmp.p, tmp_bytes, s));
+    HIP_TRY(c, vtxk_group_table(c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), nr,
+                                c->d_head_cell.as<uint32_t>(), c->d_head_umi.as<uint32_t>(), c->d_cell_scan.as<uint32_t>(),
+                                c->d_umi_scan.as<uint32_t>(), c->d_grp_row.as<uint32_t>(), c->d_grp_col.as<uint32_t>(),
+                                c->d_umi_cellgrp.as<uint32_t>(), s));
+    HIP_TRY(c, hipMemcpyAsync(&c->n_cell_groups, c->d_cell_scan.as<uint32_t>() + (nr - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&c->n_umi_groups, c->d_umi_scan.as<uint32_t>() + (nr - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    return VTX_OK;
+}
+
+uint32_t bits_for(uint64_t max_value) {   // bits needed to represent values 0..max_value
+    uint32_t b = 1;
+    while (b < 64 && (max_value >> b)) ++b;
+    return b;
+}
+
 }  // namespace
 
 extern "C" {
@@ -121,9 +175,10 @@ void vtx_config_default(vtx_config* cfg) {
 }
 
 int vtx_abi_sizes(uint32_t* out, uint32_t n) {
-    const uint32_t s[6] = {(uint32_t)sizeof(vtx_config), (uint32_t)sizeof(vtx_locus), (uint32_t)sizeof(vtx_record),
-                           (uint32_t)sizeof(vtx_batch), (uint32_t)sizeof(vtx_coo), (uint32_t)sizeof(vtx_timing)};
-    for (uint32_t i = 0; i < n && i < 6; ++i) out[i] = s[i];
+    const uint32_t s[9] = {(uint32_t)sizeof(vtx_config), (uint32_t)sizeof(vtx_locus), (uint32_t)sizeof(vtx_record),
+                           (uint32_t)sizeof(vtx_batch), (uint32_t)sizeof(vtx_coo), (uint32_t)sizeof(vtx_timing),
+                           (uint32_t)sizeof(vtx_raw_record), (uint32_t)sizeof(vtx_raw_batch), (uint32_t)sizeof(vtx_raw_stats)};
+    for (uint32_t i = 0; i < n && i < 9; ++i) out[i] = s[i];
     return VTX_ABI_VERSION;
 }
 
@@ -192,7 +247,10 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_grp_col, &c->d_umi_cellgrp, &c->d_cell_cnt, &c->d_umi_cnt, &c->d_keep, &c->d_keep_scan,
                       &c->d_scan_tmp, &c->d_o_row, &c->d_o_col, &c->d_o_alt, &c->d_o_ref, &c->d_o_unk, &c->d_o_val,
                       &c->d_o_refval, &c->d_band_ws, &c->d_band_ws2, &c->d_band, &c->d_hard, &c->d_over, &c->d_over2,
-                      &c->d_cnt, &c->d_redo, &c->d_redo_cnt};
+                      &c->d_cnt, &c->d_redo, &c->d_redo_cnt, &c->d_bc_slots, &c->d_bc_hash, &c->d_bc_off, &c->d_bc_bytes,
+                      &c->d_raw, &c->d_tags, &c->d_raw_locus, &c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2,
+                      &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
+                      &c->d_prep_cnt, &c->d_sort_tmp};
     for (DevBuf* b : bufs) b->release();
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -266,25 +324,9 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const size_t u32 = sizeof(uint32_t);
     HIP_TRY(c, c->d_loci.reserve((size_t)nl * sizeof(vtx_locus)));
-    HIP_TRY(c, c->d_records.reserve((size_t)nr * sizeof(vtx_record)));
-    HIP_TRY(c, c->d_rec_locus.reserve(nr * u32));
     HIP_TRY(c, c->d_hap.reserve(b->hap_bytes + 16));
     HIP_TRY(c, c->d_read.reserve(b->read_bytes + 16));
-    HIP_TRY(c, c->d_work.reserve(nr * u32));
-    HIP_TRY(c, c->d_redo.reserve(nr * u32));
-    HIP_TRY(c, c->d_redo_cnt.reserve(16 * u32));
-    HIP_TRY(c, c->d_ref.reserve(nr * sizeof(int32_t)));
-    HIP_TRY(c, c->d_alt.reserve(nr * sizeof(int32_t)));
-    DevBuf* per_rec[] = {&c->d_head_cell, &c->d_head_umi, &c->d_cell_scan, &c->d_umi_scan, &c->d_grp_row, &c->d_grp_col,
-                         &c->d_umi_cellgrp, &c->d_keep, &c->d_keep_scan, &c->d_o_row, &c->d_o_col, &c->d_o_alt,
-                         &c->d_o_ref, &c->d_o_unk};
-    for (DevBuf* d : per_rec) HIP_TRY(c, d->reserve(nr * u32));
-    HIP_TRY(c, c->d_cell_cnt.reserve(3 * (size_t)nr * u32));
-    HIP_TRY(c, c->d_umi_cnt.reserve(3 * (size_t)nr * u32));
-    HIP_TRY(c, c->d_o_val.reserve(nr * sizeof(double)));
-    HIP_TRY(c, c->d_o_refval.reserve(nr * sizeof(double)));
-    const size_t tmp_bytes = vtxk_scan_temp_bytes(nr);
-    HIP_TRY(c, c->d_scan_tmp.reserve(tmp_bytes));
+    if (int rc = reserve_record_buffers(c, nr)) return rc;
 
     hipStream_t s = c->stream;
     if (nl) HIP_TRY(c, hipMemcpyAsync(c->d_loci.p, b->loci, (size_t)nl * sizeof(vtx_locus), hipMemcpyHostToDevice, s));
@@ -296,24 +338,219 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
     if (b->hap_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_hap.p, b->hap_arena, b->hap_bytes, hipMemcpyHostToDevice, s));
     if (b->read_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_read.p, b->read_arena, b->read_bytes, hipMemcpyHostToDevice, s));
 
-    // ---- (row, cell) / (row, cell, umi) group structure: depends only on the records ----
-    c->n_cell_groups = c->n_umi_groups = 0;
-    if (nr) {
-        HIP_TRY(c, vtxk_group_heads(c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), nr,
-                                    c->d_head_cell.as<uint32_t>(), c->d_head_umi.as<uint32_t>(), s));
-        HIP_TRY(c, vtxk_inclusive_scan_u32(c->d_head_cell.as<uint32_t>(), c->d_cell_scan.as<uint32_t>(), nr, c->d_scan_tmp.p, tmp_bytes, s));
-        HIP_TRY(c, vtxk_inclusive_scan_u32(c->d_head_umi.as<uint32_t>(), c->d_umi_scan.as<uint32_t>(), nr, c->d_scan_tmp.p, tmp_bytes, s));
-        HIP_TRY(c, vtxk_group_table(c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), nr,
-                                    c->d_head_cell.as<uint32_t>(), c->d_head_umi.as<uint32_t>(), c->d_cell_scan.as<uint32_t>(),
-                                    c->d_umi_scan.as<uint32_t>(), c->d_grp_row.as<uint32_t>(), c->d_grp_col.as<uint32_t>(),
-                                    c->d_umi_cellgrp.as<uint32_t>(), s));
-        HIP_TRY(c, hipMemcpyAsync(&c->n_cell_groups, c->d_cell_scan.as<uint32_t>() + (nr - 1), u32, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(&c->n_umi_groups, c->d_umi_scan.as<uint32_t>() + (nr - 1), u32, hipMemcpyDeviceToHost, s));
-    }
+    if (int rc = build_groups(c, nr)) return rc;
     // rec_locus / work are host vectors: the copies must land before they die
     HIP_TRY(c, hipStreamSynchronize(s));
     c->n_loci = nl; c->n_records = nr; c->max_hap_len = max_hap; c->max_read_len = max_read; c->cells = cells;
     c->submitted = true;
+    return VTX_OK;
+}
+
+int vtx_set_barcodes(vtx_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint32_t n) {
+    if (!c) return VTX_E_INVAL;
+    if (!offsets || (n && !bytes && offsets[n] > offsets[0])) return fail(c, VTX_E_INVAL, "vtx_set_barcodes: null argument");
+    if (n != c->cfg.n_barcodes) return fail(c, VTX_E_INVAL, "vtx_set_barcodes: %u barcodes, cfg.n_barcodes is %u", n, c->cfg.n_barcodes);
+    c->bc_ready = false;
+    for (uint32_t j = 0; j < n; ++j) {
+        if (offsets[j + 1] < offsets[j]) return fail(c, VTX_E_INVAL, "vtx_set_barcodes: offsets not ascending at %u", j);
+        if (offsets[j + 1] - offsets[j] >= VTX_TAG_MISSING) return fail(c, VTX_E_UNSUPPORTED, "vtx_set_barcodes: barcode %u longer than 65534 bytes", j);
+    }
+    // open addressing, load <= 1/2; slot = index + 1, 0 = empty.  Duplicated byte strings keep the first index (:704-710).
+    uint32_t cap = 16;
+    while (cap < 2ull * n) cap <<= 1;
+    std::vector<uint32_t> slots(cap, 0);
+    std::vector<uint64_t> hashes(std::max(n, 1u));
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint8_t* b = bytes + offsets[j];
+        const uint32_t len = (uint32_t)(offsets[j + 1] - offsets[j]);
+        const uint64_t h = vtx_hash_bytes(b, len, 0);
+        hashes[j] = h;
+        bool dup = false;
+        uint32_t sidx = (uint32_t)h & (cap - 1);
+        for (; slots[sidx]; sidx = (sidx + 1) & (cap - 1)) {
+            const uint32_t k = slots[sidx] - 1;
+            if (hashes[k] == h && offsets[k + 1] - offsets[k] == len && memcmp(bytes + offsets[k], b, len) == 0) { dup = true; break; }
+        }
+        if (!dup) slots[sidx] = j + 1;
+    }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const uint64_t nbytes = n ? offsets[n] : 0;
+    HIP_TRY(c, c->d_bc_slots.reserve(cap * sizeof(uint32_t)));
+    HIP_TRY(c, c->d_bc_hash.reserve(hashes.size() * sizeof(uint64_t)));
+    HIP_TRY(c, c->d_bc_off.reserve(((size_t)n + 1) * sizeof(uint64_t)));
+    HIP_TRY(c, c->d_bc_bytes.reserve(nbytes + 16));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->d_bc_slots.p, slots.data(), cap * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_bc_hash.p, hashes.data(), hashes.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_bc_off.p, offsets, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    if (nbytes) HIP_TRY(c, hipMemcpyAsync(c->d_bc_bytes.p, bytes, nbytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->bc_mask = cap - 1;
+    c->bc_ready = true;
+    return VTX_OK;
+}
+
+int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
+    if (!c) return VTX_E_INVAL;
+    if (!b) return fail(c, VTX_E_INVAL, "vtx_submit_raw: null batch");
+    c->submitted = false; c->ran = false;
+    if (!c->bc_ready) return fail(c, VTX_E_STATE, "vtx_submit_raw: no barcode list (vtx_set_barcodes)");
+    const uint32_t nl = b->n_loci, nr = b->n_records;
+    if ((nl && !b->loci) || (nr && !b->records) || (b->hap_bytes && !b->hap_arena) || (b->read_bytes && !b->read_arena) ||
+        (b->tag_bytes && !b->tag_arena))
+        return fail(c, VTX_E_INVAL, "vtx_submit_raw: null array with non-zero count");
+    if (b->hap_bytes > 0xffffffffull || b->read_bytes > 0xffffffffull || b->tag_bytes > 0xffffffffull)
+        return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_raw: arenas above 4 GiB need more than one batch");
+    // loci: host validation is O(loci); everything per record happens on the device
+    uint32_t next_rec = 0, max_hap = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+        const vtx_locus& L = b->loci[l];
+        if (L.rec_begin != next_rec) return fail(c, VTX_E_INVAL, "vtx_submit_raw: locus %u: records not contiguous (rec_begin %u, expected %u)", l, L.rec_begin, next_rec);
+        if ((uint64_t)L.rec_begin + L.rec_count > nr) return fail(c, VTX_E_INVAL, "vtx_submit_raw: locus %u: record range exceeds n_records", l);
+        if ((uint64_t)L.ref_off + L.ref_len > b->hap_bytes || (uint64_t)L.alt_off + L.alt_len > b->hap_bytes)
+            return fail(c, VTX_E_INVAL, "vtx_submit_raw: locus %u: haplotype outside hap_arena", l);
+        if (L.ref_len > kMaxHapLen || L.alt_len > kMaxHapLen)
+            return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_raw: locus %u: haplotype longer than %u", l, kMaxHapLen);
+        max_hap = std::max(max_hap, std::max(L.ref_len, L.alt_len));
+        next_rec = L.rec_begin + L.rec_count;
+    }
+    if (next_rec != nr) return fail(c, VTX_E_INVAL, "vtx_submit_raw: %u records not covered by any locus", nr - next_rec);
+
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    const size_t u32 = sizeof(uint32_t), u64 = sizeof(uint64_t);
+    HIP_TRY(c, c->d_loci.reserve((size_t)nl * sizeof(vtx_locus)));
+    HIP_TRY(c, c->d_hap.reserve(b->hap_bytes + 16));
+    HIP_TRY(c, c->d_read.reserve(b->read_bytes + 16));
+    HIP_TRY(c, c->d_tags.reserve(b->tag_bytes + 16));
+    HIP_TRY(c, c->d_raw.reserve((size_t)nr * sizeof(vtx_raw_record)));
+    if (int rc = reserve_record_buffers(c, nr)) return rc;
+    DevBuf* k64[] = {&c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2};
+    for (DevBuf* d : k64) HIP_TRY(c, d->reserve(nr * u64));
+    DevBuf* k32[] = {&c->d_raw_locus, &c->d_idx, &c->d_idx2, &c->d_seq};
+    for (DevBuf* d : k32) HIP_TRY(c, d->reserve(nr * u32));
+    HIP_TRY(c, c->d_shape.reserve(nr + 16));
+    HIP_TRY(c, c->d_shape2.reserve(nr + 16));
+    HIP_TRY(c, c->d_locus_cnt.reserve(((size_t)nl + 1) * u32));
+    HIP_TRY(c, c->d_locus_scan.reserve(((size_t)nl + 1) * u32));
+    HIP_TRY(c, c->d_prep_cnt.reserve(8 * u64 + 32 * u32));
+    const size_t sort_tmp = vtxk_prep_sort_temp_bytes(nr);
+    HIP_TRY(c, c->d_sort_tmp.reserve(std::max(sort_tmp, vtxk_scan_temp_bytes(std::max(nr, nl)))));
+    unsigned long long* d_counters = c->d_prep_cnt.as<unsigned long long>();
+    uint32_t* d_shape_cnt = (uint32_t*)(d_counters + 8);
+    uint32_t* d_lut_flag = d_shape_cnt + 16;
+    uint32_t caps[kNumShapes];
+    for (int i = 0; i < kNumShapes; ++i) caps[i] = (uint32_t)(kShapes[i][0] * kShapes[i][1]);
+    HIP_TRY(c, vtxk_prep_set_shapes(caps, kNumShapes));
+
+    if (nl) HIP_TRY(c, hipMemcpyAsync(c->d_loci.p, b->loci, (size_t)nl * sizeof(vtx_locus), hipMemcpyHostToDevice, s));
+    if (nr) HIP_TRY(c, hipMemcpyAsync(c->d_raw.p, b->records, (size_t)nr * sizeof(vtx_raw_record), hipMemcpyHostToDevice, s));
+    if (b->hap_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_hap.p, b->hap_arena, b->hap_bytes, hipMemcpyHostToDevice, s));
+    if (b->read_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_read.p, b->read_arena, b->read_bytes, hipMemcpyHostToDevice, s));
+    if (b->tag_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_tags.p, b->tag_arena, b->tag_bytes, hipMemcpyHostToDevice, s));
+
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    const uint32_t cell_bits = bits_for(c->cfg.n_barcodes ? c->cfg.n_barcodes - 1 : 0);
+    const int end_bit = (int)(cell_bits + bits_for(nl));
+    if (end_bit > 64) return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_raw: loci x barcodes exceed a 64-bit sort key");
+    const int use_umi = c->cfg.use_umi ? 1 : 0;
+    unsigned long long cnt[8] = {0};
+    uint32_t n_kept = 0, rounds = 0;
+    // test hook: the first N rounds hash every UMI to 0, so that the collision check and the re-seed are exercised
+    const uint32_t weak_rounds = getenv("VTX_PREP_WEAK_ROUNDS") ? (uint32_t)atoi(getenv("VTX_PREP_WEAK_ROUNDS")) : 0;
+    if (nr) HIP_TRY(c, vtxk_prep_rec_locus(c->d_loci.as<vtx_locus>(), nl, c->d_raw_locus.as<uint32_t>(), s));
+    for (uint64_t seed = 0x9e3779b97f4a7c15ull;; seed = seed * 0xd1342543de82ef95ull + 1) {
+        ++rounds;
+        HIP_TRY(c, hipMemsetAsync(c->d_prep_cnt.p, 0, 8 * u64 + 32 * u32, s));
+        HIP_TRY(c, hipMemsetAsync(c->d_locus_cnt.p, 0, ((size_t)nl + 1) * u32, s));
+        HIP_TRY(c, vtxk_prep_resolve(c->d_raw.as<vtx_raw_record>(), nr, c->d_raw_locus.as<uint32_t>(), c->d_tags.as<uint8_t>(),
+                                     b->tag_bytes, b->read_bytes, kMaxReadLen, c->d_bc_slots.as<uint32_t>(), c->bc_mask,
+                                     c->d_bc_hash.as<uint64_t>(), c->d_bc_off.as<uint64_t>(), c->d_bc_bytes.as<uint8_t>(),
+                                     use_umi, seed, rounds <= weak_rounds ? 0ull : ~0ull, cell_bits, nl, c->d_key_lc.as<uint64_t>(), c->d_key_umi.as<uint64_t>(),
+                                     c->d_idx.as<uint32_t>(), d_counters, s));
+        HIP_TRY(c, hipMemcpyAsync(cnt, d_counters, 3 * u64, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (cnt[2]) return fail(c, VTX_E_INVAL, "vtx_submit_raw: a record points outside its arena or is longer than %u bases", kMaxReadLen);
+        n_kept = nr - (uint32_t)cnt[0] - (uint32_t)cnt[1];
+        // stable LSD order: UMI hash first, then (locus, cell); dropped records carry the largest key and end up last
+        const uint32_t* perm = nullptr;
+        const uint64_t* key_sorted = nullptr;
+        if (use_umi) {
+            HIP_TRY(c, vtxk_prep_sort_u64(c->d_key_umi.as<uint64_t>(), c->d_key_umi2.as<uint64_t>(), c->d_idx.as<uint32_t>(),
+                                          c->d_idx2.as<uint32_t>(), nr, 64, c->d_sort_tmp.p, sort_tmp, s));
+            HIP_TRY(c, vtxk_prep_gather_u64(c->d_key_lc.as<uint64_t>(), c->d_idx2.as<uint32_t>(), nr, c->d_key_lc2.as<uint64_t>(), s));
+            HIP_TRY(c, vtxk_prep_sort_u64(c->d_key_lc2.as<uint64_t>(), c->d_key_umi2.as<uint64_t>(), c->d_idx2.as<uint32_t>(),
+                                          c->d_idx.as<uint32_t>(), nr, end_bit, c->d_sort_tmp.p, sort_tmp, s));
+            perm = c->d_idx.as<uint32_t>(); key_sorted = c->d_key_umi2.as<uint64_t>();
+        } else {
+            HIP_TRY(c, vtxk_prep_sort_u64(c->d_key_lc.as<uint64_t>(), c->d_key_lc2.as<uint64_t>(), c->d_idx.as<uint32_t>(),
+                                          c->d_idx2.as<uint32_t>(), nr, end_bit, c->d_sort_tmp.p, sort_tmp, s));
+            perm = c->d_idx2.as<uint32_t>(); key_sorted = c->d_key_lc2.as<uint64_t>();
+        }
+        HIP_TRY(c, vtxk_prep_finalize(n_kept, perm, key_sorted, c->d_key_umi.as<uint64_t>(), c->d_raw.as<vtx_raw_record>(),
+                                      c->d_tags.as<uint8_t>(), c->d_loci.as<vtx_locus>(), cell_bits, use_umi, kNumShapes,
+                                      c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_head_umi.as<uint32_t>(),
+                                      c->d_shape.as<uint8_t>(), c->d_seq.as<uint32_t>(), c->d_locus_cnt.as<uint32_t>(),
+                                      d_shape_cnt, d_counters, s));
+        HIP_TRY(c, hipMemcpyAsync(cnt, d_counters, 6 * u64, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (!cnt[4]) break;                  // no UMI hash collision inside a (locus, cell) group
+        if (rounds == 8) return fail(c, VTX_E_STATE, "vtx_submit_raw: UMI hash collisions with 8 different seeds");
+    }
+    const size_t scan_tmp = vtxk_scan_temp_bytes(std::max(nr, nl));
+    // dense UMI group numbers; per-locus record ranges of the kept, sorted records
+    if (n_kept) {
+        HIP_TRY(c, vtxk_inclusive_scan_u32(c->d_head_umi.as<uint32_t>(), c->d_umi_scan.as<uint32_t>(), n_kept, c->d_sort_tmp.p, scan_tmp, s));
+        HIP_TRY(c, vtxk_prep_umi_ids(c->d_records.as<vtx_record>(), c->d_umi_scan.as<uint32_t>(), n_kept, s));
+    }
+    if (nl) {
+        HIP_TRY(c, vtxk_inclusive_scan_u32(c->d_locus_cnt.as<uint32_t>(), c->d_locus_scan.as<uint32_t>(), nl, c->d_sort_tmp.p, scan_tmp, s));
+        HIP_TRY(c, vtxk_prep_locus_ranges(c->d_loci.as<vtx_locus>(), c->d_locus_cnt.as<uint32_t>(), c->d_locus_scan.as<uint32_t>(), nl, s));
+    }
+    // work lists per kernel shape: stable sort of the record numbers by shape
+    HIP_TRY(c, vtxk_prep_sort_u8(c->d_shape.as<uint8_t>(), c->d_shape2.as<uint8_t>(), c->d_seq.as<uint32_t>(), c->d_work.as<uint32_t>(),
+                                 n_kept, c->d_sort_tmp.p, sort_tmp, s));
+    uint32_t shape_cnt[16] = {0};
+    HIP_TRY(c, hipMemcpyAsync(shape_cnt, d_shape_cnt, sizeof shape_cnt, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->buckets.clear();
+    uint32_t off = 0;
+    for (int sh = 0; sh < kNumShapes; ++sh) {
+        if (!shape_cnt[sh]) continue;
+        const bool lut = kShapes[sh][1] == 16 && (size_t)kLutLociCap * (max_hap + 36) * 6 * 4 <= 96 * 1024;
+        if (lut) HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), kLutLociCap,
+                                                d_lut_flag + c->buckets.size(), s));
+        c->buckets.push_back(Bucket{kShapes[sh][0], kShapes[sh][1], off, shape_cnt[sh], lut});
+        off += shape_cnt[sh];
+    }
+    uint32_t lut_flag[16] = {0};
+    HIP_TRY(c, hipMemcpyAsync(lut_flag, d_lut_flag, sizeof lut_flag, hipMemcpyDeviceToHost, s));
+    if (int rc = build_groups(c, n_kept)) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (size_t i = 0; i < c->buckets.size(); ++i) if (lut_flag[i]) c->buckets[i].lut = false;
+    float ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->n_loci = nl; c->n_records = n_kept; c->max_hap_len = max_hap; c->max_read_len = (uint32_t)cnt[5]; c->cells = cnt[3];
+    c->submitted = true;
+    if (stats) {
+        stats->num_not_cell_bc = cnt[0]; stats->num_non_umi = cnt[1]; stats->kept = n_kept; stats->prep_ms = ms;
+        stats->hash_rounds = rounds;
+    }
+    return VTX_OK;
+}
+
+int vtx_fetch_records(vtx_ctx* c, vtx_record* records, uint32_t* rec_begin, uint32_t* rec_count) {
+    if (!c) return VTX_E_INVAL;
+    if (!c->submitted) return fail(c, VTX_E_STATE, "vtx_fetch_records: no batch submitted");
+    if ((c->n_records && !records) || (c->n_loci && (!rec_begin || !rec_count))) return fail(c, VTX_E_INVAL, "vtx_fetch_records: null output");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (c->n_records) HIP_TRY(c, hipMemcpy(records, c->d_records.p, (size_t)c->n_records * sizeof(vtx_record), hipMemcpyDeviceToHost));
+    if (c->n_loci) {
+        std::vector<vtx_locus> loci(c->n_loci);
+        HIP_TRY(c, hipMemcpy(loci.data(), c->d_loci.p, (size_t)c->n_loci * sizeof(vtx_locus), hipMemcpyDeviceToHost));
+        for (uint32_t l = 0; l < c->n_loci; ++l) { rec_begin[l] = loci[l].rec_begin; rec_count[l] = loci[l].rec_count; }
+    }
     return VTX_OK;
 }
 

@@ -7,6 +7,14 @@
 
 #include "../../include/vtx.h"
 
+// 64-bit hash of a tag byte string (FNV-1a + fmix64), identical on host (barcode table build) and device
+static __host__ __device__ inline uint64_t vtx_hash_bytes(const uint8_t* p, uint32_t n, uint64_t seed) {
+    uint64_t h = (0xcbf29ce484222325ull ^ seed) + n;
+    for (uint32_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+    h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
+    return h;
+}
+
 extern "C" {
 hipError_t vtxk_launch_sw_full(int R, int GL, uint32_t n_work, const uint32_t* work, const vtx_record* records,
                                const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
@@ -54,5 +62,28 @@ hipError_t vtxk_emit_coo(const uint32_t* cell_cnt, uint32_t n_grp, int mode, con
 hipError_t vtxk_inclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes,
                                    hipStream_t s);
 size_t vtxk_scan_temp_bytes(uint32_t n);
+// ---- vtx_prep.hip: device-side preparation of raw batches ----
+hipError_t vtxk_prep_set_shapes(const uint32_t* caps, uint32_t n);
+size_t vtxk_prep_sort_temp_bytes(uint32_t n);
+hipError_t vtxk_prep_sort_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                              uint32_t n, int end_bit, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t vtxk_prep_sort_u8(const uint8_t* keys_in, uint8_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                             uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t vtxk_prep_rec_locus(const vtx_locus* loci, uint32_t n_loci, uint32_t* rec_locus, hipStream_t s);
+hipError_t vtxk_prep_resolve(const vtx_raw_record* raw, uint32_t n, const uint32_t* rec_locus, const uint8_t* tags,
+                             uint64_t tag_bytes, uint64_t read_bytes, uint32_t max_read_len, const uint32_t* bc_slots,
+                             uint32_t bc_mask, const uint64_t* bc_hash, const uint64_t* bc_off, const uint8_t* bc_bytes,
+                             int use_umi, uint64_t seed, uint64_t hash_mask, uint32_t cell_bits, uint32_t n_loci,
+                             uint64_t* key_lc, uint64_t* key_umi, uint32_t* idx, unsigned long long* counters, hipStream_t s);
+hipError_t vtxk_prep_gather_u64(const uint64_t* src, const uint32_t* idx, uint32_t n, uint64_t* dst, hipStream_t s);
+hipError_t vtxk_prep_finalize(uint32_t n_kept, const uint32_t* perm, const uint64_t* key_lc_sorted, const uint64_t* key_umi,
+                              const vtx_raw_record* raw, const uint8_t* tags, const vtx_locus* loci, uint32_t cell_bits,
+                              int use_umi, uint32_t n_shapes, vtx_record* records, uint32_t* rec_locus, uint32_t* umi_head,
+                              uint8_t* shape, uint32_t* seq, uint32_t* locus_cnt, uint32_t* shape_cnt,
+                              unsigned long long* counters, hipStream_t s);
+hipError_t vtxk_prep_umi_ids(vtx_record* records, const uint32_t* umi_scan, uint32_t n, hipStream_t s);
+hipError_t vtxk_prep_locus_ranges(vtx_locus* loci, const uint32_t* cnt, const uint32_t* cnt_scan, uint32_t n_loci, hipStream_t s);
+hipError_t vtxk_prep_lut_check(const uint32_t* work, uint32_t count, const uint32_t* rec_locus, uint32_t cap, uint32_t* flag,
+                               hipStream_t s);
 }
 #endif

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libvtx.so")
 SYMBOLS = (
     "vtx_config_default", "vtx_create", "vtx_destroy", "vtx_submit", "vtx_run", "vtx_fetch_scores",
     "vtx_fetch_coo", "vtx_device_scores", "vtx_device_coo", "vtx_last_timing", "vtx_last_cells", "vtx_strerror",
-    "vtx_status_name", "vtx_abi_sizes",
+    "vtx_status_name", "vtx_abi_sizes", "vtx_set_barcodes", "vtx_submit_raw", "vtx_fetch_records",
 )
 
 
@@ -53,6 +53,12 @@ def load():
     L.vtx_submit.argtypes = [ctxp, C.POINTER(abi.VtxBatch)]
     L.vtx_run.restype = C.c_int
     L.vtx_run.argtypes = [ctxp]
+    L.vtx_set_barcodes.restype = C.c_int
+    L.vtx_set_barcodes.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.vtx_submit_raw.restype = C.c_int
+    L.vtx_submit_raw.argtypes = [ctxp, C.POINTER(abi.VtxRawBatch), C.POINTER(abi.VtxRawStats)]
+    L.vtx_fetch_records.restype = C.c_int
+    L.vtx_fetch_records.argtypes = [ctxp, C.c_void_p, C.c_void_p, C.c_void_p]
     L.vtx_fetch_scores.restype = C.c_int
     L.vtx_fetch_scores.argtypes = [ctxp, C.c_void_p, C.c_void_p]
     L.vtx_fetch_coo.restype = C.c_int
@@ -116,6 +122,33 @@ class Context:
         st = batch.as_struct()
         self._check(self._L.vtx_submit(self._h, C.byref(st)))
         self.n_records = batch.n_records
+        self._n_loci = batch.n_loci
+
+    def set_barcodes(self, barcodes):
+        """Barcode list (bytes objects, index = matrix column) for ``submit_raw``; load_barcodes, src/main.rs:697-718."""
+        blobs = [b if isinstance(b, bytes) else b.encode() for b in barcodes]
+        offsets = np.zeros(len(blobs) + 1, np.uint64)
+        np.cumsum([len(b) for b in blobs], out=offsets[1:])
+        data = np.frombuffer(b"".join(blobs), np.uint8) if blobs else np.zeros(0, np.uint8)
+        data = np.ascontiguousarray(data)
+        self._check(self._L.vtx_set_barcodes(self._h, data.ctypes.data if data.size else None, offsets.ctypes.data, len(blobs)))
+
+    def submit_raw(self, raw: abi.RawBatch) -> abi.VtxRawStats:
+        st = raw.as_struct()
+        stats = abi.VtxRawStats()
+        self._check(self._L.vtx_submit_raw(self._h, C.byref(st), C.byref(stats)))
+        self.n_records = int(stats.kept)
+        self._n_loci = raw.n_loci
+        return stats
+
+    def fetch_records(self):
+        """Resolved, sorted records of the resident batch + per-locus (rec_begin, rec_count)."""
+        recs = np.zeros(self.n_records, abi.RECORD_DTYPE)
+        nl = getattr(self, "_n_loci", 0)
+        begin = np.zeros(nl, np.uint32)
+        count = np.zeros(nl, np.uint32)
+        self._check(self._L.vtx_fetch_records(self._h, recs.ctypes.data, begin.ctypes.data, count.ctypes.data))
+        return recs, begin, count
 
     def run(self):
         self._check(self._L.vtx_run(self._h))

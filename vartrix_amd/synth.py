@@ -300,3 +300,66 @@ def config4() -> SynthSpec:   # 100k loci x 50k barcodes, sharded across 8 GPUs
 
 def config5(n_loci: int = 100_000) -> SynthSpec:   # mixed SNV + indel, alt_frac + UMI
     return SynthSpec(n_loci=n_loci, n_barcodes=10_000, indel_frac=0.30, use_umi=True)
+
+
+def make_raw(batch: PackedBatch, n_barcodes: int, use_umi: bool, seed: int = 1, frac_unlisted: float = 0.05,
+             frac_no_umi: float = 0.02, dup_barcodes: int = 0):
+    """Raw form of a packed batch (payload of ``vtx_submit_raw``) -> (RawBatch, barcode list).
+
+    Every record gets the tag bytes of its cell (16-mer + "-1") and UMI (10-mer, injective in umi_id);
+    ``frac_unlisted`` extra records carry a barcode that is not in the list, ``frac_no_umi`` extra records
+    have no UB tag, records are shuffled inside their locus (BAM order is arbitrary with respect to cells),
+    and ``dup_barcodes`` list entries are repeated at the end of the list (first index must win)."""
+    from .abi import RAW_RECORD_DTYPE, TAG_MISSING, RawBatch
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+
+    def kmer(ids: np.ndarray, k: int, salt: int) -> np.ndarray:   # injective base-4 text of (ids * odd + salt) mod 4^k
+        v = (ids.astype(np.uint64) * np.uint64(2654435761) + np.uint64(salt)) % np.uint64(4 ** k)
+        digits = (v[:, None] >> (np.uint64(2) * np.arange(k, dtype=np.uint64)[None, :])) & np.uint64(3)
+        return acgt[digits.astype(np.int64)]
+
+    bc_text = np.concatenate([kmer(np.arange(n_barcodes), 16, 12345), np.tile(np.frombuffer(b"-1", np.uint8), (n_barcodes, 1))], axis=1)
+    barcodes = [bytes(row) for row in bc_text]
+    if dup_barcodes:
+        barcodes += barcodes[:dup_barcodes]
+    unlisted = kmer(np.arange(64), 16, 999)                        # 16 bytes, no "-1": never in the list
+    nl = batch.n_loci
+    counts = batch.loci["rec_count"].astype(np.int64)
+    extra_bc = rng.binomial(counts, frac_unlisted) if frac_unlisted > 0 else np.zeros(nl, np.int64)
+    extra_umi = rng.binomial(counts, frac_no_umi) if frac_no_umi > 0 else np.zeros(nl, np.int64)
+    new_counts = counts + extra_bc + extra_umi
+    n_new = int(new_counts.sum())
+    loc_of = np.repeat(np.arange(nl), new_counts)
+    begin_new = np.concatenate([[0], np.cumsum(new_counts)[:-1]]).astype(np.int64)
+    pos = np.arange(n_new) - begin_new[loc_of]                     # position inside the locus, before the shuffle
+    kind = np.where(pos < counts[loc_of], 0, np.where(pos < (counts + extra_bc)[loc_of], 1, 2))
+    # source record: the original one, or (extras) a random record of the same locus
+    src = batch.loci["rec_begin"].astype(np.int64)[loc_of] + np.where(kind == 0, pos, 0)
+    has = counts[loc_of] > 0
+    rnd = (rng.random(n_new) * np.maximum(counts[loc_of], 1)).astype(np.int64)
+    src = np.where(kind == 0, src, batch.loci["rec_begin"].astype(np.int64)[loc_of] + rnd)
+    keep = has | (kind == 0)
+    loc_of, kind, src = loc_of[keep], kind[keep], src[keep]
+    # shuffle inside each locus
+    order = np.lexsort((rng.random(loc_of.shape[0]), loc_of))
+    loc_of, kind, src = loc_of[order], kind[order], src[order]
+    n = loc_of.shape[0]
+    rec = batch.records[src]
+    # tag arena: per record 18 barcode bytes + 10 UMI bytes
+    tags = np.zeros((n, 28), np.uint8)
+    tags[:, :18] = bc_text[rec["cell_index"].astype(np.int64)]
+    bad = kind == 1
+    tags[bad, :16] = unlisted[rng.integers(0, 64, int(bad.sum()))]
+    tags[:, 18:] = kmer(rec["umi_id"].astype(np.int64), 10, 777)
+    raw = np.zeros(n, RAW_RECORD_DTYPE)
+    raw["read_off"], raw["read_len"] = rec["read_off"], rec["read_len"]
+    raw["bc_off"] = np.arange(n, dtype=np.int64) * 28
+    raw["bc_len"] = np.where(bad, 16, 18)
+    raw["umi_off"] = raw["bc_off"] + 18
+    raw["umi_len"] = np.where(kind == 2, TAG_MISSING, 10) if use_umi else np.where(rng.random(n) < 0.5, TAG_MISSING, 10)
+    loci = batch.loci.copy()
+    cnt = np.bincount(loc_of, minlength=nl)
+    loci["rec_count"] = cnt
+    loci["rec_begin"] = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    return RawBatch(loci, raw, batch.hap_arena, batch.read_arena, tags.reshape(-1)), barcodes
