@@ -60,6 +60,17 @@ int vtxh_pack_files(const vtxh_args* args, vtxh_pack** out);
 void vtxh_free(vtxh_pack* p);
 const char* vtxh_last_error(void);
 
+/* Same ingest, but everything per-read that follows the alignment-level filters — barcode
+ * dictionary lookup (:867-876), UB test (:879-888), UMI grouping (:1047-1057) and the sort by
+ * cell (:932) — is left to the device (vtx_submit_raw in vtx.h): records stay in BAM order inside
+ * a locus, barcode / UMI travel as tag bytes.  Metrics: num_not_cell_bc counts only the reads
+ * WITHOUT a usable barcode tag (the in-list test happens on the device) and num_non_umi is 0;
+ * add vtx_raw_stats to both.                                                                    */
+int vtxh_pack_files_raw(const vtxh_args* args, vtxh_pack** out);
+void vtxh_get_raw_batch(const vtxh_pack* p, vtx_raw_batch* out);
+/* The barcode list in the layout vtx_set_barcodes takes (n = vtxh_num_barcodes). */
+void vtxh_get_barcode_table(const vtxh_pack* p, const uint8_t** bytes, const uint64_t** offsets, uint32_t* n);
+
 /* The packed batch (pointers valid until vtxh_free). */
 void vtxh_get_batch(const vtxh_pack* p, vtx_batch* out);
 void vtxh_get_metrics(const vtxh_pack* p, vtxh_metrics* out);

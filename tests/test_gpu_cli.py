@@ -72,10 +72,11 @@ def test_coverage_mode_without_ref_matrix_flag_writes_only_main(tmp_path):
     assert os.path.exists(out) and not os.path.exists(tmp_path / "ref_matrix.mtx")
 
 
+@pytest.mark.parametrize("prep", ["host", "device"])
 @pytest.mark.parametrize("aligner", ["banded", "full"])
 @pytest.mark.parametrize("mode", ["consensus", "alt_frac", "coverage"])
 @pytest.mark.parametrize("umi", [False, True])
-def test_authored_indel_bam_end_to_end(tmp_path, mode, umi, aligner):
+def test_authored_indel_bam_end_to_end(tmp_path, mode, umi, aligner, prep):
     """test_dna.vcf (SNV + INS + DEL + multi-allelic) over an authored BAM: CLI output is byte-identical to
     the oracle pipeline (Python ingest restatement + C oracle, same aligner flavour) rendered as .mtx."""
     from tests.test_host import make_dna_bam
@@ -83,11 +84,15 @@ def test_authored_indel_bam_end_to_end(tmp_path, mode, umi, aligner):
     vcfp, fap, bcp = (os.path.join(G, n) for n in ("test_dna.vcf", "test_dna.fa", "dna_barcodes.tsv"))
     out, ref = str(tmp_path / "out.mtx"), str(tmp_path / "ref.mtx")
     args = ["-v", vcfp, "-b", bam, "-f", fap, "-c", bcp, "-o", out, "-s", mode, "--ref-matrix", ref, "--threads", "4",
-            "--aligner", aligner]
-    run_cli(args + (["--umi"] if umi else []), tmp_path)
+            "--aligner", aligner, "--prep", prep, "--log-level", "info"]
+    r = run_cli(args + (["--umi"] if umi else []), tmp_path)
     bcs = refpipe.load_barcodes(bcp)
     vcf = refpipe.read_vcf(vcfp)
-    batch, _ = refpipe.pack(vcf, refpipe.read_fasta(fap), refpipe.read_bam(bam), bcs, refpipe.Args(use_umi=umi))
+    batch, wm = refpipe.pack(vcf, refpipe.read_fasta(fap), refpipe.read_bam(bam), bcs, refpipe.Args(use_umi=umi))
+    # the counters of the log (:350-379) are the same whichever side did the barcode / UMI tests
+    log = r.stdout + r.stderr
+    assert "not being associated with a cell barcode: %d\n" % wm["num_not_cell_bc"] in log
+    assert "not having a UMI: %d\n" % wm["num_non_umi"] in log
     cfg = default_config(aligner=aligner, scoring_mode=mode, use_umi=int(umi), n_barcodes=len(bcs))
     r, a = oracle.batch_scores(batch, cfg, threads=8)
     coo = oracle.batch_reduce(batch, cfg, r, a)
@@ -95,3 +100,16 @@ def test_authored_indel_bam_end_to_end(tmp_path, mode, umi, aligner):
     if mode == "coverage":
         assert open(ref).read() == refpipe.mtx_text(len(vcf), len(bcs), coo["row"], coo["col"], coo["ref_value"])
     assert len(coo["row"]) > 50
+
+
+@pytest.mark.parametrize("umi", [False, True])
+def test_reference_fixtures_with_device_prep(tmp_path, umi):
+    """The reference's coverage fixtures (src/main.rs:1266-1339) with barcode lookup / UMI grouping / sort on the GPU."""
+    out, ref = str(tmp_path / "out.mtx"), str(tmp_path / "ref.mtx")
+    run_cli(base_args() + ["-o", out, "-s", "coverage", "--ref-matrix", ref, "--prep", "device"] + (["--umi"] if umi else []), tmp_path)
+    sfx = "_umi" if umi else ""
+    assert csr(out) == csr(os.path.join(G, "test_coverage%s.mtx" % sfx))         # the reference compares CSR (:1296-1299)
+    assert csr(ref) == csr(os.path.join(G, "test_coverage_ref%s.mtx" % sfx))
+    out2 = str(tmp_path / "c.mtx")
+    run_cli(base_args() + ["-o", out2, "--prep", "device", "--devices", "1"], tmp_path)
+    assert open(out2).read() == open(os.path.join(G, "test_consensus.mtx")).read()

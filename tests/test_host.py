@@ -207,3 +207,38 @@ def test_cli_refuses_existing_output_and_missing_input(tmp_path):
     assert r.returncode == 1
     r = _cli(["-v", i["vcf"]], tmp_path)
     assert r.returncode == 1 and "required" in r.stderr
+
+
+def _raw_equals_cooked(inputs, **kw):
+    """Raw packer output, resolved / filtered / sorted by the oracle restatement (oracle/prep.py), must be the
+    cooked packer's batch; the counters the raw packer leaves to the device are the difference of the metrics."""
+    from oracle import prep
+    cooked, m, nv, barcodes, variants = hostlib.pack_files(**kw, **inputs)
+    raw, mr, nvr, barcodes_r, variants_r = hostlib.pack_files(raw=True, **kw, **inputs)
+    assert (nv, barcodes, variants) == (nvr, barcodes_r, variants_r)
+    got, st = prep.prep_raw(raw, barcodes, bool(kw.get("use_umi", False)))
+    for k in m:
+        if k == "num_not_cell_bc":
+            assert mr[k] + st["num_not_cell_bc"] == m[k]
+        elif k == "num_non_umi":
+            assert mr[k] == 0 and st["num_non_umi"] == m[k]
+        else:
+            assert mr[k] == m[k], k
+    assert same_batch(got, cooked)
+    return raw, cooked
+
+
+@pytest.mark.parametrize("umi", [False, True])
+def test_raw_packer_equals_cooked_packer_on_reference_bam(umi):
+    raw, cooked = _raw_equals_cooked(_inputs(), use_umi=umi, threads=2)
+    assert raw.n_records >= cooked.n_records and raw.tag_arena.size > 0
+
+
+@pytest.mark.parametrize("umi", [False, True])
+def test_raw_packer_equals_cooked_packer_on_authored_bam(tmp_path, umi):
+    bam = make_dna_bam(tmp_path, seed=5, n_reads=900)
+    inputs = dict(vcf=os.path.join(G, "test_dna.vcf"), bam=bam, fasta=os.path.join(G, "test_dna.fa"),
+                  cell_barcodes=os.path.join(G, "dna_barcodes.tsv"))
+    for kw in ({}, {"mapq": 30, "no_duplicates": True}, {"primary_only": True, "padding": 40}):
+        raw, cooked = _raw_equals_cooked(inputs, use_umi=umi, **kw)
+    assert raw.n_records > cooked.n_records          # unlisted barcodes / missing UB are still in the raw batch

@@ -64,7 +64,7 @@ const Opt kOpts[] = {
     {"log-level", 0, false, "error"}, {"threads", 0, false, "1"}, {"mapq", 0, false, "0"},
     {"primary-alignments", 0, true, nullptr}, {"no-duplicates", 0, true, nullptr}, {"umi", 0, true, nullptr},
     {"bam-tag", 0, false, "CB"}, {"valid-chars", 0, false, "ATGCatgc"},
-    {"devices", 0, false, "1"}, {"aligner", 0, false, "banded"},
+    {"devices", 0, false, "1"}, {"aligner", 0, false, "banded"}, {"prep", 0, false, "host"},
 };
 
 void usage() {
@@ -74,7 +74,8 @@ void usage() {
             "  -p, --padding <INT> [100]   -s, --scoring-method consensus|coverage|alt_frac [consensus]\n"
             "  --ref-matrix <FILE> [ref_matrix.mtx]   --log-level info|debug|error [error]   --threads <INT> [1]\n"
             "  --mapq <INT> [0]   --primary-alignments   --no-duplicates   --umi   --bam-tag <TAG> [CB]\n"
-            "  --valid-chars <CHARS> [ATGCatgc]   --devices <INT> [1]   --aligner banded|full [banded]\n");
+            "  --valid-chars <CHARS> [ATGCatgc]   --devices <INT> [1]   --aligner banded|full [banded]\n"
+            "  --prep host|device [host]  (device: barcode lookup, UMI grouping and the sort run on the GPU)\n");
 }
 
 struct Shard {
@@ -82,6 +83,14 @@ struct Shard {
     std::vector<vtx_record> records;
     const uint8_t *haps, *reads;
     uint64_t hap_bytes, read_bytes;
+    // --prep device: raw records (tags as bytes) + the barcode table
+    bool raw = false;
+    std::vector<vtx_raw_record> raw_records;
+    const uint8_t *tags = nullptr, *bc_bytes = nullptr;
+    const uint64_t* bc_offsets = nullptr;
+    uint64_t tag_bytes = 0;
+    uint32_t n_bcs = 0;
+    vtx_raw_stats stats{};
     std::vector<uint32_t> row, col;
     std::vector<double> val, refval;
     std::string err;
@@ -95,7 +104,16 @@ void run_shard(Shard* s, vtx_config cfg) {
     vtx_batch b{s->loci.data(), (uint32_t)s->loci.size(), s->records.data(), (uint32_t)s->records.size(), s->haps,
                 s->hap_bytes, s->reads, s->read_bytes};
     vtx_coo coo{};
-    if ((s->rc = vtx_submit(ctx, &b)) || (s->rc = vtx_run(ctx)) || (s->rc = vtx_fetch_coo(ctx, &coo))) {
+    if (s->raw) {
+        vtx_raw_batch rb{s->loci.data(), (uint32_t)s->loci.size(), s->raw_records.data(), (uint32_t)s->raw_records.size(),
+                         s->haps, s->hap_bytes, s->reads, s->read_bytes, s->tags, s->tag_bytes};
+        if ((s->rc = vtx_set_barcodes(ctx, s->bc_bytes, s->bc_offsets, s->n_bcs)) || (s->rc = vtx_submit_raw(ctx, &rb, &s->stats))) {
+            s->err = vtx_strerror(ctx);
+            vtx_destroy(ctx);
+            return;
+        }
+    }
+    if ((!s->raw && (s->rc = vtx_submit(ctx, &b))) || (s->rc = vtx_run(ctx)) || (s->rc = vtx_fetch_coo(ctx, &coo))) {
         s->err = vtx_strerror(ctx);
         vtx_destroy(ctx);
         return;
@@ -177,8 +195,13 @@ int main(int argc, char** argv) {
     auto since = [](std::chrono::steady_clock::time_point t0) {
         return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     };
+    if (val["prep"] != "host" && val["prep"] != "device") {
+        fprintf(stderr, "error: '%s' isn't a valid value for '--prep <prep>'\n", val["prep"].c_str());
+        return 1;
+    }
+    const bool raw = val["prep"] == "device";
     vtxh_pack* pk = nullptr;
-    if (vtxh_pack_files(&ha, &pk) != 0) {
+    if ((raw ? vtxh_pack_files_raw(&ha, &pk) : vtxh_pack_files(&ha, &pk)) != 0) {
         printf("Vartrix error.\nError: %s\n", vtxh_last_error());
         return 1;
     }
@@ -191,7 +214,19 @@ int main(int argc, char** argv) {
 
     // ---- the hot path: loci sharded over --devices GPUs (contiguous row ranges by record count) ----
     vtx_batch full{};
-    vtxh_get_batch(pk, &full);
+    vtx_raw_batch full_raw{};
+    const uint8_t* bc_bytes = nullptr;
+    const uint64_t* bc_offsets = nullptr;
+    uint32_t bc_n = 0;
+    if (raw) {
+        vtxh_get_raw_batch(pk, &full_raw);
+        vtxh_get_barcode_table(pk, &bc_bytes, &bc_offsets, &bc_n);
+        full.loci = full_raw.loci; full.n_loci = full_raw.n_loci; full.n_records = full_raw.n_records;
+        full.hap_arena = full_raw.hap_arena; full.hap_bytes = full_raw.hap_bytes;
+        full.read_arena = full_raw.read_arena; full.read_bytes = full_raw.read_bytes;
+    } else {
+        vtxh_get_batch(pk, &full);
+    }
     vtx_config cfg;
     vtx_config_default(&cfg);
     if (val["aligner"] != "banded" && val["aligner"] != "full") {
@@ -220,13 +255,21 @@ int main(int argc, char** argv) {
             s.loci.assign(full.loci + cuts[(size_t)d], full.loci + cuts[(size_t)d + 1]);
             const uint32_t r0 = s.loci.empty() ? 0 : s.loci.front().rec_begin;
             const uint32_t r1 = s.loci.empty() ? 0 : s.loci.back().rec_begin + s.loci.back().rec_count;
-            s.records.assign(full.records + r0, full.records + r1);
+            if (raw) {
+                s.raw = true;
+                s.raw_records.assign(full_raw.records + r0, full_raw.records + r1);
+                s.tags = full_raw.tag_arena; s.tag_bytes = full_raw.tag_bytes;
+                s.bc_bytes = bc_bytes; s.bc_offsets = bc_offsets; s.n_bcs = bc_n;
+            } else {
+                s.records.assign(full.records + r0, full.records + r1);
+            }
             for (auto& L : s.loci) L.rec_begin -= r0;
             s.haps = full.hap_arena; s.hap_bytes = full.hap_bytes;       // arenas are shared read-only, offsets stay valid
             s.reads = full.read_arena; s.read_bytes = full.read_bytes;
         }
     }
-    LOG_INFO("Ingest + filter + pack: %.3f s (%u loci, %u scored reads)", t_ingest, full.n_loci, full.n_records);
+    LOG_INFO("Ingest + filter + pack: %.3f s (%u loci, %u %s)", t_ingest, full.n_loci, full.n_records,
+             raw ? "raw reads; barcode lookup / UMI grouping / sort on the device" : "scored reads");
     const auto t_dev = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
     for (int d = 0; d < ndev; ++d) {
@@ -250,6 +293,13 @@ int main(int argc, char** argv) {
     }
     vtxh_metrics m;
     vtxh_get_metrics(pk, &m);
+    for (auto& s : shards) {
+        if (!s.raw) continue;
+        m.num_not_cell_bc += s.stats.num_not_cell_bc;      // the in-list test ran on the device (:870-876)
+        m.num_non_umi += s.stats.num_non_umi;              // :879-888
+        LOG_INFO("Device preparation: %llu reads kept, %.3f ms, %u hash round(s)", (unsigned long long)s.stats.kept,
+                 (double)s.stats.prep_ms, s.stats.hash_rounds);
+    }
     LOG_INFO("Number of alignments evaluated: %llu", (unsigned long long)m.num_reads);                                        // :350-379
     LOG_INFO("Number of alignments skipped due to low mapping quality: %llu", (unsigned long long)m.num_low_mapq);
     LOG_INFO("Number of alignments skipped due to not being primary: %llu", (unsigned long long)m.num_non_primary);

@@ -268,6 +268,7 @@ struct LocusBuild {
     std::string ref_hap, alt_hap;
     struct Rec { uint32_t cell, umi; uint64_t read_off; uint32_t read_len; };
     std::vector<Rec> recs;
+    std::vector<vtx_raw_record> raw_recs;      // raw mode: BAM order, tags as bytes
     std::unordered_map<std::string, uint32_t> umi_ids;
 };
 
@@ -282,6 +283,10 @@ struct vtxh_pack {
     vtxh_metrics metrics{};
     uint32_t n_variants = 0;
     std::vector<std::string> barcodes, variant_names;
+    // raw mode (vtxh_pack_files_raw)
+    std::vector<vtx_raw_record> raw_records;
+    std::string tag_arena, bc_bytes;
+    std::vector<uint64_t> bc_offsets;
 };
 
 extern "C" {
@@ -338,7 +343,22 @@ uint32_t vtxh_num_barcodes(const vtxh_pack* p) { return (uint32_t)p->barcodes.si
 const char* vtxh_variant_name(const vtxh_pack* p, uint32_t i) { return i < p->variant_names.size() ? p->variant_names[i].c_str() : ""; }
 const char* vtxh_barcode(const vtxh_pack* p, uint32_t j) { return j < p->barcodes.size() ? p->barcodes[j].c_str() : ""; }
 
-int vtxh_pack_files(const vtxh_args* a, vtxh_pack** out) {
+void vtxh_get_raw_batch(const vtxh_pack* p, vtx_raw_batch* out) {
+    out->loci = p->loci.data(); out->n_loci = (uint32_t)p->loci.size();
+    out->records = p->raw_records.data(); out->n_records = (uint32_t)p->raw_records.size();
+    out->hap_arena = (const uint8_t*)p->hap_arena.data(); out->hap_bytes = p->hap_arena.size();
+    out->read_arena = (const uint8_t*)p->read_arena.data(); out->read_bytes = p->read_arena.size();
+    out->tag_arena = (const uint8_t*)p->tag_arena.data(); out->tag_bytes = p->tag_arena.size();
+}
+void vtxh_get_barcode_table(const vtxh_pack* p, const uint8_t** bytes, const uint64_t** offsets, uint32_t* n) {
+    *bytes = (const uint8_t*)p->bc_bytes.data(); *offsets = p->bc_offsets.data(); *n = (uint32_t)p->barcodes.size();
+}
+
+static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out);
+int vtxh_pack_files(const vtxh_args* a, vtxh_pack** out) { return pack_impl(a, false, out); }
+int vtxh_pack_files_raw(const vtxh_args* a, vtxh_pack** out) { return pack_impl(a, true, out); }
+
+static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     if (!a || !out || !a->vcf || !a->bam || !a->fasta || !a->cell_barcodes) return fail(VTX_E_INVAL, "vtxh_pack_files: null argument");
     *out = nullptr;
     const std::string bam_tag = a->bam_tag ? a->bam_tag : "CB";
@@ -358,6 +378,10 @@ int vtxh_pack_files(const vtxh_args* a, vtxh_pack** out) {
         for (auto& line : split_lines(data))
             if (bc_index.emplace(line, (uint32_t)P->barcodes.size()).second) P->barcodes.push_back(line);
         if (P->barcodes.empty()) return fail(VTX_E_INVAL, "Loaded 0 barcodes. Is your barcode file gzipped or empty?");
+        if (raw) {
+            P->bc_offsets.push_back(0);
+            for (auto& b : P->barcodes) { P->bc_bytes += b; P->bc_offsets.push_back(P->bc_bytes.size()); }
+        }
     }
 
     // ---- VCF records (:221-234) ----
@@ -551,7 +575,9 @@ int vtxh_pack_files(const vtxh_args* a, vtxh_pack** out) {
             if (iv[k].end > pos) hits.push_back(iv[k].locus);
         }
         if (hits.empty()) continue;
-        bool seq_ready = false;
+        bool seq_ready = false, tags_ready = false;
+        uint64_t seq_off = 0;
+        vtx_raw_record rr{};
         for (uint32_t li : hits) {
             LocusBuild& L = loci[li];
             ++P->metrics.num_reads;                                                     // :831
@@ -560,6 +586,34 @@ int vtxh_pack_files(const vtxh_args* a, vtxh_pack** out) {
             if (a->no_duplicates && (flag & FLAG_DUP)) { ++P->metrics.num_duplicates; continue; }                      // :849
             if (!useful_alignment(cig, n_cig, pos, L.start, L.end)) { ++P->metrics.num_not_useful; continue; }          // :857
             const unsigned char* val; size_t vlen;
+            if (raw) {
+                // the tag bytes go to the device as they are; only a missing / non-Z barcode tag is decided here
+                if (!tags_ready) {
+                    tags_ready = true;
+                    rr = vtx_raw_record{};
+                    rr.bc_len = VTX_TAG_MISSING;
+                    if (aux_string(aux, (size_t)(r + bs - aux), bam_tag.c_str(), &val, &vlen) && vlen < VTX_TAG_MISSING) {
+                        rr.bc_off = (uint32_t)P->tag_arena.size(); rr.bc_len = (uint16_t)vlen;
+                        P->tag_arena.append((const char*)val, vlen);
+                        rr.umi_len = VTX_TAG_MISSING;
+                        if (aux_string(aux, (size_t)(r + bs - aux), "UB", &val, &vlen) == 1 && vlen < VTX_TAG_MISSING) {
+                            rr.umi_off = (uint32_t)P->tag_arena.size(); rr.umi_len = (uint16_t)vlen;
+                            P->tag_arena.append((const char*)val, vlen);
+                        }
+                    }
+                }
+                if (rr.bc_len == VTX_TAG_MISSING) { ++P->metrics.num_not_cell_bc; continue; }
+                if (!seq_ready) {
+                    seq.resize(l_seq);
+                    for (uint32_t k = 0; k < l_seq; ++k) seq[k] = kNt16[(sq[k >> 1] >> ((~k & 1) << 2)) & 15];
+                    seq_ready = true;
+                    seq_off = reads.size();
+                    reads += seq;
+                }
+                rr.read_off = (uint32_t)seq_off; rr.read_len = l_seq;
+                L.raw_recs.push_back(rr);
+                continue;
+            }
             uint32_t cell = 0;
             bool has_cell = false;
             if (aux_string(aux, (size_t)(r + bs - aux), bam_tag.c_str(), &val, &vlen)) {                                // :867
@@ -582,6 +636,22 @@ int vtxh_pack_files(const vtxh_args* a, vtxh_pack** out) {
         }
     }
 
+    if (reads.size() > 0xffffffffull || P->tag_arena.size() > 0xffffffffull)
+        return fail(VTX_E_UNSUPPORTED, "read arena above 4 GiB: split the VCF");
+    if (raw) {
+        for (auto& L : loci) {
+            vtx_locus o{};
+            o.row = L.row; o.rec_begin = (uint32_t)P->raw_records.size(); o.rec_count = (uint32_t)L.raw_recs.size();
+            o.ref_off = (uint32_t)P->hap_arena.size(); o.ref_len = (uint32_t)L.ref_hap.size();
+            P->hap_arena += L.ref_hap;
+            o.alt_off = (uint32_t)P->hap_arena.size(); o.alt_len = (uint32_t)L.alt_hap.size();
+            P->hap_arena += L.alt_hap;
+            P->raw_records.insert(P->raw_records.end(), L.raw_recs.begin(), L.raw_recs.end());
+            P->loci.push_back(o);
+        }
+        *out = P.release();
+        return VTX_OK;
+    }
     // ---- pack: stable sort by (cell, umi) (:932 + the per-cell UMI grouping) ----
     for (auto& L : loci) {
         std::stable_sort(L.recs.begin(), L.recs.end(), [](const LocusBuild::Rec& x, const LocusBuild::Rec& y) {
