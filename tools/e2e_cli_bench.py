@@ -67,17 +67,25 @@ def main():
     bamwriter.write_bam(bam, [("chr1", len(genome))], [r for _, r in recs])
     print("authored %d reads over %d loci in %.1f s (%.1f MB BAM)" % (len(recs), V, time.time() - t0, os.path.getsize(bam) / 1e6))
     out = os.path.join(args.out, "out.mtx")
-    for f in (out, os.path.join(args.out, "ref_matrix.mtx")):
-        if os.path.exists(f):
-            os.remove(f)
-    t0 = time.time()
-    r = subprocess.run([hostlib.CLI_PATH, "-v", os.path.join(args.out, "v.vcf"), "-b", bam, "-f", fa, "-c",
-                        os.path.join(args.out, "bcs.tsv"), "-o", out, "--threads", str(args.threads), "--log-level", "info"],
-                       cwd=args.out, capture_output=True, text=True)
-    wall = time.time() - t0
-    print(r.stderr.strip())
-    assert r.returncode == 0, r.stdout
-    print("CLI wall time %.2f s" % wall)
+    texts = {}
+    for prep in ("host", "device"):
+        for umi in (False, True):
+            for f in (out, os.path.join(args.out, "ref_matrix.mtx")):
+                if os.path.exists(f):
+                    os.remove(f)
+            t0 = time.time()
+            r = subprocess.run([hostlib.CLI_PATH, "-v", os.path.join(args.out, "v.vcf"), "-b", bam, "-f", fa, "-c",
+                                os.path.join(args.out, "bcs.tsv"), "-o", out, "--threads", str(args.threads), "--log-level", "info",
+                                "--prep", prep] + (["--umi"] if umi else []), cwd=args.out, capture_output=True, text=True)
+            wall = time.time() - t0
+            assert r.returncode == 0, r.stdout
+            keep = [ln for ln in r.stderr.splitlines() if "Ingest" in ln or "Device" in ln or "shard:" in ln or "Merge +" in ln or "Waited" in ln or "Total" in ln]
+            print("--prep %s%s: CLI wall time %.2f s\n  %s" % (prep, " --umi" if umi else "", wall, "\n  ".join(keep)))
+            texts[(prep, umi)] = open(out).read()
+    assert texts[("host", False)] == texts[("device", False)] and texts[("host", True)] == texts[("device", True)]
+    print("host-prepared and device-prepared outputs are byte-identical (with and without --umi)")
+    with open(out, "w") as fh:
+        fh.write(texts[("host", False)])
     # the same inputs through the library path (C++ packer -> device), rendered with the oracle's MTX text
     batch, metrics, nv, barcodes, _ = hostlib.pack_files(os.path.join(args.out, "v.vcf"), bam, fa, os.path.join(args.out, "bcs.tsv"), threads=args.threads)
     with lib.Context(default_config(aligner="banded", n_barcodes=len(barcodes))) as ctx:

@@ -14,14 +14,18 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <charconv>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <fstream>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -138,6 +142,28 @@ const char kNt16[] = "=ACMGRSVTWYHKDBN";
 enum { FLAG_UNMAP = 0x4, FLAG_SECONDARY = 0x100, FLAG_DUP = 0x400, FLAG_SUPP = 0x800 };
 
 struct BgzfBlock { size_t coff; uint32_t clen; uint32_t isize; };
+
+// growable byte buffer that never zero-fills (the inflaters overwrite every byte they are given)
+struct ByteBuf {
+    unsigned char* p = nullptr;
+    size_t len = 0, cap = 0;
+    ~ByteBuf() { free(p); }
+    unsigned char* data() { return p; }
+    const unsigned char* data() const { return p; }
+    size_t size() const { return len; }
+    void drop_prefix(size_t n) { if (n) { memmove(p, p + n, len - n); len -= n; } }
+    unsigned char* grow(size_t add) {      // returns the start of the new bytes; nullptr when out of memory
+        if (len + add > cap || !p) {
+            size_t want = std::max<size_t>(std::max(len + add, cap + cap / 2), 64);
+            unsigned char* q = (unsigned char*)realloc(p, want);
+            if (!q) return nullptr;
+            p = q; cap = want;
+        }
+        unsigned char* r = p + len;
+        len += add;
+        return r;
+    }
+};
 
 bool index_bgzf(const MappedFile& file, std::vector<BgzfBlock>& blocks) {
     size_t o = 0;
@@ -262,14 +288,74 @@ bool useful_alignment(const unsigned char* cig, uint32_t n_ops, int64_t pos, int
     return false;
 }
 
+// Minimal persistent worker pool: run(fn) executes fn(t) for t in [0, n) — t = 0 on the caller — and waits.
+class Pool {
+  public:
+    explicit Pool(int n) : n_(n < 1 ? 1 : n) {
+        for (int t = 1; t < n_; ++t) th_.emplace_back([this, t] { loop(t); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    int size() const { return n_; }
+    void run(const std::function<void(size_t)>& fn) {
+        { std::lock_guard<std::mutex> g(m_); fn_ = &fn; pending_ = n_ - 1; ++gen_; }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    void loop(int t) {
+        uint64_t seen = 0;
+        while (true) {
+            const std::function<void(size_t)>* fn;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                fn = fn_;
+            }
+            (*fn)((size_t)t);
+            { std::lock_guard<std::mutex> g(m_); if (--pending_ == 0) done_.notify_one(); }
+        }
+    }
+    int n_;
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    int pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+// phase timer: VTXH_PROFILE=1 prints cumulative seconds per phase of vtxh_pack_files to stderr
+struct Phases {
+    bool on = getenv("VTXH_PROFILE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    std::vector<std::pair<std::string, double>> acc;
+    void mark(const char* name) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        const double d = std::chrono::duration<double>(now - t).count();
+        t = now;
+        for (auto& a : acc) if (a.first == name) { a.second += d; return; }
+        acc.emplace_back(name, d);
+    }
+    ~Phases() { if (on) for (auto& a : acc) fprintf(stderr, "[vtxh] %-18s %.3f s\n", a.first.c_str(), a.second); }
+};
+
 struct LocusBuild {
     uint32_t row;
     int64_t start, end;
     std::string ref_hap, alt_hap;
     struct Rec { uint32_t cell, umi; uint64_t read_off; uint32_t read_len; };
-    std::vector<Rec> recs;
-    std::vector<vtx_raw_record> raw_recs;      // raw mode: BAM order, tags as bytes
-    std::unordered_map<std::string, uint32_t> umi_ids;
 };
 
 struct Interval { int64_t start, end; uint32_t locus; };
@@ -279,7 +365,8 @@ struct Interval { int64_t start, end; uint32_t locus; };
 struct vtxh_pack {
     std::vector<vtx_locus> loci;
     std::vector<vtx_record> records;
-    std::string hap_arena, read_arena;
+    std::string hap_arena;
+    ByteBuf read_arena;            // grown without zero-fill, filled by the sweep's workers
     vtxh_metrics metrics{};
     uint32_t n_variants = 0;
     std::vector<std::string> barcodes, variant_names;
@@ -313,20 +400,38 @@ int vtxh_write_mtx(const char* path, uint32_t n_rows, uint32_t n_cols, uint64_t 
                    const uint32_t* col, const double* value) {
     FILE* f = fopen(path, "wb");
     if (!f) return fail(VTX_E_INVAL, "cannot open %s for writing", path);
-    std::vector<char> buf(1 << 20);
-    setvbuf(f, buf.data(), _IOFBF, buf.size());
     fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%u %u %llu\n", n_rows, n_cols,
             (unsigned long long)nnz);
-    char line[96], num[40];
-    for (uint64_t k = 0; k < nnz; ++k) {
-        char* p = line;
-        p = std::to_chars(p, p + 12, row[k] + 1u).ptr; *p++ = ' ';
-        p = std::to_chars(p, p + 12, col[k] + 1u).ptr; *p++ = ' ';
-        int n = vtxh_format_f64(value[k], num);
-        memcpy(p, num, (size_t)n); p += n; *p++ = '\n';
-        fwrite(line, 1, (size_t)(p - line), f);
+    // lines are formatted by several threads into private buffers (rounds of bounded size), written in order
+    const uint64_t kRound = 8u << 20;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t T = nnz < (1u << 16) ? 1 : std::min<size_t>(hw ? hw : 1, 16);
+    std::vector<std::string> parts(T);
+    bool ok = true;
+    for (uint64_t base = 0; base < nnz && ok; base += kRound) {
+        const uint64_t n = std::min<uint64_t>(kRound, nnz - base);
+        auto fmt = [&](size_t t) {
+            std::string& out = parts[t];
+            out.clear();
+            const uint64_t k0 = base + n * t / T, k1 = base + n * (t + 1) / T;
+            out.reserve((size_t)(k1 - k0) * 16);
+            char line[96], num[40];
+            for (uint64_t k = k0; k < k1; ++k) {
+                char* p = line;
+                p = std::to_chars(p, p + 12, row[k] + 1u).ptr; *p++ = ' ';
+                p = std::to_chars(p, p + 12, col[k] + 1u).ptr; *p++ = ' ';
+                const int m = vtxh_format_f64(value[k], num);
+                memcpy(p, num, (size_t)m); p += m; *p++ = '\n';
+                out.append(line, (size_t)(p - line));
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < T; ++t) th.emplace_back(fmt, t);
+        fmt(0);
+        for (auto& t : th) t.join();
+        for (auto& part : parts) ok = ok && fwrite(part.data(), 1, part.size(), f) == part.size();
     }
-    bool ok = fclose(f) == 0;
+    ok = (fclose(f) == 0) && ok;
     return ok ? VTX_OK : fail(VTX_E_INVAL, "error writing %s", path);
 }
 
@@ -367,6 +472,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     for (const char* c = a->valid_chars ? a->valid_chars : "ATGCatgc"; *c; ++c) valid[(unsigned char)*c] = true;
     const int threads = a->threads > 0 ? a->threads : 1;
     std::unique_ptr<vtxh_pack> P(new vtxh_pack());
+    Phases ph;
 
     // ---- load_barcodes (:697-718): first-occurrence index, whole line is the key ----
     std::unordered_map<std::string, uint32_t> bc_index;
@@ -384,6 +490,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         }
     }
 
+    ph.mark("barcodes");
     // ---- VCF records (:221-234) ----
     std::vector<VcfRec> vcf;
     {
@@ -421,6 +528,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         P->n_variants = (uint32_t)vcf.size();
     }
 
+    ph.mark("vcf");
     // ---- FASTA + .fai ----
     Fasta fa;
     {
@@ -440,6 +548,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         if (!fa.data.open(a->fasta)) return fail(VTX_E_INVAL, "error opening fasta file %s", a->fasta);
     }
 
+    ph.mark("fasta index");
     // ---- BAM: header ----
     MappedFile bam_file;
     if (!bam_file.open(a->bam)) return fail(VTX_E_INVAL, "error opening bam file: %s", a->bam);
@@ -448,26 +557,23 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     if (!index_bgzf(bam_file, blocks)) return fail(VTX_E_INVAL, "%s is not a valid BGZF/BAM file", a->bam);
 
     // streaming inflater over chunks of blocks
-    std::vector<unsigned char> buf;       // decompressed bytes not yet consumed
+    Pool pool(threads);
+    ByteBuf buf;                          // decompressed bytes not yet consumed
     size_t buf_pos = 0, next_block = 0;
     auto refill = [&](size_t need) -> bool {   // ensure buf has >= need bytes from buf_pos, if the file has them
         while (buf.size() - buf_pos < need && next_block < blocks.size()) {
-            const size_t chunk = std::min(blocks.size() - next_block, (size_t)2048);
-            if (buf_pos) { buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)buf_pos); buf_pos = 0; }
+            const size_t chunk = std::min(blocks.size() - next_block, (size_t)512);
+            if (buf_pos) { buf.drop_prefix(buf_pos); buf_pos = 0; }
             std::vector<size_t> off(chunk + 1, 0);
             for (size_t k = 0; k < chunk; ++k) off[k + 1] = off[k] + blocks[next_block + k].isize;
             const size_t base = buf.size();
-            buf.resize(base + off[chunk]);
+            if (!buf.grow(off[chunk])) return false;
             std::atomic<size_t> nextk{0};
             std::atomic<bool> ok{true};
-            auto work = [&]() {
+            pool.run([&](size_t) {
                 for (size_t k; (k = nextk.fetch_add(1)) < chunk;)
                     if (!inflate_block(bam_file, blocks[next_block + k], buf.data() + base + off[k])) ok = false;
-            };
-            std::vector<std::thread> th;
-            for (int t = 1; t < threads; ++t) th.emplace_back(work);
-            work();
-            for (auto& t : th) t.join();
+            });
             if (!ok) return false;
             next_block += chunk;
         }
@@ -490,6 +596,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     std::unordered_map<std::string, int32_t> tid_of;
     for (size_t i = 0; i < bam_refs.size(); ++i) tid_of.emplace(bam_refs[i], (int32_t)i);
 
+    ph.mark("bam header");
     // ---- validate_inputs (:545-594) + evaluate_rec pre-alignment part (:610-684) ----
     std::vector<LocusBuild> loci;
     std::vector<std::vector<Interval>> by_tid(bam_refs.size());
@@ -536,19 +643,18 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     for (auto& iv : by_tid)
         std::stable_sort(iv.begin(), iv.end(), [](const Interval& x, const Interval& y) { return x.start < y.start; });
 
+    ph.mark("haplotypes");
     // ---- sweep the BAM once (fetch + filters of evaluate_alns, :822-895) ----
-    std::string& reads = P->read_arena;
-    std::string seq;
-    std::vector<uint32_t> hits;
-    while (true) {
-        if (!refill(4)) break;
-        const uint32_t bs = rd32(buf.data() + buf_pos);
-        if (!refill(4 + (size_t)bs)) return fail(VTX_E_INVAL, "%s: truncated BAM record", a->bam);
-        const unsigned char* r = buf.data() + buf_pos + 4;
-        buf_pos += 4 + (size_t)bs;
-        if (bs < 32) return fail(VTX_E_INVAL, "%s: malformed BAM record", a->bam);
+    // Per window of inflated blocks: record boundaries are indexed sequentially (a hop per record), the
+    // records are parsed and filtered by `threads` workers over contiguous ranges into thread-local
+    // outputs, and the outputs are merged in thread order — so every locus sees its reads in BAM order,
+    // exactly like one sequential sweep.
+    struct Hit { uint32_t locus, cell; vtx_raw_record rr; };       // rr offsets are relative to the worker's arenas
+    struct WorkerOut { std::vector<Hit> hits; std::string reads, tags; vtxh_metrics m{}; std::string err; uint64_t rbase = 0; };
+    ByteBuf& reads = P->read_arena;
+    auto process = [&](const unsigned char* r, uint32_t bs, WorkerOut& o, std::vector<uint32_t>& hits, std::string& seq) -> bool {
         const int32_t tid = rdi32(r);
-        if (tid < 0 || (size_t)tid >= by_tid.size() || by_tid[(size_t)tid].empty()) continue;
+        if (tid < 0 || (size_t)tid >= by_tid.size() || by_tid[(size_t)tid].empty()) return true;
         const int64_t pos = rdi32(r + 4);
         const uint32_t l_rn = r[8], mapq = r[9];
         const uint32_t n_cig = r[12] | (r[13] << 8), flag = r[14] | (r[15] << 8);
@@ -556,7 +662,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         const unsigned char* cig = r + 32 + l_rn;
         const unsigned char* sq = cig + 4 * (size_t)n_cig;
         const unsigned char* aux = sq + (l_seq + 1) / 2 + l_seq;
-        if (aux > r + bs) return fail(VTX_E_INVAL, "%s: malformed BAM record", a->bam);
+        if (aux > r + bs) { o.err = "malformed BAM record"; return false; }
         // bam_endpos: unmapped or no reference-consuming op => pos + 1
         int64_t rlen = 0;
         if (!(flag & FLAG_UNMAP))
@@ -574,101 +680,192 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             if (iv[k].start + max_span[(size_t)tid] <= pos) break;
             if (iv[k].end > pos) hits.push_back(iv[k].locus);
         }
-        if (hits.empty()) continue;
+        if (hits.empty()) return true;
         bool seq_ready = false, tags_ready = false;
-        uint64_t seq_off = 0;
         vtx_raw_record rr{};
+        uint32_t cell = 0;
+        bool has_cell = false;
         for (uint32_t li : hits) {
-            LocusBuild& L = loci[li];
-            ++P->metrics.num_reads;                                                     // :831
-            if (mapq < a->mapq) { ++P->metrics.num_low_mapq; continue; }                 // :833
-            if (a->primary_only && (flag & (FLAG_SECONDARY | FLAG_SUPP))) { ++P->metrics.num_non_primary; continue; }   // :841
-            if (a->no_duplicates && (flag & FLAG_DUP)) { ++P->metrics.num_duplicates; continue; }                      // :849
-            if (!useful_alignment(cig, n_cig, pos, L.start, L.end)) { ++P->metrics.num_not_useful; continue; }          // :857
-            const unsigned char* val; size_t vlen;
-            if (raw) {
-                // the tag bytes go to the device as they are; only a missing / non-Z barcode tag is decided here
-                if (!tags_ready) {
-                    tags_ready = true;
-                    rr = vtx_raw_record{};
-                    rr.bc_len = VTX_TAG_MISSING;
-                    if (aux_string(aux, (size_t)(r + bs - aux), bam_tag.c_str(), &val, &vlen) && vlen < VTX_TAG_MISSING) {
-                        rr.bc_off = (uint32_t)P->tag_arena.size(); rr.bc_len = (uint16_t)vlen;
-                        P->tag_arena.append((const char*)val, vlen);
-                        rr.umi_len = VTX_TAG_MISSING;
-                        if (aux_string(aux, (size_t)(r + bs - aux), "UB", &val, &vlen) == 1 && vlen < VTX_TAG_MISSING) {
-                            rr.umi_off = (uint32_t)P->tag_arena.size(); rr.umi_len = (uint16_t)vlen;
-                            P->tag_arena.append((const char*)val, vlen);
-                        }
+            const LocusBuild& L = loci[li];
+            ++o.m.num_reads;                                                     // :831
+            if (mapq < a->mapq) { ++o.m.num_low_mapq; continue; }                 // :833
+            if (a->primary_only && (flag & (FLAG_SECONDARY | FLAG_SUPP))) { ++o.m.num_non_primary; continue; }   // :841
+            if (a->no_duplicates && (flag & FLAG_DUP)) { ++o.m.num_duplicates; continue; }                      // :849
+            if (!useful_alignment(cig, n_cig, pos, L.start, L.end)) { ++o.m.num_not_useful; continue; }          // :857
+            if (!tags_ready) {
+                // tag bytes are copied once per read; raw mode ships them to the device as they are
+                tags_ready = true;
+                const unsigned char* val; size_t vlen;
+                rr.bc_len = VTX_TAG_MISSING; rr.umi_len = VTX_TAG_MISSING;
+                if (aux_string(aux, (size_t)(r + bs - aux), bam_tag.c_str(), &val, &vlen) && vlen < VTX_TAG_MISSING) {   // :867
+                    if (raw) {
+                        rr.bc_off = (uint32_t)o.tags.size(); rr.bc_len = (uint16_t)vlen;
+                        o.tags.append((const char*)val, vlen);
+                    } else {
+                        auto it = bc_index.find(std::string((const char*)val, vlen));
+                        if (it != bc_index.end()) { has_cell = true; cell = it->second; rr.bc_len = 0; }
                     }
                 }
-                if (rr.bc_len == VTX_TAG_MISSING) { ++P->metrics.num_not_cell_bc; continue; }
-                if (!seq_ready) {
-                    seq.resize(l_seq);
-                    for (uint32_t k = 0; k < l_seq; ++k) seq[k] = kNt16[(sq[k >> 1] >> ((~k & 1) << 2)) & 15];
-                    seq_ready = true;
-                    seq_off = reads.size();
-                    reads += seq;
+                if ((raw || a->use_umi) && rr.bc_len != VTX_TAG_MISSING && aux_string(aux, (size_t)(r + bs - aux), "UB", &val, &vlen) == 1 && vlen < VTX_TAG_MISSING) {   // :879
+                    rr.umi_off = (uint32_t)o.tags.size(); rr.umi_len = (uint16_t)vlen;
+                    o.tags.append((const char*)val, vlen);
                 }
-                rr.read_off = (uint32_t)seq_off; rr.read_len = l_seq;
-                L.raw_recs.push_back(rr);
-                continue;
             }
-            uint32_t cell = 0;
-            bool has_cell = false;
-            if (aux_string(aux, (size_t)(r + bs - aux), bam_tag.c_str(), &val, &vlen)) {                                // :867
-                auto it = bc_index.find(std::string((const char*)val, vlen));
-                if (it != bc_index.end()) { has_cell = true; cell = it->second; }
-            }
-            if (!has_cell) { ++P->metrics.num_not_cell_bc; continue; }
-            std::string umi;
-            bool has_umi = aux_string(aux, (size_t)(r + bs - aux), "UB", &val, &vlen) == 1;                            // :879
-            if (a->use_umi && !has_umi) { ++P->metrics.num_non_umi; continue; }
-            if (a->use_umi) umi.assign((const char*)val, vlen); else umi.assign(1, '\1');                               // :890-894
+            // raw: only a missing / non-Z barcode tag is decided here; cooked: the in-list test too (:870-876)
+            if (raw ? rr.bc_len == VTX_TAG_MISSING : !has_cell) { ++o.m.num_not_cell_bc; continue; }
+            if (!raw && a->use_umi && rr.umi_len == VTX_TAG_MISSING) { ++o.m.num_non_umi; continue; }           // :879-888
             if (!seq_ready) {                                                               // rec.seq().as_bytes() :896
                 seq.resize(l_seq);
                 for (uint32_t k = 0; k < l_seq; ++k) seq[k] = kNt16[(sq[k >> 1] >> ((~k & 1) << 2)) & 15];
                 seq_ready = true;
+                rr.read_off = (uint32_t)o.reads.size(); o.reads += seq;      // one copy per read, shared by its loci
             }
-            uint32_t uid = L.umi_ids.emplace(umi, (uint32_t)L.umi_ids.size()).first->second;
-            L.recs.push_back(LocusBuild::Rec{cell, uid, reads.size(), l_seq});
-            reads += seq;
+            rr.read_len = l_seq;
+            o.hits.push_back(Hit{li, cell, rr});
         }
-    }
-
-    if (reads.size() > 0xffffffffull || P->tag_arena.size() > 0xffffffffull)
-        return fail(VTX_E_UNSUPPORTED, "read arena above 4 GiB: split the VCF");
-    if (raw) {
-        for (auto& L : loci) {
-            vtx_locus o{};
-            o.row = L.row; o.rec_begin = (uint32_t)P->raw_records.size(); o.rec_count = (uint32_t)L.raw_recs.size();
-            o.ref_off = (uint32_t)P->hap_arena.size(); o.ref_len = (uint32_t)L.ref_hap.size();
-            P->hap_arena += L.ref_hap;
-            o.alt_off = (uint32_t)P->hap_arena.size(); o.alt_len = (uint32_t)L.alt_hap.size();
-            P->hap_arena += L.alt_hap;
-            P->raw_records.insert(P->raw_records.end(), L.raw_recs.begin(), L.raw_recs.end());
-            P->loci.push_back(o);
+        return o.reads.size() <= 0xffffffffull && o.tags.size() <= 0xffffffffull;
+    };
+    std::vector<size_t> rec_offs;
+    // the (sequential, order-preserving) merge of window w runs on its own thread while window w+1 inflates and parses
+    std::vector<WorkerOut> out_sets[2] = {std::vector<WorkerOut>((size_t)threads), std::vector<WorkerOut>((size_t)threads)};
+    int cur_set = 0;
+    std::thread merger;
+    int merge_code = VTX_OK;
+    std::string merge_err;
+    std::vector<Hit> all_hits;                 // every surviving (read, locus) pair, BAM order, offsets into the global arenas
+    std::string& tag_store = P->tag_arena;     // raw: barcode + UMI bytes for the device; cooked: UMI bytes until the ids are assigned
+    auto merge = [&](std::vector<WorkerOut>* outs_p) {
+        for (auto& o : *outs_p) {
+            if (!o.err.empty()) { merge_code = o.err[0] == 'm' ? VTX_E_INVAL : VTX_E_UNSUPPORTED; merge_err = o.err; return; }
+            const uint64_t rbase = o.rbase, tbase = tag_store.size();
+            if (tbase + o.tags.size() > 0xffffffffull) {
+                merge_code = VTX_E_UNSUPPORTED; merge_err = "read arena above 4 GiB: split the VCF"; return;
+            }
+            tag_store += o.tags;
+            const uint64_t* src = &o.m.num_reads;
+            uint64_t* dst = &P->metrics.num_reads;
+            for (int k = 0; k < 9; ++k) dst[k] += src[k];
+            const size_t h0 = all_hits.size();
+            all_hits.insert(all_hits.end(), o.hits.begin(), o.hits.end());
+            for (size_t k = h0; k < all_hits.size(); ++k) {
+                vtx_raw_record& rr = all_hits[k].rr;
+                rr.read_off += (uint32_t)rbase; rr.bc_off += (uint32_t)tbase; rr.umi_off += (uint32_t)tbase;
+            }
         }
-        *out = P.release();
-        return VTX_OK;
-    }
-    // ---- pack: stable sort by (cell, umi) (:932 + the per-cell UMI grouping) ----
-    for (auto& L : loci) {
-        std::stable_sort(L.recs.begin(), L.recs.end(), [](const LocusBuild::Rec& x, const LocusBuild::Rec& y) {
-            return x.cell != y.cell ? x.cell < y.cell : x.umi < y.umi;
+    };
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{merger};
+    while (true) {
+        std::vector<WorkerOut>& outs = out_sets[cur_set];
+        refill(buf.size() - buf_pos + 1);             // one more chunk of blocks, if the file has one
+        ph.mark("inflate");
+        rec_offs.clear();
+        size_t p = buf_pos;
+        while (buf.size() - p >= 4) {
+            const uint32_t bs = rd32(buf.data() + p);
+            if (buf.size() - p - 4 < bs) break;
+            if (bs < 32) return fail(VTX_E_INVAL, "%s: malformed BAM record", a->bam);
+            rec_offs.push_back(p);
+            p += 4 + (size_t)bs;
+            __builtin_prefetch(buf.data() + p + 8 * (4 + (size_t)bs));      // records are of similar size: the chain is predictable
+            __builtin_prefetch(buf.data() + p + 8 * (4 + (size_t)bs) + 64);
+        }
+        const bool eof = next_block >= blocks.size();
+        if (rec_offs.empty()) {
+            if (!eof) continue;                        // a record larger than the window: load more
+            if (buf.size() - buf_pos >= 4) return fail(VTX_E_INVAL, "%s: truncated BAM record", a->bam);
+            break;
+        }
+        const size_t nrec = rec_offs.size();
+        ph.mark("record index");
+        pool.run([&](size_t t) {
+            WorkerOut& o = outs[t];
+            o.hits.clear(); o.reads.clear(); o.tags.clear(); o.m = vtxh_metrics{}; o.err.clear();
+            std::vector<uint32_t> hits;
+            std::string seq;
+            for (size_t k = nrec * t / (size_t)threads, e = nrec * (t + 1) / (size_t)threads; k < e; ++k) {
+                const unsigned char* rp = buf.data() + rec_offs[k];
+                if (!process(rp + 4, rd32(rp), o, hits, seq)) { if (o.err.empty()) o.err = "read arena above 4 GiB: split the VCF"; return; }
+            }
         });
+        // the workers' read bytes go to the global arena at prefix offsets, copied by the workers themselves
+        {
+            uint64_t total = reads.size();
+            for (auto& o : outs) { o.rbase = total; total += o.reads.size(); }
+            if (total > 0xffffffffull) return fail(VTX_E_UNSUPPORTED, "read arena above 4 GiB: split the VCF");
+            if (!reads.grow((size_t)(total - reads.size()))) return fail(VTX_E_NOMEM, "out of memory growing the read arena");
+            pool.run([&](size_t t) { if (!outs[t].reads.empty()) memcpy(reads.data() + outs[t].rbase, outs[t].reads.data(), outs[t].reads.size()); });
+        }
+        ph.mark("parse + filter");
+        if (merger.joinable()) merger.join();
+        if (merge_code != VTX_OK) return fail(merge_code, "%s: %s", a->bam, merge_err.c_str());
+        merger = std::thread(merge, &outs);
+        cur_set ^= 1;
+        ph.mark("merge");
+        buf_pos = p;
+        if (eof && buf.size() - buf_pos < 4) break;
+        if (eof && rec_offs.empty()) break;
+    }
+    if (merger.joinable()) merger.join();
+    if (merge_code != VTX_OK) return fail(merge_code, "%s: %s", a->bam, merge_err.c_str());
+    ph.mark("merge (tail)");
+
+    // ---- group the hits by locus: stable counting sort (hits are in BAM order, so every locus keeps it) ----
+    const size_t nloc = loci.size();
+    std::vector<uint32_t> l_begin(nloc + 1, 0);
+    for (const Hit& h : all_hits) ++l_begin[h.locus + 1];
+    for (size_t l = 0; l < nloc; ++l) l_begin[l + 1] += l_begin[l];
+    for (size_t l = 0; l < nloc; ++l) {
+        const LocusBuild& L = loci[l];
         vtx_locus o{};
-        o.row = L.row; o.rec_begin = (uint32_t)P->records.size(); o.rec_count = (uint32_t)L.recs.size();
+        o.row = L.row; o.rec_begin = l_begin[l]; o.rec_count = l_begin[l + 1] - l_begin[l];
         o.ref_off = (uint32_t)P->hap_arena.size(); o.ref_len = (uint32_t)L.ref_hap.size();
         P->hap_arena += L.ref_hap;
         o.alt_off = (uint32_t)P->hap_arena.size(); o.alt_len = (uint32_t)L.alt_hap.size();
         P->hap_arena += L.alt_hap;
-        for (auto& rc : L.recs) {
-            if (rc.read_off + rc.read_len > 0xffffffffull) return fail(VTX_E_UNSUPPORTED, "read arena above 4 GiB: split the VCF");
-            P->records.push_back(vtx_record{(uint32_t)rc.read_off, rc.read_len, rc.cell, rc.umi});
-        }
         P->loci.push_back(o);
     }
+    std::vector<uint32_t> cursor(l_begin.begin(), l_begin.end() - 1);
+    if (raw) {
+        P->raw_records.resize(all_hits.size());
+        for (const Hit& h : all_hits) P->raw_records[cursor[h.locus]++] = h.rr;
+        ph.mark("pack");
+        *out = P.release();
+        return VTX_OK;
+    }
+    // ---- cooked: UMI ids by first occurrence, then the stable sort by (cell, umi) (:932 + per-cell UMI grouping),
+    //      loci in parallel (disjoint output ranges) ----
+    std::vector<Hit> by_locus(all_hits.size());
+    for (const Hit& h : all_hits) by_locus[cursor[h.locus]++] = h;
+    std::vector<Hit>().swap(all_hits);
+    P->records.resize(by_locus.size());
+    {
+        std::atomic<size_t> next_locus{0};
+        auto pack_loci = [&]() {
+            std::unordered_map<std::string, uint32_t> umi_ids;
+            std::vector<LocusBuild::Rec> recs;
+            for (size_t l; (l = next_locus.fetch_add(16)) < nloc;)
+                for (size_t ll = l; ll < std::min(nloc, l + 16); ++ll) {
+                    umi_ids.clear(); recs.clear();
+                    for (uint32_t j = l_begin[ll]; j < l_begin[ll + 1]; ++j) {
+                        const Hit& h = by_locus[j];
+                        uint32_t uid = 0;     // without --umi every read carries the same dummy UMI (:890-894)
+                        if (a->use_umi) uid = umi_ids.emplace(tag_store.substr(h.rr.umi_off, h.rr.umi_len), (uint32_t)umi_ids.size()).first->second;
+                        recs.push_back(LocusBuild::Rec{h.cell, uid, h.rr.read_off, h.rr.read_len});
+                    }
+                    std::stable_sort(recs.begin(), recs.end(), [](const LocusBuild::Rec& x, const LocusBuild::Rec& y) {
+                        return x.cell != y.cell ? x.cell < y.cell : x.umi < y.umi;
+                    });
+                    for (size_t k = 0; k < recs.size(); ++k)
+                        P->records[l_begin[ll] + k] = vtx_record{(uint32_t)recs[k].read_off, recs[k].read_len, recs[k].cell, recs[k].umi};
+                }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; ++t) th.emplace_back(pack_loci);
+        pack_loci();
+        for (auto& t : th) t.join();
+    }
+    std::string().swap(tag_store);
+    ph.mark("sort + pack");
     *out = P.release();
     return VTX_OK;
 }
