@@ -462,7 +462,8 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     for (uint64_t seed = 0x9e3779b97f4a7c15ull;; seed = seed * 0xd1342543de82ef95ull + 1) {
         ++rounds;
         HIP_TRY(c, hipMemsetAsync(c->d_prep_cnt.p, 0, 8 * u64 + 32 * u32, s));
-        HIP_TRY(c, hipMemsetAsync(c->d_locus_cnt.p, 0, ((size_t)nl + 1) * u32, s));
+        HIP_TRY(c, hipMemsetAsync(c->d_locus_cnt.p, 0, ((size_t)nl + 1) * u32, s));      // first record of each locus
+        HIP_TRY(c, hipMemsetAsync(c->d_locus_scan.p, 0, ((size_t)nl + 1) * u32, s));     // one past its last record
         HIP_TRY(c, vtxk_prep_resolve(c->d_raw.as<vtx_raw_record>(), nr, c->d_raw_locus.as<uint32_t>(), c->d_tags.as<uint8_t>(),
                                      b->tag_bytes, b->read_bytes, kMaxReadLen, c->d_bc_slots.as<uint32_t>(), c->bc_mask,
                                      c->d_bc_hash.as<uint64_t>(), c->d_bc_off.as<uint64_t>(), c->d_bc_bytes.as<uint8_t>(),
@@ -491,7 +492,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
                                       c->d_tags.as<uint8_t>(), c->d_loci.as<vtx_locus>(), cell_bits, use_umi, kNumShapes,
                                       c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_head_umi.as<uint32_t>(),
                                       c->d_shape.as<uint8_t>(), c->d_seq.as<uint32_t>(), c->d_locus_cnt.as<uint32_t>(),
-                                      d_shape_cnt, d_counters, s));
+                                      c->d_locus_scan.as<uint32_t>(), d_shape_cnt, d_counters, s));
         HIP_TRY(c, hipMemcpyAsync(cnt, d_counters, 6 * u64, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         if (!cnt[4]) break;                  // no UMI hash collision inside a (locus, cell) group
@@ -504,6 +505,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
         HIP_TRY(c, vtxk_prep_umi_ids(c->d_records.as<vtx_record>(), c->d_umi_scan.as<uint32_t>(), n_kept, s));
     }
     if (nl) {
+        HIP_TRY(c, vtxk_prep_locus_counts(c->d_locus_cnt.as<uint32_t>(), c->d_locus_scan.as<uint32_t>(), nl, s));
         HIP_TRY(c, vtxk_inclusive_scan_u32(c->d_locus_cnt.as<uint32_t>(), c->d_locus_scan.as<uint32_t>(), nl, c->d_sort_tmp.p, scan_tmp, s));
         HIP_TRY(c, vtxk_prep_locus_ranges(c->d_loci.as<vtx_locus>(), c->d_locus_cnt.as<uint32_t>(), c->d_locus_scan.as<uint32_t>(), nl, s));
     }

@@ -7,12 +7,25 @@
 
 #include "../../include/vtx.h"
 
-// 64-bit hash of a tag byte string (FNV-1a + fmix64), identical on host (barcode table build) and device
+// 64-bit hash of a tag byte string (FNV-1a style over little-endian 8-byte words + fmix64), identical on the
+// host (barcode table build) and the device.  The words are read with memcpy: gfx950 global memory takes
+// unaligned dwordx2 loads, so a lane hashes an 18-byte barcode with 3 loads instead of 18.
+static __host__ __device__ inline uint64_t vtx_load_le(const uint8_t* p, uint32_t n) {   // n <= 8 bytes, zero-extended
+    uint64_t w = 0;
+    if (n == 8) { __builtin_memcpy(&w, p, 8); return w; }
+    for (uint32_t i = 0; i < n; ++i) w |= (uint64_t)p[i] << (8 * i);
+    return w;
+}
 static __host__ __device__ inline uint64_t vtx_hash_bytes(const uint8_t* p, uint32_t n, uint64_t seed) {
     uint64_t h = (0xcbf29ce484222325ull ^ seed) + n;
-    for (uint32_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+    for (uint32_t i = 0; i < n; i += 8) { h ^= vtx_load_le(p + i, n - i < 8 ? n - i : 8); h *= 0x100000001b3ull; h ^= h >> 29; }
     h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
     return h;
+}
+static __host__ __device__ inline bool vtx_bytes_equal(const uint8_t* a, const uint8_t* b, uint32_t n) {
+    bool eq = true;
+    for (uint32_t i = 0; i < n; i += 8) { const uint32_t m = n - i < 8 ? n - i : 8; eq &= vtx_load_le(a + i, m) == vtx_load_le(b + i, m); }
+    return eq;
 }
 
 extern "C" {
@@ -79,8 +92,9 @@ hipError_t vtxk_prep_gather_u64(const uint64_t* src, const uint32_t* idx, uint32
 hipError_t vtxk_prep_finalize(uint32_t n_kept, const uint32_t* perm, const uint64_t* key_lc_sorted, const uint64_t* key_umi,
                               const vtx_raw_record* raw, const uint8_t* tags, const vtx_locus* loci, uint32_t cell_bits,
                               int use_umi, uint32_t n_shapes, vtx_record* records, uint32_t* rec_locus, uint32_t* umi_head,
-                              uint8_t* shape, uint32_t* seq, uint32_t* locus_cnt, uint32_t* shape_cnt,
+                              uint8_t* shape, uint32_t* seq, uint32_t* locus_first, uint32_t* locus_end, uint32_t* shape_cnt,
                               unsigned long long* counters, hipStream_t s);
+hipError_t vtxk_prep_locus_counts(uint32_t* first_to_count, const uint32_t* end, uint32_t n_loci, hipStream_t s);
 hipError_t vtxk_prep_umi_ids(vtx_record* records, const uint32_t* umi_scan, uint32_t n, hipStream_t s);
 hipError_t vtxk_prep_locus_ranges(vtx_locus* loci, const uint32_t* cnt, const uint32_t* cnt_scan, uint32_t n_loci, hipStream_t s);
 hipError_t vtxk_prep_lut_check(const uint32_t* work, uint32_t count, const uint32_t* rec_locus, uint32_t cap, uint32_t* flag,

@@ -22,11 +22,6 @@
 
 namespace {
 
-__device__ __forceinline__ void wave_count_add(bool pred, unsigned long long* counter) {
-    const unsigned long long m = __ballot(pred);
-    if (m && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(counter, (unsigned long long)__popcll(m));
-}
-
 // rec_locus for the raw records: one wavefront per locus
 __global__ __launch_bounds__(256) void prep_rec_locus_kernel(const vtx_locus* __restrict__ loci, uint32_t n_loci,
                                                              uint32_t* __restrict__ rec_locus) {
@@ -37,6 +32,9 @@ __global__ __launch_bounds__(256) void prep_rec_locus_kernel(const vtx_locus* __
 }
 
 // counters: [0] not_cell_bc, [1] non_umi, [2] error flags, [3] cells (sum of DP cells), [4] collision, [5] max read len
+// Both record kernels walk the records with a grid-stride loop and keep their counters per workgroup
+// (registers -> LDS -> one global atomic per workgroup): a global atomic per wavefront on one address
+// costs more than the rest of the kernel.
 __global__ __launch_bounds__(256) void prep_resolve_kernel(
     const vtx_raw_record* __restrict__ raw, uint32_t n, const uint32_t* __restrict__ rec_locus,
     const uint8_t* __restrict__ tags, uint64_t tag_bytes, uint64_t read_bytes, uint32_t max_read_len,
@@ -45,16 +43,18 @@ __global__ __launch_bounds__(256) void prep_resolve_kernel(
     int use_umi, uint64_t seed, uint64_t hash_mask, uint32_t cell_bits, uint32_t n_loci,
     uint64_t* __restrict__ key_lc, uint64_t* __restrict__ key_umi, uint32_t* __restrict__ idx,
     unsigned long long* __restrict__ counters) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const bool have = i < n;
-    bool not_bc = false, no_umi = false, bad = false;
-    uint64_t klc = (uint64_t)n_loci << cell_bits, ku = 0;
-    if (have) {
+    __shared__ uint32_t s_cnt[3];
+    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t n_not_bc = 0, n_no_umi = 0, n_bad = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        uint64_t klc = (uint64_t)n_loci << cell_bits, ku = 0;
         const vtx_raw_record r = raw[i];
         const bool umi_missing = r.umi_len == VTX_TAG_MISSING;
-        bad = (uint64_t)r.bc_off + r.bc_len > tag_bytes || (uint64_t)r.read_off + r.read_len > read_bytes ||
-              r.read_len > max_read_len || (use_umi && !umi_missing && (uint64_t)r.umi_off + r.umi_len > tag_bytes);
-        if (!bad) {
+        const bool bad = (uint64_t)r.bc_off + r.bc_len > tag_bytes || (uint64_t)r.read_off + r.read_len > read_bytes ||
+                         r.read_len > max_read_len || (use_umi && !umi_missing && (uint64_t)r.umi_off + r.umi_len > tag_bytes);
+        if (bad) ++n_bad;
+        else {
             const uint8_t* b = tags + r.bc_off;
             const uint64_t h = vtx_hash_bytes(b, r.bc_len, 0);
             uint32_t cell = 0xffffffffu;
@@ -65,12 +65,10 @@ __global__ __launch_bounds__(256) void prep_resolve_kernel(
                 if (bc_hash[j] != h) continue;
                 const uint64_t o = bc_off[j];
                 if (bc_off[j + 1] - o != r.bc_len) continue;
-                bool eq = true;
-                for (uint32_t k = 0; k < r.bc_len; ++k) eq &= bc_bytes[o + k] == b[k];
-                if (eq) { cell = j; break; }
+                if (vtx_bytes_equal(bc_bytes + o, b, r.bc_len)) { cell = j; break; }
             }
-            if (cell == 0xffffffffu) not_bc = true;                 // :870-876
-            else if (use_umi && umi_missing) no_umi = true;         // :879-888
+            if (cell == 0xffffffffu) ++n_not_bc;                     // :870-876
+            else if (use_umi && umi_missing) ++n_no_umi;             // :879-888
             else {
                 klc = ((uint64_t)rec_locus[i] << cell_bits) | cell;
                 if (use_umi) ku = vtx_hash_bytes(tags + r.umi_off, r.umi_len, seed) & hash_mask;
@@ -78,9 +76,15 @@ __global__ __launch_bounds__(256) void prep_resolve_kernel(
         }
         key_lc[i] = klc; key_umi[i] = ku; idx[i] = i;
     }
-    wave_count_add(not_bc, &counters[0]);
-    wave_count_add(no_umi, &counters[1]);
-    if (bad) atomicOr(&counters[2], 1ull);
+    if (n_not_bc) atomicAdd(&s_cnt[0], n_not_bc);
+    if (n_no_umi) atomicAdd(&s_cnt[1], n_no_umi);
+    if (n_bad) atomicAdd(&s_cnt[2], n_bad);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_cnt[0]) atomicAdd(&counters[0], (unsigned long long)s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&counters[1], (unsigned long long)s_cnt[1]);
+        if (s_cnt[2]) atomicOr(&counters[2], 1ull);
+    }
 }
 
 __global__ __launch_bounds__(256) void prep_gather_u64_kernel(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx,
@@ -96,49 +100,57 @@ __global__ __launch_bounds__(256) void prep_finalize_kernel(
     const uint64_t* __restrict__ key_umi, const vtx_raw_record* __restrict__ raw, const uint8_t* __restrict__ tags,
     const vtx_locus* __restrict__ loci, uint32_t cell_bits, int use_umi, uint32_t n_shapes,
     vtx_record* __restrict__ records, uint32_t* __restrict__ rec_locus, uint32_t* __restrict__ umi_head,
-    uint8_t* __restrict__ shape, uint32_t* __restrict__ seq, uint32_t* __restrict__ locus_cnt,
-    uint32_t* __restrict__ shape_cnt, unsigned long long* __restrict__ counters) {
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    const bool have = j < n_kept;
-    uint32_t my_shape = 0xffu;
+    uint8_t* __restrict__ shape, uint32_t* __restrict__ seq, uint32_t* __restrict__ locus_first,
+    uint32_t* __restrict__ locus_end, uint32_t* __restrict__ shape_cnt, unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t s_shape[16];
+    __shared__ unsigned long long s_cells;
+    __shared__ uint32_t s_maxlen, s_collide;
+    if (threadIdx.x < 16) s_shape[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_cells = 0; s_maxlen = 0; s_collide = 0; }
+    __syncthreads();
     unsigned long long cells = 0;
-    uint32_t rl = 0;
-    if (have) {
+    uint32_t max_rl = 0;
+    bool collide = false;
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n_kept; j += gridDim.x * 256) {
         const uint32_t i = perm[j];
         const uint64_t k = key_lc_sorted[j];
         const uint32_t locus = (uint32_t)(k >> cell_bits), cell = (uint32_t)(k & ((1ull << cell_bits) - 1));
         const vtx_raw_record r = raw[i];
-        bool head = j == 0 || key_lc_sorted[j - 1] != k;
+        const uint64_t kprev = j ? key_lc_sorted[j - 1] : ~0ull;
+        bool head = kprev != k;
         if (use_umi && !head) {
             const uint32_t ip = perm[j - 1];
             if (key_umi[ip] != key_umi[i]) head = true;
             else {
                 // equal hashes inside one (locus, cell): must be the same bytes, else this seed collides
                 const vtx_raw_record q = raw[ip];
-                bool eq = q.umi_len == r.umi_len;
-                if (eq) for (uint32_t t = 0; t < r.umi_len; ++t) eq &= tags[q.umi_off + t] == tags[r.umi_off + t];
-                if (!eq) atomicOr(&counters[4], 1ull);
+                if (q.umi_len != r.umi_len || !vtx_bytes_equal(tags + q.umi_off, tags + r.umi_off, r.umi_len)) collide = true;
             }
         }
         records[j] = vtx_record{r.read_off, r.read_len, cell, 0};
         rec_locus[j] = locus;
         umi_head[j] = head ? 1u : 0u;
         seq[j] = j;
-        atomicAdd(&locus_cnt[locus], 1u);
-        rl = r.read_len;
-        my_shape = 0;
+        // records are sorted by locus: the run boundaries give every locus its record range without atomics
+        if (j == 0 || (uint32_t)(kprev >> cell_bits) != locus) locus_first[locus] = j;
+        if (j + 1 == n_kept || (uint32_t)(key_lc_sorted[j + 1] >> cell_bits) != locus) locus_end[locus] = j + 1;
+        const uint32_t rl = r.read_len;
+        uint32_t my_shape = 0;
         while (my_shape + 1 < n_shapes && c_shape_cap[my_shape] < rl) ++my_shape;
         shape[j] = (uint8_t)my_shape;
-        cells = (unsigned long long)rl * ((unsigned long long)loci[locus].ref_len + loci[locus].alt_len);
+        atomicAdd(&s_shape[my_shape], 1u);            // LDS atomic: mostly one address, the LDS unit coalesces equal-address adds
+        cells += (unsigned long long)rl * ((unsigned long long)loci[locus].ref_len + loci[locus].alt_len);
+        max_rl = max(max_rl, rl);
     }
-    for (uint32_t s = 0; s < n_shapes; ++s) {
-        const unsigned long long m = __ballot(my_shape == s);
-        if (m && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&shape_cnt[s], (uint32_t)__popcll(m));
-    }
-    for (int o = 32; o > 0; o >>= 1) { cells += __shfl_down(cells, o); rl = max(rl, __shfl_down(rl, o)); }
-    if ((threadIdx.x & 63) == 0) {
-        if (cells) atomicAdd(&counters[3], cells);
-        if (rl) atomicMax(&counters[5], (unsigned long long)rl);
+    for (int o = 32; o > 0; o >>= 1) { cells += __shfl_down(cells, o); max_rl = max(max_rl, __shfl_down(max_rl, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cells, cells); atomicMax(&s_maxlen, max_rl); }
+    if (collide) s_collide = 1;
+    __syncthreads();
+    if (threadIdx.x < n_shapes && s_shape[threadIdx.x]) atomicAdd(&shape_cnt[threadIdx.x], s_shape[threadIdx.x]);
+    if (threadIdx.x == 0) {
+        if (s_cells) atomicAdd(&counters[3], s_cells);
+        if (s_maxlen) atomicMax(&counters[5], (unsigned long long)s_maxlen);
+        if (s_collide) atomicOr(&counters[4], 1ull);
     }
 }
 
@@ -146,6 +158,11 @@ __global__ __launch_bounds__(256) void prep_finalize_kernel(
 __global__ __launch_bounds__(256) void prep_umi_id_kernel(vtx_record* __restrict__ records, const uint32_t* __restrict__ umi_scan, uint32_t n) {
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j < n) records[j].umi_id = umi_scan[j] - 1;
+}
+__global__ __launch_bounds__(256) void prep_locus_counts_kernel(uint32_t* __restrict__ first_to_count, const uint32_t* __restrict__ end,
+                                                                uint32_t n_loci) {
+    const uint32_t l = blockIdx.x * 256 + threadIdx.x;
+    if (l < n_loci) first_to_count[l] = end[l] - first_to_count[l];      // both 0 for a locus without records
 }
 __global__ __launch_bounds__(256) void prep_locus_ranges_kernel(vtx_locus* __restrict__ loci, const uint32_t* __restrict__ cnt,
                                                                 const uint32_t* __restrict__ cnt_scan, uint32_t n_loci) {
@@ -204,7 +221,7 @@ hipError_t vtxk_prep_resolve(const vtx_raw_record* raw, uint32_t n, const uint32
                              int use_umi, uint64_t seed, uint64_t hash_mask, uint32_t cell_bits, uint32_t n_loci,
                              uint64_t* key_lc, uint64_t* key_umi, uint32_t* idx, unsigned long long* counters, hipStream_t s) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(prep_resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, s, raw, n, rec_locus, tags, tag_bytes,
+    hipLaunchKernelGGL(prep_resolve_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 256 * 16)), dim3(256), 0, s, raw, n, rec_locus, tags, tag_bytes,
                        read_bytes, max_read_len, bc_slots, bc_mask, bc_hash, bc_off, bc_bytes, use_umi, seed, hash_mask,
                        cell_bits, n_loci, key_lc, key_umi, idx, counters);
     return hipGetLastError();
@@ -219,18 +236,24 @@ hipError_t vtxk_prep_gather_u64(const uint64_t* src, const uint32_t* idx, uint32
 hipError_t vtxk_prep_finalize(uint32_t n_kept, const uint32_t* perm, const uint64_t* key_lc_sorted, const uint64_t* key_umi,
                               const vtx_raw_record* raw, const uint8_t* tags, const vtx_locus* loci, uint32_t cell_bits,
                               int use_umi, uint32_t n_shapes, vtx_record* records, uint32_t* rec_locus, uint32_t* umi_head,
-                              uint8_t* shape, uint32_t* seq, uint32_t* locus_cnt, uint32_t* shape_cnt,
+                              uint8_t* shape, uint32_t* seq, uint32_t* locus_first, uint32_t* locus_end, uint32_t* shape_cnt,
                               unsigned long long* counters, hipStream_t s) {
     if (!n_kept) return hipSuccess;
-    hipLaunchKernelGGL(prep_finalize_kernel, dim3((n_kept + 255) / 256), dim3(256), 0, s, n_kept, perm, key_lc_sorted,
+    hipLaunchKernelGGL(prep_finalize_kernel, dim3(std::min<uint32_t>((n_kept + 255) / 256, 256 * 16)), dim3(256), 0, s, n_kept, perm, key_lc_sorted,
                        key_umi, raw, tags, loci, cell_bits, use_umi, n_shapes, records, rec_locus, umi_head, shape, seq,
-                       locus_cnt, shape_cnt, counters);
+                       locus_first, locus_end, shape_cnt, counters);
     return hipGetLastError();
 }
 
 hipError_t vtxk_prep_umi_ids(vtx_record* records, const uint32_t* umi_scan, uint32_t n, hipStream_t s) {
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(prep_umi_id_kernel, dim3((n + 255) / 256), dim3(256), 0, s, records, umi_scan, n);
+    return hipGetLastError();
+}
+
+hipError_t vtxk_prep_locus_counts(uint32_t* first_to_count, const uint32_t* end, uint32_t n_loci, hipStream_t s) {
+    if (!n_loci) return hipSuccess;
+    hipLaunchKernelGGL(prep_locus_counts_kernel, dim3((n_loci + 255) / 256), dim3(256), 0, s, first_to_count, end, n_loci);
     return hipGetLastError();
 }
 
