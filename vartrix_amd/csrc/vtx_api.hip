@@ -45,7 +45,7 @@ struct DevBuf {
     template <typename T> T* as() const { return (T*)p; }
 };
 
-struct Bucket { int R, GL; uint32_t offset, count; bool lut; };
+struct Bucket { int R, GL; uint32_t offset, count; bool lut; bool duo = false; };
 const uint32_t kLutLociCap = 4;     // loci tables per workgroup of the LUT kernel (6 KiB each at 257 columns)
 
 // (rows per lane, lanes per record) choices; capacity = R * GL read bases.
@@ -317,7 +317,15 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
             const size_t j = std::min(lists[s].size(), i + 16) - 1;
             if (rec_locus[lists[s][j]] - rec_locus[lists[s][i]] + 1 > kLutLociCap) lut = false;
         }
-        c->buckets.push_back(Bucket{kShapes[s][0], kShapes[s][1], (uint32_t)work.size(), (uint32_t)lists[s].size(), lut});
+        // duo kernel (two records per 16-lane row): 32-record workgroups under the same loci cap
+        bool duo = lut;
+        for (size_t i = 0; duo && i < lists[s].size(); i += 32) {
+            const size_t j = std::min(lists[s].size(), i + 32) - 1;
+            if (rec_locus[lists[s][j]] - rec_locus[lists[s][i]] + 1 > kLutLociCap) duo = false;
+        }
+        Bucket bk{kShapes[s][0], kShapes[s][1], (uint32_t)work.size(), (uint32_t)lists[s].size(), lut};
+        bk.duo = duo;
+        c->buckets.push_back(bk);
         work.insert(work.end(), lists[s].begin(), lists[s].end());
     }
 
@@ -433,7 +441,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     HIP_TRY(c, c->d_shape2.reserve(nr + 16));
     HIP_TRY(c, c->d_locus_cnt.reserve(((size_t)nl + 1) * u32));
     HIP_TRY(c, c->d_locus_scan.reserve(((size_t)nl + 1) * u32));
-    HIP_TRY(c, c->d_prep_cnt.reserve(8 * u64 + 32 * u32));
+    HIP_TRY(c, c->d_prep_cnt.reserve(8 * u64 + 48 * u32));
     const size_t sort_tmp = vtxk_prep_sort_temp_bytes(nr);
     HIP_TRY(c, c->d_sort_tmp.reserve(std::max(sort_tmp, vtxk_scan_temp_bytes(std::max(nr, nl)))));
     unsigned long long* d_counters = c->d_prep_cnt.as<unsigned long long>();
@@ -461,7 +469,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     if (nr) HIP_TRY(c, vtxk_prep_rec_locus(c->d_loci.as<vtx_locus>(), nl, c->d_raw_locus.as<uint32_t>(), s));
     for (uint64_t seed = 0x9e3779b97f4a7c15ull;; seed = seed * 0xd1342543de82ef95ull + 1) {
         ++rounds;
-        HIP_TRY(c, hipMemsetAsync(c->d_prep_cnt.p, 0, 8 * u64 + 32 * u32, s));
+        HIP_TRY(c, hipMemsetAsync(c->d_prep_cnt.p, 0, 8 * u64 + 48 * u32, s));
         HIP_TRY(c, hipMemsetAsync(c->d_locus_cnt.p, 0, ((size_t)nl + 1) * u32, s));      // first record of each locus
         HIP_TRY(c, hipMemsetAsync(c->d_locus_scan.p, 0, ((size_t)nl + 1) * u32, s));     // one past its last record
         HIP_TRY(c, vtxk_prep_resolve(c->d_raw.as<vtx_raw_record>(), nr, c->d_raw_locus.as<uint32_t>(), c->d_tags.as<uint8_t>(),
@@ -520,17 +528,26 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     for (int sh = 0; sh < kNumShapes; ++sh) {
         if (!shape_cnt[sh]) continue;
         const bool lut = kShapes[sh][1] == 16 && (size_t)kLutLociCap * (max_hap + 36) * 6 * 4 <= 96 * 1024;
-        if (lut) HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), kLutLociCap,
-                                                d_lut_flag + c->buckets.size(), s));
-        c->buckets.push_back(Bucket{kShapes[sh][0], kShapes[sh][1], off, shape_cnt[sh], lut});
+        if (lut) {
+            HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), kLutLociCap, 16,
+                                           d_lut_flag + c->buckets.size(), s));
+            HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), kLutLociCap, 32,
+                                           d_lut_flag + 16 + c->buckets.size(), s));
+        }
+        Bucket bk{kShapes[sh][0], kShapes[sh][1], off, shape_cnt[sh], lut};
+        bk.duo = lut;
+        c->buckets.push_back(bk);
         off += shape_cnt[sh];
     }
-    uint32_t lut_flag[16] = {0};
+    uint32_t lut_flag[32] = {0};
     HIP_TRY(c, hipMemcpyAsync(lut_flag, d_lut_flag, sizeof lut_flag, hipMemcpyDeviceToHost, s));
     if (int rc = build_groups(c, n_kept)) return rc;
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    for (size_t i = 0; i < c->buckets.size(); ++i) if (lut_flag[i]) c->buckets[i].lut = false;
+    for (size_t i = 0; i < c->buckets.size(); ++i) {
+        if (lut_flag[i]) c->buckets[i].lut = false;
+        if (lut_flag[i] || lut_flag[16 + i]) c->buckets[i].duo = false;
+    }
     float ms = 0;
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->n_loci = nl; c->n_records = n_kept; c->max_hap_len = max_hap; c->max_read_len = (uint32_t)cnt[5]; c->cells = cnt[3];
@@ -570,7 +587,14 @@ int vtx_run(vtx_ctx* c) {
     if (any_lut) HIP_TRY(c, hipMemsetAsync(c->d_redo_cnt.p, 0, 16 * sizeof(uint32_t), s));
     for (size_t b = 0; b < c->buckets.size(); ++b) {
         const Bucket& bk = c->buckets[b];
-        if (bk.lut) {
+        static const bool no_duo = getenv("VTX_DP_KERNEL") && !strcmp(getenv("VTX_DP_KERNEL"), "lut");
+        if (bk.lut && bk.duo && !no_duo) {
+            HIP_TRY(c, vtxk_launch_sw_full_duo(bk.R, bk.count, c->d_work.as<uint32_t>() + bk.offset, c->d_records.as<vtx_record>(),
+                                               c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                               c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
+                                               c->max_hap_len, kLutLociCap, c->d_redo.as<uint32_t>() + bk.offset,
+                                               c->d_redo_cnt.as<uint32_t>() + b, s));
+        } else if (bk.lut) {
             HIP_TRY(c, vtxk_launch_sw_full_lut(bk.R, bk.count, c->d_work.as<uint32_t>() + bk.offset, c->d_records.as<vtx_record>(),
                                                c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
                                                c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),

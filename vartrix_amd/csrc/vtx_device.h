@@ -37,6 +37,10 @@ hipError_t vtxk_launch_sw_full_lut(int R, uint32_t n_work, const uint32_t* work,
                                    const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                    const uint8_t* hap_arena, int32_t* ref_score, int32_t* alt_score, uint32_t max_hap_len,
                                    uint32_t loci_cap, uint32_t* redo, uint32_t* redo_count, hipStream_t stream);
+hipError_t vtxk_launch_sw_full_duo(int R, uint32_t n_work, const uint32_t* work, const vtx_record* records,
+                                   const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
+                                   const uint8_t* hap_arena, int32_t* ref_score, int32_t* alt_score, uint32_t max_hap_len,
+                                   uint32_t loci_cap, uint32_t* redo, uint32_t* redo_count, hipStream_t stream);
 hipError_t vtxk_launch_sw_banded(int R, int GL, uint32_t n_hard, const uint32_t* hard, const vtx_record* records,
                                  const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                  const uint8_t* hap_arena, const uint16_t* band, uint32_t band_stride, int32_t* ref_score,
@@ -97,7 +101,7 @@ hipError_t vtxk_prep_finalize(uint32_t n_kept, const uint32_t* perm, const uint6
 hipError_t vtxk_prep_locus_counts(uint32_t* first_to_count, const uint32_t* end, uint32_t n_loci, hipStream_t s);
 hipError_t vtxk_prep_umi_ids(vtx_record* records, const uint32_t* umi_scan, uint32_t n, hipStream_t s);
 hipError_t vtxk_prep_locus_ranges(vtx_locus* loci, const uint32_t* cnt, const uint32_t* cnt_scan, uint32_t n_loci, hipStream_t s);
-hipError_t vtxk_prep_lut_check(const uint32_t* work, uint32_t count, const uint32_t* rec_locus, uint32_t cap, uint32_t* flag,
-                               hipStream_t s);
+hipError_t vtxk_prep_lut_check(const uint32_t* work, uint32_t count, const uint32_t* rec_locus, uint32_t cap, uint32_t group,
+                               uint32_t* flag, hipStream_t s);
 }
 #endif

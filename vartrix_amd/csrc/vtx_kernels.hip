@@ -704,6 +704,297 @@ __global__ __launch_bounds__(256) void sw_full_lut_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// sw_full_duo_kernel — the LUT kernel with the REF == ALT haplotype prefix computed once for TWO reads.
+//
+// Before the variant column v the two haplotypes of a locus are the same string, so the {REF, ALT} halves
+// of the LUT kernel compute the same numbers there.  Here a 16-lane row takes two records A and B and
+// runs ONE systolic pipeline through three phases without draining it:
+//     P : columns [0, v4)        halves = {A vs REF, B vs REF}      (two LUT lookups + one v_perm per cell)
+//     A : columns [v4, v4 + S)   halves = {A vs REF, A vs ALT}      (as the LUT kernel)
+//     B : columns [v4, v4 + S)   halves = {B vs REF, B vs ALT}
+// v4 = (common prefix of the wave's haplotype pairs) rounded down to 4, S = suffix length rounded up.
+// Lane l is l columns behind lane 0, so it changes phase l steps later: the 16 steps after a phase
+// boundary are "window" steps in which exactly lane d = (step - boundary) rewrites its own state
+// (exec-masked), after the DPP exchange of that step, so that the lane below still receives the
+// old-phase values it needs:
+//     P -> A : the B halves of H(column v4-1), E, the diagonal carry and `best` are packed into one VGPR
+//              per row (the registers that held B's LUT addresses), the A halves are duplicated.
+//     A -> B : A's best is set aside, B's state is unpacked into both halves, B's LUT addresses are
+//              rebuilt for column v4 from its 3-bit row codes.
+// Steps per pair: v4 + 2 S + 16 instead of 2 (n + 16): 324 vs 432 for an SNV at padding 100.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t perm_b32(uint32_t hi_src, uint32_t lo_src, uint32_t sel) {
+    return __builtin_amdgcn_perm(hi_src, lo_src, sel);      // selector bytes 0-3: lo_src, 4-7: hi_src
+}
+#define SEL_LO_LO 0x01000100u      /* {x.lo, x.lo} of lo_src                     */
+#define SEL_HI_HI 0x03020302u      /* {x.hi, x.hi} of lo_src                     */
+#define SEL_LOA_LOB 0x05040100u    /* {lo_src.lo, hi_src.lo}                     */
+#define SEL_HIA_HIB 0x07060302u    /* {lo_src.hi, hi_src.hi}                     */
+#define SEL_IDENT 0x03020100u      /* lo_src                                     */
+
+template <int R>
+__global__ __launch_bounds__(256) void sw_full_duo_kernel(
+    const uint32_t* __restrict__ work, uint32_t n_work,
+    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus,
+    const vtx_locus* __restrict__ loci,
+    const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
+    int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score, uint32_t lcols, uint32_t loci_cap,
+    uint32_t* __restrict__ redo, uint32_t* __restrict__ redo_count) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ uint32_t s_v[8];                           // common REF/ALT prefix length per table
+    constexpr int GL = 16;
+    constexpr int PAIRS_PER_BLOCK = 16;
+    constexpr int PRE = GL;
+    const int tid = threadIdx.x;
+    const int grp = tid / GL;
+    const int l = tid % GL;
+    const uint32_t pair = blockIdx.x * PAIRS_PER_BLOCK + grp;
+    const bool active = 2 * pair < n_work;
+    const bool has_b = 2 * pair + 1 < n_work;
+
+    uint32_t rid_a = 0, rid_b = 0, m_a = 0, m_b = 0, roff_a = 0, roff_b = 0, loc_a = 0, loc_b = 0, n = 0;
+    const uint32_t w_first = blockIdx.x * 2 * PAIRS_PER_BLOCK;
+    const uint32_t w_last = min(n_work - 1, w_first + 2 * PAIRS_PER_BLOCK - 1);
+    const uint32_t l_first = rec_locus[work[w_first]], l_last = rec_locus[work[w_last]];
+    const uint32_t n_loc = l_last - l_first + 1;          // <= loci_cap (checked when this kernel is chosen)
+    if (active) {
+        rid_a = work[2 * pair];
+        rid_b = has_b ? work[2 * pair + 1] : rid_a;
+        const vtx_record ra = records[rid_a], rb = records[rid_b];
+        loc_a = rec_locus[rid_a]; loc_b = rec_locus[rid_b];
+        const vtx_locus la = loci[loc_a], lb = loci[loc_b];
+        m_a = ra.read_len; roff_a = ra.read_off; m_b = rb.read_len; roff_b = rb.read_off;
+        n = max(max(la.ref_len, la.alt_len), max(lb.ref_len, lb.alt_len));
+    } else {
+        loc_a = loc_b = l_first;                           // idle rows read a valid table
+    }
+
+    // ---- tables of loci l_first .. l_last (as sw_full_lut_kernel) + their common prefix lengths ----
+    const uint32_t tab_words = lcols * LUT_CODES;
+    if ((uint32_t)tid < n_loc && (uint32_t)tid < 8) s_v[tid] = min(loci[l_first + tid].ref_len, loci[l_first + tid].alt_len);
+    __syncthreads();
+    for (uint32_t t = 0; t < n_loc && t < loci_cap; ++t) {
+        const vtx_locus loc = loci[l_first + t];
+        uint32_t* tab = smem + (size_t)t * tab_words;
+        for (uint32_t idx = tid; idx < lcols; idx += 256) {
+            const int j = (int)idx - PRE;
+            uint32_t rc = 0x200u, ac = 0x200u;            // sentinel: equals no base
+            if (j >= 0) {
+                if ((uint32_t)j < loc.ref_len) rc = hap_arena[loc.ref_off + j];
+                if ((uint32_t)j < loc.alt_len) ac = hap_arena[loc.alt_off + j];
+                if (rc != ac && (uint32_t)j < min(loc.ref_len, loc.alt_len)) atomicMin(&s_v[t], (uint32_t)j);
+            }
+            const uint32_t bases[5] = {'A', 'C', 'G', 'T', 'N'};
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const uint32_t wr = (rc == bases[k]) ? 0x0001u : 0xfffbu;
+                const uint32_t wa = (ac == bases[k]) ? 0x0001u : 0xfffbu;
+                tab[idx * LUT_CODES + k] = wr | (wa << 16);
+            }
+            tab[idx * LUT_CODES + 5] = 0xfffbfffbu;
+        }
+    }
+
+    // ---- rows of this lane for both reads ----
+    const uint32_t lane_base_a = ((uint32_t)(loc_a - l_first) * tab_words + (uint32_t)(PRE - l) * LUT_CODES) * 4u;
+    const uint32_t lane_base_b = ((uint32_t)(loc_b - l_first) * tab_words + (uint32_t)(PRE - l) * LUT_CODES) * 4u;
+    uint32_t addr[R], X[R];                               // X: B's LUT addresses in phase P, B's saved state in phase A
+    uint64_t codes_b = 0;
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = (uint32_t)(l * R + r);
+        uint32_t ca = 5, cb = 5;
+        if (i < m_a) { ca = base_code(read_arena[roff_a + i]); if (ca > 5) { bad = true; ca = 5; } }
+        if (i < m_b) { cb = base_code(read_arena[roff_b + i]); if (cb > 5) { bad = true; cb = 5; } }
+        addr[r] = lane_base_a + ca * 4u;
+        X[r] = lane_base_b + cb * 4u;
+        codes_b |= (uint64_t)cb << (3 * r);
+    }
+    __syncthreads();
+    uint32_t badm = bad ? 1u : 0u;
+#pragma unroll
+    for (int off = 1; off < GL; off <<= 1) badm |= (uint32_t)__shfl_xor((int)badm, off);
+
+    // ---- wave-uniform phase lengths ----
+    uint32_t vw = min(s_v[loc_a - l_first], s_v[loc_b - l_first]);
+    vw = min(vw, (uint32_t)__shfl_xor((int)vw, 16));
+    vw = min(vw, (uint32_t)__shfl_xor((int)vw, 32));
+    uint32_t nw = n;
+    nw = max(nw, (uint32_t)__shfl_xor((int)nw, 16));
+    nw = max(nw, (uint32_t)__shfl_xor((int)nw, 32));
+    nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)nw);
+    uint32_t v4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)vw) & ~3u;
+    if (v4 > nw) v4 = nw & ~3u;
+    if (nw - v4 < 16) v4 = nw > 16 ? (nw - 16) & ~3u : 0;          // both windows need 16 steps of suffix
+    uint32_t S = (nw - v4 + 3) & ~3u;
+    if (S < 16) S = 16;
+
+    uint32_t Ha[R], Hb[R], Q[R], E[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { Ha[r] = 0; Hb[r] = 0; Q[r] = 0; E[r] = 0; }
+    uint32_t best = 0, out_a = 0, misc = 0, sel = SEL_LOA_LOB;
+    uint32_t hu_a = 0, hu_b = 0, qu = 0, fu = 0, f_last = 0, q_bottom = 0;
+    const char* lds = (const char*)smem;
+
+#define DUO_EXCHANGE(hcur, hsrc)                                                                   \
+        hcur = lane_shr1<DPP_ROW_SHR1>(hcur, hsrc);                                                \
+        qu = lane_shr1<DPP_ROW_SHR1>(qu, q_bottom);                                                \
+        fu = lane_shr1<DPP_ROW_SHR1>(fu, f_last);
+    // the DP column update given the substitution words W(r)
+#define DUO_COLUMN(HS, HD, hprev, W)                                                               \
+    {                                                                                              \
+        uint32_t hd = hprev, qa = qu, fa = fu;                                                     \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) {                                            \
+            const uint32_t w = W;                                                                  \
+            const uint32_t tt = pk_add(hd, w);                                                     \
+            hd = HS[r];                                                                            \
+            const uint32_t e = pk_max(pk_sub_sat(E[r], PK(1)), Q[r]);                              \
+            const uint32_t f = pk_max(pk_sub_sat(fa, PK(1)), qa);                                  \
+            const uint32_t h = pk_max(pk_max(tt, e), f);                                           \
+            best = pk_max(best, tt);                                                               \
+            E[r] = e;                                                                              \
+            HD[r] = h;                                                                             \
+            Q[r] = pk_sub_sat(h, PK(6));                                                           \
+            fa = f; qa = Q[r];                                                                     \
+        }                                                                                          \
+        f_last = fa; q_bottom = Q[R - 1];                                                          \
+    }
+#define LDSW(a, OFF) (*(const uint32_t*)(lds + (a) + (OFF)))
+#define W_P(OFF) perm_b32(LDSW(X[r], OFF), LDSW(addr[r], OFF), SEL_LOA_LOB)
+#define W_S(OFF) LDSW(addr[r], OFF)
+#define W_W1(OFF) perm_b32(LDSW(in_p ? X[r] : addr[r], OFF), LDSW(addr[r], OFF), sel)
+#define STEP4(STEP)                                                                                \
+        STEP(Hb, Ha, hu_b, hu_a, 0 * LUT_CODES * 4, 0)                                             \
+        STEP(Ha, Hb, hu_a, hu_b, 1 * LUT_CODES * 4, 1)                                             \
+        STEP(Hb, Ha, hu_b, hu_a, 2 * LUT_CODES * 4, 2)                                             \
+        STEP(Ha, Hb, hu_a, hu_b, 3 * LUT_CODES * 4, 3)
+
+    // ---------------- phase P: columns [0, v4), halves {A, B} ----------------
+#define P_STEP(HS, HD, hprev, hcur, OFF, SUB) { DUO_EXCHANGE(hcur, HS[R - 1]) DUO_COLUMN(HS, HD, hprev, W_P(OFF)) }
+    for (uint32_t t4 = 0; t4 < (v4 >> 2); ++t4) {
+        STEP4(P_STEP)
+#pragma unroll
+        for (int r = 0; r < R; ++r) { addr[r] += 4 * LUT_CODES * 4; X[r] += 4 * LUT_CODES * 4; }
+    }
+    // ---------------- window 1: lane d leaves phase P at step v4 + d ----------------
+#define W1_STEP(HS, HD, hprev, hcur, OFF, SUB)                                                     \
+    {                                                                                              \
+        DUO_EXCHANGE(hcur, HS[R - 1])                                                              \
+        if ((uint32_t)l == 4 * g + SUB) {                                                          \
+            _Pragma("unroll") for (int r = 0; r < R; ++r) {                                        \
+                X[r] = perm_b32(E[r], HS[r], SEL_HIA_HIB);      /* {H_B, E_B} */                    \
+                HS[r] = perm_b32(0, HS[r], SEL_LO_LO);                                             \
+                E[r] = perm_b32(0, E[r], SEL_LO_LO);                                               \
+                Q[r] = perm_b32(0, Q[r], SEL_LO_LO);                                               \
+            }                                                                                      \
+            misc = perm_b32(best, hprev, SEL_HIA_HIB);          /* {diag_B, best_B} */              \
+            hprev = perm_b32(0, hprev, SEL_LO_LO);                                                 \
+            best = perm_b32(0, best, SEL_LO_LO);                                                   \
+            sel = SEL_IDENT;                                                                       \
+        }                                                                                          \
+        const bool in_p = (uint32_t)l > 4 * g + SUB;                                               \
+        DUO_COLUMN(HS, HD, hprev, W_W1(OFF))                                                       \
+    }
+    for (uint32_t g = 0; g < 4; ++g) {
+        STEP4(W1_STEP)
+        const uint32_t inc_x = (uint32_t)l > 4 * g + 3 ? 4u * LUT_CODES * 4 : 0u;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { addr[r] += 4 * LUT_CODES * 4; X[r] += inc_x; }
+    }
+    // ---------------- phases A and B (single lookup), window 2 in between ----------------
+#define S_STEP(HS, HD, hprev, hcur, OFF, SUB) { DUO_EXCHANGE(hcur, HS[R - 1]) DUO_COLUMN(HS, HD, hprev, W_S(OFF)) }
+#define W2_STEP(HS, HD, hprev, hcur, OFF, SUB)                                                     \
+    {                                                                                              \
+        DUO_EXCHANGE(hcur, HS[R - 1])                                                              \
+        if ((uint32_t)l == 4 * g + SUB) {                                                          \
+            out_a = best;                                                                          \
+            _Pragma("unroll") for (int r = 0; r < R; ++r) {                                        \
+                HS[r] = perm_b32(0, X[r], SEL_LO_LO);                                              \
+                E[r] = perm_b32(0, X[r], SEL_HI_HI);                                               \
+                Q[r] = pk_sub_sat(HS[r], PK(6));                                                   \
+                addr[r] = lane_base_b + (v4 + 4 * g) * (LUT_CODES * 4) + ((uint32_t)(codes_b >> (3 * r)) & 7u) * 4u; \
+            }                                                                                      \
+            hprev = perm_b32(0, misc, SEL_LO_LO);                                                  \
+            best = perm_b32(0, misc, SEL_HI_HI);                                                   \
+        }                                                                                          \
+        DUO_COLUMN(HS, HD, hprev, W_S(OFF))                                                        \
+    }
+    for (uint32_t phase = 0; phase < 2; ++phase) {
+        const uint32_t n4 = (phase == 0 ? S - 16 : S) >> 2;
+        for (uint32_t t4 = 0; t4 < n4; ++t4) {
+            STEP4(S_STEP)
+#pragma unroll
+            for (int r = 0; r < R; ++r) addr[r] += 4 * LUT_CODES * 4;
+        }
+        if (phase == 0) {
+            for (uint32_t g = 0; g < 4; ++g) {
+                STEP4(W2_STEP)
+#pragma unroll
+                for (int r = 0; r < R; ++r) addr[r] += 4 * LUT_CODES * 4;
+            }
+        }
+    }
+#undef P_STEP
+#undef W1_STEP
+#undef S_STEP
+#undef W2_STEP
+#undef STEP4
+#undef W_P
+#undef W_S
+#undef W_W1
+#undef LDSW
+#undef DUO_COLUMN
+#undef DUO_EXCHANGE
+
+#pragma unroll
+    for (int off = 1; off < GL; off <<= 1) {
+        best = pk_max(best, (uint32_t)__shfl_xor((int)best, off));
+        out_a = pk_max(out_a, (uint32_t)__shfl_xor((int)out_a, off));
+    }
+    if (active && l == 0) {
+        if (badm) {
+            const uint32_t k = atomicAdd(redo_count, has_b ? 2u : 1u);
+            redo[k] = rid_a;
+            if (has_b) redo[k + 1] = rid_b;
+        } else {
+            ref_score[rid_a] = (int32_t)(int16_t)(out_a & 0xffffu);
+            alt_score[rid_a] = (int32_t)(int16_t)(out_a >> 16);
+            if (has_b) {
+                ref_score[rid_b] = (int32_t)(int16_t)(best & 0xffffu);
+                alt_score[rid_b] = (int32_t)(int16_t)(best >> 16);
+            }
+        }
+    }
+}
+
+extern "C" hipError_t vtxk_launch_sw_full_duo(int R, uint32_t n_work, const uint32_t* work, const vtx_record* records,
+                                              const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
+                                              const uint8_t* hap_arena, int32_t* ref_score, int32_t* alt_score,
+                                              uint32_t max_hap_len, uint32_t loci_cap, uint32_t* redo, uint32_t* redo_count,
+                                              hipStream_t stream) {
+    if (n_work == 0) return hipSuccess;
+    // columns: PRE sentinels + haplotype (at least the 16 steps of a window) + lane skew + 4x unroll slack
+    const uint32_t lcols = 16 + (max_hap_len > 16 ? max_hap_len : 16) + 16 + 4;
+    const size_t shmem = (size_t)loci_cap * lcols * LUT_CODES * sizeof(uint32_t);
+    const dim3 grid((n_work + 31) / 32), block(256);
+#define CASE(r)                                                                                          \
+    if (R == r) {                                                                                        \
+        if (shmem > 48 * 1024) {                                                                         \
+            hipError_t e = hipFuncSetAttribute((const void*)sw_full_duo_kernel<r>,                       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  \
+            if (e != hipSuccess) return e;                                                               \
+        }                                                                                                \
+        hipLaunchKernelGGL((sw_full_duo_kernel<r>), grid, block, shmem, stream, work, n_work, records,   \
+                           rec_locus, loci, read_arena, hap_arena, ref_score, alt_score, lcols, loci_cap, redo, redo_count); \
+        return hipGetLastError();                                                                        \
+    }
+    CASE(2) CASE(4) CASE(6) CASE(8) CASE(10) CASE(12) CASE(16)
+#undef CASE
+    return hipErrorInvalidValue;
+}
+
 extern "C" hipError_t vtxk_launch_sw_full_lut(int R, uint32_t n_work, const uint32_t* work, const vtx_record* records,
                                               const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                               const uint8_t* hap_arena, int32_t* ref_score, int32_t* alt_score,

@@ -170,13 +170,13 @@ __global__ __launch_bounds__(256) void prep_locus_ranges_kernel(vtx_locus* __res
     if (l < n_loci) { loci[l].rec_count = cnt[l]; loci[l].rec_begin = cnt_scan[l] - cnt[l]; }
 }
 
-// LUT-kernel eligibility of one work list: no 16-record workgroup may span more than `cap` loci
+// LUT-kernel eligibility of one work list: no `group`-record workgroup may span more than `cap` loci
 __global__ __launch_bounds__(256) void prep_lut_check_kernel(const uint32_t* __restrict__ work, uint32_t count,
                                                              const uint32_t* __restrict__ rec_locus, uint32_t cap,
-                                                             uint32_t* __restrict__ flag) {
+                                                             uint32_t group, uint32_t* __restrict__ flag) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    if ((uint64_t)g * 16 >= count) return;
-    const uint32_t a = work[g * 16], b = work[min(count, g * 16 + 16) - 1];
+    if ((uint64_t)g * group >= count) return;
+    const uint32_t a = work[g * group], b = work[min(count, g * group + group) - 1];
     if (rec_locus[b] - rec_locus[a] + 1 > cap) *flag = 1;
 }
 
@@ -263,11 +263,11 @@ hipError_t vtxk_prep_locus_ranges(vtx_locus* loci, const uint32_t* cnt, const ui
     return hipGetLastError();
 }
 
-hipError_t vtxk_prep_lut_check(const uint32_t* work, uint32_t count, const uint32_t* rec_locus, uint32_t cap, uint32_t* flag,
-                               hipStream_t s) {
+hipError_t vtxk_prep_lut_check(const uint32_t* work, uint32_t count, const uint32_t* rec_locus, uint32_t cap, uint32_t group,
+                               uint32_t* flag, hipStream_t s) {
     if (!count) return hipSuccess;
-    const uint32_t groups = (count + 15) / 16;
-    hipLaunchKernelGGL(prep_lut_check_kernel, dim3((groups + 255) / 256), dim3(256), 0, s, work, count, rec_locus, cap, flag);
+    const uint32_t groups = (count + group - 1) / group;
+    hipLaunchKernelGGL(prep_lut_check_kernel, dim3((groups + 255) / 256), dim3(256), 0, s, work, count, rec_locus, cap, group, flag);
     return hipGetLastError();
 }
 
