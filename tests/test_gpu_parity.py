@@ -315,3 +315,90 @@ def test_banded_repeat_rich_genome_vs_oracle():
     for aligner in ALIGNERS:
         cfg = default_config(aligner=aligner, scoring_mode="coverage", n_barcodes=30)
         assert_same(batch, cfg, threads=os.cpu_count() or 8)
+
+
+@pytest.mark.parametrize("aligner", ALIGNERS)
+def test_shared_prefix_kernel_corner_cases(aligner):
+    """sw_full_duo_kernel shares the REF == ALT prefix between two reads of a 16-lane row.  Corner cases of
+    its phase arithmetic: prefixes shorter than 4 columns (variant at the haplotype start), haplotypes shorter
+    than a 16-step window, neighbouring loci with different prefix lengths paired in one row, an odd number
+    of records, identical REF and ALT (prefix = the whole haplotype), variant in the last columns, reads of
+    mixed length inside a row, and a byte outside ACGTN in one read of a pair (both are re-scored)."""
+    rng = np.random.default_rng(2024)
+    g = bytes(rng.choice(list(b"ACGT"), 3000).tolist())
+
+    def mut(c):
+        return bytes([b"ACGT"[(b"ACGT".index(bytes([c])) + 1) % 4]])
+
+    haps, reads = [], []
+    specs = [  # (left flank, right flank, variant kind)
+        (0, 100, "snv"), (1, 100, "snv"), (3, 60, "ins"), (5, 100, "del"), (100, 100, "snv"), (100, 0, "snv"),
+        (100, 2, "ins"), (7, 6, "snv"), (2, 3, "snv"), (60, 100, "same"), (100, 100, "del"), (33, 100, "ins"),
+        (12, 9, "del"), (100, 100, "snv")]
+    for k, (lf, rf, kind) in enumerate(specs):
+        p = 200 + 190 * k
+        left, right = g[p - lf:p], g[p + 1:p + 1 + rf]
+        refa = g[p:p + 1]
+        if kind == "snv":
+            ref, alt = left + refa + right, left + mut(refa[0]) + right
+        elif kind == "ins":
+            ref, alt = left + refa + right, left + refa + b"ACGTTGCA"[:1 + k % 7] + right
+        elif kind == "del":
+            ref, alt = left + g[p:p + 6] + g[p + 6:p + 6 + rf], left + refa + g[p + 6:p + 6 + rf]
+        else:
+            ref = alt = left + refa + right
+        haps.append((ref, alt))
+        rl = []
+        n_reads = 1 + (k * 5) % 9           # 1..9 reads: rows pair reads of neighbouring loci
+        for q in range(n_reads):
+            src = alt if q % 2 else ref
+            ln = int(rng.integers(1, max(2, min(150, len(src)) + 1)))
+            s0 = int(rng.integers(0, len(src) - ln + 1))
+            rd = bytearray(src[s0:s0 + ln])
+            if rng.random() < 0.3 and ln > 4:
+                rd[int(rng.integers(0, ln))] = mut(rd[0])[0]
+            if k == 4 and q == 1:
+                rd[len(rd) // 2] = ord("R")          # IUPAC byte: not in the LUT alphabet
+            if k == 6 and q == 0:
+                rd = bytearray(rd.lower())            # lower-case read: byte equality says mismatch everywhere
+            rl.append((int(rng.integers(0, 6)), int(rng.integers(0, 3)), bytes(rd)))
+        reads.append(rl)
+    if sum(len(r) for r in reads) % 2 == 0:
+        reads[-1].append((0, 0, haps[-1][0][20:170]))
+    batch = _manual_batch(haps, reads, 6)
+    assert batch.n_records % 2 == 1
+    for mode, umi in (("coverage", 0), ("alt_frac", 1)):
+        cfg = default_config(aligner=aligner, scoring_mode=mode, use_umi=umi, n_barcodes=6)
+        assert_same(batch, cfg, threads=4)
+
+
+def test_shared_prefix_kernel_equals_single_read_kernel():
+    """The same batches through both DP kernels (VTX_DP_KERNEL=lut disables the shared-prefix kernel)."""
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np
+from vartrix_amd import lib, synth
+from vartrix_amd.abi import default_config
+out = []
+for seed, indel, jitter, rl, pad in ((1, 0.0, 0, 150, 100), (2, 0.5, 50, 120, 70), (3, 1.0, 30, 90, 10), (4, 0.3, 90, 100, 2)):
+    spec = synth.SynthSpec(n_loci=300, n_barcodes=50, reads_per_locus=37, read_len=rl, padding=pad, indel_frac=indel,
+                           read_len_jitter=jitter, seed=seed)
+    batch = synth.make_batch(spec)
+    with lib.Context(default_config(aligner="full", scoring_mode="coverage", n_barcodes=50)) as ctx:
+        ctx.submit(batch); ctx.run()
+        r, a = ctx.fetch_scores()
+    out.append(np.concatenate([r, a]))
+np.save(OUT, np.concatenate(out))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for kern in ("duo", "lut"):
+        path = "/tmp/vtx_dp_%s_%d.npy" % (kern, os.getpid())
+        env = dict(os.environ, VTX_DP_KERNEL=kern, PYTHONPATH=root)
+        p = subprocess.run([sys.executable, "-c", code.replace("OUT", repr(path))], env=env, cwd=root, capture_output=True,
+                           text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[kern] = np.load(path)
+        os.remove(path)
+    assert res["duo"].size > 80000 and np.array_equal(res["duo"], res["lut"])
