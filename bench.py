@@ -175,7 +175,7 @@ def main():
 
     # secondary: the other aligner flavour on the same resident-size batch (rank 0 only, single GPU timing)
     other = None
-    if rank == 0 and not args.no_other_aligner:
+    if rank == 0 and world == 1 and not args.no_other_aligner:      # N = 1 only: the other ranks would idle at the barrier
         oname = "full" if args.aligner == "banded" else "banded"
         ocfg = default_config(aligner=oname, scoring_mode=args.mode, use_umi=args.umi, n_barcodes=args.barcodes, device=local_rank)
         octx = lib.Context(ocfg)
@@ -216,12 +216,19 @@ def main():
                        "loci_per_gpu": args.loci, "barcodes": args.barcodes, "scored_reads_per_gpu": batch.n_records,
                        "alignments_per_step": total_aln, "dp_cells_per_step": total_cells, "triplets": total_nnz,
                        "sharding": "loci (matrix rows) per rank, COO rows gathered to rank 0" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("sw_full_lut_kernel" if args.aligner == "full" else "sw_full_lut_kernel + band_fast_kernel + band_kernel + sw_banded_kernel") + " (%d launches)" % launches,
-                         "kernel_ms": sw_avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "integer DP: the binding roof is VALU, see roofline_valu; HBM fraction is reported as north_star asks"},
-            "roofline_valu": {"bound": "valu", "kernel": "sw_full_lut_kernel", "kernel_ms": full_avg_ms,
+            # dominant kernel: sw_full_duo_kernel (62 % of the step; profiles/r01_duo_kernel_stats_100k_banded.csv).  Its
+            # duration is the ctx's hipEvent pair around the DP launches (vtx_timing.full_ms), live in this run.
+            "roofline": {"bound": "hbm", "kernel": "sw_full_duo_kernel (1 launch per step)", "kernel_ms": full_avg_ms,
+                         "achieved": alg_bytes / (full_avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_bytes / (full_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "whole_sw_stage": {"kernels": ("sw_full_duo_kernel" if args.aligner == "full" else "sw_full_duo_kernel + band_run_kernel + band_kernel + band_expand_kernel + sw_banded_kernel") + " (%d launches)" % launches,
+                                            "ms": sw_avg_ms, "achieved": achieved_gbs},
+                         "note": "integer DP: the binding roof is VALU issue, see roofline_valu; the HBM fraction is reported because north_star asks for it"},
+            "roofline_valu": {"bound": "valu", "kernel": "sw_full_duo_kernel", "kernel_ms": full_avg_ms,
+                              "note": "algorithmic ops = 9 packed ops x (read x haplotype cells of both alignments) / 2; the kernel "
+                                      "shares the REF == ALT prefix columns between two reads, so it EXECUTES ~25 % fewer cell "
+                                      "updates than that (DESIGN.md 4.1)",
                               "achieved": lane_ops / (full_avg_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS,
                               "unit": "T packed-lane-ops/s", "frac": lane_ops / (full_avg_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
                               "gcups": cells / (full_avg_ms * 1e-3) / 1e9, "ops_per_cell_pair": OPS_PER_CELL_PAIR},
@@ -232,7 +239,7 @@ def main():
         if other is not None:
             out["other_aligner"] = other
         out["timing"]["hard_tasks"] = int(ctx.timing().hard_tasks)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:                  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(batch, cfg, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     ctx.close()
