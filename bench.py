@@ -196,15 +196,16 @@ def main():
         launches = ctx.timing().sw_launches
         alg_bytes = algorithmic_bytes(batch)
         achieved_gbs = alg_bytes / (sw_avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, lds_pmc = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("workload_records") == batch.n_records:
+                if j.get("workload_records") == batch.n_records:      # counters of exactly this workload (separate rocprofv3 --pmc runs)
                     traffic = j.get("hbm_bytes_per_launch")
+                    lds_pmc = j.get("lds")
             except Exception:
-                traffic = None
+                traffic, lds_pmc = None, None
         lane_ops = cells / 2 * OPS_PER_CELL_PAIR            # useful packed ops of rank 0's sw_full_kernel launch(es)
         full_avg_ms = float(np.mean(full_ms))
         out = {
@@ -221,7 +222,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "sw_full_duo_kernel (1 launch per step)", "kernel_ms": full_avg_ms,
                          "achieved": alg_bytes / (full_avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg_bytes / (full_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_per_launch": alg_bytes, "lds_pmc": lds_pmc,
                          "whole_sw_stage": {"kernels": ("sw_full_duo_kernel" if args.aligner == "full" else "sw_full_duo_kernel + band_run_kernel + band_kernel + band_expand_kernel + sw_banded_kernel") + " (%d launches)" % launches,
                                             "ms": sw_avg_ms, "achieved": achieved_gbs},
                          "note": "integer DP: the binding roof is VALU issue, see roofline_valu; the HBM fraction is reported because north_star asks for it"},

@@ -90,3 +90,34 @@ def test_ref_alt_swap_symmetry(big):
         sref, salt, scoo = run(swapped, cfg)
         assert np.array_equal(ref, salt) and np.array_equal(alt, sref)
         assert np.array_equal(coo["alt"], scoo["ref"]) and np.array_equal(coo["ref"], scoo["alt"])
+
+
+@pytest.mark.parametrize("aligner", ["banded", "full"])
+def test_config5_shape_against_oracle(aligner):
+    """BASELINE.json configs[4] at reduced size: mixed SNV + indel (<= 20 bp) loci, alt_frac with UMI collapse —
+    every score and every matrix value against the oracle (alt_frac within the stated 1e-6; it is in fact
+    bit-identical), then the same batch as two shards (the multi-GPU path's partition) gives the same matrix."""
+    import os
+    from vartrix_amd import shard
+    spec = synth.config5(2500)
+    batch = synth.make_batch(spec)
+    assert len(np.unique(batch.loci["ref_len"] - batch.loci["alt_len"].astype(np.int64))) > 10      # indels both ways
+    cfg = default_config(aligner=aligner, scoring_mode="alt_frac", use_umi=1, n_barcodes=spec.n_barcodes)
+    ref, alt, coo = run(batch, cfg)
+    oref, oalt = oracle.batch_scores(batch, cfg, threads=os.cpu_count() or 8)
+    assert np.array_equal(ref, oref) and np.array_equal(alt, oalt)
+    ocoo = oracle.batch_reduce(batch, cfg, oref, oalt)
+    for k in ("row", "col", "alt", "ref", "unk"):
+        assert np.array_equal(coo[k], ocoo[k]), k
+    both = ~(np.isnan(coo["value"]) | np.isnan(ocoo["value"]))
+    assert np.array_equal(np.isnan(coo["value"]), np.isnan(ocoo["value"]))
+    assert np.max(np.abs(coo["value"][both] - ocoo["value"][both]), initial=0.0) <= 1e-6
+    assert np.array_equal(coo["value"].view(np.uint64), ocoo["value"].view(np.uint64))
+    # UMI collapse really collapsed something, and some UMIs were decided by the 0.75 rule
+    assert coo["alt"].sum() + coo["ref"].sum() + coo["unk"].sum() < ((oref >= 25) | (oalt >= 25)).sum()
+    parts = []
+    for lo, hi in shard.partition_loci(batch, 2):
+        sub = batch.slice_loci(lo, hi)
+        parts.append(run(sub, cfg)[2])
+    for k in ("row", "col", "alt", "ref", "unk"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), coo[k]), k
