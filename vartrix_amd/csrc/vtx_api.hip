@@ -660,7 +660,8 @@ int vtx_run(vtx_ctx* c) {
                                              c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                              c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
                                              c->d_band_ws.as<uint32_t>(), c->d_band.as<uint16_t>(), band_stride,
-                                             c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), d_cnt, s));
+                                             c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), d_cnt,
+                                             (uint32_t)(n_tasks / std::max(c->n_loci, 1u)), s));
             HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
             if (int rc = masked_dp(cnt[0])) return rc;

@@ -320,11 +320,15 @@ struct hap_table {
     const uint8_t* bytes;   // raw haplotype bytes
 };
 
-__device__ __forceinline__ uint32_t kw_hash(uint32_t lo, uint32_t hi) {
+__device__ __forceinline__ uint32_t kw_hash(uint32_t lo, uint32_t hi, uint32_t head_mask = TB_HEADS - 1) {
     uint32_t h = lo * 0x9E3779B1u ^ (hi + 0x7F4A7C15u) * 0x85EBCA77u;
-    return (h >> 18) & (TB_HEADS - 1);
+    return (h >> 18) & head_mask;
 }
 
+static size_t band_table_stride(uint32_t max_hap, uint32_t n_heads) {
+    size_t o = (size_t)max_hap * 4 + (size_t)max_hap * 2 * 2 + (size_t)n_heads * 2 + ((size_t)max_hap + 8);
+    return (o + 15) & ~(size_t)15;
+}
 extern "C" size_t vtxk_band_table_stride(uint32_t max_hap) {
     size_t o = (size_t)max_hap * 4 + (size_t)max_hap * 2 * 2 + TB_HEADS * 2 + ((size_t)max_hap + 8);
     return (o + 15) & ~(size_t)15;
@@ -841,7 +845,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
     const int32_t* __restrict__ ref_score, const int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ logbuf, uint16_t* __restrict__ band, uint32_t band_stride,
     uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters,
-    uint32_t ablate) {
+    uint32_t ablate, uint32_t n_heads) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x;
     // per-lane LDS arrays, element i of lane tid at [i * 256 + tid]
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
             uint32_t* kwlo = (uint32_t*)tb;
             uint16_t* kwhi = (uint16_t*)(tb + (size_t)max_hap * 4);
             uint16_t* head = kwhi + 2 * (size_t)max_hap;
-            uint8_t* bytes = (uint8_t*)(head + TB_HEADS);
+            uint8_t* bytes = (uint8_t*)(head + n_heads);
             for (uint32_t y = tid; y < hn; y += 256) {
                 bytes[y] = hy[y];
                 if (y + KMER <= hn) {
@@ -894,7 +898,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                     kwhi[y] = (uint16_t)((uint32_t)hy[y + 4] | ((uint32_t)hy[y + 5] << 8));
                 }
             }
-            for (uint32_t i = tid; i < TB_HEADS; i += 256) head[i] = 0xffff;
+            for (uint32_t i = tid; i < n_heads; i += 256) head[i] = 0xffff;
         }
         __syncthreads();
         if ((uint32_t)tid < n_tab) {     // one lane per table: sequential head insertion, descending y => ascending chains
@@ -907,7 +911,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
             uint16_t* head = kwhi + 2 * (size_t)max_hap;
             if (hn >= KMER)
                 for (int y = (int)hn - KMER; y >= 0; --y) {
-                    const uint32_t h = kw_hash(kwlo[y], kwhi[y]);
+                    const uint32_t h = kw_hash(kwlo[y], kwhi[y], n_heads - 1);
                     next[y] = head[h]; head[h] = (uint16_t)y;
                 }
         }
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
         const uint16_t* kwhi = (const uint16_t*)(tb + (size_t)max_hap * 4);
         const uint16_t* next = kwhi + max_hap;
         const uint16_t* head = kwhi + 2 * (size_t)max_hap;
-        const uint8_t* yb = (const uint8_t*)(head + TB_HEADS);
+        const uint8_t* yb = (const uint8_t*)(head + n_heads);
         const int32_t full = hap ? alt_score[rid] : ref_score[rid];
         if (m < KMER || n < KMER) continue;                 // no k-mer: Band::full_matrix, banded == full
         if (ablate == 1) continue;                           // (profiling aid) table build only
@@ -928,7 +932,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
             uint32_t wl = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
             uint32_t wh = (uint32_t)x[4] | ((uint32_t)x[5] << 8), cntm = 0;
             for (uint32_t xr = 0; xr + KMER <= m; ++xr) {
-                for (uint32_t y = head[kw_hash(wl, wh)]; y != 0xffff; y = next[y]) cntm += (kwlo[y] == wl && kwhi[y] == (uint16_t)wh);
+                for (uint32_t y = head[kw_hash(wl, wh, n_heads - 1)]; y != 0xffff; y = next[y]) cntm += (kwlo[y] == wl && kwhi[y] == (uint16_t)wh);
                 const uint32_t nb = (xr + KMER < m) ? x[xr + KMER] : 0;
                 wl = (wl >> 8) | (wh << 24); wh = ((wh >> 8) & 0xff) | (nb << 8);
             }
@@ -949,7 +953,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
             uint32_t whi = (uint32_t)x[4] | ((uint32_t)x[5] << 8);
             uint32_t nextb = m > KMER ? x[KMER] : 0;
             uint32_t xr = 0;
-            uint32_t ycur = head[kw_hash(wlo, whi)];          // chain cursor of the current row
+            uint32_t ycur = head[kw_hash(wlo, whi, n_heads - 1)];          // chain cursor of the current row
             bool service;
             do {
                 // ---- hot loops: kept free of the (rare, large) list-full handling, which sits after them ----
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                     whi = ((whi >> 8) & 0xff) | (nextb << 8);
                     nextb = nb2;
                     ++xr;
-                    ycur = (xr + KMER <= m) ? head[kw_hash(wlo, whi)] : 0xffffu;
+                    ycur = (xr + KMER <= m) ? head[kw_hash(wlo, whi, n_heads - 1)] : 0xffffu;
                 }
                 if (service) {
                     // list full: run the chain DP up to this match, drop segments that cannot matter any more,
@@ -1104,30 +1108,37 @@ extern "C" hipError_t vtxk_launch_band_fast(uint32_t n_tasks, uint32_t task_base
                                             const uint8_t* hap_arena, uint32_t max_hap, const int32_t* ref_score,
                                             const int32_t* alt_score, uint32_t* logbuf, uint16_t* band,
                                             uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
-                                            uint32_t* counters, hipStream_t s) {
+                                            uint32_t* counters, uint32_t tasks_per_locus, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
+    static const bool use_stream = getenv("VTX_BAND_KERNEL") && !strcmp(getenv("VTX_BAND_KERNEL"), "stream");
     const size_t lane_bytes = (size_t)(2 * PS) * 256 * 4;
-    const size_t tstride = vtxk_band_table_stride(max_hap);
-    size_t budget = 52 * 1024;   // lane arrays (40 KiB) + haplotype tables
+    // A workgroup of 256 tasks processes its loci in passes of `tables / 2` loci (the k-mer tables live in LDS); in a
+    // pass only the lanes of those loci work.  Deep data (>= 256 tasks per locus): 1-2 loci per workgroup, large
+    // head arrays, 3 workgroups per CU.  Shallow data: many loci per workgroup — small head arrays (0.5 KiB instead of
+    // 4 KiB per table, slightly longer chains) and a bigger LDS budget (2 workgroups per CU) keep up to 8 loci per pass.
+    const bool shallow = !use_stream && tasks_per_locus < 192;
+    const uint32_t n_heads = shallow ? 256 : TB_HEADS;
+    const size_t tstride = band_table_stride(max_hap, n_heads);
+    size_t budget = (shallow ? 78 : 52) * 1024;   // lane arrays (40 KiB) + haplotype tables
     uint32_t tables = (uint32_t)((budget - std::min(budget, lane_bytes)) / tstride) & ~1u;
     if (tables < 2) tables = 2;
-    if (tables > 8) tables = 8;
+    if (tables > 16) tables = 16;
     const size_t shmem = lane_bytes + (size_t)tables * tstride;
     if (shmem > 160 * 1024) return hipErrorInvalidValue;
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)band_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)band_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    static const bool use_stream = getenv("VTX_BAND_KERNEL") && !strcmp(getenv("VTX_BAND_KERNEL"), "stream");
-    auto kern = use_stream ? band_fast_kernel : band_run_kernel;
-    if (shmem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3((n_tasks + 255) / 256), dim3(256), shmem, s, n_tasks, task_base, records,
-                       rec_locus, loci, read_arena, hap_arena, max_hap, tables, (uint32_t)tstride, ref_score, alt_score,
-                       logbuf, band, band_stride, hard_list, overflow_list, counters,
-                       (uint32_t)(getenv("VTX_BAND_ABLATE") ? atoi(getenv("VTX_BAND_ABLATE")) : 0));
+    const uint32_t ablate = (uint32_t)(getenv("VTX_BAND_ABLATE") ? atoi(getenv("VTX_BAND_ABLATE")) : 0);
+    if (use_stream)
+        hipLaunchKernelGGL(band_fast_kernel, dim3((n_tasks + 255) / 256), dim3(256), shmem, s, n_tasks, task_base, records,
+                           rec_locus, loci, read_arena, hap_arena, max_hap, tables, (uint32_t)tstride, ref_score, alt_score,
+                           logbuf, band, band_stride, hard_list, overflow_list, counters, ablate);
+    else
+        hipLaunchKernelGGL(band_run_kernel, dim3((n_tasks + 255) / 256), dim3(256), shmem, s, n_tasks, task_base, records,
+                           rec_locus, loci, read_arena, hap_arena, max_hap, tables, (uint32_t)tstride, ref_score, alt_score,
+                           logbuf, band, band_stride, hard_list, overflow_list, counters, ablate, n_heads);
     return hipGetLastError();
 }
 
