@@ -47,6 +47,7 @@ struct DevBuf {
 
 struct Bucket { int R, GL; uint32_t offset, count; bool lut; bool duo = false; };
 const uint32_t kLutLociCap = 4;     // loci tables per workgroup of the LUT kernel (6 KiB each at 257 columns)
+const uint32_t kDuoLociCap = 8;     // the duo kernel runs 3 workgroups per CU (VGPRs), so up to 52 KiB of tables cost no occupancy
 
 // (rows per lane, lanes per record) choices; capacity = R * GL read bases.
 const int kShapes[][2] = {{2, 16}, {4, 16}, {6, 16}, {8, 16}, {10, 16}, {12, 16}, {16, 16}, {8, 64}, {16, 64}};
@@ -145,6 +146,12 @@ int build_groups(vtx_ctx* c, uint32_t nr) {
     HIP_TRY(c, hipMemcpyAsync(&c->n_cell_groups, c->d_cell_scan.as<uint32_t>() + (nr - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&c->n_umi_groups, c->d_umi_scan.as<uint32_t>() + (nr - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return VTX_OK;
+}
+
+// tables per workgroup of the duo kernel for this haplotype length: as many as fit 52 KiB, at most kDuoLociCap
+uint32_t duo_loci_cap(uint32_t max_hap) {
+    const size_t table_bytes = ((size_t)std::max(max_hap, 16u) + 36) * 6 * 4;
+    return (uint32_t)std::min<size_t>(kDuoLociCap, (52 * 1024) / table_bytes);
 }
 
 uint32_t bits_for(uint64_t max_value) {   // bits needed to represent values 0..max_value
@@ -317,11 +324,12 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
             const size_t j = std::min(lists[s].size(), i + 16) - 1;
             if (rec_locus[lists[s][j]] - rec_locus[lists[s][i]] + 1 > kLutLociCap) lut = false;
         }
-        // duo kernel (two records per 16-lane row): 32-record workgroups under the same loci cap
-        bool duo = lut;
+        // duo kernel (two records per 16-lane row): 32-record workgroups, up to kDuoLociCap tables
+        const uint32_t dcap = duo_loci_cap(max_hap);
+        bool duo = kShapes[s][1] == 16 && dcap >= 2;
         for (size_t i = 0; duo && i < lists[s].size(); i += 32) {
             const size_t j = std::min(lists[s].size(), i + 32) - 1;
-            if (rec_locus[lists[s][j]] - rec_locus[lists[s][i]] + 1 > kLutLociCap) duo = false;
+            if (rec_locus[lists[s][j]] - rec_locus[lists[s][i]] + 1 > dcap) duo = false;
         }
         Bucket bk{kShapes[s][0], kShapes[s][1], (uint32_t)work.size(), (uint32_t)lists[s].size(), lut};
         bk.duo = duo;
@@ -528,14 +536,14 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     for (int sh = 0; sh < kNumShapes; ++sh) {
         if (!shape_cnt[sh]) continue;
         const bool lut = kShapes[sh][1] == 16 && (size_t)kLutLociCap * (max_hap + 36) * 6 * 4 <= 96 * 1024;
-        if (lut) {
-            HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), kLutLociCap, 16,
-                                           d_lut_flag + c->buckets.size(), s));
-            HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), kLutLociCap, 32,
-                                           d_lut_flag + 16 + c->buckets.size(), s));
-        }
+        const uint32_t dcap = duo_loci_cap(max_hap);
+        const bool duo = kShapes[sh][1] == 16 && dcap >= 2;
+        if (lut) HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), kLutLociCap, 16,
+                                                d_lut_flag + c->buckets.size(), s));
+        if (duo) HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), dcap, 32,
+                                                d_lut_flag + 16 + c->buckets.size(), s));
         Bucket bk{kShapes[sh][0], kShapes[sh][1], off, shape_cnt[sh], lut};
-        bk.duo = lut;
+        bk.duo = duo;
         c->buckets.push_back(bk);
         off += shape_cnt[sh];
     }
@@ -546,7 +554,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     HIP_TRY(c, hipStreamSynchronize(s));
     for (size_t i = 0; i < c->buckets.size(); ++i) {
         if (lut_flag[i]) c->buckets[i].lut = false;
-        if (lut_flag[i] || lut_flag[16 + i]) c->buckets[i].duo = false;
+        if (lut_flag[16 + i]) c->buckets[i].duo = false;
     }
     float ms = 0;
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
@@ -583,16 +591,16 @@ int vtx_run(vtx_ctx* c) {
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     uint32_t launches = 0;
     bool any_lut = false;
-    for (const Bucket& bk : c->buckets) any_lut |= bk.lut;
+    for (const Bucket& bk : c->buckets) any_lut |= bk.lut || bk.duo;
     if (any_lut) HIP_TRY(c, hipMemsetAsync(c->d_redo_cnt.p, 0, 16 * sizeof(uint32_t), s));
     for (size_t b = 0; b < c->buckets.size(); ++b) {
         const Bucket& bk = c->buckets[b];
         static const bool no_duo = getenv("VTX_DP_KERNEL") && !strcmp(getenv("VTX_DP_KERNEL"), "lut");
-        if (bk.lut && bk.duo && !no_duo) {
+        if (bk.duo && !no_duo) {
             HIP_TRY(c, vtxk_launch_sw_full_duo(bk.R, bk.count, c->d_work.as<uint32_t>() + bk.offset, c->d_records.as<vtx_record>(),
                                                c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
                                                c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
-                                               c->max_hap_len, kLutLociCap, c->d_redo.as<uint32_t>() + bk.offset,
+                                               c->max_hap_len, duo_loci_cap(c->max_hap_len), c->d_redo.as<uint32_t>() + bk.offset,
                                                c->d_redo_cnt.as<uint32_t>() + b, s));
         } else if (bk.lut) {
             HIP_TRY(c, vtxk_launch_sw_full_lut(bk.R, bk.count, c->d_work.as<uint32_t>() + bk.offset, c->d_records.as<vtx_record>(),
@@ -615,7 +623,7 @@ int vtx_run(vtx_ctx* c) {
         HIP_TRY(c, hipStreamSynchronize(s));
         for (size_t b = 0; b < c->buckets.size(); ++b) {
             const Bucket& bk = c->buckets[b];
-            if (!bk.lut || !redo[b]) continue;
+            if (!(bk.lut || bk.duo) || !redo[b]) continue;
             HIP_TRY(c, vtxk_launch_sw_full(bk.R, bk.GL, redo[b], c->d_redo.as<uint32_t>() + bk.offset, c->d_records.as<vtx_record>(),
                                            c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
                                            c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len, s));
