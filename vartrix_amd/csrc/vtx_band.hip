@@ -1113,11 +1113,14 @@ extern "C" hipError_t vtxk_launch_band_fast(uint32_t n_tasks, uint32_t task_base
     static const bool use_stream = getenv("VTX_BAND_KERNEL") && !strcmp(getenv("VTX_BAND_KERNEL"), "stream");
     const size_t lane_bytes = (size_t)(2 * PS) * 256 * 4;
     // A workgroup of 256 tasks processes its loci in passes of `tables / 2` loci (the k-mer tables live in LDS); in a
-    // pass only the lanes of those loci work.  Deep data (>= 256 tasks per locus): 1-2 loci per workgroup, large
-    // head arrays, 3 workgroups per CU.  Shallow data: many loci per workgroup — small head arrays (0.5 KiB instead of
-    // 4 KiB per table, slightly longer chains) and a bigger LDS budget (2 workgroups per CU) keep up to 8 loci per pass.
+    // pass only the lanes of those loci work, so every extra pass repeats the per-task code for the whole wave.
+    // Deep data (>= 192 tasks per locus, <= 3 loci per workgroup): 512-entry head arrays -> two loci fit next to the
+    // 40 KiB of lane arrays at 3 workgroups per CU, one pass per workgroup (2048-entry heads fit one locus: 109 ms
+    // instead of 91 ms on config 3; 256-entry heads: 101 ms, the chains get longer).  Shallow data: a 78 KiB budget
+    // (2 workgroups per CU) keeps 6 loci resident per pass, 8 with 256-entry heads below 48 tasks per locus.
     const bool shallow = !use_stream && tasks_per_locus < 192;
-    const uint32_t n_heads = shallow ? 256 : TB_HEADS;
+    uint32_t n_heads = use_stream ? TB_HEADS : (tasks_per_locus < 48 ? 256 : 512);
+    if (!use_stream && getenv("VTX_BAND_HEADS")) n_heads = (uint32_t)atoi(getenv("VTX_BAND_HEADS"));   // experiment knob (power of two)
     const size_t tstride = band_table_stride(max_hap, n_heads);
     size_t budget = (shallow ? 78 : 52) * 1024;   // lane arrays (40 KiB) + haplotype tables
     uint32_t tables = (uint32_t)((budget - std::min(budget, lane_bytes)) / tstride) & ~1u;
