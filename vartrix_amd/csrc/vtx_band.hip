@@ -305,7 +305,7 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
 // Hard tasks get a polyline (vertex list) in their band slot, flagged 0xffff; band_expand_kernel
 // turns it into the lo / hi arrays sw_banded_kernel reads.
 // =============================================================================================
-#define PS 20       // per-lane LDS entries: parked segments (band_fast_kernel) / pieces + segments (band_run_kernel)
+#define PS 14       // per-lane LDS entries: parked segments (band_fast_kernel) / pieces + segments (band_run_kernel)
 #define LG 64       // jump-log entries per task (global)
 #define SG 10       // chain segments per task
 #define TB_HEADS 2048
@@ -803,7 +803,8 @@ __device__ void run_advance(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
     }
 }
 
-// Drop started, closed segments none of whose elements can win a query any more (2*(len-1) < x - x0 - dp0 - 1);
+// Drop started, closed segments none of whose elements can win a query any more (2*(len-1) < x - x0 - dp0 - 1,
+// or dominated by an element of another segment);
 // their ends are folded into the running best first.  Updates the indices of the two open pieces.
 __device__ void run_compact(run_state& st, uint32_t* e_id, uint32_t* e_dl, int tid, uint32_t xr, uint32_t& a_idx,
                             uint32_t& b_idx) {
@@ -820,7 +821,27 @@ __device__ void run_compact(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
             const int32_t mx = (int32_t)(mid >> 16), sx = (int32_t)(sid >> 16);
             if ((int32_t)(mid & 0xffff) - mx == (int32_t)(sid & 0xffff) - sx && mx >= sx) has_ev = true;
         }
-        if (dp0 != 0 && !open && !has_ev && 2 * (len - 1) < (int32_t)xr - (int32_t)(sid >> 16) - dp0 - 1) {
+        bool dead = dp0 != 0 && !open && !has_ev && 2 * (len - 1) < (int32_t)xr - (int32_t)(sid >> 16) - dp0 - 1;
+        if (!dead && dp0 != 0 && !open && !has_ev && (int32_t)xr > (int32_t)(sid >> 16) + len) {
+            // Dominance: a query takes the element with the largest V = dp + xe + ye among those ending at or before
+            // its start (ties: larger id).  If another started segment has an element that ends no later than this
+            // segment's FIRST element and beats the V of its LAST element strictly, no element of this segment can
+            // ever win a query.  The row after its last match is behind the sweep, so no piece can still continue
+            // it — unless that piece is already waiting in the list.
+            const int32_t qx = (int32_t)(sid >> 16) + KMER, qy = (int32_t)(sid & 0xffff) + KMER;
+            const int32_t v_last = dp0 + (len - 1) + (qx + len - 1) + (qy + len - 1);
+            const uint32_t next_id = sid + (uint32_t)len * 0x10001u;
+            int32_t bV = INT32_MIN; uint32_t bid = NONE_ID;
+            bool continued = false;
+            for (uint32_t k = 0; k < st.n_ent; ++k) {
+                if (k == j) continue;
+                const uint32_t kid = e_id[k * 256 + tid], kdl = e_dl[k * 256 + tid];
+                if ((kdl >> 16) == 0) { continued |= kid == next_id; continue; }
+                run_segq(kid, kdl >> 16, kdl & 0xffff, qx, qy, bV, bid);
+            }
+            dead = !continued && bid != NONE_ID && bV > v_last;
+        }
+        if (dead) {
             const int32_t v = dp0 + len - 1;
             const uint32_t eid = sid + (uint32_t)(len - 1) * 0x10001u;
             if (v > st.best_v || (v == st.best_v && eid > st.best_id)) { st.best_v = v; st.best_id = eid; }
@@ -949,9 +970,14 @@ __global__ __launch_bounds__(256) void band_run_kernel(
         st.best_v = -1; st.best_id = 0; st.overflow = false; st.why = 0;
         uint32_t a_idx = NONE_ID, a_id0 = 0, a_len = 0, b_idx = NONE_ID, b_id0 = 0, b_len = 0;
         {
-            uint32_t wlo = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
-            uint32_t whi = (uint32_t)x[4] | ((uint32_t)x[5] << 8);
-            uint32_t nextb = m > KMER ? x[KMER] : 0;
+            // the read streams through a 64-bit register window: one (unaligned) 8-byte global load per 8 rows
+            // instead of a byte load per row — every lane reads its own read, so each load instruction touches
+            // 64 different cache lines.  The arena is padded, bytes at or beyond m are never used.
+            uint64_t win;
+            __builtin_memcpy(&win, x, 8);
+            uint32_t wlo = (uint32_t)win;
+            uint32_t whi = (uint32_t)(win >> 32) & 0xffffu;
+            uint32_t nextb = m > KMER ? (uint32_t)(win >> 48) & 0xffu : 0;
             uint32_t xr = 0;
             uint32_t ycur = head[kw_hash(wlo, whi, n_heads - 1)];          // chain cursor of the current row
             bool service;
@@ -981,7 +1007,9 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                         pm_a[st.n_ent * 256 + tid] = id; pm_id[st.n_ent * 256 + tid] = 1; ++st.n_ent;
                     }
                     if (service) break;
-                    const uint32_t nb2 = (xr + KMER + 1 < m) ? x[xr + KMER + 1] : 0;
+                    const uint32_t bi = xr + KMER + 1;                      // byte needed by the row after next
+                    if ((bi & 7u) == 0 && bi < m) __builtin_memcpy(&win, x + bi, 8);
+                    const uint32_t nb2 = bi < m ? (uint32_t)(win >> (8 * (bi & 7u))) & 0xffu : 0;
                     wlo = (wlo >> 8) | (whi << 24);
                     whi = ((whi >> 8) & 0xff) | (nextb << 8);
                     nextb = nb2;
@@ -1122,7 +1150,7 @@ extern "C" hipError_t vtxk_launch_band_fast(uint32_t n_tasks, uint32_t task_base
     uint32_t n_heads = use_stream ? TB_HEADS : (tasks_per_locus < 48 ? 256 : 512);
     if (!use_stream && getenv("VTX_BAND_HEADS")) n_heads = (uint32_t)atoi(getenv("VTX_BAND_HEADS"));   // experiment knob (power of two)
     const size_t tstride = band_table_stride(max_hap, n_heads);
-    size_t budget = (shallow ? 78 : 52) * 1024;   // lane arrays (40 KiB) + haplotype tables
+    size_t budget = (shallow ? 78 : (PS <= 14 ? 40 : 52)) * 1024;   // lane arrays + haplotype tables
     uint32_t tables = (uint32_t)((budget - std::min(budget, lane_bytes)) / tstride) & ~1u;
     if (tables < 2) tables = 2;
     if (tables > 16) tables = 16;
