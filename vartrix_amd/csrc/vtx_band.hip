@@ -970,26 +970,50 @@ __global__ __launch_bounds__(256) void band_run_kernel(
         st.best_v = -1; st.best_id = 0; st.overflow = false; st.why = 0;
         uint32_t a_idx = NONE_ID, a_id0 = 0, a_len = 0, b_idx = NONE_ID, b_id0 = 0, b_len = 0;
         {
-            // the read streams through a 64-bit register window: one (unaligned) 8-byte global load per 8 rows
-            // instead of a byte load per row — every lane reads its own read, so each load instruction touches
-            // 64 different cache lines.  The arena is padded, bytes at or beyond m are never used.
+            // The probe is software-pipelined two rows deep — the kernel is latency-bound, and a row's lookups are a
+            // dependent chain (k-mer -> head[h] -> entry fields -> compare): while row xr is processed, the head
+            // lookup of row xr+2 and the fields of the first chain entry of row xr+1 are already in flight.
+            // The read streams through a 64-bit register window (one unaligned 8-byte global load per 8 rows; the
+            // arena is padded, bytes at or beyond m are never used).
             uint64_t win;
             __builtin_memcpy(&win, x, 8);
-            uint32_t wlo = (uint32_t)win;
+            const uint32_t hmask = n_heads - 1;
+            uint32_t wlo = (uint32_t)win;                                    // k-mer word of row xr
             uint32_t whi = (uint32_t)(win >> 32) & 0xffffu;
-            uint32_t nextb = m > KMER ? (uint32_t)(win >> 48) & 0xffu : 0;
+            const uint32_t b6 = m > KMER ? (uint32_t)(win >> 48) & 0xffu : 0;
+            uint32_t w1lo = (wlo >> 8) | (whi << 24);                        // ... of row xr + 1
+            uint32_t w1hi = ((whi >> 8) & 0xff) | (b6 << 8);
             uint32_t xr = 0;
-            uint32_t ycur = head[kw_hash(wlo, whi, n_heads - 1)];          // chain cursor of the current row
+            uint32_t ycur = head[kw_hash(wlo, whi, hmask)];                  // chain cursor of row xr
+            uint32_t y1 = (1 + KMER <= m) ? head[kw_hash(w1lo, w1hi, hmask)] : 0xffffu;   // head of row xr + 1
+            uint32_t e_lo, e_nx; uint16_t e_hi;                              // fields of the first chain entry of row xr
+            {
+                const uint32_t yy = ycur == 0xffffu ? 0u : ycur;
+                e_lo = kwlo[yy]; e_hi = kwhi[yy]; e_nx = next[yy];
+            }
+            bool first = true;                                               // the prefetched entry is still to be consumed
             bool service;
             do {
                 // ---- hot loops: kept free of the (rare, large) list-full handling, which sits after them ----
                 service = false;
                 uint32_t pend_id = 0;
                 while (xr + KMER <= m) {
+                    // lookups of the rows ahead (their results are consumed at the bottom of this iteration)
+                    const uint32_t bi = xr + KMER + 1;
+                    if ((bi & 7u) == 0 && bi < m) __builtin_memcpy(&win, x + bi, 8);
+                    const uint32_t nb2 = bi < m ? (uint32_t)(win >> (8 * (bi & 7u))) & 0xffu : 0;
+                    const uint32_t w2lo = (w1lo >> 8) | (w1hi << 24);
+                    const uint32_t w2hi = ((w1hi >> 8) & 0xff) | (nb2 << 8);
+                    const uint32_t y2 = (xr + 2 + KMER <= m) ? head[kw_hash(w2lo, w2hi, hmask)] : 0xffffu;
+                    const uint32_t y1c = y1 == 0xffffu ? 0u : y1;
+                    const uint32_t f_lo = kwlo[y1c], f_nx = next[y1c];
+                    const uint16_t f_hi = kwhi[y1c];
                     while (ycur != 0xffff) {
                         const uint32_t y = ycur;
-                        ycur = next[y];
-                        if (kwlo[y] != wlo || kwhi[y] != (uint16_t)whi) continue;
+                        uint32_t lo; uint16_t hi;
+                        if (first) { lo = e_lo; hi = e_hi; ycur = e_nx; first = false; }
+                        else { lo = kwlo[y]; hi = kwhi[y]; ycur = next[y]; }
+                        if (lo != wlo || hi != (uint16_t)whi) continue;
                         const uint32_t id = (xr << 16) | y;
                         if (a_idx != NONE_ID && id == a_id0 + a_len * 0x10001u) { ++a_len; continue; }
                         if (b_idx != NONE_ID && id == b_id0 + b_len * 0x10001u) {
@@ -1007,14 +1031,11 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                         pm_a[st.n_ent * 256 + tid] = id; pm_id[st.n_ent * 256 + tid] = 1; ++st.n_ent;
                     }
                     if (service) break;
-                    const uint32_t bi = xr + KMER + 1;                      // byte needed by the row after next
-                    if ((bi & 7u) == 0 && bi < m) __builtin_memcpy(&win, x + bi, 8);
-                    const uint32_t nb2 = bi < m ? (uint32_t)(win >> (8 * (bi & 7u))) & 0xffu : 0;
-                    wlo = (wlo >> 8) | (whi << 24);
-                    whi = ((whi >> 8) & 0xff) | (nextb << 8);
-                    nextb = nb2;
+                    // next row: everything it needs was requested above
+                    wlo = w1lo; whi = w1hi; w1lo = w2lo; w1hi = w2hi;
+                    ycur = y1; e_lo = f_lo; e_hi = f_hi; e_nx = f_nx; y1 = y2;
+                    first = true;
                     ++xr;
-                    ycur = (xr + KMER <= m) ? head[kw_hash(wlo, whi, n_heads - 1)] : 0xffffu;
                 }
                 if (service) {
                     // list full: run the chain DP up to this match, drop segments that cannot matter any more,
