@@ -709,20 +709,19 @@ __global__ __launch_bounds__(256) void sw_full_lut_kernel(
 //
 // Before the variant column v the two haplotypes of a locus are the same string, so the {REF, ALT} halves
 // of the LUT kernel compute the same numbers there.  Here a 16-lane row takes two records A and B and
-// runs ONE systolic pipeline through three phases without draining it:
-//     P : columns [0, v4)        halves = {A vs REF, B vs REF}      (two LUT lookups + one v_perm per cell)
-//     A : columns [v4, v4 + S)   halves = {A vs REF, A vs ALT}      (as the LUT kernel)
-//     B : columns [v4, v4 + S)   halves = {B vs REF, B vs ALT}
-// v4 = (common prefix of the wave's haplotype pairs) rounded down to 4, S = suffix length rounded up.
-// Lane l is l columns behind lane 0, so it changes phase l steps later: the 16 steps after a phase
-// boundary are "window" steps in which exactly lane d = (step - boundary) rewrites its own state
-// (exec-masked), after the DPP exchange of that step, so that the lane below still receives the
-// old-phase values it needs:
-//     P -> A : the B halves of H(column v4-1), E, the diagonal carry and `best` are packed into one VGPR
-//              per row (the registers that held B's LUT addresses), the A halves are duplicated.
-//     A -> B : A's best is set aside, B's state is unpacked into both halves, B's LUT addresses are
-//              rebuilt for column v4 from its 3-bit row codes.
-// Steps per pair: v4 + 2 S + 16 instead of 2 (n + 16): 324 vs 432 for an SNV at padding 100.
+// runs ONE systolic pipeline through three phases of whole steps:
+//     P : steps [0, T1)               halves = {A vs REF, B vs REF}   (two LUT lookups + one v_perm per cell)
+//     A : steps [T1, T1 + S)          halves = {A vs REF, A vs ALT}   (as the LUT kernel)
+//     B : steps [T1 + S, T1 + 2 S)    halves = {B vs REF, B vs ALT}
+// T1 = (common prefix of the wave's haplotype pairs) rounded down to 4.  Every lane changes phase at the same
+// step; lane l is then at column T1 - l, which is still inside the common prefix, where {A vs REF, A vs ALT}
+// hold equal numbers — so re-packing {A, B} into {A, A} there is exact.  At step T1 the DPP exchange delivers
+// the {A, B} values the lane above computed for exactly that column: their B halves, B's H / E of the previous
+// column, its diagonal carry and best are set aside (packed with v_perm, one VGPR per row — the registers that
+// held B's LUT addresses), the A halves are duplicated.  At step T1 + S the lane restarts B from that state at
+// column T1 - l (addresses rebuilt from B's 3-bit row codes).  S = n - T1 + 15 rounded up to 4, so the last
+// column is reached by every lane.  Steps per pair: T1 + 2 S = 332 instead of 2 x 216 = 432 for an SNV at
+// padding 100; there are no partially-switched steps, the two re-packings cost ~5 R instructions each per pair.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t perm_b32(uint32_t hi_src, uint32_t lo_src, uint32_t sel) {
     return __builtin_amdgcn_perm(hi_src, lo_src, sel);      // selector bytes 0-3: lo_src, 4-7: hi_src
@@ -818,6 +817,11 @@ __global__ __launch_bounds__(256) void sw_full_duo_kernel(
     for (int off = 1; off < GL; off <<= 1) badm |= (uint32_t)__shfl_xor((int)badm, off);
 
     // ---- wave-uniform phase lengths ----
+    // All lanes change phase at the same STEP: P for steps [0, T1), A for [T1, T1 + S), B for [T1 + S, T1 + 2S).
+    // Lane l is at column t - l, so it leaves phase P at column T1 - l <= T1 <= v: still inside the common prefix,
+    // where {A vs REF, A vs ALT} are the same numbers, so re-packing {A, B} -> {A, A} is exact at any such column.
+    // Lane l then runs columns [T1 - l, T1 - l + S) for A and again for B; S = n - T1 + 15 rounded up to 4 covers
+    // the last column for every lane.
     uint32_t vw = min(s_v[loc_a - l_first], s_v[loc_b - l_first]);
     vw = min(vw, (uint32_t)__shfl_xor((int)vw, 16));
     vw = min(vw, (uint32_t)__shfl_xor((int)vw, 32));
@@ -825,16 +829,13 @@ __global__ __launch_bounds__(256) void sw_full_duo_kernel(
     nw = max(nw, (uint32_t)__shfl_xor((int)nw, 16));
     nw = max(nw, (uint32_t)__shfl_xor((int)nw, 32));
     nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)nw);
-    uint32_t v4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)vw) & ~3u;
-    if (v4 > nw) v4 = nw & ~3u;
-    if (nw - v4 < 16) v4 = nw > 16 ? (nw - 16) & ~3u : 0;          // both windows need 16 steps of suffix
-    uint32_t S = (nw - v4 + 3) & ~3u;
-    if (S < 16) S = 16;
+    const uint32_t T1 = min((uint32_t)__builtin_amdgcn_readfirstlane((int)vw), nw) & ~3u;
+    const uint32_t S = (nw - T1 + (GL - 1) + 3) & ~3u;
 
     uint32_t Ha[R], Hb[R], Q[R], E[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { Ha[r] = 0; Hb[r] = 0; Q[r] = 0; E[r] = 0; }
-    uint32_t best = 0, out_a = 0, misc = 0, sel = SEL_LOA_LOB;
+    uint32_t best = 0, out_a = 0;
     uint32_t hu_a = 0, hu_b = 0, qu = 0, fu = 0, f_last = 0, q_bottom = 0;
     const char* lds = (const char*)smem;
 
@@ -864,86 +865,72 @@ __global__ __launch_bounds__(256) void sw_full_duo_kernel(
 #define LDSW(a, OFF) (*(const uint32_t*)(lds + (a) + (OFF)))
 #define W_P(OFF) perm_b32(LDSW(X[r], OFF), LDSW(addr[r], OFF), SEL_LOA_LOB)
 #define W_S(OFF) LDSW(addr[r], OFF)
-#define W_W1(OFF) perm_b32(LDSW(in_p ? X[r] : addr[r], OFF), LDSW(addr[r], OFF), sel)
-#define STEP4(STEP)                                                                                \
-        STEP(Hb, Ha, hu_b, hu_a, 0 * LUT_CODES * 4, 0)                                             \
-        STEP(Ha, Hb, hu_a, hu_b, 1 * LUT_CODES * 4, 1)                                             \
-        STEP(Hb, Ha, hu_b, hu_a, 2 * LUT_CODES * 4, 2)                                             \
-        STEP(Ha, Hb, hu_a, hu_b, 3 * LUT_CODES * 4, 3)
+#define P_STEP(HS, HD, hprev, hcur, OFF) { DUO_EXCHANGE(hcur, HS[R - 1]) DUO_COLUMN(HS, HD, hprev, W_P(OFF)) }
+#define S_STEP(HS, HD, hprev, hcur, OFF) { DUO_EXCHANGE(hcur, HS[R - 1]) DUO_COLUMN(HS, HD, hprev, W_S(OFF)) }
+    // a group of four steps starts with "previous column" = Hb, diagonal carry = hu_b, incoming carry = hu_a
 
-    // ---------------- phase P: columns [0, v4), halves {A, B} ----------------
-#define P_STEP(HS, HD, hprev, hcur, OFF, SUB) { DUO_EXCHANGE(hcur, HS[R - 1]) DUO_COLUMN(HS, HD, hprev, W_P(OFF)) }
-    for (uint32_t t4 = 0; t4 < (v4 >> 2); ++t4) {
-        STEP4(P_STEP)
+    // ---------------- phase P: steps [0, T1), halves {A, B} ----------------
+    for (uint32_t t4 = 0; t4 < (T1 >> 2); ++t4) {
+        P_STEP(Hb, Ha, hu_b, hu_a, 0 * LUT_CODES * 4)
+        P_STEP(Ha, Hb, hu_a, hu_b, 1 * LUT_CODES * 4)
+        P_STEP(Hb, Ha, hu_b, hu_a, 2 * LUT_CODES * 4)
+        P_STEP(Ha, Hb, hu_a, hu_b, 3 * LUT_CODES * 4)
 #pragma unroll
         for (int r = 0; r < R; ++r) { addr[r] += 4 * LUT_CODES * 4; X[r] += 4 * LUT_CODES * 4; }
     }
-    // ---------------- window 1: lane d leaves phase P at step v4 + d ----------------
-#define W1_STEP(HS, HD, hprev, hcur, OFF, SUB)                                                     \
-    {                                                                                              \
-        DUO_EXCHANGE(hcur, HS[R - 1])                                                              \
-        if ((uint32_t)l == 4 * g + SUB) {                                                          \
-            _Pragma("unroll") for (int r = 0; r < R; ++r) {                                        \
-                X[r] = perm_b32(E[r], HS[r], SEL_HIA_HIB);      /* {H_B, E_B} */                    \
-                HS[r] = perm_b32(0, HS[r], SEL_LO_LO);                                             \
-                E[r] = perm_b32(0, E[r], SEL_LO_LO);                                               \
-                Q[r] = perm_b32(0, Q[r], SEL_LO_LO);                                               \
-            }                                                                                      \
-            misc = perm_b32(best, hprev, SEL_HIA_HIB);          /* {diag_B, best_B} */              \
-            hprev = perm_b32(0, hprev, SEL_LO_LO);                                                 \
-            best = perm_b32(0, best, SEL_LO_LO);                                                   \
-            sel = SEL_IDENT;                                                                       \
-        }                                                                                          \
-        const bool in_p = (uint32_t)l > 4 * g + SUB;                                               \
-        DUO_COLUMN(HS, HD, hprev, W_W1(OFF))                                                       \
-    }
-    for (uint32_t g = 0; g < 4; ++g) {
-        STEP4(W1_STEP)
-        const uint32_t inc_x = (uint32_t)l > 4 * g + 3 ? 4u * LUT_CODES * 4 : 0u;
-#pragma unroll
-        for (int r = 0; r < R; ++r) { addr[r] += 4 * LUT_CODES * 4; X[r] += inc_x; }
-    }
-    // ---------------- phases A and B (single lookup), window 2 in between ----------------
-#define S_STEP(HS, HD, hprev, hcur, OFF, SUB) { DUO_EXCHANGE(hcur, HS[R - 1]) DUO_COLUMN(HS, HD, hprev, W_S(OFF)) }
-#define W2_STEP(HS, HD, hprev, hcur, OFF, SUB)                                                     \
-    {                                                                                              \
-        DUO_EXCHANGE(hcur, HS[R - 1])                                                              \
-        if ((uint32_t)l == 4 * g + SUB) {                                                          \
-            out_a = best;                                                                          \
-            _Pragma("unroll") for (int r = 0; r < R; ++r) {                                        \
-                HS[r] = perm_b32(0, X[r], SEL_LO_LO);                                              \
-                E[r] = perm_b32(0, X[r], SEL_HI_HI);                                               \
-                Q[r] = pk_sub_sat(HS[r], PK(6));                                                   \
-                addr[r] = lane_base_b + (v4 + 4 * g) * (LUT_CODES * 4) + ((uint32_t)(codes_b >> (3 * r)) & 7u) * 4u; \
-            }                                                                                      \
-            hprev = perm_b32(0, misc, SEL_LO_LO);                                                  \
-            best = perm_b32(0, misc, SEL_HI_HI);                                                   \
-        }                                                                                          \
-        DUO_COLUMN(HS, HD, hprev, W_S(OFF))                                                        \
-    }
+    // ---------------- phases A and B: single lookup, S steps each ----------------
+    uint32_t in_b = 0, dg_b = 0;          // B halves of the carries received at step T1 / of diagonal carry and best
     for (uint32_t phase = 0; phase < 2; ++phase) {
-        const uint32_t n4 = (phase == 0 ? S - 16 : S) >> 2;
-        for (uint32_t t4 = 0; t4 < n4; ++t4) {
-            STEP4(S_STEP)
+        // first step of the phase: the exchange delivers what the lane above produced in its LAST step of the previous
+        // phase.  At P -> A those are {A, B} values of exactly the column this lane is about to process.
+        DUO_EXCHANGE(hu_a, Hb[R - 1])
+        if (phase == 0) {
+            in_b = perm_b32(qu, hu_a, SEL_HIA_HIB);                   // {h_up_B, q_up_B}
+            dg_b = perm_b32(best, hu_b, SEL_HIA_HIB);                 // {diag_B, best_B}
+            const uint32_t fu_b = fu >> 16;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                X[r] = perm_b32(E[r], Hb[r], SEL_HIA_HIB);            // {H_B, E_B} of the column before the switch
+                Hb[r] = perm_b32(0, Hb[r], SEL_LO_LO);
+                E[r] = perm_b32(0, E[r], SEL_LO_LO);
+                Q[r] = perm_b32(0, Q[r], SEL_LO_LO);
+            }
+            hu_a = perm_b32(0, hu_a, SEL_LO_LO); qu = perm_b32(0, qu, SEL_LO_LO); fu = perm_b32(0, fu, SEL_LO_LO);
+            hu_b = perm_b32(0, hu_b, SEL_LO_LO); best = perm_b32(0, best, SEL_LO_LO);
+            out_a = fu_b;                                             // parked here until A is finished
+        } else {
+            const uint32_t fu_b = out_a;
+            out_a = best;                                             // A's {REF, ALT} best of this lane's rows
+            // B restarts at the column where this lane left phase P, with the carries the lane above sent for it
+            hu_a = perm_b32(0, in_b, SEL_LO_LO); qu = perm_b32(0, in_b, SEL_HI_HI); fu = fu_b * 0x10001u;
+            hu_b = perm_b32(0, dg_b, SEL_LO_LO); best = perm_b32(0, dg_b, SEL_HI_HI);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                Hb[r] = perm_b32(0, X[r], SEL_LO_LO);
+                E[r] = perm_b32(0, X[r], SEL_HI_HI);
+                Q[r] = pk_sub_sat(Hb[r], PK(6));
+                addr[r] = lane_base_b + T1 * (LUT_CODES * 4) + ((uint32_t)(codes_b >> (3 * r)) & 7u) * 4u;
+            }
+        }
+        DUO_COLUMN(Hb, Ha, hu_b, W_S(0 * LUT_CODES * 4))
+        S_STEP(Ha, Hb, hu_a, hu_b, 1 * LUT_CODES * 4)
+        S_STEP(Hb, Ha, hu_b, hu_a, 2 * LUT_CODES * 4)
+        S_STEP(Ha, Hb, hu_a, hu_b, 3 * LUT_CODES * 4)
+#pragma unroll
+        for (int r = 0; r < R; ++r) addr[r] += 4 * LUT_CODES * 4;
+        for (uint32_t t4 = 1; t4 < (S >> 2); ++t4) {
+            S_STEP(Hb, Ha, hu_b, hu_a, 0 * LUT_CODES * 4)
+            S_STEP(Ha, Hb, hu_a, hu_b, 1 * LUT_CODES * 4)
+            S_STEP(Hb, Ha, hu_b, hu_a, 2 * LUT_CODES * 4)
+            S_STEP(Ha, Hb, hu_a, hu_b, 3 * LUT_CODES * 4)
 #pragma unroll
             for (int r = 0; r < R; ++r) addr[r] += 4 * LUT_CODES * 4;
         }
-        if (phase == 0) {
-            for (uint32_t g = 0; g < 4; ++g) {
-                STEP4(W2_STEP)
-#pragma unroll
-                for (int r = 0; r < R; ++r) addr[r] += 4 * LUT_CODES * 4;
-            }
-        }
     }
 #undef P_STEP
-#undef W1_STEP
 #undef S_STEP
-#undef W2_STEP
-#undef STEP4
 #undef W_P
 #undef W_S
-#undef W_W1
 #undef LDSW
 #undef DUO_COLUMN
 #undef DUO_EXCHANGE
