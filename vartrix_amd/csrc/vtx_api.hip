@@ -45,7 +45,7 @@ struct DevBuf {
     template <typename T> T* as() const { return (T*)p; }
 };
 
-struct Bucket { int R, GL; uint32_t offset, count; bool lut; bool duo = false; };
+struct Bucket { int R, GL; uint32_t offset, count; bool lut; bool duo = false; bool pair = false; };
 const uint32_t kLutLociCap = 4;     // loci tables per workgroup of the LUT kernel (6 KiB each at 257 columns)
 const uint32_t kDuoLociCap = 8;     // the duo kernel runs 3 workgroups per CU (VGPRs), so up to 52 KiB of tables cost no occupancy
 
@@ -152,6 +152,17 @@ int build_groups(vtx_ctx* c, uint32_t nr) {
 uint32_t duo_loci_cap(uint32_t max_hap) {
     const size_t table_bytes = ((size_t)std::max(max_hap, 16u) + 36) * 6 * 4;
     return (uint32_t)std::min<size_t>(kDuoLociCap, (52 * 1024) / table_bytes);
+}
+
+// pair-table mode of the duo kernel (deep data: a 32-record workgroup spans <= 2 loci): columns of the per-locus
+// pair table (16 sentinels + prefix) that fit the same 52 KiB next to the two single tables; 0 = mode not available
+const uint32_t kPairLociCap = 2;
+uint32_t duo_pair_cols(uint32_t max_hap) {
+    const size_t lcols = 16 + (size_t)std::max(max_hap, 16u) + 16 + 4;
+    const size_t single = kPairLociCap * lcols * 6 * 4;
+    if (single + kPairLociCap * (16 + 32) * 38 * 4 > 52 * 1024) return 0;
+    const size_t fit = (52 * 1024 - single) / (kPairLociCap * 38 * 4);
+    return (uint32_t)std::min<size_t>(fit, 16 + (size_t)max_hap);
 }
 
 uint32_t bits_for(uint64_t max_value) {   // bits needed to represent values 0..max_value
@@ -331,8 +342,13 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
             const size_t j = std::min(lists[s].size(), i + 32) - 1;
             if (rec_locus[lists[s][j]] - rec_locus[lists[s][i]] + 1 > dcap) duo = false;
         }
+        bool pair = duo && duo_pair_cols(max_hap) != 0;
+        for (size_t i = 0; pair && i < lists[s].size(); i += 32) {
+            const size_t j = std::min(lists[s].size(), i + 32) - 1;
+            if (rec_locus[lists[s][j]] - rec_locus[lists[s][i]] + 1 > kPairLociCap) pair = false;
+        }
         Bucket bk{kShapes[s][0], kShapes[s][1], (uint32_t)work.size(), (uint32_t)lists[s].size(), lut};
-        bk.duo = duo;
+        bk.duo = duo; bk.pair = pair;
         c->buckets.push_back(bk);
         work.insert(work.end(), lists[s].begin(), lists[s].end());
     }
@@ -449,7 +465,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     HIP_TRY(c, c->d_shape2.reserve(nr + 16));
     HIP_TRY(c, c->d_locus_cnt.reserve(((size_t)nl + 1) * u32));
     HIP_TRY(c, c->d_locus_scan.reserve(((size_t)nl + 1) * u32));
-    HIP_TRY(c, c->d_prep_cnt.reserve(8 * u64 + 48 * u32));
+    HIP_TRY(c, c->d_prep_cnt.reserve(8 * u64 + 64 * u32));
     const size_t sort_tmp = vtxk_prep_sort_temp_bytes(nr);
     HIP_TRY(c, c->d_sort_tmp.reserve(std::max(sort_tmp, vtxk_scan_temp_bytes(std::max(nr, nl)))));
     unsigned long long* d_counters = c->d_prep_cnt.as<unsigned long long>();
@@ -477,7 +493,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     if (nr) HIP_TRY(c, vtxk_prep_rec_locus(c->d_loci.as<vtx_locus>(), nl, c->d_raw_locus.as<uint32_t>(), s));
     for (uint64_t seed = 0x9e3779b97f4a7c15ull;; seed = seed * 0xd1342543de82ef95ull + 1) {
         ++rounds;
-        HIP_TRY(c, hipMemsetAsync(c->d_prep_cnt.p, 0, 8 * u64 + 48 * u32, s));
+        HIP_TRY(c, hipMemsetAsync(c->d_prep_cnt.p, 0, 8 * u64 + 64 * u32, s));
         HIP_TRY(c, hipMemsetAsync(c->d_locus_cnt.p, 0, ((size_t)nl + 1) * u32, s));      // first record of each locus
         HIP_TRY(c, hipMemsetAsync(c->d_locus_scan.p, 0, ((size_t)nl + 1) * u32, s));     // one past its last record
         HIP_TRY(c, vtxk_prep_resolve(c->d_raw.as<vtx_raw_record>(), nr, c->d_raw_locus.as<uint32_t>(), c->d_tags.as<uint8_t>(),
@@ -542,12 +558,15 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
                                                 d_lut_flag + c->buckets.size(), s));
         if (duo) HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), dcap, 32,
                                                 d_lut_flag + 16 + c->buckets.size(), s));
+        const bool pair = duo && duo_pair_cols(max_hap) != 0;
+        if (pair) HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), kPairLociCap, 32,
+                                                 d_lut_flag + 32 + c->buckets.size(), s));
         Bucket bk{kShapes[sh][0], kShapes[sh][1], off, shape_cnt[sh], lut};
-        bk.duo = duo;
+        bk.duo = duo; bk.pair = pair;
         c->buckets.push_back(bk);
         off += shape_cnt[sh];
     }
-    uint32_t lut_flag[32] = {0};
+    uint32_t lut_flag[48] = {0};
     HIP_TRY(c, hipMemcpyAsync(lut_flag, d_lut_flag, sizeof lut_flag, hipMemcpyDeviceToHost, s));
     if (int rc = build_groups(c, n_kept)) return rc;
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
@@ -555,6 +574,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     for (size_t i = 0; i < c->buckets.size(); ++i) {
         if (lut_flag[i]) c->buckets[i].lut = false;
         if (lut_flag[16 + i]) c->buckets[i].duo = false;
+        if (lut_flag[16 + i] || lut_flag[32 + i]) c->buckets[i].pair = false;
     }
     float ms = 0;
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
@@ -596,12 +616,15 @@ int vtx_run(vtx_ctx* c) {
     for (size_t b = 0; b < c->buckets.size(); ++b) {
         const Bucket& bk = c->buckets[b];
         static const bool no_duo = getenv("VTX_DP_KERNEL") && !strcmp(getenv("VTX_DP_KERNEL"), "lut");
+        static const bool no_pair = getenv("VTX_DP_KERNEL") && !strcmp(getenv("VTX_DP_KERNEL"), "duo2");   // two-lookup prefix phase
+        const bool use_pair = bk.pair && !no_pair;
         if (bk.duo && !no_duo) {
             HIP_TRY(c, vtxk_launch_sw_full_duo(bk.R, bk.count, c->d_work.as<uint32_t>() + bk.offset, c->d_records.as<vtx_record>(),
                                                c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
                                                c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
-                                               c->max_hap_len, duo_loci_cap(c->max_hap_len), c->d_redo.as<uint32_t>() + bk.offset,
-                                               c->d_redo_cnt.as<uint32_t>() + b, s));
+                                               c->max_hap_len, use_pair ? kPairLociCap : duo_loci_cap(c->max_hap_len),
+                                               c->d_redo.as<uint32_t>() + bk.offset, c->d_redo_cnt.as<uint32_t>() + b,
+                                               use_pair ? duo_pair_cols(c->max_hap_len) : 0u, s));
         } else if (bk.lut) {
             HIP_TRY(c, vtxk_launch_sw_full_lut(bk.R, bk.count, c->d_work.as<uint32_t>() + bk.offset, c->d_records.as<vtx_record>(),
                                                c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),

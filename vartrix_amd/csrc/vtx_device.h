@@ -40,7 +40,8 @@ hipError_t vtxk_launch_sw_full_lut(int R, uint32_t n_work, const uint32_t* work,
 hipError_t vtxk_launch_sw_full_duo(int R, uint32_t n_work, const uint32_t* work, const vtx_record* records,
                                    const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                    const uint8_t* hap_arena, int32_t* ref_score, int32_t* alt_score, uint32_t max_hap_len,
-                                   uint32_t loci_cap, uint32_t* redo, uint32_t* redo_count, hipStream_t stream);
+                                   uint32_t loci_cap, uint32_t* redo, uint32_t* redo_count, uint32_t pair_cols,
+                                   hipStream_t stream);
 hipError_t vtxk_launch_sw_banded(int R, int GL, uint32_t n_hard, const uint32_t* hard, const vtx_record* records,
                                  const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                  const uint8_t* hap_arena, const uint16_t* band, uint32_t band_stride, int32_t* ref_score,

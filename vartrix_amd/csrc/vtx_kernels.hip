@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256) void sw_full_duo_kernel(
     const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
     int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score, uint32_t lcols, uint32_t loci_cap,
-    uint32_t* __restrict__ redo, uint32_t* __restrict__ redo_count) {
+    uint32_t* __restrict__ redo, uint32_t* __restrict__ redo_count, uint32_t pcols) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t s_v[8];                           // common REF/ALT prefix length per table
     constexpr int GL = 16;
@@ -750,18 +750,22 @@ __global__ __launch_bounds__(256) void sw_full_duo_kernel(
     const int l = tid % GL;
     const uint32_t pair = blockIdx.x * PAIRS_PER_BLOCK + grp;
     const bool active = 2 * pair < n_work;
-    const bool has_b = 2 * pair + 1 < n_work;
+    const bool has_b0 = 2 * pair + 1 < n_work;
 
     uint32_t rid_a = 0, rid_b = 0, m_a = 0, m_b = 0, roff_a = 0, roff_b = 0, loc_a = 0, loc_b = 0, n = 0;
+    uint32_t cross_b = 0xffffffffu;
     const uint32_t w_first = blockIdx.x * 2 * PAIRS_PER_BLOCK;
     const uint32_t w_last = min(n_work - 1, w_first + 2 * PAIRS_PER_BLOCK - 1);
     const uint32_t l_first = rec_locus[work[w_first]], l_last = rec_locus[work[w_last]];
     const uint32_t n_loc = l_last - l_first + 1;          // <= loci_cap (checked when this kernel is chosen)
     if (active) {
         rid_a = work[2 * pair];
-        rid_b = has_b ? work[2 * pair + 1] : rid_a;
+        rid_b = has_b0 ? work[2 * pair + 1] : rid_a;
         const vtx_record ra = records[rid_a], rb = records[rid_b];
         loc_a = rec_locus[rid_a]; loc_b = rec_locus[rid_b];
+        // pair-table mode (pcols != 0) looks both reads up in ONE table: a pair that straddles two loci scores A
+        // alone here and hands B to the redo list (one record per locus boundary)
+        if (pcols && loc_b != loc_a) { cross_b = rid_b; rid_b = rid_a; loc_b = loc_a; }
         const vtx_locus la = loci[loc_a], lb = loci[loc_b];
         m_a = ra.read_len; roff_a = ra.read_off; m_b = rb.read_len; roff_b = rb.read_off;
         n = max(max(la.ref_len, la.alt_len), max(lb.ref_len, lb.alt_len));
@@ -795,6 +799,29 @@ __global__ __launch_bounds__(256) void sw_full_duo_kernel(
         }
     }
 
+    // ---- pair tables (deep data): pair[t][column][codeA * 6 + codeB] = {m(codeA), m(codeB)} against the common
+    //      prefix, so phase P needs ONE lookup per cell and no v_perm.  38 words per column: the 16 lanes of a row
+    //      (consecutive columns) fall on distinct even banks, as with the 6-word stride of the single tables. ----
+    constexpr uint32_t PSTRIDE = 38;
+    const uint32_t pair_base_words = loci_cap * tab_words;
+    if (pcols) {
+        for (uint32_t t = 0; t < n_loc && t < loci_cap; ++t) {
+            const vtx_locus loc = loci[l_first + t];
+            uint32_t* ptab = smem + pair_base_words + (size_t)t * pcols * PSTRIDE;
+            for (uint32_t item = tid; item < pcols * LUT_CODES; item += 256) {
+                const uint32_t idx = item / LUT_CODES, a = item % LUT_CODES;
+                const int j = (int)idx - PRE;
+                uint32_t rc = 0x200u;
+                if (j >= 0 && (uint32_t)j < loc.ref_len) rc = hap_arena[loc.ref_off + j];
+                const uint32_t bases[6] = {'A', 'C', 'G', 'T', 'N', 0x300u};
+                const uint32_t ma = (rc == bases[a]) ? 0x0001u : 0xfffbu;
+#pragma unroll
+                for (int b = 0; b < LUT_CODES; ++b)
+                    ptab[idx * PSTRIDE + a * LUT_CODES + b] = ma | (((rc == bases[b]) ? 0x0001u : 0xfffbu) << 16);
+            }
+        }
+    }
+
     // ---- rows of this lane for both reads ----
     const uint32_t lane_base_a = ((uint32_t)(loc_a - l_first) * tab_words + (uint32_t)(PRE - l) * LUT_CODES) * 4u;
     const uint32_t lane_base_b = ((uint32_t)(loc_b - l_first) * tab_words + (uint32_t)(PRE - l) * LUT_CODES) * 4u;
@@ -808,7 +835,9 @@ __global__ __launch_bounds__(256) void sw_full_duo_kernel(
         if (i < m_a) { ca = base_code(read_arena[roff_a + i]); if (ca > 5) { bad = true; ca = 5; } }
         if (i < m_b) { cb = base_code(read_arena[roff_b + i]); if (cb > 5) { bad = true; cb = 5; } }
         addr[r] = lane_base_a + ca * 4u;
-        X[r] = lane_base_b + cb * 4u;
+        X[r] = pcols ? (pair_base_words + (uint32_t)(loc_a - l_first) * pcols * PSTRIDE + (uint32_t)(PRE - l) * PSTRIDE +
+                        ca * LUT_CODES + cb) * 4u
+                     : lane_base_b + cb * 4u;
         codes_b |= (uint64_t)cb << (3 * r);
     }
     __syncthreads();
@@ -829,7 +858,9 @@ __global__ __launch_bounds__(256) void sw_full_duo_kernel(
     nw = max(nw, (uint32_t)__shfl_xor((int)nw, 16));
     nw = max(nw, (uint32_t)__shfl_xor((int)nw, 32));
     nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)nw);
-    const uint32_t T1 = min((uint32_t)__builtin_amdgcn_readfirstlane((int)vw), nw) & ~3u;
+    uint32_t T1 = min((uint32_t)__builtin_amdgcn_readfirstlane((int)vw), nw);
+    if (pcols) T1 = min(T1, pcols - PRE);              // the pair tables hold PRE + (pcols - PRE) prefix columns
+    T1 &= ~3u;
     const uint32_t S = (nw - T1 + (GL - 1) + 3) & ~3u;
 
     uint32_t Ha[R], Hb[R], Q[R], E[R];
@@ -870,13 +901,28 @@ __global__ __launch_bounds__(256) void sw_full_duo_kernel(
     // a group of four steps starts with "previous column" = Hb, diagonal carry = hu_b, incoming carry = hu_a
 
     // ---------------- phase P: steps [0, T1), halves {A, B} ----------------
-    for (uint32_t t4 = 0; t4 < (T1 >> 2); ++t4) {
-        P_STEP(Hb, Ha, hu_b, hu_a, 0 * LUT_CODES * 4)
-        P_STEP(Ha, Hb, hu_a, hu_b, 1 * LUT_CODES * 4)
-        P_STEP(Hb, Ha, hu_b, hu_a, 2 * LUT_CODES * 4)
-        P_STEP(Ha, Hb, hu_a, hu_b, 3 * LUT_CODES * 4)
+    if (pcols) {
+#define W_PP(OFF) LDSW(X[r], OFF)
+#define PP_STEP(HS, HD, hprev, hcur, OFF) { DUO_EXCHANGE(hcur, HS[R - 1]) DUO_COLUMN(HS, HD, hprev, W_PP(OFF)) }
+        for (uint32_t t4 = 0; t4 < (T1 >> 2); ++t4) {
+            PP_STEP(Hb, Ha, hu_b, hu_a, 0 * PSTRIDE * 4)
+            PP_STEP(Ha, Hb, hu_a, hu_b, 1 * PSTRIDE * 4)
+            PP_STEP(Hb, Ha, hu_b, hu_a, 2 * PSTRIDE * 4)
+            PP_STEP(Ha, Hb, hu_a, hu_b, 3 * PSTRIDE * 4)
 #pragma unroll
-        for (int r = 0; r < R; ++r) { addr[r] += 4 * LUT_CODES * 4; X[r] += 4 * LUT_CODES * 4; }
+            for (int r = 0; r < R; ++r) { addr[r] += 4 * LUT_CODES * 4; X[r] += 4 * PSTRIDE * 4; }
+        }
+#undef PP_STEP
+#undef W_PP
+    } else {
+        for (uint32_t t4 = 0; t4 < (T1 >> 2); ++t4) {
+            P_STEP(Hb, Ha, hu_b, hu_a, 0 * LUT_CODES * 4)
+            P_STEP(Ha, Hb, hu_a, hu_b, 1 * LUT_CODES * 4)
+            P_STEP(Hb, Ha, hu_b, hu_a, 2 * LUT_CODES * 4)
+            P_STEP(Ha, Hb, hu_a, hu_b, 3 * LUT_CODES * 4)
+#pragma unroll
+            for (int r = 0; r < R; ++r) { addr[r] += 4 * LUT_CODES * 4; X[r] += 4 * LUT_CODES * 4; }
+        }
     }
     // ---------------- phases A and B: single lookup, S steps each ----------------
     uint32_t in_b = 0, dg_b = 0;          // B halves of the carries received at step T1 / of diagonal carry and best
@@ -941,6 +987,8 @@ __global__ __launch_bounds__(256) void sw_full_duo_kernel(
         out_a = pk_max(out_a, (uint32_t)__shfl_xor((int)out_a, off));
     }
     if (active && l == 0) {
+        if (cross_b != 0xffffffffu) redo[atomicAdd(redo_count, 1u)] = cross_b;
+        const bool has_b = has_b0 && cross_b == 0xffffffffu;
         if (badm) {
             const uint32_t k = atomicAdd(redo_count, has_b ? 2u : 1u);
             redo[k] = rid_a;
@@ -960,11 +1008,13 @@ extern "C" hipError_t vtxk_launch_sw_full_duo(int R, uint32_t n_work, const uint
                                               const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                               const uint8_t* hap_arena, int32_t* ref_score, int32_t* alt_score,
                                               uint32_t max_hap_len, uint32_t loci_cap, uint32_t* redo, uint32_t* redo_count,
-                                              hipStream_t stream) {
+                                              uint32_t pair_cols, hipStream_t stream) {
     if (n_work == 0) return hipSuccess;
-    // columns: PRE sentinels + haplotype (at least the 16 steps of a window) + lane skew + 4x unroll slack
+    // columns: PRE sentinels + haplotype (at least 16) + lane skew + 4x unroll slack
     const uint32_t lcols = 16 + (max_hap_len > 16 ? max_hap_len : 16) + 16 + 4;
-    const size_t shmem = (size_t)loci_cap * lcols * LUT_CODES * sizeof(uint32_t);
+    // pair_cols != 0: per locus also a pair table of pair_cols columns x 38 words (see the kernel)
+    const size_t shmem = ((size_t)loci_cap * lcols * LUT_CODES + (size_t)loci_cap * pair_cols * 38) * sizeof(uint32_t);
+    if (shmem > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid((n_work + 31) / 32), block(256);
 #define CASE(r)                                                                                          \
     if (R == r) {                                                                                        \
@@ -974,7 +1024,7 @@ extern "C" hipError_t vtxk_launch_sw_full_duo(int R, uint32_t n_work, const uint
             if (e != hipSuccess) return e;                                                               \
         }                                                                                                \
         hipLaunchKernelGGL((sw_full_duo_kernel<r>), grid, block, shmem, stream, work, n_work, records,   \
-                           rec_locus, loci, read_arena, hap_arena, ref_score, alt_score, lcols, loci_cap, redo, redo_count); \
+                           rec_locus, loci, read_arena, hap_arena, ref_score, alt_score, lcols, loci_cap, redo, redo_count, pair_cols); \
         return hipGetLastError();                                                                        \
     }
     CASE(2) CASE(4) CASE(6) CASE(8) CASE(10) CASE(12) CASE(16)
