@@ -402,3 +402,16 @@ np.save(OUT, np.concatenate(out))
         res[kern] = np.load(path)
         os.remove(path)
     assert res["duo"].size > 80000 and np.array_equal(res["duo"], res["lut"])
+
+
+@pytest.mark.parametrize("aligner", ALIGNERS)
+@pytest.mark.parametrize("padding,reads_per_locus", [(260, 64), (120, 64), (40, 5)])
+def test_dp_kernel_modes_by_haplotype_length_and_depth(aligner, padding, reads_per_locus):
+    """The shared-prefix DP kernel picks its lookup mode from the haplotype length and the depth: pair table (deep,
+    default padding), two lookups (long haplotypes: the pair table would not hold the prefix; or shallow loci, up to
+    8 tables per workgroup).  Same scores as the oracle in every mode."""
+    spec = synth.SynthSpec(n_loci=60 if reads_per_locus > 8 else 400, n_barcodes=100, reads_per_locus=reads_per_locus,
+                           read_len=150, padding=padding, indel_frac=0.3, read_len_jitter=20, seed=padding)
+    batch = synth.make_batch(spec)
+    cfg = default_config(aligner=aligner, scoring_mode="coverage", n_barcodes=spec.n_barcodes)
+    assert_same(batch, cfg, threads=os.cpu_count() or 8)

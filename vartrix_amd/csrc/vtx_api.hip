@@ -162,7 +162,10 @@ uint32_t duo_pair_cols(uint32_t max_hap) {
     const size_t single = kPairLociCap * lcols * 6 * 4;
     if (single + kPairLociCap * (16 + 32) * 38 * 4 > 52 * 1024) return 0;
     const size_t fit = (52 * 1024 - single) / (kPairLociCap * 38 * 4);
-    return (uint32_t)std::min<size_t>(fit, 16 + (size_t)max_hap);
+    const size_t cols = std::min<size_t>(fit, 16 + (size_t)max_hap);
+    // the shared prefix is about half of the haplotype (the padding): a pair table that cannot hold it would cut the
+    // sharing short (T1 is clamped to the table), and the two-lookup mode is the better choice then
+    return cols >= 16 + (size_t)max_hap / 2 + 4 ? (uint32_t)cols : 0u;
 }
 
 uint32_t bits_for(uint64_t max_value) {   // bits needed to represent values 0..max_value
