@@ -14,6 +14,15 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    """The CLI and both libraries are build artefacts (git-ignored): build them when the tree does not have them."""
+    from vartrix_amd import lib
+    if not (os.path.exists(hostlib.CLI_PATH) and os.path.exists(hostlib.LIB_PATH) and os.path.exists(lib.LIB_PATH)):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 def run_cli(args, cwd):
     r = subprocess.run([hostlib.CLI_PATH] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
