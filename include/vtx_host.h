@@ -71,6 +71,14 @@ void vtxh_get_raw_batch(const vtxh_pack* p, vtx_raw_batch* out);
 /* The barcode list in the layout vtx_set_barcodes takes (n = vtxh_num_barcodes). */
 void vtxh_get_barcode_table(const vtxh_pack* p, const uint8_t** bytes, const uint64_t** offsets, uint32_t* n);
 
+/* A pack holds one or more BATCHES: consecutive loci whose reads span less than 4 GiB of the arenas, so that the
+ * 32-bit offsets of vtx.h hold relative to the batch (the reference has no such limit: it streams per locus).
+ * Loci keep their global `row`; feed the batches to vtx_submit / vtx_submit_raw one after the other (or to different
+ * devices) and append their triplets in batch order.  vtxh_get_batch / vtxh_get_raw_batch return batch 0.            */
+uint32_t vtxh_num_batches(const vtxh_pack* p);
+void vtxh_get_batch_at(const vtxh_pack* p, uint32_t i, vtx_batch* out);
+void vtxh_get_raw_batch_at(const vtxh_pack* p, uint32_t i, vtx_raw_batch* out);
+
 /* The packed batch (pointers valid until vtxh_free). */
 void vtxh_get_batch(const vtxh_pack* p, vtx_batch* out);
 void vtxh_get_metrics(const vtxh_pack* p, vtxh_metrics* out);

@@ -122,3 +122,25 @@ def test_reference_fixtures_with_device_prep(tmp_path, umi):
     out2 = str(tmp_path / "c.mtx")
     run_cli(base_args() + ["-o", out2, "--prep", "device", "--devices", "1"], tmp_path)
     assert open(out2).read() == open(os.path.join(G, "test_consensus.mtx")).read()
+
+
+@pytest.mark.parametrize("prep", ["host", "device"])
+def test_multi_batch_run_equals_single_batch(tmp_path, prep):
+    """Inputs whose reads exceed the 32-bit arena limit are processed as several batches (forced here with a tiny
+    limit): same bytes in the .mtx, same counters in the log."""
+    from tests.test_host import make_dna_bam
+    bam = make_dna_bam(tmp_path, seed=4, n_reads=1500)
+    vcfp, fap, bcp = (os.path.join(G, n) for n in ("test_dna.vcf", "test_dna.fa", "dna_barcodes.tsv"))
+    outs = {}
+    for name, env in (("one", {}), ("many", {"VTXH_BATCH_BYTES": "12000"})):
+        out = str(tmp_path / (name + ".mtx"))
+        args = ["-v", vcfp, "-b", bam, "-f", fap, "-c", bcp, "-o", out, "-s", "alt_frac", "--umi", "--threads", "3", "--prep", prep,
+                "--log-level", "info", "--ref-matrix", str(tmp_path / (name + "_ref.mtx"))]
+        r = subprocess.run([hostlib.CLI_PATH] + args, cwd=tmp_path, capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        log = r.stdout + r.stderr
+        outs[name] = (open(out).read(), sorted(ln.split("] ", 1)[1] for ln in log.splitlines() if "Number of" in ln),
+                      int(log.split("pack: ")[1].split("(")[1].split(" batch")[0]))
+    assert outs["one"][2] == 1 and outs["many"][2] > 3
+    assert outs["one"][0] == outs["many"][0] and outs["one"][1] == outs["many"][1]

@@ -242,3 +242,42 @@ def test_raw_packer_equals_cooked_packer_on_authored_bam(tmp_path, umi):
     for kw in ({}, {"mapq": 30, "no_duplicates": True}, {"primary_only": True, "padding": 40}):
         raw, cooked = _raw_equals_cooked(inputs, use_umi=umi, **kw)
     assert raw.n_records > cooked.n_records          # unlisted barcodes / missing UB are still in the raw batch
+
+
+def _concat_batches(batches):
+    """Loci keep their global row; records / reads of the batches are compared through the canonical form."""
+    rows, recs = [], []
+    for b in batches:
+        for loc in b.loci:
+            rows.append(int(loc["row"]))
+            r = b.records[int(loc["rec_begin"]):int(loc["rec_begin"]) + int(loc["rec_count"])]
+            recs.append([(int(x["cell_index"]) if "cell_index" in r.dtype.names else bytes(b.tag_arena[int(x["bc_off"]):int(x["bc_off"]) + int(x["bc_len"])]),
+                          int(x["umi_id"]) if "umi_id" in r.dtype.names else (None if int(x["umi_len"]) == 0xFFFF else bytes(b.tag_arena[int(x["umi_off"]):int(x["umi_off"]) + int(x["umi_len"])])),
+                          bytes(b.read_arena[int(x["read_off"]):int(x["read_off"]) + int(x["read_len"])])) for x in r])
+    return rows, recs
+
+
+@pytest.mark.parametrize("raw", [False, True])
+@pytest.mark.parametrize("umi", [False, True])
+def test_packer_splits_large_inputs_into_batches(tmp_path, monkeypatch, raw, umi):
+    """Reads spanning more than the 32-bit arena limit come as several batches (windows of the same arenas with
+    rebased offsets).  With the limit forced down to a few KB the concatenation equals the single-batch pack."""
+    bam = make_dna_bam(tmp_path, seed=9, n_reads=1200)
+    inputs = dict(vcf=os.path.join(G, "test_dna.vcf"), bam=bam, fasta=os.path.join(G, "test_dna.fa"),
+                  cell_barcodes=os.path.join(G, "dna_barcodes.tsv"))
+    one, m1, *_ = hostlib.pack_files(use_umi=umi, raw=raw, threads=2, all_batches=True, **inputs)
+    assert len(one) == 1
+    monkeypatch.setenv("VTXH_BATCH_BYTES", "9000")
+    many, m2, *_ = hostlib.pack_files(use_umi=umi, raw=raw, threads=2, all_batches=True, **inputs)
+    assert len(many) > 3 and m1 == m2
+    assert _concat_batches(many) == _concat_batches(one)
+    for b in many:                                   # every batch is self-consistent under the 32-bit layout
+        assert b.read_arena.size <= 9000 + 200
+        ends = b.loci["rec_begin"].astype(np.int64) + b.loci["rec_count"]
+        assert ends.max(initial=0) == b.n_records
+        assert np.all(b.records["read_off"].astype(np.int64) + b.records["read_len"] <= b.read_arena.size)
+    with pytest.raises(hostlib.HostError, match="batches"):
+        hostlib.pack_files(use_umi=umi, raw=raw, **inputs)          # the single-batch call refuses a multi-batch pack
+    monkeypatch.setenv("VTXH_BATCH_BYTES", "100")
+    with pytest.raises(hostlib.HostError, match="alone needs more"):
+        hostlib.pack_files(use_umi=umi, raw=raw, all_batches=True, **inputs)

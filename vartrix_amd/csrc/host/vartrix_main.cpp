@@ -234,21 +234,8 @@ int main(int argc, char** argv) {
         LOG_ERROR("Warning! Zero variants found in input VCF. Output matrices will be by definition empty but will still be generated.");
     LOG_INFO("Initialized a %u variants x %u cell barcodes matrix", n_vars, n_bcs);
 
-    // ---- the hot path: loci sharded over --devices GPUs (contiguous row ranges by record count) ----
-    vtx_batch full{};
-    vtx_raw_batch full_raw{};
-    const uint8_t* bc_bytes = nullptr;
-    const uint64_t* bc_offsets = nullptr;
-    uint32_t bc_n = 0;
-    if (raw) {
-        vtxh_get_raw_batch(pk, &full_raw);
-        vtxh_get_barcode_table(pk, &bc_bytes, &bc_offsets, &bc_n);
-        full.loci = full_raw.loci; full.n_loci = full_raw.n_loci; full.n_records = full_raw.n_records;
-        full.hap_arena = full_raw.hap_arena; full.hap_bytes = full_raw.hap_bytes;
-        full.read_arena = full_raw.read_arena; full.read_bytes = full_raw.read_bytes;
-    } else {
-        vtxh_get_batch(pk, &full);
-    }
+    // ---- the hot path: every batch of the pack (one unless the reads span > 4 GiB) is sharded over --devices GPUs
+    //      (contiguous row ranges by record count); triplets are appended in batch order = row order ----
     vtx_config cfg;
     vtx_config_default(&cfg);
     if (val["aligner"] != "banded" && val["aligner"] != "full") {
@@ -259,75 +246,93 @@ int main(int argc, char** argv) {
     cfg.scoring_mode = mode == "consensus" ? VTX_MODE_CONSENSUS : (mode == "alt_frac" ? VTX_MODE_ALT_FRAC : VTX_MODE_COVERAGE);
     cfg.use_umi = ha.use_umi;
     cfg.n_barcodes = n_bcs;
-    std::vector<Shard> shards((size_t)ndev);
-    {
-        const uint64_t total = full.n_records;
-        std::vector<uint32_t> cuts((size_t)ndev + 1, full.n_loci);
-        cuts[0] = 0;
-        uint64_t acc = 0;
-        uint32_t l = 0;
-        for (int d = 1; d < ndev; ++d) {
-            const uint64_t target = total * (uint64_t)d / (uint64_t)ndev;
-            while (l < full.n_loci && acc < target) acc += full.loci[l++].rec_count;
-            cuts[(size_t)d] = l;
-        }
-        for (int d = 0; d < ndev; ++d) {
-            Shard& s = shards[(size_t)d];
-            s.loci.assign(full.loci + cuts[(size_t)d], full.loci + cuts[(size_t)d + 1]);
-            const uint32_t r0 = s.loci.empty() ? 0 : s.loci.front().rec_begin;
-            const uint32_t r1 = s.loci.empty() ? 0 : s.loci.back().rec_begin + s.loci.back().rec_count;
-            if (raw) {
-                s.raw = true;
-                s.raw_records.assign(full_raw.records + r0, full_raw.records + r1);
-                s.tags = full_raw.tag_arena; s.tag_bytes = full_raw.tag_bytes;
-                s.bc_bytes = bc_bytes; s.bc_offsets = bc_offsets; s.n_bcs = bc_n;
-            } else {
-                s.records.assign(full.records + r0, full.records + r1);
-            }
-            for (auto& L : s.loci) L.rec_begin -= r0;
-            s.haps = full.hap_arena; s.hap_bytes = full.hap_bytes;       // arenas are shared read-only, offsets stay valid
-            s.reads = full.read_arena; s.read_bytes = full.read_bytes;
-        }
-    }
-    LOG_INFO("Ingest + filter + pack: %.3f s (%u loci, %u %s)", t_ingest, full.n_loci, full.n_records,
-             raw ? "raw reads; barcode lookup / UMI grouping / sort on the device" : "scored reads");
+    const uint8_t* bc_bytes = nullptr;
+    const uint64_t* bc_offsets = nullptr;
+    uint32_t bc_n = 0;
+    if (raw) vtxh_get_barcode_table(pk, &bc_bytes, &bc_offsets, &bc_n);
+    const uint32_t n_batches = vtxh_num_batches(pk);
     const auto t_wait = std::chrono::steady_clock::now();
     for (auto& t : warm) t.join();
     LOG_INFO("Waited %.3f s more for the HIP runtime / device initialisation started at launch", since(t_wait));
-    const auto t_dev = std::chrono::steady_clock::now();
-    std::vector<std::thread> th;
-    for (int d = 0; d < ndev; ++d) {
-        vtx_config c = cfg;
-        c.device = d;
-        th.emplace_back(run_shard, &shards[(size_t)d], c);
-    }
-    for (auto& t : th) t.join();
-    for (auto& s : shards)
-        if (s.rc) { printf("Vartrix error.\nError: %s: %s\n", vtx_status_name(s.rc), s.err.c_str()); return 1; }
-
-    LOG_INFO("Device (create + submit + run + fetch) on %d GPU(s): %.3f s", ndev, since(t_dev));
-    for (auto& s : shards)
-        LOG_INFO("  shard: create %.3f s, submit (H2D%s) %.3f s, run %.3f s, fetch %.3f s", s.t_create,
-                 s.raw ? " + device preparation" : "", s.t_submit, s.t_run, s.t_fetch);
-    const auto t_out = std::chrono::steady_clock::now();
-    // merge in shard (= row) order: exactly the triplet order of the merge loop :320-348
     std::vector<uint32_t> row, col;
     std::vector<double> v, rv;
-    for (auto& s : shards) {
-        row.insert(row.end(), s.row.begin(), s.row.end());
-        col.insert(col.end(), s.col.begin(), s.col.end());
-        v.insert(v.end(), s.val.begin(), s.val.end());
-        rv.insert(rv.end(), s.refval.begin(), s.refval.end());
+    vtx_raw_stats raw_total{};
+    const auto t_dev = std::chrono::steady_clock::now();
+    for (uint32_t bi = 0; bi < n_batches; ++bi) {
+        vtx_batch full{};
+        vtx_raw_batch full_raw{};
+        if (raw) {
+            vtxh_get_raw_batch_at(pk, bi, &full_raw);
+            full.loci = full_raw.loci; full.n_loci = full_raw.n_loci; full.n_records = full_raw.n_records;
+            full.hap_arena = full_raw.hap_arena; full.hap_bytes = full_raw.hap_bytes;
+            full.read_arena = full_raw.read_arena; full.read_bytes = full_raw.read_bytes;
+        } else {
+            vtxh_get_batch_at(pk, bi, &full);
+        }
+        std::vector<Shard> shards((size_t)ndev);
+        {
+            const uint64_t total = full.n_records;
+            std::vector<uint32_t> cuts((size_t)ndev + 1, full.n_loci);
+            cuts[0] = 0;
+            uint64_t acc = 0;
+            uint32_t l = 0;
+            for (int d = 1; d < ndev; ++d) {
+                const uint64_t target = total * (uint64_t)d / (uint64_t)ndev;
+                while (l < full.n_loci && acc < target) acc += full.loci[l++].rec_count;
+                cuts[(size_t)d] = l;
+            }
+            for (int d = 0; d < ndev; ++d) {
+                Shard& s = shards[(size_t)d];
+                s.loci.assign(full.loci + cuts[(size_t)d], full.loci + cuts[(size_t)d + 1]);
+                const uint32_t r0 = s.loci.empty() ? 0 : s.loci.front().rec_begin;
+                const uint32_t r1 = s.loci.empty() ? 0 : s.loci.back().rec_begin + s.loci.back().rec_count;
+                if (raw) {
+                    s.raw = true;
+                    s.raw_records.assign(full_raw.records + r0, full_raw.records + r1);
+                    s.tags = full_raw.tag_arena; s.tag_bytes = full_raw.tag_bytes;
+                    s.bc_bytes = bc_bytes; s.bc_offsets = bc_offsets; s.n_bcs = bc_n;
+                } else {
+                    s.records.assign(full.records + r0, full.records + r1);
+                }
+                for (auto& L : s.loci) L.rec_begin -= r0;
+                s.haps = full.hap_arena; s.hap_bytes = full.hap_bytes;       // arenas are shared read-only, offsets stay valid
+                s.reads = full.read_arena; s.read_bytes = full.read_bytes;
+            }
+        }
+        if (bi == 0)
+            LOG_INFO("Ingest + filter + pack: %.3f s (%u batch(es); first: %u loci, %u %s)", t_ingest, n_batches, full.n_loci, full.n_records,
+                     raw ? "raw reads; barcode lookup / UMI grouping / sort on the device" : "scored reads");
+        std::vector<std::thread> th;
+        for (int d = 0; d < ndev; ++d) {
+            vtx_config c = cfg;
+            c.device = d;
+            th.emplace_back(run_shard, &shards[(size_t)d], c);
+        }
+        for (auto& t : th) t.join();
+        for (auto& s : shards)
+            if (s.rc) { printf("Vartrix error.\nError: %s: %s\n", vtx_status_name(s.rc), s.err.c_str()); return 1; }
+        for (auto& s : shards) {
+            LOG_INFO("  batch %u shard: create %.3f s, submit (H2D%s) %.3f s, run %.3f s, fetch %.3f s", bi, s.t_create,
+                     s.raw ? " + device preparation" : "", s.t_submit, s.t_run, s.t_fetch);
+            row.insert(row.end(), s.row.begin(), s.row.end());       // shard (= row) order: the triplet order of the merge loop :320-348
+            col.insert(col.end(), s.col.begin(), s.col.end());
+            v.insert(v.end(), s.val.begin(), s.val.end());
+            rv.insert(rv.end(), s.refval.begin(), s.refval.end());
+            if (s.raw) {
+                raw_total.num_not_cell_bc += s.stats.num_not_cell_bc;      // the in-list test ran on the device (:870-876)
+                raw_total.num_non_umi += s.stats.num_non_umi;              // :879-888
+                raw_total.kept += s.stats.kept;
+                LOG_INFO("  device preparation: %llu reads kept, %.3f ms, %u hash round(s)", (unsigned long long)s.stats.kept,
+                         (double)s.stats.prep_ms, s.stats.hash_rounds);
+            }
+        }
     }
+    LOG_INFO("Device (create + submit + run + fetch) on %d GPU(s): %.3f s", ndev, since(t_dev));
+    const auto t_out = std::chrono::steady_clock::now();
     vtxh_metrics m;
     vtxh_get_metrics(pk, &m);
-    for (auto& s : shards) {
-        if (!s.raw) continue;
-        m.num_not_cell_bc += s.stats.num_not_cell_bc;      // the in-list test ran on the device (:870-876)
-        m.num_non_umi += s.stats.num_non_umi;              // :879-888
-        LOG_INFO("Device preparation: %llu reads kept, %.3f ms, %u hash round(s)", (unsigned long long)s.stats.kept,
-                 (double)s.stats.prep_ms, s.stats.hash_rounds);
-    }
+    m.num_not_cell_bc += raw_total.num_not_cell_bc;
+    m.num_non_umi += raw_total.num_non_umi;
     LOG_INFO("Number of alignments evaluated: %llu", (unsigned long long)m.num_reads);                                        // :350-379
     LOG_INFO("Number of alignments skipped due to low mapping quality: %llu", (unsigned long long)m.num_low_mapq);
     LOG_INFO("Number of alignments skipped due to not being primary: %llu", (unsigned long long)m.num_non_primary);

@@ -374,6 +374,10 @@ struct vtxh_pack {
     std::vector<vtx_raw_record> raw_records;
     std::string tag_arena, bc_bytes;
     std::vector<uint64_t> bc_offsets;
+    // Batches: consecutive loci whose reads (and tags) span less than 4 GiB of the arenas, so that the 32-bit offsets
+    // of vtx.h hold relative to the batch's window.  Loci / records of all batches sit back to back in the arrays above.
+    struct Batch { uint32_t l0, l1; uint64_t rec0, rec1, rbase, rbytes, tbase, tbytes; };
+    std::vector<Batch> batches;
 };
 
 extern "C" {
@@ -436,25 +440,34 @@ int vtxh_write_mtx(const char* path, uint32_t n_rows, uint32_t n_cols, uint64_t 
 }
 
 void vtxh_free(vtxh_pack* p) { delete p; }
-void vtxh_get_batch(const vtxh_pack* p, vtx_batch* out) {
-    out->loci = p->loci.data(); out->n_loci = (uint32_t)p->loci.size();
-    out->records = p->records.data(); out->n_records = (uint32_t)p->records.size();
+uint32_t vtxh_num_batches(const vtxh_pack* p) { return (uint32_t)p->batches.size(); }
+void vtxh_get_batch_at(const vtxh_pack* p, uint32_t i, vtx_batch* out) {
+    memset(out, 0, sizeof *out);
+    if (i >= p->batches.size()) return;
+    const vtxh_pack::Batch& b = p->batches[i];
+    out->loci = p->loci.data() + b.l0; out->n_loci = b.l1 - b.l0;
+    out->records = p->records.data() + b.rec0; out->n_records = (uint32_t)(b.rec1 - b.rec0);
     out->hap_arena = (const uint8_t*)p->hap_arena.data(); out->hap_bytes = p->hap_arena.size();
-    out->read_arena = (const uint8_t*)p->read_arena.data(); out->read_bytes = p->read_arena.size();
+    out->read_arena = p->read_arena.data() + b.rbase; out->read_bytes = b.rbytes;
 }
+void vtxh_get_batch(const vtxh_pack* p, vtx_batch* out) { vtxh_get_batch_at(p, 0, out); }
 void vtxh_get_metrics(const vtxh_pack* p, vtxh_metrics* out) { *out = p->metrics; }
 uint32_t vtxh_num_variants(const vtxh_pack* p) { return p->n_variants; }
 uint32_t vtxh_num_barcodes(const vtxh_pack* p) { return (uint32_t)p->barcodes.size(); }
 const char* vtxh_variant_name(const vtxh_pack* p, uint32_t i) { return i < p->variant_names.size() ? p->variant_names[i].c_str() : ""; }
 const char* vtxh_barcode(const vtxh_pack* p, uint32_t j) { return j < p->barcodes.size() ? p->barcodes[j].c_str() : ""; }
 
-void vtxh_get_raw_batch(const vtxh_pack* p, vtx_raw_batch* out) {
-    out->loci = p->loci.data(); out->n_loci = (uint32_t)p->loci.size();
-    out->records = p->raw_records.data(); out->n_records = (uint32_t)p->raw_records.size();
+void vtxh_get_raw_batch_at(const vtxh_pack* p, uint32_t i, vtx_raw_batch* out) {
+    memset(out, 0, sizeof *out);
+    if (i >= p->batches.size()) return;
+    const vtxh_pack::Batch& b = p->batches[i];
+    out->loci = p->loci.data() + b.l0; out->n_loci = b.l1 - b.l0;
+    out->records = p->raw_records.data() + b.rec0; out->n_records = (uint32_t)(b.rec1 - b.rec0);
     out->hap_arena = (const uint8_t*)p->hap_arena.data(); out->hap_bytes = p->hap_arena.size();
-    out->read_arena = (const uint8_t*)p->read_arena.data(); out->read_bytes = p->read_arena.size();
-    out->tag_arena = (const uint8_t*)p->tag_arena.data(); out->tag_bytes = p->tag_arena.size();
+    out->read_arena = p->read_arena.data() + b.rbase; out->read_bytes = b.rbytes;
+    out->tag_arena = (const uint8_t*)p->tag_arena.data() + b.tbase; out->tag_bytes = b.tbytes;
 }
+void vtxh_get_raw_batch(const vtxh_pack* p, vtx_raw_batch* out) { vtxh_get_raw_batch_at(p, 0, out); }
 void vtxh_get_barcode_table(const vtxh_pack* p, const uint8_t** bytes, const uint64_t** offsets, uint32_t* n) {
     *bytes = (const uint8_t*)p->bc_bytes.data(); *offsets = p->bc_offsets.data(); *n = (uint32_t)p->barcodes.size();
 }
@@ -649,7 +662,8 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     // records are parsed and filtered by `threads` workers over contiguous ranges into thread-local
     // outputs, and the outputs are merged in thread order — so every locus sees its reads in BAM order,
     // exactly like one sequential sweep.
-    struct Hit { uint32_t locus, cell; vtx_raw_record rr; };       // rr offsets are relative to the worker's arenas
+    // rr offsets are relative to the worker's arenas; roff / toff: where those start in the global arenas (64-bit)
+    struct Hit { uint32_t locus, cell; vtx_raw_record rr; uint64_t roff, toff; };
     struct WorkerOut { std::vector<Hit> hits; std::string reads, tags; vtxh_metrics m{}; std::string err; uint64_t rbase = 0; };
     ByteBuf& reads = P->read_arena;
     auto process = [&](const unsigned char* r, uint32_t bs, WorkerOut& o, std::vector<uint32_t>& hits, std::string& seq) -> bool {
@@ -721,7 +735,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
                 rr.read_off = (uint32_t)o.reads.size(); o.reads += seq;      // one copy per read, shared by its loci
             }
             rr.read_len = l_seq;
-            o.hits.push_back(Hit{li, cell, rr});
+            o.hits.push_back(Hit{li, cell, rr, 0, 0});
         }
         return o.reads.size() <= 0xffffffffull && o.tags.size() <= 0xffffffffull;
     };
@@ -738,19 +752,13 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         for (auto& o : *outs_p) {
             if (!o.err.empty()) { merge_code = o.err[0] == 'm' ? VTX_E_INVAL : VTX_E_UNSUPPORTED; merge_err = o.err; return; }
             const uint64_t rbase = o.rbase, tbase = tag_store.size();
-            if (tbase + o.tags.size() > 0xffffffffull) {
-                merge_code = VTX_E_UNSUPPORTED; merge_err = "read arena above 4 GiB: split the VCF"; return;
-            }
             tag_store += o.tags;
             const uint64_t* src = &o.m.num_reads;
             uint64_t* dst = &P->metrics.num_reads;
             for (int k = 0; k < 9; ++k) dst[k] += src[k];
             const size_t h0 = all_hits.size();
             all_hits.insert(all_hits.end(), o.hits.begin(), o.hits.end());
-            for (size_t k = h0; k < all_hits.size(); ++k) {
-                vtx_raw_record& rr = all_hits[k].rr;
-                rr.read_off += (uint32_t)rbase; rr.bc_off += (uint32_t)tbase; rr.umi_off += (uint32_t)tbase;
-            }
+            for (size_t k = h0; k < all_hits.size(); ++k) { all_hits[k].roff = rbase + all_hits[k].rr.read_off; all_hits[k].toff = tbase; }
         }
     };
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{merger};
@@ -784,14 +792,13 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             std::string seq;
             for (size_t k = nrec * t / (size_t)threads, e = nrec * (t + 1) / (size_t)threads; k < e; ++k) {
                 const unsigned char* rp = buf.data() + rec_offs[k];
-                if (!process(rp + 4, rd32(rp), o, hits, seq)) { if (o.err.empty()) o.err = "read arena above 4 GiB: split the VCF"; return; }
+                if (!process(rp + 4, rd32(rp), o, hits, seq)) { if (o.err.empty()) o.err = "one window of the BAM holds more than 4 GiB of read bases"; return; }
             }
         });
         // the workers' read bytes go to the global arena at prefix offsets, copied by the workers themselves
         {
             uint64_t total = reads.size();
             for (auto& o : outs) { o.rbase = total; total += o.reads.size(); }
-            if (total > 0xffffffffull) return fail(VTX_E_UNSUPPORTED, "read arena above 4 GiB: split the VCF");
             if (!reads.grow((size_t)(total - reads.size()))) return fail(VTX_E_NOMEM, "out of memory growing the read arena");
             pool.run([&](size_t t) { if (!outs[t].reads.empty()) memcpy(reads.data() + outs[t].rbase, outs[t].reads.data(), outs[t].reads.size()); });
         }
@@ -811,32 +818,87 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
 
     // ---- group the hits by locus: stable counting sort (hits are in BAM order, so every locus keeps it) ----
     const size_t nloc = loci.size();
-    std::vector<uint32_t> l_begin(nloc + 1, 0);
+    std::vector<uint64_t> l_begin(nloc + 1, 0);
     for (const Hit& h : all_hits) ++l_begin[h.locus + 1];
     for (size_t l = 0; l < nloc; ++l) l_begin[l + 1] += l_begin[l];
+    std::vector<Hit> by_locus(all_hits.size());
+    {
+        std::vector<uint64_t> cursor(l_begin.begin(), l_begin.end() - 1);
+        for (const Hit& h : all_hits) by_locus[cursor[h.locus]++] = h;
+    }
+    std::vector<Hit>().swap(all_hits);
+    // ---- batches: consecutive loci whose reads / tags span < 4 GiB (32-bit offsets relative to the batch window) ----
+    uint64_t limit = 0xF0000000ull;
+    if (const char* e = getenv("VTXH_BATCH_BYTES")) limit = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // tests
+    const bool need_tags = raw;
+    {
+        vtxh_pack::Batch cur{0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t rlo = UINT64_MAX, rhi = 0, tlo = UINT64_MAX, thi = 0;
+        auto close = [&](uint32_t l_end) {
+            cur.l1 = l_end; cur.rec1 = l_begin[l_end];
+            cur.rbase = rlo == UINT64_MAX ? 0 : rlo; cur.rbytes = rlo == UINT64_MAX ? 0 : rhi - rlo;
+            cur.tbase = tlo == UINT64_MAX ? 0 : tlo; cur.tbytes = tlo == UINT64_MAX ? 0 : thi - tlo;
+            P->batches.push_back(cur);
+            cur = vtxh_pack::Batch{l_end, l_end, l_begin[l_end], l_begin[l_end], 0, 0, 0, 0};
+            rlo = tlo = UINT64_MAX; rhi = thi = 0;
+        };
+        for (size_t l = 0; l < nloc; ++l) {
+            uint64_t a0 = UINT64_MAX, a1 = 0, b0 = UINT64_MAX, b1 = 0;
+            for (uint64_t j = l_begin[l]; j < l_begin[l + 1]; ++j) {
+                const Hit& h = by_locus[j];
+                a0 = std::min(a0, h.roff); a1 = std::max(a1, h.roff + h.rr.read_len);
+                if (need_tags) {
+                    b0 = std::min(b0, h.toff + h.rr.bc_off);
+                    b1 = std::max(b1, h.toff + h.rr.bc_off + h.rr.bc_len);
+                    if (h.rr.umi_len != VTX_TAG_MISSING) b1 = std::max(b1, h.toff + h.rr.umi_off + h.rr.umi_len);
+                }
+            }
+            if (a1 - std::min(a0, a1) > limit || b1 - std::min(b0, b1) > limit || l_begin[l + 1] - l_begin[l] > 0x7fffffffull)
+                return fail(VTX_E_UNSUPPORTED, "locus %zu alone needs more than %llu bytes of reads", l, (unsigned long long)limit);
+            const uint64_t nr0 = std::min(rlo, a0), nr1 = std::max(rhi, a1), nt0 = std::min(tlo, b0), nt1 = std::max(thi, b1);
+            const bool fits = (nr1 <= nr0 || nr1 - nr0 <= limit) && (nt1 <= nt0 || nt1 - nt0 <= limit) &&
+                              l_begin[l + 1] - cur.rec0 <= 0x7fffffffull;
+            if (!fits && l > cur.l0) close((uint32_t)l);
+            rlo = std::min(rlo, a0); rhi = std::max(rhi, a1); tlo = std::min(tlo, b0); thi = std::max(thi, b1);
+        }
+        close((uint32_t)nloc);
+    }
     for (size_t l = 0; l < nloc; ++l) {
         const LocusBuild& L = loci[l];
         vtx_locus o{};
-        o.row = L.row; o.rec_begin = l_begin[l]; o.rec_count = l_begin[l + 1] - l_begin[l];
+        o.row = L.row; o.rec_count = (uint32_t)(l_begin[l + 1] - l_begin[l]);
         o.ref_off = (uint32_t)P->hap_arena.size(); o.ref_len = (uint32_t)L.ref_hap.size();
         P->hap_arena += L.ref_hap;
         o.alt_off = (uint32_t)P->hap_arena.size(); o.alt_len = (uint32_t)L.alt_hap.size();
         P->hap_arena += L.alt_hap;
         P->loci.push_back(o);
     }
-    std::vector<uint32_t> cursor(l_begin.begin(), l_begin.end() - 1);
+    if (P->hap_arena.size() > 0xffffffffull) return fail(VTX_E_UNSUPPORTED, "haplotype arena above 4 GiB: split the VCF");
+    std::vector<uint32_t> batch_of(nloc, 0);
+    for (size_t b = 0; b < P->batches.size(); ++b)
+        for (uint32_t l = P->batches[b].l0; l < P->batches[b].l1; ++l) {
+            batch_of[l] = (uint32_t)b;
+            P->loci[l].rec_begin = (uint32_t)(l_begin[l] - P->batches[b].rec0);
+        }
     if (raw) {
-        P->raw_records.resize(all_hits.size());
-        for (const Hit& h : all_hits) P->raw_records[cursor[h.locus]++] = h.rr;
+        P->raw_records.resize(by_locus.size());
+        for (size_t l = 0; l < nloc; ++l) {
+            const vtxh_pack::Batch& B = P->batches[batch_of[l]];
+            for (uint64_t j = l_begin[l]; j < l_begin[l + 1]; ++j) {
+                const Hit& h = by_locus[j];
+                vtx_raw_record rr = h.rr;
+                rr.read_off = (uint32_t)(h.roff - B.rbase);
+                rr.bc_off = (uint32_t)(h.toff + h.rr.bc_off - B.tbase);
+                rr.umi_off = h.rr.umi_len != VTX_TAG_MISSING ? (uint32_t)(h.toff + h.rr.umi_off - B.tbase) : 0u;
+                P->raw_records[j] = rr;
+            }
+        }
         ph.mark("pack");
         *out = P.release();
         return VTX_OK;
     }
     // ---- cooked: UMI ids by first occurrence, then the stable sort by (cell, umi) (:932 + per-cell UMI grouping),
     //      loci in parallel (disjoint output ranges) ----
-    std::vector<Hit> by_locus(all_hits.size());
-    for (const Hit& h : all_hits) by_locus[cursor[h.locus]++] = h;
-    std::vector<Hit>().swap(all_hits);
     P->records.resize(by_locus.size());
     {
         std::atomic<size_t> next_locus{0};
@@ -845,12 +907,13 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             std::vector<LocusBuild::Rec> recs;
             for (size_t l; (l = next_locus.fetch_add(16)) < nloc;)
                 for (size_t ll = l; ll < std::min(nloc, l + 16); ++ll) {
+                    const uint64_t rbase = P->batches[batch_of[ll]].rbase;
                     umi_ids.clear(); recs.clear();
-                    for (uint32_t j = l_begin[ll]; j < l_begin[ll + 1]; ++j) {
+                    for (uint64_t j = l_begin[ll]; j < l_begin[ll + 1]; ++j) {
                         const Hit& h = by_locus[j];
                         uint32_t uid = 0;     // without --umi every read carries the same dummy UMI (:890-894)
-                        if (a->use_umi) uid = umi_ids.emplace(tag_store.substr(h.rr.umi_off, h.rr.umi_len), (uint32_t)umi_ids.size()).first->second;
-                        recs.push_back(LocusBuild::Rec{h.cell, uid, h.rr.read_off, h.rr.read_len});
+                        if (a->use_umi) uid = umi_ids.emplace(tag_store.substr(h.toff + h.rr.umi_off, h.rr.umi_len), (uint32_t)umi_ids.size()).first->second;
+                        recs.push_back(LocusBuild::Rec{h.cell, uid, h.roff - rbase, h.rr.read_len});
                     }
                     std::stable_sort(recs.begin(), recs.end(), [](const LocusBuild::Rec& x, const LocusBuild::Rec& y) {
                         return x.cell != y.cell ? x.cell < y.cell : x.umi < y.umi;

@@ -16,7 +16,8 @@ CLI_PATH = os.path.join(_HERE, "bin", "vartrix")
 
 SYMBOLS = ("vtxh_pack_files", "vtxh_free", "vtxh_last_error", "vtxh_get_batch", "vtxh_get_metrics",
            "vtxh_num_variants", "vtxh_num_barcodes", "vtxh_variant_name", "vtxh_barcode", "vtxh_write_mtx",
-           "vtxh_format_f64", "vtxh_pack_files_raw", "vtxh_get_raw_batch", "vtxh_get_barcode_table")
+           "vtxh_format_f64", "vtxh_pack_files_raw", "vtxh_get_raw_batch", "vtxh_get_barcode_table", "vtxh_num_batches",
+           "vtxh_get_batch_at", "vtxh_get_raw_batch_at")
 METRIC_NAMES = ("num_reads", "num_low_mapq", "num_non_primary", "num_duplicates", "num_not_cell_bc",
                 "num_not_useful", "num_non_umi", "num_invalid_recs", "num_multiallelic_recs")
 
@@ -47,6 +48,10 @@ def load():
         L.vtxh_pack_files_raw.argtypes = [C.POINTER(VtxhArgs), C.POINTER(C.c_void_p)]
         L.vtxh_get_raw_batch.argtypes = [C.c_void_p, C.POINTER(abi.VtxRawBatch)]
         L.vtxh_get_barcode_table.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
+        L.vtxh_num_batches.restype = C.c_uint32
+        L.vtxh_num_batches.argtypes = [C.c_void_p]
+        L.vtxh_get_batch_at.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.VtxBatch)]
+        L.vtxh_get_raw_batch_at.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.VtxRawBatch)]
         L.vtxh_free.argtypes = [C.c_void_p]
         L.vtxh_last_error.restype = C.c_char_p
         L.vtxh_get_batch.argtypes = [C.c_void_p, C.POINTER(abi.VtxBatch)]
@@ -72,9 +77,11 @@ class HostError(RuntimeError):
 
 
 def pack_files(vcf, bam, fasta, cell_barcodes, padding=100, mapq=0, primary_only=False, no_duplicates=False,
-               use_umi=False, bam_tag="CB", valid_chars="ATGCatgc", threads=1, raw=False):
+               use_umi=False, bam_tag="CB", valid_chars="ATGCatgc", threads=1, raw=False, all_batches=False):
     """-> (PackedBatch, metrics dict, n_variants, barcodes list, variant names); with ``raw`` the batch is a
-    RawBatch for ``Context.submit_raw`` (vtxh_pack_files_raw: tags as bytes, BAM order inside a locus)."""
+    RawBatch for ``Context.submit_raw`` (vtxh_pack_files_raw: tags as bytes, BAM order inside a locus).
+    A pack whose reads span more than 4 GiB comes as several batches: ``all_batches`` returns the list of them
+    (loci keep their global row; triplets of the batches are appended in order)."""
     L = load()
     args = VtxhArgs(vcf.encode(), bam.encode(), fasta.encode(), cell_barcodes.encode(), padding, mapq,
                     int(primary_only), int(no_duplicates), int(use_umi), bam_tag.encode(), valid_chars.encode(), threads)
@@ -87,17 +94,23 @@ def pack_files(vcf, bam, fasta, cell_barcodes, padding=100, mapq=0, primary_only
             if not n:
                 return np.zeros(0, dt)
             return np.frombuffer(C.string_at(ptr, n * np.dtype(dt).itemsize), dtype=dt).copy()
-        if raw:
-            b = abi.VtxRawBatch()
-            L.vtxh_get_raw_batch(h, C.byref(b))
-            batch = abi.RawBatch(arr(b.loci, b.n_loci, abi.LOCUS_DTYPE), arr(b.records, b.n_records, abi.RAW_RECORD_DTYPE),
-                                 arr(b.hap_arena, b.hap_bytes, np.uint8), arr(b.read_arena, b.read_bytes, np.uint8),
-                                 arr(b.tag_arena, b.tag_bytes, np.uint8))
-        else:
-            b = abi.VtxBatch()
-            L.vtxh_get_batch(h, C.byref(b))
-            batch = abi.PackedBatch(arr(b.loci, b.n_loci, abi.LOCUS_DTYPE), arr(b.records, b.n_records, abi.RECORD_DTYPE),
-                                    arr(b.hap_arena, b.hap_bytes, np.uint8), arr(b.read_arena, b.read_bytes, np.uint8))
+        nb_batches = L.vtxh_num_batches(h)
+        if nb_batches != 1 and not all_batches:
+            raise HostError("the pack has %d batches: call pack_files(..., all_batches=True)" % nb_batches)
+        batches = []
+        for i in range(nb_batches):
+            if raw:
+                b = abi.VtxRawBatch()
+                L.vtxh_get_raw_batch_at(h, i, C.byref(b))
+                batches.append(abi.RawBatch(arr(b.loci, b.n_loci, abi.LOCUS_DTYPE), arr(b.records, b.n_records, abi.RAW_RECORD_DTYPE),
+                                            arr(b.hap_arena, b.hap_bytes, np.uint8), arr(b.read_arena, b.read_bytes, np.uint8),
+                                            arr(b.tag_arena, b.tag_bytes, np.uint8)))
+            else:
+                b = abi.VtxBatch()
+                L.vtxh_get_batch_at(h, i, C.byref(b))
+                batches.append(abi.PackedBatch(arr(b.loci, b.n_loci, abi.LOCUS_DTYPE), arr(b.records, b.n_records, abi.RECORD_DTYPE),
+                                               arr(b.hap_arena, b.hap_bytes, np.uint8), arr(b.read_arena, b.read_bytes, np.uint8)))
+        batch = batches if all_batches else batches[0]
         m = VtxhMetrics()
         L.vtxh_get_metrics(h, C.byref(m))
         metrics = {n: int(getattr(m, n)) for n in METRIC_NAMES}
