@@ -415,3 +415,33 @@ def test_dp_kernel_modes_by_haplotype_length_and_depth(aligner, padding, reads_p
     batch = synth.make_batch(spec)
     cfg = default_config(aligner=aligner, scoring_mode="coverage", n_barcodes=spec.n_barcodes)
     assert_same(batch, cfg, threads=os.cpu_count() or 8)
+
+
+def test_banded_stage_in_many_chunks():
+    """The band kernels process the tasks in chunks sized from the free HBM (one chunk for the benchmark); with the chunk
+    forced down to 3000 tasks the banded stage runs dozens of chunks — scores and hard-task count must not change."""
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np
+from vartrix_amd import lib, synth
+from vartrix_amd.abi import default_config
+spec = synth.SynthSpec(n_loci=150, n_barcodes=60, reads_per_locus=120, read_len=130, padding=90, indel_frac=0.4, sub_error=0.04,
+                       read_len_jitter=30, seed=77)
+batch = synth.make_batch(spec)
+with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=60)) as ctx:
+    ctx.submit(batch); ctx.run()
+    r, a = ctx.fetch_scores()
+    hard = ctx.timing().hard_tasks
+np.save(OUT, np.concatenate([r, a, [hard]]))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for name, env in (("one", {}), ("many", {"VTX_BAND_CHUNK": "3000"})):
+        path = "/tmp/vtx_chunk_%s_%d.npy" % (name, os.getpid())
+        p = subprocess.run([sys.executable, "-c", code.replace("OUT", repr(path))], env=dict(os.environ, PYTHONPATH=root, **env),
+                           cwd=root, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[name] = np.load(path)
+        os.remove(path)
+    assert res["one"][-1] > 100 and np.array_equal(res["one"], res["many"])

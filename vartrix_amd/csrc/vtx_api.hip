@@ -664,7 +664,19 @@ int vtx_run(vtx_ctx* c) {
         // hard scores.  Tasks the fast kernel cannot hold accumulate in ONE overflow list that the general
         // band kernel processes after the last chunk (a launch of a handful of serial lanes costs ~2 ms).
         const uint64_t n_tasks = 2ull * nr;
-        const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_tasks, 1u << 24);
+        // tasks per band-kernel launch: the per-task log / band-slot buffers cost ~1.3 KB per task of the chunk, so the
+        // chunk is as large as a third of the free HBM allows (config 3: one launch instead of three)
+        uint64_t chunk_cap = 1u << 24;
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const uint64_t per_task = 64 * 2 * 4 + 2ull * (((c->max_hap_len + 2 + 7) & ~7u)) * 2 + 4;
+                const uint64_t have = (uint64_t)free_b + c->d_band_ws.cap + c->d_band.cap + c->d_hard.cap;
+                chunk_cap = std::max<uint64_t>(chunk_cap, std::min<uint64_t>(1u << 27, have / 3 / per_task));
+            }
+        }
+        if (getenv("VTX_BAND_CHUNK")) chunk_cap = std::max<uint64_t>(256, strtoull(getenv("VTX_BAND_CHUNK"), nullptr, 10));   // test hook
+        const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_tasks, chunk_cap);
         const uint32_t band_stride = (c->max_hap_len + 2 + 7) & ~7u;
         uint32_t fast_overflow = 0;
         HIP_TRY(c, c->d_band_ws.reserve((size_t)chunk * 64 * 2 * sizeof(uint32_t)));   // jump log of the fast kernel (LG entries per task)
