@@ -121,3 +121,35 @@ def test_config5_shape_against_oracle(aligner):
         parts.append(run(sub, cfg)[2])
     for k in ("row", "col", "alt", "ref", "unk"):
         assert np.array_equal(np.concatenate([p[k] for p in parts]), coo[k]), k
+
+
+def test_config4_shape_many_barcodes():
+    """BASELINE.json configs[3] at reduced size: 50 k barcodes (matrix columns up to 49 999), rows sharded in 8 and
+    concatenated — through the host-prepared and the device-prepared submit paths, against the oracle."""
+    import os
+    from oracle import prep
+    from vartrix_amd import shard
+    spec = synth.SynthSpec(n_loci=1600, n_barcodes=50_000, reads_per_locus=64, seed=44)
+    batch = synth.make_batch(spec)
+    cfg = default_config(aligner="banded", scoring_mode="consensus", n_barcodes=spec.n_barcodes)
+    ref, alt, coo = run(batch, cfg)
+    oref, oalt = oracle.batch_scores(batch, cfg, threads=os.cpu_count() or 8)
+    ocoo = oracle.batch_reduce(batch, cfg, oref, oalt)
+    assert np.array_equal(ref, oref) and np.array_equal(alt, oalt)
+    for k in ("row", "col", "alt", "ref", "unk", "value"):
+        assert np.array_equal(coo[k], ocoo[k]), k
+    assert coo["col"].max() > 49_000
+    parts = [run(batch.slice_loci(lo, hi), cfg)[2] for lo, hi in shard.partition_loci(batch, 8)]
+    for k in ("row", "col", "value"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), coo[k]), k
+    raw, barcodes = synth.make_raw(batch, spec.n_barcodes, False, seed=3)
+    with lib.Context(default_config(aligner="banded", scoring_mode="consensus", n_barcodes=len(barcodes))) as ctx:
+        ctx.set_barcodes(barcodes)
+        st = ctx.submit_raw(raw)
+        ctx.run()
+        rcoo = ctx.fetch_coo()
+    want, wst = prep.prep_raw(raw, barcodes, False)
+    assert int(st.kept) == want.n_records and int(st.num_not_cell_bc) == wst["num_not_cell_bc"]
+    wcoo = run(want, cfg)[2]
+    for k in ("row", "col", "value"):
+        assert np.array_equal(rcoo[k], wcoo[k]), k
