@@ -26,7 +26,18 @@ def run(batch, cfg):
 @pytest.mark.parametrize("aligner", ["banded", "full"])
 def test_config2_properties(big, aligner):
     spec, batch = big
-    cfg = default_config(aligner=aligner, scoring_mode="coverage", n_barcodes=spec.n_barcodes)
+    check_properties(spec, batch, aligner, "coverage")
+
+
+def test_config3_full_size_properties():
+    """BASELINE.json configs[2], the configuration the metric is quoted on: 100 k SNV loci x 10 k barcodes, consensus
+    mode, banded aligner — 24.3 M scored reads through the same size-independent properties + the oracle spot check."""
+    spec = synth.config3()
+    check_properties(spec, synth.make_batch(spec), "banded", "consensus", sample=2000)
+
+
+def check_properties(spec, batch, aligner, mode, sample=3000):
+    cfg = default_config(aligner=aligner, scoring_mode=mode, n_barcodes=spec.n_barcodes)
     ref, alt, coo = run(batch, cfg)
     n = batch.n_records
     assert ref.shape == (n,) and ref.min() >= 0 and alt.min() >= 0
@@ -45,14 +56,23 @@ def test_config2_properties(big, aligner):
     key = coo["row"].astype(np.int64) * spec.n_barcodes + coo["col"]
     assert np.all(np.diff(key) > 0)
     rec_key = np.repeat(batch.loci["row"].astype(np.int64), batch.loci["rec_count"]) * spec.n_barcodes + batch.records["cell_index"]
-    assert len(key) == len(np.unique(rec_key))
-    # coverage mode values are the counts (:1160-1161)
-    assert np.array_equal(coo["value"], coo["alt"].astype(np.float64)) and np.array_equal(coo["ref_value"], coo["ref"].astype(np.float64))
-    # oracle spot check: 3000 random records, bit-exact
+    groups, inv = np.unique(rec_key, return_inverse=True)
+    if mode == "coverage":      # every (locus, cell) group is emitted, explicit zeros included (:1147-1164)
+        assert np.array_equal(key, groups)
+    else:                       # consensus keeps the groups that hold a REF or an ALT call (:1111-1129)
+        g_ref = np.bincount(inv, weights=((ref > alt) & ~none), minlength=len(groups))
+        g_alt = np.bincount(inv, weights=((alt > ref) & ~none), minlength=len(groups))
+        assert np.array_equal(key, groups[(g_ref > 0) | (g_alt > 0)])
+    if mode == "coverage":      # values are the counts (:1160-1161)
+        assert np.array_equal(coo["value"], coo["alt"].astype(np.float64)) and np.array_equal(coo["ref_value"], coo["ref"].astype(np.float64))
+    else:                       # consensus (:1111-1129): 1 ref only, 2 alt only, 3 both; groups without ref/alt calls are dropped
+        want = np.where((coo["ref"] > 0) & (coo["alt"] > 0), 3.0, np.where(coo["alt"] > 0, 2.0, 1.0))
+        assert np.array_equal(coo["value"], want) and np.all((coo["ref"] > 0) | (coo["alt"] > 0))
+    # oracle spot check: random records, bit-exact
     rng = np.random.default_rng(1)
-    pick = np.sort(rng.choice(n, 3000, replace=False))
+    pick = np.sort(rng.choice(n, sample, replace=False))
     rec_locus = np.repeat(np.arange(batch.n_loci), batch.loci["rec_count"])
-    for r in pick[:3000]:
+    for r in pick:
         rec = batch.records[r]
         loc = batch.loci[rec_locus[r]]
         read = bytes(batch.read_arena[rec["read_off"]:rec["read_off"] + rec["read_len"]])
