@@ -51,7 +51,9 @@ def check_properties(spec, batch, aligner, mode, sample=3000):
     calls_ref = int(((ref > alt) & ~none).sum())
     calls_alt = int(((alt > ref) & ~none).sum())
     calls_unk = int(((alt == ref) & ~none).sum())
-    assert (int(coo["ref"].sum()), int(coo["alt"].sum()), int(coo["unk"].sum())) == (calls_ref, calls_alt, calls_unk)
+    assert (int(coo["ref"].sum()), int(coo["alt"].sum())) == (calls_ref, calls_alt)
+    if mode == "coverage":      # consensus drops the groups that hold only UNKNOWN calls, their counts go with them (below)
+        assert int(coo["unk"].sum()) == calls_unk
     # one triplet per (locus, cell) group, in merge-loop order (row asc, then col asc)
     key = coo["row"].astype(np.int64) * spec.n_barcodes + coo["col"]
     assert np.all(np.diff(key) > 0)
@@ -62,7 +64,11 @@ def check_properties(spec, batch, aligner, mode, sample=3000):
     else:                       # consensus keeps the groups that hold a REF or an ALT call (:1111-1129)
         g_ref = np.bincount(inv, weights=((ref > alt) & ~none), minlength=len(groups))
         g_alt = np.bincount(inv, weights=((alt > ref) & ~none), minlength=len(groups))
-        assert np.array_equal(key, groups[(g_ref > 0) | (g_alt > 0)])
+        g_unk = np.bincount(inv, weights=((alt == ref) & ~none), minlength=len(groups))
+        kept = (g_ref > 0) | (g_alt > 0)
+        assert np.array_equal(key, groups[kept])
+        assert np.array_equal(coo["ref"], g_ref[kept].astype(np.uint32)) and np.array_equal(coo["alt"], g_alt[kept].astype(np.uint32))
+        assert np.array_equal(coo["unk"], g_unk[kept].astype(np.uint32))
     if mode == "coverage":      # values are the counts (:1160-1161)
         assert np.array_equal(coo["value"], coo["alt"].astype(np.float64)) and np.array_equal(coo["ref_value"], coo["ref"].astype(np.float64))
     else:                       # consensus (:1111-1129): 1 ref only, 2 alt only, 3 both; groups without ref/alt calls are dropped
