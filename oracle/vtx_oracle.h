@@ -123,6 +123,15 @@ void vtxo_construct_haplotypes(const uint8_t* contig, int64_t contig_len,
  * (src/main.rs:381).  buf needs >= 32 bytes.  Returns length.                 */
 int vtxo_format_f64(double v, char* buf);
 
+/* ---- vtx_certify.c: CPU restatement of the device's DP-free certificate (lower bound = score of the
+ * chain's anchor staircase, upper bound = chain of exact-match runs); see the proof in that file.   */
+int32_t vtxo_chain_cert(const uint8_t* x, int m, const uint8_t* y, int n, int k);
+int vtxo_join_same(int D);
+int32_t vtxo_runs_ub_exact(const uint8_t* x, int m, const uint8_t* y, int n, int k);
+int32_t vtxo_runs_ub(const uint8_t* x, int m, const uint8_t* y, int n, int k, int* passes_out, int* npieces_out);
+int vtxo_batch_certify(const vtx_batch* b, const vtx_config* cfg, int32_t* full, int32_t* banded, int32_t* cert,
+                       int32_t* ub_exact, int32_t* ub, int32_t* passes, int32_t* npieces, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,159 @@
+"""The DP-free certificate of the banded flavour, restated on the CPU (oracle/vtx_certify.c).
+
+The device decides an alignment without a DP when the score of the chain's anchor staircase (a lower bound of the
+banded score) equals the chain-of-exact-match-runs bound (an upper bound of the full-matrix score).  These tests pin
+the two inequalities the argument rests on, against the oracle's own full / banded aligners:
+    cert <= banded <= full <= ub_exact <= ub
+on clean, noisy, indel-rich and repeat-rich inputs.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from vartrix_amd import synth
+from vartrix_amd.abi import default_config
+
+
+def certify(batch, cfg, threads=8, exact=True):
+    L = oracle.lib()
+    n = 2 * batch.n_records
+    keys = ("full", "banded", "cert", "ub_exact", "ub", "passes", "pieces")
+    arrs = {k: np.zeros(n, np.int32) for k in keys}
+    st = batch.as_struct()
+    L.vtxo_batch_certify.restype = C.c_int
+    args = [C.c_void_p(arrs[k].ctypes.data) if (exact or k != "ub_exact") else C.c_void_p(0) for k in keys]
+    assert L.vtxo_batch_certify(C.byref(st), C.byref(cfg), *args, C.c_int(threads)) == 0
+    return arrs
+
+
+def check(r, exact=True):
+    has = r["cert"] >= 0
+    assert np.all(r["banded"] <= r["full"])
+    assert np.all(r["cert"][has] <= r["banded"][has])
+    assert np.all(r["ub"] >= r["full"])
+    if exact:
+        assert np.all(r["ub_exact"] >= r["full"])
+        assert np.all(r["ub"] >= r["ub_exact"])
+    # no k-mer match: Band::full_matrix, and an alignment without a run of 6 matches scores <= 5
+    assert np.all(r["full"][~has] <= 5) and np.all(r["banded"][~has] == r["full"][~has])
+    dec = has & (r["cert"] == r["ub"])
+    assert np.all(r["banded"][dec] == r["cert"][dec]) and np.all(r["full"][dec] == r["cert"][dec])
+    return float(dec.mean())
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),                                                   # config-2/3 shape: SNVs, 0.5 % substitutions
+    dict(indel_frac=0.5, read_len_jitter=100, seed=11),       # config-5 shape
+    dict(indel_frac=0.3, sub_error=0.03, seed=5),
+    dict(sub_error=0.08, seed=7),
+    dict(read_len=60, padding=40, sub_error=0.02, indel_frac=0.4, seed=3),
+])
+def test_bounds_on_synthetic_batches(kw):
+    spec = synth.SynthSpec(n_loci=40, n_barcodes=100, reads_per_locus=40, **kw)
+    batch = synth.make_batch(spec)
+    cfg = default_config(aligner="banded", n_barcodes=100)
+    frac = check(certify(batch, cfg, threads=os.cpu_count() or 8))
+    if not kw:
+        assert frac > 0.98      # clean SNV reads: the certificate decides nearly everything
+
+
+def _manual_batch(haps, reads_per_locus):
+    from vartrix_amd.abi import LOCUS_DTYPE, RECORD_DTYPE, PackedBatch
+    loci, recs, hb, rb = [], [], bytearray(), bytearray()
+    for i, ((ref, alt), reads) in enumerate(zip(haps, reads_per_locus)):
+        begin = len(recs)
+        for cell, seq in enumerate(reads):
+            recs.append((len(rb), len(seq), cell, 0))
+            rb += seq
+        loci.append((i, begin, len(recs) - begin, len(hb), len(ref), len(hb) + len(ref), len(alt), 0))
+        hb += ref + alt
+    return PackedBatch(np.array(loci, LOCUS_DTYPE).reshape(-1), np.array(recs, RECORD_DTYPE).reshape(-1),
+                       np.frombuffer(bytes(hb), np.uint8), np.frombuffer(bytes(rb), np.uint8))
+
+
+def test_bounds_on_repeats_and_short_sequences():
+    """Tandem repeats / homopolymers (many overlapping diagonals, chains that hop between them), reads with
+    N, reads shorter than a k-mer, reads equal to the haplotype."""
+    rng = np.random.default_rng(5)
+    units = [b"A", b"AC", b"AAT", b"ACGT", b"AAAAC", b"AG", b"T", b"CAG"]
+    g = bytearray()
+    while len(g) < 6000:
+        u = units[int(rng.integers(0, len(units)))]
+        g += u * int(rng.integers(3, 30))
+        g += bytes(rng.choice(list(b"ACGT"), int(rng.integers(5, 40))).tolist())
+    g = bytes(g)
+    haps, reads = [], []
+    for i in range(30):
+        p = int(rng.integers(200, len(g) - 400))
+        ref = g[p:p + 161]
+        alt = ref[:80] + bytes([b"ACGT"[(b"ACGT".index(ref[80:81]) + 1) % 4]]) + ref[81:]
+        if i % 3 == 0:
+            alt = ref[:80] + ref[80 + int(rng.integers(1, 15)):]
+        rl = []
+        for k in range(12):
+            o = int(rng.integers(-30, 60))
+            rd = bytearray(g[p + o:p + o + int(rng.integers(20, 120))])
+            for _ in range(int(rng.integers(0, 4))):
+                if rd:
+                    rd[int(rng.integers(0, len(rd)))] = b"ACGTN"[int(rng.integers(0, 5))]
+            if k == 0 and len(rd) > 30:
+                del rd[10:10 + int(rng.integers(1, 12))]
+            rl.append(bytes(rd))
+        rl += [b"ACG", b"", ref, b"N" * 40]
+        haps.append((ref, alt))
+        reads.append(rl)
+    batch = _manual_batch(haps, reads)
+    cfg = default_config(aligner="banded", n_barcodes=64)
+    check(certify(batch, cfg, threads=os.cpu_count() or 8))
+
+
+def test_join_cost_table():
+    """J_same(D): the cheapest way to get from one exact-match run to the next one D bases further on the same
+    diagonal, computed here by brute force over (mismatches, gaps) and compared with the closed form."""
+    L = oracle.lib()
+    L.vtxo_join_same.restype = C.c_int
+    for D in range(1, 60):
+        # gap-free: e mismatches and D - e matches in e - 1 runs of <= 5
+        best = min(6 * e - D for e in range(1, D + 1) if D - e <= 5 * (e - 1))
+        # with gaps: >= 2 gaps (total insertion = total deletion = G >= 1), D - G diagonal columns all matches
+        gap = min([10 + 3 * G - D for G in range(1, D + 1)] + [10 ** 6])
+        gap = max(gap, 7)
+        assert L.vtxo_join_same(D) == min(best, gap), D
+
+
+def test_bounds_on_random_low_entropy_strings():
+    """Adversarial for the upper bound: two- and three-letter alphabets make exact-match runs on many diagonals
+    at once, so chains that hop diagonals, re-enter pieces half way and reuse overlapping pieces all occur."""
+    rng = np.random.default_rng(2026)
+    haps, reads = [], []
+    for i in range(60):
+        alpha = [b"AC", b"ACG", b"AT"][i % 3]
+        n = int(rng.integers(12, 70))
+        y = bytes(rng.choice(list(alpha), n).tolist())
+        y2 = bytes(rng.choice(list(alpha), n + int(rng.integers(0, 9))).tolist())
+        rl = []
+        for k in range(40):
+            m = int(rng.integers(6, 60))
+            if k % 4 == 0:      # a mutated substring of y: long runs with nearby mismatches / small indels
+                o = int(rng.integers(0, max(1, n - 8)))
+                rd = bytearray(y[o:o + m])
+                for _ in range(int(rng.integers(0, 5))):
+                    if len(rd) > 2:
+                        q = int(rng.integers(0, len(rd)))
+                        if rng.random() < 0.5:
+                            rd[q] = alpha[int(rng.integers(0, len(alpha)))]
+                        elif rng.random() < 0.5:
+                            del rd[q]
+                        else:
+                            rd.insert(q, alpha[int(rng.integers(0, len(alpha)))])
+                rl.append(bytes(rd))
+            else:
+                rl.append(bytes(rng.choice(list(alpha), m).tolist()))
+        haps.append((y, y2))
+        reads.append(rl)
+    batch = _manual_batch(haps, reads)
+    cfg = default_config(aligner="banded", n_barcodes=64)
+    check(certify(batch, cfg, threads=os.cpu_count() or 8))

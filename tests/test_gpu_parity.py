@@ -232,10 +232,10 @@ def test_reference_fixtures_on_device(golden_dir, case, aligner):
         assert {(int(r), int(c)): float(v) for r, c, v in zip(coo["row"], coo["col"], coo["ref_value"])} == want
 
 
-def test_alternative_band_kernel_agrees(tmp_path):
-    """The streaming band kernel (VTX_BAND_KERNEL=stream) and the default run-level one are two
-    implementations of the same chain DP: same scores on an indel batch (separate process: the choice
-    is read once per process)."""
+def test_band_kernel_table_sizes_agree(tmp_path):
+    """The k-mer table geometry of band_run_kernel (VTX_BAND_HEADS: 256 / 512 / 2048-entry head arrays, hence
+    different chain lengths, loci per pass and probe orders inside a bucket) must not change any score
+    (separate processes: the knob is read per launch from the environment of the process)."""
     import subprocess
     import sys
     code = '''
@@ -250,16 +250,34 @@ with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_bar
 np.save(sys.argv[1], np.stack([r, a]))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for kern in ("run", "stream"):
-        out = str(tmp_path / (kern + ".npy"))
-        env = dict(os.environ, VTX_BAND_KERNEL=kern)
+    for heads in ("256", "512", "2048"):
+        out = str(tmp_path / (heads + ".npy"))
+        env = dict(os.environ, VTX_BAND_HEADS=heads)
         subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
         outs.append(np.load(out))
-    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     spec = synth.SynthSpec(n_loci=200, n_barcodes=100, reads_per_locus=40, indel_frac=0.5, read_len_jitter=50, seed=5, sub_error=0.02)
     batch = synth.make_batch(spec)
     oref, oalt = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=100), threads=8)
     assert np.array_equal(outs[0][0], oref) and np.array_equal(outs[0][1], oalt)
+
+
+def test_certificate_decides_most_clean_alignments():
+    """The DP-free certificate (cert == ub, vtx_band.hip) must leave only a small residue of a clean SNV workload
+    to the band-masked DP — and whatever it decides must equal the oracle's banded score."""
+    spec = synth.SynthSpec(n_loci=400, n_barcodes=300, reads_per_locus=64, seed=31)
+    batch = synth.make_batch(spec)
+    cfg = default_config(aligner="banded", scoring_mode="consensus", n_barcodes=spec.n_barcodes)
+    with lib.Context(cfg) as ctx:
+        ctx.submit(batch)
+        ctx.run()
+        ref, alt = ctx.fetch_scores()
+        hard = ctx.timing().hard_tasks
+    oref, oalt = oracle.batch_scores(batch, cfg, threads=os.cpu_count() or 8)
+    assert np.array_equal(ref, oref) and np.array_equal(alt, oalt)
+    frac = hard / (2.0 * batch.n_records)
+    print("hard fraction %.4f" % frac)
+    assert frac < 0.08
 
 
 @pytest.mark.parametrize("seed,sub_error,indel_frac,read_len,padding", [

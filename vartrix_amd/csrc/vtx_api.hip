@@ -614,9 +614,11 @@ int vtx_run(vtx_ctx* c) {
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     uint32_t launches = 0;
     bool any_lut = false;
+    const bool full_dp = c->cfg.aligner != VTX_ALIGNER_BANDED;      // the banded flavour never runs the full-matrix DP
     for (const Bucket& bk : c->buckets) any_lut |= bk.lut || bk.duo;
+    any_lut &= full_dp;
     if (any_lut) HIP_TRY(c, hipMemsetAsync(c->d_redo_cnt.p, 0, 16 * sizeof(uint32_t), s));
-    for (size_t b = 0; b < c->buckets.size(); ++b) {
+    for (size_t b = 0; full_dp && b < c->buckets.size(); ++b) {
         const Bucket& bk = c->buckets[b];
         static const bool no_duo = getenv("VTX_DP_KERNEL") && !strcmp(getenv("VTX_DP_KERNEL"), "lut");
         static const bool no_pair = getenv("VTX_DP_KERNEL") && !strcmp(getenv("VTX_DP_KERNEL"), "duo2");   // two-lookup prefix phase
@@ -659,9 +661,9 @@ int vtx_run(vtx_ctx* c) {
     uint32_t hard_total = 0;
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
     if (c->cfg.aligner == VTX_ALIGNER_BANDED && nr) {
-        // Banded flavour: d_ref / d_alt hold the full scores.  Per chunk of tasks (task = 2*record + hap):
-        // fast band kernel (seed, chain, certificate) -> hard list -> expand -> band-masked DP overwrites the
-        // hard scores.  Tasks the fast kernel cannot hold accumulate in ONE overflow list that the general
+        // Banded flavour.  Per chunk of tasks (task = 2*record + hap): band_run_kernel (seeds, chain, DP-free
+        // certificate: writes the score of every certified task) -> hard list -> expand -> band-masked DP writes
+        // the hard scores.  Tasks band_run_kernel cannot hold accumulate in ONE overflow list that the general
         // band kernel processes after the last chunk (a launch of a handful of serial lanes costs ~2 ms).
         const uint64_t n_tasks = 2ull * nr;
         // tasks per band-kernel launch: the per-task log / band-slot buffers cost ~1.3 KB per task of the chunk, so the
@@ -702,7 +704,7 @@ int vtx_run(vtx_ctx* c) {
         for (uint64_t base = 0; base < n_tasks; base += chunk) {
             const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, n_tasks - base);
             HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), s));                 // hard count of this chunk
-            HIP_TRY(c, vtxk_launch_band_fast(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+            HIP_TRY(c, vtxk_launch_band_run(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                              c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                              c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
                                              c->d_band_ws.as<uint32_t>(), c->d_band.as<uint16_t>(), band_stride,
@@ -716,9 +718,10 @@ int vtx_run(vtx_ctx* c) {
         }
         fast_overflow = cnt[1];
         if (getenv("VTX_DEBUG")) {
-            uint32_t why[8];
+            uint32_t why[11];
             HIP_TRY(c, hipMemcpy(why, d_cnt, sizeof why, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[vtx] fast band kernel overflow reasons: bound=%u parked-full=%u log-full=%u other=%u traceback=%u\n", why[3], why[4], why[5], why[6], why[7]);
+            fprintf(stderr, "[vtx] band_run_kernel: %u tasks hard only because pieces were dropped from a full list\n", why[10]);
+            fprintf(stderr, "[vtx] band_run_kernel overflow reasons: bound=%u parked-full=%u log-full=%u other=%u traceback=%u\n", why[3], why[4], why[5], why[6], why[7]);
         }
         // general kernel (per-task scratch slab) on the accumulated overflow list; slabs grow until every task fits
         for (uint32_t obase = 0; obase < fast_overflow; obase += chunk) {

@@ -2,12 +2,15 @@
 // (bio 0.30.0 banded::Aligner::local as restated in oracle/vtx_oracle.c; reference call site
 // src/main.rs:899-901 with K = 6, W = 20, src/main.rs:33-34).
 //
-//   band_kernel        one lane per (record, haplotype) task: k-mer seeding (chained hash of the
-//                      haplotype 6-mers), sdpkpp chaining (max-Fenwick tree over y, events merged in
-//                      order, tuple tie-breaks), traceback to the anchor polyline, band ranges per
-//                      column in closed form, and the certificate (below).
-//   sw_banded_kernel   the systolic packed-i16 DP of vtx_kernels.hip with per-column row ranges:
-//                      cells outside the band hold "-inf" (G), 0 (Q, E, F) — see the header there.
+//   band_run_kernel    one lane per (record, haplotype) task, k-mer tables of the haplotypes shared in LDS:
+//                      seeding (exact 6-mer matches as diagonal pieces), sdpkpp chaining over the pieces,
+//                      traceback to the anchor staircase, and the DP-FREE CERTIFICATE below.  Certified
+//                      tasks get their score here; the others go to the hard list with their staircase.
+//   band_kernel        general fallback (per-task global scratch, literal Fenwick-tree sdpkpp) for tasks that
+//                      exceed band_run_kernel's capacities; every task it handles goes to the hard list.
+//   band_expand_kernel staircase polyline -> per-column row ranges [lo, hi).
+//   sw_banded_kernel   (vtx_kernels.hip) the systolic packed-i16 DP restricted to those ranges: the exact
+//                      banded score of the hard tasks.
 //
 // Band in closed form.  Every cell the crate adds (set_boundaries' lazy extensions, add_kmer,
 // add_entry for continued k-mers, add_gap) lies on ONE monotone, connected staircase from
@@ -17,11 +20,23 @@
 // for j in [cA - w, cB + w], empty elsewhere.  tests/ check this against the oracle's literal
 // add_entry loops.
 //
-// Certificate.  banded <= full always (the band only removes paths).  The anchor staircase itself
-// is an in-band path, so its local-alignment score (affine gaps along the vertical / horizontal
-// pieces) is a lower bound of the banded score.  If it equals the full score (already computed by
-// sw_full_kernel) the banded score IS the full score and the task is done; otherwise the task is
-// appended to the hard list and sw_banded_kernel computes it exactly.
+// Certificate (no DP).  cert <= banded <= full <= ub, so cert == ub decides the banded score:
+//   cert  the anchor staircase is an in-band path; its local-alignment score (affine gaps along the
+//         vertical / horizontal pieces, free restart at 0) is a lower bound of the banded score.
+//   ub    upper bound of the FULL-matrix score from the exact-match runs of >= K bases (= the diagonal
+//         pieces of k-mer matches the seeding found — all of them).  Write an alignment as maximal runs of
+//         match columns separated by events (mismatch: 5; gap of length L: 5 + L).  A run of >= 6 columns
+//         is a sub-run of a piece.  Between two consecutive long runs there are e >= 1 events and e - 1 short
+//         runs (<= 5 columns each), which net <= 5 (e - 1) - 5 e - sum L = -5 - sum L, and sum L >= the
+//         difference of the two diagonals; the stretches before the first / after the last long run net <= 0;
+//         an alignment without a long run scores <= 5.  So
+//             full <= max(5, max over chains of sub-runs of pieces [ sum len - sum J ]),  J = 5 + |d' - d|,
+//         and between runs of the same diagonal, D >= 1 bases apart: J = min(6 ceil((D + 5) / 6) - D,
+//         max(7, 13 - D)) (gap-free: e mismatches cost 6 e - D; with gaps: >= 2 gaps, 10 + 3 G - D).
+//         run_ub() maximises this over the piece list (one number per piece, fixpoint over ordered pairs);
+//         oracle/vtx_certify.c restates it on the CPU with the proof in full, tests/ check ub >= full.
+//   Measured on the synthetic workloads: cert == ub for 99.3 % of SNV tasks (0.5 % substitution errors),
+//   97.5-98.7 % with indels <= 20 bp; the rest is scored exactly by the band-masked DP.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -35,6 +50,9 @@
 #define BANDW 20
 #define HASH_BITS 9
 #define HASH_SIZE (1 << HASH_BITS)
+// band slot markers (lo[0]): a staircase polyline follows / the whole matrix is in band
+#define BAND_POLYLINE 0xffffu
+#define BAND_FULL_MATRIX 0xfffeu
 
 struct band_scratch {      // per-task slices of the workspace (all sized by the launch)
     uint16_t* head;        // HASH_SIZE
@@ -216,15 +234,14 @@ __device__ void band_ranges(const band_scratch& sc, int cA, int cB, int m, int n
 }
 
 // One lane per task (task = 2 * record + hap).  tasks == nullptr: task = task_base + slot.
-// ref_score / alt_score hold the FULL scores on entry (sw_full_kernel); certified tasks keep them
-// (banded == full), hard tasks are appended to hard_list with their ranges in band[] and get their
+// Every task is appended to hard_list with its ranges in band[] (or the full-matrix marker) and gets its
 // exact score from sw_banded_kernel.  counters[0] = hard tasks, counters[1] = capacity overflows.
 __global__ __launch_bounds__(64) void band_kernel(
     const uint32_t* __restrict__ tasks, uint32_t n_tasks, uint32_t task_base,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
     uint8_t* __restrict__ workspace, uint64_t ws_stride, uint32_t m_cap, uint32_t max_hap,
-    const int32_t* __restrict__ ref_score, const int32_t* __restrict__ alt_score,
+    int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint16_t* __restrict__ band, uint32_t band_stride, uint32_t* __restrict__ hard_list,
     uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -236,7 +253,7 @@ __global__ __launch_bounds__(64) void band_kernel(
     const uint8_t* x = read_arena + rec.read_off;
     const uint8_t* y = hap_arena + (hap ? loc.alt_off : loc.ref_off);
     const int m = (int)rec.read_len, n = (int)(hap ? loc.alt_len : loc.ref_len);
-    if (m == 0 || n == 0) return;                    // score 0 either way
+    if (m == 0 || n == 0) { (hap ? alt_score : ref_score)[rid] = 0; return; }
     uint8_t* ws = workspace + (uint64_t)slot * ws_stride;
     band_scratch sc;
     size_t o = 0;
@@ -254,11 +271,10 @@ __global__ __launch_bounds__(64) void band_kernel(
     int cA = 0, cB = 0;
     const int rc = band_task(x, m, y, n, sc, m_cap, &cert, &cA, &cB);
     if (rc) { overflow_list[atomicAdd(&counters[1], 1u)] = task; return; }
-    const int32_t full = hap ? alt_score[rid] : ref_score[rid];
-    if (cert == INT32_MAX || cert == full) return;   // banded == full
     const uint32_t h = atomicAdd(&counters[0], 1u);
     hard_list[h] = task;
     uint16_t* lo = band + (size_t)h * 2 * band_stride;
+    if (cert == INT32_MAX) { lo[0] = BAND_FULL_MATRIX; return; }   // no k-mer match: Band::full_matrix
     band_ranges(sc, cA, cB, m, n, lo, lo + band_stride);
 }
 
@@ -282,45 +298,12 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
     return hipGetLastError();
 }
 
-// =============================================================================================
-// band_fast_kernel — the common-case band kernel: one lane per task, STREAMING over read rows.
-//
-// Same results as band_kernel (sdpkpp chain -> staircase -> certificate), restructured so the
-// per-lane state is a few registers + 24 LDS words instead of a per-task global scratch slab:
-//   * haplotype k-mer tables (48-bit k-mer words, chained hash with ascending-y chains, raw bytes)
-//     are built ONCE per (locus, haplotype) per workgroup in LDS and shared by its tasks;
-//   * sdpkpp needs, at a match (x, y), max (V, idx) over matches that ENDED at (<= x, <= y).  Matches
-//     are kept as SEGMENTS — linear pieces of diagonal runs (id0, dp0, len) — whose element u ends
-//     at (x0+u+K, y0+u+K) with V = V0 + 3u, so a segment's best candidate for any query is closed
-//     form, u* = min(len-1, x-x0-K, y-y0-K): descriptors are immutable except `len`, there is no
-//     per-row maintenance, and the LCSk++ continuation is a register compare;
-//   * a continuing k-mer skips the query when an upper bound (largest V of any other segment)
-//     cannot beat the continuation; only segment starts (chain starts, jumps, breakpoints) query
-//     all segments and are logged (global memory) — the traceback hops through that log, so the
-//     chain comes out as a few diagonal segments;
-//   * the certificate walk adds +1 per k-mer cell without touching bytes (k-mer cells are exact
-//     matches), bytes are compared only in gap diagonals and the lazy extensions.
-// Any capacity overflow (parked segments, log, chain segments) sends the task to band_kernel via
-// overflow_list: results never depend on which kernel handled a task.
-// Hard tasks get a polyline (vertex list) in their band slot, flagged 0xffff; band_expand_kernel
-// turns it into the lo / hi arrays sw_banded_kernel reads.
-// =============================================================================================
-#define PS 14       // per-lane LDS entries: parked segments (band_fast_kernel) / pieces + segments (band_run_kernel)
+#define PS 14       // per-lane LDS entries of band_run_kernel: pieces + segments
 #define LG 64       // jump-log entries per task (global)
 #define SG 10       // chain segments per task
-#define TB_HEADS 2048
 #define NONE_ID 0xffffffffu
 
-struct hap_table {
-    uint32_t n;
-    const uint32_t* kwlo;   // low 32 bits of the 48-bit k-mer word at y
-    const uint16_t* kwhi;   // high 16 bits
-    const uint16_t* next;   // chain (ascending y), 0xffff ends
-    const uint16_t* head;   // TB_HEADS
-    const uint8_t* bytes;   // raw haplotype bytes
-};
-
-__device__ __forceinline__ uint32_t kw_hash(uint32_t lo, uint32_t hi, uint32_t head_mask = TB_HEADS - 1) {
+__device__ __forceinline__ uint32_t kw_hash(uint32_t lo, uint32_t hi, uint32_t head_mask) {
     uint32_t h = lo * 0x9E3779B1u ^ (hi + 0x7F4A7C15u) * 0x85EBCA77u;
     return (h >> 18) & head_mask;
 }
@@ -329,16 +312,13 @@ static size_t band_table_stride(uint32_t max_hap, uint32_t n_heads) {
     size_t o = (size_t)max_hap * 4 + (size_t)max_hap * 2 * 2 + (size_t)n_heads * 2 + ((size_t)max_hap + 8);
     return (o + 15) & ~(size_t)15;
 }
-extern "C" size_t vtxk_band_table_stride(uint32_t max_hap) {
-    size_t o = (size_t)max_hap * 4 + (size_t)max_hap * 2 * 2 + TB_HEADS * 2 + ((size_t)max_hap + 8);
-    return (o + 15) & ~(size_t)15;
-}
 
-// Shared tail of the streaming band kernels: traceback through the jump log (chain = a few diagonal
-// segments), walk of the anchor staircase (certificate), polyline for hard tasks.
-// Returns 0: certified (banded == full); 1: hard (verts / *nv_out filled); 2: capacity exceeded.
+// Tail of band_run_kernel: traceback through the jump log (chain = a few diagonal segments), walk of
+// the anchor staircase (its local score = the lower bound `cert`), polyline for hard tasks.
+// Returns 0: certified (cert == ub, so banded == full == ub); 1: hard (verts / *nv_out filled);
+// 2: capacity exceeded.
 __device__ int band_finish(const uint32_t* mylog, uint32_t lg_n, uint32_t best_id, const uint8_t* x,
-                           const uint8_t* yb, uint32_t m, uint32_t n, int32_t full, uint32_t* verts_out,
+                           const uint8_t* yb, uint32_t m, uint32_t n, int32_t ub, uint32_t* verts_out,
                            uint32_t* nv_out) {
         // ---- traceback through the jump log: chain = diagonal segments (x0, y0, len), last first ----
         uint32_t seg_xy[SG], seg_len[SG];
@@ -395,275 +375,9 @@ __device__ int band_finish(const uint32_t* mylog, uint32_t lg_n, uint32_t best_i
         for (int i = 0; i < d1; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
         if (d1 > 0) EMIT();
 #undef EMIT
-        if (w.best == full) return 0;                        // banded == full
+        if (w.best == ub) return 0;                          // cert == ub: banded == full == ub
         *nv_out = nv;
         return 1;
-}
-
-__global__ __launch_bounds__(256) void band_fast_kernel(
-    uint32_t n_tasks, uint32_t task_base,
-    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
-    const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
-    uint32_t max_hap, uint32_t tables_per_pass, uint32_t table_stride,
-    const int32_t* __restrict__ ref_score, const int32_t* __restrict__ alt_score,
-    uint32_t* __restrict__ logbuf, uint16_t* __restrict__ band, uint32_t band_stride,
-    uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters,
-    uint32_t ablate) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int tid = threadIdx.x;
-    // per-lane LDS arrays, element i of lane tid at [i * 256 + tid]
-    // staircase of ended matches, stored as RUNS: elements (ye0 + t, V0 + 3t, id0 + t*(1,1)), t < len
-    // (a continued k-mer adds +1 to ye and, with dp + 1, +3 to V = dp + xe + ye)
-    uint32_t* pm_a = smem;                     // parked segments: id0 = x0 << 16 | y0
-    uint32_t* pm_id = pm_a + PS * 256;         //                  dp0 << 16 | len
-    uint8_t* tables = (uint8_t*)(pm_id + PS * 256);
-#define PM_A(i) pm_a[(i) * 256 + tid]
-#define PM_ID(i) pm_id[(i) * 256 + tid]
-
-    const uint32_t slot = blockIdx.x * 256 + tid;
-    const bool have = slot < n_tasks;
-    const uint32_t task = task_base + slot;
-    uint32_t rid = 0, hap = 0, my_locus = 0, m = 0, n = 0;
-    const uint8_t* x = nullptr;
-    if (have) {
-        rid = task >> 1; hap = task & 1;
-        const vtx_record rec = records[rid];
-        my_locus = rec_locus[rid];
-        m = rec.read_len;
-        x = read_arena + rec.read_off;
-        n = hap ? loci[my_locus].alt_len : loci[my_locus].ref_len;
-    }
-    // locus range of this workgroup (tasks are in record order, records in locus order)
-    const uint32_t first_task = task_base + blockIdx.x * 256;
-    const uint32_t last_task = min(task_base + n_tasks - 1, first_task + 255);
-    const uint32_t l_first = rec_locus[first_task >> 1], l_last = rec_locus[last_task >> 1];
-    const uint32_t loci_per_pass = tables_per_pass / 2;
-    bool done = !have || m == 0 || n == 0;     // empty read / haplotype: score 0 == full
-    uint32_t* mylog = logbuf + (size_t)slot * LG * 2;
-
-    for (uint32_t lbase = l_first; lbase <= l_last; lbase += loci_per_pass) {
-        __syncthreads();
-        // ---- build the haplotype tables of loci [lbase, lbase + loci_per_pass) ----
-        const uint32_t n_tab = min(loci_per_pass, l_last - lbase + 1) * 2;
-        for (uint32_t t = 0; t < n_tab; ++t) {
-            const vtx_locus loc = loci[lbase + (t >> 1)];
-            const uint32_t hn = (t & 1) ? loc.alt_len : loc.ref_len;
-            const uint8_t* hy = hap_arena + ((t & 1) ? loc.alt_off : loc.ref_off);
-            uint8_t* tb = tables + (size_t)t * table_stride;
-            uint32_t* kwlo = (uint32_t*)tb;
-            uint16_t* kwhi = (uint16_t*)(tb + (size_t)max_hap * 4);
-            uint16_t* head = kwhi + 2 * (size_t)max_hap;
-            uint8_t* bytes = (uint8_t*)(head + TB_HEADS);
-            for (uint32_t y = tid; y < hn; y += 256) {
-                bytes[y] = hy[y];
-                if (y + KMER <= hn) {
-                    kwlo[y] = (uint32_t)hy[y] | ((uint32_t)hy[y + 1] << 8) | ((uint32_t)hy[y + 2] << 16) | ((uint32_t)hy[y + 3] << 24);
-                    kwhi[y] = (uint16_t)((uint32_t)hy[y + 4] | ((uint32_t)hy[y + 5] << 8));
-                }
-            }
-            for (uint32_t i = tid; i < TB_HEADS; i += 256) head[i] = 0xffff;
-        }
-        __syncthreads();
-        if ((uint32_t)tid < n_tab) {     // one lane per table: sequential head insertion, descending y => ascending chains
-            const vtx_locus loc = loci[lbase + ((uint32_t)tid >> 1)];
-            const uint32_t hn = (tid & 1) ? loc.alt_len : loc.ref_len;
-            uint8_t* tb = tables + (size_t)tid * table_stride;
-            const uint32_t* kwlo = (const uint32_t*)tb;
-            uint16_t* kwhi = (uint16_t*)(tb + (size_t)max_hap * 4);
-            uint16_t* next = kwhi + max_hap;
-            uint16_t* head = kwhi + 2 * (size_t)max_hap;
-            if (hn >= KMER)
-                for (int y = (int)hn - KMER; y >= 0; --y) {
-                    const uint32_t h = kw_hash(kwlo[y], kwhi[y]);
-                    next[y] = head[h]; head[h] = (uint16_t)y;
-                }
-        }
-        __syncthreads();
-        if (done || my_locus < lbase || my_locus >= lbase + loci_per_pass) continue;
-        done = true;
-        // ---- this lane's table ----
-        const uint8_t* tb = tables + (size_t)((my_locus - lbase) * 2 + hap) * table_stride;
-        const uint32_t* kwlo = (const uint32_t*)tb;
-        const uint16_t* kwhi = (const uint16_t*)(tb + (size_t)max_hap * 4);
-        const uint16_t* next = kwhi + max_hap;
-        const uint16_t* head = kwhi + 2 * (size_t)max_hap;
-        const uint8_t* yb = (const uint8_t*)(head + TB_HEADS);
-        const int32_t full = hap ? alt_score[rid] : ref_score[rid];
-        if (m < KMER || n < KMER) continue;                 // no k-mer: Band::full_matrix, banded == full
-        if (ablate == 1) continue;                           // (profiling aid) table build only
-        if (ablate == 2) {                                   // (profiling aid) probe loop only
-            uint32_t wl = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
-            uint32_t wh = (uint32_t)x[4] | ((uint32_t)x[5] << 8), cntm = 0;
-            for (uint32_t xr = 0; xr + KMER <= m; ++xr) {
-                for (uint32_t y = head[kw_hash(wl, wh)]; y != 0xffff; y = next[y]) cntm += (kwlo[y] == wl && kwhi[y] == (uint16_t)wh);
-                const uint32_t nb = (xr + KMER < m) ? x[xr + KMER] : 0;
-                wl = (wl >> 8) | (wh << 24); wh = ((wh >> 8) & 0xff) | (nb << 8);
-            }
-            if (cntm == 0xffffffffu) counters[7] = cntm;
-            continue;
-        }
-
-        // ---- streaming sdpkpp at SEGMENT level ----
-        // A segment is a linear piece of a diagonal run: matches id0 + u*(1,1), dp = dp0 + u, u < len.
-        // Its element u ends at (x0+u+K, y0+u+K) with V = dp + xe + ye = V0 + 3u, so for a query at
-        // (x, y) the best candidate of a segment is u* = min(len-1, x-x0-K, y-y0-K) in closed form:
-        // descriptors are immutable except for `len`, no per-row maintenance.  Two segments live in
-        // registers (the two most recently extended ones), the rest in an LDS list; segments none of
-        // whose elements can win any more (V + 1 - (x + ye) < K for all of them) are dropped from the
-        // list when it fills up (they stay in the jump log, which is what the traceback reads).
-#define SEG_NONE 0xffffffffu
-        uint32_t a_id0 = SEG_NONE, a_dp0 = 0, a_len = 0;     // slot A
-        uint32_t b_id0 = SEG_NONE, b_dp0 = 0, b_len = 0;     // slot B
-        uint32_t pm_n = 0, lg_n = 0;
-        int32_t vmax_lds = 0;                                 // max V of any element of an LDS segment (upper bound)
-        int32_t best_v = -1; uint32_t best_id = 0;
-        bool overflow = false;
-        uint32_t why = 0;
-        uint32_t wlo = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
-        uint32_t whi = (uint32_t)x[4] | ((uint32_t)x[5] << 8);
-        uint32_t nextb = m > KMER ? x[KMER] : 0;
-        // candidate of one segment for a query at (qx, qy): updates (bV, bid) by tuple order
-#define SEG_QUERY(id0, dp0, len, qx, qy, bV, bid)                                                          \
-        {                                                                                                   \
-            const int32_t sx = (int32_t)((id0) >> 16), sy = (int32_t)((id0) & 0xffff);                       \
-            int32_t u = (int32_t)(len) - 1;                                                                 \
-            u = min(u, (int32_t)(qx) - sx - KMER);                                                          \
-            u = min(u, (int32_t)(qy) - sy - KMER);                                                          \
-            if (u >= 0) {                                                                                   \
-                const int32_t v = (int32_t)(dp0) + sx + sy + 2 * KMER + 3 * u;                               \
-                const uint32_t qid = (id0) + (uint32_t)u * 0x10001u;                                        \
-                if (v > bV || (v == bV && (bid == NONE_ID || qid > bid))) { bV = v; bid = qid; }             \
-            }                                                                                               \
-        }
-        for (uint32_t xr = 0; xr + KMER <= m && !overflow; ++xr) {
-            const uint32_t nextb2 = (xr + KMER + 1 < m) ? x[xr + KMER + 1] : 0;   // prefetch one row ahead
-            for (uint32_t y = head[kw_hash(wlo, whi)]; y != 0xffff; y = next[y]) {
-                if (kwlo[y] != wlo || kwhi[y] != (uint16_t)whi) continue;
-                const uint32_t id = (xr << 16) | y;
-                // which segment (if any) does this match continue?
-                int cont = 0;                                   // 1: slot A, 2: slot B
-                if (a_id0 != SEG_NONE && id == a_id0 + a_len * 0x10001u) cont = 1;
-                else if (b_id0 != SEG_NONE && id == b_id0 + b_len * 0x10001u) cont = 2;
-                if (cont == 2) {                                // keep the segment being extended in slot A
-                    uint32_t t;
-                    t = a_id0; a_id0 = b_id0; b_id0 = t;
-                    t = a_dp0; a_dp0 = b_dp0; b_dp0 = t;
-                    t = a_len; a_len = b_len; b_len = t;
-                    cont = 1;
-                }
-                int32_t cdp = -1;
-                bool need_query = true;
-                if (cont == 1) {
-                    cdp = (int32_t)(a_dp0 + a_len);              // dp of the previous match + 1
-                    // cheap bound: can any OTHER segment's candidate beat the continuation?
-                    int32_t vb = vmax_lds;
-                    if (b_id0 != SEG_NONE && (b_id0 >> 16) + KMER <= xr) {
-                        const int32_t v = (int32_t)b_dp0 + (int32_t)(b_id0 >> 16) + (int32_t)(b_id0 & 0xffff) + 2 * KMER + 3 * ((int32_t)b_len - 1);
-                        vb = max(vb, v);
-                    }
-                    // (own visible elements give dp(t-K) + 1 < dp(t-1) + 1: never win)
-                    if (vb + 1 - (int32_t)(xr + y) <= cdp) need_query = false;
-                } else if (pm_n) {
-                    // maybe it continues a segment parked in LDS (a third diagonal being extended)
-                    for (uint32_t i = 0; i < pm_n; ++i) {
-                        const uint32_t sid = PM_A(i), sdl = PM_ID(i);
-                        if (id == sid + (sdl & 0xffff) * 0x10001u) {
-                            // bring it into slot A; park A (B stays)
-                            const uint32_t pa = a_id0, pd = a_dp0, pl = a_len;
-                            a_id0 = sid; a_dp0 = sdl >> 16; a_len = sdl & 0xffff;
-                            if (pa != SEG_NONE) { PM_A(i) = pa; PM_ID(i) = (pd << 16) | pl; }
-                            else { PM_A(i) = PM_A(pm_n - 1); PM_ID(i) = PM_ID(pm_n - 1); --pm_n; }
-                            cont = 1; cdp = (int32_t)(a_dp0 + a_len);
-                            break;
-                        }
-                    }
-                }
-                int32_t dp = KMER; uint32_t prev = NONE_ID;
-                if (need_query) {
-                    int32_t bV = INT32_MIN; uint32_t bid = NONE_ID;
-                    if (a_id0 != SEG_NONE) SEG_QUERY(a_id0, a_dp0, a_len, xr, y, bV, bid)
-                    if (b_id0 != SEG_NONE) SEG_QUERY(b_id0, b_dp0, b_len, xr, y, bV, bid)
-                    for (uint32_t i = 0; i < pm_n; ++i) {
-                        const uint32_t sid = PM_A(i), sdl = PM_ID(i);
-                        SEG_QUERY(sid, (sdl >> 16), (sdl & 0xffff), xr, y, bV, bid)
-                    }
-                    if (bid != NONE_ID) {
-                        const int32_t cand = bV - 5 - (int32_t)(xr + y) + KMER;
-                        if (cand >= dp) { dp = cand; prev = bid; }
-                    }
-                }
-                if (cont == 1 && cdp >= dp) {
-                    ++a_len;                                     // plain continuation (ties: continuation wins)
-                    dp = cdp;
-                } else {
-                    // a new segment starts here (fresh start, jump, or a breakpoint inside a run)
-                    if (lg_n == LG) { overflow = true; why = 3; break; }
-                    mylog[2 * lg_n] = id; mylog[2 * lg_n + 1] = prev; ++lg_n;
-                    if (cont != 1 && a_id0 != SEG_NONE) {
-                        // slot A keeps the most recently extended segment: move A to B, park B
-                        if (b_id0 != SEG_NONE) {
-                            // park B unless none of its elements can win any more
-                            const int32_t bx = (int32_t)(b_id0 >> 16);
-                            if (2 * ((int32_t)b_len - 1) >= (int32_t)xr - bx - (int32_t)b_dp0 - 1) {
-                                if (pm_n == PS) {           // drop dead parked segments first
-                                    uint32_t w = 0; int32_t vm = 0;
-                                    for (uint32_t i = 0; i < pm_n; ++i) {
-                                        const uint32_t sid = PM_A(i), sdl = PM_ID(i);
-                                        const int32_t sx = (int32_t)(sid >> 16), sl = (int32_t)(sdl & 0xffff), sd = (int32_t)(sdl >> 16);
-                                        if (2 * (sl - 1) < (int32_t)xr - sx - sd - 1) continue;
-                                        PM_A(w) = sid; PM_ID(w) = sdl; ++w;
-                                        vm = max(vm, sd + sx + (int32_t)(sid & 0xffff) + 2 * KMER + 3 * (sl - 1));
-                                    }
-                                    pm_n = w; vmax_lds = vm;
-                                    if (pm_n == PS) { overflow = true; why = 2; break; }
-                                }
-                                PM_A(pm_n) = b_id0; PM_ID(pm_n) = (b_dp0 << 16) | b_len; ++pm_n;
-                                vmax_lds = max(vmax_lds, (int32_t)b_dp0 + bx + (int32_t)(b_id0 & 0xffff) + 2 * KMER + 3 * ((int32_t)b_len - 1));
-                            }
-                        }
-                        b_id0 = a_id0; b_dp0 = a_dp0; b_len = a_len;
-                    } else if (cont == 1) {
-                        // breakpoint inside the run in slot A: the finished piece goes to B's place via the same path
-                        if (b_id0 != SEG_NONE) {
-                            const int32_t bx = (int32_t)(b_id0 >> 16);
-                            if (2 * ((int32_t)b_len - 1) >= (int32_t)xr - bx - (int32_t)b_dp0 - 1) {
-                                if (pm_n == PS) { overflow = true; why = 2; break; }
-                                PM_A(pm_n) = b_id0; PM_ID(pm_n) = (b_dp0 << 16) | b_len; ++pm_n;
-                                vmax_lds = max(vmax_lds, (int32_t)b_dp0 + bx + (int32_t)(b_id0 & 0xffff) + 2 * KMER + 3 * ((int32_t)b_len - 1));
-                            }
-                        }
-                        b_id0 = a_id0; b_dp0 = a_dp0; b_len = a_len;
-                    }
-                    a_id0 = id; a_dp0 = (uint32_t)dp; a_len = 1;
-                }
-                if (dp >= best_v) { best_v = dp; best_id = id; }
-            }
-            // slide the 48-bit window
-            wlo = (wlo >> 8) | (whi << 24);
-            whi = ((whi >> 8) & 0xff) | (nextb << 8);
-            nextb = nextb2;
-        }
-#undef SEG_QUERY
-#undef SEG_NONE
-        if (overflow) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[2 + why], 1u); continue; }
-        if (best_v < 0) continue;                            // no match at all: full matrix
-        if (ablate == 3) { if (best_id == 0xfffffffeu) counters[7] = best_v; continue; }   // (profiling aid) no traceback / walk
-        uint32_t verts[4 * SG + 6];
-        uint32_t nv = 0;
-        {
-            const int fr = band_finish(mylog, lg_n, best_id, x, yb, m, n, full, verts, &nv);
-            if (fr == 0) continue;
-            if (fr == 2) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[7], 1u); continue; }
-        }
-        const uint32_t h = atomicAdd(&counters[0], 1u);
-        hard_list[h] = task;
-        uint16_t* lo = band + (size_t)h * 2 * band_stride;
-        lo[0] = 0xffff; lo[1] = (uint16_t)nv;
-        uint32_t* vout = (uint32_t*)(lo + 2);
-        for (uint32_t i = 0; i < nv; ++i) vout[i] = verts[i];
-    }
-#undef PM_A
-#undef PM_ID
 }
 
 // ---- band_run_kernel's chain DP over pieces (see the kernel for the overall scheme) ----------------
@@ -678,6 +392,7 @@ struct run_state {
     uint32_t n_ent, i_next, ev0, ev1, lg_n;
     int32_t best_v; uint32_t best_id;
     bool overflow; uint32_t why;
+    bool ub_ok;            // the list still holds every piece (run_compact dropped none): run_ub() is valid
 };
 
 __device__ __forceinline__ void run_segq(uint32_t id0, uint32_t dp0, uint32_t len, int32_t qx, int32_t qy, int32_t& bV,
@@ -845,6 +560,7 @@ __device__ void run_compact(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
             const int32_t v = dp0 + len - 1;
             const uint32_t eid = sid + (uint32_t)(len - 1) * 0x10001u;
             if (v > st.best_v || (v == st.best_v && eid > st.best_id)) { st.best_v = v; st.best_id = eid; }
+            st.ub_ok = false;
             continue;
         }
         if (j == a_idx) na = w;
@@ -858,12 +574,64 @@ __device__ void run_compact(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
     a_idx = na; b_idx = nb;
 }
 
+// ---- upper bound of the full-matrix score from the piece list (see the file header) --------------------
+// Entry j covers bases [x0, x0 + len + K - 1) of its diagonal (len k-mers).  G (kept in the high half of
+// e_dl, which held dp0 — dead after phase 2) = best value a chain brings into the entry minus the entry
+// offset; the value of a chain ending with the whole entry is len_bases + G.  A predecessor q is used up to
+// its last base that precedes the entry point in both coordinates, and the entry point is the first base
+// of p from which all of q is usable (later entries lose a base of p per base gained, earlier ones a base
+// of q), so one candidate per ordered pair is enough.  Entries that continue each other on a diagonal (a
+// piece split by a breakpoint or by the two-register window of phase 1) join at cost 0 through D == 0.
+// Fixpoint over ordered pairs; list order (= start order) settles in one pass plus a confirming one.
+__device__ __forceinline__ int32_t ub_join_same(int32_t D) {
+    const int32_t c = 6 * ((D + 10) / 6) - D;              // gap-free: ceil((D + 5) / 6) mismatches
+    const int32_t g = max(7, 13 - D);                      // with gaps
+    return min(c, g);
+}
+
+__device__ int32_t run_ub(const uint32_t* e_id, uint32_t* e_dl, int tid, uint32_t n_ent) {
+    for (uint32_t j = 0; j < n_ent; ++j) e_dl[j * 256 + tid] &= 0xffffu;
+    bool changed = true;
+    for (int pass = 0; pass < 4 && changed; ++pass) {
+        changed = false;
+        for (uint32_t p = 0; p < n_ent; ++p) {
+            const uint32_t idp = e_id[p * 256 + tid], dlp = e_dl[p * 256 + tid];
+            const int32_t xp = (int32_t)(idp >> 16), yp = (int32_t)(idp & 0xffff);
+            const int32_t lp = (int32_t)(dlp & 0xffff) + KMER - 1;
+            const int32_t g0 = (int32_t)(dlp >> 16);
+            int32_t g = g0;
+            for (uint32_t q = 0; q < n_ent; ++q) {
+                if (q == p) continue;
+                const uint32_t idq = e_id[q * 256 + tid], dlq = e_dl[q * 256 + tid];
+                const int32_t xq = (int32_t)(idq >> 16), yq = (int32_t)(idq & 0xffff);
+                const int32_t lq = (int32_t)(dlq & 0xffff) + KMER - 1, gq = (int32_t)(dlq >> 16);
+                int32_t s = max(xq + lq - xp, yq + lq - yp);
+                s = min(max(s, 0), lp - 1);
+                const int32_t t = min(lq - 1, min(xp - xq, yp - yq) + s - 1);
+                if (t < 0) continue;
+                const int32_t dd = (yp - xp) - (yq - xq);
+                int32_t J = 5 + abs(dd);
+                if (dd == 0) { const int32_t D = xp + s - xq - t - 1; J = D == 0 ? 0 : ub_join_same(D); }
+                g = max(g, t + 1 + gq - J - s);
+            }
+            if (g != g0) { e_dl[p * 256 + tid] = (dlp & 0xffffu) | ((uint32_t)g << 16); changed = true; }
+        }
+    }
+    if (changed) return INT32_MAX;                         // not settled: leave the task to the DP
+    int32_t ub = KMER - 1;
+    for (uint32_t j = 0; j < n_ent; ++j) {
+        const uint32_t dl = e_dl[j * 256 + tid];
+        ub = max(ub, (int32_t)(dl & 0xffff) + KMER - 1 + (int32_t)(dl >> 16));
+    }
+    return ub;
+}
+
 __global__ __launch_bounds__(256) void band_run_kernel(
     uint32_t n_tasks, uint32_t task_base,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
     uint32_t max_hap, uint32_t tables_per_pass, uint32_t table_stride,
-    const int32_t* __restrict__ ref_score, const int32_t* __restrict__ alt_score,
+    int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ logbuf, uint16_t* __restrict__ band, uint32_t band_stride,
     uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters,
     uint32_t ablate, uint32_t n_heads) {
@@ -896,8 +664,13 @@ __global__ __launch_bounds__(256) void band_run_kernel(
     const uint32_t last_task = min(task_base + n_tasks - 1, first_task + 255);
     const uint32_t l_first = rec_locus[first_task >> 1], l_last = rec_locus[last_task >> 1];
     const uint32_t loci_per_pass = tables_per_pass / 2;
-    bool done = !have || m == 0 || n == 0;     // empty read / haplotype: score 0 == full
+    int32_t* my_score = (hap ? alt_score : ref_score) + rid;
+    bool done = !have;
+    if (have && (m == 0 || n == 0)) { *my_score = 0; done = true; }     // empty read / haplotype: score 0
     uint32_t* mylog = logbuf + (size_t)slot * LG * 2;
+    // a task without any k-mer match has the whole matrix in band (Band::full_matrix): hard list, marker slot
+#define PUSH_FULL_MATRIX() { const uint32_t h_ = atomicAdd(&counters[0], 1u); hard_list[h_] = task;             \
+                             band[(size_t)h_ * 2 * band_stride] = BAND_FULL_MATRIX; }
 
     for (uint32_t lbase = l_first; lbase <= l_last; lbase += loci_per_pass) {
         __syncthreads();
@@ -946,8 +719,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
         const uint16_t* next = kwhi + max_hap;
         const uint16_t* head = kwhi + 2 * (size_t)max_hap;
         const uint8_t* yb = (const uint8_t*)(head + n_heads);
-        const int32_t full = hap ? alt_score[rid] : ref_score[rid];
-        if (m < KMER || n < KMER) continue;                 // no k-mer: Band::full_matrix, banded == full
+        if (m < KMER || n < KMER) { PUSH_FULL_MATRIX() continue; }    // no k-mer: Band::full_matrix
         if (ablate == 1) continue;                           // (profiling aid) table build only
         if (ablate == 2) {                                   // (profiling aid) probe loop only
             uint32_t wl = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
@@ -967,7 +739,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
         // adjacent piece: phase 2 treats adjacency as the LCSk++ continuation.  No queries here.
         run_state st;
         st.n_ent = 0; st.i_next = 0; st.ev0 = NONE_ID; st.ev1 = NONE_ID; st.lg_n = 0;
-        st.best_v = -1; st.best_id = 0; st.overflow = false; st.why = 0;
+        st.best_v = -1; st.best_id = 0; st.overflow = false; st.why = 0; st.ub_ok = true;
         uint32_t a_idx = NONE_ID, a_id0 = 0, a_len = 0, b_idx = NONE_ID, b_id0 = 0, b_len = 0;
         {
             // The probe is software-pipelined two rows deep — the kernel is latency-bound, and a row's lookups are a
@@ -1063,7 +835,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
         }
         bool overflow = st.overflow;
         uint32_t why = st.why;
-        if (!overflow && st.n_ent == 0 && st.best_v < 0) continue;     // no k-mer match: full matrix, banded == full
+        if (!overflow && st.n_ent == 0 && st.best_v < 0) { PUSH_FULL_MATRIX() continue; }   // no k-mer match
         if (ablate == 3) { if (st.n_ent == 0xffffu) counters[7] = st.n_ent; continue; }   // (profiling aid) phase 1 only
         // ================= phase 2: the rest of the chain DP =================
         if (!overflow) {
@@ -1081,22 +853,27 @@ __global__ __launch_bounds__(256) void band_run_kernel(
         const uint32_t lg_n = st.lg_n;
         const uint32_t best_id = st.best_id;
         if (overflow) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[2 + why], 1u); continue; }
+        // ================= certificate: chain-of-runs upper bound vs the staircase's own score =================
+        const int32_t ub = st.ub_ok ? run_ub(pm_a, pm_id, tid, st.n_ent) : INT32_MAX;
+        if (ablate == 4) { if (ub == -1) counters[7] = 1; continue; }   // (profiling aid) everything but the staircase walk
         uint32_t verts[4 * SG + 6];
         uint32_t nv = 0;
         {
-            const int fr = band_finish(mylog, lg_n, best_id, x, yb, m, n, full, verts, &nv);
-            if (fr == 0) continue;
+            const int fr = band_finish(mylog, lg_n, best_id, x, yb, m, n, ub, verts, &nv);
+            if (fr == 0) { *my_score = ub; continue; }
             if (fr == 2) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[7], 1u); continue; }
         }
+        if (!st.ub_ok) atomicAdd(&counters[10], 1u);         // statistics: hard only because pieces were dropped
         const uint32_t h = atomicAdd(&counters[0], 1u);
         hard_list[h] = task;
         uint16_t* lo = band + (size_t)h * 2 * band_stride;
-        lo[0] = 0xffff; lo[1] = (uint16_t)nv;
+        lo[0] = BAND_POLYLINE; lo[1] = (uint16_t)nv;
         uint32_t* vout = (uint32_t*)(lo + 2);
         for (uint32_t i = 0; i < nv; ++i) vout[i] = verts[i];
     }
 #undef PM_A
 #undef PM_ID
+#undef PUSH_FULL_MATRIX
 }
 
 
@@ -1112,7 +889,8 @@ __global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __rest
     const uint32_t h = blockIdx.x * 16 + grp;
     uint16_t* lo = band + (size_t)(h < n_hard ? h : 0) * 2 * band_stride;
     uint16_t* hi = lo + band_stride;
-    const bool poly = h < n_hard && lo[0] == 0xffff;
+    const bool poly = h < n_hard && lo[0] == BAND_POLYLINE;
+    const bool whole = h < n_hard && lo[0] == BAND_FULL_MATRIX;
     uint32_t nv = 0;
     if (poly) {
         nv = lo[1];
@@ -1120,12 +898,16 @@ __global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __rest
         for (uint32_t i = l; i < nv; i += 16) sv[grp][i] = vin[i];
     }
     __syncthreads();
-    if (!poly) return;
+    if (!poly && !whole) return;
     const uint32_t task = hard_list[h];
     const vtx_record rec = records[task >> 1];
     const vtx_locus loc = loci[rec_locus[task >> 1]];
     const int m = (int)rec.read_len, n = (int)((task & 1) ? loc.alt_len : loc.ref_len);
     const int rows = m + 1;
+    if (whole) {                                             // Band::full_matrix
+        for (int j = l; j <= n; j += 16) { lo[j] = 0; hi[j] = (uint16_t)rows; }
+        return;
+    }
     const uint32_t* v = sv[grp];
     const int cA = (int)(v[0] & 0xffff), cB = (int)(v[nv - 1] & 0xffff);
     for (int j = l; j <= n; j += 16) {
@@ -1152,24 +934,23 @@ __global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __rest
     }
 }
 
-extern "C" hipError_t vtxk_launch_band_fast(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
-                                            const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
-                                            const uint8_t* hap_arena, uint32_t max_hap, const int32_t* ref_score,
-                                            const int32_t* alt_score, uint32_t* logbuf, uint16_t* band,
-                                            uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
-                                            uint32_t* counters, uint32_t tasks_per_locus, hipStream_t s) {
+extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
+                                           const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
+                                           const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score,
+                                           int32_t* alt_score, uint32_t* logbuf, uint16_t* band,
+                                           uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
+                                           uint32_t* counters, uint32_t tasks_per_locus, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
-    static const bool use_stream = getenv("VTX_BAND_KERNEL") && !strcmp(getenv("VTX_BAND_KERNEL"), "stream");
     const size_t lane_bytes = (size_t)(2 * PS) * 256 * 4;
     // A workgroup of 256 tasks processes its loci in passes of `tables / 2` loci (the k-mer tables live in LDS); in a
     // pass only the lanes of those loci work, so every extra pass repeats the per-task code for the whole wave.
     // Deep data (>= 192 tasks per locus, <= 3 loci per workgroup): 512-entry head arrays -> two loci fit next to the
-    // 40 KiB of lane arrays at 3 workgroups per CU, one pass per workgroup (2048-entry heads fit one locus: 109 ms
+    // 28 KiB of lane arrays at 4 workgroups per CU, one pass per workgroup (2048-entry heads fit one locus: 109 ms
     // instead of 91 ms on config 3; 256-entry heads: 101 ms, the chains get longer).  Shallow data: a 78 KiB budget
     // (2 workgroups per CU) keeps 6 loci resident per pass, 8 with 256-entry heads below 48 tasks per locus.
-    const bool shallow = !use_stream && tasks_per_locus < 192;
-    uint32_t n_heads = use_stream ? TB_HEADS : (tasks_per_locus < 48 ? 256 : 512);
-    if (!use_stream && getenv("VTX_BAND_HEADS")) n_heads = (uint32_t)atoi(getenv("VTX_BAND_HEADS"));   // experiment knob (power of two)
+    const bool shallow = tasks_per_locus < 192;
+    uint32_t n_heads = tasks_per_locus < 48 ? 256 : 512;
+    if (getenv("VTX_BAND_HEADS")) n_heads = (uint32_t)atoi(getenv("VTX_BAND_HEADS"));   // experiment knob (power of two)
     const size_t tstride = band_table_stride(max_hap, n_heads);
     size_t budget = (shallow ? 78 : (PS <= 14 ? 40 : 52)) * 1024;   // lane arrays + haplotype tables
     uint32_t tables = (uint32_t)((budget - std::min(budget, lane_bytes)) / tstride) & ~1u;
@@ -1178,19 +959,13 @@ extern "C" hipError_t vtxk_launch_band_fast(uint32_t n_tasks, uint32_t task_base
     const size_t shmem = lane_bytes + (size_t)tables * tstride;
     if (shmem > 160 * 1024) return hipErrorInvalidValue;
     if (shmem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)band_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)band_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipError_t e = hipFuncSetAttribute((const void*)band_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
     const uint32_t ablate = (uint32_t)(getenv("VTX_BAND_ABLATE") ? atoi(getenv("VTX_BAND_ABLATE")) : 0);
-    if (use_stream)
-        hipLaunchKernelGGL(band_fast_kernel, dim3((n_tasks + 255) / 256), dim3(256), shmem, s, n_tasks, task_base, records,
-                           rec_locus, loci, read_arena, hap_arena, max_hap, tables, (uint32_t)tstride, ref_score, alt_score,
-                           logbuf, band, band_stride, hard_list, overflow_list, counters, ablate);
-    else
-        hipLaunchKernelGGL(band_run_kernel, dim3((n_tasks + 255) / 256), dim3(256), shmem, s, n_tasks, task_base, records,
-                           rec_locus, loci, read_arena, hap_arena, max_hap, tables, (uint32_t)tstride, ref_score, alt_score,
-                           logbuf, band, band_stride, hard_list, overflow_list, counters, ablate, n_heads);
+    hipLaunchKernelGGL(band_run_kernel, dim3((n_tasks + 255) / 256), dim3(256), shmem, s, n_tasks, task_base, records,
+                       rec_locus, loci, read_arena, hap_arena, max_hap, tables, (uint32_t)tstride, ref_score, alt_score,
+                       logbuf, band, band_stride, hard_list, overflow_list, counters, ablate, n_heads);
     return hipGetLastError();
 }
 

@@ -53,13 +53,12 @@ hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, uint32_t ta
                             uint32_t max_hap, int32_t* ref_score, int32_t* alt_score, uint16_t* band,
                             uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list, uint32_t* counters,
                             hipStream_t s);
-size_t vtxk_band_table_stride(uint32_t max_hap);
-hipError_t vtxk_launch_band_fast(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
-                                 const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
-                                 const uint8_t* hap_arena, uint32_t max_hap, const int32_t* ref_score,
-                                 const int32_t* alt_score, uint32_t* logbuf, uint16_t* band, uint32_t band_stride,
-                                 uint32_t* hard_list, uint32_t* overflow_list, uint32_t* counters, uint32_t tasks_per_locus,
-                                 hipStream_t s);
+hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
+                                const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
+                                const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score,
+                                int32_t* alt_score, uint32_t* logbuf, uint16_t* band, uint32_t band_stride,
+                                uint32_t* hard_list, uint32_t* overflow_list, uint32_t* counters, uint32_t tasks_per_locus,
+                                hipStream_t s);
 hipError_t vtxk_launch_band_expand(const uint32_t* hard_list, uint32_t n_hard, const vtx_record* records,
                                    const uint32_t* rec_locus, const vtx_locus* loci, uint16_t* band,
                                    uint32_t band_stride, hipStream_t s);
