@@ -35,7 +35,8 @@ def parse_cigar(s: str) -> list:
 
 
 def record(tid, pos, qname, seq, cigar, flag=0, mapq=60, tags=()):
-    """tags: iterable of (tag, type, value) with type 'Z' (bytes/str), 'i' (int) or 'A' (char)."""
+    """tags: iterable of (tag, type, value) with type 'Z' (bytes/str), 'i' (int), 'A' (char), 'd' / 'f' (float) or
+    'B' ((subtype, [ints]))."""
     qn = qname.encode() + b"\x00"
     cig = parse_cigar(cigar) if isinstance(cigar, str) else list(cigar)
     l_seq = len(seq)
@@ -52,6 +53,14 @@ def record(tid, pos, qname, seq, cigar, flag=0, mapq=60, tags=()):
             aux += tag.encode() + b"i" + struct.pack("<i", val)
         elif ty == "A":
             aux += tag.encode() + b"A" + val.encode()
+        elif ty == "d":
+            aux += tag.encode() + b"d" + struct.pack("<d", val)
+        elif ty == "f":
+            aux += tag.encode() + b"f" + struct.pack("<f", val)
+        elif ty == "B":         # val = (subtype char, list of ints)
+            sub, vals = val
+            aux += tag.encode() + b"B" + sub.encode() + struct.pack("<i", len(vals)) + b"".join(
+                struct.pack({"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I"}[sub], v) for v in vals)
     body = struct.pack("<iiBBHHHiiii", tid, pos, len(qn), mapq, 4680, len(cig), flag, l_seq, -1, -1, 0)
     body += qn + b"".join(struct.pack("<I", c) for c in cig) + bytes(packed) + b"\xff" * l_seq + aux
     return struct.pack("<i", len(body)) + body

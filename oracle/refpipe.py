@@ -139,7 +139,7 @@ def read_bam(path: str) -> Bam:
     return bam
 
 
-_AUX_FIXED = {b"A": 1, b"c": 1, b"C": 1, b"s": 2, b"S": 2, b"i": 4, b"I": 4, b"f": 4}
+_AUX_FIXED = {b"A": 1, b"c": 1, b"C": 1, b"s": 2, b"S": 2, b"i": 4, b"I": 4, b"f": 4, b"d": 8}
 
 
 def aux_string(aux: bytes, tag: bytes):

@@ -75,10 +75,19 @@ def test_coverage_matrices_umi_gzipped_bcs(tmp_path):   # :1342-1390
     assert open(ovar).read() == "1_199\n17_199\n2_199\n7_199\n"                        # 0-based pos (:1174)
 
 
-def test_coverage_mode_without_ref_matrix_flag_writes_only_main(tmp_path):
+def test_coverage_mode_without_ref_matrix_flag_writes_the_default_ref_matrix(tmp_path):
+    """src/main.rs:385 tests `args.is_present("ref_matrix")`, and clap 2.33 reports an argument that has a
+    default_value (:100) as present: coverage mode ALWAYS writes the REF-count matrix, to ./ref_matrix.mtx when the
+    flag is absent (which is also why the default path goes through validate_output_path, :509-511)."""
     out = str(tmp_path / "out.mtx")
-    run_cli(base_args() + ["-o", out, "-s", "coverage"], tmp_path)                    # :385 is_present("ref_matrix")
-    assert os.path.exists(out) and not os.path.exists(tmp_path / "ref_matrix.mtx")
+    run_cli(base_args() + ["-o", out, "-s", "coverage"], tmp_path)                    # cwd = tmp_path
+    assert os.path.exists(out) and os.path.exists(tmp_path / "ref_matrix.mtx")
+    assert csr(str(tmp_path / "ref_matrix.mtx")) == csr(os.path.join(G, "test_coverage_ref.mtx"))
+    # consensus mode does not write it
+    out2 = str(tmp_path / "out2.mtx")
+    os.remove(tmp_path / "ref_matrix.mtx")
+    run_cli(base_args() + ["-o", out2], tmp_path)
+    assert os.path.exists(out2) and not os.path.exists(tmp_path / "ref_matrix.mtx")
 
 
 @pytest.mark.parametrize("prep", ["host", "device"])

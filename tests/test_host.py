@@ -130,6 +130,9 @@ def make_dna_bam(tmp_path, seed=1, n_reads=600):
             clip = int(rng.integers(1, 15))
             cigar = "%dS%dM" % (clip, len(seq) - clip)
         tags = []
+        if rng.random() < 0.3:      # fixed-size and array fields BEFORE the barcode: the scan must step over them
+            tags.append(("XD", "d", 0.5)) if rng.random() < 0.5 else tags.append(("XB", "B", ("S", [1, 2, 3])))
+            tags.append(("XF", "f", 1.5))
         if rng.random() < 0.9:
             tags.append(("CB", "Z", bcs[int(rng.integers(0, 40))] if rng.random() < 0.9 else b"NOTLISTED-1"))
         if rng.random() < 0.85:

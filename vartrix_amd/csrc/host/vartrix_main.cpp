@@ -347,7 +347,9 @@ int main(int argc, char** argv) {
         printf("Vartrix error.\nError: Error writing out-matrix\nInfo: caused by %s\n", vtxh_last_error());
         return 1;
     }
-    if (mode == "coverage" && present.count("ref-matrix")) {                                                                 // :385-389
+    // :385-389 `args.is_present("ref_matrix")` is true even without the flag: clap 2.33 reports an argument with a
+    // default_value (:100) as present, so coverage mode always writes the REF-count matrix (default ref_matrix.mtx)
+    if (mode == "coverage") {
         if (vtxh_write_mtx(ref_matrix.c_str(), n_vars, n_bcs, row.size(), row.data(), col.data(), rv.data()) != 0) {
             printf("Vartrix error.\nError: Error writing ref-matrix\nInfo: caused by %s\n", vtxh_last_error());
             return 1;

@@ -171,11 +171,13 @@ bool index_bgzf(const MappedFile& file, std::vector<BgzfBlock>& blocks) {
         const unsigned char* h = (const unsigned char*)file.data() + o;
         if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return false;
         uint32_t xlen = h[10] | (h[11] << 8);
+        if (o + 12 + xlen > file.size()) return false;           // truncated extra field: never read past the mapping
         uint32_t bsize = 0;
         bool found = false;
         size_t x = 12;
         while (x + 4 <= 12 + xlen) {
             uint32_t slen = h[x + 2] | (h[x + 3] << 8);
+            if (x + 4 + slen > 12 + xlen) return false;          // subfield runs past the extra field
             if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) { bsize = (h[x + 4] | (h[x + 5] << 8)) + 1u; found = true; }
             x += 4 + slen;
         }
@@ -219,6 +221,7 @@ int aux_string(const unsigned char* aux, size_t n, const char* tag, const unsign
         case 'A': case 'c': case 'C': size = 1; break;
         case 's': case 'S': size = 2; break;
         case 'i': case 'I': case 'f': size = 4; break;
+        case 'd': size = 8; break;                              // htslib's bam_aux_get skips a double as 8 bytes
         case 'Z': case 'H': {
             size_t e = o;
             while (e < n && aux[e]) ++e;
