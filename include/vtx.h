@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define VTX_ABI_VERSION 1
+#define VTX_ABI_VERSION 2
 
 typedef enum vtx_status {
     VTX_OK = 0,
@@ -148,8 +148,9 @@ typedef struct vtx_coo {
 } vtx_coo;
 
 /* Device-side timing of the last vtx_run, from hipEvents on the context's
- * stream (ms).  `sw_ms` covers the alignment kernels only (full DP, and for
- * the banded flavour the band kernel + band-masked DP).                      */
+ * stream (ms).  `sw_ms` covers the alignment kernels only: the full-matrix DP
+ * (full flavour) or the band kernels + band-masked DP (banded flavour — it
+ * never runs the full-matrix DP).                                            */
 typedef struct vtx_timing {
     float total_ms;
     float sw_ms;
@@ -158,6 +159,8 @@ typedef struct vtx_timing {
     uint32_t hard_tasks;   /* banded flavour: alignments that needed the band-masked DP */
     float full_ms;         /* sw_full_kernel launches only (part of sw_ms)                */
     float band_ms;         /* band kernels + band-masked DP (banded flavour; part of sw_ms) */
+    float band_run_ms;     /* band_run_kernel launches only (seeds, chain, certificate; part of band_ms) */
+    uint32_t overflow_tasks; /* banded flavour: alignments handed to the general band kernel        */
 } vtx_timing;
 
 typedef struct vtx_ctx vtx_ctx;

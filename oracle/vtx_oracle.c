@@ -19,6 +19,21 @@
 static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 
+/* Per-thread scratch slabs (grown on demand, never shrunk): the per-read aligner of the reference allocates
+ * its DP vectors once per Aligner (banded.rs: `with_capacity`) — one malloc per call here would measure the
+ * allocator, not the algorithm, when this file is timed as the CPU baseline.                                */
+#define VTXO_SLABS 8
+static _Thread_local void* t_slab[VTXO_SLABS];
+static _Thread_local size_t t_slab_cap[VTXO_SLABS];
+static void* slab(int k, size_t bytes) {
+    if (t_slab_cap[k] < bytes) {
+        free(t_slab[k]);
+        t_slab_cap[k] = bytes + bytes / 2 + 64;
+        t_slab[k] = malloc(t_slab_cap[k]);
+    }
+    return t_slab[k];
+}
+
 /* ------------------------------------------------------------------------- */
 /* Affine local alignment, full matrix.                                       */
 /* bio::alignment::pairwise::Aligner::custom with all four clip penalties 0    */
@@ -29,7 +44,7 @@ static inline int imin(int a, int b) { return a < b ? a : b; }
 int32_t vtxo_sw_full(const uint8_t* x, int m, const uint8_t* y, int n,
                      int match, int mismatch, int gap_open, int gap_extend) {
     if (m <= 0 || n <= 0) return 0;
-    int32_t* S = (int32_t*)malloc(sizeof(int32_t) * (size_t)(m + 1) * 2);
+    int32_t* S = (int32_t*)slab(0, sizeof(int32_t) * (size_t)(m + 1) * 2);
     int32_t* D = S + (m + 1); /* D[i] = gap-in-x state of column j-1 for row i */
     int32_t best = 0;
     for (int i = 0; i <= m; ++i) { S[i] = 0; D[i] = VTXO_MIN_SCORE; }
@@ -53,7 +68,6 @@ int32_t vtxo_sw_full(const uint8_t* x, int m, const uint8_t* y, int n,
             if (s > best) best = s;
         }
     }
-    free(S);
     return best;
 }
 
@@ -77,8 +91,8 @@ int64_t vtxo_find_kmer_matches(const uint8_t* x, int m, const uint8_t* y, int n,
     int tbits = 4;
     while ((1 << tbits) < 2 * ny) ++tbits;
     const uint32_t tmask = (1u << tbits) - 1u;
-    int32_t* head = (int32_t*)malloc(sizeof(int32_t) * ((size_t)1 << tbits));
-    int32_t* next = (int32_t*)malloc(sizeof(int32_t) * (size_t)ny);
+    int32_t* head = (int32_t*)slab(1, sizeof(int32_t) * (((size_t)1 << tbits) + (size_t)ny));
+    int32_t* next = head + ((size_t)1 << tbits);
     for (uint32_t i = 0; i <= tmask; ++i) head[i] = -1;
     /* insert in descending j so each chain lists j ascending */
     for (int j = ny - 1; j >= 0; --j) {
@@ -96,7 +110,6 @@ int64_t vtxo_find_kmer_matches(const uint8_t* x, int m, const uint8_t* y, int n,
             }
         }
     }
-    free(head); free(next);
     *out = mt;
     return cnt; /* already sorted by (i, j): i ascending outer, j ascending inner */
 }
@@ -141,7 +154,7 @@ int64_t vtxo_sdpkpp(const uint32_t* mt, int64_t M, int k, int match_score,
                     int gap_open, int gap_extend, int64_t* path_out, int64_t* score_out) {
     if (score_out) *score_out = 0;
     if (M <= 0) return 0;
-    sdp_event* ev = (sdp_event*)malloc(sizeof(sdp_event) * 2 * (size_t)M);
+    sdp_event* ev = (sdp_event*)slab(2, sizeof(sdp_event) * 2 * (size_t)M);
     uint32_t nmax = 0;
     for (int64_t p = 0; p < M; ++p) {
         uint32_t x = mt[2 * p], y = mt[2 * p + 1];
@@ -153,10 +166,10 @@ int64_t vtxo_sdpkpp(const uint32_t* mt, int64_t M, int k, int match_score,
     qsort(ev, 2 * (size_t)M, sizeof(sdp_event), ev_cmp);
     /* max-Fenwick tree over column index 0..nmax (1-based internally) */
     const int64_t tn = (int64_t)nmax + 2;
-    bit_ent* tree = (bit_ent*)malloc(sizeof(bit_ent) * (size_t)(tn + 1));
+    bit_ent* tree = (bit_ent*)slab(3, sizeof(bit_ent) * (size_t)(tn + 1));
     for (int64_t i = 0; i <= tn; ++i) tree[i] = (bit_ent){INT64_MIN, -1};
-    int64_t* dps = (int64_t*)malloc(sizeof(int64_t) * (size_t)M);
-    int64_t* dpp = (int64_t*)malloc(sizeof(int64_t) * (size_t)M);
+    int64_t* dps = (int64_t*)slab(4, sizeof(int64_t) * 2 * (size_t)M);
+    int64_t* dpp = dps + M;
     const int64_t kscore = (int64_t)k * match_score;
     bit_ent best = {kscore, 0};
     for (int64_t e = 0; e < 2 * M; ++e) {
@@ -197,7 +210,6 @@ int64_t vtxo_sdpkpp(const uint32_t* mt, int64_t M, int k, int match_score,
     int64_t w = len;
     for (int64_t p = best.idx; p >= 0; p = dpp[p]) path_out[--w] = p;
     if (score_out) *score_out = best.v;
-    free(ev); free(tree); free(dps); free(dpp);
     return len;
 }
 
@@ -241,7 +253,7 @@ int64_t vtxo_band_create(const uint8_t* x, int m, const uint8_t* y, int n,
     if (M == 0) {
         for (int j = 0; j <= n; ++j) { lo[j] = 0; hi[j] = m + 1; }
     } else {
-        int64_t* path = (int64_t*)malloc(sizeof(int64_t) * (size_t)M);
+        int64_t* path = (int64_t*)slab(5, sizeof(int64_t) * (size_t)M);
         int64_t L = vtxo_sdpkpp(mt, M, k, 1 /* match_fn.score(b'A', b'A') */, -5, -1, path, NULL);
         /* NOTE: the aligner passes its own scoring's gap penalties; the
          * reference constructs it with (-5, -1) (src/main.rs:899).            */
@@ -263,7 +275,6 @@ int64_t vtxo_band_create(const uint8_t* x, int m, const uint8_t* y, int n,
             }
             px = cx; py = cy;
         }
-        free(path);
     }
     free(mt);
     int64_t cells = 0;
@@ -282,14 +293,18 @@ int32_t vtxo_sw_ranges(const uint8_t* x, int m, const uint8_t* y, int n,
                        int match, int mismatch, int gap_open, int gap_extend,
                        const int32_t* lo, const int32_t* hi) {
     const size_t R = (size_t)m + 1;
-    int32_t* buf = (int32_t*)malloc(sizeof(int32_t) * R * 4);
+    int32_t* buf = (int32_t*)slab(6, sizeof(int32_t) * R * 4);
     int32_t *Sp = buf, *Dp = buf + R, *Sc = buf + 2 * R, *Dc = buf + 3 * R;
     int32_t best = 0;
-    for (size_t i = 0; i < R; ++i) { Sp[i] = VTXO_MIN_SCORE; Dp[i] = VTXO_MIN_SCORE; }
+    for (size_t i = 0; i < 4 * R; ++i) buf[i] = VTXO_MIN_SCORE;
     /* column 0: in-band cells are 0 (y prefix clipped) */
     for (int i = lo[0]; i < hi[0]; ++i) Sp[i] = 0;
+    /* Sc / Dc still hold column j-2 when column j is written: only its band range needs resetting to
+     * MIN_SCORE (everything else in the buffer already is), not the whole column.                     */
+    int plo = 0, phi = 0;                       /* band range last written into Sc / Dc */
+    int qlo = lo[0], qhi = hi[0];               /* ... into Sp / Dp */
     for (int j = 1; j <= n; ++j) {
-        for (size_t i = 0; i < R; ++i) { Sc[i] = VTXO_MIN_SCORE; Dc[i] = VTXO_MIN_SCORE; }
+        for (int i = plo; i < phi; ++i) { Sc[i] = VTXO_MIN_SCORE; Dc[i] = VTXO_MIN_SCORE; }
         const uint8_t q = y[j - 1];
         int32_t up_i = VTXO_MIN_SCORE;
         for (int i = lo[j]; i < hi[j]; ++i) {
@@ -302,24 +317,24 @@ int32_t vtxo_sw_ranges(const uint8_t* x, int m, const uint8_t* y, int n,
             Sc[i] = s; Dc[i] = d; up_i = ii;
             if (s > best) best = s;
         }
+        plo = qlo; phi = qhi;
+        qlo = lo[j]; qhi = hi[j] > lo[j] ? hi[j] : lo[j];
         int32_t* t;
         t = Sp; Sp = Sc; Sc = t;
         t = Dp; Dp = Dc; Dc = t;
     }
-    free(buf);
     return best;
 }
 
 int32_t vtxo_sw_banded(const uint8_t* x, int m, const uint8_t* y, int n,
                        int match, int mismatch, int gap_open, int gap_extend, int k, int w) {
     if (m <= 0 || n <= 0) return 0;
-    int32_t* lo = (int32_t*)malloc(sizeof(int32_t) * 2 * ((size_t)n + 1));
+    int32_t* lo = (int32_t*)slab(7, sizeof(int32_t) * 2 * ((size_t)n + 1));
     int32_t* hi = lo + (n + 1);
     int64_t cells = vtxo_band_create(x, m, y, n, k, w, lo, hi);
     int32_t s;
     if (cells > VTXO_MAX_CELLS) s = VTXO_MIN_SCORE; /* banded.rs: empty alignment, score MIN_SCORE */
     else s = vtxo_sw_ranges(x, m, y, n, match, mismatch, gap_open, gap_extend, lo, hi);
-    free(lo);
     return s;
 }
 

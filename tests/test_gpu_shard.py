@@ -1,0 +1,69 @@
+"""The RCCL leg on the GPU box (one rank — the box has one GPU): `nccl` process group, the context's device-resident
+triplets wrapped as torch tensors through their raw device pointers, shard.GatherPipeline — compared bit for bit with
+vtx_fetch_coo; and bench.py's own gather path (VTX_FORCE_GATHER=1) against its plain single-GPU run.  The N > 1
+exchange itself is covered by the world_size-2 gloo tests (tests/test_shard.py), which drive the same objects."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CODE = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from vartrix_amd import lib, shard, synth
+from vartrix_amd.abi import MODES, default_config
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29631"
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+for mode, umi in (("consensus", 0), ("alt_frac", 1), ("coverage", 1)):
+    spec = synth.SynthSpec(n_loci=300, n_barcodes=500, reads_per_locus=40, use_umi=bool(umi), indel_frac=0.3, seed=9)
+    batch = synth.make_batch(spec)
+    cfg = default_config(aligner="banded", scoring_mode=mode, use_umi=umi, n_barcodes=500)
+    with lib.Context(cfg) as ctx:
+        ctx.submit(batch)
+        pipe = shard.GatherPipeline(MODES[mode])
+        for _ in range(3):
+            ctx.run()
+            pipe.push(shard.device_coo_tensors(ctx, dev))
+        got = shard.tensors_to_coo(pipe.drain())
+        want = ctx.fetch_coo()
+    assert pipe.completed == 3
+    for k in want:
+        assert np.array_equal(got[k].view(np.uint8), want[k].view(np.uint8)), (mode, k)
+    assert len(want["row"]) > 1000
+dist.barrier(); dist.destroy_process_group()
+print("rccl-one-rank-ok")
+''' % ROOT
+
+
+def test_rccl_gather_one_rank_equals_fetch_coo():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _CODE], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl-one-rank-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def _bench(extra_env, args):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29633", **extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-other-aligner"] + args, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_gather_path_matches_plain_run():
+    """bench.py with the RCCL gather forced on one rank must report the same matrix summary (nnz, checksum) as the
+    plain run of the same workload, in config-4 shape (many barcodes) at reduced size."""
+    args = ["--loci", "1500", "--barcodes", "5000", "--reads-per-locus", "64"]
+    plain = _bench({}, args)
+    gath = _bench({"VTX_FORCE_GATHER": "1"}, args)
+    assert plain["result"] == gath["result"] and plain["result"]["nnz"] > 10000
+    assert plain["config"]["alignments_per_step"] == gath["config"]["alignments_per_step"]
+    for j in (plain, gath):
+        assert j["roofline"]["kernel"].startswith("band_run_kernel") and j["roofline"]["kernel_ms"] > 0
+        assert j["scaling"] == "strong" and j["n_gpus"] == 1

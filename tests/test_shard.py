@@ -89,3 +89,60 @@ def test_slice_loci_is_self_contained():
     assert list(sub.loci["row"]) == list(range(5, 13))
     empty = batch.slice_loci(7, 7)
     assert empty.n_loci == 0 and empty.n_records == 0
+
+
+def _pipeline_worker(rank, world, port, out_path):
+    """bench.py's per-step exchange (shard.GatherPipeline) on CPU tensors: three steps with different triplets per
+    step; after drain rank 0 must hold the LAST step's rows of both ranks, in rank order."""
+    from oracle import oracle
+    from vartrix_amd.abi import MODES
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pipe = shard.GatherPipeline(MODES["coverage"])
+    wants = []
+    for stepno in range(3):
+        spec = synth.SynthSpec(n_loci=16 + 4 * stepno, n_barcodes=20, reads_per_locus=12, read_len=50, padding=30, seed=100 + stepno)
+        batch = synth.make_batch(spec)
+        cfg = default_config(aligner="full", scoring_mode="coverage", n_barcodes=20)
+        lo, hi = shard.partition_loci(batch, world)[rank]
+        mine = batch.slice_loci(lo, hi)
+        ref, alt = oracle.batch_scores(mine, cfg)
+        pipe.push(shard.coo_to_tensors(oracle.batch_reduce(mine, cfg, ref, alt)))
+        if rank == 0:
+            fr, fa = oracle.batch_scores(batch, cfg)
+            wants.append(oracle.batch_reduce(batch, cfg, fr, fa))
+        assert pipe.completed == stepno          # the gather of step k completes while step k + 1 is pushed
+    got = pipe.drain()
+    assert pipe.completed == 3
+    if rank == 0:
+        got = shard.tensors_to_coo(got)
+        ok = all(np.array_equal(got[k].view(np.uint8), wants[-1][k].view(np.uint8)) for k in wants[-1])
+        with open(out_path, "w") as fh:
+            fh.write("ok" if ok else "mismatch")
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_pipeline_two_ranks(tmp_path):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_partition_covers_config4_shape():
+    """Strong-scaling cut of bench.py --gpus N (BASELINE configs[3]): 1 / 2 / 4 / 8 ranges that tile the loci, and
+    slices whose union is the unsharded batch."""
+    spec = synth.SynthSpec(n_loci=400, n_barcodes=2000, reads_per_locus=24)
+    batch = synth.make_batch(spec)
+    for world in (1, 2, 4, 8):
+        parts = shard.partition_loci(batch, world)
+        pieces = [batch.slice_loci(lo, hi) for lo, hi in parts]
+        assert sum(p.n_records for p in pieces) == batch.n_records
+        rows = np.concatenate([p.loci["row"] for p in pieces])
+        assert np.array_equal(rows, batch.loci["row"])
+        reads = np.concatenate([p.read_arena[:int(p.records["read_len"].astype(np.int64).sum())] if p.n_records else np.zeros(0, np.uint8)
+                                for p in pieces])
+        assert reads.shape[0] == int(batch.records["read_len"].astype(np.int64).sum())

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-VTX_ABI_VERSION = 1
+VTX_ABI_VERSION = 2
 
 VTX_OK = 0
 VTX_E_INVAL = -1
@@ -114,6 +114,8 @@ class VtxTiming(C.Structure):
         ("hard_tasks", C.c_uint32),
         ("full_ms", C.c_float),
         ("band_ms", C.c_float),
+        ("band_run_ms", C.c_float),
+        ("overflow_tasks", C.c_uint32),
     ]
 
 

@@ -62,7 +62,7 @@ thread_local std::string g_create_err;
 struct vtx_ctx {
     vtx_config cfg{};
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string err;
     bool submitted = false, ran = false;
     uint32_t n_loci = 0, n_records = 0, n_cell_groups = 0, n_umi_groups = 0, max_hap_len = 0;
@@ -611,6 +611,7 @@ int vtx_run(vtx_ctx* c) {
     hipStream_t s = c->stream;
     const uint32_t nr = c->n_records;
     c->ran = false;
+    c->fast_overflow = 0;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     uint32_t launches = 0;
     bool any_lut = false;
@@ -659,6 +660,7 @@ int vtx_run(vtx_ctx* c) {
         }
     }
     uint32_t hard_total = 0;
+    float band_run_ms = 0;
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
     if (c->cfg.aligner == VTX_ALIGNER_BANDED && nr) {
         // Banded flavour.  Per chunk of tasks (task = 2*record + hap): band_run_kernel (seeds, chain, DP-free
@@ -704,14 +706,21 @@ int vtx_run(vtx_ctx* c) {
         for (uint64_t base = 0; base < n_tasks; base += chunk) {
             const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, n_tasks - base);
             HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), s));                 // hard count of this chunk
+            HIP_TRY(c, hipEventRecord(c->ev[4], s));
             HIP_TRY(c, vtxk_launch_band_run(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                              c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                              c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
                                              c->d_band_ws.as<uint32_t>(), c->d_band.as<uint16_t>(), band_stride,
                                              c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), d_cnt,
                                              (uint32_t)(n_tasks / std::max(c->n_loci, 1u)), s));
+            HIP_TRY(c, hipEventRecord(c->ev[5], s));
             HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
+            {
+                float ms = 0;
+                HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
+                band_run_ms += ms;
+            }
             if (int rc = masked_dp(cnt[0])) return rc;
             hard_total += cnt[0];
             launches += 3;
@@ -792,6 +801,7 @@ int vtx_run(vtx_ctx* c) {
     HIP_TRY(c, hipEventElapsedTime(&t12, c->ev[1], c->ev[2]));
     c->timing.sw_ms = t01; c->timing.reduce_ms = t12; c->timing.total_ms = t01 + t12;
     c->timing.sw_launches = launches; c->timing.hard_tasks = hard_total;
+    c->timing.band_run_ms = band_run_ms; c->timing.overflow_tasks = c->fast_overflow;
     c->ran = true;
     return VTX_OK;
 }

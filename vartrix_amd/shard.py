@@ -162,3 +162,30 @@ def gather_coo_async(local: dict, mode: int, group=None, dst: int = 0) -> Gather
 def gather_coo(local: dict, mode: int = 2, group=None, dst: int = 0):
     """Blocking form of gather_coo_async."""
     return gather_coo_async(local, mode, group, dst).wait()
+
+
+class GatherPipeline:
+    """The per-step row exchange of a sharded run, one step deep: ``push`` starts the gather of this step's
+    triplets and completes the previous one, so the exchange of step k overlaps with the kernels of step k+1;
+    ``drain`` completes the last one.  ``last`` holds the most recent gathered matrix on ``dst`` (None elsewhere).
+    bench.py's timed loop and the CPU (gloo) tests drive this same object."""
+
+    def __init__(self, mode: int, group=None, dst: int = 0):
+        self.mode, self.group, self.dst = mode, group, dst
+        self._pending = None
+        self.last = None
+        self.completed = 0
+
+    def push(self, local: dict):
+        handle = gather_coo_async(local, self.mode, self.group, self.dst)
+        if self._pending is not None:
+            self.last = self._pending.wait()
+            self.completed += 1
+        self._pending = handle
+
+    def drain(self):
+        if self._pending is not None:
+            self.last = self._pending.wait()
+            self.completed += 1
+            self._pending = None
+        return self.last

@@ -45,13 +45,25 @@ class SynthSpec:
     use_umi: bool = False
     umi_flip: float = 0.02
     read_len_jitter: int = 0     # reads get length read_len - U[0, jitter]
+    depth_sigma: float = 0.0     # > 0: reads per locus ~ log-normal, median reads_per_locus, this sigma (>= 1 read)
 
     @property
     def name(self) -> str:
         kind = "SNV" if self.indel_frac == 0 else "SNV+indel<=%d" % self.max_indel
-        return "synthetic %d %s loci x %d barcodes, %d x %dbp reads/locus%s" % (
-            self.n_loci, kind, self.n_barcodes, self.reads_per_locus, self.read_len,
-            ", UMI" if self.use_umi else "")
+        depth = "%d" % self.reads_per_locus if self.depth_sigma == 0 else "log-normal(median %d, sigma %g)" % (
+            self.reads_per_locus, self.depth_sigma)
+        return "synthetic %d %s loci x %d barcodes, %s x %dbp reads/locus%s" % (
+            self.n_loci, kind, self.n_barcodes, depth, self.read_len, ", UMI" if self.use_umi else "")
+
+
+
+def _depths(spec: "SynthSpec", rng, nl: int) -> np.ndarray:
+    """Reads generated per locus (before the unlisted-barcode filter)."""
+    if spec.depth_sigma <= 0:
+        return np.full(nl, spec.reads_per_locus, np.int64)
+    d = np.rint(spec.reads_per_locus * np.exp(spec.depth_sigma * rng.standard_normal(nl)))
+    return np.clip(d, 1, 64 * spec.reads_per_locus).astype(np.int64)
+
 
 
 def _mix(a: np.ndarray, b: np.ndarray, seed: int) -> np.ndarray:
@@ -98,8 +110,9 @@ def _make_batch_snv(spec: SynthSpec, chunk_loci: int = 4096) -> PackedBatch:
         haps[:, 1, :] = haps[:, 0, :]
         haps[:, 1, pad] = snv_alt
         hap_parts.append(haps.reshape(-1))
-        n = nl * R
-        lidx = np.repeat(np.arange(nl, dtype=np.int64), R)
+        depth = _depths(spec, rng, nl)
+        n = int(depth.sum())
+        lidx = np.repeat(np.arange(nl, dtype=np.int64), depth)
         cell = rng.integers(0, n_total_cells, size=n)
         start_rel = rng.integers(-(Lr - 1), 1, size=n)
         coin = rng.random(n, dtype=np.float32)
@@ -213,8 +226,9 @@ def make_batch(spec: SynthSpec, chunk_loci: int = 2048) -> PackedBatch:
         alt_offs = ref_offs + ref_len
         hap_off += int((ref_len + alt_len).sum())
         # --- reads ------------------------------------------------------------
-        n = nl * R
-        lidx = np.repeat(np.arange(nl), R)
+        depth = _depths(spec, rng, nl)
+        n = int(depth.sum())
+        lidx = np.repeat(np.arange(nl), depth)
         cell = rng.integers(0, int(round(B / (1.0 - spec.unlisted_frac))) if spec.unlisted_frac > 0 else B, size=n)
         keep = cell < B                                               # unlisted barcodes are filtered by the host
         rl = np.full(n, Lr, np.int64)
