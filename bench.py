@@ -87,7 +87,10 @@ def cpu_baseline(batch, cfg, target_seconds=12.0):
     """Oracle ("port" of the reference CPU path: static chunks of loci over the host threads like
     src/main.rs:250-254, :279-291) on a bounded sample of the same workload; 1 thread and all threads."""
     from oracle import oracle   # test infrastructure: imported here only, as the reported baseline
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))      # the cores this process may run on (a container may expose fewer
+    except AttributeError:                         # than os.cpu_count() reports)
+        cores = os.cpu_count() or 1
     per_locus = max(batch.n_records / max(batch.n_loci, 1), 1)
     one = batch.slice_loci(0, min(batch.n_loci, 4))
     t0 = time.perf_counter()
@@ -111,7 +114,7 @@ def cpu_baseline(batch, cfg, target_seconds=12.0):
     oracle.batch_reduce(sample, cfg, ref, alt)
     dt = time.perf_counter() - t0
     value = 2 * sample.n_records / dt
-    return {"value": value, "unit": "read-alignments/s", "cores": cores, "kind": "port",
+    return {"value": value, "unit": "read-alignments/s", "cores": cores, "os_cpu_count": os.cpu_count(), "kind": "port",
             "per_thread": value / cores, "one_thread": {"value": rate1, "sample": "first %d loci, %.1f s" % (s1.n_loci, dt1)},
             "sample": "first %d loci (%d scored reads, %.1f s) of the same batch, %s aligner, %d OpenMP threads, static "
                       "chunks of loci per thread" % (sample.n_loci, sample.n_records, dt,

@@ -53,7 +53,9 @@ def _bench(extra_env, args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                         "--no-other-aligner"] + args, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads(lines[-1])
 
 
 def test_bench_gather_path_matches_plain_run():

@@ -11,8 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "vtx_device.h"
@@ -82,6 +84,13 @@ struct vtx_ctx {
     DevBuf d_raw, d_tags, d_raw_locus, d_key_lc, d_key_lc2, d_key_umi, d_key_umi2, d_idx, d_idx2, d_shape, d_shape2, d_seq,
         d_locus_cnt, d_locus_scan, d_prep_cnt, d_sort_tmp;
     uint32_t max_read_len = 0, fast_overflow = 0;
+    // host -> device feed: pinned staging buffers + one stream per copy worker (see upload())
+    static constexpr int kUpWorkers = 6, kUpSlots = 2;
+    static constexpr size_t kUpChunk = 8u << 20;
+    void* up_pin[kUpWorkers][kUpSlots] = {};
+    hipEvent_t up_ev[kUpWorkers][kUpSlots] = {};
+    hipStream_t up_stream[kUpWorkers] = {};
+    bool up_ready = false;
     std::vector<uint32_t> h_row, h_col, h_alt, h_ref, h_unk;
     std::vector<double> h_val, h_refval;
 };
@@ -105,6 +114,89 @@ int fail(vtx_ctx* c, int code, const char* fmt, ...) {
             return fail((c), _e == hipErrorOutOfMemory ? VTX_E_NOMEM : VTX_E_HIP, "%s: %s", #expr, \
                         hipGetErrorString(_e));                                                \
     } while (0)
+
+// ---- host -> device feed ------------------------------------------------------------------------------------
+// The caller's arrays are pageable: a plain hipMemcpy of 3.65 GB (config 3's read arena) runs at ~17 GB/s through
+// the runtime's single staging path.  Here kUpWorkers threads each copy 8 MiB chunks into their own pinned buffers
+// (two per worker, so the memcpy of chunk k+1 overlaps the DMA of chunk k) and push them on their own stream: the
+// host memcpys and the DMAs of different workers overlap, and the link — not one core's memcpy — is the limit.
+struct UploadJob { void* dst; const void* src; size_t bytes; };
+
+int upload_init(vtx_ctx* c) {
+    if (c->up_ready) return VTX_OK;
+    for (int w = 0; w < vtx_ctx::kUpWorkers; ++w) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->up_stream[w], hipStreamNonBlocking));
+        for (int k = 0; k < vtx_ctx::kUpSlots; ++k) {
+            HIP_TRY(c, hipHostMalloc(&c->up_pin[w][k], vtx_ctx::kUpChunk, hipHostMallocDefault));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->up_ev[w][k], hipEventDisableTiming));
+        }
+    }
+    c->up_ready = true;
+    return VTX_OK;
+}
+
+void upload_release(vtx_ctx* c) {
+    for (int w = 0; w < vtx_ctx::kUpWorkers; ++w) {
+        for (int k = 0; k < vtx_ctx::kUpSlots; ++k) {
+            if (c->up_pin[w][k]) (void)hipHostFree(c->up_pin[w][k]);
+            if (c->up_ev[w][k]) (void)hipEventDestroy(c->up_ev[w][k]);
+            c->up_pin[w][k] = nullptr; c->up_ev[w][k] = nullptr;
+        }
+        if (c->up_stream[w]) (void)hipStreamDestroy(c->up_stream[w]);
+        c->up_stream[w] = nullptr;
+    }
+    c->up_ready = false;
+}
+
+// Copies every job to the device and returns when all bytes have landed.
+int upload(vtx_ctx* c, const std::vector<UploadJob>& jobs) {
+    struct Chunk { char* dst; const char* src; size_t bytes; };
+    std::vector<Chunk> chunks;
+    size_t total = 0;
+    for (const UploadJob& j : jobs)
+        for (size_t o = 0; o < j.bytes; o += vtx_ctx::kUpChunk) {
+            chunks.push_back(Chunk{(char*)j.dst + o, (const char*)j.src + o, std::min(vtx_ctx::kUpChunk, j.bytes - o)});
+            total += chunks.back().bytes;
+        }
+    if (chunks.empty()) return VTX_OK;
+    if (total < (4u << 20)) {                    // small batches: not worth the threads
+        for (const Chunk& ch : chunks) HIP_TRY(c, hipMemcpyAsync(ch.dst, ch.src, ch.bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return VTX_OK;
+    }
+    if (int rc = upload_init(c)) return rc;
+    std::atomic<size_t> next{0};
+    std::atomic<int> err{(int)hipSuccess};
+    const int device = c->cfg.device;
+    auto worker = [&](int w) {
+        if (hipSetDevice(device) != hipSuccess) { err = (int)hipErrorInvalidDevice; return; }
+        bool used[vtx_ctx::kUpSlots] = {};
+        int slot = 0;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= chunks.size() || err.load() != (int)hipSuccess) break;
+            hipError_t e = used[slot] ? hipEventSynchronize(c->up_ev[w][slot]) : hipSuccess;   // the DMA out of this buffer is done
+            if (e == hipSuccess) {
+                memcpy(c->up_pin[w][slot], chunks[i].src, chunks[i].bytes);
+                e = hipMemcpyAsync(chunks[i].dst, c->up_pin[w][slot], chunks[i].bytes, hipMemcpyHostToDevice, c->up_stream[w]);
+            }
+            if (e == hipSuccess) e = hipEventRecord(c->up_ev[w][slot], c->up_stream[w]);
+            if (e != hipSuccess) { err = (int)e; break; }
+            used[slot] = true;
+            slot = (slot + 1) % vtx_ctx::kUpSlots;
+        }
+        const hipError_t e = hipStreamSynchronize(c->up_stream[w]);
+        if (e != hipSuccess) err = (int)e;
+    };
+    const int nw = (int)std::min<size_t>(vtx_ctx::kUpWorkers, chunks.size());
+    std::vector<std::thread> th;
+    for (int w = 1; w < nw; ++w) th.emplace_back(worker, w);
+    worker(0);
+    for (auto& t : th) t.join();
+    if (err.load() != (int)hipSuccess)
+        return fail(c, VTX_E_HIP, "upload: %s", hipGetErrorString((hipError_t)err.load()));
+    return VTX_OK;
+}
 
 // per-record device buffers of the resident batch (scores, group structure, COO staging)
 int reserve_record_buffers(vtx_ctx* c, uint32_t nr) {
@@ -166,6 +258,41 @@ uint32_t duo_pair_cols(uint32_t max_hap) {
     // the shared prefix is about half of the haplotype (the padding): a pair table that cannot hold it would cut the
     // sharing short (T1 is clamped to the table), and the two-lookup mode is the better choice then
     return cols >= 16 + (size_t)max_hap / 2 + 4 ? (uint32_t)cols : 0u;
+}
+
+// Kernel choice per work list (one list per read-length shape, already in d_work): LUT / shared-prefix (duo) /
+// pair-table eligibility is a property of how many loci a workgroup of consecutive list entries spans.
+int make_buckets(vtx_ctx* c, const uint32_t* shape_cnt, uint32_t max_hap, uint32_t* d_lut_flag) {
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemsetAsync(d_lut_flag, 0, 48 * sizeof(uint32_t), s));
+    c->buckets.clear();
+    uint32_t off = 0;
+    for (int sh = 0; sh < kNumShapes; ++sh) {
+        if (!shape_cnt[sh]) continue;
+        const bool lut = kShapes[sh][1] == 16 && (size_t)kLutLociCap * (max_hap + 36) * 6 * 4 <= 96 * 1024;
+        const uint32_t dcap = duo_loci_cap(max_hap);
+        const bool duo = kShapes[sh][1] == 16 && dcap >= 2;
+        if (lut) HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), kLutLociCap, 16,
+                                                d_lut_flag + c->buckets.size(), s));
+        if (duo) HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), dcap, 32,
+                                                d_lut_flag + 16 + c->buckets.size(), s));
+        const bool pair = duo && duo_pair_cols(max_hap) != 0;
+        if (pair) HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), kPairLociCap, 32,
+                                                 d_lut_flag + 32 + c->buckets.size(), s));
+        Bucket bk{kShapes[sh][0], kShapes[sh][1], off, shape_cnt[sh], lut};
+        bk.duo = duo; bk.pair = pair;
+        c->buckets.push_back(bk);
+        off += shape_cnt[sh];
+    }
+    uint32_t lut_flag[48] = {0};
+    HIP_TRY(c, hipMemcpyAsync(lut_flag, d_lut_flag, sizeof lut_flag, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (size_t i = 0; i < c->buckets.size(); ++i) {
+        if (lut_flag[i]) c->buckets[i].lut = false;
+        if (lut_flag[16 + i]) c->buckets[i].duo = false;
+        if (lut_flag[16 + i] || lut_flag[32 + i]) c->buckets[i].pair = false;
+    }
+    return VTX_OK;
 }
 
 uint32_t bits_for(uint64_t max_value) {   // bits needed to represent values 0..max_value
@@ -273,6 +400,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
                       &c->d_prep_cnt, &c->d_sort_tmp};
     for (DevBuf* b : bufs) b->release();
+    upload_release(c);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -288,10 +416,8 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
     if (b->hap_bytes > 0xffffffffull || b->read_bytes > 0xffffffffull)
         return fail(c, VTX_E_UNSUPPORTED, "vtx_submit: arenas above 4 GiB need more than one batch");
 
-    // ---- validate + derive rec_locus, buckets, cell count (host; O(records)) ----
-    std::vector<uint32_t> rec_locus(nr);
-    uint32_t next_rec = 0, max_hap = 0, max_read = 0;
-    uint64_t cells = 0;
+    // ---- loci: validated on the host (O(loci)); everything per record happens on the device ----
+    uint32_t next_rec = 0, max_hap = 0;
     for (uint32_t l = 0; l < nl; ++l) {
         const vtx_locus& L = b->loci[l];
         if (L.rec_begin != next_rec) return fail(c, VTX_E_INVAL, "vtx_submit: locus %u: records not contiguous (rec_begin %u, expected %u)", l, L.rec_begin, next_rec);
@@ -301,82 +427,62 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
         if (L.ref_len > kMaxHapLen || L.alt_len > kMaxHapLen)
             return fail(c, VTX_E_UNSUPPORTED, "vtx_submit: locus %u: haplotype longer than %u", l, kMaxHapLen);
         max_hap = std::max(max_hap, std::max(L.ref_len, L.alt_len));
-        for (uint32_t r = L.rec_begin; r < L.rec_begin + L.rec_count; ++r) {
-            const vtx_record& R = b->records[r];
-            if ((uint64_t)R.read_off + R.read_len > b->read_bytes) return fail(c, VTX_E_INVAL, "vtx_submit: record %u: read outside read_arena", r);
-            if (R.read_len > kMaxReadLen) return fail(c, VTX_E_UNSUPPORTED, "vtx_submit: record %u: read length %u above %u", r, R.read_len, kMaxReadLen);
-            if (R.cell_index >= c->cfg.n_barcodes) return fail(c, VTX_E_INVAL, "vtx_submit: record %u: cell_index %u >= n_barcodes %u", r, R.cell_index, c->cfg.n_barcodes);
-            if (r > L.rec_begin) {
-                const vtx_record& P = b->records[r - 1];
-                if (P.cell_index > R.cell_index || (P.cell_index == R.cell_index && P.umi_id > R.umi_id))
-                    return fail(c, VTX_E_INVAL, "vtx_submit: record %u: not sorted by (cell_index, umi_id) within locus %u", r, l);
-            }
-            rec_locus[r] = l;
-            max_read = std::max(max_read, R.read_len);
-            cells += (uint64_t)R.read_len * ((uint64_t)L.ref_len + L.alt_len);
-        }
         next_rec = L.rec_begin + L.rec_count;
     }
     if (next_rec != nr) return fail(c, VTX_E_INVAL, "vtx_submit: %u records not covered by any locus", nr - next_rec);
 
-    // work lists per kernel shape (smallest R*GL that holds the read)
-    std::vector<std::vector<uint32_t>> lists(kNumShapes);
-    for (uint32_t r = 0; r < nr; ++r) {
-        const uint32_t m = b->records[r].read_len;
-        int s = 0;
-        while ((uint32_t)(kShapes[s][0] * kShapes[s][1]) < m) ++s;
-        lists[s].push_back(r);
-    }
-    std::vector<uint32_t> work;
-    work.reserve(nr);
-    c->buckets.clear();
-    for (int s = 0; s < kNumShapes; ++s) {
-        if (lists[s].empty()) continue;
-        // LUT kernel eligibility: every 16-record workgroup must span at most kLutLociCap loci
-        bool lut = kShapes[s][1] == 16 && (size_t)kLutLociCap * (max_hap + 36) * 6 * 4 <= 96 * 1024;
-        for (size_t i = 0; lut && i < lists[s].size(); i += 16) {
-            const size_t j = std::min(lists[s].size(), i + 16) - 1;
-            if (rec_locus[lists[s][j]] - rec_locus[lists[s][i]] + 1 > kLutLociCap) lut = false;
-        }
-        // duo kernel (two records per 16-lane row): 32-record workgroups, up to kDuoLociCap tables
-        const uint32_t dcap = duo_loci_cap(max_hap);
-        bool duo = kShapes[s][1] == 16 && dcap >= 2;
-        for (size_t i = 0; duo && i < lists[s].size(); i += 32) {
-            const size_t j = std::min(lists[s].size(), i + 32) - 1;
-            if (rec_locus[lists[s][j]] - rec_locus[lists[s][i]] + 1 > dcap) duo = false;
-        }
-        bool pair = duo && duo_pair_cols(max_hap) != 0;
-        for (size_t i = 0; pair && i < lists[s].size(); i += 32) {
-            const size_t j = std::min(lists[s].size(), i + 32) - 1;
-            if (rec_locus[lists[s][j]] - rec_locus[lists[s][i]] + 1 > kPairLociCap) pair = false;
-        }
-        Bucket bk{kShapes[s][0], kShapes[s][1], (uint32_t)work.size(), (uint32_t)lists[s].size(), lut};
-        bk.duo = duo; bk.pair = pair;
-        c->buckets.push_back(bk);
-        work.insert(work.end(), lists[s].begin(), lists[s].end());
-    }
-
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const size_t u32 = sizeof(uint32_t);
+    const size_t u32 = sizeof(uint32_t), u64 = sizeof(uint64_t);
     HIP_TRY(c, c->d_loci.reserve((size_t)nl * sizeof(vtx_locus)));
     HIP_TRY(c, c->d_hap.reserve(b->hap_bytes + 16));
     HIP_TRY(c, c->d_read.reserve(b->read_bytes + 16));
     if (int rc = reserve_record_buffers(c, nr)) return rc;
+    HIP_TRY(c, c->d_seq.reserve(nr * u32));
+    HIP_TRY(c, c->d_shape.reserve(nr + 16));
+    HIP_TRY(c, c->d_shape2.reserve(nr + 16));
+    HIP_TRY(c, c->d_prep_cnt.reserve(8 * u64 + 64 * u32));
+    const size_t sort_tmp = vtxk_prep_sort_temp_bytes(nr);
+    HIP_TRY(c, c->d_sort_tmp.reserve(std::max(sort_tmp, vtxk_scan_temp_bytes(std::max(nr, nl)))));
+    unsigned long long* d_counters = c->d_prep_cnt.as<unsigned long long>();
+    uint32_t* d_shape_cnt = (uint32_t*)(d_counters + 8);
+    uint32_t caps[kNumShapes];
+    for (int i = 0; i < kNumShapes; ++i) caps[i] = (uint32_t)(kShapes[i][0] * kShapes[i][1]);
+    HIP_TRY(c, vtxk_prep_set_shapes(caps, kNumShapes));
 
+    // ---- feed: descriptors first, then the record checks run on the device while the read bases still stream in ----
     hipStream_t s = c->stream;
-    if (nl) HIP_TRY(c, hipMemcpyAsync(c->d_loci.p, b->loci, (size_t)nl * sizeof(vtx_locus), hipMemcpyHostToDevice, s));
+    if (int rc = upload(c, {{c->d_loci.p, b->loci, (size_t)nl * sizeof(vtx_locus)},
+                            {c->d_records.p, b->records, (size_t)nr * sizeof(vtx_record)},
+                            {c->d_hap.p, b->hap_arena, (size_t)b->hap_bytes}})) return rc;
+    unsigned long long cnt[8] = {0};
+    uint32_t shape_cnt[16] = {0};
+    HIP_TRY(c, hipMemsetAsync(c->d_prep_cnt.p, 0, 8 * u64 + 64 * u32, s));
+    HIP_TRY(c, hipMemsetAsync(d_counters + 6, 0xff, u64, s));                       // "no offending record"
     if (nr) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_records.p, b->records, (size_t)nr * sizeof(vtx_record), hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(c->d_rec_locus.p, rec_locus.data(), nr * u32, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(c->d_work.p, work.data(), nr * u32, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, vtxk_prep_rec_locus(c->d_loci.as<vtx_locus>(), nl, c->d_rec_locus.as<uint32_t>(), s));
+        HIP_TRY(c, vtxk_prep_check(c->d_records.as<vtx_record>(), nr, c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
+                                   b->read_bytes, kMaxReadLen, c->cfg.n_barcodes, kNumShapes, c->d_shape.as<uint8_t>(),
+                                   c->d_seq.as<uint32_t>(), d_shape_cnt, d_counters, s));
+        // work lists per kernel shape: stable sort of the record numbers by shape
+        HIP_TRY(c, vtxk_prep_sort_u8(c->d_shape.as<uint8_t>(), c->d_shape2.as<uint8_t>(), c->d_seq.as<uint32_t>(),
+                                     c->d_work.as<uint32_t>(), nr, c->d_sort_tmp.p, sort_tmp, s));
     }
-    if (b->hap_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_hap.p, b->hap_arena, b->hap_bytes, hipMemcpyHostToDevice, s));
-    if (b->read_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_read.p, b->read_arena, b->read_bytes, hipMemcpyHostToDevice, s));
-
-    if (int rc = build_groups(c, nr)) return rc;
-    // rec_locus / work are host vectors: the copies must land before they die
+    HIP_TRY(c, hipMemcpyAsync(cnt, d_counters, 7 * u64, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(shape_cnt, d_shape_cnt, sizeof shape_cnt, hipMemcpyDeviceToHost, s));
+    if (int rc = upload(c, {{c->d_read.p, b->read_arena, (size_t)b->read_bytes}})) return rc;     // overlaps with the kernels above
     HIP_TRY(c, hipStreamSynchronize(s));
-    c->n_loci = nl; c->n_records = nr; c->max_hap_len = max_hap; c->max_read_len = max_read; c->cells = cells;
+    if (cnt[6] != ~0ull) {
+        const uint32_t r = (uint32_t)(cnt[6] >> 3), code = (uint32_t)(cnt[6] & 7);
+        const vtx_record& R = b->records[r];
+        if (code == 1) return fail(c, VTX_E_INVAL, "vtx_submit: record %u: read outside read_arena", r);
+        if (code == 2) return fail(c, VTX_E_UNSUPPORTED, "vtx_submit: record %u: read length %u above %u", r, R.read_len, kMaxReadLen);
+        if (code == 3) return fail(c, VTX_E_INVAL, "vtx_submit: record %u: cell_index %u >= n_barcodes %u", r, R.cell_index, c->cfg.n_barcodes);
+        return fail(c, VTX_E_INVAL, "vtx_submit: record %u: not sorted by (cell_index, umi_id) within its locus", r);
+    }
+    if (int rc = make_buckets(c, shape_cnt, max_hap, d_shape_cnt + 16)) return rc;
+    if (int rc = build_groups(c, nr)) return rc;
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->n_loci = nl; c->n_records = nr; c->max_hap_len = max_hap; c->max_read_len = (uint32_t)cnt[5]; c->cells = cnt[3];
     c->submitted = true;
     return VTX_OK;
 }
@@ -478,11 +584,11 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     for (int i = 0; i < kNumShapes; ++i) caps[i] = (uint32_t)(kShapes[i][0] * kShapes[i][1]);
     HIP_TRY(c, vtxk_prep_set_shapes(caps, kNumShapes));
 
-    if (nl) HIP_TRY(c, hipMemcpyAsync(c->d_loci.p, b->loci, (size_t)nl * sizeof(vtx_locus), hipMemcpyHostToDevice, s));
-    if (nr) HIP_TRY(c, hipMemcpyAsync(c->d_raw.p, b->records, (size_t)nr * sizeof(vtx_raw_record), hipMemcpyHostToDevice, s));
-    if (b->hap_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_hap.p, b->hap_arena, b->hap_bytes, hipMemcpyHostToDevice, s));
-    if (b->read_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_read.p, b->read_arena, b->read_bytes, hipMemcpyHostToDevice, s));
-    if (b->tag_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_tags.p, b->tag_arena, b->tag_bytes, hipMemcpyHostToDevice, s));
+    if (int rc = upload(c, {{c->d_loci.p, b->loci, (size_t)nl * sizeof(vtx_locus)},
+                            {c->d_raw.p, b->records, (size_t)nr * sizeof(vtx_raw_record)},
+                            {c->d_hap.p, b->hap_arena, (size_t)b->hap_bytes},
+                            {c->d_tags.p, b->tag_arena, (size_t)b->tag_bytes},
+                            {c->d_read.p, b->read_arena, (size_t)b->read_bytes}})) return rc;
 
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     const uint32_t cell_bits = bits_for(c->cfg.n_barcodes ? c->cfg.n_barcodes - 1 : 0);
@@ -550,35 +656,10 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     uint32_t shape_cnt[16] = {0};
     HIP_TRY(c, hipMemcpyAsync(shape_cnt, d_shape_cnt, sizeof shape_cnt, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    c->buckets.clear();
-    uint32_t off = 0;
-    for (int sh = 0; sh < kNumShapes; ++sh) {
-        if (!shape_cnt[sh]) continue;
-        const bool lut = kShapes[sh][1] == 16 && (size_t)kLutLociCap * (max_hap + 36) * 6 * 4 <= 96 * 1024;
-        const uint32_t dcap = duo_loci_cap(max_hap);
-        const bool duo = kShapes[sh][1] == 16 && dcap >= 2;
-        if (lut) HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), kLutLociCap, 16,
-                                                d_lut_flag + c->buckets.size(), s));
-        if (duo) HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), dcap, 32,
-                                                d_lut_flag + 16 + c->buckets.size(), s));
-        const bool pair = duo && duo_pair_cols(max_hap) != 0;
-        if (pair) HIP_TRY(c, vtxk_prep_lut_check(c->d_work.as<uint32_t>() + off, shape_cnt[sh], c->d_rec_locus.as<uint32_t>(), kPairLociCap, 32,
-                                                 d_lut_flag + 32 + c->buckets.size(), s));
-        Bucket bk{kShapes[sh][0], kShapes[sh][1], off, shape_cnt[sh], lut};
-        bk.duo = duo; bk.pair = pair;
-        c->buckets.push_back(bk);
-        off += shape_cnt[sh];
-    }
-    uint32_t lut_flag[48] = {0};
-    HIP_TRY(c, hipMemcpyAsync(lut_flag, d_lut_flag, sizeof lut_flag, hipMemcpyDeviceToHost, s));
+    if (int rc = make_buckets(c, shape_cnt, max_hap, d_lut_flag)) return rc;
     if (int rc = build_groups(c, n_kept)) return rc;
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    for (size_t i = 0; i < c->buckets.size(); ++i) {
-        if (lut_flag[i]) c->buckets[i].lut = false;
-        if (lut_flag[16 + i]) c->buckets[i].duo = false;
-        if (lut_flag[16 + i] || lut_flag[32 + i]) c->buckets[i].pair = false;
-    }
     float ms = 0;
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->n_loci = nl; c->n_records = n_kept; c->max_hap_len = max_hap; c->max_read_len = (uint32_t)cnt[5]; c->cells = cnt[3];

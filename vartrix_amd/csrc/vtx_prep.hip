@@ -170,6 +170,58 @@ __global__ __launch_bounds__(256) void prep_locus_ranges_kernel(vtx_locus* __res
     if (l < n_loci) { loci[l].rec_count = cnt[l]; loci[l].rec_begin = cnt_scan[l] - cnt[l]; }
 }
 
+// Per-record half of vtx_submit's validation, on the device (the host only checks the loci): bounds of the read,
+// length limit, cell index range, order (cell_index, umi_id) inside the locus; plus what the host loop used to derive —
+// kernel shape per record, shape histogram, DP-cell count, longest read.  counters[6] = min over offending records of
+// (record << 3 | code): 1 read outside the arena, 2 read too long, 3 cell_index >= n_barcodes, 4 order.
+__global__ __launch_bounds__(256) void prep_check_kernel(
+    const vtx_record* __restrict__ records, uint32_t n, const uint32_t* __restrict__ rec_locus,
+    const vtx_locus* __restrict__ loci, uint64_t read_bytes, uint32_t max_read_len, uint32_t n_barcodes, uint32_t n_shapes,
+    uint8_t* __restrict__ shape, uint32_t* __restrict__ seq, uint32_t* __restrict__ shape_cnt,
+    unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t s_shape[16];
+    __shared__ unsigned long long s_cells, s_bad;
+    __shared__ uint32_t s_maxlen;
+    if (threadIdx.x < 16) s_shape[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_cells = 0; s_maxlen = 0; s_bad = ~0ull; }
+    __syncthreads();
+    unsigned long long cells = 0, bad = ~0ull;
+    uint32_t max_rl = 0;
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const vtx_record r = records[j];
+        const uint32_t locus = rec_locus[j];
+        uint32_t code = 0;
+        if ((uint64_t)r.read_off + r.read_len > read_bytes) code = 1;
+        else if (r.read_len > max_read_len) code = 2;
+        else if (r.cell_index >= n_barcodes) code = 3;
+        else if (j > 0 && rec_locus[j - 1] == locus) {
+            const vtx_record q = records[j - 1];
+            if (q.cell_index > r.cell_index || (q.cell_index == r.cell_index && q.umi_id > r.umi_id)) code = 4;
+        }
+        if (code) bad = min(bad, ((unsigned long long)j << 3) | code);
+        const uint32_t rl = min(r.read_len, max_read_len);
+        uint32_t my_shape = 0;
+        while (my_shape + 1 < n_shapes && c_shape_cap[my_shape] < rl) ++my_shape;
+        shape[j] = (uint8_t)my_shape;
+        seq[j] = j;
+        atomicAdd(&s_shape[my_shape], 1u);
+        cells += (unsigned long long)r.read_len * ((unsigned long long)loci[locus].ref_len + loci[locus].alt_len);
+        max_rl = max(max_rl, r.read_len);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        cells += __shfl_down(cells, o); max_rl = max(max_rl, __shfl_down(max_rl, o));
+        bad = min(bad, (unsigned long long)__shfl_down(bad, o));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cells, cells); atomicMax(&s_maxlen, max_rl); atomicMin(&s_bad, bad); }
+    __syncthreads();
+    if (threadIdx.x < n_shapes && s_shape[threadIdx.x]) atomicAdd(&shape_cnt[threadIdx.x], s_shape[threadIdx.x]);
+    if (threadIdx.x == 0) {
+        if (s_cells) atomicAdd(&counters[3], s_cells);
+        if (s_maxlen) atomicMax(&counters[5], (unsigned long long)s_maxlen);
+        if (s_bad != ~0ull) atomicMin(&counters[6], s_bad);
+    }
+}
+
 // LUT-kernel eligibility of one work list: no `group`-record workgroup may span more than `cap` loci
 __global__ __launch_bounds__(256) void prep_lut_check_kernel(const uint32_t* __restrict__ work, uint32_t count,
                                                              const uint32_t* __restrict__ rec_locus, uint32_t cap,
@@ -268,6 +320,16 @@ hipError_t vtxk_prep_lut_check(const uint32_t* work, uint32_t count, const uint3
     if (!count) return hipSuccess;
     const uint32_t groups = (count + group - 1) / group;
     hipLaunchKernelGGL(prep_lut_check_kernel, dim3((groups + 255) / 256), dim3(256), 0, s, work, count, rec_locus, cap, group, flag);
+    return hipGetLastError();
+}
+
+hipError_t vtxk_prep_check(const vtx_record* records, uint32_t n, const uint32_t* rec_locus, const vtx_locus* loci,
+                           uint64_t read_bytes, uint32_t max_read_len, uint32_t n_barcodes, uint32_t n_shapes, uint8_t* shape,
+                           uint32_t* seq, uint32_t* shape_cnt, unsigned long long* counters, hipStream_t s) {
+    if (!n) return hipSuccess;
+    const uint32_t blocks = std::min<uint32_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(prep_check_kernel, dim3(blocks), dim3(256), 0, s, records, n, rec_locus, loci, read_bytes, max_read_len,
+                       n_barcodes, n_shapes, shape, seq, shape_cnt, counters);
     return hipGetLastError();
 }
 
