@@ -75,7 +75,7 @@ struct vtx_ctx {
     DevBuf d_head_cell, d_head_umi, d_cell_scan, d_umi_scan, d_grp_row, d_grp_col, d_umi_cellgrp;
     DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
-    DevBuf d_band_ws, d_band_ws2, d_band, d_hard, d_over, d_over2, d_cnt;   // banded flavour
+    DevBuf d_band_ws, d_band_ws2, d_band, d_hard, d_over, d_over2, d_pend, d_cnt;   // banded flavour
     DevBuf d_redo, d_redo_cnt;                                               // LUT kernel: records with non-ACGTN bytes
     // raw batches (vtx_submit_raw): barcode table + preparation scratch
     DevBuf d_bc_slots, d_bc_hash, d_bc_off, d_bc_bytes;
@@ -394,7 +394,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_alt, &c->d_head_cell, &c->d_head_umi, &c->d_cell_scan, &c->d_umi_scan, &c->d_grp_row,
                       &c->d_grp_col, &c->d_umi_cellgrp, &c->d_cell_cnt, &c->d_umi_cnt, &c->d_keep, &c->d_keep_scan,
                       &c->d_scan_tmp, &c->d_o_row, &c->d_o_col, &c->d_o_alt, &c->d_o_ref, &c->d_o_unk, &c->d_o_val,
-                      &c->d_o_refval, &c->d_band_ws, &c->d_band_ws2, &c->d_band, &c->d_hard, &c->d_over, &c->d_over2,
+                      &c->d_o_refval, &c->d_band_ws, &c->d_band_ws2, &c->d_band, &c->d_hard, &c->d_over, &c->d_over2, &c->d_pend,
                       &c->d_cnt, &c->d_redo, &c->d_redo_cnt, &c->d_bc_slots, &c->d_bc_hash, &c->d_bc_off, &c->d_bc_bytes,
                       &c->d_raw, &c->d_tags, &c->d_raw_locus, &c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2,
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
@@ -755,7 +755,7 @@ int vtx_run(vtx_ctx* c) {
         {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                const uint64_t per_task = 64 * 2 * 4 + 2ull * (((c->max_hap_len + 2 + 7) & ~7u)) * 2 + 4;
+                const uint64_t per_task = vtxk_band_task_words() * 4ull + 2ull * (((c->max_hap_len + 2 + 7) & ~7u)) * 2 + 8;
                 const uint64_t have = (uint64_t)free_b + c->d_band_ws.cap + c->d_band.cap + c->d_hard.cap;
                 chunk_cap = std::max<uint64_t>(chunk_cap, std::min<uint64_t>(1u << 27, have / 3 / per_task));
             }
@@ -764,12 +764,13 @@ int vtx_run(vtx_ctx* c) {
         const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_tasks, chunk_cap);
         const uint32_t band_stride = (c->max_hap_len + 2 + 7) & ~7u;
         uint32_t fast_overflow = 0;
-        HIP_TRY(c, c->d_band_ws.reserve((size_t)chunk * 64 * 2 * sizeof(uint32_t)));   // jump log of the fast kernel (LG entries per task)
+        HIP_TRY(c, c->d_band_ws.reserve((size_t)chunk * vtxk_band_task_words() * sizeof(uint32_t)));   // per task: jump log + spilled pieces
+        HIP_TRY(c, c->d_pend.reserve((size_t)chunk * sizeof(uint32_t)));
         HIP_TRY(c, c->d_band.reserve((size_t)chunk * 2 * band_stride * sizeof(uint16_t)));
         HIP_TRY(c, c->d_hard.reserve((size_t)chunk * sizeof(uint32_t)));
         HIP_TRY(c, c->d_over.reserve((size_t)n_tasks * sizeof(uint32_t)));
         HIP_TRY(c, c->d_cnt.reserve(16 * sizeof(uint32_t)));
-        uint32_t* d_cnt = c->d_cnt.as<uint32_t>();        // [0] hard, [1] overflow (fast), [2..7] reasons; [8],[9] general kernel
+        uint32_t* d_cnt = c->d_cnt.as<uint32_t>();        // [0] hard, [1] overflow, [2..7] reasons; [8],[9] general kernel; [10] stats; [11] pending
         int shape = 0;
         while ((uint32_t)(kShapes[shape][0] * kShapes[shape][1]) < c->max_read_len) ++shape;
         auto masked_dp = [&](uint32_t n_hard) -> int {
@@ -783,16 +784,18 @@ int vtx_run(vtx_ctx* c) {
             return VTX_OK;
         };
         HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 16 * sizeof(uint32_t), s));
-        uint32_t cnt[2] = {0, 0};
+        uint32_t cnt[12] = {0};
+        uint32_t pending_total = 0;
         for (uint64_t base = 0; base < n_tasks; base += chunk) {
             const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, n_tasks - base);
             HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), s));                 // hard count of this chunk
+            HIP_TRY(c, hipMemsetAsync(d_cnt + 11, 0, sizeof(uint32_t), s));            // pending count of this chunk
             HIP_TRY(c, hipEventRecord(c->ev[4], s));
             HIP_TRY(c, vtxk_launch_band_run(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                              c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                              c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
                                              c->d_band_ws.as<uint32_t>(), c->d_band.as<uint16_t>(), band_stride,
-                                             c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), d_cnt,
+                                             c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(), d_cnt,
                                              (uint32_t)(n_tasks / std::max(c->n_loci, 1u)), s));
             HIP_TRY(c, hipEventRecord(c->ev[5], s));
             HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
@@ -801,6 +804,16 @@ int vtx_run(vtx_ctx* c) {
                 float ms = 0;
                 HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
                 band_run_ms += ms;
+            }
+            if (cnt[11]) {
+                // tasks whose piece list overflowed its LDS slots: the same certificate, from their global area
+                HIP_TRY(c, vtxk_launch_band_pending(c->d_pend.as<uint32_t>(), cnt[11], (uint32_t)base, c->d_band_ws.as<uint32_t>(),
+                                                    c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_band.as<uint16_t>(),
+                                                    band_stride, c->d_hard.as<uint32_t>(), d_cnt, s));
+                HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipStreamSynchronize(s));
+                pending_total += cnt[11];
+                ++launches;
             }
             if (int rc = masked_dp(cnt[0])) return rc;
             hard_total += cnt[0];
@@ -845,7 +858,7 @@ int vtx_run(vtx_ctx* c) {
             launches += 2;
         }
         c->fast_overflow = fast_overflow;
-        if (getenv("VTX_DEBUG")) fprintf(stderr, "[vtx] banded: %llu tasks, %u overflowed the fast band kernel, %u hard\n", (unsigned long long)n_tasks, fast_overflow, hard_total);
+        if (getenv("VTX_DEBUG")) fprintf(stderr, "[vtx] banded: %llu tasks, %u overflowed band_run_kernel, %u bounded by the pending kernel, %u hard\n", (unsigned long long)n_tasks, fast_overflow, pending_total, hard_total);
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     uint32_t nnz32 = 0;

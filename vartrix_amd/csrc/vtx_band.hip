@@ -300,6 +300,8 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
 
 #define PS 14       // per-lane LDS entries of band_run_kernel: pieces + segments
 #define LG 64       // jump-log entries per task (global)
+#define SPILL 18    // pieces run_compact may drop from a task's list and still leave it to the pending kernel (global)
+#define TASK_WORDS (LG * 2 + SPILL * 2)   // per-task global area: jump log, then the spilled pieces
 #define SG 10       // chain segments per task
 #define NONE_ID 0xffffffffu
 
@@ -319,7 +321,7 @@ static size_t band_table_stride(uint32_t max_hap, uint32_t n_heads) {
 // 2: capacity exceeded.
 __device__ int band_finish(const uint32_t* mylog, uint32_t lg_n, uint32_t best_id, const uint8_t* x,
                            const uint8_t* yb, uint32_t m, uint32_t n, int32_t ub, uint32_t* verts_out,
-                           uint32_t* nv_out) {
+                           uint32_t* nv_out, int32_t* cert_out) {
         // ---- traceback through the jump log: chain = diagonal segments (x0, y0, len), last first ----
         uint32_t seg_xy[SG], seg_len[SG];
         uint32_t n_seg = 0;
@@ -375,6 +377,7 @@ __device__ int band_finish(const uint32_t* mylog, uint32_t lg_n, uint32_t best_i
         for (int i = 0; i < d1; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
         if (d1 > 0) EMIT();
 #undef EMIT
+        *cert_out = w.best;
         if (w.best == ub) return 0;                          // cert == ub: banded == full == ub
         *nv_out = nv;
         return 1;
@@ -392,7 +395,8 @@ struct run_state {
     uint32_t n_ent, i_next, ev0, ev1, lg_n;
     int32_t best_v; uint32_t best_id;
     bool overflow; uint32_t why;
-    bool ub_ok;            // the list still holds every piece (run_compact dropped none): run_ub() is valid
+    bool ub_ok;            // every piece is still known: in the list, or (n_sp of them) spilled to the task's global area
+    uint32_t n_sp;
 };
 
 __device__ __forceinline__ void run_segq(uint32_t id0, uint32_t dp0, uint32_t len, int32_t qx, int32_t qy, int32_t& bV,
@@ -522,7 +526,7 @@ __device__ void run_advance(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
 // or dominated by an element of another segment);
 // their ends are folded into the running best first.  Updates the indices of the two open pieces.
 __device__ void run_compact(run_state& st, uint32_t* e_id, uint32_t* e_dl, int tid, uint32_t xr, uint32_t& a_idx,
-                            uint32_t& b_idx) {
+                            uint32_t& b_idx, uint32_t* spill) {
     uint32_t w = 0, na = NONE_ID, nb = NONE_ID, ni = NONE_ID;
     for (uint32_t j = 0; j < st.n_ent; ++j) {
         const uint32_t sid = e_id[j * 256 + tid], dl = e_dl[j * 256 + tid];
@@ -560,7 +564,9 @@ __device__ void run_compact(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
             const int32_t v = dp0 + len - 1;
             const uint32_t eid = sid + (uint32_t)(len - 1) * 0x10001u;
             if (v > st.best_v || (v == st.best_v && eid > st.best_id)) { st.best_v = v; st.best_id = eid; }
-            st.ub_ok = false;
+            // the upper bound needs every piece: park the dropped one (start, k-mers) behind the jump log
+            if (st.n_sp < SPILL) { spill[2 * st.n_sp] = sid; spill[2 * st.n_sp + 1] = (uint32_t)len; ++st.n_sp; }
+            else st.ub_ok = false;
             continue;
         }
         if (j == a_idx) na = w;
@@ -592,7 +598,10 @@ __device__ __forceinline__ int32_t ub_join_same(int32_t D) {
 __device__ int32_t run_ub(const uint32_t* e_id, uint32_t* e_dl, int tid, uint32_t n_ent) {
     for (uint32_t j = 0; j < n_ent; ++j) e_dl[j * 256 + tid] &= 0xffffu;
     bool changed = true;
-    for (int pass = 0; pass < 4 && changed; ++pass) {
+    // Pass 0 walks the entries in list order, so an edge q -> p with q before p sees q's settled value; pass 1 only
+    // has to re-examine the BACK edges (q after p), whose q was still unsettled in pass 0.  If that changes nothing
+    // the forward edges are still right; otherwise full passes until nothing moves.
+    for (int pass = 0; pass < 5 && changed; ++pass) {
         changed = false;
         for (uint32_t p = 0; p < n_ent; ++p) {
             const uint32_t idp = e_id[p * 256 + tid], dlp = e_dl[p * 256 + tid];
@@ -600,7 +609,7 @@ __device__ int32_t run_ub(const uint32_t* e_id, uint32_t* e_dl, int tid, uint32_
             const int32_t lp = (int32_t)(dlp & 0xffff) + KMER - 1;
             const int32_t g0 = (int32_t)(dlp >> 16);
             int32_t g = g0;
-            for (uint32_t q = 0; q < n_ent; ++q) {
+            for (uint32_t q = pass == 1 ? p + 1 : 0; q < n_ent; ++q) {
                 if (q == p) continue;
                 const uint32_t idq = e_id[q * 256 + tid], dlq = e_dl[q * 256 + tid];
                 const int32_t xq = (int32_t)(idq >> 16), yq = (int32_t)(idq & 0xffff);
@@ -633,8 +642,8 @@ __global__ __launch_bounds__(256) void band_run_kernel(
     uint32_t max_hap, uint32_t tables_per_pass, uint32_t table_stride,
     int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ logbuf, uint16_t* __restrict__ band, uint32_t band_stride,
-    uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters,
-    uint32_t ablate, uint32_t n_heads) {
+    uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ pending_list,
+    uint32_t* __restrict__ counters, uint32_t ablate, uint32_t n_heads) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x;
     // per-lane LDS arrays, element i of lane tid at [i * 256 + tid]
@@ -667,7 +676,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
     int32_t* my_score = (hap ? alt_score : ref_score) + rid;
     bool done = !have;
     if (have && (m == 0 || n == 0)) { *my_score = 0; done = true; }     // empty read / haplotype: score 0
-    uint32_t* mylog = logbuf + (size_t)slot * LG * 2;
+    uint32_t* mylog = logbuf + (size_t)slot * TASK_WORDS;
     // a task without any k-mer match has the whole matrix in band (Band::full_matrix): hard list, marker slot
 #define PUSH_FULL_MATRIX() { const uint32_t h_ = atomicAdd(&counters[0], 1u); hard_list[h_] = task;             \
                              band[(size_t)h_ * 2 * band_stride] = BAND_FULL_MATRIX; }
@@ -739,7 +748,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
         // adjacent piece: phase 2 treats adjacency as the LCSk++ continuation.  No queries here.
         run_state st;
         st.n_ent = 0; st.i_next = 0; st.ev0 = NONE_ID; st.ev1 = NONE_ID; st.lg_n = 0;
-        st.best_v = -1; st.best_id = 0; st.overflow = false; st.why = 0; st.ub_ok = true;
+        st.best_v = -1; st.best_id = 0; st.overflow = false; st.why = 0; st.ub_ok = true; st.n_sp = 0;
         uint32_t a_idx = NONE_ID, a_id0 = 0, a_len = 0, b_idx = NONE_ID, b_id0 = 0, b_len = 0;
         {
             // The probe is software-pipelined two rows deep — the kernel is latency-bound, and a row's lookups are a
@@ -815,7 +824,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                     if (a_idx != NONE_ID) pm_id[a_idx * 256 + tid] = (pm_id[a_idx * 256 + tid] & 0xffff0000u) | a_len;
                     if (b_idx != NONE_ID) pm_id[b_idx * 256 + tid] = (pm_id[b_idx * 256 + tid] & 0xffff0000u) | b_len;
                     run_advance(st, pm_a, pm_id, tid, pend_id, a_idx, b_idx, mylog);
-                    if (!st.overflow) run_compact(st, pm_a, pm_id, tid, xr, a_idx, b_idx);
+                    if (!st.overflow) run_compact(st, pm_a, pm_id, tid, xr, a_idx, b_idx, mylog + LG * 2);
                     if (st.n_ent == PS && !st.overflow) { st.overflow = true; st.why = 2; }
                     if (!st.overflow) {
                         // a breakpoint may have split an open piece and compaction renumbers: reload the register copies
@@ -854,16 +863,32 @@ __global__ __launch_bounds__(256) void band_run_kernel(
         const uint32_t best_id = st.best_id;
         if (overflow) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[2 + why], 1u); continue; }
         // ================= certificate: chain-of-runs upper bound vs the staircase's own score =================
-        const int32_t ub = st.ub_ok ? run_ub(pm_a, pm_id, tid, st.n_ent) : INT32_MAX;
+        // Tasks whose list lost pieces to run_compact cannot bound here: their pieces (list + spill area) go to
+        // band_pending_kernel, which computes the same bound with a wavefront's lanes over up to PS + SPILL pieces.
+        const bool pending = st.ub_ok && st.n_sp > 0;
+        const int32_t ub = (st.ub_ok && !pending) ? run_ub(pm_a, pm_id, tid, st.n_ent) : INT32_MAX;
         if (ablate == 4) { if (ub == -1) counters[7] = 1; continue; }   // (profiling aid) everything but the staircase walk
         uint32_t verts[4 * SG + 6];
         uint32_t nv = 0;
+        int32_t cert = 0;
         {
-            const int fr = band_finish(mylog, lg_n, best_id, x, yb, m, n, ub, verts, &nv);
+            const int fr = band_finish(mylog, lg_n, best_id, x, yb, m, n, ub, verts, &nv, &cert);
             if (fr == 0) { *my_score = ub; continue; }
             if (fr == 2) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[7], 1u); continue; }
         }
-        if (!st.ub_ok) atomicAdd(&counters[10], 1u);         // statistics: hard only because pieces were dropped
+        if (pending) {
+            // the jump log is dead now: header, list entries, staircase — the spilled pieces already sit behind it
+            mylog[0] = st.n_ent | (st.n_sp << 8) | (nv << 16);
+            mylog[1] = (uint32_t)cert;
+            for (uint32_t j = 0; j < st.n_ent; ++j) {
+                mylog[2 + 2 * j] = pm_a[j * 256 + tid];
+                mylog[3 + 2 * j] = pm_id[j * 256 + tid] & 0xffffu;
+            }
+            for (uint32_t i = 0; i < nv; ++i) mylog[2 + 2 * PS + i] = verts[i];
+            pending_list[atomicAdd(&counters[11], 1u)] = task;
+            continue;
+        }
+        if (!st.ub_ok) atomicAdd(&counters[10], 1u);         // statistics: hard only because too many pieces were dropped
         const uint32_t h = atomicAdd(&counters[0], 1u);
         hard_list[h] = task;
         uint16_t* lo = band + (size_t)h * 2 * band_stride;
@@ -876,6 +901,89 @@ __global__ __launch_bounds__(256) void band_run_kernel(
 #undef PUSH_FULL_MATRIX
 }
 
+
+// =============================================================================================
+// band_pending_kernel — the run bound (see run_ub / the file header) for tasks whose piece list overflowed its LDS
+// slots: their pieces were kept in the task's global area (list entries + spilled ones), together with the
+// certificate and the staircase.  32 lanes per task, one piece per lane, G iterated Jacobi-style (every lane
+// re-evaluates all its in-edges from the values of the previous round) until no lane of the wave moves.
+// cert == ub: the score is written; otherwise the task joins the hard list with its staircase.
+// =============================================================================================
+__global__ __launch_bounds__(256) void band_pending_kernel(
+    const uint32_t* __restrict__ pending, uint32_t n_pending, uint32_t task_base, const uint32_t* __restrict__ logbuf,
+    int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score, uint16_t* __restrict__ band, uint32_t band_stride,
+    uint32_t* __restrict__ hard_list, uint32_t* __restrict__ counters) {
+    __shared__ uint32_t s_id[8][32], s_lg[8][32];      // per task: piece start, (bases << 16 | G)
+    const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const uint32_t pi = blockIdx.x * 8 + grp;
+    const bool have = pi < n_pending;
+    const uint32_t task = have ? pending[pi] : 0;
+    const uint32_t* area = logbuf + (size_t)(task - task_base) * TASK_WORDS;
+    uint32_t hdr = 0; int32_t cert = 0;
+    if (have) { hdr = area[0]; cert = (int32_t)area[1]; }
+    const uint32_t n_ent = hdr & 0xff, n_sp = (hdr >> 8) & 0xff, nv = hdr >> 16;
+    const uint32_t n = n_ent + n_sp;                    // <= PS + SPILL = 32
+    uint32_t id = 0; int32_t len = 0;
+    if ((uint32_t)l < n) {
+        const uint32_t* e = (uint32_t)l < n_ent ? area + 2 + 2 * l : area + LG * 2 + 2 * (l - n_ent);
+        id = e[0]; len = (int32_t)e[1] + KMER - 1;
+    }
+    const int32_t xp = (int32_t)(id >> 16), yp = (int32_t)(id & 0xffff);
+    int32_t g = 0;
+    s_id[grp][l] = id;
+    bool moving = true;
+    for (int round = 0; round < 40 && moving; ++round) {
+        s_lg[grp][l] = ((uint32_t)len << 16) | (uint32_t)g;
+        __builtin_amdgcn_wave_barrier();
+        int32_t gn = g;
+        if ((uint32_t)l < n) {
+            for (uint32_t q = 0; q < n; ++q) {
+                if (q == (uint32_t)l) continue;
+                const uint32_t idq = s_id[grp][q], lgq = s_lg[grp][q];
+                const int32_t xq = (int32_t)(idq >> 16), yq = (int32_t)(idq & 0xffff);
+                const int32_t lq = (int32_t)(lgq >> 16), gq = (int32_t)(lgq & 0xffff);
+                int32_t sdx = max(xq + lq - xp, yq + lq - yp);
+                sdx = min(max(sdx, 0), len - 1);
+                const int32_t t = min(lq - 1, min(xp - xq, yp - yq) + sdx - 1);
+                if (t < 0) continue;
+                const int32_t dd = (yp - xp) - (yq - xq);
+                int32_t J = 5 + abs(dd);
+                if (dd == 0) { const int32_t D = xp + sdx - xq - t - 1; J = D == 0 ? 0 : ub_join_same(D); }
+                gn = max(gn, t + 1 + gq - J - sdx);
+            }
+        }
+        moving = __any(gn != g);
+        g = gn;
+        __builtin_amdgcn_wave_barrier();
+    }
+    int32_t ub = (uint32_t)l < n ? len + g : KMER - 1;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) ub = max(ub, __shfl_xor(ub, o));
+    if (moving) ub = INT32_MAX;                         // not settled: leave the task to the DP
+    if (!have) return;
+    if (ub == cert) {
+        if (l == 0) ((task & 1) ? alt_score : ref_score)[task >> 1] = cert;
+        return;
+    }
+    uint32_t h = 0;
+    if (l == 0) { h = atomicAdd(&counters[0], 1u); hard_list[h] = task; }
+    h = (uint32_t)__shfl((int)h, 0, 32);
+    uint16_t* lo = band + (size_t)h * 2 * band_stride;
+    if (l == 0) { lo[0] = BAND_POLYLINE; lo[1] = (uint16_t)nv; }
+    uint32_t* vout = (uint32_t*)(lo + 2);
+    for (uint32_t i = l; i < nv; i += 32) vout[i] = area[2 + 2 * PS + i];
+}
+
+extern "C" uint32_t vtxk_band_task_words(void) { return TASK_WORDS; }
+
+extern "C" hipError_t vtxk_launch_band_pending(const uint32_t* pending, uint32_t n_pending, uint32_t task_base,
+                                               const uint32_t* logbuf, int32_t* ref_score, int32_t* alt_score, uint16_t* band,
+                                               uint32_t band_stride, uint32_t* hard_list, uint32_t* counters, hipStream_t s) {
+    if (!n_pending) return hipSuccess;
+    hipLaunchKernelGGL(band_pending_kernel, dim3((n_pending + 7) / 8), dim3(256), 0, s, pending, n_pending, task_base, logbuf,
+                       ref_score, alt_score, band, band_stride, hard_list, counters);
+    return hipGetLastError();
+}
 
 // Polyline -> lo / hi arrays, one 16-lane group per hard slot (slots written by band_kernel already
 // hold arrays and are skipped).  Vertices are joined by pure diagonal / vertical / horizontal pieces.
@@ -939,7 +1047,8 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
                                            const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score,
                                            int32_t* alt_score, uint32_t* logbuf, uint16_t* band,
                                            uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
-                                           uint32_t* counters, uint32_t tasks_per_locus, hipStream_t s) {
+                                           uint32_t* pending_list, uint32_t* counters, uint32_t tasks_per_locus,
+                                           hipStream_t s) {
     if (!n_tasks) return hipSuccess;
     const size_t lane_bytes = (size_t)(2 * PS) * 256 * 4;
     // A workgroup of 256 tasks processes its loci in passes of `tables / 2` loci (the k-mer tables live in LDS); in a
@@ -965,7 +1074,7 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     const uint32_t ablate = (uint32_t)(getenv("VTX_BAND_ABLATE") ? atoi(getenv("VTX_BAND_ABLATE")) : 0);
     hipLaunchKernelGGL(band_run_kernel, dim3((n_tasks + 255) / 256), dim3(256), shmem, s, n_tasks, task_base, records,
                        rec_locus, loci, read_arena, hap_arena, max_hap, tables, (uint32_t)tstride, ref_score, alt_score,
-                       logbuf, band, band_stride, hard_list, overflow_list, counters, ablate, n_heads);
+                       logbuf, band, band_stride, hard_list, overflow_list, pending_list, counters, ablate, n_heads);
     return hipGetLastError();
 }
 
