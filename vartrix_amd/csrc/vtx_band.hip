@@ -304,6 +304,8 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
 #define TASK_WORDS (LG * 2 + SPILL * 2)   // per-task global area: jump log, then the spilled pieces
 #define SG 10       // chain segments per task
 #define NONE_ID 0xffffffffu
+#define CH_END 0x7fffu     // end of a k-mer chain / empty bucket (haplotype positions are < 2^15)
+#define CH_UNIQ 0x8000u    // next[y] bit 15: the k-mer at y occurs nowhere else in this haplotype
 
 __device__ __forceinline__ uint32_t kw_hash(uint32_t lo, uint32_t hi, uint32_t head_mask) {
     uint32_t h = lo * 0x9E3779B1u ^ (hi + 0x7F4A7C15u) * 0x85EBCA77u;
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                     kwhi[y] = (uint16_t)((uint32_t)hy[y + 4] | ((uint32_t)hy[y + 5] << 8));
                 }
             }
-            for (uint32_t i = tid; i < n_heads; i += 256) head[i] = 0xffff;
+            for (uint32_t i = tid; i < n_heads; i += 256) head[i] = CH_END;
         }
         __syncthreads();
         if ((uint32_t)tid < n_tab) {     // one lane per table: sequential head insertion, descending y => ascending chains
@@ -719,6 +721,25 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                 }
         }
         __syncthreads();
+        // uniqueness flags: a read k-mer that continues an open piece onto a UNIQUE haplotype k-mer has no other match
+        // in this haplotype, so phase 1 may extend the piece without probing the table (bit 15 of next[y])
+        for (uint32_t t = 0; t < n_tab; ++t) {
+            const vtx_locus loc = loci[lbase + (t >> 1)];
+            const uint32_t hn = (t & 1) ? loc.alt_len : loc.ref_len;
+            uint8_t* tb = tables + (size_t)t * table_stride;
+            const uint32_t* kwlo = (const uint32_t*)tb;
+            const uint16_t* kwhi = (const uint16_t*)(tb + (size_t)max_hap * 4);
+            uint16_t* next = (uint16_t*)kwhi + max_hap;
+            const uint16_t* head = kwhi + 2 * (size_t)max_hap;
+            for (uint32_t y = tid; y + KMER <= hn; y += 256) {
+                const uint32_t lo = kwlo[y]; const uint16_t hi = kwhi[y];
+                uint32_t same = 0;
+                for (uint32_t e = head[kw_hash(lo, hi, n_heads - 1)]; e != CH_END; e = next[e] & CH_END)
+                    same += (kwlo[e] == lo && kwhi[e] == hi);
+                if (same == 1) next[y] = (uint16_t)(next[y] | CH_UNIQ);     // only this thread writes next[y]; readers mask bit 15
+            }
+        }
+        __syncthreads();
         if (done || my_locus < lbase || my_locus >= lbase + loci_per_pass) continue;
         done = true;
         // ---- this lane's table ----
@@ -734,7 +755,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
             uint32_t wl = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
             uint32_t wh = (uint32_t)x[4] | ((uint32_t)x[5] << 8), cntm = 0;
             for (uint32_t xr = 0; xr + KMER <= m; ++xr) {
-                for (uint32_t y = head[kw_hash(wl, wh, n_heads - 1)]; y != 0xffff; y = next[y]) cntm += (kwlo[y] == wl && kwhi[y] == (uint16_t)wh);
+                for (uint32_t y = head[kw_hash(wl, wh, n_heads - 1)]; y != CH_END; y = next[y] & CH_END) cntm += (kwlo[y] == wl && kwhi[y] == (uint16_t)wh);
                 const uint32_t nb = (xr + KMER < m) ? x[xr + KMER] : 0;
                 wl = (wl >> 8) | (wh << 24); wh = ((wh >> 8) & 0xff) | (nb << 8);
             }
@@ -751,72 +772,81 @@ __global__ __launch_bounds__(256) void band_run_kernel(
         st.best_v = -1; st.best_id = 0; st.overflow = false; st.why = 0; st.ub_ok = true; st.n_sp = 0;
         uint32_t a_idx = NONE_ID, a_id0 = 0, a_len = 0, b_idx = NONE_ID, b_id0 = 0, b_len = 0;
         {
-            // The probe is software-pipelined two rows deep — the kernel is latency-bound, and a row's lookups are a
-            // dependent chain (k-mer -> head[h] -> entry fields -> compare): while row xr is processed, the head
-            // lookup of row xr+2 and the fields of the first chain entry of row xr+1 are already in flight.
-            // The read streams through a 64-bit register window (one unaligned 8-byte global load per 8 rows; the
-            // arena is padded, bytes at or beyond m are never used).
-            uint64_t win;
-            __builtin_memcpy(&win, x, 8);
+            // The probe is a flat loop of WORK UNITS, every lane at its own row: a unit is either one step along the
+            // k-mer chain of the lane's current row, or the advance to its next row.  A wavefront therefore pays the
+            // maximum over its lanes of the SUM of their chain steps, not the sum over rows of the per-row maximum
+            // (with 64 lanes nearly every row has one lane with a 3-entry bucket).  The advance first tries the
+            // continuation shortcut: if the piece in `a` continues at (row, y), its last 5 bases are already known to
+            // match, so one byte compare decides the k-mer; and if the haplotype k-mer at y is unique in its
+            // haplotype (CH_UNIQ) there can be no other match in this row — the piece is extended without hashing or
+            // walking a chain.  On clean reads 4 of 5 rows take the shortcut.
+            // The read streams through a 64-bit register window (one unaligned 8-byte global load per 8 rows, issued
+            // four rows ahead; the arena is padded, bytes at or beyond m are never used).
             const uint32_t hmask = n_heads - 1;
+            uint64_t win, win_nx;
+            __builtin_memcpy(&win, x, 8);
+            __builtin_memcpy(&win_nx, x + 8, 8);
             uint32_t wlo = (uint32_t)win;                                    // k-mer word of row xr
             uint32_t whi = (uint32_t)(win >> 32) & 0xffffu;
-            const uint32_t b6 = m > KMER ? (uint32_t)(win >> 48) & 0xffu : 0;
-            uint32_t w1lo = (wlo >> 8) | (whi << 24);                        // ... of row xr + 1
-            uint32_t w1hi = ((whi >> 8) & 0xff) | (b6 << 8);
             uint32_t xr = 0;
             uint32_t ycur = head[kw_hash(wlo, whi, hmask)];                  // chain cursor of row xr
-            uint32_t y1 = (1 + KMER <= m) ? head[kw_hash(w1lo, w1hi, hmask)] : 0xffffu;   // head of row xr + 1
-            uint32_t e_lo, e_nx; uint16_t e_hi;                              // fields of the first chain entry of row xr
-            {
-                const uint32_t yy = ycur == 0xffffu ? 0u : ycur;
-                e_lo = kwlo[yy]; e_hi = kwhi[yy]; e_nx = next[yy];
-            }
-            bool first = true;                                               // the prefetched entry is still to be consumed
+            bool live = true;
             bool service;
             do {
-                // ---- hot loops: kept free of the (rare, large) list-full handling, which sits after them ----
+                // ---- hot loop: kept free of the (rare, large) list-full handling, which sits after it ----
                 service = false;
                 uint32_t pend_id = 0;
-                while (xr + KMER <= m) {
-                    // lookups of the rows ahead (their results are consumed at the bottom of this iteration)
-                    const uint32_t bi = xr + KMER + 1;
-                    if ((bi & 7u) == 0 && bi < m) __builtin_memcpy(&win, x + bi, 8);
-                    const uint32_t nb2 = bi < m ? (uint32_t)(win >> (8 * (bi & 7u))) & 0xffu : 0;
-                    const uint32_t w2lo = (w1lo >> 8) | (w1hi << 24);
-                    const uint32_t w2hi = ((w1hi >> 8) & 0xff) | (nb2 << 8);
-                    const uint32_t y2 = (xr + 2 + KMER <= m) ? head[kw_hash(w2lo, w2hi, hmask)] : 0xffffu;
-                    const uint32_t y1c = y1 == 0xffffu ? 0u : y1;
-                    const uint32_t f_lo = kwlo[y1c], f_nx = next[y1c];
-                    const uint16_t f_hi = kwhi[y1c];
-                    while (ycur != 0xffff) {
+                while (live && !service) {
+                    // (written as two predicated blocks, not if / else with `continue`: with back edges inside the
+                    // branches the structurizer turns one of them into an inner loop, and the lanes of the other kind
+                    // then wait for whole bursts — measured 3x slower than the row-lockstep loop)
+                    const bool chain = ycur != CH_END;
+                    if (chain) {
+                        // ---- unit: one chain entry of row xr ----
                         const uint32_t y = ycur;
-                        uint32_t lo; uint16_t hi;
-                        if (first) { lo = e_lo; hi = e_hi; ycur = e_nx; first = false; }
-                        else { lo = kwlo[y]; hi = kwhi[y]; ycur = next[y]; }
-                        if (lo != wlo || hi != (uint16_t)whi) continue;
-                        const uint32_t id = (xr << 16) | y;
-                        if (a_idx != NONE_ID && id == a_id0 + a_len * 0x10001u) { ++a_len; continue; }
-                        if (b_idx != NONE_ID && id == b_id0 + b_len * 0x10001u) {
-                            ++b_len;
-                            uint32_t t;
-                            t = a_idx; a_idx = b_idx; b_idx = t;
-                            t = a_id0; a_id0 = b_id0; b_id0 = t;
-                            t = a_len; a_len = b_len; b_len = t;
-                            continue;
+                        const uint32_t lo = kwlo[y]; const uint16_t hi = kwhi[y];
+                        ycur = next[y] & CH_END;
+                        if (lo == wlo && hi == (uint16_t)whi) {
+                            const uint32_t id = (xr << 16) | y;
+                            if (a_idx != NONE_ID && id == a_id0 + a_len * 0x10001u) {
+                                ++a_len;
+                            } else if (b_idx != NONE_ID && id == b_id0 + b_len * 0x10001u) {
+                                ++b_len;
+                                uint32_t t;
+                                t = a_idx; a_idx = b_idx; b_idx = t;
+                                t = a_id0; a_id0 = b_id0; b_id0 = t;
+                                t = a_len; a_len = b_len; b_len = t;
+                            } else if (st.n_ent == PS) {
+                                service = true; pend_id = id;
+                            } else {
+                                if (b_idx != NONE_ID) pm_id[b_idx * 256 + tid] = (pm_id[b_idx * 256 + tid] & 0xffff0000u) | b_len;
+                                b_idx = a_idx; b_id0 = a_id0; b_len = a_len;
+                                a_idx = st.n_ent; a_id0 = id; a_len = 1;
+                                pm_a[st.n_ent * 256 + tid] = id; pm_id[st.n_ent * 256 + tid] = 1; ++st.n_ent;
+                            }
                         }
-                        if (st.n_ent == PS) { service = true; pend_id = id; break; }
-                        if (b_idx != NONE_ID) pm_id[b_idx * 256 + tid] = (pm_id[b_idx * 256 + tid] & 0xffff0000u) | b_len;
-                        b_idx = a_idx; b_id0 = a_id0; b_len = a_len;
-                        a_idx = st.n_ent; a_id0 = id; a_len = 1;
-                        pm_a[st.n_ent * 256 + tid] = id; pm_id[st.n_ent * 256 + tid] = 1; ++st.n_ent;
                     }
-                    if (service) break;
-                    // next row: everything it needs was requested above
-                    wlo = w1lo; whi = w1hi; w1lo = w2lo; w1hi = w2hi;
-                    ycur = y1; e_lo = f_lo; e_hi = f_hi; e_nx = f_nx; y1 = y2;
-                    first = true;
-                    ++xr;
+                    if (!chain) {
+                        // ---- unit: advance to row xr + 1 ----
+                        ++xr;
+                        live = xr + KMER <= m;
+                        if (live) {
+                            const uint32_t bi = xr + KMER - 1;               // index of the base that enters the k-mer
+                            if ((bi & 7u) == 0) { win = win_nx; }
+                            if ((bi & 7u) == 4 && (bi | 7u) + 1 < m) __builtin_memcpy(&win_nx, x + (bi | 7u) + 1, 8);
+                            const uint32_t nb = (uint32_t)(win >> (8 * (bi & 7u))) & 0xffu;
+                            wlo = (wlo >> 8) | (whi << 24);
+                            whi = ((whi >> 8) & 0xff) | (nb << 8);
+                            bool cont = false;
+                            if (a_idx != NONE_ID) {
+                                const uint32_t aid = a_id0 + a_len * 0x10001u;   // where piece a would continue
+                                const uint32_t ay = aid & 0xffffu;
+                                cont = (aid >> 16) == xr && ay + KMER <= n && yb[ay + KMER - 1] == nb && (next[ay] & CH_UNIQ);
+                            }
+                            if (cont) ++a_len;                               // the only match of this row
+                            else ycur = head[kw_hash(wlo, whi, hmask)];
+                        }
+                    }
                 }
                 if (service) {
                     // list full: run the chain DP up to this match, drop segments that cannot matter any more,
