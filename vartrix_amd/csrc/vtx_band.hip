@@ -304,18 +304,24 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
 #define TASK_WORDS (LG * 2 + SPILL * 2)   // per-task global area: jump log, then the spilled pieces
 #define SG 10       // chain segments per task
 #define NONE_ID 0xffffffffu
-#define CH_END 0x7fffu     // end of a k-mer chain / empty bucket (haplotype positions are < 2^15)
-#define CH_UNIQ 0x8000u    // next[y] bit 15: the k-mer at y occurs nowhere else in this haplotype
+#define CH_END 0xffffu     // end of a k-mer chain / empty bucket
 
 __device__ __forceinline__ uint32_t kw_hash(uint32_t lo, uint32_t hi, uint32_t head_mask) {
     uint32_t h = lo * 0x9E3779B1u ^ (hi + 0x7F4A7C15u) * 0x85EBCA77u;
     return (h >> 18) & head_mask;
 }
 
+// LDS table of one haplotype (band_run_kernel): ent[y] = {k-mer bytes 0-3, bytes 4-5 | next y << 16} (one 8-byte load per
+// chain step), head[n_heads] u16, bytes[max_hap + 8] raw haplotype bytes (staircase walk), fb[max_hap + 8] flag bytes:
+// fb[y] = (byte y & 0x7f) | 0x80 if the k-mer that ENDS at y is unique in the haplotype (continuation shortcut).
 static size_t band_table_stride(uint32_t max_hap, uint32_t n_heads) {
-    size_t o = (size_t)max_hap * 4 + (size_t)max_hap * 2 * 2 + (size_t)n_heads * 2 + ((size_t)max_hap + 8);
+    size_t o = (size_t)max_hap * 8 + (size_t)n_heads * 2 + 2 * ((size_t)max_hap + 8);
     return (o + 15) & ~(size_t)15;
 }
+#define TB_ENT(tb) ((uint2*)(tb))
+#define TB_HEAD(tb) ((uint16_t*)((tb) + (size_t)max_hap * 8))
+#define TB_BYTES(tb) ((uint8_t*)(TB_HEAD(tb) + n_heads))
+#define TB_FB(tb) (TB_BYTES(tb) + max_hap + 8)
 
 // Tail of band_run_kernel: traceback through the jump log (chain = a few diagonal segments), walk of
 // the anchor staircase (its local score = the lower bound `cert`), polyline for hard tasks.
@@ -647,6 +653,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
     uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ pending_list,
     uint32_t* __restrict__ counters, uint32_t ablate, uint32_t n_heads) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ uint32_t s_hibyte[16];          // per table: the haplotype holds a byte >= 0x80 (no continuation shortcut)
     const int tid = threadIdx.x;
     // per-lane LDS arrays, element i of lane tid at [i * 256 + tid]
     // staircase of ended matches, stored as RUNS: elements (ye0 + t, V0 + 3t, id0 + t*(1,1)), t < len
@@ -692,15 +699,17 @@ __global__ __launch_bounds__(256) void band_run_kernel(
             const uint32_t hn = (t & 1) ? loc.alt_len : loc.ref_len;
             const uint8_t* hy = hap_arena + ((t & 1) ? loc.alt_off : loc.ref_off);
             uint8_t* tb = tables + (size_t)t * table_stride;
-            uint32_t* kwlo = (uint32_t*)tb;
-            uint16_t* kwhi = (uint16_t*)(tb + (size_t)max_hap * 4);
-            uint16_t* head = kwhi + 2 * (size_t)max_hap;
-            uint8_t* bytes = (uint8_t*)(head + n_heads);
+            uint2* ent = TB_ENT(tb);
+            uint16_t* head = TB_HEAD(tb);
+            uint8_t* bytes = TB_BYTES(tb);
+            uint8_t* fb = TB_FB(tb);
+            if (tid == 0) s_hibyte[t] = 0;
             for (uint32_t y = tid; y < hn; y += 256) {
                 bytes[y] = hy[y];
+                fb[y] = hy[y] & 0x7f;
                 if (y + KMER <= hn) {
-                    kwlo[y] = (uint32_t)hy[y] | ((uint32_t)hy[y + 1] << 8) | ((uint32_t)hy[y + 2] << 16) | ((uint32_t)hy[y + 3] << 24);
-                    kwhi[y] = (uint16_t)((uint32_t)hy[y + 4] | ((uint32_t)hy[y + 5] << 8));
+                    ent[y].x = (uint32_t)hy[y] | ((uint32_t)hy[y + 1] << 8) | ((uint32_t)hy[y + 2] << 16) | ((uint32_t)hy[y + 3] << 24);
+                    ent[y].y = (uint32_t)hy[y + 4] | ((uint32_t)hy[y + 5] << 8) | (CH_END << 16);
                 }
             }
             for (uint32_t i = tid; i < n_heads; i += 256) head[i] = CH_END;
@@ -710,33 +719,42 @@ __global__ __launch_bounds__(256) void band_run_kernel(
             const vtx_locus loc = loci[lbase + ((uint32_t)tid >> 1)];
             const uint32_t hn = (tid & 1) ? loc.alt_len : loc.ref_len;
             uint8_t* tb = tables + (size_t)tid * table_stride;
-            const uint32_t* kwlo = (const uint32_t*)tb;
-            uint16_t* kwhi = (uint16_t*)(tb + (size_t)max_hap * 4);
-            uint16_t* next = kwhi + max_hap;
-            uint16_t* head = kwhi + 2 * (size_t)max_hap;
+            uint2* ent = TB_ENT(tb);
+            uint16_t* head = TB_HEAD(tb);
             if (hn >= KMER)
                 for (int y = (int)hn - KMER; y >= 0; --y) {
-                    const uint32_t h = kw_hash(kwlo[y], kwhi[y], n_heads - 1);
-                    next[y] = head[h]; head[h] = (uint16_t)y;
+                    const uint2 e = ent[y];
+                    const uint32_t h = kw_hash(e.x, e.y & 0xffffu, n_heads - 1);
+                    ent[y].y = (e.y & 0xffffu) | ((uint32_t)head[h] << 16);
+                    head[h] = (uint16_t)y;
                 }
         }
         __syncthreads();
         // uniqueness flags: a read k-mer that continues an open piece onto a UNIQUE haplotype k-mer has no other match
-        // in this haplotype, so phase 1 may extend the piece without probing the table (bit 15 of next[y])
+        // in this haplotype, so phase 1 may extend the piece without probing the table.  The flag rides in bit 7 of the
+        // flag byte of the k-mer's LAST base; a haplotype with a byte >= 0x80 gets no flags (shortcut off).
         for (uint32_t t = 0; t < n_tab; ++t) {
             const vtx_locus loc = loci[lbase + (t >> 1)];
             const uint32_t hn = (t & 1) ? loc.alt_len : loc.ref_len;
             uint8_t* tb = tables + (size_t)t * table_stride;
-            const uint32_t* kwlo = (const uint32_t*)tb;
-            const uint16_t* kwhi = (const uint16_t*)(tb + (size_t)max_hap * 4);
-            uint16_t* next = (uint16_t*)kwhi + max_hap;
-            const uint16_t* head = kwhi + 2 * (size_t)max_hap;
+            const uint8_t* bytes = TB_BYTES(tb);
+            for (uint32_t y = tid; y < hn; y += 256) if (bytes[y] & 0x80) s_hibyte[t] = 1;
+        }
+        __syncthreads();
+        for (uint32_t t = 0; t < n_tab; ++t) {
+            if (s_hibyte[t]) continue;
+            const vtx_locus loc = loci[lbase + (t >> 1)];
+            const uint32_t hn = (t & 1) ? loc.alt_len : loc.ref_len;
+            uint8_t* tb = tables + (size_t)t * table_stride;
+            const uint2* ent = TB_ENT(tb);
+            const uint16_t* head = TB_HEAD(tb);
+            uint8_t* fb = TB_FB(tb);
             for (uint32_t y = tid; y + KMER <= hn; y += 256) {
-                const uint32_t lo = kwlo[y]; const uint16_t hi = kwhi[y];
+                const uint2 k = ent[y];
                 uint32_t same = 0;
-                for (uint32_t e = head[kw_hash(lo, hi, n_heads - 1)]; e != CH_END; e = next[e] & CH_END)
-                    same += (kwlo[e] == lo && kwhi[e] == hi);
-                if (same == 1) next[y] = (uint16_t)(next[y] | CH_UNIQ);     // only this thread writes next[y]; readers mask bit 15
+                for (uint32_t e = head[kw_hash(k.x, k.y & 0xffffu, n_heads - 1)]; e != CH_END; e = ent[e].y >> 16)
+                    same += (ent[e].x == k.x && ((ent[e].y ^ k.y) & 0xffffu) == 0);
+                if (same == 1) fb[y + KMER - 1] |= 0x80;      // only this thread touches that byte
             }
         }
         __syncthreads();
@@ -744,18 +762,17 @@ __global__ __launch_bounds__(256) void band_run_kernel(
         done = true;
         // ---- this lane's table ----
         const uint8_t* tb = tables + (size_t)((my_locus - lbase) * 2 + hap) * table_stride;
-        const uint32_t* kwlo = (const uint32_t*)tb;
-        const uint16_t* kwhi = (const uint16_t*)(tb + (size_t)max_hap * 4);
-        const uint16_t* next = kwhi + max_hap;
-        const uint16_t* head = kwhi + 2 * (size_t)max_hap;
-        const uint8_t* yb = (const uint8_t*)(head + n_heads);
+        const uint2* ent = TB_ENT(tb);
+        const uint16_t* head = TB_HEAD(tb);
+        const uint8_t* yb = TB_BYTES(tb);
+        const uint8_t* fb = TB_FB(tb);
         if (m < KMER || n < KMER) { PUSH_FULL_MATRIX() continue; }    // no k-mer: Band::full_matrix
         if (ablate == 1) continue;                           // (profiling aid) table build only
         if (ablate == 2) {                                   // (profiling aid) probe loop only
             uint32_t wl = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
             uint32_t wh = (uint32_t)x[4] | ((uint32_t)x[5] << 8), cntm = 0;
             for (uint32_t xr = 0; xr + KMER <= m; ++xr) {
-                for (uint32_t y = head[kw_hash(wl, wh, n_heads - 1)]; y != CH_END; y = next[y] & CH_END) cntm += (kwlo[y] == wl && kwhi[y] == (uint16_t)wh);
+                for (uint32_t y = head[kw_hash(wl, wh, n_heads - 1)]; y != CH_END; y = ent[y].y >> 16) cntm += (ent[y].x == wl && (ent[y].y & 0xffffu) == wh);
                 const uint32_t nb = (xr + KMER < m) ? x[xr + KMER] : 0;
                 wl = (wl >> 8) | (wh << 24); wh = ((wh >> 8) & 0xff) | (nb << 8);
             }
@@ -801,12 +818,26 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                     // branches the structurizer turns one of them into an inner loop, and the lanes of the other kind
                     // then wait for whole bursts — measured 3x slower than the row-lockstep loop)
                     const bool chain = ycur != CH_END;
+                    // ---- everything either kind of unit reads from LDS, requested together: one round trip per unit.
+                    //      (The kernel waits on LDS latency, not on VALU issue: the lanes of the other kind compute a
+                    //      few addresses they do not need.) ----
+                    const uint2 e = ent[chain ? ycur : 0u];                          // chain step: the entry
+                    const uint32_t xn = xr + 1;                                       // advance: next row ...
+                    const uint32_t bi = xn + KMER - 1;                                // ... the base that enters its k-mer
+                    const uint64_t wsrc = (bi & 7u) == 0 ? win_nx : win;
+                    const uint32_t nb = (uint32_t)(wsrc >> (8 * (bi & 7u))) & 0xffu;
+                    const uint32_t nwlo = (wlo >> 8) | (whi << 24);
+                    const uint32_t nwhi = ((whi >> 8) & 0xff) | (nb << 8);
+                    const uint32_t hd = head[kw_hash(nwlo, nwhi, hmask)];             // ... its bucket
+                    const uint32_t aid = a_id0 + a_len * 0x10001u;                    // ... where piece a would continue
+                    const uint32_t ay = aid & 0xffffu;
+                    const bool a_ok = a_idx != NONE_ID && (aid >> 16) == xn && ay + KMER <= n;
+                    const uint32_t fbv = fb[a_ok ? ay + KMER - 1 : 0u];               // ... flag byte of that k-mer's last base
                     if (chain) {
                         // ---- unit: one chain entry of row xr ----
                         const uint32_t y = ycur;
-                        const uint32_t lo = kwlo[y]; const uint16_t hi = kwhi[y];
-                        ycur = next[y] & CH_END;
-                        if (lo == wlo && hi == (uint16_t)whi) {
+                        ycur = e.y >> 16;
+                        if (e.x == wlo && (e.y & 0xffffu) == whi) {
                             const uint32_t id = (xr << 16) | y;
                             if (a_idx != NONE_ID && id == a_id0 + a_len * 0x10001u) {
                                 ++a_len;
@@ -828,23 +859,15 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                     }
                     if (!chain) {
                         // ---- unit: advance to row xr + 1 ----
-                        ++xr;
-                        live = xr + KMER <= m;
+                        xr = xn;
+                        live = xn + KMER <= m;
                         if (live) {
-                            const uint32_t bi = xr + KMER - 1;               // index of the base that enters the k-mer
-                            if ((bi & 7u) == 0) { win = win_nx; }
+                            if ((bi & 7u) == 0) win = win_nx;
                             if ((bi & 7u) == 4 && (bi | 7u) + 1 < m) __builtin_memcpy(&win_nx, x + (bi | 7u) + 1, 8);
-                            const uint32_t nb = (uint32_t)(win >> (8 * (bi & 7u))) & 0xffu;
-                            wlo = (wlo >> 8) | (whi << 24);
-                            whi = ((whi >> 8) & 0xff) | (nb << 8);
-                            bool cont = false;
-                            if (a_idx != NONE_ID) {
-                                const uint32_t aid = a_id0 + a_len * 0x10001u;   // where piece a would continue
-                                const uint32_t ay = aid & 0xffffu;
-                                cont = (aid >> 16) == xr && ay + KMER <= n && yb[ay + KMER - 1] == nb && (next[ay] & CH_UNIQ);
-                            }
-                            if (cont) ++a_len;                               // the only match of this row
-                            else ycur = head[kw_hash(wlo, whi, hmask)];
+                            wlo = nwlo; whi = nwhi;
+                            // piece a continues onto a k-mer that is unique in the haplotype: the only match of this row
+                            if (a_ok && fbv == nb + 0x80u) ++a_len;
+                            else ycur = hd;
                         }
                     }
                 }
