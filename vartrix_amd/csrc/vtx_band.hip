@@ -797,14 +797,21 @@ __global__ __launch_bounds__(256) void band_run_kernel(
             // match, so one byte compare decides the k-mer; and if the haplotype k-mer at y is unique in its
             // haplotype (CH_UNIQ) there can be no other match in this row — the piece is extended without hashing or
             // walking a chain.  On clean reads 4 of 5 rows take the shortcut.
-            // The read streams through a 64-bit register window (one unaligned 8-byte global load per 8 rows, issued
-            // four rows ahead; the arena is padded, bytes at or beyond m are never used).
+            // The read streams through three 8-byte register blocks A, B, C (bytes [base, base + 24) of the read).  A
+            // lane takes at most one byte per unit, so every 8th unit — a wave-uniform point — each lane that has moved
+            // into B shifts (A = B, B = C) and requests the next C with one 8-byte global load.  That load is only
+            // touched 8 units later: the loop never waits on global memory (a per-lane refill "when needed" makes some
+            // lane issue a load in nearly every iteration, and vmcnt cannot tell the loads of different lanes apart).
+            // The arena is padded; bytes at or beyond m are never used.
             const uint32_t hmask = n_heads - 1;
-            uint64_t win, win_nx;
-            __builtin_memcpy(&win, x, 8);
-            __builtin_memcpy(&win_nx, x + 8, 8);
-            uint32_t wlo = (uint32_t)win;                                    // k-mer word of row xr
-            uint32_t whi = (uint32_t)(win >> 32) & 0xffffu;
+            uint64_t wA, wB, wC;
+            __builtin_memcpy(&wA, x, 8);
+            __builtin_memcpy(&wB, x + 8, 8);
+            __builtin_memcpy(&wC, x + 16, 8);
+            uint32_t wbase = 0;                                              // read index of A's first byte
+            uint32_t unit = 0;
+            uint32_t wlo = (uint32_t)wA;                                     // k-mer word of row xr
+            uint32_t whi = (uint32_t)(wA >> 32) & 0xffffu;
             uint32_t xr = 0;
             uint32_t ycur = head[kw_hash(wlo, whi, hmask)];                  // chain cursor of row xr
             bool live = true;
@@ -817,6 +824,12 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                     // (written as two predicated blocks, not if / else with `continue`: with back edges inside the
                     // branches the structurizer turns one of them into an inner loop, and the lanes of the other kind
                     // then wait for whole bursts — measured 3x slower than the row-lockstep loop)
+                    if ((++unit & 7u) == 0) {                                        // wave-uniform: window refill point
+                        if (xr + KMER - wbase >= 8) { wA = wB; wB = wC; wbase += 8; }  // the next base lies in B: shift
+                        // every lane (re)requests its C block: unconditional, so the result is not merged with the old
+                        // value (a merge would be a use, and a use waits for the load)
+                        __builtin_memcpy(&wC, x + (wbase + 16 < m ? wbase + 16 : 0u), 8);   // (a block past the read is never used)
+                    }
                     const bool chain = ycur != CH_END;
                     // ---- everything either kind of unit reads from LDS, requested together: one round trip per unit.
                     //      (The kernel waits on LDS latency, not on VALU issue: the lanes of the other kind compute a
@@ -824,8 +837,9 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                     const uint2 e = ent[chain ? ycur : 0u];                          // chain step: the entry
                     const uint32_t xn = xr + 1;                                       // advance: next row ...
                     const uint32_t bi = xn + KMER - 1;                                // ... the base that enters its k-mer
-                    const uint64_t wsrc = (bi & 7u) == 0 ? win_nx : win;
-                    const uint32_t nb = (uint32_t)(wsrc >> (8 * (bi & 7u))) & 0xffu;
+                    const uint32_t woff = bi - wbase;                                 // 0 .. 15 by the refill rule
+                    const uint64_t wsrc = (woff & 8u) ? wB : wA;
+                    const uint32_t nb = (uint32_t)(wsrc >> (8 * (woff & 7u))) & 0xffu;
                     const uint32_t nwlo = (wlo >> 8) | (whi << 24);
                     const uint32_t nwhi = ((whi >> 8) & 0xff) | (nb << 8);
                     const uint32_t hd = head[kw_hash(nwlo, nwhi, hmask)];             // ... its bucket
@@ -833,6 +847,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                     const uint32_t ay = aid & 0xffffu;
                     const bool a_ok = a_idx != NONE_ID && (aid >> 16) == xn && ay + KMER <= n;
                     const uint32_t fbv = fb[a_ok ? ay + KMER - 1 : 0u];               // ... flag byte of that k-mer's last base
+                    asm volatile("" ::"v"(e.x), "v"(e.y), "v"(hd), "v"(fbv));        // all three loads before either branch
                     if (chain) {
                         // ---- unit: one chain entry of row xr ----
                         const uint32_t y = ycur;
@@ -862,8 +877,6 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                         xr = xn;
                         live = xn + KMER <= m;
                         if (live) {
-                            if ((bi & 7u) == 0) win = win_nx;
-                            if ((bi & 7u) == 4 && (bi | 7u) + 1 < m) __builtin_memcpy(&win_nx, x + (bi | 7u) + 1, 8);
                             wlo = nwlo; whi = nwhi;
                             // piece a continues onto a k-mer that is unique in the haplotype: the only match of this row
                             if (a_ok && fbv == nb + 0x80u) ++a_len;
