@@ -280,6 +280,19 @@ def test_certificate_decides_most_clean_alignments():
     assert frac < 0.08
 
 
+@pytest.mark.parametrize("kw", [dict(reads_per_locus=4), dict(reads_per_locus=16), dict(reads_per_locus=8, depth_sigma=1.0),
+                                dict(reads_per_locus=3, indel_frac=0.4, read_len_jitter=60), dict(reads_per_locus=70)])
+def test_shallow_and_mixed_depth_loci(kw):
+    """Real single-cell loci are shallow: a handful of reads per locus, log-normal over loci.  The band kernel then runs
+    one wavefront per workgroup with all of its loci resident (tables of up to 32 haplotypes), the DP kernels fall back
+    from the per-locus LUTs when a workgroup spans too many loci: every score and triplet vs the oracle, both flavours."""
+    spec = synth.SynthSpec(n_loci=1500, n_barcodes=400, seed=77, **kw)
+    batch = synth.make_batch(spec)
+    for aligner in ALIGNERS:
+        cfg = default_config(aligner=aligner, scoring_mode="coverage", n_barcodes=spec.n_barcodes)
+        assert_same(batch, cfg, threads=os.cpu_count() or 8)
+
+
 @pytest.mark.parametrize("seed,sub_error,indel_frac,read_len,padding", [
     (101, 0.03, 0.5, 150, 100), (102, 0.08, 0.3, 100, 60), (103, 0.01, 0.7, 151, 120), (104, 0.15, 0.5, 80, 100)])
 def test_banded_large_random_vs_oracle(seed, sub_error, indel_frac, read_len, padding):

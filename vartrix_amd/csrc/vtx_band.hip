@@ -439,17 +439,18 @@ __device__ __forceinline__ void run_gen_event(run_state& st, uint32_t s_id, uint
 }
 
 // events both ways between the (new) segment at index ni and every other started segment
+template <int NT>
 __device__ void run_pair_events(run_state& st, const uint32_t* e_id, const uint32_t* e_dl, int tid, uint32_t ni,
                                 uint32_t open_a, uint32_t open_b) {
-    const uint32_t nid = e_id[ni * 256 + tid], ndl = e_dl[ni * 256 + tid];
+    const uint32_t nid = e_id[ni * NT + tid], ndl = e_dl[ni * NT + tid];
     const uint32_t nd = ndl >> 16, nl = ndl & 0xffff;
     const bool n_open = ni == open_a || ni == open_b;
     if (!(nl >= 2 || n_open || nd + nl - 1 > KMER)) return;     // an isolated k-mer with dp = K: no events either way
     for (uint32_t j = 0; j < st.n_ent && !st.overflow; ++j) {
         if (j == ni) continue;
-        const uint32_t dl = e_dl[j * 256 + tid];
+        const uint32_t dl = e_dl[j * NT + tid];
         if ((dl >> 16) == 0) continue;
-        const uint32_t sid = e_id[j * 256 + tid];
+        const uint32_t sid = e_id[j * NT + tid];
         const bool j_open = j == open_a || j == open_b;
         if (nl >= 2 || n_open) run_gen_event(st, sid, dl >> 16, dl & 0xffff, nid, nd, n_open ? 0xffffu : nl);
         if ((dl & 0xffff) >= 2 || j_open) run_gen_event(st, nid, nd, nl, sid, dl >> 16, j_open ? 0xffffu : (dl & 0xffff));
@@ -457,14 +458,15 @@ __device__ void run_pair_events(run_state& st, const uint32_t* e_id, const uint3
 }
 
 // Process, in match order, every event and every piece start with id < limit.
+template <int NT>
 __device__ void run_advance(run_state& st, uint32_t* e_id, uint32_t* e_dl, int tid, uint32_t limit, uint32_t& open_a,
                             uint32_t& open_b, uint32_t* mylog) {
     while (!st.overflow) {
         // next unstarted piece
         uint32_t i = st.i_next;
-        while (i < st.n_ent && (e_dl[i * 256 + tid] >> 16) != 0) ++i;
+        while (i < st.n_ent && (e_dl[i * NT + tid] >> 16) != 0) ++i;
         st.i_next = i;
-        uint32_t start_id = i < st.n_ent ? e_id[i * 256 + tid] : NONE_ID;
+        uint32_t start_id = i < st.n_ent ? e_id[i * NT + tid] : NONE_ID;
         if (start_id >= limit) start_id = limit;
         // ---- events (possible breakpoints) due before that, in match order ----
         while (!st.overflow) {
@@ -475,9 +477,9 @@ __device__ void run_advance(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
             int32_t bV = INT32_MIN; uint32_t bid = NONE_ID;
             uint32_t e = NONE_ID, eid = 0, edp = 0, elen = 0;
             for (uint32_t j = 0; j < st.n_ent; ++j) {
-                const uint32_t dl = e_dl[j * 256 + tid];
+                const uint32_t dl = e_dl[j * NT + tid];
                 if ((dl >> 16) == 0) continue;
-                const uint32_t sid = e_id[j * 256 + tid];
+                const uint32_t sid = e_id[j * NT + tid];
                 const int32_t sx = (int32_t)(sid >> 16);
                 if ((int32_t)(sid & 0xffff) - sx == my - mx && sx <= mx && mx < sx + (int32_t)(dl & 0xffff)) {
                     e = j; eid = sid; edp = dl >> 16; elen = dl & 0xffff;
@@ -491,25 +493,25 @@ __device__ void run_advance(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
             if (cand <= (int32_t)(edp + t)) continue;          // continuation wins (ties included)
             // breakpoint: split segment e at t; the tail becomes a new segment (keeps e's open status if it was open)
             if (st.n_ent == PS || st.lg_n == LG) { st.overflow = true; st.why = 3; break; }
-            e_dl[e * 256 + tid] = (edp << 16) | t;
-            e_id[st.n_ent * 256 + tid] = mid;
-            e_dl[st.n_ent * 256 + tid] = ((uint32_t)cand << 16) | (elen - t);
+            e_dl[e * NT + tid] = (edp << 16) | t;
+            e_id[st.n_ent * NT + tid] = mid;
+            e_dl[st.n_ent * NT + tid] = ((uint32_t)cand << 16) | (elen - t);
             mylog[2 * st.lg_n] = mid; mylog[2 * st.lg_n + 1] = bid; ++st.lg_n;
             const uint32_t ni = st.n_ent++;
             if (open_a == e) open_a = ni;                     // the growing end of an open piece is its tail
             if (open_b == e) open_b = ni;
-            run_pair_events(st, e_id, e_dl, tid, ni, open_a, open_b);
+            run_pair_events<NT>(st, e_id, e_dl, tid, ni, open_a, open_b);
         }
         if (st.overflow || start_id >= limit || i >= st.n_ent) break;
         // ---- start of piece i ----
         const int32_t px = (int32_t)(start_id >> 16), py = (int32_t)(start_id & 0xffff);
-        const uint32_t plen = e_dl[i * 256 + tid] & 0xffff;
+        const uint32_t plen = e_dl[i * NT + tid] & 0xffff;
         int32_t bV = INT32_MIN; uint32_t bid = NONE_ID;
         int32_t cdp = -1;
         for (uint32_t j = 0; j < st.n_ent; ++j) {
-            const uint32_t dl = e_dl[j * 256 + tid];
+            const uint32_t dl = e_dl[j * NT + tid];
             if ((dl >> 16) == 0) continue;
-            const uint32_t sid = e_id[j * 256 + tid];
+            const uint32_t sid = e_id[j * NT + tid];
             if (sid + (dl & 0xffff) * 0x10001u == start_id) cdp = (int32_t)((dl >> 16) + (dl & 0xffff));
             run_segq(sid, dl >> 16, dl & 0xffff, px, py, bV, bid);
         }
@@ -524,20 +526,21 @@ __device__ void run_advance(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
             if (st.lg_n == LG) { st.overflow = true; st.why = 3; break; }
             mylog[2 * st.lg_n] = start_id; mylog[2 * st.lg_n + 1] = prev; ++st.lg_n;
         }
-        e_dl[i * 256 + tid] = ((uint32_t)dp << 16) | plen;
+        e_dl[i * NT + tid] = ((uint32_t)dp << 16) | plen;
         st.i_next = i + 1;
-        run_pair_events(st, e_id, e_dl, tid, i, open_a, open_b);
+        run_pair_events<NT>(st, e_id, e_dl, tid, i, open_a, open_b);
     }
 }
 
 // Drop started, closed segments none of whose elements can win a query any more (2*(len-1) < x - x0 - dp0 - 1,
 // or dominated by an element of another segment);
 // their ends are folded into the running best first.  Updates the indices of the two open pieces.
+template <int NT>
 __device__ void run_compact(run_state& st, uint32_t* e_id, uint32_t* e_dl, int tid, uint32_t xr, uint32_t& a_idx,
                             uint32_t& b_idx, uint32_t* spill) {
     uint32_t w = 0, na = NONE_ID, nb = NONE_ID, ni = NONE_ID;
     for (uint32_t j = 0; j < st.n_ent; ++j) {
-        const uint32_t sid = e_id[j * 256 + tid], dl = e_dl[j * 256 + tid];
+        const uint32_t sid = e_id[j * NT + tid], dl = e_dl[j * NT + tid];
         const int32_t dp0 = (int32_t)(dl >> 16), len = (int32_t)(dl & 0xffff);
         const bool open = j == a_idx || j == b_idx;
         // an event still queued for one of its matches keeps a segment
@@ -562,7 +565,7 @@ __device__ void run_compact(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
             bool continued = false;
             for (uint32_t k = 0; k < st.n_ent; ++k) {
                 if (k == j) continue;
-                const uint32_t kid = e_id[k * 256 + tid], kdl = e_dl[k * 256 + tid];
+                const uint32_t kid = e_id[k * NT + tid], kdl = e_dl[k * NT + tid];
                 if ((kdl >> 16) == 0) { continued |= kid == next_id; continue; }
                 run_segq(kid, kdl >> 16, kdl & 0xffff, qx, qy, bV, bid);
             }
@@ -580,7 +583,7 @@ __device__ void run_compact(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
         if (j == a_idx) na = w;
         if (j == b_idx) nb = w;
         if (ni == NONE_ID && dp0 == 0) ni = w;
-        if (w != j) { e_id[w * 256 + tid] = sid; e_dl[w * 256 + tid] = dl; }
+        if (w != j) { e_id[w * NT + tid] = sid; e_dl[w * NT + tid] = dl; }
         ++w;
     }
     st.n_ent = w;
@@ -603,8 +606,9 @@ __device__ __forceinline__ int32_t ub_join_same(int32_t D) {
     return min(c, g);
 }
 
+template <int NT>
 __device__ int32_t run_ub(const uint32_t* e_id, uint32_t* e_dl, int tid, uint32_t n_ent) {
-    for (uint32_t j = 0; j < n_ent; ++j) e_dl[j * 256 + tid] &= 0xffffu;
+    for (uint32_t j = 0; j < n_ent; ++j) e_dl[j * NT + tid] &= 0xffffu;
     bool changed = true;
     // Pass 0 walks the entries in list order, so an edge q -> p with q before p sees q's settled value; pass 1 only
     // has to re-examine the BACK edges (q after p), whose q was still unsettled in pass 0.  If that changes nothing
@@ -612,14 +616,14 @@ __device__ int32_t run_ub(const uint32_t* e_id, uint32_t* e_dl, int tid, uint32_
     for (int pass = 0; pass < 5 && changed; ++pass) {
         changed = false;
         for (uint32_t p = 0; p < n_ent; ++p) {
-            const uint32_t idp = e_id[p * 256 + tid], dlp = e_dl[p * 256 + tid];
+            const uint32_t idp = e_id[p * NT + tid], dlp = e_dl[p * NT + tid];
             const int32_t xp = (int32_t)(idp >> 16), yp = (int32_t)(idp & 0xffff);
             const int32_t lp = (int32_t)(dlp & 0xffff) + KMER - 1;
             const int32_t g0 = (int32_t)(dlp >> 16);
             int32_t g = g0;
             for (uint32_t q = pass == 1 ? p + 1 : 0; q < n_ent; ++q) {
                 if (q == p) continue;
-                const uint32_t idq = e_id[q * 256 + tid], dlq = e_dl[q * 256 + tid];
+                const uint32_t idq = e_id[q * NT + tid], dlq = e_dl[q * NT + tid];
                 const int32_t xq = (int32_t)(idq >> 16), yq = (int32_t)(idq & 0xffff);
                 const int32_t lq = (int32_t)(dlq & 0xffff) + KMER - 1, gq = (int32_t)(dlq >> 16);
                 int32_t s = max(xq + lq - xp, yq + lq - yp);
@@ -631,19 +635,20 @@ __device__ int32_t run_ub(const uint32_t* e_id, uint32_t* e_dl, int tid, uint32_
                 if (dd == 0) { const int32_t D = xp + s - xq - t - 1; J = D == 0 ? 0 : ub_join_same(D); }
                 g = max(g, t + 1 + gq - J - s);
             }
-            if (g != g0) { e_dl[p * 256 + tid] = (dlp & 0xffffu) | ((uint32_t)g << 16); changed = true; }
+            if (g != g0) { e_dl[p * NT + tid] = (dlp & 0xffffu) | ((uint32_t)g << 16); changed = true; }
         }
     }
     if (changed) return INT32_MAX;                         // not settled: leave the task to the DP
     int32_t ub = KMER - 1;
     for (uint32_t j = 0; j < n_ent; ++j) {
-        const uint32_t dl = e_dl[j * 256 + tid];
+        const uint32_t dl = e_dl[j * NT + tid];
         ub = max(ub, (int32_t)(dl & 0xffff) + KMER - 1 + (int32_t)(dl >> 16));
     }
     return ub;
 }
 
-__global__ __launch_bounds__(256) void band_run_kernel(
+template <int NT>
+__global__ __launch_bounds__(NT) void band_run_kernel(
     uint32_t n_tasks, uint32_t task_base,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
@@ -653,18 +658,18 @@ __global__ __launch_bounds__(256) void band_run_kernel(
     uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ pending_list,
     uint32_t* __restrict__ counters, uint32_t ablate, uint32_t n_heads) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    __shared__ uint32_t s_hibyte[16];          // per table: the haplotype holds a byte >= 0x80 (no continuation shortcut)
+    __shared__ uint32_t s_hibyte;              // bit t: the haplotype of table t holds a byte >= 0x80 (no continuation shortcut)
     const int tid = threadIdx.x;
-    // per-lane LDS arrays, element i of lane tid at [i * 256 + tid]
+    // per-lane LDS arrays, element i of lane tid at [i * NT + tid]
     // staircase of ended matches, stored as RUNS: elements (ye0 + t, V0 + 3t, id0 + t*(1,1)), t < len
     // (a continued k-mer adds +1 to ye and, with dp + 1, +3 to V = dp + xe + ye)
     uint32_t* pm_a = smem;                     // parked segments: id0 = x0 << 16 | y0
-    uint32_t* pm_id = pm_a + PS * 256;         //                  dp0 << 16 | len
-    uint8_t* tables = (uint8_t*)(pm_id + PS * 256);
-#define PM_A(i) pm_a[(i) * 256 + tid]
-#define PM_ID(i) pm_id[(i) * 256 + tid]
+    uint32_t* pm_id = pm_a + PS * NT;         //                  dp0 << 16 | len
+    uint8_t* tables = (uint8_t*)(pm_id + PS * NT);
+#define PM_A(i) pm_a[(i) * NT + tid]
+#define PM_ID(i) pm_id[(i) * NT + tid]
 
-    const uint32_t slot = blockIdx.x * 256 + tid;
+    const uint32_t slot = blockIdx.x * NT + tid;
     const bool have = slot < n_tasks;
     const uint32_t task = task_base + slot;
     uint32_t rid = 0, hap = 0, my_locus = 0, m = 0, n = 0;
@@ -678,8 +683,8 @@ __global__ __launch_bounds__(256) void band_run_kernel(
         n = hap ? loci[my_locus].alt_len : loci[my_locus].ref_len;
     }
     // locus range of this workgroup (tasks are in record order, records in locus order)
-    const uint32_t first_task = task_base + blockIdx.x * 256;
-    const uint32_t last_task = min(task_base + n_tasks - 1, first_task + 255);
+    const uint32_t first_task = task_base + blockIdx.x * NT;
+    const uint32_t last_task = min(task_base + n_tasks - 1, first_task + NT - 1);
     const uint32_t l_first = rec_locus[first_task >> 1], l_last = rec_locus[last_task >> 1];
     const uint32_t loci_per_pass = tables_per_pass / 2;
     int32_t* my_score = (hap ? alt_score : ref_score) + rid;
@@ -703,8 +708,8 @@ __global__ __launch_bounds__(256) void band_run_kernel(
             uint16_t* head = TB_HEAD(tb);
             uint8_t* bytes = TB_BYTES(tb);
             uint8_t* fb = TB_FB(tb);
-            if (tid == 0) s_hibyte[t] = 0;
-            for (uint32_t y = tid; y < hn; y += 256) {
+            if (tid == 0 && t == 0) s_hibyte = 0;
+            for (uint32_t y = tid; y < hn; y += NT) {
                 bytes[y] = hy[y];
                 fb[y] = hy[y] & 0x7f;
                 if (y + KMER <= hn) {
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                     ent[y].y = (uint32_t)hy[y + 4] | ((uint32_t)hy[y + 5] << 8) | (CH_END << 16);
                 }
             }
-            for (uint32_t i = tid; i < n_heads; i += 256) head[i] = CH_END;
+            for (uint32_t i = tid; i < n_heads; i += NT) head[i] = CH_END;
         }
         __syncthreads();
         if ((uint32_t)tid < n_tab) {     // one lane per table: sequential head insertion, descending y => ascending chains
@@ -738,18 +743,18 @@ __global__ __launch_bounds__(256) void band_run_kernel(
             const uint32_t hn = (t & 1) ? loc.alt_len : loc.ref_len;
             uint8_t* tb = tables + (size_t)t * table_stride;
             const uint8_t* bytes = TB_BYTES(tb);
-            for (uint32_t y = tid; y < hn; y += 256) if (bytes[y] & 0x80) s_hibyte[t] = 1;
+            for (uint32_t y = tid; y < hn; y += NT) if (bytes[y] & 0x80) atomicOr(&s_hibyte, 1u << t);
         }
         __syncthreads();
         for (uint32_t t = 0; t < n_tab; ++t) {
-            if (s_hibyte[t]) continue;
+            if ((s_hibyte >> t) & 1u) continue;
             const vtx_locus loc = loci[lbase + (t >> 1)];
             const uint32_t hn = (t & 1) ? loc.alt_len : loc.ref_len;
             uint8_t* tb = tables + (size_t)t * table_stride;
             const uint2* ent = TB_ENT(tb);
             const uint16_t* head = TB_HEAD(tb);
             uint8_t* fb = TB_FB(tb);
-            for (uint32_t y = tid; y + KMER <= hn; y += 256) {
+            for (uint32_t y = tid; y + KMER <= hn; y += NT) {
                 const uint2 k = ent[y];
                 uint32_t same = 0;
                 for (uint32_t e = head[kw_hash(k.x, k.y & 0xffffu, n_heads - 1)]; e != CH_END; e = ent[e].y >> 16)
@@ -865,10 +870,10 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                             } else if (st.n_ent == PS) {
                                 service = true; pend_id = id;
                             } else {
-                                if (b_idx != NONE_ID) pm_id[b_idx * 256 + tid] = (pm_id[b_idx * 256 + tid] & 0xffff0000u) | b_len;
+                                if (b_idx != NONE_ID) pm_id[b_idx * NT + tid] = (pm_id[b_idx * NT + tid] & 0xffff0000u) | b_len;
                                 b_idx = a_idx; b_id0 = a_id0; b_len = a_len;
                                 a_idx = st.n_ent; a_id0 = id; a_len = 1;
-                                pm_a[st.n_ent * 256 + tid] = id; pm_id[st.n_ent * 256 + tid] = 1; ++st.n_ent;
+                                pm_a[st.n_ent * NT + tid] = id; pm_id[st.n_ent * NT + tid] = 1; ++st.n_ent;
                             }
                         }
                     }
@@ -887,26 +892,26 @@ __global__ __launch_bounds__(256) void band_run_kernel(
                 if (service) {
                     // list full: run the chain DP up to this match, drop segments that cannot matter any more,
                     // then open the pending piece and resume the probe where it stopped
-                    if (a_idx != NONE_ID) pm_id[a_idx * 256 + tid] = (pm_id[a_idx * 256 + tid] & 0xffff0000u) | a_len;
-                    if (b_idx != NONE_ID) pm_id[b_idx * 256 + tid] = (pm_id[b_idx * 256 + tid] & 0xffff0000u) | b_len;
-                    run_advance(st, pm_a, pm_id, tid, pend_id, a_idx, b_idx, mylog);
-                    if (!st.overflow) run_compact(st, pm_a, pm_id, tid, xr, a_idx, b_idx, mylog + LG * 2);
+                    if (a_idx != NONE_ID) pm_id[a_idx * NT + tid] = (pm_id[a_idx * NT + tid] & 0xffff0000u) | a_len;
+                    if (b_idx != NONE_ID) pm_id[b_idx * NT + tid] = (pm_id[b_idx * NT + tid] & 0xffff0000u) | b_len;
+                    run_advance<NT>(st, pm_a, pm_id, tid, pend_id, a_idx, b_idx, mylog);
+                    if (!st.overflow) run_compact<NT>(st, pm_a, pm_id, tid, xr, a_idx, b_idx, mylog + LG * 2);
                     if (st.n_ent == PS && !st.overflow) { st.overflow = true; st.why = 2; }
                     if (!st.overflow) {
                         // a breakpoint may have split an open piece and compaction renumbers: reload the register copies
-                        if (a_idx != NONE_ID) { a_id0 = pm_a[a_idx * 256 + tid]; a_len = pm_id[a_idx * 256 + tid] & 0xffff; }
+                        if (a_idx != NONE_ID) { a_id0 = pm_a[a_idx * NT + tid]; a_len = pm_id[a_idx * NT + tid] & 0xffff; }
                         if (b_idx != NONE_ID) {
-                            b_id0 = pm_a[b_idx * 256 + tid]; b_len = pm_id[b_idx * 256 + tid] & 0xffff;
-                            pm_id[b_idx * 256 + tid] = (pm_id[b_idx * 256 + tid] & 0xffff0000u) | b_len;
+                            b_id0 = pm_a[b_idx * NT + tid]; b_len = pm_id[b_idx * NT + tid] & 0xffff;
+                            pm_id[b_idx * NT + tid] = (pm_id[b_idx * NT + tid] & 0xffff0000u) | b_len;
                         }
                         b_idx = a_idx; b_id0 = a_id0; b_len = a_len;
                         a_idx = st.n_ent; a_id0 = pend_id; a_len = 1;
-                        pm_a[st.n_ent * 256 + tid] = pend_id; pm_id[st.n_ent * 256 + tid] = 1; ++st.n_ent;
+                        pm_a[st.n_ent * NT + tid] = pend_id; pm_id[st.n_ent * NT + tid] = 1; ++st.n_ent;
                     }
                 }
             } while (service && !st.overflow);
-            if (a_idx != NONE_ID) pm_id[a_idx * 256 + tid] = (pm_id[a_idx * 256 + tid] & 0xffff0000u) | a_len;
-            if (b_idx != NONE_ID) pm_id[b_idx * 256 + tid] = (pm_id[b_idx * 256 + tid] & 0xffff0000u) | b_len;
+            if (a_idx != NONE_ID) pm_id[a_idx * NT + tid] = (pm_id[a_idx * NT + tid] & 0xffff0000u) | a_len;
+            if (b_idx != NONE_ID) pm_id[b_idx * NT + tid] = (pm_id[b_idx * NT + tid] & 0xffff0000u) | b_len;
         }
         bool overflow = st.overflow;
         uint32_t why = st.why;
@@ -915,13 +920,13 @@ __global__ __launch_bounds__(256) void band_run_kernel(
         // ================= phase 2: the rest of the chain DP =================
         if (!overflow) {
             uint32_t no_a = NONE_ID, no_b = NONE_ID;
-            run_advance(st, pm_a, pm_id, tid, NONE_ID, no_a, no_b, mylog);
+            run_advance<NT>(st, pm_a, pm_id, tid, NONE_ID, no_a, no_b, mylog);
             overflow = st.overflow; why = st.why;
             // best match = end of the segment with the largest (dp, index)
             for (uint32_t j = 0; j < st.n_ent && !overflow; ++j) {
-                const uint32_t dl = pm_id[j * 256 + tid];
+                const uint32_t dl = pm_id[j * NT + tid];
                 const int32_t v = (int32_t)((dl >> 16) + (dl & 0xffff)) - 1;
-                const uint32_t eid = pm_a[j * 256 + tid] + ((dl & 0xffff) - 1) * 0x10001u;
+                const uint32_t eid = pm_a[j * NT + tid] + ((dl & 0xffff) - 1) * 0x10001u;
                 if (v > st.best_v || (v == st.best_v && eid > st.best_id)) { st.best_v = v; st.best_id = eid; }
             }
         }
@@ -932,7 +937,7 @@ __global__ __launch_bounds__(256) void band_run_kernel(
         // Tasks whose list lost pieces to run_compact cannot bound here: their pieces (list + spill area) go to
         // band_pending_kernel, which computes the same bound with a wavefront's lanes over up to PS + SPILL pieces.
         const bool pending = st.ub_ok && st.n_sp > 0;
-        const int32_t ub = (st.ub_ok && !pending) ? run_ub(pm_a, pm_id, tid, st.n_ent) : INT32_MAX;
+        const int32_t ub = (st.ub_ok && !pending) ? run_ub<NT>(pm_a, pm_id, tid, st.n_ent) : INT32_MAX;
         if (ablate == 4) { if (ub == -1) counters[7] = 1; continue; }   // (profiling aid) everything but the staircase walk
         uint32_t verts[4 * SG + 6];
         uint32_t nv = 0;
@@ -947,8 +952,8 @@ __global__ __launch_bounds__(256) void band_run_kernel(
             mylog[0] = st.n_ent | (st.n_sp << 8) | (nv << 16);
             mylog[1] = (uint32_t)cert;
             for (uint32_t j = 0; j < st.n_ent; ++j) {
-                mylog[2 + 2 * j] = pm_a[j * 256 + tid];
-                mylog[3 + 2 * j] = pm_id[j * 256 + tid] & 0xffffu;
+                mylog[2 + 2 * j] = pm_a[j * NT + tid];
+                mylog[3 + 2 * j] = pm_id[j * NT + tid] & 0xffffu;
             }
             for (uint32_t i = 0; i < nv; ++i) mylog[2 + 2 * PS + i] = verts[i];
             pending_list[atomicAdd(&counters[11], 1u)] = task;
@@ -1116,31 +1121,48 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
                                            uint32_t* pending_list, uint32_t* counters, uint32_t tasks_per_locus,
                                            hipStream_t s) {
     if (!n_tasks) return hipSuccess;
-    const size_t lane_bytes = (size_t)(2 * PS) * 256 * 4;
-    // A workgroup of 256 tasks processes its loci in passes of `tables / 2` loci (the k-mer tables live in LDS); in a
-    // pass only the lanes of those loci work, so every extra pass repeats the per-task code for the whole wave.
-    // Deep data (>= 192 tasks per locus, <= 3 loci per workgroup): 512-entry head arrays -> two loci fit next to the
-    // 28 KiB of lane arrays at 4 workgroups per CU, one pass per workgroup (2048-entry heads fit one locus: 109 ms
-    // instead of 91 ms on config 3; 256-entry heads: 101 ms, the chains get longer).  Shallow data: a 78 KiB budget
-    // (2 workgroups per CU) keeps 6 loci resident per pass, 8 with 256-entry heads below 48 tasks per locus.
-    const bool shallow = tasks_per_locus < 192;
+    // Deep data (>= 64 tasks per locus): 256-task workgroups.  A workgroup processes its loci in passes of `tables / 2`
+    // loci (the k-mer tables live in LDS); in a pass only the lanes of those loci work.  512-entry head arrays: two loci
+    // fit next to the 28 KiB of lane arrays at 4 workgroups per CU, one pass per workgroup nearly always (2048-entry heads
+    // fit one locus: 109 ms instead of 91 ms on config 3; 256-entry heads: 101 ms, the chains get longer).
+    // Shallow data: one WAVEFRONT per workgroup (64 tasks), all of its loci resident at once when they fit — with
+    // 256-task workgroups the wavefronts of a workgroup took turns (a pass holds the loci of one wavefront's tasks and
+    // the other three wait at the barrier), so a CU had two working wavefronts; now every resident wavefront works.
+    const bool wave_wg = tasks_per_locus < 64;
+    const uint32_t nt = wave_wg ? 64 : 256;
+    const size_t lane_bytes = (size_t)(2 * PS) * nt * 4;
     uint32_t n_heads = tasks_per_locus < 48 ? 256 : 512;
     if (getenv("VTX_BAND_HEADS")) n_heads = (uint32_t)atoi(getenv("VTX_BAND_HEADS"));   // experiment knob (power of two)
     const size_t tstride = band_table_stride(max_hap, n_heads);
-    size_t budget = (shallow ? 78 : (PS <= 14 ? 40 : 52)) * 1024;   // lane arrays + haplotype tables
-    uint32_t tables = (uint32_t)((budget - std::min(budget, lane_bytes)) / tstride) & ~1u;
-    if (tables < 2) tables = 2;
-    if (tables > 16) tables = 16;
-    const size_t shmem = lane_bytes + (size_t)tables * tstride;
-    if (shmem > 160 * 1024) return hipErrorInvalidValue;
-    if (shmem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)band_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
+    uint32_t tables;
+    if (wave_wg) {
+        // loci of 64 consecutive tasks (+1 for the straddling locus), at most what 52 KiB hold (3 workgroups per CU)
+        const uint32_t want = 2 * (64 / std::max(tasks_per_locus, 1u) + 2);
+        const uint32_t fit = (uint32_t)((52 * 1024 - lane_bytes) / tstride) & ~1u;
+        tables = std::min(want, fit);
+    } else {
+        const size_t budget = (tasks_per_locus < 192 ? 78 : 40) * 1024 - 64;   // lane arrays + haplotype tables (+ 128 B static)
+        tables = (uint32_t)((budget - std::min(budget, lane_bytes)) / tstride) & ~1u;
     }
+    if (tables < 2) tables = 2;
+    if (tables > 32) tables = 32;
+    const size_t shmem = lane_bytes + (size_t)tables * tstride;
+    if (shmem > 160 * 1024 - 256) return hipErrorInvalidValue;
     const uint32_t ablate = (uint32_t)(getenv("VTX_BAND_ABLATE") ? atoi(getenv("VTX_BAND_ABLATE")) : 0);
-    hipLaunchKernelGGL(band_run_kernel, dim3((n_tasks + 255) / 256), dim3(256), shmem, s, n_tasks, task_base, records,
-                       rec_locus, loci, read_arena, hap_arena, max_hap, tables, (uint32_t)tstride, ref_score, alt_score,
-                       logbuf, band, band_stride, hard_list, overflow_list, pending_list, counters, ablate, n_heads);
+#define LAUNCH_RUN(NTV)                                                                                              \
+    {                                                                                                                \
+        if (shmem > 48 * 1024) {                                                                                     \
+            hipError_t e = hipFuncSetAttribute((const void*)band_run_kernel<NTV>,                                    \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);              \
+            if (e != hipSuccess) return e;                                                                           \
+        }                                                                                                            \
+        hipLaunchKernelGGL(band_run_kernel<NTV>, dim3((n_tasks + NTV - 1) / NTV), dim3(NTV), shmem, s, n_tasks,      \
+                           task_base, records, rec_locus, loci, read_arena, hap_arena, max_hap, tables,              \
+                           (uint32_t)tstride, ref_score, alt_score, logbuf, band, band_stride, hard_list,            \
+                           overflow_list, pending_list, counters, ablate, n_heads);                                  \
+    }
+    if (wave_wg) LAUNCH_RUN(64) else LAUNCH_RUN(256)
+#undef LAUNCH_RUN
     return hipGetLastError();
 }
 
