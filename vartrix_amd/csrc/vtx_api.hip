@@ -64,6 +64,10 @@ thread_local std::string g_create_err;
 struct vtx_ctx {
     vtx_config cfg{};
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;           // side stream: the general band kernel runs beside the pending / masked kernels
+    hipEvent_t ev2 = nullptr;
+    uint32_t* h_pin = nullptr;               // pinned words for counters read back asynchronously (a D2H copy into pageable
+                                             // memory blocks the host until the stream reaches it)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string err;
     bool submitted = false, ran = false;
@@ -75,7 +79,7 @@ struct vtx_ctx {
     DevBuf d_head_cell, d_head_umi, d_cell_scan, d_umi_scan, d_grp_row, d_grp_col, d_umi_cellgrp;
     DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
-    DevBuf d_band_ws, d_band_ws2, d_band, d_hard, d_over, d_over2, d_pend, d_cnt;   // banded flavour
+    DevBuf d_band_ws, d_band_ws2, d_band, d_hard, d_over, d_over2, d_pend, d_cnt, d_band2, d_hard2;   // banded flavour
     DevBuf d_redo, d_redo_cnt;                                               // LUT kernel: records with non-ACGTN bytes
     // raw batches (vtx_submit_raw): barcode table + preparation scratch
     DevBuf d_bc_slots, d_bc_hash, d_bc_off, d_bc_bytes;
@@ -394,7 +398,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_alt, &c->d_head_cell, &c->d_head_umi, &c->d_cell_scan, &c->d_umi_scan, &c->d_grp_row,
                       &c->d_grp_col, &c->d_umi_cellgrp, &c->d_cell_cnt, &c->d_umi_cnt, &c->d_keep, &c->d_keep_scan,
                       &c->d_scan_tmp, &c->d_o_row, &c->d_o_col, &c->d_o_alt, &c->d_o_ref, &c->d_o_unk, &c->d_o_val,
-                      &c->d_o_refval, &c->d_band_ws, &c->d_band_ws2, &c->d_band, &c->d_hard, &c->d_over, &c->d_over2, &c->d_pend,
+                      &c->d_o_refval, &c->d_band_ws, &c->d_band_ws2, &c->d_band, &c->d_hard, &c->d_over, &c->d_over2, &c->d_pend, &c->d_band2, &c->d_hard2,
                       &c->d_cnt, &c->d_redo, &c->d_redo_cnt, &c->d_bc_slots, &c->d_bc_hash, &c->d_bc_off, &c->d_bc_bytes,
                       &c->d_raw, &c->d_tags, &c->d_raw_locus, &c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2,
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
@@ -402,6 +406,9 @@ void vtx_destroy(vtx_ctx* c) {
     for (DevBuf* b : bufs) b->release();
     upload_release(c);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev2) (void)hipEventDestroy(c->ev2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -773,14 +780,73 @@ int vtx_run(vtx_ctx* c) {
         uint32_t* d_cnt = c->d_cnt.as<uint32_t>();        // [0] hard, [1] overflow, [2..7] reasons; [8],[9] general kernel; [10] stats; [11] pending
         int shape = 0;
         while ((uint32_t)(kShapes[shape][0] * kShapes[shape][1]) < c->max_read_len) ++shape;
-        auto masked_dp = [&](uint32_t n_hard) -> int {
-            HIP_TRY(c, vtxk_launch_band_expand(c->d_hard.as<uint32_t>(), n_hard, c->d_records.as<vtx_record>(),
-                                               c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_band.as<uint16_t>(),
-                                               band_stride, s));
-            HIP_TRY(c, vtxk_launch_sw_banded(kShapes[shape][0], kShapes[shape][1], n_hard, c->d_hard.as<uint32_t>(),
-                                             c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
-                                             c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_band.as<uint16_t>(), band_stride,
-                                             c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len, s));
+        auto masked_dp = [&](uint32_t n_hard, uint32_t* hard, uint16_t* band, hipStream_t st) -> int {
+            HIP_TRY(c, vtxk_launch_band_expand(hard, n_hard, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                               c->d_loci.as<vtx_locus>(), band, band_stride, st));
+            HIP_TRY(c, vtxk_launch_sw_banded(kShapes[shape][0], kShapes[shape][1], n_hard, hard, c->d_records.as<vtx_record>(),
+                                             c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                             c->d_hap.as<uint8_t>(), band, band_stride, c->d_ref.as<int32_t>(),
+                                             c->d_alt.as<int32_t>(), c->max_hap_len, st));
+            return VTX_OK;
+        };
+        // The general band kernel (tasks band_run_kernel could not hold) is a handful of serial lanes: ~4.5 ms of latency
+        // for 0.1 % of config 3.  It runs on a side stream, with its own hard list, beside the pending kernel and the
+        // masked DP of the last chunk.  Started once the overflow list is complete; finished (host loop: slabs grow
+        // until every task fits) after the main path's launches are queued.
+        if (!c->stream2) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev2, hipEventDisableTiming));
+            HIP_TRY(c, hipHostMalloc((void**)&c->h_pin, 64 * sizeof(uint32_t), hipHostMallocDefault));
+        }
+        hipStream_t s2 = c->stream2;
+        struct { uint32_t n_over = 0, cap2 = 0, todo = 0, off = 0, total = 0; const uint32_t* tasks = nullptr; bool active = false; uint32_t gcnt[2] = {0, 0}; } fb;
+        auto fallback_launch = [&]() -> int {
+            const uint64_t worst = (uint64_t)c->max_read_len * c->max_hap_len;
+            if (fb.cap2 >= worst && fb.cap2 >= 512) return fail(c, VTX_E_STATE, "vtx_run: band kernel overflow with a worst-case slab");
+            fb.cap2 = (uint32_t)std::max<uint64_t>(std::min<uint64_t>((uint64_t)fb.cap2 * 16, worst), 512);
+            const size_t stride2 = vtxk_band_ws_stride(fb.cap2, c->max_hap_len);
+            HIP_TRY(c, c->d_band_ws2.reserve((size_t)fb.todo * stride2));
+            HIP_TRY(c, hipMemsetAsync(d_cnt + 9, 0, sizeof(uint32_t), s2));
+            uint32_t* other = c->d_over2.as<uint32_t>() + ((fb.tasks == c->d_over2.as<uint32_t>()) ? fb.n_over : 0);
+            HIP_TRY(c, vtxk_launch_band(fb.tasks, fb.todo, 0, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                        c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                        c->d_band_ws2.as<uint8_t>(), stride2, fb.cap2, c->max_hap_len, c->d_ref.as<int32_t>(),
+                                        c->d_alt.as<int32_t>(), c->d_band2.as<uint16_t>(), band_stride, c->d_hard2.as<uint32_t>(),
+                                        other, d_cnt + 8, s2));
+            HIP_TRY(c, hipMemcpyAsync(c->h_pin, d_cnt + 8, sizeof fb.gcnt, hipMemcpyDeviceToHost, s2));   // pinned: does not block
+            ++launches;
+            return VTX_OK;
+        };
+        auto fallback_start = [&](uint32_t off, uint32_t total) -> int {   // the overflow list d_over[0, total) is complete and visible
+            const uint32_t n_over = std::min(chunk, total - off);            // slices of at most one chunk (bounds d_band2)
+            fb.off = off; fb.total = total;
+            fb.n_over = n_over; fb.todo = n_over; fb.cap2 = 512 / 16; fb.tasks = c->d_over.as<uint32_t>() + off; fb.active = true;
+            HIP_TRY(c, c->d_over2.reserve(2 * (size_t)n_over * sizeof(uint32_t)));
+            HIP_TRY(c, c->d_hard2.reserve((size_t)n_over * sizeof(uint32_t)));
+            HIP_TRY(c, c->d_band2.reserve((size_t)n_over * 2 * band_stride * sizeof(uint16_t)));
+            HIP_TRY(c, hipMemsetAsync(d_cnt + 8, 0, 2 * sizeof(uint32_t), s2));
+            return fallback_launch();
+        };
+        auto fallback_finish = [&]() -> int {
+            if (!fb.active) return VTX_OK;
+            for (;;) {
+                for (;;) {
+                    HIP_TRY(c, hipStreamSynchronize(s2));
+                    fb.gcnt[0] = c->h_pin[0]; fb.gcnt[1] = c->h_pin[1];
+                    // tasks that still do not fit were written to the other half of d_over2: rerun them with a larger slab
+                    fb.tasks = c->d_over2.as<uint32_t>() + ((fb.tasks == c->d_over2.as<uint32_t>()) ? fb.n_over : 0);
+                    fb.todo = fb.gcnt[1];
+                    if (!fb.todo) break;
+                    if (int rc = fallback_launch()) return rc;
+                }
+                if (int rc = masked_dp(fb.gcnt[0], c->d_hard2.as<uint32_t>(), c->d_band2.as<uint16_t>(), s2)) return rc;
+                hard_total += fb.gcnt[0];
+                launches += 2;
+                if (fb.off + fb.n_over >= fb.total) break;
+                if (int rc = fallback_start(fb.off + fb.n_over, fb.total)) return rc;      // next slice (same stream: in order)
+            }
+            HIP_TRY(c, hipEventRecord(c->ev2, s2));
+            HIP_TRY(c, hipStreamWaitEvent(s, c->ev2, 0));             // the reduction kernels read every score
             return VTX_OK;
         };
         HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 16 * sizeof(uint32_t), s));
@@ -805,6 +871,8 @@ int vtx_run(vtx_ctx* c) {
                 HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
                 band_run_ms += ms;
             }
+            if (base + chunk >= n_tasks && cnt[1])                     // last chunk: the overflow list is complete
+                if (int rc = fallback_start(0, cnt[1])) return rc;
             if (cnt[11]) {
                 // tasks whose piece list overflowed its LDS slots: the same certificate, from their global area
                 HIP_TRY(c, vtxk_launch_band_pending(c->d_pend.as<uint32_t>(), cnt[11], (uint32_t)base, c->d_band_ws.as<uint32_t>(),
@@ -815,7 +883,7 @@ int vtx_run(vtx_ctx* c) {
                 pending_total += cnt[11];
                 ++launches;
             }
-            if (int rc = masked_dp(cnt[0])) return rc;
+            if (int rc = masked_dp(cnt[0], c->d_hard.as<uint32_t>(), c->d_band.as<uint16_t>(), s)) return rc;
             hard_total += cnt[0];
             launches += 3;
         }
@@ -826,37 +894,7 @@ int vtx_run(vtx_ctx* c) {
             fprintf(stderr, "[vtx] band_run_kernel: %u tasks hard only because pieces were dropped from a full list\n", why[10]);
             fprintf(stderr, "[vtx] band_run_kernel overflow reasons: bound=%u parked-full=%u log-full=%u other=%u traceback=%u\n", why[3], why[4], why[5], why[6], why[7]);
         }
-        // general kernel (per-task scratch slab) on the accumulated overflow list; slabs grow until every task fits
-        for (uint32_t obase = 0; obase < fast_overflow; obase += chunk) {
-            const uint32_t n_over = std::min(chunk, fast_overflow - obase);
-            uint32_t cap2 = 512 / 16, todo = n_over;
-            const uint32_t* tasks = c->d_over.as<uint32_t>() + obase;
-            HIP_TRY(c, hipMemsetAsync(d_cnt + 8, 0, 2 * sizeof(uint32_t), s));
-            uint32_t gcnt[2] = {0, 0};
-            while (todo > 0) {
-                const uint64_t worst = (uint64_t)c->max_read_len * c->max_hap_len;
-                if (cap2 >= worst && cap2 >= 512) return fail(c, VTX_E_STATE, "vtx_run: band kernel overflow with a worst-case slab");
-                cap2 = (uint32_t)std::max<uint64_t>(std::min<uint64_t>((uint64_t)cap2 * 16, worst), 512);
-                const size_t stride2 = vtxk_band_ws_stride(cap2, c->max_hap_len);
-                HIP_TRY(c, c->d_band_ws2.reserve((size_t)todo * stride2));
-                HIP_TRY(c, c->d_over2.reserve(2 * (size_t)n_over * sizeof(uint32_t)));
-                HIP_TRY(c, hipMemsetAsync(d_cnt + 9, 0, sizeof(uint32_t), s));
-                HIP_TRY(c, vtxk_launch_band(tasks, todo, 0, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                            c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
-                                            c->d_band_ws2.as<uint8_t>(), stride2, cap2, c->max_hap_len, c->d_ref.as<int32_t>(),
-                                            c->d_alt.as<int32_t>(), c->d_band.as<uint16_t>(), band_stride, c->d_hard.as<uint32_t>(),
-                                            c->d_over2.as<uint32_t>() + ((tasks == c->d_over2.as<uint32_t>()) ? n_over : 0), d_cnt + 8, s));
-                HIP_TRY(c, hipMemcpyAsync(gcnt, d_cnt + 8, sizeof gcnt, hipMemcpyDeviceToHost, s));
-                HIP_TRY(c, hipStreamSynchronize(s));
-                // tasks that still do not fit were written to the other half of d_over2: rerun them with a larger slab
-                tasks = c->d_over2.as<uint32_t>() + ((tasks == c->d_over2.as<uint32_t>()) ? n_over : 0);
-                todo = gcnt[1];
-                ++launches;
-            }
-            if (int rc = masked_dp(gcnt[0])) return rc;
-            hard_total += gcnt[0];
-            launches += 2;
-        }
+        if (int rc = fallback_finish()) return rc;
         c->fast_overflow = fast_overflow;
         if (getenv("VTX_DEBUG")) fprintf(stderr, "[vtx] banded: %llu tasks, %u overflowed band_run_kernel, %u bounded by the pending kernel, %u hard\n", (unsigned long long)n_tasks, fast_overflow, pending_total, hard_total);
     }
