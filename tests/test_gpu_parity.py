@@ -280,6 +280,35 @@ def test_certificate_decides_most_clean_alignments():
     assert frac < 0.08
 
 
+def test_band_buffer_caps_spill_into_the_general_kernel(tmp_path):
+    """Band slots and pending records are sized for a fraction of the tasks; whatever exceeds them must take the general
+    kernel's route and still come out exact.  VTX_BAND_HARD_CAP=3 leaves three slots of each kind (separate process: the
+    hook is read from the environment)."""
+    import subprocess
+    import sys
+    code = '''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from vartrix_amd import lib, synth
+from vartrix_amd.abi import default_config
+spec = synth.SynthSpec(n_loci=150, n_barcodes=100, reads_per_locus=48, indel_frac=0.5, read_len_jitter=50, seed=15, sub_error=0.03)
+b = synth.make_batch(spec)
+with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=100)) as ctx:
+    ctx.submit(b); ctx.run(); r, a = ctx.fetch_scores(); t = ctx.timing()
+np.save(sys.argv[1], np.stack([r, a])); print("hard", t.hard_tasks, "overflow", t.overflow_tasks)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "capped.npy")
+    r = subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, VTX_BAND_HARD_CAP="3"), timeout=300,
+                       capture_output=True, text=True)
+    got = np.load(out)
+    spec = synth.SynthSpec(n_loci=150, n_barcodes=100, reads_per_locus=48, indel_frac=0.5, read_len_jitter=50, seed=15, sub_error=0.03)
+    batch = synth.make_batch(spec)
+    oref, oalt = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=100), threads=8)
+    assert np.array_equal(got[0], oref) and np.array_equal(got[1], oalt)
+    overflow = int(r.stdout.split("overflow")[1])
+    assert overflow > 100, r.stdout          # the caps really were exceeded
+
+
 @pytest.mark.parametrize("kw", [dict(reads_per_locus=4), dict(reads_per_locus=16), dict(reads_per_locus=8, depth_sigma=1.0),
                                 dict(reads_per_locus=3, indel_frac=0.4, read_len_jitter=60), dict(reads_per_locus=70)])
 def test_shallow_and_mixed_depth_loci(kw):

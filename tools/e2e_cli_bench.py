@@ -19,8 +19,154 @@ from vartrix_amd import hostlib, lib  # noqa: E402
 from vartrix_amd.abi import default_config  # noqa: E402
 
 
+def _compress_blocks(args):
+    """BGZF-compress consecutive 60 000-byte slices [lo, hi) of a shared byte file (worker of author_fast)."""
+    path, lo, hi, level = args
+    import zlib as _z
+    out = []
+    with open(path, "rb") as fh:
+        fh.seek(lo)
+        data = fh.read(hi - lo)
+    for o in range(0, len(data), 60000):
+        blk = data[o:o + 60000]
+        comp = _z.compressobj(level, _z.DEFLATED, -15)
+        cdata = comp.compress(blk) + comp.flush()
+        import struct as _s
+        out.append(_s.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(cdata) + 25) + cdata +
+                   _s.pack("<II", _z.crc32(blk) & 0xFFFFFFFF, len(blk)))
+    return b"".join(out)
+
+
+def author_fast(out_dir, V, R, B, Lr=150, seed=7, procs=32, chunk_loci=2000):
+    """Vectorised authoring of the synthetic model at config-3 scale: every record has the same layout (150M, fixed-size
+    name and CB / UB tags), so a chunk of records is one numpy byte matrix; BGZF blocks are compressed by a process pool."""
+    import struct
+    import multiprocessing as mp
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    codes = rng.integers(0, 4, 1000 * V + 1000, dtype=np.uint8)
+    genome = acgt[codes]
+    fa = os.path.join(out_dir, "g.fa")
+    with open(fa, "wb") as fh:
+        fh.write(b">chr1\n")
+        body = genome[:len(genome) // 60 * 60].reshape(-1, 60)
+        lines = np.concatenate([body, np.full((body.shape[0], 1), 10, np.uint8)], axis=1)
+        fh.write(lines.tobytes())
+        if len(genome) % 60:
+            fh.write(genome[len(genome) // 60 * 60:].tobytes() + b"\n")
+    with open(fa + ".fai", "w") as fh:
+        fh.write("chr1\t%d\t6\t60\t61\n" % len(genome))
+    n_total = int(round(B / 0.95))
+    bc_codes = rng.integers(0, 4, (n_total, 16), dtype=np.uint8)
+    bc_text = np.concatenate([acgt[bc_codes], np.tile(np.frombuffer(b"-1", np.uint8), (n_total, 1))], axis=1)   # 18 bytes
+    listed = [bytes(r) for r in bc_text[:B]]
+    assert len(set(listed)) == B
+    with open(os.path.join(out_dir, "bcs.tsv"), "wb") as fh:
+        fh.write(b"\n".join(listed) + b"\n")
+    pos0_all = 500 + 1000 * np.arange(V, dtype=np.int64)
+    alt_codes = (codes[pos0_all] + 1 + rng.integers(0, 3, V)) % 4
+    with open(os.path.join(out_dir, "v.vcf"), "w") as vf:
+        vf.write("##fileformat=VCFv4.2\n##contig=<ID=chr1,length=%d>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n" % len(genome))
+        vf.write("".join("chr1\t%d\t.\t%s\t%s\t.\t.\t.\n" % (p + 1, "ACGT"[codes[p]], "ACGT"[a]) for p, a in zip(pos0_all, alt_codes)))
+    # fixed record layout
+    name_len, n_name = 10, 9                                  # "r" + 8 hex + NUL
+    aux_len = 3 + 19 + 3 + 11                                 # CB:Z:<18>\0 UB:Z:<10>\0
+    body_len = 32 + name_len + 4 + (Lr + 1) // 2 + Lr + aux_len
+    rec_len = 4 + body_len
+    nt16 = np.array([1, 2, 4, 8], np.uint8)                  # A C G T in BAM's 4-bit code
+    windows = np.lib.stride_tricks.sliding_window_view(codes, Lr)
+    raw = os.path.join(out_dir, "r.raw")
+    text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:%d\n" % len(genome)
+    hdr = b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\x00" + \
+        struct.pack("<i", len(genome))
+    n_reads = 0
+    with open(raw, "wb") as fh:
+        fh.write(hdr)
+        for a in range(0, V, chunk_loci):
+            b = min(a + chunk_loci, V)
+            nl = b - a
+            n = nl * R
+            li = np.repeat(np.arange(a, b, dtype=np.int64), R)
+            start = pos0_all[li] - rng.integers(0, Lr, n)
+            order = np.lexsort((start, li))
+            li, start = li[order], start[order]
+            seq = windows[start].copy()                                   # (n, Lr) base codes
+            carry = rng.random(n) < 0.5
+            rows = np.nonzero(carry)[0]
+            seq[rows, (pos0_all[li] - start)[rows]] = alt_codes[li[rows]]
+            err = rng.random((n, Lr)) < 0.005
+            seq[err] = (seq[err] + 1) % 4
+            cell = rng.integers(0, n_total, n)
+            rec = np.zeros((n, rec_len), np.uint8)
+            rec[:, 0:4] = np.frombuffer(struct.pack("<i", body_len), np.uint8)
+            rec[:, 4:8] = 0                                               # refID 0
+            rec[:, 8:12] = start.astype("<i4").view(np.uint8).reshape(n, 4)
+            rec[:, 12] = name_len
+            rec[:, 13] = 60                                               # mapq
+            rec[:, 14:16] = np.frombuffer(struct.pack("<H", 4680), np.uint8)
+            rec[:, 16:18] = np.frombuffer(struct.pack("<H", 1), np.uint8)   # n_cigar_op
+            rec[:, 18:20] = 0                                             # flag
+            rec[:, 20:24] = np.frombuffer(struct.pack("<i", Lr), np.uint8)
+            rec[:, 24:28] = 0xff; rec[:, 28:32] = 0xff                    # next refID / pos = -1
+            rec[:, 32:36] = 0
+            o = 36
+            ids = (n_reads + np.arange(n, dtype=np.int64))
+            hexd = np.frombuffer(b"0123456789abcdef", np.uint8)
+            rec[:, o] = ord("r")
+            for k in range(8):
+                rec[:, o + 1 + k] = hexd[(ids >> (4 * (7 - k))) & 15]
+            o += name_len                                                 # NUL already 0
+            rec[:, o:o + 4] = np.frombuffer(struct.pack("<I", (Lr << 4) | 0), np.uint8)
+            o += 4
+            c4 = nt16[seq]
+            if Lr % 2:
+                c4 = np.concatenate([c4, np.zeros((n, 1), np.uint8)], axis=1)
+            rec[:, o:o + (Lr + 1) // 2] = (c4[:, 0::2] << 4) | c4[:, 1::2]
+            o += (Lr + 1) // 2
+            rec[:, o:o + Lr] = 0xff
+            o += Lr
+            rec[:, o:o + 3] = np.frombuffer(b"CBZ", np.uint8)
+            rec[:, o + 3:o + 21] = bc_text[cell]
+            o += 22
+            rec[:, o:o + 3] = np.frombuffer(b"UBZ", np.uint8)
+            rec[:, o + 3:o + 13] = acgt[rng.integers(0, 4, (n, 10), dtype=np.uint8)]
+            fh.write(rec.tobytes())
+            n_reads += n
+    size = os.path.getsize(raw)
+    step = 60000 * 64
+    jobs = [(raw, lo, min(lo + step, size), 1) for lo in range(0, size, step)]
+    bam = os.path.join(out_dir, "r.bam")
+    with mp.Pool(procs) as pool, open(bam, "wb") as fh:
+        for blob in pool.imap(_compress_blocks, jobs, chunksize=1):
+            fh.write(blob)
+        fh.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))      # BGZF EOF block
+    os.remove(raw)
+    with open(bam + ".bai", "wb") as fh:
+        fh.write(b"BAI\x01" + struct.pack("<i", 0))
+    return fa, os.path.join(out_dir, "v.vcf"), bam, os.path.join(out_dir, "bcs.tsv"), n_reads
+
+
+def run_cli_timed(out_dir, fa, vcf, bam, bcs, threads, extra, label):
+    out = os.path.join(out_dir, "out.mtx")
+    for f in (out, os.path.join(out_dir, "ref_matrix.mtx")):
+        if os.path.exists(f):
+            os.remove(f)
+    t0 = time.time()
+    r = subprocess.run([hostlib.CLI_PATH, "-v", vcf, "-b", bam, "-f", fa, "-c", bcs, "-o", out, "--threads", str(threads),
+                        "--log-level", "info"] + extra, cwd=out_dir, capture_output=True, text=True)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stdout + r.stderr
+    keep = [ln for ln in r.stderr.splitlines() if any(k in ln for k in ("Ingest", "Device", "shard:", "Merge +", "Waited", "Total",
+                                                                       "packer", "alignments evaluated", "device preparation"))]
+    print("%s: CLI wall time %.2f s\n  %s" % (label, wall, "\n  ".join(keep)), flush=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--fast", action="store_true", help="vectorised authoring (config-3 scale); timing runs only, with an "
+                    "internal consistency check between --prep host and --prep device")
+    ap.add_argument("--procs", type=int, default=32)
     ap.add_argument("--loci", type=int, default=1000)
     ap.add_argument("--reads", type=int, default=256)
     ap.add_argument("--barcodes", type=int, default=2000)
@@ -28,6 +174,20 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
+    if args.fast:
+        t0 = time.time()
+        fa, vcf, bam, bcs, n_reads = author_fast(args.out, args.loci, args.reads, args.barcodes, procs=args.procs)
+        print("authored %d reads over %d loci in %.1f s (%.1f MB BAM)" % (n_reads, args.loci, time.time() - t0, os.path.getsize(bam) / 1e6), flush=True)
+        texts = []
+        for extra, label in ((["--prep", "host"], "--prep host"), (["--prep", "device"], "--prep device"),
+                             (["--prep", "device"], "--prep device (second run, page cache warm)")):
+            out = run_cli_timed(args.out, fa, vcf, bam, bcs, args.threads, extra, label)
+            import hashlib
+            texts.append(hashlib.sha256(open(out, "rb").read()).hexdigest())
+            print("  .mtx %.1f MB, sha256 %s" % (os.path.getsize(out) / 1e6, texts[-1][:16]), flush=True)
+        assert texts[0] == texts[1] == texts[2], "host-prepared and device-prepared outputs differ"
+        print("host-prepared and device-prepared .mtx are byte-identical")
+        return
     rng = np.random.default_rng(7)
     V, R, B, Lr = args.loci, args.reads, args.barcodes, 150
     genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 1000 * V + 1000)]

@@ -79,7 +79,7 @@ struct vtx_ctx {
     DevBuf d_head_cell, d_head_umi, d_cell_scan, d_umi_scan, d_grp_row, d_grp_col, d_umi_cellgrp;
     DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
-    DevBuf d_band_ws, d_band_ws2, d_band, d_hard, d_over, d_over2, d_pend, d_cnt, d_band2, d_hard2;   // banded flavour
+    DevBuf d_band_ws, d_band_ws2, d_band, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2;   // banded flavour
     DevBuf d_redo, d_redo_cnt;                                               // LUT kernel: records with non-ACGTN bytes
     // raw batches (vtx_submit_raw): barcode table + preparation scratch
     DevBuf d_bc_slots, d_bc_hash, d_bc_off, d_bc_bytes;
@@ -398,7 +398,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_alt, &c->d_head_cell, &c->d_head_umi, &c->d_cell_scan, &c->d_umi_scan, &c->d_grp_row,
                       &c->d_grp_col, &c->d_umi_cellgrp, &c->d_cell_cnt, &c->d_umi_cnt, &c->d_keep, &c->d_keep_scan,
                       &c->d_scan_tmp, &c->d_o_row, &c->d_o_col, &c->d_o_alt, &c->d_o_ref, &c->d_o_unk, &c->d_o_val,
-                      &c->d_o_refval, &c->d_band_ws, &c->d_band_ws2, &c->d_band, &c->d_hard, &c->d_over, &c->d_over2, &c->d_pend, &c->d_band2, &c->d_hard2,
+                      &c->d_o_refval, &c->d_band_ws, &c->d_band_ws2, &c->d_band, &c->d_hard, &c->d_over, &c->d_over2, &c->d_pend, &c->d_pend_buf, &c->d_band2, &c->d_hard2,
                       &c->d_cnt, &c->d_redo, &c->d_redo_cnt, &c->d_bc_slots, &c->d_bc_hash, &c->d_bc_off, &c->d_bc_bytes,
                       &c->d_raw, &c->d_tags, &c->d_raw_locus, &c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2,
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
@@ -756,25 +756,22 @@ int vtx_run(vtx_ctx* c) {
         // the hard scores.  Tasks band_run_kernel cannot hold accumulate in ONE overflow list that the general
         // band kernel processes after the last chunk (a launch of a handful of serial lanes costs ~2 ms).
         const uint64_t n_tasks = 2ull * nr;
-        // tasks per band-kernel launch: the per-task log / band-slot buffers cost ~1.3 KB per task of the chunk, so the
-        // chunk is as large as a third of the free HBM allows (config 3: one launch instead of three)
-        uint64_t chunk_cap = 1u << 24;
-        {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                const uint64_t per_task = vtxk_band_task_words() * 4ull + 2ull * (((c->max_hap_len + 2 + 7) & ~7u)) * 2 + 8;
-                const uint64_t have = (uint64_t)free_b + c->d_band_ws.cap + c->d_band.cap + c->d_hard.cap;
-                chunk_cap = std::max<uint64_t>(chunk_cap, std::min<uint64_t>(1u << 27, have / 3 / per_task));
-            }
-        }
+        // One launch covers every task unless a test hook asks for chunks.  Memory: the scratch of band_run_kernel belongs
+        // to its RESIDENT lanes (persistent workgroups), band slots and pending records are sized for a fraction of the
+        // tasks — whatever exceeds them goes to the general kernel's list, which is processed in slices.
+        uint64_t chunk_cap = 1u << 31;
         if (getenv("VTX_BAND_CHUNK")) chunk_cap = std::max<uint64_t>(256, strtoull(getenv("VTX_BAND_CHUNK"), nullptr, 10));   // test hook
         const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_tasks, chunk_cap);
         const uint32_t band_stride = (c->max_hap_len + 2 + 7) & ~7u;
+        uint32_t hard_cap = (uint32_t)std::min<uint64_t>(chunk, chunk / 16 + (1u << 20));
+        uint32_t pend_cap = hard_cap;
+        if (getenv("VTX_BAND_HARD_CAP")) hard_cap = pend_cap = std::max(1u, (uint32_t)atoi(getenv("VTX_BAND_HARD_CAP")));         // test hook
         uint32_t fast_overflow = 0;
-        HIP_TRY(c, c->d_band_ws.reserve((size_t)chunk * vtxk_band_task_words() * sizeof(uint32_t)));   // per task: jump log + spilled pieces
-        HIP_TRY(c, c->d_pend.reserve((size_t)chunk * sizeof(uint32_t)));
-        HIP_TRY(c, c->d_band.reserve((size_t)chunk * 2 * band_stride * sizeof(uint16_t)));
-        HIP_TRY(c, c->d_hard.reserve((size_t)chunk * sizeof(uint32_t)));
+        HIP_TRY(c, c->d_band_ws.reserve((size_t)vtxk_band_run_lanes() * vtxk_band_task_words() * sizeof(uint32_t)));   // per resident lane
+        HIP_TRY(c, c->d_pend.reserve((size_t)pend_cap * sizeof(uint32_t)));
+        HIP_TRY(c, c->d_pend_buf.reserve((size_t)pend_cap * vtxk_band_pend_words() * sizeof(uint32_t)));
+        HIP_TRY(c, c->d_band.reserve(((size_t)hard_cap + pend_cap) * 2 * band_stride * sizeof(uint16_t)));
+        HIP_TRY(c, c->d_hard.reserve(((size_t)hard_cap + pend_cap) * sizeof(uint32_t)));
         HIP_TRY(c, c->d_over.reserve((size_t)n_tasks * sizeof(uint32_t)));
         HIP_TRY(c, c->d_cnt.reserve(16 * sizeof(uint32_t)));
         uint32_t* d_cnt = c->d_cnt.as<uint32_t>();        // [0] hard, [1] overflow, [2..7] reasons; [8],[9] general kernel; [10] stats; [11] pending
@@ -818,7 +815,7 @@ int vtx_run(vtx_ctx* c) {
             return VTX_OK;
         };
         auto fallback_start = [&](uint32_t off, uint32_t total) -> int {   // the overflow list d_over[0, total) is complete and visible
-            const uint32_t n_over = std::min(chunk, total - off);            // slices of at most one chunk (bounds d_band2)
+            const uint32_t n_over = std::min(std::max(hard_cap, 1024u), total - off);   // slices (bounds d_band2)
             fb.off = off; fb.total = total;
             fb.n_over = n_over; fb.todo = n_over; fb.cap2 = 512 / 16; fb.tasks = c->d_over.as<uint32_t>() + off; fb.active = true;
             HIP_TRY(c, c->d_over2.reserve(2 * (size_t)n_over * sizeof(uint32_t)));
@@ -855,13 +852,14 @@ int vtx_run(vtx_ctx* c) {
         for (uint64_t base = 0; base < n_tasks; base += chunk) {
             const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, n_tasks - base);
             HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), s));                 // hard count of this chunk
-            HIP_TRY(c, hipMemsetAsync(d_cnt + 11, 0, sizeof(uint32_t), s));            // pending count of this chunk
+            HIP_TRY(c, hipMemsetAsync(d_cnt + 11, 0, 2 * sizeof(uint32_t), s));        // pending count of this chunk, block counter
             HIP_TRY(c, hipEventRecord(c->ev[4], s));
             HIP_TRY(c, vtxk_launch_band_run(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                              c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                              c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
                                              c->d_band_ws.as<uint32_t>(), c->d_band.as<uint16_t>(), band_stride,
-                                             c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(), d_cnt,
+                                             c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
+                                             c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt,
                                              (uint32_t)(n_tasks / std::max(c->n_loci, 1u)), s));
             HIP_TRY(c, hipEventRecord(c->ev[5], s));
             HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
@@ -873,9 +871,14 @@ int vtx_run(vtx_ctx* c) {
             }
             if (base + chunk >= n_tasks && cnt[1])                     // last chunk: the overflow list is complete
                 if (int rc = fallback_start(0, cnt[1])) return rc;
+            if (cnt[0] > hard_cap) {               // the excess went to the general kernel's list: slots in use = hard_cap
+                cnt[0] = hard_cap;
+                HIP_TRY(c, hipMemcpyAsync(d_cnt, cnt, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            }
+            cnt[11] = std::min(cnt[11], pend_cap);
             if (cnt[11]) {
-                // tasks whose piece list overflowed its LDS slots: the same certificate, from their global area
-                HIP_TRY(c, vtxk_launch_band_pending(c->d_pend.as<uint32_t>(), cnt[11], (uint32_t)base, c->d_band_ws.as<uint32_t>(),
+                // tasks whose piece list overflowed its LDS slots: the same certificate, from their pending records
+                HIP_TRY(c, vtxk_launch_band_pending(c->d_pend.as<uint32_t>(), cnt[11], c->d_pend_buf.as<uint32_t>(),
                                                     c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_band.as<uint16_t>(),
                                                     band_stride, c->d_hard.as<uint32_t>(), d_cnt, s));
                 HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, s));

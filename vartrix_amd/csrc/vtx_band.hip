@@ -301,7 +301,8 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
 #define PS 14       // per-lane LDS entries of band_run_kernel: pieces + segments
 #define LG 64       // jump-log entries per task (global)
 #define SPILL 18    // pieces run_compact may drop from a task's list and still leave it to the pending kernel (global)
-#define TASK_WORDS (LG * 2 + SPILL * 2)   // per-task global area: jump log, then the spilled pieces
+#define TASK_WORDS (LG * 2 + SPILL * 2)   // scratch of one RESIDENT lane (global, reused block after block): jump log, spilled pieces
+#define PEND_WORDS (2 + 2 * PS + (4 * SG + 6) + 2 * SPILL)   // record of a pending task: header, cert, list, staircase, spill
 #define SG 10       // chain segments per task
 #define NONE_ID 0xffffffffu
 #define CH_END 0xffffu     // end of a k-mer chain / empty bucket
@@ -656,9 +657,10 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
     int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ logbuf, uint16_t* __restrict__ band, uint32_t band_stride,
     uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ pending_list,
+    uint32_t* __restrict__ pend_buf, uint32_t hard_cap, uint32_t pend_cap,
     uint32_t* __restrict__ counters, uint32_t ablate, uint32_t n_heads) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    __shared__ uint32_t s_hibyte;              // bit t: the haplotype of table t holds a byte >= 0x80 (no continuation shortcut)
+    __shared__ uint32_t s_hibyte, s_blk;              // bit t: the haplotype of table t holds a byte >= 0x80 (no continuation shortcut)
     const int tid = threadIdx.x;
     // per-lane LDS arrays, element i of lane tid at [i * NT + tid]
     // staircase of ended matches, stored as RUNS: elements (ye0 + t, V0 + 3t, id0 + t*(1,1)), t < len
@@ -669,7 +671,18 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
 #define PM_A(i) pm_a[(i) * NT + tid]
 #define PM_ID(i) pm_id[(i) * NT + tid]
 
-    const uint32_t slot = blockIdx.x * NT + tid;
+    // Persistent workgroups: the grid is what the chip holds at once; a workgroup claims blocks of NT consecutive tasks
+    // from a counter until none is left.  The per-lane global scratch (jump log, spilled pieces) therefore belongs to the
+    // RESIDENT lane — a few hundred MB that stay in the caches instead of 656 B x every task of the batch.
+    uint32_t* mylog = logbuf + (size_t)(blockIdx.x * NT + tid) * TASK_WORDS;
+    const uint32_t n_blocks = (n_tasks + NT - 1) / NT;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_blk = atomicAdd(&counters[12], 1u);
+    __syncthreads();
+    const uint32_t blk = s_blk;
+    if (blk >= n_blocks) break;
+    const uint32_t slot = blk * NT + tid;
     const bool have = slot < n_tasks;
     const uint32_t task = task_base + slot;
     uint32_t rid = 0, hap = 0, my_locus = 0, m = 0, n = 0;
@@ -683,17 +696,18 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
         n = hap ? loci[my_locus].alt_len : loci[my_locus].ref_len;
     }
     // locus range of this workgroup (tasks are in record order, records in locus order)
-    const uint32_t first_task = task_base + blockIdx.x * NT;
+    const uint32_t first_task = task_base + blk * NT;
     const uint32_t last_task = min(task_base + n_tasks - 1, first_task + NT - 1);
     const uint32_t l_first = rec_locus[first_task >> 1], l_last = rec_locus[last_task >> 1];
     const uint32_t loci_per_pass = tables_per_pass / 2;
     int32_t* my_score = (hap ? alt_score : ref_score) + rid;
     bool done = !have;
     if (have && (m == 0 || n == 0)) { *my_score = 0; done = true; }     // empty read / haplotype: score 0
-    uint32_t* mylog = logbuf + (size_t)slot * TASK_WORDS;
     // a task without any k-mer match has the whole matrix in band (Band::full_matrix): hard list, marker slot
-#define PUSH_FULL_MATRIX() { const uint32_t h_ = atomicAdd(&counters[0], 1u); hard_list[h_] = task;             \
-                             band[(size_t)h_ * 2 * band_stride] = BAND_FULL_MATRIX; }
+    // (hard slots beyond the capacity of the band buffer go to the general kernel's list, which makes them hard in slices)
+#define PUSH_FULL_MATRIX() { const uint32_t h_ = atomicAdd(&counters[0], 1u);                                    \
+                             if (h_ < hard_cap) { hard_list[h_] = task; band[(size_t)h_ * 2 * band_stride] = BAND_FULL_MATRIX; } \
+                             else overflow_list[atomicAdd(&counters[1], 1u)] = task; }
 
     for (uint32_t lbase = l_first; lbase <= l_last; lbase += loci_per_pass) {
         __syncthreads();
@@ -948,25 +962,31 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
             if (fr == 2) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[7], 1u); continue; }
         }
         if (pending) {
-            // the jump log is dead now: header, list entries, staircase — the spilled pieces already sit behind it
-            mylog[0] = st.n_ent | (st.n_sp << 8) | (nv << 16);
-            mylog[1] = (uint32_t)cert;
+            // a record for band_pending_kernel: header, certificate, list entries, staircase, spilled pieces
+            const uint32_t pi = atomicAdd(&counters[11], 1u);
+            if (pi >= pend_cap) { overflow_list[atomicAdd(&counters[1], 1u)] = task; continue; }
+            uint32_t* prec = pend_buf + (size_t)pi * PEND_WORDS;
+            prec[0] = st.n_ent | (st.n_sp << 8) | (nv << 16);
+            prec[1] = (uint32_t)cert;
             for (uint32_t j = 0; j < st.n_ent; ++j) {
-                mylog[2 + 2 * j] = pm_a[j * NT + tid];
-                mylog[3 + 2 * j] = pm_id[j * NT + tid] & 0xffffu;
+                prec[2 + 2 * j] = pm_a[j * NT + tid];
+                prec[3 + 2 * j] = pm_id[j * NT + tid] & 0xffffu;
             }
-            for (uint32_t i = 0; i < nv; ++i) mylog[2 + 2 * PS + i] = verts[i];
-            pending_list[atomicAdd(&counters[11], 1u)] = task;
+            for (uint32_t i = 0; i < nv; ++i) prec[2 + 2 * PS + i] = verts[i];
+            for (uint32_t i = 0; i < 2 * st.n_sp; ++i) prec[2 + 2 * PS + (4 * SG + 6) + i] = mylog[LG * 2 + i];
+            pending_list[pi] = task;
             continue;
         }
         if (!st.ub_ok) atomicAdd(&counters[10], 1u);         // statistics: hard only because too many pieces were dropped
         const uint32_t h = atomicAdd(&counters[0], 1u);
+        if (h >= hard_cap) { overflow_list[atomicAdd(&counters[1], 1u)] = task; continue; }
         hard_list[h] = task;
         uint16_t* lo = band + (size_t)h * 2 * band_stride;
         lo[0] = BAND_POLYLINE; lo[1] = (uint16_t)nv;
         uint32_t* vout = (uint32_t*)(lo + 2);
         for (uint32_t i = 0; i < nv; ++i) vout[i] = verts[i];
     }
+  }   // next block of tasks
 #undef PM_A
 #undef PM_ID
 #undef PUSH_FULL_MATRIX
@@ -981,7 +1001,7 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
 // cert == ub: the score is written; otherwise the task joins the hard list with its staircase.
 // =============================================================================================
 __global__ __launch_bounds__(256) void band_pending_kernel(
-    const uint32_t* __restrict__ pending, uint32_t n_pending, uint32_t task_base, const uint32_t* __restrict__ logbuf,
+    const uint32_t* __restrict__ pending, uint32_t n_pending, const uint32_t* __restrict__ pend_buf,
     int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score, uint16_t* __restrict__ band, uint32_t band_stride,
     uint32_t* __restrict__ hard_list, uint32_t* __restrict__ counters) {
     __shared__ uint32_t s_id[8][32], s_lg[8][32];      // per task: piece start, (bases << 16 | G)
@@ -989,14 +1009,14 @@ __global__ __launch_bounds__(256) void band_pending_kernel(
     const uint32_t pi = blockIdx.x * 8 + grp;
     const bool have = pi < n_pending;
     const uint32_t task = have ? pending[pi] : 0;
-    const uint32_t* area = logbuf + (size_t)(task - task_base) * TASK_WORDS;
+    const uint32_t* area = pend_buf + (size_t)(have ? pi : 0) * PEND_WORDS;
     uint32_t hdr = 0; int32_t cert = 0;
     if (have) { hdr = area[0]; cert = (int32_t)area[1]; }
     const uint32_t n_ent = hdr & 0xff, n_sp = (hdr >> 8) & 0xff, nv = hdr >> 16;
     const uint32_t n = n_ent + n_sp;                    // <= PS + SPILL = 32
     uint32_t id = 0; int32_t len = 0;
     if ((uint32_t)l < n) {
-        const uint32_t* e = (uint32_t)l < n_ent ? area + 2 + 2 * l : area + LG * 2 + 2 * (l - n_ent);
+        const uint32_t* e = (uint32_t)l < n_ent ? area + 2 + 2 * l : area + 2 + 2 * PS + (4 * SG + 6) + 2 * (l - n_ent);
         id = e[0]; len = (int32_t)e[1] + KMER - 1;
     }
     const int32_t xp = (int32_t)(id >> 16), yp = (int32_t)(id & 0xffff);
@@ -1047,11 +1067,13 @@ __global__ __launch_bounds__(256) void band_pending_kernel(
 
 extern "C" uint32_t vtxk_band_task_words(void) { return TASK_WORDS; }
 
-extern "C" hipError_t vtxk_launch_band_pending(const uint32_t* pending, uint32_t n_pending, uint32_t task_base,
-                                               const uint32_t* logbuf, int32_t* ref_score, int32_t* alt_score, uint16_t* band,
+extern "C" uint32_t vtxk_band_pend_words(void) { return PEND_WORDS; }
+
+extern "C" hipError_t vtxk_launch_band_pending(const uint32_t* pending, uint32_t n_pending, const uint32_t* pend_buf,
+                                               int32_t* ref_score, int32_t* alt_score, uint16_t* band,
                                                uint32_t band_stride, uint32_t* hard_list, uint32_t* counters, hipStream_t s) {
     if (!n_pending) return hipSuccess;
-    hipLaunchKernelGGL(band_pending_kernel, dim3((n_pending + 7) / 8), dim3(256), 0, s, pending, n_pending, task_base, logbuf,
+    hipLaunchKernelGGL(band_pending_kernel, dim3((n_pending + 7) / 8), dim3(256), 0, s, pending, n_pending, pend_buf,
                        ref_score, alt_score, band, band_stride, hard_list, counters);
     return hipGetLastError();
 }
@@ -1113,13 +1135,18 @@ __global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __rest
     }
 }
 
+// Resident workgroups of band_run_kernel (an upper bound: 256 CUs x the most workgroups a CU can hold for that block
+// size); the per-lane scratch is sized from it.
+extern "C" uint32_t vtxk_band_run_grid(uint32_t nt) { return 256u * (nt == 64 ? 16u : 4u); }
+extern "C" uint32_t vtxk_band_run_lanes(void) { return 256u * 16u * 64u; }     // max over both block sizes of grid x nt
+
 extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
                                            const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                            const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score,
                                            int32_t* alt_score, uint32_t* logbuf, uint16_t* band,
                                            uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
-                                           uint32_t* pending_list, uint32_t* counters, uint32_t tasks_per_locus,
-                                           hipStream_t s) {
+                                           uint32_t* pending_list, uint32_t* pend_buf, uint32_t hard_cap, uint32_t pend_cap,
+                                           uint32_t* counters, uint32_t tasks_per_locus, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
     // Deep data (>= 64 tasks per locus): 256-task workgroups.  A workgroup processes its loci in passes of `tables / 2`
     // loci (the k-mer tables live in LDS); in a pass only the lanes of those loci work.  512-entry head arrays: two loci
@@ -1156,10 +1183,11 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);              \
             if (e != hipSuccess) return e;                                                                           \
         }                                                                                                            \
-        hipLaunchKernelGGL(band_run_kernel<NTV>, dim3((n_tasks + NTV - 1) / NTV), dim3(NTV), shmem, s, n_tasks,      \
+        hipLaunchKernelGGL(band_run_kernel<NTV>, dim3(std::min((n_tasks + NTV - 1) / NTV, vtxk_band_run_grid(NTV))),  \
+                           dim3(NTV), shmem, s, n_tasks,                                                             \
                            task_base, records, rec_locus, loci, read_arena, hap_arena, max_hap, tables,              \
                            (uint32_t)tstride, ref_score, alt_score, logbuf, band, band_stride, hard_list,            \
-                           overflow_list, pending_list, counters, ablate, n_heads);                                  \
+                           overflow_list, pending_list, pend_buf, hard_cap, pend_cap, counters, ablate, n_heads);    \
     }
     if (wave_wg) LAUNCH_RUN(64) else LAUNCH_RUN(256)
 #undef LAUNCH_RUN

@@ -57,10 +57,14 @@ hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base, const vtx_
                                 const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                 const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score,
                                 int32_t* alt_score, uint32_t* logbuf, uint16_t* band, uint32_t band_stride,
-                                uint32_t* hard_list, uint32_t* overflow_list, uint32_t* pending_list, uint32_t* counters,
-                                uint32_t tasks_per_locus, hipStream_t s);
+                                uint32_t* hard_list, uint32_t* overflow_list, uint32_t* pending_list, uint32_t* pend_buf,
+                                uint32_t hard_cap, uint32_t pend_cap, uint32_t* counters, uint32_t tasks_per_locus,
+                                hipStream_t s);
 uint32_t vtxk_band_task_words(void);
-hipError_t vtxk_launch_band_pending(const uint32_t* pending, uint32_t n_pending, uint32_t task_base, const uint32_t* logbuf,
+uint32_t vtxk_band_pend_words(void);
+uint32_t vtxk_band_run_grid(uint32_t nt);
+uint32_t vtxk_band_run_lanes(void);
+hipError_t vtxk_launch_band_pending(const uint32_t* pending, uint32_t n_pending, const uint32_t* pend_buf,
                                     int32_t* ref_score, int32_t* alt_score, uint16_t* band, uint32_t band_stride,
                                     uint32_t* hard_list, uint32_t* counters, hipStream_t s);
 hipError_t vtxk_launch_band_expand(const uint32_t* hard_list, uint32_t n_hard, const vtx_record* records,
