@@ -339,6 +339,15 @@ def main():
                        "overflow_tasks": int(ctx.timing().overflow_tasks),
                        "pcie_inclusive_alignments_per_s": n_aln / (t_sub + elapsed / args.steps)},
         }
+        if pmc_extra and pmc_extra.get("valu_instructions_per_launch") and dom_ms > 0:
+            # issue rate of the dominant kernel: VALU wave-instructions counted by the PMC pass (same code, same workload)
+            # over this run's live kernel time; 64 lanes per instruction against the 39.3 T lane-ops/s issue roof
+            vi = pmc_extra["valu_instructions_per_launch"]
+            out["roofline_valu_issue"] = {"bound": "valu", "kernel": dom_name, "kernel_ms": dom_ms,
+                                          "valu_wave_instructions_per_launch": vi,
+                                          "achieved": vi * 64 / (dom_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS,
+                                          "unit": "T lane-ops/s issued", "frac": vi * 64 / (dom_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                                          "note": "every VALU instruction counted as one 4-cycle issue slot of a wave64"}
         if not banded:
             lane_ops = cells / 2 * OPS_PER_CELL_PAIR
             out["roofline_valu"] = {"bound": "valu", "kernel": "sw_full_duo_kernel", "kernel_ms": full_avg_ms,
