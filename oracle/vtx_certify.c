@@ -34,6 +34,7 @@
  *   maximisation may range over ALL sub-runs of pieces (length >= 1).
  */
 #include "vtx_oracle.h"
+#include "../include/vtx_band_semantics.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -62,7 +63,7 @@ int32_t vtxo_chain_cert(const uint8_t* x, int m, const uint8_t* y, int n, int k)
     if (M == 0) { free(mt); return -1; }
     int64_t* path = (int64_t*)malloc(sizeof(int64_t) * (size_t)M);
     int64_t L = vtxo_sdpkpp(mt, M, k, 1, -5, -1, path, NULL);
-    const int lazy = 2 * k;
+    const int lazy = VTX_BAND_LAZY_EXT(k);
     const int fx = (int)mt[2 * path[0]], fy = (int)mt[2 * path[0] + 1];
     int d0 = imin(imin(fx, fy), lazy);
     int r = fx - d0, c = fy - d0;
@@ -76,7 +77,7 @@ int32_t vtxo_chain_cert(const uint8_t* x, int m, const uint8_t* y, int n, int k)
         dr = px - r; dc = py - c;
         for (int i = 0; i < dr; ++i) { ++r; walk_gap(&w, 1); }
         for (int i = 0; i < dc; ++i) { ++c; walk_gap(&w, 2); }
-        int steps = k;
+        int steps = VTX_BAND_KMER_LAST_ANCHOR(k);
         if (t + 1 < L) {
             const int qx = (int)mt[2 * path[t + 1]], qy = (int)mt[2 * path[t + 1] + 1];
             if (qx == px + 1 && qy == py + 1) steps = 1;

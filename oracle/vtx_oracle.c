@@ -7,6 +7,7 @@
  * clarity first; it is also the "port" CPU baseline bench.py times.
  */
 #include "vtx_oracle.h"
+#include "../include/vtx_band_semantics.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -234,8 +235,12 @@ static void band_add_entry(band_t* b, int r, int c) {
     }
 }
 static void band_add_kmer(band_t* b, int r, int c, int k) {
-    for (int d = 0; d <= k; ++d) band_add_entry(b, r + d, c + d);
+    for (int d = 0; d <= VTX_BAND_KMER_LAST_ANCHOR(k); ++d) band_add_entry(b, r + d, c + d);
 }
+
+/* Test hook: override of VTX_BAND_LAZY_EXT for the sensitivity tests (tests/test_band_variants.py); < 0 = the constant. */
+static int g_lazy_override = -1;
+void vtxo_set_lazy_extension(int ext) { g_lazy_override = ext; }
 static void band_add_gap(band_t* b, int r0, int c0, int r1, int c1) {
     const int dr = r1 - r0, dc = c1 - c0;
     const int diag = imin(dr, dc);
@@ -251,13 +256,14 @@ int64_t vtxo_band_create(const uint8_t* x, int m, const uint8_t* y, int n,
     uint32_t* mt = NULL;
     int64_t M = vtxo_find_kmer_matches(x, m, y, n, k, &mt);
     if (M == 0) {
+        /* VTX_BAND_NO_SEED_FULL_MATRIX */
         for (int j = 0; j <= n; ++j) { lo[j] = 0; hi[j] = m + 1; }
     } else {
         int64_t* path = (int64_t*)slab(5, sizeof(int64_t) * (size_t)M);
         int64_t L = vtxo_sdpkpp(mt, M, k, 1 /* match_fn.score(b'A', b'A') */, -5, -1, path, NULL);
         /* NOTE: the aligner passes its own scoring's gap penalties; the
          * reference constructs it with (-5, -1) (src/main.rs:899).            */
-        const int lazy = 2 * k;
+        const int lazy = g_lazy_override >= 0 ? g_lazy_override : VTX_BAND_LAZY_EXT(k);
         const int fx = (int)mt[2 * path[0]], fy = (int)mt[2 * path[0] + 1];
         const int lx = (int)mt[2 * path[L - 1]] + k, ly = (int)mt[2 * path[L - 1] + 1] + k;
         int d = imin(imin(fx, fy), lazy);

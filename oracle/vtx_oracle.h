@@ -70,6 +70,10 @@ int64_t vtxo_sdpkpp(const uint32_t* matches, int64_t n_matches, int k,
 int64_t vtxo_band_create(const uint8_t* x, int m, const uint8_t* y, int n,
                          int k, int w, int32_t* lo, int32_t* hi);
 
+/* Test hook: lazy-extension length of set_boundaries for the NEXT band constructions (any value >= 0;
+ * VTX_BAND_EXT_TO_EDGE = to the matrix corner); negative restores the constant of include/vtx_band_semantics.h.   */
+void vtxo_set_lazy_extension(int ext);
+
 /* banded::Aligner::local(x, y).score */
 int32_t vtxo_sw_banded(const uint8_t* x, int m, const uint8_t* y, int n,
                        int match, int mismatch, int gap_open, int gap_extend,

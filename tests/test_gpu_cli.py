@@ -109,8 +109,21 @@ def test_authored_indel_bam_end_to_end(tmp_path, mode, umi, aligner, prep):
     batch, wm = refpipe.pack(vcf, refpipe.read_fasta(fap), refpipe.read_bam(bam), bcs, refpipe.Args(use_umi=umi))
     # the counters of the log (:350-379) are the same whichever side did the barcode / UMI tests
     log = r.stdout + r.stderr
-    assert "not being associated with a cell barcode: %d\n" % wm["num_not_cell_bc"] in log
-    assert "not having a UMI: %d\n" % wm["num_non_umi"] in log
+    # all nine Metrics counters (src/main.rs:449-459) as the info log prints them (:350-379)
+    want_lines = [
+        "Number of alignments evaluated: %d" % wm["num_reads"],
+        "Number of alignments skipped due to low mapping quality: %d" % wm["num_low_mapq"],
+        "Number of alignments skipped due to not being primary: %d" % wm["num_non_primary"],
+        "Number of alignments skipped due to being duplicates: %d" % wm["num_duplicates"],
+        "Number of alignments skipped due to not being associated with a cell barcode: %d" % wm["num_not_cell_bc"],
+        "Number of alignments skipped due to not intersecting variant: %d" % wm["num_not_useful"],
+        "Number of alignments skipped due to not having a UMI: %d" % wm["num_non_umi"],
+        "Number of VCF records skipped due to having invalid characters in the alternative haplotype: %d" % wm["num_invalid_recs"],
+        "Number of VCF records skipped due to being multi-allelic: %d" % wm["num_multiallelic_recs"],
+    ]
+    for ln in want_lines:
+        assert ln + "\n" in log, ln
+    assert wm["num_reads"] > wm["num_not_cell_bc"] > 0 and wm["num_not_useful"] > 0 and wm["num_multiallelic_recs"] == 1
     cfg = default_config(aligner=aligner, scoring_mode=mode, use_umi=int(umi), n_barcodes=len(bcs))
     r, a = oracle.batch_scores(batch, cfg, threads=8)
     coo = oracle.batch_reduce(batch, cfg, r, a)

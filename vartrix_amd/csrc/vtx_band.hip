@@ -45,6 +45,7 @@
 #include <cstring>
 
 #include "vtx_device.h"
+#include "../../include/vtx_band_semantics.h"
 
 #define KMER 6
 #define BANDW 20
@@ -178,7 +179,7 @@ __device__ int band_task(const uint8_t* x, int m, const uint8_t* y, int n, band_
     const int32_t first = nxt;                       // dpp[] now holds the successor on the chain
     // ---- anchor staircase -> rmin / rmax per anchored column, and the certificate walk ----
     const int fx = (int)(sc.mt[first] >> 16), fy = (int)(sc.mt[first] & 0xffff);
-    int d0 = fx < fy ? fx : fy; if (d0 > 2 * KMER) d0 = 2 * KMER;
+    int d0 = fx < fy ? fx : fy; if (d0 > VTX_BAND_LAZY_EXT(KMER)) d0 = VTX_BAND_LAZY_EXT(KMER);
     int r = fx - d0, c = fy - d0;                    // current anchor (DP coordinates: cell (r, c))
     const int cA = c;
     walk_state w = {0, -100000, 0, 0};
@@ -201,7 +202,7 @@ __device__ int band_task(const uint8_t* x, int m, const uint8_t* y, int n, band_
         for (int i = 0; i < dc; ++i) STEP_RIGHT()
         // the k-mer itself (add_kmer, or add_entry for a continued k-mer: same cells)
         const int32_t nx = sc.dpp[p];
-        int steps = KMER;
+        int steps = VTX_BAND_KMER_LAST_ANCHOR(KMER);      // add_kmer: anchors d = 0 .. k
         if (nx >= 0) {
             const int qx = (int)(sc.mt[nx] >> 16), qy = (int)(sc.mt[nx] & 0xffff);
             if (qx == px + 1 && qy == py + 1) steps = 1;     // next match continues: advance one cell only
@@ -209,7 +210,7 @@ __device__ int band_task(const uint8_t* x, int m, const uint8_t* y, int n, band_
         for (int i = 0; i < steps; ++i) STEP_DIAG()
         p = nx;
     }
-    int d1 = (m - r) < (n - c) ? (m - r) : (n - c); if (d1 > 2 * KMER) d1 = 2 * KMER;
+    int d1 = (m - r) < (n - c) ? (m - r) : (n - c); if (d1 > VTX_BAND_LAZY_EXT(KMER)) d1 = VTX_BAND_LAZY_EXT(KMER);
     for (int i = 0; i < d1; ++i) STEP_DIAG()
 #undef STEP_DIAG
 #undef STEP_DOWN
@@ -356,7 +357,7 @@ __device__ int band_finish(const uint32_t* mylog, uint32_t lg_n, uint32_t best_i
         uint32_t nv = 0;
         const uint32_t fst = seg_xy[n_seg - 1];
         const int fx = (int)(fst >> 16), fy = (int)(fst & 0xffff);
-        int d0 = fx < fy ? fx : fy; if (d0 > 2 * KMER) d0 = 2 * KMER;
+        int d0 = fx < fy ? fx : fy; if (d0 > VTX_BAND_LAZY_EXT(KMER)) d0 = VTX_BAND_LAZY_EXT(KMER);
         int r = fx - d0, c = fy - d0;
         walk_state w = {0, -100000, 0, 0};
 #define EMIT() verts[nv++] = ((uint32_t)r << 16) | (uint32_t)c
@@ -375,14 +376,14 @@ __device__ int band_finish(const uint32_t* mylog, uint32_t lg_n, uint32_t best_i
             for (int i = 0; i < dc; ++i) { ++c; walk_gap(w, 2); }
             if (dc > 0) EMIT();
             // the segment's k-mer cells: len + K - 1 diagonal steps, every one an exact match
-            const int run = (int)seg_len[sgi] + KMER - 1;
+            const int run = (int)seg_len[sgi] - 1 + VTX_BAND_KMER_LAST_ANCHOR(KMER);
             const int32_t v = (w.s > w.gap ? w.s : w.gap) + 1;      // s >= 0, so v >= 1
             w.s = v + (run - 1); w.gap = -100000; w.dir = 0;
             if (w.s > w.best) w.best = w.s;
             r += run; c += run;
             EMIT();
         }
-        int d1 = ((int)m - r) < ((int)n - c) ? ((int)m - r) : ((int)n - c); if (d1 > 2 * KMER) d1 = 2 * KMER;
+        int d1 = ((int)m - r) < ((int)n - c) ? ((int)m - r) : ((int)n - c); if (d1 > VTX_BAND_LAZY_EXT(KMER)) d1 = VTX_BAND_LAZY_EXT(KMER);
         for (int i = 0; i < d1; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
         if (d1 > 0) EMIT();
 #undef EMIT
