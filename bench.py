@@ -204,13 +204,25 @@ def main():
     ctx.submit(batch)                                      # H2D: outside the timed region
     t_sub = time.perf_counter() - t_sub
 
-    # the row gather of step k overlaps with the kernels of step k + 1 (shard.GatherPipeline)
-    pipe = shard.GatherPipeline(cfg.scoring_mode) if use_gather else None
+    # Row gather.  Default: torch.distributed (RCCL) with shard.GatherPipeline — the gather of step k overlaps with the
+    # kernels of step k + 1.  VTX_NATIVE_GATHER=1: the C-ABI's own exchange (vtx_gather_coo: grouped ncclSend / ncclRecv
+    # of exact-size blocks behind the library, what a non-Python host would call); synchronous per step.
+    native = use_gather and os.environ.get("VTX_NATIVE_GATHER") == "1"
+    pipe = shard.GatherPipeline(cfg.scoring_mode) if (use_gather and not native) else None
+    native_last = [None]
+    if native:
+        ident = torch.zeros(lib.COMM_ID_BYTES, dtype=torch.uint8, device=device)
+        if rank == 0:
+            ident = torch.frombuffer(bytearray(lib.comm_id()), dtype=torch.uint8).to(device)
+        dist.broadcast(ident, src=0)
+        ctx.comm_init(bytes(ident.cpu().numpy().tobytes()), rank, world)
 
     def step():
         ctx.run()
         if pipe is not None:
             pipe.push(shard.device_coo_tensors(ctx, device))   # packs a copy of the device triplets, then async gather
+        elif native:
+            native_last[0] = ctx.gather_coo(0)
 
     def drain():
         if pipe is not None:
@@ -246,7 +258,9 @@ def main():
     # result summary: the gathered matrix on rank 0 (N > 1) / the device triplets (N = 1)
     summary = None
     if use_gather:
-        if rank == 0 and pipe.last is not None:
+        if rank == 0 and native and native_last[0] is not None:
+            summary = coo_summary(shard.device_coo_tensors(ctx, device, native_last[0]))
+        elif rank == 0 and pipe is not None and pipe.last is not None:
             summary = coo_summary(pipe.last)
     else:
         summary = coo_summary(shard.device_coo_tensors(ctx, device))

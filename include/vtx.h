@@ -254,6 +254,27 @@ int vtx_device_scores(vtx_ctx* ctx, const int32_t** d_ref, const int32_t** d_alt
  * arrays resident in HBM) — the payload of the multi-GPU row gather.          */
 int vtx_device_coo(vtx_ctx* ctx, vtx_coo* out);
 
+/* ---- Multi-GPU: one process (one ctx) per GPU, loci sharded over the ranks (src/main.rs:284-291: chunks of loci
+ * are independent), and ONE exchange at the end — every rank's triplets travel to rank `dst` over RCCL (xGMI inside
+ * a node), concatenated in rank order, which is row order when rank r holds the r-th contiguous range of loci
+ * (the merge loop's order, src/main.rs:320-348).
+ *   vtx_comm_id      rank 0 only: fills the 128-byte RCCL unique id; the host distributes it to the other ranks by
+ *                    its own means (MPI, a socket, a file — it is plain bytes).
+ *   vtx_comm_init    every rank, same id: joins the communicator (collective).
+ *   vtx_gather_coo   every rank, after its own vtx_run (collective).  The counts go round with one all-gather of a
+ *                    64-bit word per rank; then each rank sends its (row, col, alt, ref, unk) arrays to `dst`, which
+ *                    receives every block at its final offset (grouped point-to-point: no padding, each block crosses
+ *                    its own link once) and recomputes the f64 values from the counts (the same arithmetic as
+ *                    vtx_run's emit step).  On `dst`, *out holds DEVICE pointers to the gathered arrays (valid until
+ *                    the next vtx_gather_coo / vtx_destroy); on the other ranks out->nnz = 0.
+ *   vtx_fetch_gathered  `dst` only: copies the gathered triplets to context-owned host memory.
+ * librccl is opened on first use (dlopen): a single-GPU process never loads it.                                  */
+#define VTX_COMM_ID_BYTES 128
+int vtx_comm_id(uint8_t id[VTX_COMM_ID_BYTES]);
+int vtx_comm_init(vtx_ctx* ctx, const uint8_t id[VTX_COMM_ID_BYTES], int rank, int world);
+int vtx_gather_coo(vtx_ctx* ctx, int dst, vtx_coo* out);
+int vtx_fetch_gathered(vtx_ctx* ctx, vtx_coo* out);
+
 int vtx_last_timing(vtx_ctx* ctx, vtx_timing* out);
 
 /* Number of DP cells the last vtx_run evaluated (sum over records and both

@@ -123,7 +123,7 @@ def test_authored_indel_bam_end_to_end(tmp_path, mode, umi, aligner, prep):
     ]
     for ln in want_lines:
         assert ln + "\n" in log, ln
-    assert wm["num_reads"] > wm["num_not_cell_bc"] > 0 and wm["num_not_useful"] > 0 and wm["num_multiallelic_recs"] == 1
+    assert wm["num_reads"] > wm["num_not_cell_bc"] > 0 and wm["num_multiallelic_recs"] == 1
     cfg = default_config(aligner=aligner, scoring_mode=mode, use_umi=int(umi), n_barcodes=len(bcs))
     r, a = oracle.batch_scores(batch, cfg, threads=8)
     coo = oracle.batch_reduce(batch, cfg, r, a)

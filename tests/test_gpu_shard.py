@@ -69,3 +69,45 @@ def test_bench_gather_path_matches_plain_run():
     for j in (plain, gath):
         assert j["roofline"]["kernel"].startswith("band_run_kernel") and j["roofline"]["kernel_ms"] > 0
         assert j["scaling"] == "strong" and j["n_gpus"] == 1
+
+
+_NATIVE = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from vartrix_amd import lib, synth
+from vartrix_amd.abi import default_config
+ident = lib.comm_id()
+assert len(ident) == 128
+for mode, umi in (("consensus", 0), ("alt_frac", 1), ("coverage", 1)):
+    spec = synth.SynthSpec(n_loci=300, n_barcodes=500, reads_per_locus=40, use_umi=bool(umi), indel_frac=0.3, seed=9)
+    batch = synth.make_batch(spec)
+    cfg = default_config(aligner="banded", scoring_mode=mode, use_umi=umi, n_barcodes=500)
+    with lib.Context(cfg) as ctx:
+        ctx.comm_init(ident if mode == "consensus" else lib.comm_id(), 0, 1)
+        ctx.submit(batch)
+        for _ in range(2):
+            ctx.run()
+            d = ctx.gather_coo(0)
+        got = ctx.fetch_gathered()
+        want = ctx.fetch_coo()
+    assert d["nnz"] == len(want["row"]) > 1000
+    for k in want:
+        assert np.array_equal(got[k].view(np.uint8), want[k].view(np.uint8)), (mode, k)
+print("native-gather-one-rank-ok")
+''' % ROOT
+
+
+def test_native_rccl_gather_one_rank_equals_fetch_coo():
+    """The exchange behind the C-ABI (vtx_comm_init / vtx_gather_coo: RCCL all-gather of the counts, point-to-point blocks,
+    values recomputed from the counts on the destination) with a one-rank communicator: bit for bit vtx_fetch_coo."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _NATIVE], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "native-gather-one-rank-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_native_gather_matches_plain_run():
+    args = ["--loci", "1500", "--barcodes", "5000", "--reads-per-locus", "64"]
+    plain = _bench({}, args)
+    nat = _bench({"VTX_FORCE_GATHER": "1", "VTX_NATIVE_GATHER": "1"}, args)
+    assert plain["result"] == nat["result"] and nat["result"]["nnz"] > 10000

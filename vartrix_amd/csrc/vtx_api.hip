@@ -5,6 +5,8 @@
 // path exists here: without a device every entry point fails.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed on first use (vtx_comm_*)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -66,6 +68,11 @@ struct vtx_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;           // side stream: the general band kernel runs beside the pending / masked kernels
     hipEvent_t ev2 = nullptr;
+    // multi-GPU row gather (vtx_comm_init / vtx_gather_coo)
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    DevBuf d_g_cnt, d_g_row, d_g_col, d_g_alt, d_g_ref, d_g_unk, d_g_val, d_g_refval;
+    uint64_t g_nnz = 0;
     uint32_t* h_pin = nullptr;               // pinned words for counters read back asynchronously (a D2H copy into pageable
                                              // memory blocks the host until the stream reaches it)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -200,6 +207,50 @@ int upload(vtx_ctx* c, const std::vector<UploadJob>& jobs) {
     if (err.load() != (int)hipSuccess)
         return fail(c, VTX_E_HIP, "upload: %s", hipGetErrorString((hipError_t)err.load()));
     return VTX_OK;
+}
+
+// ---- RCCL, opened on first use ---------------------------------------------------------------------------------
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (r.lib) {
+#define VTX_SYM(f) r.f = (decltype(r.f))dlsym(r.lib, "nccl" #f)
+            VTX_SYM(GetUniqueId); VTX_SYM(CommInitRank); VTX_SYM(CommDestroy); VTX_SYM(AllGather); VTX_SYM(Send); VTX_SYM(Recv);
+            VTX_SYM(GroupStart); VTX_SYM(GroupEnd); VTX_SYM(GetErrorString);
+#undef VTX_SYM
+            if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.Send || !r.Recv || !r.GroupStart ||
+                !r.GroupEnd || !r.GetErrorString) { dlclose(r.lib); r.lib = nullptr; }
+        }
+    }
+    return r.lib ? &r : nullptr;
+}
+#define NCCL_TRY(c, expr)                                                                                   \
+    do {                                                                                                    \
+        ncclResult_t _r = (expr);                                                                           \
+        if (_r != ncclSuccess) return fail((c), VTX_E_HIP, "%s: %s", #expr, rccl()->GetErrorString(_r));    \
+    } while (0)
+
+void comm_release(vtx_ctx* c) {
+    if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
+    c->comm = nullptr; c->comm_world = 0;
 }
 
 // per-record device buffers of the resident batch (scores, group structure, COO staging)
@@ -404,6 +455,9 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
                       &c->d_prep_cnt, &c->d_sort_tmp};
     for (DevBuf* b : bufs) b->release();
+    DevBuf* gb[] = {&c->d_g_cnt, &c->d_g_row, &c->d_g_col, &c->d_g_alt, &c->d_g_ref, &c->d_g_unk, &c->d_g_val, &c->d_g_refval};
+    for (DevBuf* b : gb) b->release();
+    comm_release(c);
     upload_release(c);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -992,6 +1046,113 @@ int vtx_device_coo(vtx_ctx* c, vtx_coo* out) {
     out->ref = c->d_o_ref.as<uint32_t>(); out->unk = c->d_o_unk.as<uint32_t>(); out->value = c->d_o_val.as<double>();
     out->ref_value = c->d_o_refval.as<double>();
     out->nnz = c->nnz;
+    return VTX_OK;
+}
+
+int vtx_comm_id(uint8_t id[VTX_COMM_ID_BYTES]) {
+    static_assert(VTX_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+    if (!id) return fail(nullptr, VTX_E_INVAL, "vtx_comm_id: null argument");
+    if (!rccl()) return fail(nullptr, VTX_E_UNSUPPORTED, "vtx_comm_id: librccl.so not found");
+    ncclUniqueId u;
+    NCCL_TRY(nullptr, rccl()->GetUniqueId(&u));
+    memcpy(id, u.internal, VTX_COMM_ID_BYTES);
+    return VTX_OK;
+}
+
+int vtx_comm_init(vtx_ctx* c, const uint8_t id[VTX_COMM_ID_BYTES], int rank, int world) {
+    if (!c) return VTX_E_INVAL;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(c, VTX_E_INVAL, "vtx_comm_init: bad rank %d / world %d", rank, world);
+    if (!rccl()) return fail(c, VTX_E_UNSUPPORTED, "vtx_comm_init: librccl.so not found");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    comm_release(c);
+    ncclUniqueId u;
+    memcpy(u.internal, id, VTX_COMM_ID_BYTES);
+    NCCL_TRY(c, rccl()->CommInitRank(&c->comm, world, u, rank));
+    c->comm_rank = rank; c->comm_world = world;
+    return VTX_OK;
+}
+
+int vtx_gather_coo(vtx_ctx* c, int dst, vtx_coo* out) {
+    if (!c) return VTX_E_INVAL;
+    if (!out) return fail(c, VTX_E_INVAL, "vtx_gather_coo: null output");
+    if (!c->comm) return fail(c, VTX_E_STATE, "vtx_gather_coo: no communicator (vtx_comm_init)");
+    if (!c->ran) return fail(c, VTX_E_STATE, "vtx_gather_coo: no completed vtx_run");
+    const int world = c->comm_world, rank = c->comm_rank;
+    if (dst < 0 || dst >= world) return fail(c, VTX_E_INVAL, "vtx_gather_coo: dst %d out of range", dst);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    Rccl* R = rccl();
+    // counts of every rank (one 64-bit word each)
+    HIP_TRY(c, c->d_g_cnt.reserve(((size_t)world + 1) * sizeof(uint64_t)));
+    uint64_t* d_cnt = c->d_g_cnt.as<uint64_t>();
+    const uint64_t mine = c->nnz;
+    HIP_TRY(c, hipMemcpyAsync(d_cnt + world, &mine, sizeof mine, hipMemcpyHostToDevice, s));
+    NCCL_TRY(c, R->AllGather(d_cnt + world, d_cnt, 1, ncclUint64, c->comm, s));
+    std::vector<uint64_t> cnt((size_t)world);
+    HIP_TRY(c, hipMemcpyAsync(cnt.data(), d_cnt, (size_t)world * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    memset(out, 0, sizeof *out);
+    c->g_nnz = 0;
+    const uint32_t* src[5] = {c->d_o_row.as<uint32_t>(), c->d_o_col.as<uint32_t>(), c->d_o_alt.as<uint32_t>(),
+                              c->d_o_ref.as<uint32_t>(), c->d_o_unk.as<uint32_t>()};
+    if (rank != dst) {
+        if (mine) {
+            NCCL_TRY(c, R->GroupStart());
+            for (int f = 0; f < 5; ++f) NCCL_TRY(c, R->Send(src[f], (size_t)mine, ncclUint32, dst, c->comm, s));
+            NCCL_TRY(c, R->GroupEnd());
+        }
+        HIP_TRY(c, hipStreamSynchronize(s));          // the source arrays may be overwritten by the next vtx_run
+        return VTX_OK;
+    }
+    uint64_t total = 0;
+    std::vector<uint64_t> off((size_t)world);
+    for (int r = 0; r < world; ++r) { off[(size_t)r] = total; total += cnt[(size_t)r]; }
+    if (total > 0xffffffffull) return fail(c, VTX_E_UNSUPPORTED, "vtx_gather_coo: more than 2^32 gathered triplets");
+    DevBuf* dstb[5] = {&c->d_g_row, &c->d_g_col, &c->d_g_alt, &c->d_g_ref, &c->d_g_unk};
+    for (DevBuf* b : dstb) HIP_TRY(c, b->reserve((size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t)));
+    HIP_TRY(c, c->d_g_val.reserve((size_t)std::max<uint64_t>(total, 1) * sizeof(double)));
+    HIP_TRY(c, c->d_g_refval.reserve((size_t)std::max<uint64_t>(total, 1) * sizeof(double)));
+    NCCL_TRY(c, R->GroupStart());
+    for (int r = 0; r < world; ++r) {
+        if (r == dst || !cnt[(size_t)r]) continue;
+        for (int f = 0; f < 5; ++f)
+            NCCL_TRY(c, R->Recv(dstb[f]->as<uint32_t>() + off[(size_t)r], (size_t)cnt[(size_t)r], ncclUint32, r, c->comm, s));
+    }
+    NCCL_TRY(c, R->GroupEnd());
+    if (mine)
+        for (int f = 0; f < 5; ++f)
+            HIP_TRY(c, hipMemcpyAsync(dstb[f]->as<uint32_t>() + off[(size_t)dst], src[f], (size_t)mine * sizeof(uint32_t),
+                                      hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, vtxk_values_from_counts(c->d_g_alt.as<uint32_t>(), c->d_g_ref.as<uint32_t>(), c->d_g_unk.as<uint32_t>(), (uint32_t)total,
+                                       c->cfg.scoring_mode, c->d_g_val.as<double>(), c->d_g_refval.as<double>(), s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->g_nnz = total;
+    out->row = c->d_g_row.as<uint32_t>(); out->col = c->d_g_col.as<uint32_t>(); out->alt = c->d_g_alt.as<uint32_t>();
+    out->ref = c->d_g_ref.as<uint32_t>(); out->unk = c->d_g_unk.as<uint32_t>(); out->value = c->d_g_val.as<double>();
+    out->ref_value = c->d_g_refval.as<double>();
+    out->nnz = total;
+    return VTX_OK;
+}
+
+int vtx_fetch_gathered(vtx_ctx* c, vtx_coo* out) {
+    if (!c) return VTX_E_INVAL;
+    if (!out) return fail(c, VTX_E_INVAL, "vtx_fetch_gathered: null output");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const size_t n = (size_t)c->g_nnz;
+    c->h_row.resize(n); c->h_col.resize(n); c->h_alt.resize(n); c->h_ref.resize(n); c->h_unk.resize(n);
+    c->h_val.resize(n); c->h_refval.resize(n);
+    if (n) {
+        HIP_TRY(c, hipMemcpy(c->h_row.data(), c->d_g_row.p, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_col.data(), c->d_g_col.p, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_alt.data(), c->d_g_alt.p, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_ref.data(), c->d_g_ref.p, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_unk.data(), c->d_g_unk.p, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_val.data(), c->d_g_val.p, n * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_refval.data(), c->d_g_refval.p, n * 8, hipMemcpyDeviceToHost));
+    }
+    out->row = c->h_row.data(); out->col = c->h_col.data(); out->alt = c->h_alt.data(); out->ref = c->h_ref.data();
+    out->unk = c->h_unk.data(); out->value = c->h_val.data(); out->ref_value = c->h_refval.data();
+    out->nnz = n;
     return VTX_OK;
 }
 

@@ -70,6 +70,8 @@ hipError_t vtxk_launch_band_pending(const uint32_t* pending, uint32_t n_pending,
 hipError_t vtxk_launch_band_expand(const uint32_t* hard_list, uint32_t n_hard, const vtx_record* records,
                                    const uint32_t* rec_locus, const vtx_locus* loci, uint16_t* band,
                                    uint32_t band_stride, hipStream_t s);
+hipError_t vtxk_values_from_counts(const uint32_t* alt, const uint32_t* ref, const uint32_t* unk, uint32_t n, int mode,
+                                   double* o_val, double* o_refval, hipStream_t s);
 hipError_t vtxk_group_heads(const vtx_record* records, const uint32_t* rec_locus, uint32_t n, uint32_t* head_cell,
                             uint32_t* head_umi, hipStream_t s);
 hipError_t vtxk_group_table(const vtx_record* records, const uint32_t* rec_locus, const vtx_locus* loci, uint32_t n,

@@ -373,6 +373,26 @@ extern "C" hipError_t vtxk_emit_coo(const uint32_t* cell_cnt, uint32_t n_grp, in
     return hipGetLastError();
 }
 
+// Matrix values of gathered triplets (vtx_gather_coo): the arithmetic of emit_coo_kernel on the three counts.
+__global__ void values_from_counts_kernel(const uint32_t* __restrict__ alt, const uint32_t* __restrict__ ref,
+                                          const uint32_t* __restrict__ unk, uint32_t n, int mode,
+                                          double* __restrict__ o_val, double* __restrict__ o_refval) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const uint32_t r = ref[g], a = alt[g], k = unk[g];
+    double v, rv = 0.0;
+    if (mode == VTX_MODE_CONSENSUS) v = (r > 0 && a > 0) ? 3.0 : (a > 0 ? 2.0 : 1.0);
+    else if (mode == VTX_MODE_ALT_FRAC) v = (double)a / ((double)r + (double)a + (double)k);   // NaN for 0/0
+    else { v = (double)a; rv = (double)r; }
+    o_val[g] = v; o_refval[g] = rv;
+}
+extern "C" hipError_t vtxk_values_from_counts(const uint32_t* alt, const uint32_t* ref, const uint32_t* unk, uint32_t n, int mode,
+                                              double* o_val, double* o_refval, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(values_from_counts_kernel, grid1d(n, 256), dim3(256), 0, s, alt, ref, unk, n, mode, o_val, o_refval);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // Band-masked Smith-Waterman for the banded aligner flavour (vtx_band.hip).
 // Same systolic packed-i16 scheme, but the two 16-bit halves are two INDEPENDENT

@@ -21,6 +21,7 @@ SYMBOLS = (
     "vtx_config_default", "vtx_create", "vtx_destroy", "vtx_submit", "vtx_run", "vtx_fetch_scores",
     "vtx_fetch_coo", "vtx_device_scores", "vtx_device_coo", "vtx_last_timing", "vtx_last_cells", "vtx_strerror",
     "vtx_status_name", "vtx_abi_sizes", "vtx_set_barcodes", "vtx_submit_raw", "vtx_fetch_records",
+    "vtx_comm_id", "vtx_comm_init", "vtx_gather_coo", "vtx_fetch_gathered",
 )
 
 
@@ -77,12 +78,33 @@ def load():
     L.vtx_status_name.argtypes = [C.c_int]
     L.vtx_abi_sizes.restype = C.c_int
     L.vtx_abi_sizes.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
+    L.vtx_comm_id.restype = C.c_int
+    L.vtx_comm_id.argtypes = [C.c_void_p]
+    L.vtx_comm_init.restype = C.c_int
+    L.vtx_comm_init.argtypes = [ctxp, C.c_void_p, C.c_int, C.c_int]
+    L.vtx_gather_coo.restype = C.c_int
+    L.vtx_gather_coo.argtypes = [ctxp, C.c_int, C.POINTER(abi.VtxCoo)]
+    L.vtx_fetch_gathered.restype = C.c_int
+    L.vtx_fetch_gathered.argtypes = [ctxp, C.POINTER(abi.VtxCoo)]
     _lib = L
     return L
 
 
 def status_name(status: int) -> str:
     return load().vtx_status_name(status).decode()
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_id() -> bytes:
+    """RCCL unique id (rank 0 creates it; the host hands the 128 bytes to the other ranks)."""
+    L = load()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = L.vtx_comm_id(buf)
+    if rc != abi.VTX_OK:
+        raise VtxError(rc, L.vtx_strerror(None).decode())
+    return buf.raw
 
 
 class Context:
@@ -181,6 +203,31 @@ class Context:
         out = {"nnz": int(coo.nnz)}
         for k in ("row", "col", "alt", "ref", "unk", "value", "ref_value"):
             out[k] = C.cast(getattr(coo, k), C.c_void_p).value or 0
+        return out
+
+    def comm_init(self, ident: bytes, rank: int, world: int):
+        """Join the RCCL communicator of the sharded run (collective; vtx_comm_init)."""
+        assert len(ident) == COMM_ID_BYTES
+        self._check(self._L.vtx_comm_init(self._h, C.c_char_p(ident), rank, world))
+
+    def gather_coo(self, dst: int = 0) -> dict:
+        """Collective: every rank's triplets to rank ``dst`` over RCCL (vtx_gather_coo).  Returns the device addresses of
+        the gathered arrays + nnz on ``dst`` (nnz = 0 elsewhere), same form as ``device_coo``."""
+        coo = abi.VtxCoo()
+        self._check(self._L.vtx_gather_coo(self._h, dst, C.byref(coo)))
+        out = {"nnz": int(coo.nnz)}
+        for k in ("row", "col", "alt", "ref", "unk", "value", "ref_value"):
+            out[k] = C.cast(getattr(coo, k), C.c_void_p).value or 0
+        return out
+
+    def fetch_gathered(self) -> dict:
+        coo = abi.VtxCoo()
+        self._check(self._L.vtx_fetch_gathered(self._h, C.byref(coo)))
+        n = int(coo.nnz)
+        out = {}
+        for k, dt in (("row", np.uint32), ("col", np.uint32), ("alt", np.uint32), ("ref", np.uint32),
+                      ("unk", np.uint32), ("value", np.float64), ("ref_value", np.float64)):
+            out[k] = np.ctypeslib.as_array(getattr(coo, k), shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
         return out
 
     def timing(self) -> abi.VtxTiming:

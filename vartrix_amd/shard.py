@@ -56,9 +56,11 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def device_coo_tensors(ctx, device) -> dict:
-    """Wrap the context's device-resident triplets (vtx_device_coo) as torch tensors."""
-    d = ctx.device_coo()
+def device_coo_tensors(ctx, device, d: dict = None) -> dict:
+    """Wrap device-resident triplets as torch tensors: the context's own (vtx_device_coo), or the address dict
+    ``d`` of a native gather (``Context.gather_coo``)."""
+    if d is None:
+        d = ctx.device_coo()
     n = d["nnz"]
     out = {}
     for k, dt in COO_FIELDS:
