@@ -97,6 +97,9 @@ struct Shard {
     std::string err;
     int rc = 0;
     double t_create = 0, t_submit = 0, t_run = 0, t_fetch = 0;
+    // --devices N > 1: the shards' rows meet on device 0 through the library's RCCL gather (vtx_gather_coo)
+    const uint8_t* comm_id = nullptr;
+    int rank = 0, world = 1;
 };
 
 double since(std::chrono::steady_clock::time_point t0) {
@@ -110,6 +113,9 @@ void run_shard(Shard* s, vtx_config cfg) {
     double t0 = now_s();
     s->rc = vtx_create(&cfg, &ctx);
     if (s->rc) { s->err = vtx_strerror(nullptr); return; }
+    if (s->comm_id && (s->rc = vtx_comm_init(ctx, s->comm_id, s->rank, s->world))) {     // collective over the shard threads
+        s->err = vtx_strerror(ctx); vtx_destroy(ctx); return;
+    }
     s->t_create = now_s() - t0; t0 = now_s();
     vtx_batch b{s->loci.data(), (uint32_t)s->loci.size(), s->records.data(), (uint32_t)s->records.size(), s->haps,
                 s->hap_bytes, s->reads, s->read_bytes};
@@ -127,7 +133,13 @@ void run_shard(Shard* s, vtx_config cfg) {
     s->t_submit = now_s() - t0; t0 = now_s();
     if ((s->rc = vtx_run(ctx))) { s->err = vtx_strerror(ctx); vtx_destroy(ctx); return; }
     s->t_run = now_s() - t0; t0 = now_s();
-    if ((s->rc = vtx_fetch_coo(ctx, &coo))) { s->err = vtx_strerror(ctx); vtx_destroy(ctx); return; }
+    if (s->comm_id) {
+        // every shard's triplets to rank 0 over RCCL (rank order = row order); rank 0 copies the gathered matrix out
+        vtx_coo dev{};
+        if ((s->rc = vtx_gather_coo(ctx, 0, &dev))) { s->err = vtx_strerror(ctx); vtx_destroy(ctx); return; }
+        if (s->rank != 0) { s->t_fetch = now_s() - t0; vtx_destroy(ctx); return; }
+        if ((s->rc = vtx_fetch_gathered(ctx, &coo))) { s->err = vtx_strerror(ctx); vtx_destroy(ctx); return; }
+    } else if ((s->rc = vtx_fetch_coo(ctx, &coo))) { s->err = vtx_strerror(ctx); vtx_destroy(ctx); return; }
     s->row.assign(coo.row, coo.row + coo.nnz);
     s->col.assign(coo.col, coo.col + coo.nnz);
     s->val.assign(coo.value, coo.value + coo.nnz);
@@ -302,6 +314,13 @@ int main(int argc, char** argv) {
         if (bi == 0)
             LOG_INFO("Ingest + filter + pack: %.3f s (%u batch(es); first: %u loci, %u %s)", t_ingest, n_batches, full.n_loci, full.n_records,
                      raw ? "raw reads; barcode lookup / UMI grouping / sort on the device" : "scored reads");
+        // more than one device (or the test hook): the row exchange runs behind the C-ABI over RCCL
+        uint8_t comm_id[VTX_COMM_ID_BYTES];
+        const bool use_comm = ndev > 1 || getenv("VTX_CLI_FORCE_GATHER");
+        if (use_comm) {
+            if (int rc = vtx_comm_id(comm_id)) { printf("Vartrix error.\nError: %s: %s\n", vtx_status_name(rc), vtx_strerror(nullptr)); return 1; }
+            for (int d = 0; d < ndev; ++d) { shards[(size_t)d].comm_id = comm_id; shards[(size_t)d].rank = d; shards[(size_t)d].world = ndev; }
+        }
         std::vector<std::thread> th;
         for (int d = 0; d < ndev; ++d) {
             vtx_config c = cfg;
