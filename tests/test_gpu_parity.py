@@ -280,6 +280,41 @@ def test_certificate_decides_most_clean_alignments():
     assert frac < 0.08
 
 
+def test_records_beyond_the_fast_limits_take_the_exact_slow_path():
+    """A 3 000-base read, a haplotype pair of 2 600 / 5 400 bases (a long sequence-resolved insertion), and ordinary
+    records around them in one batch: the reference aligns any length (src/main.rs:898-901), so nothing may be rejected
+    and every score must match the oracle — both flavours, all modes going through the same reduction."""
+    rng = np.random.default_rng(41)
+    g = bytes(rng.choice(list(b"ACGT"), 12000).tolist())
+
+    def mutate(seq, n):
+        b = bytearray(seq)
+        for _ in range(n):
+            b[int(rng.integers(0, len(b)))] = b"ACGT"[int(rng.integers(0, 4))]
+        return bytes(b)
+    ins = bytes(rng.choice(list(b"ACGT"), 2800).tolist())
+    haps = [
+        (g[100:301], g[100:200] + b"T" + g[201:301]),                         # ordinary SNV locus
+        (g[1000:3600], g[1000:2300] + ins + g[2300:3600]),                    # haplotypes beyond the LDS tables
+        (g[5000:5201], g[5000:5100] + b"G" + g[5101:5201]),                   # ordinary locus with one very long read
+        (g[7000:7201], g[7000:7100] + g[7108:7201]),
+    ]
+    reads = [
+        [(0, 0, g[120:270]), (1, 0, mutate(g[130:280], 2)), (2, 0, g[100:200] + b"T" + g[201:260])],
+        [(0, 0, g[2200:2350]), (1, 0, g[2250:2300] + ins[:100]), (2, 0, mutate(g[1000:2300] + ins[:700], 12)),
+         (3, 0, ins[2700:] + g[2300:2400]), (4, 0, b"ACG")],
+        [(0, 0, g[5050:5200]), (1, 0, mutate(g[4000:5100] + b"G" + g[5101:7000], 25)), (2, 0, g[5090:5101] + b"G" + g[5101:5160])],
+        [(0, 0, g[7010:7160]), (0, 1, g[7020:7100] + g[7108:7180])],
+    ]
+    batch = _manual_batch(haps, reads, 8)
+    assert int(batch.records["read_len"].max()) == 3000 and int(batch.loci["alt_len"].max()) == 5400
+    for aligner in ALIGNERS:
+        for mode, umi in (("coverage", 0), ("alt_frac", 1)):
+            cfg = default_config(aligner=aligner, scoring_mode=mode, use_umi=umi, n_barcodes=8)
+            ref_s, alt_s, coo = assert_same(batch, cfg, threads=4)
+    assert ref_s.max() > 1000          # the long read really aligned end to end
+
+
 def test_band_buffer_caps_spill_into_the_general_kernel(tmp_path):
     """Band slots and pending records are sized for a fraction of the tasks; whatever exceeds them must take the general
     kernel's route and still come out exact.  VTX_BAND_HARD_CAP=3 leaves three slots of each kind (separate process: the

@@ -56,8 +56,12 @@ const uint32_t kDuoLociCap = 8;     // the duo kernel runs 3 workgroups per CU (
 // (rows per lane, lanes per record) choices; capacity = R * GL read bases.
 const int kShapes[][2] = {{2, 16}, {4, 16}, {6, 16}, {8, 16}, {10, 16}, {12, 16}, {16, 16}, {8, 64}, {16, 64}};
 const int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
-const uint32_t kMaxReadLen = 16 * 64;
-const uint32_t kMaxHapLen = 2400;   // 16 record slots x (len + 35) words must fit 160 KiB of LDS
+const uint32_t kFastReadLen = VTX_FAST_READ_LEN;   // 16 rows x 64 lanes
+const uint32_t kFastHapLen = VTX_FAST_HAP_LEN;     // 16 record slots x (len + 35) words must fit 160 KiB of LDS
+// Beyond the fast limits a record is scored by slow_align_kernel (exact, one lane per alignment); its 16-bit coordinates
+// set the hard limits.
+const uint32_t kMaxReadLen = 30000;
+const uint32_t kMaxHapLen = 30000;
 
 thread_local std::string g_create_err;
 
@@ -95,6 +99,8 @@ struct vtx_ctx {
     DevBuf d_raw, d_tags, d_raw_locus, d_key_lc, d_key_lc2, d_key_umi, d_key_umi2, d_idx, d_idx2, d_shape, d_shape2, d_seq,
         d_locus_cnt, d_locus_scan, d_prep_cnt, d_sort_tmp;
     uint32_t max_read_len = 0, fast_overflow = 0;
+    uint32_t slow_off = 0, slow_cnt = 0, max_hap_all = 0, max_read_all = 0;   // records of the slow list (d_work[slow_off ..])
+    DevBuf d_slow_ws, d_slow_retry;
     // host -> device feed: pinned staging buffers + one stream per copy worker (see upload())
     static constexpr int kUpWorkers = 6, kUpSlots = 2;
     static constexpr size_t kUpChunk = 8u << 20;
@@ -339,6 +345,7 @@ int make_buckets(vtx_ctx* c, const uint32_t* shape_cnt, uint32_t max_hap, uint32
         c->buckets.push_back(bk);
         off += shape_cnt[sh];
     }
+    c->slow_off = off; c->slow_cnt = shape_cnt[kNumShapes];          // the slow list sorts last (shape index kNumShapes)
     uint32_t lut_flag[48] = {0};
     HIP_TRY(c, hipMemcpyAsync(lut_flag, d_lut_flag, sizeof lut_flag, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -455,6 +462,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
                       &c->d_prep_cnt, &c->d_sort_tmp};
     for (DevBuf* b : bufs) b->release();
+    c->d_slow_ws.release(); c->d_slow_retry.release();
     DevBuf* gb[] = {&c->d_g_cnt, &c->d_g_row, &c->d_g_col, &c->d_g_alt, &c->d_g_ref, &c->d_g_unk, &c->d_g_val, &c->d_g_refval};
     for (DevBuf* b : gb) b->release();
     comm_release(c);
@@ -478,7 +486,7 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
         return fail(c, VTX_E_UNSUPPORTED, "vtx_submit: arenas above 4 GiB need more than one batch");
 
     // ---- loci: validated on the host (O(loci)); everything per record happens on the device ----
-    uint32_t next_rec = 0, max_hap = 0;
+    uint32_t next_rec = 0, max_hap = 0, max_hap_all = 0;
     for (uint32_t l = 0; l < nl; ++l) {
         const vtx_locus& L = b->loci[l];
         if (L.rec_begin != next_rec) return fail(c, VTX_E_INVAL, "vtx_submit: locus %u: records not contiguous (rec_begin %u, expected %u)", l, L.rec_begin, next_rec);
@@ -487,7 +495,9 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
             return fail(c, VTX_E_INVAL, "vtx_submit: locus %u: haplotype outside hap_arena", l);
         if (L.ref_len > kMaxHapLen || L.alt_len > kMaxHapLen)
             return fail(c, VTX_E_UNSUPPORTED, "vtx_submit: locus %u: haplotype longer than %u", l, kMaxHapLen);
-        max_hap = std::max(max_hap, std::max(L.ref_len, L.alt_len));
+        const uint32_t hl = std::max(L.ref_len, L.alt_len);
+        max_hap_all = std::max(max_hap_all, hl);
+        if (hl <= kFastHapLen) max_hap = std::max(max_hap, hl);      // LDS tables are sized for the loci the fast kernels take
         next_rec = L.rec_begin + L.rec_count;
     }
     if (next_rec != nr) return fail(c, VTX_E_INVAL, "vtx_submit: %u records not covered by any locus", nr - next_rec);
@@ -508,7 +518,7 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
     uint32_t* d_shape_cnt = (uint32_t*)(d_counters + 8);
     uint32_t caps[kNumShapes];
     for (int i = 0; i < kNumShapes; ++i) caps[i] = (uint32_t)(kShapes[i][0] * kShapes[i][1]);
-    HIP_TRY(c, vtxk_prep_set_shapes(caps, kNumShapes));
+    HIP_TRY(c, vtxk_prep_set_shapes(caps, kNumShapes, kFastReadLen, kFastHapLen));
 
     // ---- feed: descriptors first, then the record checks run on the device while the read bases still stream in ----
     hipStream_t s = c->stream;
@@ -528,7 +538,7 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
         HIP_TRY(c, vtxk_prep_sort_u8(c->d_shape.as<uint8_t>(), c->d_shape2.as<uint8_t>(), c->d_seq.as<uint32_t>(),
                                      c->d_work.as<uint32_t>(), nr, c->d_sort_tmp.p, sort_tmp, s));
     }
-    HIP_TRY(c, hipMemcpyAsync(cnt, d_counters, 7 * u64, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(cnt, d_counters, 8 * u64, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(shape_cnt, d_shape_cnt, sizeof shape_cnt, hipMemcpyDeviceToHost, s));
     if (int rc = upload(c, {{c->d_read.p, b->read_arena, (size_t)b->read_bytes}})) return rc;     // overlaps with the kernels above
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -544,6 +554,7 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
     if (int rc = build_groups(c, nr)) return rc;
     HIP_TRY(c, hipStreamSynchronize(s));
     c->n_loci = nl; c->n_records = nr; c->max_hap_len = max_hap; c->max_read_len = (uint32_t)cnt[5]; c->cells = cnt[3];
+    c->max_hap_all = max_hap_all; c->max_read_all = std::max<uint32_t>((uint32_t)cnt[7], std::max<uint32_t>((uint32_t)cnt[5], 1u));
     c->submitted = true;
     return VTX_OK;
 }
@@ -604,7 +615,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     if (b->hap_bytes > 0xffffffffull || b->read_bytes > 0xffffffffull || b->tag_bytes > 0xffffffffull)
         return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_raw: arenas above 4 GiB need more than one batch");
     // loci: host validation is O(loci); everything per record happens on the device
-    uint32_t next_rec = 0, max_hap = 0;
+    uint32_t next_rec = 0, max_hap = 0, max_hap_all = 0;
     for (uint32_t l = 0; l < nl; ++l) {
         const vtx_locus& L = b->loci[l];
         if (L.rec_begin != next_rec) return fail(c, VTX_E_INVAL, "vtx_submit_raw: locus %u: records not contiguous (rec_begin %u, expected %u)", l, L.rec_begin, next_rec);
@@ -613,7 +624,9 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
             return fail(c, VTX_E_INVAL, "vtx_submit_raw: locus %u: haplotype outside hap_arena", l);
         if (L.ref_len > kMaxHapLen || L.alt_len > kMaxHapLen)
             return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_raw: locus %u: haplotype longer than %u", l, kMaxHapLen);
-        max_hap = std::max(max_hap, std::max(L.ref_len, L.alt_len));
+        const uint32_t hl = std::max(L.ref_len, L.alt_len);
+        max_hap_all = std::max(max_hap_all, hl);
+        if (hl <= kFastHapLen) max_hap = std::max(max_hap, hl);
         next_rec = L.rec_begin + L.rec_count;
     }
     if (next_rec != nr) return fail(c, VTX_E_INVAL, "vtx_submit_raw: %u records not covered by any locus", nr - next_rec);
@@ -643,7 +656,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     uint32_t* d_lut_flag = d_shape_cnt + 16;
     uint32_t caps[kNumShapes];
     for (int i = 0; i < kNumShapes; ++i) caps[i] = (uint32_t)(kShapes[i][0] * kShapes[i][1]);
-    HIP_TRY(c, vtxk_prep_set_shapes(caps, kNumShapes));
+    HIP_TRY(c, vtxk_prep_set_shapes(caps, kNumShapes, kFastReadLen, kFastHapLen));
 
     if (int rc = upload(c, {{c->d_loci.p, b->loci, (size_t)nl * sizeof(vtx_locus)},
                             {c->d_raw.p, b->records, (size_t)nr * sizeof(vtx_raw_record)},
@@ -695,7 +708,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
                                       c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_head_umi.as<uint32_t>(),
                                       c->d_shape.as<uint8_t>(), c->d_seq.as<uint32_t>(), c->d_locus_cnt.as<uint32_t>(),
                                       c->d_locus_scan.as<uint32_t>(), d_shape_cnt, d_counters, s));
-        HIP_TRY(c, hipMemcpyAsync(cnt, d_counters, 6 * u64, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(cnt, d_counters, 8 * u64, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         if (!cnt[4]) break;                  // no UMI hash collision inside a (locus, cell) group
         if (rounds == 8) return fail(c, VTX_E_STATE, "vtx_submit_raw: UMI hash collisions with 8 different seeds");
@@ -724,6 +737,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     float ms = 0;
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->n_loci = nl; c->n_records = n_kept; c->max_hap_len = max_hap; c->max_read_len = (uint32_t)cnt[5]; c->cells = cnt[3];
+    c->max_hap_all = max_hap_all; c->max_read_all = std::max<uint32_t>((uint32_t)cnt[7], std::max<uint32_t>((uint32_t)cnt[5], 1u));
     c->submitted = true;
     if (stats) {
         stats->num_not_cell_bc = cnt[0]; stats->num_non_umi = cnt[1]; stats->kept = n_kept; stats->prep_ms = ms;
@@ -954,6 +968,36 @@ int vtx_run(vtx_ctx* c) {
         if (int rc = fallback_finish()) return rc;
         c->fast_overflow = fast_overflow;
         if (getenv("VTX_DEBUG")) fprintf(stderr, "[vtx] banded: %llu tasks, %u overflowed band_run_kernel, %u bounded by the pending kernel, %u hard\n", (unsigned long long)n_tasks, fast_overflow, pending_total, hard_total);
+    }
+    if (c->slow_cnt) {
+        // records beyond the fast kernels' limits: exact slow path, both flavours (slabs grow until every chain fits)
+        const uint32_t n_slow = 2 * c->slow_cnt;
+        const int banded = c->cfg.aligner == VTX_ALIGNER_BANDED;
+        HIP_TRY(c, c->d_cnt.reserve(16 * sizeof(uint32_t)));
+        uint32_t* d_scnt = c->d_cnt.as<uint32_t>() + 13;
+        HIP_TRY(c, c->d_slow_retry.reserve(2 * (size_t)n_slow * sizeof(uint32_t)));
+        const uint32_t* tasks = nullptr;
+        uint32_t todo = n_slow, cap = 1024;
+        const uint32_t mh = std::max(c->max_hap_all, 1u);
+        for (;;) {
+            const uint64_t worst = (uint64_t)c->max_read_all * mh;
+            const size_t stride = vtxk_slow_ws_stride(cap, mh, c->max_read_all);
+            HIP_TRY(c, c->d_slow_ws.reserve((size_t)todo * stride));
+            HIP_TRY(c, hipMemsetAsync(d_scnt, 0, sizeof(uint32_t), s));
+            uint32_t* retry = c->d_slow_retry.as<uint32_t>() + ((tasks == c->d_slow_retry.as<uint32_t>()) ? n_slow : 0);
+            HIP_TRY(c, vtxk_launch_slow_align(c->d_work.as<uint32_t>() + c->slow_off, tasks, todo, banded, c->d_records.as<vtx_record>(),
+                                              c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                              c->d_hap.as<uint8_t>(), c->d_slow_ws.as<uint8_t>(), stride, cap, mh, c->max_read_all,
+                                              c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), retry, d_scnt, s));
+            uint32_t left = 0;
+            HIP_TRY(c, hipMemcpyAsync(&left, d_scnt, sizeof left, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            ++launches;
+            if (!left) break;
+            if (cap >= worst) return fail(c, VTX_E_STATE, "vtx_run: slow path overflow with a worst-case slab");
+            cap = (uint32_t)std::min<uint64_t>((uint64_t)cap * 16, std::max<uint64_t>(worst, 1024));
+            tasks = retry; todo = left;
+        }
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     uint32_t nnz32 = 0;

@@ -704,6 +704,8 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
     int32_t* my_score = (hap ? alt_score : ref_score) + rid;
     bool done = !have;
     if (have && (m == 0 || n == 0)) { *my_score = 0; done = true; }     // empty read / haplotype: score 0
+    // reads / haplotypes beyond what these tables and lists hold are scored by slow_align_kernel (the host lists them)
+    if (have && (m > VTX_FAST_READ_LEN || max(loci[my_locus].ref_len, loci[my_locus].alt_len) > max_hap)) done = true;
     // a task without any k-mer match has the whole matrix in band (Band::full_matrix): hard list, marker slot
     // (hard slots beyond the capacity of the band buffer go to the general kernel's list, which makes them hard in slices)
 #define PUSH_FULL_MATRIX() { const uint32_t h_ = atomicAdd(&counters[0], 1u);                                    \
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
         const uint32_t n_tab = min(loci_per_pass, l_last - lbase + 1) * 2;
         for (uint32_t t = 0; t < n_tab; ++t) {
             const vtx_locus loc = loci[lbase + (t >> 1)];
-            const uint32_t hn = (t & 1) ? loc.alt_len : loc.ref_len;
+            const uint32_t hn = max(loc.ref_len, loc.alt_len) > max_hap ? 0u : ((t & 1) ? loc.alt_len : loc.ref_len);   // (a locus of the slow list: no table)
             const uint8_t* hy = hap_arena + ((t & 1) ? loc.alt_off : loc.ref_off);
             uint8_t* tb = tables + (size_t)t * table_stride;
             uint2* ent = TB_ENT(tb);
@@ -737,7 +739,7 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
         __syncthreads();
         if ((uint32_t)tid < n_tab) {     // one lane per table: sequential head insertion, descending y => ascending chains
             const vtx_locus loc = loci[lbase + ((uint32_t)tid >> 1)];
-            const uint32_t hn = (tid & 1) ? loc.alt_len : loc.ref_len;
+            const uint32_t hn = max(loc.ref_len, loc.alt_len) > max_hap ? 0u : ((tid & 1) ? loc.alt_len : loc.ref_len);
             uint8_t* tb = tables + (size_t)tid * table_stride;
             uint2* ent = TB_ENT(tb);
             uint16_t* head = TB_HEAD(tb);
@@ -755,7 +757,7 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
         // flag byte of the k-mer's LAST base; a haplotype with a byte >= 0x80 gets no flags (shortcut off).
         for (uint32_t t = 0; t < n_tab; ++t) {
             const vtx_locus loc = loci[lbase + (t >> 1)];
-            const uint32_t hn = (t & 1) ? loc.alt_len : loc.ref_len;
+            const uint32_t hn = max(loc.ref_len, loc.alt_len) > max_hap ? 0u : ((t & 1) ? loc.alt_len : loc.ref_len);   // (a locus of the slow list: no table)
             uint8_t* tb = tables + (size_t)t * table_stride;
             const uint8_t* bytes = TB_BYTES(tb);
             for (uint32_t y = tid; y < hn; y += NT) if (bytes[y] & 0x80) atomicOr(&s_hibyte, 1u << t);
@@ -764,7 +766,7 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
         for (uint32_t t = 0; t < n_tab; ++t) {
             if ((s_hibyte >> t) & 1u) continue;
             const vtx_locus loc = loci[lbase + (t >> 1)];
-            const uint32_t hn = (t & 1) ? loc.alt_len : loc.ref_len;
+            const uint32_t hn = max(loc.ref_len, loc.alt_len) > max_hap ? 0u : ((t & 1) ? loc.alt_len : loc.ref_len);   // (a locus of the slow list: no table)
             uint8_t* tb = tables + (size_t)t * table_stride;
             const uint2* ent = TB_ENT(tb);
             const uint16_t* head = TB_HEAD(tb);
@@ -1076,6 +1078,112 @@ extern "C" hipError_t vtxk_launch_band_pending(const uint32_t* pending, uint32_t
     if (!n_pending) return hipSuccess;
     hipLaunchKernelGGL(band_pending_kernel, dim3((n_pending + 7) / 8), dim3(256), 0, s, pending, n_pending, pend_buf,
                        ref_score, alt_score, band, band_stride, hard_list, counters);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// slow_align_kernel — the exact path for records the fast kernels cannot hold (reads above VTX_FAST_READ_LEN bases,
+// haplotypes above VTX_FAST_HAP_LEN: a long sequence-resolved indel, a large --padding, long-read data).  One lane per
+// alignment, everything in a per-task global slab: the literal seeding / chaining / band of band_task (banded flavour) or
+// the whole matrix (full flavour), then the affine local DP over the column ranges in 32-bit arithmetic.  Throughput is
+// not a goal here — the reference aligns any length, so must this library, instead of rejecting the batch.
+// =============================================================================================
+__global__ __launch_bounds__(64) void slow_align_kernel(
+    const uint32_t* __restrict__ recs, const uint32_t* __restrict__ tasks, uint32_t n_tasks, int banded,
+    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
+    const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
+    uint8_t* __restrict__ workspace, uint64_t ws_stride, uint32_t m_cap, uint32_t max_hap, uint32_t max_read,
+    int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score, uint32_t* __restrict__ retry_list,
+    uint32_t* __restrict__ counters) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_tasks) return;
+    const uint32_t task = tasks ? tasks[slot] : 2u * recs[slot >> 1] + (slot & 1u);
+    const uint32_t rid = task >> 1, hap = task & 1;
+    const vtx_record rec = records[rid];
+    const vtx_locus loc = loci[rec_locus[rid]];
+    const uint8_t* x = read_arena + rec.read_off;
+    const uint8_t* y = hap_arena + (hap ? loc.alt_off : loc.ref_off);
+    const int m = (int)rec.read_len, n = (int)(hap ? loc.alt_len : loc.ref_len);
+    int32_t* out = (hap ? alt_score : ref_score) + rid;
+    if (m == 0 || n == 0) { *out = 0; return; }
+    uint8_t* ws = workspace + (uint64_t)slot * ws_stride;
+    band_scratch sc;
+    size_t o = 0;
+    sc.head = (uint16_t*)(ws + o); o += HASH_SIZE * 2;
+    sc.next = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
+    sc.rmin = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
+    sc.rmax = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
+    uint16_t* lo = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
+    uint16_t* hi = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
+    o = (o + 15) & ~(size_t)15;
+    sc.tree_v = (int32_t*)(ws + o); o += ((size_t)max_hap + KMER + 4) * 4;
+    sc.tree_i = (int32_t*)(ws + o); o += ((size_t)max_hap + KMER + 4) * 4;
+    int32_t* Sp = (int32_t*)(ws + o); o += ((size_t)max_read + 2) * 4;
+    int32_t* Dp = (int32_t*)(ws + o); o += ((size_t)max_read + 2) * 4;
+    int32_t* Sc = (int32_t*)(ws + o); o += ((size_t)max_read + 2) * 4;
+    int32_t* Dc = (int32_t*)(ws + o); o += ((size_t)max_read + 2) * 4;
+    sc.mt = (uint32_t*)(ws + o); o += (size_t)m_cap * 4;
+    sc.dps = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
+    sc.dpp = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
+    bool whole = !banded;
+    if (banded) {
+        int32_t cert = 0;
+        int cA = 0, cB = 0;
+        if (band_task(x, m, y, n, sc, m_cap, &cert, &cA, &cB)) { retry_list[atomicAdd(&counters[0], 1u)] = task; return; }
+        if (cert == INT32_MAX) whole = true;                       // no k-mer match: Band::full_matrix
+        else band_ranges(sc, cA, cB, m, n, lo, hi);
+    }
+    // banded::Aligner::compute_alignment in local mode (oracle/vtx_oracle.c:vtxo_sw_ranges): cells outside the ranges
+    // hold MIN; every in-band cell may start at 0; row 0 / column 0 cells are 0 when in band
+    const int32_t MINS = -858993459;
+    for (int i = 0; i <= m; ++i) { Sp[i] = MINS; Dp[i] = MINS; Sc[i] = MINS; Dc[i] = MINS; }
+    {
+        const int l0 = whole ? 0 : (int)lo[0], h0 = whole ? m + 1 : (int)hi[0];
+        for (int i = l0; i < h0; ++i) Sp[i] = 0;
+    }
+    int32_t best = 0;
+    int plo = 0, phi = 0;
+    int qlo = whole ? 0 : (int)lo[0], qhi = whole ? m + 1 : max((int)hi[0], qlo);
+    for (int j = 1; j <= n; ++j) {
+        for (int i = plo; i < phi; ++i) { Sc[i] = MINS; Dc[i] = MINS; }
+        const int lj = whole ? 0 : (int)lo[j], hj = whole ? m + 1 : (int)hi[j];
+        const uint8_t q = y[j - 1];
+        int32_t up_i = MINS;
+        for (int i = lj; i < hj; ++i) {
+            if (i == 0) { Sc[0] = 0; up_i = MINS; continue; }
+            const int32_t d = max(Dp[i] - 1, Sp[i] - 6);
+            const int32_t ii = max(up_i - 1, Sc[i - 1] - 6);
+            int32_t sv = Sp[i - 1] + (x[i - 1] == q ? 1 : -5);
+            sv = max(max(sv, max(d, ii)), 0);
+            Sc[i] = sv; Dc[i] = d; up_i = ii;
+            best = max(best, sv);
+        }
+        plo = qlo; phi = qhi;
+        qlo = lj; qhi = hj > lj ? hj : lj;
+        int32_t* t;
+        t = Sp; Sp = Sc; Sc = t;
+        t = Dp; Dp = Dc; Dc = t;
+    }
+    *out = best;
+}
+
+extern "C" size_t vtxk_slow_ws_stride(uint32_t m_cap, uint32_t max_hap, uint32_t max_read) {
+    size_t o = HASH_SIZE * 2 + 5 * ((size_t)max_hap + 2) * 2;
+    o = (o + 15) & ~(size_t)15;
+    o += 2 * ((size_t)max_hap + KMER + 4) * 4 + 4 * ((size_t)max_read + 2) * 4 + 3 * (size_t)m_cap * 4;
+    return (o + 63) & ~(size_t)63;
+}
+
+extern "C" hipError_t vtxk_launch_slow_align(const uint32_t* recs, const uint32_t* tasks, uint32_t n_tasks, int banded,
+                                             const vtx_record* records, const uint32_t* rec_locus, const vtx_locus* loci,
+                                             const uint8_t* read_arena, const uint8_t* hap_arena, uint8_t* workspace,
+                                             uint64_t ws_stride, uint32_t m_cap, uint32_t max_hap, uint32_t max_read,
+                                             int32_t* ref_score, int32_t* alt_score, uint32_t* retry_list, uint32_t* counters,
+                                             hipStream_t s) {
+    if (!n_tasks) return hipSuccess;
+    hipLaunchKernelGGL(slow_align_kernel, dim3((n_tasks + 63) / 64), dim3(64), 0, s, recs, tasks, n_tasks, banded, records,
+                       rec_locus, loci, read_arena, hap_arena, workspace, ws_stride, m_cap, max_hap, max_read, ref_score,
+                       alt_score, retry_list, counters);
     return hipGetLastError();
 }
 

@@ -70,6 +70,16 @@ hipError_t vtxk_launch_band_pending(const uint32_t* pending, uint32_t n_pending,
 hipError_t vtxk_launch_band_expand(const uint32_t* hard_list, uint32_t n_hard, const vtx_record* records,
                                    const uint32_t* rec_locus, const vtx_locus* loci, uint16_t* band,
                                    uint32_t band_stride, hipStream_t s);
+/* Records the fast kernels hold: reads up to VTX_FAST_READ_LEN bases (16 rows x 64 lanes), haplotypes up to
+ * VTX_FAST_HAP_LEN (LDS tables).  Longer ones take slow_align_kernel (exact, one lane per alignment, global scratch). */
+#define VTX_FAST_READ_LEN 1024u
+#define VTX_FAST_HAP_LEN 2400u
+size_t vtxk_slow_ws_stride(uint32_t m_cap, uint32_t max_hap, uint32_t max_read);
+hipError_t vtxk_launch_slow_align(const uint32_t* recs, const uint32_t* tasks, uint32_t n_tasks, int banded,
+                                  const vtx_record* records, const uint32_t* rec_locus, const vtx_locus* loci,
+                                  const uint8_t* read_arena, const uint8_t* hap_arena, uint8_t* workspace, uint64_t ws_stride,
+                                  uint32_t m_cap, uint32_t max_hap, uint32_t max_read, int32_t* ref_score, int32_t* alt_score,
+                                  uint32_t* retry_list, uint32_t* counters, hipStream_t s);
 hipError_t vtxk_values_from_counts(const uint32_t* alt, const uint32_t* ref, const uint32_t* unk, uint32_t n, int mode,
                                    double* o_val, double* o_refval, hipStream_t s);
 hipError_t vtxk_group_heads(const vtx_record* records, const uint32_t* rec_locus, uint32_t n, uint32_t* head_cell,
@@ -91,7 +101,7 @@ hipError_t vtxk_inclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n
                                    hipStream_t s);
 size_t vtxk_scan_temp_bytes(uint32_t n);
 // ---- vtx_prep.hip: device-side preparation of raw batches ----
-hipError_t vtxk_prep_set_shapes(const uint32_t* caps, uint32_t n);
+hipError_t vtxk_prep_set_shapes(const uint32_t* caps, uint32_t n, uint32_t fast_read_len, uint32_t fast_hap_len);
 size_t vtxk_prep_sort_temp_bytes(uint32_t n);
 hipError_t vtxk_prep_sort_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                               uint32_t n, int end_bit, void* temp, size_t temp_bytes, hipStream_t s);

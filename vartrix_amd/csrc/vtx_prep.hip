@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void prep_gather_u64_kernel(const uint64_t* __
 }
 
 __constant__ uint32_t c_shape_cap[16];
+__constant__ uint32_t c_fast_limit[2];     // longest read / haplotype the fast kernels hold; beyond: shape n_shapes = the slow list
 
 __global__ __launch_bounds__(256) void prep_finalize_kernel(
     uint32_t n_kept, const uint32_t* __restrict__ perm, const uint64_t* __restrict__ key_lc_sorted,
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void prep_finalize_kernel(
     if (threadIdx.x == 0) { s_cells = 0; s_maxlen = 0; s_collide = 0; }
     __syncthreads();
     unsigned long long cells = 0;
-    uint32_t max_rl = 0;
+    uint32_t max_rl = 0, max_all = 0;
     bool collide = false;
     for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n_kept; j += gridDim.x * 256) {
         const uint32_t i = perm[j];
@@ -135,18 +136,22 @@ __global__ __launch_bounds__(256) void prep_finalize_kernel(
         if (j == 0 || (uint32_t)(kprev >> cell_bits) != locus) locus_first[locus] = j;
         if (j + 1 == n_kept || (uint32_t)(key_lc_sorted[j + 1] >> cell_bits) != locus) locus_end[locus] = j + 1;
         const uint32_t rl = r.read_len;
+        const bool slow = rl > c_fast_limit[0] || max(loci[locus].ref_len, loci[locus].alt_len) > c_fast_limit[1];
         uint32_t my_shape = 0;
         while (my_shape + 1 < n_shapes && c_shape_cap[my_shape] < rl) ++my_shape;
+        if (slow) my_shape = n_shapes;                // the slow list (sorted last)
         shape[j] = (uint8_t)my_shape;
         atomicAdd(&s_shape[my_shape], 1u);            // LDS atomic: mostly one address, the LDS unit coalesces equal-address adds
         cells += (unsigned long long)rl * ((unsigned long long)loci[locus].ref_len + loci[locus].alt_len);
-        max_rl = max(max_rl, rl);
+        if (!slow) max_rl = max(max_rl, rl);
+        max_all = max(max_all, rl);
     }
-    for (int o = 32; o > 0; o >>= 1) { cells += __shfl_down(cells, o); max_rl = max(max_rl, __shfl_down(max_rl, o)); }
+    for (int o = 32; o > 0; o >>= 1) { cells += __shfl_down(cells, o); max_rl = max(max_rl, __shfl_down(max_rl, o)); max_all = max(max_all, __shfl_down(max_all, o)); }
+    if ((threadIdx.x & 63) == 0 && max_all > VTX_FAST_READ_LEN) atomicMax(&counters[7], (unsigned long long)max_all);   // only slow records exceed it
     if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cells, cells); atomicMax(&s_maxlen, max_rl); }
     if (collide) s_collide = 1;
     __syncthreads();
-    if (threadIdx.x < n_shapes && s_shape[threadIdx.x]) atomicAdd(&shape_cnt[threadIdx.x], s_shape[threadIdx.x]);
+    if (threadIdx.x <= n_shapes && s_shape[threadIdx.x]) atomicAdd(&shape_cnt[threadIdx.x], s_shape[threadIdx.x]);
     if (threadIdx.x == 0) {
         if (s_cells) atomicAdd(&counters[3], s_cells);
         if (s_maxlen) atomicMax(&counters[5], (unsigned long long)s_maxlen);
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256) void prep_check_kernel(
     if (threadIdx.x == 0) { s_cells = 0; s_maxlen = 0; s_bad = ~0ull; }
     __syncthreads();
     unsigned long long cells = 0, bad = ~0ull;
-    uint32_t max_rl = 0;
+    uint32_t max_rl = 0, max_all = 0;
     for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
         const vtx_record r = records[j];
         const uint32_t locus = rec_locus[j];
@@ -200,21 +205,25 @@ __global__ __launch_bounds__(256) void prep_check_kernel(
         }
         if (code) bad = min(bad, ((unsigned long long)j << 3) | code);
         const uint32_t rl = min(r.read_len, max_read_len);
+        const bool slow = rl > c_fast_limit[0] || max(loci[locus].ref_len, loci[locus].alt_len) > c_fast_limit[1];
         uint32_t my_shape = 0;
         while (my_shape + 1 < n_shapes && c_shape_cap[my_shape] < rl) ++my_shape;
+        if (slow) my_shape = n_shapes;                // the slow list (sorted last)
         shape[j] = (uint8_t)my_shape;
         seq[j] = j;
         atomicAdd(&s_shape[my_shape], 1u);
         cells += (unsigned long long)r.read_len * ((unsigned long long)loci[locus].ref_len + loci[locus].alt_len);
-        max_rl = max(max_rl, r.read_len);
+        if (!slow) max_rl = max(max_rl, r.read_len);
+        max_all = max(max_all, min(r.read_len, max_read_len));
     }
     for (int o = 32; o > 0; o >>= 1) {
-        cells += __shfl_down(cells, o); max_rl = max(max_rl, __shfl_down(max_rl, o));
+        cells += __shfl_down(cells, o); max_rl = max(max_rl, __shfl_down(max_rl, o)); max_all = max(max_all, __shfl_down(max_all, o));
         bad = min(bad, (unsigned long long)__shfl_down(bad, o));
     }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cells, cells); atomicMax(&s_maxlen, max_rl); atomicMin(&s_bad, bad); }
+    if ((threadIdx.x & 63) == 0 && max_all > VTX_FAST_READ_LEN) atomicMax(&counters[7], (unsigned long long)max_all);   // only slow records exceed it
     __syncthreads();
-    if (threadIdx.x < n_shapes && s_shape[threadIdx.x]) atomicAdd(&shape_cnt[threadIdx.x], s_shape[threadIdx.x]);
+    if (threadIdx.x <= n_shapes && s_shape[threadIdx.x]) atomicAdd(&shape_cnt[threadIdx.x], s_shape[threadIdx.x]);
     if (threadIdx.x == 0) {
         if (s_cells) atomicAdd(&counters[3], s_cells);
         if (s_maxlen) atomicMax(&counters[5], (unsigned long long)s_maxlen);
@@ -236,7 +245,10 @@ __global__ __launch_bounds__(256) void prep_lut_check_kernel(const uint32_t* __r
 
 extern "C" {
 
-hipError_t vtxk_prep_set_shapes(const uint32_t* caps, uint32_t n) {
+hipError_t vtxk_prep_set_shapes(const uint32_t* caps, uint32_t n, uint32_t fast_read_len, uint32_t fast_hap_len) {
+    const uint32_t lim[2] = {fast_read_len, fast_hap_len};
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_fast_limit), lim, sizeof lim);
+    if (e != hipSuccess) return e;
     return hipMemcpyToSymbol(HIP_SYMBOL(c_shape_cap), caps, n * sizeof(uint32_t));
 }
 
