@@ -82,6 +82,9 @@ void vtxh_get_raw_batch_at(const vtxh_pack* p, uint32_t i, vtx_raw_batch* out);
 /* The packed batch (pointers valid until vtxh_free). */
 void vtxh_get_batch(const vtxh_pack* p, vtx_batch* out);
 void vtxh_get_metrics(const vtxh_pack* p, vtxh_metrics* out);
+/* Ingest statistics: {BGZF blocks inflated, BGZF blocks in the file, index-guided jumps}.  With a usable .bai only the
+ * stretches of the BAM that can hold reads of a locus are inflated (the reference's indexed fetch, src/main.rs:822-826). */
+void vtxh_get_ingest_stats(const vtxh_pack* p, uint64_t out[3]);
 uint32_t vtxh_num_variants(const vtxh_pack* p);   /* matrix rows = VCF records (:237)      */
 uint32_t vtxh_num_barcodes(const vtxh_pack* p);   /* matrix cols = distinct barcodes (:245) */
 /* "{chrom}_{pos0}" of VCF record i (write_variants :1174); barcode of column j. */

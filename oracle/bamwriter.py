@@ -66,17 +66,56 @@ def record(tid, pos, qname, seq, cigar, flag=0, mapq=60, tags=()):
     return struct.pack("<i", len(body)) + body
 
 
-def write_bam(path: str, refs: list, records: list, block: int = 60000):
-    """refs = [(name, length)], records = output of record() in coordinate order."""
+def _ref_span(rec: bytes):
+    """(tid, pos, end) of one encoded record (end like bam_endpos: pos + 1 without a reference-consuming op)."""
+    tid, pos, l_rn, _mq, _bin, n_cig, flag = struct.unpack_from("<iiBBHHH", rec, 4)
+    o = 36 + l_rn
+    rlen = 0
+    if not flag & 4:
+        for k in range(n_cig):
+            c, = struct.unpack_from("<I", rec, o + 4 * k)
+            if (c & 15) in (0, 2, 3, 7, 8):
+                rlen += c >> 4
+    return tid, pos, pos + (rlen if rlen > 0 else 1)
+
+
+def write_bam(path: str, refs: list, records: list, block: int = 60000, index: str = "linear"):
+    """refs = [(name, length)], records = output of record() in coordinate order.
+    index: "linear" writes a .bai whose LINEAR index is real (smallest virtual offset of an alignment overlapping each
+    16 kb window, gaps filled with the previous value like htslib does) and whose bin index is empty — enough for the
+    packer's index-guided skipping; "fake" writes the magic with zero references (the packer then sweeps everything)."""
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
     hdr = b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs))
     for name, ln in refs:
         n = name.encode() + b"\x00"
         hdr += struct.pack("<i", len(n)) + n + struct.pack("<i", ln)
     data = hdr + b"".join(records)
+    coffs = []
     with open(path, "wb") as fh:
         for o in range(0, len(data), block):
+            coffs.append(fh.tell())
             fh.write(_bgzf_block(data[o:o + block]))
         fh.write(_bgzf_block(b""))          # EOF marker
-    with open(path + ".bai", "wb") as fh:   # presence is all the host checks (it sweeps the file)
-        fh.write(b"BAI\x01" + struct.pack("<i", 0))
+    with open(path + ".bai", "wb") as fh:
+        if index != "linear":
+            fh.write(b"BAI\x01" + struct.pack("<i", 0))
+            return
+        lin = [[0] * ((ln >> 14) + 1) for _, ln in refs]
+        u = len(hdr)
+        for rec in records:
+            tid, pos, end = _ref_span(rec)
+            if 0 <= tid < len(refs):
+                voff = (coffs[u // block] << 16) | (u % block)
+                for w in range(max(pos, 0) >> 14, min(((end - 1) >> 14) + 1, len(lin[tid]))):
+                    if lin[tid][w] == 0:
+                        lin[tid][w] = voff
+            u += len(rec)
+        out = b"BAI\x01" + struct.pack("<i", len(refs))
+        for l in lin:
+            n_intv = max((i + 1 for i, v in enumerate(l) if v), default=0)
+            l = l[:n_intv]
+            for i in range(1, len(l)):
+                if l[i] == 0:
+                    l[i] = l[i - 1]
+            out += struct.pack("<i", 0) + struct.pack("<i", len(l)) + b"".join(struct.pack("<Q", v) for v in l)
+        fh.write(out)

@@ -284,3 +284,60 @@ def test_packer_splits_large_inputs_into_batches(tmp_path, monkeypatch, raw, umi
     monkeypatch.setenv("VTXH_BATCH_BYTES", "100")
     with pytest.raises(hostlib.HostError, match="alone needs more"):
         hostlib.pack_files(use_umi=umi, raw=raw, all_batches=True, **inputs)
+
+
+def test_index_guided_skipping_on_a_sparse_vcf(tmp_path, monkeypatch):
+    """A few loci over a BAM that covers the whole contig: with the .bai the packer inflates only the stretches that can
+    hold their reads (the reference does an indexed fetch per locus, src/main.rs:822-826) — and packs exactly what the
+    full sweep packs.  Reads with long reference skips (spliced, N) start far before the locus they overlap: the linear
+    index accounts for them."""
+    from oracle import bamwriter
+    rng = np.random.default_rng(12)
+    fa = refpipe.read_fasta(os.path.join(G, "test_dna.fa"))["1"].upper()
+    bcs = list(refpipe.load_barcodes(os.path.join(G, "dna_barcodes.tsv")).keys())
+    def clean(p):                                                       # first position >= p whose +-100 window is pure ACGT
+        while any(c not in b"ACGT" for c in fa[p - 100:p + 101]):
+            p += 50
+        return p
+    loci_pos = [clean(p) for p in (5000, 5300, 60000, 150000, 150090, 230000)]   # two pairs close together, the rest far apart
+    vcf = tmp_path / "sparse.vcf"
+    with open(vcf, "w") as fh:
+        fh.write("##fileformat=VCFv4.2\n##contig=<ID=1,length=%d>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n" % len(fa))
+        for p in loci_pos:
+            ref = chr(fa[p])
+            fh.write("1\t%d\t.\t%s\t%s\t.\t.\t.\n" % (p + 1, ref, "ACGT"[("ACGT".index(ref) + 1) % 4]))
+    recs = []
+    for k in range(24000):                                              # reads all over the contig
+        start = int(rng.integers(0, len(fa) - 200))
+        ln = int(rng.integers(60, 151))
+        recs.append((start, bamwriter.record(0, start, "r%05d" % k, fa[start:start + ln].decode(), "%dM" % ln, mapq=60,
+                                             tags=[("CB", "Z", bcs[int(rng.integers(0, 40))]), ("UB", "Z", "U%03d" % int(rng.integers(0, 99)))])))
+    for p in loci_pos:                                                  # reads at the loci, some spliced across 30 kb
+        for k in range(30):
+            start = p - int(rng.integers(0, 100))
+            recs.append((start, bamwriter.record(0, start, "l%d_%d" % (p, k), fa[start:start + 120].decode(), "120M", mapq=60,
+                                                 tags=[("CB", "Z", bcs[int(rng.integers(0, 40))]), ("UB", "Z", "U%03d" % k)])))
+        if p > 40000:
+            s0 = p - 30050
+            seq = fa[s0:s0 + 40] + fa[p - 10:p + 70]
+            recs.append((s0, bamwriter.record(0, s0, "sp%d" % p, seq.decode(), "40M%dN80M" % (p - 10 - (s0 + 40)), mapq=60,
+                                              tags=[("CB", "Z", bcs[3]), ("UB", "Z", "USP")])))
+    recs.sort(key=lambda t: t[0])
+    bam = str(tmp_path / "wide.bam")
+    bamwriter.write_bam(bam, [("1", len(fa))], [r for _, r in recs], block=4000)
+    fap, bcp = os.path.join(G, "test_dna.fa"), os.path.join(G, "dna_barcodes.tsv")
+    got, gm, nv, _, _ = hostlib.pack_files(str(vcf), bam, fap, bcp, threads=3, use_umi=True)
+    st = dict(hostlib.last_ingest_stats)
+    monkeypatch.setenv("VTXH_NO_INDEX", "1")
+    full, fm, _, _, _ = hostlib.pack_files(str(vcf), bam, fap, bcp, threads=3, use_umi=True)
+    st_full = dict(hostlib.last_ingest_stats)
+    monkeypatch.delenv("VTXH_NO_INDEX")
+    want, wm = refpipe.pack(refpipe.read_vcf(str(vcf)), refpipe.read_fasta(fap), refpipe.read_bam(bam),
+                            refpipe.load_barcodes(bcp), refpipe.Args(use_umi=True))
+    assert gm == fm == wm
+    assert same_batch(got, want) and same_batch(full, want)
+    assert got.n_records > 150 and any(int(c) > 30 for c in got.loci["rec_count"])     # the spliced reads were found
+    assert st_full["blocks_inflated"] == st_full["blocks_total"] and st_full["index_jumps"] == 0
+    # (each far locus drags in the 30 kb its spliced read spans, and a restart over-reads up to ~100 of these tiny 4 kB
+    # blocks: a third of the file stays untouched here; with 64 kB blocks and a 50 GB BAM it is nearly all of it)
+    assert st["index_jumps"] >= 2 and st["blocks_inflated"] < 0.7 * st["blocks_total"], st

@@ -141,7 +141,7 @@ struct VcfRec { std::string chrom; int64_t pos; std::vector<std::string> alleles
 const char kNt16[] = "=ACMGRSVTWYHKDBN";
 enum { FLAG_UNMAP = 0x4, FLAG_SECONDARY = 0x100, FLAG_DUP = 0x400, FLAG_SUPP = 0x800 };
 
-struct BgzfBlock { size_t coff; uint32_t clen; uint32_t isize; };
+struct BgzfBlock { size_t coff; uint32_t clen; uint32_t isize; size_t start; };   // start: file offset of the block header
 
 // growable byte buffer that never zero-fills (the inflaters overwrite every byte they are given)
 struct ByteBuf {
@@ -184,7 +184,7 @@ bool index_bgzf(const MappedFile& file, std::vector<BgzfBlock>& blocks) {
         if (!found || o + bsize > file.size() || bsize < 12 + xlen + 8) return false;
         const unsigned char* t = h + bsize - 4;
         uint32_t isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
-        blocks.push_back(BgzfBlock{o + 12 + xlen, bsize - 12 - xlen - 8, isize});
+        blocks.push_back(BgzfBlock{o + 12 + xlen, bsize - 12 - xlen - 8, isize, o});
         o += bsize;
     }
     return o == file.size();
@@ -202,6 +202,39 @@ bool inflate_block(const MappedFile& file, const BgzfBlock& b, unsigned char* ds
     int rc = inflate(&zs, Z_FINISH);
     inflateEnd(&zs);
     return rc == Z_STREAM_END && zs.avail_out == 0;
+}
+
+// Linear index of a .bai (SAM spec 5.2): per reference, for every 16 kb window the smallest virtual file offset of an
+// alignment overlapping the window.  Only the linear index is used (bins are skipped).  Returns false when the file is
+// absent, malformed or empty (the packer then sweeps the whole BAM, as it does for .csi-only inputs).
+bool read_bai_linear(const std::string& path, size_t n_ref_expected, std::vector<std::vector<uint64_t>>& lin) {
+    std::string d;
+    if (!read_file(path, d) || d.size() < 8 || memcmp(d.data(), "BAI\1", 4) != 0) return false;
+    const unsigned char* p = (const unsigned char*)d.data();
+    size_t o = 4;
+    auto u32 = [&](uint32_t& v) { if (o + 4 > d.size()) return false; v = p[o] | (p[o + 1] << 8) | (p[o + 2] << 16) | ((uint32_t)p[o + 3] << 24); o += 4; return true; };
+    uint32_t n_ref;
+    if (!u32(n_ref) || n_ref != n_ref_expected) return false;
+    lin.assign(n_ref, {});
+    bool any = false;
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        uint32_t n_bin, n_intv;
+        if (!u32(n_bin)) return false;
+        for (uint32_t b = 0; b < n_bin; ++b) {
+            uint32_t bin, n_chunk;
+            if (!u32(bin) || !u32(n_chunk) || o + 16ull * n_chunk > d.size()) return false;
+            o += 16ull * n_chunk;
+        }
+        if (!u32(n_intv) || o + 8ull * n_intv > d.size()) return false;
+        lin[r].resize(n_intv);
+        for (uint32_t i = 0; i < n_intv; ++i) {
+            uint64_t v = 0;
+            for (int k = 7; k >= 0; --k) v = (v << 8) | p[o + (size_t)k];
+            lin[r][i] = v; o += 8;
+            any |= v != 0;
+        }
+    }
+    return any;
 }
 
 inline uint32_t rd32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -366,6 +399,7 @@ struct Interval { int64_t start, end; uint32_t locus; };
 }  // namespace
 
 struct vtxh_pack {
+    uint64_t blocks_inflated = 0, blocks_total = 0, index_jumps = 0;      // ingest statistics (vtxh_get_ingest_stats)
     std::vector<vtx_locus> loci;
     std::vector<vtx_record> records;
     std::string hap_arena;
@@ -455,6 +489,7 @@ void vtxh_get_batch_at(const vtxh_pack* p, uint32_t i, vtx_batch* out) {
 }
 void vtxh_get_batch(const vtxh_pack* p, vtx_batch* out) { vtxh_get_batch_at(p, 0, out); }
 void vtxh_get_metrics(const vtxh_pack* p, vtxh_metrics* out) { *out = p->metrics; }
+void vtxh_get_ingest_stats(const vtxh_pack* p, uint64_t out[3]) { out[0] = p->blocks_inflated; out[1] = p->blocks_total; out[2] = p->index_jumps; }
 uint32_t vtxh_num_variants(const vtxh_pack* p) { return p->n_variants; }
 uint32_t vtxh_num_barcodes(const vtxh_pack* p) { return (uint32_t)p->barcodes.size(); }
 const char* vtxh_variant_name(const vtxh_pack* p, uint32_t i) { return i < p->variant_names.size() ? p->variant_names[i].c_str() : ""; }
@@ -576,9 +611,16 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     Pool pool(threads);
     ByteBuf buf;                          // decompressed bytes not yet consumed
     size_t buf_pos = 0, next_block = 0;
+    size_t chunk_blocks = 512;            // blocks per inflate round; restarts small after an index-guided jump
+    size_t chunk_limit_block = SIZE_MAX;  // index-guided sweep: no read-ahead beyond the block the sweep would jump to anyway
+    uint64_t n_inflated = 0, n_jumps = 0;
     auto refill = [&](size_t need) -> bool {   // ensure buf has >= need bytes from buf_pos, if the file has them
         while (buf.size() - buf_pos < need && next_block < blocks.size()) {
-            const size_t chunk = std::min(blocks.size() - next_block, (size_t)512);
+            size_t chunk = std::min(blocks.size() - next_block, chunk_blocks);
+            // a jump is ahead: small rounds, so that the sweep notices the end of its segment before it has inflated its way
+            // to the jump target (dense VCFs have no jump ahead and keep the large rounds)
+            if (chunk_limit_block != SIZE_MAX) chunk = std::min<size_t>(chunk, 32);
+            chunk_blocks = std::min<size_t>(512, chunk_blocks * 2);
             if (buf_pos) { buf.drop_prefix(buf_pos); buf_pos = 0; }
             std::vector<size_t> off(chunk + 1, 0);
             for (size_t k = 0; k < chunk; ++k) off[k + 1] = off[k] + blocks[next_block + k].isize;
@@ -592,6 +634,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             });
             if (!ok) return false;
             next_block += chunk;
+            n_inflated += chunk;
         }
         return buf.size() - buf_pos >= need;
     };
@@ -660,7 +703,34 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         std::stable_sort(iv.begin(), iv.end(), [](const Interval& x, const Interval& y) { return x.start < y.start; });
 
     ph.mark("haplotypes");
-    // ---- sweep the BAM once (fetch + filters of evaluate_alns, :822-895) ----
+    // ---- index-guided skipping (the reference does an indexed fetch per locus, :822-826) ----
+    // With a usable .bai the sweep only visits the stretches of the file that can hold reads of a locus: for every locus,
+    // in (contig, start) order, the linear index gives the smallest virtual offset of an alignment overlapping its first
+    // 16 kb window; the sweep starts there and runs until a record lies at or beyond the end of the loci it is serving
+    // (coordinate-sorted file: nothing later can overlap them), then jumps to the next locus' offset — unless that is
+    // within a few blocks, where sweeping on is cheaper than a restart.  Dense VCFs degenerate to the single sweep.
+    struct Target { int32_t tid; int64_t start, end; uint64_t voff; };
+    std::vector<Target> targets;
+    bool use_index = false;
+    {
+        std::vector<std::vector<uint64_t>> lin;
+        if (!getenv("VTXH_NO_INDEX") && read_bai_linear(std::string(a->bam) + ".bai", bam_refs.size(), lin)) {
+            use_index = true;
+            for (size_t t = 0; t < by_tid.size(); ++t) {
+                const auto& iv = by_tid[t];
+                const auto& li = lin[t];
+                for (const Interval& x : iv) {
+                    if (li.empty()) continue;                                  // no alignment on this contig
+                    size_t w = (size_t)(x.start >> 14);
+                    if (w >= li.size()) continue;                              // nothing overlaps this window or any later one
+                    uint64_t v = 0;
+                    for (size_t k = w + 1; k-- > 0 && !v;) v = li[k];          // 0 = "not recorded": fall back to an earlier window
+                    targets.push_back(Target{(int32_t)t, x.start, x.end, v});  // v == 0: from the first alignment of the file
+                }
+            }
+        }
+    }
+    // ---- sweep the BAM (fetch + filters of evaluate_alns, :822-895) ----
     // Per window of inflated blocks: record boundaries are indexed sequentially (a hop per record), the
     // records are parsed and filtered by `threads` workers over contiguous ranges into thread-local
     // outputs, and the outputs are merged in thread order — so every locus sees its reads in BAM order,
@@ -765,22 +835,92 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         }
     };
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{merger};
+    // index-guided sweep state: targets [tg, ...) still to serve; the running segment ends at (seg_tid, seg_end)
+    size_t tg = 0;
+    int32_t seg_tid = -1;
+    int64_t seg_end = 0;
+    const size_t kNearBlocks = 64;                    // a next offset this close is reached by sweeping on
+    const uint64_t first_voff = ((uint64_t)0);        // (targets with voff 0 start where the header ended: no jump needed)
+    (void)first_voff;
+    auto open_segment = [&]() {                       // targets[tg] opens a segment; loci starting inside it join it
+        seg_tid = targets[tg].tid; seg_end = targets[tg].end;
+        size_t k = tg + 1;
+        while (k < targets.size() && targets[k].tid == seg_tid && targets[k].start < seg_end) { seg_end = std::max(seg_end, targets[k].end); ++k; }
+    };
+    auto block_of = [&](uint64_t voff) -> size_t {    // index of the block that starts at the compressed offset of voff
+        const size_t co = (size_t)(voff >> 16);
+        size_t lo = 0, hi = blocks.size();
+        while (lo < hi) { const size_t mid = (lo + hi) / 2; if (blocks[mid].start < co) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    bool jump_pending = false;
+    uint64_t jump_voff = 0;
+    size_t far_ptr = 0;                               // first target whose offset lies beyond the near range of the sweep
+    auto update_read_ahead = [&]() {                  // the next offset the sweep would JUMP to bounds the read-ahead
+        if (far_ptr < tg) far_ptr = tg;
+        while (far_ptr < targets.size() && (!targets[far_ptr].voff || block_of(targets[far_ptr].voff) <= next_block + kNearBlocks)) ++far_ptr;
+        chunk_limit_block = far_ptr < targets.size() ? block_of(targets[far_ptr].voff) : SIZE_MAX;
+    };
+    if (use_index) {
+        if (targets.empty()) { buf.drop_prefix(buf.size()); buf_pos = 0; next_block = blocks.size(); }   // no locus can have reads
+        else {
+            open_segment();
+            if (targets[0].voff && block_of(targets[0].voff) > next_block + kNearBlocks) { jump_pending = true; jump_voff = targets[0].voff; }
+        }
+    }
     while (true) {
         std::vector<WorkerOut>& outs = out_sets[cur_set];
+        if (jump_pending) {
+            // restart the record stream at a virtual offset: drop what is buffered, inflate from that block on
+            jump_pending = false;
+            ++n_jumps;
+            const size_t b = block_of(jump_voff);
+            if (b >= blocks.size() || blocks[b].start != (size_t)(jump_voff >> 16)) return fail(VTX_E_INVAL, "%s.bai: offset outside the BAM", a->bam);
+            buf.drop_prefix(buf.size());
+            buf_pos = 0;
+            next_block = b; chunk_blocks = 32;
+            refill((size_t)(jump_voff & 0xffff) + 1);
+            buf_pos = (size_t)(jump_voff & 0xffff);
+            if (buf_pos > buf.size()) return fail(VTX_E_INVAL, "%s.bai: offset outside its block", a->bam);
+        }
+        if (use_index) update_read_ahead();
         refill(buf.size() - buf_pos + 1);             // one more chunk of blocks, if the file has one
         ph.mark("inflate");
         rec_offs.clear();
         size_t p = buf_pos;
+        bool all_served = false;
         while (buf.size() - p >= 4) {
             const uint32_t bs = rd32(buf.data() + p);
             if (buf.size() - p - 4 < bs) break;
             if (bs < 32) return fail(VTX_E_INVAL, "%s: malformed BAM record", a->bam);
+            if (use_index) {
+                // a record at or beyond the end of the running segment: its loci are served (sorted file)
+                const int32_t rt = rdi32(buf.data() + p + 4);
+                const int64_t rp = rdi32(buf.data() + p + 8);
+                bool moved = false;
+                while (tg < targets.size() && (rt < 0 || rt > seg_tid || (rt == seg_tid && rp >= seg_end))) {
+                    while (tg < targets.size() && targets[tg].tid == seg_tid && targets[tg].start < seg_end) ++tg;   // served
+                    if (tg == targets.size()) break;
+                    open_segment();
+                    moved = true;
+                }
+                if (tg == targets.size()) { all_served = true; break; }
+                if (moved && targets[tg].voff) {
+                    // where does the next segment's first possible record live?  far ahead: jump; near (or behind): sweep on
+                    const size_t nb = block_of(targets[tg].voff);
+                    if (nb > next_block + kNearBlocks) { jump_pending = true; jump_voff = targets[tg].voff; break; }
+                }
+            }
             rec_offs.push_back(p);
             p += 4 + (size_t)bs;
             __builtin_prefetch(buf.data() + p + 8 * (4 + (size_t)bs));      // records are of similar size: the chain is predictable
             __builtin_prefetch(buf.data() + p + 8 * (4 + (size_t)bs) + 64);
         }
         const bool eof = next_block >= blocks.size();
+        if (rec_offs.empty() && (all_served || jump_pending)) {
+            if (all_served) break;
+            continue;                                  // nothing to parse before the jump
+        }
         if (rec_offs.empty()) {
             if (!eof) continue;                        // a record larger than the window: load more
             if (buf.size() - buf_pos >= 4) return fail(VTX_E_INVAL, "%s: truncated BAM record", a->bam);
@@ -812,11 +952,14 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         cur_set ^= 1;
         ph.mark("merge");
         buf_pos = p;
+        if (all_served) break;
+        if (jump_pending) continue;
         if (eof && buf.size() - buf_pos < 4) break;
         if (eof && rec_offs.empty()) break;
     }
     if (merger.joinable()) merger.join();
     if (merge_code != VTX_OK) return fail(merge_code, "%s: %s", a->bam, merge_err.c_str());
+    P->blocks_inflated = n_inflated; P->blocks_total = blocks.size(); P->index_jumps = n_jumps;
     ph.mark("merge (tail)");
 
     // ---- group the hits by locus: stable counting sort (hits are in BAM order, so every locus keeps it) ----

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvtxhost.so")
 CLI_PATH = os.path.join(_HERE, "bin", "vartrix")
 
-SYMBOLS = ("vtxh_pack_files", "vtxh_free", "vtxh_last_error", "vtxh_get_batch", "vtxh_get_metrics",
+SYMBOLS = ("vtxh_pack_files", "vtxh_free", "vtxh_last_error", "vtxh_get_batch", "vtxh_get_metrics", "vtxh_get_ingest_stats",
            "vtxh_num_variants", "vtxh_num_barcodes", "vtxh_variant_name", "vtxh_barcode", "vtxh_write_mtx",
            "vtxh_format_f64", "vtxh_pack_files_raw", "vtxh_get_raw_batch", "vtxh_get_barcode_table", "vtxh_num_batches",
            "vtxh_get_batch_at", "vtxh_get_raw_batch_at")
@@ -68,8 +68,13 @@ def load():
         L.vtxh_write_mtx.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vtxh_format_f64.restype = C.c_int
         L.vtxh_format_f64.argtypes = [C.c_double, C.c_char_p]
+        L.vtxh_get_ingest_stats.restype = None
+        L.vtxh_get_ingest_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 3)]
         _lib = L
     return _lib
+
+
+last_ingest_stats = {}        # of the most recent pack_files call: BGZF blocks inflated / in the file, index-guided jumps
 
 
 class HostError(RuntimeError):
@@ -114,6 +119,10 @@ def pack_files(vcf, bam, fasta, cell_barcodes, padding=100, mapq=0, primary_only
         m = VtxhMetrics()
         L.vtxh_get_metrics(h, C.byref(m))
         metrics = {n: int(getattr(m, n)) for n in METRIC_NAMES}
+        st = (C.c_uint64 * 3)()
+        L.vtxh_get_ingest_stats(h, C.byref(st))
+        global last_ingest_stats
+        last_ingest_stats = {"blocks_inflated": int(st[0]), "blocks_total": int(st[1]), "index_jumps": int(st[2])}
         nv, nb = L.vtxh_num_variants(h), L.vtxh_num_barcodes(h)
         barcodes = [L.vtxh_barcode(h, j) for j in range(nb)]
         variants = [L.vtxh_variant_name(h, i).decode() for i in range(nv)]
