@@ -157,7 +157,7 @@ def run_cli_timed(out_dir, fa, vcf, bam, bcs, threads, extra, label):
     wall = time.time() - t0
     assert r.returncode == 0, r.stdout + r.stderr
     keep = [ln for ln in r.stderr.splitlines() if any(k in ln for k in ("Ingest", "Device", "shard:", "Merge +", "Waited", "Total",
-                                                                       "packer", "alignments evaluated", "device preparation"))]
+                                                                       "[vtxh]", "alignments evaluated", "device preparation"))]
     print("%s: CLI wall time %.2f s\n  %s" % (label, wall, "\n  ".join(keep)), flush=True)
     return out
 
@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--fast", action="store_true", help="vectorised authoring (config-3 scale); timing runs only, with an "
                     "internal consistency check between --prep host and --prep device")
     ap.add_argument("--procs", type=int, default=32)
+    ap.add_argument("--more-threads", type=int, nargs="*", default=[], help="--fast: extra CLI runs with these --threads values")
     ap.add_argument("--loci", type=int, default=1000)
     ap.add_argument("--reads", type=int, default=256)
     ap.add_argument("--barcodes", type=int, default=2000)
@@ -179,9 +180,12 @@ def main():
         fa, vcf, bam, bcs, n_reads = author_fast(args.out, args.loci, args.reads, args.barcodes, procs=args.procs)
         print("authored %d reads over %d loci in %.1f s (%.1f MB BAM)" % (n_reads, args.loci, time.time() - t0, os.path.getsize(bam) / 1e6), flush=True)
         texts = []
-        for extra, label in ((["--prep", "host"], "--prep host"), (["--prep", "device"], "--prep device"),
-                             (["--prep", "device"], "--prep device (second run, page cache warm)")):
-            out = run_cli_timed(args.out, fa, vcf, bam, bcs, args.threads, extra, label)
+        runs = [(["--prep", "host"], "--prep host", args.threads), (["--prep", "device"], "--prep device", args.threads),
+                (["--prep", "device"], "--prep device (second run, page cache warm)", args.threads)]
+        for th in args.more_threads:
+            runs.append((["--prep", "device"], "--prep device, --threads %d" % th, th))
+        for extra, label, th in runs:
+            out = run_cli_timed(args.out, fa, vcf, bam, bcs, th, extra, label)
             import hashlib
             texts.append(hashlib.sha256(open(out, "rb").read()).hexdigest())
             print("  .mtx %.1f MB, sha256 %s" % (os.path.getsize(out) / 1e6, texts[-1][:16]), flush=True)

@@ -309,7 +309,8 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
 #define CH_END 0xffffu     // end of a k-mer chain / empty bucket
 
 __device__ __forceinline__ uint32_t kw_hash(uint32_t lo, uint32_t hi, uint32_t head_mask) {
-    uint32_t h = lo * 0x9E3779B1u ^ (hi + 0x7F4A7C15u) * 0x85EBCA77u;
+    // one 32-bit multiply (a quarter-rate instruction): the two bytes of `hi` are folded in with a rotation first
+    const uint32_t h = (lo ^ (hi << 11) ^ (hi >> 3)) * 0x9E3779B1u;
     return (h >> 18) & head_mask;
 }
 
@@ -809,7 +810,9 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
         run_state st;
         st.n_ent = 0; st.i_next = 0; st.ev0 = NONE_ID; st.ev1 = NONE_ID; st.lg_n = 0;
         st.best_v = -1; st.best_id = 0; st.overflow = false; st.why = 0; st.ub_ok = true; st.n_sp = 0;
-        uint32_t a_idx = NONE_ID, a_id0 = 0, a_len = 0, b_idx = NONE_ID, b_id0 = 0, b_len = 0;
+        // the two open pieces: list index, k-mers so far, and the id (x << 16 | y) of the match that would continue them
+        // (kept incrementally: a multiply-add per unit costs four issue slots on this target)
+        uint32_t a_idx = NONE_ID, a_nx = 0, a_len = 0, b_idx = NONE_ID, b_nx = 0, b_len = 0;
         {
             // The probe is a flat loop of WORK UNITS, every lane at its own row: a unit is either one step along the
             // k-mer chain of the lane's current row, or the advance to its next row.  A wavefront therefore pays the
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
                     const uint32_t nwlo = (wlo >> 8) | (whi << 24);
                     const uint32_t nwhi = ((whi >> 8) & 0xff) | (nb << 8);
                     const uint32_t hd = head[kw_hash(nwlo, nwhi, hmask)];             // ... its bucket
-                    const uint32_t aid = a_id0 + a_len * 0x10001u;                    // ... where piece a would continue
+                    const uint32_t aid = a_nx;                                        // ... where piece a would continue
                     const uint32_t ay = aid & 0xffffu;
                     const bool a_ok = a_idx != NONE_ID && (aid >> 16) == xn && ay + KMER <= n;
                     const uint32_t fbv = fb[a_ok ? ay + KMER - 1 : 0u];               // ... flag byte of that k-mer's last base
@@ -876,20 +879,20 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
                         ycur = e.y >> 16;
                         if (e.x == wlo && (e.y & 0xffffu) == whi) {
                             const uint32_t id = (xr << 16) | y;
-                            if (a_idx != NONE_ID && id == a_id0 + a_len * 0x10001u) {
-                                ++a_len;
-                            } else if (b_idx != NONE_ID && id == b_id0 + b_len * 0x10001u) {
-                                ++b_len;
+                            if (a_idx != NONE_ID && id == a_nx) {
+                                ++a_len; a_nx += 0x10001u;
+                            } else if (b_idx != NONE_ID && id == b_nx) {
+                                ++b_len; b_nx += 0x10001u;
                                 uint32_t t;
                                 t = a_idx; a_idx = b_idx; b_idx = t;
-                                t = a_id0; a_id0 = b_id0; b_id0 = t;
+                                t = a_nx; a_nx = b_nx; b_nx = t;
                                 t = a_len; a_len = b_len; b_len = t;
                             } else if (st.n_ent == PS) {
                                 service = true; pend_id = id;
                             } else {
                                 if (b_idx != NONE_ID) pm_id[b_idx * NT + tid] = (pm_id[b_idx * NT + tid] & 0xffff0000u) | b_len;
-                                b_idx = a_idx; b_id0 = a_id0; b_len = a_len;
-                                a_idx = st.n_ent; a_id0 = id; a_len = 1;
+                                b_idx = a_idx; b_nx = a_nx; b_len = a_len;
+                                a_idx = st.n_ent; a_nx = id + 0x10001u; a_len = 1;
                                 pm_a[st.n_ent * NT + tid] = id; pm_id[st.n_ent * NT + tid] = 1; ++st.n_ent;
                             }
                         }
@@ -901,7 +904,7 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
                         if (live) {
                             wlo = nwlo; whi = nwhi;
                             // piece a continues onto a k-mer that is unique in the haplotype: the only match of this row
-                            if (a_ok && fbv == nb + 0x80u) ++a_len;
+                            if (a_ok && fbv == nb + 0x80u) { ++a_len; a_nx += 0x10001u; }
                             else ycur = hd;
                         }
                     }
@@ -916,13 +919,13 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
                     if (st.n_ent == PS && !st.overflow) { st.overflow = true; st.why = 2; }
                     if (!st.overflow) {
                         // a breakpoint may have split an open piece and compaction renumbers: reload the register copies
-                        if (a_idx != NONE_ID) { a_id0 = pm_a[a_idx * NT + tid]; a_len = pm_id[a_idx * NT + tid] & 0xffff; }
+                        if (a_idx != NONE_ID) { a_len = pm_id[a_idx * NT + tid] & 0xffff; a_nx = pm_a[a_idx * NT + tid] + a_len * 0x10001u; }
                         if (b_idx != NONE_ID) {
-                            b_id0 = pm_a[b_idx * NT + tid]; b_len = pm_id[b_idx * NT + tid] & 0xffff;
+                            b_len = pm_id[b_idx * NT + tid] & 0xffff; b_nx = pm_a[b_idx * NT + tid] + b_len * 0x10001u;
                             pm_id[b_idx * NT + tid] = (pm_id[b_idx * NT + tid] & 0xffff0000u) | b_len;
                         }
-                        b_idx = a_idx; b_id0 = a_id0; b_len = a_len;
-                        a_idx = st.n_ent; a_id0 = pend_id; a_len = 1;
+                        b_idx = a_idx; b_nx = a_nx; b_len = a_len;
+                        a_idx = st.n_ent; a_nx = pend_id + 0x10001u; a_len = 1;
                         pm_a[st.n_ent * NT + tid] = pend_id; pm_id[st.n_ent * NT + tid] = 1; ++st.n_ent;
                     }
                 }
