@@ -58,6 +58,7 @@ static void walk_gap(walk_t* w, int dir) {
 
 /* Returns the certificate, or -1 when there is no k-mer match (Band::full_matrix). */
 int32_t vtxo_chain_cert(const uint8_t* x, int m, const uint8_t* y, int n, int k) {
+    const int band_w = 20;   /* W of src/main.rs:34 */
     uint32_t* mt = NULL;
     int64_t M = vtxo_find_kmer_matches(x, m, y, n, k, &mt);
     if (M == 0) { free(mt); return -1; }
@@ -68,6 +69,12 @@ int32_t vtxo_chain_cert(const uint8_t* x, int m, const uint8_t* y, int n, int k)
     int d0 = imin(imin(fx, fy), lazy);
     int r = fx - d0, c = fy - d0;
     walk_t w = {0, -100000, 0, 0};
+    /* the (2w+1)-square around the first anchor is in band: the diagonal may be walked from up to w cells before it */
+    {
+        const int t0 = imin(imin(r, c), band_w);
+        int rr = r - t0, cc = c - t0;
+        for (int i = 0; i < t0; ++i) { ++rr; ++cc; walk_diag(&w, x[rr - 1] == y[cc - 1]); }
+    }
     for (int i = 0; i < d0; ++i) { ++r; ++c; walk_diag(&w, x[r - 1] == y[c - 1]); }
     for (int64_t t = 0; t < L; ++t) {
         const int px = (int)mt[2 * path[t]], py = (int)mt[2 * path[t] + 1];
@@ -86,6 +93,11 @@ int32_t vtxo_chain_cert(const uint8_t* x, int m, const uint8_t* y, int n, int k)
     }
     int d1 = imin(imin(m - r, n - c), lazy);
     for (int i = 0; i < d1; ++i) { ++r; ++c; walk_diag(&w, x[r - 1] == y[c - 1]); }
+    /* ... and up to w cells past the last anchor */
+    {
+        const int t1 = imin(imin(m - r, n - c), band_w);
+        for (int i = 0; i < t1; ++i) { ++r; ++c; walk_diag(&w, x[r - 1] == y[c - 1]); }
+    }
     free(path); free(mt);
     return w.best;
 }

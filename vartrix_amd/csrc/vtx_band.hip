@@ -363,6 +363,14 @@ __device__ int band_finish(const uint32_t* mylog, uint32_t lg_n, uint32_t best_i
         walk_state w = {0, -100000, 0, 0};
 #define EMIT() verts[nv++] = ((uint32_t)r << 16) | (uint32_t)c
         EMIT();
+        {
+            // the (2w+1)-square around the first anchor is in band, so the path may start up to w cells further up its
+            // diagonal (not part of the staircase: no vertex) — a mismatch a few bases inside the read's end no longer
+            // costs the certificate the bases beyond it
+            const int t0 = min(min(r, c), BANDW);
+            int rr = r - t0, cc = c - t0;
+            for (int i = 0; i < t0; ++i) { ++rr; ++cc; walk_diag(w, x[rr - 1] == yb[cc - 1]); }
+        }
         for (int i = 0; i < d0; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
         if (d0 > 0) EMIT();
         for (uint32_t sgi = n_seg; sgi-- > 0;) {
@@ -387,6 +395,10 @@ __device__ int band_finish(const uint32_t* mylog, uint32_t lg_n, uint32_t best_i
         int d1 = ((int)m - r) < ((int)n - c) ? ((int)m - r) : ((int)n - c); if (d1 > VTX_BAND_LAZY_EXT(KMER)) d1 = VTX_BAND_LAZY_EXT(KMER);
         for (int i = 0; i < d1; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
         if (d1 > 0) EMIT();
+        {
+            const int t1 = min(min((int)m - r, (int)n - c), BANDW);      // ... and up to w cells past the last anchor
+            for (int i = 0; i < t1; ++i) { ++r; ++c; walk_diag(w, x[r - 1] == yb[c - 1]); }
+        }
 #undef EMIT
         *cert_out = w.best;
         if (w.best == ub) return 0;                          // cert == ub: banded == full == ub
