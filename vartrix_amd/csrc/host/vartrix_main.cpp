@@ -80,13 +80,14 @@ void usage() {
 }
 
 struct Shard {
-    std::vector<vtx_locus> loci;
-    std::vector<vtx_record> records;
+    std::vector<vtx_locus> loci;                 // rec_begin rebased to the shard's first record
+    const vtx_record* records = nullptr;         // the shard's slice of the pack's arrays (not copied)
+    uint32_t n_records = 0;
     const uint8_t *haps, *reads;
     uint64_t hap_bytes, read_bytes;
     // --prep device: raw records (tags as bytes) + the barcode table
     bool raw = false;
-    std::vector<vtx_raw_record> raw_records;
+    const vtx_raw_record* raw_records = nullptr;
     const uint8_t *tags = nullptr, *bc_bytes = nullptr;
     const uint64_t* bc_offsets = nullptr;
     uint64_t tag_bytes = 0;
@@ -94,6 +95,9 @@ struct Shard {
     vtx_raw_stats stats{};
     std::vector<uint32_t> row, col;
     std::vector<double> val, refval;
+    // a run of one batch on one shard writes the matrices straight from the context's arrays (ctx kept until exit)
+    bool keep_ctx = false;
+    vtx_coo kept{};
     std::string err;
     int rc = 0;
     double t_create = 0, t_submit = 0, t_run = 0, t_fetch = 0;
@@ -117,11 +121,11 @@ void run_shard(Shard* s, vtx_config cfg) {
         s->err = vtx_strerror(ctx); vtx_destroy(ctx); return;
     }
     s->t_create = now_s() - t0; t0 = now_s();
-    vtx_batch b{s->loci.data(), (uint32_t)s->loci.size(), s->records.data(), (uint32_t)s->records.size(), s->haps,
+    vtx_batch b{s->loci.data(), (uint32_t)s->loci.size(), s->records, s->n_records, s->haps,
                 s->hap_bytes, s->reads, s->read_bytes};
     vtx_coo coo{};
     if (s->raw) {
-        vtx_raw_batch rb{s->loci.data(), (uint32_t)s->loci.size(), s->raw_records.data(), (uint32_t)s->raw_records.size(),
+        vtx_raw_batch rb{s->loci.data(), (uint32_t)s->loci.size(), s->raw_records, s->n_records,
                          s->haps, s->hap_bytes, s->reads, s->read_bytes, s->tags, s->tag_bytes};
         if ((s->rc = vtx_set_barcodes(ctx, s->bc_bytes, s->bc_offsets, s->n_bcs)) || (s->rc = vtx_submit_raw(ctx, &rb, &s->stats))) {
             s->err = vtx_strerror(ctx);
@@ -140,6 +144,7 @@ void run_shard(Shard* s, vtx_config cfg) {
         if (s->rank != 0) { s->t_fetch = now_s() - t0; vtx_destroy(ctx); return; }
         if ((s->rc = vtx_fetch_gathered(ctx, &coo))) { s->err = vtx_strerror(ctx); vtx_destroy(ctx); return; }
     } else if ((s->rc = vtx_fetch_coo(ctx, &coo))) { s->err = vtx_strerror(ctx); vtx_destroy(ctx); return; }
+    if (s->keep_ctx) { s->kept = coo; s->t_fetch = now_s() - t0; return; }
     s->row.assign(coo.row, coo.row + coo.nnz);
     s->col.assign(coo.col, coo.col + coo.nnz);
     s->val.assign(coo.value, coo.value + coo.nnz);
@@ -267,6 +272,9 @@ int main(int argc, char** argv) {
     for (auto& t : warm) t.join();
     LOG_INFO("Waited %.3f s more for the HIP runtime / device initialisation started at launch", since(t_wait));
     std::vector<uint32_t> row, col;
+    uint64_t out_nnz = 0;                                  // the matrix to write: either the vectors or one kept context's arrays
+    const uint32_t *out_row = nullptr, *out_col = nullptr;
+    const double *out_v = nullptr, *out_rv = nullptr;
     std::vector<double> v, rv;
     vtx_raw_stats raw_total{};
     const auto t_dev = std::chrono::steady_clock::now();
@@ -298,13 +306,15 @@ int main(int argc, char** argv) {
                 s.loci.assign(full.loci + cuts[(size_t)d], full.loci + cuts[(size_t)d + 1]);
                 const uint32_t r0 = s.loci.empty() ? 0 : s.loci.front().rec_begin;
                 const uint32_t r1 = s.loci.empty() ? 0 : s.loci.back().rec_begin + s.loci.back().rec_count;
+                s.n_records = r1 - r0;
+                s.keep_ctx = n_batches == 1 && ndev == 1;
                 if (raw) {
                     s.raw = true;
-                    s.raw_records.assign(full_raw.records + r0, full_raw.records + r1);
+                    s.raw_records = full_raw.records + r0;
                     s.tags = full_raw.tag_arena; s.tag_bytes = full_raw.tag_bytes;
                     s.bc_bytes = bc_bytes; s.bc_offsets = bc_offsets; s.n_bcs = bc_n;
                 } else {
-                    s.records.assign(full.records + r0, full.records + r1);
+                    s.records = full.records + r0;
                 }
                 for (auto& L : s.loci) L.rec_begin -= r0;
                 s.haps = full.hap_arena; s.hap_bytes = full.hap_bytes;       // arenas are shared read-only, offsets stay valid
@@ -333,6 +343,7 @@ int main(int argc, char** argv) {
         for (auto& s : shards) {
             LOG_INFO("  batch %u shard: create %.3f s, submit (H2D%s) %.3f s, run %.3f s, fetch %.3f s", bi, s.t_create,
                      s.raw ? " + device preparation" : "", s.t_submit, s.t_run, s.t_fetch);
+            if (s.keep_ctx) { out_nnz = s.kept.nnz; out_row = s.kept.row; out_col = s.kept.col; out_v = s.kept.value; out_rv = s.kept.ref_value; }
             row.insert(row.end(), s.row.begin(), s.row.end());       // shard (= row) order: the triplet order of the merge loop :320-348
             col.insert(col.end(), s.col.begin(), s.col.end());
             v.insert(v.end(), s.val.begin(), s.val.end());
@@ -362,14 +373,15 @@ int main(int argc, char** argv) {
     LOG_INFO("Number of VCF records skipped due to having invalid characters in the alternative haplotype: %llu", (unsigned long long)m.num_invalid_recs);
     LOG_INFO("Number of VCF records skipped due to being multi-allelic: %llu", (unsigned long long)m.num_multiallelic_recs);
 
-    if (vtxh_write_mtx(out_matrix.c_str(), n_vars, n_bcs, row.size(), row.data(), col.data(), v.data()) != 0) {
+    if (!out_row) { out_nnz = row.size(); out_row = row.data(); out_col = col.data(); out_v = v.data(); out_rv = rv.data(); }
+    if (vtxh_write_mtx(out_matrix.c_str(), n_vars, n_bcs, out_nnz, out_row, out_col, out_v) != 0) {
         printf("Vartrix error.\nError: Error writing out-matrix\nInfo: caused by %s\n", vtxh_last_error());
         return 1;
     }
     // :385-389 `args.is_present("ref_matrix")` is true even without the flag: clap 2.33 reports an argument with a
     // default_value (:100) as present, so coverage mode always writes the REF-count matrix (default ref_matrix.mtx)
     if (mode == "coverage") {
-        if (vtxh_write_mtx(ref_matrix.c_str(), n_vars, n_bcs, row.size(), row.data(), col.data(), rv.data()) != 0) {
+        if (vtxh_write_mtx(ref_matrix.c_str(), n_vars, n_bcs, out_nnz, out_row, out_col, out_rv) != 0) {
             printf("Vartrix error.\nError: Error writing ref-matrix\nInfo: caused by %s\n", vtxh_last_error());
             return 1;
         }
@@ -390,7 +402,7 @@ int main(int argc, char** argv) {
     }
     LOG_INFO("Merge + output files: %.3f s", since(t_out));
     double sum = 0;
-    for (double x : v) sum += x;
+    for (uint64_t k = 0; k < out_nnz; ++k) sum += out_v[k];
     if (sum == 0.0) LOG_ERROR("The resulting matrix has a sum of 0. Did you use the --umi flag on data without UMIs?");       // :410-415
     LOG_INFO("Total since launch: %.3f s", since(t_main));
     // every output file is closed: skip the teardown of a GB of host arrays and of the HIP runtime (~0.1 s)

@@ -152,6 +152,7 @@ struct ByteBuf {
     const unsigned char* data() const { return p; }
     size_t size() const { return len; }
     void drop_prefix(size_t n) { if (n) { memmove(p, p + n, len - n); len -= n; } }
+    void release() { free(p); p = nullptr; len = cap = 0; }
     unsigned char* grow(size_t add) {      // returns the start of the new bytes; nullptr when out of memory
         if (len + add > cap || !p) {
             size_t want = std::max<size_t>(std::max(len + add, cap + cap / 2), 64);
@@ -409,7 +410,8 @@ struct vtxh_pack {
     std::vector<std::string> barcodes, variant_names;
     // raw mode (vtxh_pack_files_raw)
     std::vector<vtx_raw_record> raw_records;
-    std::string tag_arena, bc_bytes;
+    ByteBuf tag_arena;
+    std::string bc_bytes;
     std::vector<uint64_t> bc_offsets;
     // Batches: consecutive loci whose reads (and tags) span less than 4 GiB of the arenas, so that the 32-bit offsets
     // of vtx.h hold relative to the batch's window.  Loci / records of all batches sit back to back in the arrays above.
@@ -813,28 +815,12 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         return o.reads.size() <= 0xffffffffull && o.tags.size() <= 0xffffffffull;
     };
     std::vector<size_t> rec_offs;
-    // the (sequential, order-preserving) merge of window w runs on its own thread while window w+1 inflates and parses
-    std::vector<WorkerOut> out_sets[2] = {std::vector<WorkerOut>((size_t)threads), std::vector<WorkerOut>((size_t)threads)};
-    int cur_set = 0;
-    std::thread merger;
-    int merge_code = VTX_OK;
-    std::string merge_err;
-    std::vector<Hit> all_hits;                 // every surviving (read, locus) pair, BAM order, offsets into the global arenas
-    std::string& tag_store = P->tag_arena;     // raw: barcode + UMI bytes for the device; cooked: UMI bytes until the ids are assigned
-    auto merge = [&](std::vector<WorkerOut>* outs_p) {
-        for (auto& o : *outs_p) {
-            if (!o.err.empty()) { merge_code = o.err[0] == 'm' ? VTX_E_INVAL : VTX_E_UNSUPPORTED; merge_err = o.err; return; }
-            const uint64_t rbase = o.rbase, tbase = tag_store.size();
-            tag_store += o.tags;
-            const uint64_t* src = &o.m.num_reads;
-            uint64_t* dst = &P->metrics.num_reads;
-            for (int k = 0; k < 9; ++k) dst[k] += src[k];
-            const size_t h0 = all_hits.size();
-            all_hits.insert(all_hits.end(), o.hits.begin(), o.hits.end());
-            for (size_t k = h0; k < all_hits.size(); ++k) { all_hits[k].roff = rbase + all_hits[k].rr.read_off; all_hits[k].toff = tbase; }
-        }
-    };
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{merger};
+    // every window's worker outputs go to the global arrays at prefix offsets (thread order = BAM order), copied by the
+    // workers themselves
+    std::vector<WorkerOut> outs((size_t)threads);
+    ByteBuf hit_store;                         // Hit[]: every surviving (read, locus) pair, BAM order, offsets into the global arenas
+    size_t n_hits = 0;
+    ByteBuf& tag_store = P->tag_arena;         // raw: barcode + UMI bytes for the device; cooked: UMI bytes until the ids are assigned
     // index-guided sweep state: targets [tg, ...) still to serve; the running segment ends at (seg_tid, seg_end)
     size_t tg = 0;
     int32_t seg_tid = -1;
@@ -869,7 +855,6 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         }
     }
     while (true) {
-        std::vector<WorkerOut>& outs = out_sets[cur_set];
         if (jump_pending) {
             // restart the record stream at a virtual offset: drop what is buffered, inflate from that block on
             jump_pending = false;
@@ -938,41 +923,84 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
                 if (!process(rp + 4, rd32(rp), o, hits, seq)) { if (o.err.empty()) o.err = "one window of the BAM holds more than 4 GiB of read bases"; return; }
             }
         });
-        // the workers' read bytes go to the global arena at prefix offsets, copied by the workers themselves
         {
-            uint64_t total = reads.size();
-            for (auto& o : outs) { o.rbase = total; total += o.reads.size(); }
-            if (!reads.grow((size_t)(total - reads.size()))) return fail(VTX_E_NOMEM, "out of memory growing the read arena");
-            pool.run([&](size_t t) { if (!outs[t].reads.empty()) memcpy(reads.data() + outs[t].rbase, outs[t].reads.data(), outs[t].reads.size()); });
+            std::vector<uint64_t> tbase((size_t)threads), hbase((size_t)threads);
+            uint64_t rtotal = reads.size(), ttotal = tag_store.size(), htotal = n_hits;
+            for (size_t t = 0; t < outs.size(); ++t) {
+                WorkerOut& o = outs[t];
+                if (!o.err.empty()) return fail(o.err[0] == 'm' ? VTX_E_INVAL : VTX_E_UNSUPPORTED, "%s: %s", a->bam, o.err.c_str());
+                o.rbase = rtotal; rtotal += o.reads.size();
+                tbase[t] = ttotal; ttotal += o.tags.size();
+                hbase[t] = htotal; htotal += o.hits.size();
+                const uint64_t* src = &o.m.num_reads;
+                uint64_t* dst = &P->metrics.num_reads;
+                for (int k = 0; k < 9; ++k) dst[k] += src[k];
+            }
+            if (!reads.grow((size_t)(rtotal - reads.size())) || !tag_store.grow((size_t)(ttotal - tag_store.size())) ||
+                !hit_store.grow((size_t)(htotal - n_hits) * sizeof(Hit)))
+                return fail(VTX_E_NOMEM, "out of memory growing the read arenas");
+            n_hits = (size_t)htotal;
+            Hit* all = (Hit*)hit_store.data();
+            pool.run([&](size_t t) {
+                const WorkerOut& o = outs[t];
+                if (!o.reads.empty()) memcpy(reads.data() + o.rbase, o.reads.data(), o.reads.size());
+                if (!o.tags.empty()) memcpy(tag_store.data() + tbase[t], o.tags.data(), o.tags.size());
+                Hit* dst = all + hbase[t];
+                for (size_t k = 0; k < o.hits.size(); ++k) {
+                    Hit h = o.hits[k];
+                    h.roff = o.rbase + h.rr.read_off; h.toff = tbase[t];
+                    dst[k] = h;
+                }
+            });
         }
         ph.mark("parse + filter");
-        if (merger.joinable()) merger.join();
-        if (merge_code != VTX_OK) return fail(merge_code, "%s: %s", a->bam, merge_err.c_str());
-        merger = std::thread(merge, &outs);
-        cur_set ^= 1;
-        ph.mark("merge");
         buf_pos = p;
         if (all_served) break;
         if (jump_pending) continue;
         if (eof && buf.size() - buf_pos < 4) break;
         if (eof && rec_offs.empty()) break;
     }
-    if (merger.joinable()) merger.join();
-    if (merge_code != VTX_OK) return fail(merge_code, "%s: %s", a->bam, merge_err.c_str());
     P->blocks_inflated = n_inflated; P->blocks_total = blocks.size(); P->index_jumps = n_jumps;
-    ph.mark("merge (tail)");
 
-    // ---- group the hits by locus: stable counting sort (hits are in BAM order, so every locus keeps it) ----
+    // ---- group the hits by locus: stable counting sort (hits are in BAM order, so every locus keeps it); thread t owns the
+    //      t-th slice of the hits, and within a locus the slices land in thread order ----
     const size_t nloc = loci.size();
+    const Hit* all_hits = (const Hit*)hit_store.data();
     std::vector<uint64_t> l_begin(nloc + 1, 0);
-    for (const Hit& h : all_hits) ++l_begin[h.locus + 1];
-    for (size_t l = 0; l < nloc; ++l) l_begin[l + 1] += l_begin[l];
-    std::vector<Hit> by_locus(all_hits.size());
+    ByteBuf sorted_store;
+    if (!sorted_store.grow(n_hits * sizeof(Hit))) return fail(VTX_E_NOMEM, "out of memory sorting the reads");
+    Hit* by_locus = (Hit*)sorted_store.data();
     {
-        std::vector<uint64_t> cursor(l_begin.begin(), l_begin.end() - 1);
-        for (const Hit& h : all_hits) by_locus[cursor[h.locus]++] = h;
+        const size_t T = (size_t)threads;
+        std::vector<std::vector<uint32_t>> hist(T);
+        pool.run([&](size_t t) {
+            hist[t].assign(nloc, 0);
+            for (size_t k = n_hits * t / T, e = n_hits * (t + 1) / T; k < e; ++k) ++hist[t][all_hits[k].locus];
+        });
+        for (size_t l = 0; l < nloc; ++l) {
+            uint64_t c = 0;
+            for (size_t t = 0; t < T; ++t) c += hist[t][l];
+            l_begin[l + 1] = l_begin[l] + c;
+        }
+        pool.run([&](size_t t) {
+            // this slice's first slot within every locus it touches: the slices before it come first
+            std::vector<uint64_t> cursor;
+            size_t k0 = n_hits * t / T, e = n_hits * (t + 1) / T;
+            if (k0 == e) return;
+            // a sorted file keeps a slice's loci in a narrow range; any order is handled all the same
+            uint32_t lmin = UINT32_MAX, lmax = 0;
+            for (size_t k = k0; k < e; ++k) { lmin = std::min(lmin, all_hits[k].locus); lmax = std::max(lmax, all_hits[k].locus); }
+            cursor.resize((size_t)lmax - lmin + 1);
+            for (uint32_t l = lmin; l <= lmax; ++l) {
+                uint64_t c = l_begin[l];
+                for (size_t u = 0; u < t; ++u) c += hist[u][l];
+                cursor[l - lmin] = c;
+            }
+            for (size_t k = k0; k < e; ++k) by_locus[cursor[all_hits[k].locus - lmin]++] = all_hits[k];
+        });
     }
-    std::vector<Hit>().swap(all_hits);
+    hit_store.release();
+    const size_t n_sorted = n_hits;
     // ---- batches: consecutive loci whose reads / tags span < 4 GiB (32-bit offsets relative to the batch window) ----
     uint64_t limit = 0xF0000000ull;
     if (const char* e = getenv("VTXH_BATCH_BYTES")) limit = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // tests
@@ -988,17 +1016,26 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             cur = vtxh_pack::Batch{l_end, l_end, l_begin[l_end], l_begin[l_end], 0, 0, 0, 0};
             rlo = tlo = UINT64_MAX; rhi = thi = 0;
         };
-        for (size_t l = 0; l < nloc; ++l) {
-            uint64_t a0 = UINT64_MAX, a1 = 0, b0 = UINT64_MAX, b1 = 0;
-            for (uint64_t j = l_begin[l]; j < l_begin[l + 1]; ++j) {
-                const Hit& h = by_locus[j];
-                a0 = std::min(a0, h.roff); a1 = std::max(a1, h.roff + h.rr.read_len);
-                if (need_tags) {
-                    b0 = std::min(b0, h.toff + h.rr.bc_off);
-                    b1 = std::max(b1, h.toff + h.rr.bc_off + h.rr.bc_len);
-                    if (h.rr.umi_len != VTX_TAG_MISSING) b1 = std::max(b1, h.toff + h.rr.umi_off + h.rr.umi_len);
+        // the byte extents of every locus' reads and tags, loci in parallel
+        struct Extent { uint64_t a0, a1, b0, b1; };
+        std::vector<Extent> ext(nloc);
+        pool.run([&](size_t t) {
+            for (size_t l = nloc * t / (size_t)threads, e = nloc * (t + 1) / (size_t)threads; l < e; ++l) {
+                uint64_t a0 = UINT64_MAX, a1 = 0, b0 = UINT64_MAX, b1 = 0;
+                for (uint64_t j = l_begin[l]; j < l_begin[l + 1]; ++j) {
+                    const Hit& h = by_locus[j];
+                    a0 = std::min(a0, h.roff); a1 = std::max(a1, h.roff + h.rr.read_len);
+                    if (need_tags) {
+                        b0 = std::min(b0, h.toff + h.rr.bc_off);
+                        b1 = std::max(b1, h.toff + h.rr.bc_off + h.rr.bc_len);
+                        if (h.rr.umi_len != VTX_TAG_MISSING) b1 = std::max(b1, h.toff + h.rr.umi_off + h.rr.umi_len);
+                    }
                 }
+                ext[l] = Extent{a0, a1, b0, b1};
             }
+        });
+        for (size_t l = 0; l < nloc; ++l) {
+            const uint64_t a0 = ext[l].a0, a1 = ext[l].a1, b0 = ext[l].b0, b1 = ext[l].b1;
             if (a1 - std::min(a0, a1) > limit || b1 - std::min(b0, b1) > limit || l_begin[l + 1] - l_begin[l] > 0x7fffffffull)
                 return fail(VTX_E_UNSUPPORTED, "locus %zu alone needs more than %llu bytes of reads", l, (unsigned long long)limit);
             const uint64_t nr0 = std::min(rlo, a0), nr1 = std::max(rhi, a1), nt0 = std::min(tlo, b0), nt1 = std::max(thi, b1);
@@ -1027,25 +1064,27 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             P->loci[l].rec_begin = (uint32_t)(l_begin[l] - P->batches[b].rec0);
         }
     if (raw) {
-        P->raw_records.resize(by_locus.size());
-        for (size_t l = 0; l < nloc; ++l) {
-            const vtxh_pack::Batch& B = P->batches[batch_of[l]];
-            for (uint64_t j = l_begin[l]; j < l_begin[l + 1]; ++j) {
-                const Hit& h = by_locus[j];
-                vtx_raw_record rr = h.rr;
-                rr.read_off = (uint32_t)(h.roff - B.rbase);
-                rr.bc_off = (uint32_t)(h.toff + h.rr.bc_off - B.tbase);
-                rr.umi_off = h.rr.umi_len != VTX_TAG_MISSING ? (uint32_t)(h.toff + h.rr.umi_off - B.tbase) : 0u;
-                P->raw_records[j] = rr;
+        P->raw_records.resize(n_sorted);
+        pool.run([&](size_t t) {
+            for (size_t l = nloc * t / (size_t)threads, e = nloc * (t + 1) / (size_t)threads; l < e; ++l) {
+                const vtxh_pack::Batch& B = P->batches[batch_of[l]];
+                for (uint64_t j = l_begin[l]; j < l_begin[l + 1]; ++j) {
+                    const Hit& h = by_locus[j];
+                    vtx_raw_record rr = h.rr;
+                    rr.read_off = (uint32_t)(h.roff - B.rbase);
+                    rr.bc_off = (uint32_t)(h.toff + h.rr.bc_off - B.tbase);
+                    rr.umi_off = h.rr.umi_len != VTX_TAG_MISSING ? (uint32_t)(h.toff + h.rr.umi_off - B.tbase) : 0u;
+                    P->raw_records[j] = rr;
+                }
             }
-        }
+        });
         ph.mark("pack");
         *out = P.release();
         return VTX_OK;
     }
     // ---- cooked: UMI ids by first occurrence, then the stable sort by (cell, umi) (:932 + per-cell UMI grouping),
     //      loci in parallel (disjoint output ranges) ----
-    P->records.resize(by_locus.size());
+    P->records.resize(n_sorted);
     {
         std::atomic<size_t> next_locus{0};
         auto pack_loci = [&]() {
@@ -1058,7 +1097,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
                     for (uint64_t j = l_begin[ll]; j < l_begin[ll + 1]; ++j) {
                         const Hit& h = by_locus[j];
                         uint32_t uid = 0;     // without --umi every read carries the same dummy UMI (:890-894)
-                        if (a->use_umi) uid = umi_ids.emplace(tag_store.substr(h.toff + h.rr.umi_off, h.rr.umi_len), (uint32_t)umi_ids.size()).first->second;
+                        if (a->use_umi) uid = umi_ids.emplace(std::string((const char*)tag_store.data() + h.toff + h.rr.umi_off, h.rr.umi_len), (uint32_t)umi_ids.size()).first->second;
                         recs.push_back(LocusBuild::Rec{h.cell, uid, h.roff - rbase, h.rr.read_len});
                     }
                     std::stable_sort(recs.begin(), recs.end(), [](const LocusBuild::Rec& x, const LocusBuild::Rec& y) {
@@ -1073,7 +1112,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         pack_loci();
         for (auto& t : th) t.join();
     }
-    std::string().swap(tag_store);
+    tag_store.release();
     ph.mark("sort + pack");
     *out = P.release();
     return VTX_OK;

@@ -67,6 +67,18 @@ thread_local std::string g_create_err;
 
 }  // namespace
 
+template <class T>
+struct HostArr {
+    T* p = nullptr;
+    size_t n = 0;
+    ~HostArr() { free(p); }
+    bool alloc(size_t count) {
+        if (count > n || !p) { free(p); p = (T*)malloc(std::max<size_t>(count, 1) * sizeof(T)); n = p ? count : 0; }
+        return p != nullptr;
+    }
+    T* data() { return p; }
+};
+
 struct vtx_ctx {
     vtx_config cfg{};
     hipStream_t stream = nullptr;
@@ -108,8 +120,8 @@ struct vtx_ctx {
     hipEvent_t up_ev[kUpWorkers][kUpSlots] = {};
     hipStream_t up_stream[kUpWorkers] = {};
     bool up_ready = false;
-    std::vector<uint32_t> h_row, h_col, h_alt, h_ref, h_unk;
-    std::vector<double> h_val, h_refval;
+    HostArr<uint32_t> h_row, h_col, h_alt, h_ref, h_unk;   // fetched triplets (uninitialised storage: written by the download)
+    HostArr<double> h_val, h_refval;
 };
 
 namespace {
@@ -212,6 +224,84 @@ int upload(vtx_ctx* c, const std::vector<UploadJob>& jobs) {
     for (auto& t : th) t.join();
     if (err.load() != (int)hipSuccess)
         return fail(c, VTX_E_HIP, "upload: %s", hipGetErrorString((hipError_t)err.load()));
+    return VTX_OK;
+}
+
+// The way back: device arrays into the caller-visible (pageable, freshly allocated) host arrays.  Same workers and
+// pinned buffers as the upload: a worker keeps one DMA in flight while it copies the previous chunk out of its other
+// pinned buffer, so the page faults of the fresh host pages are spread over the workers.
+int download(vtx_ctx* c, const std::vector<UploadJob>& jobs) {     // dst = host, src = device
+    struct Chunk { char* dst; const char* src; size_t bytes; };
+    std::vector<Chunk> chunks;
+    size_t total = 0;
+    for (const UploadJob& j : jobs)
+        for (size_t o = 0; o < j.bytes; o += vtx_ctx::kUpChunk) {
+            chunks.push_back(Chunk{(char*)j.dst + o, (const char*)j.src + o, std::min(vtx_ctx::kUpChunk, j.bytes - o)});
+            total += chunks.back().bytes;
+        }
+    if (chunks.empty()) return VTX_OK;
+    if (total < (4u << 20)) {
+        for (const Chunk& ch : chunks) HIP_TRY(c, hipMemcpy(ch.dst, ch.src, ch.bytes, hipMemcpyDeviceToHost));
+        return VTX_OK;
+    }
+    if (int rc = upload_init(c)) return rc;
+    std::atomic<size_t> next{0};
+    std::atomic<int> err{(int)hipSuccess};
+    const int device = c->cfg.device;
+    auto worker = [&](int w) {
+        if (hipSetDevice(device) != hipSuccess) { err = (int)hipErrorInvalidDevice; return; }
+        size_t held[vtx_ctx::kUpSlots];
+        bool used[vtx_ctx::kUpSlots] = {};
+        auto drain = [&](int slot) -> hipError_t {
+            if (!used[slot]) return hipSuccess;
+            used[slot] = false;
+            const hipError_t e = hipEventSynchronize(c->up_ev[w][slot]);
+            if (e == hipSuccess) memcpy(chunks[held[slot]].dst, c->up_pin[w][slot], chunks[held[slot]].bytes);
+            return e;
+        };
+        int slot = 0;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            hipError_t e = drain(slot);
+            if (e == hipSuccess && i < chunks.size() && err.load() == (int)hipSuccess) {
+                e = hipMemcpyAsync(c->up_pin[w][slot], chunks[i].src, chunks[i].bytes, hipMemcpyDeviceToHost, c->up_stream[w]);
+                if (e == hipSuccess) e = hipEventRecord(c->up_ev[w][slot], c->up_stream[w]);
+                if (e == hipSuccess) { used[slot] = true; held[slot] = i; }
+            } else {
+                for (int k = 1; k < vtx_ctx::kUpSlots && e == hipSuccess; ++k) e = drain((slot + k) % vtx_ctx::kUpSlots);
+                if (e != hipSuccess) err = (int)e;
+                break;
+            }
+            if (e != hipSuccess) { err = (int)e; break; }
+            slot = (slot + 1) % vtx_ctx::kUpSlots;
+        }
+        (void)hipStreamSynchronize(c->up_stream[w]);
+    };
+    const int nw = (int)std::min<size_t>(vtx_ctx::kUpWorkers, chunks.size());
+    std::vector<std::thread> th;
+    for (int w = 1; w < nw; ++w) th.emplace_back(worker, w);
+    worker(0);
+    for (auto& t : th) t.join();
+    if (err.load() != (int)hipSuccess)
+        return fail(c, VTX_E_HIP, "download: %s", hipGetErrorString((hipError_t)err.load()));
+    return VTX_OK;
+}
+
+// the seven triplet arrays of n entries, device -> host
+int fetch_arrays(vtx_ctx* c, size_t n, const void* row, const void* col, const void* alt, const void* ref, const void* unk,
+                 const void* val, const void* refval, vtx_coo* out) {
+    if (!c->h_row.alloc(n) || !c->h_col.alloc(n) || !c->h_alt.alloc(n) || !c->h_ref.alloc(n) || !c->h_unk.alloc(n) ||
+        !c->h_val.alloc(n) || !c->h_refval.alloc(n))
+        return fail(c, VTX_E_NOMEM, "out of host memory for %zu triplets", n);
+    if (n) {
+        if (int rc = download(c, {{c->h_row.data(), row, n * 4}, {c->h_col.data(), col, n * 4}, {c->h_alt.data(), alt, n * 4},
+                                  {c->h_ref.data(), ref, n * 4}, {c->h_unk.data(), unk, n * 4}, {c->h_val.data(), val, n * 8},
+                                  {c->h_refval.data(), refval, n * 8}}))
+            return rc;
+    }
+    out->row = c->h_row.data(); out->col = c->h_col.data(); out->alt = c->h_alt.data(); out->ref = c->h_ref.data();
+    out->unk = c->h_unk.data(); out->value = c->h_val.data(); out->ref_value = c->h_refval.data();
+    out->nnz = n;
     return VTX_OK;
 }
 
@@ -1064,22 +1154,7 @@ int vtx_fetch_coo(vtx_ctx* c, vtx_coo* out) {
     if (!out) return fail(c, VTX_E_INVAL, "vtx_fetch_coo: null output");
     if (!c->ran) return fail(c, VTX_E_STATE, "vtx_fetch_coo: no completed vtx_run");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const size_t n = c->nnz;
-    c->h_row.resize(n); c->h_col.resize(n); c->h_alt.resize(n); c->h_ref.resize(n); c->h_unk.resize(n);
-    c->h_val.resize(n); c->h_refval.resize(n);
-    if (n) {
-        HIP_TRY(c, hipMemcpy(c->h_row.data(), c->d_o_row.p, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(c->h_col.data(), c->d_o_col.p, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(c->h_alt.data(), c->d_o_alt.p, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(c->h_ref.data(), c->d_o_ref.p, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(c->h_unk.data(), c->d_o_unk.p, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(c->h_val.data(), c->d_o_val.p, n * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(c->h_refval.data(), c->d_o_refval.p, n * 8, hipMemcpyDeviceToHost));
-    }
-    out->row = c->h_row.data(); out->col = c->h_col.data(); out->alt = c->h_alt.data(); out->ref = c->h_ref.data();
-    out->unk = c->h_unk.data(); out->value = c->h_val.data(); out->ref_value = c->h_refval.data();
-    out->nnz = n;
-    return VTX_OK;
+    return fetch_arrays(c, c->nnz, c->d_o_row.p, c->d_o_col.p, c->d_o_alt.p, c->d_o_ref.p, c->d_o_unk.p, c->d_o_val.p, c->d_o_refval.p, out);
 }
 
 int vtx_device_coo(vtx_ctx* c, vtx_coo* out) {
@@ -1182,22 +1257,7 @@ int vtx_fetch_gathered(vtx_ctx* c, vtx_coo* out) {
     if (!c) return VTX_E_INVAL;
     if (!out) return fail(c, VTX_E_INVAL, "vtx_fetch_gathered: null output");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    const size_t n = (size_t)c->g_nnz;
-    c->h_row.resize(n); c->h_col.resize(n); c->h_alt.resize(n); c->h_ref.resize(n); c->h_unk.resize(n);
-    c->h_val.resize(n); c->h_refval.resize(n);
-    if (n) {
-        HIP_TRY(c, hipMemcpy(c->h_row.data(), c->d_g_row.p, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(c->h_col.data(), c->d_g_col.p, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(c->h_alt.data(), c->d_g_alt.p, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(c->h_ref.data(), c->d_g_ref.p, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(c->h_unk.data(), c->d_g_unk.p, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(c->h_val.data(), c->d_g_val.p, n * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(c->h_refval.data(), c->d_g_refval.p, n * 8, hipMemcpyDeviceToHost));
-    }
-    out->row = c->h_row.data(); out->col = c->h_col.data(); out->alt = c->h_alt.data(); out->ref = c->h_ref.data();
-    out->unk = c->h_unk.data(); out->value = c->h_val.data(); out->ref_value = c->h_refval.data();
-    out->nnz = n;
-    return VTX_OK;
+    return fetch_arrays(c, (size_t)c->g_nnz, c->d_g_row.p, c->d_g_col.p, c->d_g_alt.p, c->d_g_ref.p, c->d_g_unk.p, c->d_g_val.p, c->d_g_refval.p, out);
 }
 
 int vtx_last_timing(vtx_ctx* c, vtx_timing* out) {
