@@ -299,7 +299,13 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
     return hipGetLastError();
 }
 
-#define PS 14       // per-lane LDS entries of band_run_kernel: pieces + segments
+#ifndef VTX_PS
+#define VTX_PS 14
+#endif
+#ifndef VTX_WPE
+#define VTX_WPE 4   // wavefronts per SIMD band_run_kernel is compiled and launched for
+#endif
+#define PS VTX_PS   // per-lane LDS entries of band_run_kernel: pieces + segments
 #define LG 64       // jump-log entries per task (global)
 #define SPILL 18    // pieces run_compact may drop from a task's list and still leave it to the pending kernel (global)
 #define TASK_WORDS (LG * 2 + SPILL * 2)   // scratch of one RESIDENT lane (global, reused block after block): jump log, spilled pieces
@@ -330,7 +336,7 @@ static size_t band_table_stride(uint32_t max_hap, uint32_t n_heads) {
 // the anchor staircase (its local score = the lower bound `cert`), polyline for hard tasks.
 // Returns 0: certified (cert == ub, so banded == full == ub); 1: hard (verts / *nv_out filled);
 // 2: capacity exceeded.
-__device__ int band_finish(const uint32_t* mylog, uint32_t lg_n, uint32_t best_id, const uint8_t* x,
+__device__ int band_finish(const uint32_t* mylog, uint32_t ls, uint32_t lg_n, uint32_t best_id, const uint8_t* x,
                            const uint8_t* yb, uint32_t m, uint32_t n, int32_t ub, uint32_t* verts_out,
                            uint32_t* nv_out, int32_t* cert_out) {
         // ---- traceback through the jump log: chain = diagonal segments (x0, y0, len), last first ----
@@ -342,9 +348,9 @@ __device__ int band_finish(const uint32_t* mylog, uint32_t lg_n, uint32_t best_i
             const int32_t cx = (int32_t)(cur >> 16), cy = (int32_t)(cur & 0xffff);
             int32_t bx = -1; uint32_t bprev = NONE_ID, bid = 0;
             for (uint32_t i = 0; i < lg_n; ++i) {
-                const uint32_t p = mylog[2 * i];
+                const uint32_t p = mylog[i * ls];
                 const int32_t px = (int32_t)(p >> 16), py = (int32_t)(p & 0xffff);
-                if (py - px == cy - cx && px <= cx && px > bx) { bx = px; bprev = mylog[2 * i + 1]; bid = p; }
+                if (py - px == cy - cx && px <= cx && px > bx) { bx = px; bprev = mylog[i * ls + 1]; bid = p; }
             }
             if (bx < 0 || n_seg == SG) { bad = true; break; }
             seg_xy[n_seg] = bid; seg_len[n_seg] = (uint32_t)(cx - bx + 1); ++n_seg;
@@ -511,7 +517,7 @@ __device__ void run_advance(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
             e_dl[e * NT + tid] = (edp << 16) | t;
             e_id[st.n_ent * NT + tid] = mid;
             e_dl[st.n_ent * NT + tid] = ((uint32_t)cand << 16) | (elen - t);
-            mylog[2 * st.lg_n] = mid; mylog[2 * st.lg_n + 1] = bid; ++st.lg_n;
+            mylog[st.lg_n * (2 * NT)] = mid; mylog[st.lg_n * (2 * NT) + 1] = bid; ++st.lg_n;
             const uint32_t ni = st.n_ent++;
             if (open_a == e) open_a = ni;                     // the growing end of an open piece is its tail
             if (open_b == e) open_b = ni;
@@ -539,7 +545,7 @@ __device__ void run_advance(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
             dp = cdp;                                          // adjacent piece: LCSk++ continuation, no log entry
         } else {
             if (st.lg_n == LG) { st.overflow = true; st.why = 3; break; }
-            mylog[2 * st.lg_n] = start_id; mylog[2 * st.lg_n + 1] = prev; ++st.lg_n;
+            mylog[st.lg_n * (2 * NT)] = start_id; mylog[st.lg_n * (2 * NT) + 1] = prev; ++st.lg_n;
         }
         e_dl[i * NT + tid] = ((uint32_t)dp << 16) | plen;
         st.i_next = i + 1;
@@ -591,7 +597,7 @@ __device__ void run_compact(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
             const uint32_t eid = sid + (uint32_t)(len - 1) * 0x10001u;
             if (v > st.best_v || (v == st.best_v && eid > st.best_id)) { st.best_v = v; st.best_id = eid; }
             // the upper bound needs every piece: park the dropped one (start, k-mers) behind the jump log
-            if (st.n_sp < SPILL) { spill[2 * st.n_sp] = sid; spill[2 * st.n_sp + 1] = (uint32_t)len; ++st.n_sp; }
+            if (st.n_sp < SPILL) { spill[st.n_sp * (2 * NT)] = sid; spill[st.n_sp * (2 * NT) + 1] = (uint32_t)len; ++st.n_sp; }
             else st.ub_ok = false;
             continue;
         }
@@ -663,7 +669,7 @@ __device__ int32_t run_ub(const uint32_t* e_id, uint32_t* e_dl, int tid, uint32_
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void band_run_kernel(
+__global__ __launch_bounds__(NT, VTX_WPE) void band_run_kernel(
     uint32_t n_tasks, uint32_t task_base,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
@@ -688,7 +694,9 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
     // Persistent workgroups: the grid is what the chip holds at once; a workgroup claims blocks of NT consecutive tasks
     // from a counter until none is left.  The per-lane global scratch (jump log, spilled pieces) therefore belongs to the
     // RESIDENT lane — a few hundred MB that stay in the caches instead of 656 B x every task of the batch.
-    uint32_t* mylog = logbuf + (size_t)(blockIdx.x * NT + tid) * TASK_WORDS;
+    // jump log + spill area, entry-major within the workgroup: entry e of lane t at (e * NT + t) * 2 words, so the
+    // entries the lanes of a wave write at about the same time share cache lines
+    uint32_t* mylog = logbuf + (size_t)blockIdx.x * NT * TASK_WORDS + tid * 2;
     const uint32_t n_blocks = (n_tasks + NT - 1) / NT;
   for (;;) {
     __syncthreads();
@@ -927,7 +935,7 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
                     if (a_idx != NONE_ID) pm_id[a_idx * NT + tid] = (pm_id[a_idx * NT + tid] & 0xffff0000u) | a_len;
                     if (b_idx != NONE_ID) pm_id[b_idx * NT + tid] = (pm_id[b_idx * NT + tid] & 0xffff0000u) | b_len;
                     run_advance<NT>(st, pm_a, pm_id, tid, pend_id, a_idx, b_idx, mylog);
-                    if (!st.overflow) run_compact<NT>(st, pm_a, pm_id, tid, xr, a_idx, b_idx, mylog + LG * 2);
+                    if (!st.overflow) run_compact<NT>(st, pm_a, pm_id, tid, xr, a_idx, b_idx, mylog + LG * (2 * NT));
                     if (st.n_ent == PS && !st.overflow) { st.overflow = true; st.why = 2; }
                     if (!st.overflow) {
                         // a breakpoint may have split an open piece and compaction renumbers: reload the register copies
@@ -975,7 +983,7 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
         uint32_t nv = 0;
         int32_t cert = 0;
         {
-            const int fr = band_finish(mylog, lg_n, best_id, x, yb, m, n, ub, verts, &nv, &cert);
+            const int fr = band_finish(mylog, 2 * NT, lg_n, best_id, x, yb, m, n, ub, verts, &nv, &cert);
             if (fr == 0) { *my_score = ub; continue; }
             if (fr == 2) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[7], 1u); continue; }
         }
@@ -991,7 +999,7 @@ __global__ __launch_bounds__(NT) void band_run_kernel(
                 prec[3 + 2 * j] = pm_id[j * NT + tid] & 0xffffu;
             }
             for (uint32_t i = 0; i < nv; ++i) prec[2 + 2 * PS + i] = verts[i];
-            for (uint32_t i = 0; i < 2 * st.n_sp; ++i) prec[2 + 2 * PS + (4 * SG + 6) + i] = mylog[LG * 2 + i];
+            for (uint32_t i = 0; i < 2 * st.n_sp; ++i) prec[2 + 2 * PS + (4 * SG + 6) + i] = mylog[(LG + (i >> 1)) * (2 * NT) + (i & 1)];
             pending_list[pi] = task;
             continue;
         }
@@ -1261,8 +1269,8 @@ __global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __rest
 
 // Resident workgroups of band_run_kernel (an upper bound: 256 CUs x the most workgroups a CU can hold for that block
 // size); the per-lane scratch is sized from it.
-extern "C" uint32_t vtxk_band_run_grid(uint32_t nt) { return 256u * (nt == 64 ? 16u : 4u); }
-extern "C" uint32_t vtxk_band_run_lanes(void) { return 256u * 16u * 64u; }     // max over both block sizes of grid x nt
+extern "C" uint32_t vtxk_band_run_grid(uint32_t nt) { return 256u * (nt == 64 ? 16u : (uint32_t)VTX_WPE); }
+extern "C" uint32_t vtxk_band_run_lanes(void) { return 256u * std::max(16u * 64u, (uint32_t)VTX_WPE * 256u); }     // max over both block sizes of grid x nt
 
 extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
                                            const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
@@ -1292,7 +1300,7 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
         const uint32_t fit = (uint32_t)((52 * 1024 - lane_bytes) / tstride) & ~1u;
         tables = std::min(want, fit);
     } else {
-        const size_t budget = (tasks_per_locus < 192 ? 78 : 40) * 1024 - 64;   // lane arrays + haplotype tables (+ 128 B static)
+        const size_t budget = (tasks_per_locus < 192 ? 78 : 160 / VTX_WPE) * 1024 - 64;   // lane arrays + haplotype tables (+ 128 B static)
         tables = (uint32_t)((budget - std::min(budget, lane_bytes)) / tstride) & ~1u;
     }
     if (tables < 2) tables = 2;
