@@ -971,32 +971,48 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     if (!sorted_store.grow(n_hits * sizeof(Hit))) return fail(VTX_E_NOMEM, "out of memory sorting the reads");
     Hit* by_locus = (Hit*)sorted_store.data();
     {
+        // thread t counts its slice over the locus range the slice touches (narrow in a sorted file); the cursors are
+        // then handed out in thread order, so within a locus the slices land in BAM order
         const size_t T = (size_t)threads;
-        std::vector<std::vector<uint32_t>> hist(T);
+        struct Slice { size_t k0, k1; uint32_t lmin, lmax; std::vector<uint64_t> cur; };
+        std::vector<Slice> sl(T);
         pool.run([&](size_t t) {
-            hist[t].assign(nloc, 0);
-            for (size_t k = n_hits * t / T, e = n_hits * (t + 1) / T; k < e; ++k) ++hist[t][all_hits[k].locus];
+            Slice& S = sl[t];
+            S.k0 = n_hits * t / T; S.k1 = n_hits * (t + 1) / T; S.lmin = UINT32_MAX; S.lmax = 0;
+            for (size_t k = S.k0; k < S.k1; ++k) { S.lmin = std::min(S.lmin, all_hits[k].locus); S.lmax = std::max(S.lmax, all_hits[k].locus); }
         });
-        for (size_t l = 0; l < nloc; ++l) {
-            uint64_t c = 0;
-            for (size_t t = 0; t < T; ++t) c += hist[t][l];
-            l_begin[l + 1] = l_begin[l] + c;
+        {
+            // an unsorted file spreads every slice over all loci: T full-width counters would not pay — one slice then
+            size_t width = 0;
+            for (const Slice& S : sl) if (S.k0 < S.k1) width += (size_t)S.lmax - S.lmin + 1;
+            if (width > (size_t)(64u << 20) && T > 1) {
+                Slice all{0, n_hits, UINT32_MAX, 0, {}};
+                for (const Slice& S : sl) if (S.k0 < S.k1) { all.lmin = std::min(all.lmin, S.lmin); all.lmax = std::max(all.lmax, S.lmax); }
+                sl.assign(T, Slice{0, 0, UINT32_MAX, 0, {}});
+                sl[0] = all;
+            }
         }
         pool.run([&](size_t t) {
-            // this slice's first slot within every locus it touches: the slices before it come first
-            std::vector<uint64_t> cursor;
-            size_t k0 = n_hits * t / T, e = n_hits * (t + 1) / T;
-            if (k0 == e) return;
-            // a sorted file keeps a slice's loci in a narrow range; any order is handled all the same
-            uint32_t lmin = UINT32_MAX, lmax = 0;
-            for (size_t k = k0; k < e; ++k) { lmin = std::min(lmin, all_hits[k].locus); lmax = std::max(lmax, all_hits[k].locus); }
-            cursor.resize((size_t)lmax - lmin + 1);
-            for (uint32_t l = lmin; l <= lmax; ++l) {
-                uint64_t c = l_begin[l];
-                for (size_t u = 0; u < t; ++u) c += hist[u][l];
-                cursor[l - lmin] = c;
-            }
-            for (size_t k = k0; k < e; ++k) by_locus[cursor[all_hits[k].locus - lmin]++] = all_hits[k];
+            Slice& S = sl[t];
+            if (S.k0 == S.k1) return;
+            S.cur.assign((size_t)S.lmax - S.lmin + 1, 0);
+            for (size_t k = S.k0; k < S.k1; ++k) ++S.cur[all_hits[k].locus - S.lmin];
+        });
+        for (const Slice& S : sl)
+            for (size_t i = 0; i < S.cur.size(); ++i) l_begin[S.lmin + i + 1] += S.cur[i];
+        for (size_t l = 0; l < nloc; ++l) l_begin[l + 1] += l_begin[l];
+        {
+            std::vector<uint64_t> taken(nloc, 0);          // slots of locus l handed to the slices before this one
+            for (Slice& S : sl)
+                for (size_t i = 0; i < S.cur.size(); ++i) {
+                    const uint64_t c = S.cur[i];
+                    S.cur[i] = l_begin[S.lmin + i] + taken[S.lmin + i];
+                    taken[S.lmin + i] += c;
+                }
+        }
+        pool.run([&](size_t t) {
+            Slice& S = sl[t];
+            for (size_t k = S.k0; k < S.k1; ++k) by_locus[S.cur[all_hits[k].locus - S.lmin]++] = all_hits[k];
         });
     }
     hit_store.release();
