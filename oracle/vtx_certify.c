@@ -124,6 +124,17 @@ static int64_t find_pieces(const uint8_t* x, int m, const uint8_t* y, int n, int
     return np;
 }
 
+int vtxo_join_same(int D);
+static int g_join_exact = 0;     /* experiment: count the mismatches between same-diagonal bases instead of their minimum */
+void vtxo_set_join_exact(int on) { g_join_exact = on; }
+static int join_same_e(const uint8_t* x, const uint8_t* y, int xb, int yb, int D) {
+    /* bases (xb+1 .. xb+D) on the diagonal of (xb, yb) */
+    if (!g_join_exact) return vtxo_join_same(D);
+    int e = 0;
+    for (int i = 1; i <= D; ++i) e += x[xb + i] != y[yb + i];
+    return imin(6 * e - D, imax(7, 13 - D));
+}
+
 int vtxo_join_same(int D) {
     const int c = 6 * ((D + 10) / 6) - D;      /* 6 ceil((D + 5) / 6) - D */
     const int g = imax(7, 13 - D);
@@ -153,7 +164,7 @@ int32_t vtxo_runs_ub_exact(const uint8_t* x, int m, const uint8_t* y, int n, int
             int cand;
             if (nd[b] == nd[a]) {
                 const int D = nx[a] - nx[b] - 1;
-                cand = D == 0 ? ub[b] : ub[b] - vtxo_join_same(D);
+                cand = D == 0 ? ub[b] : ub[b] - join_same_e(x, y, nx[b], ny[b], D);
             } else {
                 cand = ub[b] - 5 - abs(nd[a] - nd[b]);
             }
@@ -189,7 +200,7 @@ int32_t vtxo_runs_ub(const uint8_t* x, int m, const uint8_t* y, int n, int k, in
                 int J;
                 if (dq == dp) {
                     const int D = (ps[p].xs + s) - (ps[q].xs + t) - 1;
-                    J = D == 0 ? 0 : vtxo_join_same(D);
+                    J = D == 0 ? 0 : join_same_e(x, y, ps[q].xs + t, ps[q].ys + t, D);
                 } else {
                     J = 5 + abs(dp - dq);
                 }

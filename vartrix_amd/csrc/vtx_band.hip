@@ -61,8 +61,8 @@ struct band_scratch {      // per-task slices of the workspace (all sized by the
     uint32_t* mt;          // M_cap packed (x << 16 | y)
     int32_t* dps;          // M_cap
     int32_t* dpp;          // M_cap
-    int32_t* tree_v;       // n + KMER + 4
-    int32_t* tree_i;       // n + KMER + 4
+    int2* tree;            // n + KMER + 4 Fenwick nodes {v, match index}
+    int32_t* cont;         // M_cap: the match one step up the diagonal (-1: none)
     uint16_t* rmin;        // n + 2
     uint16_t* rmax;        // n + 2
 };
@@ -125,10 +125,16 @@ __device__ int band_task(const uint8_t* x, int m, const uint8_t* y, int n, band_
     if (M > m_cap) return 1;
     if (M == 0) { *cert_out = INT32_MAX; return 0; }   // Band::full_matrix
     // ---- sdpkpp ----
+    // Fenwick queries and updates request all of their nodes before looking at any (a lane is alone with its task:
+    // every dependent round trip to the slab is latency nobody hides)
     const int tn = n + KMER + 2;
-    for (int i = 0; i <= tn; ++i) { sc.tree_v[i] = INT32_MIN; sc.tree_i[i] = -1; }
+    for (int i = 0; i <= tn; ++i) sc.tree[i] = make_int2(INT32_MIN, -1);
     int32_t best_v = KMER, best_i = 0;
     uint32_t s_ptr = 0, e_ptr = 0;    // next start / end event (both in match order)
+    // continuation partner of a match = the match one step up its diagonal: the matches are sorted by (x, y), so a
+    // pointer into the previous row follows the current row (merge scan)
+    int row_x = -2;
+    uint32_t row_begin = 0, prev_hi = 0, scan = 0;
     while (e_ptr < M) {
         // next event: start (xs, ys, s+M) vs end (xe+K, ye+K, e); start ids sort after end ids
         bool take_start = false;
@@ -142,35 +148,45 @@ __device__ int band_task(const uint8_t* x, int m, const uint8_t* y, int n, band_
             const int32_t px = (int32_t)(sc.mt[p] >> 16), py = (int32_t)(sc.mt[p] & 0xffff);
             int32_t dv = KMER, dp = -1;
             int32_t bv = INT32_MIN, bi = -1;
-            for (int i = py + 1; i > 0; i -= i & (-i))
-                if (ent_gt(sc.tree_v[i], sc.tree_i[i], bv, bi)) { bv = sc.tree_v[i]; bi = sc.tree_i[i]; }
+            for (int i = py + 1; i > 0;) {
+                int2 e[6]; bool on[6];
+#pragma unroll
+                for (int l = 0; l < 6; ++l) { on[l] = i > 0; e[l] = sc.tree[on[l] ? i : 1]; i -= i & (-i); }
+#pragma unroll
+                for (int l = 0; l < 6; ++l) if (on[l] && ent_gt(e[l].x, e[l].y, bv, bi)) { bv = e[l].x; bi = e[l].y; }
+            }
             if (bi >= 0) {
                 const int32_t cand = bv - 5 - (px + py) + KMER;      // stored v = dp + (xe + ye); gap_open -5, extend -1
                 if (cand > dv || (cand == dv && bi > dp)) { dv = cand; dp = bi; }
             }
-            sc.dps[p] = dv; sc.dpp[p] = dp;
+            if (px != row_x) {
+                if (px == row_x + 1) { scan = row_begin; prev_hi = p; } else { scan = prev_hi = p; }
+                row_x = px; row_begin = p;
+            }
+            int32_t c = -1;
+            if (py > 0) {
+                while (scan < prev_hi && (int32_t)(sc.mt[scan] & 0xffff) < py - 1) ++scan;
+                if (scan < prev_hi && (int32_t)(sc.mt[scan] & 0xffff) == py - 1) c = (int32_t)scan;
+            }
+            sc.dps[p] = dv; sc.dpp[p] = dp; sc.cont[p] = c;
         } else {
             const uint32_t p = e_ptr++;
             const int32_t px = (int32_t)(sc.mt[p] >> 16), py = (int32_t)(sc.mt[p] & 0xffff);
-            if (px > 0 && py > 0) {
-                // continuation of the match one step up the diagonal: binary search (px-1, py-1)
-                const uint32_t key = ((uint32_t)(px - 1) << 16) | (uint32_t)(py - 1);
-                int32_t a = 0, b = (int32_t)p - 1, c = -1;
-                while (a <= b) {
-                    const int32_t mid = (a + b) >> 1;
-                    const uint32_t v = sc.mt[mid];
-                    if (v == key) { c = mid; break; }
-                    if (v < key) a = mid + 1; else b = mid - 1;
-                }
-                if (c >= 0) {
-                    const int32_t cand = sc.dps[c] + 1;
-                    if (cand > sc.dps[p] || (cand == sc.dps[p] && c > sc.dpp[p])) { sc.dps[p] = cand; sc.dpp[p] = c; }
-                }
+            const int32_t c = sc.cont[p];
+            int32_t dv = sc.dps[p];
+            if (c >= 0) {
+                const int32_t cand = sc.dps[c] + 1;
+                if (cand > dv || (cand == dv && c > sc.dpp[p])) { dv = cand; sc.dps[p] = cand; sc.dpp[p] = c; }
             }
-            const int32_t v = sc.dps[p] + (px + KMER) + (py + KMER);
-            for (int i = py + KMER + 1; i <= tn; i += i & (-i))
-                if (ent_gt(v, (int32_t)p, sc.tree_v[i], sc.tree_i[i])) { sc.tree_v[i] = v; sc.tree_i[i] = (int32_t)p; }
-            if (ent_gt(sc.dps[p], (int32_t)p, best_v, best_i)) { best_v = sc.dps[p]; best_i = (int32_t)p; }
+            const int32_t v = dv + (px + KMER) + (py + KMER);
+            for (int i = py + KMER + 1; i <= tn;) {
+                int2 e[6]; int at[6];
+#pragma unroll
+                for (int l = 0; l < 6; ++l) { at[l] = i <= tn ? i : 0; e[l] = sc.tree[at[l] ? at[l] : 1]; i += i & (-i); }
+#pragma unroll
+                for (int l = 0; l < 6; ++l) if (at[l] && ent_gt(v, (int32_t)p, e[l].x, e[l].y)) sc.tree[at[l]] = make_int2(v, (int32_t)p);
+            }
+            if (ent_gt(dv, (int32_t)p, best_v, best_i)) { best_v = dv; best_i = (int32_t)p; }
         }
     }
     // ---- traceback: reverse the prev links in place so the chain can be walked forward ----
@@ -263,11 +279,11 @@ __global__ __launch_bounds__(64) void band_kernel(
     sc.rmin = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
     sc.rmax = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
     o = (o + 15) & ~(size_t)15;
-    sc.tree_v = (int32_t*)(ws + o); o += ((size_t)max_hap + KMER + 4) * 4;
-    sc.tree_i = (int32_t*)(ws + o); o += ((size_t)max_hap + KMER + 4) * 4;
+    sc.tree = (int2*)(ws + o); o += ((size_t)max_hap + KMER + 4) * 8;
     sc.mt = (uint32_t*)(ws + o); o += (size_t)m_cap * 4;
     sc.dps = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
     sc.dpp = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
+    sc.cont = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
     int32_t cert = 0;
     int cA = 0, cB = 0;
     const int rc = band_task(x, m, y, n, sc, m_cap, &cert, &cA, &cB);
@@ -282,7 +298,7 @@ __global__ __launch_bounds__(64) void band_kernel(
 extern "C" size_t vtxk_band_ws_stride(uint32_t m_cap, uint32_t max_hap) {
     size_t o = HASH_SIZE * 2 + 3 * ((size_t)max_hap + 2) * 2;
     o = (o + 15) & ~(size_t)15;
-    o += 2 * ((size_t)max_hap + KMER + 4) * 4 + 3 * (size_t)m_cap * 4;
+    o += 2 * ((size_t)max_hap + KMER + 4) * 4 + 4 * (size_t)m_cap * 4;
     return (o + 63) & ~(size_t)63;
 }
 
@@ -1139,8 +1155,7 @@ __global__ __launch_bounds__(64) void slow_align_kernel(
     uint16_t* lo = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
     uint16_t* hi = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
     o = (o + 15) & ~(size_t)15;
-    sc.tree_v = (int32_t*)(ws + o); o += ((size_t)max_hap + KMER + 4) * 4;
-    sc.tree_i = (int32_t*)(ws + o); o += ((size_t)max_hap + KMER + 4) * 4;
+    sc.tree = (int2*)(ws + o); o += ((size_t)max_hap + KMER + 4) * 8;
     int32_t* Sp = (int32_t*)(ws + o); o += ((size_t)max_read + 2) * 4;
     int32_t* Dp = (int32_t*)(ws + o); o += ((size_t)max_read + 2) * 4;
     int32_t* Sc = (int32_t*)(ws + o); o += ((size_t)max_read + 2) * 4;
@@ -1148,6 +1163,7 @@ __global__ __launch_bounds__(64) void slow_align_kernel(
     sc.mt = (uint32_t*)(ws + o); o += (size_t)m_cap * 4;
     sc.dps = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
     sc.dpp = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
+    sc.cont = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
     bool whole = !banded;
     if (banded) {
         int32_t cert = 0;
@@ -1193,7 +1209,7 @@ __global__ __launch_bounds__(64) void slow_align_kernel(
 extern "C" size_t vtxk_slow_ws_stride(uint32_t m_cap, uint32_t max_hap, uint32_t max_read) {
     size_t o = HASH_SIZE * 2 + 5 * ((size_t)max_hap + 2) * 2;
     o = (o + 15) & ~(size_t)15;
-    o += 2 * ((size_t)max_hap + KMER + 4) * 4 + 4 * ((size_t)max_read + 2) * 4 + 3 * (size_t)m_cap * 4;
+    o += 2 * ((size_t)max_hap + KMER + 4) * 4 + 4 * ((size_t)max_read + 2) * 4 + 4 * (size_t)m_cap * 4;
     return (o + 63) & ~(size_t)63;
 }
 
