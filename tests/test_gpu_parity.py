@@ -315,10 +315,12 @@ def test_records_beyond_the_fast_limits_take_the_exact_slow_path():
     assert ref_s.max() > 1000          # the long read really aligned end to end
 
 
-def test_band_buffer_caps_spill_into_the_general_kernel(tmp_path):
-    """Band slots and pending records are sized for a fraction of the tasks; whatever exceeds them must take the general
-    kernel's route and still come out exact.  VTX_BAND_HARD_CAP=3 leaves three slots of each kind (separate process: the
-    hook is read from the environment)."""
+@pytest.mark.parametrize("hook", ["VTX_BAND_HARD_CAP", "VTX_BAND_SLOTS"])
+def test_band_buffer_caps_spill_into_the_general_kernel(tmp_path, hook):
+    """Polyline records, pending records and band slots are sized for a fraction of the tasks.  VTX_BAND_HARD_CAP=3 leaves
+    three of each kind: whatever exceeds them must take the general kernel's route and still come out exact.
+    VTX_BAND_SLOTS=3 leaves three band slots only: the masked DP then runs in many slices of three hard tasks
+    (separate process: the hooks are read from the environment)."""
     import subprocess
     import sys
     code = '''
@@ -333,7 +335,7 @@ with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_bar
 np.save(sys.argv[1], np.stack([r, a])); print("hard", t.hard_tasks, "overflow", t.overflow_tasks)
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "capped.npy")
-    r = subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, VTX_BAND_HARD_CAP="3"), timeout=300,
+    r = subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, **{hook: "3"}), timeout=300,
                        capture_output=True, text=True)
     got = np.load(out)
     spec = synth.SynthSpec(n_loci=150, n_barcodes=100, reads_per_locus=48, indel_frac=0.5, read_len_jitter=50, seed=15, sub_error=0.03)
@@ -341,7 +343,11 @@ np.save(sys.argv[1], np.stack([r, a])); print("hard", t.hard_tasks, "overflow", 
     oref, oalt = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=100), threads=8)
     assert np.array_equal(got[0], oref) and np.array_equal(got[1], oalt)
     overflow = int(r.stdout.split("overflow")[1])
-    assert overflow > 100, r.stdout          # the caps really were exceeded
+    hard = int(r.stdout.split("hard")[1].split()[0])
+    if hook == "VTX_BAND_HARD_CAP":
+        assert overflow > 100, r.stdout      # the caps really were exceeded
+    else:
+        assert hard > 100, r.stdout          # many slices of three
 
 
 @pytest.mark.parametrize("kw", [dict(reads_per_locus=4), dict(reads_per_locus=16), dict(reads_per_locus=8, depth_sigma=1.0),

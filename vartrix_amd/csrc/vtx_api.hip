@@ -102,7 +102,7 @@ struct vtx_ctx {
     DevBuf d_head_cell, d_head_umi, d_cell_scan, d_umi_scan, d_grp_row, d_grp_col, d_umi_cellgrp;
     DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
-    DevBuf d_band_ws, d_band_ws2, d_band, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2;   // banded flavour
+    DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2;   // banded flavour
     DevBuf d_redo, d_redo_cnt;                                               // LUT kernel: records with non-ACGTN bytes
     // raw batches (vtx_submit_raw): barcode table + preparation scratch
     DevBuf d_bc_slots, d_bc_hash, d_bc_off, d_bc_bytes;
@@ -546,7 +546,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_alt, &c->d_head_cell, &c->d_head_umi, &c->d_cell_scan, &c->d_umi_scan, &c->d_grp_row,
                       &c->d_grp_col, &c->d_umi_cellgrp, &c->d_cell_cnt, &c->d_umi_cnt, &c->d_keep, &c->d_keep_scan,
                       &c->d_scan_tmp, &c->d_o_row, &c->d_o_col, &c->d_o_alt, &c->d_o_ref, &c->d_o_unk, &c->d_o_val,
-                      &c->d_o_refval, &c->d_band_ws, &c->d_band_ws2, &c->d_band, &c->d_hard, &c->d_over, &c->d_over2, &c->d_pend, &c->d_pend_buf, &c->d_band2, &c->d_hard2,
+                      &c->d_o_refval, &c->d_band_ws, &c->d_band_ws2, &c->d_band, &c->d_poly, &c->d_hard, &c->d_over, &c->d_over2, &c->d_pend, &c->d_pend_buf, &c->d_band2, &c->d_hard2,
                       &c->d_cnt, &c->d_redo, &c->d_redo_cnt, &c->d_bc_slots, &c->d_bc_hash, &c->d_bc_off, &c->d_bc_bytes,
                       &c->d_raw, &c->d_tags, &c->d_raw_locus, &c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2,
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
@@ -921,27 +921,40 @@ int vtx_run(vtx_ctx* c) {
         if (getenv("VTX_BAND_CHUNK")) chunk_cap = std::max<uint64_t>(256, strtoull(getenv("VTX_BAND_CHUNK"), nullptr, 10));   // test hook
         const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_tasks, chunk_cap);
         const uint32_t band_stride = (c->max_hap_len + 2 + 7) & ~7u;
-        uint32_t hard_cap = (uint32_t)std::min<uint64_t>(chunk, chunk / 16 + (1u << 20));
-        uint32_t pend_cap = hard_cap;
-        if (getenv("VTX_BAND_HARD_CAP")) hard_cap = pend_cap = std::max(1u, (uint32_t)atoi(getenv("VTX_BAND_HARD_CAP")));         // test hook
+        // Hard tasks leave band_run_kernel / band_pending_kernel as compact staircase records (192 B); the masked DP expands
+        // them into band slots (2 x band_stride u16) one slice of `slots` tasks at a time.  A quarter of the tasks may be
+        // hard (noisy reads: 11 % at 3 % substitution errors) before anything spills to the general kernel's list.
+        uint32_t hard_cap = (uint32_t)std::min<uint64_t>(chunk, chunk / 4 + (1u << 20));
+        uint32_t pend_cap = (uint32_t)std::min<uint64_t>(chunk, chunk / 8 + (1u << 20));
+        uint32_t slots = (uint32_t)std::min<uint64_t>(chunk, chunk / 16 + (1u << 20));
+        if (getenv("VTX_BAND_HARD_CAP")) hard_cap = pend_cap = slots = std::max(1u, (uint32_t)atoi(getenv("VTX_BAND_HARD_CAP")));   // test hook
+        if (getenv("VTX_BAND_SLOTS")) slots = std::max(1u, (uint32_t)atoi(getenv("VTX_BAND_SLOTS")));                              // test hook
+        const uint32_t poly_stride = vtxk_band_poly_stride();
         uint32_t fast_overflow = 0;
         HIP_TRY(c, c->d_band_ws.reserve((size_t)vtxk_band_run_lanes() * vtxk_band_task_words() * sizeof(uint32_t)));   // per resident lane
         HIP_TRY(c, c->d_pend.reserve((size_t)pend_cap * sizeof(uint32_t)));
         HIP_TRY(c, c->d_pend_buf.reserve((size_t)pend_cap * vtxk_band_pend_words() * sizeof(uint32_t)));
-        HIP_TRY(c, c->d_band.reserve(((size_t)hard_cap + pend_cap) * 2 * band_stride * sizeof(uint16_t)));
+        HIP_TRY(c, c->d_poly.reserve(((size_t)hard_cap + pend_cap) * poly_stride * sizeof(uint16_t)));
+        HIP_TRY(c, c->d_band.reserve((size_t)slots * 2 * band_stride * sizeof(uint16_t)));
         HIP_TRY(c, c->d_hard.reserve(((size_t)hard_cap + pend_cap) * sizeof(uint32_t)));
         HIP_TRY(c, c->d_over.reserve((size_t)n_tasks * sizeof(uint32_t)));
         HIP_TRY(c, c->d_cnt.reserve(16 * sizeof(uint32_t)));
         uint32_t* d_cnt = c->d_cnt.as<uint32_t>();        // [0] hard, [1] overflow, [2..7] reasons; [8],[9] general kernel; [10] stats; [11] pending
         int shape = 0;
         while ((uint32_t)(kShapes[shape][0] * kShapes[shape][1]) < c->max_read_len) ++shape;
-        auto masked_dp = [&](uint32_t n_hard, uint32_t* hard, uint16_t* band, hipStream_t st) -> int {
-            HIP_TRY(c, vtxk_launch_band_expand(hard, n_hard, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                               c->d_loci.as<vtx_locus>(), band, band_stride, st));
-            HIP_TRY(c, vtxk_launch_sw_banded(kShapes[shape][0], kShapes[shape][1], n_hard, hard, c->d_records.as<vtx_record>(),
-                                             c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
-                                             c->d_hap.as<uint8_t>(), band, band_stride, c->d_ref.as<int32_t>(),
-                                             c->d_alt.as<int32_t>(), c->max_hap_len, st));
+        // src == nullptr: the band slots already hold arrays (or the full-matrix marker), one slot per task
+        auto masked_dp = [&](uint32_t n_hard, uint32_t* hard, const uint16_t* src, uint16_t* band, uint32_t n_slots, hipStream_t st) -> int {
+            for (uint32_t off = 0; off < n_hard; off += n_slots) {
+                const uint32_t cnt_s = std::min(n_slots, n_hard - off);
+                HIP_TRY(c, vtxk_launch_band_expand(hard + off, cnt_s, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                   c->d_loci.as<vtx_locus>(), src ? src + (size_t)off * poly_stride : band,
+                                                   src ? poly_stride : 2 * band_stride, band, band_stride, st));
+                HIP_TRY(c, vtxk_launch_sw_banded(kShapes[shape][0], kShapes[shape][1], cnt_s, hard + off, c->d_records.as<vtx_record>(),
+                                                 c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                                 c->d_hap.as<uint8_t>(), band, band_stride, c->d_ref.as<int32_t>(),
+                                                 c->d_alt.as<int32_t>(), c->max_hap_len, st));
+                launches += 2;
+            }
             return VTX_OK;
         };
         // The general band kernel (tasks band_run_kernel could not hold) is a handful of serial lanes: ~4.5 ms of latency
@@ -973,7 +986,7 @@ int vtx_run(vtx_ctx* c) {
             return VTX_OK;
         };
         auto fallback_start = [&](uint32_t off, uint32_t total) -> int {   // the overflow list d_over[0, total) is complete and visible
-            const uint32_t n_over = std::min(std::max(hard_cap, 1024u), total - off);   // slices (bounds d_band2)
+            const uint32_t n_over = std::min(std::max(slots, 1024u), total - off);   // slices (bounds d_band2)
             fb.off = off; fb.total = total;
             fb.n_over = n_over; fb.todo = n_over; fb.cap2 = 512 / 16; fb.tasks = c->d_over.as<uint32_t>() + off; fb.active = true;
             HIP_TRY(c, c->d_over2.reserve(2 * (size_t)n_over * sizeof(uint32_t)));
@@ -994,9 +1007,8 @@ int vtx_run(vtx_ctx* c) {
                     if (!fb.todo) break;
                     if (int rc = fallback_launch()) return rc;
                 }
-                if (int rc = masked_dp(fb.gcnt[0], c->d_hard2.as<uint32_t>(), c->d_band2.as<uint16_t>(), s2)) return rc;
+                if (int rc = masked_dp(fb.gcnt[0], c->d_hard2.as<uint32_t>(), nullptr, c->d_band2.as<uint16_t>(), std::max(fb.gcnt[0], 1u), s2)) return rc;
                 hard_total += fb.gcnt[0];
-                launches += 2;
                 if (fb.off + fb.n_over >= fb.total) break;
                 if (int rc = fallback_start(fb.off + fb.n_over, fb.total)) return rc;      // next slice (same stream: in order)
             }
@@ -1015,7 +1027,7 @@ int vtx_run(vtx_ctx* c) {
             HIP_TRY(c, vtxk_launch_band_run(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                              c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                              c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
-                                             c->d_band_ws.as<uint32_t>(), c->d_band.as<uint16_t>(), band_stride,
+                                             c->d_band_ws.as<uint32_t>(), c->d_poly.as<uint16_t>(), poly_stride / 2,
                                              c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
                                              c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt,
                                              (uint32_t)(n_tasks / std::max(c->n_loci, 1u)), s));
@@ -1037,16 +1049,16 @@ int vtx_run(vtx_ctx* c) {
             if (cnt[11]) {
                 // tasks whose piece list overflowed its LDS slots: the same certificate, from their pending records
                 HIP_TRY(c, vtxk_launch_band_pending(c->d_pend.as<uint32_t>(), cnt[11], c->d_pend_buf.as<uint32_t>(),
-                                                    c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_band.as<uint16_t>(),
-                                                    band_stride, c->d_hard.as<uint32_t>(), d_cnt, s));
+                                                    c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_poly.as<uint16_t>(),
+                                                    poly_stride / 2, c->d_hard.as<uint32_t>(), d_cnt, s));
                 HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                 HIP_TRY(c, hipStreamSynchronize(s));
                 pending_total += cnt[11];
                 ++launches;
             }
-            if (int rc = masked_dp(cnt[0], c->d_hard.as<uint32_t>(), c->d_band.as<uint16_t>(), s)) return rc;
+            if (int rc = masked_dp(cnt[0], c->d_hard.as<uint32_t>(), c->d_poly.as<uint16_t>(), c->d_band.as<uint16_t>(), slots, s)) return rc;
             hard_total += cnt[0];
-            launches += 3;
+            ++launches;
         }
         fast_overflow = cnt[1];
         if (getenv("VTX_DEBUG")) {

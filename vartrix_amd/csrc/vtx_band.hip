@@ -1232,18 +1232,22 @@ __global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __rest
                                                           const vtx_record* __restrict__ records,
                                                           const uint32_t* __restrict__ rec_locus,
                                                           const vtx_locus* __restrict__ loci,
-                                                          uint16_t* __restrict__ band, uint32_t band_stride) {
+                                                          const uint16_t* src, uint32_t src_stride,
+                                                          uint16_t* band, uint32_t band_stride) {
+    // src: one record of src_stride u16 per hard task (marker, vertex count, vertices) — the compact polyline records
+    // of band_run_kernel / band_pending_kernel, or the band slots themselves (general kernel: arrays or a marker)
     __shared__ uint32_t sv[16][4 * SG + 8];
     const int grp = threadIdx.x / 16, l = threadIdx.x % 16;
     const uint32_t h = blockIdx.x * 16 + grp;
+    const uint16_t* in = src + (size_t)(h < n_hard ? h : 0) * src_stride;
     uint16_t* lo = band + (size_t)(h < n_hard ? h : 0) * 2 * band_stride;
     uint16_t* hi = lo + band_stride;
-    const bool poly = h < n_hard && lo[0] == BAND_POLYLINE;
-    const bool whole = h < n_hard && lo[0] == BAND_FULL_MATRIX;
+    const bool poly = h < n_hard && in[0] == BAND_POLYLINE;
+    const bool whole = h < n_hard && in[0] == BAND_FULL_MATRIX;
     uint32_t nv = 0;
     if (poly) {
-        nv = lo[1];
-        const uint32_t* vin = (const uint32_t*)(lo + 2);
+        nv = in[1];
+        const uint32_t* vin = (const uint32_t*)(in + 2);
         for (uint32_t i = l; i < nv; i += 16) sv[grp][i] = vin[i];
     }
     __syncthreads();
@@ -1342,11 +1346,13 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     return hipGetLastError();
 }
 
+extern "C" uint32_t vtxk_band_poly_stride(void) { return (2 + 2 * (4 * SG + 6) + 7) & ~7u; }   // u16 per polyline record
+
 extern "C" hipError_t vtxk_launch_band_expand(const uint32_t* hard_list, uint32_t n_hard, const vtx_record* records,
-                                              const uint32_t* rec_locus, const vtx_locus* loci, uint16_t* band,
-                                              uint32_t band_stride, hipStream_t s) {
+                                              const uint32_t* rec_locus, const vtx_locus* loci, const uint16_t* src,
+                                              uint32_t src_stride, uint16_t* band, uint32_t band_stride, hipStream_t s) {
     if (!n_hard) return hipSuccess;
     hipLaunchKernelGGL(band_expand_kernel, dim3((n_hard + 15) / 16), dim3(256), 0, s, hard_list, n_hard, records,
-                       rec_locus, loci, band, band_stride);
+                       rec_locus, loci, src, src_stride, band, band_stride);
     return hipGetLastError();
 }

@@ -67,9 +67,10 @@ uint32_t vtxk_band_run_lanes(void);
 hipError_t vtxk_launch_band_pending(const uint32_t* pending, uint32_t n_pending, const uint32_t* pend_buf,
                                     int32_t* ref_score, int32_t* alt_score, uint16_t* band, uint32_t band_stride,
                                     uint32_t* hard_list, uint32_t* counters, hipStream_t s);
+uint32_t vtxk_band_poly_stride(void);
 hipError_t vtxk_launch_band_expand(const uint32_t* hard_list, uint32_t n_hard, const vtx_record* records,
-                                   const uint32_t* rec_locus, const vtx_locus* loci, uint16_t* band,
-                                   uint32_t band_stride, hipStream_t s);
+                                   const uint32_t* rec_locus, const vtx_locus* loci, const uint16_t* src,
+                                   uint32_t src_stride, uint16_t* band, uint32_t band_stride, hipStream_t s);
 /* Records the fast kernels hold: reads up to VTX_FAST_READ_LEN bases (16 rows x 64 lanes), haplotypes up to
  * VTX_FAST_HAP_LEN (LDS tables).  Longer ones take slow_align_kernel (exact, one lane per alignment, global scratch). */
 #define VTX_FAST_READ_LEN 1024u
