@@ -91,6 +91,14 @@ def cpu_baseline(batch, cfg, target_seconds=12.0):
         cores = len(os.sched_getaffinity(0))      # the cores this process may run on (a container may expose fewer
     except AttributeError:                         # than os.cpu_count() reports)
         cores = os.cpu_count() or 1
+    quota = None                                   # ... and a cgroup CPU quota fewer still: 256 threads on a 16-CPU quota
+    try:                                           # are throttled to a quarter of the 16-thread rate (tools/cpu_probe.py)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+            cores = min(cores, quota)
+    except (OSError, ValueError):
+        pass
     per_locus = max(batch.n_records / max(batch.n_loci, 1), 1)
     one = batch.slice_loci(0, min(batch.n_loci, 4))
     t0 = time.perf_counter()
@@ -114,7 +122,7 @@ def cpu_baseline(batch, cfg, target_seconds=12.0):
     oracle.batch_reduce(sample, cfg, ref, alt)
     dt = time.perf_counter() - t0
     value = 2 * sample.n_records / dt
-    return {"value": value, "unit": "read-alignments/s", "cores": cores, "os_cpu_count": os.cpu_count(), "kind": "port",
+    return {"value": value, "unit": "read-alignments/s", "cores": cores, "os_cpu_count": os.cpu_count(), "cgroup_cpu_quota": quota, "kind": "port",
             "per_thread": value / cores, "one_thread": {"value": rate1, "sample": "first %d loci, %.1f s" % (s1.n_loci, dt1)},
             "sample": "first %d loci (%d scored reads, %.1f s) of the same batch, %s aligner, %d OpenMP threads, static "
                       "chunks of loci per thread" % (sample.n_loci, sample.n_records, dt,
