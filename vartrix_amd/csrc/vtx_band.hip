@@ -1064,27 +1064,40 @@ __global__ __launch_bounds__(256) void band_pending_kernel(
     const int32_t xp = (int32_t)(id >> 16), yp = (int32_t)(id & 0xffff);
     int32_t g = 0;
     s_id[grp][l] = id;
-    bool moving = true;
-    for (int round = 0; round < 40 && moving; ++round) {
-        s_lg[grp][l] = ((uint32_t)len << 16) | (uint32_t)g;
-        __builtin_amdgcn_wave_barrier();
-        int32_t gn = g;
-        if ((uint32_t)l < n) {
-            for (uint32_t q = 0; q < n; ++q) {
-                if (q == (uint32_t)l) continue;
-                const uint32_t idq = s_id[grp][q], lgq = s_lg[grp][q];
-                const int32_t xq = (int32_t)(idq >> 16), yq = (int32_t)(idq & 0xffff);
-                const int32_t lq = (int32_t)(lgq >> 16), gq = (int32_t)(lgq & 0xffff);
-                int32_t sdx = max(xq + lq - xp, yq + lq - yp);
-                sdx = min(max(sdx, 0), len - 1);
-                const int32_t t = min(lq - 1, min(xp - xq, yp - yq) + sdx - 1);
-                if (t < 0) continue;
+    s_lg[grp][l] = (uint32_t)len;
+    __builtin_amdgcn_wave_barrier();
+    // The geometry of an ordered pair (q -> this piece) never changes between rounds, only G[q] does: the pair's
+    // constant  t + 1 - J - s  is computed once (NO_EDGE: q cannot precede this piece), a round is then one add and one
+    // max per predecessor.
+    constexpr int32_t NO_EDGE = -30000;
+    int32_t cq[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        int32_t c = NO_EDGE;
+        if ((uint32_t)l < n && (uint32_t)q < n && q != l) {
+            const uint32_t idq = s_id[grp][q];
+            const int32_t lq = (int32_t)s_lg[grp][q];
+            const int32_t xq = (int32_t)(idq >> 16), yq = (int32_t)(idq & 0xffff);
+            int32_t sdx = max(xq + lq - xp, yq + lq - yp);
+            sdx = min(max(sdx, 0), len - 1);
+            const int32_t t = min(lq - 1, min(xp - xq, yp - yq) + sdx - 1);
+            if (t >= 0) {
                 const int32_t dd = (yp - xp) - (yq - xq);
                 int32_t J = 5 + abs(dd);
                 if (dd == 0) { const int32_t D = xp + sdx - xq - t - 1; J = D == 0 ? 0 : ub_join_same(D); }
-                gn = max(gn, t + 1 + gq - J - sdx);
+                c = t + 1 - J - sdx;
             }
         }
+        cq[q] = c;
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool moving = true;
+    for (int round = 0; round < 40 && moving; ++round) {
+        s_lg[grp][l] = (uint32_t)g;
+        __builtin_amdgcn_wave_barrier();
+        int32_t gn = g;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) gn = max(gn, cq[q] + (int32_t)s_lg[grp][q]);
         moving = __any(gn != g);
         g = gn;
         __builtin_amdgcn_wave_barrier();
