@@ -350,6 +350,36 @@ np.save(sys.argv[1], np.stack([r, a])); print("hard", t.hard_tasks, "overflow", 
         assert hard > 100, r.stdout          # many slices of three
 
 
+@pytest.mark.parametrize("reads_per_locus", [5, 40])
+def test_lds_table_variants_at_shallow_depth(tmp_path, reads_per_locus):
+    """Below ~208 tasks per locus the k-mer tables live in global memory (band_tables_kernel); the LDS-table variants of
+    band_run_kernel (one-wavefront workgroups below 64 tasks per locus, 256-lane workgroups above) remain for batches
+    whose tables would not fit the buffer.  VTX_BAND_GT_MAX_TPL=0 forces them (separate process: read from the
+    environment); both must equal the oracle."""
+    import subprocess
+    import sys
+    code = '''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from vartrix_amd import lib, synth
+from vartrix_amd.abi import default_config
+spec = synth.SynthSpec(n_loci=400, n_barcodes=100, reads_per_locus=int(sys.argv[2]), indel_frac=0.3, read_len_jitter=40, seed=33, sub_error=0.02)
+b = synth.make_batch(spec)
+with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=100)) as ctx:
+    ctx.submit(b); ctx.run(); r, a = ctx.fetch_scores()
+np.save(sys.argv[1], np.stack([r, a]))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = synth.SynthSpec(n_loci=400, n_barcodes=100, reads_per_locus=reads_per_locus, indel_frac=0.3, read_len_jitter=40, seed=33, sub_error=0.02)
+    batch = synth.make_batch(spec)
+    oref, oalt = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=100), threads=8)
+    for knob in ("0", "100000"):
+        out = str(tmp_path / ("t%s.npy" % knob))
+        subprocess.run([sys.executable, "-c", code, out, str(reads_per_locus)], check=True,
+                       env=dict(os.environ, VTX_BAND_GT_MAX_TPL=knob), timeout=300, capture_output=True, text=True)
+        got = np.load(out)
+        assert np.array_equal(got[0], oref) and np.array_equal(got[1], oalt), knob
+
+
 @pytest.mark.parametrize("kw", [dict(reads_per_locus=4), dict(reads_per_locus=16), dict(reads_per_locus=8, depth_sigma=1.0),
                                 dict(reads_per_locus=3, indel_frac=0.4, read_len_jitter=60), dict(reads_per_locus=70)])
 def test_shallow_and_mixed_depth_loci(kw):

@@ -102,7 +102,7 @@ struct vtx_ctx {
     DevBuf d_head_cell, d_head_umi, d_cell_scan, d_umi_scan, d_grp_row, d_grp_col, d_umi_cellgrp;
     DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
-    DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2;   // banded flavour
+    DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2;   // banded flavour
     DevBuf d_redo, d_redo_cnt;                                               // LUT kernel: records with non-ACGTN bytes
     // raw batches (vtx_submit_raw): barcode table + preparation scratch
     DevBuf d_bc_slots, d_bc_hash, d_bc_off, d_bc_bytes;
@@ -546,7 +546,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_alt, &c->d_head_cell, &c->d_head_umi, &c->d_cell_scan, &c->d_umi_scan, &c->d_grp_row,
                       &c->d_grp_col, &c->d_umi_cellgrp, &c->d_cell_cnt, &c->d_umi_cnt, &c->d_keep, &c->d_keep_scan,
                       &c->d_scan_tmp, &c->d_o_row, &c->d_o_col, &c->d_o_alt, &c->d_o_ref, &c->d_o_unk, &c->d_o_val,
-                      &c->d_o_refval, &c->d_band_ws, &c->d_band_ws2, &c->d_band, &c->d_poly, &c->d_hard, &c->d_over, &c->d_over2, &c->d_pend, &c->d_pend_buf, &c->d_band2, &c->d_hard2,
+                      &c->d_o_refval, &c->d_band_ws, &c->d_band_ws2, &c->d_band, &c->d_poly, &c->d_gtables, &c->d_hard, &c->d_over, &c->d_over2, &c->d_pend, &c->d_pend_buf, &c->d_band2, &c->d_hard2,
                       &c->d_cnt, &c->d_redo, &c->d_redo_cnt, &c->d_bc_slots, &c->d_bc_hash, &c->d_bc_off, &c->d_bc_bytes,
                       &c->d_raw, &c->d_tags, &c->d_raw_locus, &c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2,
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
@@ -932,6 +932,10 @@ int vtx_run(vtx_ctx* c) {
         const uint32_t poly_stride = vtxk_band_poly_stride();
         uint32_t fast_overflow = 0;
         HIP_TRY(c, c->d_band_ws.reserve((size_t)vtxk_band_run_lanes() * vtxk_band_task_words() * sizeof(uint32_t)));   // per resident lane
+        // shallow loci: the k-mer tables of every locus in global memory, built once per run (0 bytes: tables in LDS)
+        const uint32_t tasks_per_locus = (uint32_t)(n_tasks / std::max(c->n_loci, 1u));
+        const size_t gt_bytes = vtxk_band_gtables_bytes(c->n_loci, c->max_hap_len, tasks_per_locus);
+        if (gt_bytes) HIP_TRY(c, c->d_gtables.reserve(gt_bytes));
         HIP_TRY(c, c->d_pend.reserve((size_t)pend_cap * sizeof(uint32_t)));
         HIP_TRY(c, c->d_pend_buf.reserve((size_t)pend_cap * vtxk_band_pend_words() * sizeof(uint32_t)));
         HIP_TRY(c, c->d_poly.reserve(((size_t)hard_cap + pend_cap) * poly_stride * sizeof(uint16_t)));
@@ -1030,7 +1034,7 @@ int vtx_run(vtx_ctx* c) {
                                              c->d_band_ws.as<uint32_t>(), c->d_poly.as<uint16_t>(), poly_stride / 2,
                                              c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
                                              c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt,
-                                             (uint32_t)(n_tasks / std::max(c->n_loci, 1u)), s));
+                                             tasks_per_locus, c->n_loci, c->d_gtables.as<uint8_t>(), gt_bytes, s));
             HIP_TRY(c, hipEventRecord(c->ev[5], s));
             HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));

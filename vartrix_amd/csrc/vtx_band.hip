@@ -684,75 +684,15 @@ __device__ int32_t run_ub(const uint32_t* e_id, uint32_t* e_dl, int tid, uint32_
     return ub;
 }
 
+// Builds the k-mer tables of loci [lbase, lbase + n_tab / 2) in LDS (layout: band_table_stride); called by every
+// thread of the workgroup; the tables are complete after the last barrier inside.
 template <int NT>
-__global__ __launch_bounds__(NT, VTX_WPE) void band_run_kernel(
-    uint32_t n_tasks, uint32_t task_base,
-    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
-    const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
-    uint32_t max_hap, uint32_t tables_per_pass, uint32_t table_stride,
-    int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
-    uint32_t* __restrict__ logbuf, uint16_t* __restrict__ band, uint32_t band_stride,
-    uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ pending_list,
-    uint32_t* __restrict__ pend_buf, uint32_t hard_cap, uint32_t pend_cap,
-    uint32_t* __restrict__ counters, uint32_t ablate, uint32_t n_heads) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    __shared__ uint32_t s_hibyte, s_blk;              // bit t: the haplotype of table t holds a byte >= 0x80 (no continuation shortcut)
-    const int tid = threadIdx.x;
-    // per-lane LDS arrays, element i of lane tid at [i * NT + tid]
-    // staircase of ended matches, stored as RUNS: elements (ye0 + t, V0 + 3t, id0 + t*(1,1)), t < len
-    // (a continued k-mer adds +1 to ye and, with dp + 1, +3 to V = dp + xe + ye)
-    uint32_t* pm_a = smem;                     // parked segments: id0 = x0 << 16 | y0
-    uint32_t* pm_id = pm_a + PS * NT;         //                  dp0 << 16 | len
-    uint8_t* tables = (uint8_t*)(pm_id + PS * NT);
-#define PM_A(i) pm_a[(i) * NT + tid]
-#define PM_ID(i) pm_id[(i) * NT + tid]
-
-    // Persistent workgroups: the grid is what the chip holds at once; a workgroup claims blocks of NT consecutive tasks
-    // from a counter until none is left.  The per-lane global scratch (jump log, spilled pieces) therefore belongs to the
-    // RESIDENT lane — a few hundred MB that stay in the caches instead of 656 B x every task of the batch.
-    // jump log + spill area, entry-major within the workgroup: entry e of lane t at (e * NT + t) * 2 words, so the
-    // entries the lanes of a wave write at about the same time share cache lines
-    uint32_t* mylog = logbuf + (size_t)blockIdx.x * NT * TASK_WORDS + tid * 2;
-    const uint32_t n_blocks = (n_tasks + NT - 1) / NT;
-  for (;;) {
-    __syncthreads();
-    if (tid == 0) s_blk = atomicAdd(&counters[12], 1u);
-    __syncthreads();
-    const uint32_t blk = s_blk;
-    if (blk >= n_blocks) break;
-    const uint32_t slot = blk * NT + tid;
-    const bool have = slot < n_tasks;
-    const uint32_t task = task_base + slot;
-    uint32_t rid = 0, hap = 0, my_locus = 0, m = 0, n = 0;
-    const uint8_t* x = nullptr;
-    if (have) {
-        rid = task >> 1; hap = task & 1;
-        const vtx_record rec = records[rid];
-        my_locus = rec_locus[rid];
-        m = rec.read_len;
-        x = read_arena + rec.read_off;
-        n = hap ? loci[my_locus].alt_len : loci[my_locus].ref_len;
-    }
-    // locus range of this workgroup (tasks are in record order, records in locus order)
-    const uint32_t first_task = task_base + blk * NT;
-    const uint32_t last_task = min(task_base + n_tasks - 1, first_task + NT - 1);
-    const uint32_t l_first = rec_locus[first_task >> 1], l_last = rec_locus[last_task >> 1];
-    const uint32_t loci_per_pass = tables_per_pass / 2;
-    int32_t* my_score = (hap ? alt_score : ref_score) + rid;
-    bool done = !have;
-    if (have && (m == 0 || n == 0)) { *my_score = 0; done = true; }     // empty read / haplotype: score 0
-    // reads / haplotypes beyond what these tables and lists hold are scored by slow_align_kernel (the host lists them)
-    if (have && (m > VTX_FAST_READ_LEN || max(loci[my_locus].ref_len, loci[my_locus].alt_len) > max_hap)) done = true;
-    // a task without any k-mer match has the whole matrix in band (Band::full_matrix): hard list, marker slot
-    // (hard slots beyond the capacity of the band buffer go to the general kernel's list, which makes them hard in slices)
-#define PUSH_FULL_MATRIX() { const uint32_t h_ = atomicAdd(&counters[0], 1u);                                    \
-                             if (h_ < hard_cap) { hard_list[h_] = task; band[(size_t)h_ * 2 * band_stride] = BAND_FULL_MATRIX; } \
-                             else overflow_list[atomicAdd(&counters[1], 1u)] = task; }
-
-    for (uint32_t lbase = l_first; lbase <= l_last; lbase += loci_per_pass) {
+__device__ __forceinline__ void build_tables(uint8_t* tables, uint32_t n_tab, uint32_t lbase,
+                                             const vtx_locus* __restrict__ loci, const uint8_t* __restrict__ hap_arena,
+                                             uint32_t max_hap, uint32_t table_stride, uint32_t n_heads, int tid,
+                                             uint32_t& s_hibyte) {
         __syncthreads();
         // ---- build the haplotype tables of loci [lbase, lbase + loci_per_pass) ----
-        const uint32_t n_tab = min(loci_per_pass, l_last - lbase + 1) * 2;
         for (uint32_t t = 0; t < n_tab; ++t) {
             const vtx_locus loc = loci[lbase + (t >> 1)];
             const uint32_t hn = max(loc.ref_len, loc.alt_len) > max_hap ? 0u : ((t & 1) ? loc.alt_len : loc.ref_len);   // (a locus of the slow list: no table)
@@ -817,10 +757,99 @@ __global__ __launch_bounds__(NT, VTX_WPE) void band_run_kernel(
             }
         }
         __syncthreads();
+}
+
+// One workgroup (one wavefront) per locus: both tables in LDS, then copied to gtables[locus * 2 * table_stride].
+__global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __restrict__ loci, uint32_t n_loci,
+                                                         const uint8_t* __restrict__ hap_arena, uint32_t max_hap,
+                                                         uint32_t table_stride, uint32_t n_heads, uint8_t* __restrict__ gtables) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ uint32_t s_hibyte;
+    const int tid = threadIdx.x;
+    for (uint32_t l = blockIdx.x; l < n_loci; l += gridDim.x) {
+        build_tables<64>((uint8_t*)smem, 2, l, loci, hap_arena, max_hap, table_stride, n_heads, tid, s_hibyte);
+        const uint4* src = (const uint4*)smem;
+        uint4* dst = (uint4*)(gtables + (size_t)l * 2 * table_stride);
+        for (uint32_t i = tid; i < 2 * table_stride / 16; i += 64) dst[i] = src[i];
+    }
+}
+
+template <int NT, bool GT>
+__global__ __launch_bounds__(NT, VTX_WPE) void band_run_kernel(
+    uint32_t n_tasks, uint32_t task_base,
+    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
+    const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
+    uint32_t max_hap, uint32_t tables_per_pass, uint32_t table_stride,
+    int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
+    uint32_t* __restrict__ logbuf, uint16_t* __restrict__ band, uint32_t band_stride,
+    uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ pending_list,
+    uint32_t* __restrict__ pend_buf, uint32_t hard_cap, uint32_t pend_cap,
+    uint32_t* __restrict__ counters, uint32_t ablate, uint32_t n_heads, const uint8_t* __restrict__ gtables) {
+    // GT: the tables of every locus were built by band_tables_kernel in global memory (shallow loci: a wavefront's 64
+    // tasks span many loci, tables in LDS cost the occupancy); !GT: built here, per block, in LDS
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ uint32_t s_hibyte, s_blk;              // bit t: the haplotype of table t holds a byte >= 0x80 (no continuation shortcut)
+    const int tid = threadIdx.x;
+    // per-lane LDS arrays, element i of lane tid at [i * NT + tid]
+    // staircase of ended matches, stored as RUNS: elements (ye0 + t, V0 + 3t, id0 + t*(1,1)), t < len
+    // (a continued k-mer adds +1 to ye and, with dp + 1, +3 to V = dp + xe + ye)
+    uint32_t* pm_a = smem;                     // parked segments: id0 = x0 << 16 | y0
+    uint32_t* pm_id = pm_a + PS * NT;         //                  dp0 << 16 | len
+    uint8_t* tables = (uint8_t*)(pm_id + PS * NT);
+#define PM_A(i) pm_a[(i) * NT + tid]
+#define PM_ID(i) pm_id[(i) * NT + tid]
+
+    // Persistent workgroups: the grid is what the chip holds at once; a workgroup claims blocks of NT consecutive tasks
+    // from a counter until none is left.  The per-lane global scratch (jump log, spilled pieces) therefore belongs to the
+    // RESIDENT lane — a few hundred MB that stay in the caches instead of 656 B x every task of the batch.
+    // jump log + spill area, entry-major within the workgroup: entry e of lane t at (e * NT + t) * 2 words, so the
+    // entries the lanes of a wave write at about the same time share cache lines
+    uint32_t* mylog = logbuf + (size_t)blockIdx.x * NT * TASK_WORDS + tid * 2;
+    const uint32_t n_blocks = (n_tasks + NT - 1) / NT;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_blk = atomicAdd(&counters[12], 1u);
+    __syncthreads();
+    const uint32_t blk = s_blk;
+    if (blk >= n_blocks) break;
+    const uint32_t slot = blk * NT + tid;
+    const bool have = slot < n_tasks;
+    const uint32_t task = task_base + slot;
+    uint32_t rid = 0, hap = 0, my_locus = 0, m = 0, n = 0;
+    const uint8_t* x = nullptr;
+    if (have) {
+        rid = task >> 1; hap = task & 1;
+        const vtx_record rec = records[rid];
+        my_locus = rec_locus[rid];
+        m = rec.read_len;
+        x = read_arena + rec.read_off;
+        n = hap ? loci[my_locus].alt_len : loci[my_locus].ref_len;
+    }
+    // locus range of this workgroup (tasks are in record order, records in locus order)
+    const uint32_t first_task = task_base + blk * NT;
+    const uint32_t last_task = min(task_base + n_tasks - 1, first_task + NT - 1);
+    const uint32_t l_first = rec_locus[first_task >> 1], l_last = rec_locus[last_task >> 1];
+    const uint32_t loci_per_pass = GT ? 0x40000000u : tables_per_pass / 2;
+    int32_t* my_score = (hap ? alt_score : ref_score) + rid;
+    bool done = !have;
+    if (have && (m == 0 || n == 0)) { *my_score = 0; done = true; }     // empty read / haplotype: score 0
+    // reads / haplotypes beyond what these tables and lists hold are scored by slow_align_kernel (the host lists them)
+    if (have && (m > VTX_FAST_READ_LEN || max(loci[my_locus].ref_len, loci[my_locus].alt_len) > max_hap)) done = true;
+    // a task without any k-mer match has the whole matrix in band (Band::full_matrix): hard list, marker slot
+    // (hard slots beyond the capacity of the band buffer go to the general kernel's list, which makes them hard in slices)
+#define PUSH_FULL_MATRIX() { const uint32_t h_ = atomicAdd(&counters[0], 1u);                                    \
+                             if (h_ < hard_cap) { hard_list[h_] = task; band[(size_t)h_ * 2 * band_stride] = BAND_FULL_MATRIX; } \
+                             else overflow_list[atomicAdd(&counters[1], 1u)] = task; }
+
+    for (uint32_t lbase = l_first; lbase <= l_last; lbase += loci_per_pass) {
+        const uint32_t n_tab = GT ? 0u : min(loci_per_pass, l_last - lbase + 1) * 2;
+        if constexpr (!GT) build_tables<NT>(tables, n_tab, lbase, loci, hap_arena, max_hap, table_stride, n_heads, tid, s_hibyte);
         if (done || my_locus < lbase || my_locus >= lbase + loci_per_pass) continue;
         done = true;
         // ---- this lane's table ----
-        const uint8_t* tb = tables + (size_t)((my_locus - lbase) * 2 + hap) * table_stride;
+        const uint8_t* tb;
+        if constexpr (GT) tb = gtables + ((size_t)my_locus * 2 + hap) * table_stride;
+        else tb = tables + (size_t)((my_locus - lbase) * 2 + hap) * table_stride;
         const uint2* ent = TB_ENT(tb);
         const uint16_t* head = TB_HEAD(tb);
         const uint8_t* yb = TB_BYTES(tb);
@@ -1302,6 +1331,19 @@ __global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __rest
 
 // Resident workgroups of band_run_kernel (an upper bound: 256 CUs x the most workgroups a CU can hold for that block
 // size); the per-lane scratch is sized from it.
+// tables in global memory below this many tasks per locus (experiment knob VTX_BAND_GT_MAX_TPL; 0: never)
+static uint32_t gt_max_tpl() {
+    static const uint32_t v = getenv("VTX_BAND_GT_MAX_TPL") ? (uint32_t)atoi(getenv("VTX_BAND_GT_MAX_TPL")) : 208u;
+    return v;
+}
+
+// bytes of the global table buffer vtxk_launch_band_run wants for this shape of data (0: tables live in LDS)
+extern "C" size_t vtxk_band_gtables_bytes(uint32_t n_loci, uint32_t max_hap, uint32_t tasks_per_locus) {
+    if (tasks_per_locus >= gt_max_tpl()) return 0;
+    const size_t need = (size_t)n_loci * 2 * band_table_stride(max_hap, tasks_per_locus < 48 ? 256 : 512);
+    return need <= ((size_t)4 << 30) ? need : 0;
+}
+
 extern "C" uint32_t vtxk_band_run_grid(uint32_t nt) { return 256u * (nt == 64 ? 16u : (uint32_t)VTX_WPE); }
 extern "C" uint32_t vtxk_band_run_lanes(void) { return 256u * std::max(16u * 64u, (uint32_t)VTX_WPE * 256u); }     // max over both block sizes of grid x nt
 
@@ -1311,7 +1353,8 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
                                            int32_t* alt_score, uint32_t* logbuf, uint16_t* band,
                                            uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
                                            uint32_t* pending_list, uint32_t* pend_buf, uint32_t hard_cap, uint32_t pend_cap,
-                                           uint32_t* counters, uint32_t tasks_per_locus, hipStream_t s) {
+                                           uint32_t* counters, uint32_t tasks_per_locus, uint32_t n_loci, uint8_t* gtables,
+                                           size_t gtables_bytes, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
     // Deep data (>= 64 tasks per locus): 256-task workgroups.  A workgroup processes its loci in passes of `tables / 2`
     // loci (the k-mer tables live in LDS); in a pass only the lanes of those loci work.  512-entry head arrays: two loci
@@ -1326,8 +1369,14 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     uint32_t n_heads = tasks_per_locus < 48 ? 256 : 512;
     if (getenv("VTX_BAND_HEADS")) n_heads = (uint32_t)atoi(getenv("VTX_BAND_HEADS"));   // experiment knob (power of two)
     const size_t tstride = band_table_stride(max_hap, n_heads);
+    // Shallow data with a table buffer from the caller: every locus' tables are built once, in global memory
+    // (band_tables_kernel), and the wavefronts keep only their lane arrays in LDS — 16 wavefronts per CU instead of 3,
+    // no table passes with idle lanes.
+    const bool global_tables = tasks_per_locus < gt_max_tpl() && gtables && (size_t)n_loci * 2 * tstride <= gtables_bytes;
     uint32_t tables;
-    if (wave_wg) {
+    if (global_tables) {
+        tables = 2;
+    } else if (wave_wg) {
         // loci of 64 consecutive tasks (+1 for the straddling locus), at most what 52 KiB hold (3 workgroups per CU)
         const uint32_t want = 2 * (64 / std::max(tasks_per_locus, 1u) + 2);
         const uint32_t fit = (uint32_t)((52 * 1024 - lane_bytes) / tstride) & ~1u;
@@ -1338,23 +1387,29 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     }
     if (tables < 2) tables = 2;
     if (tables > 32) tables = 32;
-    const size_t shmem = lane_bytes + (size_t)tables * tstride;
+    const size_t shmem = lane_bytes + (global_tables ? 0 : (size_t)tables * tstride);
     if (shmem > 160 * 1024 - 256) return hipErrorInvalidValue;
+    if (global_tables && task_base == 0) {       // (a chunked run builds them with its first chunk)
+        hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(n_loci, 256u * 16u)), dim3(64), 2 * tstride, s, loci, n_loci,
+                           hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
+    }
     const uint32_t ablate = (uint32_t)(getenv("VTX_BAND_ABLATE") ? atoi(getenv("VTX_BAND_ABLATE")) : 0);
-#define LAUNCH_RUN(NTV)                                                                                              \
+#define LAUNCH_RUN(NTV, GTV)                                                                                         \
     {                                                                                                                \
         if (shmem > 48 * 1024) {                                                                                     \
-            hipError_t e = hipFuncSetAttribute((const void*)band_run_kernel<NTV>,                                    \
+            hipError_t e = hipFuncSetAttribute((const void*)band_run_kernel<NTV, GTV>,                               \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);              \
             if (e != hipSuccess) return e;                                                                           \
         }                                                                                                            \
-        hipLaunchKernelGGL(band_run_kernel<NTV>, dim3(std::min((n_tasks + NTV - 1) / NTV, vtxk_band_run_grid(NTV))),  \
+        hipLaunchKernelGGL((band_run_kernel<NTV, GTV>), dim3(std::min((n_tasks + NTV - 1) / NTV, vtxk_band_run_grid(NTV))), \
                            dim3(NTV), shmem, s, n_tasks,                                                             \
                            task_base, records, rec_locus, loci, read_arena, hap_arena, max_hap, tables,              \
                            (uint32_t)tstride, ref_score, alt_score, logbuf, band, band_stride, hard_list,            \
-                           overflow_list, pending_list, pend_buf, hard_cap, pend_cap, counters, ablate, n_heads);    \
+                           overflow_list, pending_list, pend_buf, hard_cap, pend_cap, counters, ablate, n_heads,     \
+                           (const uint8_t*)gtables);                                                                 \
     }
-    if (wave_wg) LAUNCH_RUN(64) else LAUNCH_RUN(256)
+    if (global_tables && wave_wg) LAUNCH_RUN(64, true) else if (global_tables) LAUNCH_RUN(256, true)
+    else if (wave_wg) LAUNCH_RUN(64, false) else LAUNCH_RUN(256, false)
 #undef LAUNCH_RUN
     return hipGetLastError();
 }
