@@ -972,19 +972,25 @@ int vtx_run(vtx_ctx* c) {
         }
         hipStream_t s2 = c->stream2;
         struct { uint32_t n_over = 0, cap2 = 0, todo = 0, off = 0, total = 0; const uint32_t* tasks = nullptr; bool active = false; uint32_t gcnt[2] = {0, 0}; } fb;
+        // A few overflow tasks (shallow data: some hundreds per run) first try the in-LDS variant of the general kernel
+        // with a slab for kLdsMatches k-mer matches: their ~2 ms of serial HBM latency were a third of a shallow step.
+        const uint32_t kLdsMatches = 512;
+        static const uint32_t kLdsTasks = getenv("VTX_BAND_LDS_TASKS") ? (uint32_t)atoi(getenv("VTX_BAND_LDS_TASKS")) : 4096u;   // experiment knob
         auto fallback_launch = [&]() -> int {
             const uint64_t worst = (uint64_t)c->max_read_len * c->max_hap_len;
             if (fb.cap2 >= worst && fb.cap2 >= 512) return fail(c, VTX_E_STATE, "vtx_run: band kernel overflow with a worst-case slab");
-            fb.cap2 = (uint32_t)std::max<uint64_t>(std::min<uint64_t>((uint64_t)fb.cap2 * 16, worst), 512);
+            const bool in_lds = fb.cap2 < 512 && fb.todo <= kLdsTasks && !getenv("VTX_BAND_NO_LDS_FALLBACK") &&
+                                vtxk_band_lds_stride(kLdsMatches, c->max_hap_len, c->max_read_len) <= 160 * 1024 - 512;
+            fb.cap2 = in_lds ? kLdsMatches : (uint32_t)std::max<uint64_t>(std::min<uint64_t>((uint64_t)fb.cap2 * 16, worst), 512);
             const size_t stride2 = vtxk_band_ws_stride(fb.cap2, c->max_hap_len);
-            HIP_TRY(c, c->d_band_ws2.reserve((size_t)fb.todo * stride2));
+            if (!in_lds) HIP_TRY(c, c->d_band_ws2.reserve((size_t)fb.todo * stride2));
             HIP_TRY(c, hipMemsetAsync(d_cnt + 9, 0, sizeof(uint32_t), s2));
             uint32_t* other = c->d_over2.as<uint32_t>() + ((fb.tasks == c->d_over2.as<uint32_t>()) ? fb.n_over : 0);
             HIP_TRY(c, vtxk_launch_band(fb.tasks, fb.todo, 0, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                         c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                         c->d_band_ws2.as<uint8_t>(), stride2, fb.cap2, c->max_hap_len, c->d_ref.as<int32_t>(),
                                         c->d_alt.as<int32_t>(), c->d_band2.as<uint16_t>(), band_stride, c->d_hard2.as<uint32_t>(),
-                                        other, d_cnt + 8, s2));
+                                        other, d_cnt + 8, in_lds ? 1 : 0, c->max_read_len, s2));
             HIP_TRY(c, hipMemcpyAsync(c->h_pin, d_cnt + 8, sizeof fb.gcnt, hipMemcpyDeviceToHost, s2));   // pinned: does not block
             ++launches;
             return VTX_OK;

@@ -253,6 +253,11 @@ __device__ void band_ranges(const band_scratch& sc, int cA, int cB, int m, int n
 // One lane per task (task = 2 * record + hap).  tasks == nullptr: task = task_base + slot.
 // Every task is appended to hard_list with its ranges in band[] (or the full-matrix marker) and gets its
 // exact score from sw_banded_kernel.  counters[0] = hard tasks, counters[1] = capacity overflows.
+// IN_LDS: the task's slab (and a copy of its read and haplotype) lives in LDS, `lds_tasks` tasks per workgroup (one
+// lane each, the other lanes idle): a serial lane pays ~30 ns per dependent access instead of a round trip to HBM —
+// for a FEW tasks (shallow data: a few hundred overflows per run, whose 2 ms of latency were a third of the step);
+// many tasks keep the global slabs, where every lane of the chip works.
+template <bool IN_LDS>
 __global__ __launch_bounds__(64) void band_kernel(
     const uint32_t* __restrict__ tasks, uint32_t n_tasks, uint32_t task_base,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
@@ -260,8 +265,15 @@ __global__ __launch_bounds__(64) void band_kernel(
     uint8_t* __restrict__ workspace, uint64_t ws_stride, uint32_t m_cap, uint32_t max_hap,
     int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint16_t* __restrict__ band, uint32_t band_stride, uint32_t* __restrict__ hard_list,
-    uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters, uint32_t lds_tasks, uint32_t max_read) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_slab[];
+    uint32_t slot;
+    if constexpr (IN_LDS) {
+        if (threadIdx.x >= lds_tasks) return;
+        slot = blockIdx.x * lds_tasks + threadIdx.x;
+    } else {
+        slot = blockIdx.x * blockDim.x + threadIdx.x;
+    }
     if (slot >= n_tasks) return;
     const uint32_t task = tasks ? tasks[slot] : task_base + slot;
     const uint32_t rid = task >> 1, hap = task & 1;
@@ -271,7 +283,9 @@ __global__ __launch_bounds__(64) void band_kernel(
     const uint8_t* y = hap_arena + (hap ? loc.alt_off : loc.ref_off);
     const int m = (int)rec.read_len, n = (int)(hap ? loc.alt_len : loc.ref_len);
     if (m == 0 || n == 0) { (hap ? alt_score : ref_score)[rid] = 0; return; }
-    uint8_t* ws = workspace + (uint64_t)slot * ws_stride;
+    uint8_t* ws;
+    if constexpr (IN_LDS) ws = lds_slab + (size_t)threadIdx.x * ws_stride;
+    else ws = workspace + (uint64_t)slot * ws_stride;
     band_scratch sc;
     size_t o = 0;
     sc.head = (uint16_t*)(ws + o); o += HASH_SIZE * 2;
@@ -284,6 +298,14 @@ __global__ __launch_bounds__(64) void band_kernel(
     sc.dps = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
     sc.dpp = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
     sc.cont = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
+    if constexpr (IN_LDS) {
+        // the task's read and haplotype next to its slab (every k-mer probe compares bytes of both)
+        uint8_t* xl = ws + o; o += ((size_t)max_read + 3) & ~(size_t)3;
+        uint8_t* yl = ws + o;
+        for (int i = 0; i < m; ++i) xl[i] = x[i];
+        for (int j = 0; j < n; ++j) yl[j] = y[j];
+        x = xl; y = yl;
+    }
     int32_t cert = 0;
     int cA = 0, cB = 0;
     const int rc = band_task(x, m, y, n, sc, m_cap, &cert, &cA, &cB);
@@ -302,16 +324,35 @@ extern "C" size_t vtxk_band_ws_stride(uint32_t m_cap, uint32_t max_hap) {
     return (o + 63) & ~(size_t)63;
 }
 
+// lds_stride: bytes per task of the in-LDS variant (slab for m_cap matches + read + haplotype)
+extern "C" size_t vtxk_band_lds_stride(uint32_t m_cap, uint32_t max_hap, uint32_t max_read) {
+    return (vtxk_band_ws_stride(m_cap, max_hap) + (((size_t)max_read + 3) & ~(size_t)3) + max_hap + 15) & ~(size_t)15;
+}
+
+// in_lds != 0: the in-LDS variant (workspace unused); the caller has checked that at least one task fits 160 KiB
 extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, uint32_t task_base,
                                        const vtx_record* records, const uint32_t* rec_locus, const vtx_locus* loci,
                                        const uint8_t* read_arena, const uint8_t* hap_arena, uint8_t* workspace,
                                        uint64_t ws_stride, uint32_t m_cap, uint32_t max_hap, int32_t* ref_score,
                                        int32_t* alt_score, uint16_t* band, uint32_t band_stride, uint32_t* hard_list,
-                                       uint32_t* overflow_list, uint32_t* counters, hipStream_t s) {
+                                       uint32_t* overflow_list, uint32_t* counters, int in_lds, uint32_t max_read,
+                                       hipStream_t s) {
     if (!n_tasks) return hipSuccess;
-    hipLaunchKernelGGL(band_kernel, dim3((n_tasks + 63) / 64), dim3(64), 0, s, tasks, n_tasks, task_base, records,
+    if (in_lds) {
+        const size_t stride = vtxk_band_lds_stride(m_cap, max_hap, max_read);
+        const uint32_t per_wg = (uint32_t)std::min<size_t>(64, (160 * 1024 - 512) / stride);
+        if (!per_wg) return hipErrorInvalidValue;
+        const size_t shmem = (size_t)per_wg * stride;
+        hipError_t e = hipFuncSetAttribute((const void*)band_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(band_kernel<true>, dim3((n_tasks + per_wg - 1) / per_wg), dim3(64), shmem, s, tasks, n_tasks,
+                           task_base, records, rec_locus, loci, read_arena, hap_arena, workspace, (uint64_t)stride, m_cap,
+                           max_hap, ref_score, alt_score, band, band_stride, hard_list, overflow_list, counters, per_wg, max_read);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(band_kernel<false>, dim3((n_tasks + 63) / 64), dim3(64), 0, s, tasks, n_tasks, task_base, records,
                        rec_locus, loci, read_arena, hap_arena, workspace, ws_stride, m_cap, max_hap, ref_score, alt_score,
-                       band, band_stride, hard_list, overflow_list, counters);
+                       band, band_stride, hard_list, overflow_list, counters, 0u, 0u);
     return hipGetLastError();
 }
 

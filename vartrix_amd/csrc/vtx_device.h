@@ -47,11 +47,12 @@ hipError_t vtxk_launch_sw_banded(int R, int GL, uint32_t n_hard, const uint32_t*
                                  const uint8_t* hap_arena, const uint16_t* band, uint32_t band_stride, int32_t* ref_score,
                                  int32_t* alt_score, uint32_t max_hap_len, hipStream_t stream);
 size_t vtxk_band_ws_stride(uint32_t m_cap, uint32_t max_hap);
+size_t vtxk_band_lds_stride(uint32_t m_cap, uint32_t max_hap, uint32_t max_read);
 hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
                             const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                             const uint8_t* hap_arena, uint8_t* workspace, uint64_t ws_stride, uint32_t m_cap,
-                            uint32_t max_hap, int32_t* ref_score, int32_t* alt_score, uint16_t* band,
-                            uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list, uint32_t* counters,
+                            uint32_t max_hap, int32_t* ref_score, int32_t* alt_score, uint16_t* band, uint32_t band_stride,
+                            uint32_t* hard_list, uint32_t* overflow_list, uint32_t* counters, int in_lds, uint32_t max_read,
                             hipStream_t s);
 hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
                                 const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
