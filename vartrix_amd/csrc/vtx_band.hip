@@ -815,8 +815,8 @@ __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __rest
     }
 }
 
-template <int NT, bool GT>
-__global__ __launch_bounds__(NT, VTX_WPE) void band_run_kernel(
+template <int NT, bool GT, int WPE>
+__global__ __launch_bounds__(NT, WPE) void band_run_kernel(
     uint32_t n_tasks, uint32_t task_base,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
@@ -1385,8 +1385,9 @@ extern "C" size_t vtxk_band_gtables_bytes(uint32_t n_loci, uint32_t max_hap, uin
     return need <= ((size_t)4 << 30) ? need : 0;
 }
 
-extern "C" uint32_t vtxk_band_run_grid(uint32_t nt) { return 256u * (nt == 64 ? 16u : (uint32_t)VTX_WPE); }
-extern "C" uint32_t vtxk_band_run_lanes(void) { return 256u * std::max(16u * 64u, (uint32_t)VTX_WPE * 256u); }     // max over both block sizes of grid x nt
+// persistent grid of band_run_kernel<nt, ., wpe>: what the chip holds (wavefronts per SIMD x 4 SIMDs x 256 CUs)
+extern "C" uint32_t vtxk_band_run_grid(uint32_t nt, uint32_t wpe) { return 256u * (nt == 64 ? 4u * wpe : wpe); }
+extern "C" uint32_t vtxk_band_run_lanes(void) { return 256u * 256u * (uint32_t)std::max(VTX_WPE, 5); }     // max over both block sizes of grid x nt
 
 extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
                                            const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
@@ -1435,22 +1436,27 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
                            hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
     }
     const uint32_t ablate = (uint32_t)(getenv("VTX_BAND_ABLATE") ? atoi(getenv("VTX_BAND_ABLATE")) : 0);
-#define LAUNCH_RUN(NTV, GTV)                                                                                         \
+#define LAUNCH_RUN(NTV, GTV, WV)                                                                                     \
     {                                                                                                                \
         if (shmem > 48 * 1024) {                                                                                     \
-            hipError_t e = hipFuncSetAttribute((const void*)band_run_kernel<NTV, GTV>,                               \
+            hipError_t e = hipFuncSetAttribute((const void*)band_run_kernel<NTV, GTV, WV>,                           \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);              \
             if (e != hipSuccess) return e;                                                                           \
         }                                                                                                            \
-        hipLaunchKernelGGL((band_run_kernel<NTV, GTV>), dim3(std::min((n_tasks + NTV - 1) / NTV, vtxk_band_run_grid(NTV))), \
+        hipLaunchKernelGGL((band_run_kernel<NTV, GTV, WV>),                                                          \
+                           dim3(std::min((n_tasks + NTV - 1) / NTV, vtxk_band_run_grid(NTV, WV))),                    \
                            dim3(NTV), shmem, s, n_tasks,                                                             \
                            task_base, records, rec_locus, loci, read_arena, hap_arena, max_hap, tables,              \
                            (uint32_t)tstride, ref_score, alt_score, logbuf, band, band_stride, hard_list,            \
                            overflow_list, pending_list, pend_buf, hard_cap, pend_cap, counters, ablate, n_heads,     \
                            (const uint8_t*)gtables);                                                                 \
     }
-    if (global_tables && wave_wg) LAUNCH_RUN(64, true) else if (global_tables) LAUNCH_RUN(256, true)
-    else if (wave_wg) LAUNCH_RUN(64, false) else LAUNCH_RUN(256, false)
+    // wavefronts per SIMD: 4 with the tables in LDS (111 VGPRs; 5 -> 93 VGPRs cost more than the occupancy gave, 3 less
+    // still); the global-table variants wait on L2 / HBM instead of LDS and take 5 (measured: 16 reads per locus +6 %,
+    // 64 reads per locus +12 %), except the very shallow case, where the grid does not fill the chip anyway
+    if (global_tables && wave_wg) { if (tasks_per_locus < 16) LAUNCH_RUN(64, true, 4) else LAUNCH_RUN(64, true, 5) }
+    else if (global_tables) LAUNCH_RUN(256, true, 5)
+    else if (wave_wg) LAUNCH_RUN(64, false, VTX_WPE) else LAUNCH_RUN(256, false, VTX_WPE)
 #undef LAUNCH_RUN
     return hipGetLastError();
 }

@@ -64,7 +64,7 @@ hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base, const vtx_
 size_t vtxk_band_gtables_bytes(uint32_t n_loci, uint32_t max_hap, uint32_t tasks_per_locus);
 uint32_t vtxk_band_task_words(void);
 uint32_t vtxk_band_pend_words(void);
-uint32_t vtxk_band_run_grid(uint32_t nt);
+uint32_t vtxk_band_run_grid(uint32_t nt, uint32_t wpe);
 uint32_t vtxk_band_run_lanes(void);
 hipError_t vtxk_launch_band_pending(const uint32_t* pending, uint32_t n_pending, const uint32_t* pend_buf,
                                     int32_t* ref_score, int32_t* alt_score, uint16_t* band, uint32_t band_stride,
