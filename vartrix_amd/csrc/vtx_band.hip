@@ -357,17 +357,18 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
 }
 
 #ifndef VTX_PS
-#define VTX_PS 14
+#define VTX_PS 15
 #endif
 #ifndef VTX_WPE
 #define VTX_WPE 4   // wavefronts per SIMD band_run_kernel is compiled and launched for
 #endif
 #define PS VTX_PS   // per-lane LDS entries of band_run_kernel: pieces + segments
 #define LG 64       // jump-log entries per task (global)
-#define SPILL 18    // pieces run_compact may drop from a task's list and still leave it to the pending kernel (global)
+#define SPILL (32 - PS)   // pieces run_compact may drop from a task's list and still leave it to the pending kernel (global): list + spill = the 32 lanes of band_pending_kernel
 #define TASK_WORDS (LG * 2 + SPILL * 2)   // scratch of one RESIDENT lane (global, reused block after block): jump log, spilled pieces
 #define PEND_WORDS (2 + 2 * PS + (4 * SG + 6) + 2 * SPILL)   // record of a pending task: header, cert, list, staircase, spill
 #define SG 10       // chain segments per task
+static_assert(VTX_PS >= 8 && VTX_PS <= 24, "list + spill entries of a task are the 32 lanes of band_pending_kernel");
 #define NONE_ID 0xffffffffu
 #define CH_END 0xffffu     // end of a k-mer chain / empty bucket
 
@@ -1374,15 +1375,21 @@ __global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __rest
 // size); the per-lane scratch is sized from it.
 // tables in global memory below this many tasks per locus (experiment knob VTX_BAND_GT_MAX_TPL; 0: never)
 static uint32_t gt_max_tpl() {
-    static const uint32_t v = getenv("VTX_BAND_GT_MAX_TPL") ? (uint32_t)atoi(getenv("VTX_BAND_GT_MAX_TPL")) : 208u;
+    static const uint32_t v = getenv("VTX_BAND_GT_MAX_TPL") ? (uint32_t)atoi(getenv("VTX_BAND_GT_MAX_TPL")) : 0x7fffffffu;
     return v;
+}
+// buckets of a table's hash (power of two; experiment knob VTX_BAND_HEADS)
+static uint32_t pick_heads(uint32_t tasks_per_locus, bool global_tables) {
+    if (getenv("VTX_BAND_HEADS")) return (uint32_t)atoi(getenv("VTX_BAND_HEADS"));
+    if (tasks_per_locus < 48) return 256;
+    return global_tables ? 1024 : 512;       // no LDS to fit: shorter chains (2048: no further gain)
 }
 
 // bytes of the global table buffer vtxk_launch_band_run wants for this shape of data (0: tables live in LDS)
 extern "C" size_t vtxk_band_gtables_bytes(uint32_t n_loci, uint32_t max_hap, uint32_t tasks_per_locus) {
     if (tasks_per_locus >= gt_max_tpl()) return 0;
-    const size_t need = (size_t)n_loci * 2 * band_table_stride(max_hap, tasks_per_locus < 48 ? 256 : 512);
-    return need <= ((size_t)4 << 30) ? need : 0;
+    const size_t need = (size_t)n_loci * 2 * band_table_stride(max_hap, pick_heads(tasks_per_locus, true));
+    return need <= ((size_t)24 << 30) ? need : 0;
 }
 
 // persistent grid of band_run_kernel<nt, ., wpe>: what the chip holds (wavefronts per SIMD x 4 SIMDs x 256 CUs)
@@ -1408,13 +1415,17 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     const bool wave_wg = tasks_per_locus < 64;
     const uint32_t nt = wave_wg ? 64 : 256;
     const size_t lane_bytes = (size_t)(2 * PS) * nt * 4;
-    uint32_t n_heads = tasks_per_locus < 48 ? 256 : 512;
-    if (getenv("VTX_BAND_HEADS")) n_heads = (uint32_t)atoi(getenv("VTX_BAND_HEADS"));   // experiment knob (power of two)
-    const size_t tstride = band_table_stride(max_hap, n_heads);
+    const bool want_global = tasks_per_locus < gt_max_tpl() && gtables;
+    uint32_t n_heads = pick_heads(tasks_per_locus, want_global);
+    size_t tstride = band_table_stride(max_hap, n_heads);
+    if (want_global && (size_t)n_loci * 2 * tstride > gtables_bytes) {       // the buffer is too small: tables in LDS
+        n_heads = pick_heads(tasks_per_locus, false);
+        tstride = band_table_stride(max_hap, n_heads);
+    }
     // Shallow data with a table buffer from the caller: every locus' tables are built once, in global memory
     // (band_tables_kernel), and the wavefronts keep only their lane arrays in LDS — 16 wavefronts per CU instead of 3,
     // no table passes with idle lanes.
-    const bool global_tables = tasks_per_locus < gt_max_tpl() && gtables && (size_t)n_loci * 2 * tstride <= gtables_bytes;
+    const bool global_tables = want_global && (size_t)n_loci * 2 * tstride <= gtables_bytes;
     uint32_t tables;
     if (global_tables) {
         tables = 2;
