@@ -1405,16 +1405,19 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
                                            uint32_t* counters, uint32_t tasks_per_locus, uint32_t n_loci, uint8_t* gtables,
                                            size_t gtables_bytes, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
-    // Deep data (>= 64 tasks per locus): 256-task workgroups.  A workgroup processes its loci in passes of `tables / 2`
+    // (LDS-table variants, the fallback:) deep data (>= 64 tasks per locus): 256-task workgroups.  A workgroup processes its loci in passes of `tables / 2`
     // loci (the k-mer tables live in LDS); in a pass only the lanes of those loci work.  512-entry head arrays: two loci
     // fit next to the 28 KiB of lane arrays at 4 workgroups per CU, one pass per workgroup nearly always (2048-entry heads
     // fit one locus: 109 ms instead of 91 ms on config 3; 256-entry heads: 101 ms, the chains get longer).
     // Shallow data: one WAVEFRONT per workgroup (64 tasks), all of its loci resident at once when they fit — with
     // 256-task workgroups the wavefronts of a workgroup took turns (a pass holds the loci of one wavefront's tasks and
     // the other three wait at the barrier), so a CU had two working wavefronts; now every resident wavefront works.
-    const bool wave_wg = tasks_per_locus < 64;
-    const uint32_t nt = wave_wg ? 64 : 256;
-    const size_t lane_bytes = (size_t)(2 * PS) * nt * 4;
+    // Tables.  With a table buffer from the caller every locus' tables are built once per run in global memory
+    // (band_tables_kernel) and the workgroups keep only their lane arrays in LDS: no table passes with idle lanes, five
+    // wavefronts per SIMD, and nothing ties the lanes of a workgroup together any more — one wavefront per workgroup
+    // (no barrier per block: config 3 51.1 -> 50.6 ms, 64 reads per locus +4 %).  Without the buffer (or when the
+    // tables would not fit it) they live in LDS: 256-task workgroups for deep loci (two tables per pass next to the lane
+    // arrays, four workgroups per CU), one-wavefront workgroups with up to 32 tables below 64 tasks per locus.
     const bool want_global = tasks_per_locus < gt_max_tpl() && gtables;
     uint32_t n_heads = pick_heads(tasks_per_locus, want_global);
     size_t tstride = band_table_stride(max_hap, n_heads);
@@ -1422,10 +1425,10 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
         n_heads = pick_heads(tasks_per_locus, false);
         tstride = band_table_stride(max_hap, n_heads);
     }
-    // Shallow data with a table buffer from the caller: every locus' tables are built once, in global memory
-    // (band_tables_kernel), and the wavefronts keep only their lane arrays in LDS — 16 wavefronts per CU instead of 3,
-    // no table passes with idle lanes.
     const bool global_tables = want_global && (size_t)n_loci * 2 * tstride <= gtables_bytes;
+    const bool wave_wg = global_tables || tasks_per_locus < 64;
+    const uint32_t nt = wave_wg ? 64 : 256;
+    const size_t lane_bytes = (size_t)(2 * PS) * nt * 4;
     uint32_t tables;
     if (global_tables) {
         tables = 2;
@@ -1465,8 +1468,7 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     // wavefronts per SIMD: 4 with the tables in LDS (111 VGPRs; 5 -> 93 VGPRs cost more than the occupancy gave, 3 less
     // still); the global-table variants wait on L2 / HBM instead of LDS and take 5 (measured: 16 reads per locus +6 %,
     // 64 reads per locus +12 %), except the very shallow case, where the grid does not fill the chip anyway
-    if (global_tables && wave_wg) { if (tasks_per_locus < 16) LAUNCH_RUN(64, true, 4) else LAUNCH_RUN(64, true, 5) }
-    else if (global_tables) LAUNCH_RUN(256, true, 5)
+    if (global_tables) { if (tasks_per_locus < 16) LAUNCH_RUN(64, true, 4) else LAUNCH_RUN(64, true, 5) }
     else if (wave_wg) LAUNCH_RUN(64, false, VTX_WPE) else LAUNCH_RUN(256, false, VTX_WPE)
 #undef LAUNCH_RUN
     return hipGetLastError();
