@@ -942,7 +942,7 @@ int vtx_run(vtx_ctx* c) {
         HIP_TRY(c, c->d_band.reserve((size_t)slots * 2 * band_stride * sizeof(uint16_t)));
         HIP_TRY(c, c->d_hard.reserve(((size_t)hard_cap + pend_cap) * sizeof(uint32_t)));
         HIP_TRY(c, c->d_over.reserve((size_t)n_tasks * sizeof(uint32_t)));
-        HIP_TRY(c, c->d_cnt.reserve(16 * sizeof(uint32_t)));
+        HIP_TRY(c, c->d_cnt.reserve(32 * sizeof(uint32_t)));
         uint32_t* d_cnt = c->d_cnt.as<uint32_t>();        // [0] hard, [1] overflow, [2..7] reasons; [8],[9] general kernel; [10] stats; [11] pending
         int shape = 0;
         while ((uint32_t)(kShapes[shape][0] * kShapes[shape][1]) < c->max_read_len) ++shape;
@@ -1026,13 +1026,14 @@ int vtx_run(vtx_ctx* c) {
             HIP_TRY(c, hipStreamWaitEvent(s, c->ev2, 0));             // the reduction kernels read every score
             return VTX_OK;
         };
-        HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 16 * sizeof(uint32_t), s));
+        HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 32 * sizeof(uint32_t), s));
         uint32_t cnt[12] = {0};
         uint32_t pending_total = 0;
         for (uint64_t base = 0; base < n_tasks; base += chunk) {
             const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, n_tasks - base);
             HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), s));                 // hard count of this chunk
-            HIP_TRY(c, hipMemsetAsync(d_cnt + 11, 0, 2 * sizeof(uint32_t), s));        // pending count of this chunk, block counter
+            HIP_TRY(c, hipMemsetAsync(d_cnt + 11, 0, sizeof(uint32_t), s));            // pending count of this chunk
+            HIP_TRY(c, hipMemsetAsync(d_cnt + 16, 0, 8 * sizeof(uint32_t), s));        // block counters (one per XCD)
             HIP_TRY(c, hipEventRecord(c->ev[4], s));
             HIP_TRY(c, vtxk_launch_band_run(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                              c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
@@ -1085,7 +1086,7 @@ int vtx_run(vtx_ctx* c) {
         // records beyond the fast kernels' limits: exact slow path, both flavours (slabs grow until every chain fits)
         const uint32_t n_slow = 2 * c->slow_cnt;
         const int banded = c->cfg.aligner == VTX_ALIGNER_BANDED;
-        HIP_TRY(c, c->d_cnt.reserve(16 * sizeof(uint32_t)));
+        HIP_TRY(c, c->d_cnt.reserve(32 * sizeof(uint32_t)));
         uint32_t* d_scnt = c->d_cnt.as<uint32_t>() + 13;
         HIP_TRY(c, c->d_slow_retry.reserve(2 * (size_t)n_slow * sizeof(uint32_t)));
         const uint32_t* tasks = nullptr;

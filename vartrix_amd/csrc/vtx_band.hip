@@ -826,7 +826,8 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
     uint32_t* __restrict__ logbuf, uint16_t* __restrict__ band, uint32_t band_stride,
     uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ pending_list,
     uint32_t* __restrict__ pend_buf, uint32_t hard_cap, uint32_t pend_cap,
-    uint32_t* __restrict__ counters, uint32_t ablate, uint32_t n_heads, const uint8_t* __restrict__ gtables) {
+    uint32_t* __restrict__ counters, uint32_t ablate, uint32_t n_heads, const uint8_t* __restrict__ gtables,
+    uint32_t xcd_claim) {
     // GT: the tables of every locus were built by band_tables_kernel in global memory (shallow loci: a wavefront's 64
     // tasks span many loci, tables in LDS cost the occupancy); !GT: built here, per block, in LDS
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -848,12 +849,30 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
     // entries the lanes of a wave write at about the same time share cache lines
     uint32_t* mylog = logbuf + (size_t)blockIdx.x * NT * TASK_WORDS + tid * 2;
     const uint32_t n_blocks = (n_tasks + NT - 1) / NT;
+    // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); each XCD claims blocks from its own eighth of the
+    // batch first (counters[16 + xcd]), so the ~8 wavefronts that share a locus' tables and reads meet in one L2, and
+    // helps the other eighths out when its own is done.
+    // (xcd_claim == 0: one range for all)
+    const bool by_xcd = xcd_claim != 0;
+    const uint32_t xcd = by_xcd ? (blockIdx.x & 7u) : 0u;
+    const uint32_t per_xcd = by_xcd ? (n_blocks + 7) / 8 : n_blocks;
+    uint32_t turn = 0;
   for (;;) {
     __syncthreads();
-    if (tid == 0) s_blk = atomicAdd(&counters[12], 1u);
+    if (tid == 0) {
+        uint32_t b = 0xffffffffu;
+        while (turn < 8) {
+            const uint32_t r = (xcd + turn) & 7u;
+            const uint32_t lo = r * per_xcd, hi = min(n_blocks, lo + per_xcd);
+            const uint32_t k = lo + atomicAdd(&counters[16 + r], 1u);
+            if (lo < hi && k < hi) { b = k; break; }
+            ++turn;
+        }
+        s_blk = b;
+    }
     __syncthreads();
     const uint32_t blk = s_blk;
-    if (blk >= n_blocks) break;
+    if (blk == 0xffffffffu) break;
     const uint32_t slot = blk * NT + tid;
     const bool have = slot < n_tasks;
     const uint32_t task = task_base + slot;
@@ -1450,6 +1469,7 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
                            hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
     }
     const uint32_t ablate = (uint32_t)(getenv("VTX_BAND_ABLATE") ? atoi(getenv("VTX_BAND_ABLATE")) : 0);
+    const uint32_t xcd_claim = ((tasks_per_locus >= 24 || getenv("VTX_BAND_XCD")) && !getenv("VTX_BAND_NO_XCD")) ? 1u : 0u;   // (measured: config 3 -3 %, 64 / 32 reads per locus -4.5 %, 16: -1 %, 4: +2 %)
 #define LAUNCH_RUN(NTV, GTV, WV)                                                                                     \
     {                                                                                                                \
         if (shmem > 48 * 1024) {                                                                                     \
@@ -1463,7 +1483,7 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
                            task_base, records, rec_locus, loci, read_arena, hap_arena, max_hap, tables,              \
                            (uint32_t)tstride, ref_score, alt_score, logbuf, band, band_stride, hard_list,            \
                            overflow_list, pending_list, pend_buf, hard_cap, pend_cap, counters, ablate, n_heads,     \
-                           (const uint8_t*)gtables);                                                                 \
+                           (const uint8_t*)gtables, xcd_claim);                                                      \
     }
     // wavefronts per SIMD: 4 with the tables in LDS (111 VGPRs; 5 -> 93 VGPRs cost more than the occupancy gave, 3 less
     // still); the global-table variants wait on L2 / HBM instead of LDS and take 5 (measured: 16 reads per locus +6 %,
