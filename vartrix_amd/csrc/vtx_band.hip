@@ -55,16 +55,42 @@
 #define BAND_POLYLINE 0xffffu
 #define BAND_FULL_MATRIX 0xfffeu
 
-struct band_scratch {      // per-task slices of the workspace (all sized by the launch)
-    uint16_t* head;        // HASH_SIZE
-    uint16_t* next;        // n
-    uint32_t* mt;          // M_cap packed (x << 16 | y)
-    int32_t* dps;          // M_cap
-    int32_t* dpp;          // M_cap
-    int2* tree;            // n + KMER + 4 Fenwick nodes {v, match index}
-    int32_t* cont;         // M_cap: the match one step up the diagonal (-1: none)
-    uint16_t* rmin;        // n + 2
-    uint16_t* rmax;        // n + 2
+// Per-task slices of the workspace (all sized by the launch).  S = element stride: 1 = every task owns a contiguous slab
+// (LDS variant, slow path); 64 = the slabs of the 64 lanes of a wavefront are interleaved element by element, so the
+// lanes' accesses to the same index (the lanes of a wavefront run the serial algorithm nearly in step) share cache lines.
+template <typename T, int S>
+struct strided {
+    T* p;
+    __device__ __forceinline__ T& operator[](size_t i) const { return p[i * S]; }
+};
+template <int S>
+struct band_scratch_t {
+    strided<uint16_t, S> head;   // HASH_SIZE
+    strided<uint16_t, S> next;   // n
+    strided<uint32_t, S> mt;     // M_cap packed (x << 16 | y)
+    strided<int32_t, S> dps;     // M_cap
+    strided<int32_t, S> dpp;     // M_cap
+    strided<int2, S> tree;       // n + KMER + 4 Fenwick nodes {v, match index}
+    strided<int32_t, S> cont;    // M_cap: the match one step up the diagonal (-1: none)
+    strided<uint16_t, S> rmin;   // n + 2
+    strided<uint16_t, S> rmax;   // n + 2
+    // carve the arrays out of a slab; `lane` = this task's position among the S interleaved ones
+    __device__ __forceinline__ size_t carve(uint8_t* ws, uint32_t lane, uint32_t m_cap, uint32_t max_hap) {
+        size_t o = 0;
+#define CARVE(field, T, count) field.p = (T*)(ws + o * S) + lane; o += (size_t)(count) * sizeof(T);
+        CARVE(head, uint16_t, HASH_SIZE)
+        CARVE(next, uint16_t, (size_t)max_hap + 2)
+        CARVE(rmin, uint16_t, (size_t)max_hap + 2)
+        CARVE(rmax, uint16_t, (size_t)max_hap + 2)
+        o = (o + 15) & ~(size_t)15;
+        CARVE(tree, int2, (size_t)max_hap + KMER + 4)
+        CARVE(mt, uint32_t, m_cap)
+        CARVE(dps, int32_t, m_cap)
+        CARVE(dpp, int32_t, m_cap)
+        CARVE(cont, int32_t, m_cap)
+#undef CARVE
+        return o;
+    }
 };
 
 __device__ __forceinline__ uint32_t kmer_hash_dev(const uint8_t* s) {
@@ -101,7 +127,8 @@ __device__ __forceinline__ void walk_gap(walk_state& w, int dir) {
 
 // Returns: 0 ok; 1 match capacity exceeded (needs a larger slab).  *cert_out = INT32_MAX when there is no
 // k-mer match (Band::full_matrix: banded == full by construction).
-__device__ int band_task(const uint8_t* x, int m, const uint8_t* y, int n, band_scratch sc, uint32_t m_cap,
+template <int S>
+__device__ int band_task(const uint8_t* x, int m, const uint8_t* y, int n, band_scratch_t<S> sc, uint32_t m_cap,
                          int32_t* cert_out, int* cA_out, int* cB_out) {
     *cert_out = 0;
     // ---- find_kmer_matches: chained hash of y's k-mers, probes in x order, j ascending ----
@@ -237,7 +264,8 @@ __device__ int band_task(const uint8_t* x, int m, const uint8_t* y, int n, band_
 }
 
 // per-column ranges from the staircase (closed form, see the file header)
-__device__ void band_ranges(const band_scratch& sc, int cA, int cB, int m, int n, uint16_t* lo, uint16_t* hi) {
+template <int S>
+__device__ void band_ranges(const band_scratch_t<S>& sc, int cA, int cB, int m, int n, uint16_t* lo, uint16_t* hi) {
     const int rows = m + 1;
     for (int j = 0; j <= n; ++j) {
         if (j < cA - BANDW || j > cB + BANDW) { lo[j] = 0x7fff; hi[j] = 0; continue; }
@@ -283,28 +311,20 @@ __global__ __launch_bounds__(64) void band_kernel(
     const uint8_t* y = hap_arena + (hap ? loc.alt_off : loc.ref_off);
     const int m = (int)rec.read_len, n = (int)(hap ? loc.alt_len : loc.ref_len);
     if (m == 0 || n == 0) { (hap ? alt_score : ref_score)[rid] = 0; return; }
-    uint8_t* ws;
-    if constexpr (IN_LDS) ws = lds_slab + (size_t)threadIdx.x * ws_stride;
-    else ws = workspace + (uint64_t)slot * ws_stride;
-    band_scratch sc;
-    size_t o = 0;
-    sc.head = (uint16_t*)(ws + o); o += HASH_SIZE * 2;
-    sc.next = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
-    sc.rmin = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
-    sc.rmax = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
-    o = (o + 15) & ~(size_t)15;
-    sc.tree = (int2*)(ws + o); o += ((size_t)max_hap + KMER + 4) * 8;
-    sc.mt = (uint32_t*)(ws + o); o += (size_t)m_cap * 4;
-    sc.dps = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
-    sc.dpp = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
-    sc.cont = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
+    // IN_LDS: a contiguous slab per task; global: the slabs of a wavefront's 64 tasks interleaved element by element
+    constexpr int S = IN_LDS ? 1 : 64;
+    band_scratch_t<S> sc;
     if constexpr (IN_LDS) {
+        uint8_t* ws = lds_slab + (size_t)threadIdx.x * ws_stride;
+        size_t o = sc.carve(ws, 0, m_cap, max_hap);
         // the task's read and haplotype next to its slab (every k-mer probe compares bytes of both)
         uint8_t* xl = ws + o; o += ((size_t)max_read + 3) & ~(size_t)3;
         uint8_t* yl = ws + o;
         for (int i = 0; i < m; ++i) xl[i] = x[i];
         for (int j = 0; j < n; ++j) yl[j] = y[j];
         x = xl; y = yl;
+    } else {
+        sc.carve(workspace + (uint64_t)(slot & ~63u) * ws_stride, slot & 63u, m_cap, max_hap);
     }
     int32_t cert = 0;
     int cA = 0, cB = 0;
@@ -1248,25 +1268,18 @@ __global__ __launch_bounds__(64) void slow_align_kernel(
     const int m = (int)rec.read_len, n = (int)(hap ? loc.alt_len : loc.ref_len);
     int32_t* out = (hap ? alt_score : ref_score) + rid;
     if (m == 0 || n == 0) { *out = 0; return; }
+    // slab layout: the band scratch (vtxk_band_ws_stride's arrays), then lo / hi and the four DP columns
     uint8_t* ws = workspace + (uint64_t)slot * ws_stride;
-    band_scratch sc;
-    size_t o = 0;
-    sc.head = (uint16_t*)(ws + o); o += HASH_SIZE * 2;
-    sc.next = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
-    sc.rmin = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
-    sc.rmax = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
+    band_scratch_t<1> sc;
+    size_t o = sc.carve(ws, 0, m_cap, max_hap);
+    o = (o + 15) & ~(size_t)15;
     uint16_t* lo = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
     uint16_t* hi = (uint16_t*)(ws + o); o += ((size_t)max_hap + 2) * 2;
     o = (o + 15) & ~(size_t)15;
-    sc.tree = (int2*)(ws + o); o += ((size_t)max_hap + KMER + 4) * 8;
     int32_t* Sp = (int32_t*)(ws + o); o += ((size_t)max_read + 2) * 4;
     int32_t* Dp = (int32_t*)(ws + o); o += ((size_t)max_read + 2) * 4;
     int32_t* Sc = (int32_t*)(ws + o); o += ((size_t)max_read + 2) * 4;
     int32_t* Dc = (int32_t*)(ws + o); o += ((size_t)max_read + 2) * 4;
-    sc.mt = (uint32_t*)(ws + o); o += (size_t)m_cap * 4;
-    sc.dps = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
-    sc.dpp = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
-    sc.cont = (int32_t*)(ws + o); o += (size_t)m_cap * 4;
     bool whole = !banded;
     if (banded) {
         int32_t cert = 0;
@@ -1310,9 +1323,10 @@ __global__ __launch_bounds__(64) void slow_align_kernel(
 }
 
 extern "C" size_t vtxk_slow_ws_stride(uint32_t m_cap, uint32_t max_hap, uint32_t max_read) {
-    size_t o = HASH_SIZE * 2 + 5 * ((size_t)max_hap + 2) * 2;
+    size_t o = vtxk_band_ws_stride(m_cap, max_hap);            // (a multiple of 64)
+    o += 2 * ((size_t)max_hap + 2) * 2;
     o = (o + 15) & ~(size_t)15;
-    o += 2 * ((size_t)max_hap + KMER + 4) * 4 + 4 * ((size_t)max_read + 2) * 4 + 4 * (size_t)m_cap * 4;
+    o += 4 * ((size_t)max_read + 2) * 4;
     return (o + 63) & ~(size_t)63;
 }
 
