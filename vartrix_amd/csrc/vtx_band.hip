@@ -162,17 +162,19 @@ __device__ int band_task(const uint8_t* x, int m, const uint8_t* y, int n, band_
     // pointer into the previous row follows the current row (merge scan)
     int row_x = -2;
     uint32_t row_begin = 0, prev_hi = 0, scan = 0;
+    // the next start and end matches stay in registers (requested when their pointer moves, not when they are needed)
+    uint32_t ms = sc.mt[0], me = ms;
     while (e_ptr < M) {
         // next event: start (xs, ys, s+M) vs end (xe+K, ye+K, e); start ids sort after end ids
         bool take_start = false;
         if (s_ptr < M) {
-            const uint32_t ms = sc.mt[s_ptr], me = sc.mt[e_ptr];
             const uint32_t sx = ms >> 16, sy = ms & 0xffff, ex = (me >> 16) + KMER, ey = (me & 0xffff) + KMER;
             take_start = (sx < ex) || (sx == ex && sy < ey);   // equal coordinates: end first
         }
         if (take_start) {
             const uint32_t p = s_ptr++;
-            const int32_t px = (int32_t)(sc.mt[p] >> 16), py = (int32_t)(sc.mt[p] & 0xffff);
+            const int32_t px = (int32_t)(ms >> 16), py = (int32_t)(ms & 0xffff);
+            if (s_ptr < M) ms = sc.mt[s_ptr];
             int32_t dv = KMER, dp = -1;
             int32_t bv = INT32_MIN, bi = -1;
             for (int i = py + 1; i > 0;) {
@@ -198,7 +200,8 @@ __device__ int band_task(const uint8_t* x, int m, const uint8_t* y, int n, band_
             sc.dps[p] = dv; sc.dpp[p] = dp; sc.cont[p] = c;
         } else {
             const uint32_t p = e_ptr++;
-            const int32_t px = (int32_t)(sc.mt[p] >> 16), py = (int32_t)(sc.mt[p] & 0xffff);
+            const int32_t px = (int32_t)(me >> 16), py = (int32_t)(me & 0xffff);
+            if (e_ptr < M) me = sc.mt[e_ptr];
             const int32_t c = sc.cont[p];
             int32_t dv = sc.dps[p];
             if (c >= 0) {
@@ -591,7 +594,7 @@ __device__ void run_advance(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
             const int32_t cand = bV - 5 - (mx + my) + KMER;
             if (cand <= (int32_t)(edp + t)) continue;          // continuation wins (ties included)
             // breakpoint: split segment e at t; the tail becomes a new segment (keeps e's open status if it was open)
-            if (st.n_ent == PS || st.lg_n == LG) { st.overflow = true; st.why = 3; break; }
+            if (st.n_ent == PS || st.lg_n == LG) { st.overflow = true; st.why = st.lg_n == LG ? 5 : 3; break; }
             e_dl[e * NT + tid] = (edp << 16) | t;
             e_id[st.n_ent * NT + tid] = mid;
             e_dl[st.n_ent * NT + tid] = ((uint32_t)cand << 16) | (elen - t);
@@ -622,7 +625,7 @@ __device__ void run_advance(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
         if (cdp >= dp) {
             dp = cdp;                                          // adjacent piece: LCSk++ continuation, no log entry
         } else {
-            if (st.lg_n == LG) { st.overflow = true; st.why = 3; break; }
+            if (st.lg_n == LG) { st.overflow = true; st.why = 5; break; }
             mylog[st.lg_n * (2 * NT)] = start_id; mylog[st.lg_n * (2 * NT) + 1] = prev; ++st.lg_n;
         }
         e_dl[i * NT + tid] = ((uint32_t)dp << 16) | plen;
