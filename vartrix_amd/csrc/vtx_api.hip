@@ -934,8 +934,11 @@ int vtx_run(vtx_ctx* c) {
         HIP_TRY(c, c->d_band_ws.reserve((size_t)vtxk_band_run_lanes() * vtxk_band_task_words() * sizeof(uint32_t)));   // per resident lane
         // shallow loci: the k-mer tables of every locus in global memory, built once per run (0 bytes: tables in LDS)
         const uint32_t tasks_per_locus = (uint32_t)(n_tasks / std::max(c->n_loci, 1u));
-        const size_t gt_bytes = vtxk_band_gtables_bytes(c->n_loci, c->max_hap_len, tasks_per_locus);
-        if (gt_bytes) HIP_TRY(c, c->d_gtables.reserve(gt_bytes));
+        size_t gt_bytes = vtxk_band_gtables_bytes(c->n_loci, c->max_hap_len, tasks_per_locus);
+        if (gt_bytes && c->d_gtables.reserve(gt_bytes) != hipSuccess) {     // no room for them: the LDS-table kernels need none
+            (void)hipGetLastError();
+            gt_bytes = 0;
+        }
         HIP_TRY(c, c->d_pend.reserve((size_t)pend_cap * sizeof(uint32_t)));
         HIP_TRY(c, c->d_pend_buf.reserve((size_t)pend_cap * vtxk_band_pend_words() * sizeof(uint32_t)));
         HIP_TRY(c, c->d_poly.reserve(((size_t)hard_cap + pend_cap) * poly_stride * sizeof(uint16_t)));
@@ -1041,7 +1044,7 @@ int vtx_run(vtx_ctx* c) {
                                              c->d_band_ws.as<uint32_t>(), c->d_poly.as<uint16_t>(), poly_stride / 2,
                                              c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
                                              c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt,
-                                             tasks_per_locus, c->n_loci, c->d_gtables.as<uint8_t>(), gt_bytes, s));
+                                             tasks_per_locus, c->n_loci, gt_bytes ? c->d_gtables.as<uint8_t>() : nullptr, gt_bytes, s));
             HIP_TRY(c, hipEventRecord(c->ev[5], s));
             HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
