@@ -565,6 +565,61 @@ void vtx_destroy(vtx_ctx* c) {
     delete c;
 }
 
+// ---- buffers of the banded stage -------------------------------------------------------------------------------
+// One launch covers every task unless a test hook asks for chunks.  The scratch of band_run_kernel belongs to its
+// RESIDENT lanes (persistent workgroups).  Hard tasks leave band_run_kernel / band_pending_kernel as compact staircase
+// records (192 B); the masked DP expands them into band slots (2 x band_stride u16) one slice of `slots` tasks at a
+// time.  A quarter of the tasks may be hard (noisy reads: 11 % at 3 % substitution errors) before anything spills to
+// the general kernel's list.  gt_bytes: the k-mer tables of every locus in global memory (0: tables in LDS).
+struct BandPlan {
+    uint64_t n_tasks = 0;
+    uint32_t chunk = 0, band_stride = 0, hard_cap = 0, pend_cap = 0, slots = 0, poly_stride = 0, tasks_per_locus = 0;
+    size_t gt_bytes = 0;
+};
+static BandPlan band_plan(uint32_t nr, uint32_t n_loci, uint32_t max_hap_len) {
+    BandPlan p;
+    p.n_tasks = 2ull * nr;
+    uint64_t chunk_cap = 1u << 31;
+    if (getenv("VTX_BAND_CHUNK")) chunk_cap = std::max<uint64_t>(256, strtoull(getenv("VTX_BAND_CHUNK"), nullptr, 10));   // test hook
+    p.chunk = (uint32_t)std::min<uint64_t>(p.n_tasks, chunk_cap);
+    p.band_stride = (max_hap_len + 2 + 7) & ~7u;
+    p.hard_cap = (uint32_t)std::min<uint64_t>(p.chunk, p.chunk / 4 + (1u << 20));
+    p.pend_cap = (uint32_t)std::min<uint64_t>(p.chunk, p.chunk / 8 + (1u << 20));
+    p.slots = (uint32_t)std::min<uint64_t>(p.chunk, p.chunk / 16 + (1u << 20));
+    if (getenv("VTX_BAND_HARD_CAP")) p.hard_cap = p.pend_cap = p.slots = std::max(1u, (uint32_t)atoi(getenv("VTX_BAND_HARD_CAP")));   // test hook
+    if (getenv("VTX_BAND_SLOTS")) p.slots = std::max(1u, (uint32_t)atoi(getenv("VTX_BAND_SLOTS")));                                  // test hook
+    p.poly_stride = vtxk_band_poly_stride();
+    p.tasks_per_locus = (uint32_t)(p.n_tasks / std::max(n_loci, 1u));
+    p.gt_bytes = vtxk_band_gtables_bytes(n_loci, max_hap_len, p.tasks_per_locus);
+    return p;
+}
+// (hipMalloc of these GBs costs ~0.1 s the first time a context runs.  Doing it on a helper thread during the upload of
+// vtx_submit was tried: hipMalloc stalls the copy workers, the submit got slower by more than the run got faster.)
+static int band_reserve(vtx_ctx* c, BandPlan& p, bool quiet) {
+#define RES(buf, bytes)                                                                             \
+    do {                                                                                            \
+        const hipError_t e_ = c->buf.reserve(bytes);                                                \
+        if (e_ != hipSuccess) {                                                                     \
+            if (quiet) { (void)hipGetLastError(); return VTX_E_HIP; }                               \
+            return fail(c, e_ == hipErrorOutOfMemory ? VTX_E_NOMEM : VTX_E_HIP, "banded stage buffers: %s", hipGetErrorString(e_)); \
+        }                                                                                           \
+    } while (0)
+    RES(d_band_ws, (size_t)vtxk_band_run_lanes() * vtxk_band_task_words() * sizeof(uint32_t));       // per resident lane
+    if (p.gt_bytes && c->d_gtables.reserve(p.gt_bytes) != hipSuccess) {     // no room for them: the LDS-table kernels need none
+        (void)hipGetLastError();
+        p.gt_bytes = 0;
+    }
+    RES(d_pend, (size_t)p.pend_cap * sizeof(uint32_t));
+    RES(d_pend_buf, (size_t)p.pend_cap * vtxk_band_pend_words() * sizeof(uint32_t));
+    RES(d_poly, ((size_t)p.hard_cap + p.pend_cap) * p.poly_stride * sizeof(uint16_t));
+    RES(d_band, (size_t)p.slots * 2 * p.band_stride * sizeof(uint16_t));
+    RES(d_hard, ((size_t)p.hard_cap + p.pend_cap) * sizeof(uint32_t));
+    RES(d_over, (size_t)p.n_tasks * sizeof(uint32_t));
+    RES(d_cnt, 32 * sizeof(uint32_t));
+#undef RES
+    return VTX_OK;
+}
+
 int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
     if (!c) return VTX_E_INVAL;
     if (!b) return fail(c, VTX_E_INVAL, "vtx_submit: null batch");
@@ -913,39 +968,13 @@ int vtx_run(vtx_ctx* c) {
         // certificate: writes the score of every certified task) -> hard list -> expand -> band-masked DP writes
         // the hard scores.  Tasks band_run_kernel cannot hold accumulate in ONE overflow list that the general
         // band kernel processes after the last chunk (a launch of a handful of serial lanes costs ~2 ms).
-        const uint64_t n_tasks = 2ull * nr;
-        // One launch covers every task unless a test hook asks for chunks.  Memory: the scratch of band_run_kernel belongs
-        // to its RESIDENT lanes (persistent workgroups), band slots and pending records are sized for a fraction of the
-        // tasks — whatever exceeds them goes to the general kernel's list, which is processed in slices.
-        uint64_t chunk_cap = 1u << 31;
-        if (getenv("VTX_BAND_CHUNK")) chunk_cap = std::max<uint64_t>(256, strtoull(getenv("VTX_BAND_CHUNK"), nullptr, 10));   // test hook
-        const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_tasks, chunk_cap);
-        const uint32_t band_stride = (c->max_hap_len + 2 + 7) & ~7u;
-        // Hard tasks leave band_run_kernel / band_pending_kernel as compact staircase records (192 B); the masked DP expands
-        // them into band slots (2 x band_stride u16) one slice of `slots` tasks at a time.  A quarter of the tasks may be
-        // hard (noisy reads: 11 % at 3 % substitution errors) before anything spills to the general kernel's list.
-        uint32_t hard_cap = (uint32_t)std::min<uint64_t>(chunk, chunk / 4 + (1u << 20));
-        uint32_t pend_cap = (uint32_t)std::min<uint64_t>(chunk, chunk / 8 + (1u << 20));
-        uint32_t slots = (uint32_t)std::min<uint64_t>(chunk, chunk / 16 + (1u << 20));
-        if (getenv("VTX_BAND_HARD_CAP")) hard_cap = pend_cap = slots = std::max(1u, (uint32_t)atoi(getenv("VTX_BAND_HARD_CAP")));   // test hook
-        if (getenv("VTX_BAND_SLOTS")) slots = std::max(1u, (uint32_t)atoi(getenv("VTX_BAND_SLOTS")));                              // test hook
-        const uint32_t poly_stride = vtxk_band_poly_stride();
+        BandPlan bp = band_plan(nr, c->n_loci, c->max_hap_len);
+        if (int rc = band_reserve(c, bp, false)) return rc;
+        const uint64_t n_tasks = bp.n_tasks;
+        const uint32_t chunk = bp.chunk, band_stride = bp.band_stride, hard_cap = bp.hard_cap, pend_cap = bp.pend_cap;
+        const uint32_t slots = bp.slots, poly_stride = bp.poly_stride, tasks_per_locus = bp.tasks_per_locus;
+        const size_t gt_bytes = bp.gt_bytes;
         uint32_t fast_overflow = 0;
-        HIP_TRY(c, c->d_band_ws.reserve((size_t)vtxk_band_run_lanes() * vtxk_band_task_words() * sizeof(uint32_t)));   // per resident lane
-        // shallow loci: the k-mer tables of every locus in global memory, built once per run (0 bytes: tables in LDS)
-        const uint32_t tasks_per_locus = (uint32_t)(n_tasks / std::max(c->n_loci, 1u));
-        size_t gt_bytes = vtxk_band_gtables_bytes(c->n_loci, c->max_hap_len, tasks_per_locus);
-        if (gt_bytes && c->d_gtables.reserve(gt_bytes) != hipSuccess) {     // no room for them: the LDS-table kernels need none
-            (void)hipGetLastError();
-            gt_bytes = 0;
-        }
-        HIP_TRY(c, c->d_pend.reserve((size_t)pend_cap * sizeof(uint32_t)));
-        HIP_TRY(c, c->d_pend_buf.reserve((size_t)pend_cap * vtxk_band_pend_words() * sizeof(uint32_t)));
-        HIP_TRY(c, c->d_poly.reserve(((size_t)hard_cap + pend_cap) * poly_stride * sizeof(uint16_t)));
-        HIP_TRY(c, c->d_band.reserve((size_t)slots * 2 * band_stride * sizeof(uint16_t)));
-        HIP_TRY(c, c->d_hard.reserve(((size_t)hard_cap + pend_cap) * sizeof(uint32_t)));
-        HIP_TRY(c, c->d_over.reserve((size_t)n_tasks * sizeof(uint32_t)));
-        HIP_TRY(c, c->d_cnt.reserve(32 * sizeof(uint32_t)));
         uint32_t* d_cnt = c->d_cnt.as<uint32_t>();        // [0] hard, [1] overflow, [2..7] reasons; [8],[9] general kernel; [10] stats; [11] pending
         int shape = 0;
         while ((uint32_t)(kShapes[shape][0] * kShapes[shape][1]) < c->max_read_len) ++shape;
