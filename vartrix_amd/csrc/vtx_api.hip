@@ -575,6 +575,7 @@ struct BandPlan {
     uint64_t n_tasks = 0;
     uint32_t chunk = 0, band_stride = 0, hard_cap = 0, pend_cap = 0, slots = 0, poly_stride = 0, tasks_per_locus = 0;
     size_t gt_bytes = 0;
+    uint32_t gt_loci = 0;      // loci the table buffer holds (< n_loci: the stage runs in chunks of tasks whose loci fit)
 };
 static BandPlan band_plan(uint32_t nr, uint32_t n_loci, uint32_t max_hap_len) {
     BandPlan p;
@@ -590,7 +591,14 @@ static BandPlan band_plan(uint32_t nr, uint32_t n_loci, uint32_t max_hap_len) {
     if (getenv("VTX_BAND_SLOTS")) p.slots = std::max(1u, (uint32_t)atoi(getenv("VTX_BAND_SLOTS")));                                  // test hook
     p.poly_stride = vtxk_band_poly_stride();
     p.tasks_per_locus = (uint32_t)(p.n_tasks / std::max(n_loci, 1u));
-    p.gt_bytes = vtxk_band_gtables_bytes(n_loci, max_hap_len, p.tasks_per_locus);
+    p.gt_bytes = vtxk_band_gtables_bytes(n_loci, max_hap_len, p.tasks_per_locus, &p.gt_loci);
+    if (p.gt_bytes && p.gt_loci < n_loci) {
+        // chunks of tasks spanning about half the loci the buffer holds (loci differ in depth; a chunk whose loci do not
+        // fit after all takes the LDS-table kernel)
+        const uint64_t t = std::max<uint64_t>(4096, (uint64_t)p.gt_loci * std::max(p.tasks_per_locus, 1u) / 2);
+        p.chunk = (uint32_t)std::min<uint64_t>(p.chunk, t & ~63ull);
+        p.hard_cap = std::min(p.hard_cap, p.chunk); p.pend_cap = std::min(p.pend_cap, p.chunk); p.slots = std::min(p.slots, p.chunk);
+    }
     return p;
 }
 // (hipMalloc of these GBs costs ~0.1 s the first time a context runs.  Doing it on a helper thread during the upload of
@@ -974,6 +982,7 @@ int vtx_run(vtx_ctx* c) {
         const uint32_t chunk = bp.chunk, band_stride = bp.band_stride, hard_cap = bp.hard_cap, pend_cap = bp.pend_cap;
         const uint32_t slots = bp.slots, poly_stride = bp.poly_stride, tasks_per_locus = bp.tasks_per_locus;
         const size_t gt_bytes = bp.gt_bytes;
+        const bool gt_chunked = gt_bytes && bp.gt_loci < c->n_loci;
         uint32_t fast_overflow = 0;
         uint32_t* d_cnt = c->d_cnt.as<uint32_t>();        // [0] hard, [1] overflow, [2..7] reasons; [8],[9] general kernel; [10] stats; [11] pending
         int shape = 0;
@@ -1066,6 +1075,17 @@ int vtx_run(vtx_ctx* c) {
             HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), s));                 // hard count of this chunk
             HIP_TRY(c, hipMemsetAsync(d_cnt + 11, 0, sizeof(uint32_t), s));            // pending count of this chunk
             HIP_TRY(c, hipMemsetAsync(d_cnt + 16, 0, 8 * sizeof(uint32_t), s));        // block counters (one per XCD)
+            // the loci of this range of tasks (tables in global memory are built per range)
+            uint32_t gt_l0 = 0, gt_n = gt_bytes ? c->n_loci : 0;
+            if (gt_chunked) {
+                uint32_t ends[2];
+                HIP_TRY(c, hipMemcpyAsync(&ends[0], c->d_rec_locus.as<uint32_t>() + base / 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipMemcpyAsync(&ends[1], c->d_rec_locus.as<uint32_t>() + (base + nt - 1) / 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipStreamSynchronize(s));
+                gt_l0 = ends[0];
+                gt_n = ends[1] - ends[0] + 1;
+                if (gt_n > bp.gt_loci) gt_n = 0;              // does not fit after all: tables in LDS for this chunk
+            }
             HIP_TRY(c, hipEventRecord(c->ev[4], s));
             HIP_TRY(c, vtxk_launch_band_run(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                              c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
@@ -1073,7 +1093,7 @@ int vtx_run(vtx_ctx* c) {
                                              c->d_band_ws.as<uint32_t>(), c->d_poly.as<uint16_t>(), poly_stride / 2,
                                              c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
                                              c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt,
-                                             tasks_per_locus, c->n_loci, gt_bytes ? c->d_gtables.as<uint8_t>() : nullptr, gt_bytes, s));
+                                             tasks_per_locus, gt_l0, gt_n, gt_n ? c->d_gtables.as<uint8_t>() : nullptr, gt_bytes, s));
             HIP_TRY(c, hipEventRecord(c->ev[5], s));
             HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));

@@ -824,15 +824,16 @@ __device__ __forceinline__ void build_tables(uint8_t* tables, uint32_t n_tab, ui
         __syncthreads();
 }
 
-// One workgroup (one wavefront) per locus: both tables in LDS, then copied to gtables[locus * 2 * table_stride].
-__global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __restrict__ loci, uint32_t n_loci,
+// One workgroup (one wavefront) per locus of [l0, l0 + n_loci): both tables in LDS, then copied to
+// gtables[(locus - l0) * 2 * table_stride].
+__global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __restrict__ loci, uint32_t l0, uint32_t n_loci,
                                                          const uint8_t* __restrict__ hap_arena, uint32_t max_hap,
                                                          uint32_t table_stride, uint32_t n_heads, uint8_t* __restrict__ gtables) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t s_hibyte;
     const int tid = threadIdx.x;
     for (uint32_t l = blockIdx.x; l < n_loci; l += gridDim.x) {
-        build_tables<64>((uint8_t*)smem, 2, l, loci, hap_arena, max_hap, table_stride, n_heads, tid, s_hibyte);
+        build_tables<64>((uint8_t*)smem, 2, l0 + l, loci, hap_arena, max_hap, table_stride, n_heads, tid, s_hibyte);
         const uint4* src = (const uint4*)smem;
         uint4* dst = (uint4*)(gtables + (size_t)l * 2 * table_stride);
         for (uint32_t i = tid; i < 2 * table_stride / 16; i += 64) dst[i] = src[i];
@@ -850,7 +851,7 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
     uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ pending_list,
     uint32_t* __restrict__ pend_buf, uint32_t hard_cap, uint32_t pend_cap,
     uint32_t* __restrict__ counters, uint32_t ablate, uint32_t n_heads, const uint8_t* __restrict__ gtables,
-    uint32_t xcd_claim) {
+    uint32_t gt_l0, uint32_t xcd_claim) {
     // GT: the tables of every locus were built by band_tables_kernel in global memory (shallow loci: a wavefront's 64
     // tasks span many loci, tables in LDS cost the occupancy); !GT: built here, per block, in LDS
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -932,12 +933,26 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
         done = true;
         // ---- this lane's table ----
         const uint8_t* tb;
-        if constexpr (GT) tb = gtables + ((size_t)my_locus * 2 + hap) * table_stride;
+        if constexpr (GT) tb = gtables + ((size_t)(my_locus - gt_l0) * 2 + hap) * table_stride;
         else tb = tables + (size_t)((my_locus - lbase) * 2 + hap) * table_stride;
         const uint2* ent = TB_ENT(tb);
         const uint16_t* head = TB_HEAD(tb);
         const uint8_t* yb = TB_BYTES(tb);
         const uint8_t* fb = TB_FB(tb);
+        // GT: one uniform base (gtables, in scalar registers) + a 32-bit per-lane offset — the loads take the
+        // scalar-base addressing form and the lanes do 32-bit arithmetic (tables <= 4 GB: vtxk_band_gtables_bytes)
+        const uint32_t t_ent = GT ? (uint32_t)(((size_t)(my_locus - gt_l0) * 2 + hap) * table_stride) : 0u;
+        const uint32_t t_head = t_ent + max_hap * 8u;
+        const uint32_t t_fb = t_head + n_heads * 2u + max_hap + 8u;
+        auto ENT = [&](uint32_t i) -> uint2 {
+            if constexpr (GT) return *(const uint2*)(gtables + (size_t)(t_ent + i * 8u)); else return ent[i];
+        };
+        auto HEAD = [&](uint32_t i) -> uint32_t {
+            if constexpr (GT) return *(const uint16_t*)(gtables + (size_t)(t_head + i * 2u)); else return head[i];
+        };
+        auto FB = [&](uint32_t i) -> uint32_t {
+            if constexpr (GT) return gtables[(size_t)(t_fb + i)]; else return fb[i];
+        };
         if (m < KMER || n < KMER) { PUSH_FULL_MATRIX() continue; }    // no k-mer: Band::full_matrix
         if (ablate == 1) continue;                           // (profiling aid) table build only
         if (ablate == 2) {                                   // (profiling aid) probe loop only
@@ -987,7 +1002,7 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
             uint32_t wlo = (uint32_t)wA;                                     // k-mer word of row xr
             uint32_t whi = (uint32_t)(wA >> 32) & 0xffffu;
             uint32_t xr = 0;
-            uint32_t ycur = head[kw_hash(wlo, whi, hmask)];                  // chain cursor of row xr
+            uint32_t ycur = HEAD(kw_hash(wlo, whi, hmask));                  // chain cursor of row xr
             bool live = true;
             bool service;
             do {
@@ -1008,7 +1023,7 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
                     // ---- everything either kind of unit reads from LDS, requested together: one round trip per unit.
                     //      (The kernel waits on LDS latency, not on VALU issue: the lanes of the other kind compute a
                     //      few addresses they do not need.) ----
-                    const uint2 e = ent[chain ? ycur : 0u];                          // chain step: the entry
+                    const uint2 e = ENT(chain ? ycur : 0u);                          // chain step: the entry
                     const uint32_t xn = xr + 1;                                       // advance: next row ...
                     const uint32_t bi = xn + KMER - 1;                                // ... the base that enters its k-mer
                     const uint32_t woff = bi - wbase;                                 // 0 .. 15 by the refill rule
@@ -1016,11 +1031,11 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
                     const uint32_t nb = (uint32_t)(wsrc >> (8 * (woff & 7u))) & 0xffu;
                     const uint32_t nwlo = (wlo >> 8) | (whi << 24);
                     const uint32_t nwhi = ((whi >> 8) & 0xff) | (nb << 8);
-                    const uint32_t hd = head[kw_hash(nwlo, nwhi, hmask)];             // ... its bucket
+                    const uint32_t hd = HEAD(kw_hash(nwlo, nwhi, hmask));             // ... its bucket
                     const uint32_t aid = a_nx;                                        // ... where piece a would continue
                     const uint32_t ay = aid & 0xffffu;
                     const bool a_ok = a_idx != NONE_ID && (aid >> 16) == xn && ay + KMER <= n;
-                    const uint32_t fbv = fb[a_ok ? ay + KMER - 1 : 0u];               // ... flag byte of that k-mer's last base
+                    const uint32_t fbv = FB(a_ok ? ay + KMER - 1 : 0u);               // ... flag byte of that k-mer's last base
                     asm volatile("" ::"v"(e.x), "v"(e.y), "v"(hd), "v"(fbv));        // all three loads before either branch
                     if (chain) {
                         // ---- unit: one chain entry of row xr ----
@@ -1421,11 +1436,18 @@ static uint32_t pick_heads(uint32_t tasks_per_locus, bool global_tables) {
     return global_tables ? 1024 : 512;       // no LDS to fit: shorter chains (2048: no further gain)
 }
 
-// bytes of the global table buffer vtxk_launch_band_run wants for this shape of data (0: tables live in LDS)
-extern "C" size_t vtxk_band_gtables_bytes(uint32_t n_loci, uint32_t max_hap, uint32_t tasks_per_locus) {
+// Global table buffer for this shape of data: bytes to reserve (0: tables live in LDS) and how many loci they hold.  The
+// kernel addresses the tables with 32-bit offsets: at most 4 GB, i.e. ~400 k deep / ~580 k shallow loci at padding 100 —
+// a batch with more loci runs the banded stage in chunks of tasks whose loci fit (vtx_run).
+extern "C" size_t vtxk_band_gtables_bytes(uint32_t n_loci, uint32_t max_hap, uint32_t tasks_per_locus, uint32_t* loci_cap) {
+    if (loci_cap) *loci_cap = 0;
     if (tasks_per_locus >= gt_max_tpl()) return 0;
-    const size_t need = (size_t)n_loci * 2 * band_table_stride(max_hap, pick_heads(tasks_per_locus, true));
-    return need <= ((size_t)24 << 30) ? need : 0;
+    const size_t per_locus = 2 * band_table_stride(max_hap, pick_heads(tasks_per_locus, true));
+    size_t cap = ((size_t)4 << 30) - 65536;
+    if (getenv("VTX_BAND_GT_BYTES")) cap = std::max<size_t>(per_locus, strtoull(getenv("VTX_BAND_GT_BYTES"), nullptr, 10));   // test hook
+    const size_t hold = std::min<size_t>(n_loci, cap / per_locus);
+    if (loci_cap) *loci_cap = (uint32_t)hold;
+    return hold * per_locus;
 }
 
 // persistent grid of band_run_kernel<nt, ., wpe>: what the chip holds (wavefronts per SIMD x 4 SIMDs x 256 CUs)
@@ -1438,8 +1460,10 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
                                            int32_t* alt_score, uint32_t* logbuf, uint16_t* band,
                                            uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
                                            uint32_t* pending_list, uint32_t* pend_buf, uint32_t hard_cap, uint32_t pend_cap,
-                                           uint32_t* counters, uint32_t tasks_per_locus, uint32_t n_loci, uint8_t* gtables,
-                                           size_t gtables_bytes, hipStream_t s) {
+                                           uint32_t* counters, uint32_t tasks_per_locus, uint32_t gt_l0, uint32_t n_loci,
+                                           uint8_t* gtables, size_t gtables_bytes, hipStream_t s) {
+    // gtables != nullptr: room for the tables of loci [gt_l0, gt_l0 + n_loci) — the loci of THIS range of tasks; they are
+    // built here, then read by the kernel
     if (!n_tasks) return hipSuccess;
     // (LDS-table variants, the fallback:) deep data (>= 64 tasks per locus): 256-task workgroups.  A workgroup processes its loci in passes of `tables / 2`
     // loci (the k-mer tables live in LDS); in a pass only the lanes of those loci work.  512-entry head arrays: two loci
@@ -1481,10 +1505,9 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     if (tables > 32) tables = 32;
     const size_t shmem = lane_bytes + (global_tables ? 0 : (size_t)tables * tstride);
     if (shmem > 160 * 1024 - 256) return hipErrorInvalidValue;
-    if (global_tables && task_base == 0) {       // (a chunked run builds them with its first chunk)
-        hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(n_loci, 256u * 16u)), dim3(64), 2 * tstride, s, loci, n_loci,
+    if (global_tables)
+        hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(n_loci, 256u * 16u)), dim3(64), 2 * tstride, s, loci, gt_l0, n_loci,
                            hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
-    }
     const uint32_t ablate = (uint32_t)(getenv("VTX_BAND_ABLATE") ? atoi(getenv("VTX_BAND_ABLATE")) : 0);
     const uint32_t xcd_claim = ((tasks_per_locus >= 24 || getenv("VTX_BAND_XCD")) && !getenv("VTX_BAND_NO_XCD")) ? 1u : 0u;   // (measured: config 3 -3 %, 64 / 32 reads per locus -4.5 %, 16: -1 %, 4: +2 %)
 #define LAUNCH_RUN(NTV, GTV, WV)                                                                                     \
@@ -1500,7 +1523,7 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
                            task_base, records, rec_locus, loci, read_arena, hap_arena, max_hap, tables,              \
                            (uint32_t)tstride, ref_score, alt_score, logbuf, band, band_stride, hard_list,            \
                            overflow_list, pending_list, pend_buf, hard_cap, pend_cap, counters, ablate, n_heads,     \
-                           (const uint8_t*)gtables, xcd_claim);                                                      \
+                           (const uint8_t*)gtables, gt_l0, xcd_claim);                                               \
     }
     // wavefronts per SIMD: 4 with the tables in LDS (111 VGPRs; 5 -> 93 VGPRs cost more than the occupancy gave, 3 less
     // still); the global-table variants wait on L2 / HBM instead of LDS and take 5 (measured: 16 reads per locus +6 %,
