@@ -622,7 +622,7 @@ static int band_reserve(vtx_ctx* c, BandPlan& p, bool quiet) {
     RES(d_poly, ((size_t)p.hard_cap + p.pend_cap) * p.poly_stride * sizeof(uint16_t));
     RES(d_band, (size_t)p.slots * 2 * p.band_stride * sizeof(uint16_t));
     RES(d_hard, ((size_t)p.hard_cap + p.pend_cap) * sizeof(uint32_t));
-    RES(d_over, (size_t)p.n_tasks * sizeof(uint32_t));
+    RES(d_over, 2 * (size_t)p.n_tasks * sizeof(uint32_t));      // second chance: what overflows again is appended behind the first list
     RES(d_cnt, 32 * sizeof(uint32_t));
 #undef RES
     return VTX_OK;
@@ -1069,7 +1069,7 @@ int vtx_run(vtx_ctx* c) {
         };
         HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 32 * sizeof(uint32_t), s));
         uint32_t cnt[12] = {0};
-        uint32_t pending_total = 0;
+        uint32_t pending_total = 0, over_before = 0;
         for (uint64_t base = 0; base < n_tasks; base += chunk) {
             const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, n_tasks - base);
             HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), s));                 // hard count of this chunk
@@ -1093,9 +1093,33 @@ int vtx_run(vtx_ctx* c) {
                                              c->d_band_ws.as<uint32_t>(), c->d_poly.as<uint16_t>(), poly_stride / 2,
                                              c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
                                              c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt,
-                                             tasks_per_locus, gt_l0, gt_n, gt_n ? c->d_gtables.as<uint8_t>() : nullptr, gt_bytes, s));
-            HIP_TRY(c, hipEventRecord(c->ev[5], s));
+                                             tasks_per_locus, gt_l0, gt_n, gt_n ? c->d_gtables.as<uint8_t>() : nullptr, gt_bytes,
+                                             nullptr, s));
             HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            if (gt_n && vtxk_band_second_chance(tasks_per_locus) && cnt[1] > over_before) {
+                // The six-wavefront variant keeps 12-entry lists: the tasks that overflowed them ([a0, a1) of the overflow
+                // list) get a second chance in the 15-entry variant before the general kernel — what overflows again is
+                // appended behind a1 and then moved down to a0.
+                const uint32_t a0 = over_before, a1 = cnt[1];
+                HIP_TRY(c, hipMemsetAsync(d_cnt + 16, 0, 8 * sizeof(uint32_t), s));
+                HIP_TRY(c, vtxk_launch_band_run(a1 - a0, 0, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                 c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                                 c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
+                                                 c->d_band_ws.as<uint32_t>(), c->d_poly.as<uint16_t>(), poly_stride / 2,
+                                                 c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
+                                                 c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt, tasks_per_locus, gt_l0,
+                                                 gt_n, c->d_gtables.as<uint8_t>(), gt_bytes, c->d_over.as<uint32_t>() + a0, s));
+                HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipStreamSynchronize(s));
+                const uint32_t again = cnt[1] - a1;          // <= a1 - a0: source and destination do not overlap
+                if (again) HIP_TRY(c, hipMemcpyAsync(c->d_over.as<uint32_t>() + a0, c->d_over.as<uint32_t>() + a1, (size_t)again * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+                cnt[1] = a0 + again;
+                HIP_TRY(c, hipMemcpyAsync(d_cnt + 1, cnt + 1, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+                ++launches;
+            }
+            over_before = cnt[1];
+            HIP_TRY(c, hipEventRecord(c->ev[5], s));
             HIP_TRY(c, hipStreamSynchronize(s));
             {
                 float ms = 0;

@@ -385,13 +385,17 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
 #ifndef VTX_WPE
 #define VTX_WPE 4   // wavefronts per SIMD band_run_kernel is compiled and launched for
 #endif
-#define PS VTX_PS   // per-lane LDS entries of band_run_kernel: pieces + segments
+// PSV (template parameter of band_run_kernel and its list functions): per-lane LDS entries, pieces + segments.
+// 15 at five wavefronts per SIMD (7.7 KiB per wavefront), 12 at six (6.1 KiB) — VTX_PS is the default / LDS-table value.
 #define LG 64       // jump-log entries per task (global)
-#define SPILL (32 - PS)   // pieces run_compact may drop from a task's list and still leave it to the pending kernel (global): list + spill = the 32 lanes of band_pending_kernel
-#define TASK_WORDS (LG * 2 + SPILL * 2)   // scratch of one RESIDENT lane (global, reused block after block): jump log, spilled pieces
-#define PEND_WORDS (2 + 2 * PS + (4 * SG + 6) + 2 * SPILL)   // record of a pending task: header, cert, list, staircase, spill
+// pieces run_compact may drop from a task's list and still leave it to the pending kernel: list + spill = the 32 lanes of
+// band_pending_kernel
+#define SPILL_OF(psv) (32 - (psv))
+#define PS_MIN 12
+#define TASK_WORDS (LG * 2 + SPILL_OF(PS_MIN) * 2)   // scratch of one RESIDENT lane (global, reused block after block): jump log, spilled pieces
+#define PEND_WORDS (2 + 2 * 32 + (4 * SG + 6))       // record of a pending task: header, cert, 32 pieces (list entries, then spilled ones), staircase
 #define SG 10       // chain segments per task
-static_assert(VTX_PS >= 8 && VTX_PS <= 24, "list + spill entries of a task are the 32 lanes of band_pending_kernel");
+static_assert(VTX_PS >= PS_MIN && VTX_PS <= 24, "list + spill entries of a task are the 32 lanes of band_pending_kernel");
 #define NONE_ID 0xffffffffu
 #define CH_END 0xffffu     // end of a k-mer chain / empty bucket
 
@@ -560,7 +564,7 @@ __device__ void run_pair_events(run_state& st, const uint32_t* e_id, const uint3
 }
 
 // Process, in match order, every event and every piece start with id < limit.
-template <int NT>
+template <int NT, int PSV>
 __device__ void run_advance(run_state& st, uint32_t* e_id, uint32_t* e_dl, int tid, uint32_t limit, uint32_t& open_a,
                             uint32_t& open_b, uint32_t* mylog) {
     while (!st.overflow) {
@@ -594,7 +598,7 @@ __device__ void run_advance(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
             const int32_t cand = bV - 5 - (mx + my) + KMER;
             if (cand <= (int32_t)(edp + t)) continue;          // continuation wins (ties included)
             // breakpoint: split segment e at t; the tail becomes a new segment (keeps e's open status if it was open)
-            if (st.n_ent == PS || st.lg_n == LG) { st.overflow = true; st.why = st.lg_n == LG ? 5 : 3; break; }
+            if (st.n_ent == PSV || st.lg_n == LG) { st.overflow = true; st.why = st.lg_n == LG ? 5 : 3; break; }
             e_dl[e * NT + tid] = (edp << 16) | t;
             e_id[st.n_ent * NT + tid] = mid;
             e_dl[st.n_ent * NT + tid] = ((uint32_t)cand << 16) | (elen - t);
@@ -637,7 +641,7 @@ __device__ void run_advance(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
 // Drop started, closed segments none of whose elements can win a query any more (2*(len-1) < x - x0 - dp0 - 1,
 // or dominated by an element of another segment);
 // their ends are folded into the running best first.  Updates the indices of the two open pieces.
-template <int NT>
+template <int NT, int PSV>
 __device__ void run_compact(run_state& st, uint32_t* e_id, uint32_t* e_dl, int tid, uint32_t xr, uint32_t& a_idx,
                             uint32_t& b_idx, uint32_t* spill) {
     uint32_t w = 0, na = NONE_ID, nb = NONE_ID, ni = NONE_ID;
@@ -678,7 +682,7 @@ __device__ void run_compact(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
             const uint32_t eid = sid + (uint32_t)(len - 1) * 0x10001u;
             if (v > st.best_v || (v == st.best_v && eid > st.best_id)) { st.best_v = v; st.best_id = eid; }
             // the upper bound needs every piece: park the dropped one (start, k-mers) behind the jump log
-            if (st.n_sp < SPILL) { spill[st.n_sp * (2 * NT)] = sid; spill[st.n_sp * (2 * NT) + 1] = (uint32_t)len; ++st.n_sp; }
+            if (st.n_sp < SPILL_OF(PSV)) { spill[st.n_sp * (2 * NT)] = sid; spill[st.n_sp * (2 * NT) + 1] = (uint32_t)len; ++st.n_sp; }
             else st.ub_ok = false;
             continue;
         }
@@ -840,7 +844,7 @@ __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __rest
     }
 }
 
-template <int NT, bool GT, int WPE>
+template <int NT, bool GT, int WPE, int PSV>
 __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
     uint32_t n_tasks, uint32_t task_base,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
@@ -851,7 +855,9 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
     uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ pending_list,
     uint32_t* __restrict__ pend_buf, uint32_t hard_cap, uint32_t pend_cap,
     uint32_t* __restrict__ counters, uint32_t ablate, uint32_t n_heads, const uint8_t* __restrict__ gtables,
-    uint32_t gt_l0, uint32_t xcd_claim) {
+    uint32_t gt_l0, uint32_t xcd_claim, const uint32_t* __restrict__ task_list) {
+    // task_list != nullptr (GT only): the tasks are task_list[0 .. n_tasks) instead of task_base + 0 .. n_tasks — the second
+    // chance of the tasks whose 12-entry lists overflowed, in the 15-entry variant
     // GT: the tables of every locus were built by band_tables_kernel in global memory (shallow loci: a wavefront's 64
     // tasks span many loci, tables in LDS cost the occupancy); !GT: built here, per block, in LDS
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -861,8 +867,8 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
     // staircase of ended matches, stored as RUNS: elements (ye0 + t, V0 + 3t, id0 + t*(1,1)), t < len
     // (a continued k-mer adds +1 to ye and, with dp + 1, +3 to V = dp + xe + ye)
     uint32_t* pm_a = smem;                     // parked segments: id0 = x0 << 16 | y0
-    uint32_t* pm_id = pm_a + PS * NT;         //                  dp0 << 16 | len
-    uint8_t* tables = (uint8_t*)(pm_id + PS * NT);
+    uint32_t* pm_id = pm_a + PSV * NT;        //                  dp0 << 16 | len
+    uint8_t* tables = (uint8_t*)(pm_id + PSV * NT);
 #define PM_A(i) pm_a[(i) * NT + tid]
 #define PM_ID(i) pm_id[(i) * NT + tid]
 
@@ -899,7 +905,7 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
     if (blk == 0xffffffffu) break;
     const uint32_t slot = blk * NT + tid;
     const bool have = slot < n_tasks;
-    const uint32_t task = task_base + slot;
+    const uint32_t task = (GT && task_list) ? (have ? task_list[slot] : 0u) : task_base + slot;
     uint32_t rid = 0, hap = 0, my_locus = 0, m = 0, n = 0;
     const uint8_t* x = nullptr;
     if (have) {
@@ -926,7 +932,7 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
                              if (h_ < hard_cap) { hard_list[h_] = task; band[(size_t)h_ * 2 * band_stride] = BAND_FULL_MATRIX; } \
                              else overflow_list[atomicAdd(&counters[1], 1u)] = task; }
 
-    for (uint32_t lbase = l_first; lbase <= l_last; lbase += loci_per_pass) {
+    for (uint32_t lbase = GT ? 0u : l_first; lbase <= (GT ? 0u : l_last); lbase += loci_per_pass) {     // GT: one pass over every locus
         const uint32_t n_tab = GT ? 0u : min(loci_per_pass, l_last - lbase + 1) * 2;
         if constexpr (!GT) build_tables<NT>(tables, n_tab, lbase, loci, hap_arena, max_hap, table_stride, n_heads, tid, s_hibyte);
         if (done || my_locus < lbase || my_locus >= lbase + loci_per_pass) continue;
@@ -1051,7 +1057,7 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
                                 t = a_idx; a_idx = b_idx; b_idx = t;
                                 t = a_nx; a_nx = b_nx; b_nx = t;
                                 t = a_len; a_len = b_len; b_len = t;
-                            } else if (st.n_ent == PS) {
+                            } else if (st.n_ent == PSV) {
                                 service = true; pend_id = id;
                             } else {
                                 if (b_idx != NONE_ID) pm_id[b_idx * NT + tid] = (pm_id[b_idx * NT + tid] & 0xffff0000u) | b_len;
@@ -1078,9 +1084,9 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
                     // then open the pending piece and resume the probe where it stopped
                     if (a_idx != NONE_ID) pm_id[a_idx * NT + tid] = (pm_id[a_idx * NT + tid] & 0xffff0000u) | a_len;
                     if (b_idx != NONE_ID) pm_id[b_idx * NT + tid] = (pm_id[b_idx * NT + tid] & 0xffff0000u) | b_len;
-                    run_advance<NT>(st, pm_a, pm_id, tid, pend_id, a_idx, b_idx, mylog);
-                    if (!st.overflow) run_compact<NT>(st, pm_a, pm_id, tid, xr, a_idx, b_idx, mylog + LG * (2 * NT));
-                    if (st.n_ent == PS && !st.overflow) { st.overflow = true; st.why = 2; }
+                    run_advance<NT, PSV>(st, pm_a, pm_id, tid, pend_id, a_idx, b_idx, mylog);
+                    if (!st.overflow) run_compact<NT, PSV>(st, pm_a, pm_id, tid, xr, a_idx, b_idx, mylog + LG * (2 * NT));
+                    if (st.n_ent == PSV && !st.overflow) { st.overflow = true; st.why = 2; }
                     if (!st.overflow) {
                         // a breakpoint may have split an open piece and compaction renumbers: reload the register copies
                         if (a_idx != NONE_ID) { a_len = pm_id[a_idx * NT + tid] & 0xffff; a_nx = pm_a[a_idx * NT + tid] + a_len * 0x10001u; }
@@ -1104,7 +1110,7 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
         // ================= phase 2: the rest of the chain DP =================
         if (!overflow) {
             uint32_t no_a = NONE_ID, no_b = NONE_ID;
-            run_advance<NT>(st, pm_a, pm_id, tid, NONE_ID, no_a, no_b, mylog);
+            run_advance<NT, PSV>(st, pm_a, pm_id, tid, NONE_ID, no_a, no_b, mylog);
             overflow = st.overflow; why = st.why;
             // best match = end of the segment with the largest (dp, index)
             for (uint32_t j = 0; j < st.n_ent && !overflow; ++j) {
@@ -1119,7 +1125,7 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
         if (overflow) { overflow_list[atomicAdd(&counters[1], 1u)] = task; atomicAdd(&counters[2 + why], 1u); continue; }
         // ================= certificate: chain-of-runs upper bound vs the staircase's own score =================
         // Tasks whose list lost pieces to run_compact cannot bound here: their pieces (list + spill area) go to
-        // band_pending_kernel, which computes the same bound with a wavefront's lanes over up to PS + SPILL pieces.
+        // band_pending_kernel, which computes the same bound with a wavefront's lanes over up to 32 pieces.
         const bool pending = st.ub_ok && st.n_sp > 0;
         const int32_t ub = (st.ub_ok && !pending) ? run_ub<NT>(pm_a, pm_id, tid, st.n_ent) : INT32_MAX;
         if (ablate == 4) { if (ub == -1) counters[7] = 1; continue; }   // (profiling aid) everything but the staircase walk
@@ -1142,8 +1148,8 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
                 prec[2 + 2 * j] = pm_a[j * NT + tid];
                 prec[3 + 2 * j] = pm_id[j * NT + tid] & 0xffffu;
             }
-            for (uint32_t i = 0; i < nv; ++i) prec[2 + 2 * PS + i] = verts[i];
-            for (uint32_t i = 0; i < 2 * st.n_sp; ++i) prec[2 + 2 * PS + (4 * SG + 6) + i] = mylog[(LG + (i >> 1)) * (2 * NT) + (i & 1)];
+            for (uint32_t i = 0; i < 2 * st.n_sp; ++i) prec[2 + 2 * st.n_ent + i] = mylog[(LG + (i >> 1)) * (2 * NT) + (i & 1)];
+            for (uint32_t i = 0; i < nv; ++i) prec[2 + 2 * 32 + i] = verts[i];
             pending_list[pi] = task;
             continue;
         }
@@ -1183,10 +1189,10 @@ __global__ __launch_bounds__(256) void band_pending_kernel(
     uint32_t hdr = 0; int32_t cert = 0;
     if (have) { hdr = area[0]; cert = (int32_t)area[1]; }
     const uint32_t n_ent = hdr & 0xff, n_sp = (hdr >> 8) & 0xff, nv = hdr >> 16;
-    const uint32_t n = n_ent + n_sp;                    // <= PS + SPILL = 32
+    const uint32_t n = n_ent + n_sp;                    // <= 32: list entries, then spilled pieces
     uint32_t id = 0; int32_t len = 0;
     if ((uint32_t)l < n) {
-        const uint32_t* e = (uint32_t)l < n_ent ? area + 2 + 2 * l : area + 2 + 2 * PS + (4 * SG + 6) + 2 * (l - n_ent);
+        const uint32_t* e = area + 2 + 2 * l;
         id = e[0]; len = (int32_t)e[1] + KMER - 1;
     }
     const int32_t xp = (int32_t)(id >> 16), yp = (int32_t)(id & 0xffff);
@@ -1245,7 +1251,7 @@ __global__ __launch_bounds__(256) void band_pending_kernel(
     uint16_t* lo = band + (size_t)h * 2 * band_stride;
     if (l == 0) { lo[0] = BAND_POLYLINE; lo[1] = (uint16_t)nv; }
     uint32_t* vout = (uint32_t*)(lo + 2);
-    for (uint32_t i = l; i < nv; i += 32) vout[i] = area[2 + 2 * PS + i];
+    for (uint32_t i = l; i < nv; i += 32) vout[i] = area[2 + 2 * 32 + i];
 }
 
 extern "C" uint32_t vtxk_band_task_words(void) { return TASK_WORDS; }
@@ -1450,9 +1456,16 @@ extern "C" size_t vtxk_band_gtables_bytes(uint32_t n_loci, uint32_t max_hap, uin
     return hold * per_locus;
 }
 
+// 1: vtxk_launch_band_run picks the six-wavefront / 12-entry variant for this shape — its overflow list deserves a second
+// chance in the 15-entry variant (task_list mode) before the general kernel
+extern "C" int vtxk_band_second_chance(uint32_t tasks_per_locus) {
+    const uint32_t w6 = getenv("VTX_BAND_W6_MIN_TPL") ? (uint32_t)atoi(getenv("VTX_BAND_W6_MIN_TPL")) : 80u;
+    return tasks_per_locus >= w6 && tasks_per_locus < gt_max_tpl() && !getenv("VTX_BAND_NO_SECOND_CHANCE");
+}
+
 // persistent grid of band_run_kernel<nt, ., wpe>: what the chip holds (wavefronts per SIMD x 4 SIMDs x 256 CUs)
 extern "C" uint32_t vtxk_band_run_grid(uint32_t nt, uint32_t wpe) { return 256u * (nt == 64 ? 4u * wpe : wpe); }
-extern "C" uint32_t vtxk_band_run_lanes(void) { return 256u * 256u * (uint32_t)std::max(VTX_WPE, 5); }     // max over both block sizes of grid x nt
+extern "C" uint32_t vtxk_band_run_lanes(void) { return 256u * 256u * (uint32_t)std::max(VTX_WPE, 6); }     // max over both block sizes of grid x nt
 
 extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
                                            const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
@@ -1461,7 +1474,7 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
                                            uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
                                            uint32_t* pending_list, uint32_t* pend_buf, uint32_t hard_cap, uint32_t pend_cap,
                                            uint32_t* counters, uint32_t tasks_per_locus, uint32_t gt_l0, uint32_t n_loci,
-                                           uint8_t* gtables, size_t gtables_bytes, hipStream_t s) {
+                                           uint8_t* gtables, size_t gtables_bytes, const uint32_t* task_list, hipStream_t s) {
     // gtables != nullptr: room for the tables of loci [gt_l0, gt_l0 + n_loci) — the loci of THIS range of tasks; they are
     // built here, then read by the kernel
     if (!n_tasks) return hipSuccess;
@@ -1488,7 +1501,15 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     const bool global_tables = want_global && (size_t)n_loci * 2 * tstride <= gtables_bytes;
     const bool wave_wg = global_tables || tasks_per_locus < 64;
     const uint32_t nt = wave_wg ? 64 : 256;
-    const size_t lane_bytes = (size_t)(2 * PS) * nt * 4;
+    // wavefronts per SIMD and list entries per lane.  Tables in LDS: 4 x 15 (111 VGPRs; 5 -> 93 VGPRs cost more than the
+    // occupancy gave, 3 less still).  Tables in global memory: the lanes wait on L2 / HBM instead of LDS and LDS holds
+    // only the lists — 6 x 12 for deeper loci (config 3: band_run 45.0 -> 39.9 ms; the shorter lists send 2.7x the
+    // tasks to the general kernel, still -2.5 ms per step), 5 x 15 for shallower ones (16 reads per locus: 6.9 vs 7.7 ms),
+    // 4 x 15 when the grid does not fill the chip anyway.
+    static const uint32_t w6_min_tpl = getenv("VTX_BAND_W6_MIN_TPL") ? (uint32_t)atoi(getenv("VTX_BAND_W6_MIN_TPL")) : 80u;   // experiment knob (crossover between 32 and 48 reads per locus)
+    const int variant = !global_tables ? 0 : (task_list ? 2 : (tasks_per_locus < 16 ? 1 : (tasks_per_locus < w6_min_tpl ? 2 : 3)));
+    const uint32_t psv = variant == 3 ? 12u : (uint32_t)VTX_PS;
+    const size_t lane_bytes = (size_t)(2 * psv) * nt * 4;
     uint32_t tables;
     if (global_tables) {
         tables = 2;
@@ -1505,31 +1526,31 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     if (tables > 32) tables = 32;
     const size_t shmem = lane_bytes + (global_tables ? 0 : (size_t)tables * tstride);
     if (shmem > 160 * 1024 - 256) return hipErrorInvalidValue;
-    if (global_tables)
+    if (task_list && !global_tables) return hipErrorInvalidValue;    // (list mode reads the tables the first pass built)
+    if (global_tables && !task_list)
         hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(n_loci, 256u * 16u)), dim3(64), 2 * tstride, s, loci, gt_l0, n_loci,
                            hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
     const uint32_t ablate = (uint32_t)(getenv("VTX_BAND_ABLATE") ? atoi(getenv("VTX_BAND_ABLATE")) : 0);
     const uint32_t xcd_claim = ((tasks_per_locus >= 24 || getenv("VTX_BAND_XCD")) && !getenv("VTX_BAND_NO_XCD")) ? 1u : 0u;   // (measured: config 3 -3 %, 64 / 32 reads per locus -4.5 %, 16: -1 %, 4: +2 %)
-#define LAUNCH_RUN(NTV, GTV, WV)                                                                                     \
+#define LAUNCH_RUN(NTV, GTV, WV, PV)                                                                                 \
     {                                                                                                                \
         if (shmem > 48 * 1024) {                                                                                     \
-            hipError_t e = hipFuncSetAttribute((const void*)band_run_kernel<NTV, GTV, WV>,                           \
+            hipError_t e = hipFuncSetAttribute((const void*)band_run_kernel<NTV, GTV, WV, PV>,                       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);              \
             if (e != hipSuccess) return e;                                                                           \
         }                                                                                                            \
-        hipLaunchKernelGGL((band_run_kernel<NTV, GTV, WV>),                                                          \
+        hipLaunchKernelGGL((band_run_kernel<NTV, GTV, WV, PV>),                                                      \
                            dim3(std::min((n_tasks + NTV - 1) / NTV, vtxk_band_run_grid(NTV, WV))),                    \
                            dim3(NTV), shmem, s, n_tasks,                                                             \
                            task_base, records, rec_locus, loci, read_arena, hap_arena, max_hap, tables,              \
                            (uint32_t)tstride, ref_score, alt_score, logbuf, band, band_stride, hard_list,            \
                            overflow_list, pending_list, pend_buf, hard_cap, pend_cap, counters, ablate, n_heads,     \
-                           (const uint8_t*)gtables, gt_l0, xcd_claim);                                               \
+                           (const uint8_t*)gtables, gt_l0, task_list ? 0u : xcd_claim, task_list);                   \
     }
-    // wavefronts per SIMD: 4 with the tables in LDS (111 VGPRs; 5 -> 93 VGPRs cost more than the occupancy gave, 3 less
-    // still); the global-table variants wait on L2 / HBM instead of LDS and take 5 (measured: 16 reads per locus +6 %,
-    // 64 reads per locus +12 %), except the very shallow case, where the grid does not fill the chip anyway
-    if (global_tables) { if (tasks_per_locus < 16) LAUNCH_RUN(64, true, 4) else LAUNCH_RUN(64, true, 5) }
-    else if (wave_wg) LAUNCH_RUN(64, false, VTX_WPE) else LAUNCH_RUN(256, false, VTX_WPE)
+    if (variant == 1) LAUNCH_RUN(64, true, 4, VTX_PS)
+    else if (variant == 2) LAUNCH_RUN(64, true, 5, VTX_PS)
+    else if (variant == 3) LAUNCH_RUN(64, true, 6, 12)
+    else if (wave_wg) LAUNCH_RUN(64, false, VTX_WPE, VTX_PS) else LAUNCH_RUN(256, false, VTX_WPE, VTX_PS)
 #undef LAUNCH_RUN
     return hipGetLastError();
 }
