@@ -102,6 +102,7 @@ struct vtx_ctx {
     DevBuf d_head_cell, d_head_umi, d_cell_scan, d_umi_scan, d_grp_row, d_grp_col, d_umi_cellgrp;
     DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
+    bool band_long_lists = false;      // (performance feedback between runs: see vtx_run)
     DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2;   // banded flavour
     DevBuf d_redo, d_redo_cnt;                                               // LUT kernel: records with non-ACGTN bytes
     // raw batches (vtx_submit_raw): barcode table + preparation scratch
@@ -1094,10 +1095,16 @@ int vtx_run(vtx_ctx* c) {
                                              c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
                                              c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt,
                                              tasks_per_locus, gt_l0, gt_n, gt_n ? c->d_gtables.as<uint8_t>() : nullptr, gt_bytes,
-                                             nullptr, s));
+                                             nullptr, c->band_long_lists ? 1 : 0, s));
             HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
-            if (gt_n && vtxk_band_second_chance(tasks_per_locus) && cnt[1] > over_before) {
+            const bool short_lists = gt_n && vtxk_band_second_chance(tasks_per_locus, c->band_long_lists ? 1 : 0);
+            if (short_lists && nt >= (1u << 20)) {
+                // feedback for the next run of this context: many overflows of the 12-entry lists (noisy reads: 3.3 % of the
+                // tasks at 3 % substitution errors, 0.2 % at 0.5 %) make the 15-entry variant the better first pass
+                if ((uint64_t)(cnt[1] - over_before) * 50 > nt) c->band_long_lists = true;
+            }
+            if (short_lists && cnt[1] > over_before) {
                 // The six-wavefront variant keeps 12-entry lists: the tasks that overflowed them ([a0, a1) of the overflow
                 // list) get a second chance in the 15-entry variant before the general kernel — what overflows again is
                 // appended behind a1 and then moved down to a0.
@@ -1109,7 +1116,7 @@ int vtx_run(vtx_ctx* c) {
                                                  c->d_band_ws.as<uint32_t>(), c->d_poly.as<uint16_t>(), poly_stride / 2,
                                                  c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
                                                  c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt, tasks_per_locus, gt_l0,
-                                                 gt_n, c->d_gtables.as<uint8_t>(), gt_bytes, c->d_over.as<uint32_t>() + a0, s));
+                                                 gt_n, c->d_gtables.as<uint8_t>(), gt_bytes, c->d_over.as<uint32_t>() + a0, 0, s));
                 HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
                 HIP_TRY(c, hipStreamSynchronize(s));
                 const uint32_t again = cnt[1] - a1;          // <= a1 - a0: source and destination do not overlap

@@ -1458,7 +1458,8 @@ extern "C" size_t vtxk_band_gtables_bytes(uint32_t n_loci, uint32_t max_hap, uin
 
 // 1: vtxk_launch_band_run picks the six-wavefront / 12-entry variant for this shape — its overflow list deserves a second
 // chance in the 15-entry variant (task_list mode) before the general kernel
-extern "C" int vtxk_band_second_chance(uint32_t tasks_per_locus) {
+extern "C" int vtxk_band_second_chance(uint32_t tasks_per_locus, int long_lists) {
+    if (long_lists) return 0;
     const uint32_t w6 = getenv("VTX_BAND_W6_MIN_TPL") ? (uint32_t)atoi(getenv("VTX_BAND_W6_MIN_TPL")) : 80u;
     return tasks_per_locus >= w6 && tasks_per_locus < gt_max_tpl() && !getenv("VTX_BAND_NO_SECOND_CHANCE");
 }
@@ -1474,7 +1475,9 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
                                            uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
                                            uint32_t* pending_list, uint32_t* pend_buf, uint32_t hard_cap, uint32_t pend_cap,
                                            uint32_t* counters, uint32_t tasks_per_locus, uint32_t gt_l0, uint32_t n_loci,
-                                           uint8_t* gtables, size_t gtables_bytes, const uint32_t* task_list, hipStream_t s) {
+                                           uint8_t* gtables, size_t gtables_bytes, const uint32_t* task_list, int long_lists,
+                                           hipStream_t s) {
+    // long_lists: the caller saw many tasks overflow the 12-entry lists (noisy reads): 15-entry lists from the start
     // gtables != nullptr: room for the tables of loci [gt_l0, gt_l0 + n_loci) — the loci of THIS range of tasks; they are
     // built here, then read by the kernel
     if (!n_tasks) return hipSuccess;
@@ -1507,7 +1510,7 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     // tasks to the general kernel, still -2.5 ms per step), 5 x 15 for shallower ones (16 reads per locus: 6.9 vs 7.7 ms),
     // 4 x 15 when the grid does not fill the chip anyway.
     static const uint32_t w6_min_tpl = getenv("VTX_BAND_W6_MIN_TPL") ? (uint32_t)atoi(getenv("VTX_BAND_W6_MIN_TPL")) : 80u;   // experiment knob (crossover between 32 and 48 reads per locus)
-    const int variant = !global_tables ? 0 : (task_list ? 2 : (tasks_per_locus < 16 ? 1 : (tasks_per_locus < w6_min_tpl ? 2 : 3)));
+    const int variant = !global_tables ? 0 : ((task_list || long_lists) ? (tasks_per_locus < 16 && !task_list ? 1 : 2) : (tasks_per_locus < 16 ? 1 : (tasks_per_locus < w6_min_tpl ? 2 : 3)));
     const uint32_t psv = variant == 3 ? 12u : (uint32_t)VTX_PS;
     const size_t lane_bytes = (size_t)(2 * psv) * nt * 4;
     uint32_t tables;

@@ -61,8 +61,8 @@ hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base, const vtx_
                                 uint32_t* hard_list, uint32_t* overflow_list, uint32_t* pending_list, uint32_t* pend_buf,
                                 uint32_t hard_cap, uint32_t pend_cap, uint32_t* counters, uint32_t tasks_per_locus,
                                 uint32_t gt_l0, uint32_t n_loci, uint8_t* gtables, size_t gtables_bytes, const uint32_t* task_list,
-                                hipStream_t s);
-int vtxk_band_second_chance(uint32_t tasks_per_locus);
+                                int long_lists, hipStream_t s);
+int vtxk_band_second_chance(uint32_t tasks_per_locus, int long_lists);
 size_t vtxk_band_gtables_bytes(uint32_t n_loci, uint32_t max_hap, uint32_t tasks_per_locus, uint32_t* loci_cap);
 uint32_t vtxk_band_task_words(void);
 uint32_t vtxk_band_pend_words(void);
