@@ -139,6 +139,12 @@ struct VcfRec { std::string chrom; int64_t pos; std::vector<std::string> alleles
 
 // ---- BAM ------------------------------------------------------------------------
 const char kNt16[] = "=ACMGRSVTWYHKDBN";
+struct Nt16Pairs {                    // byte of two 4-bit codes -> its two letters
+    uint16_t v[256];
+    Nt16Pairs() { for (int b = 0; b < 256; ++b) { const char two[2] = {kNt16[b >> 4], kNt16[b & 15]}; memcpy(&v[b], two, 2); } }
+    const uint16_t& operator[](size_t i) const { return v[i]; }
+};
+const Nt16Pairs kNt16Pair;
 enum { FLAG_UNMAP = 0x4, FLAG_SECONDARY = 0x100, FLAG_DUP = 0x400, FLAG_SUPP = 0x800 };
 
 struct BgzfBlock { size_t coff; uint32_t clen; uint32_t isize; size_t start; };   // start: file offset of the block header
@@ -542,6 +548,37 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             for (auto& b : P->barcodes) { P->bc_bytes += b; P->bc_offsets.push_back(P->bc_bytes.size()); }
         }
     }
+    // the per-read lookup (cooked packs): open addressing over the barcode bytes, no allocation per probe
+    // (std::unordered_map<std::string, .>::find needs a std::string: a malloc per read for 18-byte barcodes)
+    struct BcTable {
+        std::vector<uint32_t> slot;            // index + 1; 0 = empty
+        const std::vector<std::string>* names = nullptr;
+        uint64_t mask = 0;
+        static uint64_t hash(const unsigned char* p, size_t n) {
+            uint64_t h = 1469598103934665603ull;
+            for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+            return h ^ (h >> 29);
+        }
+        void build(const std::vector<std::string>& v) {
+            names = &v;
+            size_t cap = 16;
+            while (cap < 2 * v.size()) cap <<= 1;
+            slot.assign(cap, 0); mask = cap - 1;
+            for (size_t i = 0; i < v.size(); ++i) {
+                uint64_t k = hash((const unsigned char*)v[i].data(), v[i].size()) & mask;
+                while (slot[k]) k = (k + 1) & mask;
+                slot[k] = (uint32_t)i + 1;
+            }
+        }
+        bool find(const unsigned char* p, size_t n, uint32_t* out) const {
+            for (uint64_t k = hash(p, n) & mask; slot[k]; k = (k + 1) & mask) {
+                const std::string& s = (*names)[slot[k] - 1];
+                if (s.size() == n && memcmp(s.data(), p, n) == 0) { *out = slot[k] - 1; return true; }
+            }
+            return false;
+        }
+    } bc_table;
+    bc_table.build(P->barcodes);
 
     ph.mark("barcodes");
     // ---- VCF records (:221-234) ----
@@ -741,7 +778,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     struct Hit { uint32_t locus, cell; vtx_raw_record rr; uint64_t roff, toff; };
     struct WorkerOut { std::vector<Hit> hits; std::string reads, tags; vtxh_metrics m{}; std::string err; uint64_t rbase = 0; };
     ByteBuf& reads = P->read_arena;
-    auto process = [&](const unsigned char* r, uint32_t bs, WorkerOut& o, std::vector<uint32_t>& hits, std::string& seq) -> bool {
+    auto process = [&](const unsigned char* r, uint32_t bs, WorkerOut& o, std::vector<uint32_t>& hits) -> bool {
         const int32_t tid = rdi32(r);
         if (tid < 0 || (size_t)tid >= by_tid.size() || by_tid[(size_t)tid].empty()) return true;
         const int64_t pos = rdi32(r + 4);
@@ -791,8 +828,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
                         rr.bc_off = (uint32_t)o.tags.size(); rr.bc_len = (uint16_t)vlen;
                         o.tags.append((const char*)val, vlen);
                     } else {
-                        auto it = bc_index.find(std::string((const char*)val, vlen));
-                        if (it != bc_index.end()) { has_cell = true; cell = it->second; rr.bc_len = 0; }
+                        if (bc_table.find(val, vlen, &cell)) { has_cell = true; rr.bc_len = 0; }
                     }
                 }
                 if ((raw || a->use_umi) && rr.bc_len != VTX_TAG_MISSING && aux_string(aux, (size_t)(r + bs - aux), "UB", &val, &vlen) == 1 && vlen < VTX_TAG_MISSING) {   // :879
@@ -804,10 +840,12 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             if (raw ? rr.bc_len == VTX_TAG_MISSING : !has_cell) { ++o.m.num_not_cell_bc; continue; }
             if (!raw && a->use_umi && rr.umi_len == VTX_TAG_MISSING) { ++o.m.num_non_umi; continue; }           // :879-888
             if (!seq_ready) {                                                               // rec.seq().as_bytes() :896
-                seq.resize(l_seq);
-                for (uint32_t k = 0; k < l_seq; ++k) seq[k] = kNt16[(sq[k >> 1] >> ((~k & 1) << 2)) & 15];
                 seq_ready = true;
-                rr.read_off = (uint32_t)o.reads.size(); o.reads += seq;      // one copy per read, shared by its loci
+                rr.read_off = (uint32_t)o.reads.size();                       // one copy per read, shared by its loci
+                o.reads.resize(o.reads.size() + l_seq);
+                char* dst = &o.reads[rr.read_off];
+                for (uint32_t k = 0; k + 1 < l_seq; k += 2) memcpy(dst + k, &kNt16Pair[sq[k >> 1]], 2);
+                if (l_seq & 1) dst[l_seq - 1] = kNt16[sq[l_seq >> 1] >> 4];
             }
             rr.read_len = l_seq;
             o.hits.push_back(Hit{li, cell, rr, 0, 0});
@@ -917,10 +955,9 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             WorkerOut& o = outs[t];
             o.hits.clear(); o.reads.clear(); o.tags.clear(); o.m = vtxh_metrics{}; o.err.clear();
             std::vector<uint32_t> hits;
-            std::string seq;
             for (size_t k = nrec * t / (size_t)threads, e = nrec * (t + 1) / (size_t)threads; k < e; ++k) {
                 const unsigned char* rp = buf.data() + rec_offs[k];
-                if (!process(rp + 4, rd32(rp), o, hits, seq)) { if (o.err.empty()) o.err = "one window of the BAM holds more than 4 GiB of read bases"; return; }
+                if (!process(rp + 4, rd32(rp), o, hits)) { if (o.err.empty()) o.err = "one window of the BAM holds more than 4 GiB of read bases"; return; }
             }
         });
         {
