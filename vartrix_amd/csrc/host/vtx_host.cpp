@@ -853,10 +853,6 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         return o.reads.size() <= 0xffffffffull && o.tags.size() <= 0xffffffffull;
     };
     std::vector<size_t> rec_offs;
-    size_t n_spec_ok = 0, n_spec_fallback = 0;        // windows whose speculative record index was accepted / redone sequentially
-    struct RecRef { size_t off; uint32_t bs; int32_t tid, pos; };
-    std::vector<std::vector<RecRef>> piece((size_t)threads);      // (kept across windows: their pages stay mapped)
-    std::vector<size_t> piece_first((size_t)threads, SIZE_MAX), piece_next((size_t)threads, SIZE_MAX);
     // every window's worker outputs go to the global arrays at prefix offsets (thread order = BAM order), copied by the
     // workers themselves
     std::vector<WorkerOut> outs((size_t)threads);
@@ -916,117 +912,14 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         rec_offs.clear();
         size_t p = buf_pos;
         bool all_served = false;
-        // ---- record boundaries of the window.  The chain (every record names the start of the next) is sequential and one
-        //      cache miss per hop; the window is cut into `threads` pieces, every piece but the first GUESSES a record start
-        //      (three plausible headers in a row) and follows the chain to the next piece.  The guesses are then verified:
-        //      piece t must end exactly where piece t + 1 began — by induction from the known start of piece 0 the joined
-        //      chain is the sequential one.  Any mismatch (or a malformed record) falls back to the sequential walk. ----
-        const size_t w_end = buf.size();
-        const int32_t n_ref_i = (int32_t)bam_refs.size();
-        auto plausible = [&](size_t o) -> bool {
-            if (w_end - o < 36) return false;
-            const unsigned char* r = buf.data() + o;
-            const uint32_t bs = rd32(r);
-            if (bs < 32 || bs > (1u << 28)) return false;
-            const int32_t tid = rdi32(r + 4), pos = rdi32(r + 8), ntid = rdi32(r + 24), npos = rdi32(r + 28);
-            if (tid < -1 || tid >= n_ref_i || pos < -1 || ntid < -1 || ntid >= n_ref_i || npos < -1) return false;
-            const uint32_t l_rn = r[12], n_cig = r[16] | (r[17] << 8), l_seq = rd32(r + 20);
-            if (l_rn < 1 || l_seq > (1u << 28)) return false;
-            if ((uint64_t)32 + l_rn + 4ull * n_cig + (l_seq + 1) / 2 + l_seq > bs) return false;
-            if (w_end - o >= 36 + (size_t)l_rn && r[36 + l_rn - 1] != 0) return false;      // the read name ends with NUL
-            return true;
-        };
-        for (auto& v : piece) v.clear();
-        std::fill(piece_first.begin(), piece_first.end(), SIZE_MAX);
-        std::fill(piece_next.begin(), piece_next.end(), SIZE_MAX);
-        bool spec_ok = threads > 1 && w_end - buf_pos > ((size_t)4 << 20);
-        if (spec_ok) {
-            const size_t span = w_end - buf_pos;
-            pool.run([&](size_t t) {
-                const size_t s0 = buf_pos + span * t / (size_t)threads, s1 = t + 1 == (size_t)threads ? w_end : buf_pos + span * (t + 1) / (size_t)threads;
-                size_t o = s0;
-                if (t) {
-                    for (;; ++o) {
-                        if (o >= s1 || w_end - o < 36) return;                       // no start found in this piece
-                        if (!plausible(o)) continue;
-                        const size_t o2 = o + 4 + rd32(buf.data() + o);
-                        if (o2 < w_end && w_end - o2 >= 36) {
-                            if (!plausible(o2)) continue;
-                            const size_t o3 = o2 + 4 + rd32(buf.data() + o2);
-                            if (o3 < w_end && w_end - o3 >= 36 && !plausible(o3)) continue;
-                        }
-                        break;
-                    }
-                }
-                piece_first[t] = o;
-                auto& v = piece[t];
-                while (o < s1) {
-                    if (w_end - o < 4) break;
-                    const unsigned char* r = buf.data() + o;
-                    const uint32_t bs = rd32(r);
-                    if (w_end - o - 4 < bs || bs < 32) break;                        // incomplete (or malformed: the check below catches it)
-                    v.push_back(RecRef{o, bs, rdi32(r + 4), rdi32(r + 8)});
-                    o += 4 + (size_t)bs;
-                    __builtin_prefetch(buf.data() + o + 8 * (4 + (size_t)bs));
-                }
-                piece_next[t] = o;
-            });
-            // Verification.  `expect` is the next offset of the true chain not covered yet (piece 0 starts at the known
-            // start).  A piece's records are accepted from the entry whose offset is `expect` on — the chain is
-            // deterministic from any true record start — and what precedes that entry (a guess inside the previous
-            // piece's last record) is dropped; a piece the chain jumps over entirely is skipped.
-            size_t expect = buf_pos;
-            const size_t span_ = w_end - buf_pos;
-            for (size_t t = 0; t < (size_t)threads; ++t) {
-                const size_t s0 = buf_pos + span_ * t / (size_t)threads;
-                const size_t s1 = t + 1 == (size_t)threads ? w_end : buf_pos + span_ * (t + 1) / (size_t)threads;
-                auto& v = piece[t];
-                if (expect >= s1) { v.clear(); continue; }                  // the chain jumps over this piece
-                if (expect < s0) {                                            // the chain stopped before this piece (window end)
-                    for (size_t u = t; u < (size_t)threads; ++u) piece[u].clear();
-                    break;
-                }
-                size_t k = 0;
-                while (k < v.size() && v[k].off < expect) ++k;
-                if (k == v.size() || v[k].off != expect) {
-                    // no record at `expect` in this piece: only right if the chain stops there (checked below)
-                    for (size_t u = t; u < (size_t)threads; ++u) piece[u].clear();
-                    break;
-                }
-                if (k) v.erase(v.begin(), v.begin() + (long)k);
-                expect = piece_next[t];
-            }
-            // the chain must stop where the sequential walk would: fewer than 4 bytes left, or an incomplete record
-            if (w_end - expect >= 4) {
-                const uint32_t bs = rd32(buf.data() + expect);
-                if (!(w_end - expect - 4 < bs)) spec_ok = false;            // a complete (or malformed) record was not covered: walk sequentially
-            }
-        }
-        if (threads > 1 && w_end - buf_pos > ((size_t)4 << 20)) ++(spec_ok ? n_spec_ok : n_spec_fallback);
-        size_t pi = 0, pk = 0;                            // cursor over the pieces (speculative index accepted)
-        auto next_ref = [&](RecRef& out) -> bool {
-            if (spec_ok) {
-                while (pi < piece.size() && pk >= piece[pi].size()) { ++pi; pk = 0; }
-                if (pi == piece.size()) return false;
-                out = piece[pi][pk++];
-                return true;
-            }
-            if (buf.size() - p < 4) return false;
+        while (buf.size() - p >= 4) {
             const uint32_t bs = rd32(buf.data() + p);
-            if (buf.size() - p - 4 < bs) return false;
-            out = RecRef{p, bs, bs >= 32 ? rdi32(buf.data() + p + 4) : 0, bs >= 32 ? rdi32(buf.data() + p + 8) : 0};
-            __builtin_prefetch(buf.data() + p + 9 * (4 + (size_t)bs));      // records are of similar size: the chain is predictable
-            __builtin_prefetch(buf.data() + p + 9 * (4 + (size_t)bs) + 64);
-            return true;
-        };
-        RecRef rr_;
-        while (next_ref(rr_)) {
-            const uint32_t bs = rr_.bs;
+            if (buf.size() - p - 4 < bs) break;
             if (bs < 32) return fail(VTX_E_INVAL, "%s: malformed BAM record", a->bam);
             if (use_index) {
                 // a record at or beyond the end of the running segment: its loci are served (sorted file)
-                const int32_t rt = rr_.tid;
-                const int64_t rp = rr_.pos;
+                const int32_t rt = rdi32(buf.data() + p + 4);
+                const int64_t rp = rdi32(buf.data() + p + 8);
                 bool moved = false;
                 while (tg < targets.size() && (rt < 0 || rt > seg_tid || (rt == seg_tid && rp >= seg_end))) {
                     while (tg < targets.size() && targets[tg].tid == seg_tid && targets[tg].start < seg_end) ++tg;   // served
@@ -1041,8 +934,10 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
                     if (nb > next_block + kNearBlocks) { jump_pending = true; jump_voff = targets[tg].voff; break; }
                 }
             }
-            rec_offs.push_back(rr_.off);
-            p = rr_.off + 4 + (size_t)bs;
+            rec_offs.push_back(p);
+            p += 4 + (size_t)bs;
+            __builtin_prefetch(buf.data() + p + 8 * (4 + (size_t)bs));      // records are of similar size: the chain is predictable
+            __builtin_prefetch(buf.data() + p + 8 * (4 + (size_t)bs) + 64);
         }
         const bool eof = next_block >= blocks.size();
         if (rec_offs.empty() && (all_served || jump_pending)) {
@@ -1103,7 +998,6 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         if (eof && rec_offs.empty()) break;
     }
     P->blocks_inflated = n_inflated; P->blocks_total = blocks.size(); P->index_jumps = n_jumps;
-    if (getenv("VTXH_PROFILE")) fprintf(stderr, "  [vtxh] record index: %zu windows speculated, %zu walked sequentially\n", n_spec_ok, n_spec_fallback);
 
     // ---- group the hits by locus: stable counting sort (hits are in BAM order, so every locus keeps it); thread t owns the
     //      t-th slice of the hits, and within a locus the slices land in thread order ----
