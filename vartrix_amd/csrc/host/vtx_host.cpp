@@ -159,6 +159,7 @@ struct ByteBuf {
     size_t size() const { return len; }
     void drop_prefix(size_t n) { if (n) { memmove(p, p + n, len - n); len -= n; } }
     void release() { free(p); p = nullptr; len = cap = 0; }
+    void swap_with(ByteBuf& o) { std::swap(p, o.p); std::swap(len, o.len); std::swap(cap, o.cap); }
     unsigned char* grow(size_t add) {      // returns the start of the new bytes; nullptr when out of memory
         if (len + add > cap || !p) {
             size_t want = std::max<size_t>(std::max(len + add, cap + cap / 2), 64);
@@ -653,6 +654,11 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     size_t chunk_blocks = 512;            // blocks per inflate round; restarts small after an index-guided jump
     size_t chunk_limit_block = SIZE_MAX;  // index-guided sweep: no read-ahead beyond the block the sweep would jump to anyway
     uint64_t n_inflated = 0, n_jumps = 0;
+    // the window whose records are indexed but not parsed yet (the parse of window k runs beside the indexing of window
+    // k + 1): set while it waits; its bytes move to pend_store when the sweep needs the buffer for more data
+    size_t pend_begin = SIZE_MAX;
+    bool pend_detached = false;
+    ByteBuf pend_store;
     auto refill = [&](size_t need) -> bool {   // ensure buf has >= need bytes from buf_pos, if the file has them
         while (buf.size() - buf_pos < need && next_block < blocks.size()) {
             size_t chunk = std::min(blocks.size() - next_block, chunk_blocks);
@@ -660,7 +666,19 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             // to the jump target (dense VCFs have no jump ahead and keep the large rounds)
             if (chunk_limit_block != SIZE_MAX) chunk = std::min<size_t>(chunk, 32);
             chunk_blocks = std::min<size_t>(512, chunk_blocks * 2);
-            if (buf_pos) { buf.drop_prefix(buf_pos); buf_pos = 0; }
+            if (pend_begin != SIZE_MAX && !pend_detached) {
+                // a window is indexed and waits for its parse: its bytes stay where they are (pend_store); the sweep goes on
+                // in the spare buffer, which starts with the unconsumed tail (a partial record)
+                buf.swap_with(pend_store);
+                const size_t tail = pend_store.size() - buf_pos;
+                buf.len = 0;
+                if (!buf.grow(tail)) return false;
+                memcpy(buf.data(), pend_store.data() + buf_pos, tail);
+                buf_pos = 0;
+                pend_detached = true;
+            } else if (buf_pos) {
+                buf.drop_prefix(buf_pos); buf_pos = 0;
+            }
             std::vector<size_t> off(chunk + 1, 0);
             for (size_t k = 0; k < chunk; ++k) off[k + 1] = off[k] + blocks[next_block + k].isize;
             const size_t base = buf.size();
@@ -892,8 +910,66 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             if (targets[0].voff && block_of(targets[0].voff) > next_block + kNearBlocks) { jump_pending = true; jump_voff = targets[0].voff; }
         }
     }
+    // ---- parse + filter of one indexed window (pend_offs), all threads; then every worker copies its output to prefix
+    //      offsets of the global arrays (thread order = BAM order) ----
+    std::vector<size_t> pend_offs;
+    int parse_rc = VTX_OK;
+    std::string parse_msg;
+    auto parse_pending = [&]() {
+        const size_t nrec = pend_offs.size();
+        if (!nrec) return;
+        const unsigned char* pend_base = pend_detached ? pend_store.data() : buf.data();
+        pool.run([&](size_t t) {
+            WorkerOut& o = outs[t];
+            o.hits.clear(); o.reads.clear(); o.tags.clear(); o.m = vtxh_metrics{}; o.err.clear();
+            std::vector<uint32_t> hits;
+            for (size_t k = nrec * t / (size_t)threads, e = nrec * (t + 1) / (size_t)threads; k < e; ++k) {
+                const unsigned char* rp = pend_base + pend_offs[k];
+                if (!process(rp + 4, rd32(rp), o, hits)) { if (o.err.empty()) o.err = "one window of the BAM holds more than 4 GiB of read bases"; return; }
+            }
+        });
+        std::vector<uint64_t> tbase((size_t)threads), hbase((size_t)threads);
+        uint64_t rtotal = reads.size(), ttotal = tag_store.size(), htotal = n_hits;
+        for (size_t t = 0; t < outs.size(); ++t) {
+            WorkerOut& o = outs[t];
+            if (!o.err.empty()) { parse_rc = o.err[0] == 'm' ? VTX_E_INVAL : VTX_E_UNSUPPORTED; parse_msg = o.err; return; }
+            o.rbase = rtotal; rtotal += o.reads.size();
+            tbase[t] = ttotal; ttotal += o.tags.size();
+            hbase[t] = htotal; htotal += o.hits.size();
+            const uint64_t* src = &o.m.num_reads;
+            uint64_t* dst = &P->metrics.num_reads;
+            for (int k = 0; k < 9; ++k) dst[k] += src[k];
+        }
+        if (!reads.grow((size_t)(rtotal - reads.size())) || !tag_store.grow((size_t)(ttotal - tag_store.size())) ||
+            !hit_store.grow((size_t)(htotal - n_hits) * sizeof(Hit))) { parse_rc = VTX_E_NOMEM; parse_msg = "out of memory growing the read arenas"; return; }
+        n_hits = (size_t)htotal;
+        Hit* all = (Hit*)hit_store.data();
+        pool.run([&](size_t t) {
+            const WorkerOut& o = outs[t];
+            if (!o.reads.empty()) memcpy(reads.data() + o.rbase, o.reads.data(), o.reads.size());
+            if (!o.tags.empty()) memcpy(tag_store.data() + tbase[t], o.tags.data(), o.tags.size());
+            Hit* dst = all + hbase[t];
+            for (size_t k = 0; k < o.hits.size(); ++k) {
+                Hit h = o.hits[k];
+                h.roff = o.rbase + h.rr.read_off; h.toff = tbase[t];
+                dst[k] = h;
+            }
+        });
+        pend_offs.clear();
+        pend_begin = SIZE_MAX; pend_detached = false;
+    };
+    // the pending window is parsed on a helper thread (which drives the pool) while this thread indexes the next one
+    std::thread parse_thread;
+    auto finish_parse = [&]() -> bool {
+        if (parse_thread.joinable()) parse_thread.join();
+        return parse_rc == VTX_OK;
+    };
+    struct ParseJoiner { std::thread& t; ~ParseJoiner() { if (t.joinable()) t.join(); } } parse_joiner{parse_thread};
     while (true) {
         if (jump_pending) {
+            // the buffer restarts elsewhere: the window still waiting for its parse goes first
+            parse_pending();
+            if (parse_rc != VTX_OK) return fail(parse_rc, "%s: %s", a->bam, parse_msg.c_str());
             // restart the record stream at a virtual offset: drop what is buffered, inflate from that block on
             jump_pending = false;
             ++n_jumps;
@@ -909,6 +985,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         if (use_index) update_read_ahead();
         refill(buf.size() - buf_pos + 1);             // one more chunk of blocks, if the file has one
         ph.mark("inflate");
+        if (!pend_offs.empty()) parse_thread = std::thread(parse_pending);      // ... beside the indexing below
         rec_offs.clear();
         size_t p = buf_pos;
         bool all_served = false;
@@ -939,6 +1016,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             __builtin_prefetch(buf.data() + p + 8 * (4 + (size_t)bs));      // records are of similar size: the chain is predictable
             __builtin_prefetch(buf.data() + p + 8 * (4 + (size_t)bs) + 64);
         }
+        if (!finish_parse()) return fail(parse_rc, "%s: %s", a->bam, parse_msg.c_str());
         const bool eof = next_block >= blocks.size();
         if (rec_offs.empty() && (all_served || jump_pending)) {
             if (all_served) break;
@@ -949,54 +1027,17 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             if (buf.size() - buf_pos >= 4) return fail(VTX_E_INVAL, "%s: truncated BAM record", a->bam);
             break;
         }
-        const size_t nrec = rec_offs.size();
-        ph.mark("record index");
-        pool.run([&](size_t t) {
-            WorkerOut& o = outs[t];
-            o.hits.clear(); o.reads.clear(); o.tags.clear(); o.m = vtxh_metrics{}; o.err.clear();
-            std::vector<uint32_t> hits;
-            for (size_t k = nrec * t / (size_t)threads, e = nrec * (t + 1) / (size_t)threads; k < e; ++k) {
-                const unsigned char* rp = buf.data() + rec_offs[k];
-                if (!process(rp + 4, rd32(rp), o, hits)) { if (o.err.empty()) o.err = "one window of the BAM holds more than 4 GiB of read bases"; return; }
-            }
-        });
-        {
-            std::vector<uint64_t> tbase((size_t)threads), hbase((size_t)threads);
-            uint64_t rtotal = reads.size(), ttotal = tag_store.size(), htotal = n_hits;
-            for (size_t t = 0; t < outs.size(); ++t) {
-                WorkerOut& o = outs[t];
-                if (!o.err.empty()) return fail(o.err[0] == 'm' ? VTX_E_INVAL : VTX_E_UNSUPPORTED, "%s: %s", a->bam, o.err.c_str());
-                o.rbase = rtotal; rtotal += o.reads.size();
-                tbase[t] = ttotal; ttotal += o.tags.size();
-                hbase[t] = htotal; htotal += o.hits.size();
-                const uint64_t* src = &o.m.num_reads;
-                uint64_t* dst = &P->metrics.num_reads;
-                for (int k = 0; k < 9; ++k) dst[k] += src[k];
-            }
-            if (!reads.grow((size_t)(rtotal - reads.size())) || !tag_store.grow((size_t)(ttotal - tag_store.size())) ||
-                !hit_store.grow((size_t)(htotal - n_hits) * sizeof(Hit)))
-                return fail(VTX_E_NOMEM, "out of memory growing the read arenas");
-            n_hits = (size_t)htotal;
-            Hit* all = (Hit*)hit_store.data();
-            pool.run([&](size_t t) {
-                const WorkerOut& o = outs[t];
-                if (!o.reads.empty()) memcpy(reads.data() + o.rbase, o.reads.data(), o.reads.size());
-                if (!o.tags.empty()) memcpy(tag_store.data() + tbase[t], o.tags.data(), o.tags.size());
-                Hit* dst = all + hbase[t];
-                for (size_t k = 0; k < o.hits.size(); ++k) {
-                    Hit h = o.hits[k];
-                    h.roff = o.rbase + h.rr.read_off; h.toff = tbase[t];
-                    dst[k] = h;
-                }
-            });
-        }
-        ph.mark("parse + filter");
+        ph.mark("record index + parse of the window before");
+        // this window's parse runs beside the indexing of the next one
+        pend_offs.swap(rec_offs);
+        pend_begin = pend_offs.front(); pend_detached = false;
         buf_pos = p;
         if (all_served) break;
         if (jump_pending) continue;
         if (eof && buf.size() - buf_pos < 4) break;
-        if (eof && rec_offs.empty()) break;
     }
+    parse_pending();                                   // the last window
+    if (parse_rc != VTX_OK) return fail(parse_rc, "%s: %s", a->bam, parse_msg.c_str());
     P->blocks_inflated = n_inflated; P->blocks_total = blocks.size(); P->index_jumps = n_jumps;
 
     // ---- group the hits by locus: stable counting sort (hits are in BAM order, so every locus keeps it); thread t owns the
