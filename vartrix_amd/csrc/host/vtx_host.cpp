@@ -125,11 +125,20 @@ struct Fasta {
     // fetch [start, end) of contig, upper-cased (read_locus :947-952)
     void fetch_upper(const FaiEntry& e, uint64_t start, uint64_t end, std::string& out) const {
         out.clear();
-        for (uint64_t p = start; p < end; ++p) {
-            uint64_t off = e.offset + (p / e.linebases) * e.linewidth + p % e.linebases;
-            unsigned char c = off < data.size() ? data.data()[off] : 'N';
-            if (c >= 'a' && c <= 'z') c = (unsigned char)(c - 32);
-            out.push_back((char)c);
+        if (end <= start) return;
+        out.resize((size_t)(end - start));
+        char* dst = &out[0];
+        uint64_t p = start;
+        while (p < end) {                                   // one FASTA line at a time (no division per base)
+            const uint64_t col = p % e.linebases;
+            const uint64_t n = std::min<uint64_t>(end - p, e.linebases - col);
+            const uint64_t off = e.offset + (p / e.linebases) * e.linewidth + col;
+            for (uint64_t k = 0; k < n; ++k) {
+                unsigned char c = off + k < data.size() ? data.data()[off + k] : 'N';
+                if (c >= 'a' && c <= 'z') c = (unsigned char)(c - 32);
+                dst[p - start + k] = (char)c;
+            }
+            p += n;
         }
     }
 };
@@ -717,7 +726,6 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     std::vector<LocusBuild> loci;
     std::vector<std::vector<Interval>> by_tid(bam_refs.size());
     std::vector<int64_t> max_span(bam_refs.size(), 1);
-    std::string left, right;
     for (size_t i = 0; i < vcf.size(); ++i) {
         const VcfRec& v = vcf[i];
         auto fi = fa.by_name.find(v.chrom);
@@ -730,31 +738,43 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             return fail(VTX_E_INVAL, "Record %s:%lld has end position %lld, which is larger than the chromosome length (%llu). Does your FASTA match your VCF?",
                         v.chrom.c_str(), (long long)v.pos, (long long)end, (unsigned long long)fe.len);
     }
-    for (size_t i = 0; i < vcf.size(); ++i) {
-        const VcfRec& v = vcf[i];
-        if (v.alleles.size() > 2) { ++P->metrics.num_multiallelic_recs; continue; }          // :646-653
-        const std::string alt = v.alleles.size() == 2 ? v.alleles[1] : std::string();          // :656-659
-        const FaiEntry& fe = fa.seqs[fa.by_name[v.chrom]];
-        const int64_t start = v.pos, end = v.pos + (int64_t)v.alleles[0].size();
-        const int64_t pad = a->padding;
-        LocusBuild L;
-        L.row = (uint32_t)i; L.start = start; L.end = end;
-        // construct_haplotypes :958-994
-        const int64_t ls = start >= pad ? start - pad : 0;
-        const int64_t re = std::min<int64_t>(end + pad, (int64_t)fe.len);
-        fa.fetch_upper(fe, (uint64_t)ls, (uint64_t)std::min<int64_t>(start, (int64_t)fe.len), left);
-        fa.fetch_upper(fe, (uint64_t)end, (uint64_t)re, right);
-        L.alt_hap = left + alt + right;
-        int64_t rs = (int64_t)((int32_t)start - (int32_t)pad);       // i32 casts, :944
-        if (rs < 0) rs = 0;
-        fa.fetch_upper(fe, (uint64_t)rs, (uint64_t)re, L.ref_hap);
-        bool ok = true;
-        for (unsigned char c : L.alt_hap) if (!valid[c]) { ok = false; break; }                 // :675-684
-        if (!ok) { ++P->metrics.num_invalid_recs; continue; }
-        const int32_t tid = tid_of[v.chrom];
-        by_tid[(size_t)tid].push_back(Interval{start, end, (uint32_t)loci.size()});
-        max_span[(size_t)tid] = std::max(max_span[(size_t)tid], end - start);
-        loci.push_back(std::move(L));
+    {
+        // haplotypes of all records in parallel (verdict per record), then the loci in VCF order
+        std::vector<LocusBuild> built(vcf.size());
+        std::vector<uint8_t> verdict(vcf.size(), 0);            // 0 locus, 1 multi-allelic, 2 invalid characters
+        std::vector<int32_t> tid_i(vcf.size(), 0);
+        pool.run([&](size_t t) {
+            std::string left, right;
+            for (size_t i = vcf.size() * t / (size_t)threads, e = vcf.size() * (t + 1) / (size_t)threads; i < e; ++i) {
+                const VcfRec& v = vcf[i];
+                if (v.alleles.size() > 2) { verdict[i] = 1; continue; }                                // :646-653
+                const std::string alt = v.alleles.size() == 2 ? v.alleles[1] : std::string();          // :656-659
+                const FaiEntry& fe = fa.seqs[fa.by_name.find(v.chrom)->second];
+                const int64_t start = v.pos, end = v.pos + (int64_t)v.alleles[0].size();
+                const int64_t pad = a->padding;
+                LocusBuild& L = built[i];
+                L.row = (uint32_t)i; L.start = start; L.end = end;
+                // construct_haplotypes :958-994
+                const int64_t ls = start >= pad ? start - pad : 0;
+                const int64_t re = std::min<int64_t>(end + pad, (int64_t)fe.len);
+                fa.fetch_upper(fe, (uint64_t)ls, (uint64_t)std::min<int64_t>(start, (int64_t)fe.len), left);
+                fa.fetch_upper(fe, (uint64_t)end, (uint64_t)re, right);
+                L.alt_hap = left + alt + right;
+                int64_t rs = (int64_t)((int32_t)start - (int32_t)pad);       // i32 casts, :944
+                if (rs < 0) rs = 0;
+                fa.fetch_upper(fe, (uint64_t)rs, (uint64_t)re, L.ref_hap);
+                for (unsigned char c : L.alt_hap) if (!valid[c]) { verdict[i] = 2; break; }             // :675-684
+                tid_i[i] = tid_of.find(v.chrom)->second;
+            }
+        });
+        for (size_t i = 0; i < vcf.size(); ++i) {
+            if (verdict[i] == 1) { ++P->metrics.num_multiallelic_recs; continue; }
+            if (verdict[i] == 2) { ++P->metrics.num_invalid_recs; continue; }
+            const int32_t tid = tid_i[i];
+            by_tid[(size_t)tid].push_back(Interval{built[i].start, built[i].end, (uint32_t)loci.size()});
+            max_span[(size_t)tid] = std::max(max_span[(size_t)tid], built[i].end - built[i].start);
+            loci.push_back(std::move(built[i]));
+        }
     }
     for (auto& iv : by_tid)
         std::stable_sort(iv.begin(), iv.end(), [](const Interval& x, const Interval& y) { return x.start < y.start; });
