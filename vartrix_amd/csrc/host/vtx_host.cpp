@@ -457,16 +457,29 @@ int vtxh_format_f64(double v, char* buf) {
 
 int vtxh_write_mtx(const char* path, uint32_t n_rows, uint32_t n_cols, uint64_t nnz, const uint32_t* row,
                    const uint32_t* col, const double* value) {
-    FILE* f = fopen(path, "wb");
-    if (!f) return fail(VTX_E_INVAL, "cannot open %s for writing", path);
-    fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%u %u %llu\n", n_rows, n_cols,
-            (unsigned long long)nnz);
-    // lines are formatted by several threads into private buffers (rounds of bounded size), written in order
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return fail(VTX_E_INVAL, "cannot open %s for writing", path);
+    char head[160];
+    const int hl = snprintf(head, sizeof head, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%u %u %llu\n", n_rows,
+                            n_cols, (unsigned long long)nnz);
+    auto write_at = [&](const char* p, size_t n, uint64_t off) -> bool {
+        while (n) {
+            const ssize_t w = pwrite(fd, p, n, (off_t)off);
+            if (w <= 0) return false;
+            p += w; n -= (size_t)w; off += (uint64_t)w;
+        }
+        return true;
+    };
+    bool ok = write_at(head, (size_t)hl, 0);
+    uint64_t file_off = (uint64_t)hl;
+    // lines are formatted by several threads into private buffers (rounds of bounded size); every thread then writes its
+    // buffer at its own offset (the copy into the page cache is most of the time of a 300 MB file)
     const uint64_t kRound = 8u << 20;
     const unsigned hw = std::thread::hardware_concurrency();
     const size_t T = nnz < (1u << 16) ? 1 : std::min<size_t>(hw ? hw : 1, 16);
     std::vector<std::string> parts(T);
-    bool ok = true;
+    std::vector<uint64_t> offs(T);
+    std::vector<uint8_t> wok(T, 1);
     for (uint64_t base = 0; base < nnz && ok; base += kRound) {
         const uint64_t n = std::min<uint64_t>(kRound, nnz - base);
         auto fmt = [&](size_t t) {
@@ -484,13 +497,23 @@ int vtxh_write_mtx(const char* path, uint32_t n_rows, uint32_t n_cols, uint64_t 
                 out.append(line, (size_t)(p - line));
             }
         };
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < T; ++t) th.emplace_back(fmt, t);
-        fmt(0);
-        for (auto& t : th) t.join();
-        for (auto& part : parts) ok = ok && fwrite(part.data(), 1, part.size(), f) == part.size();
+        auto put = [&](size_t t) { wok[t] = write_at(parts[t].data(), parts[t].size(), offs[t]) ? 1 : 0; };
+        {
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < T; ++t) th.emplace_back(fmt, t);
+            fmt(0);
+            for (auto& t : th) t.join();
+        }
+        for (size_t t = 0; t < T; ++t) { offs[t] = file_off; file_off += parts[t].size(); }
+        {
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < T; ++t) th.emplace_back(put, t);
+            put(0);
+            for (auto& t : th) t.join();
+        }
+        for (size_t t = 0; t < T; ++t) ok = ok && wok[t];
     }
-    ok = (fclose(f) == 0) && ok;
+    ok = (close(fd) == 0) && ok;
     return ok ? VTX_OK : fail(VTX_E_INVAL, "error writing %s", path);
 }
 
