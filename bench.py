@@ -410,11 +410,26 @@ def main():
                                 "that replaces it.  The certificate decides %.1f %% of the alignments without evaluating any DP cell, "
                                 "so this is a work-avoided figure, not an issue rate; the issue rate of the kernels is in roofline.pmc "
                                 "when the PMC file matches this code" % (100.0 * (1.0 - ctx.timing().hard_tasks / max(n_aln, 1)))}
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     ctx.close()
     if use_gather:
         dist.barrier()
         dist.destroy_process_group()
+    # The JSON line is the LAST thing this process prints: RCCL writes a version banner through C stdio (buffered on a pipe
+    # until exit), so the C buffers are flushed first and the interpreter then leaves without running any more teardown.
+    sys.stdout.flush()
+    sys.stderr.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if line is not None:
+        print(line, flush=True)
+    if use_gather:
+        os._exit(0)
 
 
 if __name__ == "__main__":
