@@ -414,11 +414,9 @@ def main():
     else:
         line = None
     ctx.close()
-    if use_gather:
-        dist.barrier()
-        dist.destroy_process_group()
-    # The JSON line is the LAST thing this process prints: RCCL writes a version banner through C stdio (buffered on a pipe
-    # until exit), so the C buffers are flushed first and the interpreter then leaves without running any more teardown.
+    # The JSON line is the LAST thing the job prints: RCCL writes a version banner through C stdio (buffered on a pipe until
+    # exit), so every rank flushes its C and Python buffers, the ranks meet at a barrier, rank 0 prints the line, and the
+    # interpreters leave without running any more teardown.
     sys.stdout.flush()
     sys.stderr.flush()
     try:
@@ -426,6 +424,9 @@ def main():
         ctypes.CDLL(None).fflush(None)
     except OSError:
         pass
+    if use_gather:
+        dist.barrier()
+        torch.cuda.synchronize()
     if line is not None:
         print(line, flush=True)
     if use_gather:
