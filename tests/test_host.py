@@ -148,11 +148,16 @@ def make_dna_bam(tmp_path, seed=1, n_reads=600):
     return bam
 
 
+@pytest.mark.parametrize("window_blocks", [0, 1, 2])
 @pytest.mark.parametrize("kw", [dict(), dict(use_umi=True), dict(mapq=30), dict(primary_only=True, no_duplicates=True),
                                 dict(padding=20), dict(use_umi=True, padding=150)])
-def test_packer_on_authored_indel_bam(tmp_path, kw):
+def test_packer_on_authored_indel_bam(tmp_path, kw, monkeypatch, window_blocks):
     """C++ packer == Python restatement on a BAM with indel reads over test_dna.vcf (46 records: 37 SNV,
-    5 DEL, 3 INS, 1 multi-allelic -> skipped with its row kept, :646-653)."""
+    5 DEL, 3 INS, 1 multi-allelic -> skipped with its row kept, :646-653).  window_blocks: the sweep inflates that
+    many BGZF blocks per window (VTXH_CHUNK_BLOCKS) — with 1 or 2 the file is many windows, records straddle them, and
+    the parse of one window runs beside the indexing of the next (the waiting window moves to the second buffer)."""
+    if window_blocks:
+        monkeypatch.setenv("VTXH_CHUNK_BLOCKS", str(window_blocks))
     bam = make_dna_bam(tmp_path)
     vcfp, fap, bcp = (os.path.join(G, n) for n in ("test_dna.vcf", "test_dna.fa", "dna_barcodes.tsv"))
     batch, metrics, nv, barcodes, variants = hostlib.pack_files(vcfp, bam, fap, bcp, threads=2, **kw)
@@ -173,6 +178,21 @@ def test_mtx_writer_bytes(tmp_path):
     p = str(tmp_path / "m.mtx")
     hostlib.write_mtx(p, 4, 20, [0, 1, 1, 2], [19, 14, 19, 17], [1.0, 1.0, 1.0, 2.0])
     assert open(p).read() == open(os.path.join(G, "test_consensus.mtx")).read()
+
+
+def test_mtx_writer_many_threads(tmp_path):
+    """Above 65 536 triplets the lines are formatted by several threads and every thread writes its buffer at its own
+    file offset: same text as the sequential restatement (integers, fractions, NaN)."""
+    rng = np.random.default_rng(3)
+    n = 150_000
+    row = np.sort(rng.integers(0, 5000, n)).astype(np.uint32)
+    col = rng.integers(0, 700, n).astype(np.uint32)
+    val = rng.integers(0, 4, n).astype(np.float64)
+    val[::7] = rng.integers(1, 9, len(val[::7])) / rng.integers(1, 9, len(val[::7]))
+    val[::1001] = np.nan
+    p = str(tmp_path / "big.mtx")
+    hostlib.write_mtx(p, 5000, 700, row, col, val)
+    assert open(p).read() == refpipe.mtx_text(5000, 700, row, col, val)
 
 
 def test_oracle_on_cpp_packed_batch_reproduces_fixtures():

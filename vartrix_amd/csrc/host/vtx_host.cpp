@@ -684,6 +684,8 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     ByteBuf buf;                          // decompressed bytes not yet consumed
     size_t buf_pos = 0, next_block = 0;
     size_t chunk_blocks = 512;            // blocks per inflate round; restarts small after an index-guided jump
+    size_t max_chunk_blocks = 512;
+    if (const char* e = getenv("VTXH_CHUNK_BLOCKS")) chunk_blocks = max_chunk_blocks = std::max<size_t>(1, strtoull(e, nullptr, 10));   // tests: many windows
     size_t chunk_limit_block = SIZE_MAX;  // index-guided sweep: no read-ahead beyond the block the sweep would jump to anyway
     uint64_t n_inflated = 0, n_jumps = 0;
     // the window whose records are indexed but not parsed yet (the parse of window k runs beside the indexing of window
@@ -697,7 +699,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             // a jump is ahead: small rounds, so that the sweep notices the end of its segment before it has inflated its way
             // to the jump target (dense VCFs have no jump ahead and keep the large rounds)
             if (chunk_limit_block != SIZE_MAX) chunk = std::min<size_t>(chunk, 32);
-            chunk_blocks = std::min<size_t>(512, chunk_blocks * 2);
+            chunk_blocks = std::min<size_t>(max_chunk_blocks, chunk_blocks * 2);
             if (pend_begin != SIZE_MAX && !pend_detached) {
                 // a window is indexed and waits for its parse: its bytes stay where they are (pend_store); the sweep goes on
                 // in the spare buffer, which starts with the unconsumed tail (a partial record)
@@ -1020,7 +1022,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             if (b >= blocks.size() || blocks[b].start != (size_t)(jump_voff >> 16)) return fail(VTX_E_INVAL, "%s.bai: offset outside the BAM", a->bam);
             buf.drop_prefix(buf.size());
             buf_pos = 0;
-            next_block = b; chunk_blocks = 32;
+            next_block = b; chunk_blocks = std::min<size_t>(32, max_chunk_blocks);
             refill((size_t)(jump_voff & 0xffff) + 1);
             buf_pos = (size_t)(jump_voff & 0xffff);
             if (buf_pos > buf.size()) return fail(VTX_E_INVAL, "%s.bai: offset outside its block", a->bam);
