@@ -361,3 +361,60 @@ def test_index_guided_skipping_on_a_sparse_vcf(tmp_path, monkeypatch):
     # (each far locus drags in the 30 kb its spliced read spans, and a restart over-reads up to ~100 of these tiny 4 kB
     # blocks: a third of the file stays untouched here; with 64 kB blocks and a 50 GB BAM it is nearly all of it)
     assert st["index_jumps"] >= 2 and st["blocks_inflated"] < 0.7 * st["blocks_total"], st
+
+
+def test_packer_survives_corrupted_bam(tmp_path):
+    """Truncated payloads, flipped bytes and random 32-bit words inside an authored BAM: the packer either packs
+    what is still a consistent file or returns an error — it never reads outside its buffers (the cases run in one child
+    process, so a crash shows up as its exit code)."""
+    import struct
+    import subprocess
+    import sys
+    import zlib
+    from oracle import bamwriter
+    bam = make_dna_bam(tmp_path)
+    raw = open(bam, "rb").read()
+    payload, o = b"", 0
+    while o + 18 <= len(raw):
+        bs = int.from_bytes(raw[o + 16:o + 18], "little") + 1
+        payload += zlib.decompress(raw[o + 18:o + bs - 8], -15)
+        o += bs
+    rng = np.random.default_rng(5)
+    cases = [payload[:int(c)] for c in rng.integers(50, len(payload), 12)]
+    for _ in range(12):
+        b = bytearray(payload)
+        b[int(rng.integers(300, len(payload)))] = int(rng.integers(0, 256))
+        cases.append(bytes(b))
+    for _ in range(8):
+        b = bytearray(payload)
+        pos = int(rng.integers(300, len(payload) - 4))
+        b[pos:pos + 4] = struct.pack("<I", int(rng.integers(0, 2 ** 32)))
+        cases.append(bytes(b))
+    paths = []
+    for k, pay in enumerate(cases):
+        p = str(tmp_path / ("c%02d.bam" % k))
+        with open(p, "wb") as fh:
+            for q in range(0, len(pay), 20000):
+                fh.write(bamwriter._bgzf_block(pay[q:q + 20000]))
+            fh.write(bamwriter._bgzf_block(b""))
+        if k % 2:                                       # half of them with the (now stale) index of the intact file
+            with open(p + ".bai", "wb") as fh:
+                fh.write(open(bam + ".bai", "rb").read())
+        paths.append(p)
+    code = '''
+import sys
+sys.path.insert(0, %r)
+from vartrix_amd import hostlib
+ok = err = 0
+for p in sys.argv[4:]:
+    try:
+        hostlib.pack_files(sys.argv[1], p, sys.argv[2], sys.argv[3], threads=2)
+        ok += 1
+    except Exception:
+        err += 1
+print("packed", ok, "refused", err)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    vcfp, fap, bcp = (os.path.join(G, n) for n in ("test_dna.vcf", "test_dna.fa", "dna_barcodes.tsv"))
+    r = subprocess.run([sys.executable, "-c", code, vcfp, fap, bcp] + paths, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-400:])
+    assert "packed" in r.stdout and int(r.stdout.split()[3]) > 0, r.stdout     # the truncations inside a record are refused
