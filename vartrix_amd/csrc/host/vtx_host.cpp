@@ -839,7 +839,10 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     // exactly like one sequential sweep.
     // rr offsets are relative to the worker's arenas; roff / toff: where those start in the global arenas (64-bit)
     struct Hit { uint32_t locus, cell; vtx_raw_record rr; uint64_t roff, toff; };
-    struct WorkerOut { std::vector<Hit> hits; std::string reads, tags; vtxh_metrics m{}; std::string err; uint64_t rbase = 0; };
+    // reads are not copied by the filter pass: it notes where each kept read's packed bases lie (the window's bytes stay
+    // put until the parse is over) and the second pass decodes them straight into the global arena
+    struct Decode { const unsigned char* sq; uint32_t l_seq; uint32_t off; };
+    struct WorkerOut { std::vector<Hit> hits; std::vector<Decode> dec; uint64_t reads_size = 0; std::string tags; vtxh_metrics m{}; std::string err; uint64_t rbase = 0; };
     ByteBuf& reads = P->read_arena;
     auto process = [&](const unsigned char* r, uint32_t bs, WorkerOut& o, std::vector<uint32_t>& hits) -> bool {
         const int32_t tid = rdi32(r);
@@ -904,16 +907,14 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             if (!raw && a->use_umi && rr.umi_len == VTX_TAG_MISSING) { ++o.m.num_non_umi; continue; }           // :879-888
             if (!seq_ready) {                                                               // rec.seq().as_bytes() :896
                 seq_ready = true;
-                rr.read_off = (uint32_t)o.reads.size();                       // one copy per read, shared by its loci
-                o.reads.resize(o.reads.size() + l_seq);
-                char* dst = &o.reads[rr.read_off];
-                for (uint32_t k = 0; k + 1 < l_seq; k += 2) memcpy(dst + k, &kNt16Pair[sq[k >> 1]], 2);
-                if (l_seq & 1) dst[l_seq - 1] = kNt16[sq[l_seq >> 1] >> 4];
+                rr.read_off = (uint32_t)o.reads_size;                           // one copy per read, shared by its loci
+                o.dec.push_back(Decode{sq, l_seq, rr.read_off});
+                o.reads_size += l_seq;
             }
             rr.read_len = l_seq;
             o.hits.push_back(Hit{li, cell, rr, 0, 0});
         }
-        return o.reads.size() <= 0xffffffffull && o.tags.size() <= 0xffffffffull;
+        return o.reads_size <= 0xffffffffull && o.tags.size() <= 0xffffffffull;
     };
     std::vector<size_t> rec_offs;
     // every window's worker outputs go to the global arrays at prefix offsets (thread order = BAM order), copied by the
@@ -966,7 +967,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         const unsigned char* pend_base = pend_detached ? pend_store.data() : buf.data();
         pool.run([&](size_t t) {
             WorkerOut& o = outs[t];
-            o.hits.clear(); o.reads.clear(); o.tags.clear(); o.m = vtxh_metrics{}; o.err.clear();
+            o.hits.clear(); o.dec.clear(); o.reads_size = 0; o.tags.clear(); o.m = vtxh_metrics{}; o.err.clear();
             std::vector<uint32_t> hits;
             for (size_t k = nrec * t / (size_t)threads, e = nrec * (t + 1) / (size_t)threads; k < e; ++k) {
                 const unsigned char* rp = pend_base + pend_offs[k];
@@ -978,7 +979,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         for (size_t t = 0; t < outs.size(); ++t) {
             WorkerOut& o = outs[t];
             if (!o.err.empty()) { parse_rc = o.err[0] == 'm' ? VTX_E_INVAL : VTX_E_UNSUPPORTED; parse_msg = o.err; return; }
-            o.rbase = rtotal; rtotal += o.reads.size();
+            o.rbase = rtotal; rtotal += o.reads_size;
             tbase[t] = ttotal; ttotal += o.tags.size();
             hbase[t] = htotal; htotal += o.hits.size();
             const uint64_t* src = &o.m.num_reads;
@@ -991,7 +992,11 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         Hit* all = (Hit*)hit_store.data();
         pool.run([&](size_t t) {
             const WorkerOut& o = outs[t];
-            if (!o.reads.empty()) memcpy(reads.data() + o.rbase, o.reads.data(), o.reads.size());
+            for (const Decode& d : o.dec) {                                                  // rec.seq().as_bytes() :896
+                unsigned char* dst = reads.data() + o.rbase + d.off;
+                for (uint32_t k = 0; k + 1 < d.l_seq; k += 2) memcpy(dst + k, &kNt16Pair[d.sq[k >> 1]], 2);
+                if (d.l_seq & 1) dst[d.l_seq - 1] = (unsigned char)kNt16[d.sq[d.l_seq >> 1] >> 4];
+            }
             if (!o.tags.empty()) memcpy(tag_store.data() + tbase[t], o.tags.data(), o.tags.size());
             Hit* dst = all + hbase[t];
             for (size_t k = 0; k < o.hits.size(); ++k) {
