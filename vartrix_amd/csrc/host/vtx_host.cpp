@@ -159,6 +159,20 @@ enum { FLAG_UNMAP = 0x4, FLAG_SECONDARY = 0x100, FLAG_DUP = 0x400, FLAG_SUPP = 0
 struct BgzfBlock { size_t coff; uint32_t clen; uint32_t isize; size_t start; };   // start: file offset of the block header
 
 // growable byte buffer that never zero-fills (the inflaters overwrite every byte they are given)
+// n elements of uninitialised storage (std::vector::resize would write every byte once on one thread before the
+// workers fill it: the pages are touched by the threads that write them instead)
+template <class T>
+struct RawArr {
+    T* p = nullptr;
+    size_t n = 0;
+    ~RawArr() { free(p); }
+    bool alloc(size_t count) { free(p); p = (T*)malloc(std::max<size_t>(count, 1) * sizeof(T)); n = p ? count : 0; return p != nullptr; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    T& operator[](size_t i) { return p[i]; }
+    size_t size() const { return n; }
+};
+
 struct ByteBuf {
     unsigned char* p = nullptr;
     size_t len = 0, cap = 0;
@@ -418,14 +432,14 @@ struct Interval { int64_t start, end; uint32_t locus; };
 struct vtxh_pack {
     uint64_t blocks_inflated = 0, blocks_total = 0, index_jumps = 0;      // ingest statistics (vtxh_get_ingest_stats)
     std::vector<vtx_locus> loci;
-    std::vector<vtx_record> records;
+    RawArr<vtx_record> records;
     std::string hap_arena;
     ByteBuf read_arena;            // grown without zero-fill, filled by the sweep's workers
     vtxh_metrics metrics{};
     uint32_t n_variants = 0;
     std::vector<std::string> barcodes, variant_names;
     // raw mode (vtxh_pack_files_raw)
-    std::vector<vtx_raw_record> raw_records;
+    RawArr<vtx_raw_record> raw_records;
     ByteBuf tag_arena;
     std::string bc_bytes;
     std::vector<uint64_t> bc_offsets;
@@ -1208,7 +1222,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             P->loci[l].rec_begin = (uint32_t)(l_begin[l] - P->batches[b].rec0);
         }
     if (raw) {
-        P->raw_records.resize(n_sorted);
+        if (!P->raw_records.alloc(n_sorted)) return fail(VTX_E_NOMEM, "out of memory for %zu records", n_sorted);
         pool.run([&](size_t t) {
             for (size_t l = nloc * t / (size_t)threads, e = nloc * (t + 1) / (size_t)threads; l < e; ++l) {
                 const vtxh_pack::Batch& B = P->batches[batch_of[l]];
@@ -1228,7 +1242,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     }
     // ---- cooked: UMI ids by first occurrence, then the stable sort by (cell, umi) (:932 + per-cell UMI grouping),
     //      loci in parallel (disjoint output ranges) ----
-    P->records.resize(n_sorted);
+    if (!P->records.alloc(n_sorted)) return fail(VTX_E_NOMEM, "out of memory for %zu records", n_sorted);
     {
         std::atomic<size_t> next_locus{0};
         auto pack_loci = [&]() {
