@@ -315,6 +315,33 @@ def test_records_beyond_the_fast_limits_take_the_exact_slow_path():
     assert ref_s.max() > 1000          # the long read really aligned end to end
 
 
+@pytest.mark.parametrize("raw", [False, True])
+def test_slow_records_with_ordinary_reads_only(raw):
+    """--padding 1500: every haplotype (3 001 bases) exceeds the fast kernels' tables, so EVERY record is on the slow
+    list — with reads of 150 bases only.  The slow path's DP columns are sized by the longest read among the slow
+    records (round-2 ADVICE: they were sized by the longest read above 1 024 bases, i.e. by nothing here, and the
+    columns of neighbouring lanes overlapped).  Both submit paths compute that maximum."""
+    spec = synth.SynthSpec(n_loci=5, n_barcodes=24, reads_per_locus=14, padding=1500, seed=77, read_len_jitter=30)
+    batch = synth.make_batch(spec)
+    assert int(batch.loci["ref_len"].min()) == 3001 and int(batch.records["read_len"].max()) <= 150
+    for aligner in ALIGNERS:
+        cfg = default_config(aligner=aligner, scoring_mode="coverage", use_umi=0, n_barcodes=spec.n_barcodes)
+        if not raw:
+            ref_s, _, _ = assert_same(batch, cfg, threads=4)
+            assert ref_s.max() > 100
+            continue
+        rb, barcodes = synth.make_raw(batch, spec.n_barcodes, use_umi=False, seed=3)
+        with lib.Context(cfg) as ctx:
+            ctx.set_barcodes(barcodes)
+            ctx.submit_raw(rb)
+            ctx.run()
+            coo = ctx.fetch_coo()
+        oref, oalt = oracle.batch_scores(batch, cfg, threads=4)
+        ocoo = oracle.batch_reduce(batch, cfg, oref, oalt)
+        for k in ("row", "col", "alt", "ref", "unk"):
+            assert np.array_equal(coo[k], ocoo[k]), k
+
+
 @pytest.mark.parametrize("hook", ["VTX_BAND_HARD_CAP", "VTX_BAND_SLOTS"])
 def test_band_buffer_caps_spill_into_the_general_kernel(tmp_path, hook):
     """Polyline records, pending records and band slots are sized for a fraction of the tasks.  VTX_BAND_HARD_CAP=3 leaves

@@ -144,10 +144,10 @@ __global__ __launch_bounds__(256) void prep_finalize_kernel(
         atomicAdd(&s_shape[my_shape], 1u);            // LDS atomic: mostly one address, the LDS unit coalesces equal-address adds
         cells += (unsigned long long)rl * ((unsigned long long)loci[locus].ref_len + loci[locus].alt_len);
         if (!slow) max_rl = max(max_rl, rl);
-        max_all = max(max_all, rl);
+        else max_all = max(max_all, rl);              // longest read among the SLOW records (long read or long haplotype)
     }
     for (int o = 32; o > 0; o >>= 1) { cells += __shfl_down(cells, o); max_rl = max(max_rl, __shfl_down(max_rl, o)); max_all = max(max_all, __shfl_down(max_all, o)); }
-    if ((threadIdx.x & 63) == 0 && max_all > VTX_FAST_READ_LEN) atomicMax(&counters[7], (unsigned long long)max_all);   // only slow records exceed it
+    if ((threadIdx.x & 63) == 0 && max_all) atomicMax(&counters[7], (unsigned long long)max_all);   // sizes slow_align_kernel's DP columns: a record is slow for a long read OR a long haplotype
     if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cells, cells); atomicMax(&s_maxlen, max_rl); }
     if (collide) s_collide = 1;
     __syncthreads();
@@ -214,14 +214,14 @@ __global__ __launch_bounds__(256) void prep_check_kernel(
         atomicAdd(&s_shape[my_shape], 1u);
         cells += (unsigned long long)r.read_len * ((unsigned long long)loci[locus].ref_len + loci[locus].alt_len);
         if (!slow) max_rl = max(max_rl, r.read_len);
-        max_all = max(max_all, min(r.read_len, max_read_len));
+        else max_all = max(max_all, min(r.read_len, max_read_len));   // longest read among the SLOW records
     }
     for (int o = 32; o > 0; o >>= 1) {
         cells += __shfl_down(cells, o); max_rl = max(max_rl, __shfl_down(max_rl, o)); max_all = max(max_all, __shfl_down(max_all, o));
         bad = min(bad, (unsigned long long)__shfl_down(bad, o));
     }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cells, cells); atomicMax(&s_maxlen, max_rl); atomicMin(&s_bad, bad); }
-    if ((threadIdx.x & 63) == 0 && max_all > VTX_FAST_READ_LEN) atomicMax(&counters[7], (unsigned long long)max_all);   // only slow records exceed it
+    if ((threadIdx.x & 63) == 0 && max_all) atomicMax(&counters[7], (unsigned long long)max_all);   // sizes slow_align_kernel's DP columns: a record is slow for a long read OR a long haplotype
     __syncthreads();
     if (threadIdx.x <= n_shapes && s_shape[threadIdx.x]) atomicAdd(&shape_cnt[threadIdx.x], s_shape[threadIdx.x]);
     if (threadIdx.x == 0) {
