@@ -245,7 +245,7 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    sw_ms, red_ms, full_ms, band_ms, run_ms = [], [], [], [], []
+    sw_ms, red_ms, full_ms, band_ms, run_ms, diag_ms = [], [], [], [], [], []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -256,6 +256,7 @@ def main():
         full_ms.append(t.full_ms)
         band_ms.append(t.band_ms)
         run_ms.append(t.band_run_ms)
+        diag_ms.append(t.diag_ms)
     drain()               # every step's gather has completed inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
@@ -356,7 +357,8 @@ def main():
                          "note": "integer seed / chain / DP work: neither HBM nor MFMA binds it (86 B per alignment); the HBM "
                                  "fraction is reported because north_star asks for it, see roofline_valu"},
             "timing": {"sw_kernel_ms": sw_avg_ms, "full_kernel_ms": full_avg_ms, "band_kernels_ms": float(np.mean(band_ms)),
-                       "band_run_kernel_ms": run_avg_ms, "reduce_ms": float(np.mean(red_ms)), "submit_h2d_s": t_sub,
+                       "band_run_kernel_ms": run_avg_ms, "band_diag_ms": float(np.mean(diag_ms)),
+                       "diag_left_tasks": int(ctx.timing().diag_left), "reduce_ms": float(np.mean(red_ms)), "submit_h2d_s": t_sub,
                        "generate_s": t_gen, "hard_tasks": int(ctx.timing().hard_tasks),
                        "overflow_tasks": int(ctx.timing().overflow_tasks),
                        "pcie_inclusive_alignments_per_s": n_aln / (t_sub + elapsed / args.steps)},

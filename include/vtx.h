@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define VTX_ABI_VERSION 2
+#define VTX_ABI_VERSION 3
 
 typedef enum vtx_status {
     VTX_OK = 0,
@@ -58,7 +58,8 @@ typedef enum vtx_status {
     VTX_E_HIP = -3,        /* a HIP runtime call failed                           */
     VTX_E_NOMEM = -4,      /* host or device allocation failed                    */
     VTX_E_UNSUPPORTED = -5,/* valid request this build cannot serve               */
-    VTX_E_STATE = -6       /* call sequence error (e.g. fetch before run)         */
+    VTX_E_STATE = -6,      /* call sequence error (e.g. fetch before run)         */
+    VTX_E_PEER = -7        /* a collective was abandoned because another rank reported an error */
 } vtx_status;
 
 /* Which restatement of bio::alignment::pairwise::banded::Aligner::local
@@ -161,6 +162,8 @@ typedef struct vtx_timing {
     float band_ms;         /* band kernels + band-masked DP (banded flavour; part of sw_ms) */
     float band_run_ms;     /* band_run_kernel launches only (seeds, chain, certificate; part of band_ms) */
     uint32_t overflow_tasks; /* banded flavour: alignments handed to the general band kernel        */
+    float diag_ms;         /* band_tables_kernel + band_diag_kernel (single-diagonal stage; part of band_run_ms)   */
+    uint32_t diag_left;    /* alignments the single-diagonal stage left to band_run_kernel                          */
 } vtx_timing;
 
 typedef struct vtx_ctx vtx_ctx;

@@ -1,0 +1,77 @@
+// fastcore_host.cpp — HOST build of the per-task logic of band_diag_kernel (vartrix_amd/csrc/vtx_fast_core.h), for the
+// CPU unit tests of that logic against the oracle (tests/test_fastcore.py).  TEST INFRASTRUCTURE ONLY: the product
+// (libvtx.so) never links or loads this; it exists because the container that runs `pytest -m "not gpu"` has no GPU and
+// the kernel's decisions (which tasks it may score without a DP, and with what) must be checked on millions of cases.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/vtx.h"
+#include "../../vartrix_amd/csrc/vtx_fast_core.h"
+
+namespace {
+// serial restatement of build_tables (vtx_band.hip): same layout, same chain order (ascending y), same flags
+void build_table(uint8_t* tb, const uint8_t* hy, uint32_t hn, uint32_t max_hap, uint32_t n_heads) {
+    using namespace vtxf;
+    memset(tb, 0, tab_stride(max_hap, n_heads));
+    uint64_t* ent = (uint64_t*)tb;
+    uint16_t* head = (uint16_t*)(tb + (size_t)max_hap * 8);
+    uint8_t* bytes = tb + tab_bytes_off(max_hap, n_heads);
+    uint8_t* fb = tb + tab_fb_off(max_hap, n_heads);
+    uint32_t* uq = (uint32_t*)(tb + tab_uq_off(max_hap, n_heads)) + UQ_PAD_WORDS;
+    for (uint32_t i = 0; i < n_heads; ++i) head[i] = 0xffff;
+    for (uint32_t y = 0; y < hn; ++y) { bytes[y] = hy[y]; fb[y] = hy[y] & 0x7f; }
+    if (hn < 6) return;
+    auto lo_of = [&](uint32_t y) { return (uint32_t)hy[y] | ((uint32_t)hy[y + 1] << 8) | ((uint32_t)hy[y + 2] << 16) | ((uint32_t)hy[y + 3] << 24); };
+    auto hi_of = [&](uint32_t y) { return (uint32_t)hy[y + 4] | ((uint32_t)hy[y + 5] << 8); };
+    for (int y = (int)hn - 6; y >= 0; --y) {
+        const uint32_t h = kw_hash(lo_of((uint32_t)y), hi_of((uint32_t)y), n_heads - 1);
+        ent[y] = (uint64_t)lo_of((uint32_t)y) | ((uint64_t)hi_of((uint32_t)y) << 32) | ((uint64_t)head[h] << 48);
+        head[h] = (uint16_t)y;
+    }
+    for (uint32_t y = 0; y + 6 <= hn; ++y) {
+        uint32_t same = 0;
+        for (uint32_t z = 0; z + 6 <= hn; ++z) same += memcmp(hy + y, hy + z, 6) == 0;
+        if (same == 1) { uq[y >> 5] |= 1u << (y & 31); fb[y + 5] |= 0x80; }
+    }
+}
+}  // namespace
+
+extern "C" {
+// Per task t = 2 * record + hap of a packed batch: score[t] (-1: left to band_run_kernel) and why[t].
+int vtxt_fastcore_batch(const vtx_batch* b, uint32_t n_heads, int32_t* score, uint32_t* why) {
+    using namespace vtxf;
+    uint32_t max_hap = 8;
+    for (uint32_t l = 0; l < b->n_loci; ++l) max_hap = std::max(max_hap, std::max(b->loci[l].ref_len, b->loci[l].alt_len));
+    const uint32_t stride = tab_stride(max_hap, n_heads);
+    std::vector<uint8_t> gt((size_t)2 * stride + 64);
+    std::vector<uint8_t> readbuf;
+    uint32_t lane[LANE_WORDS];
+    for (uint32_t l = 0; l < b->n_loci; ++l) {
+        const vtx_locus& L = b->loci[l];
+        build_table(gt.data(), b->hap_arena + L.ref_off, L.ref_len, max_hap, n_heads);
+        build_table(gt.data() + stride, b->hap_arena + L.alt_off, L.alt_len, max_hap, n_heads);
+        for (uint32_t r = L.rec_begin; r < L.rec_begin + L.rec_count; ++r) {
+            const vtx_record& R = b->records[r];
+            readbuf.assign(R.read_len + 16, 0);
+            memcpy(readbuf.data(), b->read_arena + R.read_off, R.read_len);
+            for (int h = 0; h < 2; ++h) {
+                Tab tb;
+                tb.gt = gt.data();
+                tb.ent = (uint32_t)h * stride;
+                tb.head = tb.ent + max_hap * 8;
+                tb.bytes = tb.ent + tab_bytes_off(max_hap, n_heads);
+                tb.uq = tb.ent + tab_uq_off(max_hap, n_heads);
+                tb.hmask = n_heads - 1;
+                Lane ln{lane, 1};
+                const Result res = fast_task(readbuf.data(), (int)R.read_len, tb, (int)(h ? L.alt_len : L.ref_len), ln);
+                score[2 * (size_t)r + h] = res.score;
+                why[2 * (size_t)r + h] = res.why;
+            }
+        }
+    }
+    return 0;
+}
+}

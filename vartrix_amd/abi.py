@@ -12,7 +12,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-VTX_ABI_VERSION = 2
+VTX_ABI_VERSION = 3
 
 VTX_OK = 0
 VTX_E_INVAL = -1
@@ -21,6 +21,7 @@ VTX_E_HIP = -3
 VTX_E_NOMEM = -4
 VTX_E_UNSUPPORTED = -5
 VTX_E_STATE = -6
+VTX_E_PEER = -7
 
 ALIGNER_BANDED = 0
 ALIGNER_FULL = 1
@@ -116,6 +117,8 @@ class VtxTiming(C.Structure):
         ("band_ms", C.c_float),
         ("band_run_ms", C.c_float),
         ("overflow_tasks", C.c_uint32),
+        ("diag_ms", C.c_float),
+        ("diag_left", C.c_uint32),
     ]
 
 

@@ -91,7 +91,7 @@ struct vtx_ctx {
     uint64_t g_nnz = 0;
     uint32_t* h_pin = nullptr;               // pinned words for counters read back asynchronously (a D2H copy into pageable
                                              // memory blocks the host until the stream reaches it)
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {};
     std::string err;
     bool submitted = false, ran = false;
     uint32_t n_loci = 0, n_records = 0, n_cell_groups = 0, n_umi_groups = 0, max_hap_len = 0;
@@ -103,7 +103,7 @@ struct vtx_ctx {
     DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
     bool band_long_lists = false;      // (performance feedback between runs: see vtx_run)
-    DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2;   // banded flavour
+    DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail;   // banded flavour
     DevBuf d_redo, d_redo_cnt;                                               // LUT kernel: records with non-ACGTN bytes
     // raw batches (vtx_submit_raw): barcode table + preparation scratch
     DevBuf d_bc_slots, d_bc_hash, d_bc_off, d_bc_bytes;
@@ -492,6 +492,7 @@ const char* vtx_status_name(int status) {
     case VTX_E_NOMEM: return "VTX_E_NOMEM";
     case VTX_E_UNSUPPORTED: return "VTX_E_UNSUPPORTED";
     case VTX_E_STATE: return "VTX_E_STATE";
+    case VTX_E_PEER: return "VTX_E_PEER";
     default: return "VTX_E_?";
     }
 }
@@ -624,7 +625,8 @@ static int band_reserve(vtx_ctx* c, BandPlan& p, bool quiet) {
     RES(d_band, (size_t)p.slots * 2 * p.band_stride * sizeof(uint16_t));
     RES(d_hard, ((size_t)p.hard_cap + p.pend_cap) * sizeof(uint32_t));
     RES(d_over, 2 * (size_t)p.n_tasks * sizeof(uint32_t));      // second chance: what overflows again is appended behind the first list
-    RES(d_cnt, 32 * sizeof(uint32_t));
+    RES(d_cnt, 64 * sizeof(uint32_t));
+    if (p.gt_bytes) RES(d_fail, (size_t)p.chunk * sizeof(uint32_t));      // tasks band_diag_kernel leaves to band_run_kernel
 #undef RES
     return VTX_OK;
 }
@@ -1068,9 +1070,11 @@ int vtx_run(vtx_ctx* c) {
             HIP_TRY(c, hipStreamWaitEvent(s, c->ev2, 0));             // the reduction kernels read every score
             return VTX_OK;
         };
-        HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 32 * sizeof(uint32_t), s));
+        HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 64 * sizeof(uint32_t), s));
         uint32_t cnt[12] = {0};
         uint32_t pending_total = 0, over_before = 0;
+        uint64_t diag_total = 0, diag_left = 0;
+        float diag_ms = 0;
         for (uint64_t base = 0; base < n_tasks; base += chunk) {
             const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, n_tasks - base);
             HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), s));                 // hard count of this chunk
@@ -1088,17 +1092,44 @@ int vtx_run(vtx_ctx* c) {
                 if (gt_n > bp.gt_loci) gt_n = 0;              // does not fit after all: tables in LDS for this chunk
             }
             HIP_TRY(c, hipEventRecord(c->ev[4], s));
-            HIP_TRY(c, vtxk_launch_band_run(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                             c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
-                                             c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
-                                             c->d_band_ws.as<uint32_t>(), c->d_poly.as<uint16_t>(), poly_stride / 2,
-                                             c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
-                                             c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt,
-                                             tasks_per_locus, gt_l0, gt_n, gt_n ? c->d_gtables.as<uint8_t>() : nullptr, gt_bytes,
-                                             nullptr, c->band_long_lists ? 1 : 0, s));
+            // Stage 1 (tables in global memory): band_diag_kernel decides the tasks whose alignment lives on one diagonal
+            // (vtx_fast_core.h) and lists the others; band_run_kernel then takes that LIST instead of the whole range.
+            static const bool no_diag = getenv("VTX_BAND_NO_DIAG") != nullptr;          // experiment / test hook: stage 1 off
+            static const int diag_stats = getenv("VTX_DEBUG") ? 1 : 0;
+            bool diag = false;
+            uint32_t n_fail = 0;
+            if (gt_n && !no_diag) {
+                HIP_TRY(c, hipMemsetAsync(d_cnt + 12, 0, sizeof(uint32_t), s));
+                const hipError_t e = vtxk_launch_band_diag(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                           c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                                           c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
+                                                           c->d_fail.as<uint32_t>(), d_cnt, tasks_per_locus, gt_l0, gt_n,
+                                                           c->d_gtables.as<uint8_t>(), gt_bytes, diag_stats, s);
+                if (e == hipSuccess) {
+                    diag = true;
+                    HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipEventRecord(c->ev[6], s));
+                    HIP_TRY(c, hipStreamSynchronize(s));
+                    n_fail = c->h_pin[8];
+                    diag_total += nt; diag_left += n_fail;
+                    ++launches;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+            if (!diag || n_fail)
+                HIP_TRY(c, vtxk_launch_band_run(diag ? n_fail : nt, diag ? 0u : (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                 c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                                 c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
+                                                 c->d_band_ws.as<uint32_t>(), c->d_poly.as<uint16_t>(), poly_stride / 2,
+                                                 c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
+                                                 c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt,
+                                                 tasks_per_locus, gt_l0, gt_n, gt_n ? c->d_gtables.as<uint8_t>() : nullptr, gt_bytes,
+                                                 diag ? c->d_fail.as<uint32_t>() : nullptr, c->band_long_lists ? 1 : 0, s));
             HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
-            const bool short_lists = gt_n && vtxk_band_second_chance(tasks_per_locus, c->band_long_lists ? 1 : 0);
+            // (task-list mode runs the 15-entry variant: nothing to give a second chance to)
+            const bool short_lists = !diag && gt_n && vtxk_band_second_chance(tasks_per_locus, c->band_long_lists ? 1 : 0);
             if (short_lists && nt >= (1u << 20)) {
                 // feedback for the next run of this context: many overflows of the 12-entry lists (noisy reads: 3.3 % of the
                 // tasks at 3 % substitution errors, 0.2 % at 0.5 %) make the 15-entry variant the better first pass
@@ -1132,6 +1163,7 @@ int vtx_run(vtx_ctx* c) {
                 float ms = 0;
                 HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
                 band_run_ms += ms;
+                if (diag) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[6])); diag_ms += ms; }
             }
             if (base + chunk >= n_tasks && cnt[1])                     // last chunk: the overflow list is complete
                 if (int rc = fallback_start(0, cnt[1])) return rc;
@@ -1163,13 +1195,21 @@ int vtx_run(vtx_ctx* c) {
         }
         if (int rc = fallback_finish()) return rc;
         c->fast_overflow = fast_overflow;
+        c->timing.diag_ms = diag_ms; c->timing.diag_left = (uint32_t)std::min<uint64_t>(diag_left, 0xffffffffull);
+        if (getenv("VTX_DEBUG") && diag_total) {
+            uint32_t why[16];
+            HIP_TRY(c, hipMemcpy(why, d_cnt + 32, sizeof why, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[vtx] band_diag_kernel: %llu of %llu tasks left to band_run_kernel (%.2f %%), %.2f ms: shape=%u no-diagonal=%u pieces=%u matches=%u not-harmless=%u generic=%u not-tight=%u no-main=%u\n",
+                    (unsigned long long)diag_left, (unsigned long long)diag_total, 100.0 * (double)diag_left / (double)diag_total, (double)diag_ms,
+                    why[1], why[2], why[3], why[4], why[5], why[7], why[8], why[9]);
+        }
         if (getenv("VTX_DEBUG")) fprintf(stderr, "[vtx] banded: %llu tasks, %u overflowed band_run_kernel, %u bounded by the pending kernel, %u hard\n", (unsigned long long)n_tasks, fast_overflow, pending_total, hard_total);
     }
     if (c->slow_cnt) {
         // records beyond the fast kernels' limits: exact slow path, both flavours (slabs grow until every chain fits)
         const uint32_t n_slow = 2 * c->slow_cnt;
         const int banded = c->cfg.aligner == VTX_ALIGNER_BANDED;
-        HIP_TRY(c, c->d_cnt.reserve(32 * sizeof(uint32_t)));
+        HIP_TRY(c, c->d_cnt.reserve(64 * sizeof(uint32_t)));
         uint32_t* d_scnt = c->d_cnt.as<uint32_t>() + 13;
         HIP_TRY(c, c->d_slow_retry.reserve(2 * (size_t)n_slow * sizeof(uint32_t)));
         const uint32_t* tasks = nullptr;

@@ -45,6 +45,7 @@
 #include <cstring>
 
 #include "vtx_device.h"
+#include "vtx_fast_core.h"
 #include "../../include/vtx_band_semantics.h"
 
 #define KMER 6
@@ -408,14 +409,14 @@ __device__ __forceinline__ uint32_t kw_hash(uint32_t lo, uint32_t hi, uint32_t h
 // LDS table of one haplotype (band_run_kernel): ent[y] = {k-mer bytes 0-3, bytes 4-5 | next y << 16} (one 8-byte load per
 // chain step), head[n_heads] u16, bytes[max_hap + 8] raw haplotype bytes (staircase walk), fb[max_hap + 8] flag bytes:
 // fb[y] = (byte y & 0x7f) | 0x80 if the k-mer that ENDS at y is unique in the haplotype (continuation shortcut).
-static size_t band_table_stride(uint32_t max_hap, uint32_t n_heads) {
-    size_t o = (size_t)max_hap * 8 + (size_t)n_heads * 2 + 2 * ((size_t)max_hap + 8);
-    return (o + 15) & ~(size_t)15;
-}
+// ... and uq[] (vtx_fast_core.h: tab_uq_off): one bit per position, set if the k-mer STARTING there is unique, behind
+// UQ_PAD_WORDS zero words (band_diag_kernel reads 192 bits of it at the bit offset of its diagonal).
+static size_t band_table_stride(uint32_t max_hap, uint32_t n_heads) { return vtxf::tab_stride(max_hap, n_heads); }
 #define TB_ENT(tb) ((uint2*)(tb))
 #define TB_HEAD(tb) ((uint16_t*)((tb) + (size_t)max_hap * 8))
 #define TB_BYTES(tb) ((uint8_t*)(TB_HEAD(tb) + n_heads))
 #define TB_FB(tb) (TB_BYTES(tb) + max_hap + 8)
+#define TB_UQ(tb) ((uint32_t*)((tb) + vtxf::tab_uq_off(max_hap, n_heads)))
 
 // Tail of band_run_kernel: traceback through the jump log (chain = a few diagonal segments), walk of
 // the anchor staircase (its local score = the lower bound `cert`), polyline for hard tasks.
@@ -781,6 +782,8 @@ __device__ __forceinline__ void build_tables(uint8_t* tables, uint32_t n_tab, ui
                 }
             }
             for (uint32_t i = tid; i < n_heads; i += NT) head[i] = CH_END;
+            uint32_t* uq = TB_UQ(tb);
+            for (uint32_t i = tid; i < vtxf::tab_uq_words(max_hap); i += NT) uq[i] = 0;
         }
         __syncthreads();
         if ((uint32_t)tid < n_tab) {     // one lane per table: sequential head insertion, descending y => ascending chains
@@ -817,12 +820,16 @@ __device__ __forceinline__ void build_tables(uint8_t* tables, uint32_t n_tab, ui
             const uint2* ent = TB_ENT(tb);
             const uint16_t* head = TB_HEAD(tb);
             uint8_t* fb = TB_FB(tb);
+            uint32_t* uq = TB_UQ(tb) + vtxf::UQ_PAD_WORDS;
             for (uint32_t y = tid; y + KMER <= hn; y += NT) {
                 const uint2 k = ent[y];
                 uint32_t same = 0;
                 for (uint32_t e = head[kw_hash(k.x, k.y & 0xffffu, n_heads - 1)]; e != CH_END; e = ent[e].y >> 16)
                     same += (ent[e].x == k.x && ((ent[e].y ^ k.y) & 0xffffu) == 0);
-                if (same == 1) fb[y + KMER - 1] |= 0x80;      // only this thread touches that byte
+                if (same == 1) {
+                    fb[y + KMER - 1] |= 0x80;      // only this thread touches that byte
+                    atomicOr(&uq[y >> 5], 1u << (y & 31u));
+                }
             }
         }
         __syncthreads();
@@ -1428,6 +1435,72 @@ __global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __rest
     }
 }
 
+// =============================================================================================
+// band_diag_kernel — first stage of the banded flavour when the k-mer tables live in global memory: one lane per task,
+// the per-task logic of vtx_fast_core.h (main-diagonal match mask, probes of the few rows that can hold an off-diagonal
+// k-mer match, closed-form sdpkpp on the diagonal, certificate = best local score of the mask, run bound over the generic
+// pieces).  Tasks it decides get their score here; the others are appended to fail_list for band_run_kernel (task-list
+// mode), which handles every shape.  One wavefront per workgroup, 64 consecutive tasks (lanes 2i / 2i + 1 = the two
+// haplotypes of one record: their read loads coalesce); the blocks are dealt so that each XCD works through one
+// contiguous eighth of the batch (workgroups go to the XCDs round-robin): the ~8 wavefronts that share a locus' tables
+// and reads meet in one L2.
+// counters[12] = tasks left to band_run_kernel; counters[32 + why] = reasons (stats != 0).
+// =============================================================================================
+template <int WPE>
+__global__ __launch_bounds__(64, WPE) void band_diag_kernel(
+    uint32_t n_tasks, uint32_t task_base, uint32_t n_blocks,
+    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
+    const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
+    const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
+    uint32_t* __restrict__ fail_list, uint32_t* __restrict__ counters, uint32_t stats) {
+    __shared__ uint32_t lane_mem[vtxf::LANE_WORDS * 64];
+    const int tid = threadIdx.x;
+    const uint32_t per_xcd = (n_blocks + 7) / 8;
+    const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (blk >= n_blocks) return;
+    const uint32_t slot = blk * 64 + tid;
+    const bool have = slot < n_tasks;
+    const uint32_t task = task_base + slot;
+    bool fail = false;
+    uint32_t why = 0;
+    if (have) {
+        const uint32_t rid = task >> 1, hap = task & 1;
+        const vtx_record rec = records[rid];
+        const uint32_t my_locus = rec_locus[rid];
+        const vtx_locus loc = loci[my_locus];
+        const uint32_t m = rec.read_len, n = hap ? loc.alt_len : loc.ref_len;
+        int32_t* my_score = (hap ? alt_score : ref_score) + rid;
+        if (m == 0 || n == 0) {
+            *my_score = 0;                                               // empty read / haplotype: score 0
+        } else if (m > VTX_FAST_READ_LEN || max(loc.ref_len, loc.alt_len) > max_hap) {
+            // beyond the fast kernels: slow_align_kernel scores it (the host lists these records)
+        } else {
+            vtxf::Tab tb;
+            tb.gt = gtables;
+            tb.ent = (uint32_t)(((size_t)(my_locus - gt_l0) * 2 + hap) * table_stride);
+            tb.head = tb.ent + max_hap * 8u;
+            tb.bytes = tb.ent + vtxf::tab_bytes_off(max_hap, n_heads);
+            tb.uq = tb.ent + vtxf::tab_uq_off(max_hap, n_heads);
+            tb.hmask = n_heads - 1;
+            const vtxf::Lane ln{lane_mem + tid, 64};
+            const vtxf::Result res = vtxf::fast_task(read_arena + rec.read_off, (int)m, tb, (int)n, ln);
+            if (res.score >= 0) *my_score = res.score;
+            else { fail = true; why = res.why; }
+        }
+    }
+    const uint64_t fm = __ballot(fail);
+    if (fm) {
+        uint32_t base = 0;
+        const int leader = __ffsll((long long)fm) - 1;
+        if (tid == leader) base = atomicAdd(&counters[12], (uint32_t)__popcll(fm));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (fail) {
+            fail_list[base + (uint32_t)__popcll(fm & ((1ull << tid) - 1ull))] = task;
+            if (stats) atomicAdd(&counters[32 + why], 1u);
+        }
+    }
+}
+
 // Resident workgroups of band_run_kernel (an upper bound: 256 CUs x the most workgroups a CU can hold for that block
 // size); the per-lane scratch is sized from it.
 // tables in global memory below this many tasks per locus (experiment knob VTX_BAND_GT_MAX_TPL; 0: never)
@@ -1555,6 +1628,27 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     else if (variant == 3) LAUNCH_RUN(64, true, 6, 12)
     else if (wave_wg) LAUNCH_RUN(64, false, VTX_WPE, VTX_PS) else LAUNCH_RUN(256, false, VTX_WPE, VTX_PS)
 #undef LAUNCH_RUN
+    return hipGetLastError();
+}
+
+// Tables of loci [gt_l0, gt_l0 + n_loci) into gtables (the same layout and bucket count vtxk_launch_band_run picks for this
+// shape of data), then band_diag_kernel over tasks [task_base, task_base + n_tasks).  Returns hipErrorInvalidValue when the
+// tables do not fit the buffer (the caller then runs band_run_kernel alone, which falls back to tables in LDS).
+extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
+                                            const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
+                                            const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score, int32_t* alt_score,
+                                            uint32_t* fail_list, uint32_t* counters, uint32_t tasks_per_locus, uint32_t gt_l0,
+                                            uint32_t n_loci, uint8_t* gtables, size_t gtables_bytes, int stats, hipStream_t s) {
+    if (!n_tasks) return hipSuccess;
+    const uint32_t n_heads = pick_heads(tasks_per_locus, true);
+    const size_t tstride = band_table_stride(max_hap, n_heads);
+    if (!gtables || (size_t)n_loci * 2 * tstride > gtables_bytes) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(n_loci, 256u * 16u)), dim3(64), 2 * tstride, s, loci, gt_l0, n_loci,
+                       hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
+    const uint32_t n_blocks = (n_tasks + 63) / 64;
+    hipLaunchKernelGGL(band_diag_kernel<4>, dim3(((n_blocks + 7) / 8) * 8), dim3(64), 0, s, n_tasks, task_base, n_blocks, records,
+                       rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
+                       alt_score, fail_list, counters, (uint32_t)stats);
     return hipGetLastError();
 }
 
