@@ -21,16 +21,25 @@ void build_table(uint8_t* tb, const uint8_t* hy, uint32_t hn, uint32_t max_hap, 
     uint8_t* bytes = tb + tab_bytes_off(max_hap, n_heads);
     uint8_t* fb = tb + tab_fb_off(max_hap, n_heads);
     uint32_t* uq = (uint32_t*)(tb + tab_uq_off(max_hap, n_heads)) + UQ_PAD_WORDS;
+    uint32_t* pb = (uint32_t*)(tb + tab_pb_off(max_hap, n_heads));
     for (uint32_t i = 0; i < n_heads; ++i) head[i] = 0xffff;
     for (uint32_t y = 0; y < hn; ++y) { bytes[y] = hy[y]; fb[y] = hy[y] & 0x7f; }
     if (hn < 6) return;
     auto lo_of = [&](uint32_t y) { return (uint32_t)hy[y] | ((uint32_t)hy[y + 1] << 8) | ((uint32_t)hy[y + 2] << 16) | ((uint32_t)hy[y + 3] << 24); };
     auto hi_of = [&](uint32_t y) { return (uint32_t)hy[y + 4] | ((uint32_t)hy[y + 5] << 8); };
+    std::vector<uint32_t> count(n_heads, 0), tag(n_heads, 0);
     for (int y = (int)hn - 6; y >= 0; --y) {
-        const uint32_t h = kw_hash(lo_of((uint32_t)y), hi_of((uint32_t)y), n_heads - 1);
+        const uint32_t hh = kw_mix(lo_of((uint32_t)y), hi_of((uint32_t)y));
+        const uint32_t h = kw_bucket(hh, n_heads - 1);
         ent[y] = (uint64_t)lo_of((uint32_t)y) | ((uint64_t)hi_of((uint32_t)y) << 32) | ((uint64_t)head[h] << 48);
         head[h] = (uint16_t)y;
+        ++count[h]; tag[h] = kw_tag(hh);
+        const uint32_t code = kw_code(lo_of((uint32_t)y), hi_of((uint32_t)y));
+        pb[code >> 5] |= 1u << (code & 31);
     }
+    // tags: a bucket with one entry carries 4 hash bits of its k-mer, a bucket with more HEAD_MULTI
+    for (uint32_t h = 0; h < n_heads; ++h)
+        if (count[h]) head[h] = (uint16_t)(head[h] | ((count[h] == 1 ? tag[h] : HEAD_MULTI) << 12));
     for (uint32_t y = 0; y + 6 <= hn; ++y) {
         uint32_t same = 0;
         for (uint32_t z = 0; z + 6 <= hn; ++z) same += memcmp(hy + y, hy + z, 6) == 0;
@@ -64,6 +73,7 @@ int vtxt_fastcore_batch(const vtx_batch* b, uint32_t n_heads, int32_t* score, ui
                 tb.head = tb.ent + max_hap * 8;
                 tb.bytes = tb.ent + tab_bytes_off(max_hap, n_heads);
                 tb.uq = tb.ent + tab_uq_off(max_hap, n_heads);
+                tb.pb = tb.ent + tab_pb_off(max_hap, n_heads);
                 tb.hmask = n_heads - 1;
                 Lane ln{lane, 1};
                 const Result res = fast_task(readbuf.data(), (int)R.read_len, tb, (int)(h ? L.alt_len : L.ref_len), ln);

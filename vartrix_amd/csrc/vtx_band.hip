@@ -400,6 +400,8 @@ static_assert(VTX_PS >= PS_MIN && VTX_PS <= 24, "list + spill entries of a task 
 #define NONE_ID 0xffffffffu
 #define CH_END 0xffffu     // end of a k-mer chain / empty bucket
 
+// position part of a tagged head word (build_tables: bits 12-15 carry a tag for band_diag_kernel); CH_END stays CH_END
+__device__ __forceinline__ uint32_t head_pos(uint32_t raw) { return raw == 0xffffu ? 0xffffu : (raw & 0xfffu); }
 __device__ __forceinline__ uint32_t kw_hash(uint32_t lo, uint32_t hi, uint32_t head_mask) {
     // one 32-bit multiply (a quarter-rate instruction): the two bytes of `hi` are folded in with a rotation first
     const uint32_t h = (lo ^ (hi << 11) ^ (hi >> 3)) * 0x9E3779B1u;
@@ -417,6 +419,7 @@ static size_t band_table_stride(uint32_t max_hap, uint32_t n_heads) { return vtx
 #define TB_BYTES(tb) ((uint8_t*)(TB_HEAD(tb) + n_heads))
 #define TB_FB(tb) (TB_BYTES(tb) + max_hap + 8)
 #define TB_UQ(tb) ((uint32_t*)((tb) + vtxf::tab_uq_off(max_hap, n_heads)))
+#define TB_PB(tb) ((uint32_t*)((tb) + vtxf::tab_pb_off(max_hap, n_heads)))
 
 // Tail of band_run_kernel: traceback through the jump log (chain = a few diagonal segments), walk of
 // the anchor staircase (its local score = the lower bound `cert`), polyline for hard tasks.
@@ -783,7 +786,7 @@ __device__ __forceinline__ void build_tables(uint8_t* tables, uint32_t n_tab, ui
             }
             for (uint32_t i = tid; i < n_heads; i += NT) head[i] = CH_END;
             uint32_t* uq = TB_UQ(tb);
-            for (uint32_t i = tid; i < vtxf::tab_uq_words(max_hap); i += NT) uq[i] = 0;
+            for (uint32_t i = tid; i < vtxf::tab_uq_words(max_hap) + 128u; i += NT) uq[i] = 0;     // uq[] and, behind it, pb[128]
         }
         __syncthreads();
         if ((uint32_t)tid < n_tab) {     // one lane per table: sequential head insertion, descending y => ascending chains
@@ -830,6 +833,32 @@ __device__ __forceinline__ void build_tables(uint8_t* tables, uint32_t n_tab, ui
                     fb[y + KMER - 1] |= 0x80;      // only this thread touches that byte
                     atomicOr(&uq[y >> 5], 1u << (y & 31u));
                 }
+            }
+        }
+        __syncthreads();
+        // bucket tags (band_diag_kernel, vtx_fast_core.h: walk_bucket): a bucket with ONE entry carries 4 hash bits of its k-mer
+        // in bits 12-15 of its head word, a bucket with more HEAD_MULTI — most probes of a k-mer that is not in the haplotype end at
+        // the head word.  Readers that want the plain position strip the tag (head_pos).
+        for (uint32_t t = 0; t < n_tab; ++t) {
+            uint8_t* tb = tables + (size_t)t * table_stride;
+            const uint2* ent = TB_ENT(tb);
+            uint16_t* head = TB_HEAD(tb);
+            // presence bitmap: one bit per 12-bit k-mer code (vtx_fast_core.h: kw_code)
+            {
+                const vtx_locus loc = loci[lbase + (t >> 1)];
+                const uint32_t hn = max(loc.ref_len, loc.alt_len) > max_hap ? 0u : ((t & 1) ? loc.alt_len : loc.ref_len);
+                uint32_t* pb = TB_PB(tb);
+                for (uint32_t y = tid; y + KMER <= hn; y += NT) {
+                    const uint32_t code = vtxf::kw_code(ent[y].x, ent[y].y & 0xffffu);
+                    atomicOr(&pb[code >> 5], 1u << (code & 31u));
+                }
+            }
+            for (uint32_t h = tid; h < n_heads; h += NT) {
+                const uint32_t y0 = head[h];
+                if (y0 == CH_END) continue;
+                const uint2 k = ent[y0];
+                const uint32_t tag = (k.y >> 16) == CH_END ? vtxf::kw_tag(vtxf::kw_mix(k.x, k.y & 0xffffu)) : vtxf::HEAD_MULTI;
+                head[h] = (uint16_t)(y0 | (tag << 12));
             }
         }
         __syncthreads();
@@ -961,7 +990,7 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
             if constexpr (GT) return *(const uint2*)(gtables + (size_t)(t_ent + i * 8u)); else return ent[i];
         };
         auto HEAD = [&](uint32_t i) -> uint32_t {
-            if constexpr (GT) return *(const uint16_t*)(gtables + (size_t)(t_head + i * 2u)); else return head[i];
+            if constexpr (GT) return head_pos(*(const uint16_t*)(gtables + (size_t)(t_head + i * 2u))); else return head_pos(head[i]);
         };
         auto FB = [&](uint32_t i) -> uint32_t {
             if constexpr (GT) return gtables[(size_t)(t_fb + i)]; else return fb[i];
@@ -972,7 +1001,7 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
             uint32_t wl = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
             uint32_t wh = (uint32_t)x[4] | ((uint32_t)x[5] << 8), cntm = 0;
             for (uint32_t xr = 0; xr + KMER <= m; ++xr) {
-                for (uint32_t y = head[kw_hash(wl, wh, n_heads - 1)]; y != CH_END; y = ent[y].y >> 16) cntm += (ent[y].x == wl && (ent[y].y & 0xffffu) == wh);
+                for (uint32_t y = head_pos(head[kw_hash(wl, wh, n_heads - 1)]); y != CH_END; y = ent[y].y >> 16) cntm += (ent[y].x == wl && (ent[y].y & 0xffffu) == wh);
                 const uint32_t nb = (xr + KMER < m) ? x[xr + KMER] : 0;
                 wl = (wl >> 8) | (wh << 24); wh = ((wh >> 8) & 0xff) | (nb << 8);
             }
@@ -1446,47 +1475,178 @@ __global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __rest
 // and reads meet in one L2.
 // counters[12] = tasks left to band_run_kernel; counters[32 + why] = reasons (stats != 0).
 // =============================================================================================
+// LDS exchanged between the lanes of ONE wavefront (its instructions reach the LDS in program order): a compiler-level
+// fence is all the ordering it needs
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int WPE>
-__global__ __launch_bounds__(64, WPE) void band_diag_kernel(
+__global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     uint32_t n_tasks, uint32_t task_base, uint32_t n_blocks,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
     const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ fail_list, uint32_t* __restrict__ counters, uint32_t stats) {
-    __shared__ uint32_t lane_mem[vtxf::LANE_WORDS * 64];
-    const int tid = threadIdx.x;
+    // Four wavefronts per workgroup, each on its own 64 consecutive tasks and its own slice of the LDS (no workgroup barrier
+    // anywhere): the four share their loci's tables in the CU's L1.
+    constexpr int QROWS = 12;                                  // rows a lane contributes to the pool per round
+    static_assert(64 * QROWS * 2 >= vtxf::GM * 64 * 4, "back() borrows the probe queue for its generic pieces");
+    __shared__ uint32_t lane_mem_[4][vtxf::LANE_WORDS * 64];
+    __shared__ uint16_t q_ent_[4][64 * QROWS];                 // pooled probes of one round: owner lane << 8 | row
+    __shared__ uint32_t o_read_[4][64], o_tab_[4][64], s_cnt_[4][64];      // per owner lane: read offset, table offset, matches found
+    __shared__ int32_t o_diag_[4][64];
+    __shared__ uint32_t q_count_[4][2];
+    const int wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
+    uint32_t* lane_mem = lane_mem_[wv];
+    uint16_t* q_ent = q_ent_[wv];
+    uint32_t *o_read = o_read_[wv], *o_tab = o_tab_[wv], *s_cnt = s_cnt_[wv], *q_count = q_count_[wv];
+    int32_t* o_diag = o_diag_[wv];
     const uint32_t per_xcd = (n_blocks + 7) / 8;
     const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (blk >= n_blocks) return;
-    const uint32_t slot = blk * 64 + tid;
+    const uint32_t slot = blk * 256 + threadIdx.x;
     const bool have = slot < n_tasks;
     const uint32_t task = task_base + slot;
-    bool fail = false;
+    bool fail = false, live = false;
     uint32_t why = 0;
+    int32_t* my_score = nullptr;
+    vtxf::Front fr;
+    fr.why = vtxf::W_SHAPE; fr.d = 0; fr.need = vtxf::M192{0, 0, 0};
+    const vtxf::Lane ln{lane_mem + tid, 64};
+    vtxf::Tab tb;
+    tb.gt = gtables; tb.ent = tb.head = tb.bytes = tb.uq = tb.pb = 0; tb.hmask = n_heads - 1;
+    s_cnt[tid] = 0;
+    const uint8_t* x = read_arena;
+    int m = 0, n = 0;
     if (have) {
         const uint32_t rid = task >> 1, hap = task & 1;
         const vtx_record rec = records[rid];
         const uint32_t my_locus = rec_locus[rid];
         const vtx_locus loc = loci[my_locus];
-        const uint32_t m = rec.read_len, n = hap ? loc.alt_len : loc.ref_len;
-        int32_t* my_score = (hap ? alt_score : ref_score) + rid;
+        m = (int)rec.read_len; n = (int)(hap ? loc.alt_len : loc.ref_len);
+        my_score = (hap ? alt_score : ref_score) + rid;
         if (m == 0 || n == 0) {
             *my_score = 0;                                               // empty read / haplotype: score 0
-        } else if (m > VTX_FAST_READ_LEN || max(loc.ref_len, loc.alt_len) > max_hap) {
+        } else if ((uint32_t)m > VTX_FAST_READ_LEN || max(loc.ref_len, loc.alt_len) > max_hap) {
             // beyond the fast kernels: slow_align_kernel scores it (the host lists these records)
+        } else if (m < vtxf::K || n < vtxf::K || m > vtxf::MAX_READ) {
+            fail = true; why = vtxf::W_SHAPE;
         } else {
-            vtxf::Tab tb;
-            tb.gt = gtables;
             tb.ent = (uint32_t)(((size_t)(my_locus - gt_l0) * 2 + hap) * table_stride);
             tb.head = tb.ent + max_hap * 8u;
             tb.bytes = tb.ent + vtxf::tab_bytes_off(max_hap, n_heads);
             tb.uq = tb.ent + vtxf::tab_uq_off(max_hap, n_heads);
-            tb.hmask = n_heads - 1;
-            const vtxf::Lane ln{lane_mem + tid, 64};
-            const vtxf::Result res = vtxf::fast_task(read_arena + rec.read_off, (int)m, tb, (int)n, ln);
-            if (res.score >= 0) *my_score = res.score;
-            else { fail = true; why = res.why; }
+            tb.pb = tb.ent + vtxf::tab_pb_off(max_hap, n_heads);
+            x = read_arena + rec.read_off;
+            o_read[tid] = rec.read_off;
+            live = true;
         }
+    }
+    // ---- the main diagonal.  Lanes 2i / 2i + 1 hold the two haplotypes of one record: each looks ONE sample row up in its own
+    //      table per round and the two exchange their candidates (a candidate is only ever a candidate: the lane keeps it if
+    //      ITS mask has >= 20 matching bases) ----
+    {
+        bool have_d = !live;
+        int d = 0, tried = vtxf::NO_DIAG;
+        vtxf::M192 M{0, 0, 0};
+#pragma unroll 1
+        for (int round = 0; round < 3; ++round) {
+            if (!__any(!have_d)) break;
+            const int c_own = have_d ? vtxf::NO_DIAG : vtxf::cand_diag(x, vtxf::sample_row(2 * round + (tid & 1), m), tb);
+            const int c_par = __shfl_xor(c_own, 1);
+#pragma unroll 1
+            for (int u = 0; u < 2; ++u) {
+                const int dc = u ? c_par : c_own;
+                if (have_d || dc == vtxf::NO_DIAG || dc == tried || dc < -(m - vtxf::K) || dc > n - vtxf::K) continue;
+                tried = dc;
+                const vtxf::M192 Mc = vtxf::diag_mask(x, m, tb, n, dc);
+                if (vtxf::m_pop(Mc) >= 20) { d = dc; M = Mc; have_d = true; }
+            }
+        }
+        if (live && !have_d) { live = false; fail = true; why = vtxf::W_NO_DIAG; }
+        if (live) {
+            fr = vtxf::front_rest(x, m, tb, n, ln, d, M);
+            if (fr.why != vtxf::W_OK) { live = false; fail = true; why = fr.why; }
+        }
+    }
+    o_tab[tid] = tb.ent;
+    o_diag[tid] = fr.d;
+    // ---- pooled probes: the rows the lanes still have to look up differ a lot from lane to lane (a read that hangs over
+    //      the padded window has up to 49 rows without a main-diagonal k-mer), so the wavefront's rows go through one queue
+    //      and every lane probes for whoever owns the row.  Pass 1: the presence bitmap (one word of 512 bytes per
+    //      haplotype) — most k-mers are not in the haplotype at all; the survivors are compacted in place.  Pass 2: bucket
+    //      walk for the survivors; matches land in the owner's list. ----
+    vtxf::M192 need = live ? fr.need : vtxf::M192{0, 0, 0};
+    if ((stats >> 8) == 1) { if (live && fr.cert == 0x7fffffff) counters[40] = 1; return; }      // (profiling aid) front only
+    const uint32_t pb_rel = vtxf::tab_pb_off(max_hap, n_heads), head_rel = max_hap * 8u;
+    for (;;) {
+        if (tid == 0) { q_count[0] = 0; q_count[1] = 0; }
+        wave_sync();
+        const int cnt = min(QROWS, vtxf::m_pop(need));
+        if (!__any(cnt > 0)) break;
+        if (cnt > 0) {
+            const uint32_t base = atomicAdd(&q_count[0], (uint32_t)cnt);
+            for (int t = 0; t < cnt; ++t) q_ent[base + t] = (uint16_t)(((uint32_t)tid << 8) | (uint32_t)vtxf::m_pop_lowest(need));
+        }
+        wave_sync();
+        const uint32_t total = q_count[0];
+        for (uint32_t i0 = 0; i0 < total; i0 += 128) {
+            // two queue entries per lane and trip: their loads go out together
+            uint32_t ent2[2], code[2], bits[2];
+            uint64_t w8[2];
+            bool on[2];
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t i = i0 + 64u * u + tid;
+                on[u] = i < total;
+                ent2[u] = q_ent[on[u] ? i : 0];
+                w8[u] = vtxf::ld8(read_arena + o_read[ent2[u] >> 8] + (ent2[u] & 0xffu));
+            }
+            for (int u = 0; u < 2; ++u) {
+                code[u] = vtxf::kw_code((uint32_t)w8[u], (uint32_t)(w8[u] >> 32) & 0xffffu);
+                bits[u] = *(const uint32_t*)(gtables + o_tab[ent2[u] >> 8] + pb_rel + 4u * (code[u] >> 5));
+            }
+            wave_sync();                                             // (every lane has read its entries: survivors may overwrite them)
+            for (int u = 0; u < 2; ++u) {
+                const bool hit = on[u] && ((bits[u] >> (code[u] & 31u)) & 1u);
+                const uint64_t hm = __ballot(hit);
+                if (hm) {
+                    uint32_t base = 0;
+                    const int leader = __ffsll((long long)hm) - 1;
+                    if (tid == leader) { base = q_count[1]; q_count[1] = base + (uint32_t)__popcll(hm); }
+                    base = (uint32_t)__shfl((int)base, leader);
+                    if (hit) q_ent[base + (uint32_t)__popcll(hm & ((1ull << tid) - 1ull))] = (uint16_t)ent2[u];
+                }
+            }
+        }
+        wave_sync();
+        const uint32_t n_walk = q_count[1];
+        for (uint32_t i0 = 0; i0 < n_walk; i0 += 64) {
+            const uint32_t i = i0 + tid;
+            if (i >= n_walk) continue;
+            const uint32_t e = q_ent[i];
+            const uint32_t own = e >> 8, row = e & 0xffu;
+            const uint64_t w8 = vtxf::ld8(read_arena + o_read[own] + row);
+            const uint32_t hh = vtxf::kw_mix((uint32_t)w8, (uint32_t)(w8 >> 32) & 0xffffu);
+            vtxf::Tab to = tb;
+            to.ent = o_tab[own];
+            const uint32_t raw = vtxf::ld2(gtables + to.ent + head_rel + 2u * vtxf::kw_bucket(hh, n_heads - 1));
+            const int od = o_diag[own];
+            vtxf::walk_bucket(to, w8, hh, raw, [&](uint32_t yc) {
+                if ((int)yc - (int)row == od) return;
+                const uint32_t pos = atomicAdd(&s_cnt[own], 1u);
+                if (pos < (uint32_t)vtxf::SM) lane_mem[pos * 64 + own] = (row << 16) | yc;
+            });
+        }
+        wave_sync();
+    }
+    if ((stats >> 8) == 2) { if (live && s_cnt[tid] == 0x7fffffff) counters[40] = 1; return; }   // (profiling aid) front + probes
+    if (live) {
+        const vtxf::Lane gl{(uint32_t*)q_ent + tid, 64};                 // (the queue is dead by now)
+        const int32_t sc = vtxf::back(fr, (int)min(s_cnt[tid], (uint32_t)vtxf::SM + 1u), ln, gl, &why);
+        if (sc >= 0) *my_score = sc; else fail = true;
     }
     const uint64_t fm = __ballot(fail);
     if (fm) {
@@ -1496,7 +1656,7 @@ __global__ __launch_bounds__(64, WPE) void band_diag_kernel(
         base = (uint32_t)__shfl((int)base, leader);
         if (fail) {
             fail_list[base + (uint32_t)__popcll(fm & ((1ull << tid) - 1ull))] = task;
-            if (stats) atomicAdd(&counters[32 + why], 1u);
+            if (stats & 0xffu) atomicAdd(&counters[32 + why], 1u);
         }
     }
 }
@@ -1645,10 +1805,10 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     if (!gtables || (size_t)n_loci * 2 * tstride > gtables_bytes) return hipErrorInvalidValue;
     hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(n_loci, 256u * 16u)), dim3(64), 2 * tstride, s, loci, gt_l0, n_loci,
                        hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
-    const uint32_t n_blocks = (n_tasks + 63) / 64;
-    hipLaunchKernelGGL(band_diag_kernel<4>, dim3(((n_blocks + 7) / 8) * 8), dim3(64), 0, s, n_tasks, task_base, n_blocks, records,
+    const uint32_t n_blocks = (n_tasks + 255) / 256;
+    hipLaunchKernelGGL(band_diag_kernel<4>, dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
                        rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                       alt_score, fail_list, counters, (uint32_t)stats);
+                       alt_score, fail_list, counters, (uint32_t)stats | (getenv("VTX_DIAG_ABLATE") ? (uint32_t)atoi(getenv("VTX_DIAG_ABLATE")) << 8 : 0u));
     return hipGetLastError();
 }
 

@@ -2,8 +2,8 @@
 // (bio 0.30.0 banded::Aligner::local as restated in oracle/vtx_oracle.c; reference call site src/main.rs:898-901).
 //
 // Plain C++ without HIP types, so that the SAME source compiles into the device kernel (vtx_band.hip) and into the
-// host unit test of the kernel logic (tests/fastcore_host.cpp, checked against the oracle on the CPU).  The host build
-// is test infrastructure only; nothing in the product path calls it.
+// host unit test of the kernel logic (tests/fastcore/fastcore_host.cpp, checked against the oracle on the CPU).  The host
+// build is test infrastructure only; nothing in the product path calls it.
 //
 // What a task is: one read x (m bases) against one haplotype y (n bases).  band_run_kernel decides a task without a DP
 // when  cert == ub  (cert <= banded <= full <= ub; proof in vtx_band.hip / oracle/vtx_certify.c) but builds the general
@@ -18,34 +18,40 @@
 //          are probed in the k-mer table (~28 of 145 on the synthetic workloads).
 //
 //   chain  sdpkpp restricted to the main diagonal is a closed form over its pieces (runs of >= 6 matching bases):
-//          inside a piece every k-mer continues the previous one (+1), the first k-mer of a piece takes the best
-//          earlier piece end (V = dp + xe + ye, ties to the later piece) if that gives >= 6.  An off-diagonal match s
-//          is HARMLESS when no main-diagonal match can take it as its predecessor:  V_s - (x_p + y_p) + 1 < dp(p)  for
-//          every main match p that starts at or after the end of s (checked at the first such p of every piece: the left
-//          side falls by 2 per row, the right side grows by 1), and dp(s) < the best chain score.  dp(s) itself is exact:
-//          its candidates are the main matches and the earlier off-diagonal matches that end before it, plus the
-//          continuation of an off-diagonal match one step up its diagonal.  If every s is harmless, every dp and every
-//          predecessor of the main matches is what it would be without S, so the chain of the reference — first match,
-//          last match — is the chain of the closed form.  Anything else (a tie that would need the match order, an s
-//          that is not harmless, too many pieces / matches) leaves the task to band_run_kernel.
+//          inside a piece every k-mer continues the previous one (+1); the first k-mer of a piece takes the best
+//          earlier piece end (largest V = dp + xe + ye, ties to the later piece) if that gives >= 6.  An off-diagonal
+//          match s is HARMLESS when no main-diagonal match can take it as its predecessor:
+//              V_s - (x_p + y_p) + 1 < dp(p)   for every main match p that starts at or after the end of s
+//          (checked at the first such p of every piece: the left side falls by 2 per row, the right side grows by 1), and
+//          dp(s) < the best chain score.  For dp(s) an UPPER bound is enough (the test is one-sided):
+//              dp(s) <= max(6, best main match that ends before s, 1 + max dp bound of the off-diagonal matches before s)
+//          — a match reached from another off-diagonal match s' gets dp(s') + 1 - gap <= dp(s') (gap >= 1 unless it
+//          continues s' on its diagonal: + 1).  If every s is harmless, every dp and every predecessor of the main
+//          matches is what it would be without S, so the reference's chain — first match, last match — is the chain
+//          of the closed form.  Anything else leaves the task to band_run_kernel.
 //   cert   the chain lies on diagonal d, so the staircase of band_finish is the diagonal itself from (first - d0 - t0)
 //          to (last + K + d1 + t1): the certificate is the best local score (match +1, mismatch -5, restart at 0) of M
-//          over that window — a scan over the runs of M.
+//          over that window — a scan over the zeros of M.
 //   ub     the run bound over the GENERIC pieces only: the main-diagonal pieces plus the off-diagonal pieces within
-//          T = 20 diagonals of the hull of the generic diagonals (closure).  The other off-diagonal pieces are FAR: every
-//          one lies >= T diagonals outside the hull.  With E = the number of far k-mer matches (sum of len - 5 over the
-//          far pieces, <= SM = 20):
+//          T - 1 diagonals of the hull of the generic diagonals (closure).  The other off-diagonal pieces are FAR: every
+//          one lies >= T diagonals outside the hull.  With E = the number of far k-mer matches (sum of bases - 5 over
+//          the far pieces; E <= ns, the number of off-diagonal matches) and T = max(ns, 5), so that T >= E, 2T >= E + 5:
 //            * a chain of far pieces between two generic pieces g1, g2 nets at most E - 5 - 2T - |d1 - d2| (every join
-//              costs >= 5 + its diagonal difference, the way out and back is >= 2T + |d1 - d2|), the direct join g1 -> g2
-//              costs 5 + |d1 - d2| or J_same <= 10:  replacing the excursion by the direct join never lowers the value
-//              (E <= 2T, E + 5 <= 2T);
-//            * far pieces before the first / after the last generic piece net at most E - T <= 0: dropping them never lowers it;
+//              costs >= 5 + its diagonal difference, the way out of the hull and back is >= 2T + |d1 - d2|), the direct
+//              join g1 -> g2 costs 5 + |d1 - d2| or J_same <= 10: replacing the excursion by the direct join never
+//              lowers the value;
+//            * far pieces before the first / after the last generic piece net at most E - T <= 0: dropping them never
+//              lowers it;
 //            * a chain of far pieces only is worth at most E + 5.
 //          Hence  full <= max(5, E + 5, ub_generic)  with ub_generic the fixpoint of run_ub over the generic pieces.
-//          (oracle/vtx_certify.c: vtxo_runs_ub_generic restates this on the CPU; tests check full <= it.)
 //
 // Capacities: reads up to 192 bases (3 mask words), RM main pieces, SM off-diagonal matches, GM generic off-diagonal
 // pieces; tasks beyond them are not wrong, they are band_run_kernel's.
+//
+// Three phases, so that the device can do the middle one cooperatively (a wavefront's probes pooled over its lanes):
+//   front()   diagonal, mask, pieces + chain, certificate, the rows to probe
+//   probe     every match (row, y) with y - row != d of the rows in Front::need, appended to the lane's list
+//   back()    sort the list, harmless test, closure, run bound, verdict
 #ifndef VTX_FAST_CORE_H
 #define VTX_FAST_CORE_H
 
@@ -71,72 +77,83 @@ constexpr int LAZY = VTX_BAND_LAZY_EXT(6);
 constexpr int MAX_READ = 192;   // mask capacity
 constexpr int RM = 6;           // main-diagonal pieces
 constexpr int SM = 20;          // off-diagonal k-mer matches
-constexpr int GM = 4;           // off-diagonal pieces admitted to the generic set
-constexpr int TFAR = 20;        // far = at least this many diagonals outside the hull of the generic diagonals
-constexpr int PM = RM + GM;     // generic pieces
-constexpr int LANE_WORDS = SM + 2 * PM;   // per-lane scratch: off-diagonal matches, then (id, len | G << 16) per generic piece
-static_assert(2 * TFAR >= SM + 5 && TFAR >= SM, "far-piece lemma: E <= SM must satisfy E + 5 <= 2T and E <= T");
+constexpr int GM = 6;           // off-diagonal pieces admitted to the generic set
+constexpr int LANE_WORDS = SM + RM;   // per-lane scratch: off-diagonal matches, main pieces (+ GM words for back(): generic off-diagonal pieces)
+constexpr int DMAX = 120;       // diagonal offsets of generic pieces are stored in a signed byte
 constexpr uint32_t UQ_PAD_WORDS = 6;      // zero words in front of a table's unique-k-mer bit array (a negative diagonal reads them)
-constexpr uint32_t CH_END_ = 0xffffu;
+constexpr uint32_t HEAD_END = 0xffffu;    // empty bucket / end of a chain
+constexpr uint32_t HEAD_MULTI = 15u;      // tag of a bucket with more than one entry
 
 // reasons a task is left to band_run_kernel (statistics)
-enum Why : uint32_t { W_OK = 0, W_SHAPE = 1, W_NO_DIAG = 2, W_PIECES = 3, W_MATCHES = 4, W_NOT_HARMLESS = 5, W_TIE = 6,
+enum Why : uint32_t { W_OK = 0, W_SHAPE = 1, W_NO_DIAG = 2, W_PIECES = 3, W_MATCHES = 4, W_NOT_HARMLESS = 5, W_UNUSED6 = 6,
                       W_GENERIC = 7, W_NOT_TIGHT = 8, W_NO_MAIN = 9, W_COUNT = 10 };
 
 // k-mer table of one haplotype in global memory (layout: band_table_stride / build_tables in vtx_band.hip):
-// ent[max_hap] {bytes 0-3, bytes 4-5 | next << 16}, head[n_heads] u16, bytes[max_hap + 8], fb[max_hap + 8],
-// uq[UQ_PAD_WORDS + max_hap / 32 + 8] (bit y of the array behind the padding: the k-mer starting at y is unique)
+// ent[max_hap] {bytes 0-3, bytes 4-5 | next << 16}, head[n_heads] u16 (position of the first entry | tag << 12: a bucket
+// with ONE entry carries 4 hash bits that are not part of the bucket index, a bucket with more HEAD_MULTI),
+// bytes[max_hap + 8], fb[max_hap + 8], uq[UQ_PAD_WORDS + max_hap / 32 + 8] (bit y behind the padding: the k-mer
+// starting at y is unique in the haplotype), pb[128] (4096 bits: bit kw_code(k-mer) set for every k-mer of the haplotype — a
+// probe of a k-mer that is not there ends at ONE word of these 512 bytes instead of a head word of a 2 KB array)
 struct Tab {
     const uint8_t* gt;      // uniform base of the table buffer
-    uint32_t ent, head, bytes, uq;   // byte offsets of this haplotype's arrays
+    uint32_t ent, head, bytes, uq, pb;   // byte offsets of this haplotype's arrays
     uint32_t hmask;         // n_heads - 1
 };
 VTXF_HD uint32_t tab_bytes_off(uint32_t max_hap, uint32_t n_heads) { return max_hap * 8u + n_heads * 2u; }
 VTXF_HD uint32_t tab_fb_off(uint32_t max_hap, uint32_t n_heads) { return tab_bytes_off(max_hap, n_heads) + max_hap + 8u; }
 VTXF_HD uint32_t tab_uq_off(uint32_t max_hap, uint32_t n_heads) { return (tab_fb_off(max_hap, n_heads) + max_hap + 8u + 3u) & ~3u; }
 VTXF_HD uint32_t tab_uq_words(uint32_t max_hap) { return UQ_PAD_WORDS + (max_hap + 31u) / 32u + 8u; }
-VTXF_HD uint32_t tab_stride(uint32_t max_hap, uint32_t n_heads) { return (tab_uq_off(max_hap, n_heads) + 4u * tab_uq_words(max_hap) + 15u) & ~15u; }
-
-VTXF_FN uint32_t kw_hash(uint32_t lo, uint32_t hi, uint32_t head_mask) {
-    const uint32_t h = (lo ^ (hi << 11) ^ (hi >> 3)) * 0x9E3779B1u;
-    return (h >> 18) & head_mask;
+VTXF_HD uint32_t tab_pb_off(uint32_t max_hap, uint32_t n_heads) { return tab_uq_off(max_hap, n_heads) + 4u * tab_uq_words(max_hap); }
+VTXF_HD uint32_t tab_stride(uint32_t max_hap, uint32_t n_heads) { return (tab_pb_off(max_hap, n_heads) + 512u + 15u) & ~15u; }
+// 12-bit code of a k-mer, two bits per byte ((b >> 1) & 3: A 0, C 1, T 2, G 3; any other byte lands on one of them — equal
+// bytes always give equal codes, which is all a presence filter needs)
+VTXF_HD uint32_t kw_code(uint32_t lo, uint32_t hi) {
+    uint32_t a = (lo >> 1) & 0x03030303u, b = (hi >> 1) & 0x0303u;
+    a |= a >> 6; a = (a | (a >> 12)) & 0xffu;          // bytes 0-3 -> bits 0-7
+    b = (b | (b >> 6)) & 0xfu;                         // bytes 4-5 -> bits 0-3
+    return a | (b << 8);
 }
+
+// hash of a k-mer (bytes 0-3 in lo, bytes 4-5 in hi): bucket = bits 18.. of the product, tag = its top 4 bits
+VTXF_HD uint32_t kw_mix(uint32_t lo, uint32_t hi) { return (lo ^ (hi << 11) ^ (hi >> 3)) * 0x9E3779B1u; }
+VTXF_HD uint32_t kw_bucket(uint32_t h, uint32_t head_mask) { return (h >> 18) & head_mask; }
+VTXF_HD uint32_t kw_tag(uint32_t h) { const uint32_t t = h >> 28; return t == HEAD_MULTI ? HEAD_MULTI - 1u : t; }
+
 VTXF_FN uint64_t ld8(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
-VTXF_FN uint32_t ld4(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 VTXF_FN uint32_t ld2(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
 VTXF_FN int imin(int a, int b) { return a < b ? a : b; }
 VTXF_FN int imax(int a, int b) { return a > b ? a : b; }
 VTXF_FN int iabs(int a) { return a < 0 ? -a : a; }
 
-// ---- 192-bit masks ----
-struct M192 { uint64_t w[3]; };
+// ---- 192-bit masks: three 64-bit words, always indexed with compile-time constants ----
+struct M192 { uint64_t w0, w1, w2; };
 VTXF_FN int ctz64(uint64_t v) { return __builtin_ctzll(v); }
-VTXF_FN M192 m_and(M192 a, M192 b) { return M192{{a.w[0] & b.w[0], a.w[1] & b.w[1], a.w[2] & b.w[2]}}; }
-VTXF_FN M192 m_andn(M192 a, M192 b) { return M192{{a.w[0] & ~b.w[0], a.w[1] & ~b.w[1], a.w[2] & ~b.w[2]}}; }
+VTXF_FN M192 m_and(M192 a, M192 b) { return M192{a.w0 & b.w0, a.w1 & b.w1, a.w2 & b.w2}; }
+VTXF_FN M192 m_andn(M192 a, M192 b) { return M192{a.w0 & ~b.w0, a.w1 & ~b.w1, a.w2 & ~b.w2}; }
+VTXF_FN bool m_any(M192 a) { return (a.w0 | a.w1 | a.w2) != 0; }
+VTXF_FN int m_pop(M192 a) { return __builtin_popcountll(a.w0) + __builtin_popcountll(a.w1) + __builtin_popcountll(a.w2); }
 template <int S> VTXF_FN M192 m_shr(M192 a) {      // 0 < S < 64
-    return M192{{(a.w[0] >> S) | (a.w[1] << (64 - S)), (a.w[1] >> S) | (a.w[2] << (64 - S)), a.w[2] >> S}};
+    return M192{(a.w0 >> S) | (a.w1 << (64 - S)), (a.w1 >> S) | (a.w2 << (64 - S)), a.w2 >> S};
 }
-// bits [lo, hi) set, 0 <= lo, hi <= 192
 VTXF_FN uint64_t ones_below(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull)); }
-VTXF_FN M192 m_range(int lo, int hi) {
-    M192 r;
-    for (int k = 0; k < 3; ++k) r.w[k] = ones_below(hi - 64 * k) & ~ones_below(lo - 64 * k);
+VTXF_FN M192 m_range(int lo, int hi) {             // bits [lo, hi)
+    return M192{ones_below(hi) & ~ones_below(lo), ones_below(hi - 64) & ~ones_below(lo - 64), ones_below(hi - 128) & ~ones_below(lo - 128)};
+}
+// lowest set bit: its index (192: none), cleared in a
+VTXF_FN int m_pop_lowest(M192& a) {
+    const bool z0 = a.w0 == 0, z1 = z0 && a.w1 == 0;
+    const uint64_t cur = z1 ? a.w2 : (z0 ? a.w1 : a.w0);
+    if (cur == 0) return 192;
+    const int r = (z1 ? 128 : (z0 ? 64 : 0)) + ctz64(cur);
+    const uint64_t nxt = cur & (cur - 1);
+    a.w0 = z0 ? a.w0 : nxt; a.w1 = (z0 && !z1) ? nxt : a.w1; a.w2 = z1 ? nxt : a.w2;
     return r;
 }
-// first set bit at or after p (192 if none)
-VTXF_FN int m_next_set(const M192& a, int p) {
-    if (p >= 192) return 192;
-    int k = p >> 6;
-    uint64_t v = a.w[k] & ~ones_below(p & 63);
-    while (v == 0) { if (++k == 3) return 192; v = a.w[k]; }
-    return 64 * k + ctz64(v);
-}
-VTXF_FN int m_next_clear(const M192& a, int p) {
-    if (p >= 192) return 192;
-    int k = p >> 6;
-    uint64_t v = ~a.w[k] & ~ones_below(p & 63);
-    while (v == 0) { if (++k == 3) return 192; v = ~a.w[k]; }
-    return 64 * k + ctz64(v);
+// f(position) for every set bit, ascending
+template <class F> VTXF_FN void m_for_each(M192 a, F f) {
+    for (uint64_t v = a.w0; v; v &= v - 1) f(ctz64(v));
+    for (uint64_t v = a.w1; v; v &= v - 1) f(64 + ctz64(v));
+    for (uint64_t v = a.w2; v; v &= v - 1) f(128 + ctz64(v));
 }
 
 // 8 byte-equality flags of two 8-byte words as 8 bits
@@ -156,262 +173,310 @@ VTXF_FN int join_same(int D) {                      // run_ub's same-diagonal jo
 }
 
 // per-lane scratch: element i at base[i * stride] (device: LDS, the 64 lanes of a wavefront interleaved; host: stride 1)
+//   [0, SM)                 off-diagonal matches x << 16 | y
+//   [SM, SM + RM)           main pieces: first base | last base << 8 | dp of the first k-mer << 16 | G << 24
+// and a second, GM-word scratch for back() only (the device lends it the probe queue's LDS):
+//   [0, GM)                 generic off-diagonal pieces: x | (delta + 128) << 8 | bases << 16 | G << 24
 struct Lane {
     uint32_t* base; int stride;
     VTXF_MEM uint32_t& at(int i) const { return base[i * stride]; }
 };
 
-struct Result { int32_t score; uint32_t why; };
+struct Front {
+    uint32_t why;           // W_OK: go on with the probes
+    int d, r;               // main diagonal, main pieces
+    int best_dp, cert;
+    M192 need;              // rows to probe
+};
 
 // The match mask of diagonal d: bit i = (x[i] == y[i + d]), i in [max(0, -d), min(m, n - d)).
 VTXF_FN M192 diag_mask(const uint8_t* x, int m, const Tab& tb, int n, int d) {
-    M192 M{{0, 0, 0}};
+    uint64_t w0 = 0, w1 = 0, w2 = 0;
     const uint8_t* yb = tb.gt + tb.bytes;
     // only the 8-base words that overlap the haplotype: the 8-byte loads stay within 7 bytes of bytes[0, n)
-    const int w0 = d < 0 ? (-d) >> 3 : 0;
-    for (int w = w0; 8 * w < m && 8 * w + d < n; ++w) {
-        const uint64_t rd = ld8(x + 8 * w);
-        const uint64_t hp = ld8(yb + (8 * w + d));     // (bytes outside [0, n) are padding / neighbouring arrays: masked below)
-        M.w[w >> 3] |= (uint64_t)eq8(rd, hp) << (8 * (w & 7));
+    const int wa = d < 0 ? (-d) >> 3 : 0;
+    const int wb = imin((m + 7) >> 3, (n - d + 7) >> 3);
+    for (int w = wa; w < wb; ++w) {
+        const uint64_t e = (uint64_t)eq8(ld8(x + 8 * w), ld8(yb + (8 * w + d))) << (8 * (w & 7));
+        if (w < 8) w0 |= e; else if (w < 16) w1 |= e; else w2 |= e;
     }
-    return m_and(M, m_range(imax(0, -d), imin(m, n - d)));
+    return m_and(M192{w0, w1, w2}, m_range(imax(0, -d), imin(m, n - d)));
 }
 
-// Decide one task.  Returns {score, W_OK} or {-1, reason}.
-VTXF_FN Result fast_task(const uint8_t* x, int m, const Tab& tb, int n, const Lane& ln) {
-    if (m < K || n < K || m > MAX_READ) return Result{-1, W_SHAPE};
+// One bucket lookup for the k-mer in w8's low 6 bytes: f(y) for every position of the haplotype that holds it.
+// head word `raw` already loaded (so that callers can issue the loads of several rows together).
+template <class F> VTXF_FN void walk_bucket(const Tab& tb, uint64_t w8, uint32_t h, uint32_t raw, F f) {
+    if (raw == HEAD_END) return;
+    const uint32_t tag = raw >> 12;
+    if (tag != HEAD_MULTI && tag != kw_tag(h)) return;     // the bucket's only k-mer is another one
+    const uint32_t lo = (uint32_t)w8, hi = (uint32_t)(w8 >> 32) & 0xffffu;
     const uint8_t* ent = tb.gt + tb.ent;
-    const uint8_t* head = tb.gt + tb.head;
-    const uint32_t* uq = (const uint32_t*)(tb.gt + tb.uq);
+    uint32_t yc = raw & 0xfffu;
+    do {
+        const uint64_t e = ld8(ent + 8u * yc);
+        if ((uint32_t)e == lo && ((uint32_t)(e >> 32) & 0xffffu) == hi) f(yc);
+        yc = (uint32_t)(e >> 48);
+    } while (yc != HEAD_END);
+}
 
-    // ---- 1. the main diagonal: a sampled row whose k-mer has exactly one match, on a unique haplotype k-mer; the
-    //         candidate is kept if its mask holds at least one piece and 20 matching bases ----
-    int d = 0;
-    M192 M{{0, 0, 0}};
-    bool have_d = false;
-    {
-        const int last = m - K;
-        const int step = imax(1, last / 5);
-        // middle rows first: the ends of a read hang over the padded window more often than its middle
-        const int order[6] = {2, 3, 1, 4, 0, 5};
-        for (int t = 0; t < 6 && !have_d; ++t) {
-            const int row = imin(order[t] * step, last);
-            const uint64_t w8 = ld8(x + row);
-            const uint32_t lo = (uint32_t)w8, hi = (uint32_t)(w8 >> 32) & 0xffffu;
-            uint32_t yc = ld2(head + 2u * kw_hash(lo, hi, tb.hmask));
-            int cnt = 0, ycand = 0;
-            while (yc != CH_END_) {
-                const uint64_t e = ld8(ent + 8u * yc);
-                if ((uint32_t)e == lo && ((uint32_t)(e >> 32) & 0xffffu) == hi) { ++cnt; ycand = (int)yc; }
-                yc = (uint32_t)(e >> 48);
-            }
-            if (cnt != 1) continue;
-            const uint32_t ub_ = (uint32_t)ycand + 32u * UQ_PAD_WORDS;
-            if (!((uq[ub_ >> 5] >> (ub_ & 31u)) & 1u)) continue;
-            const int dc = ycand - row;
-            const M192 Mc = diag_mask(x, m, tb, n, dc);
-            const int pop = __builtin_popcountll(Mc.w[0]) + __builtin_popcountll(Mc.w[1]) + __builtin_popcountll(Mc.w[2]);
-            if (pop < 20) continue;
-            d = dc; M = Mc; have_d = true;
-        }
+// ---- phase 1 ----
+constexpr int NO_DIAG = -100000;
+// row of the t-th sample (t = 0 .. 5) of the main-diagonal search: middle rows first — the ends of a read hang over the padded
+// window more often than its middle
+VTXF_FN int sample_row(int t, int m) {
+    const int last = m - K;
+    return imin((int)((0x504132u >> (4 * t)) & 0xfu) * imax(1, last / 5), last);
+}
+// candidate diagonal from one row: its k-mer sits alone in its bucket and matches it (then the haplotype holds it exactly once)
+VTXF_FN int cand_diag(const uint8_t* x, int row, const Tab& tb) {
+    const uint64_t w8 = ld8(x + row);
+    const uint32_t hh = kw_mix((uint32_t)w8, (uint32_t)(w8 >> 32) & 0xffffu);
+    const uint32_t raw = ld2(tb.gt + tb.head + 2u * kw_bucket(hh, tb.hmask));
+    if (raw == HEAD_END || (raw >> 12) != kw_tag(hh)) return NO_DIAG;
+    const uint32_t yc = raw & 0xfffu;
+    const uint64_t e = ld8(tb.gt + tb.ent + 8u * yc);
+    if ((uint32_t)e != (uint32_t)w8 || ((uint32_t)(e >> 32) & 0xffffu) != ((uint32_t)(w8 >> 32) & 0xffffu)) return NO_DIAG;
+    return (int)yc - row;
+}
+VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const Lane& ln, int d, M192 M);
+
+// one lane on its own: the six sample rows in turn; a candidate is kept if its mask has at least 20 matching bases
+VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, int n, const Lane& ln) {
+    Front fr;
+    fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.need = M192{0, 0, 0};
+    if (m < K || n < K || m > MAX_READ) { fr.why = W_SHAPE; return fr; }
+    int prev = NO_DIAG;
+    for (int t = 0; t < 6; ++t) {
+        const int dc = cand_diag(x, sample_row(t, m), tb);
+        if (dc == NO_DIAG || dc == prev) continue;
+        prev = dc;
+        const M192 Mc = diag_mask(x, m, tb, n, dc);
+        if (m_pop(Mc) >= 20) return front_rest(x, m, tb, n, ln, dc, Mc);
     }
-    if (!have_d) return Result{-1, W_NO_DIAG};
+    fr.why = W_NO_DIAG;
+    return fr;
+}
 
-    // ---- 2. main-diagonal pieces: runs of >= K matching bases [pu, pv] ----
-    int pu[RM], pv[RM];
+// everything of phase 1 behind the choice of the diagonal d (M = diag_mask(d))
+VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const Lane& ln, int d, M192 M) {
+    (void)x;
+    Front fr;
+    fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.need = M192{0, 0, 0};
+    fr.d = d;
+
+    // ---- main pieces (runs of >= K matching bases, found between the zeros of M) and sdpkpp on the diagonal ----
+    // piece: k-mer matches at rows a = first base .. b = last base - 5; dpf = dp of its first match, dpl of its last.
+    // bestV = max over earlier pieces of dpl + 2 (b + K) (their V without the constant d): the first match of a piece takes
+    // it as predecessor if that gives >= K (ties: the later piece = the larger match index)
     int r = 0;
+    int bestV = -1000000, bestRoot = 0;
+    int best_dp = -1, best_root = 0, best_last = 0;
+    bool too_many = false;
     {
-        int p = 0;
-        for (;;) {
-            const int u = m_next_set(M, p);
-            if (u >= m) break;
-            const int e = imin(m_next_clear(M, u), m);        // run [u, e)
-            if (e - u >= K) {
-                if (r == RM) return Result{-1, W_PIECES};
-                pu[r] = u; pv[r] = e - 1; ++r;
-            }
-            p = e;
-        }
+        // (bases outside [vlo, vhi) face no haplotype base: zeros of M, but nothing to iterate over)
+        const int vlo = imax(0, -d), vhi = imin(m, n - d);
+        int prev = vlo - 1;
+        auto piece = [&](int u, int v) {                    // bases [u, v]
+            if (v - u + 1 < K) return;
+            if (r == RM) { too_many = true; return; }
+            const int a = u, b = v - 5;
+            const int c = bestV - 2 * a + 1;
+            int dpf = K, root = a;
+            if (c >= K) { dpf = c; root = bestRoot; }
+            const int dpl = dpf + (b - a);
+            const int Vl = dpl + 2 * (b + K);
+            if (Vl >= bestV) { bestV = Vl; bestRoot = root; }
+            if (dpl >= best_dp) { best_dp = dpl; best_root = root; best_last = v; }
+            ln.at(SM + r) = (uint32_t)u | ((uint32_t)v << 8) | ((uint32_t)dpf << 16);
+            ++r;
+        };
+        m_for_each(m_andn(m_range(vlo, vhi), M), [&](int z) { piece(prev + 1, z - 1); prev = z; });
+        piece(prev + 1, vhi - 1);
     }
-    if (r == 0) return Result{-1, W_NO_MAIN};
+    if (too_many) { fr.why = W_PIECES; return fr; }
+    if (r == 0) { fr.why = W_NO_MAIN; return fr; }
+    fr.r = r; fr.best_dp = best_dp;
 
-    // ---- 3. rows that may hold an off-diagonal match: all but those whose main-diagonal k-mer is intact and unique ----
-    M192 need;
+    // ---- certificate: best local score of M over the in-band stretch of the diagonal ----
+    {
+        const int fx = best_root, fy = fx + d;
+        const int d0 = imin(imin(fx, fy), LAZY);
+        const int t0 = imin(imin(fx - d0, fy - d0), W);
+        const int lo = fx - d0 - t0;
+        int re = best_last + 1, ce = re + d;                           // cell after the last k-mer: (b + K, b + K + d)
+        const int d1 = imin(imin(m - re, n - ce), LAZY);
+        re += d1; ce += d1;
+        const int t1 = imin(imin(m - re, n - ce), W);
+        const int hi = re + t1;
+        int s = 0, best = 0, prev = lo - 1;
+        m_for_each(m_andn(m_range(lo, hi), M), [&](int z) {
+            s += z - prev - 1;
+            best = imax(best, s);
+            s = imax(0, s - 5);
+            prev = z;
+        });
+        s += hi - prev - 1;
+        fr.cert = imax(best, s);
+    }
+
+    // ---- rows that may hold an off-diagonal match: all but those whose main-diagonal k-mer is intact and unique ----
     {
         const M192 A = m_and(M, m_shr<1>(M));
         const M192 B = m_and(A, m_shr<2>(A));
         const M192 I6 = m_and(B, m_shr<4>(A));              // bit i: bases i .. i + 5 all match
         // unique-k-mer bits of haplotype positions [d, d + 192): the array carries 192 zero bits in front
+        const uint32_t* uq = (const uint32_t*)(tb.gt + tb.uq);
         const uint32_t bo = (uint32_t)(d + 32 * (int)UQ_PAD_WORDS);
         const uint32_t wi = bo >> 5, sh = bo & 31u;
         uint32_t q[7];
         for (int k = 0; k < 7; ++k) q[k] = uq[wi + k];
-        M192 U;
+        uint64_t u[3];
         for (int k = 0; k < 3; ++k) {
             const uint32_t a = (uint32_t)((((uint64_t)q[2 * k + 1] << 32) | q[2 * k]) >> sh);
             const uint32_t b = (uint32_t)((((uint64_t)q[2 * k + 2] << 32) | q[2 * k + 1]) >> sh);
-            U.w[k] = ((uint64_t)b << 32) | a;
+            u[k] = ((uint64_t)b << 32) | a;
         }
-        need = m_andn(m_range(0, m - K + 1), m_and(I6, U));
+        fr.need = m_andn(m_range(0, m - K + 1), m_and(I6, M192{u[0], u[1], u[2]}));
     }
+    return fr;
+}
 
-    // ---- 4. probe those rows: off-diagonal matches, in (x, y) order ----
+// ---- phase 2, one lane on its own: the rows of fr.need four at a time (their loads go out together); a row whose k-mer is not
+//      in the haplotype's presence bitmap is done after one word.  Returns the number of off-diagonal matches appended to
+//      ln[0 ..), or SM + 1 when there are more than SM. ----
+VTXF_FN int probe_rows(const uint8_t* x, const Tab& tb, const Front& fr, const Lane& ln) {
+    const uint8_t* head = tb.gt + tb.head;
+    const uint32_t* pb = (const uint32_t*)(tb.gt + tb.pb);
+    M192 need = fr.need;
     int ns = 0;
-    for (int row = m_next_set(need, 0); row < 192; row = m_next_set(need, row + 1)) {
-        const uint64_t w8 = ld8(x + row);
-        const uint32_t lo = (uint32_t)w8, hi = (uint32_t)(w8 >> 32) & 0xffffu;
-        uint32_t yc = ld2(head + 2u * kw_hash(lo, hi, tb.hmask));
-        while (yc != CH_END_) {
-            const uint64_t e = ld8(ent + 8u * yc);
-            if ((uint32_t)e == lo && ((uint32_t)(e >> 32) & 0xffffu) == hi && (int)yc - row != d) {
-                if (ns == SM) return Result{-1, W_MATCHES};
-                ln.at(ns++) = ((uint32_t)row << 16) | yc;
-            }
-            yc = (uint32_t)(e >> 48);
+    while (m_any(need)) {
+        int row[4];
+        uint64_t w8[4];
+        uint32_t code[4], bits[4];
+        for (int t = 0; t < 4; ++t) row[t] = m_pop_lowest(need);
+        for (int t = 0; t < 4; ++t) w8[t] = ld8(x + (row[t] < 192 ? row[t] : 0));
+        for (int t = 0; t < 4; ++t) {
+            code[t] = kw_code((uint32_t)w8[t], (uint32_t)(w8[t] >> 32) & 0xffffu);
+            bits[t] = pb[code[t] >> 5];
         }
-    }
-
-    // ---- 5. sdpkpp on the main diagonal (closed form over the pieces) ----
-    // piece i: k-mer matches at rows a .. b = pv - 5; dpf = dp of its first match, dpl of its last
-    int dpf[RM], pred[RM];
-    int best_i = 0;
-    for (int i = 0; i < r; ++i) {
-        int bc = -1000000, bj = -1;
-        for (int j = 0; j < i; ++j) {
-            const int dpl_j = dpf[j] + (pv[j] - 5 - pu[j]);
-            const int c = dpl_j + 1 - 2 * (pu[i] - (pv[j] + 1));       // gap of pu[i] - (b_j + 6) rows and columns
-            if (c >= bc) { bc = c; bj = j; }                          // equal V: the later piece (larger match index)
+        for (int t = 0; t < 4; ++t) {
+            if (row[t] >= 192 || !((bits[t] >> (code[t] & 31u)) & 1u)) continue;       // not a k-mer of this haplotype
+            const uint32_t hh = kw_mix((uint32_t)w8[t], (uint32_t)(w8[t] >> 32) & 0xffffu);
+            walk_bucket(tb, w8[t], hh, ld2(head + 2u * kw_bucket(hh, tb.hmask)), [&](uint32_t yc) {
+                if ((int)yc - row[t] == fr.d) return;
+                if (ns < SM) ln.at(ns) = ((uint32_t)row[t] << 16) | yc;
+                ++ns;
+            });
         }
-        if (bj >= 0 && bc >= K) { dpf[i] = bc; pred[i] = bj; } else { dpf[i] = K; pred[i] = -1; }
-        const int dpl_i = dpf[i] + (pv[i] - 5 - pu[i]);
-        const int dpl_b = dpf[best_i] + (pv[best_i] - 5 - pu[best_i]);
-        if (dpl_i >= dpl_b) best_i = i;                               // equal score: the later match
+        if (ns > SM) return SM + 1;
     }
-    const int best_dp = dpf[best_i] + (pv[best_i] - 5 - pu[best_i]);
-    int root = best_i;
-    while (pred[root] >= 0) root = pred[root];
+    return ns;
+}
 
-    // ---- 6. every off-diagonal match must be harmless (see the file header) ----
-    // V of the best main match visible to a start (px, py): ended at or before it in both coordinates
-    int sdp[SM];
+// ---- phase 3 ----
+// Returns the score (>= 0) or -1 with *why set.
+VTXF_FN int32_t back(const Front& fr, int ns, const Lane& ln, const Lane& gl, uint32_t* why) {
+    const int d = fr.d, r = fr.r;
+    if (ns > SM) { *why = W_MATCHES; return -1; }
+    // (x, y) order (a lane probing its own rows produces it; pooled probes arrive in any order)
+    for (int k = 1; k < ns; ++k) {
+        const uint32_t v = ln.at(k);
+        int j = k - 1;
+        while (j >= 0 && ln.at(j) > v) { ln.at(j + 1) = ln.at(j); --j; }
+        ln.at(j + 1) = v;
+    }
+    // ---- harmless test of every off-diagonal match ----
+    int far_e = 0, runmax = 0;
+    const int nc = ns;
     for (int k = 0; k < ns; ++k) {
-        const int sx = (int)(ln.at(k) >> 16), sy = (int)(ln.at(k) & 0xffffu);
-        // exact dp of this match: candidates = main matches and earlier off-diagonal matches that end before it
-        int bv = -1000000;
-        {
-            const int lim = imin(sx, sy - d) - K;                     // last main row that ends before (sx, sy)
-            for (int i = 0; i < r; ++i) {
-                const int t = imin(lim - pu[i], pv[i] - 5 - pu[i]);
-                if (t < 0) continue;
-                const int v = dpf[i] + t + 2 * (pu[i] + t + K) + d;
-                bv = imax(bv, v);
-            }
-        }
-        int cont = -1;
-        for (int j = 0; j < k; ++j) {
-            const int jx = (int)(ln.at(j) >> 16), jy = (int)(ln.at(j) & 0xffffu);
-            if (jx + 1 == sx && jy + 1 == sy) cont = j;
-            if (jx + K <= sx && jy + K <= sy) {
-                bv = imax(bv, sdp[j] + jx + jy + 2 * K);
-            }
-        }
-        int dp = K;
-        if (bv > -1000000) {
-            const int cand = bv - (sx + sy) + 1;
-            if (cand >= K) dp = cand;          // (WHICH predecessor an off-diagonal match takes never matters: it is not on the chain)
-        }
-        if (cont >= 0 && sdp[cont] + 1 >= dp) dp = sdp[cont] + 1;
-        sdp[k] = dp;
-        if (dp >= best_dp) return Result{-1, W_NOT_HARMLESS};         // could end the chain
-        const int vs = dp + sx + sy + 2 * K;
-        // no main match may prefer it: first match of every piece that starts at or after its end
+        const uint32_t w = ln.at(k);
+        const int sx = (int)(w >> 16), sy = (int)(w & 0xffffu);
+        const int q = sx + sy - d;
+        const int lim = imin(sx, sy - d) - K;                      // last main row that ends before (sx, sy)
+        int bv = -1000000, minH = 1000000;
         for (int i = 0; i < r; ++i) {
-            const int t0 = imax(0, imax(sx + K - pu[i], sy + K - d - pu[i]));
-            if (t0 > pv[i] - 5 - pu[i]) continue;
-            const int cand = vs - (2 * (pu[i] + t0) + d) + 1;
-            if (cand >= dpf[i] + t0) return Result{-1, W_NOT_HARMLESS};
+            const uint32_t pw = ln.at(SM + i);
+            const int pu = (int)(pw & 0xffu), pv = (int)((pw >> 8) & 0xffu), dpf = (int)((pw >> 16) & 0xffu);
+            const int lm1 = pv - 5 - pu;
+            const int t = imin(lim - pu, lm1);
+            if (t >= 0) bv = imax(bv, dpf + t + 2 * (pu + t + K));           // V of the piece's last visible match (without d)
+            const int t0 = imax(0, imax(sx + K - pu, sy + K - d - pu));      // first match of the piece that starts after s ends
+            if (t0 <= lm1) minH = imin(minH, dpf + 3 * t0 + 2 * pu);
         }
+        int dp = imax(K, runmax + 1);
+        if (bv > -1000000) dp = imax(dp, bv - q + 1);
+        runmax = imax(runmax, dp);
+        // s could end the chain, or a main match could prefer it:  dp + (sx + K) + (sy + K) - (x_p + y_p) + 1 >= dp(p)
+        if (dp >= fr.best_dp || dp + q + 2 * K + 1 >= minH) { *why = W_NOT_HARMLESS; return -1; }
     }
-
-    // ---- 7. certificate: best local score of M over the in-band stretch of the diagonal ----
-    int cert = 0;
-    {
-        const int fx = pu[root], fy = fx + d;
-        const int d0 = imin(imin(fx, fy), LAZY);
-        const int t0 = imin(imin(fx - d0, fy - d0), W);
-        const int lo = fx - d0 - t0;
-        int re = pv[best_i] + 1, ce = re + d;                          // cell after the last k-mer: (b + K, b + K + d)
-        const int d1 = imin(imin(m - re, n - ce), LAZY);
-        re += d1; ce += d1;
-        const int t1 = imin(imin(m - re, n - ce), W);
-        const int hi = re + t1;
-        int s = 0, p = lo;
-        while (p < hi) {
-            const int q = imin(m_next_set(M, p), hi);
-            s = imax(0, s - 5 * (q - p));
-            if (q >= hi) break;
-            const int e = imin(m_next_clear(M, q), hi);
-            s += e - q;
-            cert = imax(cert, s);
-            p = e;
-        }
-    }
-
-    // ---- 8. run bound over the generic pieces; far pieces by the lemma ----
-    // generic list: (id = x0 << 16 | y0, bases | G << 16) at ln[SM + 2 j], ln[SM + 2 j + 1]
+    // ---- generic set: closure of the hull over the off-diagonal pieces.  T = the smallest distance the far-piece lemma
+    //      allows for E <= ns far matches: T >= E and 2T >= E + 5 ----
+    const int TFAR = imax(ns, 5);
     int ng = 0;
-    for (int i = 0; i < r; ++i) {
-        ln.at(SM + 2 * ng) = ((uint32_t)pu[i] << 16) | (uint32_t)(pu[i] + d);
-        ln.at(SM + 2 * ng + 1) = (uint32_t)(pv[i] - pu[i] + 1);
-        ++ng;
-    }
-    int far_e = 0;
     {
-        // off-diagonal pieces: a match that continues another one belongs to its piece (matches are in (x, y) order, a
-        // continuation sits in the next row)
-        int hull_lo = d, hull_hi = d;
-        uint32_t used = 0;                                            // matches already assigned (heads of generic pieces, or members)
+        int hull_lo = 0, hull_hi = 0;
+        uint32_t used = 0;
         bool grew = true;
         while (grew) {
             grew = false;
-            for (int k = 0; k < ns; ++k) {
+            for (int k = 0; k < nc; ++k) {
                 if ((used >> k) & 1u) continue;
-                const int sx = (int)(ln.at(k) >> 16), sy = (int)(ln.at(k) & 0xffffu);
+                const uint32_t w = ln.at(k);
+                const int sx = (int)(w >> 16), sy = (int)(w & 0xffffu);
+                const int delta = sy - sx - d;
+                if (delta > hull_hi + TFAR - 1 || delta < hull_lo - TFAR + 1) continue;      // (still) far
+                // a match that continues another one belongs to that one's piece (it sits in the row before)
                 bool is_head = true;
-                for (int j = 0; j < k; ++j) if ((int)(ln.at(j) >> 16) + 1 == sx && (int)(ln.at(j) & 0xffffu) + 1 == sy) is_head = false;
+                for (int j = k - 1; j >= 0; --j) {
+                    const uint32_t wj = ln.at(j);
+                    if ((int)(wj >> 16) + 1 < sx) break;
+                    if (wj + 0x10001u == w) is_head = false;
+                }
                 if (!is_head) continue;
-                const int ds = sy - sx;
-                if (ds > hull_hi + TFAR - 1 || ds < hull_lo - TFAR + 1) continue;     // (still) far
-                // piece length in k-mers
                 int len = 1;
                 uint32_t members = 1u << k;
-                for (int j = k + 1; j < ns; ++j)
-                    if ((int)(ln.at(j) >> 16) == sx + len && (int)(ln.at(j) & 0xffffu) == sy + len) { ++len; members |= 1u << j; }
-                if (ng == PM) return Result{-1, W_GENERIC};
-                ln.at(SM + 2 * ng) = ln.at(k);
-                ln.at(SM + 2 * ng + 1) = (uint32_t)(len + K - 1);
+                for (int j = k + 1; j < nc; ++j) {
+                    const uint32_t wj = ln.at(j);
+                    if ((int)(wj >> 16) > sx + len) break;
+                    if (wj == w + (uint32_t)len * 0x10001u) { ++len; members |= 1u << j; }
+                }
+                if (ng == GM || iabs(delta) > DMAX) { *why = W_GENERIC; return -1; }
+                gl.at(ng) = (uint32_t)sx | ((uint32_t)(delta + 128) << 8) | ((uint32_t)(len + K - 1) << 16);
                 ++ng;
                 used |= members;
-                hull_lo = imin(hull_lo, ds); hull_hi = imax(hull_hi, ds);
+                hull_lo = imin(hull_lo, delta); hull_hi = imax(hull_hi, delta);
                 grew = true;
             }
         }
-        for (int k = 0; k < ns; ++k) if (!((used >> k) & 1u)) ++far_e;     // E = far k-mer matches = sum over far pieces of bases - 5
+        // what the closure left is >= T diagonals outside the hull: far.  E = their k-mer matches
+        far_e = nc - __builtin_popcount(used);
     }
+    // ---- run bound over the generic pieces: main pieces at ln[SM, SM + r), off-diagonal ones at gl[0, ng) ----
     int ub = imax(K - 1, far_e > 0 ? far_e + 5 : 0);
     {
-        bool changed = true;
+        const int n_all = r + ng;
+        auto word = [&](int i) -> uint32_t& { return i < r ? ln.at(SM + i) : gl.at(i - r); };
+        auto decode = [&](int i, uint32_t w, int& xp, int& yp, int& lp) {
+            if (i < r) { xp = (int)(w & 0xffu); yp = xp + d; lp = (int)((w >> 8) & 0xffu) - xp + 1; }
+            else { xp = (int)(w & 0xffu); yp = xp + d + (int)((w >> 8) & 0xffu) - 128; lp = (int)((w >> 16) & 0xffu); }
+        };
+        // G lives in the top byte of every piece word
+        for (int i = 0; i < n_all; ++i) word(i) &= 0x00ffffffu;
+        bool changed = n_all > 1;
         for (int pass = 0; pass < 6 && changed; ++pass) {
             changed = false;
-            for (int p = 0; p < ng; ++p) {
-                const uint32_t idp = ln.at(SM + 2 * p), dlp = ln.at(SM + 2 * p + 1);
-                const int xp = (int)(idp >> 16), yp = (int)(idp & 0xffffu), lp = (int)(dlp & 0xffffu);
-                const int g0 = (int)(dlp >> 16);
+            for (int p = 0; p < n_all; ++p) {
+                const uint32_t wp = word(p);
+                int xp, yp, lp;
+                decode(p, wp, xp, yp, lp);
+                const int g0 = (int)(wp >> 24);
                 int g = g0;
-                for (int q = 0; q < ng; ++q) {
+                for (int q = 0; q < n_all; ++q) {
                     if (q == p) continue;
-                    const uint32_t idq = ln.at(SM + 2 * q), dlq = ln.at(SM + 2 * q + 1);
-                    const int xq = (int)(idq >> 16), yq = (int)(idq & 0xffffu), lq = (int)(dlq & 0xffffu), gq = (int)(dlq >> 16);
+                    const uint32_t wq = word(q);
+                    int xq, yq, lq;
+                    decode(q, wq, xq, yq, lq);
+                    const int gq = (int)(wq >> 24);
                     int s = imax(xq + lq - xp, yq + lq - yp);
                     s = imin(imax(s, 0), lp - 1);
                     const int t = imin(lq - 1, imin(xp - xq, yp - yq) + s - 1);
@@ -421,17 +486,32 @@ VTXF_FN Result fast_task(const uint8_t* x, int m, const Tab& tb, int n, const La
                     if (dd == 0) { const int D = xp + s - xq - t - 1; J = D == 0 ? 0 : join_same(D); }
                     g = imax(g, t + 1 + gq - J - s);
                 }
-                if (g != g0) { ln.at(SM + 2 * p + 1) = (dlp & 0xffffu) | ((uint32_t)g << 16); changed = true; }
+                if (g != g0) { word(p) = (wp & 0x00ffffffu) | ((uint32_t)g << 24); changed = true; }
             }
         }
-        if (changed) return Result{-1, W_NOT_TIGHT};
-        for (int p = 0; p < ng; ++p) {
-            const uint32_t dl = ln.at(SM + 2 * p + 1);
-            ub = imax(ub, (int)(dl & 0xffffu) + (int)(dl >> 16));
+        if (changed) { *why = W_NOT_TIGHT; return -1; }
+        for (int p = 0; p < n_all; ++p) {
+            const uint32_t wp = word(p);
+            int xp, yp, lp;
+            decode(p, wp, xp, yp, lp);
+            ub = imax(ub, lp + (int)(wp >> 24));
         }
     }
-    if (cert != ub) return Result{-1, W_NOT_TIGHT};
-    return Result{cert, W_OK};
+    if (fr.cert != ub) { *why = W_NOT_TIGHT; return -1; }
+    *why = W_OK;
+    return fr.cert;
+}
+
+struct Result { int32_t score; uint32_t why; };
+// all three phases on one lane (host test; device variant without pooled probes)
+VTXF_FN Result fast_task(const uint8_t* x, int m, const Tab& tb, int n, const Lane& ln) {
+    const Front fr = front(x, m, tb, n, ln);
+    if (fr.why != W_OK) return Result{-1, fr.why};
+    const int ns = probe_rows(x, tb, fr, ln);
+    uint32_t why = W_OK;
+    uint32_t generic[GM];
+    const int32_t sc = back(fr, ns, ln, Lane{generic, 1}, &why);
+    return Result{sc, why};
 }
 
 }  // namespace vtxf
