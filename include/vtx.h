@@ -265,7 +265,8 @@ int vtx_device_coo(vtx_ctx* ctx, vtx_coo* out);
  *                    its own means (MPI, a socket, a file — it is plain bytes).
  *   vtx_comm_init    every rank, same id: joins the communicator (collective).
  *   vtx_gather_coo   every rank, after its own vtx_run (collective).  The counts go round with one all-gather of a
- *                    64-bit word per rank; then each rank sends its (row, col, alt, ref, unk) arrays to `dst`, which
+ *                    (count, status) pair per rank — any rank in error makes EVERY rank return VTX_E_PEER before the data
+ *                    exchange, so nobody waits for a peer that left; then each rank sends its (row, col, alt, ref, unk) arrays to `dst`, which
  *                    receives every block at its final offset (grouped point-to-point: no padding, each block crosses
  *                    its own link once) and recomputes the f64 values from the counts (the same arithmetic as
  *                    vtx_run's emit step).  On `dst`, *out holds DEVICE pointers to the gathered arrays (valid until
@@ -277,6 +278,12 @@ int vtx_comm_id(uint8_t id[VTX_COMM_ID_BYTES]);
 int vtx_comm_init(vtx_ctx* ctx, const uint8_t id[VTX_COMM_ID_BYTES], int rank, int world);
 int vtx_gather_coo(vtx_ctx* ctx, int dst, vtx_coo* out);
 int vtx_fetch_gathered(vtx_ctx* ctx, vtx_coo* out);
+/* A rank whose own work failed after vtx_comm_init (vtx_submit / vtx_run error) calls this INSTEAD of vtx_gather_coo: it takes
+ * part in the status round, and every other rank's vtx_gather_coo returns VTX_E_PEER instead of waiting for ever.          */
+int vtx_gather_abort(vtx_ctx* ctx);
+/* The layout of the exchange as a pure function (no device): offsets[r] = where rank r's counts[r] triplets land, *total =
+ * their sum; VTX_E_UNSUPPORTED when the total exceeds 2^32 - 1.  vtx_gather_coo follows exactly this plan.                  */
+int vtx_gather_plan(int world, const uint64_t* counts, uint64_t* offsets, uint64_t* total);
 
 int vtx_last_timing(vtx_ctx* ctx, vtx_timing* out);
 

@@ -31,6 +31,7 @@ static void* slab(int k, size_t bytes) {
         free(t_slab[k]);
         t_slab_cap[k] = bytes + bytes / 2 + 64;
         t_slab[k] = malloc(t_slab_cap[k]);
+        if (!t_slab[k]) { fprintf(stderr, "vtx_oracle: out of memory (%zu bytes of scratch)\n", t_slab_cap[k]); abort(); }
     }
     return t_slab[k];
 }

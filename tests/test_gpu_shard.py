@@ -94,6 +94,20 @@ for mode, umi in (("consensus", 0), ("alt_frac", 1), ("coverage", 1)):
     assert d["nnz"] == len(want["row"]) > 1000
     for k in want:
         assert np.array_equal(got[k].view(np.uint8), want[k].view(np.uint8)), (mode, k)
+# status round: a rank without a completed vtx_run reports it instead of entering the exchange (the other ranks would get
+# VTX_E_PEER); vtx_gather_abort is the same round for a rank whose own work failed
+from vartrix_amd import abi
+with lib.Context(default_config(aligner="banded", n_barcodes=500)) as ctx:
+    ctx.comm_init(lib.comm_id(), 0, 1)
+    ctx.submit(batch)
+    try:
+        ctx.gather_coo(0)
+        raise SystemExit("gather_coo before vtx_run must fail")
+    except lib.VtxError as e:
+        assert e.status == abi.VTX_E_STATE, e
+    ctx.gather_abort()
+    ctx.run()
+    assert ctx.gather_coo(0)["nnz"] > 1000
 print("native-gather-one-rank-ok")
 ''' % ROOT
 

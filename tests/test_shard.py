@@ -146,3 +146,27 @@ def test_partition_covers_config4_shape():
         reads = np.concatenate([p.read_arena[:int(p.records["read_len"].astype(np.int64).sum())] if p.n_records else np.zeros(0, np.uint8)
                                 for p in pieces])
         assert reads.shape[0] == int(batch.records["read_len"].astype(np.int64).sum())
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_gather_plan_is_the_concatenation_in_rank_order(world):
+    """vtx_gather_plan — the count -> offset layout vtx_gather_coo follows on every rank (src/main.rs:320-348: the chunks'
+    results concatenated in chunk order) — as a pure function: empty ranks, one rank holding everything, the 2^32 limit."""
+    from vartrix_amd import abi, lib
+    rng = np.random.default_rng(world)
+    cases = [[0] * world, [5] * world, [0] * (world - 1) + [7], [7] + [0] * (world - 1),
+             [int(v) for v in rng.integers(0, 1 << 20, world)], [int(v) if i % 2 else 0 for i, v in enumerate(rng.integers(1, 99, world))]]
+    for counts in cases:
+        rc, off, total = lib.gather_plan(counts)
+        assert rc == abi.VTX_OK
+        assert total == sum(counts)
+        assert off == [sum(counts[:r]) for r in range(world)]
+        # blocks tile [0, total) without overlap, in rank order
+        ends = [o + c for o, c in zip(off, counts)]
+        assert all(ends[r] == (off[r + 1] if r + 1 < world else total) for r in range(world))
+    # more than 2^32 - 1 gathered triplets: every rank gets the same refusal (before any point-to-point call)
+    big = [(1 << 32) // world + 1] * world
+    rc, off, total = lib.gather_plan(big)
+    assert rc == abi.VTX_E_UNSUPPORTED and total == sum(big)
+    rc, _, total = lib.gather_plan([(1 << 32) - 1] + [0] * (world - 1))
+    assert rc == abi.VTX_OK and total == (1 << 32) - 1

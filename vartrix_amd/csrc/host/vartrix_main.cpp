@@ -13,6 +13,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -79,6 +81,24 @@ void usage() {
             "  --prep host|device [host]  (device: barcode lookup, UMI grouping and the sort run on the GPU)\n");
 }
 
+// The shard threads of one batch meet here before each RCCL collective, carrying their status: if any shard has failed,
+// NONE enters the collective (a communicator a rank never joins, a Send whose Recv never comes, would block for ever).
+struct ShardGate {
+    std::mutex mu;
+    std::condition_variable cv;
+    int world = 1, arrived = 0, generation = 0;
+    bool failed = false, verdict = false;
+    // returns true when every shard arrived with ok == true
+    bool meet(bool ok) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!ok) failed = true;
+        const int gen = generation;
+        if (++arrived == world) { verdict = !failed; arrived = 0; failed = false; ++generation; cv.notify_all(); return verdict; }
+        cv.wait(lk, [&] { return generation != gen; });
+        return verdict;
+    }
+};
+
 struct Shard {
     std::vector<vtx_locus> loci;                 // rec_begin rebased to the shard's first record
     const vtx_record* records = nullptr;         // the shard's slice of the pack's arrays (not copied)
@@ -104,6 +124,7 @@ struct Shard {
     // --devices N > 1: the shards' rows meet on device 0 through the library's RCCL gather (vtx_gather_coo)
     const uint8_t* comm_id = nullptr;
     int rank = 0, world = 1;
+    ShardGate* gate = nullptr;
 };
 
 double since(std::chrono::steady_clock::time_point t0) {
@@ -116,10 +137,17 @@ void run_shard(Shard* s, vtx_config cfg) {
     vtx_ctx* ctx = nullptr;
     double t0 = now_s();
     s->rc = vtx_create(&cfg, &ctx);
-    if (s->rc) { s->err = vtx_strerror(nullptr); return; }
-    if (s->comm_id && (s->rc = vtx_comm_init(ctx, s->comm_id, s->rank, s->world))) {     // collective over the shard threads
-        s->err = vtx_strerror(ctx); vtx_destroy(ctx); return;
-    }
+    if (s->rc) s->err = vtx_strerror(nullptr);
+    if (s->comm_id) {
+        // every shard has a context, or none joins the communicator
+        if (!s->gate->meet(s->rc == 0)) {
+            if (!s->rc) { s->rc = VTX_E_PEER; s->err = "another shard failed before the communicator was set up"; vtx_destroy(ctx); }
+            return;
+        }
+        if ((s->rc = vtx_comm_init(ctx, s->comm_id, s->rank, s->world))) {     // collective over the shard threads
+            s->err = vtx_strerror(ctx); vtx_destroy(ctx); return;
+        }
+    } else if (s->rc) return;
     s->t_create = now_s() - t0; t0 = now_s();
     vtx_batch b{s->loci.data(), (uint32_t)s->loci.size(), s->records, s->n_records, s->haps,
                 s->hap_bytes, s->reads, s->read_bytes};
@@ -129,13 +157,14 @@ void run_shard(Shard* s, vtx_config cfg) {
                          s->haps, s->hap_bytes, s->reads, s->read_bytes, s->tags, s->tag_bytes};
         if ((s->rc = vtx_set_barcodes(ctx, s->bc_bytes, s->bc_offsets, s->n_bcs)) || (s->rc = vtx_submit_raw(ctx, &rb, &s->stats))) {
             s->err = vtx_strerror(ctx);
+            if (s->comm_id) (void)vtx_gather_abort(ctx);      // the other shards leave their vtx_gather_coo with VTX_E_PEER
             vtx_destroy(ctx);
             return;
         }
     }
-    if (!s->raw && (s->rc = vtx_submit(ctx, &b))) { s->err = vtx_strerror(ctx); vtx_destroy(ctx); return; }
+    if (!s->raw && (s->rc = vtx_submit(ctx, &b))) { s->err = vtx_strerror(ctx); if (s->comm_id) (void)vtx_gather_abort(ctx); vtx_destroy(ctx); return; }
     s->t_submit = now_s() - t0; t0 = now_s();
-    if ((s->rc = vtx_run(ctx))) { s->err = vtx_strerror(ctx); vtx_destroy(ctx); return; }
+    if ((s->rc = vtx_run(ctx))) { s->err = vtx_strerror(ctx); if (s->comm_id) (void)vtx_gather_abort(ctx); vtx_destroy(ctx); return; }
     s->t_run = now_s() - t0; t0 = now_s();
     if (s->comm_id) {
         // every shard's triplets to rank 0 over RCCL (rank order = row order); rank 0 copies the gathered matrix out
@@ -326,10 +355,12 @@ int main(int argc, char** argv) {
                      raw ? "raw reads; barcode lookup / UMI grouping / sort on the device" : "scored reads");
         // more than one device (or the test hook): the row exchange runs behind the C-ABI over RCCL
         uint8_t comm_id[VTX_COMM_ID_BYTES];
+        ShardGate gate;
+        gate.world = ndev;
         const bool use_comm = ndev > 1 || getenv("VTX_CLI_FORCE_GATHER");
         if (use_comm) {
             if (int rc = vtx_comm_id(comm_id)) { printf("Vartrix error.\nError: %s: %s\n", vtx_status_name(rc), vtx_strerror(nullptr)); return 1; }
-            for (int d = 0; d < ndev; ++d) { shards[(size_t)d].comm_id = comm_id; shards[(size_t)d].rank = d; shards[(size_t)d].world = ndev; }
+            for (int d = 0; d < ndev; ++d) { shards[(size_t)d].comm_id = comm_id; shards[(size_t)d].rank = d; shards[(size_t)d].world = ndev; shards[(size_t)d].gate = &gate; }
         }
         std::vector<std::thread> th;
         for (int d = 0; d < ndev; ++d) {
@@ -338,8 +369,9 @@ int main(int argc, char** argv) {
             th.emplace_back(run_shard, &shards[(size_t)d], c);
         }
         for (auto& t : th) t.join();
-        for (auto& s : shards)
-            if (s.rc) { printf("Vartrix error.\nError: %s: %s\n", vtx_status_name(s.rc), s.err.c_str()); return 1; }
+        for (int pass = 0; pass < 2; ++pass)              // the shard that failed on its own first, not the VTX_E_PEER followers
+            for (auto& s : shards)
+                if (s.rc && (pass == 1 || s.rc != VTX_E_PEER)) { printf("Vartrix error.\nError: %s: %s\n", vtx_status_name(s.rc), s.err.c_str()); return 1; }
         for (auto& s : shards) {
             LOG_INFO("  batch %u shard: create %.3f s, submit (H2D%s) %.3f s, run %.3f s, fetch %.3f s", bi, s.t_create,
                      s.raw ? " + device preparation" : "", s.t_submit, s.t_run, s.t_fetch);

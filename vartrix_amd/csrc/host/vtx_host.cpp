@@ -707,6 +707,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     size_t pend_begin = SIZE_MAX;
     bool pend_detached = false;
     ByteBuf pend_store;
+    bool refill_failed = false;           // a block did not inflate / the buffer could not grow (as opposed to: the file has no more)
     auto refill = [&](size_t need) -> bool {   // ensure buf has >= need bytes from buf_pos, if the file has them
         while (buf.size() - buf_pos < need && next_block < blocks.size()) {
             size_t chunk = std::min(blocks.size() - next_block, chunk_blocks);
@@ -720,7 +721,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
                 buf.swap_with(pend_store);
                 const size_t tail = pend_store.size() - buf_pos;
                 buf.len = 0;
-                if (!buf.grow(tail)) return false;
+                if (!buf.grow(tail)) { refill_failed = true; return false; }
                 memcpy(buf.data(), pend_store.data() + buf_pos, tail);
                 buf_pos = 0;
                 pend_detached = true;
@@ -730,14 +731,14 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             std::vector<size_t> off(chunk + 1, 0);
             for (size_t k = 0; k < chunk; ++k) off[k + 1] = off[k] + blocks[next_block + k].isize;
             const size_t base = buf.size();
-            if (!buf.grow(off[chunk])) return false;
+            if (!buf.grow(off[chunk])) { refill_failed = true; return false; }
             std::atomic<size_t> nextk{0};
             std::atomic<bool> ok{true};
             pool.run([&](size_t) {
                 for (size_t k; (k = nextk.fetch_add(1)) < chunk;)
                     if (!inflate_block(bam_file, blocks[next_block + k], buf.data() + base + off[k])) ok = false;
             });
-            if (!ok) return false;
+            if (!ok) { buf.len = base; refill_failed = true; return false; }     // nothing half-inflated is ever indexed as records
             next_block += chunk;
             n_inflated += chunk;
         }
@@ -1043,11 +1044,13 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
             buf_pos = 0;
             next_block = b; chunk_blocks = std::min<size_t>(32, max_chunk_blocks);
             refill((size_t)(jump_voff & 0xffff) + 1);
+            if (refill_failed) return fail(VTX_E_INVAL, "%s: a BGZF block does not inflate (or out of memory)", a->bam);
             buf_pos = (size_t)(jump_voff & 0xffff);
             if (buf_pos > buf.size()) return fail(VTX_E_INVAL, "%s.bai: offset outside its block", a->bam);
         }
         if (use_index) update_read_ahead();
         refill(buf.size() - buf_pos + 1);             // one more chunk of blocks, if the file has one
+        if (refill_failed) return fail(VTX_E_INVAL, "%s: a BGZF block does not inflate (or out of memory)", a->bam);
         ph.mark("inflate");
         if (!pend_offs.empty()) parse_thread = std::thread(parse_pending);      // ... beside the indexing below
         rec_offs.clear();

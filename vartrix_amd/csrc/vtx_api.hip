@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -321,9 +322,8 @@ struct Rccl {
 };
 Rccl* rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;          // vtx_comm_init is called from several threads at once (one context per GPU)
+    std::call_once(once, [] {
         for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
             r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
@@ -336,7 +336,7 @@ Rccl* rccl() {
             if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.Send || !r.Recv || !r.GroupStart ||
                 !r.GroupEnd || !r.GetErrorString) { dlclose(r.lib); r.lib = nullptr; }
         }
-    }
+    });
     return r.lib ? &r : nullptr;
 }
 #define NCCL_TRY(c, expr)                                                                                   \
@@ -1337,27 +1337,83 @@ int vtx_comm_init(vtx_ctx* c, const uint8_t id[VTX_COMM_ID_BYTES], int rank, int
     return VTX_OK;
 }
 
+// The exchange's plan as a pure function of the counts (no device, no communicator): rank r's block lands at
+// offsets[r] of the gathered arrays (rank order = row order), *total triplets in all.  VTX_E_UNSUPPORTED when the gathered
+// arrays would not fit 32-bit indices.  Every rank computes the same plan from the same all-gathered counts, so every rank
+// takes the same decision.
+int vtx_gather_plan(int world, const uint64_t* counts, uint64_t* offsets, uint64_t* total) {
+    if (world < 1 || !counts || !offsets || !total) return VTX_E_INVAL;
+    uint64_t t = 0;
+    for (int r = 0; r < world; ++r) { offsets[r] = t; t += counts[r]; }
+    *total = t;
+    return t > 0xffffffffull ? VTX_E_UNSUPPORTED : VTX_OK;
+}
+
+// One all-gather of (count, status) per rank: a rank that cannot take part in the data exchange (its own vtx_run failed,
+// the destination could not reserve its buffers) says so HERE, and every rank leaves with VTX_E_PEER before any
+// point-to-point call — a Send whose Recv never comes would block for ever.
+static int gather_agree(vtx_ctx* c, uint64_t mine, uint64_t status, std::vector<uint64_t>& cnt, std::vector<uint64_t>& st) {
+    const int world = c->comm_world;
+    hipStream_t s = c->stream;
+    Rccl* R = rccl();
+    HIP_TRY(c, c->d_g_cnt.reserve(2 * ((size_t)world + 1) * sizeof(uint64_t)));
+    uint64_t* d_cnt = c->d_g_cnt.as<uint64_t>();
+    const uint64_t pair[2] = {mine, status};
+    HIP_TRY(c, hipMemcpyAsync(d_cnt + 2 * world, pair, sizeof pair, hipMemcpyHostToDevice, s));
+    NCCL_TRY(c, R->AllGather(d_cnt + 2 * world, d_cnt, 2, ncclUint64, c->comm, s));
+    std::vector<uint64_t> both(2 * (size_t)world);
+    HIP_TRY(c, hipMemcpyAsync(both.data(), d_cnt, both.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    cnt.resize((size_t)world); st.resize((size_t)world);
+    for (int r = 0; r < world; ++r) { cnt[(size_t)r] = both[2 * (size_t)r]; st[(size_t)r] = both[2 * (size_t)r + 1]; }
+    return VTX_OK;
+}
+
+int vtx_gather_abort(vtx_ctx* c) {
+    if (!c) return VTX_E_INVAL;
+    if (!c->comm) return fail(c, VTX_E_STATE, "vtx_gather_abort: no communicator (vtx_comm_init)");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    std::vector<uint64_t> cnt, st;
+    if (int rc = gather_agree(c, 0, 1, cnt, st)) return rc;
+    return VTX_OK;
+}
+
 int vtx_gather_coo(vtx_ctx* c, int dst, vtx_coo* out) {
     if (!c) return VTX_E_INVAL;
     if (!out) return fail(c, VTX_E_INVAL, "vtx_gather_coo: null output");
     if (!c->comm) return fail(c, VTX_E_STATE, "vtx_gather_coo: no communicator (vtx_comm_init)");
-    if (!c->ran) return fail(c, VTX_E_STATE, "vtx_gather_coo: no completed vtx_run");
     const int world = c->comm_world, rank = c->comm_rank;
     if (dst < 0 || dst >= world) return fail(c, VTX_E_INVAL, "vtx_gather_coo: dst %d out of range", dst);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
     Rccl* R = rccl();
-    // counts of every rank (one 64-bit word each)
-    HIP_TRY(c, c->d_g_cnt.reserve(((size_t)world + 1) * sizeof(uint64_t)));
-    uint64_t* d_cnt = c->d_g_cnt.as<uint64_t>();
-    const uint64_t mine = c->nnz;
-    HIP_TRY(c, hipMemcpyAsync(d_cnt + world, &mine, sizeof mine, hipMemcpyHostToDevice, s));
-    NCCL_TRY(c, R->AllGather(d_cnt + world, d_cnt, 1, ncclUint64, c->comm, s));
-    std::vector<uint64_t> cnt((size_t)world);
-    HIP_TRY(c, hipMemcpyAsync(cnt.data(), d_cnt, (size_t)world * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
     memset(out, 0, sizeof *out);
     c->g_nnz = 0;
+    // round 1: counts + "my vtx_run completed"
+    const uint64_t mine = c->ran ? c->nnz : 0;
+    std::vector<uint64_t> cnt, st;
+    if (int rc = gather_agree(c, mine, c->ran ? 0 : 1, cnt, st)) return rc;
+    for (int r = 0; r < world; ++r)
+        if (st[(size_t)r]) return fail(c, r == rank ? VTX_E_STATE : VTX_E_PEER, r == rank ? "vtx_gather_coo: no completed vtx_run"
+                                       : "vtx_gather_coo: rank %d reported an error; exchange abandoned", r);
+    std::vector<uint64_t> off((size_t)world);
+    uint64_t total = 0;
+    if (vtx_gather_plan(world, cnt.data(), off.data(), &total) != VTX_OK)      // (the same verdict on every rank)
+        return fail(c, VTX_E_UNSUPPORTED, "vtx_gather_coo: more than 2^32 gathered triplets");
+    // round 2: the destination has its buffers (the only step before the exchange that can fail on one rank alone)
+    DevBuf* dstb[5] = {&c->d_g_row, &c->d_g_col, &c->d_g_alt, &c->d_g_ref, &c->d_g_unk};
+    uint64_t ready = 0;
+    if (rank == dst) {
+        const size_t cap = (size_t)std::max<uint64_t>(total, 1);
+        for (DevBuf* b : dstb) if (b->reserve(cap * sizeof(uint32_t)) != hipSuccess) ready = 1;
+        if (c->d_g_val.reserve(cap * sizeof(double)) != hipSuccess || c->d_g_refval.reserve(cap * sizeof(double)) != hipSuccess) ready = 1;
+        if (ready) (void)hipGetLastError();
+    }
+    {
+        std::vector<uint64_t> c2, s2;
+        if (int rc = gather_agree(c, 0, ready, c2, s2)) return rc;
+        if (s2[(size_t)dst]) return fail(c, rank == dst ? VTX_E_NOMEM : VTX_E_PEER, "vtx_gather_coo: rank %d could not reserve the gathered arrays", dst);
+    }
     const uint32_t* src[5] = {c->d_o_row.as<uint32_t>(), c->d_o_col.as<uint32_t>(), c->d_o_alt.as<uint32_t>(),
                               c->d_o_ref.as<uint32_t>(), c->d_o_unk.as<uint32_t>()};
     if (rank != dst) {
@@ -1369,14 +1425,6 @@ int vtx_gather_coo(vtx_ctx* c, int dst, vtx_coo* out) {
         HIP_TRY(c, hipStreamSynchronize(s));          // the source arrays may be overwritten by the next vtx_run
         return VTX_OK;
     }
-    uint64_t total = 0;
-    std::vector<uint64_t> off((size_t)world);
-    for (int r = 0; r < world; ++r) { off[(size_t)r] = total; total += cnt[(size_t)r]; }
-    if (total > 0xffffffffull) return fail(c, VTX_E_UNSUPPORTED, "vtx_gather_coo: more than 2^32 gathered triplets");
-    DevBuf* dstb[5] = {&c->d_g_row, &c->d_g_col, &c->d_g_alt, &c->d_g_ref, &c->d_g_unk};
-    for (DevBuf* b : dstb) HIP_TRY(c, b->reserve((size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t)));
-    HIP_TRY(c, c->d_g_val.reserve((size_t)std::max<uint64_t>(total, 1) * sizeof(double)));
-    HIP_TRY(c, c->d_g_refval.reserve((size_t)std::max<uint64_t>(total, 1) * sizeof(double)));
     NCCL_TRY(c, R->GroupStart());
     for (int r = 0; r < world; ++r) {
         if (r == dst || !cnt[(size_t)r]) continue;

@@ -21,7 +21,7 @@ SYMBOLS = (
     "vtx_config_default", "vtx_create", "vtx_destroy", "vtx_submit", "vtx_run", "vtx_fetch_scores",
     "vtx_fetch_coo", "vtx_device_scores", "vtx_device_coo", "vtx_last_timing", "vtx_last_cells", "vtx_strerror",
     "vtx_status_name", "vtx_abi_sizes", "vtx_set_barcodes", "vtx_submit_raw", "vtx_fetch_records",
-    "vtx_comm_id", "vtx_comm_init", "vtx_gather_coo", "vtx_fetch_gathered",
+    "vtx_comm_id", "vtx_comm_init", "vtx_gather_coo", "vtx_fetch_gathered", "vtx_gather_abort", "vtx_gather_plan",
 )
 
 
@@ -86,6 +86,10 @@ def load():
     L.vtx_gather_coo.argtypes = [ctxp, C.c_int, C.POINTER(abi.VtxCoo)]
     L.vtx_fetch_gathered.restype = C.c_int
     L.vtx_fetch_gathered.argtypes = [ctxp, C.POINTER(abi.VtxCoo)]
+    L.vtx_gather_abort.restype = C.c_int
+    L.vtx_gather_abort.argtypes = [ctxp]
+    L.vtx_gather_plan.restype = C.c_int
+    L.vtx_gather_plan.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -95,6 +99,17 @@ def status_name(status: int) -> str:
 
 
 COMM_ID_BYTES = 128
+
+
+def gather_plan(counts):
+    """(status, offsets, total) of vtx_gather_plan: where every rank's triplets land in the gathered arrays (pure; no GPU)."""
+    L = load()
+    n = len(counts)
+    c = (C.c_uint64 * n)(*[int(v) for v in counts])
+    off = (C.c_uint64 * n)()
+    tot = C.c_uint64(0)
+    rc = L.vtx_gather_plan(n, c, off, C.byref(tot))
+    return rc, list(off), int(tot.value)
 
 
 def comm_id() -> bytes:
@@ -219,6 +234,11 @@ class Context:
         for k in ("row", "col", "alt", "ref", "unk", "value", "ref_value"):
             out[k] = C.cast(getattr(coo, k), C.c_void_p).value or 0
         return out
+
+    def gather_abort(self):
+        """Collective: takes part in the status round of ``gather_coo`` with an error flag, so that the other ranks leave
+        their ``gather_coo`` with VTX_E_PEER (vtx_gather_abort)."""
+        self._check(self._L.vtx_gather_abort(self._h))
 
     def fetch_gathered(self) -> dict:
         coo = abi.VtxCoo()
