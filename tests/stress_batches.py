@@ -1,0 +1,137 @@
+"""Batches shared by the stress tests (CPU: tests/test_certify_stress.py, tests/test_fastcore.py; GPU: tests/test_gpu_stress.py)
+and by tools/certify_stress.py / tools/gpu_parity_stress.py, which run the same generators at full size.
+
+  synthetic_batches   config-3 generator from clean to 30 % substitution errors, with indel loci, ragged read lengths and paddings
+  repeat_rich_batches tandem-repeat genomes over 2- to 4-letter alphabets: hundreds of k-mer pieces per alignment
+  real_shape_batches  what real 10x reads add to `150M`: soft-clipped ends (the clip is random sequence), adapter tails, spliced
+                      reads (the read skips an intron of the reference: CIGAR N), lower-case / N bases
+"""
+import numpy as np
+
+from vartrix_amd import synth
+from vartrix_amd.abi import LOCUS_DTYPE, RECORD_DTYPE, PackedBatch
+
+ERROR_MODELS = [(0.005, 0, 0, 150, 100), (0.02, 0.3, 40, 150, 100), (0.05, 0.5, 60, 120, 60), (0.1, 0.2, 30, 100, 150),
+                (0.15, 0.6, 50, 80, 40), (0.01, 0.8, 70, 150, 200), (0.3, 0.1, 0, 150, 100)]
+
+
+def manual_batch(haps, reads_per_locus, n_barcodes):
+    loci, recs, hb, rb = [], [], bytearray(), bytearray()
+    for i, ((ref, alt), reads) in enumerate(zip(haps, reads_per_locus)):
+        begin = len(recs)
+        for cell, umi, seq in sorted(reads, key=lambda t: (t[0], t[1])):
+            recs.append((len(rb), len(seq), cell, umi))
+            rb += seq
+        loci.append((i, begin, len(recs) - begin, len(hb), len(ref), len(hb) + len(ref), len(alt), 0))
+        hb += ref + alt
+    return PackedBatch(np.array(loci, LOCUS_DTYPE).reshape(-1), np.array(recs, RECORD_DTYPE).reshape(-1),
+                       np.frombuffer(bytes(hb), np.uint8), np.frombuffer(bytes(rb), np.uint8))
+
+
+def synthetic_batches(per_model=3, n_loci=150, reads=48):
+    seed = 1000
+    for (sub, indel, jitter, rl, pad) in ERROR_MODELS:
+        for _ in range(per_model):
+            seed += 1
+            spec = synth.SynthSpec(n_loci=n_loci, n_barcodes=500, reads_per_locus=reads, indel_frac=indel, sub_error=sub,
+                                   read_len_jitter=jitter, read_len=rl, padding=pad, seed=seed)
+            yield ("sub %.3f indel %.1f jitter %d len %d pad %d" % (sub, indel, jitter, rl, pad), synth.make_batch(spec), 500)
+
+
+def repeat_rich_batches(trials=12, loci=60, reads=24):
+    rng = np.random.default_rng(2024)
+    for trial in range(trials):
+        alpha = [b"ACGT", b"AC", b"AT", b"ACG"][trial % 4]
+        units = [b"A", b"AC", b"AAT", b"ACGT", b"AAAAC", b"AG", b"T", b"CAG", b"ACACAT", b"GATTACA"]
+        g = bytearray()
+        while len(g) < 40000:
+            g += units[int(rng.integers(0, len(units)))] * int(rng.integers(2, 40))
+            g += bytes(rng.choice(list(alpha), int(rng.integers(0, 30))).tolist())
+        g = bytes(g)
+        haps, rds = [], []
+        for _ in range(loci):
+            p = int(rng.integers(300, len(g) - 500))
+            pad = int(rng.integers(30, 160))
+            ref = g[p - pad:p + pad + 1]
+            kind = rng.random()
+            if kind < 0.5:
+                alt = ref[:pad] + bytes([b"ACGT"[(b"ACGT".index(ref[pad:pad + 1]) + 1) % 4]]) + ref[pad + 1:]
+            elif kind < 0.75:
+                alt = ref[:pad + 1] + bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 21))).tolist()) + ref[pad + 1:]
+            else:
+                alt = ref[:pad + 1] + ref[pad + 1 + int(rng.integers(1, min(20, pad - 1))):]
+            haps.append((ref, alt))
+            rl = []
+            for _k in range(reads):
+                ln = int(rng.integers(40, 200))
+                s = max(p - int(rng.integers(0, ln)), 0)
+                rd = bytearray(g[s:s + ln])
+                for e in np.nonzero(rng.random(len(rd)) < rng.choice([0.0, 0.02, 0.08]))[0]:
+                    rd[e] = b"ACGT"[int(rng.integers(0, 4))]
+                if len(rd) >= 10:
+                    rl.append((int(rng.integers(0, 30)), 0, bytes(rd)))
+            rds.append(rl)
+        yield ("repeat-rich, alphabet %s" % alpha.decode(), manual_batch(haps, rds, 30), 30)
+
+
+def real_shape_batches(trials=4, loci=80, reads=40, seed=77):
+    """Reads as an aligner reports them for 10x libraries, against the haplotypes of SNV / indel loci at padding 100.  A read
+    reaches the aligner with ALL its bases (`rec.seq()`, src/main.rs:896): soft clips included, introns excluded."""
+    rng = np.random.default_rng(seed)
+    acgt = list(b"ACGT")
+    for trial in range(trials):
+        g = bytes(rng.choice(acgt, 1000 * loci + 3000).tolist())
+        haps, rds = [], []
+        for i in range(loci):
+            p = 1500 + 1000 * i
+            pad = 100
+            kind = rng.random()
+            if kind < 0.6:
+                ref_al, alt_al = g[p:p + 1], bytes([b"ACGT"[(b"ACGT".index(g[p:p + 1]) + 1 + int(rng.integers(0, 3))) % 4]])
+            elif kind < 0.8:
+                ref_al, alt_al = g[p:p + 1], g[p:p + 1] + bytes(rng.choice(acgt, int(rng.integers(1, 21))).tolist())
+            else:
+                k = int(rng.integers(1, 21))
+                ref_al, alt_al = g[p:p + 1 + k], g[p:p + 1]
+            ref = g[p - pad:p] + ref_al + g[p + len(ref_al):p + len(ref_al) + pad]
+            alt = g[p - pad:p] + alt_al + g[p + len(ref_al):p + len(ref_al) + pad]
+            haps.append((ref, alt))
+            rl = []
+            for _k in range(reads):
+                ln = int(rng.choice([91, 98, 124, 150, 151]))
+                allele_alt = rng.random() < 0.5
+                # the "chromosome" this molecule came from: with the ALT allele spliced in, or not
+                chrom = g[:p] + (alt_al if allele_alt else ref_al) + g[p + len(ref_al):]
+                vpos = p
+                shape = rng.random()
+                if shape < 0.35:                                    # plain
+                    s = vpos - int(rng.integers(0, ln))
+                    rd = bytearray(chrom[s:s + ln])
+                elif shape < 0.6:                                   # soft clip / adapter at the 3' end: random tail (111M13S and the like)
+                    clip = int(rng.integers(4, 60))
+                    s = vpos - int(rng.integers(0, ln - clip))
+                    rd = bytearray(chrom[s:s + ln - clip]) + bytearray(rng.choice(acgt, clip).tolist())
+                elif shape < 0.75:                                  # soft clip at the 5' end (template-switch oligo)
+                    clip = int(rng.integers(4, 40))
+                    s = vpos - int(rng.integers(0, ln - clip))
+                    rd = bytearray(rng.choice(acgt, clip).tolist()) + bytearray(chrom[s:s + ln - clip])
+                elif shape < 0.9:                                   # spliced: the read skips an intron right or left of the variant
+                    intron = int(rng.integers(60, 2000))
+                    a = int(rng.integers(20, ln - 20))              # bases before the junction
+                    if rng.random() < 0.5:                          # variant in the first exon
+                        s = vpos - int(rng.integers(0, a))
+                        rd = bytearray(chrom[s:s + a]) + bytearray(chrom[s + a + intron:s + a + intron + ln - a])
+                    else:                                           # variant in the second exon
+                        s2 = vpos - int(rng.integers(0, ln - a))
+                        rd = bytearray(chrom[max(s2 - intron - a, 0):max(s2 - intron - a, 0) + a]) + bytearray(chrom[s2:s2 + ln - a])
+                else:                                               # poly-A tail + N bases
+                    tail = int(rng.integers(5, 50))
+                    s = vpos - int(rng.integers(0, ln - tail))
+                    rd = bytearray(chrom[s:s + ln - tail]) + bytearray(b"A" * tail)
+                    for e in rng.integers(0, len(rd), 2):
+                        rd[int(e)] = ord("N")
+                for e in np.nonzero(rng.random(len(rd)) < 0.006)[0]:
+                    rd[e] = b"ACGT"[int(rng.integers(0, 4))]
+                rl.append((int(rng.integers(0, 30)), int(rng.integers(0, 5)), bytes(rd)))
+            rds.append(rl)
+        yield ("real-read shapes (clips, adapters, splices, poly-A, N), trial %d" % trial, manual_batch(haps, rds, 30), 30)

@@ -1,0 +1,100 @@
+"""CPU unit test of the per-task logic of band_diag_kernel (vartrix_amd/csrc/vtx_fast_core.h) — the SAME source the device
+kernel is compiled from, built for the host by tests/fastcore/Makefile — against the oracle.
+
+band_diag_kernel may score a task only when its certificate equals its upper bound, and must leave every other task to
+band_run_kernel.  So for every task: either the host build declines (score -1, with a reason), or its score IS the oracle's
+banded score (bio 0.30 banded::Aligner::local as restated, reference call site src/main.rs:898-901).  The device runs the same
+checks through the C-ABI in tests/test_gpu_*.py; this file is where the logic meets adversarial shapes without a GPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from vartrix_amd import synth
+from vartrix_amd.abi import VtxBatch, default_config
+
+import stress_batches as SB
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+WHY = ["ok", "shape", "no-diagonal", "pieces", "matches", "not-harmless", "-", "generic", "not-tight", "no-main"]
+
+
+@pytest.fixture(scope="module")
+def core():
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "fastcore"), "-s"])
+    L = C.CDLL(os.path.join(HERE, "fastcore", "libfastcore_host.so"))
+    L.vtxt_fastcore_batch.argtypes = [C.POINTER(VtxBatch), C.c_uint32, C.c_void_p, C.c_void_p]
+    L.vtxt_fastcore_batch.restype = C.c_int
+    return L
+
+
+def run_core(L, batch, n_heads=1024):
+    st = batch.as_struct()
+    sc = np.zeros(2 * batch.n_records, np.int32)
+    why = np.zeros(2 * batch.n_records, np.uint32)
+    assert L.vtxt_fastcore_batch(C.byref(st), n_heads, sc.ctypes.data, why.ctypes.data) == 0
+    return sc, why
+
+
+def check(L, batch, n_barcodes, label, n_heads=1024):
+    sc, why = run_core(L, batch, n_heads)
+    r, a = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=n_barcodes), threads=8)
+    want = np.empty(2 * batch.n_records, np.int32)
+    want[0::2], want[1::2] = r, a
+    decided = sc >= 0
+    bad = np.nonzero(decided & (sc != want))[0]
+    assert bad.size == 0, "%s: task %d scored %d, oracle %d" % (label, bad[0], sc[bad[0]], want[bad[0]])
+    assert np.all((why == 0) == decided)
+    return float(decided.mean()), {WHY[k]: int(v) for k, v in zip(*np.unique(why, return_counts=True))}
+
+
+def test_config3_shape_is_decided_and_exact(core):
+    spec = synth.SynthSpec(n_loci=300, n_barcodes=500, reads_per_locus=64)
+    frac, why = check(core, synth.make_batch(spec), 500, "config-3 shape")
+    assert frac > 0.95, why          # the point of the stage: nearly every task of the headline workload ends here
+
+
+@pytest.mark.parametrize("n_heads", [256, 1024])
+def test_error_models_and_indels(core, n_heads):
+    tot = 0
+    for label, batch, nb in SB.synthetic_batches(per_model=1):
+        frac, why = check(core, batch, nb, label, n_heads)
+        tot += 2 * batch.n_records
+    assert tot > 80000
+
+
+def test_repeat_rich_and_small_alphabets(core):
+    """Hundreds of k-mer matches per alignment, ties everywhere: nearly everything must be declined, nothing may be wrong."""
+    for label, batch, nb in SB.repeat_rich_batches(trials=8):
+        check(core, batch, nb, label)
+
+
+def test_real_read_shapes(core):
+    """Soft clips, adapter tails, spliced reads, poly-A, N bases (tests/stress_batches.py)."""
+    fr = []
+    for label, batch, nb in SB.real_shape_batches(trials=3):
+        frac, why = check(core, batch, nb, label)
+        fr.append(frac)
+    print("decided on real-read shapes: %s" % ", ".join("%.3f" % f for f in fr))
+
+
+def test_edge_shapes(core):
+    """Reads at the capacity edge (192 bases), beyond it, shorter than a k-mer; haplotypes shorter than the read; lower-case and
+    N bytes; identical haplotypes; a read that is a pure repeat."""
+    rng = np.random.default_rng(5)
+    g = bytes(rng.choice(list(b"ACGT"), 3000).tolist())
+    haps = [(g[100:301], g[100:200] + b"T" + g[201:301]), (g[500:520], g[500:510] + g[512:520]),
+            (g[800:1001], g[800:900] + b"n" + g[901:1001]), (b"AC" * 100, b"AC" * 50 + b"G" + b"AC" * 50),
+            (g[1500:1900], g[1500:1700] + b"ACGTACGTAC" + g[1700:1900])]
+    reads = [
+        [(0, 0, g[80:272]), (1, 0, g[60:253]), (2, 0, g[150:155]), (3, 0, g[150:156]), (4, 0, g[100:292]), (5, 0, b"")],
+        [(0, 0, g[480:560]), (1, 0, g[500:520]), (2, 0, g[505:511])],
+        [(0, 0, g[820:970]), (1, 0, g[820:900] + b"n" + g[901:970]), (2, 0, g[820:900] + b"N" + g[901:970])],
+        [(0, 0, b"AC" * 75), (1, 0, b"CA" * 60), (2, 0, b"AC" * 40 + b"G" + b"AC" * 30)],
+        [(0, 0, g[1600:1750]), (1, 0, g[1620:1700] + b"ACGTACGTAC" + g[1700:1760]), (2, 0, g[1400:1550])],
+    ]
+    check(core, SB.manual_batch(haps, reads, 8), 8, "edge shapes")

@@ -1,0 +1,107 @@
+"""GPU parity on the distributions that clean synthetic reads do not cover ("real reads on the device: 15"):
+
+  * every read of the reference's test/test.bam that reaches the aligner when the barcode list is ignored (576 real,
+    soft-clipped minimap2 reads; the fixtures of src/main.rs:1208-1390 score 15 of them),
+  * the stress distributions of tools/certify_stress.py / tools/gpu_parity_stress.py, size-capped,
+  * real-read shapes: soft clips, adapter tails, spliced reads, poly-A, N (tests/stress_batches.py),
+
+both aligner flavours, every alignment against the oracle, through the C-ABI.  The banded runs also report how many
+alignments each stage of the banded flavour decided (band_diag_kernel / band_run_kernel / band-masked DP).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from vartrix_amd import lib
+from vartrix_amd.abi import default_config
+
+import stress_batches as SB
+from test_band_variants import _all_reads_batch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def device_vs_oracle(batch, nb, label, aligners=("banded", "full"), mode="coverage"):
+    stats = {}
+    for aligner in aligners:
+        cfg = default_config(aligner=aligner, scoring_mode=mode, n_barcodes=nb)
+        with lib.Context(cfg) as ctx:
+            ctx.submit(batch)
+            ctx.run()
+            r, a = ctx.fetch_scores()
+            t = ctx.timing()
+        oref, oalt = oracle.batch_scores(batch, cfg, threads=os.cpu_count() or 8)
+        bad = np.nonzero((r != oref) | (a != oalt))[0]
+        assert bad.size == 0, "%s, %s: record %d device (%d, %d) oracle (%d, %d)" % (
+            label, aligner, bad[0], r[bad[0]], a[bad[0]], oref[bad[0]], oalt[bad[0]])
+        if aligner == "banded":
+            n = 2 * batch.n_records
+            stats = {"alignments": n, "left_by_diag_stage": int(t.diag_left), "hard": int(t.hard_tasks), "overflow": int(t.overflow_tasks)}
+    return stats
+
+
+def test_all_real_reads_of_test_bam():
+    batch, metrics, n_cb = _all_reads_batch()
+    assert batch.n_records > 400
+    st = device_vs_oracle(batch, n_cb, "test.bam, every barcode accepted")
+    print("test.bam real reads: %d alignments, %d left by band_diag_kernel (%.1f %%), %d needed the band-masked DP (%.2f %%), %d general kernel"
+          % (st["alignments"], st["left_by_diag_stage"], 100.0 * st["left_by_diag_stage"] / st["alignments"], st["hard"],
+             100.0 * st["hard"] / st["alignments"], st["overflow"]))
+    # the hard-task fraction on REAL reads (DESIGN §4.3 quotes it): an upper bound that catches a regression of the certificate
+    assert st["hard"] <= 0.10 * st["alignments"]
+
+
+def test_error_models_and_indels():
+    tot = 0
+    for label, batch, nb in SB.synthetic_batches(per_model=1):
+        st = device_vs_oracle(batch, nb, label)
+        tot += st["alignments"]
+    assert tot > 80000
+
+
+def test_repeat_rich():
+    for label, batch, nb in SB.repeat_rich_batches(trials=4):
+        device_vs_oracle(batch, nb, label)
+
+
+def test_real_read_shapes():
+    rows = []
+    for label, batch, nb in SB.real_shape_batches(trials=3):
+        st = device_vs_oracle(batch, nb, label)
+        rows.append(st)
+    n = sum(s["alignments"] for s in rows)
+    print("real-read shapes: %d alignments, %.1f %% left by band_diag_kernel, %.2f %% band-masked DP" % (
+        n, 100.0 * sum(s["left_by_diag_stage"] for s in rows) / n, 100.0 * sum(s["hard"] for s in rows) / n))
+
+
+def test_single_diagonal_stage_on_and_off_give_the_same_scores():
+    """VTX_BAND_NO_DIAG=1 runs the banded flavour without band_diag_kernel (band_run_kernel takes every task, the round-2 path):
+    identical scores (separate process: the hook is read from the environment)."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import stress_batches as SB
+from vartrix_amd import lib
+from vartrix_amd.abi import default_config
+out = []
+for label, batch, nb in list(SB.synthetic_batches(per_model=1))[:3] + list(SB.real_shape_batches(trials=1)):
+    with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb)) as ctx:
+        ctx.submit(batch); ctx.run(); r, a = ctx.fetch_scores(); t = ctx.timing()
+    out.append(np.concatenate([r, a])); print(label, int(t.diag_left), file=sys.stderr)
+np.save(sys.argv[1], np.concatenate(out))
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        res = []
+        for env_extra in ({}, {"VTX_BAND_NO_DIAG": "1"}):
+            path = os.path.join(td, "s%d.npy" % len(res))
+            r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=900,
+                               env=dict(os.environ, **env_extra))
+            assert r.returncode == 0, r.stderr[-3000:]
+            res.append(np.load(path))
+        assert np.array_equal(res[0], res[1])

@@ -19,17 +19,7 @@ from vartrix_amd import synth  # noqa: E402
 from vartrix_amd.abi import default_config  # noqa: E402
 
 
-def synthetic_batches():
-    """(label, batch, n_barcodes) over a range of error models"""
-    seed = 1000
-    for (sub, indel, jitter, rl, pad) in [(0.005, 0, 0, 150, 100), (0.02, 0.3, 40, 150, 100), (0.05, 0.5, 60, 120, 60),
-                                          (0.1, 0.2, 30, 100, 150), (0.15, 0.6, 50, 80, 40), (0.01, 0.8, 70, 150, 200),
-                                          (0.3, 0.1, 0, 150, 100)]:
-        for _ in range(3):
-            seed += 1
-            spec = synth.SynthSpec(n_loci=150, n_barcodes=500, reads_per_locus=48, indel_frac=indel, sub_error=sub,
-                                   read_len_jitter=jitter, read_len=rl, padding=pad, seed=seed)
-            yield ("sub %.3f indel %.1f jitter %d len %d pad %d" % (sub, indel, jitter, rl, pad), synth.make_batch(spec), 500)
+from stress_batches import repeat_rich_batches, synthetic_batches  # noqa: E402,F401  (tests/stress_batches.py)
 
 
 def synthetic():
@@ -50,43 +40,6 @@ def synthetic():
             print("sub %.3f indel %.1f jitter %d len %d pad %d: %d tasks, %d violations, cert == ub %.3f"
                   % (sub, indel, jitter, rl, pad, len(r["full"]), v, float((r["cert"] == r["ub"]).mean())), flush=True)
     return tot, bad
-
-
-def repeat_rich_batches():
-    """(label, batch, n_barcodes): tandem-repeat genomes over 2- to 4-letter alphabets"""
-    rng = np.random.default_rng(2024)
-    for trial in range(12):
-        alpha = [b"ACGT", b"AC", b"AT", b"ACG"][trial % 4]
-        units = [b"A", b"AC", b"AAT", b"ACGT", b"AAAAC", b"AG", b"T", b"CAG", b"ACACAT", b"GATTACA"]
-        g = bytearray()
-        while len(g) < 40000:
-            g += units[int(rng.integers(0, len(units)))] * int(rng.integers(2, 40))
-            g += bytes(rng.choice(list(alpha), int(rng.integers(0, 30))).tolist())
-        g = bytes(g)
-        haps, reads = [], []
-        for _ in range(60):
-            p = int(rng.integers(300, len(g) - 500))
-            pad = int(rng.integers(30, 160))
-            ref = g[p - pad:p + pad + 1]
-            kind = rng.random()
-            if kind < 0.5:
-                alt = ref[:pad] + bytes([b"ACGT"[(b"ACGT".index(ref[pad:pad + 1]) + 1) % 4]]) + ref[pad + 1:]
-            elif kind < 0.75:
-                alt = ref[:pad + 1] + bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 21))).tolist()) + ref[pad + 1:]
-            else:
-                alt = ref[:pad + 1] + ref[pad + 1 + int(rng.integers(1, min(20, pad - 1))):]
-            haps.append((ref, alt))
-            rl = []
-            for _k in range(24):
-                ln = int(rng.integers(40, 200))
-                s = max(p - int(rng.integers(0, ln)), 0)
-                rd = bytearray(g[s:s + ln])
-                for e in np.nonzero(rng.random(len(rd)) < rng.choice([0.0, 0.02, 0.08]))[0]:
-                    rd[e] = b"ACGT"[int(rng.integers(0, 4))]
-                if len(rd) >= 10:
-                    rl.append((int(rng.integers(0, 30)), 0, bytes(rd)))
-            reads.append(rl)
-        yield ("repeat-rich, alphabet %s" % alpha.decode(), TP._manual_batch(haps, reads, 30), 30)
 
 
 def repeat_rich():
