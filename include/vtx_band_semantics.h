@@ -20,8 +20,26 @@
 #define VTX_BAND_SEMANTICS_H
 
 #define VTX_BAND_EXT_TO_EDGE 0x7fffffff
+/* (every constant may be overridden on the compiler command line: `make -C vartrix_amd/csrc variants` builds
+ * libvtx_lazy0.so with -D'VTX_BAND_LAZY_EXT(k)=0', and tests/test_gpu_variants.py checks that the device then follows the
+ * oracle run with the same override — a maintainer correcting one of these edits this header and nothing else) */
+#ifndef VTX_BAND_LAZY_EXT
 #define VTX_BAND_LAZY_EXT(k) (2 * (k))
+#endif
+#ifndef VTX_BAND_KMER_LAST_ANCHOR
 #define VTX_BAND_KMER_LAST_ANCHOR(k) (k)
+#endif
+#ifndef VTX_BAND_NO_SEED_FULL_MATRIX
 #define VTX_BAND_NO_SEED_FULL_MATRIX 1
+#endif
+
+/* The scoring the kernels, the certificate's proof (oracle/vtx_certify.c) and ub_join_same are derived for: the reference's
+ * constants src/main.rs:33-38.  vtx_create rejects any other configuration; the device code static_asserts these values. */
+#define VTX_REF_K 6
+#define VTX_REF_W 20
+#define VTX_REF_MATCH 1
+#define VTX_REF_MISMATCH (-5)
+#define VTX_REF_GAP_OPEN (-5)
+#define VTX_REF_GAP_EXTEND (-1)
 
 #endif

@@ -129,8 +129,20 @@ int64_t vtxo_find_kmer_matches(const uint8_t* x, int m, const uint8_t* y, int n,
 /* resolved by tuple comparison (score, match index).  Result: the highest        */
 /* scoring chain as match indices.                                             */
 /* ------------------------------------------------------------------------- */
+/* Test hooks (tests/test_band_variants.py, tools/band_semantics_table.py): the recollected details of the un-vendored crate,
+ * switchable one at a time, so that the exposure of every one of them can be measured.  Process globals: single-threaded use.
+ *   VTXO_VAR_LAZY_EXT     Band::set_boundaries' lazy extension (default VTX_BAND_LAZY_EXT(k); any value >= 0)
+ *   VTXO_VAR_LAST_ANCHOR  add_kmer's last anchor offset (default VTX_BAND_KMER_LAST_ANCHOR(k) = k; alternative k - 1)
+ *   VTXO_VAR_NO_SEED      1: no k-mer match = whole matrix (default); 0: empty band (score 0)
+ *   VTXO_VAR_TIE          sdpkpp ties: 1 = the larger match index wins (default, tuple comparison); 0 = the smaller
+ * (The `x > 0 && y > 0` guard of the LCSk++ continuation is not a variant: without it the lookup of (x - 1, y - 1) wraps and
+ * finds nothing, the same result.)                                                                                          */
+static int g_var[4] = {-1, -1, -1, -1};
+void vtxo_set_variant(int which, int value) { if (which >= 0 && which < 4) g_var[which] = value; }
+static inline int var_tie_larger(void) { return g_var[3] != 0; }
+
 typedef struct { int64_t v; int64_t idx; } bit_ent;
-static inline int ent_gt(bit_ent a, bit_ent b) { return a.v > b.v || (a.v == b.v && a.idx > b.idx); }
+static inline int ent_gt(bit_ent a, bit_ent b) { return a.v > b.v || (a.v == b.v && (var_tie_larger() ? a.idx > b.idx : (b.idx < 0 || (a.idx >= 0 && a.idx < b.idx)))); }
 
 typedef struct { uint32_t x, y, id; } sdp_event;
 static int ev_cmp(const void* a, const void* b) {
@@ -187,16 +199,16 @@ int64_t vtxo_sdpkpp(const uint32_t* mt, int64_t M, int k, int match_score,
                 /* stored value = dp[q] - gap_extend*(xe+ye); gap d = (x+y)-(xe+ye) */
                 int64_t cand = bq.v + (int64_t)gap_open
                              + (int64_t)gap_extend * ((int64_t)ev[e].x + (int64_t)ev[e].y) + kscore;
-                if (cand > dps[p] || (cand == dps[p] && bq.idx > dpp[p])) { dps[p] = cand; dpp[p] = bq.idx; }
+                if (cand > dps[p] || (cand == dps[p] && (var_tie_larger() ? bq.idx > dpp[p] : dpp[p] < 0))) { dps[p] = cand; dpp[p] = bq.idx; }
             }
         } else {
             /* does this k-mer continue the diagonal of the match one step back? */
             const uint32_t x = ev[e].x - (uint32_t)k, y = ev[e].y - (uint32_t)k;
-            if (x > 0 && y > 0) {
+            if (x > 0 && y > 0) {   /* (the guard only avoids an unsigned wrap: without it (x - 1, y - 1) would never be found either) */
                 int64_t c = match_find(mt, M, x - 1, y - 1);
                 if (c >= 0) {
                     int64_t cand = dps[c] + match_score;
-                    if (cand > dps[p] || (cand == dps[p] && c > dpp[p])) { dps[p] = cand; dpp[p] = c; }
+                    if (cand > dps[p] || (cand == dps[p] && (var_tie_larger() ? c > dpp[p] : (dpp[p] < 0 || c < dpp[p])))) { dps[p] = cand; dpp[p] = c; }
                 }
             }
             bit_ent me = {dps[p] - (int64_t)gap_extend * ((int64_t)ev[e].x + (int64_t)ev[e].y), p};
@@ -236,12 +248,13 @@ static void band_add_entry(band_t* b, int r, int c) {
     }
 }
 static void band_add_kmer(band_t* b, int r, int c, int k) {
-    for (int d = 0; d <= VTX_BAND_KMER_LAST_ANCHOR(k); ++d) band_add_entry(b, r + d, c + d);
+    const int last = g_var[1] >= 0 ? g_var[1] : VTX_BAND_KMER_LAST_ANCHOR(k);
+    for (int d = 0; d <= last; ++d) band_add_entry(b, r + d, c + d);
 }
 
 /* Test hook: override of VTX_BAND_LAZY_EXT for the sensitivity tests (tests/test_band_variants.py); < 0 = the constant. */
-static int g_lazy_override = -1;
-void vtxo_set_lazy_extension(int ext) { g_lazy_override = ext; }
+#define g_lazy_override (g_var[0])
+void vtxo_set_lazy_extension(int ext) { g_var[0] = ext; }
 static void band_add_gap(band_t* b, int r0, int c0, int r1, int c1) {
     const int dr = r1 - r0, dc = c1 - c0;
     const int diag = imin(dr, dc);
@@ -257,8 +270,8 @@ int64_t vtxo_band_create(const uint8_t* x, int m, const uint8_t* y, int n,
     uint32_t* mt = NULL;
     int64_t M = vtxo_find_kmer_matches(x, m, y, n, k, &mt);
     if (M == 0) {
-        /* VTX_BAND_NO_SEED_FULL_MATRIX */
-        for (int j = 0; j <= n; ++j) { lo[j] = 0; hi[j] = m + 1; }
+        /* VTX_BAND_NO_SEED_FULL_MATRIX (g_var[2] == 0: the alternative — an empty band) */
+        if (g_var[2] >= 0 ? g_var[2] : VTX_BAND_NO_SEED_FULL_MATRIX) for (int j = 0; j <= n; ++j) { lo[j] = 0; hi[j] = m + 1; }
     } else {
         int64_t* path = (int64_t*)slab(5, sizeof(int64_t) * (size_t)M);
         int64_t L = vtxo_sdpkpp(mt, M, k, 1 /* match_fn.score(b'A', b'A') */, -5, -1, path, NULL);
@@ -275,7 +288,8 @@ int64_t vtxo_band_create(const uint8_t* x, int m, const uint8_t* y, int n,
         for (int64_t t = 0; t < L; ++t) {
             const int cx = (int)mt[2 * path[t]], cy = (int)mt[2 * path[t] + 1];
             if (t > 0 && cx == px + 1 && cy == py + 1) {
-                band_add_entry(&b, cx + k, cy + k);
+                const int last = g_var[1] >= 0 ? g_var[1] : VTX_BAND_KMER_LAST_ANCHOR(k);
+                band_add_entry(&b, cx + last, cy + last);
             } else {
                 if (t > 0) band_add_gap(&b, px + k, py + k, cx, cy);
                 band_add_kmer(&b, cx, cy, k);

@@ -73,6 +73,8 @@ int64_t vtxo_band_create(const uint8_t* x, int m, const uint8_t* y, int n,
 /* Test hook: lazy-extension length of set_boundaries for the NEXT band constructions (any value >= 0;
  * VTX_BAND_EXT_TO_EDGE = to the matrix corner); negative restores the constant of include/vtx_band_semantics.h.   */
 void vtxo_set_lazy_extension(int ext);
+/* Test hook: one of the recollected details of the crate (see vtx_oracle.c: VTXO_VAR_*), value < 0 restores the default.    */
+void vtxo_set_variant(int which, int value);
 
 /* banded::Aligner::local(x, y).score */
 int32_t vtxo_sw_banded(const uint8_t* x, int m, const uint8_t* y, int n,

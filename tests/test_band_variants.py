@@ -73,3 +73,31 @@ def test_default_variant_is_the_named_constant():
     a = _scores(batch, cfg, -1)
     b = _scores(batch, cfg, 12)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_every_recollected_detail_is_switchable_and_bounded():
+    """tools/band_semantics_table.py at reduced size: every recollected detail of the crate (lazy extension, add_kmer's last
+    anchor, no-seed band, sdpkpp tie direction) switched one at a time in the oracle.  The full-size table is
+    profiles/r03_band_semantics_sensitivity.json; here: the hooks work, restore, and nothing but the lazy
+    extension moves more than a handful of alignments."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import band_semantics_table as T
+    rows = T.table(T.workloads(small=True))
+    by = {}
+    for r in rows:
+        by.setdefault(r["workload"], {})[r["variant"]] = r
+    for wl, v in by.items():
+        assert v["default (the recollection)"]["alignments_changed_vs_default"] == 0
+        n = v["default (the recollection)"]["alignments"]
+        assert v["lazy extension to the matrix edge"]["alignments_ne_full_matrix"] == 0       # band out to the corners == full SW here
+        for name in ("add_kmer anchors 0..k-1 instead of 0..k", "no k-mer match: empty band instead of the whole matrix",
+                     "sdpkpp ties to the smaller match index"):
+            assert v[name]["alignments_changed_vs_default"] <= max(2, n // 2000), (wl, name, v[name])
+        assert v["lazy extension 0 instead of 2k"]["alignments_changed_vs_default"] <= max(6, n // 200)
+    # the hooks restore: a default run afterwards equals the first
+    batch, _, n_cb = _all_reads_batch()
+    cfg = default_config(aligner="banded", n_barcodes=n_cb)
+    a = oracle.batch_scores(batch, cfg, threads=1)
+    b = _scores(batch, cfg, -1)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "vtx_device.h"
+#include "../../include/vtx_band_semantics.h"
 
 extern "C" hipError_t vtxk_inclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, void* temp,
                                               size_t temp_bytes, hipStream_t s) {
@@ -509,10 +510,11 @@ int vtx_create(const vtx_config* cfg, vtx_ctx** out) {
     if (cfg->scoring_mode < VTX_MODE_CONSENSUS || cfg->scoring_mode > VTX_MODE_COVERAGE)
         return fail(nullptr, VTX_E_INVAL, "vtx_create: unknown scoring_mode %d", cfg->scoring_mode);
     // The kernels bake the reference's scoring constants (src/main.rs:33-38) in as immediates.
-    if (cfg->match_score != 1 || cfg->mismatch_score != -5 || cfg->gap_open != -5 || cfg->gap_extend != -1)
+    if (cfg->match_score != VTX_REF_MATCH || cfg->mismatch_score != VTX_REF_MISMATCH || cfg->gap_open != VTX_REF_GAP_OPEN ||
+        cfg->gap_extend != VTX_REF_GAP_EXTEND)
         return fail(nullptr, VTX_E_UNSUPPORTED,
                     "vtx_create: only the reference scoring (+1/-5, gap -5/-1; src/main.rs:35-38) is built");
-    if (cfg->kmer_k != 6 || cfg->band_w != 20)
+    if (cfg->kmer_k != VTX_REF_K || cfg->band_w != VTX_REF_W)
         return fail(nullptr, VTX_E_UNSUPPORTED, "vtx_create: only K=6, W=20 (src/main.rs:33-34) is built");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);

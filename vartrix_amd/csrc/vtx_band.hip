@@ -50,6 +50,11 @@
 
 #define KMER 6
 #define BANDW 20
+// The certificate (run_ub / ub_join_same: "a mismatch costs 5 + 1", "short runs <= K - 1 = 5", "a gap of length L costs 5 + L",
+// "two gaps cost >= 10 + 3 G - D") and the closed-form sdpkpp (k-mer = K matches, gap_open + d * gap_extend) are DERIVED for the
+// reference's constants; vtx_create refuses any other configuration (vtx_api.hip), and this ties the two together:
+static_assert(KMER == VTX_REF_K && BANDW == VTX_REF_W && VTX_REF_MATCH == 1 && VTX_REF_MISMATCH == -5 && VTX_REF_GAP_OPEN == -5 &&
+              VTX_REF_GAP_EXTEND == -1, "vtx_band.hip's bounds are proved for K = 6, W = 20, +1 / -5, gap -5 / -1 (src/main.rs:33-38) only");
 #define HASH_BITS 9
 #define HASH_SIZE (1 << HASH_BITS)
 // band slot markers (lo[0]): a staircase polyline follows / the whole matrix is in band

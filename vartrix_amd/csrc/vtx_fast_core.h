@@ -71,8 +71,10 @@
 
 namespace vtxf {
 
-constexpr int K = 6;
-constexpr int W = 20;
+constexpr int K = VTX_REF_K;
+constexpr int W = VTX_REF_W;
+static_assert(K == 6 && W == 20 && VTX_REF_MATCH == 1 && VTX_REF_MISMATCH == -5 && VTX_REF_GAP_OPEN == -5 && VTX_REF_GAP_EXTEND == -1,
+              "the closed forms below (piece dp, join_same, the far-piece lemma, the +1 / -5 scan) are derived for the reference's scoring only");
 constexpr int LAZY = VTX_BAND_LAZY_EXT(6);
 constexpr int MAX_READ = 192;   // mask capacity
 constexpr int RM = 6;           // main-diagonal pieces

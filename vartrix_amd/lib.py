@@ -15,7 +15,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvtx.so")
+# VTX_LIB_VARIANT=lazy0 loads a build variant of the SAME sources (tests/test_gpu_variants.py); never set in production
+LIB_PATH = os.path.join(_HERE, "libvtx%s.so" % ("_" + os.environ["VTX_LIB_VARIANT"] if os.environ.get("VTX_LIB_VARIANT") else ""))
 
 SYMBOLS = (
     "vtx_config_default", "vtx_create", "vtx_destroy", "vtx_submit", "vtx_run", "vtx_fetch_scores",
