@@ -46,7 +46,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_TOPS = 39.3          # packed 16-bit VALU ops issue at 4 cycles / wave64 on gfx950: 256 CU x 4 SIMD x 16
                                # lanes/clk x 2.4 GHz (measured 38.7, profiles/r01_valu_peak_microbench.txt)
 OPS_PER_CELL_PAIR = 9          # packed VALU ops per DP cell pair of the LUT / duo DP kernels
-KERNEL_SOURCES = ("vartrix_amd/csrc/vtx_band.hip", "vartrix_amd/csrc/vtx_kernels.hip", "vartrix_amd/csrc/vtx_api.hip")
+KERNEL_SOURCES = ("vartrix_amd/csrc/vtx_band.hip", "vartrix_amd/csrc/vtx_kernels.hip", "vartrix_amd/csrc/vtx_api.hip",
+                  "vartrix_amd/csrc/vtx_fast_core.h")
+SIMDS = 256 * 4                # per chip
+NOMINAL_GHZ = 2.4
 
 
 def kernel_source_hash() -> str:
@@ -317,8 +320,15 @@ def main():
         launches = ctx.timing().sw_launches
         alg_bytes = algorithmic_bytes(batch)                 # of rank 0's launch
         banded = args.aligner == "banded"
-        dom_name = "band_run_kernel" if banded else "sw_full_duo_kernel"
-        dom_ms = run_avg_ms if banded else full_avg_ms
+        diag_avg_ms = float(np.mean(diag_ms))
+        # dominant kernel of the step: band_diag_kernel when the single-diagonal stage ran (its time includes band_tables_kernel,
+        # ~0.8 ms of it), band_run_kernel otherwise (VTX_BAND_NO_DIAG / tables that do not fit), the DP kernel for the full flavour
+        if banded and diag_avg_ms > 0:
+            dom_name, dom_label, dom_ms = "band_diag_kernel", "band_diag_kernel (+ band_tables_kernel: 2 launches per step)", diag_avg_ms
+        elif banded:
+            dom_name, dom_label, dom_ms = "band_run_kernel", "band_run_kernel (1 launch per step)", run_avg_ms
+        else:
+            dom_name, dom_label, dom_ms = "sw_full_duo_kernel", "sw_full_duo_kernel (1 launch per step)", full_avg_ms
         traffic, pmc_extra = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -328,14 +338,17 @@ def main():
                 # counters are quoted only for this exact code (source stamp) and this exact workload
                 if e and j.get("source_hash") == kernel_source_hash() and e.get("workload_records") == batch.n_records:
                     traffic = e.get("hbm_bytes_per_launch")
+                    if traffic is not None and dom_name == "band_diag_kernel" and j.get("band_tables_kernel", {}).get("hbm_bytes_per_launch"):
+                        traffic += j["band_tables_kernel"]["hbm_bytes_per_launch"]
                     pmc_extra = {k: e[k] for k in e if k not in ("hbm_bytes_per_launch", "workload_records")}
+                    pmc_extra["from"] = j.get("from")
             except Exception:
                 traffic, pmc_extra = None, None
         out = {
             "metric": "read-alignments/sec at 100k loci x 10k cells; bit-exact .mtx vs ref",
             "value": value, "unit": "read-alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
-            "dtype": "i16x2 / i32 (packed int16 DP cells, int32 chain and score arithmetic)", "data": "synthetic",
+            "dtype": "i32 (diagonal masks, chain and score arithmetic; packed i16 DP cells for the residue)", "data": "synthetic",
             "config": {"workload": spec.name + ", %s mode, %s aligner" % (args.mode, args.aligner),
                        "baseline_config": {"config3": "configs[2]", "config4": "configs[3]"}.get(workload, "custom"),
                        "loci": n_loci * (world if weak else 1), "barcodes": n_barcodes,
@@ -346,32 +359,57 @@ def main():
                                     "gathered to rank 0 over RCCL") if world > 1 else "single GPU"},
             "result": summary,
             # dominant kernel; its duration is a hipEvent pair around its launch(es) on the context's stream, live in this run
-            "roofline": {"bound": "hbm", "kernel": dom_name + " (1 launch per step)", "kernel_ms": dom_ms,
+            "roofline": {"bound": "hbm", "kernel": dom_label, "kernel_ms": dom_ms,
                          "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dom_ms > 0 else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "pmc": pmc_extra,
+                         "traffic_method": "L2 -> fabric bytes of the dominant kernel's launch(es): 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024, separate "
+                                           "rocprofv3 --pmc passes; the x2 is calibrated for this kernel's 8-byte scattered loads "
+                                           "(profiles/r03_fetch_calibration.json: every request is a 128-byte line tallied at 64)",
                          "whole_sw_stage": {"kernels": ("sw_full_duo_kernel" if not banded else
-                                                        "band_run_kernel + band_kernel + band_expand_kernel + sw_banded_kernel")
+                                                        "band_tables + band_diag + band_run + band_pending + band_kernel + band_expand + sw_banded kernels")
                                             + " (%d launches)" % launches, "ms": sw_avg_ms,
                                             "achieved": alg_bytes / (sw_avg_ms * 1e-3) / 1e9},
-                         "note": "integer seed / chain / DP work: neither HBM nor MFMA binds it (86 B per alignment); the HBM "
-                                 "fraction is reported because north_star asks for it, see roofline_valu"},
+                         "note": "integer mask / chain / bound work: neither HBM nor MFMA binds it (86 B per alignment); the HBM "
+                                 "fraction is reported because north_star asks for it, the binding resource is VALU issue: roofline_valu_issue"},
             "timing": {"sw_kernel_ms": sw_avg_ms, "full_kernel_ms": full_avg_ms, "band_kernels_ms": float(np.mean(band_ms)),
-                       "band_run_kernel_ms": run_avg_ms, "band_diag_ms": float(np.mean(diag_ms)),
+                       "band_run_kernel_ms": run_avg_ms - diag_avg_ms, "band_diag_ms": diag_avg_ms,
                        "diag_left_tasks": int(ctx.timing().diag_left), "reduce_ms": float(np.mean(red_ms)), "submit_h2d_s": t_sub,
                        "generate_s": t_gen, "hard_tasks": int(ctx.timing().hard_tasks),
                        "overflow_tasks": int(ctx.timing().overflow_tasks),
                        "pcie_inclusive_alignments_per_s": n_aln / (t_sub + elapsed / args.steps)},
         }
         if pmc_extra and pmc_extra.get("valu_instructions_per_launch") and dom_ms > 0:
-            # issue rate of the dominant kernel: VALU wave-instructions counted by the PMC pass (same code, same workload)
-            # over this run's live kernel time; 64 lanes per instruction against the 39.3 T lane-ops/s issue roof
+            # VALU pipe occupancy of the dominant kernel.  VALU wave-instructions come from the PMC pass (same code, same workload);
+            # what ONE instruction occupies the pipe for is not 4 cycles across the board on gfx950 (SIMD-32: 32-bit add / and / or /
+            # xor / mov / right shift issue over 2 cycles, v_max / v_min / v_cndmask / 3-operand / left shift / multiply over 4 —
+            # profiles/r03_valu_peak_microbench.txt), so the instruction count is weighted with the kernel's STATIC opcode mix
+            # (tools/isa_mix.py; the dynamic mix is not observable: SQ_ACTIVE_INST_VALU equals the instruction count on this
+            # part).  Both bounds ride along: every instruction at 2 cycles / at 4 cycles.
             vi = pmc_extra["valu_instructions_per_launch"]
-            out["roofline_valu_issue"] = {"bound": "valu", "kernel": dom_name, "kernel_ms": dom_ms,
-                                          "valu_wave_instructions_per_launch": vi,
-                                          "achieved": vi * 64 / (dom_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS,
-                                          "unit": "T lane-ops/s issued", "frac": vi * 64 / (dom_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
-                                          "note": "every VALU instruction counted as one 4-cycle issue slot of a wave64"}
+            cpi = pmc_extra.get("cycles_per_valu_instruction_static_mix")
+            ghz = NOMINAL_GHZ
+            if pmc_extra.get("grbm_gui_active_per_launch") and pmc_extra.get("kernel_ms_in_profiled_runs"):
+                ghz = pmc_extra["grbm_gui_active_per_launch"] / 8 / (pmc_extra["kernel_ms_in_profiled_runs"] * 1e-3) / 1e9   # one count per XCD
+            kernel_cycles = dom_ms * 1e-3 * ghz * 1e9
+
+            def occ(c):
+                return vi * c / (SIMDS * kernel_cycles)
+            out["roofline_valu_issue"] = {
+                "bound": "valu", "kernel": dom_name, "kernel_ms": dom_ms, "valu_wave_instructions_per_launch": vi,
+                "salu_instructions_per_launch": pmc_extra.get("salu_instructions_per_launch"),
+                "valu_active_lanes_mean_of_64": pmc_extra.get("valu_active_lanes_mean"),
+                "effective_clock_ghz": ghz, "cycles_per_valu_instruction_static_mix": cpi,
+                "achieved": vi * 64 / (dom_ms * 1e-3) / 1e12, "unit": "T lane-slots/s issued (64 per wave-instruction, active or not)",
+                "frac": occ(cpi) if cpi else None, "frac_if_every_instruction_issued_over_2_cycles": occ(2.0),
+                "frac_if_every_instruction_issued_over_4_cycles": occ(4.0),
+                "wait_inst_any_share_of_wave_cycles": (pmc_extra["wait_inst_any_cycles"] / pmc_extra["wave_cycles_quad_per_launch"]
+                                                       if pmc_extra.get("wait_inst_any_cycles") and pmc_extra.get("wave_cycles_quad_per_launch") else None),
+                "wait_any_share_of_wave_cycles": (pmc_extra["wait_any_cycles"] / pmc_extra["wave_cycles_quad_per_launch"]
+                                                  if pmc_extra.get("wait_any_cycles") and pmc_extra.get("wave_cycles_quad_per_launch") else None),
+                "note": "frac = VALU wave-instructions (PMC) x issue cycles per instruction (static opcode mix x measured per-opcode cycles) / "
+                        "(1024 SIMDs x kernel cycles at the effective clock of the profiled run); a fraction of the time the VALU pipes are "
+                        "occupied, lanes masked off by divergence included (valu_active_lanes_mean_of_64)"}
         if not banded:
             lane_ops = cells / 2 * OPS_PER_CELL_PAIR
             out["roofline_valu"] = {"bound": "valu", "kernel": "sw_full_duo_kernel", "kernel_ms": full_avg_ms,
@@ -402,16 +440,15 @@ def main():
                 per_aln = band_cells_sample(batch, cfg)
                 if per_aln:
                     eq_ops = per_aln * n_aln * OPS_PER_CELL_PAIR / 2
-                    out["roofline_valu"] = {
-                        "bound": "valu", "kernel": "whole alignment stage (band_run_kernel + masked DP of the residue)",
+                    out["work_avoided_equivalent"] = {
+                        "what": "NOT a roofline: the DP work of the reference's own algorithm, divided by the time of the stage that replaces it",
                         "in_band_cells_per_alignment": per_aln, "sampled_on": "first 32 loci (oracle.batch_cells)",
                         "equivalent_packed_ops_per_step": eq_ops, "stage_ms": sw_avg_ms,
-                        "achieved": eq_ops / (sw_avg_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS, "unit": "T packed-lane-ops/s (equivalent)",
-                        "frac": eq_ops / (sw_avg_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                        "equivalent_rate": eq_ops / (sw_avg_ms * 1e-3) / 1e12, "unit": "T packed-lane-ops/s (equivalent)",
+                        "ratio_to_packed_valu_peak": eq_ops / (sw_avg_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
                         "note": "EQUIVALENT rate: the in-band cells of bio's banded DP x 4.5 packed ops, divided by the time of the stage "
                                 "that replaces it.  The certificate decides %.1f %% of the alignments without evaluating any DP cell, "
-                                "so this is a work-avoided figure, not an issue rate; the issue rate of the kernels is in roofline.pmc "
-                                "when the PMC file matches this code" % (100.0 * (1.0 - ctx.timing().hard_tasks / max(n_aln, 1)))}
+                                "so this may exceed 1; the issue occupancy of the kernels is roofline_valu_issue" % (100.0 * (1.0 - ctx.timing().hard_tasks / max(n_aln, 1)))}
         line = json.dumps(out)
     else:
         line = None

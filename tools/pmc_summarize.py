@@ -29,13 +29,24 @@ def main():
             kern[k][row["Counter_Name"]] += float(row["Counter_Value"])
             launches[(k, row["Counter_Name"])].add(row["Dispatch_Id"])
     out = {}
+    # kernel durations of the passes (kernel trace of the same runs): the effective clock = GRBM_GUI_ACTIVE / duration
+    dur = collections.defaultdict(list)
+    for path in glob.glob(os.path.join(src, "pass*", "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            dur[short(row["Kernel_Name"])].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6)
     for k, c in kern.items():
-        if not any(s in k for s in ("sw_", "band_", "prep_")):
+        if not any(s in k for s in ("sw_", "band_", "prep_", "calib_")):
             continue
         d = {n: v for n, v in sorted(c.items())}
         d["launches"] = max(len(v) for (kk, _), v in launches.items() if kk == k)
         if "FETCH_SIZE" in c:
+            # tools/fetch_calib.hip (profiles/r03_fetch_calibration.json): every TCC_EA0_RDREQ is a 128-byte line, for 16-, 8-byte
+            # and sector-strided loads alike, and FETCH_SIZE tallies it at 64 bytes -> x 2 for every access shape measured
             d["hbm_bytes"] = int(2 * c["FETCH_SIZE"] * 1024 + c.get("WRITE_SIZE", 0) * 1024)
+        if "TCC_EA0_RDREQ_sum" in c:
+            d["read_bytes_from_rdreq"] = int(c["TCC_EA0_RDREQ_sum"] * 128)
+        if dur.get(k):
+            d["kernel_ms_in_profiled_runs"] = sum(dur[k]) / len(dur[k])
         out[k] = d
     doc = {"method": "rocprofv3 --pmc <group> --kernel-trace, one counter group per run (tools/pmc_collect.sh), MI355X; "
                      "bench.py --steps 1 --warmup 0 (one vtx_run)",
@@ -47,7 +58,8 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import hashlib
     h = hashlib.sha256()
-    for rel in ("vartrix_amd/csrc/vtx_band.hip", "vartrix_amd/csrc/vtx_kernels.hip", "vartrix_amd/csrc/vtx_api.hip"):
+    for rel in ("vartrix_amd/csrc/vtx_band.hip", "vartrix_amd/csrc/vtx_kernels.hip", "vartrix_amd/csrc/vtx_api.hip",
+                "vartrix_amd/csrc/vtx_fast_core.h"):
         h.update(open(os.path.join(root, rel), "rb").read())
     digest = {"source_hash": h.hexdigest()[:16], "from": os.path.basename(dst),
               "method": "rocprofv3 --pmc, one counter group per pass (FETCH_SIZE and WRITE_SIZE in separate passes; read bytes = "
@@ -69,12 +81,36 @@ def main():
         if "SQ_WAIT_ANY" in d:
             e["wait_any_cycles"] = d["SQ_WAIT_ANY"] / n
             e["wait_inst_any_cycles"] = d.get("SQ_WAIT_INST_ANY", 0) / n
+        for cn, key in (("SQ_INSTS_SALU", "salu_instructions_per_launch"), ("SQ_THREAD_CYCLES_VALU", "valu_thread_cycles_per_launch"),
+                        ("SQ_ACTIVE_INST_VALU", "active_inst_valu_quad_cycles_per_launch"), ("SQ_ACTIVE_INST_ANY", "active_inst_any_quad_cycles_per_launch"),
+                        ("SQ_WAVES", "waves_per_launch"), ("GRBM_GUI_ACTIVE", "grbm_gui_active_per_launch"),
+                        ("SQ_BUSY_CYCLES", "sq_busy_cycles_per_launch"), ("TCC_EA0_RDREQ_sum", "tcc_ea0_rdreq_per_launch")):
+            if cn in d:
+                e[key] = d[cn] / n
+        if "kernel_ms_in_profiled_runs" in d:
+            e["kernel_ms_in_profiled_runs"] = d["kernel_ms_in_profiled_runs"]
+        if "SQ_THREAD_CYCLES_VALU" in d and d.get("SQ_ACTIVE_INST_VALU"):
+            e["valu_active_lanes_mean"] = round(d["SQ_THREAD_CYCLES_VALU"] / d["SQ_ACTIVE_INST_VALU"], 2)
         # several template variants of one kernel (band_run_kernel: the first pass and the small second-chance pass): the
         # digest quotes the one that issues the most instructions, with its variant named
         base = re.sub(r"<.*", "", k)
         e["variant"] = k
         if base not in digest or e.get("valu_instructions_per_launch", 0) > digest[base].get("valu_instructions_per_launch", 0):
             digest[base] = e
+    # VALU issue cycles per instruction of the band kernels: static opcode mix x measured per-opcode cycles (tools/isa_mix.py)
+    try:
+        import subprocess
+        asm = "/tmp/vtx_band_pmc.s"
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+                               "-o", asm, os.path.join(root, "vartrix_amd/csrc/vtx_band.hip")], stderr=subprocess.DEVNULL)
+        for base, sym in (("band_diag_kernel", "band_diag_kernel"), ("band_run_kernel", "band_run_kernelILi64ELb1ELi5ELi15"),
+                          ("band_tables_kernel", "band_tables_kernel")):
+            if base in digest:
+                mix = json.loads(subprocess.check_output([sys.executable, os.path.join(root, "tools", "isa_mix.py"), asm, sym]))
+                digest[base]["cycles_per_valu_instruction_static_mix"] = mix["cycles_per_valu_instruction_static_mix"]
+                digest[base]["static_mix_share_measured"] = mix["share_of_instructions_with_measured_cycles"]
+    except Exception as ex:      # no hipcc here: the digest simply lacks the mix
+        print("isa_mix skipped:", ex)
     if len(sys.argv) > 4:
         json.dump(digest, open(sys.argv[4], "w"), indent=1)
     for k, d in sorted(out.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0)):

@@ -20,7 +20,7 @@
                          ASM(%5) "\n" ASM(%6) "\n" ASM(%7)                                   \
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5),       \
                            "+v"(a6), "+v"(a7)                                                \
-                         : "v"(b), "v"(c));                                                 \
+                         : "v"(b), "v"(c) : "vcc", "s20", "s21");                                 \
         }                                                                                  \
         out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;       \
     }
@@ -122,6 +122,44 @@ KERNEL(k_max3f16, OP_MAX3F16)
 KERNEL(k_subi16c, OP_SUBREVC)
 KERNEL(k_min3u16, OP_MIN3U16)
 KERNEL(k_pkmaxu16, OP_PKMAXU16)
+#define OP_X_LSHL(x) "v_lshlrev_b32 " #x ", 1, " #x
+#define OP_X_LSHR(x) "v_lshrrev_b32 " #x ", 1, " #x
+#define OP_X_OR(x) "v_or_b32 " #x ", " #x ", %8"
+#define OP_X_NOT(x) "v_not_b32 " #x ", " #x
+#define OP_X_FFBL(x) "v_ffbl_b32 " #x ", " #x
+#define OP_X_BFE(x) "v_bfe_u32 " #x ", " #x ", 3, 8"
+#define OP_X_ALIGNBIT(x) "v_alignbit_b32 " #x ", " #x ", %8, 7"
+#define OP_X_MULLO(x) "v_mul_lo_u32 " #x ", " #x ", %8"
+#define OP_X_MUL24(x) "v_mul_u32_u24 " #x ", " #x ", %8"
+#define OP_X_MAD24(x) "v_mad_u32_u24 " #x ", " #x ", %8, %9"
+#define OP_X_OR3(x) "v_or3_b32 " #x ", " #x ", %8, %9"
+#define OP_X_LSHLOR(x) "v_lshl_or_b32 " #x ", " #x ", 3, %8"
+#define OP_X_BCNT(x) "v_bcnt_u32_b32 " #x ", " #x ", %8"
+#define OP_X_MINI32(x) "v_min_i32 " #x ", " #x ", %8"
+#define OP_X_MINU32(x) "v_min_u32 " #x ", " #x ", %8"
+#define OP_X_CMPCND(x) "v_cmp_lt_u32 vcc, " #x ", %8\n v_cndmask_b32 " #x ", " #x ", %9, vcc"
+#define OP_X_CMPE64(x) "v_cmp_eq_u32 s[20:21], " #x ", %8\n v_cndmask_b32 " #x ", " #x ", %9, s[20:21]"
+#define OP_X_SDWAADD(x) "v_add_u32_sdwa " #x ", " #x ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+#define OP_X_XAD(x) "v_xad_u32 " #x ", " #x ", %8, %9"
+KERNEL(k_x_lshl, OP_X_LSHL)
+KERNEL(k_x_lshr, OP_X_LSHR)
+KERNEL(k_x_or, OP_X_OR)
+KERNEL(k_x_not, OP_X_NOT)
+KERNEL(k_x_ffbl, OP_X_FFBL)
+KERNEL(k_x_bfe, OP_X_BFE)
+KERNEL(k_x_alignbit, OP_X_ALIGNBIT)
+KERNEL(k_x_mullo, OP_X_MULLO)
+KERNEL(k_x_mul24, OP_X_MUL24)
+KERNEL(k_x_mad24, OP_X_MAD24)
+KERNEL(k_x_or3, OP_X_OR3)
+KERNEL(k_x_lshlor, OP_X_LSHLOR)
+KERNEL(k_x_bcnt, OP_X_BCNT)
+KERNEL(k_x_mini32, OP_X_MINI32)
+KERNEL(k_x_minu32, OP_X_MINU32)
+KERNEL(k_x_cmpcnd, OP_X_CMPCND)
+KERNEL(k_x_cmpe64, OP_X_CMPE64)
+KERNEL(k_x_sdwaadd, OP_X_SDWAADD)
+KERNEL(k_x_xad, OP_X_XAD)
 typedef void (*kern_t)(uint32_t*, uint32_t);
 
 int main() {
@@ -137,7 +175,7 @@ int main() {
         {"v_pk_min_u16", k_pkmin}, {"v_pk_mad_i16", k_pkmad}, {"v_xor_b32", k_xor}, {"v_max_i32", k_maxi32},
         {"v_add_u32", k_addu32}, {"v_max3_i32", k_max3}, {"v_mov_b32_dpp row_shr:1", k_dpp}, {"v_fma_f32", k_fma},
         {"v_max_i32_dpp", k_maxdpp}, {"v_perm_b32", k_perm}, {"v_bfi_b32", k_bfi}, {"v_cndmask_b32", k_cnd},
-        {"v_sad_u8", k_sad}, {"v_max_u16", k_maxu16}, {"v_max3_f32", k_max3f}, {"v_max_f32", k_maxf}, {"v_add_f32", k_addf}, {"v_med3_f32", k_med3f}, {"v_max3_i16", k_max3i16}, {"v_max3_u16", k_max3u16}, {"v_max_i16", k_maxi16}, {"v_sub_u16", k_subu16}, {"v_sub_u16 clamp", k_subu16c}, {"v_add_u16", k_addu16}, {"v_min_u16", k_minu16}, {"v_mad_u16", k_madu16}, {"v_mad_i16", k_madi16}, {"v_add_u16_sdwa", k_addu16s}, {"v_max_u32", k_maxu32}, {"v_sub_u32", k_subu32}, {"v_add3_u32", k_add3}, {"v_and_b32", k_and}, {"v_and_or_b32", k_andor}, {"v_mov_b32", k_mov}, {"v_lshl_add_u32", k_lshladd}, {"v_max_f16", k_maxf16}, {"v_pk_max_f16", k_pkmaxf16}, {"v_pk_add_f16", k_pkaddf16}, {"v_pk_fma_f16", k_pkfmaf16}, {"v_max3_f16", k_max3f16}, {"v_sub_i16 clamp", k_subi16c}, {"v_min3_u16", k_min3u16}, {"v_pk_max_u16", k_pkmaxu16}};
+        {"v_sad_u8", k_sad}, {"v_max_u16", k_maxu16}, {"v_max3_f32", k_max3f}, {"v_max_f32", k_maxf}, {"v_add_f32", k_addf}, {"v_med3_f32", k_med3f}, {"v_max3_i16", k_max3i16}, {"v_max3_u16", k_max3u16}, {"v_max_i16", k_maxi16}, {"v_sub_u16", k_subu16}, {"v_sub_u16 clamp", k_subu16c}, {"v_add_u16", k_addu16}, {"v_min_u16", k_minu16}, {"v_mad_u16", k_madu16}, {"v_mad_i16", k_madi16}, {"v_add_u16_sdwa", k_addu16s}, {"v_max_u32", k_maxu32}, {"v_sub_u32", k_subu32}, {"v_add3_u32", k_add3}, {"v_and_b32", k_and}, {"v_and_or_b32", k_andor}, {"v_mov_b32", k_mov}, {"v_lshl_add_u32", k_lshladd}, {"v_max_f16", k_maxf16}, {"v_pk_max_f16", k_pkmaxf16}, {"v_pk_add_f16", k_pkaddf16}, {"v_pk_fma_f16", k_pkfmaf16}, {"v_max3_f16", k_max3f16}, {"v_sub_i16 clamp", k_subi16c}, {"v_min3_u16", k_min3u16}, {"v_pk_max_u16", k_pkmaxu16}, {"v_lshlrev_b32", k_x_lshl}, {"v_lshrrev_b32", k_x_lshr}, {"v_or_b32", k_x_or}, {"v_not_b32", k_x_not}, {"v_ffbl_b32", k_x_ffbl}, {"v_bfe_u32", k_x_bfe}, {"v_alignbit_b32", k_x_alignbit}, {"v_mul_lo_u32", k_x_mullo}, {"v_mul_u32_u24", k_x_mul24}, {"v_mad_u32_u24", k_x_mad24}, {"v_or3_b32", k_x_or3}, {"v_lshl_or_b32", k_x_lshlor}, {"v_bcnt_u32_b32", k_x_bcnt}, {"v_min_i32", k_x_mini32}, {"v_min_u32", k_x_minu32}, {"v_cmp_lt_u32 + v_cndmask_b32 (pair)", k_x_cmpcnd}, {"v_cmp_eq_u32_e64 + v_cndmask_b32_e64 (pair, SGPR mask)", k_x_cmpe64}, {"v_add_u32_sdwa", k_x_sdwaadd}, {"v_xad_u32", k_x_xad}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (auto& kk : ks) {

@@ -105,7 +105,7 @@ struct vtx_ctx {
     DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
     bool band_long_lists = false;      // (performance feedback between runs: see vtx_run)
-    DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail;   // banded flavour
+    DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail, d_fail_tmp;   // banded flavour
     DevBuf d_redo, d_redo_cnt;                                               // LUT kernel: records with non-ACGTN bytes
     // raw batches (vtx_submit_raw): barcode table + preparation scratch
     DevBuf d_bc_slots, d_bc_hash, d_bc_off, d_bc_bytes;
@@ -554,7 +554,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_cnt, &c->d_redo, &c->d_redo_cnt, &c->d_bc_slots, &c->d_bc_hash, &c->d_bc_off, &c->d_bc_bytes,
                       &c->d_raw, &c->d_tags, &c->d_raw_locus, &c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2,
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
-                      &c->d_prep_cnt, &c->d_sort_tmp};
+                      &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp};
     for (DevBuf* b : bufs) b->release();
     c->d_slow_ws.release(); c->d_slow_retry.release();
     DevBuf* gb[] = {&c->d_g_cnt, &c->d_g_row, &c->d_g_col, &c->d_g_alt, &c->d_g_ref, &c->d_g_unk, &c->d_g_val, &c->d_g_refval};
@@ -628,7 +628,7 @@ static int band_reserve(vtx_ctx* c, BandPlan& p, bool quiet) {
     RES(d_hard, ((size_t)p.hard_cap + p.pend_cap) * sizeof(uint32_t));
     RES(d_over, 2 * (size_t)p.n_tasks * sizeof(uint32_t));      // second chance: what overflows again is appended behind the first list
     RES(d_cnt, 64 * sizeof(uint32_t));
-    if (p.gt_bytes) RES(d_fail, (size_t)p.chunk * sizeof(uint32_t));      // tasks band_diag_kernel leaves to band_run_kernel
+    if (p.gt_bytes) RES(d_fail, 2 * (size_t)p.chunk * sizeof(uint32_t));  // tasks band_diag_kernel leaves to band_run_kernel (as listed, then sorted)
 #undef RES
     return VTX_OK;
 }
@@ -1100,6 +1100,7 @@ int vtx_run(vtx_ctx* c) {
             static const int diag_stats = getenv("VTX_DEBUG") ? 1 : 0;
             bool diag = false;
             uint32_t n_fail = 0;
+            const uint32_t* fail_list = c->d_fail.as<uint32_t>();
             if (gt_n && !no_diag) {
                 HIP_TRY(c, hipMemsetAsync(d_cnt + 12, 0, sizeof(uint32_t), s));
                 const hipError_t e = vtxk_launch_band_diag(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
@@ -1115,6 +1116,16 @@ int vtx_run(vtx_ctx* c) {
                     n_fail = c->h_pin[8];
                     diag_total += nt; diag_left += n_fail;
                     ++launches;
+                    if (n_fail > 64) {
+                        // the list comes out in the order the wavefronts finished: eight XCD ranges interleaved.  Sorted by task, the
+                        // 64 tasks of a band_run_kernel wavefront share their loci's tables and reads again (12.7 -> GB of L2 misses
+                        // for 2 % of the tasks otherwise)
+                        const size_t tb = vtxk_sort_keys_u32_temp_bytes(n_fail);
+                        if (c->d_fail_tmp.reserve(tb) == hipSuccess) {
+                            HIP_TRY(c, vtxk_sort_keys_u32(c->d_fail.as<uint32_t>(), c->d_fail.as<uint32_t>() + nt, n_fail, c->d_fail_tmp.p, tb, s));
+                            fail_list = c->d_fail.as<uint32_t>() + nt;
+                        } else (void)hipGetLastError();
+                    }
                 } else {
                     (void)hipGetLastError();
                 }
@@ -1127,7 +1138,7 @@ int vtx_run(vtx_ctx* c) {
                                                  c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
                                                  c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt,
                                                  tasks_per_locus, gt_l0, gt_n, gt_n ? c->d_gtables.as<uint8_t>() : nullptr, gt_bytes,
-                                                 diag ? c->d_fail.as<uint32_t>() : nullptr, c->band_long_lists ? 1 : 0, s));
+                                                 diag ? fail_list : nullptr, c->band_long_lists ? 1 : 0, s));
             HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
             // (task-list mode runs the 15-entry variant: nothing to give a second chance to)

@@ -115,6 +115,8 @@ hipError_t vtxk_prep_set_shapes(const uint32_t* caps, uint32_t n, uint32_t fast_
 size_t vtxk_prep_sort_temp_bytes(uint32_t n);
 hipError_t vtxk_prep_sort_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                               uint32_t n, int end_bit, void* temp, size_t temp_bytes, hipStream_t s);
+size_t vtxk_sort_keys_u32_temp_bytes(uint32_t n);
+hipError_t vtxk_sort_keys_u32(const uint32_t* keys_in, uint32_t* keys_out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t vtxk_prep_sort_u8(const uint8_t* keys_in, uint8_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                              uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t vtxk_prep_rec_locus(const vtx_locus* loci, uint32_t n_loci, uint32_t* rec_locus, hipStream_t s);

@@ -267,6 +267,17 @@ hipError_t vtxk_prep_sort_u64(const uint64_t* keys_in, uint64_t* keys_out, const
     return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit, s);
 }
 
+size_t vtxk_sort_keys_u32_temp_bytes(uint32_t n) {
+    size_t a = 0;
+    hipcub::DeviceRadixSort::SortKeys(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)std::max(n, 1u));
+    return a;
+}
+
+hipError_t vtxk_sort_keys_u32(const uint32_t* keys_in, uint32_t* keys_out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s) {
+    if (!n) return hipSuccess;
+    return hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys_in, keys_out, (int)n, 0, 32, s);
+}
+
 hipError_t vtxk_prep_sort_u8(const uint8_t* keys_in, uint8_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                              uint32_t n, void* temp, size_t temp_bytes, hipStream_t s) {
     if (!n) return hipSuccess;
