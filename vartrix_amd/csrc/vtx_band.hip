@@ -1550,13 +1550,38 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             live = true;
         }
     }
+    if ((stats >> 8) == 4) { if (live && m == 0x7fffffff) counters[40] = 1; return; }           // (profiling aid) task set-up only
+    // ---- the read, once: lanes 2i / 2i + 1 hold the two haplotypes of ONE record, so each loads half of its 8-byte words (16-byte
+    //      loads) and the two swap halves — a quarter of the load instructions and of the L2 lines 8-byte loads per lane cost ----
+    vtxf::ReadWords rw;
+    {
+        static_assert(vtxf::RW == 24, "12 words per lane of a pair");
+        const int half = tid & 1;
+        uint64_t mine[12];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {                                  // words [12 half + 2k, + 2): bytes [96 half + 16 k, + 16)
+            const int off = 96 * half + 16 * k;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (live && off < m) __builtin_memcpy(&v, x + off, 16);    // (the arena is padded by 16 bytes)
+            mine[2 * k] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+            mine[2 * k + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mine[k], 1), hi = (uint32_t)__shfl_xor((int)(uint32_t)(mine[k] >> 32), 1);
+            const uint64_t theirs = (uint64_t)lo | ((uint64_t)hi << 32);
+            rw.w[k] = half ? theirs : mine[k];
+            rw.w[12 + k] = half ? mine[k] : theirs;
+        }
+    }
     // ---- the main diagonal.  Lanes 2i / 2i + 1 hold the two haplotypes of one record: each looks ONE sample row up in its own
     //      table per round and the two exchange their candidates (a candidate is only ever a candidate: the lane keeps it if
     //      ITS mask has >= 20 matching bases) ----
     {
+        // rounds of candidate search (cheap: a bucket lookup and an 8-base check each), THEN one mask per lane — a mask per
+        // candidate inside the rounds ran the expensive part up to six times per wavefront for a handful of lanes
         bool have_d = !live;
-        int d = 0, tried = vtxf::NO_DIAG;
-        vtxf::M192 M{0, 0, 0};
+        int d = 0;
 #pragma unroll 1
         for (int round = 0; round < 3; ++round) {
             if (!__any(!have_d)) break;
@@ -1565,13 +1590,17 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
 #pragma unroll 1
             for (int u = 0; u < 2; ++u) {
                 const int dc = u ? c_par : c_own;
-                if (have_d || dc == vtxf::NO_DIAG || dc == tried || dc < -(m - vtxf::K) || dc > n - vtxf::K) continue;
-                tried = dc;
-                const vtxf::M192 Mc = vtxf::diag_mask(x, m, tb, n, dc);
-                if (vtxf::m_pop(Mc) >= 20) { d = dc; M = Mc; have_d = true; }
+                if (have_d || dc == vtxf::NO_DIAG || dc < -(m - vtxf::K) || dc > n - vtxf::K) continue;
+                if (vtxf::verify_diag(x, m, tb, n, dc)) { d = dc; have_d = true; }
             }
         }
+        vtxf::M192 M{0, 0, 0};
+        if (live && have_d) {
+            M = vtxf::diag_mask(rw, m, tb, n, d);
+            if (vtxf::m_pop(M) < 20) have_d = false;
+        }
         if (live && !have_d) { live = false; fail = true; why = vtxf::W_NO_DIAG; }
+        if ((stats >> 8) == 3) { if (live && d == 0x7fffffff) counters[40] = 1; return; }       // (profiling aid) up to the diagonal and its mask
         if (live) {
             fr = vtxf::front_rest(x, m, tb, n, ln, d, M);
             if (fr.why != vtxf::W_OK) { live = false; fail = true; why = fr.why; }
@@ -1598,23 +1627,26 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         }
         wave_sync();
         const uint32_t total = q_count[0];
-        for (uint32_t i0 = 0; i0 < total; i0 += 128) {
-            // two queue entries per lane and trip: their loads go out together
-            uint32_t ent2[2], code[2], bits[2];
-            uint64_t w8[2];
-            bool on[2];
-            for (int u = 0; u < 2; ++u) {
+        constexpr int EPL = 4;                                        // queue entries per lane and trip: their loads go out together
+        for (uint32_t i0 = 0; i0 < total; i0 += 64 * EPL) {
+            uint32_t ent2[EPL], code[EPL], bits[EPL];
+            uint64_t w8[EPL];
+            bool on[EPL];
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
                 const uint32_t i = i0 + 64u * u + tid;
                 on[u] = i < total;
                 ent2[u] = q_ent[on[u] ? i : 0];
                 w8[u] = vtxf::ld8(read_arena + o_read[ent2[u] >> 8] + (ent2[u] & 0xffu));
             }
-            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
                 code[u] = vtxf::kw_code((uint32_t)w8[u], (uint32_t)(w8[u] >> 32) & 0xffffu);
                 bits[u] = *(const uint32_t*)(gtables + o_tab[ent2[u] >> 8] + pb_rel + 4u * (code[u] >> 5));
             }
             wave_sync();                                             // (every lane has read its entries: survivors may overwrite them)
-            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
                 const bool hit = on[u] && ((bits[u] >> (code[u] & 31u)) & 1u);
                 const uint64_t hm = __ballot(hit);
                 if (hm) {

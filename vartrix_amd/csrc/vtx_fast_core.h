@@ -63,7 +63,9 @@
 #define VTXF_FN __device__ __forceinline__
 #define VTXF_MEM __device__ __forceinline__
 #define VTXF_HD static __host__ __device__ inline
+#define VTXF_UNROLL _Pragma("unroll")
 #else
+#define VTXF_UNROLL
 #define VTXF_FN static inline
 #define VTXF_MEM inline
 #define VTXF_HD static inline
@@ -191,18 +193,47 @@ struct Front {
     M192 need;              // rows to probe
 };
 
+// The read as 8-byte words in registers (RW words cover MAX_READ bases): loaded once per task — by the device with 16-byte
+// loads split between the two haplotype lanes of a record (read_words_pair in vtx_band.hip), by the host plainly.
+constexpr int RW = MAX_READ / 8;
+struct ReadWords { uint64_t w[RW]; };
+VTXF_FN ReadWords read_words(const uint8_t* x, int m) {
+    ReadWords r;
+    for (int k = 0; k < RW; ++k) r.w[k] = 8 * k < m ? ld8(x + 8 * k) : 0ull;
+    return r;
+}
+
 // The match mask of diagonal d: bit i = (x[i] == y[i + d]), i in [max(0, -d), min(m, n - d)).
-VTXF_FN M192 diag_mask(const uint8_t* x, int m, const Tab& tb, int n, int d) {
-    uint64_t w0 = 0, w1 = 0, w2 = 0;
+// Eight 8-base words per mask word, their haplotype loads issued together (a loop of load - wait - compare steps is a chain of
+// 19 L2 round trips per task); words that do not overlap the haplotype load a clamped address and are masked.
+template <int C> VTXF_FN uint64_t diag_mask_word(const ReadWords& rw, const uint8_t* yb, int d, int wa, int wb) {
+    uint64_t h[8];
+VTXF_UNROLL
+    for (int k = 0; k < 8; ++k) {
+        const int w = 8 * C + k;
+        const int wc = w < wa ? wa : (w >= wb ? wb - 1 : w);      // (wa < wb: the caller checked)
+        h[k] = ld8(yb + (8 * wc + d));
+    }
+    uint64_t out = 0;
+VTXF_UNROLL
+    for (int k = 0; k < 8; ++k) {
+        const int w = 8 * C + k;
+        const uint64_t e = (uint64_t)eq8(rw.w[w], h[k]) << (8 * k);
+        out |= (w >= wa && w < wb) ? e : 0ull;
+    }
+    return out;
+}
+VTXF_FN M192 diag_mask(const ReadWords& rw, int m, const Tab& tb, int n, int d) {
     const uint8_t* yb = tb.gt + tb.bytes;
     // only the 8-base words that overlap the haplotype: the 8-byte loads stay within 7 bytes of bytes[0, n)
     const int wa = d < 0 ? (-d) >> 3 : 0;
     const int wb = imin((m + 7) >> 3, (n - d + 7) >> 3);
-    for (int w = wa; w < wb; ++w) {
-        const uint64_t e = (uint64_t)eq8(ld8(x + 8 * w), ld8(yb + (8 * w + d))) << (8 * (w & 7));
-        if (w < 8) w0 |= e; else if (w < 16) w1 |= e; else w2 |= e;
-    }
-    return m_and(M192{w0, w1, w2}, m_range(imax(0, -d), imin(m, n - d)));
+    if (wa >= wb) return M192{0, 0, 0};
+    M192 M;
+    M.w0 = diag_mask_word<0>(rw, yb, d, wa, wb);
+    M.w1 = wb > 8 ? diag_mask_word<1>(rw, yb, d, wa, wb) : 0ull;
+    M.w2 = wb > 16 ? diag_mask_word<2>(rw, yb, d, wa, wb) : 0ull;
+    return m_and(M, m_range(imax(0, -d), imin(m, n - d)));
 }
 
 // One bucket lookup for the k-mer in w8's low 6 bytes: f(y) for every position of the haplotype that holds it.
@@ -240,6 +271,14 @@ VTXF_FN int cand_diag(const uint8_t* x, int row, const Tab& tb) {
     if ((uint32_t)e != (uint32_t)w8 || ((uint32_t)(e >> 32) & 0xffffu) != ((uint32_t)(w8 >> 32) & 0xffffu)) return NO_DIAG;
     return (int)yc - row;
 }
+// cheap check of a candidate diagonal before its whole mask is computed: 8 bases in the middle of the overlap, at least 6 of
+// them equal (a chance k-mer match elsewhere in the haplotype passes with probability ~1e-3)
+VTXF_FN bool verify_diag(const uint8_t* x, int m, const Tab& tb, int n, int dc) {
+    const int vlo = imax(0, -dc), vhi = imin(m, n - dc);
+    if (vhi - vlo < 20) return false;                     // (the mask must hold >= 20 matching bases anyway)
+    const int p = vlo + ((vhi - vlo - 8) >> 1);
+    return __builtin_popcount(eq8(ld8(x + p), ld8(tb.gt + tb.bytes + (p + dc)))) >= 6;
+}
 VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const Lane& ln, int d, M192 M);
 
 // one lane on its own: the six sample rows in turn; a candidate is kept if its mask has at least 20 matching bases
@@ -248,11 +287,13 @@ VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, int n, const Lane& l
     fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.need = M192{0, 0, 0};
     if (m < K || n < K || m > MAX_READ) { fr.why = W_SHAPE; return fr; }
     int prev = NO_DIAG;
+    const ReadWords rw = read_words(x, m);
     for (int t = 0; t < 6; ++t) {
         const int dc = cand_diag(x, sample_row(t, m), tb);
         if (dc == NO_DIAG || dc == prev) continue;
         prev = dc;
-        const M192 Mc = diag_mask(x, m, tb, n, dc);
+        if (!verify_diag(x, m, tb, n, dc)) continue;
+        const M192 Mc = diag_mask(rw, m, tb, n, dc);
         if (m_pop(Mc) >= 20) return front_rest(x, m, tb, n, ln, dc, Mc);
     }
     fr.why = W_NO_DIAG;
@@ -465,6 +506,24 @@ VTXF_FN int32_t back(const Front& fr, int ns, const Lane& ln, const Lane& gl, ui
         // G lives in the top byte of every piece word
         for (int i = 0; i < n_all; ++i) word(i) &= 0x00ffffffu;
         bool changed = n_all > 1;
+        if (ng == 0) {
+            // main pieces only: all on one diagonal, in base order — a predecessor always lies before its successor, so one pass over
+            // the ordered pairs q < p settles every G (no back edges), and every join is a same-diagonal join
+            for (int p = 1; p < r; ++p) {
+                const uint32_t wp = ln.at(SM + p);
+                const int xp = (int)(wp & 0xffu);
+                int g = 0;
+                for (int q = 0; q < p; ++q) {
+                    const uint32_t wq = ln.at(SM + q);
+                    const int xq = (int)(wq & 0xffu), lq = (int)((wq >> 8) & 0xffu) - xq + 1, gq = (int)(wq >> 24);
+                    // entry at the first base of p (s = 0), q used whole (t = lq - 1): D bases between them
+                    const int D = xp - (xq + lq);
+                    g = imax(g, lq + gq - (D == 0 ? 0 : join_same(D)));
+                }
+                ln.at(SM + p) = (wp & 0x00ffffffu) | ((uint32_t)g << 24);
+            }
+            changed = false;
+        }
         for (int pass = 0; pass < 6 && changed; ++pass) {
             changed = false;
             for (int p = 0; p < n_all; ++p) {
