@@ -714,6 +714,13 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
     c->n_loci = nl; c->n_records = nr; c->max_hap_len = max_hap; c->max_read_len = (uint32_t)cnt[5]; c->cells = cnt[3];
     c->max_hap_all = max_hap_all; c->max_read_all = std::max<uint32_t>((uint32_t)cnt[7], std::max<uint32_t>((uint32_t)cnt[5], 1u));
     c->submitted = true;
+    // the banded stage's buffers (a few GB for a config-3 batch) now, not inside the first vtx_run of the context: a drop-in CLI
+    // calls vtx_run ONCE per batch, and 0.1 s of hipMalloc inside it was two thirds of that call.  Best effort: vtx_run reserves
+    // again (a no-op when this succeeded) and reports a failure there.
+    if (c->cfg.aligner == VTX_ALIGNER_BANDED && c->n_records) {
+        BandPlan bp = band_plan(c->n_records, c->n_loci, c->max_hap_len);
+        (void)band_reserve(c, bp, true);
+    }
     return VTX_OK;
 }
 
@@ -897,6 +904,13 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     c->n_loci = nl; c->n_records = n_kept; c->max_hap_len = max_hap; c->max_read_len = (uint32_t)cnt[5]; c->cells = cnt[3];
     c->max_hap_all = max_hap_all; c->max_read_all = std::max<uint32_t>((uint32_t)cnt[7], std::max<uint32_t>((uint32_t)cnt[5], 1u));
     c->submitted = true;
+    // the banded stage's buffers (a few GB for a config-3 batch) now, not inside the first vtx_run of the context: a drop-in CLI
+    // calls vtx_run ONCE per batch, and 0.1 s of hipMalloc inside it was two thirds of that call.  Best effort: vtx_run reserves
+    // again (a no-op when this succeeded) and reports a failure there.
+    if (c->cfg.aligner == VTX_ALIGNER_BANDED && c->n_records) {
+        BandPlan bp = band_plan(c->n_records, c->n_loci, c->max_hap_len);
+        (void)band_reserve(c, bp, true);
+    }
     if (stats) {
         stats->num_not_cell_bc = cnt[0]; stats->num_non_umi = cnt[1]; stats->kept = n_kept; stats->prep_ms = ms;
         stats->hash_rounds = rounds;

@@ -1708,8 +1708,9 @@ static uint32_t gt_max_tpl() {
 // buckets of a table's hash (power of two; experiment knob VTX_BAND_HEADS)
 static uint32_t pick_heads(uint32_t tasks_per_locus, bool global_tables) {
     if (getenv("VTX_BAND_HEADS")) return (uint32_t)atoi(getenv("VTX_BAND_HEADS"));
+    if (global_tables) return 1024;          // no LDS to fit: short chains, and band_diag_kernel's bucket tags want single-entry buckets
     if (tasks_per_locus < 48) return 256;
-    return global_tables ? 1024 : 512;       // no LDS to fit: shorter chains (2048: no further gain)
+    return 512;
 }
 
 // Global table buffer for this shape of data: bytes to reserve (0: tables live in LDS) and how many loci they hold.  The

@@ -79,7 +79,7 @@ static_assert(K == 6 && W == 20 && VTX_REF_MATCH == 1 && VTX_REF_MISMATCH == -5 
               "the closed forms below (piece dp, join_same, the far-piece lemma, the +1 / -5 scan) are derived for the reference's scoring only");
 constexpr int LAZY = VTX_BAND_LAZY_EXT(6);
 constexpr int MAX_READ = 192;   // mask capacity
-constexpr int RM = 6;           // main-diagonal pieces
+constexpr int RM = 8;           // main-diagonal pieces
 constexpr int SM = 20;          // off-diagonal k-mer matches
 constexpr int GM = 6;           // off-diagonal pieces admitted to the generic set
 constexpr int LANE_WORDS = SM + RM;   // per-lane scratch: off-diagonal matches, main pieces (+ GM words for back(): generic off-diagonal pieces)
