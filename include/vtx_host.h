@@ -71,6 +71,13 @@ void vtxh_get_raw_batch(const vtxh_pack* p, vtx_raw_batch* out);
 /* The barcode list in the layout vtx_set_barcodes takes (n = vtxh_num_barcodes). */
 void vtxh_get_barcode_table(const vtxh_pack* p, const uint8_t** bytes, const uint64_t** offsets, uint32_t* n);
 
+/* Streaming: the same ingest restricted to the VCF records (matrix rows) [row_begin, row_end).  Rows outside the range keep their
+ * place in the matrix (vtxh_num_variants, names) but bring no loci, no reads and no metrics; with a usable .bai only the stretches
+ * of the BAM that can hold reads of the range are inflated.  The packs of consecutive ranges add up to vtxh_pack_files of the whole
+ * input (same triplets in range order, metrics summed), so a host can hold ONE range in memory at a time — the reference itself
+ * holds one locus' reads at a time (src/main.rs:822-830) — and pack range k + 1 while the device works on range k.           */
+int vtxh_pack_files_range(const vtxh_args* args, int raw, uint32_t row_begin, uint32_t row_end, vtxh_pack** out);
+
 /* A pack holds one or more BATCHES: consecutive loci whose reads span less than 4 GiB of the arenas, so that the
  * 32-bit offsets of vtx.h hold relative to the batch (the reference has no such limit: it streams per locus).
  * Loci keep their global `row`; feed the batches to vtx_submit / vtx_submit_raw one after the other (or to different

@@ -157,13 +157,13 @@ def test_multi_batch_run_equals_single_batch(tmp_path, prep):
     for name, env in (("one", {}), ("many", {"VTXH_BATCH_BYTES": "12000"})):
         out = str(tmp_path / (name + ".mtx"))
         args = ["-v", vcfp, "-b", bam, "-f", fap, "-c", bcp, "-o", out, "-s", "alt_frac", "--umi", "--threads", "3", "--prep", prep,
-                "--log-level", "info", "--ref-matrix", str(tmp_path / (name + "_ref.mtx"))]
+                "--log-level", "info", "--ref-matrix", str(tmp_path / (name + "_ref.mtx")), "--stream-loci", "0"]
         r = subprocess.run([hostlib.CLI_PATH] + args, cwd=tmp_path, capture_output=True, text=True, timeout=300,
                            env=dict(os.environ, **env))
         assert r.returncode == 0, r.stdout + r.stderr
         log = r.stdout + r.stderr
         outs[name] = (open(out).read(), sorted(ln.split("] ", 1)[1] for ln in log.splitlines() if "Number of" in ln),
-                      int(log.split("pack: ")[1].split("(")[1].split(" batch")[0]))
+                      int(__import__("re").search(r"pack of range 0: [\d.]+ s \((\d+) batch", log).group(1)))
     assert outs["one"][2] == 1 and outs["many"][2] > 3
     assert outs["one"][0] == outs["many"][0] and outs["one"][1] == outs["many"][1]
 
@@ -178,3 +178,27 @@ def test_cli_row_gather_through_the_library(tmp_path):
                        timeout=300, env=dict(os.environ, VTX_CLI_FORCE_GATHER="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert open(out1).read() == open(out2).read() == open(os.path.join(G, "test_frac.mtx")).read()
+
+
+@pytest.mark.parametrize("prep", ["host", "device"])
+def test_streamed_ranges_give_the_same_files_and_counters(tmp_path, prep):
+    """--stream-loci: the VCF taken in ranges of 7 records (7 ranges for test_dna.vcf, packed by a producer thread while the
+    device works on the range before) writes byte-identical matrices and logs the same nine counters as the whole input at once
+    (--stream-loci 0) — the reference has no such knob because it streams per locus anyway (src/main.rs:822-830)."""
+    import re
+    from tests.test_host import make_dna_bam
+    bam = make_dna_bam(tmp_path, seed=5, n_reads=2500)
+    vcfp, fap, bcp = (os.path.join(G, n) for n in ("test_dna.vcf", "test_dna.fa", "dna_barcodes.tsv"))
+    outs = {}
+    for name, sl in (("whole", "0"), ("ranges", "7"), ("single", "1")):
+        out, ref, ov = (str(tmp_path / ("%s_%s" % (name, n))) for n in ("out.mtx", "ref.mtx", "vars.txt"))
+        r = run_cli(["-v", vcfp, "-b", bam, "-f", fap, "-c", bcp, "-o", out, "-s", "coverage", "--ref-matrix", ref, "--umi",
+                     "--threads", "4", "--prep", prep, "--log-level", "info", "--stream-loci", sl, "--out-variants", ov], tmp_path)
+        log = r.stdout + r.stderr
+        counters = re.findall(r"Number of [^:]+: (\d+)", log)
+        assert len(counters) == 9
+        outs[name] = (open(out).read(), open(ref).read(), open(ov).read(), counters)
+        n_ranges = len(re.findall(r"pack of range \d+", log))
+        assert n_ranges == {"whole": 1, "ranges": 7, "single": 46}[name]
+    assert outs["whole"] == outs["ranges"] == outs["single"]
+    assert len(outs["whole"][0]) > 500

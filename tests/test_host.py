@@ -306,6 +306,32 @@ def test_packer_splits_large_inputs_into_batches(tmp_path, monkeypatch, raw, umi
         hostlib.pack_files(use_umi=umi, raw=raw, all_batches=True, **inputs)
 
 
+@pytest.mark.parametrize("raw", [False, True])
+def test_packs_of_row_ranges_add_up_to_the_whole_pack(tmp_path, raw):
+    """Streaming (vtxh_pack_files_range): the packs of consecutive ranges of VCF records hold, together, exactly the loci,
+    records and reads of the whole pack, in order, and their metrics sum to its metrics — so a host can keep ONE range in
+    memory at a time (the reference holds one locus' reads at a time, src/main.rs:822-830).  Every range pack holds only
+    the reads of ITS loci: its size follows the range, not the BAM."""
+    bam = make_dna_bam(tmp_path, seed=11, n_reads=1500)
+    inputs = dict(vcf=os.path.join(G, "test_dna.vcf"), bam=bam, fasta=os.path.join(G, "test_dna.fa"),
+                  cell_barcodes=os.path.join(G, "dna_barcodes.tsv"))
+    whole, m, nv, bcs, names = hostlib.pack_files(use_umi=True, raw=raw, threads=2, all_batches=True, **inputs)
+    assert nv == 46 and len(whole) == 1
+    for cuts in ([0, 46], [0, 10, 20, 46], [0, 1, 2, 45, 46, 46], list(range(0, 47, 5)) + [46]):
+        parts, msum = [], None
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            b, mm, nv2, bcs2, names2 = hostlib.pack_files(use_umi=True, raw=raw, threads=2, all_batches=True, rows=(lo, hi), **inputs)
+            assert nv2 == nv and bcs2 == bcs and names2 == names          # the matrix keeps its shape in every range
+            assert all(lo <= r < hi for bb in b for r in bb.loci["row"])
+            parts += b
+            msum = dict(mm) if msum is None else {k: msum[k] + mm[k] for k in mm}
+        assert msum == m
+        assert _concat_batches(parts) == _concat_batches(whole)
+    # a range holds its own reads only
+    b, *_ = hostlib.pack_files(use_umi=True, raw=raw, threads=2, all_batches=True, rows=(0, 5), **inputs)
+    assert sum(bb.n_records for bb in b) < 0.5 * whole[0].n_records
+
+
 def test_index_guided_skipping_on_a_sparse_vcf(tmp_path, monkeypatch):
     """A few loci over a BAM that covers the whole contig: with the .bai the packer inflates only the stretches that can
     hold their reads (the reference does an indexed fetch per locus, src/main.rs:822-826) — and packs exactly what the

@@ -80,6 +80,7 @@ def author_fast(out_dir, V, R, B, Lr=150, seed=7, procs=32, chunk_loci=2000):
     hdr = b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\x00" + \
         struct.pack("<i", len(genome))
     n_reads = 0
+    all_starts = []
     with open(raw, "wb") as fh:
         fh.write(hdr)
         for a in range(0, V, chunk_loci):
@@ -131,6 +132,7 @@ def author_fast(out_dir, V, R, B, Lr=150, seed=7, procs=32, chunk_loci=2000):
             rec[:, o:o + 3] = np.frombuffer(b"UBZ", np.uint8)
             rec[:, o + 3:o + 13] = acgt[rng.integers(0, 4, (n, 10), dtype=np.uint8)]
             fh.write(rec.tobytes())
+            all_starts.append(start.astype(np.int64))
             n_reads += n
     size = os.path.getsize(raw)
     step = 60000 * 64
@@ -141,8 +143,25 @@ def author_fast(out_dir, V, R, B, Lr=150, seed=7, procs=32, chunk_loci=2000):
             fh.write(blob)
         fh.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))      # BGZF EOF block
     os.remove(raw)
+    # a real linear index (the packer's index-guided sweep and its streamed ranges jump with it; the bin index stays empty — only
+    # the linear part is read): ioffset[w] = virtual offset of the first record that overlaps the 16 kb window w
+    coffs = []                                               # compressed offset of every BGZF block (60 000 uncompressed bytes each)
+    with open(bam, "rb") as fh:
+        data = np.frombuffer(fh.read(), np.uint8)
+    o = 0
+    while o + 18 <= len(data):
+        coffs.append(o)
+        o += int(data[o + 16]) + (int(data[o + 17]) << 8) + 1
+    coffs = np.array(coffs, np.int64)
+    starts = np.concatenate(all_starts) if all_starts else np.zeros(0, np.int64)
+    assert np.all(starts[1:] >= starts[:-1])
+    u = len(hdr) + np.arange(len(starts), dtype=np.int64) * rec_len      # uncompressed stream offset of record k
+    voff = (coffs[u // 60000] << 16) | (u % 60000)
+    n_win = (len(genome) >> 14) + 1
+    first = np.searchsorted(starts + Lr, np.arange(n_win, dtype=np.int64) << 14, side="right")   # first record with end > window start
+    ioff = np.where(first < len(starts), voff[np.minimum(first, max(len(starts) - 1, 0))], 0).astype("<u8")
     with open(bam + ".bai", "wb") as fh:
-        fh.write(b"BAI\x01" + struct.pack("<i", 0))
+        fh.write(b"BAI\x01" + struct.pack("<i", 1) + struct.pack("<i", 0) + struct.pack("<i", n_win) + ioff.tobytes())
     return fa, os.path.join(out_dir, "v.vcf"), bam, os.path.join(out_dir, "bcs.tsv"), n_reads
 
 

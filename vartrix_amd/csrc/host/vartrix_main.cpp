@@ -68,6 +68,7 @@ const Opt kOpts[] = {
     {"primary-alignments", 0, true, nullptr}, {"no-duplicates", 0, true, nullptr}, {"umi", 0, true, nullptr},
     {"bam-tag", 0, false, "CB"}, {"valid-chars", 0, false, "ATGCatgc"},
     {"devices", 0, false, "1"}, {"aligner", 0, false, "banded"}, {"prep", 0, false, "host"},
+    {"stream-loci", 0, false, "32768"},
 };
 
 void usage() {
@@ -78,7 +79,9 @@ void usage() {
             "  --ref-matrix <FILE> [ref_matrix.mtx]   --log-level info|debug|error [error]   --threads <INT> [1]\n"
             "  --mapq <INT> [0]   --primary-alignments   --no-duplicates   --umi   --bam-tag <TAG> [CB]\n"
             "  --valid-chars <CHARS> [ATGCatgc]   --devices <INT> [1]   --aligner banded|full [banded]\n"
-            "  --prep host|device [host]  (device: barcode lookup, UMI grouping and the sort run on the GPU)\n");
+            "  --prep host|device [host]  (device: barcode lookup, UMI grouping and the sort run on the GPU)\n"
+            "  --stream-loci <INT> [32768]  VCF records per streamed range (ingest of range k + 1 overlaps the device work on range k;\n"
+            "                               host memory follows the range, not the BAM); 0 = the whole input at once\n");
 }
 
 // The shard threads of one batch meet here before each RCCL collective, carrying their status: if any shard has failed,
@@ -268,13 +271,60 @@ int main(int argc, char** argv) {
     std::vector<std::thread> warm;
     for (int d = 0; d < ndev; ++d) warm.emplace_back(warm_device, d);
     struct JoinAll { std::vector<std::thread>& v; ~JoinAll() { for (auto& t : v) if (t.joinable()) t.join(); } } join_warm{warm};
-    vtxh_pack* pk = nullptr;
-    if ((raw ? vtxh_pack_files_raw(&ha, &pk) : vtxh_pack_files(&ha, &pk)) != 0) {
-        printf("Vartrix error.\nError: %s\n", vtxh_last_error());
-        return 1;
-    }
+    // ---- streaming: the VCF records are taken in ranges of --stream-loci rows.  A producer thread packs range k + 1 (BGZF
+    //      inflate, filters, haplotypes: the host-bound 70 % of a run) while this thread drives the device through range k and
+    //      collects its triplets; at most two ranges are in memory.  The reference itself holds one locus' reads at a time
+    //      (src/main.rs:822-830); results do not depend on the ranges (tests/test_host.py, tests/test_gpu_cli.py). ----
+    const uint32_t stream_loci = (uint32_t)strtoul(val["stream-loci"].c_str(), nullptr, 10);
+    struct Packed { vtxh_pack* pk = nullptr; int rc = 0; std::string err; double secs = 0; bool last = false; };
+    std::mutex q_mu;
+    std::condition_variable q_cv;
+    std::vector<Packed> q;                 // at most one packed range waiting (plus the one being consumed)
+    bool consumer_gone = false;
+    std::thread producer([&] {
+        uint32_t begin = 0, n_total = 0xffffffffu;
+        for (;;) {
+            Packed pc;
+            const auto t0 = std::chrono::steady_clock::now();
+            const uint32_t end = stream_loci ? (begin + stream_loci < begin ? 0xffffffffu : begin + stream_loci) : 0xffffffffu;
+            pc.rc = vtxh_pack_files_range(&ha, raw ? 1 : 0, begin, end, &pc.pk);
+            if (pc.rc) pc.err = vtxh_last_error();
+            else n_total = vtxh_num_variants(pc.pk);
+            pc.secs = since(t0);
+            pc.last = pc.rc != 0 || end >= n_total;
+            const bool last = pc.last;
+            {
+                std::unique_lock<std::mutex> lk(q_mu);
+                q_cv.wait(lk, [&] { return q.empty() || consumer_gone; });
+                if (consumer_gone) { if (pc.pk) vtxh_free(pc.pk); return; }
+                q.push_back(std::move(pc));
+            }
+            q_cv.notify_all();
+            if (last) return;
+            begin = end;
+        }
+    });
+    struct ProducerJoin { std::thread& t; std::mutex& mu; std::condition_variable& cv; bool& gone;
+                          ~ProducerJoin() { { std::lock_guard<std::mutex> lk(mu); gone = true; } cv.notify_all(); if (t.joinable()) t.join(); } }
+        producer_join{producer, q_mu, q_cv, consumer_gone};
+    auto next_pack = [&]() -> Packed {
+        std::unique_lock<std::mutex> lk(q_mu);
+        q_cv.wait(lk, [&] { return !q.empty(); });
+        Packed pc = std::move(q.front());
+        q.erase(q.begin());
+        lk.unlock();
+        q_cv.notify_all();
+        return pc;
+    };
+    Packed first = next_pack();
+    if (first.rc) { printf("Vartrix error.\nError: %s\n", first.err.c_str()); return 1; }
+    vtxh_pack* pk = first.pk;
     const uint32_t n_vars = vtxh_num_variants(pk), n_bcs = vtxh_num_barcodes(pk);
-    const double t_ingest = since(t_start);
+    // names for --out-variants / --out-barcodes outlive the packs
+    std::vector<std::string> variant_names, barcode_names;
+    if (present.count("out-variants")) for (uint32_t i = 0; i < n_vars; ++i) variant_names.emplace_back(vtxh_variant_name(pk, i));
+    if (present.count("out-barcodes")) for (uint32_t j = 0; j < n_bcs; ++j) barcode_names.emplace_back(vtxh_barcode(pk, j));
+    double t_ingest = first.secs;
     LOG_INFO("Loaded %u barcodes", n_bcs);
     if (n_vars == 0)
         LOG_ERROR("Warning! Zero variants found in input VCF. Output matrices will be by definition empty but will still be generated.");
@@ -295,8 +345,6 @@ int main(int argc, char** argv) {
     const uint8_t* bc_bytes = nullptr;
     const uint64_t* bc_offsets = nullptr;
     uint32_t bc_n = 0;
-    if (raw) vtxh_get_barcode_table(pk, &bc_bytes, &bc_offsets, &bc_n);
-    const uint32_t n_batches = vtxh_num_batches(pk);
     const auto t_wait = std::chrono::steady_clock::now();
     for (auto& t : warm) t.join();
     LOG_INFO("Waited %.3f s more for the HIP runtime / device initialisation started at launch", since(t_wait));
@@ -306,7 +354,13 @@ int main(int argc, char** argv) {
     const double *out_v = nullptr, *out_rv = nullptr;
     std::vector<double> v, rv;
     vtx_raw_stats raw_total{};
+    vtxh_metrics m{};
     const auto t_dev = std::chrono::steady_clock::now();
+    Packed cur = std::move(first);
+    for (uint32_t range_idx = 0;; ++range_idx) {
+    pk = cur.pk;
+    if (raw) vtxh_get_barcode_table(pk, &bc_bytes, &bc_offsets, &bc_n);
+    const uint32_t n_batches = vtxh_num_batches(pk);
     for (uint32_t bi = 0; bi < n_batches; ++bi) {
         vtx_batch full{};
         vtx_raw_batch full_raw{};
@@ -336,7 +390,7 @@ int main(int argc, char** argv) {
                 const uint32_t r0 = s.loci.empty() ? 0 : s.loci.front().rec_begin;
                 const uint32_t r1 = s.loci.empty() ? 0 : s.loci.back().rec_begin + s.loci.back().rec_count;
                 s.n_records = r1 - r0;
-                s.keep_ctx = n_batches == 1 && ndev == 1;
+                s.keep_ctx = n_batches == 1 && ndev == 1 && range_idx == 0 && cur.last;
                 if (raw) {
                     s.raw = true;
                     s.raw_records = full_raw.records + r0;
@@ -351,7 +405,7 @@ int main(int argc, char** argv) {
             }
         }
         if (bi == 0)
-            LOG_INFO("Ingest + filter + pack: %.3f s (%u batch(es); first: %u loci, %u %s)", t_ingest, n_batches, full.n_loci, full.n_records,
+            LOG_INFO("Ingest + filter + pack of range %u: %.3f s (%u batch(es); first: %u loci, %u %s)", range_idx, cur.secs, n_batches, full.n_loci, full.n_records,
                      raw ? "raw reads; barcode lookup / UMI grouping / sort on the device" : "scored reads");
         // more than one device (or the test hook): the row exchange runs behind the C-ABI over RCCL
         uint8_t comm_id[VTX_COMM_ID_BYTES];
@@ -389,10 +443,23 @@ int main(int argc, char** argv) {
             }
         }
     }
+    {
+        vtxh_metrics mr;
+        vtxh_get_metrics(pk, &mr);
+        m.num_reads += mr.num_reads; m.num_low_mapq += mr.num_low_mapq; m.num_non_primary += mr.num_non_primary;
+        m.num_duplicates += mr.num_duplicates; m.num_not_cell_bc += mr.num_not_cell_bc; m.num_not_useful += mr.num_not_useful;
+        m.num_non_umi += mr.num_non_umi; m.num_invalid_recs += mr.num_invalid_recs; m.num_multiallelic_recs += mr.num_multiallelic_recs;
+    }
+    vtxh_free(pk);                                         // this range's reads leave the host before the next range is consumed
+    pk = nullptr;
+    if (cur.last) break;
+    cur = next_pack();
+    if (cur.rc) { printf("Vartrix error.\nError: %s\n", cur.err.c_str()); return 1; }
+    t_ingest += cur.secs;
+    }
+    LOG_INFO("Ingest + filter + pack, all ranges: %.3f s of packer time (overlapped with the device work on the range before)", t_ingest);
     LOG_INFO("Device (create + submit + run + fetch) on %d GPU(s): %.3f s", ndev, since(t_dev));
     const auto t_out = std::chrono::steady_clock::now();
-    vtxh_metrics m;
-    vtxh_get_metrics(pk, &m);
     m.num_not_cell_bc += raw_total.num_not_cell_bc;
     m.num_non_umi += raw_total.num_non_umi;
     LOG_INFO("Number of alignments evaluated: %llu", (unsigned long long)m.num_reads);                                        // :350-379
@@ -422,14 +489,14 @@ int main(int argc, char** argv) {
         validate_output_path(val["out-variants"]);
         FILE* f = fopen(val["out-variants"].c_str(), "wb");
         if (!f) { printf("Vartrix error.\nError: error writing variants file\n"); return 1; }
-        for (uint32_t i = 0; i < n_vars; ++i) fprintf(f, "%s\n", vtxh_variant_name(pk, i));
+        for (uint32_t i = 0; i < n_vars; ++i) fprintf(f, "%s\n", variant_names[i].c_str());
         fclose(f);
     }
     if (present.count("out-barcodes")) {                                                                                     // :400-407
         validate_output_path(val["out-barcodes"]);
         FILE* f = fopen(val["out-barcodes"].c_str(), "wb");
         if (!f) { printf("Vartrix error.\nError: error writing barcodes file\n"); return 1; }
-        for (uint32_t j = 0; j < n_bcs; ++j) fprintf(f, "%s\n", vtxh_barcode(pk, j));
+        for (uint32_t j = 0; j < n_bcs; ++j) fprintf(f, "%s\n", barcode_names[j].c_str());
         fclose(f);
     }
     LOG_INFO("Merge + output files: %.3f s", since(t_out));

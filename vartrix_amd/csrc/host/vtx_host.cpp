@@ -565,11 +565,17 @@ void vtxh_get_barcode_table(const vtxh_pack* p, const uint8_t** bytes, const uin
     *bytes = (const uint8_t*)p->bc_bytes.data(); *offsets = p->bc_offsets.data(); *n = (uint32_t)p->barcodes.size();
 }
 
-static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out);
-int vtxh_pack_files(const vtxh_args* a, vtxh_pack** out) { return pack_impl(a, false, out); }
-int vtxh_pack_files_raw(const vtxh_args* a, vtxh_pack** out) { return pack_impl(a, true, out); }
+static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t row_end, vtxh_pack** out);
+int vtxh_pack_files(const vtxh_args* a, vtxh_pack** out) { return pack_impl(a, false, 0, 0xffffffffu, out); }
+int vtxh_pack_files_raw(const vtxh_args* a, vtxh_pack** out) { return pack_impl(a, true, 0, 0xffffffffu, out); }
+int vtxh_pack_files_range(const vtxh_args* a, int raw, uint32_t row_begin, uint32_t row_end, vtxh_pack** out) {
+    if (row_begin > row_end) return fail(VTX_E_INVAL, "vtxh_pack_files_range: row_begin > row_end");
+    return pack_impl(a, raw != 0, row_begin, row_end, out);
+}
 
-static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
+// VCF records [row_begin, row_end) only: the other records keep their matrix rows (n_variants, names) but get no haplotypes, no
+// loci and no reads, and are not counted in the metrics — the packs of consecutive ranges add up to the pack of the whole file.
+static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t row_end, vtxh_pack** out) {
     if (!a || !out || !a->vcf || !a->bam || !a->fasta || !a->cell_barcodes) return fail(VTX_E_INVAL, "vtxh_pack_files: null argument");
     *out = nullptr;
     const std::string bam_tag = a->bam_tag ? a->bam_tag : "CB";
@@ -781,12 +787,13 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
     {
         // haplotypes of all records in parallel (verdict per record), then the loci in VCF order
         std::vector<LocusBuild> built(vcf.size());
-        std::vector<uint8_t> verdict(vcf.size(), 0);            // 0 locus, 1 multi-allelic, 2 invalid characters
+        std::vector<uint8_t> verdict(vcf.size(), 0);            // 0 locus, 1 multi-allelic, 2 invalid characters, 3 outside this range of rows
         std::vector<int32_t> tid_i(vcf.size(), 0);
         pool.run([&](size_t t) {
             std::string left, right;
             for (size_t i = vcf.size() * t / (size_t)threads, e = vcf.size() * (t + 1) / (size_t)threads; i < e; ++i) {
                 const VcfRec& v = vcf[i];
+                if (i < row_begin || i >= row_end) { verdict[i] = 3; continue; }
                 if (v.alleles.size() > 2) { verdict[i] = 1; continue; }                                // :646-653
                 const std::string alt = v.alleles.size() == 2 ? v.alleles[1] : std::string();          // :656-659
                 const FaiEntry& fe = fa.seqs[fa.by_name.find(v.chrom)->second];
@@ -810,6 +817,7 @@ static int pack_impl(const vtxh_args* a, bool raw, vtxh_pack** out) {
         for (size_t i = 0; i < vcf.size(); ++i) {
             if (verdict[i] == 1) { ++P->metrics.num_multiallelic_recs; continue; }
             if (verdict[i] == 2) { ++P->metrics.num_invalid_recs; continue; }
+            if (verdict[i] == 3) continue;
             const int32_t tid = tid_i[i];
             by_tid[(size_t)tid].push_back(Interval{built[i].start, built[i].end, (uint32_t)loci.size()});
             max_span[(size_t)tid] = std::max(max_span[(size_t)tid], built[i].end - built[i].start);

@@ -17,7 +17,7 @@ CLI_PATH = os.path.join(_HERE, "bin", "vartrix")
 SYMBOLS = ("vtxh_pack_files", "vtxh_free", "vtxh_last_error", "vtxh_get_batch", "vtxh_get_metrics", "vtxh_get_ingest_stats",
            "vtxh_num_variants", "vtxh_num_barcodes", "vtxh_variant_name", "vtxh_barcode", "vtxh_write_mtx",
            "vtxh_format_f64", "vtxh_pack_files_raw", "vtxh_get_raw_batch", "vtxh_get_barcode_table", "vtxh_num_batches",
-           "vtxh_get_batch_at", "vtxh_get_raw_batch_at")
+           "vtxh_get_batch_at", "vtxh_get_raw_batch_at", "vtxh_pack_files_range")
 METRIC_NAMES = ("num_reads", "num_low_mapq", "num_non_primary", "num_duplicates", "num_not_cell_bc",
                 "num_not_useful", "num_non_umi", "num_invalid_recs", "num_multiallelic_recs")
 
@@ -46,6 +46,8 @@ def load():
         L.vtxh_pack_files.argtypes = [C.POINTER(VtxhArgs), C.POINTER(C.c_void_p)]
         L.vtxh_pack_files_raw.restype = C.c_int
         L.vtxh_pack_files_raw.argtypes = [C.POINTER(VtxhArgs), C.POINTER(C.c_void_p)]
+        L.vtxh_pack_files_range.restype = C.c_int
+        L.vtxh_pack_files_range.argtypes = [C.POINTER(VtxhArgs), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         L.vtxh_get_raw_batch.argtypes = [C.c_void_p, C.POINTER(abi.VtxRawBatch)]
         L.vtxh_get_barcode_table.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
         L.vtxh_num_batches.restype = C.c_uint32
@@ -82,7 +84,7 @@ class HostError(RuntimeError):
 
 
 def pack_files(vcf, bam, fasta, cell_barcodes, padding=100, mapq=0, primary_only=False, no_duplicates=False,
-               use_umi=False, bam_tag="CB", valid_chars="ATGCatgc", threads=1, raw=False, all_batches=False):
+               use_umi=False, bam_tag="CB", valid_chars="ATGCatgc", threads=1, raw=False, all_batches=False, rows=None):
     """-> (PackedBatch, metrics dict, n_variants, barcodes list, variant names); with ``raw`` the batch is a
     RawBatch for ``Context.submit_raw`` (vtxh_pack_files_raw: tags as bytes, BAM order inside a locus).
     A pack whose reads span more than 4 GiB comes as several batches: ``all_batches`` returns the list of them
@@ -91,7 +93,10 @@ def pack_files(vcf, bam, fasta, cell_barcodes, padding=100, mapq=0, primary_only
     args = VtxhArgs(vcf.encode(), bam.encode(), fasta.encode(), cell_barcodes.encode(), padding, mapq,
                     int(primary_only), int(no_duplicates), int(use_umi), bam_tag.encode(), valid_chars.encode(), threads)
     h = C.c_void_p()
-    rc = (L.vtxh_pack_files_raw if raw else L.vtxh_pack_files)(C.byref(args), C.byref(h))
+    if rows is not None:      # streaming: VCF records [rows[0], rows[1]) only (vtxh_pack_files_range)
+        rc = L.vtxh_pack_files_range(C.byref(args), int(raw), int(rows[0]), int(rows[1]), C.byref(h))
+    else:
+        rc = (L.vtxh_pack_files_raw if raw else L.vtxh_pack_files)(C.byref(args), C.byref(h))
     if rc != 0:
         raise HostError(L.vtxh_last_error().decode())
     try:
