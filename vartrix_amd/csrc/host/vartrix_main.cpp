@@ -68,7 +68,7 @@ const Opt kOpts[] = {
     {"primary-alignments", 0, true, nullptr}, {"no-duplicates", 0, true, nullptr}, {"umi", 0, true, nullptr},
     {"bam-tag", 0, false, "CB"}, {"valid-chars", 0, false, "ATGCatgc"},
     {"devices", 0, false, "1"}, {"aligner", 0, false, "banded"}, {"prep", 0, false, "host"},
-    {"stream-loci", 0, false, "32768"},
+    {"stream-loci", 0, false, "auto"},
 };
 
 void usage() {
@@ -80,8 +80,9 @@ void usage() {
             "  --mapq <INT> [0]   --primary-alignments   --no-duplicates   --umi   --bam-tag <TAG> [CB]\n"
             "  --valid-chars <CHARS> [ATGCatgc]   --devices <INT> [1]   --aligner banded|full [banded]\n"
             "  --prep host|device [host]  (device: barcode lookup, UMI grouping and the sort run on the GPU)\n"
-            "  --stream-loci <INT> [32768]  VCF records per streamed range (ingest of range k + 1 overlaps the device work on range k;\n"
-            "                               host memory follows the range, not the BAM); 0 = the whole input at once\n");
+            "  --stream-loci <INT>|auto [auto]  VCF records per streamed range (ingest of range k + 1 overlaps the device work on\n"
+            "                               range k; host memory follows the range, not the BAM); 0 = the whole input at once;\n"
+            "                               auto = at once when the BAM is below 4 GiB (faster: one sweep), ranges of 32768 above\n");
 }
 
 // The shard threads of one batch meet here before each RCCL collective, carrying their status: if any shard has failed,
@@ -275,7 +276,15 @@ int main(int argc, char** argv) {
     //      inflate, filters, haplotypes: the host-bound 70 % of a run) while this thread drives the device through range k and
     //      collects its triplets; at most two ranges are in memory.  The reference itself holds one locus' reads at a time
     //      (src/main.rs:822-830); results do not depend on the ranges (tests/test_host.py, tests/test_gpu_cli.py). ----
-    const uint32_t stream_loci = (uint32_t)strtoul(val["stream-loci"].c_str(), nullptr, 10);
+    uint32_t stream_loci = 0;
+    if (val["stream-loci"] == "auto") {
+        // measured at config-3 scale (profiles/r03_e2e_cli_*.log): one sweep of a 0.9 GB BAM 2.0 s, four streamed ranges 3.1 s — the
+        // packer's threads scale worse on a third of the data; streaming is for inputs whose reads do not fit the host
+        struct stat st;
+        if (stat(val["bam"].c_str(), &st) == 0 && (uint64_t)st.st_size > (4ull << 30)) stream_loci = 32768;
+    } else {
+        stream_loci = (uint32_t)strtoul(val["stream-loci"].c_str(), nullptr, 10);
+    }
     struct Packed { vtxh_pack* pk = nullptr; int rc = 0; std::string err; double secs = 0; bool last = false; };
     std::mutex q_mu;
     std::condition_variable q_cv;
