@@ -392,12 +392,23 @@ def main():
             ghz = NOMINAL_GHZ
             if pmc_extra.get("grbm_gui_active_per_launch") and pmc_extra.get("kernel_ms_in_profiled_runs"):
                 ghz = pmc_extra["grbm_gui_active_per_launch"] / 8 / (pmc_extra["kernel_ms_in_profiled_runs"] * 1e-3) / 1e9   # one count per XCD
-            kernel_cycles = dom_ms * 1e-3 * ghz * 1e9
+            issue_ms = dom_ms
+            if dom_name == "band_diag_kernel":
+                # dom_ms spans band_tables_kernel + band_diag_kernel (one event pair); the instructions are band_diag_kernel's alone:
+                # its share of the span, from the durations of the two kernels in the profiled runs
+                try:
+                    tj = json.load(open(pmc)).get("band_tables_kernel", {})
+                    a, b = pmc_extra.get("kernel_ms_in_profiled_runs"), tj.get("kernel_ms_in_profiled_runs")
+                    if a and b:
+                        issue_ms = dom_ms * a / (a + b)
+                except Exception:
+                    pass
+            kernel_cycles = issue_ms * 1e-3 * ghz * 1e9
 
             def occ(c):
                 return vi * c / (SIMDS * kernel_cycles)
             out["roofline_valu_issue"] = {
-                "bound": "valu", "kernel": dom_name, "kernel_ms": dom_ms, "valu_wave_instructions_per_launch": vi,
+                "bound": "valu", "kernel": dom_name, "kernel_ms": issue_ms, "valu_wave_instructions_per_launch": vi,
                 "salu_instructions_per_launch": pmc_extra.get("salu_instructions_per_launch"),
                 "valu_active_lanes_mean_of_64": pmc_extra.get("valu_active_lanes_mean"),
                 "effective_clock_ghz": ghz, "cycles_per_valu_instruction_static_mix": cpi,
