@@ -179,3 +179,72 @@ def test_config4_shape_many_barcodes():
     wcoo = run(want, cfg)[2]
     for k in ("row", "col", "value"):
         assert np.array_equal(rcoo[k], wcoo[k]), k
+
+
+def test_config4_full_size_properties():
+    """BASELINE.json configs[3] at FULL size on one GPU (100 k SNV loci x 50 k barcodes, consensus; the 8-GPU run cuts exactly
+    this workload over the ranks): the size-independent properties + the oracle spot check, and the matrix summary that
+    `bench.py --gpus N` compares its gathered result with (profiles/expected_results.json)."""
+    import json
+    import os
+    spec = synth.config4()
+    batch = synth.make_batch(spec)
+    check_properties(spec, batch, "banded", "consensus", sample=1000)
+    exp_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "expected_results.json")
+    exp = json.load(open(exp_path)).get(spec.name + ", consensus mode, banded aligner")
+    assert exp is not None
+    cfg = default_config(aligner="banded", scoring_mode="consensus", n_barcodes=spec.n_barcodes)
+    coo = run(batch, cfg)[2]
+    assert len(coo["row"]) == exp["nnz"]
+
+
+def test_config5_full_size_properties():
+    """BASELINE.json configs[4] at FULL size on one GPU: 100 k loci, 70 % SNV / 15 % insertions / 15 % deletions (<= 20 bp),
+    alt_frac with UMI collapse.  The whole reduction is recomputed on the host with numpy from the device's per-read scores
+    (evaluate_scores :1019-1030, the 0.75 rule of parse_scores :1070-1081 as 4a >= 3t, alt_frac :1131-1145 incl. NaN for 0 / 0)
+    and must equal the device's triplets bit for bit; a sample of records is scored by the oracle."""
+    spec = synth.config5()
+    batch = synth.make_batch(spec)
+    assert len(np.unique(batch.loci["ref_len"].astype(np.int64) - batch.loci["alt_len"])) > 30
+    cfg = default_config(aligner="banded", scoring_mode="alt_frac", use_umi=1, n_barcodes=spec.n_barcodes)
+    ref, alt, coo = run(batch, cfg)
+    n = batch.n_records
+    assert ref.min() >= 0 and alt.min() >= 0 and max(ref.max(), alt.max()) <= spec.read_len
+    none = (ref < 25) & (alt < 25)
+    is_r, is_a, is_u = (ref > alt) & ~none, (alt > ref) & ~none, (alt == ref) & ~none
+    row = np.repeat(batch.loci["row"].astype(np.int64), batch.loci["rec_count"])
+    cell_key = row * spec.n_barcodes + batch.records["cell_index"]
+    # records are sorted by (locus, cell, umi): groups are runs
+    umi = batch.records["umi_id"].astype(np.int64)
+    head_u = np.ones(n, bool)
+    head_u[1:] = (cell_key[1:] != cell_key[:-1]) | (umi[1:] != umi[:-1])
+    gid = np.cumsum(head_u) - 1
+    ng = int(gid[-1]) + 1
+    r = np.bincount(gid, weights=is_r, minlength=ng).astype(np.int64)
+    a = np.bincount(gid, weights=is_a, minlength=ng).astype(np.int64)
+    u = np.bincount(gid, weights=is_u, minlength=ng).astype(np.int64)
+    t = r + a + u
+    call_a = (t > 0) & (4 * a >= 3 * t)
+    call_r = (t > 0) & ~call_a & (4 * r >= 3 * t)
+    call_u = (t > 0) & ~call_a & ~call_r
+    g_cell = cell_key[head_u]
+    cells, inv = np.unique(g_cell, return_inverse=True)
+    ca = np.bincount(inv, weights=call_a, minlength=len(cells)).astype(np.uint32)
+    cr = np.bincount(inv, weights=call_r, minlength=len(cells)).astype(np.uint32)
+    cu = np.bincount(inv, weights=call_u, minlength=len(cells)).astype(np.uint32)
+    key = coo["row"].astype(np.int64) * spec.n_barcodes + coo["col"]
+    assert np.array_equal(key, cells)                      # alt_frac emits every (locus, cell) group, in merge-loop order
+    assert np.array_equal(coo["alt"], ca) and np.array_equal(coo["ref"], cr) and np.array_equal(coo["unk"], cu)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want = ca.astype(np.float64) / (ca.astype(np.float64) + cr + cu)
+    assert np.array_equal(coo["value"].view(np.uint64) & 0x7fffffffffffffff, want.view(np.uint64) & 0x7fffffffffffffff)   # NaN where 0 / 0 (sign aside)
+    assert np.isnan(coo["value"]).sum() == int(((ca + cr + cu) == 0).sum())
+    assert (t > 1).sum() > 100000 and (call_u.sum() > 0)    # UMI families really collapsed, some by the 0.75 rule into UNKNOWN
+    rng = np.random.default_rng(2)
+    rec_locus = np.repeat(np.arange(batch.n_loci), batch.loci["rec_count"])
+    for k in np.sort(rng.choice(n, 1500, replace=False)):
+        rec, loc = batch.records[k], batch.loci[rec_locus[k]]
+        read = bytes(batch.read_arena[rec["read_off"]:rec["read_off"] + rec["read_len"]])
+        rh = bytes(batch.hap_arena[loc["ref_off"]:loc["ref_off"] + loc["ref_len"]])
+        ah = bytes(batch.hap_arena[loc["alt_off"]:loc["alt_off"] + loc["alt_len"]])
+        assert (oracle.sw_banded(read, rh), oracle.sw_banded(read, ah)) == (int(ref[k]), int(alt[k])), k

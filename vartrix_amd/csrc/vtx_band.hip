@@ -1682,7 +1682,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     if ((stats >> 8) == 2) { if (live && s_cnt[tid] == 0x7fffffff) counters[40] = 1; return; }   // (profiling aid) front + probes
     if (live) {
         const vtxf::Lane gl{(uint32_t*)q_ent + tid, 64};                 // (the queue is dead by now)
-        const int32_t sc = vtxf::back(fr, (int)min(s_cnt[tid], (uint32_t)vtxf::SM + 1u), ln, gl, &why);
+        const int32_t sc = vtxf::back(fr, (int)min(s_cnt[tid], (uint32_t)vtxf::SM + 1u), ln, gl, &why, (int)(stats >> 8));
         if (sc >= 0) *my_score = sc; else fail = true;
     }
     const uint64_t fm = __ballot(fail);

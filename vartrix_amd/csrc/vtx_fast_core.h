@@ -418,7 +418,7 @@ VTXF_FN int probe_rows(const uint8_t* x, const Tab& tb, const Front& fr, const L
 
 // ---- phase 3 ----
 // Returns the score (>= 0) or -1 with *why set.
-VTXF_FN int32_t back(const Front& fr, int ns, const Lane& ln, const Lane& gl, uint32_t* why) {
+VTXF_FN int32_t back(const Front& fr, int ns, const Lane& ln, const Lane& gl, uint32_t* why, int ablate = 0) {
     const int d = fr.d, r = fr.r;
     if (ns > SM) { *why = W_MATCHES; return -1; }
     // (x, y) order (a lane probing its own rows produces it; pooled probes arrive in any order)
@@ -452,6 +452,7 @@ VTXF_FN int32_t back(const Front& fr, int ns, const Lane& ln, const Lane& gl, ui
         // s could end the chain, or a main match could prefer it:  dp + (sx + K) + (sy + K) - (x_p + y_p) + 1 >= dp(p)
         if (dp >= fr.best_dp || dp + q + 2 * K + 1 >= minH) { *why = W_NOT_HARMLESS; return -1; }
     }
+    if (ablate == 5) { *why = W_NOT_TIGHT; return -1 - runmax; }          // (profiling aid) sort + harmless tests only
     // ---- generic set: closure of the hull over the off-diagonal pieces.  T = the smallest distance the far-piece lemma
     //      allows for E <= ns far matches: T >= E and 2T >= E + 5 ----
     const int TFAR = imax(ns, 5);
@@ -494,6 +495,7 @@ VTXF_FN int32_t back(const Front& fr, int ns, const Lane& ln, const Lane& gl, ui
         // what the closure left is >= T diagonals outside the hull: far.  E = their k-mer matches
         far_e = nc - __builtin_popcount(used);
     }
+    if (ablate == 6) { *why = W_NOT_TIGHT; return -1 - far_e - ng; }      // (profiling aid) ... + closure
     // ---- run bound over the generic pieces: main pieces at ln[SM, SM + r), off-diagonal ones at gl[0, ng) ----
     int ub = imax(K - 1, far_e > 0 ? far_e + 5 : 0);
     {
