@@ -22,17 +22,19 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "vtx_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    # make decides (the Makefile lists every source and header the library depends on); -B only when forced
+    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
+        try:
             build()
+        except (OSError, subprocess.CalledProcessError):
+            if not os.path.exists(_SO):                 # (a box without make / gcc uses the prebuilt library)
+                raise
         L = C.CDLL(_SO)
         u8p = C.c_char_p
         i32p = C.POINTER(C.c_int32)

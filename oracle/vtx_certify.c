@@ -25,11 +25,16 @@
  *   scores <= 5.  Hence
  *       full <= max(5, max over chains of sub-runs of pieces of
  *                       sum(len) - sum over joins of J),          J >= 5 + |d' - d|.
- *   Same diagonal, D >= 1 positions between the two runs: the only gap-free path costs
- *   6 e - D with e >= ceil((D + 5) / 6) mismatches (short runs <= 5), and a path with gaps
- *   needs >= 2 gaps of total length 2 G >= 2 and has D - G diagonal columns, so it costs
- *   >= 10 + 3 G - D >= 13 - D, and >= 5 + sum(L) >= 7:
- *       J_same(D) = min(6 ceil((D + 5) / 6) - D, max(7, 13 - D)).
+ *   Same diagonal, D >= 1 positions between the two runs.  Without gaps the stretch IS the diagonal: it costs exactly
+ *   6 e - D, e = the mismatching ones among the D positions (the bases are at hand), and e >= ceil((D + 5) / 6) in any
+ *   case (short runs <= 5): J_free(D) = 6 ceil((D + 5) / 6) - D.  With gaps: g >= 2 gap events whose insertions and
+ *   deletions both total G >= ceil(g / 2), so D - G diagonal columns, mm of them mismatches; the g + mm events separate
+ *   at most g + mm - 1 short runs, D - G - mm <= 5 (g + mm - 1); cost = 5 g + 2 G + 5 mm - (D - G - mm).  Minimised over
+ *   (g, G, mm) (tests/test_certify.py does it by brute force):
+ *       J_gap(1) = 12,   J_gap(D) = {7, 9, 11, 10, 9, 8}[D mod 6]  (>= J_free(D), and J_gap(D + 1) >= J_gap(D) - 1),
+ *       J_same(D, e) = min(6 e - D, J_gap(D));      J_same(D) = J_free(D) when the bases are not looked at.
+ *   (Round 2 used max(7, 13 - D) for the gapped path: it forgot that 5 (g - 1) matches cannot span a long stretch, and
+ *   took e at its minimum: at 3 % substitution errors that made 10.5 % of the tasks hard, this form 6.0 %.)
  *   Any designation of further (short) runs as chain members keeps the inequality, so the
  *   maximisation may range over ALL sub-runs of pieces (length >= 1).
  */
@@ -125,20 +130,23 @@ static int64_t find_pieces(const uint8_t* x, int m, const uint8_t* y, int n, int
 }
 
 int vtxo_join_same(int D);
-static int g_join_exact = 0;     /* experiment: count the mismatches between same-diagonal bases instead of their minimum */
+int vtxo_join_gap(int D);
+static int g_join_exact = 1;     /* 0: the closed form J_free(D) only (what a caller without the bases uses) */
 void vtxo_set_join_exact(int on) { g_join_exact = on; }
 static int join_same_e(const uint8_t* x, const uint8_t* y, int xb, int yb, int D) {
     /* bases (xb+1 .. xb+D) on the diagonal of (xb, yb) */
     if (!g_join_exact) return vtxo_join_same(D);
     int e = 0;
     for (int i = 1; i <= D; ++i) e += x[xb + i] != y[yb + i];
-    return imin(6 * e - D, imax(7, 13 - D));
+    return imin(6 * e - D, vtxo_join_gap(D));
 }
 
+int vtxo_join_gap(int D) {
+    static const int jg[6] = {7, 9, 11, 10, 9, 8};
+    return D == 1 ? 12 : jg[D % 6];
+}
 int vtxo_join_same(int D) {
-    const int c = 6 * ((D + 10) / 6) - D;      /* 6 ceil((D + 5) / 6) - D */
-    const int g = imax(7, 13 - D);
-    return imin(c, g);
+    return 6 * ((D + 10) / 6) - D;             /* 6 ceil((D + 5) / 6) - D  (<= J_gap(D)) */
 }
 
 /* Exact form of the bound: DP over every matched base of every piece (O(N^2)).               */

@@ -111,17 +111,31 @@ def test_bounds_on_repeats_and_short_sequences():
 
 
 def test_join_cost_table():
-    """J_same(D): the cheapest way to get from one exact-match run to the next one D bases further on the same
-    diagonal, computed here by brute force over (mismatches, gaps) and compared with the closed form."""
+    """The cheapest way to get from one exact-match run to the next one D bases further on the same diagonal, by brute
+    force over (mismatches, gap events, gap length), against the closed forms of oracle/vtx_certify.c.
+    Gap-free: e mismatches and D - e matches in e - 1 runs of <= 5.  With gaps: g >= 2 gap events, insertions and
+    deletions both total G >= ceil(g / 2), D - G diagonal columns of which mm mismatch, the g + mm events separate at
+    most g + mm - 1 short runs of <= 5."""
     L = oracle.lib()
     L.vtxo_join_same.restype = C.c_int
-    for D in range(1, 60):
-        # gap-free: e mismatches and D - e matches in e - 1 runs of <= 5
-        best = min(6 * e - D for e in range(1, D + 1) if D - e <= 5 * (e - 1))
-        # with gaps: >= 2 gaps (total insertion = total deletion = G >= 1), D - G diagonal columns all matches
-        gap = min([10 + 3 * G - D for G in range(1, D + 1)] + [10 ** 6])
-        gap = max(gap, 7)
-        assert L.vtxo_join_same(D) == min(best, gap), D
+    L.vtxo_join_gap.restype = C.c_int
+    prev_gap = None
+    for D in range(1, 120):
+        free = min(6 * e - D for e in range(1, D + 1) if D - e <= 5 * (e - 1))
+        gap = 10 ** 6
+        for g in range(2, 2 * D + 2):
+            for G in range((g + 1) // 2, D + 1):
+                for mm in range(0, D - G + 1):
+                    matches = D - G - mm
+                    if matches <= 5 * (g + mm - 1):
+                        gap = min(gap, 5 * g + 2 * G + 5 * mm - matches)
+                        break                      # the cost grows by 6 per further mismatch
+        assert L.vtxo_join_same(D) == free, D
+        assert L.vtxo_join_gap(D) == gap, D
+        assert gap >= free, D
+        if prev_gap is not None:
+            assert gap >= prev_gap - 1, D          # leaving a run one base earlier never pays (see the proof)
+        prev_gap = gap
 
 
 def test_bounds_on_random_low_entropy_strings():

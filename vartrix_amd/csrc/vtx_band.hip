@@ -31,8 +31,9 @@
 //         difference of the two diagonals; the stretches before the first / after the last long run net <= 0;
 //         an alignment without a long run scores <= 5.  So
 //             full <= max(5, max over chains of sub-runs of pieces [ sum len - sum J ]),  J = 5 + |d' - d|,
-//         and between runs of the same diagonal, D >= 1 bases apart: J = min(6 ceil((D + 5) / 6) - D,
-//         max(7, 13 - D)) (gap-free: e mismatches cost 6 e - D; with gaps: >= 2 gaps, 10 + 3 G - D).
+//         and between runs of the same diagonal, D >= 1 bases apart: J = 6 ceil((D + 5) / 6) - D (gap-free: e mismatches
+//         cost 6 e - D and short runs need e >= ceil((D + 5) / 6); a stretch with gaps costs at least J_gap(D) >= that).
+//         (band_diag_kernel, which has the match mask of its diagonal, uses min(6 e - D, J_gap(D)) with the true e.)
 //         run_ub() maximises this over the piece list (one number per piece, fixpoint over ordered pairs);
 //         oracle/vtx_certify.c restates it on the CPU with the proof in full, tests/ check ub >= full.
 //   Measured on the synthetic workloads: cert == ub for 99.3 % of SNV tasks (0.5 % substitution errors),
@@ -51,7 +52,7 @@
 #define KMER 6
 #define BANDW 20
 // The certificate (run_ub / ub_join_same: "a mismatch costs 5 + 1", "short runs <= K - 1 = 5", "a gap of length L costs 5 + L",
-// "two gaps cost >= 10 + 3 G - D") and the closed-form sdpkpp (k-mer = K matches, gap_open + d * gap_extend) are DERIVED for the
+// "J_gap") and the closed-form sdpkpp (k-mer = K matches, gap_open + d * gap_extend) are DERIVED for the
 // reference's constants; vtx_create refuses any other configuration (vtx_api.hip), and this ties the two together:
 static_assert(KMER == VTX_REF_K && BANDW == VTX_REF_W && VTX_REF_MATCH == 1 && VTX_REF_MISMATCH == -5 && VTX_REF_GAP_OPEN == -5 &&
               VTX_REF_GAP_EXTEND == -1, "vtx_band.hip's bounds are proved for K = 6, W = 20, +1 / -5, gap -5 / -1 (src/main.rs:33-38) only");
@@ -716,9 +717,7 @@ __device__ void run_compact(run_state& st, uint32_t* e_id, uint32_t* e_dl, int t
 // piece split by a breakpoint or by the two-register window of phase 1) join at cost 0 through D == 0.
 // Fixpoint over ordered pairs; list order (= start order) settles in one pass plus a confirming one.
 __device__ __forceinline__ int32_t ub_join_same(int32_t D) {
-    const int32_t c = 6 * ((D + 10) / 6) - D;              // gap-free: ceil((D + 5) / 6) mismatches
-    const int32_t g = max(7, 13 - D);                      // with gaps
-    return min(c, g);
+    return 6 * ((D + 10) / 6) - D;                         // gap-free with ceil((D + 5) / 6) mismatches; a stretch with gaps costs more (J_gap, oracle/vtx_certify.c)
 }
 
 template <int NT>

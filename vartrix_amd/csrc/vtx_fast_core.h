@@ -35,10 +35,10 @@
 //   ub     the run bound over the GENERIC pieces only: the main-diagonal pieces plus the off-diagonal pieces within
 //          T - 1 diagonals of the hull of the generic diagonals (closure).  The other off-diagonal pieces are FAR: every
 //          one lies >= T diagonals outside the hull.  With E = the number of far k-mer matches (sum of bases - 5 over
-//          the far pieces; E <= ns, the number of off-diagonal matches) and T = max(ns, 5), so that T >= E, 2T >= E + 5:
+//          the far pieces; E <= ns, the number of off-diagonal matches) and T = max(ns, 5) (6 for ns = 5), so that T >= E, 2T >= E + 6:
 //            * a chain of far pieces between two generic pieces g1, g2 nets at most E - 5 - 2T - |d1 - d2| (every join
 //              costs >= 5 + its diagonal difference, the way out of the hull and back is >= 2T + |d1 - d2|), the direct
-//              join g1 -> g2 costs 5 + |d1 - d2| or J_same <= 10: replacing the excursion by the direct join never
+//              join g1 -> g2 costs 5 + |d1 - d2| or J_same <= 11: replacing the excursion by the direct join never
 //              lowers the value;
 //            * far pieces before the first / after the last generic piece net at most E - T <= 0: dropping them never
 //              lowers it;
@@ -170,10 +170,17 @@ VTXF_FN uint32_t eq8(uint64_t a, uint64_t b) {
     return cl | (ch << 4);
 }
 
-VTXF_FN int join_same(int D) {                      // run_ub's same-diagonal join (vtx_band.hip: ub_join_same)
-    const int c = 6 * ((D + 10) / 6) - D;
-    const int g = imax(7, 13 - D);
-    return imin(c, g);
+// Same-diagonal joins of the run bound (proof: oracle/vtx_certify.c).  D >= 1 bases between two runs on one diagonal:
+//   join_free(D)     6 ceil((D + 5) / 6) - D: the gap-free stretch with as few mismatches as runs of <= 5 allow (a caller that
+//                    does not look at the bases; vtx_band.hip: ub_join_same)
+//   join_same(D, e)  min(6 e - D, J_gap(D)): the gap-free stretch costs exactly 6 e - D when e of the D bases mismatch (an e
+//                    below the true count only loosens the bound), a stretch with gaps at least J_gap(D) = {7, 9, 11, 10, 9, 8}
+//                    [D mod 6] (J_gap(1) = 12 > 6 e - D = 5)
+VTXF_FN int div6(int D) { return (D * 43) >> 8; }                    // D / 6 for 0 <= D < 258
+VTXF_FN int join_free(int D) { return 6 * div6(D + 10) - D; }
+VTXF_FN int join_same(int D, int e) {
+    const int jg = (int)((0x89ab97u >> (4 * (D - 6 * div6(D)))) & 15u);
+    return imin(6 * e - D, jg);
 }
 
 // per-lane scratch: element i at base[i * stride] (device: LDS, the 64 lanes of a wavefront interleaved; host: stride 1)
@@ -190,6 +197,7 @@ struct Front {
     uint32_t why;           // W_OK: go on with the probes
     int d, r;               // main diagonal, main pieces
     int best_dp, cert;
+    uint32_t zc;            // nibble i: mismatching bases between main pieces i - 1 and i (capped at 15; nibble 0 unused)
     M192 need;              // rows to probe
 };
 
@@ -284,7 +292,7 @@ VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const La
 // one lane on its own: the six sample rows in turn; a candidate is kept if its mask has at least 20 matching bases
 VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, int n, const Lane& ln) {
     Front fr;
-    fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.need = M192{0, 0, 0};
+    fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.zc = 0; fr.need = M192{0, 0, 0};
     if (m < K || n < K || m > MAX_READ) { fr.why = W_SHAPE; return fr; }
     int prev = NO_DIAG;
     const ReadWords rw = read_words(x, m);
@@ -304,7 +312,7 @@ VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, int n, const Lane& l
 VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const Lane& ln, int d, M192 M) {
     (void)x;
     Front fr;
-    fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.need = M192{0, 0, 0};
+    fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.zc = 0; fr.need = M192{0, 0, 0};
     fr.d = d;
 
     // ---- main pieces (runs of >= K matching bases, found between the zeros of M) and sdpkpp on the diagonal ----
@@ -315,13 +323,17 @@ VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const La
     int bestV = -1000000, bestRoot = 0;
     int best_dp = -1, best_root = 0, best_last = 0;
     bool too_many = false;
+    uint32_t zc = 0;
     {
         // (bases outside [vlo, vhi) face no haplotype base: zeros of M, but nothing to iterate over)
         const int vlo = imax(0, -d), vhi = imin(m, n - d);
         int prev = vlo - 1;
+        int nz = 0, nz_piece = 0;                           // zeros of M seen so far / when the last piece was taken
         auto piece = [&](int u, int v) {                    // bases [u, v]
             if (v - u + 1 < K) return;
             if (r == RM) { too_many = true; return; }
+            zc |= (uint32_t)imin(nz - nz_piece, 15) << (4 * r);
+            nz_piece = nz;
             const int a = u, b = v - 5;
             const int c = bestV - 2 * a + 1;
             int dpf = K, root = a;
@@ -333,12 +345,12 @@ VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const La
             ln.at(SM + r) = (uint32_t)u | ((uint32_t)v << 8) | ((uint32_t)dpf << 16);
             ++r;
         };
-        m_for_each(m_andn(m_range(vlo, vhi), M), [&](int z) { piece(prev + 1, z - 1); prev = z; });
+        m_for_each(m_andn(m_range(vlo, vhi), M), [&](int z) { piece(prev + 1, z - 1); prev = z; ++nz; });
         piece(prev + 1, vhi - 1);
     }
     if (too_many) { fr.why = W_PIECES; return fr; }
     if (r == 0) { fr.why = W_NO_MAIN; return fr; }
-    fr.r = r; fr.best_dp = best_dp;
+    fr.r = r; fr.best_dp = best_dp; fr.zc = zc;
 
     // ---- certificate: best local score of M over the in-band stretch of the diagonal ----
     {
@@ -454,8 +466,8 @@ VTXF_FN int32_t back(const Front& fr, int ns, const Lane& ln, const Lane& gl, ui
     }
     if (ablate == 5) { *why = W_NOT_TIGHT; return -1 - runmax; }          // (profiling aid) sort + harmless tests only
     // ---- generic set: closure of the hull over the off-diagonal pieces.  T = the smallest distance the far-piece lemma
-    //      allows for E <= ns far matches: T >= E and 2T >= E + 5 ----
-    const int TFAR = imax(ns, 5);
+    //      allows for E <= ns far matches: T >= E and 2T >= E + 6 (J_same <= 11) ----
+    const int TFAR = imax(ns, ns <= 4 ? 5 : 6);
     int ng = 0;
     {
         int hull_lo = 0, hull_hi = 0;
@@ -514,17 +526,23 @@ VTXF_FN int32_t back(const Front& fr, int ns, const Lane& ln, const Lane& gl, ui
             for (int p = 1; p < r; ++p) {
                 const uint32_t wp = ln.at(SM + p);
                 const int xp = (int)(wp & 0xffu);
-                int g = 0;
-                for (int q = 0; q < p; ++q) {
+                int g = 0, e = 0;
+                for (int q = p - 1; q >= 0; --q) {
                     const uint32_t wq = ln.at(SM + q);
                     const int xq = (int)(wq & 0xffu), lq = (int)((wq >> 8) & 0xffu) - xq + 1, gq = (int)(wq >> 24);
-                    // entry at the first base of p (s = 0), q used whole (t = lq - 1): D bases between them
+                    // entry at the first base of p (s = 0), q used whole (t = lq - 1): D bases between them, e of them mismatches
                     const int D = xp - (xq + lq);
-                    g = imax(g, lq + gq - (D == 0 ? 0 : join_same(D)));
+                    e += (int)((fr.zc >> (4 * (q + 1))) & 15u);
+                    g = imax(g, lq + gq - (D == 0 ? 0 : join_same(D, e)));
                 }
                 ln.at(SM + p) = (wp & 0x00ffffffu) | ((uint32_t)g << 24);
             }
             changed = false;
+        }
+        uint64_t zpre = 0;                                  // byte i: mismatching bases between main pieces 0 and i
+        if (changed) {
+            int acc = 0;
+            for (int i = 1; i < r; ++i) { acc += (int)((fr.zc >> (4 * i)) & 15u); zpre |= (uint64_t)acc << (8 * i); }
         }
         for (int pass = 0; pass < 6 && changed; ++pass) {
             changed = false;
@@ -546,7 +564,11 @@ VTXF_FN int32_t back(const Front& fr, int ns, const Lane& ln, const Lane& gl, ui
                     if (t < 0) continue;
                     const int dd = (yp - xp) - (yq - xq);
                     int J = 5 + iabs(dd);
-                    if (dd == 0) { const int D = xp + s - xq - t - 1; J = D == 0 ? 0 : join_same(D); }
+                    if (dd == 0) {
+                        const int D = xp + s - xq - t - 1;
+                        // two main pieces (q before p, whole: s = 0, t = lq - 1): the mismatches between them are counted
+                        J = D == 0 ? 0 : (p < r && q < r ? join_same(D, (int)((zpre >> (8 * p)) & 0xffu) - (int)((zpre >> (8 * q)) & 0xffu)) : join_free(D));
+                    }
                     g = imax(g, t + 1 + gq - J - s);
                 }
                 if (g != g0) { word(p) = (wp & 0x00ffffffu) | ((uint32_t)g << 24); changed = true; }
