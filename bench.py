@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--umi", type=int, default=0)
     ap.add_argument("--indel-frac", type=float, default=0.0)
     ap.add_argument("--sub-error", type=float, default=0.005)
+    ap.add_argument("--genome", default="", help="FASTA: draw the loci from this sequence instead of an iid genome (sensitivity runs, "
+                    "e.g. tests/golden/test_dna.fa: 181 kb of real sequence; the headline workload is the iid one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-aligner", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -185,7 +187,7 @@ def main():
 
     workload = args.workload
     if workload == "auto":
-        workload = "custom" if (args.loci or args.barcodes) else ("config3" if world == 1 else "config4")
+        workload = "custom" if (args.loci or args.barcodes or args.genome) else ("config3" if world == 1 else "config4")
     scaling = args.scaling
     if scaling == "auto":
         scaling = "strong"
@@ -196,7 +198,7 @@ def main():
     # ---- the workload: every rank generates the same batch (same seed) and keeps its range of loci ----
     spec = synth.SynthSpec(n_loci=n_loci, n_barcodes=n_barcodes, reads_per_locus=args.reads_per_locus,
                            use_umi=bool(args.umi), indel_frac=args.indel_frac, sub_error=args.sub_error,
-                           depth_sigma=args.depth_sigma, seed=20260926 + (rank if weak else 0))
+                           depth_sigma=args.depth_sigma, genome_fasta=args.genome, seed=20260926 + (rank if weak else 0))
     t_gen = time.perf_counter()
     whole = synth.make_batch(spec)
     if weak:

@@ -50,7 +50,11 @@ void build_table(uint8_t* tb, const uint8_t* hy, uint32_t hn, uint32_t max_hap, 
 
 extern "C" {
 // Per task t = 2 * record + hap of a packed batch: score[t] (-1: left to band_run_kernel) and why[t].
+// n_heads bit 31: use the four-byte match entries (20 per task) even when every haplotype has <= 255 bases — the variant the
+// device takes for longer haplotypes.
 int vtxt_fastcore_batch(const vtx_batch* b, uint32_t n_heads, int32_t* score, uint32_t* why) {
+    const bool force_wide = (n_heads >> 31) != 0;
+    n_heads &= 0x7fffffffu;
     using namespace vtxf;
     uint32_t max_hap = 8;
     for (uint32_t l = 0; l < b->n_loci; ++l) max_hap = std::max(max_hap, std::max(b->loci[l].ref_len, b->loci[l].alt_len));
@@ -58,6 +62,7 @@ int vtxt_fastcore_batch(const vtx_batch* b, uint32_t n_heads, int32_t* score, ui
     std::vector<uint8_t> gt((size_t)2 * stride + 64);
     std::vector<uint8_t> readbuf;
     uint32_t lane[LANE_WORDS];
+    const bool narrow = max_hap <= 255 && !force_wide;          // (vtxk_launch_band_diag makes the same choice)
     for (uint32_t l = 0; l < b->n_loci; ++l) {
         const vtx_locus& L = b->loci[l];
         build_table(gt.data(), b->hap_arena + L.ref_off, L.ref_len, max_hap, n_heads);
@@ -75,8 +80,14 @@ int vtxt_fastcore_batch(const vtx_batch* b, uint32_t n_heads, int32_t* score, ui
                 tb.uq = tb.ent + tab_uq_off(max_hap, n_heads);
                 tb.pb = tb.ent + tab_pb_off(max_hap, n_heads);
                 tb.hmask = n_heads - 1;
-                Lane ln{lane, 1};
-                const Result res = fast_task(readbuf.data(), (int)R.read_len, tb, (int)(h ? L.alt_len : L.ref_len), ln);
+                Result res;
+                if (narrow) {
+                    const LaneS<uint16_t> ln{lane + S_WORDS, 1, (uint16_t*)lane, 1};
+                    res = fast_task(readbuf.data(), (int)R.read_len, tb, (int)(h ? L.alt_len : L.ref_len), ln);
+                } else {
+                    const LaneS<uint32_t> ln{lane + S_WORDS, 1, lane, 1};
+                    res = fast_task(readbuf.data(), (int)R.read_len, tb, (int)(h ? L.alt_len : L.ref_len), ln);
+                }
                 score[2 * (size_t)r + h] = res.score;
                 why[2 * (size_t)r + h] = res.why;
             }

@@ -3,6 +3,10 @@ and by tools/certify_stress.py / tools/gpu_parity_stress.py, which run the same 
 
   synthetic_batches   config-3 generator from clean to 30 % substitution errors, with indel loci, ragged read lengths and paddings
   repeat_rich_batches tandem-repeat genomes over 2- to 4-letter alphabets: hundreds of k-mer pieces per alignment
+  near_repeat_batches iid genomes with short words copied a few bases further on (period 4-40, 6-12 bases): chance-like off-diagonal
+                      matches AT CHOSEN DISTANCES from the main diagonal — the adversary of band_diag_kernel's far-piece condition
+  real_sequence_batches loci at random positions of tests/golden/test_dna.fa (181 kb of real sequence: 2-3 x the chance 6-mer
+                      matches of iid bases, satellite repeats in the tail)
   real_shape_batches  what real 10x reads add to `150M`: soft-clipped ends (the clip is random sequence), adapter tails, spliced
                       reads (the read skips an intron of the reference: CIGAR N), lower-case / N bases
 """
@@ -72,6 +76,47 @@ def repeat_rich_batches(trials=12, loci=60, reads=24):
                     rl.append((int(rng.integers(0, 30)), 0, bytes(rd)))
             rds.append(rl)
         yield ("repeat-rich, alphabet %s" % alpha.decode(), manual_batch(haps, rds, 30), 30)
+
+
+def near_repeat_batches(trials=8, loci=80, reads=32, seed=4242):
+    rng = np.random.default_rng(seed)
+    for trial in range(trials):
+        n_plant = [1, 2, 4, 8, 12, 3, 6, 16][trial % 8]
+        haps, rds = [], []
+        for _ in range(loci):
+            pad = 100
+            g = bytearray(rng.choice(list(b"ACGT"), 2 * pad + 1 + 400).tolist())
+            for _p in range(n_plant):
+                ln = int(rng.integers(6, 13))
+                per = int(rng.integers(4, 41)) if rng.random() < 0.8 else int(rng.integers(1, 4))
+                y0 = int(rng.integers(150, 150 + 2 * pad - ln - per))
+                g[y0 + per:y0 + per + ln] = g[y0:y0 + ln]
+            g = bytes(g)
+            p = 200 + pad
+            ref = g[p - pad:p + pad + 1]
+            alt = ref[:pad] + bytes([b"ACGT"[(b"ACGT".index(ref[pad:pad + 1]) + 1) % 4]]) + ref[pad + 1:]
+            haps.append((ref, alt))
+            rl = []
+            for _k in range(reads):
+                ln = int(rng.integers(100, 151))
+                s0 = p - int(rng.integers(0, ln))
+                rd = bytearray(g[s0:s0 + ln])
+                if s0 <= p < s0 + ln and rng.random() < 0.5:
+                    rd[p - s0] = alt[pad]
+                for e in np.nonzero(rng.random(len(rd)) < rng.choice([0.0, 0.005, 0.02]))[0]:
+                    rd[e] = b"ACGT"[int(rng.integers(0, 4))]
+                rl.append((int(rng.integers(0, 30)), 0, bytes(rd)))
+            rds.append(rl)
+        yield ("near repeats, %d planted per locus" % n_plant, manual_batch(haps, rds, 30), 30)
+
+
+def real_sequence_batches(trials=3, n_loci=300, reads=24, seed=9000):
+    import os
+    fasta = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test_dna.fa")
+    for trial in range(trials):
+        err = [0.002, 0.01, 0.03][trial % 3]
+        spec = synth.SynthSpec(n_loci=n_loci, n_barcodes=500, reads_per_locus=reads, sub_error=err, genome_fasta=fasta, seed=seed + trial)
+        yield ("real sequence (test_dna.fa), %.1f %% errors" % (100 * err), synth.make_batch(spec), 500)
 
 
 def real_shape_batches(trials=4, loci=80, reads=40, seed=77):

@@ -73,6 +73,21 @@ def test_repeat_rich_and_small_alphabets(core):
         check(core, batch, nb, label)
 
 
+@pytest.mark.parametrize("wide", [0, 1])
+def test_near_repeats_and_real_sequence(core, wide):
+    """The far-piece condition of back() (vtx_fast_core.h, condition (*)): chance-like off-diagonal matches planted 1-40 diagonals
+    from the main one, and loci drawn from 181 kb of real sequence (20-40 off-diagonal matches per task are ordinary there).
+    wide = 1: the four-byte match entries (20 per task) the device uses for haplotypes above 255 bases."""
+    heads = 1024 | (wide << 31)
+    fr = []
+    for label, batch, nb in SB.near_repeat_batches(trials=8):
+        fr.append(check(core, batch, nb, label, heads)[0])
+    assert min(fr) > (0.2 if wide else 0.6) and max(fr) > (0.9 if wide else 0.95), fr
+    fr = [check(core, batch, nb, label, heads)[0] for label, batch, nb in SB.real_sequence_batches(trials=3)]
+    print("decided on real sequence (%s entries): %s" % ("4-byte" if wide else "2-byte", ", ".join("%.3f" % f for f in fr)))
+    assert fr[0] > (0.5 if wide else 0.75), fr
+
+
 def test_real_read_shapes(core):
     """Soft clips, adapter tails, spliced reads, poly-A, N bases (tests/stress_batches.py)."""
     fr = []

@@ -79,6 +79,53 @@ def test_real_read_shapes():
         n, 100.0 * sum(s["left_by_diag_stage"] for s in rows) / n, 100.0 * sum(s["hard"] for s in rows) / n))
 
 
+def test_near_repeats_and_real_sequence():
+    """Off-diagonal matches at chosen distances from the main diagonal and loci drawn from real sequence (tests/stress_batches.py):
+    the far-piece condition of band_diag_kernel on the device, every alignment against the oracle."""
+    rows = []
+    for label, batch, nb in list(SB.near_repeat_batches(trials=8)) + list(SB.real_sequence_batches(trials=3)):
+        rows.append((label, device_vs_oracle(batch, nb, label, aligners=("banded",))))
+    for label, st in rows:
+        print("%s: %d alignments, %.1f %% left by band_diag_kernel, %.2f %% band-masked DP" % (
+            label, st["alignments"], 100.0 * st["left_by_diag_stage"] / st["alignments"], 100.0 * st["hard"] / st["alignments"]))
+    real = rows[8][1]
+    assert real["left_by_diag_stage"] < 0.3 * real["alignments"]       # 40 % with 20 entries and the T-rule (round 3, first version)
+
+
+def test_four_byte_match_entries_give_the_same_scores():
+    """VTX_DIAG_WIDE=1 runs band_diag_kernel<., uint32_t> (20 match entries per task: the variant for haplotypes above 255 bases) on
+    batches that normally take the two-byte variant: identical scores (separate process: the hook is read once)."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import stress_batches as SB
+from vartrix_amd import lib
+from vartrix_amd.abi import default_config
+out = []
+for label, batch, nb in list(SB.near_repeat_batches(trials=3)) + list(SB.real_sequence_batches(trials=1)):
+    with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb)) as ctx:
+        ctx.submit(batch); ctx.run()
+        r, a = ctx.fetch_scores()
+        out.append(r); out.append(a); out.append(np.array([ctx.timing().diag_left], np.int32))
+np.save(sys.argv[1], np.concatenate(out))
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    import tempfile
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for wide in (0, 1):
+            env = dict(os.environ)
+            env.pop("VTX_DIAG_WIDE", None)
+            if wide:
+                env["VTX_DIAG_WIDE"] = "1"
+            path = os.path.join(td, "w%d.npy" % wide)
+            subprocess.check_call([sys.executable, "-c", code, path], env=env)
+            res.append(np.load(path))
+    # the scores agree; the counts of tasks left to band_run_kernel (every fourth block's last entry) differ — that is the point
+    assert res[0].shape == res[1].shape
+    diff = np.nonzero(res[0] != res[1])[0]
+    assert 0 < diff.size <= 4, diff[:10]
+
+
 def test_single_diagonal_stage_on_and_off_give_the_same_scores():
     """VTX_BAND_NO_DIAG=1 runs the banded flavour without band_diag_kernel (band_run_kernel takes every task, the round-2 path):
     identical scores (separate process: the hook is read from the environment)."""

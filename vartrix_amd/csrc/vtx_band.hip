@@ -1487,7 +1487,9 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int WPE>
+// ST: type of an off-diagonal match entry — uint16_t (x << 8 | y: 40 entries per task in the same LDS) when every haplotype of
+// the batch has <= 255 bases, else uint32_t (20 entries).
+template <int WPE, class ST>
 __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     uint32_t n_tasks, uint32_t task_base, uint32_t n_blocks,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
@@ -1519,7 +1521,8 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     int32_t* my_score = nullptr;
     vtxf::Front fr;
     fr.why = vtxf::W_SHAPE; fr.d = 0; fr.need = vtxf::M192{0, 0, 0};
-    const vtxf::Lane ln{lane_mem + tid, 64};
+    typedef vtxf::LaneS<ST> LaneT;
+    const LaneT ln{lane_mem + vtxf::S_WORDS * 64 + tid, 64, (ST*)lane_mem + tid, 64};
     vtxf::Tab tb;
     tb.gt = gtables; tb.ent = tb.head = tb.bytes = tb.uq = tb.pb = 0; tb.hmask = n_heads - 1;
     s_cnt[tid] = 0;
@@ -1673,7 +1676,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             vtxf::walk_bucket(to, w8, hh, raw, [&](uint32_t yc) {
                 if ((int)yc - (int)row == od) return;
                 const uint32_t pos = atomicAdd(&s_cnt[own], 1u);
-                if (pos < (uint32_t)vtxf::SM) lane_mem[pos * 64 + own] = (row << 16) | yc;
+                if (pos < (uint32_t)LaneT::SMAX) ((ST*)lane_mem)[pos * 64 + own] = (ST)((row << LaneT::XS) | yc);
             });
         }
         wave_sync();
@@ -1681,7 +1684,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     if ((stats >> 8) == 2) { if (live && s_cnt[tid] == 0x7fffffff) counters[40] = 1; return; }   // (profiling aid) front + probes
     if (live) {
         const vtxf::Lane gl{(uint32_t*)q_ent + tid, 64};                 // (the queue is dead by now)
-        const int32_t sc = vtxf::back(fr, (int)min(s_cnt[tid], (uint32_t)vtxf::SM + 1u), ln, gl, &why, (int)(stats >> 8));
+        const int32_t sc = vtxf::back(fr, (int)min(s_cnt[tid], (uint32_t)LaneT::SMAX + 1u), ln, gl, &why, (int)(stats >> 8));
         if (sc >= 0) *my_score = sc; else fail = true;
     }
     const uint64_t fm = __ballot(fail);
@@ -1843,9 +1846,17 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(n_loci, 256u * 16u)), dim3(64), 2 * tstride, s, loci, gt_l0, n_loci,
                        hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
     const uint32_t n_blocks = (n_tasks + 255) / 256;
-    hipLaunchKernelGGL(band_diag_kernel<4>, dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
-                       rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                       alt_score, fail_list, counters, (uint32_t)stats | (getenv("VTX_DIAG_ABLATE") ? (uint32_t)atoi(getenv("VTX_DIAG_ABLATE")) << 8 : 0u));
+    const uint32_t st = (uint32_t)stats | (getenv("VTX_DIAG_ABLATE") ? (uint32_t)atoi(getenv("VTX_DIAG_ABLATE")) << 8 : 0u);
+    // two-byte match entries (40 per task) whenever a haplotype position fits a byte; VTX_DIAG_WIDE=1 forces the four-byte variant (tests)
+    static const bool force_wide = getenv("VTX_DIAG_WIDE") != nullptr;
+    if (max_hap <= 255 && !force_wide)
+        hipLaunchKernelGGL((band_diag_kernel<4, uint16_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
+                           rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
+                           alt_score, fail_list, counters, st);
+    else
+        hipLaunchKernelGGL((band_diag_kernel<4, uint32_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
+                           rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
+                           alt_score, fail_list, counters, st);
     return hipGetLastError();
 }
 

@@ -32,18 +32,23 @@
 //   cert   the chain lies on diagonal d, so the staircase of band_finish is the diagonal itself from (first - d0 - t0)
 //          to (last + K + d1 + t1): the certificate is the best local score (match +1, mismatch -5, restart at 0) of M
 //          over that window — a scan over the zeros of M.
-//   ub     the run bound over the GENERIC pieces only: the main-diagonal pieces plus the off-diagonal pieces within
-//          T - 1 diagonals of the hull of the generic diagonals (closure).  The other off-diagonal pieces are FAR: every
-//          one lies >= T diagonals outside the hull.  With E = the number of far k-mer matches (sum of bases - 5 over
-//          the far pieces; E <= ns, the number of off-diagonal matches) and T = max(ns, 5) (6 for ns = 5), so that T >= E, 2T >= E + 6:
-//            * a chain of far pieces between two generic pieces g1, g2 nets at most E - 5 - 2T - |d1 - d2| (every join
-//              costs >= 5 + its diagonal difference, the way out of the hull and back is >= 2T + |d1 - d2|), the direct
-//              join g1 -> g2 costs 5 + |d1 - d2| or J_same <= 11: replacing the excursion by the direct join never
-//              lowers the value;
-//            * far pieces before the first / after the last generic piece net at most E - T <= 0: dropping them never
-//              lowers it;
-//            * a chain of far pieces only is worth at most E + 5.
-//          Hence  full <= max(5, E + 5, ub_generic)  with ub_generic the fixpoint of run_ub over the generic pieces.
+//   ub     the run bound over the GENERIC pieces only: the main-diagonal pieces plus the off-diagonal pieces of the closure
+//          below.  The other off-diagonal pieces are FAR: piece f lies D_f >= 1 diagonals outside the hull of the generic
+//          diagonals and holds E_f k-mer matches (bases - 5).  Condition (*): for every far piece j
+//              sum of E_f over the far pieces with D_f <= D_j   <=   bound(D_j) = min(D_j, 2 D_j - 6).
+//          Take a chain of sub-runs of pieces (the objects of the run bound, oracle/vtx_certify.c) and a maximal run S of
+//          consecutive far pieces in it, D = the largest D_f in S, E = sum of E_f over S <= bound(D) by (*):
+//            * between two generic pieces g1, g2 (diagonals d1, d2 inside the hull): the k + 1 joins cost >= 5 each plus the
+//              way out to distance D and back, >= 2 D + |d1 - d2|, the k pieces bring E + 5 k bases: the excursion nets
+//              <= E - 5 - 2 D - |d1 - d2|; the direct join g1 -> g2 (possible: g2 is entered after g1 is left, in both
+//              coordinates) costs 5 + |d1 - d2|, or J_same <= 11 when d1 == d2.  E <= 2 D - 6: replacing the excursion by
+//              the direct join never lowers the value;
+//            * before the first / after the last generic piece: S nets <= E - D <= 0 (k - 1 joins among the far pieces, one
+//              join >= 5 + the way to the hull): dropping it never lowers the value;
+//            * a chain of far pieces only is worth <= (all far matches) + 5.
+//          Hence  full <= max(5, E_far + 5, ub_generic)  with ub_generic the fixpoint of run_ub over the generic pieces.
+//          (Round 3 first used the special case "every far piece >= T = max(ns, 5) diagonals out": with the 20-40 chance
+//          matches of real sequence T made everything generic.)
 //
 // Capacities: reads up to 192 bases (3 mask words), RM main pieces, SM off-diagonal matches, GM generic off-diagonal
 // pieces; tasks beyond them are not wrong, they are band_run_kernel's.
@@ -80,9 +85,9 @@ static_assert(K == 6 && W == 20 && VTX_REF_MATCH == 1 && VTX_REF_MISMATCH == -5 
 constexpr int LAZY = VTX_BAND_LAZY_EXT(6);
 constexpr int MAX_READ = 192;   // mask capacity
 constexpr int RM = 8;           // main-diagonal pieces
-constexpr int SM = 20;          // off-diagonal k-mer matches
+constexpr int S_WORDS = 20;     // LDS words per lane for the off-diagonal k-mer matches: 40 two-byte entries (haplotypes <= 255 bases) or 20 four-byte ones
 constexpr int GM = 6;           // off-diagonal pieces admitted to the generic set
-constexpr int LANE_WORDS = SM + RM;   // per-lane scratch: off-diagonal matches, main pieces (+ GM words for back(): generic off-diagonal pieces)
+constexpr int LANE_WORDS = S_WORDS + RM;   // per-lane scratch: off-diagonal matches, main pieces (+ GM words for back(): generic off-diagonal pieces)
 constexpr int DMAX = 120;       // diagonal offsets of generic pieces are stored in a signed byte
 constexpr uint32_t UQ_PAD_WORDS = 6;      // zero words in front of a table's unique-k-mer bit array (a negative diagonal reads them)
 constexpr uint32_t HEAD_END = 0xffffu;    // empty bucket / end of a chain
@@ -183,14 +188,25 @@ VTXF_FN int join_same(int D, int e) {
     return imin(6 * e - D, jg);
 }
 
-// per-lane scratch: element i at base[i * stride] (device: LDS, the 64 lanes of a wavefront interleaved; host: stride 1)
-//   [0, SM)                 off-diagonal matches x << 16 | y
-//   [SM, SM + RM)           main pieces: first base | last base << 8 | dp of the first k-mer << 16 | G << 24
+// per-lane scratch (device: LDS, the 64 lanes of a wavefront interleaved; host: stride 1)
+//   s(k), k < SMAX          off-diagonal matches x << XS | y, ST = uint16_t (XS = 8, 40 entries: every haplotype of the batch has
+//                           <= 255 bases — padding 100 with indels up to 54) or uint32_t (XS = 16, 20 entries)
+//   at(i), i < RM           main pieces: first base | last base << 8 | dp of the first k-mer << 16 | G << 24
 // and a second, GM-word scratch for back() only (the device lends it the probe queue's LDS):
-//   [0, GM)                 generic off-diagonal pieces: x | (delta + 128) << 8 | bases << 16 | G << 24
+//   at(i), i < GM           generic off-diagonal pieces: x | (delta + 128) << 8 | bases << 16 | G << 24
 struct Lane {
     uint32_t* base; int stride;
     VTXF_MEM uint32_t& at(int i) const { return base[i * stride]; }
+};
+template <class ST> struct LaneS {
+    typedef ST SType;
+    uint32_t* base; int stride;
+    ST* sb; int sstride;
+    static constexpr int XS = sizeof(ST) == 2 ? 8 : 16;
+    static constexpr int SMAX = S_WORDS * 4 / (int)sizeof(ST);
+    static constexpr uint32_t YM = (1u << XS) - 1u, ONE = (1u << XS) | 1u;
+    VTXF_MEM uint32_t& at(int i) const { return base[i * stride]; }
+    VTXF_MEM ST& s(int k) const { return sb[k * sstride]; }
 };
 
 struct Front {
@@ -287,10 +303,10 @@ VTXF_FN bool verify_diag(const uint8_t* x, int m, const Tab& tb, int n, int dc) 
     const int p = vlo + ((vhi - vlo - 8) >> 1);
     return __builtin_popcount(eq8(ld8(x + p), ld8(tb.gt + tb.bytes + (p + dc)))) >= 6;
 }
-VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const Lane& ln, int d, M192 M);
+template <class LN> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, int d, M192 M);
 
 // one lane on its own: the six sample rows in turn; a candidate is kept if its mask has at least 20 matching bases
-VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, int n, const Lane& ln) {
+template <class LN> VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln) {
     Front fr;
     fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.zc = 0; fr.need = M192{0, 0, 0};
     if (m < K || n < K || m > MAX_READ) { fr.why = W_SHAPE; return fr; }
@@ -309,7 +325,7 @@ VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, int n, const Lane& l
 }
 
 // everything of phase 1 behind the choice of the diagonal d (M = diag_mask(d))
-VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const Lane& ln, int d, M192 M) {
+template <class LN> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, int d, M192 M) {
     (void)x;
     Front fr;
     fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.zc = 0; fr.need = M192{0, 0, 0};
@@ -342,7 +358,7 @@ VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const La
             const int Vl = dpl + 2 * (b + K);
             if (Vl >= bestV) { bestV = Vl; bestRoot = root; }
             if (dpl >= best_dp) { best_dp = dpl; best_root = root; best_last = v; }
-            ln.at(SM + r) = (uint32_t)u | ((uint32_t)v << 8) | ((uint32_t)dpf << 16);
+            ln.at(r) = (uint32_t)u | ((uint32_t)v << 8) | ((uint32_t)dpf << 16);
             ++r;
         };
         m_for_each(m_andn(m_range(vlo, vhi), M), [&](int z) { piece(prev + 1, z - 1); prev = z; ++nz; });
@@ -399,7 +415,8 @@ VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const La
 // ---- phase 2, one lane on its own: the rows of fr.need four at a time (their loads go out together); a row whose k-mer is not
 //      in the haplotype's presence bitmap is done after one word.  Returns the number of off-diagonal matches appended to
 //      ln[0 ..), or SM + 1 when there are more than SM. ----
-VTXF_FN int probe_rows(const uint8_t* x, const Tab& tb, const Front& fr, const Lane& ln) {
+template <class LN> VTXF_FN int probe_rows(const uint8_t* x, const Tab& tb, const Front& fr, const LN& ln) {
+    constexpr int SM = LN::SMAX;
     const uint8_t* head = tb.gt + tb.head;
     const uint32_t* pb = (const uint32_t*)(tb.gt + tb.pb);
     M192 need = fr.need;
@@ -419,7 +436,7 @@ VTXF_FN int probe_rows(const uint8_t* x, const Tab& tb, const Front& fr, const L
             const uint32_t hh = kw_mix((uint32_t)w8[t], (uint32_t)(w8[t] >> 32) & 0xffffu);
             walk_bucket(tb, w8[t], hh, ld2(head + 2u * kw_bucket(hh, tb.hmask)), [&](uint32_t yc) {
                 if ((int)yc - row[t] == fr.d) return;
-                if (ns < SM) ln.at(ns) = ((uint32_t)row[t] << 16) | yc;
+                if (ns < SM) ln.s(ns) = (typename LN::SType)(((uint32_t)row[t] << LN::XS) | yc);
                 ++ns;
             });
         }
@@ -430,27 +447,29 @@ VTXF_FN int probe_rows(const uint8_t* x, const Tab& tb, const Front& fr, const L
 
 // ---- phase 3 ----
 // Returns the score (>= 0) or -1 with *why set.
-VTXF_FN int32_t back(const Front& fr, int ns, const Lane& ln, const Lane& gl, uint32_t* why, int ablate = 0) {
+template <class LN> VTXF_FN int32_t back(const Front& fr, int ns, const LN& ln, const Lane& gl, uint32_t* why, int ablate = 0) {
+    constexpr int SM = LN::SMAX, XS = LN::XS;
+    constexpr uint32_t YM = LN::YM, ONE = LN::ONE;
     const int d = fr.d, r = fr.r;
     if (ns > SM) { *why = W_MATCHES; return -1; }
     // (x, y) order (a lane probing its own rows produces it; pooled probes arrive in any order)
     for (int k = 1; k < ns; ++k) {
-        const uint32_t v = ln.at(k);
+        const uint32_t v = ln.s(k);
         int j = k - 1;
-        while (j >= 0 && ln.at(j) > v) { ln.at(j + 1) = ln.at(j); --j; }
-        ln.at(j + 1) = v;
+        while (j >= 0 && ln.s(j) > v) { ln.s(j + 1) = ln.s(j); --j; }
+        ln.s(j + 1) = (typename LN::SType)v;
     }
     // ---- harmless test of every off-diagonal match ----
     int far_e = 0, runmax = 0;
     const int nc = ns;
     for (int k = 0; k < ns; ++k) {
-        const uint32_t w = ln.at(k);
-        const int sx = (int)(w >> 16), sy = (int)(w & 0xffffu);
+        const uint32_t w = ln.s(k);
+        const int sx = (int)(w >> XS), sy = (int)(w & YM);
         const int q = sx + sy - d;
         const int lim = imin(sx, sy - d) - K;                      // last main row that ends before (sx, sy)
         int bv = -1000000, minH = 1000000;
         for (int i = 0; i < r; ++i) {
-            const uint32_t pw = ln.at(SM + i);
+            const uint32_t pw = ln.at(i);
             const int pu = (int)(pw & 0xffu), pv = (int)((pw >> 8) & 0xffu), dpf = (int)((pw >> 16) & 0xffu);
             const int lm1 = pv - 5 - pu;
             const int t = imin(lim - pu, lm1);
@@ -465,54 +484,70 @@ VTXF_FN int32_t back(const Front& fr, int ns, const Lane& ln, const Lane& gl, ui
         if (dp >= fr.best_dp || dp + q + 2 * K + 1 >= minH) { *why = W_NOT_HARMLESS; return -1; }
     }
     if (ablate == 5) { *why = W_NOT_TIGHT; return -1 - runmax; }          // (profiling aid) sort + harmless tests only
-    // ---- generic set: closure of the hull over the off-diagonal pieces.  T = the smallest distance the far-piece lemma
-    //      allows for E <= ns far matches: T >= E and 2T >= E + 6 (J_same <= 11) ----
-    const int TFAR = imax(ns, ns <= 4 ? 5 : 6);
+    // ---- generic set: the main pieces plus the off-diagonal pieces that may not be left out as FAR (header: condition (*)).
+    //      Far matches are binned by their distance D from the hull of the generic diagonals; the cumulative count up to a
+    //      bin's upper edge must stay within bound(lower edge), bound(t) = min(t, 2t - 6) — conservative for (*), which asks
+    //      cnt(D' <= D) <= bound(D) at every far match.  On a violation the nearest far piece joins the generic set (the hull
+    //      grows, every distance is taken again). ----
     int ng = 0;
     {
         int hull_lo = 0, hull_hi = 0;
-        uint32_t used = 0;
-        bool grew = true;
-        while (grew) {
-            grew = false;
+        uint64_t used = 0;
+        for (;;) {
+            // cumulative counters, one byte each: D <= 5, 7, 11, 15, 23, 31, 39 (a match at D >= 40 > ns can never be in the way)
+            uint64_t cum = 0;
+            int near_k = -1, near_d = 1 << 20;
             for (int k = 0; k < nc; ++k) {
-                if ((used >> k) & 1u) continue;
-                const uint32_t w = ln.at(k);
-                const int sx = (int)(w >> 16), sy = (int)(w & 0xffffu);
-                const int delta = sy - sx - d;
-                if (delta > hull_hi + TFAR - 1 || delta < hull_lo - TFAR + 1) continue;      // (still) far
-                // a match that continues another one belongs to that one's piece (it sits in the row before)
-                bool is_head = true;
-                for (int j = k - 1; j >= 0; --j) {
-                    const uint32_t wj = ln.at(j);
-                    if ((int)(wj >> 16) + 1 < sx) break;
-                    if (wj + 0x10001u == w) is_head = false;
+                if ((used >> k) & 1ull) continue;
+                const uint32_t w = ln.s(k);
+                const int delta = (int)(w & YM) - (int)(w >> XS) - d;
+                const int D = delta > hull_hi ? delta - hull_hi : (delta < hull_lo ? hull_lo - delta : 0);
+                if (D < near_d) { near_d = D; near_k = k; }
+                if (D < 40) {
+                    const int bin = (D >= 6) + (D >= 8) + (D >= 12) + (D >= 16) + (D >= 24) + (D >= 32);
+                    cum += 0x0001010101010101ull << (8 * bin);
                 }
-                if (!is_head) continue;
-                int len = 1;
-                uint32_t members = 1u << k;
-                for (int j = k + 1; j < nc; ++j) {
-                    const uint32_t wj = ln.at(j);
-                    if ((int)(wj >> 16) > sx + len) break;
-                    if (wj == w + (uint32_t)len * 0x10001u) { ++len; members |= 1u << j; }
-                }
-                if (ng == GM || iabs(delta) > DMAX) { *why = W_GENERIC; return -1; }
-                gl.at(ng) = (uint32_t)sx | ((uint32_t)(delta + 128) << 8) | ((uint32_t)(len + K - 1) << 16);
-                ++ng;
-                used |= members;
-                hull_lo = imin(hull_lo, delta); hull_hi = imax(hull_hi, delta);
-                grew = true;
             }
+            if (near_k < 0) break;                                        // nothing is far
+            bool ok = near_d >= 4;                                         // bound(t) <= 0 for t <= 3
+            if (ok) {
+                const uint64_t lim = 0x002018100c080602ull;                // bound(4, 6, 8, 12, 16, 24, 32), one byte each
+                // every byte of cum <= its byte of lim: byte-wise (0x80 + lim) - cum keeps bit 7 (no borrow crosses a byte: cum <= SM < 128)
+                ok = (((lim | 0x8080808080808080ull) - cum) & 0x0080808080808080ull) == 0x0080808080808080ull;
+            }
+            if (ok) break;
+            // the nearest far match: its piece (head = the match no other match continues into; members = its continuations)
+            int k = near_k;
+            for (int j = k - 1; j >= 0; --j) {
+                const uint32_t wj = ln.s(j);
+                if ((int)(wj >> XS) + 1 < (int)((uint32_t)ln.s(k) >> XS)) break;
+                if (wj + ONE == (uint32_t)ln.s(k)) { k = j; }
+            }
+            const uint32_t w = ln.s(k);
+            const int sx = (int)(w >> XS), sy = (int)(w & YM);
+            const int delta = sy - sx - d;
+            int len = 1;
+            uint64_t members = 1ull << k;
+            for (int j = k + 1; j < nc; ++j) {
+                const uint32_t wj = ln.s(j);
+                if ((int)(wj >> XS) > sx + len) break;
+                if (wj == w + (uint32_t)len * ONE) { ++len; members |= 1ull << j; }
+            }
+            if (ng == GM || iabs(delta) > DMAX) { *why = W_GENERIC; return -1; }
+            gl.at(ng) = (uint32_t)sx | ((uint32_t)(delta + 128) << 8) | ((uint32_t)(len + K - 1) << 16);
+            ++ng;
+            used |= members;
+            hull_lo = imin(hull_lo, delta); hull_hi = imax(hull_hi, delta);
         }
-        // what the closure left is >= T diagonals outside the hull: far.  E = their k-mer matches
-        far_e = nc - __builtin_popcount(used);
+        // what is left is far.  E = their k-mer matches
+        far_e = nc - __builtin_popcountll(used);
     }
     if (ablate == 6) { *why = W_NOT_TIGHT; return -1 - far_e - ng; }      // (profiling aid) ... + closure
     // ---- run bound over the generic pieces: main pieces at ln[SM, SM + r), off-diagonal ones at gl[0, ng) ----
     int ub = imax(K - 1, far_e > 0 ? far_e + 5 : 0);
     {
         const int n_all = r + ng;
-        auto word = [&](int i) -> uint32_t& { return i < r ? ln.at(SM + i) : gl.at(i - r); };
+        auto word = [&](int i) -> uint32_t& { return i < r ? ln.at(i) : gl.at(i - r); };
         auto decode = [&](int i, uint32_t w, int& xp, int& yp, int& lp) {
             if (i < r) { xp = (int)(w & 0xffu); yp = xp + d; lp = (int)((w >> 8) & 0xffu) - xp + 1; }
             else { xp = (int)(w & 0xffu); yp = xp + d + (int)((w >> 8) & 0xffu) - 128; lp = (int)((w >> 16) & 0xffu); }
@@ -524,18 +559,18 @@ VTXF_FN int32_t back(const Front& fr, int ns, const Lane& ln, const Lane& gl, ui
             // main pieces only: all on one diagonal, in base order — a predecessor always lies before its successor, so one pass over
             // the ordered pairs q < p settles every G (no back edges), and every join is a same-diagonal join
             for (int p = 1; p < r; ++p) {
-                const uint32_t wp = ln.at(SM + p);
+                const uint32_t wp = ln.at(p);
                 const int xp = (int)(wp & 0xffu);
                 int g = 0, e = 0;
                 for (int q = p - 1; q >= 0; --q) {
-                    const uint32_t wq = ln.at(SM + q);
+                    const uint32_t wq = ln.at(q);
                     const int xq = (int)(wq & 0xffu), lq = (int)((wq >> 8) & 0xffu) - xq + 1, gq = (int)(wq >> 24);
                     // entry at the first base of p (s = 0), q used whole (t = lq - 1): D bases between them, e of them mismatches
                     const int D = xp - (xq + lq);
                     e += (int)((fr.zc >> (4 * (q + 1))) & 15u);
                     g = imax(g, lq + gq - (D == 0 ? 0 : join_same(D, e)));
                 }
-                ln.at(SM + p) = (wp & 0x00ffffffu) | ((uint32_t)g << 24);
+                ln.at(p) = (wp & 0x00ffffffu) | ((uint32_t)g << 24);
             }
             changed = false;
         }
@@ -589,7 +624,7 @@ VTXF_FN int32_t back(const Front& fr, int ns, const Lane& ln, const Lane& gl, ui
 
 struct Result { int32_t score; uint32_t why; };
 // all three phases on one lane (host test; device variant without pooled probes)
-VTXF_FN Result fast_task(const uint8_t* x, int m, const Tab& tb, int n, const Lane& ln) {
+template <class LN> VTXF_FN Result fast_task(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln) {
     const Front fr = front(x, m, tb, n, ln);
     if (fr.why != W_OK) return Result{-1, fr.why};
     const int ns = probe_rows(x, tb, fr, ln);

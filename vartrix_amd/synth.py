@@ -23,6 +23,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import os
+
 import numpy as np
 
 from .abi import LOCUS_DTYPE, RECORD_DTYPE, PackedBatch
@@ -46,14 +48,17 @@ class SynthSpec:
     umi_flip: float = 0.02
     read_len_jitter: int = 0     # reads get length read_len - U[0, jitter]
     depth_sigma: float = 0.0     # > 0: reads per locus ~ log-normal, median reads_per_locus, this sigma (>= 1 read)
+    genome_fasta: str = ""       # SNV fast path only: loci at random positions of THIS sequence (its ACGT bases) instead of an
+                                 # iid genome — real sequence has 2-3x the chance 6-mer matches of iid bases, and repeats
 
     @property
     def name(self) -> str:
         kind = "SNV" if self.indel_frac == 0 else "SNV+indel<=%d" % self.max_indel
         depth = "%d" % self.reads_per_locus if self.depth_sigma == 0 else "log-normal(median %d, sigma %g)" % (
             self.reads_per_locus, self.depth_sigma)
-        return "synthetic %d %s loci x %d barcodes, %s x %dbp reads/locus%s" % (
-            self.n_loci, kind, self.n_barcodes, depth, self.read_len, ", UMI" if self.use_umi else "")
+        return "synthetic %d %s loci x %d barcodes, %s x %dbp reads/locus%s%s" % (
+            self.n_loci, kind, self.n_barcodes, depth, self.read_len, ", UMI" if self.use_umi else "",
+            ", loci drawn from " + os.path.basename(self.genome_fasta) if self.genome_fasta else "")
 
 
 
@@ -91,8 +96,17 @@ def _make_batch_snv(spec: SynthSpec, chunk_loci: int = 4096) -> PackedBatch:
     generated with row gathers from sliding windows of the genome (no per-base index arrays)."""
     rng = np.random.default_rng(spec.seed)
     V, B, R, Lr, pad = spec.n_loci, spec.n_barcodes, spec.reads_per_locus, spec.read_len, spec.padding
-    genome_codes = rng.integers(0, 4, size=1000 * V + 1000, dtype=np.uint8)
-    genome = _ACGT[genome_codes]
+    if spec.genome_fasta:
+        raw = np.frombuffer(b"".join(l.strip().upper() for l in open(spec.genome_fasta, "rb") if not l.startswith(b">")), np.uint8)
+        genome = raw[np.isin(raw, _ACGT)]
+        if genome.shape[0] < 4 * (Lr + pad):
+            raise ValueError("genome_fasta holds too few ACGT bases")
+        genome_codes = np.searchsorted(_ACGT, genome).astype(np.uint8)
+        all_pos0 = rng.integers(Lr + pad, genome.shape[0] - Lr - pad, size=V)
+    else:
+        genome_codes = rng.integers(0, 4, size=1000 * V + 1000, dtype=np.uint8)
+        genome = _ACGT[genome_codes]
+        all_pos0 = 500 + 1000 * np.arange(V, dtype=np.int64)
     read_rows = np.lib.stride_tricks.sliding_window_view(genome, Lr)
     hap_len = 2 * pad + 1
     hap_rows = np.lib.stride_tricks.sliding_window_view(genome, hap_len)
@@ -103,7 +117,7 @@ def _make_batch_snv(spec: SynthSpec, chunk_loci: int = 4096) -> PackedBatch:
         b = min(a + chunk_loci, V)
         nl = b - a
         li = np.arange(a, b, dtype=np.int64)
-        pos0 = 500 + 1000 * li
+        pos0 = all_pos0[a:b]
         snv_alt = _ACGT[(genome_codes[pos0] + 1 + rng.integers(0, 3, size=nl)) % 4]
         haps = np.empty((nl, 2, hap_len), np.uint8)
         haps[:, 0, :] = hap_rows[pos0 - pad]
@@ -171,6 +185,8 @@ def _make_batch_snv(spec: SynthSpec, chunk_loci: int = 4096) -> PackedBatch:
 def make_batch(spec: SynthSpec, chunk_loci: int = 2048) -> PackedBatch:
     if spec.indel_frac == 0 and spec.read_len_jitter == 0 and spec.read_len <= 499 - spec.padding:
         return _make_batch_snv(spec)
+    if spec.genome_fasta:
+        raise ValueError("genome_fasta is implemented for the SNV fast path only")
     rng = np.random.default_rng(spec.seed)
     V, B, R, Lr, pad = spec.n_loci, spec.n_barcodes, spec.reads_per_locus, spec.read_len, spec.padding
     margin = 4 * (Lr + pad + spec.max_indel + 8)
