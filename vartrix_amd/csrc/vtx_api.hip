@@ -1043,7 +1043,10 @@ int vtx_run(vtx_ctx* c) {
                                 vtxk_band_lds_stride(kLdsMatches, c->max_hap_len, c->max_read_len) <= 160 * 1024 - 512;
             fb.cap2 = in_lds ? kLdsMatches : (uint32_t)std::max<uint64_t>(std::min<uint64_t>((uint64_t)fb.cap2 * 16, worst), 512);
             const size_t stride2 = vtxk_band_ws_stride(fb.cap2, c->max_hap_len);
-            if (!in_lds) HIP_TRY(c, c->d_band_ws2.reserve(((size_t)fb.todo + 63) / 64 * 64 * stride2));   // whole wavefronts: the 64 slabs are interleaved
+            if (!in_lds) {                                                  // whole wavefronts: the 64 slabs are interleaved, vtxk_band_lanes() of them in use
+                const size_t lanes = vtxk_band_lanes(fb.todo);
+                HIP_TRY(c, c->d_band_ws2.reserve(lanes < 64 ? (size_t)fb.todo * stride2 : ((size_t)fb.todo + 63) / 64 * 64 * stride2));   // (sparse lanes: a contiguous slab per task)
+            }
             HIP_TRY(c, hipMemsetAsync(d_cnt + 9, 0, sizeof(uint32_t), s2));
             uint32_t* other = c->d_over2.as<uint32_t>() + ((fb.tasks == c->d_over2.as<uint32_t>()) ? fb.n_over : 0);
             HIP_TRY(c, vtxk_launch_band(fb.tasks, fb.todo, 0, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),

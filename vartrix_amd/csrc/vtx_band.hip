@@ -295,7 +295,7 @@ __device__ void band_ranges(const band_scratch_t<S>& sc, int cA, int cB, int m, 
 // lane each, the other lanes idle): a serial lane pays ~30 ns per dependent access instead of a round trip to HBM —
 // for a FEW tasks (shallow data: a few hundred overflows per run, whose 2 ms of latency were a third of the step);
 // many tasks keep the global slabs, where every lane of the chip works.
-template <bool IN_LDS>
+template <bool IN_LDS, int SG = 64>
 __global__ __launch_bounds__(64) void band_kernel(
     const uint32_t* __restrict__ tasks, uint32_t n_tasks, uint32_t task_base,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
@@ -304,13 +304,17 @@ __global__ __launch_bounds__(64) void band_kernel(
     int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint16_t* __restrict__ band, uint32_t band_stride, uint32_t* __restrict__ hard_list,
     uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters, uint32_t lds_tasks, uint32_t max_read) {
+    // lds_tasks: IN_LDS: tasks per workgroup; global slabs: ACTIVE lanes per wavefront (a power of two <= 64).  The lanes of a
+    // wavefront run different serial loops (event order, Fenwick depths, chain lengths all differ): the wavefront pays for the
+    // union of their paths.  A short list (config 3: 9 k tasks on a chip that holds 260 k lanes) spreads thin instead.
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_slab[];
     uint32_t slot;
     if constexpr (IN_LDS) {
         if (threadIdx.x >= lds_tasks) return;
         slot = blockIdx.x * lds_tasks + threadIdx.x;
     } else {
-        slot = blockIdx.x * blockDim.x + threadIdx.x;
+        if (threadIdx.x >= lds_tasks) return;
+        slot = blockIdx.x * lds_tasks + threadIdx.x;
     }
     if (slot >= n_tasks) return;
     const uint32_t task = tasks ? tasks[slot] : task_base + slot;
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(64) void band_kernel(
     const int m = (int)rec.read_len, n = (int)(hap ? loc.alt_len : loc.ref_len);
     if (m == 0 || n == 0) { (hap ? alt_score : ref_score)[rid] = 0; return; }
     // IN_LDS: a contiguous slab per task; global: the slabs of a wavefront's 64 tasks interleaved element by element
-    constexpr int S = IN_LDS ? 1 : 64;
+    constexpr int S = IN_LDS ? 1 : SG;
     band_scratch_t<S> sc;
     if constexpr (IN_LDS) {
         uint8_t* ws = lds_slab + (size_t)threadIdx.x * ws_stride;
@@ -334,7 +338,8 @@ __global__ __launch_bounds__(64) void band_kernel(
         for (int j = 0; j < n; ++j) yl[j] = y[j];
         x = xl; y = yl;
     } else {
-        sc.carve(workspace + (uint64_t)(slot & ~63u) * ws_stride, slot & 63u, m_cap, max_hap);
+        if constexpr (SG == 1) sc.carve(workspace + (uint64_t)slot * ws_stride, 0, m_cap, max_hap);      // a contiguous slab per task
+        else sc.carve(workspace + (uint64_t)blockIdx.x * 64u * ws_stride, threadIdx.x, m_cap, max_hap);
     }
     int32_t cert = 0;
     int cA = 0, cB = 0;
@@ -347,6 +352,14 @@ __global__ __launch_bounds__(64) void band_kernel(
     band_ranges(sc, cA, cB, m, n, lo, lo + band_stride);
 }
 
+// active lanes per wavefront of band_kernel<false> for a list of n_tasks (the workspace holds 64 slabs per wavefront either way)
+extern "C" uint32_t vtxk_band_lanes(uint32_t n_tasks) {
+    static const int forced = getenv("VTX_BAND_LANES") ? atoi(getenv("VTX_BAND_LANES")) : 0;       // experiment knob
+    if (forced) return (uint32_t)forced;
+    uint32_t lanes = 64;
+    while (lanes > 4 && (n_tasks + lanes - 1) / lanes < 4096u) lanes >>= 1;        // >= 4096 wavefronts: 16 per CU
+    return lanes;
+}
 extern "C" size_t vtxk_band_ws_stride(uint32_t m_cap, uint32_t max_hap) {
     size_t o = HASH_SIZE * 2 + 3 * ((size_t)max_hap + 2) * 2;
     o = (o + 15) & ~(size_t)15;
@@ -380,9 +393,15 @@ extern "C" hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, 
                            max_hap, ref_score, alt_score, band, band_stride, hard_list, overflow_list, counters, per_wg, max_read);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(band_kernel<false>, dim3((n_tasks + 63) / 64), dim3(64), 0, s, tasks, n_tasks, task_base, records,
-                       rec_locus, loci, read_arena, hap_arena, workspace, ws_stride, m_cap, max_hap, ref_score, alt_score,
-                       band, band_stride, hard_list, overflow_list, counters, 0u, 0u);
+    const uint32_t lanes = vtxk_band_lanes(n_tasks);
+    if (lanes < 64)
+        hipLaunchKernelGGL((band_kernel<false, 1>), dim3((n_tasks + lanes - 1) / lanes), dim3(64), 0, s, tasks, n_tasks, task_base, records,
+                           rec_locus, loci, read_arena, hap_arena, workspace, ws_stride, m_cap, max_hap, ref_score, alt_score,
+                           band, band_stride, hard_list, overflow_list, counters, lanes, 0u);
+    else
+        hipLaunchKernelGGL((band_kernel<false, 64>), dim3((n_tasks + lanes - 1) / lanes), dim3(64), 0, s, tasks, n_tasks, task_base, records,
+                           rec_locus, loci, read_arena, hap_arena, workspace, ws_stride, m_cap, max_hap, ref_score, alt_score,
+                           band, band_stride, hard_list, overflow_list, counters, lanes, 0u);
     return hipGetLastError();
 }
 

@@ -68,6 +68,7 @@ hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base, const vtx
                                  uint32_t tasks_per_locus, uint32_t gt_l0, uint32_t n_loci, uint8_t* gtables,
                                  size_t gtables_bytes, int stats, hipStream_t s);
 int vtxk_band_second_chance(uint32_t tasks_per_locus, int long_lists);
+uint32_t vtxk_band_lanes(uint32_t n_tasks);
 size_t vtxk_band_gtables_bytes(uint32_t n_loci, uint32_t max_hap, uint32_t tasks_per_locus, uint32_t* loci_cap);
 uint32_t vtxk_band_task_words(void);
 uint32_t vtxk_band_pend_words(void);
