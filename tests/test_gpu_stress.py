@@ -126,6 +126,43 @@ np.save(sys.argv[1], np.concatenate(out))
     assert 0 < diff.size <= 4, diff[:10]
 
 
+def test_cooperative_and_serial_general_kernel_give_the_same_scores():
+    """VTX_BAND_NO_COOP=1 sends the tasks whose piece lists overflow to band_kernel (one lane per task) instead of
+    band_coop_kernel (a wavefront per task, everything in LDS): identical scores and identical counts of hard tasks on repeat-rich
+    genomes and on loci drawn from real sequence — the two build the same band (separate process: the hook is read once)."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import stress_batches as SB
+from vartrix_amd import lib
+from vartrix_amd.abi import default_config
+out = []
+over = 0
+for label, batch, nb in list(SB.repeat_rich_batches(trials=4)) + list(SB.real_sequence_batches(trials=2)) + list(SB.near_repeat_batches(trials=8))[4:6]:
+    with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb)) as ctx:
+        ctx.submit(batch); ctx.run()
+        r, a = ctx.fetch_scores()
+        t = ctx.timing()
+        out.append(r); out.append(a); out.append(np.array([t.hard_tasks, t.overflow_tasks], np.int32))
+        over += int(t.overflow_tasks)
+out.append(np.array([over], np.int32))
+np.save(sys.argv[1], np.concatenate(out))
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    import tempfile
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for serial in (0, 1):
+            env = dict(os.environ)
+            env.pop("VTX_BAND_NO_COOP", None)
+            if serial:
+                env["VTX_BAND_NO_COOP"] = "1"
+            path = os.path.join(td, "s%d.npy" % serial)
+            subprocess.check_call([sys.executable, "-c", code, path], env=env)
+            res.append(np.load(path))
+    assert res[0].shape == res[1].shape and np.array_equal(res[0], res[1])
+    assert res[0][-1] > 1000                                   # tasks really took the general path
+
+
 def test_single_diagonal_stage_on_and_off_give_the_same_scores():
     """VTX_BAND_NO_DIAG=1 runs the banded flavour without band_diag_kernel (band_run_kernel takes every task, the round-2 path):
     identical scores (separate process: the hook is read from the environment)."""

@@ -1039,6 +1039,23 @@ int vtx_run(vtx_ctx* c) {
         auto fallback_launch = [&]() -> int {
             const uint64_t worst = (uint64_t)c->max_read_len * c->max_hap_len;
             if (fb.cap2 >= worst && fb.cap2 >= 512) return fail(c, VTX_E_STATE, "vtx_run: band kernel overflow with a worst-case slab");
+            // first two rounds: the cooperative kernel, everything in LDS (band_coop_kernel: a wavefront per task, up to 1024 matches,
+            // then up to 4096; reads up to 256 bases); what that cannot hold takes the serial kernel below
+            static const bool no_coop = getenv("VTX_BAND_NO_COOP") != nullptr;             // experiment / test hook
+            const int tier = fb.cap2 < 512 ? 0 : (fb.cap2 == 1024 ? 1 : -1);
+            if (tier >= 0 && !no_coop && c->max_read_len <= 256 &&
+                vtxk_band_coop_lds(c->max_hap_len, tier ? 4096u : 1024u) <= (tier ? 64u : 16u) * 1024) {
+                fb.cap2 = tier ? 4096 : 1024;
+                HIP_TRY(c, hipMemsetAsync(d_cnt + 9, 0, sizeof(uint32_t), s2));
+                uint32_t* other = c->d_over2.as<uint32_t>() + ((fb.tasks == c->d_over2.as<uint32_t>()) ? fb.n_over : 0);
+                HIP_TRY(c, vtxk_launch_band_coop(tier, fb.tasks, fb.todo, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                 c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->max_hap_len,
+                                                 c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_band2.as<uint16_t>(), band_stride,
+                                                 c->d_hard2.as<uint32_t>(), other, d_cnt + 8, s2));
+                HIP_TRY(c, hipMemcpyAsync(c->h_pin, d_cnt + 8, sizeof fb.gcnt, hipMemcpyDeviceToHost, s2));
+                ++launches;
+                return VTX_OK;
+            }
             const bool in_lds = fb.cap2 < 512 && fb.todo <= kLdsTasks && !getenv("VTX_BAND_NO_LDS_FALLBACK") &&
                                 vtxk_band_lds_stride(kLdsMatches, c->max_hap_len, c->max_read_len) <= 160 * 1024 - 512;
             fb.cap2 = in_lds ? kLdsMatches : (uint32_t)std::max<uint64_t>(std::min<uint64_t>((uint64_t)fb.cap2 * 16, worst), 512);

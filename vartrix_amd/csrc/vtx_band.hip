@@ -352,6 +352,310 @@ __global__ __launch_bounds__(64) void band_kernel(
     band_ranges(sc, cA, cB, m, n, lo, lo + band_stride);
 }
 
+// =============================================================================================
+// band_coop_kernel — the general path for ONE task per WAVEFRONT (round 3; band_kernel above is one task per lane).
+// Tasks reach the general path because their piece lists overflow: repeats (satellites, poly-A, microsatellites) with hundreds
+// of k-mer matches.  On loci drawn from real sequence that is 12 % of the tasks, and one serial lane per task with its slab in
+// global memory took 650 of the step's 800 ms.  Here the 64 lanes share the task, everything lives in LDS:
+//   A  k-mer matches: a lane per read row compares its 6 bytes with every haplotype 6-mer (an LDS broadcast per column) —
+//      count pass, prefix sum over the rows, write pass: the list comes out in (x, y) order, as find_kmer_matches gives it.
+//   B  sdpkpp row by row.  The reference processes events in (x, y) order, END events (x + k, y + k) before START events at
+//      equal coordinates.  All END events of row X (the matches of row X - k) first, then all START events of row X, gives
+//      every START the same query result: an END of the same row with a larger column is outside its prefix either way.  The
+//      max-Fenwick tree holds v << 16 | match index (v = dp + xe + ye < 2^16, index < 2^16: ent_gt is the unsigned order), so
+//      an update is ds_max_u32 along the tree path and the lanes of a row need no other ordering.  The continuation partner
+//      of a START (the match one step up its diagonal) is a binary search in the previous row.
+//   C  the staircase: traceback by one lane, then a lane per chain link writes the anchor rows of its columns (consecutive
+//      links own consecutive column ranges; a vertical run raises rmax of ONE column, possibly the previous link's last: an
+//      atomic max in a second pass), then a lane per column turns rmin / rmax into the band's row range (band_ranges).
+// Same outputs as band_kernel: hard_list + band[] (or the full-matrix marker), overflow_list for tasks beyond CAP matches
+// or the LDS shapes (they take band_kernel).  counters[0] = hard tasks, counters[1] = overflows.
+// =============================================================================================
+__device__ __forceinline__ void wave_sync();
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v = max(v, __shfl_xor(v, d));
+    return v;
+}
+#define COOP_MAX_READ 256u
+#define COOP_NONE 0xffffu
+// bytes of LDS per task for MC matches
+extern "C" size_t vtxk_band_coop_lds(uint32_t max_hap, uint32_t mc) {
+    const size_t cols = ((size_t)max_hap + KMER + 9) & ~(size_t)1;
+    // mt, dpv: 4 B per match; cont: 2 B; row_off: u16 x (COOP_MAX_READ + 4); path: u16 x COOP_MAX_READ; tree: u32 x cols;
+    // rmin, rmax: u32 x cols each (the 8-byte haplotype words of phase A alias them: 8-byte aligned)
+    // lastm: u32 x cols x 2 (the match of the last two rows at every column: the continuation partner without a search)
+    const size_t o = (size_t)mc * 10 + 2 * (COOP_MAX_READ + 4) + 2 * COOP_MAX_READ + 4 * cols + 8 * cols + 8 * cols;
+    return (o + 63) & ~(size_t)63;
+}
+
+// G lanes per task (64 / G tasks per wavefront, in lockstep), MC matches per task
+template <int G, int MC>
+__global__ __launch_bounds__(64) void band_coop_kernel(
+    const uint32_t* __restrict__ tasks, uint32_t n_tasks,
+    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
+    const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena, uint32_t max_hap, uint32_t task_bytes,
+    int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
+    uint16_t* __restrict__ band, uint32_t band_stride, uint32_t* __restrict__ hard_list,
+    uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters, uint32_t ablate) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t coop_lds[];
+    constexpr int TPW = 64 / G;                                       // tasks per wavefront
+    const int grp = threadIdx.x / G, l = threadIdx.x % G;
+    const uint32_t cols = (max_hap + KMER + 9u) & ~1u;
+    uint8_t* base = coop_lds + (size_t)grp * task_bytes;
+    uint32_t* mt = (uint32_t*)base;                                   // x << 16 | y
+    uint32_t* dpv = mt + MC;                                          // dp << 16 | predecessor (COOP_NONE: none)
+    uint16_t* cont = (uint16_t*)(dpv + MC);                           // the match one step up the diagonal
+    uint16_t* row_off = cont + MC;                                    // first match of row i; [rows] = M
+    uint16_t* path = row_off + (COOP_MAX_READ + 4);
+    uint32_t* tree = (uint32_t*)(path + COOP_MAX_READ);
+    uint32_t* rmin = tree + cols;
+    uint32_t* rmax = rmin + cols;
+    uint32_t* lastm = rmax + cols;                                    // [2][cols]: (row + 1) << 16 | match index, by row parity
+    uint64_t* y6 = (uint64_t*)rmin;                                   // phase A only
+    __shared__ uint32_t s_len[TPW], s_slot[TPW];
+
+    const uint32_t slot = blockIdx.x * TPW + (uint32_t)grp;
+    bool live = slot < n_tasks;
+    uint32_t task = 0, rid = 0, hap = 0;
+    const uint8_t *x = read_arena, *y = hap_arena;
+    int m = 0, n = 0;
+    if (live) {
+        task = tasks[slot];
+        rid = task >> 1; hap = task & 1;
+        const vtx_record rec = records[rid];
+        const vtx_locus loc = loci[rec_locus[rid]];
+        x = read_arena + rec.read_off;
+        y = hap_arena + (hap ? loc.alt_off : loc.ref_off);
+        m = (int)rec.read_len; n = (int)(hap ? loc.alt_len : loc.ref_len);
+        if (m == 0 || n == 0) { if (l == 0) (hap ? alt_score : ref_score)[rid] = 0; live = false; }
+        else if ((uint32_t)m > COOP_MAX_READ || (uint32_t)n > max_hap) {   // beyond the LDS shapes: band_kernel
+            if (l == 0) overflow_list[atomicAdd(&counters[1], 1u)] = task;
+            live = false;
+        }
+    }
+    if (!live) { m = 0; n = 0; }
+    // ---- A: matches ----
+    const int rows = m >= KMER ? m - KMER + 1 : 0, ycols = (n >= KMER && rows > 0) ? n - KMER + 1 : 0;
+    auto six = [](const uint8_t* p) -> uint64_t {
+        return (uint64_t)p[0] | ((uint64_t)p[1] << 8) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 24) | ((uint64_t)p[4] << 32) | ((uint64_t)p[5] << 40);
+    };
+    for (int j = l; j < ycols; j += G) y6[j] = six(y + j);
+    constexpr int RPL = COOP_MAX_READ / G;                            // rows per lane: row = l + G k
+    uint64_t x6[RPL];
+    uint32_t cnt[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) { const int i = l + G * k; x6[k] = i < rows ? six(x + i) : ~0ull; cnt[k] = 0; }
+    wave_sync();
+    const int ycols_w = wave_max_i32(ycols);
+    for (int j = 0; j < ycols_w; ++j) {
+        const uint64_t w = j < ycols ? y6[j] : ~1ull;
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) cnt[k] += (x6[k] == w) ? 1u : 0u;
+    }
+    // exclusive prefix over the rows of the task (the rounds k in order, the group's lanes in order within a round)
+    uint32_t off[RPL];
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+        uint32_t inc = cnt[k];
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, G); if (l >= d) inc += o; }
+        off[k] = run + inc - cnt[k];
+        run += (uint32_t)__shfl((int)inc, G - 1, G);
+    }
+    const uint32_t M = run;
+    if (live && M > (uint32_t)MC) { if (l == 0) overflow_list[atomicAdd(&counters[1], 1u)] = task; live = false; }
+    if (live && M == 0) {                                              // Band::full_matrix
+        if (l == 0) { const uint32_t h = atomicAdd(&counters[0], 1u); hard_list[h] = task; band[(size_t)h * 2 * band_stride] = BAND_FULL_MATRIX; }
+        live = false;
+    }
+    if (!__any(live)) return;
+    const int rows_l = live ? rows : 0;                                // (a task that left keeps its lanes idle)
+    const int m_l = live ? m : -1;
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) { const int i = l + G * k; if (i < rows) row_off[i] = (uint16_t)off[k]; }
+        if (l == 0) row_off[rows] = (uint16_t)M;
+    }
+    for (int j = 0; j < ycols_w; ++j) {
+        const uint64_t w = (live && j < ycols) ? y6[j] : ~1ull;
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) if (x6[k] == w) { mt[off[k]] = ((uint32_t)(l + G * k) << 16) | (uint32_t)j; ++off[k]; }
+    }
+    wave_sync();                                                       // (y6 is dead: rmin / rmax may be written)
+    if (ablate == 1) { if (mt[0] == 0x7fffffffu) counters[2] = 1; return; }     // (profiling aid: phase A only; results are wrong)
+    // ---- B: sdpkpp ----
+    const int tn = n + KMER + 2;
+    if (live) for (int i = l; i <= tn; i += G) tree[i] = 0;
+    if (live) for (int i = l; i < 2 * (int)cols; i += G) lastm[i] = 0;
+    uint32_t best = 0;                                                 // dp << 16 | index of the best END so far (this lane's)
+    wave_sync();
+    const int m_w = wave_max_i32(m_l);
+    for (int X = 0; X <= m_w; ++X) {
+        const int er = X - KMER;                                       // END events: the matches of row X - k
+        if (er >= 0 && er < rows_l) {
+            const uint32_t b = row_off[er], e = row_off[er + 1];
+            for (uint32_t p = b + l; p < e; p += G) {
+                const uint32_t yv = mt[p] & 0xffffu, dv0 = dpv[p];
+                uint32_t dv = dv0 >> 16, pr = dv0 & 0xffffu;
+                const uint32_t c = cont[p];
+                if (c != COOP_NONE) {
+                    const uint32_t cand = (dpv[c] >> 16) + 1u;
+                    if (cand > dv || (cand == dv && (pr == COOP_NONE || c > pr))) { dv = cand; pr = c; dpv[p] = (dv << 16) | pr; }
+                }
+                const uint32_t v = dv + (uint32_t)X + yv + KMER;       // dp + (x + k) + (y + k)
+                const uint32_t packed = (v << 16) | p;
+                {   // (the whole tree path at once: nine nodes at most for tn < 512)
+                    int i = (int)yv + KMER + 1;
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) { if (i <= tn) atomicMax(&tree[i], packed); i += i & (-i); }
+                }
+                const uint32_t me = (dv << 16) | p;
+                best = me > best ? me : best;
+            }
+        }
+        wave_sync();
+        if (X < rows_l) {
+            const uint32_t b = row_off[X], e = row_off[X + 1];
+            for (uint32_t p = b + l; p < e; p += G) {
+                const uint32_t yv = mt[p] & 0xffffu;
+                uint32_t bq = 0;
+                {   // every node of the query path is requested before any is looked at
+                    uint32_t tv[10];
+                    int i = (int)yv + 1;
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) { tv[u] = i > 0 ? tree[i] : 0u; i -= i & (-i); }
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) bq = tv[u] > bq ? tv[u] : bq;
+                }
+                const uint32_t lm = yv > 0 ? lastm[((X + 1) & 1) * cols + yv - 1] : 0u;      // row X - 1, column y - 1
+                uint32_t dv = KMER, pr = COOP_NONE;
+                if (bq) {
+                    const int cand = (int)(bq >> 16) - 5 - (X + (int)yv) + KMER;        // gap_open -5, extend -1 per unit of (x + y)
+                    if (cand >= (int)dv) { dv = (uint32_t)cand; pr = bq & 0xffffu; }      // (a tie goes to the tree's entry: its index > -1)
+                }
+                const uint32_t c = (X > 0 && (lm >> 16) == (uint32_t)X) ? (lm & 0xffffu) : COOP_NONE;    // tag = row + 1
+                dpv[p] = (dv << 16) | pr;
+                cont[p] = (uint16_t)c;
+                lastm[(X & 1) * cols + yv] = ((uint32_t)(X + 1) << 16) | p;
+            }
+        }
+        wave_sync();
+    }
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)best, d, G); best = o > best ? o : best; }
+    // (the reference starts `best` at (k, match 0): an END beats it iff (dp, index) > (k, 0) — dp >= k always, so the maximum
+    //  over (dp, index) is the same entry)
+    if (ablate == 2) { if (best == 0x7fffffffu) counters[2] = 1; return; }      // (profiling aid: phases A + B)
+    // ---- traceback (one lane per task), the chain reversed in path[] ----
+    if (live && l == 0) {
+        uint32_t cur = best & 0xffffu, len = 0;
+        while (cur != COOP_NONE && len < COOP_MAX_READ) { path[len++] = (uint16_t)cur; cur = dpv[cur] & 0xffffu; }
+        s_len[grp] = len;
+        s_slot[grp] = atomicAdd(&counters[0], 1u);
+    }
+    wave_sync();
+    if (!live) return;                                                 // (no wave_sync below this point is needed by other groups... see pass 2)
+    const int L = (int)s_len[grp];
+    const uint32_t hslot = s_slot[grp];
+    auto link = [&](int t) -> uint32_t { return mt[path[L - 1 - t]]; };  // link t of the chain, forward
+    const int fx = (int)(link(0) >> 16), fy = (int)(link(0) & 0xffffu);
+    const int d0 = min(min(fx, fy), (int)VTX_BAND_LAZY_EXT(KMER));
+    const int cA = fy - d0;
+    int lx, ly;                                                        // cell behind the last chained k-mer
+    {
+        const uint32_t w = link(L - 1);
+        lx = (int)(w >> 16) + VTX_BAND_KMER_LAST_ANCHOR(KMER); ly = (int)(w & 0xffffu) + VTX_BAND_KMER_LAST_ANCHOR(KMER);
+    }
+    const int d1 = min(min(m - lx, n - ly), (int)VTX_BAND_LAZY_EXT(KMER));
+    const int cB = ly + d1;
+    // pass 1: every link writes the anchor row of its own columns
+    for (int t = l; t < L + 1; t += G) {
+        if (t == L) {                                                  // the lazy extension behind the chain
+            for (int i = 1; i <= d1; ++i) { rmin[ly + i] = (uint32_t)(lx + i); rmax[ly + i] = (uint32_t)(lx + i); }
+            continue;
+        }
+        const uint32_t w = link(t);
+        const int px = (int)(w >> 16), py = (int)(w & 0xffffu);
+        int ax, ay;
+        if (t == 0) { ax = fx - d0; ay = fy - d0; rmin[ay] = (uint32_t)ax; rmax[ay] = (uint32_t)ax; }
+        else {
+            const uint32_t q = link(t - 1);
+            const int qx = (int)(q >> 16), qy = (int)(q & 0xffffu);
+            const int sq = (px == qx + 1 && py == qy + 1) ? 1 : VTX_BAND_KMER_LAST_ANCHOR(KMER);
+            ax = qx + sq; ay = qy + sq;
+        }
+        const int dr = px - ax, dc = py - ay, dg = min(dr, dc);
+        for (int i = 1; i <= dg; ++i) { rmin[ay + i] = (uint32_t)(ax + i); rmax[ay + i] = (uint32_t)(ax + i); }
+        for (int c = ay + dg + 1; c <= py; ++c) { rmin[c] = (uint32_t)px; rmax[c] = (uint32_t)px; }       // horizontal remainder (dc > dr)
+        int st = VTX_BAND_KMER_LAST_ANCHOR(KMER);
+        if (t + 1 < L) { const uint32_t nx = link(t + 1); if ((int)(nx >> 16) == px + 1 && (int)(nx & 0xffffu) == py + 1) st = 1; }
+        for (int i = 1; i <= st; ++i) { rmin[py + i] = (uint32_t)(px + i); rmax[py + i] = (uint32_t)(px + i); }
+    }
+    wave_sync();
+    // pass 2: vertical remainders (dr > dc) raise rmax of the column the run happens in
+    for (int t = l; t < L; t += G) {
+        const uint32_t w = link(t);
+        const int px = (int)(w >> 16), py = (int)(w & 0xffffu);
+        int ax, ay;
+        if (t == 0) { ax = fx - d0; ay = fy - d0; }
+        else {
+            const uint32_t q = link(t - 1);
+            const int qx = (int)(q >> 16), qy = (int)(q & 0xffffu);
+            const int sq = (px == qx + 1 && py == qy + 1) ? 1 : VTX_BAND_KMER_LAST_ANCHOR(KMER);
+            ax = qx + sq; ay = qy + sq;
+        }
+        const int dr = px - ax, dc = py - ay;
+        if (dr > dc) atomicMax(&rmax[ay + dc], (uint32_t)px);
+    }
+    wave_sync();
+    // ---- per-column ranges (band_ranges) ----
+    if (l == 0) hard_list[hslot] = task;
+    uint16_t* lo = band + (size_t)hslot * 2 * band_stride;
+    uint16_t* hi = lo + band_stride;
+    const int nrows = m + 1;
+    for (int j = l; j <= n; j += G) {
+        if (j < cA - BANDW || j > cB + BANDW) { lo[j] = 0x7fff; hi[j] = 0; continue; }
+        const int c0 = j - BANDW > cA ? j - BANDW : cA;
+        const int c1 = j + BANDW < cB ? j + BANDW : cB;
+        const int lw = (int)rmin[c0] - BANDW;
+        const int hw = (int)rmax[c1] + BANDW + 1;
+        lo[j] = (uint16_t)(lw > 0 ? lw : 0);
+        hi[j] = (uint16_t)(hw < nrows ? hw : nrows);
+    }
+}
+
+// a wavefront per task; tier 0: 1024 matches (15.6 KB of LDS: 10 tasks per CU), tier 1: 4096 matches (3 per CU).
+// Measured on the real-sequence workload at 30 k loci (tools/coop_ablate.sh): matches 39, sdpkpp 110, staircase 8 of 157 ms for
+// 1.75 M tasks (the step: 257 ms with the serial kernel alone, 234 ms with this one in front of it).  The kernel is bound by the chain of LDS round trips per row
+// (~2 600 cycles per row and task, 150 rows) times the 10 tasks a CU's LDS holds: 32 or 16 lanes per task (two or four tasks
+// per wavefront in lockstep, the template's G) were SLOWER, 171 and 258 ms — the same number of tasks in flight, longer rows.)
+extern "C" hipError_t vtxk_launch_band_coop(int tier, const uint32_t* tasks, uint32_t n_tasks, const vtx_record* records,
+                                            const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
+                                            const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score, int32_t* alt_score,
+                                            uint16_t* band, uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
+                                            uint32_t* counters, hipStream_t s) {
+    if (!n_tasks) return hipSuccess;
+    const uint32_t mc = tier ? 4096u : 1024u, tpw = 1u;
+    static const uint32_t ablate = getenv("VTX_COOP_ABLATE") ? (uint32_t)atoi(getenv("VTX_COOP_ABLATE")) : 0u;     // profiling aid
+    const size_t task_bytes = vtxk_band_coop_lds(max_hap, mc), shmem = task_bytes * tpw;
+    if (shmem > 64 * 1024) return hipErrorInvalidValue;
+#define LAUNCH_COOP(G, MC)                                                                                               \
+    {                                                                                                                    \
+        if (shmem > 48 * 1024) {                                                                                         \
+            hipError_t e = hipFuncSetAttribute((const void*)band_coop_kernel<G, MC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+            if (e != hipSuccess) return e;                                                                               \
+        }                                                                                                                \
+        hipLaunchKernelGGL((band_coop_kernel<G, MC>), dim3((n_tasks + tpw - 1) / tpw), dim3(64), shmem, s, tasks, n_tasks, records, rec_locus, \
+                           loci, read_arena, hap_arena, max_hap, (uint32_t)task_bytes, ref_score, alt_score, band, band_stride,   \
+                           hard_list, overflow_list, counters, ablate);                                                  \
+    }
+    if (tier) LAUNCH_COOP(64, 4096) else LAUNCH_COOP(64, 1024)
+#undef LAUNCH_COOP
+    return hipGetLastError();
+}
+
 // active lanes per wavefront of band_kernel<false> for a list of n_tasks (the workspace holds 64 slabs per wavefront either way)
 extern "C" uint32_t vtxk_band_lanes(uint32_t n_tasks) {
     static const int forced = getenv("VTX_BAND_LANES") ? atoi(getenv("VTX_BAND_LANES")) : 0;       // experiment knob

@@ -69,6 +69,11 @@ hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base, const vtx
                                  size_t gtables_bytes, int stats, hipStream_t s);
 int vtxk_band_second_chance(uint32_t tasks_per_locus, int long_lists);
 uint32_t vtxk_band_lanes(uint32_t n_tasks);
+size_t vtxk_band_coop_lds(uint32_t max_hap, uint32_t mc);
+hipError_t vtxk_launch_band_coop(int tier, const uint32_t* tasks, uint32_t n_tasks, const vtx_record* records, const uint32_t* rec_locus,
+                                 const vtx_locus* loci, const uint8_t* read_arena, const uint8_t* hap_arena, uint32_t max_hap,
+                                 int32_t* ref_score, int32_t* alt_score, uint16_t* band, uint32_t band_stride, uint32_t* hard_list,
+                                 uint32_t* overflow_list, uint32_t* counters, hipStream_t s);
 size_t vtxk_band_gtables_bytes(uint32_t n_loci, uint32_t max_hap, uint32_t tasks_per_locus, uint32_t* loci_cap);
 uint32_t vtxk_band_task_words(void);
 uint32_t vtxk_band_pend_words(void);
