@@ -1938,17 +1938,17 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     //      and every lane probes for whoever owns the row.  Pass 1: the presence bitmap (one word of 512 bytes per
     //      haplotype) — most k-mers are not in the haplotype at all; the survivors are compacted in place.  Pass 2: bucket
     //      walk for the survivors; matches land in the owner's list. ----
-    vtxf::M192 need = live ? fr.need : vtxf::M192{0, 0, 0};
+    vtxf::MIter need_it = vtxf::m_iter(live ? fr.need : vtxf::M192{0, 0, 0});
     if ((stats >> 8) == 1) { if (live && fr.cert == 0x7fffffff) counters[40] = 1; return; }      // (profiling aid) front only
     const uint32_t pb_rel = vtxf::tab_pb_off(max_hap, n_heads), head_rel = max_hap * 8u;
     for (;;) {
         if (tid == 0) { q_count[0] = 0; q_count[1] = 0; }
         wave_sync();
-        const int cnt = min(QROWS, vtxf::m_pop(need));
+        const int cnt = min(QROWS, need_it.left);
         if (!__any(cnt > 0)) break;
         if (cnt > 0) {
             const uint32_t base = atomicAdd(&q_count[0], (uint32_t)cnt);
-            for (int t = 0; t < cnt; ++t) q_ent[base + t] = (uint16_t)(((uint32_t)tid << 8) | (uint32_t)vtxf::m_pop_lowest(need));
+            for (int t = 0; t < cnt; ++t) q_ent[base + t] = (uint16_t)(((uint32_t)tid << 8) | (uint32_t)vtxf::m_next(need_it));
         }
         wave_sync();
         const uint32_t total = q_count[0];

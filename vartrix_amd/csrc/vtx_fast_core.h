@@ -158,6 +158,20 @@ VTXF_FN int m_pop_lowest(M192& a) {
     a.w0 = z0 ? a.w0 : nxt; a.w1 = (z0 && !z1) ? nxt : a.w1; a.w2 = z1 ? nxt : a.w2;
     return r;
 }
+// the set bits of a mask in ascending order, one per call: the words shift down as they run empty (twice in a mask's life), so a
+// call is one count-trailing-zeros and one clear on ONE word — m_pop_lowest selects among three words on every call
+struct MIter {
+    uint64_t cur, n1, n2;
+    int base, left;
+};
+VTXF_FN MIter m_iter(M192 a) { return MIter{a.w0, a.w1, a.w2, 0, m_pop(a)}; }
+VTXF_FN int m_next(MIter& it) {              // precondition: it.left > 0
+    while (it.cur == 0) { it.cur = it.n1; it.n1 = it.n2; it.n2 = 0; it.base += 64; }
+    const int r = it.base + ctz64(it.cur);
+    it.cur &= it.cur - 1;
+    --it.left;
+    return r;
+}
 // f(position) for every set bit, ascending
 template <class F> VTXF_FN void m_for_each(M192 a, F f) {
     for (uint64_t v = a.w0; v; v &= v - 1) f(ctz64(v));
