@@ -1039,13 +1039,13 @@ int vtx_run(vtx_ctx* c) {
         auto fallback_launch = [&]() -> int {
             const uint64_t worst = (uint64_t)c->max_read_len * c->max_hap_len;
             if (fb.cap2 >= worst && fb.cap2 >= 512) return fail(c, VTX_E_STATE, "vtx_run: band kernel overflow with a worst-case slab");
-            // first two rounds: the cooperative kernel, everything in LDS (band_coop_kernel: a wavefront per task, up to 1024 matches,
-            // then up to 4096; reads up to 256 bases); what that cannot hold takes the serial kernel below
+            // first three rounds: the cooperative kernel, everything in LDS (band_coop_kernel: a wavefront per task, up to 512 matches,
+            // then 1024, then 4096; reads up to 256 bases); what that cannot hold takes the serial kernel below
             static const bool no_coop = getenv("VTX_BAND_NO_COOP") != nullptr;             // experiment / test hook
-            const int tier = fb.cap2 < 512 ? 0 : (fb.cap2 == 1024 ? 1 : -1);
-            if (tier >= 0 && !no_coop && c->max_read_len <= 256 &&
-                vtxk_band_coop_lds(c->max_hap_len, tier ? 4096u : 1024u) <= (tier ? 64u : 16u) * 1024) {
-                fb.cap2 = tier ? 4096 : 1024;
+            const int tier = fb.cap2 < 512 ? 0 : (fb.cap2 == 512 ? 1 : (fb.cap2 == 1024 ? 2 : -1));
+            const uint32_t tier_cap = tier == 0 ? 512u : (tier == 1 ? 1024u : 4096u);
+            if (tier >= 0 && !no_coop && c->max_read_len <= 256 && vtxk_band_coop_lds(c->max_hap_len, tier_cap) <= 64u * 1024) {
+                fb.cap2 = tier_cap;
                 HIP_TRY(c, hipMemsetAsync(d_cnt + 9, 0, sizeof(uint32_t), s2));
                 uint32_t* other = c->d_over2.as<uint32_t>() + ((fb.tasks == c->d_over2.as<uint32_t>()) ? fb.n_over : 0);
                 HIP_TRY(c, vtxk_launch_band_coop(tier, fb.tasks, fb.todo, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),

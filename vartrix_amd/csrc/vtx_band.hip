@@ -384,8 +384,8 @@ extern "C" size_t vtxk_band_coop_lds(uint32_t max_hap, uint32_t mc) {
     const size_t cols = ((size_t)max_hap + KMER + 9) & ~(size_t)1;
     // mt, dpv: 4 B per match; cont: 2 B; row_off: u16 x (COOP_MAX_READ + 4); path: u16 x COOP_MAX_READ; tree: u32 x cols;
     // rmin, rmax: u32 x cols each (the 8-byte haplotype words of phase A alias them: 8-byte aligned)
-    // lastm: u32 x cols x 2 (the match of the last two rows at every column: the continuation partner without a search)
-    const size_t o = (size_t)mc * 10 + 2 * (COOP_MAX_READ + 4) + 2 * COOP_MAX_READ + 4 * cols + 8 * cols + 8 * cols;
+    // lastm (phase B: the match of the last two rows at every column — the continuation partner without a search) aliases them too
+    const size_t o = (size_t)mc * 10 + 2 * (COOP_MAX_READ + 4) + 2 * COOP_MAX_READ + 4 * cols + 8 * cols;
     return (o + 63) & ~(size_t)63;
 }
 
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) void band_coop_kernel(
     uint32_t* tree = (uint32_t*)(path + COOP_MAX_READ);
     uint32_t* rmin = tree + cols;
     uint32_t* rmax = rmin + cols;
-    uint32_t* lastm = rmax + cols;                                    // [2][cols]: (row + 1) << 16 | match index, by row parity
+    uint32_t* lastm = rmin;                                           // phase B only: [2][cols]: (row + 1) << 16 | match index, by row parity
     uint64_t* y6 = (uint64_t*)rmin;                                   // phase A only
     __shared__ uint32_t s_len[TPW], s_slot[TPW];
 
@@ -492,53 +492,79 @@ __global__ __launch_bounds__(64) void band_coop_kernel(
     uint32_t best = 0;                                                 // dp << 16 | index of the best END so far (this lane's)
     wave_sync();
     const int m_w = wave_max_i32(m_l);
-    for (int X = 0; X <= m_w; ++X) {
-        const int er = X - KMER;                                       // END events: the matches of row X - k
-        if (er >= 0 && er < rows_l) {
-            const uint32_t b = row_off[er], e = row_off[er + 1];
-            for (uint32_t p = b + l; p < e; p += G) {
-                const uint32_t yv = mt[p] & 0xffffu, dv0 = dpv[p];
-                uint32_t dv = dv0 >> 16, pr = dv0 & 0xffffu;
-                const uint32_t c = cont[p];
-                if (c != COOP_NONE) {
-                    const uint32_t cand = (dpv[c] >> 16) + 1u;
-                    if (cand > dv || (cand == dv && (pr == COOP_NONE || c > pr))) { dv = cand; pr = c; dpv[p] = (dv << 16) | pr; }
-                }
-                const uint32_t v = dv + (uint32_t)X + yv + KMER;       // dp + (x + k) + (y + k)
-                const uint32_t packed = (v << 16) | p;
-                {   // (the whole tree path at once: nine nodes at most for tn < 512)
-                    int i = (int)yv + KMER + 1;
+    // One iteration = the START events of row X - 1 (upper half of the lanes) and the END events of row X - k (lower half), in ONE
+    // instruction stream: two rounds of LDS loads, then the writes and the tree updates.  START(X - 1) must see the END events up
+    // to row X - 1 (earlier iterations) and none of row X: its tree loads are issued before this iteration's atomics, and the LDS
+    // keeps a wavefront's order.  END(X) reads the dp of its continuation partner, settled by END(X - 1).  Rows k apart never
+    // touch the same match.  (END(X) then START(X) as two passes with a fence each was twice the chain of round trips.)
+    constexpr uint32_t HALF = G / 2;
+    const bool is_start = (uint32_t)l >= HALF;
+    const uint32_t hl = (uint32_t)l & (HALF - 1);
+    auto do_start = [&](uint32_t p, int sr, uint32_t yv, const uint32_t* tv, uint32_t lm) {
+        uint32_t bq = 0;
 #pragma unroll
-                    for (int u = 0; u < 10; ++u) { if (i <= tn) atomicMax(&tree[i], packed); i += i & (-i); }
-                }
-                const uint32_t me = (dv << 16) | p;
-                best = me > best ? me : best;
-            }
+        for (int u = 0; u < 10; ++u) bq = tv[u] > bq ? tv[u] : bq;
+        uint32_t dv = KMER, pr = COOP_NONE;
+        if (bq) {
+            const int cand = (int)(bq >> 16) - 5 - (sr + (int)yv) + KMER;            // gap_open -5, extend -1 per unit of (x + y)
+            if (cand >= (int)dv) { dv = (uint32_t)cand; pr = bq & 0xffffu; }          // (a tie goes to the tree's entry: its index > -1)
         }
-        wave_sync();
-        if (X < rows_l) {
-            const uint32_t b = row_off[X], e = row_off[X + 1];
-            for (uint32_t p = b + l; p < e; p += G) {
+        const uint32_t c = (sr > 0 && (lm >> 16) == (uint32_t)sr) ? (lm & 0xffffu) : COOP_NONE;   // tag = row + 1 of the writer
+        dpv[p] = (dv << 16) | pr;
+        cont[p] = (uint16_t)c;
+        lastm[(sr & 1) * cols + yv] = ((uint32_t)(sr + 1) << 16) | p;
+    };
+    auto do_end = [&](uint32_t p, int X, uint32_t yv, uint32_t d0, uint32_t c, uint32_t dc) {
+        uint32_t dv = d0 >> 16, pr = d0 & 0xffffu;
+        if (c != COOP_NONE) {
+            const uint32_t cand = (dc >> 16) + 1u;
+            if (cand > dv || (cand == dv && (pr == COOP_NONE || c > pr))) { dv = cand; pr = c; dpv[p] = (dv << 16) | pr; }
+        }
+        const uint32_t v = dv + (uint32_t)X + yv + KMER;                             // dp + (x + k) + (y + k)
+        const uint32_t packed = (v << 16) | p;
+        int i = (int)yv + KMER + 1;
+#pragma unroll
+        for (int u = 0; u < 10; ++u) { if (i <= tn) atomicMax(&tree[i], packed); i += i & (-i); }     // (nine nodes at most for tn < 512)
+        const uint32_t me = (dv << 16) | p;
+        best = me > best ? me : best;
+    };
+    for (int X = 0; X <= m_w; ++X) {
+        const int sr = X - 1, er = X - KMER;
+        uint32_t sb = 0, se = 0, eb = 0, ee = 0;
+        if (sr >= 0 && sr < rows_l) { sb = row_off[sr]; se = row_off[sr + 1]; }
+        if (er >= 0 && er < rows_l) { eb = row_off[er]; ee = row_off[er + 1]; }
+        if (!__any(se - sb > HALF || ee - eb > HALF)) {
+            const uint32_t p = (is_start ? sb : eb) + hl;
+            const bool act = p < (is_start ? se : ee);
+            uint32_t w = 0, d0 = 0, c = COOP_NONE;
+            if (act) { w = mt[p]; d0 = dpv[p]; c = cont[p]; }                        // (a START lane does not use d0 and c)
+            const uint32_t yv = w & 0xffffu;
+            uint32_t tv[10], x0 = 0;
+            {
+                const bool st = act && is_start;
+                int i = (int)yv + 1;
+#pragma unroll
+                for (int u = 0; u < 10; ++u) { tv[u] = (st && i > 0) ? tree[i] : 0u; i -= i & (-i); }
+                if (st) { if (yv > 0) x0 = lastm[((sr + 1) & 1) * cols + yv - 1]; }   // row sr - 1, column y - 1
+                else if (act && c != COOP_NONE) x0 = dpv[c];
+            }
+            if (act && is_start) do_start(p, sr, yv, tv, x0);
+            if (act && !is_start) do_end(p, X, yv, d0, c, x0);
+        } else {
+            // a row with more events than half a wavefront holds (satellites): the two kinds in turn, START first
+            for (uint32_t p = sb + (uint32_t)l; p < se; p += G) {
                 const uint32_t yv = mt[p] & 0xffffu;
-                uint32_t bq = 0;
-                {   // every node of the query path is requested before any is looked at
-                    uint32_t tv[10];
-                    int i = (int)yv + 1;
+                uint32_t tv[10];
+                int i = (int)yv + 1;
 #pragma unroll
-                    for (int u = 0; u < 10; ++u) { tv[u] = i > 0 ? tree[i] : 0u; i -= i & (-i); }
-#pragma unroll
-                    for (int u = 0; u < 10; ++u) bq = tv[u] > bq ? tv[u] : bq;
-                }
-                const uint32_t lm = yv > 0 ? lastm[((X + 1) & 1) * cols + yv - 1] : 0u;      // row X - 1, column y - 1
-                uint32_t dv = KMER, pr = COOP_NONE;
-                if (bq) {
-                    const int cand = (int)(bq >> 16) - 5 - (X + (int)yv) + KMER;        // gap_open -5, extend -1 per unit of (x + y)
-                    if (cand >= (int)dv) { dv = (uint32_t)cand; pr = bq & 0xffffu; }      // (a tie goes to the tree's entry: its index > -1)
-                }
-                const uint32_t c = (X > 0 && (lm >> 16) == (uint32_t)X) ? (lm & 0xffffu) : COOP_NONE;    // tag = row + 1
-                dpv[p] = (dv << 16) | pr;
-                cont[p] = (uint16_t)c;
-                lastm[(X & 1) * cols + yv] = ((uint32_t)(X + 1) << 16) | p;
+                for (int u = 0; u < 10; ++u) { tv[u] = i > 0 ? tree[i] : 0u; i -= i & (-i); }
+                const uint32_t lm = yv > 0 ? lastm[((sr + 1) & 1) * cols + yv - 1] : 0u;
+                do_start(p, sr, yv, tv, lm);
+            }
+            wave_sync();
+            for (uint32_t p = eb + (uint32_t)l; p < ee; p += G) {
+                const uint32_t yv = mt[p] & 0xffffu, d0 = dpv[p], c = cont[p];
+                do_end(p, X, yv, d0, c, c != COOP_NONE ? dpv[c] : 0u);
             }
         }
         wave_sync();
@@ -626,18 +652,20 @@ __global__ __launch_bounds__(64) void band_coop_kernel(
     }
 }
 
-// a wavefront per task; tier 0: 1024 matches (15.6 KB of LDS: 10 tasks per CU), tier 1: 4096 matches (3 per CU).
-// Measured on the real-sequence workload at 30 k loci (tools/coop_ablate.sh): matches 39, sdpkpp 110, staircase 8 of 157 ms for
-// 1.75 M tasks (the step: 257 ms with the serial kernel alone, 234 ms with this one in front of it).  The kernel is bound by the chain of LDS round trips per row
-// (~2 600 cycles per row and task, 150 rows) times the 10 tasks a CU's LDS holds: 32 or 16 lanes per task (two or four tasks
-// per wavefront in lockstep, the template's G) were SLOWER, 171 and 258 ms — the same number of tasks in flight, longer rows.)
+// a wavefront per task; tier 0: 512 matches (8.7 KB of LDS: 18 tasks per CU), tier 1: 1024 (13.8 KB: 11), tier 2: 4096 (3 per CU).
+// The kernel is bound by its chain of LDS round trips per read row times the tasks a CU's LDS holds, not by instruction issue:
+// on the real-sequence workload at 30 k loci (tools/coop_ablate.sh) one 1024-match tier with END and START as two fenced
+// passes per row took 157 ms for 1.75 M tasks (matches 39, sdpkpp 110, staircase 8); 32 or 16 lanes per task (two or four tasks
+// per wavefront in lockstep, the template's G) were SLOWER, 171 and 258 ms — the same number of tasks in flight, longer rows;
+// START and END of neighbouring rows in one instruction stream plus the 512-match tier: 90 + 11 ms (the step: 257 ms with the
+// serial kernel alone, 234 ms with the first version, 200 ms now; full size 800 -> 590 ms).
 extern "C" hipError_t vtxk_launch_band_coop(int tier, const uint32_t* tasks, uint32_t n_tasks, const vtx_record* records,
                                             const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                             const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score, int32_t* alt_score,
                                             uint16_t* band, uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
                                             uint32_t* counters, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
-    const uint32_t mc = tier ? 4096u : 1024u, tpw = 1u;
+    const uint32_t mc = tier == 0 ? 512u : (tier == 1 ? 1024u : 4096u), tpw = 1u;
     static const uint32_t ablate = getenv("VTX_COOP_ABLATE") ? (uint32_t)atoi(getenv("VTX_COOP_ABLATE")) : 0u;     // profiling aid
     const size_t task_bytes = vtxk_band_coop_lds(max_hap, mc), shmem = task_bytes * tpw;
     if (shmem > 64 * 1024) return hipErrorInvalidValue;
@@ -651,7 +679,7 @@ extern "C" hipError_t vtxk_launch_band_coop(int tier, const uint32_t* tasks, uin
                            loci, read_arena, hap_arena, max_hap, (uint32_t)task_bytes, ref_score, alt_score, band, band_stride,   \
                            hard_list, overflow_list, counters, ablate);                                                  \
     }
-    if (tier) LAUNCH_COOP(64, 4096) else LAUNCH_COOP(64, 1024)
+    if (tier == 0) LAUNCH_COOP(64, 512) else if (tier == 1) LAUNCH_COOP(64, 1024) else LAUNCH_COOP(64, 4096)
 #undef LAUNCH_COOP
     return hipGetLastError();
 }
