@@ -448,10 +448,16 @@ __global__ __launch_bounds__(64) void band_coop_kernel(
     for (int k = 0; k < RPL; ++k) { const int i = l + G * k; x6[k] = i < rows ? six(x + i) : ~0ull; cnt[k] = 0; }
     wave_sync();
     const int ycols_w = wave_max_i32(ycols);
-    for (int j = 0; j < ycols_w; ++j) {
-        const uint64_t w = j < ycols ? y6[j] : ~1ull;
+    // (eight columns per trip: their LDS loads go out together — one load per trip was a round trip per column)
+    for (int j0 = 0; j0 < ycols_w; j0 += 8) {
+        uint64_t w[8];
 #pragma unroll
-        for (int k = 0; k < RPL; ++k) cnt[k] += (x6[k] == w) ? 1u : 0u;
+        for (int u = 0; u < 8; ++u) w[u] = j0 + u < ycols ? y6[j0 + u] : ~1ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) cnt[k] += (x6[k] == w[u]) ? 1u : 0u;
+        }
     }
     // exclusive prefix over the rows of the task (the rounds k in order, the group's lanes in order within a round)
     uint32_t off[RPL];
@@ -478,10 +484,15 @@ __global__ __launch_bounds__(64) void band_coop_kernel(
         for (int k = 0; k < RPL; ++k) { const int i = l + G * k; if (i < rows) row_off[i] = (uint16_t)off[k]; }
         if (l == 0) row_off[rows] = (uint16_t)M;
     }
-    for (int j = 0; j < ycols_w; ++j) {
-        const uint64_t w = (live && j < ycols) ? y6[j] : ~1ull;
+    for (int j0 = 0; j0 < ycols_w; j0 += 8) {
+        uint64_t w[8];
 #pragma unroll
-        for (int k = 0; k < RPL; ++k) if (x6[k] == w) { mt[off[k]] = ((uint32_t)(l + G * k) << 16) | (uint32_t)j; ++off[k]; }
+        for (int u = 0; u < 8; ++u) w[u] = (live && j0 + u < ycols) ? y6[j0 + u] : ~1ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) if (x6[k] == w[u]) { mt[off[k]] = ((uint32_t)(l + G * k) << 16) | (uint32_t)(j0 + u); ++off[k]; }
+        }
     }
     wave_sync();                                                       // (y6 is dead: rmin / rmax may be written)
     if (ablate == 1) { if (mt[0] == 0x7fffffffu) counters[2] = 1; return; }     // (profiling aid: phase A only; results are wrong)
