@@ -133,14 +133,70 @@ int vtxo_join_same(int D);
 int vtxo_join_gap(int D);
 static int g_join_exact = 1;     /* 0: the closed form J_free(D) only (what a caller without the bases uses) */
 void vtxo_set_join_exact(int on) { g_join_exact = on; }
-static int join_same_e(const uint8_t* x, const uint8_t* y, int xb, int yb, int D) {
+/* J_gap restricted to stretches whose gaps total G >= 3 / 4 / 5 per direction (they reach a diagonal >= G away and come back):
+   brute force over (g, G, mm) as for J_gap, tests/test_certify.py */
+static int join_gap_min_g(int D, int g0) {
+    int best = 1 << 20;
+    for (int g = 2; g <= 2 * D + 4; ++g)
+        for (int G = (g + 1) / 2 > g0 ? (g + 1) / 2 : g0; G <= D; ++G)
+            for (int mm = 0; mm <= D - G; ++mm) {
+                const int matches = D - G - mm;
+                if (matches <= 5 * (g + mm - 1)) { const int c = 5 * g + 2 * G + 5 * mm - matches; if (c < best) best = c; break; }
+            }
+    return best;
+}
+/* Exact cost of the cheapest stretch between base (xb, yb) of one run and the base D + 1 further on the same diagonal that
+   stays within kc diagonals of it, leaving the first run up to mu_a bases early / entering the second up to mu_b bases late at
+   1 per base (affine DP without a floor over the corridor; the runs' own bases are part of the corridor).                    */
+static int corridor_cost(const uint8_t* x, int m, const uint8_t* y, int n, int xb, int yb, int D, int kc, int mu_a, int mu_b) {
+    const int NEG = -100000;
+    const int d = yb - xb;
+    const int r0 = xb + 1 - mu_a, r1 = xb + D + 1 + mu_b + 1;       /* prefix cells (i, j): rows r0 .. r1 */
+    const int W = 2 * kc + 1;
+    int Hp[16], Fp[16], Hc[16], Fc[16];
+    for (int k = 0; k < W; ++k) { Hp[k] = NEG; Fp[k] = NEG; }
+    Hp[kc] = -mu_a;                                                     /* cell (r0, r0 + d) */
+    /* row r0: horizontal gaps from the seed */
+    { int E = NEG; for (int k = kc + 1; k < W; ++k) { E = (E - 1 > Hp[k - 1] - 6) ? E - 1 : Hp[k - 1] - 6; Hp[k] = E; } }
+    for (int i = r0 + 1; i <= r1; ++i) {
+        int E = NEG;
+        for (int k = 0; k < W; ++k) {
+            const int j = i + d + (k - kc);
+            int h = NEG, f = NEG;
+            if (j >= 0 && j <= n && i >= 0 && i <= m) {
+                /* diagonal: from (i - 1, j - 1): same k */
+                if (i >= 1 && j >= 1 && Hp[k] > NEG / 2) h = Hp[k] + (x[i - 1] == y[j - 1] ? 1 : -5);
+                /* vertical (consumes x): from (i - 1, j): diagonal index k + 1 in the previous row */
+                if (k + 1 < W) { const int a = Fp[k + 1] - 1, b = Hp[k + 1] - 6; f = a > b ? a : b; if (f < NEG / 2) f = NEG; }
+                /* horizontal (consumes y): from (i, j - 1): k - 1 in this row */
+                if (k >= 1) { const int a = E - 1, b = Hc[k - 1] - 6; E = a > b ? a : b; if (E < NEG / 2) E = NEG; } else E = NEG;
+                if (f > h) h = f;
+                if (E > h) h = E;
+            } else E = NEG;
+            Hc[k] = h; Fc[k] = f;
+        }
+        for (int k = 0; k < W; ++k) { Hp[k] = Hc[k]; Fp[k] = Fc[k]; }
+    }
+    /* cell (r1, r1 + d): the second run's bases 0 .. mu_b consumed */
+    return Hp[kc] <= NEG / 2 ? (1 << 20) : -(Hp[kc] - (mu_b + 1));
+}
+static int g_corridor = 0;       /* experiment: diagonals each side of the corridor (0: off) */
+void vtxo_set_corridor(int kc) { g_corridor = kc; }
+/* avail_a: bases of the first run in front of (xb, yb) that the chain may give up (leave early); avail_b: likewise behind the
+   second run's entry base */
+static int join_same_e(const uint8_t* x, int m, const uint8_t* y, int n, int xb, int yb, int D, int avail_a, int avail_b) {
     /* bases (xb+1 .. xb+D) on the diagonal of (xb, yb) */
     if (!g_join_exact) return vtxo_join_same(D);
     int e = 0;
     for (int i = 1; i <= D; ++i) e += x[xb + i] != y[yb + i];
-    return imin(6 * e - D, vtxo_join_gap(D));
+    const int free_cost = 6 * e - D, jg = vtxo_join_gap(D);
+    if (free_cost <= jg || !g_corridor) return imin(free_cost, jg);
+    /* the gap-free stretch costs more than a hypothetical one with gaps: price the real ones.  Inside the corridor exactly
+       (a stretch that gives up more than mu bases of a run costs >= 7 + mu + 1 >= free_cost); outside it the gaps total >= kc + 1 */
+    const int mu = imax(0, free_cost - 8);
+    const int inside = corridor_cost(x, m, y, n, xb, yb, D, g_corridor, imin(mu, avail_a), imin(mu, avail_b));
+    return imin(inside, join_gap_min_g(D, g_corridor + 1));
 }
-
 int vtxo_join_gap(int D) {
     static const int jg[6] = {7, 9, 11, 10, 9, 8};
     return D == 1 ? 12 : jg[D % 6];
@@ -172,7 +228,7 @@ int32_t vtxo_runs_ub_exact(const uint8_t* x, int m, const uint8_t* y, int n, int
             int cand;
             if (nd[b] == nd[a]) {
                 const int D = nx[a] - nx[b] - 1;
-                cand = D == 0 ? ub[b] : ub[b] - join_same_e(x, y, nx[b], ny[b], D);
+                cand = D == 0 ? ub[b] : ub[b] - join_same_e(x, m, y, n, nx[b], ny[b], D, 0, 0);
             } else {
                 cand = ub[b] - 5 - abs(nd[a] - nd[b]);
             }
@@ -208,7 +264,7 @@ int32_t vtxo_runs_ub(const uint8_t* x, int m, const uint8_t* y, int n, int k, in
                 int J;
                 if (dq == dp) {
                     const int D = (ps[p].xs + s) - (ps[q].xs + t) - 1;
-                    J = D == 0 ? 0 : join_same_e(x, y, ps[q].xs + t, ps[q].ys + t, D);
+                    J = D == 0 ? 0 : join_same_e(x, m, y, n, ps[q].xs + t, ps[q].ys + t, D, t, ps[p].len - 1 - s);
                 } else {
                     J = 5 + abs(dp - dq);
                 }

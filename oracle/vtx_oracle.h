@@ -135,6 +135,7 @@ int32_t vtxo_chain_cert(const uint8_t* x, int m, const uint8_t* y, int n, int k)
 int vtxo_join_same(int D);
 int vtxo_join_gap(int D);
 void vtxo_set_join_exact(int on);
+void vtxo_set_corridor(int kc);
 int32_t vtxo_runs_ub_exact(const uint8_t* x, int m, const uint8_t* y, int n, int k);
 int32_t vtxo_runs_ub(const uint8_t* x, int m, const uint8_t* y, int n, int k, int* passes_out, int* npieces_out);
 int vtxo_batch_certify(const vtx_batch* b, const vtx_config* cfg, int32_t* full, int32_t* banded, int32_t* cert,

@@ -54,14 +54,15 @@ extern "C" {
 // device takes for longer haplotypes.
 int vtxt_fastcore_batch(const vtx_batch* b, uint32_t n_heads, int32_t* score, uint32_t* why) {
     const bool force_wide = (n_heads >> 31) != 0;
-    n_heads &= 0x7fffffffu;
+    const bool refine = ((n_heads >> 30) & 1u) != 0;          // bit 30: the corridor refinement of band_refine_kernel
+    n_heads &= 0x3fffffffu;
     using namespace vtxf;
     uint32_t max_hap = 8;
     for (uint32_t l = 0; l < b->n_loci; ++l) max_hap = std::max(max_hap, std::max(b->loci[l].ref_len, b->loci[l].alt_len));
     const uint32_t stride = tab_stride(max_hap, n_heads);
     std::vector<uint8_t> gt((size_t)2 * stride + 64);
     std::vector<uint8_t> readbuf;
-    uint32_t lane[LANE_WORDS];
+    uint32_t lane[LANE_WORDS], generic[GM];
     const bool narrow = max_hap <= 255 && !force_wide;          // (vtxk_launch_band_diag makes the same choice)
     for (uint32_t l = 0; l < b->n_loci; ++l) {
         const vtx_locus& L = b->loci[l];
@@ -83,10 +84,10 @@ int vtxt_fastcore_batch(const vtx_batch* b, uint32_t n_heads, int32_t* score, ui
                 Result res;
                 if (narrow) {
                     const LaneS<uint16_t> ln{lane + S_WORDS, 1, (uint16_t*)lane, 1};
-                    res = fast_task(readbuf.data(), (int)R.read_len, tb, (int)(h ? L.alt_len : L.ref_len), ln);
+                    res = fast_task(readbuf.data(), (int)R.read_len, tb, (int)(h ? L.alt_len : L.ref_len), ln, Lane{generic, 1}, refine);
                 } else {
                     const LaneS<uint32_t> ln{lane + S_WORDS, 1, lane, 1};
-                    res = fast_task(readbuf.data(), (int)R.read_len, tb, (int)(h ? L.alt_len : L.ref_len), ln);
+                    res = fast_task(readbuf.data(), (int)R.read_len, tb, (int)(h ? L.alt_len : L.ref_len), ln, Lane{generic, 1}, refine);
                 }
                 score[2 * (size_t)r + h] = res.score;
                 why[2 * (size_t)r + h] = res.why;

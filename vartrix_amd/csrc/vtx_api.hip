@@ -1109,7 +1109,7 @@ int vtx_run(vtx_ctx* c) {
         HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 64 * sizeof(uint32_t), s));
         uint32_t cnt[12] = {0};
         uint32_t pending_total = 0, over_before = 0;
-        uint64_t diag_total = 0, diag_left = 0;
+        uint64_t diag_total = 0, diag_left = 0, refined_total = 0;
         float diag_ms = 0;
         for (uint64_t base = 0; base < n_tasks; base += chunk) {
             const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, n_tasks - base);
@@ -1137,17 +1137,35 @@ int vtx_run(vtx_ctx* c) {
             const uint32_t* fail_list = c->d_fail.as<uint32_t>();
             if (gt_n && !no_diag) {
                 HIP_TRY(c, hipMemsetAsync(d_cnt + 12, 0, sizeof(uint32_t), s));
+                HIP_TRY(c, hipMemsetAsync(d_cnt + 14, 0, sizeof(uint32_t), s));
+                // tasks whose bounds do not meet get a second chance in band_refine_kernel (their list: the half of d_fail the
+                // sorted copy will use afterwards)
+                static const bool no_refine = getenv("VTX_BAND_NO_REFINE") != nullptr;        // experiment / test hook
+                uint32_t* refine_list = no_refine ? nullptr : c->d_fail.as<uint32_t>() + nt;
                 const hipError_t e = vtxk_launch_band_diag(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                                            c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                                            c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
-                                                           c->d_fail.as<uint32_t>(), d_cnt, tasks_per_locus, gt_l0, gt_n,
+                                                           c->d_fail.as<uint32_t>(), refine_list, d_cnt, tasks_per_locus, gt_l0, gt_n,
                                                            c->d_gtables.as<uint8_t>(), gt_bytes, diag_stats, s);
                 if (e == hipSuccess) {
                     diag = true;
                     HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipMemcpyAsync(c->h_pin + 9, d_cnt + 14, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     HIP_TRY(c, hipEventRecord(c->ev[6], s));
                     HIP_TRY(c, hipStreamSynchronize(s));
                     n_fail = c->h_pin[8];
+                    const uint32_t n_refine = c->h_pin[9];
+                    if (n_refine) {
+                        HIP_TRY(c, vtxk_launch_band_refine(refine_list, n_refine, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                           c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
+                                                           c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
+                                                           tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, s));
+                        HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                        HIP_TRY(c, hipStreamSynchronize(s));
+                        n_fail = c->h_pin[8];
+                        refined_total += n_refine;
+                        ++launches;
+                    }
                     diag_total += nt; diag_left += n_fail;
                     ++launches;
                     if (n_fail > 64) {
@@ -1246,6 +1264,7 @@ int vtx_run(vtx_ctx* c) {
         if (getenv("VTX_DEBUG") && diag_total) {
             uint32_t why[16];
             HIP_TRY(c, hipMemcpy(why, d_cnt + 32, sizeof why, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[vtx] band_refine_kernel: %llu tasks listed\n", (unsigned long long)refined_total);
             fprintf(stderr, "[vtx] band_diag_kernel: %llu of %llu tasks left to band_run_kernel (%.2f %%), %.2f ms: shape=%u no-diagonal=%u pieces=%u matches=%u not-harmless=%u generic=%u not-tight=%u no-main=%u\n",
                     (unsigned long long)diag_left, (unsigned long long)diag_total, 100.0 * (double)diag_left / (double)diag_total, (double)diag_ms,
                     why[1], why[2], why[3], why[4], why[5], why[7], why[8], why[9]);

@@ -1857,7 +1857,9 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
     const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
-    uint32_t* __restrict__ fail_list, uint32_t* __restrict__ counters, uint32_t stats) {
+    uint32_t* __restrict__ fail_list, uint32_t* __restrict__ refine_list, uint32_t* __restrict__ counters, uint32_t stats) {
+    // refine_list != nullptr: a task whose bounds do not meet goes to band_refine_kernel's list (counters[14]) instead of
+    // band_run_kernel's: that kernel prices the stretches of >= 3 errors within a few bases from the real neighbour diagonals.
     // Four wavefronts per workgroup, each on its own 64 consecutive tasks and its own slice of the LDS (no workgroup barrier
     // anywhere): the four share their loci's tables in the CU's L1.
     constexpr int QROWS = 12;                                  // rows a lane contributes to the pool per round
@@ -2049,6 +2051,68 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         const int32_t sc = vtxf::back(fr, (int)min(s_cnt[tid], (uint32_t)LaneT::SMAX + 1u), ln, gl, &why, (int)(stats >> 8));
         if (sc >= 0) *my_score = sc; else fail = true;
     }
+    const bool again = fail && why == vtxf::W_NOT_TIGHT && refine_list != nullptr;
+    const uint64_t am = __ballot(again);
+    if (am) {
+        uint32_t base = 0;
+        const int leader = __ffsll((long long)am) - 1;
+        if (tid == leader) base = atomicAdd(&counters[14], (uint32_t)__popcll(am));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (again) refine_list[base + (uint32_t)__popcll(am & ((1ull << tid) - 1ull))] = task;
+    }
+    const uint64_t fm = __ballot(fail && !again);
+    if (fm) {
+        uint32_t base = 0;
+        const int leader = __ffsll((long long)fm) - 1;
+        if (tid == leader) base = atomicAdd(&counters[12], (uint32_t)__popcll(fm));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (fail && !again) fail_list[base + (uint32_t)__popcll(fm & ((1ull << tid) - 1ull))] = task;
+    }
+    if (fail && !again && (stats & 0xffu)) atomicAdd(&counters[32 + why], 1u);
+}
+
+// =============================================================================================
+// band_refine_kernel — second chance of the tasks band_diag_kernel left because cert != ub (round 3).  One lane per listed task
+// runs the whole per-task logic again (vtxf::fast_task: the path the host unit test runs), this time with the corridor
+// refinement of the same-diagonal joins (vtx_fast_core.h: corridor_cost): where >= 3 errors fall within a few bases the
+// gap-free cost 6 e - D is above J_gap(D), the price of a hypothetical excursion over perfectly matching neighbour diagonals;
+// an affine DP over the five diagonals around the stretch (~25 rows) prices the real ones.  At 3 % substitution errors that
+// decides 55 % of the listed tasks (hard tasks 6.5 -> 2.9 % of all); what is still undecided goes to band_run_kernel's list.
+// A compact list instead of a branch inside band_diag_kernel: there the DP would run in nearly every wavefront for 6 % of the lanes.
+// =============================================================================================
+template <class ST>
+__global__ __launch_bounds__(256) void band_refine_kernel(
+    const uint32_t* __restrict__ list, uint32_t n_list,
+    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
+    const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
+    const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
+    uint32_t* __restrict__ fail_list, uint32_t* __restrict__ counters, uint32_t stats) {
+    __shared__ uint32_t lane_mem_[4][(vtxf::LANE_WORDS + vtxf::GM) * 64];
+    const int wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
+    uint32_t* lane_mem = lane_mem_[wv];
+    const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
+    bool fail = false;
+    uint32_t why = 0, task = 0;
+    if (slot < n_list) {
+        task = list[slot];
+        const uint32_t rid = task >> 1, hap = task & 1;
+        const vtx_record rec = records[rid];
+        const uint32_t my_locus = rec_locus[rid];
+        const vtx_locus loc = loci[my_locus];
+        const int m = (int)rec.read_len, n = (int)(hap ? loc.alt_len : loc.ref_len);
+        vtxf::Tab tb;
+        tb.gt = gtables; tb.hmask = n_heads - 1;
+        tb.ent = (uint32_t)(((size_t)(my_locus - gt_l0) * 2 + hap) * table_stride);
+        tb.head = tb.ent + max_hap * 8u;
+        tb.bytes = tb.ent + vtxf::tab_bytes_off(max_hap, n_heads);
+        tb.uq = tb.ent + vtxf::tab_uq_off(max_hap, n_heads);
+        tb.pb = tb.ent + vtxf::tab_pb_off(max_hap, n_heads);
+        const vtxf::LaneS<ST> ln{lane_mem + vtxf::S_WORDS * 64 + tid, 64, (ST*)lane_mem + tid, 64};
+        const vtxf::Lane gl{lane_mem + vtxf::LANE_WORDS * 64 + tid, 64};
+        const vtxf::Result res = vtxf::fast_task(read_arena + rec.read_off, m, tb, n, ln, gl, true);
+        if (res.score >= 0) (hap ? alt_score : ref_score)[rid] = res.score;
+        else { fail = true; why = res.why; }
+    }
     const uint64_t fm = __ballot(fail);
     if (fm) {
         uint32_t base = 0;
@@ -2199,8 +2263,9 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
 extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
                                             const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                             const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score, int32_t* alt_score,
-                                            uint32_t* fail_list, uint32_t* counters, uint32_t tasks_per_locus, uint32_t gt_l0,
-                                            uint32_t n_loci, uint8_t* gtables, size_t gtables_bytes, int stats, hipStream_t s) {
+                                            uint32_t* fail_list, uint32_t* refine_list, uint32_t* counters, uint32_t tasks_per_locus,
+                                            uint32_t gt_l0, uint32_t n_loci, uint8_t* gtables, size_t gtables_bytes, int stats,
+                                            hipStream_t s) {
     if (!n_tasks) return hipSuccess;
     const uint32_t n_heads = pick_heads(tasks_per_locus, true);
     const size_t tstride = band_table_stride(max_hap, n_heads);
@@ -2214,11 +2279,31 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     if (max_hap <= 255 && !force_wide)
         hipLaunchKernelGGL((band_diag_kernel<4, uint16_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
                            rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                           alt_score, fail_list, counters, st);
+                           alt_score, fail_list, refine_list, counters, st);
     else
         hipLaunchKernelGGL((band_diag_kernel<4, uint32_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
                            rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                           alt_score, fail_list, counters, st);
+                           alt_score, fail_list, refine_list, counters, st);
+    return hipGetLastError();
+}
+
+// band_refine_kernel over refine_list[0, n_list): the tables are the ones vtxk_launch_band_diag built
+extern "C" hipError_t vtxk_launch_band_refine(const uint32_t* refine_list, uint32_t n_list, const vtx_record* records,
+                                              const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
+                                              uint32_t max_hap, int32_t* ref_score, int32_t* alt_score, uint32_t* fail_list,
+                                              uint32_t* counters, uint32_t tasks_per_locus, uint32_t gt_l0, const uint8_t* gtables,
+                                              int stats, hipStream_t s) {
+    if (!n_list) return hipSuccess;
+    const uint32_t n_heads = pick_heads(tasks_per_locus, true);
+    const size_t tstride = band_table_stride(max_hap, n_heads);
+    static const bool force_wide = getenv("VTX_DIAG_WIDE") != nullptr;
+    const dim3 grid((n_list + 255) / 256), block(256);
+    if (max_hap <= 255 && !force_wide)
+        hipLaunchKernelGGL((band_refine_kernel<uint16_t>), grid, block, 0, s, refine_list, n_list, records, rec_locus, loci, read_arena,
+                           max_hap, (uint32_t)tstride, n_heads, gtables, gt_l0, ref_score, alt_score, fail_list, counters, (uint32_t)stats);
+    else
+        hipLaunchKernelGGL((band_refine_kernel<uint32_t>), grid, block, 0, s, refine_list, n_list, records, rec_locus, loci, read_arena,
+                           max_hap, (uint32_t)tstride, n_heads, gtables, gt_l0, ref_score, alt_score, fail_list, counters, (uint32_t)stats);
     return hipGetLastError();
 }
 

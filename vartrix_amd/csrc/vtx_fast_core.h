@@ -202,6 +202,56 @@ VTXF_FN int join_same(int D, int e) {
     return imin(6 * e - D, jg);
 }
 
+// ---- refinement of a same-diagonal join whose gap-free cost 6 e - D exceeds J_gap(D) (three or more errors within a few
+//      bases): J_gap prices a HYPOTHETICAL stretch over perfectly matching neighbour diagonals; the real ones are looked at.
+//      A stretch either stays within CORR diagonals of the runs' diagonal — then its cost is at least the exact optimum of an
+//      affine DP without a floor over that corridor, started up to mu bases before the first run's end and ended up to mu bases
+//      behind the second run's start at 1 per base given up (a stretch that gives up more costs >= 7 + mu + 1 >= 6 e - D for
+//      mu = 6 e - D - 8) — or its gaps total >= CORR + 1 per direction: J_gap restricted to G >= 3 (join_gap3; brute force and
+//      proof as for J_gap: oracle/vtx_certify.c, tests/test_certify.py).  The join costs the smaller of the two. ----
+constexpr int CORR = 2;
+VTXF_FN int join_gap3(int D) {                    // J_gap for G >= 3, D >= 3 (a lower bound of it above D = 22: 11 or 12)
+    if (D > 22) return 11;
+    const uint64_t lo = 0x0122001232012345ull;    // D = 3 .. 18: value - 11, a nibble each
+    const uint32_t hi = 0x1200u;                  // D = 19 .. 22
+    return 11 + (int)(D <= 18 ? (lo >> (4 * (D - 3))) & 15u : (hi >> (4 * (D - 19))) & 15u);
+}
+// x, yb: the read and the haplotype bytes; (xb, xb + d): the first run's last base; cells are prefix cells (i, j) = i read
+// bases and j haplotype bases consumed, diagonal index k = j - i - d + CORR
+VTXF_FN int corridor_cost(const uint8_t* x, int m, const uint8_t* yb, int n, int xb, int d, int D, int mu_a, int mu_b) {
+    constexpr int NEG = -100000, W = 2 * CORR + 1;
+    const int r0 = xb + 1 - mu_a, r1 = xb + D + 2 + mu_b;
+    int Hp[W], Fp[W];
+    VTXF_UNROLL
+    for (int k = 0; k < W; ++k) { Hp[k] = NEG; Fp[k] = NEG; }
+    Hp[CORR] = -mu_a;
+    {
+        int E = NEG;
+        VTXF_UNROLL
+        for (int k = CORR + 1; k < W; ++k) { E = imax(E - 1, Hp[k - 1] - 6); Hp[k] = E; }
+    }
+    for (int i = r0 + 1; i <= r1; ++i) {
+        const uint32_t xc = (i >= 1 && i <= m) ? x[i - 1] : 0x100u;
+        int Hc[W], Fc[W];
+        int E = NEG;
+        VTXF_UNROLL
+        for (int k = 0; k < W; ++k) {
+            const int j = i + d + (k - CORR);
+            int h = NEG, f = NEG;
+            if (j >= 0 && j <= n && i <= m) {
+                if (j >= 1 && Hp[k] > NEG / 2) h = Hp[k] + ((uint32_t)yb[j - 1] == xc ? 1 : -5);
+                if (k + 1 < W) { f = imax(Fp[k + 1] - 1, Hp[k + 1] - 6); if (f < NEG / 2) f = NEG; }
+                if (k >= 1) { E = imax(E - 1, Hc[k - 1] - 6); if (E < NEG / 2) E = NEG; } else E = NEG;
+                h = imax(h, imax(f, E));
+            } else E = NEG;
+            Hc[k] = h; Fc[k] = f;
+        }
+        VTXF_UNROLL
+        for (int k = 0; k < W; ++k) { Hp[k] = Hc[k]; Fp[k] = Fc[k]; }
+    }
+    return Hp[CORR] <= NEG / 2 ? (1 << 20) : mu_b + 1 - Hp[CORR];
+}
+
 // per-lane scratch (device: LDS, the 64 lanes of a wavefront interleaved; host: stride 1)
 //   s(k), k < SMAX          off-diagonal matches x << XS | y, ST = uint16_t (XS = 8, 40 entries: every haplotype of the batch has
 //                           <= 255 bases — padding 100 with indels up to 54) or uint32_t (XS = 16, 20 entries)
@@ -461,7 +511,10 @@ template <class LN> VTXF_FN int probe_rows(const uint8_t* x, const Tab& tb, cons
 
 // ---- phase 3 ----
 // Returns the score (>= 0) or -1 with *why set.
-template <class LN> VTXF_FN int32_t back(const Front& fr, int ns, const LN& ln, const Lane& gl, uint32_t* why, int ablate = 0) {
+// rf != nullptr: same-diagonal joins between main pieces are refined by the corridor DP (band_refine_kernel; the host test)
+struct Refine { const uint8_t* x; const uint8_t* yb; int m, n; };
+template <class LN> VTXF_FN int32_t back(const Front& fr, int ns, const LN& ln, const Lane& gl, uint32_t* why, int ablate = 0,
+                                         const Refine* rf = nullptr) {
     constexpr int SM = LN::SMAX, XS = LN::XS;
     constexpr uint32_t YM = LN::YM, ONE = LN::ONE;
     const int d = fr.d, r = fr.r;
@@ -582,7 +635,15 @@ template <class LN> VTXF_FN int32_t back(const Front& fr, int ns, const LN& ln, 
                     // entry at the first base of p (s = 0), q used whole (t = lq - 1): D bases between them, e of them mismatches
                     const int D = xp - (xq + lq);
                     e += (int)((fr.zc >> (4 * (q + 1))) & 15u);
-                    g = imax(g, lq + gq - (D == 0 ? 0 : join_same(D, e)));
+                    int J = D == 0 ? 0 : join_same(D, e);
+                    if (rf && D > 0 && J < 6 * e - D && e < 15) {
+                        // (e is exact below the nibbles' cap; the whole of q may be given up to its first base, p to its last)
+                        const int mu = imax(0, 6 * e - D - 8);
+                        const int lp = (int)((wp >> 8) & 0xffu) - xp + 1;
+                        const int inside = corridor_cost(rf->x, rf->m, rf->yb, rf->n, xq + lq - 1, d, D, imin(mu, lq - 1), imin(mu, lp - 1));
+                        J = imin(6 * e - D, imin(inside, join_gap3(D)));
+                    }
+                    g = imax(g, lq + gq - J);
                 }
                 ln.at(p) = (wp & 0x00ffffffu) | ((uint32_t)g << 24);
             }
@@ -638,13 +699,13 @@ template <class LN> VTXF_FN int32_t back(const Front& fr, int ns, const LN& ln, 
 
 struct Result { int32_t score; uint32_t why; };
 // all three phases on one lane (host test; device variant without pooled probes)
-template <class LN> VTXF_FN Result fast_task(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln) {
+template <class LN> VTXF_FN Result fast_task(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, const Lane& gl, bool refine) {
     const Front fr = front(x, m, tb, n, ln);
     if (fr.why != W_OK) return Result{-1, fr.why};
     const int ns = probe_rows(x, tb, fr, ln);
     uint32_t why = W_OK;
-    uint32_t generic[GM];
-    const int32_t sc = back(fr, ns, ln, Lane{generic, 1}, &why);
+    const Refine rf{x, tb.gt + tb.bytes, m, n};
+    const int32_t sc = back(fr, ns, ln, gl, &why, 0, refine ? &rf : nullptr);
     return Result{sc, why};
 }
 
