@@ -105,7 +105,7 @@ struct vtx_ctx {
     DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
     bool band_long_lists = false;      // (performance feedback between runs: see vtx_run)
-    DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail, d_fail_tmp;   // banded flavour
+    DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail, d_fail_tmp, d_refine;   // banded flavour
     DevBuf d_redo, d_redo_cnt;                                               // LUT kernel: records with non-ACGTN bytes
     // raw batches (vtx_submit_raw): barcode table + preparation scratch
     DevBuf d_bc_slots, d_bc_hash, d_bc_off, d_bc_bytes;
@@ -554,7 +554,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_cnt, &c->d_redo, &c->d_redo_cnt, &c->d_bc_slots, &c->d_bc_hash, &c->d_bc_off, &c->d_bc_bytes,
                       &c->d_raw, &c->d_tags, &c->d_raw_locus, &c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2,
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
-                      &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp};
+                      &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp, &c->d_refine};
     for (DevBuf* b : bufs) b->release();
     c->d_slow_ws.release(); c->d_slow_retry.release();
     DevBuf* gb[] = {&c->d_g_cnt, &c->d_g_row, &c->d_g_col, &c->d_g_alt, &c->d_g_ref, &c->d_g_unk, &c->d_g_val, &c->d_g_refval};
@@ -575,6 +575,9 @@ void vtx_destroy(vtx_ctx* c) {
 // records (192 B); the masked DP expands them into band slots (2 x band_stride u16) one slice of `slots` tasks at a
 // time.  A quarter of the tasks may be hard (noisy reads: 11 % at 3 % substitution errors) before anything spills to
 // the general kernel's list.  gt_bytes: the k-mer tables of every locus in global memory (0: tables in LDS).
+// records band_diag_kernel may leave for band_refine_kernel per chunk of tasks (a quarter of the tasks: 22 % are listed at 8 %
+// substitution errors; what does not fit goes to band_run_kernel as before)
+static uint32_t band_refine_cap(uint32_t chunk) { return std::max(65536u, chunk / 4); }
 struct BandPlan {
     uint64_t n_tasks = 0;
     uint32_t chunk = 0, band_stride = 0, hard_cap = 0, pend_cap = 0, slots = 0, poly_stride = 0, tasks_per_locus = 0;
@@ -629,6 +632,7 @@ static int band_reserve(vtx_ctx* c, BandPlan& p, bool quiet) {
     RES(d_over, 2 * (size_t)p.n_tasks * sizeof(uint32_t));      // second chance: what overflows again is appended behind the first list
     RES(d_cnt, 64 * sizeof(uint32_t));
     if (p.gt_bytes) RES(d_fail, 2 * (size_t)p.chunk * sizeof(uint32_t));  // tasks band_diag_kernel leaves to band_run_kernel (as listed, then sorted)
+    if (p.gt_bytes) RES(d_refine, (size_t)band_refine_cap(p.chunk) * vtxk_band_refine_words() * sizeof(uint32_t));   // records for band_refine_kernel
 #undef RES
     return VTX_OK;
 }
@@ -1138,14 +1142,14 @@ int vtx_run(vtx_ctx* c) {
             if (gt_n && !no_diag) {
                 HIP_TRY(c, hipMemsetAsync(d_cnt + 12, 0, sizeof(uint32_t), s));
                 HIP_TRY(c, hipMemsetAsync(d_cnt + 14, 0, sizeof(uint32_t), s));
-                // tasks whose bounds do not meet get a second chance in band_refine_kernel (their list: the half of d_fail the
-                // sorted copy will use afterwards)
+                // tasks with main pieces only whose bounds do not meet leave a record for band_refine_kernel
                 static const bool no_refine = getenv("VTX_BAND_NO_REFINE") != nullptr;        // experiment / test hook
-                uint32_t* refine_list = no_refine ? nullptr : c->d_fail.as<uint32_t>() + nt;
+                const uint32_t refine_cap = band_refine_cap(chunk);
+                uint32_t* refine_list = no_refine ? nullptr : c->d_refine.as<uint32_t>();
                 const hipError_t e = vtxk_launch_band_diag(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                                            c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                                            c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
-                                                           c->d_fail.as<uint32_t>(), refine_list, d_cnt, tasks_per_locus, gt_l0, gt_n,
+                                                           c->d_fail.as<uint32_t>(), refine_list, refine_cap, d_cnt, tasks_per_locus, gt_l0, gt_n,
                                                            c->d_gtables.as<uint8_t>(), gt_bytes, diag_stats, s);
                 if (e == hipSuccess) {
                     diag = true;
@@ -1154,7 +1158,7 @@ int vtx_run(vtx_ctx* c) {
                     HIP_TRY(c, hipEventRecord(c->ev[6], s));
                     HIP_TRY(c, hipStreamSynchronize(s));
                     n_fail = c->h_pin[8];
-                    const uint32_t n_refine = c->h_pin[9];
+                    const uint32_t n_refine = std::min(c->h_pin[9], refine_cap);
                     if (n_refine) {
                         HIP_TRY(c, vtxk_launch_band_refine(refine_list, n_refine, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                                            c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,

@@ -1849,6 +1849,8 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#define REFINE_WORDS 12u       // record of band_refine_kernel: task, d, r | cert << 4 | far matches << 16, zc, RM piece words
+extern "C" uint32_t vtxk_band_refine_words(void) { return REFINE_WORDS; }
 // ST: type of an off-diagonal match entry — uint16_t (x << 8 | y: 40 entries per task in the same LDS) when every haplotype of
 // the batch has <= 255 bases, else uint32_t (20 entries).
 template <int WPE, class ST>
@@ -1857,9 +1859,11 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
     const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
-    uint32_t* __restrict__ fail_list, uint32_t* __restrict__ refine_list, uint32_t* __restrict__ counters, uint32_t stats) {
-    // refine_list != nullptr: a task whose bounds do not meet goes to band_refine_kernel's list (counters[14]) instead of
-    // band_run_kernel's: that kernel prices the stretches of >= 3 errors within a few bases from the real neighbour diagonals.
+    uint32_t* __restrict__ fail_list, uint32_t* __restrict__ refine_rec, uint32_t refine_cap, uint32_t* __restrict__ counters,
+    uint32_t stats) {
+    // refine_rec != nullptr: a task with main pieces only whose bounds do not meet leaves a 12-word record for band_refine_kernel
+    // (counters[14]; REFINE_WORDS) instead of going to band_run_kernel's list: that kernel prices the stretches of >= 3 errors
+    // within a few bases from the real neighbour diagonals and needs nothing else of what this one found.
     // Four wavefronts per workgroup, each on its own 64 consecutive tasks and its own slice of the LDS (no workgroup barrier
     // anywhere): the four share their loci's tables in the CU's L1.
     constexpr int QROWS = 12;                                  // rows a lane contributes to the pool per round
@@ -2046,19 +2050,28 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         wave_sync();
     }
     if ((stats >> 8) == 2) { if (live && s_cnt[tid] == 0x7fffffff) counters[40] = 1; return; }   // (profiling aid) front + probes
+    uint32_t aux = 0xffffffffu;
     if (live) {
         const vtxf::Lane gl{(uint32_t*)q_ent + tid, 64};                 // (the queue is dead by now)
-        const int32_t sc = vtxf::back(fr, (int)min(s_cnt[tid], (uint32_t)LaneT::SMAX + 1u), ln, gl, &why, (int)(stats >> 8));
+        const int32_t sc = vtxf::back(fr, (int)min(s_cnt[tid], (uint32_t)LaneT::SMAX + 1u), ln, gl, &why, (int)(stats >> 8), nullptr, &aux);
         if (sc >= 0) *my_score = sc; else fail = true;
     }
-    const bool again = fail && why == vtxf::W_NOT_TIGHT && refine_list != nullptr;
+    bool again = fail && why == vtxf::W_NOT_TIGHT && refine_rec != nullptr && aux != 0xffffffffu;
     const uint64_t am = __ballot(again);
     if (am) {
         uint32_t base = 0;
         const int leader = __ffsll((long long)am) - 1;
         if (tid == leader) base = atomicAdd(&counters[14], (uint32_t)__popcll(am));
         base = (uint32_t)__shfl((int)base, leader);
-        if (again) refine_list[base + (uint32_t)__popcll(am & ((1ull << tid) - 1ull))] = task;
+        const uint32_t pos = base + (uint32_t)__popcll(am & ((1ull << tid) - 1ull));
+        if (again && pos >= refine_cap) again = false;              // (the record buffer is full: band_run_kernel takes it)
+        if (again) {
+            uint32_t* rec = refine_rec + (size_t)pos * REFINE_WORDS;
+            rec[0] = task; rec[1] = (uint32_t)fr.d;
+            rec[2] = (uint32_t)fr.r | ((uint32_t)fr.cert << 4) | (aux << 16);
+            rec[3] = fr.zc;
+            for (int i = 0; i < vtxf::RM; ++i) rec[4 + i] = i < fr.r ? ln.at(i) : 0u;
+        }
     }
     const uint64_t fm = __ballot(fail && !again);
     if (fm) {
@@ -2072,46 +2085,43 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
 }
 
 // =============================================================================================
-// band_refine_kernel — second chance of the tasks band_diag_kernel left because cert != ub (round 3).  One lane per listed task
-// runs the whole per-task logic again (vtxf::fast_task: the path the host unit test runs), this time with the corridor
-// refinement of the same-diagonal joins (vtx_fast_core.h: corridor_cost): where >= 3 errors fall within a few bases the
-// gap-free cost 6 e - D is above J_gap(D), the price of a hypothetical excursion over perfectly matching neighbour diagonals;
-// an affine DP over the five diagonals around the stretch (~25 rows) prices the real ones.  At 3 % substitution errors that
-// decides 55 % of the listed tasks (hard tasks 6.5 -> 2.9 % of all); what is still undecided goes to band_run_kernel's list.
-// A compact list instead of a branch inside band_diag_kernel: there the DP would run in nearly every wavefront for 6 % of the lanes.
+// band_refine_kernel — second chance of the tasks band_diag_kernel left because cert != ub (round 3).  One lane per record
+// (task, diagonal, certificate, far matches, the main pieces and the mismatches between them: everything the main-only run bound
+// needs) runs that bound again (vtxf::main_pieces_ub, the function band_diag_kernel ran), this time with the corridor refinement
+// of the same-diagonal joins (vtx_fast_core.h: corridor_cost): where >= 3 errors fall within a few bases the gap-free cost
+// 6 e - D is above J_gap(D), the price of a hypothetical excursion over perfectly matching neighbour diagonals; an affine DP
+// over the five diagonals around the stretch (~25 rows) prices the real ones.  At 3 % substitution errors that decides 55 % of
+// the records (hard tasks 6.5 -> 3.3 % of all); what is still undecided goes to band_run_kernel's list.  A compact list instead
+// of a branch inside band_diag_kernel: there the DP would run in nearly every wavefront for 6 % of the lanes.
 // =============================================================================================
-template <class ST>
 __global__ __launch_bounds__(256) void band_refine_kernel(
-    const uint32_t* __restrict__ list, uint32_t n_list,
+    const uint32_t* __restrict__ recs, uint32_t n_recs,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
     const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ fail_list, uint32_t* __restrict__ counters, uint32_t stats) {
-    __shared__ uint32_t lane_mem_[4][(vtxf::LANE_WORDS + vtxf::GM) * 64];
+    __shared__ uint32_t piece_mem_[4][vtxf::RM * 64];
     const int wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
-    uint32_t* lane_mem = lane_mem_[wv];
     const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
     bool fail = false;
-    uint32_t why = 0, task = 0;
-    if (slot < n_list) {
-        task = list[slot];
+    uint32_t task = 0;
+    if (slot < n_recs) {
+        const uint4* rp = (const uint4*)(recs + (size_t)slot * REFINE_WORDS);
+        const uint4 h = rp[0], p0 = rp[1], p1 = rp[2];
+        task = h.x;
+        const int d = (int)h.y, r = (int)(h.z & 15u), cert = (int)((h.z >> 4) & 0xfffu), far_e = (int)(h.z >> 16);
         const uint32_t rid = task >> 1, hap = task & 1;
         const vtx_record rec = records[rid];
         const uint32_t my_locus = rec_locus[rid];
         const vtx_locus loc = loci[my_locus];
-        const int m = (int)rec.read_len, n = (int)(hap ? loc.alt_len : loc.ref_len);
-        vtxf::Tab tb;
-        tb.gt = gtables; tb.hmask = n_heads - 1;
-        tb.ent = (uint32_t)(((size_t)(my_locus - gt_l0) * 2 + hap) * table_stride);
-        tb.head = tb.ent + max_hap * 8u;
-        tb.bytes = tb.ent + vtxf::tab_bytes_off(max_hap, n_heads);
-        tb.uq = tb.ent + vtxf::tab_uq_off(max_hap, n_heads);
-        tb.pb = tb.ent + vtxf::tab_pb_off(max_hap, n_heads);
-        const vtxf::LaneS<ST> ln{lane_mem + vtxf::S_WORDS * 64 + tid, 64, (ST*)lane_mem + tid, 64};
-        const vtxf::Lane gl{lane_mem + vtxf::LANE_WORDS * 64 + tid, 64};
-        const vtxf::Result res = vtxf::fast_task(read_arena + rec.read_off, m, tb, n, ln, gl, true);
-        if (res.score >= 0) (hap ? alt_score : ref_score)[rid] = res.score;
-        else { fail = true; why = res.why; }
+        const vtxf::Lane pl{piece_mem_[wv] + tid, 64};
+        pl.at(0) = p0.x; pl.at(1) = p0.y; pl.at(2) = p0.z; pl.at(3) = p0.w;
+        pl.at(4) = p1.x; pl.at(5) = p1.y; pl.at(6) = p1.z; pl.at(7) = p1.w;
+        const uint8_t* yb = gtables + ((size_t)(my_locus - gt_l0) * 2 + hap) * table_stride + vtxf::tab_bytes_off(max_hap, n_heads);
+        const vtxf::Refine rf{read_arena + rec.read_off, yb, (int)rec.read_len, (int)(hap ? loc.alt_len : loc.ref_len)};
+        const int ub = max(max(vtxf::K - 1, far_e > 0 ? far_e + 5 : 0), vtxf::main_pieces_ub(pl, r, h.w, d, &rf));
+        if (ub == cert) (hap ? alt_score : ref_score)[rid] = cert;
+        else fail = true;
     }
     const uint64_t fm = __ballot(fail);
     if (fm) {
@@ -2121,7 +2131,7 @@ __global__ __launch_bounds__(256) void band_refine_kernel(
         base = (uint32_t)__shfl((int)base, leader);
         if (fail) {
             fail_list[base + (uint32_t)__popcll(fm & ((1ull << tid) - 1ull))] = task;
-            if (stats & 0xffu) atomicAdd(&counters[32 + why], 1u);
+            if (stats & 0xffu) atomicAdd(&counters[32 + vtxf::W_NOT_TIGHT], 1u);
         }
     }
 }
@@ -2263,9 +2273,9 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
 extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
                                             const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                             const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score, int32_t* alt_score,
-                                            uint32_t* fail_list, uint32_t* refine_list, uint32_t* counters, uint32_t tasks_per_locus,
-                                            uint32_t gt_l0, uint32_t n_loci, uint8_t* gtables, size_t gtables_bytes, int stats,
-                                            hipStream_t s) {
+                                            uint32_t* fail_list, uint32_t* refine_rec, uint32_t refine_cap, uint32_t* counters,
+                                            uint32_t tasks_per_locus, uint32_t gt_l0, uint32_t n_loci, uint8_t* gtables,
+                                            size_t gtables_bytes, int stats, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
     const uint32_t n_heads = pick_heads(tasks_per_locus, true);
     const size_t tstride = band_table_stride(max_hap, n_heads);
@@ -2279,31 +2289,25 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     if (max_hap <= 255 && !force_wide)
         hipLaunchKernelGGL((band_diag_kernel<4, uint16_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
                            rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                           alt_score, fail_list, refine_list, counters, st);
+                           alt_score, fail_list, refine_rec, refine_cap, counters, st);
     else
         hipLaunchKernelGGL((band_diag_kernel<4, uint32_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
                            rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                           alt_score, fail_list, refine_list, counters, st);
+                           alt_score, fail_list, refine_rec, refine_cap, counters, st);
     return hipGetLastError();
 }
 
-// band_refine_kernel over refine_list[0, n_list): the tables are the ones vtxk_launch_band_diag built
-extern "C" hipError_t vtxk_launch_band_refine(const uint32_t* refine_list, uint32_t n_list, const vtx_record* records,
+// band_refine_kernel over n_recs records of REFINE_WORDS words: the tables are the ones vtxk_launch_band_diag built
+extern "C" hipError_t vtxk_launch_band_refine(const uint32_t* recs, uint32_t n_recs, const vtx_record* records,
                                               const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                               uint32_t max_hap, int32_t* ref_score, int32_t* alt_score, uint32_t* fail_list,
                                               uint32_t* counters, uint32_t tasks_per_locus, uint32_t gt_l0, const uint8_t* gtables,
                                               int stats, hipStream_t s) {
-    if (!n_list) return hipSuccess;
+    if (!n_recs) return hipSuccess;
     const uint32_t n_heads = pick_heads(tasks_per_locus, true);
     const size_t tstride = band_table_stride(max_hap, n_heads);
-    static const bool force_wide = getenv("VTX_DIAG_WIDE") != nullptr;
-    const dim3 grid((n_list + 255) / 256), block(256);
-    if (max_hap <= 255 && !force_wide)
-        hipLaunchKernelGGL((band_refine_kernel<uint16_t>), grid, block, 0, s, refine_list, n_list, records, rec_locus, loci, read_arena,
-                           max_hap, (uint32_t)tstride, n_heads, gtables, gt_l0, ref_score, alt_score, fail_list, counters, (uint32_t)stats);
-    else
-        hipLaunchKernelGGL((band_refine_kernel<uint32_t>), grid, block, 0, s, refine_list, n_list, records, rec_locus, loci, read_arena,
-                           max_hap, (uint32_t)tstride, n_heads, gtables, gt_l0, ref_score, alt_score, fail_list, counters, (uint32_t)stats);
+    hipLaunchKernelGGL(band_refine_kernel, dim3((n_recs + 255) / 256), dim3(256), 0, s, recs, n_recs, records, rec_locus, loci, read_arena,
+                       max_hap, (uint32_t)tstride, n_heads, gtables, gt_l0, ref_score, alt_score, fail_list, counters, (uint32_t)stats);
     return hipGetLastError();
 }
 

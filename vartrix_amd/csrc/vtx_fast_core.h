@@ -513,8 +513,41 @@ template <class LN> VTXF_FN int probe_rows(const uint8_t* x, const Tab& tb, cons
 // Returns the score (>= 0) or -1 with *why set.
 // rf != nullptr: same-diagonal joins between main pieces are refined by the corridor DP (band_refine_kernel; the host test)
 struct Refine { const uint8_t* x; const uint8_t* yb; int m, n; };
+
+// The run bound over main pieces only (pl.at(i), i < r: first base | last base << 8 | . | G << 24, in base order; zc: mismatching
+// bases between consecutive pieces, a nibble each): all on one diagonal — a predecessor always lies before its successor, so one
+// pass over the ordered pairs q < p settles every G (no back edges), and every join is a same-diagonal join.
+template <class PL> VTXF_FN int main_pieces_ub(const PL& pl, int r, uint32_t zc, int d, const Refine* rf) {
+    int ub = 0;
+    for (int p = 0; p < r; ++p) {
+        const uint32_t wp = pl.at(p);
+        const int xp = (int)(wp & 0xffu), lp = (int)((wp >> 8) & 0xffu) - xp + 1;
+        int g = 0, e = 0;
+        for (int q = p - 1; q >= 0; --q) {
+            const uint32_t wq = pl.at(q);
+            const int xq = (int)(wq & 0xffu), lq = (int)((wq >> 8) & 0xffu) - xq + 1, gq = (int)(wq >> 24);
+            // entry at the first base of p (s = 0), q used whole (t = lq - 1): D bases between them, e of them mismatches
+            const int D = xp - (xq + lq);
+            e += (int)((zc >> (4 * (q + 1))) & 15u);
+            int J = D == 0 ? 0 : join_same(D, e);
+            if (rf && D > 0 && J < 6 * e - D && e < 15) {
+                // (e is exact below the nibbles' cap; the whole of q may be given up to its first base, p to its last)
+                const int mu = imax(0, 6 * e - D - 8);
+                const int inside = corridor_cost(rf->x, rf->m, rf->yb, rf->n, xq + lq - 1, d, D, imin(mu, lq - 1), imin(mu, lp - 1));
+                J = imin(6 * e - D, imin(inside, join_gap3(D)));
+            }
+            g = imax(g, lq + gq - J);
+        }
+        pl.at(p) = (wp & 0x00ffffffu) | ((uint32_t)g << 24);
+        ub = imax(ub, lp + g);
+    }
+    return ub;
+}
+// aux (optional): when the verdict is W_NOT_TIGHT with main pieces only, the number of far matches (the refinement needs nothing
+// else of the off-diagonal matches); 0xffffffff otherwise
 template <class LN> VTXF_FN int32_t back(const Front& fr, int ns, const LN& ln, const Lane& gl, uint32_t* why, int ablate = 0,
-                                         const Refine* rf = nullptr) {
+                                         const Refine* rf = nullptr, uint32_t* aux = nullptr) {
+    if (aux) *aux = 0xffffffffu;
     constexpr int SM = LN::SMAX, XS = LN::XS;
     constexpr uint32_t YM = LN::YM, ONE = LN::ONE;
     const int d = fr.d, r = fr.r;
@@ -623,30 +656,7 @@ template <class LN> VTXF_FN int32_t back(const Front& fr, int ns, const LN& ln, 
         for (int i = 0; i < n_all; ++i) word(i) &= 0x00ffffffu;
         bool changed = n_all > 1;
         if (ng == 0) {
-            // main pieces only: all on one diagonal, in base order — a predecessor always lies before its successor, so one pass over
-            // the ordered pairs q < p settles every G (no back edges), and every join is a same-diagonal join
-            for (int p = 1; p < r; ++p) {
-                const uint32_t wp = ln.at(p);
-                const int xp = (int)(wp & 0xffu);
-                int g = 0, e = 0;
-                for (int q = p - 1; q >= 0; --q) {
-                    const uint32_t wq = ln.at(q);
-                    const int xq = (int)(wq & 0xffu), lq = (int)((wq >> 8) & 0xffu) - xq + 1, gq = (int)(wq >> 24);
-                    // entry at the first base of p (s = 0), q used whole (t = lq - 1): D bases between them, e of them mismatches
-                    const int D = xp - (xq + lq);
-                    e += (int)((fr.zc >> (4 * (q + 1))) & 15u);
-                    int J = D == 0 ? 0 : join_same(D, e);
-                    if (rf && D > 0 && J < 6 * e - D && e < 15) {
-                        // (e is exact below the nibbles' cap; the whole of q may be given up to its first base, p to its last)
-                        const int mu = imax(0, 6 * e - D - 8);
-                        const int lp = (int)((wp >> 8) & 0xffu) - xp + 1;
-                        const int inside = corridor_cost(rf->x, rf->m, rf->yb, rf->n, xq + lq - 1, d, D, imin(mu, lq - 1), imin(mu, lp - 1));
-                        J = imin(6 * e - D, imin(inside, join_gap3(D)));
-                    }
-                    g = imax(g, lq + gq - J);
-                }
-                ln.at(p) = (wp & 0x00ffffffu) | ((uint32_t)g << 24);
-            }
+            ub = imax(ub, main_pieces_ub(ln, r, fr.zc, d, rf));
             changed = false;
         }
         uint64_t zpre = 0;                                  // byte i: mismatching bases between main pieces 0 and i
@@ -692,7 +702,7 @@ template <class LN> VTXF_FN int32_t back(const Front& fr, int ns, const LN& ln, 
             ub = imax(ub, lp + (int)(wp >> 24));
         }
     }
-    if (fr.cert != ub) { *why = W_NOT_TIGHT; return -1; }
+    if (fr.cert != ub) { *why = W_NOT_TIGHT; if (aux && ng == 0) *aux = (uint32_t)far_e; return -1; }
     *why = W_OK;
     return fr.cert;
 }
