@@ -35,6 +35,15 @@
  *       J_same(D, e) = min(6 e - D, J_gap(D));      J_same(D) = J_free(D) when the bases are not looked at.
  *   (Round 2 used max(7, 13 - D) for the gapped path: it forgot that 5 (g - 1) matches cannot span a long stretch, and
  *   took e at its minimum: at 3 % substitution errors that made 10.5 % of the tasks hard, this form 6.0 %.)
+ *   Refinement (vtxo_set_corridor(2); on the device: band_refine_kernel / vtx_fast_core.h corridor_cost).  Where 6 e - D >
+ *   J_gap(D) — three or more errors within a few bases — J_gap is the price of a stretch over PERFECTLY matching neighbour
+ *   diagonals.  A stretch either stays within kc diagonals of the runs' diagonal: then it costs at least the optimum of an affine
+ *   DP without a floor over that corridor, with the real bases, from a base of the first run to a base of the second, 1 per base
+ *   of a run given up (up to mu = 6 e - D - 8 bases each side: a stretch that gives up more costs >= 7 + mu + 1 >= 6 e - D) —
+ *   or it reaches a diagonal >= kc + 1 away and comes back: gaps of total length G >= kc + 1 per direction, priced by J_gap
+ *   restricted to G >= kc + 1 (same brute force; for kc = 2: 16, 15, 14, 13, 12, 11, 13, 14, ... >= 11).  The join costs the
+ *   smaller of the two.  Both forms keep J(D + 1) >= J(D) - 1, so the piece-level bound may still join at the latest exit and the
+ *   earliest entry.  At 3 % substitution errors: 6.0 -> 2.4 % of the tasks with cert != ub.
  *   Any designation of further (short) runs as chain members keeps the inequality, so the
  *   maximisation may range over ALL sub-runs of pieces (length >= 1).
  */

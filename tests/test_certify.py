@@ -138,6 +138,56 @@ def test_join_cost_table():
         prev_gap = gap
 
 
+def test_join_gap_with_long_gaps_table():
+    """join_gap3 of vtx_fast_core.h (a stretch whose gaps total G >= 3 per direction: it leaves the five-diagonal corridor of the
+    refinement) against the brute force over (gap events, gap length, mismatches); the device table is exact up to D = 22 and
+    the constant 11 above, which must be a lower bound; leaving a run one base earlier never pays (J(D + 1) >= J(D) - 1)."""
+    def brute(D, g0):
+        best = 10 ** 6
+        for g in range(2, 2 * D + 4):
+            for G in range(max((g + 1) // 2, g0), D + 1):
+                for mm in range(0, D - G + 1):
+                    matches = D - G - mm
+                    if matches <= 5 * (g + mm - 1):
+                        best = min(best, 5 * g + 2 * G + 5 * mm - matches)
+                        break
+        return best
+    lo, hi = 0x0122001232012345, 0x1200
+    prev = None
+    for D in range(3, 120):
+        want = brute(D, 3)
+        have = 11 if D > 22 else 11 + ((lo >> (4 * (D - 3))) & 15 if D <= 18 else (hi >> (4 * (D - 19))) & 15)
+        assert have == want if D <= 22 else 11 <= want <= 12, (D, have, want)
+        if prev is not None:
+            assert want >= prev - 1, D
+        prev = want
+
+
+def test_corridor_refinement_keeps_the_bound_valid():
+    """vtxo_set_corridor(2): same-diagonal joins whose gap-free cost exceeds J_gap are priced by the corridor DP (the oracle's
+    restatement of vtx_fast_core.h: corridor_cost).  ub >= full must still hold on noisy reads, repeat-rich genomes and planted
+    near-diagonal repeats, and the refinement must really decide more tasks."""
+    import stress_batches as SB
+    from vartrix_amd import synth
+    L = oracle.lib()
+    batches = [("3 %% errors", synth.make_batch(synth.SynthSpec(n_loci=60, n_barcodes=500, reads_per_locus=48, sub_error=0.03)), 500),
+               ("8 %% errors", synth.make_batch(synth.SynthSpec(n_loci=40, n_barcodes=500, reads_per_locus=48, sub_error=0.08)), 500)]
+    batches += list(SB.repeat_rich_batches(trials=2, loci=20, reads=12)) + list(SB.near_repeat_batches(trials=4, loci=30))
+    tight = {0: 0, 2: 0}
+    try:
+        for kc in (0, 2):
+            L.vtxo_set_corridor(kc)
+            for label, batch, nb in batches:
+                r = certify(batch, default_config(aligner="banded", n_barcodes=nb), threads=os.cpu_count() or 8)
+                assert int((r["ub"] < r["full"]).sum()) == 0, (label, kc)
+                assert int((r["ub_exact"] < r["full"]).sum()) == 0, (label, kc)
+                assert int((r["ub"] < r["ub_exact"]).sum()) == 0, (label, kc)
+                tight[kc] += int((r["cert"] == r["ub"]).sum())
+    finally:
+        L.vtxo_set_corridor(0)
+    assert tight[2] > tight[0] + 100, tight
+
+
 def test_bounds_on_random_low_entropy_strings():
     """Adversarial for the upper bound: two- and three-letter alphabets make exact-match runs on many diagonals
     at once, so chains that hop diagonals, re-enter pieces half way and reuse overlapping pieces all occur."""

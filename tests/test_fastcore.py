@@ -88,6 +88,22 @@ def test_near_repeats_and_real_sequence(core, wide):
     assert fr[0] > (0.5 if wide else 0.75), fr
 
 
+def test_corridor_refinement_is_exact_and_decides_more(core):
+    """Bit 30 of the harness' flags: back() prices same-diagonal joins of >= 3 close errors by the corridor DP over the real
+    neighbour diagonals (what band_refine_kernel runs on the records band_diag_kernel leaves).  Every decided score is still the
+    oracle's, and at 3 % substitution errors clearly more tasks are decided."""
+    dec = {}
+    for err in (0.01, 0.03, 0.08):
+        for rl, pad in ((150, 100), (100, 60)):
+            batch = synth.make_batch(synth.SynthSpec(n_loci=120, n_barcodes=500, reads_per_locus=48, sub_error=err, read_len=rl, padding=pad, seed=77))
+            for rf in (0, 1):
+                frac, why = check(core, batch, 500, "err %g len %d, refine %d" % (err, rl, rf), 1024 | (rf << 30))
+                dec[(err, rl, rf)] = frac
+    assert dec[(0.03, 150, 1)] > dec[(0.03, 150, 0)] + 0.02, dec
+    for label, batch, nb in list(SB.near_repeat_batches(trials=4)) + list(SB.repeat_rich_batches(trials=3)):
+        check(core, batch, nb, label, 1024 | (1 << 30))
+
+
 def test_real_read_shapes(core):
     """Soft clips, adapter tails, spliced reads, poly-A, N bases (tests/stress_batches.py)."""
     fr = []

@@ -163,6 +163,41 @@ np.save(sys.argv[1], np.concatenate(out))
     assert res[0][-1] > 1000                                   # tasks really took the general path
 
 
+def test_refine_kernel_on_and_off_give_the_same_scores():
+    """VTX_BAND_NO_REFINE=1 sends the tasks whose bounds do not meet straight to band_run_kernel (no band_refine_kernel): identical
+    scores on noisy reads, fewer hard tasks with the kernel on (separate process: the hook is read once)."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from vartrix_amd import lib, synth
+from vartrix_amd.abi import default_config
+out = []
+hard = 0
+for err in (0.01, 0.03, 0.08):
+    batch = synth.make_batch(synth.SynthSpec(n_loci=300, n_barcodes=500, reads_per_locus=48, sub_error=err, seed=91))
+    with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=500)) as ctx:
+        ctx.submit(batch); ctx.run()
+        r, a = ctx.fetch_scores()
+        hard += int(ctx.timing().hard_tasks)
+        out.append(r); out.append(a)
+out.append(np.array([hard], np.int32))
+np.save(sys.argv[1], np.concatenate(out))
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    import tempfile
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for off in (0, 1):
+            env = dict(os.environ)
+            env.pop("VTX_BAND_NO_REFINE", None)
+            if off:
+                env["VTX_BAND_NO_REFINE"] = "1"
+            path = os.path.join(td, "r%d.npy" % off)
+            subprocess.check_call([sys.executable, "-c", code, path], env=env)
+            res.append(np.load(path))
+    assert np.array_equal(res[0][:-1], res[1][:-1])
+    assert res[0][-1] < 0.8 * res[1][-1], (res[0][-1], res[1][-1])
+
+
 def test_single_diagonal_stage_on_and_off_give_the_same_scores():
     """VTX_BAND_NO_DIAG=1 runs the banded flavour without band_diag_kernel (band_run_kernel takes every task, the round-2 path):
     identical scores (separate process: the hook is read from the environment)."""
