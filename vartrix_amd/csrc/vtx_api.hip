@@ -1195,6 +1195,7 @@ int vtx_run(vtx_ctx* c) {
                                                  c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt,
                                                  tasks_per_locus, gt_l0, gt_n, gt_n ? c->d_gtables.as<uint8_t>() : nullptr, gt_bytes,
                                                  diag ? fail_list : nullptr, c->band_long_lists ? 1 : 0, s));
+            HIP_TRY(c, hipEventRecord(c->ev[5], s));                  // (complete once the read-back below is: no synchronisation of its own)
             HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
             // (task-list mode runs the 15-entry variant: nothing to give a second chance to)
@@ -1217,6 +1218,7 @@ int vtx_run(vtx_ctx* c) {
                                                  c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
                                                  c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt, tasks_per_locus, gt_l0,
                                                  gt_n, c->d_gtables.as<uint8_t>(), gt_bytes, c->d_over.as<uint32_t>() + a0, 0, s));
+                HIP_TRY(c, hipEventRecord(c->ev[5], s));
                 HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
                 HIP_TRY(c, hipStreamSynchronize(s));
                 const uint32_t again = cnt[1] - a1;          // <= a1 - a0: source and destination do not overlap
@@ -1226,8 +1228,6 @@ int vtx_run(vtx_ctx* c) {
                 ++launches;
             }
             over_before = cnt[1];
-            HIP_TRY(c, hipEventRecord(c->ev[5], s));
-            HIP_TRY(c, hipStreamSynchronize(s));
             {
                 float ms = 0;
                 HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));

@@ -1146,8 +1146,12 @@ __device__ __forceinline__ void build_tables(uint8_t* tables, uint32_t n_tab, ui
                 bytes[y] = hy[y];
                 fb[y] = hy[y] & 0x7f;
                 if (y + KMER <= hn) {
-                    ent[y].x = (uint32_t)hy[y] | ((uint32_t)hy[y + 1] << 8) | ((uint32_t)hy[y + 2] << 16) | ((uint32_t)hy[y + 3] << 24);
-                    ent[y].y = (uint32_t)hy[y + 4] | ((uint32_t)hy[y + 5] << 8) | (CH_END << 16);
+                    // (the bucket rides in the next-pointer field until the chains are linked: the serial loop below is a quarter of
+                    //  this kernel's instructions, and the hash was most of an iteration)
+                    const uint32_t lo = (uint32_t)hy[y] | ((uint32_t)hy[y + 1] << 8) | ((uint32_t)hy[y + 2] << 16) | ((uint32_t)hy[y + 3] << 24);
+                    const uint32_t hi = (uint32_t)hy[y + 4] | ((uint32_t)hy[y + 5] << 8);
+                    ent[y].x = lo;
+                    ent[y].y = hi | (kw_hash(lo, hi, n_heads - 1) << 16);
                 }
             }
             for (uint32_t i = tid; i < n_heads; i += NT) head[i] = CH_END;
@@ -1163,9 +1167,9 @@ __device__ __forceinline__ void build_tables(uint8_t* tables, uint32_t n_tab, ui
             uint16_t* head = TB_HEAD(tb);
             if (hn >= KMER)
                 for (int y = (int)hn - KMER; y >= 0; --y) {
-                    const uint2 e = ent[y];
-                    const uint32_t h = kw_hash(e.x, e.y & 0xffffu, n_heads - 1);
-                    ent[y].y = (e.y & 0xffffu) | ((uint32_t)head[h] << 16);
+                    const uint32_t ey = ent[y].y;
+                    const uint32_t h = ey >> 16;
+                    ent[y].y = (ey & 0xffffu) | ((uint32_t)head[h] << 16);
                     head[h] = (uint16_t)y;
                 }
         }
