@@ -2055,9 +2055,17 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     }
     if ((stats >> 8) == 2) { if (live && s_cnt[tid] == 0x7fffffff) counters[40] = 1; return; }   // (profiling aid) front + probes
     uint32_t aux = 0xffffffffu;
+    // ---- the last phase, every lane for itself: sort, harmless tests, closure, run bound (vtx_fast_core.h).  (Pooling the harmless
+    //      tests over the wavefront like the probes — one queue entry per match, A | T << 8 left in the entry, a short recurrence per
+    //      owner — was built and measured: 1.67 ms pooled against 1.7 ms per lane, 18.24 against 18.33 ms per step: not kept.) ----
+    const int ns = (int)min(s_cnt[tid], (uint32_t)LaneT::SMAX + 1u);
+    if (live && ns > LaneT::SMAX) { live = false; fail = true; why = vtxf::W_MATCHES; }
+    if (live) vtxf::back_sort(ns, ln);
+    if ((stats >> 8) == 7) { if (live && ns == 0x7fffffff) counters[40] = 1; return; }            // (profiling aid) ... + the sort
+    if (live && !vtxf::back_harmless(fr, ns, ln)) { live = false; fail = true; why = vtxf::W_NOT_HARMLESS; }
     if (live) {
         const vtxf::Lane gl{(uint32_t*)q_ent + tid, 64};                 // (the queue is dead by now)
-        const int32_t sc = vtxf::back(fr, (int)min(s_cnt[tid], (uint32_t)LaneT::SMAX + 1u), ln, gl, &why, (int)(stats >> 8), nullptr, &aux);
+        const int32_t sc = vtxf::back_rest(fr, ns, ln, gl, &why, (int)(stats >> 8), nullptr, &aux);
         if (sc >= 0) *my_score = sc; else fail = true;
     }
     bool again = fail && why == vtxf::W_NOT_TIGHT && refine_rec != nullptr && aux != 0xffffffffu;

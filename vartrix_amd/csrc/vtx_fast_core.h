@@ -545,45 +545,72 @@ template <class PL> VTXF_FN int main_pieces_ub(const PL& pl, int r, uint32_t zc,
 }
 // aux (optional): when the verdict is W_NOT_TIGHT with main pieces only, the number of far matches (the refinement needs nothing
 // else of the off-diagonal matches); 0xffffffff otherwise
-template <class LN> VTXF_FN int32_t back(const Front& fr, int ns, const LN& ln, const Lane& gl, uint32_t* why, int ablate = 0,
-                                         const Refine* rf = nullptr, uint32_t* aux = nullptr) {
-    if (aux) *aux = 0xffffffffu;
-    constexpr int SM = LN::SMAX, XS = LN::XS;
-    constexpr uint32_t YM = LN::YM, ONE = LN::ONE;
-    const int d = fr.d, r = fr.r;
-    if (ns > SM) { *why = W_MATCHES; return -1; }
-    // (x, y) order (a lane probing its own rows produces it; pooled probes arrive in any order)
+// ---- the harmless test in two parts, so that the device can pool the first over a wavefront (band_diag_kernel) ----
+// harmless_item: one off-diagonal match (sx, sy) of a task against the task's main pieces pl.at(i), i < r.  Returns A | T << 8:
+//   A  the dp bound the main matches that end before it give (bv - q + 1; 0: none),
+//   T  the largest dp + 1 that keeps it harmless: it may neither end the chain (dp < best_dp) nor be preferred by a main match
+//      (dp + (sx + K) + (sy + K) - (x_p + y_p) + 1 < dp(p) at the first match p of every piece that starts after it ends).
+// Both clamped to a byte: dp bounds never exceed best_dp <= 187, and A = 255 fails every T.
+// harmless_step: the matches of a task in (x, y) order: dp = max(K, 1 + the largest bound so far, A); harmless iff dp < T.
+template <class PL> VTXF_FN uint32_t harmless_item(const PL& pl, int r, int d, int best_dp, int sx, int sy) {
+    const int q = sx + sy - d;
+    const int lim = imin(sx, sy - d) - K;                          // last main row that ends before (sx, sy)
+    int bv = -1000000, minH = 1000000;
+    for (int i = 0; i < r; ++i) {
+        const uint32_t pw = pl.at(i);
+        const int pu = (int)(pw & 0xffu), pv = (int)((pw >> 8) & 0xffu), dpf = (int)((pw >> 16) & 0xffu);
+        const int lm1 = pv - 5 - pu;
+        const int t = imin(lim - pu, lm1);
+        if (t >= 0) bv = imax(bv, dpf + t + 2 * (pu + t + K));               // V of the piece's last visible match (without d)
+        const int t0 = imax(0, imax(sx + K - pu, sy + K - d - pu));          // first match of the piece that starts after s ends
+        if (t0 <= lm1) minH = imin(minH, dpf + 3 * t0 + 2 * pu);
+    }
+    const int A = bv > -1000000 ? imin(imax(bv - q + 1, 0), 255) : 0;
+    const int T = imin(imax(imin(best_dp, minH - q - 2 * K - 1), 0), 255);
+    return (uint32_t)A | ((uint32_t)T << 8);
+}
+VTXF_FN bool harmless_step(uint32_t at, int& runmax) {
+    const int dp = imax(imax(K, runmax + 1), (int)(at & 0xffu));
+    runmax = imax(runmax, dp);
+    return dp < (int)(at >> 8);
+}
+// (x, y) order of the off-diagonal matches (a lane probing its own rows produces it; pooled probes arrive in any order)
+template <class LN> VTXF_FN void back_sort(int ns, const LN& ln) {
     for (int k = 1; k < ns; ++k) {
         const uint32_t v = ln.s(k);
         int j = k - 1;
         while (j >= 0 && ln.s(j) > v) { ln.s(j + 1) = ln.s(j); --j; }
         ln.s(j + 1) = (typename LN::SType)v;
     }
-    // ---- harmless test of every off-diagonal match ----
-    int far_e = 0, runmax = 0;
-    const int nc = ns;
+}
+template <class LN> VTXF_FN bool back_harmless(const Front& fr, int ns, const LN& ln) {
+    int runmax = 0;
     for (int k = 0; k < ns; ++k) {
         const uint32_t w = ln.s(k);
-        const int sx = (int)(w >> XS), sy = (int)(w & YM);
-        const int q = sx + sy - d;
-        const int lim = imin(sx, sy - d) - K;                      // last main row that ends before (sx, sy)
-        int bv = -1000000, minH = 1000000;
-        for (int i = 0; i < r; ++i) {
-            const uint32_t pw = ln.at(i);
-            const int pu = (int)(pw & 0xffu), pv = (int)((pw >> 8) & 0xffu), dpf = (int)((pw >> 16) & 0xffu);
-            const int lm1 = pv - 5 - pu;
-            const int t = imin(lim - pu, lm1);
-            if (t >= 0) bv = imax(bv, dpf + t + 2 * (pu + t + K));           // V of the piece's last visible match (without d)
-            const int t0 = imax(0, imax(sx + K - pu, sy + K - d - pu));      // first match of the piece that starts after s ends
-            if (t0 <= lm1) minH = imin(minH, dpf + 3 * t0 + 2 * pu);
-        }
-        int dp = imax(K, runmax + 1);
-        if (bv > -1000000) dp = imax(dp, bv - q + 1);
-        runmax = imax(runmax, dp);
-        // s could end the chain, or a main match could prefer it:  dp + (sx + K) + (sy + K) - (x_p + y_p) + 1 >= dp(p)
-        if (dp >= fr.best_dp || dp + q + 2 * K + 1 >= minH) { *why = W_NOT_HARMLESS; return -1; }
+        if (!harmless_step(harmless_item(ln, fr.r, fr.d, fr.best_dp, (int)(w >> LN::XS), (int)(w & LN::YM)), runmax)) return false;
     }
-    if (ablate == 5) { *why = W_NOT_TIGHT; return -1 - runmax; }          // (profiling aid) sort + harmless tests only
+    return true;
+}
+template <class LN> VTXF_FN int32_t back_rest(const Front& fr, int ns, const LN& ln, const Lane& gl, uint32_t* why, int ablate,
+                                              const Refine* rf, uint32_t* aux);
+template <class LN> VTXF_FN int32_t back(const Front& fr, int ns, const LN& ln, const Lane& gl, uint32_t* why, int ablate = 0,
+                                         const Refine* rf = nullptr, uint32_t* aux = nullptr) {
+    if (aux) *aux = 0xffffffffu;
+    if (ns > LN::SMAX) { *why = W_MATCHES; return -1; }
+    back_sort(ns, ln);
+    if (!back_harmless(fr, ns, ln)) { *why = W_NOT_HARMLESS; return -1; }
+    return back_rest(fr, ns, ln, gl, why, ablate, rf, aux);
+}
+// closure, run bound, verdict (the matches sorted and found harmless)
+template <class LN> VTXF_FN int32_t back_rest(const Front& fr, int ns, const LN& ln, const Lane& gl, uint32_t* why, int ablate,
+                                              const Refine* rf, uint32_t* aux) {
+    if (aux) *aux = 0xffffffffu;
+    constexpr int XS = LN::XS;
+    constexpr uint32_t YM = LN::YM, ONE = LN::ONE;
+    const int d = fr.d, r = fr.r;
+    int far_e = 0;
+    const int nc = ns;
+    if (ablate == 5) { *why = W_NOT_TIGHT; return -1; }                   // (profiling aid) sort + harmless tests only
     // ---- generic set: the main pieces plus the off-diagonal pieces that may not be left out as FAR (header: condition (*)).
     //      Far matches are binned by their distance D from the hull of the generic diagonals; the cumulative count up to a
     //      bin's upper edge must stay within bound(lower edge), bound(t) = min(t, 2t - 6) — conservative for (*), which asks
