@@ -42,8 +42,8 @@ def synthetic_batches(per_model=3, n_loci=150, reads=48):
             yield ("sub %.3f indel %.1f jitter %d len %d pad %d" % (sub, indel, jitter, rl, pad), synth.make_batch(spec), 500)
 
 
-def repeat_rich_batches(trials=12, loci=60, reads=24):
-    rng = np.random.default_rng(2024)
+def repeat_rich_batches(trials=12, loci=60, reads=24, pad_range=(30, 160), seed=2024):
+    rng = np.random.default_rng(seed)
     for trial in range(trials):
         alpha = [b"ACGT", b"AC", b"AT", b"ACG"][trial % 4]
         units = [b"A", b"AC", b"AAT", b"ACGT", b"AAAAC", b"AG", b"T", b"CAG", b"ACACAT", b"GATTACA"]
@@ -54,8 +54,8 @@ def repeat_rich_batches(trials=12, loci=60, reads=24):
         g = bytes(g)
         haps, rds = [], []
         for _ in range(loci):
-            p = int(rng.integers(300, len(g) - 500))
-            pad = int(rng.integers(30, 160))
+            p = int(rng.integers(pad_range[1] + 250, len(g) - pad_range[1] - 400))
+            pad = int(rng.integers(pad_range[0], pad_range[1]))
             ref = g[p - pad:p + pad + 1]
             kind = rng.random()
             if kind < 0.5:

@@ -69,6 +69,17 @@ def test_repeat_rich():
         device_vs_oracle(batch, nb, label)
 
 
+def test_repeat_rich_wide_windows():
+    """Haplotypes of 600 - 1000 bases (padding 300 - 490) over repeat-rich genomes: band_coop_kernel's Fenwick paths at their
+    longest (ten nodes), its LDS arrays at their largest; and padding 520 - 600 (haplotypes above 1000 bases), where the host
+    must hand the general path to the serial kernel.  Both have hard tasks: the band-masked DP keeps three LDS arrays per record
+    slot, which no longer fit 16 slots per workgroup above ~800 bases (round 3 found that launch failing; fewer slots now)."""
+    for pad_range, seed in (((300, 490), 31), ((520, 600), 32)):
+        for label, batch, nb in SB.repeat_rich_batches(trials=2, loci=30, reads=16, pad_range=pad_range, seed=seed):
+            st = device_vs_oracle(batch, nb, label + ", padding %d-%d" % pad_range)
+            assert st["overflow"] > 50 and st["hard"] > 50, st
+
+
 def test_real_read_shapes():
     rows = []
     for label, batch, nb in SB.real_shape_batches(trials=3):

@@ -1048,7 +1048,9 @@ int vtx_run(vtx_ctx* c) {
             static const bool no_coop = getenv("VTX_BAND_NO_COOP") != nullptr;             // experiment / test hook
             const int tier = fb.cap2 < 512 ? 0 : (fb.cap2 == 512 ? 1 : (fb.cap2 == 1024 ? 2 : -1));
             const uint32_t tier_cap = tier == 0 ? 512u : (tier == 1 ? 1024u : 4096u);
-            if (tier >= 0 && !no_coop && c->max_read_len <= 256 && vtxk_band_coop_lds(c->max_hap_len, tier_cap) <= 64u * 1024) {
+            // (haplotypes up to 1000 bases: the kernel walks its Fenwick tree in ten unrolled steps, tn = n + 8 < 1024)
+            if (tier >= 0 && !no_coop && c->max_read_len <= 256 && c->max_hap_len <= 1000 &&
+                vtxk_band_coop_lds(c->max_hap_len, tier_cap) <= 64u * 1024) {
                 fb.cap2 = tier_cap;
                 HIP_TRY(c, hipMemsetAsync(d_cnt + 9, 0, sizeof(uint32_t), s2));
                 uint32_t* other = c->d_over2.as<uint32_t>() + ((fb.tasks == c->d_over2.as<uint32_t>()) ? fb.n_over : 0);

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(64) void band_coop_kernel(
     wave_sync();                                                       // (y6 is dead: rmin / rmax may be written)
     if (ablate == 1) { if (mt[0] == 0x7fffffffu) counters[2] = 1; return; }     // (profiling aid: phase A only; results are wrong)
     // ---- B: sdpkpp ----
-    const int tn = n + KMER + 2;
+    const int tn = n + KMER + 2;                                      // < 1024 (the host launches this kernel for haplotypes <= 1000 bases): tree paths of <= 10 nodes
     if (live) for (int i = l; i <= tn; i += G) tree[i] = 0;
     if (live) for (int i = l; i < 2 * (int)cols; i += G) lastm[i] = 0;
     uint32_t best = 0;                                                 // dp << 16 | index of the best END so far (this lane's)

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void sw_banded_kernel(
     const uint8_t* __restrict__ hap_arena, const uint16_t* __restrict__ band, uint32_t band_stride,
     int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score, uint32_t lcols) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    constexpr int GROUPS_PER_BLOCK = 256 / GL;
+    const int GROUPS_PER_BLOCK = (int)blockDim.x / GL;     // 256 threads, or fewer when three LDS arrays per record slot of a wide haplotype do not fit
     constexpr int DPP = (GL == 16) ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
     // One extra leading column: hap index j = -1 is the oracle's boundary column 0, processed like any
     // other column (never-matching sentinel base, ranges lo[0], hi[0]), so the boundary state is
@@ -552,11 +552,17 @@ extern "C" hipError_t vtxk_launch_sw_banded(int R, int GL, uint32_t n_hard, cons
                                             uint32_t band_stride, int32_t* ref_score, int32_t* alt_score,
                                             uint32_t max_hap_len, hipStream_t stream) {
     if (n_hard == 0) return hipSuccess;
-    const uint32_t groups = 256 / GL;
     const uint32_t pairs = (n_hard + 1) / 2;
     const uint32_t lcols = ((GL + max_hap_len + GL + 8) + 3u) & ~3u;
+    // 256 threads per workgroup unless the three LDS arrays per record slot do not fit (haplotypes above ~800 bases: round 3
+    // found the launch failing there — no test had a hard task on a wide window): then 128 or 64
+    uint32_t threads = 256;
+    while (threads > 64 && (size_t)(threads / GL) * 3 * lcols * sizeof(uint32_t) > 150 * 1024) threads >>= 1;
+    if (threads < (uint32_t)GL) threads = (uint32_t)GL;
+    const uint32_t groups = threads / GL;
     const size_t shmem = (size_t)groups * 3 * lcols * sizeof(uint32_t);
-    const dim3 grid((pairs + groups - 1) / groups), block(256);
+    if (shmem > 160 * 1024 - 512) return hipErrorInvalidValue;
+    const dim3 grid((pairs + groups - 1) / groups), block(threads);
 #define CASE(r, gl)                                                                                       \
     if (R == r && GL == gl) {                                                                             \
         if (shmem > 48 * 1024) {                                                                          \
