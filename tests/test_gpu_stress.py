@@ -80,6 +80,18 @@ def test_repeat_rich_wide_windows():
             assert st["overflow"] > 50 and st["hard"] > 50, st
 
 
+def test_long_reads():
+    """Reads of 200 - 320 bases (band_diag_kernel holds 192, band_coop_kernel 256: both must step aside) on 700-base windows, with
+    indel loci and 2 % errors; and 250-base reads, which band_coop_kernel does hold."""
+    from vartrix_amd import synth
+    for rl, jitter, pad in ((320, 120, 350), (250, 40, 200)):
+        spec = synth.SynthSpec(n_loci=40, n_barcodes=200, reads_per_locus=24, read_len=rl, read_len_jitter=jitter, padding=pad,
+                               sub_error=0.02, indel_frac=0.3, seed=rl)
+        batch = synth.make_batch(spec)
+        assert batch.records["read_len"].max() > 192
+        device_vs_oracle(batch, 200, "reads up to %d bases, padding %d" % (rl, pad))
+
+
 def test_real_read_shapes():
     rows = []
     for label, batch, nb in SB.real_shape_batches(trials=3):
