@@ -49,6 +49,13 @@ void build_table(uint8_t* tb, const uint8_t* hy, uint32_t hn, uint32_t max_hap, 
 }  // namespace
 
 extern "C" {
+// the closed forms and the corridor DP of the run bound, for unit tests against brute force (tests/test_fastcore.py)
+int vtxt_join_free(int D) { return vtxf::join_free(D); }
+int vtxt_join_same(int D, int e) { return vtxf::join_same(D, e); }
+int vtxt_join_gap3(int D) { return vtxf::join_gap3(D); }
+int vtxt_corridor_cost(const uint8_t* x, int m, const uint8_t* y, int n, int xb, int d, int D, int mu_a, int mu_b) {
+    return vtxf::corridor_cost(x, m, y, n, xb, d, D, mu_a, mu_b);
+}
 // Per task t = 2 * record + hap of a packed batch: score[t] (-1: left to band_run_kernel) and why[t].
 // n_heads bit 31: use the four-byte match entries (20 per task) even when every haplotype has <= 255 bases — the variant the
 // device takes for longer haplotypes.

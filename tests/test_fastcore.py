@@ -104,6 +104,87 @@ def test_corridor_refinement_is_exact_and_decides_more(core):
         check(core, batch, nb, label, 1024 | (1 << 30))
 
 
+def test_join_closed_forms_of_the_kernel_header(core):
+    """join_free / join_same / join_gap3 AS COMPILED from vtx_fast_core.h against brute force over (gap events g, gap length G per
+    direction, mismatches mm): a stretch of D bases between two runs on one diagonal has D - G diagonal columns, mm of them
+    mismatches, the g + mm events separate at most g + mm - 1 short runs of <= 5 matches; cost 5 g + 2 G + 5 mm - matches."""
+    def brute(D, g0):
+        best = 10 ** 6
+        for g in range(2, 2 * D + 4):
+            for G in range(max((g + 1) // 2, g0), D + 1):
+                for mm in range(0, D - G + 1):
+                    if D - G - mm <= 5 * (g + mm - 1):
+                        best = min(best, 5 * g + 2 * G + 5 * mm - (D - G - mm))
+                        break
+        return best
+    for D in range(1, 190):
+        free = min(6 * e - D for e in range(1, D + 1) if D - e <= 5 * (e - 1))
+        assert core.vtxt_join_free(D) == free, D
+        gap = brute(D, 1)
+        for e in range(1, min(D, 14) + 1):
+            if D >= 2 or e == 1:
+                want = min(6 * e - D, gap)
+                assert core.vtxt_join_same(D, e) == want, (D, e)
+        if D >= 3:
+            g3 = brute(D, 3)
+            have = core.vtxt_join_gap3(D)
+            assert have == g3 if D <= 22 else 11 <= have <= g3, (D, have, g3)
+
+
+def test_corridor_cost_is_the_optimum_of_the_corridor(core):
+    """corridor_cost AS COMPILED from vtx_fast_core.h against a plain dictionary DP written here: the cheapest path (match -1,
+    mismatch +5, gap of length L +5 + L, no floor) from a base of the first run, up to mu_a bases before its end, to a base of the
+    second run, up to mu_b bases behind its start, at 1 per base given up, over the diagonals d - 2 .. d + 2."""
+    import itertools
+    rng = np.random.default_rng(12)
+    NEG = -10 ** 6
+
+    def reference(x, y, xb, d, D, mu_a, mu_b):
+        r0, r1 = xb + 1 - mu_a, xb + D + 2 + mu_b
+        H, E, F = {}, {}, {}
+        H[(r0, r0 + d)] = -mu_a
+        for i in range(r0, r1 + 1):
+            for k in range(-2, 3):
+                j = i + d + k
+                if not (0 <= j <= len(y) and 0 <= i <= len(x)) or (i, j) == (r0, r0 + d):
+                    continue
+                if i == r0 and k < 0:
+                    continue
+                h = NEG
+                if i > r0 and (i - 1, j - 1) in H and H[(i - 1, j - 1)] > NEG // 2 and i >= 1 and j >= 1:
+                    h = H[(i - 1, j - 1)] + (1 if x[i - 1] == y[j - 1] else -5)
+                f = max(F.get((i - 1, j), NEG) - 1, H.get((i - 1, j), NEG) - 6) if k + 1 <= 2 and i > r0 else NEG
+                e = max(E.get((i, j - 1), NEG) - 1, H.get((i, j - 1), NEG) - 6) if k - 1 >= -2 else NEG
+                f = f if f > NEG // 2 else NEG
+                e = e if e > NEG // 2 else NEG
+                F[(i, j)], E[(i, j)] = f, e
+                H[(i, j)] = max(h, f, e)
+        end = H.get((r1, r1 + d), NEG)
+        return (1 << 20) if end <= NEG // 2 else mu_b + 1 - end
+
+    core.vtxt_corridor_cost.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    n_checked = 0
+    for trial in range(400):
+        alpha = b"ACGT" if trial % 3 else b"AC"
+        y = bytes(rng.choice(list(alpha), 120).tolist())
+        d = int(rng.integers(-3, 8))
+        xs = int(rng.integers(10, 30))
+        x = bytearray(y[xs + d:xs + d + 80]) if xs + d >= 0 else bytearray(y[:80])
+        d = d if xs + d >= 0 else 0
+        lo = 20
+        D = int(rng.integers(3, 14))
+        for p in rng.choice(np.arange(lo + 1, lo + D + 1), size=min(D, int(rng.integers(2, 6))), replace=False):
+            x[int(p)] = b"ACGT"[(b"ACGT".index(bytes([x[int(p)]])) + 1 + int(rng.integers(0, 3))) % 4]
+        # diagonal of x vs y: x[i] faces y[i + xs + d]... the runs' diagonal in haplotype coordinates
+        dd = xs + d
+        mu_a, mu_b = int(rng.integers(0, 9)), int(rng.integers(0, 9))
+        have = core.vtxt_corridor_cost(bytes(x), len(x), y, len(y), lo, dd, D, mu_a, mu_b)
+        want = reference(bytes(x), y, lo, dd, D, mu_a, mu_b)
+        assert have == want, (trial, have, want)
+        n_checked += 1
+    assert n_checked == 400
+
+
 def test_real_read_shapes(core):
     """Soft clips, adapter tails, spliced reads, poly-A, N bases (tests/stress_batches.py)."""
     fr = []

@@ -195,7 +195,7 @@ VTXF_FN uint32_t eq8(uint64_t a, uint64_t b) {
 //   join_same(D, e)  min(6 e - D, J_gap(D)): the gap-free stretch costs exactly 6 e - D when e of the D bases mismatch (an e
 //                    below the true count only loosens the bound), a stretch with gaps at least J_gap(D) = {7, 9, 11, 10, 9, 8}
 //                    [D mod 6] (J_gap(1) = 12 > 6 e - D = 5)
-VTXF_FN int div6(int D) { return (D * 43) >> 8; }                    // D / 6 for 0 <= D < 258
+VTXF_FN int div6(int D) { return (D * 10923) >> 16; }                // D / 6 for 0 <= D < 30000 ((D * 43) >> 8, first version, is off from D = 131: found by tests/test_fastcore.py::test_join_closed_forms_of_the_kernel_header)
 VTXF_FN int join_free(int D) { return 6 * div6(D + 10) - D; }
 VTXF_FN int join_same(int D, int e) {
     const int jg = (int)((0x89ab97u >> (4 * (D - 6 * div6(D)))) & 15u);
