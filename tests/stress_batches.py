@@ -5,6 +5,7 @@ and by tools/certify_stress.py / tools/gpu_parity_stress.py, which run the same 
   repeat_rich_batches tandem-repeat genomes over 2- to 4-letter alphabets: hundreds of k-mer pieces per alignment
   near_repeat_batches iid genomes with short words copied a few bases further on (period 4-40, 6-12 bases): chance-like off-diagonal
                       matches AT CHOSEN DISTANCES from the main diagonal — the adversary of band_diag_kernel's far-piece condition
+  far_apart_batches   reads whose two matching ends sit 100 - 170 bases apart on one diagonal (main or off-diagonal)
   real_sequence_batches loci at random positions of tests/golden/test_dna.fa (181 kb of real sequence: 2-3 x the chance 6-mer
                       matches of iid bases, satellite repeats in the tail)
   real_shape_batches  what real 10x reads add to `150M`: soft-clipped ends (the clip is random sequence), adapter tails, spliced
@@ -108,6 +109,42 @@ def near_repeat_batches(trials=8, loci=80, reads=32, seed=4242):
                 rl.append((int(rng.integers(0, 30)), 0, bytes(rd)))
             rds.append(rl)
         yield ("near repeats, %d planted per locus" % n_plant, manual_batch(haps, rds, 30), 30)
+
+
+def far_apart_batches(trials=4, loci=60, reads=24, seed=515):
+    """Reads whose two ends match the haplotype on ONE diagonal, 100 - 170 bases apart, with a middle that does not (random bases,
+    or the haplotype's own bases at 30 - 60 % errors): same-diagonal joins at the long end of their range (the closed forms of the
+    run bound are periodic in D: a division by 6 that is only right for short D goes unnoticed on ordinary reads), and the same
+    construction copied onto an off-diagonal (the read's ends taken 7 - 40 bases further along the haplotype)."""
+    rng = np.random.default_rng(seed)
+    for trial in range(trials):
+        haps, rds = [], []
+        for _ in range(loci):
+            pad = int(rng.integers(100, 140))
+            g = bytes(rng.choice(list(b"ACGT"), 2 * pad + 1 + 500).tolist())
+            p = 250 + pad
+            ref = g[p - pad:p + pad + 1]
+            alt = ref[:pad] + bytes([b"ACGT"[(b"ACGT".index(ref[pad:pad + 1]) + 1) % 4]]) + ref[pad + 1:]
+            haps.append((ref, alt))
+            rl = []
+            for _k in range(reads):
+                ln = int(rng.integers(150, 193))
+                s0 = p - int(rng.integers(20, ln - 20))
+                rd = bytearray(g[s0:s0 + ln])
+                la, lb = int(rng.integers(6, 25)), int(rng.integers(6, 25))
+                mid = slice(la, ln - lb)
+                if trial % 2 == 0:
+                    rd[mid] = bytes(rng.choice(list(b"ACGT"), ln - la - lb).tolist())
+                else:
+                    for e in np.nonzero(rng.random(ln - la - lb) < rng.choice([0.3, 0.45, 0.6]))[0]:
+                        rd[la + int(e)] = b"ACGT"[int(rng.integers(0, 4))]
+                if trial >= 2:                                   # the ends from another diagonal
+                    sh = int(rng.integers(7, 41))
+                    rd[:la] = g[s0 + sh:s0 + sh + la]
+                    rd[ln - lb:] = g[s0 + sh + ln - lb:s0 + sh + ln]
+                rl.append((int(rng.integers(0, 30)), 0, bytes(rd)))
+            rds.append(rl)
+        yield ("two ends far apart on one diagonal, variant %d" % trial, manual_batch(haps, rds, 30), 30)
 
 
 def real_sequence_batches(trials=3, n_loci=300, reads=24, seed=9000):

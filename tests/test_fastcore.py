@@ -104,6 +104,13 @@ def test_corridor_refinement_is_exact_and_decides_more(core):
         check(core, batch, nb, label, 1024 | (1 << 30))
 
 
+def test_pieces_far_apart_on_one_diagonal(core):
+    """Same-diagonal joins of 100 - 170 bases (tests/stress_batches.py: far_apart_batches), with and without the refinement."""
+    for rf in (0, 1):
+        for label, batch, nb in SB.far_apart_batches(trials=4):
+            check(core, batch, nb, label, 1024 | (rf << 30))
+
+
 def test_join_closed_forms_of_the_kernel_header(core):
     """join_free / join_same / join_gap3 AS COMPILED from vtx_fast_core.h against brute force over (gap events g, gap length G per
     direction, mismatches mm): a stretch of D bases between two runs on one diagonal has D - G diagonal columns, mm of them

@@ -80,6 +80,13 @@ def test_repeat_rich_wide_windows():
             assert st["overflow"] > 50 and st["hard"] > 50, st
 
 
+def test_pieces_far_apart_on_one_diagonal():
+    """Reads whose two matching ends sit 100 - 170 bases apart on one diagonal (main or off-diagonal), the middle random or at
+    30 - 60 % errors: same-diagonal joins at the long end of their range, on the device."""
+    for label, batch, nb in SB.far_apart_batches(trials=4):
+        device_vs_oracle(batch, nb, label)
+
+
 def test_long_reads():
     """Reads of 200 - 320 bases (band_diag_kernel holds 192, band_coop_kernel 256: both must step aside) on 700-base windows, with
     indel loci and 2 % errors; and 250-base reads, which band_coop_kernel does hold."""
