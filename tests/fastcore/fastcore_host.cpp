@@ -56,6 +56,28 @@ int vtxt_join_gap3(int D) { return vtxf::join_gap3(D); }
 int vtxt_corridor_cost(const uint8_t* x, int m, const uint8_t* y, int n, int xb, int d, int D, int mu_a, int mu_b) {
     return vtxf::corridor_cost(x, m, y, n, xb, d, D, mu_a, mu_b);
 }
+// diag_mask (the match mask of one diagonal) and the pieces / mismatch nibbles front_rest() derives from it, for a single read and
+// haplotype: out[0..2] = mask words, out[3] = number of main pieces, out[4] = zc, out[5] = certificate
+int vtxt_front_of_diagonal(const uint8_t* x, int m, const uint8_t* y, int n, int d, uint64_t* out) {
+    using namespace vtxf;
+    const uint32_t max_hap = (uint32_t)std::max(n, 8), n_heads = 1024;
+    std::vector<uint8_t> gt(tab_stride(max_hap, n_heads) + 64);
+    build_table(gt.data(), y, (uint32_t)n, max_hap, n_heads);
+    Tab tb;
+    tb.gt = gt.data(); tb.ent = 0; tb.head = max_hap * 8; tb.bytes = tab_bytes_off(max_hap, n_heads);
+    tb.uq = tab_uq_off(max_hap, n_heads); tb.pb = tab_pb_off(max_hap, n_heads); tb.hmask = n_heads - 1;
+    std::vector<uint8_t> xb((size_t)m + 16, 0);
+    memcpy(xb.data(), x, (size_t)m);
+    const ReadWords rw = read_words(xb.data(), m);
+    const M192 M = diag_mask(rw, m, tb, n, d);
+    out[0] = M.w0; out[1] = M.w1; out[2] = M.w2;
+    uint32_t lane[LANE_WORDS];
+    const LaneS<uint32_t> ln{lane + S_WORDS, 1, lane, 1};
+    const Front fr = front_rest(xb.data(), m, tb, n, ln, d, M);
+    out[3] = (uint64_t)fr.r | ((uint64_t)fr.why << 32); out[4] = fr.zc; out[5] = (uint64_t)(int64_t)fr.cert;
+    for (int i = 0; i < RM; ++i) out[6 + i] = i < fr.r ? lane[S_WORDS + i] : 0;
+    return 0;
+}
 // Per task t = 2 * record + hap of a packed batch: score[t] (-1: left to band_run_kernel) and why[t].
 // n_heads bit 31: use the four-byte match entries (20 per task) even when every haplotype has <= 255 bases — the variant the
 // device takes for longer haplotypes.

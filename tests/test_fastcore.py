@@ -104,6 +104,59 @@ def test_corridor_refinement_is_exact_and_decides_more(core):
         check(core, batch, nb, label, 1024 | (1 << 30))
 
 
+def test_mask_pieces_and_mismatch_counts_of_a_diagonal(core):
+    """diag_mask and front_rest AS COMPILED from vtx_fast_core.h on single (read, haplotype, diagonal) triples against the
+    definitions: bit i of the mask = (x[i] == y[i + d]) where both exist; the main pieces = the runs of >= 6 ones, in order;
+    nibble i of zc = the zeros between piece i - 1 and piece i (capped at 15).  Reads up to 192 bases, diagonals from far left of
+    the haplotype to far right of it, bytes above 0x7f, lower case, N."""
+    core.vtxt_front_of_diagonal.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(99)
+    out = np.zeros(16, np.uint64)
+    n_pieces = 0
+    for trial in range(1500):
+        n = int(rng.integers(8, 256))
+        alpha = [b"ACGT", b"ACGTN", b"AC", bytes([65, 67, 71, 84, 0x80, 0xff, 97, 110])][trial % 4]
+        y = bytes(rng.choice(list(alpha), n).tolist())
+        m = int(rng.integers(6, 193))
+        d = int(rng.integers(-m + 1, n))
+        x = bytearray(rng.choice(list(alpha), m).tolist())
+        for i in range(m):                                     # mostly the haplotype's own bases on that diagonal
+            if 0 <= i + d < n and rng.random() < 0.93:
+                x[i] = y[i + d]
+        assert core.vtxt_front_of_diagonal(bytes(x), m, y, n, d, out.ctypes.data) == 0
+        want = 0
+        for i in range(m):
+            if 0 <= i + d < n and x[i] == y[i + d]:
+                want |= 1 << i
+        have = int(out[0]) | (int(out[1]) << 64) | (int(out[2]) << 128)
+        assert have == want, (trial, m, n, d)
+        # pieces and nibbles from the definition (front_rest declines above RM pieces or without any: skip those)
+        lo, hi = max(0, -d), min(m, n - d)
+        runs, zeros_before, z = [], [], 0
+        i = lo
+        while i < hi:
+            if (want >> i) & 1:
+                j = i
+                while j < hi and (want >> j) & 1:
+                    j += 1
+                if j - i >= 6:
+                    runs.append((i, j - 1)); zeros_before.append(z); z = 0
+                i = j
+            else:
+                z += 1; i += 1
+        why = int(out[3]) >> 32
+        if why == 0:
+            r = int(out[3]) & 0xffffffff
+            assert r == len(runs) and r <= 8, (trial, r, runs)
+            for k, (a, b) in enumerate(runs):
+                w = int(out[6 + k])
+                assert (w & 0xff, (w >> 8) & 0xff) == (a, b), (trial, k)
+                if k:
+                    assert (int(out[4]) >> (4 * k)) & 15 == min(zeros_before[k], 15), (trial, k)
+            n_pieces += r
+    assert n_pieces > 2000
+
+
 def test_pieces_far_apart_on_one_diagonal(core):
     """Same-diagonal joins of 100 - 170 bases (tests/stress_batches.py: far_apart_batches), with and without the refinement."""
     for rf in (0, 1):
