@@ -121,3 +121,107 @@ def test_rowwise_order_gives_the_reference_chain():
             x = bytearray(y[s0:s0 + 150])
         total += check(bytes(x), bytes(y))
     assert total > 100000
+
+
+W = 20
+LAZY = 2 * K            # VTX_BAND_LAZY_EXT(k)
+LAST = K                # VTX_BAND_KMER_LAST_ANCHOR(k)
+
+
+def staircase_ranges(mt, chain, m, n):
+    """band_coop_kernel's phase C: a 'lane' per chain link writes the anchor row of its own columns (pass 1), vertical remainders
+    raise rmax of the column they happen in (pass 2, an atomic max on the device), then every column takes its row range from
+    rmin / rmax of the columns within W (band_ranges).  Returns (lo, hi) as oracle.band_create gives them."""
+    L = len(chain)
+    link = [(int(mt[p, 0]), int(mt[p, 1])) for p in chain]
+    fx, fy = link[0]
+    d0 = min(fx, fy, LAZY)
+    cA = fy - d0
+    lx, ly = link[-1][0] + LAST, link[-1][1] + LAST
+    d1 = min(m - lx, n - ly, LAZY)
+    cB = ly + d1
+    rmin, rmax = {}, {}
+
+    def start_of(t):
+        if t == 0:
+            return fx - d0, fy - d0
+        (qx, qy), (px, py) = link[t - 1], link[t]
+        sq = 1 if (px == qx + 1 and py == qy + 1) else LAST
+        return qx + sq, qy + sq
+
+    for t in range(L + 1):                                   # pass 1 (any order: the links own disjoint columns)
+        if t == L:
+            for i in range(1, d1 + 1):
+                rmin[ly + i] = rmax[ly + i] = lx + i
+            continue
+        px, py = link[t]
+        ax, ay = start_of(t)
+        if t == 0:
+            rmin[ay] = rmax[ay] = ax
+        dr, dc = px - ax, py - ay
+        dg = min(dr, dc)
+        for i in range(1, dg + 1):
+            rmin[ay + i] = rmax[ay + i] = ax + i
+        for c in range(ay + dg + 1, py + 1):
+            rmin[c] = rmax[c] = px
+        st = LAST
+        if t + 1 < L and link[t + 1] == (px + 1, py + 1):
+            st = 1
+        for i in range(1, st + 1):
+            rmin[py + i] = rmax[py + i] = px + i
+    for t in range(L):                                       # pass 2
+        px, py = link[t]
+        ax, ay = start_of(t)
+        dr, dc = px - ax, py - ay
+        if dr > dc:
+            rmax[ay + dc] = max(rmax[ay + dc], px)
+    lo = np.zeros(n + 1, np.int32)
+    hi = np.zeros(n + 1, np.int32)
+    for j in range(n + 1):
+        if j < cA - W or j > cB + W:
+            lo[j], hi[j] = 0x7FFF, 0
+            continue
+        c0, c1 = max(j - W, cA), min(j + W, cB)
+        lo[j] = max(rmin[c0] - W, 0)
+        hi[j] = min(rmax[c1] + W + 1, m + 1)
+    return lo, hi
+
+
+def test_parallel_staircase_gives_the_reference_band():
+    rng = np.random.default_rng(32)
+    n_checked = 0
+    for trial in range(400):
+        kind = trial % 4
+        y = bytes(rng.choice(list(b"ACGT"), 221).tolist())
+        s0 = int(rng.integers(0, 40))
+        if kind == 0:                                        # substitutions only
+            x = bytearray(y[s0:s0 + 150])
+            for e in rng.integers(0, len(x), size=int(rng.integers(0, 8))):
+                x[int(e)] = b"ACGT"[int(rng.integers(0, 4))]
+        elif kind == 1:                                      # deletion in the read: a vertical / horizontal remainder in the staircase
+            cut, gap = int(rng.integers(30, 100)), int(rng.integers(1, 25))
+            x = bytearray(y[s0:s0 + cut] + y[s0 + cut + gap:s0 + cut + gap + 90])
+        elif kind == 2:                                      # insertion in the read
+            cut = int(rng.integers(30, 100))
+            x = bytearray(y[s0:s0 + cut] + bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 25))).tolist()) + y[s0 + cut:s0 + cut + 80])
+        else:                                                # repeats: chains that hop
+            unit = [b"AC", b"AAT", b"CAG", b"ACACAT"][int(rng.integers(0, 4))]
+            y = (bytes(rng.choice(list(b"ACGT"), 40).tolist()) + unit * 30 + bytes(rng.choice(list(b"ACGT"), 60).tolist()))[:221]
+            x = bytearray(y[s0:s0 + int(rng.integers(60, 150))])
+            for e in rng.integers(0, len(x), size=int(rng.integers(0, 4))):
+                x[int(e)] = b"ACGT"[int(rng.integers(0, 4))]
+        x = bytes(x)
+        mt = oracle.kmer_matches(x, y)
+        if len(mt) == 0:
+            continue
+        chain, _ = oracle.sdpkpp(mt)
+        lo, hi = staircase_ranges(mt.astype(np.int64), [int(p) for p in chain], len(x), len(y))
+        want_lo, want_hi, _cells = oracle.band_create(x, y)
+        # the oracle leaves columns outside the band as lo = hi (empty); compare the in-band columns and the emptiness of the others
+        for j in range(len(y) + 1):
+            if want_hi[j] > want_lo[j]:
+                assert (lo[j], hi[j]) == (want_lo[j], want_hi[j]), (trial, j, lo[j], hi[j], want_lo[j], want_hi[j])
+            else:
+                assert hi[j] <= lo[j], (trial, j)
+        n_checked += 1
+    assert n_checked > 350
