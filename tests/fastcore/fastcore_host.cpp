@@ -78,6 +78,39 @@ int vtxt_front_of_diagonal(const uint8_t* x, int m, const uint8_t* y, int n, int
     for (int i = 0; i < RM; ++i) out[6 + i] = i < fr.r ? lane[S_WORDS + i] : 0;
     return 0;
 }
+// The probe phase for a single read and haplotype on diagonal d: out[0..2] = the rows front_rest() wants probed, then the
+// off-diagonal matches probe_rows() finds (x << 16 | y, up to cap); returns their number (-1: front_rest declined)
+int vtxt_probe_of_diagonal(const uint8_t* x, int m, const uint8_t* y, int n, int d, uint64_t* need_out, uint32_t* s_out, int cap) {
+    using namespace vtxf;
+    const uint32_t max_hap = (uint32_t)std::max(n, 8), n_heads = 1024;
+    std::vector<uint8_t> gt(tab_stride(max_hap, n_heads) + 64);
+    build_table(gt.data(), y, (uint32_t)n, max_hap, n_heads);
+    Tab tb;
+    tb.gt = gt.data(); tb.ent = 0; tb.head = max_hap * 8; tb.bytes = tab_bytes_off(max_hap, n_heads);
+    tb.uq = tab_uq_off(max_hap, n_heads); tb.pb = tab_pb_off(max_hap, n_heads); tb.hmask = n_heads - 1;
+    std::vector<uint8_t> xb((size_t)m + 16, 0);
+    memcpy(xb.data(), x, (size_t)m);
+    const ReadWords rw = read_words(xb.data(), m);
+    const M192 M = diag_mask(rw, m, tb, n, d);
+    uint32_t lane[LANE_WORDS];
+    const LaneS<uint32_t> ln{lane + S_WORDS, 1, lane, 1};
+    const Front fr = front_rest(xb.data(), m, tb, n, ln, d, M);
+    if (fr.why != W_OK) return -1;
+    need_out[0] = fr.need.w0; need_out[1] = fr.need.w1; need_out[2] = fr.need.w2;
+    // probe_rows() stops counting above the lane's capacity: probe the rows in slices so that every match is seen
+    int total = 0;
+    M192 need = fr.need;
+    while (m_any(need)) {
+        Front one = fr;
+        one.need = M192{0, 0, 0};
+        const int row = m_pop_lowest(need);
+        if (row < 64) one.need.w0 = 1ull << row; else if (row < 128) one.need.w1 = 1ull << (row - 64); else one.need.w2 = 1ull << (row - 128);
+        const int ns = probe_rows(xb.data(), tb, one, ln);
+        if (ns > LaneS<uint32_t>::SMAX) return -2;                    // more matches in ONE row than a lane holds
+        for (int k = 0; k < ns && total < cap; ++k) s_out[total++] = lane[k];
+    }
+    return total;
+}
 // Per task t = 2 * record + hap of a packed batch: score[t] (-1: left to band_run_kernel) and why[t].
 // n_heads bit 31: use the four-byte match entries (20 per task) even when every haplotype has <= 255 bases — the variant the
 // device takes for longer haplotypes.

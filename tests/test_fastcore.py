@@ -157,6 +157,55 @@ def test_mask_pieces_and_mismatch_counts_of_a_diagonal(core):
     assert n_pieces > 2000
 
 
+def test_probe_phase_finds_every_off_diagonal_match(core):
+    """The claim behind probing only SOME rows (vtx_fast_core.h, front_rest): a row whose main-diagonal k-mer is intact and unique in
+    the haplotype holds no other match.  For single (read, haplotype, diagonal) triples: every off-diagonal k-mer match the oracle
+    lists sits in a row front_rest() asks for, and probe_rows() (presence bitmap, tagged heads, bucket walk: AS COMPILED) returns
+    exactly the off-diagonal matches of those rows — on iid, two-letter, tandem-repeat and poly-A haplotypes."""
+    core.vtxt_probe_of_diagonal.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(123)
+    need = np.zeros(3, np.uint64)
+    sbuf = np.zeros(20000, np.uint32)
+    n_matches = n_done = 0
+    for trial in range(600):
+        kind = trial % 4
+        n = int(rng.integers(60, 250))
+        if kind == 0:
+            y = bytes(rng.choice(list(b"ACGT"), n).tolist())
+        elif kind == 1:
+            y = bytes(rng.choice(list(b"AC"), n).tolist())
+        elif kind == 2:
+            unit = [b"AC", b"AAT", b"CAG", b"ACACAT"][int(rng.integers(0, 4))]
+            y = (bytes(rng.choice(list(b"ACGT"), 30).tolist()) + unit * 40)[:n]
+            n = len(y)
+        else:
+            yb = bytearray(rng.choice(list(b"ACGT"), n).tolist())
+            a0 = int(rng.integers(10, n - 40))
+            yb[a0:a0 + 25] = b"A" * 25
+            y = bytes(yb)
+        m = int(rng.integers(30, 160))
+        d = int(rng.integers(-20, max(n - m + 20, -19)))
+        x = bytearray(rng.choice(list(b"ACGT"), m).tolist())
+        for i in range(m):
+            if 0 <= i + d < n and rng.random() < 0.97:
+                x[i] = y[i + d]
+        x = bytes(x)
+        got = core.vtxt_probe_of_diagonal(x, m, y, n, d, need.ctypes.data, sbuf.ctypes.data, len(sbuf))
+        if got < 0:
+            continue
+        nmask = int(need[0]) | (int(need[1]) << 64) | (int(need[2]) << 128)
+        mt = oracle.kmer_matches(x, y)
+        off = {(int(a), int(b)) for a, b in mt if int(b) - int(a) != d}
+        for (a, b) in off:
+            assert (nmask >> a) & 1, (trial, a, b, d)          # no off-diagonal match outside the rows asked for
+        have = {(int(v) >> 16, int(v) & 0xffff) for v in sbuf[:got]}
+        assert got == len(have)
+        assert have == off, (trial, sorted(have ^ off)[:5])
+        n_matches += len(off)
+        n_done += 1
+    assert n_done > 400 and n_matches > 20000, (n_done, n_matches)
+
+
 def test_pieces_far_apart_on_one_diagonal(core):
     """Same-diagonal joins of 100 - 170 bases (tests/stress_batches.py: far_apart_batches), with and without the refinement."""
     for rf in (0, 1):
