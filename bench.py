@@ -354,7 +354,7 @@ def main():
             "dtype": "i32 (diagonal masks, chain and score arithmetic; packed i16 DP cells for the residue)", "data": "synthetic",
             "config": {"workload": spec.name + ", %s mode, %s aligner" % (args.mode, args.aligner),
                        "baseline_config": {"config3": "configs[2]", "config4": "configs[3]"}.get(workload, "custom"),
-                       "loci": n_loci * (world if weak else 1), "barcodes": n_barcodes,
+                       "loci": n_loci * (world if weak else 1), "barcodes": n_barcodes, "sub_error": args.sub_error,
                        "scored_reads_rank0": batch.n_records, "alignments_per_step": total_aln,
                        "full_matrix_dp_cells_per_step": total_cells, "triplets": total_nnz,
                        "sharding": ("one shard of %d loci per rank (weak)" % n_loci if weak else
