@@ -364,7 +364,7 @@ int main(int argc, char** argv) {
     std::vector<double> v, rv;
     vtx_raw_stats raw_total{};
     vtxh_metrics m{};
-    const auto t_dev = std::chrono::steady_clock::now();
+    double t_device = 0;
     Packed cur = std::move(first);
     for (uint32_t range_idx = 0;; ++range_idx) {
     pk = cur.pk;
@@ -426,12 +426,14 @@ int main(int argc, char** argv) {
             for (int d = 0; d < ndev; ++d) { shards[(size_t)d].comm_id = comm_id; shards[(size_t)d].rank = d; shards[(size_t)d].world = ndev; shards[(size_t)d].gate = &gate; }
         }
         std::vector<std::thread> th;
+        const auto t_shards = std::chrono::steady_clock::now();
         for (int d = 0; d < ndev; ++d) {
             vtx_config c = cfg;
             c.device = d;
             th.emplace_back(run_shard, &shards[(size_t)d], c);
         }
         for (auto& t : th) t.join();
+        t_device += since(t_shards);                      // (the shards' work only: not the packer, not the release of a range's reads)
         for (int pass = 0; pass < 2; ++pass)              // the shard that failed on its own first, not the VTX_E_PEER followers
             for (auto& s : shards)
                 if (s.rc && (pass == 1 || s.rc != VTX_E_PEER)) { printf("Vartrix error.\nError: %s: %s\n", vtx_status_name(s.rc), s.err.c_str()); return 1; }
@@ -467,7 +469,7 @@ int main(int argc, char** argv) {
     t_ingest += cur.secs;
     }
     LOG_INFO("Ingest + filter + pack, all ranges: %.3f s of packer time (overlapped with the device work on the range before)", t_ingest);
-    LOG_INFO("Device (create + submit + run + fetch) on %d GPU(s): %.3f s", ndev, since(t_dev));
+    LOG_INFO("Device (create + submit + run + fetch) on %d GPU(s): %.3f s", ndev, t_device);
     const auto t_out = std::chrono::steady_clock::now();
     m.num_not_cell_bc += raw_total.num_not_cell_bc;
     m.num_non_umi += raw_total.num_non_umi;
