@@ -111,6 +111,28 @@ int vtxt_probe_of_diagonal(const uint8_t* x, int m, const uint8_t* y, int n, int
     }
     return total;
 }
+// The harmless verdict for a single read and haplotype: 1 = every off-diagonal match is harmless (then the reference's chain lies on
+// the main diagonal *d_out), 0 = not, -1 = the logic declined before that (no diagonal, capacities)
+int vtxt_harmless(const uint8_t* x, int m, const uint8_t* y, int n, int* d_out) {
+    using namespace vtxf;
+    const uint32_t max_hap = (uint32_t)std::max(n, 8), n_heads = 1024;
+    std::vector<uint8_t> gt(tab_stride(max_hap, n_heads) + 64);
+    build_table(gt.data(), y, (uint32_t)n, max_hap, n_heads);
+    Tab tb;
+    tb.gt = gt.data(); tb.ent = 0; tb.head = max_hap * 8; tb.bytes = tab_bytes_off(max_hap, n_heads);
+    tb.uq = tab_uq_off(max_hap, n_heads); tb.pb = tab_pb_off(max_hap, n_heads); tb.hmask = n_heads - 1;
+    std::vector<uint8_t> xb((size_t)m + 16, 0);
+    memcpy(xb.data(), x, (size_t)m);
+    uint32_t lane[LANE_WORDS];
+    const LaneS<uint32_t> ln{lane + S_WORDS, 1, lane, 1};
+    const Front fr = front(xb.data(), m, tb, n, ln);
+    if (fr.why != W_OK) return -1;
+    const int ns = probe_rows(xb.data(), tb, fr, ln);
+    if (ns > LaneS<uint32_t>::SMAX) return -1;
+    back_sort(ns, ln);
+    *d_out = fr.d;
+    return back_harmless(fr, ns, ln) ? 1 : 0;
+}
 // Per task t = 2 * record + hap of a packed batch: score[t] (-1: left to band_run_kernel) and why[t].
 // n_heads bit 31: use the four-byte match entries (20 per task) even when every haplotype has <= 255 bases — the variant the
 // device takes for longer haplotypes.

@@ -206,6 +206,55 @@ def test_probe_phase_finds_every_off_diagonal_match(core):
     assert n_done > 400 and n_matches > 20000, (n_done, n_matches)
 
 
+def test_harmless_verdict_means_the_chain_stays_on_the_diagonal(core):
+    """What the harmless test promises (vtx_fast_core.h): if every off-diagonal k-mer match is harmless, the reference's sdpkpp
+    chain — computed here by the oracle over ALL matches — consists of main-diagonal matches only.  Reads with indels against
+    the other allele, planted near repeats and tandem repeats make chains that do leave the diagonal: the verdict must then be
+    'not harmless' (or the logic must have declined earlier)."""
+    core.vtxt_harmless.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(2718)
+    said_yes = off_chain_seen = 0
+    for trial in range(3000):
+        kind = trial % 5
+        n = 201
+        yb = bytearray(rng.choice(list(b"ACGT"), n).tolist())
+        if kind == 1:                                        # planted short repeats near the diagonal
+            for _ in range(int(rng.integers(1, 6))):
+                ln_, per = int(rng.integers(6, 13)), int(rng.integers(4, 30))
+                y0 = int(rng.integers(10, n - ln_ - per - 1))
+                yb[y0 + per:y0 + per + ln_] = yb[y0:y0 + ln_]
+        elif kind == 2:                                      # a tandem repeat inside
+            unit = [b"AC", b"AAT", b"CAG", b"ACACAT"][int(rng.integers(0, 4))]
+            a0 = int(rng.integers(20, 120))
+            rep = (unit * 30)[:int(rng.integers(12, 50))]
+            yb[a0:a0 + len(rep)] = rep
+        y = bytes(yb[:n])
+        s0 = int(rng.integers(0, 50))
+        x = bytearray(y[s0:s0 + 150])
+        if kind == 3:                                        # deletion in the read (a chain over two diagonals)
+            cut, gap = int(rng.integers(30, 100)), int(rng.integers(1, 21))
+            x = bytearray(y[s0:s0 + cut] + y[s0 + cut + gap:s0 + cut + gap + 90])
+        elif kind == 4:                                      # insertion in the read
+            cut = int(rng.integers(30, 100))
+            x = bytearray(y[s0:s0 + cut] + bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 21))).tolist()) + y[s0 + cut:s0 + cut + 90])
+        for e in rng.integers(0, len(x), size=int(rng.integers(0, 5))):
+            x[int(e)] = b"ACGT"[int(rng.integers(0, 4))]
+        x = bytes(x)
+        d = C.c_int(0)
+        verdict = core.vtxt_harmless(x, len(x), y, len(y), C.byref(d))
+        mt = oracle.kmer_matches(x, y)
+        if len(mt) == 0:
+            continue
+        chain, _ = oracle.sdpkpp(mt)
+        off = [int(p) for p in chain if int(mt[p, 1]) - int(mt[p, 0]) != d.value]
+        if verdict == 1:
+            said_yes += 1
+            assert not off, (trial, d.value, [(int(mt[p, 0]), int(mt[p, 1])) for p in off][:4])
+        elif off:
+            off_chain_seen += 1
+    assert said_yes > 700 and off_chain_seen > 300, (said_yes, off_chain_seen)
+
+
 def test_pieces_far_apart_on_one_diagonal(core):
     """Same-diagonal joins of 100 - 170 bases (tests/stress_batches.py: far_apart_batches), with and without the refinement."""
     for rf in (0, 1):
