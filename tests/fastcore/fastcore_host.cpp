@@ -113,7 +113,7 @@ int vtxt_probe_of_diagonal(const uint8_t* x, int m, const uint8_t* y, int n, int
 }
 // The harmless verdict for a single read and haplotype: 1 = every off-diagonal match is harmless (then the reference's chain lies on
 // the main diagonal *d_out), 0 = not, -1 = the logic declined before that (no diagonal, capacities)
-int vtxt_harmless(const uint8_t* x, int m, const uint8_t* y, int n, int* d_out) {
+int vtxt_harmless(const uint8_t* x, int m, const uint8_t* y, int n, int* d_out, int* cert_out) {
     using namespace vtxf;
     const uint32_t max_hap = (uint32_t)std::max(n, 8), n_heads = 1024;
     std::vector<uint8_t> gt(tab_stride(max_hap, n_heads) + 64);
@@ -131,6 +131,7 @@ int vtxt_harmless(const uint8_t* x, int m, const uint8_t* y, int n, int* d_out) 
     if (ns > LaneS<uint32_t>::SMAX) return -1;
     back_sort(ns, ln);
     *d_out = fr.d;
+    *cert_out = fr.cert;
     return back_harmless(fr, ns, ln) ? 1 : 0;
 }
 // Per task t = 2 * record + hap of a packed batch: score[t] (-1: left to band_run_kernel) and why[t].

@@ -210,8 +210,10 @@ def test_harmless_verdict_means_the_chain_stays_on_the_diagonal(core):
     """What the harmless test promises (vtx_fast_core.h): if every off-diagonal k-mer match is harmless, the reference's sdpkpp
     chain — computed here by the oracle over ALL matches — consists of main-diagonal matches only.  Reads with indels against
     the other allele, planted near repeats and tandem repeats make chains that do leave the diagonal: the verdict must then be
-    'not harmless' (or the logic must have declined earlier)."""
-    core.vtxt_harmless.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    'not harmless' (or the logic must have declined earlier).  With a harmless verdict the closed-form certificate equals the
+    oracle's walk of the chain's staircase."""
+    core.vtxt_harmless.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    oracle.lib().vtxo_chain_cert.restype = C.c_int32
     rng = np.random.default_rng(2718)
     said_yes = off_chain_seen = 0
     for trial in range(3000):
@@ -240,8 +242,8 @@ def test_harmless_verdict_means_the_chain_stays_on_the_diagonal(core):
         for e in rng.integers(0, len(x), size=int(rng.integers(0, 5))):
             x[int(e)] = b"ACGT"[int(rng.integers(0, 4))]
         x = bytes(x)
-        d = C.c_int(0)
-        verdict = core.vtxt_harmless(x, len(x), y, len(y), C.byref(d))
+        d, cert = C.c_int(0), C.c_int(0)
+        verdict = core.vtxt_harmless(x, len(x), y, len(y), C.byref(d), C.byref(cert))
         mt = oracle.kmer_matches(x, y)
         if len(mt) == 0:
             continue
@@ -250,6 +252,8 @@ def test_harmless_verdict_means_the_chain_stays_on_the_diagonal(core):
         if verdict == 1:
             said_yes += 1
             assert not off, (trial, d.value, [(int(mt[p, 0]), int(mt[p, 1])) for p in off][:4])
+            # ... and then the certificate is the oracle's walk of that chain's staircase (oracle/vtx_certify.c: vtxo_chain_cert)
+            assert cert.value == oracle.lib().vtxo_chain_cert(x, len(x), y, len(y), 6), trial
         elif off:
             off_chain_seen += 1
     assert said_yes > 700 and off_chain_seen > 300, (said_yes, off_chain_seen)
