@@ -163,6 +163,10 @@ def main():
     ap.add_argument("--genome", default="", help="FASTA: draw the loci from this sequence instead of an iid genome (sensitivity runs, "
                     "e.g. tests/golden/test_dna.fa: 181 kb of real sequence; the headline workload is the iid one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sensitivity", action="store_true",
+                    help="skip the `sensitivity` object (N = 1, default workload): the same 100 k x 10 k job with its loci drawn from real "
+                         "sequence and with 3 %% / 8 %% substitution errors, a few steps each — the floor next to the headline's ceiling")
+    ap.add_argument("--sensitivity-steps", type=int, default=3)
     ap.add_argument("--no-other-aligner", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -251,7 +255,7 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    sw_ms, red_ms, full_ms, band_ms, run_ms, diag_ms = [], [], [], [], [], []
+    sw_ms, red_ms, full_ms, band_ms, run_ms, diag_ms, check_ms, sweep_ms = [], [], [], [], [], [], [], []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -263,6 +267,8 @@ def main():
         band_ms.append(t.band_ms)
         run_ms.append(t.band_run_ms)
         diag_ms.append(t.diag_ms)
+        check_ms.append(t.check_ms)
+        sweep_ms.append(t.sweep_ms)
     drain()               # every step's gather has completed inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
@@ -314,6 +320,38 @@ def main():
         versus = {"alignments_banded_ne_full": int((r_a != r_b).sum() + (a_a != a_b).sum()),
                   "read_calls_differing": int((calls(r_a, a_a) != calls(r_b, a_b)).sum()), "alignments": int(n_aln)}
         octx.close()
+
+    # The floor next to the ceiling (N = 1, headline workload only): the same job on loci drawn from real, repeat-rich sequence and
+    # on noisy reads, measured in this process.  The headline's iid genome with 0.5 % errors is what BASELINE.json names; a
+    # production BAM looks like something between these.
+    sensitivity = None
+    if rank == 0 and world == 1 and workload == "config3" and args.aligner == "banded" and not args.no_sensitivity:
+        sensitivity = {}
+        cases = [("real_sequence_loci", dict(genome_fasta=os.path.join(ROOT, "tests", "golden", "test_dna.fa"))),
+                 ("sub_error_3pct", dict(sub_error=0.03)), ("sub_error_8pct", dict(sub_error=0.08))]
+        for name, kw in cases:
+            if "genome_fasta" in kw and not os.path.exists(kw["genome_fasta"]):
+                continue
+            sspec = synth.SynthSpec(n_loci=n_loci, n_barcodes=n_barcodes, reads_per_locus=args.reads_per_locus, seed=20260926,
+                                    **dict(dict(sub_error=args.sub_error), **kw))
+            sb = synth.make_batch(sspec)
+            sctx = lib.Context(cfg)
+            sctx.submit(sb)
+            sctx.run()                                   # warm-up (first run of a context allocates)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(args.sensitivity_steps):
+                sctx.run()
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - ts) / args.sensitivity_steps
+            st = sctx.timing()
+            sensitivity[name] = {"workload": sspec.name, "alignments_per_step": 2 * sb.n_records, "steps": args.sensitivity_steps,
+                                 "ms_per_step": 1e3 * dts, "value": 2 * sb.n_records / dts, "unit": "read-alignments/s",
+                                 "left_by_certificate_stages": int(st.diag_left), "full_matrix_checked": int(st.checked_tasks),
+                                 "swept": int(st.swept_tasks), "masked_dp_tasks": int(st.hard_tasks), "declined_by_sweep": int(st.overflow_tasks),
+                                 "diag_ms": float(st.diag_ms), "check_ms": float(st.check_ms), "sweep_and_dp_ms": float(st.sweep_ms)}
+            sctx.close()
+            del sb
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -370,13 +408,15 @@ def main():
                                            "rocprofv3 --pmc passes; the x2 is calibrated for this kernel's 8-byte scattered loads "
                                            "(profiles/r03_fetch_calibration.json: every request is a 128-byte line tallied at 64)",
                          "whole_sw_stage": {"kernels": ("sw_full_duo_kernel" if not banded else
-                                                        "band_tables + band_diag + band_run + band_pending + band_kernel + band_expand + sw_banded kernels")
+                                                        "band_tables + band_diag + band_refine + sw_banded<full> (check) + band_sweep + sw_banded kernels")
                                             + " (%d launches)" % launches, "ms": sw_avg_ms,
                                             "achieved": alg_bytes / (sw_avg_ms * 1e-3) / 1e9},
                          "note": "integer mask / chain / bound work: neither HBM nor MFMA binds it (86 B per alignment); the HBM "
                                  "fraction is reported because north_star asks for it, the binding resource is VALU issue: roofline_valu_issue"},
             "timing": {"sw_kernel_ms": sw_avg_ms, "full_kernel_ms": full_avg_ms, "band_kernels_ms": float(np.mean(band_ms)),
-                       "band_run_kernel_ms": run_avg_ms - diag_avg_ms, "band_diag_ms": diag_avg_ms,
+                       "band_run_kernel_ms": max(run_avg_ms - diag_avg_ms, 0.0), "band_diag_ms": diag_avg_ms,
+                       "full_matrix_check_ms": float(np.mean(check_ms)), "sweep_and_masked_dp_ms": float(np.mean(sweep_ms)),
+                       "checked_tasks": int(ctx.timing().checked_tasks), "swept_tasks": int(ctx.timing().swept_tasks),
                        "diag_left_tasks": int(ctx.timing().diag_left), "reduce_ms": float(np.mean(red_ms)), "submit_h2d_s": t_sub,
                        "generate_s": t_gen, "hard_tasks": int(ctx.timing().hard_tasks),
                        "overflow_tasks": int(ctx.timing().overflow_tasks),
@@ -442,6 +482,8 @@ def main():
             out["result_matches_unsharded"] = (None if exp is None or summary is None else
                                                bool(exp["nnz"] == summary["nnz"] and exp["checksum"] == summary["checksum"]))
             out["result_key"] = key
+        if sensitivity is not None:
+            out["sensitivity"] = sensitivity
         if other is not None:
             out["other_aligner"] = other
         if versus is not None:

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define VTX_ABI_VERSION 3
+#define VTX_ABI_VERSION 4
 
 typedef enum vtx_status {
     VTX_OK = 0,
@@ -163,7 +163,11 @@ typedef struct vtx_timing {
     float band_run_ms;     /* band_run_kernel launches only (seeds, chain, certificate; part of band_ms) */
     uint32_t overflow_tasks; /* banded flavour: alignments handed to the general band kernel        */
     float diag_ms;         /* band_tables_kernel + band_diag_kernel (single-diagonal stage; part of band_run_ms)   */
-    uint32_t diag_left;    /* alignments the single-diagonal stage left to band_run_kernel                          */
+    uint32_t diag_left;    /* alignments the certificate stages left: band_sweep_kernel + masked DP take them       */
+    float check_ms;        /* full-matrix check of the tasks that left with a certificate (part of band_ms)          */
+    float sweep_ms;        /* band_sweep_kernel + band-masked DP over what is left (part of band_ms)                 */
+    uint32_t checked_tasks; /* alignments that went through the full-matrix check (full == certificate decides them) */
+    uint32_t swept_tasks;  /* alignments handed to band_sweep_kernel                                                 */
 } vtx_timing;
 
 typedef struct vtx_ctx vtx_ctx;
@@ -286,6 +290,34 @@ int vtx_gather_abort(vtx_ctx* ctx);
 int vtx_gather_plan(int world, const uint64_t* counts, uint64_t* offsets, uint64_t* total);
 
 int vtx_last_timing(vtx_ctx* ctx, vtx_timing* out);
+
+/* ---- audit / test hooks: none changes a result, none is needed in production --------------------------------------------
+ * vtx_set_debug(ctx, VTX_DEBUG_STAGE_TRACE, 0 | 1): the next vtx_run records, one byte per task (task = 2 * record + haplotype,
+ *   0 = REF), which stage decided that alignment's score (Scores.ref_score / alt_score, src/main.rs:926-927): a certificate
+ *   (no DP cell touched), the full-matrix check of a certificate, or a DP.  vtx_fetch_stage copies the 2 * n_records bytes.
+ *   The invariant it lets a test assert over EVERY alignment: a banded score that differs from the full-matrix score was
+ *   produced by a DP stage, never by a certificate.
+ * vtx_set_debug(ctx, VTX_DEBUG_POISON_SCORES, 1) / (.., VTX_DEBUG_POISON_VALUE, v): every later vtx_run first fills both score
+ *   arrays with v, so that a stage that fails to write a task's score cannot hide behind the previous run's value.
+ * vtx_debug_bands: the band (banded::Aligner's Band: per column of the DP matrix the row range [lo, hi), columns 0 .. hap_len,
+ *   rows 0 .. read_len) band_sweep_kernel builds for n_tasks tasks of the resident batch — lo / hi hold `stride` uint16 per
+ *   task (stride >= longest haplotype + 1; empty column: lo 0x7fff, hi 0); status[i] = 0 band written, != 0 declined (the
+ *   general kernel takes such a task in vtx_run).  Parity of the BAND, not only of the score it leads to.                   */
+#define VTX_STAGE_UNKNOWN 0        /* VTX_BAND_LEGACY path: band_run_kernel's / band_pending_kernel's certificate */
+#define VTX_STAGE_DIAG_CERT 1      /* band_diag_kernel: cert == ub */
+#define VTX_STAGE_REFINE_CERT 2    /* band_refine_kernel: cert == refined ub */
+#define VTX_STAGE_FULL_CHECK 3     /* full-matrix score == certificate (cert <= banded <= full) */
+#define VTX_STAGE_SWEEP_DP 4       /* band_sweep_kernel's band + band-masked DP */
+#define VTX_STAGE_GENERAL_DP 5     /* general band kernel (tasks the sweep declined) + band-masked DP */
+#define VTX_STAGE_RUN_DP 6         /* VTX_BAND_LEGACY path: band_run_kernel's staircase + band-masked DP */
+#define VTX_STAGE_SLOW 8           /* slow_align_kernel (records beyond the fast kernels' limits): exact DP */
+#define VTX_STAGE_FULL_DP 9        /* full flavour: the full-matrix DP */
+#define VTX_DEBUG_STAGE_TRACE 1
+#define VTX_DEBUG_POISON_SCORES 2
+#define VTX_DEBUG_POISON_VALUE 3
+int vtx_set_debug(vtx_ctx* ctx, int key, int64_t value);
+int vtx_fetch_stage(vtx_ctx* ctx, uint8_t* stage);
+int vtx_debug_bands(vtx_ctx* ctx, const uint32_t* tasks, uint32_t n_tasks, uint32_t stride, uint16_t* lo, uint16_t* hi, uint8_t* status);
 
 /* Number of DP cells the last vtx_run evaluated (sum over records and both
  * haplotypes of rows x columns actually computed) — the roofline numerator.  */

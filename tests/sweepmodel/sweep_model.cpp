@@ -1,0 +1,179 @@
+// sweep_model.cpp — scalar CPU model of band_sweep_kernel's per-task algorithm (vartrix_amd/csrc/vtx_sweep.hip).
+// TEST INFRASTRUCTURE ONLY (tests/test_sweep_model.py): it restates, step by step and with the same packed words, what
+// the eight lanes of a task do on the device, so that the ALGORITHM (row sweep instead of the sorted event list,
+// dp finalised at the start event, the section log instead of per-match predecessor links, the closed-form band) is
+// checked against the oracle's literal restatement of bio 0.30.0 (oracle/vtx_oracle.c: vtxo_find_kmer_matches,
+// vtxo_sdpkpp, vtxo_band_create; reference call site src/main.rs:898-901) on the CPU, without a GPU.
+//
+// The algorithm (K = 6, W = 20; include/vtx_band_semantics.h):
+//   rows     match mask of read row x over the haplotype columns: M6(x) = AND_t Eq[x[x + t]] >> t  (bit y: the 6-mers at
+//            x and y are equal).  Bytes outside ACGTN: the task is declined (the general kernel takes it).
+//   sweep    x ascending; END events of row x (the matches that started at row x - 6) enter a max-Fenwick tree over
+//            their end column with the word  V << 16 | xq << 8 | yq  (V = dp + xe + ye: the tuple order of sdpkpp's
+//            tree, ties to the larger match index = the lexicographically larger start); then the START events of
+//            row x: dp = max(6, prefix-max(y).V - (x + y) + 1, dp(x - 1, y - 1) + 1) — the continuation wins ties, a
+//            jump needs >= 6 (oracle: cand > dp || cand == dp && larger index; every jump source has a smaller index
+//            than the continuation partner).  dp is FINAL at the start event: the continuation partner's dp was.
+//   log      every match that does NOT continue its diagonal opens a section: (x, y, source or none).
+//   chain    from the best (dp, x, y): the section is the log entry of this diagonal with the largest x' <= x; go on
+//            from its source.
+//   band     anchors of the staircase (lazy extension, sections, gaps) -> rmin / rmax per column -> lo / hi
+//            (closed form, vtx_band.hip's header).
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/vtx_band_semantics.h"
+
+namespace {
+constexpr int K = VTX_REF_K, W = VTX_REF_W;
+constexpr int MAXLEN = 255;
+
+inline int code_of(uint8_t b) {
+    switch (b) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case 'N': return 4; default: return -1; }
+}
+
+struct Mask256 { uint32_t w[8]; };
+inline Mask256 shr(const Mask256& a, int s) {          // bit j of the result = bit j + s of a
+    Mask256 r;
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t lo = a.w[i] >> s;
+        const uint32_t hi = (i + 1 < 8 && s) ? a.w[i + 1] << (32 - s) : 0u;
+        r.w[i] = lo | hi;
+    }
+    return r;
+}
+inline Mask256 band(const Mask256& a, const Mask256& b) { Mask256 r; for (int i = 0; i < 8; ++i) r.w[i] = a.w[i] & b.w[i]; return r; }
+}  // namespace
+
+extern "C" {
+
+// status: 0 band written; 1 declined (bytes outside ACGTN / lengths above 255); 2 log capacity exceeded; 3 too many sections.
+// lo / hi: n + 1 entries (oracle format: empty columns lo = m + 1, hi = 0).  stats[0] = log entries, [1] = sections, [2] = matches.
+int vtxs_band(const uint8_t* x, int m, const uint8_t* y, int n, int log_cap, int sec_cap, int32_t* lo, int32_t* hi, int32_t* stats) {
+    if (stats) stats[0] = stats[1] = stats[2] = 0;
+    if (m > MAXLEN || n > MAXLEN) return 1;
+    std::vector<int> cx(m), cy(n);
+    for (int i = 0; i < m; ++i) if ((cx[i] = code_of(x[i])) < 0) return 1;
+    for (int j = 0; j < n; ++j) if ((cy[j] = code_of(y[j])) < 0) return 1;
+    Mask256 eq[5];
+    memset(eq, 0, sizeof eq);
+    for (int j = 0; j < n; ++j) eq[cy[j]].w[j >> 5] |= 1u << (j & 31);
+    const int rows_m = m - K + 1;                         // rows with a 6-mer
+    std::vector<Mask256> m6(std::max(rows_m, 0));
+    long total = 0;
+    for (int r = 0; r < rows_m; ++r) {
+        Mask256 a = eq[cx[r]];
+        for (int t = 1; t < K; ++t) a = band(a, shr(eq[cx[r + t]], t));
+        m6[r] = a;
+        for (int i = 0; i < 8; ++i) total += __builtin_popcount(a.w[i]);
+    }
+    if (stats) stats[2] = (int32_t)total;
+    for (int j = 0; j <= n; ++j) { lo[j] = m + 1; hi[j] = 0; }
+    if (total == 0) {
+        if (VTX_BAND_NO_SEED_FULL_MATRIX) for (int j = 0; j <= n; ++j) { lo[j] = 0; hi[j] = m + 1; }
+        return 0;
+    }
+    // ---- sweep ----
+    uint8_t ring[8][256];
+    memset(ring, 0, sizeof ring);
+    uint32_t tree[257];
+    memset(tree, 0, sizeof tree);
+    std::vector<uint32_t> log;                            // x << 24 | y << 16 | source (xq << 8 | yq, 0xffff: none)
+    uint32_t best = 0;
+    for (int r = 0; r <= m; ++r) {
+        if (r >= K && r - K < rows_m) {                   // END events of row r
+            const int xs = r - K;
+            for (int yy = 0; yy < n; ++yy) {
+                if (!((m6[xs].w[yy >> 5] >> (yy & 31)) & 1u)) continue;
+                const uint32_t dp = ring[xs & 7][yy];
+                const uint32_t V = dp + (uint32_t)r + (uint32_t)(yy + K);
+                const uint32_t val = (V << 16) | ((uint32_t)xs << 8) | (uint32_t)yy;
+                for (int i = yy + K + 1; i <= 256; i += i & (-i)) tree[i] = std::max(tree[i], val);
+                best = std::max(best, (dp << 16) | ((uint32_t)xs << 8) | (uint32_t)yy);
+            }
+        }
+        if (r < rows_m) {                                 // START events of row r
+            memset(ring[r & 7], 0, 256);
+            for (int yy = 0; yy < n; ++yy) {
+                if (!((m6[r].w[yy >> 5] >> (yy & 31)) & 1u)) continue;
+                uint32_t q = 0;
+                for (int i = yy + 1; i > 0; i -= i & (-i)) q = std::max(q, tree[i]);
+                int dv = K;
+                uint32_t src = 0xffffu;
+                bool cont = false;
+                if (q) {
+                    const int cand = (int)(q >> 16) - (r + yy) + 1;
+                    if (cand >= K) { dv = cand; src = q & 0xffffu; }
+                }
+                if (r > 0 && yy > 0) {
+                    const int dpc = ring[(r - 1) & 7][yy - 1];
+                    if (dpc && dpc + 1 >= dv) { dv = dpc + 1; cont = true; }
+                }
+                ring[r & 7][yy] = (uint8_t)dv;
+                if (!cont) {
+                    if ((int)log.size() >= log_cap) return 2;
+                    log.push_back(((uint32_t)r << 24) | ((uint32_t)yy << 16) | src);
+                }
+            }
+        }
+    }
+    if (stats) stats[0] = (int32_t)log.size();
+    // ---- chain: sections, last first ----
+    struct Sec { int x0, y0, len; };
+    std::vector<Sec> secs;
+    int cxr = (int)((best >> 8) & 0xffu), cyr = (int)(best & 0xffu);
+    for (;;) {
+        const int d = cyr - cxr;
+        int found = -1, fx = -1;
+        for (size_t e = 0; e < log.size(); ++e) {
+            const int ex = (int)(log[e] >> 24), ey = (int)((log[e] >> 16) & 0xffu);
+            if (ey - ex == d && ex <= cxr && ex > fx) { fx = ex; found = (int)e; }
+        }
+        if (found < 0) return 4;                          // cannot happen: every piece start is logged
+        const int ex = (int)(log[found] >> 24), ey = (int)((log[found] >> 16) & 0xffu);
+        if ((int)secs.size() >= sec_cap) return 3;
+        secs.push_back(Sec{ex, ey, cxr - ex + 1});
+        const uint32_t src = log[found] & 0xffffu;
+        if (src == 0xffffu) break;
+        cxr = (int)(src >> 8); cyr = (int)(src & 0xffu);
+    }
+    std::reverse(secs.begin(), secs.end());
+    if (stats) stats[1] = (int32_t)secs.size();
+    // ---- anchors -> rmin / rmax ----
+    std::vector<int> rmin(n + 2, 1 << 20), rmax(n + 2, -1);
+    auto anchor = [&](int r, int c) { rmin[c] = std::min(rmin[c], r); rmax[c] = std::max(rmax[c], r); };
+    const int lazy = VTX_BAND_LAZY_EXT(K), last = VTX_BAND_KMER_LAST_ANCHOR(K);
+    const int fx0 = secs.front().x0, fy0 = secs.front().y0;
+    const int d0 = std::min(std::min(fx0, fy0), lazy);
+    for (int t = 0; t <= d0; ++t) anchor(fx0 - d0 + t, fy0 - d0 + t);
+    const int cA = fy0 - d0;
+    int pr = -1, pc = -1;                                  // end anchor of the previous section = (last match + K): add_gap's origin
+    for (size_t s = 0; s < secs.size(); ++s) {
+        const Sec& S = secs[s];
+        if (s > 0) {
+            const int dr = S.x0 - pr, dc = S.y0 - pc, dg = std::min(dr, dc);
+            for (int t = 0; t <= dg; ++t) anchor(pr + t, pc + t);
+            if (dr > dc) { for (int r = pr + dg; r <= S.x0; ++r) anchor(r, pc + dg); }
+            else { for (int c = pc + dg; c <= S.y0; ++c) anchor(pr + dg, c); }
+        }
+        const int span = S.len - 1 + last;                // first match: anchors 0 .. last; every continued match adds (+ last)
+        for (int t = 0; t <= span; ++t) anchor(S.x0 + t, S.y0 + t);
+        pr = S.x0 + S.len - 1 + K; pc = S.y0 + S.len - 1 + K;
+    }
+    const int lx = pr, ly = pc;
+    const int d1 = std::min(std::min(m - lx, n - ly), lazy);
+    for (int t = 0; t <= d1; ++t) anchor(lx + t, ly + t);
+    const int cB = ly + d1;
+    // (with LAST_ANCHOR = k - 1 the cell (lx, ly) itself is only reached by add_gap's origin: it is anchored above either way)
+    for (int j = 0; j <= n; ++j) {
+        if (j < cA - W || j > cB + W) continue;
+        const int c0 = std::max(j - W, cA), c1 = std::min(j + W, cB);
+        lo[j] = std::max(rmin[c0] - W, 0);
+        hi[j] = std::min(rmax[c1] + W + 1, m + 1);
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -362,7 +362,9 @@ with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_bar
 np.save(sys.argv[1], np.stack([r, a])); print("hard", t.hard_tasks, "overflow", t.overflow_tasks)
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "capped.npy")
-    r = subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, **{hook: "3"}), timeout=300,
+    # (VTX_BAND_HARD_CAP bounds the polyline / pending records of the round-3 path: VTX_BAND_LEGACY=1; the band slots bound both paths)
+    extra = {hook: "3", "VTX_BAND_LEGACY": "1"} if hook == "VTX_BAND_HARD_CAP" else {hook: "3"}
+    r = subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, **extra), timeout=300,
                        capture_output=True, text=True)
     got = np.load(out)
     spec = synth.SynthSpec(n_loci=150, n_barcodes=100, reads_per_locus=48, indel_frac=0.5, read_len_jitter=50, seed=15, sub_error=0.03)

@@ -182,7 +182,7 @@ np.save(sys.argv[1], np.concatenate(out))
     res = []
     with tempfile.TemporaryDirectory() as td:
         for serial in (0, 1):
-            env = dict(os.environ)
+            env = dict(os.environ, VTX_BAND_LEGACY="1")             # (the general kernels are the round-3 path; round 4's default only sends them what band_sweep_kernel declines)
             env.pop("VTX_BAND_NO_COOP", None)
             if serial:
                 env["VTX_BAND_NO_COOP"] = "1"
@@ -217,7 +217,7 @@ np.save(sys.argv[1], np.concatenate(out))
     res = []
     with tempfile.TemporaryDirectory() as td:
         for off in (0, 1):
-            env = dict(os.environ)
+            env = dict(os.environ, VTX_BAND_LEGACY="1")             # (hard-task counts of the round-3 path; with the full-matrix check in front the refinement changes little)
             env.pop("VTX_BAND_NO_REFINE", None)
             if off:
                 env["VTX_BAND_NO_REFINE"] = "1"

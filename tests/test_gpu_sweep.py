@@ -1,0 +1,198 @@
+"""GPU tests of round 4's robust path of the banded flavour (reference call site src/main.rs:898-901):
+
+  * band_sweep_kernel's BAND, column by column, against the oracle's Band::create (vtx_debug_bands): the kernel is checked on
+    what it computes, not only on the score the masked DP derives from it;
+  * the per-task stage byte (vtx_fetch_stage) and the invariant it audits: banded != full  =>  decided by a DP stage, never by a
+    certificate or by the full-matrix check;
+  * poisoned score arrays: every stage writes every score it is responsible for, run after run;
+  * the round-3 path (VTX_BAND_LEGACY=1) and the hooks of the new one give identical scores.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from vartrix_amd import abi, lib, synth
+from vartrix_amd.abi import default_config
+
+import stress_batches as SB
+from audit_util import assert_stage_invariant, stage_report
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def model_lib():
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "sweepmodel"), "-s"])
+    L = C.CDLL(os.path.join(HERE, "sweepmodel", "libsweep_model.so"))
+    L.vtxs_band.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.vtxs_band.restype = C.c_int
+    return L
+
+
+def bands_vs_oracle(batch, nb, label, max_tasks=6000):
+    """Every task of the batch through vtx_debug_bands; the band of every accepted task equals the oracle's, and a task is declined
+    exactly when the CPU model of the kernel (same capacities) declines it."""
+    M = model_lib()
+    n_tasks = min(2 * batch.n_records, max_tasks)
+    tasks = np.arange(n_tasks, dtype=np.uint32)
+    stride = int(max(batch.loci["ref_len"].max(), batch.loci["alt_len"].max())) + 1
+    with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb)) as ctx:
+        ctx.submit(batch)
+        lo, hi, status = ctx.debug_bands(tasks, stride)
+    rec_locus = np.repeat(np.arange(batch.n_loci), batch.loci["rec_count"])
+    hb, rb = batch.hap_arena.tobytes(), batch.read_arena.tobytes()
+    declined = 0
+    for t in range(n_tasks):
+        rec = batch.records[t >> 1]
+        loc = batch.loci[rec_locus[t >> 1]]
+        x = rb[int(rec["read_off"]):int(rec["read_off"]) + int(rec["read_len"])]
+        off, ln = (int(loc["alt_off"]), int(loc["alt_len"])) if t & 1 else (int(loc["ref_off"]), int(loc["ref_len"]))
+        y = hb[off:off + ln]
+        mlo = np.zeros(len(y) + 1, np.int32)
+        mhi = np.zeros(len(y) + 1, np.int32)
+        rc = M.vtxs_band(x, len(x), y, len(y), 128, 12, mlo.ctypes.data, mhi.ctypes.data, None) if len(x) and len(y) else 0
+        assert (status[t] != 0) == (rc != 0), "%s: task %d device status %d, model %d" % (label, t, status[t], rc)
+        if status[t]:
+            declined += 1
+            continue
+        if not len(x) or not len(y):
+            continue
+        olo, ohi, _ = oracle.band_create(x, y)
+        dlo = lo[t, :len(y) + 1].astype(np.int64)
+        dhi = hi[t, :len(y) + 1].astype(np.int64)
+        empty = ohi <= olo
+        assert np.array_equal(dhi[empty], np.zeros(int(empty.sum()), np.int64)), "%s: task %d: column outside the band" % (label, t)
+        assert np.array_equal(dlo[~empty], olo[~empty]) and np.array_equal(dhi[~empty], ohi[~empty]), \
+            "%s: task %d (read %d bases, haplotype %d): band differs from the oracle's" % (label, t, len(x), len(y))
+    return n_tasks, declined
+
+
+def test_bands_of_clean_noisy_and_indel_batches():
+    tot = dec = 0
+    for label, batch, nb in SB.synthetic_batches(per_model=1, n_loci=40, reads=16):
+        if max(int(batch.loci["ref_len"].max()), int(batch.loci["alt_len"].max())) > 255:
+            continue                                          # (the run takes the round-3 path for such a batch)
+        n, d = bands_vs_oracle(batch, nb, label, 1500)
+        tot += n
+        dec += d
+    assert tot > 5000 and dec == 0
+
+
+def test_bands_of_repeats_real_sequence_and_read_shapes():
+    tot = dec = 0
+    for gen in (SB.repeat_rich_batches(trials=4, loci=20, reads=12, pad_range=(30, 120)), SB.near_repeat_batches(trials=2),
+                SB.real_sequence_batches(trials=2), SB.real_shape_batches(trials=2)):
+        for label, batch, nb in gen:
+            n, d = bands_vs_oracle(batch, nb, label, 1200)
+            tot += n
+            dec += d
+    print("band parity: %d tasks, %d declined (capacities, bytes outside ACGTN)" % (tot, dec))
+    assert tot > 8000 and 0 < dec < 0.25 * tot
+
+
+def run_both(batch, nb, trace=True, poison=None, runs=1):
+    out = {}
+    for aligner in ("banded", "full"):
+        cfg = default_config(aligner=aligner, scoring_mode="coverage", n_barcodes=nb)
+        with lib.Context(cfg) as ctx:
+            ctx.submit(batch)
+            if trace:
+                ctx.set_stage_trace(True)
+            if poison is not None:
+                ctx.set_poison(poison)
+            for _ in range(runs):
+                ctx.run()
+                r, a = ctx.fetch_scores()
+                if poison is not None:
+                    assert not (r == poison).any() and not (a == poison).any(), "%s: a score was never written" % aligner
+            out[aligner] = (r, a, ctx.fetch_stage() if trace else None, ctx.timing())
+    return out
+
+
+@pytest.mark.parametrize("kind", ["clean", "noisy", "indels", "real-sequence", "repeats", "read-shapes"])
+def test_stage_invariant_and_oracle(kind):
+    if kind == "clean":
+        batches = [("config-3 shape", synth.make_batch(synth.SynthSpec(n_loci=300, n_barcodes=500, reads_per_locus=64, seed=5)), 500)]
+    elif kind == "noisy":
+        batches = [("%.0f %% errors" % (100 * e), synth.make_batch(synth.SynthSpec(n_loci=200, n_barcodes=500, reads_per_locus=48, sub_error=e, seed=6)), 500)
+                   for e in (0.03, 0.08)]
+    elif kind == "indels":
+        batches = [("config-5 shape", synth.make_batch(synth.SynthSpec(n_loci=256, n_barcodes=200, reads_per_locus=48, indel_frac=0.6,
+                                                                         read_len_jitter=60, seed=23, sub_error=0.02, use_umi=True)), 200)]
+    elif kind == "real-sequence":
+        batches = list(SB.real_sequence_batches(trials=2))
+    elif kind == "repeats":
+        batches = list(SB.repeat_rich_batches(trials=4, loci=30, reads=16, pad_range=(30, 120))) + list(SB.near_repeat_batches(trials=2))
+    else:
+        batches = list(SB.real_shape_batches(trials=2))
+    for label, batch, nb in batches:
+        out = run_both(batch, nb, poison=-31337)
+        rb, ab, stage, t = out["banded"]
+        rf, af, stage_f, _ = out["full"]
+        assert np.all(stage_f == abi.STAGE_FULL_DP)
+        differ = assert_stage_invariant(stage, (rb, ab), (rf, af), label)
+        oref, oalt = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=nb), threads=os.cpu_count() or 8)
+        bad = np.nonzero((rb != oref) | (ab != oalt))[0]
+        assert bad.size == 0, "%s: record %d device (%d, %d) oracle (%d, %d), stages %s" % (
+            label, bad[0], rb[bad[0]], ab[bad[0]], oref[bad[0]], oalt[bad[0]], stage[2 * bad[0]:2 * bad[0] + 2])
+        print("%s: %d alignments, banded != full on %d; decided by %s; checked %d, swept %d, declined %d" % (
+            label, len(stage), int(differ.sum()), stage_report(stage), t.checked_tasks, t.swept_tasks, t.overflow_tasks))
+        assert int(t.swept_tasks) >= int(np.isin(stage, (abi.STAGE_SWEEP_DP, abi.STAGE_GENERAL_DP)).sum())
+
+
+def test_poisoned_reruns_write_every_score():
+    """Three runs of one context with the score arrays poisoned before each (banded: the certificate stages, the check, the sweep
+    and the masked DP each own a disjoint set of tasks; a task nobody writes would keep the poison)."""
+    for label, batch, nb in list(SB.real_sequence_batches(trials=1)) + list(SB.synthetic_batches(per_model=1, n_loci=60, reads=24))[:3]:
+        if max(int(batch.loci["ref_len"].max()), int(batch.loci["alt_len"].max())) > 255:
+            continue
+        out = run_both(batch, nb, trace=False, poison=-7, runs=3)
+        oref, oalt = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=nb), threads=os.cpu_count() or 8)
+        assert np.array_equal(out["banded"][0], oref) and np.array_equal(out["banded"][1], oalt), label
+
+
+CODE = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import stress_batches as SB
+from vartrix_amd import lib, synth
+from vartrix_amd.abi import default_config
+out = []
+batches = list(SB.real_sequence_batches(trials=1)) + list(SB.repeat_rich_batches(trials=2, loci=30, reads=16)) + list(SB.real_shape_batches(trials=1))
+batches += [("noisy", synth.make_batch(synth.SynthSpec(n_loci=200, n_barcodes=300, reads_per_locus=48, sub_error=0.05, indel_frac=0.3, seed=3)), 300)]
+for label, batch, nb in batches:
+    with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb)) as ctx:
+        ctx.submit(batch); ctx.run()
+        r, a = ctx.fetch_scores()
+        t = ctx.timing()
+        out.append(r); out.append(a)
+        print(label, "left", t.diag_left, "checked", t.checked_tasks, "swept", t.swept_tasks, "hard", t.hard_tasks, "declined", t.overflow_tasks, file=sys.stderr)
+np.save(sys.argv[1], np.concatenate(out))
+''' % (ROOT, HERE)
+
+
+@pytest.mark.parametrize("hook", ["VTX_BAND_LEGACY", "VTX_BAND_NO_CHECK", "VTX_BAND_SLOTS"])
+def test_hooks_give_the_same_scores(hook):
+    """VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending / general kernels instead of the check + sweep; VTX_BAND_NO_CHECK=1:
+    every task the certificate stages leave goes to the sweep; VTX_BAND_SLOTS=5: the sweep + masked DP in slices of five band slots.
+    Identical scores (separate processes: the hooks are read once)."""
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for on in (0, 1):
+            env = dict(os.environ)
+            env.pop(hook, None)
+            if on:
+                env[hook] = "5" if hook == "VTX_BAND_SLOTS" else "1"
+            path = os.path.join(td, "h%d.npy" % on)
+            p = subprocess.run([sys.executable, "-c", CODE, path], env=env, capture_output=True, text=True, timeout=1200)
+            assert p.returncode == 0, p.stderr[-3000:]
+            print(hook, on, p.stderr.strip().replace("\n", " | "))
+            res.append(np.load(path))
+    assert np.array_equal(res[0], res[1])

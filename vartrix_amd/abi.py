@@ -12,7 +12,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-VTX_ABI_VERSION = 3
+VTX_ABI_VERSION = 4
 
 VTX_OK = 0
 VTX_E_INVAL = -1
@@ -119,7 +119,20 @@ class VtxTiming(C.Structure):
         ("overflow_tasks", C.c_uint32),
         ("diag_ms", C.c_float),
         ("diag_left", C.c_uint32),
+        ("check_ms", C.c_float),
+        ("sweep_ms", C.c_float),
+        ("checked_tasks", C.c_uint32),
+        ("swept_tasks", C.c_uint32),
     ]
+
+
+# vtx_fetch_stage: which stage decided an alignment's score (include/vtx.h)
+STAGE_UNKNOWN, STAGE_DIAG_CERT, STAGE_REFINE_CERT, STAGE_FULL_CHECK, STAGE_SWEEP_DP, STAGE_GENERAL_DP, STAGE_RUN_DP = range(7)
+STAGE_SLOW, STAGE_FULL_DP = 8, 9
+STAGE_NAMES = {0: "legacy certificate", 1: "diag certificate", 2: "refine certificate", 3: "full-matrix check", 4: "sweep + masked DP",
+               5: "general kernel + masked DP", 6: "band_run + masked DP", 8: "slow path", 9: "full DP"}
+DP_STAGES = (STAGE_SWEEP_DP, STAGE_GENERAL_DP, STAGE_RUN_DP, STAGE_SLOW, STAGE_FULL_DP)
+DEBUG_STAGE_TRACE, DEBUG_POISON_SCORES, DEBUG_POISON_VALUE = 1, 2, 3
 
 
 TAG_MISSING = 0xFFFF

@@ -93,7 +93,7 @@ struct vtx_ctx {
     uint64_t g_nnz = 0;
     uint32_t* h_pin = nullptr;               // pinned words for counters read back asynchronously (a D2H copy into pageable
                                              // memory blocks the host until the stream reaches it)
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[10] = {};
     std::string err;
     bool submitted = false, ran = false;
     uint32_t n_loci = 0, n_records = 0, n_cell_groups = 0, n_umi_groups = 0, max_hap_len = 0;
@@ -106,6 +106,9 @@ struct vtx_ctx {
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
     bool band_long_lists = false;      // (performance feedback between runs: see vtx_run)
     DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail, d_fail_tmp, d_refine;   // banded flavour
+    DevBuf d_tight, d_stage;                                                 // round 4: tasks with a provisional score (full-matrix check); stage bytes (vtx_fetch_stage)
+    bool stage_trace = false, poison = false;                                // test / audit hooks (vtx_set_debug)
+    int32_t poison_value = 0;
     DevBuf d_redo, d_redo_cnt;                                               // LUT kernel: records with non-ACGTN bytes
     // raw batches (vtx_submit_raw): barcode table + preparation scratch
     DevBuf d_bc_slots, d_bc_hash, d_bc_off, d_bc_bytes;
@@ -554,7 +557,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_cnt, &c->d_redo, &c->d_redo_cnt, &c->d_bc_slots, &c->d_bc_hash, &c->d_bc_off, &c->d_bc_bytes,
                       &c->d_raw, &c->d_tags, &c->d_raw_locus, &c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2,
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
-                      &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp, &c->d_refine};
+                      &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp, &c->d_refine, &c->d_tight, &c->d_stage};
     for (DevBuf* b : bufs) b->release();
     c->d_slow_ws.release(); c->d_slow_retry.release();
     DevBuf* gb[] = {&c->d_g_cnt, &c->d_g_row, &c->d_g_col, &c->d_g_alt, &c->d_g_ref, &c->d_g_unk, &c->d_g_val, &c->d_g_refval};
@@ -633,6 +636,7 @@ static int band_reserve(vtx_ctx* c, BandPlan& p, bool quiet) {
     RES(d_cnt, 64 * sizeof(uint32_t));
     if (p.gt_bytes) RES(d_fail, 2 * (size_t)p.chunk * sizeof(uint32_t));  // tasks band_diag_kernel leaves to band_run_kernel (as listed, then sorted)
     if (p.gt_bytes) RES(d_refine, (size_t)band_refine_cap(p.chunk) * vtxk_band_refine_words() * sizeof(uint32_t));   // records for band_refine_kernel
+    if (p.gt_bytes) RES(d_tight, (size_t)p.chunk * sizeof(uint32_t));     // tasks with a certificate but no verdict: the full-matrix check's list
 #undef RES
     return VTX_OK;
 }
@@ -944,6 +948,18 @@ int vtx_run(vtx_ctx* c) {
     const uint32_t nr = c->n_records;
     c->ran = false;
     c->fast_overflow = 0;
+    // test / audit hooks (vtx_set_debug): poison the score arrays so that a stage that fails to write a task's score cannot hide
+    // behind the previous run's value; one byte per task saying which stage decided it (vtx_fetch_stage)
+    uint8_t* stage = nullptr;
+    if (c->stage_trace && nr) {
+        HIP_TRY(c, c->d_stage.reserve(2 * (size_t)nr));
+        stage = c->d_stage.as<uint8_t>();
+        HIP_TRY(c, hipMemsetAsync(stage, c->cfg.aligner == VTX_ALIGNER_BANDED ? VTX_STAGE_UNKNOWN : VTX_STAGE_FULL_DP, 2 * (size_t)nr, s));
+    }
+    if (c->poison && nr) {
+        HIP_TRY(c, vtxk_fill_i32(c->d_ref.as<int32_t>(), nr, c->poison_value, s));
+        HIP_TRY(c, vtxk_fill_i32(c->d_alt.as<int32_t>(), nr, c->poison_value, s));
+    }
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     uint32_t launches = 0;
     bool any_lut = false;
@@ -1011,7 +1027,8 @@ int vtx_run(vtx_ctx* c) {
         int shape = 0;
         while ((uint32_t)(kShapes[shape][0] * kShapes[shape][1]) < c->max_read_len) ++shape;
         // src == nullptr: the band slots already hold arrays (or the full-matrix marker), one slot per task
-        auto masked_dp = [&](uint32_t n_hard, uint32_t* hard, const uint16_t* src, uint16_t* band, uint32_t n_slots, hipStream_t st) -> int {
+        auto masked_dp = [&](uint32_t n_hard, uint32_t* hard, const uint16_t* src, uint16_t* band, uint32_t n_slots, hipStream_t st, uint8_t code) -> int {
+            if (stage) HIP_TRY(c, vtxk_mark_stage(hard, n_hard, nullptr, code, stage, st));
             for (uint32_t off = 0; off < n_hard; off += n_slots) {
                 const uint32_t cnt_s = std::min(n_slots, n_hard - off);
                 HIP_TRY(c, vtxk_launch_band_expand(hard + off, cnt_s, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
@@ -1103,7 +1120,7 @@ int vtx_run(vtx_ctx* c) {
                     if (!fb.todo) break;
                     if (int rc = fallback_launch()) return rc;
                 }
-                if (int rc = masked_dp(fb.gcnt[0], c->d_hard2.as<uint32_t>(), nullptr, c->d_band2.as<uint16_t>(), std::max(fb.gcnt[0], 1u), s2)) return rc;
+                if (int rc = masked_dp(fb.gcnt[0], c->d_hard2.as<uint32_t>(), nullptr, c->d_band2.as<uint16_t>(), std::max(fb.gcnt[0], 1u), s2, VTX_STAGE_GENERAL_DP)) return rc;
                 hard_total += fb.gcnt[0];
                 if (fb.off + fb.n_over >= fb.total) break;
                 if (int rc = fallback_start(fb.off + fb.n_over, fb.total)) return rc;      // next slice (same stream: in order)
@@ -1115,10 +1132,22 @@ int vtx_run(vtx_ctx* c) {
         HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 64 * sizeof(uint32_t), s));
         uint32_t cnt[12] = {0};
         uint32_t pending_total = 0, over_before = 0;
-        uint64_t diag_total = 0, diag_left = 0, refined_total = 0;
-        float diag_ms = 0;
+        uint64_t diag_total = 0, diag_left = 0, refined_total = 0, checked_total = 0, swept_total = 0;
+        float diag_ms = 0, check_ms = 0, sweep_ms = 0;
+        bool sweep_pending = false;                 // the events of a swept chunk have not been read yet
+        auto collect_sweep_times = [&]() -> int {
+            if (!sweep_pending) return VTX_OK;
+            sweep_pending = false;
+            HIP_TRY(c, hipEventSynchronize(c->ev[8]));
+            float ms = 0;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[7], c->ev[5])); check_ms += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[5], c->ev[8])); sweep_ms += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[6])); diag_ms += ms;
+            return VTX_OK;
+        };
         for (uint64_t base = 0; base < n_tasks; base += chunk) {
             const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, n_tasks - base);
+            if (int rc = collect_sweep_times()) return rc;                              // (a chunk re-records the events)
             HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), s));                 // hard count of this chunk
             HIP_TRY(c, hipMemsetAsync(d_cnt + 11, 0, sizeof(uint32_t), s));            // pending count of this chunk
             HIP_TRY(c, hipMemsetAsync(d_cnt + 16, 0, 8 * sizeof(uint32_t), s));        // block counters (one per XCD)
@@ -1138,12 +1167,19 @@ int vtx_run(vtx_ctx* c) {
             // (vtx_fast_core.h) and lists the others; band_run_kernel then takes that LIST instead of the whole range.
             static const bool no_diag = getenv("VTX_BAND_NO_DIAG") != nullptr;          // experiment / test hook: stage 1 off
             static const int diag_stats = getenv("VTX_DEBUG") ? 1 : 0;
-            bool diag = false;
+            bool diag = false, swept = false;
             uint32_t n_fail = 0;
             const uint32_t* fail_list = c->d_fail.as<uint32_t>();
+            // Round 4: what band_diag_kernel / band_refine_kernel leave goes (a) with a certificate: through the full-matrix CHECK
+            // (full == cert decides it: cert <= banded <= full), (b) otherwise, or when the check fails: through band_sweep_kernel
+            // (the band of ANY task, vtx_sweep.hip) and the masked DP.  VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending /
+            // general path instead (kept for A/B tests; also what takes over when a haplotype of the batch exceeds 255 bases).
+            static const bool legacy = getenv("VTX_BAND_LEGACY") != nullptr;
+            static const bool no_check = getenv("VTX_BAND_NO_CHECK") != nullptr;          // experiment / test hook: no full-matrix check
+            const bool sweep_path = !legacy && c->max_hap_len <= vtxk_band_sweep_max_len() && c->max_hap_len > 0;
+            uint32_t* tight_list = (sweep_path && !no_check) ? c->d_tight.as<uint32_t>() : nullptr;
             if (gt_n && !no_diag) {
-                HIP_TRY(c, hipMemsetAsync(d_cnt + 12, 0, sizeof(uint32_t), s));
-                HIP_TRY(c, hipMemsetAsync(d_cnt + 14, 0, sizeof(uint32_t), s));
+                HIP_TRY(c, hipMemsetAsync(d_cnt + 12, 0, 4 * sizeof(uint32_t), s));   // [12] left, [14] refine records, [15] tasks with a provisional score
                 // tasks with main pieces only whose bounds do not meet leave a record for band_refine_kernel
                 static const bool no_refine = getenv("VTX_BAND_NO_REFINE") != nullptr;        // experiment / test hook
                 const uint32_t refine_cap = band_refine_cap(chunk);
@@ -1152,8 +1188,61 @@ int vtx_run(vtx_ctx* c) {
                                                            c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                                            c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
                                                            c->d_fail.as<uint32_t>(), refine_list, refine_cap, d_cnt, tasks_per_locus, gt_l0, gt_n,
-                                                           c->d_gtables.as<uint8_t>(), gt_bytes, diag_stats, s);
-                if (e == hipSuccess) {
+                                                           c->d_gtables.as<uint8_t>(), gt_bytes, diag_stats, tight_list, stage, s);
+                if (e == hipSuccess && sweep_path) {
+                    diag = true; swept = true;
+                    HIP_TRY(c, hipEventRecord(c->ev[6], s));
+                    // band_refine_kernel over the records left for it, the full-matrix check over the tasks with a provisional
+                    // score: both lists are counted on the device (grids sized for the lists' capacities: a workgroup beyond the
+                    // count returns at once) — no host round trip before the one that sizes the sweep
+                    if (refine_list)
+                        HIP_TRY(c, vtxk_launch_band_refine(refine_list, std::min(refine_cap, nt), c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                           c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
+                                                           c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
+                                                           tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, tight_list, stage, d_cnt + 14, s));
+                    HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));   // [12] fail, [14] refine, [15] tight
+                    HIP_TRY(c, hipStreamSynchronize(s));
+                    const uint32_t n_refine = std::min(c->h_pin[10], refine_cap), n_tight = std::min(c->h_pin[11], nt);
+                    refined_total += n_refine;
+                    launches += 2;
+                    HIP_TRY(c, hipEventRecord(c->ev[7], s));
+                    if (n_tight) {
+                        HIP_TRY(c, vtxk_launch_sw_check(kShapes[shape][0], kShapes[shape][1], n_tight, tight_list, nullptr, c->d_records.as<vtx_record>(),
+                                                        c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                                        c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len,
+                                                        c->d_fail.as<uint32_t>(), d_cnt + 12, stage, s));
+                        HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                        HIP_TRY(c, hipStreamSynchronize(s));
+                        ++launches;
+                    }
+                    HIP_TRY(c, hipEventRecord(c->ev[5], s));
+                    n_fail = c->h_pin[8];
+                    checked_total += n_tight;
+                    diag_total += nt; diag_left += n_fail;
+                    if (n_fail > 64) {                                  // by task: neighbours share their locus' haplotypes (and the hard list comes out in a fixed order)
+                        const size_t tb = vtxk_sort_keys_u32_temp_bytes(n_fail);
+                        if (c->d_fail_tmp.reserve(tb) == hipSuccess) {
+                            HIP_TRY(c, vtxk_sort_keys_u32(c->d_fail.as<uint32_t>(), c->d_fail.as<uint32_t>() + nt, n_fail, c->d_fail_tmp.p, tb, s));
+                            fail_list = c->d_fail.as<uint32_t>() + nt;
+                        } else (void)hipGetLastError();
+                    }
+                    // the band of every task that is left, one slice of band slots at a time, then the masked DP over the slice
+                    // (its length — the tasks the sweep did not decline — is read on the device)
+                    for (uint32_t off = 0; off < n_fail; off += slots) {
+                        const uint32_t cnt_s = std::min(slots, n_fail - off);
+                        HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), s));
+                        HIP_TRY(c, vtxk_launch_band_sweep(fail_list + off, cnt_s, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                          c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                                          c->d_band.as<uint16_t>(), band_stride, c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(),
+                                                          d_cnt, diag_stats, stage, s));
+                        HIP_TRY(c, vtxk_launch_sw_banded_dev(kShapes[shape][0], kShapes[shape][1], cnt_s, c->d_hard.as<uint32_t>(), d_cnt,
+                                                             c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
+                                                             c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_band.as<uint16_t>(), band_stride,
+                                                             c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len, s));
+                        launches += 2;
+                    }
+                    swept_total += n_fail;
+                } else if (e == hipSuccess) {
                     diag = true;
                     HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     HIP_TRY(c, hipMemcpyAsync(c->h_pin + 9, d_cnt + 14, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1165,7 +1254,7 @@ int vtx_run(vtx_ctx* c) {
                         HIP_TRY(c, vtxk_launch_band_refine(refine_list, n_refine, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                                            c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
                                                            c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
-                                                           tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, s));
+                                                           tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, nullptr, stage, nullptr, s));
                         HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                         HIP_TRY(c, hipStreamSynchronize(s));
                         n_fail = c->h_pin[8];
@@ -1187,6 +1276,17 @@ int vtx_run(vtx_ctx* c) {
                 } else {
                     (void)hipGetLastError();
                 }
+            }
+            if (swept) {
+                HIP_TRY(c, hipEventRecord(c->ev[8], s));
+                sweep_pending = true;
+                if (base + chunk >= n_tasks) {                              // last chunk: what the sweep declined is complete
+                    HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipStreamSynchronize(s));
+                    if (int rc = collect_sweep_times()) return rc;
+                    if (cnt[1]) { if (int rc = fallback_start(0, cnt[1])) return rc; }
+                }
+                continue;
             }
             if (!diag || n_fail)
                 HIP_TRY(c, vtxk_launch_band_run(diag ? n_fail : nt, diag ? 0u : (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
@@ -1253,7 +1353,7 @@ int vtx_run(vtx_ctx* c) {
                 pending_total += cnt[11];
                 ++launches;
             }
-            if (int rc = masked_dp(cnt[0], c->d_hard.as<uint32_t>(), c->d_poly.as<uint16_t>(), c->d_band.as<uint16_t>(), slots, s)) return rc;
+            if (int rc = masked_dp(cnt[0], c->d_hard.as<uint32_t>(), c->d_poly.as<uint16_t>(), c->d_band.as<uint16_t>(), slots, s, VTX_STAGE_RUN_DP)) return rc;
             hard_total += cnt[0];
             ++launches;
         }
@@ -1267,6 +1367,10 @@ int vtx_run(vtx_ctx* c) {
         if (int rc = fallback_finish()) return rc;
         c->fast_overflow = fast_overflow;
         c->timing.diag_ms = diag_ms; c->timing.diag_left = (uint32_t)std::min<uint64_t>(diag_left, 0xffffffffull);
+        c->timing.check_ms = check_ms; c->timing.sweep_ms = sweep_ms;
+        c->timing.checked_tasks = (uint32_t)std::min<uint64_t>(checked_total, 0xffffffffull);
+        c->timing.swept_tasks = (uint32_t)std::min<uint64_t>(swept_total, 0xffffffffull);
+        if (swept_total) hard_total += (uint32_t)std::min<uint64_t>(swept_total - std::min<uint64_t>(swept_total, fast_overflow), 0xffffffffull);
         if (getenv("VTX_DEBUG") && diag_total) {
             uint32_t why[16];
             HIP_TRY(c, hipMemcpy(why, d_cnt + 32, sizeof why, hipMemcpyDeviceToHost));
@@ -1281,6 +1385,7 @@ int vtx_run(vtx_ctx* c) {
         // records beyond the fast kernels' limits: exact slow path, both flavours (slabs grow until every chain fits)
         const uint32_t n_slow = 2 * c->slow_cnt;
         const int banded = c->cfg.aligner == VTX_ALIGNER_BANDED;
+        if (stage) HIP_TRY(c, vtxk_mark_stage_records(c->d_work.as<uint32_t>() + c->slow_off, c->slow_cnt, VTX_STAGE_SLOW, stage, s));
         HIP_TRY(c, c->d_cnt.reserve(64 * sizeof(uint32_t)));
         uint32_t* d_scnt = c->d_cnt.as<uint32_t>() + 13;
         HIP_TRY(c, c->d_slow_retry.reserve(2 * (size_t)n_slow * sizeof(uint32_t)));
@@ -1357,6 +1462,74 @@ int vtx_fetch_scores(vtx_ctx* c, int32_t* ref_score, int32_t* alt_score) {
         HIP_TRY(c, hipMemcpy(alt_score, c->d_alt.p, (size_t)c->n_records * sizeof(int32_t), hipMemcpyDeviceToHost));
     }
     return VTX_OK;
+}
+
+int vtx_set_debug(vtx_ctx* c, int key, int64_t value) {
+    if (!c) return VTX_E_INVAL;
+    switch (key) {
+        case VTX_DEBUG_STAGE_TRACE: c->stage_trace = value != 0; return VTX_OK;
+        case VTX_DEBUG_POISON_SCORES: c->poison = value != 0; return VTX_OK;
+        case VTX_DEBUG_POISON_VALUE: c->poison_value = (int32_t)value; return VTX_OK;
+        default: return fail(c, VTX_E_INVAL, "vtx_set_debug: unknown key %d", key);
+    }
+}
+
+int vtx_fetch_stage(vtx_ctx* c, uint8_t* stage) {
+    if (!c) return VTX_E_INVAL;
+    if (!c->ran) return fail(c, VTX_E_STATE, "vtx_fetch_stage: no completed vtx_run");
+    if (!c->stage_trace || (c->n_records && c->d_stage.cap < 2 * (size_t)c->n_records))
+        return fail(c, VTX_E_STATE, "vtx_fetch_stage: the last vtx_run was not traced (vtx_set_debug(ctx, VTX_DEBUG_STAGE_TRACE, 1) before it)");
+    if (c->n_records && !stage) return fail(c, VTX_E_INVAL, "vtx_fetch_stage: null output");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (c->n_records) HIP_TRY(c, hipMemcpy(stage, c->d_stage.p, 2 * (size_t)c->n_records, hipMemcpyDeviceToHost));
+    return VTX_OK;
+}
+
+int vtx_debug_bands(vtx_ctx* c, const uint32_t* tasks, uint32_t n_tasks, uint32_t stride, uint16_t* lo, uint16_t* hi, uint8_t* status) {
+    if (!c) return VTX_E_INVAL;
+    if (!c->submitted) return fail(c, VTX_E_STATE, "vtx_debug_bands: no batch submitted");
+    if (!n_tasks) return VTX_OK;
+    if (!tasks || !lo || !hi || !status) return fail(c, VTX_E_INVAL, "vtx_debug_bands: null array");
+    if (stride < c->max_hap_all + 1) return fail(c, VTX_E_INVAL, "vtx_debug_bands: stride %u < longest haplotype + 1 (%u)", stride, c->max_hap_all + 1);
+    for (uint32_t i = 0; i < n_tasks; ++i)
+        if (tasks[i] >= 2ull * c->n_records) return fail(c, VTX_E_INVAL, "vtx_debug_bands: task %u out of range", tasks[i]);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    // scratch of its own (one task per launch slot; a debug call may be slow): tasks, hard list, overflow list, counters, bands
+    DevBuf d_t, d_h, d_o, d_c, d_b;
+    const uint32_t bs = (stride + 7u) & ~7u;
+    auto done = [&](int rc) { d_t.release(); d_h.release(); d_o.release(); d_c.release(); d_b.release(); return rc; };
+#define DBG_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return done(fail(c, VTX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_))); } while (0)
+    DBG_TRY(d_t.reserve((size_t)n_tasks * 4)); DBG_TRY(d_h.reserve((size_t)n_tasks * 4)); DBG_TRY(d_o.reserve((size_t)n_tasks * 4));
+    DBG_TRY(d_c.reserve(64 * 4)); DBG_TRY(d_b.reserve((size_t)n_tasks * 2 * bs * sizeof(uint16_t)));
+    DBG_TRY(hipMemcpyAsync(d_t.p, tasks, (size_t)n_tasks * 4, hipMemcpyHostToDevice, s));
+    DBG_TRY(hipMemsetAsync(d_c.p, 0, 64 * 4, s));
+    DBG_TRY(vtxk_launch_band_sweep(d_t.as<uint32_t>(), n_tasks, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                   c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), d_b.as<uint16_t>(), bs,
+                                   d_h.as<uint32_t>(), d_o.as<uint32_t>(), d_c.as<uint32_t>(), 0, nullptr, s));
+    uint32_t cnt[2] = {0, 0};
+    DBG_TRY(hipMemcpyAsync(cnt, d_c.p, sizeof cnt, hipMemcpyDeviceToHost, s));
+    DBG_TRY(hipStreamSynchronize(s));
+    std::vector<uint32_t> hard(cnt[0]);
+    std::vector<uint16_t> bands((size_t)cnt[0] * 2 * bs);
+    if (cnt[0]) {
+        DBG_TRY(hipMemcpy(hard.data(), d_h.p, (size_t)cnt[0] * 4, hipMemcpyDeviceToHost));
+        DBG_TRY(hipMemcpy(bands.data(), d_b.p, bands.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    }
+#undef DBG_TRY
+    // slots come out in any order, and a task may be listed more than once: every occurrence of a task gets the band of one of its slots
+    std::vector<std::pair<uint32_t, uint32_t>> by_task(cnt[0]);
+    for (uint32_t h = 0; h < cnt[0]; ++h) by_task[h] = {hard[h], h};
+    std::sort(by_task.begin(), by_task.end());
+    for (uint32_t i = 0; i < n_tasks; ++i) {
+        auto it = std::lower_bound(by_task.begin(), by_task.end(), std::make_pair(tasks[i], 0u));
+        if (it == by_task.end() || it->first != tasks[i]) { status[i] = 1; continue; }
+        status[i] = 0;
+        const uint16_t* src = bands.data() + (size_t)it->second * 2 * bs;
+        memcpy(lo + (size_t)i * stride, src, (size_t)stride * sizeof(uint16_t));
+        memcpy(hi + (size_t)i * stride, src + bs, (size_t)stride * sizeof(uint16_t));
+    }
+    return done(VTX_OK);
 }
 
 int vtx_device_scores(vtx_ctx* c, const int32_t** d_ref, const int32_t** d_alt) {

@@ -1864,7 +1864,11 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
     const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ fail_list, uint32_t* __restrict__ refine_rec, uint32_t refine_cap, uint32_t* __restrict__ counters,
-    uint32_t stats) {
+    uint32_t stats, uint32_t* __restrict__ tight_list, uint8_t* __restrict__ stage) {
+    // tight_list != nullptr (round 4): a task whose off-diagonal matches are all harmless but whose bounds do not meet (or whose
+    // generic set overflows) HAS a certificate — the chain is the closed form's, cert <= banded — so it leaves with
+    // score = cert as a PROVISIONAL score on tight_list (counters[15]) for the full-matrix check (sw_banded_kernel<.., true>:
+    // full == cert decides it), not on fail_list.  stage != nullptr: stage[task] = 1 for every task decided here (vtx_fetch_stage).
     // refine_rec != nullptr: a task with main pieces only whose bounds do not meet leaves a 12-word record for band_refine_kernel
     // (counters[14]; REFINE_WORDS) instead of going to band_run_kernel's list: that kernel prices the stretches of >= 3 errors
     // within a few bases from the real neighbour diagonals and needs nothing else of what this one found.
@@ -1909,6 +1913,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         my_score = (hap ? alt_score : ref_score) + rid;
         if (m == 0 || n == 0) {
             *my_score = 0;                                               // empty read / haplotype: score 0
+            if (stage) stage[task] = 1;
         } else if ((uint32_t)m > VTX_FAST_READ_LEN || max(loc.ref_len, loc.alt_len) > max_hap) {
             // beyond the fast kernels: slow_align_kernel scores it (the host lists these records)
         } else if (m < vtxf::K || n < vtxf::K || m > vtxf::MAX_READ) {
@@ -2055,6 +2060,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     }
     if ((stats >> 8) == 2) { if (live && s_cnt[tid] == 0x7fffffff) counters[40] = 1; return; }   // (profiling aid) front + probes
     uint32_t aux = 0xffffffffu;
+    bool tight = false;
     // ---- the last phase, every lane for itself: sort, harmless tests, closure, run bound (vtx_fast_core.h).  (Pooling the harmless
     //      tests over the wavefront like the probes — one queue entry per match, A | T << 8 left in the entry, a short recurrence per
     //      owner — was built and measured: 1.67 ms pooled against 1.7 ms per lane, 18.24 against 18.33 ms per step: not kept.) ----
@@ -2066,7 +2072,8 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     if (live) {
         const vtxf::Lane gl{(uint32_t*)q_ent + tid, 64};                 // (the queue is dead by now)
         const int32_t sc = vtxf::back_rest(fr, ns, ln, gl, &why, (int)(stats >> 8), nullptr, &aux);
-        if (sc >= 0) *my_score = sc; else fail = true;
+        if (sc >= 0) { *my_score = sc; if (stage) stage[task] = 1; }
+        else { fail = true; tight = tight_list != nullptr; }
     }
     bool again = fail && why == vtxf::W_NOT_TIGHT && refine_rec != nullptr && aux != 0xffffffffu;
     const uint64_t am = __ballot(again);
@@ -2085,13 +2092,25 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             for (int i = 0; i < vtxf::RM; ++i) rec[4 + i] = i < fr.r ? ln.at(i) : 0u;
         }
     }
-    const uint64_t fm = __ballot(fail && !again);
+    tight = tight && fail && !again;
+    const uint64_t tm = __ballot(tight);
+    if (tm) {
+        uint32_t base = 0;
+        const int leader = __ffsll((long long)tm) - 1;
+        if (tid == leader) base = atomicAdd(&counters[15], (uint32_t)__popcll(tm));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (tight) {
+            tight_list[base + (uint32_t)__popcll(tm & ((1ull << tid) - 1ull))] = task;
+            *my_score = fr.cert;                                      // provisional: a lower bound of the banded score
+        }
+    }
+    const uint64_t fm = __ballot(fail && !again && !tight);
     if (fm) {
         uint32_t base = 0;
         const int leader = __ffsll((long long)fm) - 1;
         if (tid == leader) base = atomicAdd(&counters[12], (uint32_t)__popcll(fm));
         base = (uint32_t)__shfl((int)base, leader);
-        if (fail && !again) fail_list[base + (uint32_t)__popcll(fm & ((1ull << tid) - 1ull))] = task;
+        if (fail && !again && !tight) fail_list[base + (uint32_t)__popcll(fm & ((1ull << tid) - 1ull))] = task;
     }
     if (fail && !again && (stats & 0xffu)) atomicAdd(&counters[32 + why], 1u);
 }
@@ -2111,8 +2130,12 @@ __global__ __launch_bounds__(256) void band_refine_kernel(
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
     const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
-    uint32_t* __restrict__ fail_list, uint32_t* __restrict__ counters, uint32_t stats) {
+    uint32_t* __restrict__ fail_list, uint32_t* __restrict__ counters, uint32_t stats, uint32_t* __restrict__ tight_list,
+    uint8_t* __restrict__ stage, const uint32_t* __restrict__ n_dev) {
+    // tight_list != nullptr (round 4): an undecided record still has its certificate: provisional score + tight_list (counters[15])
+    // instead of fail_list (see band_diag_kernel).  n_dev: the record count lives on the device (min(*n_dev, n_recs)).
     __shared__ uint32_t piece_mem_[4][vtxf::RM * 64];
+    if (n_dev) { const uint32_t nd = *n_dev; n_recs = nd < n_recs ? nd : n_recs; }
     const int wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
     const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
     bool fail = false;
@@ -2132,17 +2155,18 @@ __global__ __launch_bounds__(256) void band_refine_kernel(
         const uint8_t* yb = gtables + ((size_t)(my_locus - gt_l0) * 2 + hap) * table_stride + vtxf::tab_bytes_off(max_hap, n_heads);
         const vtxf::Refine rf{read_arena + rec.read_off, yb, (int)rec.read_len, (int)(hap ? loc.alt_len : loc.ref_len)};
         const int ub = max(max(vtxf::K - 1, far_e > 0 ? far_e + 5 : 0), vtxf::main_pieces_ub(pl, r, h.w, d, &rf));
-        if (ub == cert) (hap ? alt_score : ref_score)[rid] = cert;
+        (hap ? alt_score : ref_score)[rid] = cert;                     // final when ub == cert, provisional otherwise
+        if (ub == cert) { if (stage) stage[task] = 2; }
         else fail = true;
     }
     const uint64_t fm = __ballot(fail);
     if (fm) {
         uint32_t base = 0;
         const int leader = __ffsll((long long)fm) - 1;
-        if (tid == leader) base = atomicAdd(&counters[12], (uint32_t)__popcll(fm));
+        if (tid == leader) base = atomicAdd(&counters[tight_list ? 15 : 12], (uint32_t)__popcll(fm));
         base = (uint32_t)__shfl((int)base, leader);
         if (fail) {
-            fail_list[base + (uint32_t)__popcll(fm & ((1ull << tid) - 1ull))] = task;
+            (tight_list ? tight_list : fail_list)[base + (uint32_t)__popcll(fm & ((1ull << tid) - 1ull))] = task;
             if (stats & 0xffu) atomicAdd(&counters[32 + vtxf::W_NOT_TIGHT], 1u);
         }
     }
@@ -2287,7 +2311,7 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
                                             const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score, int32_t* alt_score,
                                             uint32_t* fail_list, uint32_t* refine_rec, uint32_t refine_cap, uint32_t* counters,
                                             uint32_t tasks_per_locus, uint32_t gt_l0, uint32_t n_loci, uint8_t* gtables,
-                                            size_t gtables_bytes, int stats, hipStream_t s) {
+                                            size_t gtables_bytes, int stats, uint32_t* tight_list, uint8_t* stage, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
     const uint32_t n_heads = pick_heads(tasks_per_locus, true);
     const size_t tstride = band_table_stride(max_hap, n_heads);
@@ -2301,11 +2325,11 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     if (max_hap <= 255 && !force_wide)
         hipLaunchKernelGGL((band_diag_kernel<4, uint16_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
                            rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                           alt_score, fail_list, refine_rec, refine_cap, counters, st);
+                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, stage);
     else
         hipLaunchKernelGGL((band_diag_kernel<4, uint32_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
                            rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                           alt_score, fail_list, refine_rec, refine_cap, counters, st);
+                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, stage);
     return hipGetLastError();
 }
 
@@ -2314,12 +2338,13 @@ extern "C" hipError_t vtxk_launch_band_refine(const uint32_t* recs, uint32_t n_r
                                               const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                               uint32_t max_hap, int32_t* ref_score, int32_t* alt_score, uint32_t* fail_list,
                                               uint32_t* counters, uint32_t tasks_per_locus, uint32_t gt_l0, const uint8_t* gtables,
-                                              int stats, hipStream_t s) {
+                                              int stats, uint32_t* tight_list, uint8_t* stage, const uint32_t* n_dev, hipStream_t s) {
     if (!n_recs) return hipSuccess;
     const uint32_t n_heads = pick_heads(tasks_per_locus, true);
     const size_t tstride = band_table_stride(max_hap, n_heads);
     hipLaunchKernelGGL(band_refine_kernel, dim3((n_recs + 255) / 256), dim3(256), 0, s, recs, n_recs, records, rec_locus, loci, read_arena,
-                       max_hap, (uint32_t)tstride, n_heads, gtables, gt_l0, ref_score, alt_score, fail_list, counters, (uint32_t)stats);
+                       max_hap, (uint32_t)tstride, n_heads, gtables, gt_l0, ref_score, alt_score, fail_list, counters, (uint32_t)stats,
+                       tight_list, stage, n_dev);
     return hipGetLastError();
 }
 

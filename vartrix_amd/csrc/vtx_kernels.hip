@@ -413,14 +413,22 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
 
 #define NEG_G PK(-16000)
 
-template <int R, int GL>
+// FULL (round 4): the same kernel WITHOUT a band — every cell is in band, the mask arithmetic folds away (12 packed ops per
+// cell pair instead of 19) — used as a CHECK, not as a score: the tasks of `hard` carry a provisional score (the certificate
+// of band_diag_kernel / band_refine_kernel, a lower bound of the banded score: cert <= banded <= full); where the full-matrix
+// score EQUALS it the provisional score is the banded score and stays; the other tasks are appended to recheck_list
+// (recheck_count) for band_sweep_kernel + the masked DP.  n_dev != nullptr: the list length lives on the device
+// (min(*n_dev, n_hard) entries; the grid is sized for n_hard).
+template <int R, int GL, bool FULL>
 __global__ __launch_bounds__(256) void sw_banded_kernel(
-    const uint32_t* __restrict__ hard, uint32_t n_hard,
+    const uint32_t* __restrict__ hard, uint32_t n_hard, const uint32_t* __restrict__ n_dev,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus,
     const vtx_locus* __restrict__ loci, const uint8_t* __restrict__ read_arena,
     const uint8_t* __restrict__ hap_arena, const uint16_t* __restrict__ band, uint32_t band_stride,
-    int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score, uint32_t lcols) {
+    int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score, uint32_t lcols,
+    uint32_t* __restrict__ recheck_list, uint32_t* __restrict__ recheck_count, uint8_t* __restrict__ stage) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    if (n_dev) { const uint32_t nd = *n_dev; n_hard = nd < n_hard ? nd : n_hard; }
     const int GROUPS_PER_BLOCK = (int)blockDim.x / GL;     // 256 threads, or fewer when three LDS arrays per record slot of a wide haplotype do not fit
     constexpr int DPP = (GL == 16) ? DPP_ROW_SHR1 : DPP_WAVE_SHR1;
     // One extra leading column: hap index j = -1 is the oracle's boundary column 0, processed like any
@@ -431,6 +439,7 @@ __global__ __launch_bounds__(256) void sw_banded_kernel(
     const int grp = tid / GL;
     const int l = tid % GL;
     const uint32_t pair = blockIdx.x * GROUPS_PER_BLOCK + grp;
+    if (2u * (blockIdx.x * (uint32_t)GROUPS_PER_BLOCK) >= n_hard) return;      // (whole workgroup: uniform)
 
     // the two tasks of this record slot
     uint32_t task[2], m[2] = {0, 0}, n[2] = {0, 0}, roff[2] = {0, 0}, hoff[2] = {0, 0};
@@ -468,12 +477,11 @@ __global__ __launch_bounds__(256) void sw_banded_kernel(
         const int j = (int)idx - PRE;
         uint32_t ca = HAP_PAD, cb = HAP_PAD, la = 0x7fff, lb = 0x7fff, ha = 0, hb = 0;
         if (j >= -1) {
-            if (act[0] && j < (int)n[0]) { if (j >= 0) ca = hap_arena[hoff[0] + j]; la = bandA[j + 1]; ha = bandA[band_stride + j + 1]; }
-            if (act[1] && j < (int)n[1]) { if (j >= 0) cb = hap_arena[hoff[1] + j]; lb = bandB[j + 1]; hb = bandB[band_stride + j + 1]; }
+            if (act[0] && j < (int)n[0]) { if (j >= 0) ca = hap_arena[hoff[0] + j]; if (!FULL) { la = bandA[j + 1]; ha = bandA[band_stride + j + 1]; } }
+            if (act[1] && j < (int)n[1]) { if (j >= 0) cb = hap_arena[hoff[1] + j]; if (!FULL) { lb = bandB[j + 1]; hb = bandB[band_stride + j + 1]; } }
         }
         cols[idx] = ca | (cb << 16);
-        los[idx] = la | (lb << 16);
-        his[idx] = ha | (hb << 16);
+        if (!FULL) { los[idx] = la | (lb << 16); his[idx] = ha | (hb << 16); }
     }
     uint32_t c[R];
 #pragma unroll
@@ -501,15 +509,15 @@ __global__ __launch_bounds__(256) void sw_banded_kernel(
 
 #define SWB_STEP(GS, QS, ES, GD, QD, ED, gprev, gcur, gsrc, t)                                     \
     {                                                                                              \
-        const uint32_t hp = colp[t], lo2 = lop[t], hi2 = hip[t];                                   \
-        gcur = bfi(ROW0_MASK(lo2, hi2), one, NEG_G);          /* lane 0: boundary row of this column */ \
+        const uint32_t hp = colp[t], lo2 = FULL ? 0u : lop[t], hi2 = FULL ? PK(0x7fff) : hip[t];   \
+        gcur = FULL ? one : bfi(ROW0_MASK(lo2, hi2), one, NEG_G);   /* lane 0: boundary row of this column */ \
         gcur = lane_shr1<DPP>(gcur, gsrc);                                                         \
         qu = lane_shr1<DPP>(qu, q_bottom);                                                         \
         fu = lane_shr1<DPP>(fu, f_last);                                                           \
         const uint32_t am = pk_sub(lo2, rowbase), bm = pk_sub(hi2, rowbase);                       \
         uint32_t gd = gprev, qa = qu, fa = fu;                                                     \
         _Pragma("unroll") for (int r = 0; r < R; ++r) {                                            \
-            const uint32_t mk = pk_sign(pk_sub(am, PK(r + 1))) & pk_sign(pk_sub(PK(r), bm));       \
+            const uint32_t mk = FULL ? 0xffffffffu : (pk_sign(pk_sub(am, PK(r + 1))) & pk_sign(pk_sub(PK(r), bm))); \
             const uint32_t ne = pk_min_u(c[r] ^ hp, one);                                          \
             const uint32_t tt = pk_mad(ne, neg6, gd) & mk;                                         \
             gd = GS[r];                                                                            \
@@ -541,9 +549,49 @@ __global__ __launch_bounds__(256) void sw_banded_kernel(
         for (int k = 0; k < 2; ++k) {
             if (!act[k]) continue;
             const int32_t sc = (int32_t)(int16_t)((best >> (16 * k)) & 0xffffu);
-            if (task[k] & 1) alt_score[task[k] >> 1] = sc; else ref_score[task[k] >> 1] = sc;
+            int32_t* dst = ((task[k] & 1) ? alt_score : ref_score) + (task[k] >> 1);
+            if (FULL) { if (*dst != sc) recheck_list[atomicAdd(recheck_count, 1u)] = task[k]; else if (stage) stage[task[k]] = 3; }
+            else *dst = sc;
         }
     }
+}
+
+static hipError_t launch_sw_pairs(bool full, int R, int GL, uint32_t n_hard, const uint32_t* hard, const uint32_t* n_dev,
+                                  const vtx_record* records, const uint32_t* rec_locus, const vtx_locus* loci,
+                                  const uint8_t* read_arena, const uint8_t* hap_arena, const uint16_t* band,
+                                  uint32_t band_stride, int32_t* ref_score, int32_t* alt_score, uint32_t max_hap_len,
+                                  uint32_t* recheck_list, uint32_t* recheck_count, uint8_t* stage, hipStream_t stream) {
+    if (n_hard == 0) return hipSuccess;
+    const uint32_t pairs = (n_hard + 1) / 2;
+    const uint32_t lcols = ((GL + max_hap_len + GL + 8) + 3u) & ~3u;
+    const uint32_t arrays = full ? 1u : 3u;
+    // 256 threads per workgroup unless the three LDS arrays per record slot do not fit (haplotypes above ~800 bases: round 3
+    // found the launch failing there — no test had a hard task on a wide window): then 128 or 64
+    uint32_t threads = 256;
+    while (threads > 64 && (size_t)(threads / GL) * 3 * lcols * sizeof(uint32_t) > 150 * 1024) threads >>= 1;
+    if (threads < (uint32_t)GL) threads = (uint32_t)GL;
+    const uint32_t groups = threads / GL;
+    const size_t shmem = (size_t)groups * 3 * lcols * sizeof(uint32_t);      // (the FULL variant keeps the layout, it only skips two of the arrays)
+    (void)arrays;
+    if (shmem > 160 * 1024 - 512) return hipErrorInvalidValue;
+    const dim3 grid((pairs + groups - 1) / groups), block(threads);
+#define CASE_F(r, gl, f)                                                                                  \
+    {                                                                                                     \
+        if (shmem > 48 * 1024) {                                                                          \
+            hipError_t e = hipFuncSetAttribute((const void*)sw_banded_kernel<r, gl, f>,                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);   \
+            if (e != hipSuccess) return e;                                                                \
+        }                                                                                                 \
+        hipLaunchKernelGGL((sw_banded_kernel<r, gl, f>), grid, block, shmem, stream, hard, n_hard, n_dev, records, \
+                           rec_locus, loci, read_arena, hap_arena, band, band_stride, ref_score, alt_score, lcols, \
+                           recheck_list, recheck_count, stage);                                           \
+        return hipGetLastError();                                                                         \
+    }
+#define CASE(r, gl) if (R == r && GL == gl) { if (full) CASE_F(r, gl, true) else CASE_F(r, gl, false) }
+    CASE(2, 16) CASE(4, 16) CASE(6, 16) CASE(8, 16) CASE(10, 16) CASE(12, 16) CASE(16, 16) CASE(8, 64) CASE(16, 64)
+#undef CASE
+#undef CASE_F
+    return hipErrorInvalidValue;
 }
 
 extern "C" hipError_t vtxk_launch_sw_banded(int R, int GL, uint32_t n_hard, const uint32_t* hard,
@@ -551,32 +599,58 @@ extern "C" hipError_t vtxk_launch_sw_banded(int R, int GL, uint32_t n_hard, cons
                                             const uint8_t* read_arena, const uint8_t* hap_arena, const uint16_t* band,
                                             uint32_t band_stride, int32_t* ref_score, int32_t* alt_score,
                                             uint32_t max_hap_len, hipStream_t stream) {
-    if (n_hard == 0) return hipSuccess;
-    const uint32_t pairs = (n_hard + 1) / 2;
-    const uint32_t lcols = ((GL + max_hap_len + GL + 8) + 3u) & ~3u;
-    // 256 threads per workgroup unless the three LDS arrays per record slot do not fit (haplotypes above ~800 bases: round 3
-    // found the launch failing there — no test had a hard task on a wide window): then 128 or 64
-    uint32_t threads = 256;
-    while (threads > 64 && (size_t)(threads / GL) * 3 * lcols * sizeof(uint32_t) > 150 * 1024) threads >>= 1;
-    if (threads < (uint32_t)GL) threads = (uint32_t)GL;
-    const uint32_t groups = threads / GL;
-    const size_t shmem = (size_t)groups * 3 * lcols * sizeof(uint32_t);
-    if (shmem > 160 * 1024 - 512) return hipErrorInvalidValue;
-    const dim3 grid((pairs + groups - 1) / groups), block(threads);
-#define CASE(r, gl)                                                                                       \
-    if (R == r && GL == gl) {                                                                             \
-        if (shmem > 48 * 1024) {                                                                          \
-            hipError_t e = hipFuncSetAttribute((const void*)sw_banded_kernel<r, gl>,                      \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);   \
-            if (e != hipSuccess) return e;                                                                \
-        }                                                                                                 \
-        hipLaunchKernelGGL((sw_banded_kernel<r, gl>), grid, block, shmem, stream, hard, n_hard, records,  \
-                           rec_locus, loci, read_arena, hap_arena, band, band_stride, ref_score, alt_score, lcols); \
-        return hipGetLastError();                                                                         \
-    }
-    CASE(2, 16) CASE(4, 16) CASE(6, 16) CASE(8, 16) CASE(10, 16) CASE(12, 16) CASE(16, 16) CASE(8, 64) CASE(16, 64)
-#undef CASE
-    return hipErrorInvalidValue;
+    return launch_sw_pairs(false, R, GL, n_hard, hard, nullptr, records, rec_locus, loci, read_arena, hap_arena, band, band_stride,
+                           ref_score, alt_score, max_hap_len, nullptr, nullptr, nullptr, stream);
+}
+// the masked DP over a list whose length lives on the device (n_dev; n_cap bounds the grid)
+extern "C" hipError_t vtxk_launch_sw_banded_dev(int R, int GL, uint32_t n_cap, const uint32_t* hard, const uint32_t* n_dev,
+                                                const vtx_record* records, const uint32_t* rec_locus, const vtx_locus* loci,
+                                                const uint8_t* read_arena, const uint8_t* hap_arena, const uint16_t* band,
+                                                uint32_t band_stride, int32_t* ref_score, int32_t* alt_score,
+                                                uint32_t max_hap_len, hipStream_t stream) {
+    return launch_sw_pairs(false, R, GL, n_cap, hard, n_dev, records, rec_locus, loci, read_arena, hap_arena, band, band_stride,
+                           ref_score, alt_score, max_hap_len, nullptr, nullptr, nullptr, stream);
+}
+// full-matrix CHECK of provisional scores (see the kernel): tasks whose full score differs go to recheck_list
+extern "C" hipError_t vtxk_launch_sw_check(int R, int GL, uint32_t n_cap, const uint32_t* list, const uint32_t* n_dev,
+                                           const vtx_record* records, const uint32_t* rec_locus, const vtx_locus* loci,
+                                           const uint8_t* read_arena, const uint8_t* hap_arena, int32_t* ref_score,
+                                           int32_t* alt_score, uint32_t max_hap_len, uint32_t* recheck_list,
+                                           uint32_t* recheck_count, uint8_t* stage, hipStream_t stream) {
+    return launch_sw_pairs(true, R, GL, n_cap, list, n_dev, records, rec_locus, loci, read_arena, hap_arena, nullptr, 0,
+                           ref_score, alt_score, max_hap_len, recheck_list, recheck_count, stage, stream);
+}
+
+__global__ void fill_i32_kernel(int32_t* __restrict__ p, uint32_t n, int32_t v) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+extern "C" hipError_t vtxk_fill_i32(int32_t* p, uint32_t n, int32_t v, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(fill_i32_kernel, grid1d(n, 256), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}
+// both tasks of every listed RECORD
+__global__ void mark_stage_records_kernel(const uint32_t* __restrict__ recs, uint32_t n, uint8_t code, uint8_t* __restrict__ stage) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { stage[2 * (size_t)recs[i]] = code; stage[2 * (size_t)recs[i] + 1] = code; }
+}
+extern "C" hipError_t vtxk_mark_stage_records(const uint32_t* recs, uint32_t n, uint8_t code, uint8_t* stage, hipStream_t s) {
+    if (!n || !stage) return hipSuccess;
+    hipLaunchKernelGGL(mark_stage_records_kernel, grid1d(n, 256), dim3(256), 0, s, recs, n, code, stage);
+    return hipGetLastError();
+}
+// stage[list[i]] = code for the first min(n, *n_dev) entries (vtx_fetch_stage: which stage decided a task's score)
+__global__ void mark_stage_kernel(const uint32_t* __restrict__ list, uint32_t n, const uint32_t* __restrict__ n_dev, uint8_t code,
+                                  uint8_t* __restrict__ stage) {
+    if (n_dev) { const uint32_t nd = *n_dev; n = nd < n ? nd : n; }
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) stage[list[i]] = code;
+}
+extern "C" hipError_t vtxk_mark_stage(const uint32_t* list, uint32_t n, const uint32_t* n_dev, uint8_t code, uint8_t* stage, hipStream_t s) {
+    if (!n || !stage) return hipSuccess;
+    hipLaunchKernelGGL(mark_stage_kernel, grid1d(n, 256), dim3(256), 0, s, list, n, n_dev, code, stage);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------

@@ -23,6 +23,7 @@ SYMBOLS = (
     "vtx_fetch_coo", "vtx_device_scores", "vtx_device_coo", "vtx_last_timing", "vtx_last_cells", "vtx_strerror",
     "vtx_status_name", "vtx_abi_sizes", "vtx_set_barcodes", "vtx_submit_raw", "vtx_fetch_records",
     "vtx_comm_id", "vtx_comm_init", "vtx_gather_coo", "vtx_fetch_gathered", "vtx_gather_abort", "vtx_gather_plan",
+    "vtx_set_debug", "vtx_fetch_stage", "vtx_debug_bands",
 )
 
 
@@ -91,6 +92,12 @@ def load():
     L.vtx_gather_abort.argtypes = [ctxp]
     L.vtx_gather_plan.restype = C.c_int
     L.vtx_gather_plan.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.vtx_set_debug.restype = C.c_int
+    L.vtx_set_debug.argtypes = [ctxp, C.c_int, C.c_int64]
+    L.vtx_fetch_stage.restype = C.c_int
+    L.vtx_fetch_stage.argtypes = [ctxp, C.c_void_p]
+    L.vtx_debug_bands.restype = C.c_int
+    L.vtx_debug_bands.argtypes = [ctxp, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -250,6 +257,31 @@ class Context:
                       ("unk", np.uint32), ("value", np.float64), ("ref_value", np.float64)):
             out[k] = np.ctypeslib.as_array(getattr(coo, k), shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
         return out
+
+    # ---- audit / test hooks (include/vtx.h: vtx_set_debug) ----
+    def set_stage_trace(self, on: bool = True):
+        self._check(self._L.vtx_set_debug(self._h, abi.DEBUG_STAGE_TRACE, int(bool(on))))
+
+    def set_poison(self, value=None):
+        """Every later run first fills the score arrays with ``value`` (None: off)."""
+        if value is not None:
+            self._check(self._L.vtx_set_debug(self._h, abi.DEBUG_POISON_VALUE, int(value)))
+        self._check(self._L.vtx_set_debug(self._h, abi.DEBUG_POISON_SCORES, 0 if value is None else 1))
+
+    def fetch_stage(self) -> np.ndarray:
+        """One byte per task (2 * record + haplotype): the stage that decided its score (abi.STAGE_*)."""
+        st = np.zeros(2 * self.n_records, np.uint8)
+        self._check(self._L.vtx_fetch_stage(self._h, st.ctypes.data))
+        return st
+
+    def debug_bands(self, tasks, stride: int):
+        """(lo, hi, status) of band_sweep_kernel for the given tasks of the resident batch (vtx_debug_bands)."""
+        t = np.ascontiguousarray(tasks, np.uint32)
+        lo = np.zeros((len(t), stride), np.uint16)
+        hi = np.zeros((len(t), stride), np.uint16)
+        status = np.zeros(len(t), np.uint8)
+        self._check(self._L.vtx_debug_bands(self._h, t.ctypes.data, len(t), stride, lo.ctypes.data, hi.ctypes.data, status.ctypes.data))
+        return lo, hi, status
 
     def timing(self) -> abi.VtxTiming:
         t = abi.VtxTiming()
