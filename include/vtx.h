@@ -164,10 +164,12 @@ typedef struct vtx_timing {
     uint32_t overflow_tasks; /* banded flavour: alignments handed to the general band kernel        */
     float diag_ms;         /* band_tables_kernel + band_diag_kernel (single-diagonal stage; part of band_run_ms)   */
     uint32_t diag_left;    /* alignments the certificate stages left: band_sweep_kernel + masked DP take them       */
-    float check_ms;        /* full-matrix check of the tasks that left with a certificate (part of band_ms)          */
+    float check_ms;        /* band-masked DP (and, with VTX_BAND_CHECK, the full-matrix check) of the tasks that left with a certificate */
     float sweep_ms;        /* band_sweep_kernel + band-masked DP over what is left (part of band_ms)                 */
-    uint32_t checked_tasks; /* alignments that went through the full-matrix check (full == certificate decides them) */
+    uint32_t checked_tasks; /* alignments that left the certificate stages WITH a certificate: one-diagonal band + masked DP */
     uint32_t swept_tasks;  /* alignments handed to band_sweep_kernel                                                 */
+    uint32_t resweep_tasks; /* ... of which its first pass declined (more than 128 sections): second pass, 1024 sections; what
+                              that declines too (overflow_tasks) takes the general band kernel                               */
 } vtx_timing;
 
 typedef struct vtx_ctx vtx_ctx;
@@ -306,10 +308,11 @@ int vtx_last_timing(vtx_ctx* ctx, vtx_timing* out);
 #define VTX_STAGE_UNKNOWN 0        /* VTX_BAND_LEGACY path: band_run_kernel's / band_pending_kernel's certificate */
 #define VTX_STAGE_DIAG_CERT 1      /* band_diag_kernel: cert == ub */
 #define VTX_STAGE_REFINE_CERT 2    /* band_refine_kernel: cert == refined ub */
-#define VTX_STAGE_FULL_CHECK 3     /* full-matrix score == certificate (cert <= banded <= full) */
+#define VTX_STAGE_FULL_CHECK 3     /* full-matrix score == certificate (cert <= banded <= full); experiment hook VTX_BAND_CHECK only */
 #define VTX_STAGE_SWEEP_DP 4       /* band_sweep_kernel's band + band-masked DP */
 #define VTX_STAGE_GENERAL_DP 5     /* general band kernel (tasks the sweep declined) + band-masked DP */
 #define VTX_STAGE_RUN_DP 6         /* VTX_BAND_LEGACY path: band_run_kernel's staircase + band-masked DP */
+#define VTX_STAGE_DIAG_DP 7        /* the certificate stages' one-diagonal band (every off-diagonal match harmless) + band-masked DP */
 #define VTX_STAGE_SLOW 8           /* slow_align_kernel (records beyond the fast kernels' limits): exact DP */
 #define VTX_STAGE_FULL_DP 9        /* full flavour: the full-matrix DP */
 #define VTX_DEBUG_STAGE_TRACE 1

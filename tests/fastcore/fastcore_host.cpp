@@ -111,6 +111,7 @@ int vtxt_probe_of_diagonal(const uint8_t* x, int m, const uint8_t* y, int n, int
     }
     return total;
 }
+static uint32_t g_last_pack = 0;
 // The harmless verdict for a single read and haplotype: 1 = every off-diagonal match is harmless (then the reference's chain lies on
 // the main diagonal *d_out), 0 = not, -1 = the logic declined before that (no diagonal, capacities)
 int vtxt_harmless(const uint8_t* x, int m, const uint8_t* y, int n, int* d_out, int* cert_out) {
@@ -132,8 +133,11 @@ int vtxt_harmless(const uint8_t* x, int m, const uint8_t* y, int n, int* d_out, 
     back_sort(ns, ln);
     *d_out = fr.d;
     *cert_out = fr.cert;
+    g_last_pack = band_pack(fr);
     return back_harmless(fr, ns, ln) ? 1 : 0;
 }
+// vtxf::band_pack of the last vtxt_harmless call: (d + 256) << 16 | ca << 8 | cb — the one-diagonal band sw_banded_kernel<.., 2> expands
+uint32_t vtxt_last_band_pack(void) { return g_last_pack; }
 // Per task t = 2 * record + hap of a packed batch: score[t] (-1: left to band_run_kernel) and why[t].
 // n_heads bit 31: use the four-byte match entries (20 per task) even when every haplotype has <= 255 bases — the variant the
 // device takes for longer haplotypes.

@@ -213,6 +213,7 @@ def test_harmless_verdict_means_the_chain_stays_on_the_diagonal(core):
     'not harmless' (or the logic must have declined earlier).  With a harmless verdict the closed-form certificate equals the
     oracle's walk of the chain's staircase."""
     core.vtxt_harmless.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    core.vtxt_last_band_pack.restype = C.c_uint32
     oracle.lib().vtxo_chain_cert.restype = C.c_int32
     rng = np.random.default_rng(2718)
     said_yes = off_chain_seen = 0
@@ -254,6 +255,19 @@ def test_harmless_verdict_means_the_chain_stays_on_the_diagonal(core):
             assert not off, (trial, d.value, [(int(mt[p, 0]), int(mt[p, 1])) for p in off][:4])
             # ... and then the certificate is the oracle's walk of that chain's staircase (oracle/vtx_certify.c: vtxo_chain_cert)
             assert cert.value == oracle.lib().vtxo_chain_cert(x, len(x), y, len(y), 6), trial
+            # ... and the band the masked DP expands from vtxf::band_pack (sw_banded_kernel<.., 2>: one diagonal stretch widened by
+            # the (2w + 1)-squares) is the oracle's Band::create, column by column
+            pk = core.vtxt_last_band_pack()
+            dd, ca, cb = (pk >> 16) - 256, (pk >> 8) & 0xff, pk & 0xff
+            assert dd == d.value
+            olo, ohi, _ = oracle.band_create(x, y)
+            for j in range(len(y) + 1):
+                if ca - 20 <= j <= cb + 20:
+                    lo_j = max(0, max(j - 20, ca) - dd - 20)
+                    hi_j = min(len(x) + 1, min(j + 20, cb) - dd + 21)
+                    assert (lo_j, hi_j) == (int(olo[j]), int(ohi[j])), (trial, j)
+                else:
+                    assert ohi[j] <= olo[j], (trial, j)
         elif off:
             off_chain_seen += 1
     assert said_yes > 700 and off_chain_seen > 300, (said_yes, off_chain_seen)

@@ -36,16 +36,21 @@ def model_lib():
     return L
 
 
-def bands_vs_oracle(batch, nb, label, max_tasks=6000):
+def bands_vs_oracle(batch, nb, label, max_tasks=6000, tier=0):
     """Every task of the batch through vtx_debug_bands; the band of every accepted task equals the oracle's, and a task is declined
     exactly when the CPU model of the kernel (same capacities) declines it."""
     M = model_lib()
     n_tasks = min(2 * batch.n_records, max_tasks)
     tasks = np.arange(n_tasks, dtype=np.uint32)
     stride = int(max(batch.loci["ref_len"].max(), batch.loci["alt_len"].max())) + 1
-    with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb)) as ctx:
-        ctx.submit(batch)
-        lo, hi, status = ctx.debug_bands(tasks, stride)
+    os.environ["VTX_SWEEP_TIER"] = str(tier)                       # (read at every vtx_debug_bands call)
+    try:
+        with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb)) as ctx:
+            ctx.submit(batch)
+            lo, hi, status = ctx.debug_bands(tasks, stride)
+    finally:
+        os.environ.pop("VTX_SWEEP_TIER", None)
+    log_cap = 1024 if tier else 128
     rec_locus = np.repeat(np.arange(batch.n_loci), batch.loci["rec_count"])
     hb, rb = batch.hap_arena.tobytes(), batch.read_arena.tobytes()
     declined = 0
@@ -57,7 +62,7 @@ def bands_vs_oracle(batch, nb, label, max_tasks=6000):
         y = hb[off:off + ln]
         mlo = np.zeros(len(y) + 1, np.int32)
         mhi = np.zeros(len(y) + 1, np.int32)
-        rc = M.vtxs_band(x, len(x), y, len(y), 128, 12, mlo.ctypes.data, mhi.ctypes.data, None) if len(x) and len(y) else 0
+        rc = M.vtxs_band(x, len(x), y, len(y), log_cap, 28, mlo.ctypes.data, mhi.ctypes.data, None) if len(x) and len(y) else 0
         assert (status[t] != 0) == (rc != 0), "%s: task %d device status %d, model %d" % (label, t, status[t], rc)
         if status[t]:
             declined += 1
@@ -95,6 +100,17 @@ def test_bands_of_repeats_real_sequence_and_read_shapes():
             dec += d
     print("band parity: %d tasks, %d declined (capacities, bytes outside ACGTN)" % (tot, dec))
     assert tot > 8000 and 0 < dec < 0.25 * tot
+
+
+def test_bands_of_the_second_pass():
+    """The 1024-section variant of the kernel (what the first pass declines with a full log) on tandem repeats: far fewer declined."""
+    tot = dec = 0
+    for label, batch, nb in SB.repeat_rich_batches(trials=4, loci=20, reads=12, pad_range=(30, 120)):
+        n, d = bands_vs_oracle(batch, nb, label, 800, tier=1)
+        tot += n
+        dec += d
+    print("second pass: %d tasks, %d declined" % (tot, dec))
+    assert tot > 1500 and dec < 0.05 * tot
 
 
 def run_both(batch, nb, trace=True, poison=None, runs=1):
@@ -178,11 +194,12 @@ np.save(sys.argv[1], np.concatenate(out))
 ''' % (ROOT, HERE)
 
 
-@pytest.mark.parametrize("hook", ["VTX_BAND_LEGACY", "VTX_BAND_NO_CHECK", "VTX_BAND_SLOTS"])
+@pytest.mark.parametrize("hook", ["VTX_BAND_LEGACY", "VTX_BAND_CHECK", "VTX_BAND_NO_TIGHT", "VTX_BAND_SLOTS"])
 def test_hooks_give_the_same_scores(hook):
-    """VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending / general kernels instead of the check + sweep; VTX_BAND_NO_CHECK=1:
-    every task the certificate stages leave goes to the sweep; VTX_BAND_SLOTS=5: the sweep + masked DP in slices of five band slots.
-    Identical scores (separate processes: the hooks are read once)."""
+    """VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending / general kernels instead of the sweep; VTX_BAND_CHECK=1: the full-matrix
+    check in front of the DP of the tasks that left with a certificate; VTX_BAND_NO_TIGHT=1: those tasks go to the sweep like the
+    others (the sweep's band and the certificate's one-diagonal band must give the same scores); VTX_BAND_SLOTS=5: the sweep + masked
+    DP in slices of five band slots.  Identical scores (separate processes: the hooks are read once)."""
     res = []
     with tempfile.TemporaryDirectory() as td:
         for on in (0, 1):

@@ -106,7 +106,7 @@ struct vtx_ctx {
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
     bool band_long_lists = false;      // (performance feedback between runs: see vtx_run)
     DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail, d_fail_tmp, d_refine;   // banded flavour
-    DevBuf d_tight, d_stage;                                                 // round 4: tasks with a provisional score (full-matrix check); stage bytes (vtx_fetch_stage)
+    DevBuf d_tight, d_tight_pack, d_dband, d_dband_pack, d_stage;                                                 // round 4: tasks with a provisional score (full-matrix check); stage bytes (vtx_fetch_stage)
     bool stage_trace = false, poison = false;                                // test / audit hooks (vtx_set_debug)
     int32_t poison_value = 0;
     DevBuf d_redo, d_redo_cnt;                                               // LUT kernel: records with non-ACGTN bytes
@@ -557,7 +557,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_cnt, &c->d_redo, &c->d_redo_cnt, &c->d_bc_slots, &c->d_bc_hash, &c->d_bc_off, &c->d_bc_bytes,
                       &c->d_raw, &c->d_tags, &c->d_raw_locus, &c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2,
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
-                      &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp, &c->d_refine, &c->d_tight, &c->d_stage};
+                      &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp, &c->d_refine, &c->d_tight, &c->d_tight_pack, &c->d_dband, &c->d_dband_pack, &c->d_stage};
     for (DevBuf* b : bufs) b->release();
     c->d_slow_ws.release(); c->d_slow_retry.release();
     DevBuf* gb[] = {&c->d_g_cnt, &c->d_g_row, &c->d_g_col, &c->d_g_alt, &c->d_g_ref, &c->d_g_unk, &c->d_g_val, &c->d_g_refval};
@@ -636,7 +636,8 @@ static int band_reserve(vtx_ctx* c, BandPlan& p, bool quiet) {
     RES(d_cnt, 64 * sizeof(uint32_t));
     if (p.gt_bytes) RES(d_fail, 2 * (size_t)p.chunk * sizeof(uint32_t));  // tasks band_diag_kernel leaves to band_run_kernel (as listed, then sorted)
     if (p.gt_bytes) RES(d_refine, (size_t)band_refine_cap(p.chunk) * vtxk_band_refine_words() * sizeof(uint32_t));   // records for band_refine_kernel
-    if (p.gt_bytes) RES(d_tight, (size_t)p.chunk * sizeof(uint32_t));     // tasks with a certificate but no verdict: the full-matrix check's list
+    if (p.gt_bytes) RES(d_tight, (size_t)p.chunk * sizeof(uint32_t));       // tasks with a certificate but no verdict ...
+    if (p.gt_bytes) RES(d_tight_pack, (size_t)p.chunk * sizeof(uint32_t));  // ... and their bands (one diagonal stretch each: one word)
 #undef RES
     return VTX_OK;
 }
@@ -1134,6 +1135,26 @@ int vtx_run(vtx_ctx* c) {
         uint32_t pending_total = 0, over_before = 0;
         uint64_t diag_total = 0, diag_left = 0, refined_total = 0, checked_total = 0, swept_total = 0;
         float diag_ms = 0, check_ms = 0, sweep_ms = 0;
+        // the band of every listed task (band_sweep_kernel, tier 0 / 1), one slice of band slots at a time, then the masked DP over
+        // the slice (its length — the tasks the sweep did not decline — is read on the device: counters[0]; declined: counters[1])
+        auto sweep_slices = [&](int tier, const uint32_t* list, uint32_t n, uint32_t* over_out, uint32_t* counters) -> int {
+            static const int sweep_stats = getenv("VTX_DEBUG") ? 1 : 0;
+            for (uint32_t off = 0; off < n; off += slots) {
+                const uint32_t cnt_s = std::min(slots, n - off);
+                HIP_TRY(c, hipMemsetAsync(counters, 0, sizeof(uint32_t), s));
+                HIP_TRY(c, vtxk_launch_band_sweep(tier, list + off, cnt_s, nullptr, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                  c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                                  c->d_band.as<uint16_t>(), band_stride, c->d_hard.as<uint32_t>(), over_out,
+                                                  counters, sweep_stats, stage, nullptr, s));
+                HIP_TRY(c, vtxk_launch_sw_banded_dev(kShapes[shape][0], kShapes[shape][1], cnt_s, c->d_hard.as<uint32_t>(), counters,
+                                                     c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
+                                                     c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_band.as<uint16_t>(), band_stride,
+                                                     c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len, s));
+                launches += 2;
+            }
+            return VTX_OK;
+        };
+        uint32_t resweep_total = 0;
         bool sweep_pending = false;                 // the events of a swept chunk have not been read yet
         auto collect_sweep_times = [&]() -> int {
             if (!sweep_pending) return VTX_OK;
@@ -1175,9 +1196,11 @@ int vtx_run(vtx_ctx* c) {
             // (the band of ANY task, vtx_sweep.hip) and the masked DP.  VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending /
             // general path instead (kept for A/B tests; also what takes over when a haplotype of the batch exceeds 255 bases).
             static const bool legacy = getenv("VTX_BAND_LEGACY") != nullptr;
-            static const bool no_check = getenv("VTX_BAND_NO_CHECK") != nullptr;          // experiment / test hook: no full-matrix check
+            static const bool no_tight = getenv("VTX_BAND_NO_TIGHT") != nullptr;          // test hook: tasks with a certificate go to the sweep like the others
+            static const bool use_check = getenv("VTX_BAND_CHECK") != nullptr;            // experiment hook: full-matrix check in front of their DP
             const bool sweep_path = !legacy && c->max_hap_len <= vtxk_band_sweep_max_len() && c->max_hap_len > 0;
-            uint32_t* tight_list = (sweep_path && !no_check) ? c->d_tight.as<uint32_t>() : nullptr;
+            uint32_t* tight_list = (sweep_path && !no_tight) ? c->d_tight.as<uint32_t>() : nullptr;
+            uint32_t* tight_pack = tight_list ? c->d_tight_pack.as<uint32_t>() : nullptr;
             if (gt_n && !no_diag) {
                 HIP_TRY(c, hipMemsetAsync(d_cnt + 12, 0, 4 * sizeof(uint32_t), s));   // [12] left, [14] refine records, [15] tasks with a provisional score
                 // tasks with main pieces only whose bounds do not meet leave a record for band_refine_kernel
@@ -1188,7 +1211,7 @@ int vtx_run(vtx_ctx* c) {
                                                            c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                                            c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
                                                            c->d_fail.as<uint32_t>(), refine_list, refine_cap, d_cnt, tasks_per_locus, gt_l0, gt_n,
-                                                           c->d_gtables.as<uint8_t>(), gt_bytes, diag_stats, tight_list, stage, s);
+                                                           c->d_gtables.as<uint8_t>(), gt_bytes, diag_stats, tight_list, tight_pack, stage, s);
                 if (e == hipSuccess && sweep_path) {
                     diag = true; swept = true;
                     HIP_TRY(c, hipEventRecord(c->ev[6], s));
@@ -1199,7 +1222,7 @@ int vtx_run(vtx_ctx* c) {
                         HIP_TRY(c, vtxk_launch_band_refine(refine_list, std::min(refine_cap, nt), c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                                            c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
                                                            c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
-                                                           tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, tight_list, stage, d_cnt + 14, s));
+                                                           tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, tight_list, tight_pack, stage, d_cnt + 14, s));
                     HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));   // [12] fail, [14] refine, [15] tight
                     HIP_TRY(c, hipStreamSynchronize(s));
                     const uint32_t n_refine = std::min(c->h_pin[10], refine_cap), n_tight = std::min(c->h_pin[11], nt);
@@ -1207,12 +1230,28 @@ int vtx_run(vtx_ctx* c) {
                     launches += 2;
                     HIP_TRY(c, hipEventRecord(c->ev[7], s));
                     if (n_tight) {
-                        HIP_TRY(c, vtxk_launch_sw_check(kShapes[shape][0], kShapes[shape][1], n_tight, tight_list, nullptr, c->d_records.as<vtx_record>(),
-                                                        c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
-                                                        c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len,
-                                                        c->d_fail.as<uint32_t>(), d_cnt + 12, stage, s));
-                        HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                        HIP_TRY(c, hipStreamSynchronize(s));
+                        // tasks with a certificate but no verdict: their band is one diagonal stretch (tight_pack): the masked DP
+                        // expands it itself.  (VTX_BAND_CHECK=1: the full-matrix check first — full == cert decides a task, cert <=
+                        // banded <= full; measured: 5.6 ns per task against 10 for the DP it saves on 20 - 30 % of noisy reads.)
+                        const uint32_t* dp_list = tight_list;
+                        const uint32_t* dp_pack = tight_pack;
+                        const uint32_t* dp_cnt = nullptr;
+                        if (use_check) {
+                            HIP_TRY(c, c->d_dband.reserve((size_t)chunk * sizeof(uint32_t)));
+                            HIP_TRY(c, c->d_dband_pack.reserve((size_t)chunk * sizeof(uint32_t)));
+                            HIP_TRY(c, hipMemsetAsync(d_cnt + 24, 0, sizeof(uint32_t), s));
+                            HIP_TRY(c, vtxk_launch_sw_check(kShapes[shape][0], kShapes[shape][1], n_tight, tight_list, tight_pack, nullptr,
+                                                            c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
+                                                            c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(),
+                                                            c->d_alt.as<int32_t>(), c->max_hap_len, c->d_dband.as<uint32_t>(),
+                                                            c->d_dband_pack.as<uint32_t>(), d_cnt + 24, stage, s));
+                            dp_list = c->d_dband.as<uint32_t>(); dp_pack = c->d_dband_pack.as<uint32_t>(); dp_cnt = d_cnt + 24;
+                            ++launches;
+                        }
+                        HIP_TRY(c, vtxk_launch_sw_diag_band(kShapes[shape][0], kShapes[shape][1], n_tight, dp_list, dp_pack, dp_cnt,
+                                                            c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
+                                                            c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(),
+                                                            c->d_alt.as<int32_t>(), c->max_hap_len, stage, s));
                         ++launches;
                     }
                     HIP_TRY(c, hipEventRecord(c->ev[5], s));
@@ -1226,21 +1265,7 @@ int vtx_run(vtx_ctx* c) {
                             fail_list = c->d_fail.as<uint32_t>() + nt;
                         } else (void)hipGetLastError();
                     }
-                    // the band of every task that is left, one slice of band slots at a time, then the masked DP over the slice
-                    // (its length — the tasks the sweep did not decline — is read on the device)
-                    for (uint32_t off = 0; off < n_fail; off += slots) {
-                        const uint32_t cnt_s = std::min(slots, n_fail - off);
-                        HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), s));
-                        HIP_TRY(c, vtxk_launch_band_sweep(fail_list + off, cnt_s, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                                          c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
-                                                          c->d_band.as<uint16_t>(), band_stride, c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(),
-                                                          d_cnt, diag_stats, stage, s));
-                        HIP_TRY(c, vtxk_launch_sw_banded_dev(kShapes[shape][0], kShapes[shape][1], cnt_s, c->d_hard.as<uint32_t>(), d_cnt,
-                                                             c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
-                                                             c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_band.as<uint16_t>(), band_stride,
-                                                             c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len, s));
-                        launches += 2;
-                    }
+                    if (int rc = sweep_slices(0, fail_list, n_fail, c->d_over.as<uint32_t>(), d_cnt)) return rc;
                     swept_total += n_fail;
                 } else if (e == hipSuccess) {
                     diag = true;
@@ -1254,7 +1279,7 @@ int vtx_run(vtx_ctx* c) {
                         HIP_TRY(c, vtxk_launch_band_refine(refine_list, n_refine, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                                            c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
                                                            c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
-                                                           tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, nullptr, stage, nullptr, s));
+                                                           tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, nullptr, nullptr, stage, nullptr, s));
                         HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                         HIP_TRY(c, hipStreamSynchronize(s));
                         n_fail = c->h_pin[8];
@@ -1283,8 +1308,19 @@ int vtx_run(vtx_ctx* c) {
                 if (base + chunk >= n_tasks) {                              // last chunk: what the sweep declined is complete
                     HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
                     HIP_TRY(c, hipStreamSynchronize(s));
+                    // what the first pass declined (log of 128 sections full: satellites) takes the second, 1024 sections; what that
+                    // declines too (bytes outside ACGTN, reads above 255 bases, still more sections) takes the general band kernel
+                    const uint32_t n1 = cnt[1];
+                    if (n1) {
+                        resweep_total = n1;
+                        if (int rc = sweep_slices(1, c->d_over.as<uint32_t>(), n1, c->d_over.as<uint32_t>() + n1, d_cnt + 2)) return rc;
+                        HIP_TRY(c, hipEventRecord(c->ev[8], s));
+                        HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
+                        HIP_TRY(c, hipStreamSynchronize(s));
+                    }
                     if (int rc = collect_sweep_times()) return rc;
-                    if (cnt[1]) { if (int rc = fallback_start(0, cnt[1])) return rc; }
+                    cnt[1] = n1 ? cnt[3] : 0;                                       // tasks for the general kernel: d_over[n1, n1 + cnt[3])
+                    if (cnt[1]) { if (int rc = fallback_start(n1, n1 + cnt[1])) return rc; }
                 }
                 continue;
             }
@@ -1370,7 +1406,9 @@ int vtx_run(vtx_ctx* c) {
         c->timing.check_ms = check_ms; c->timing.sweep_ms = sweep_ms;
         c->timing.checked_tasks = (uint32_t)std::min<uint64_t>(checked_total, 0xffffffffull);
         c->timing.swept_tasks = (uint32_t)std::min<uint64_t>(swept_total, 0xffffffffull);
+        c->timing.resweep_tasks = resweep_total;
         if (swept_total) hard_total += (uint32_t)std::min<uint64_t>(swept_total - std::min<uint64_t>(swept_total, fast_overflow), 0xffffffffull);
+        hard_total += (uint32_t)std::min<uint64_t>(checked_total, 0xffffffffull);      // (tasks with a certificate: masked DP over their diagonal band; with VTX_BAND_CHECK an upper bound)
         if (getenv("VTX_DEBUG") && diag_total) {
             uint32_t why[16];
             HIP_TRY(c, hipMemcpy(why, d_cnt + 32, sizeof why, hipMemcpyDeviceToHost));
@@ -1496,17 +1534,20 @@ int vtx_debug_bands(vtx_ctx* c, const uint32_t* tasks, uint32_t n_tasks, uint32_
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
     // scratch of its own (one task per launch slot; a debug call may be slow): tasks, hard list, overflow list, counters, bands
-    DevBuf d_t, d_h, d_o, d_c, d_b;
+    DevBuf d_t, d_h, d_o, d_c, d_b, d_d;
     const uint32_t bs = (stride + 7u) & ~7u;
-    auto done = [&](int rc) { d_t.release(); d_h.release(); d_o.release(); d_c.release(); d_b.release(); return rc; };
+    auto done = [&](int rc) { d_t.release(); d_h.release(); d_o.release(); d_c.release(); d_b.release(); d_d.release(); return rc; };
 #define DBG_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return done(fail(c, VTX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_))); } while (0)
     DBG_TRY(d_t.reserve((size_t)n_tasks * 4)); DBG_TRY(d_h.reserve((size_t)n_tasks * 4)); DBG_TRY(d_o.reserve((size_t)n_tasks * 4));
     DBG_TRY(d_c.reserve(64 * 4)); DBG_TRY(d_b.reserve((size_t)n_tasks * 2 * bs * sizeof(uint16_t)));
+    const bool dbg_on = getenv("VTX_SWEEP_DBG") != nullptr;        // developer aid: the kernel's per-task intermediate state on stderr
+    if (dbg_on) DBG_TRY(d_d.reserve((size_t)n_tasks * 64 * 4));
     DBG_TRY(hipMemcpyAsync(d_t.p, tasks, (size_t)n_tasks * 4, hipMemcpyHostToDevice, s));
     DBG_TRY(hipMemsetAsync(d_c.p, 0, 64 * 4, s));
-    DBG_TRY(vtxk_launch_band_sweep(d_t.as<uint32_t>(), n_tasks, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+    const int dbg_tier = getenv("VTX_SWEEP_TIER") ? atoi(getenv("VTX_SWEEP_TIER")) : 0;      // (tests: the 1024-section variant)
+    DBG_TRY(vtxk_launch_band_sweep(dbg_tier, d_t.as<uint32_t>(), n_tasks, nullptr, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                    c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), d_b.as<uint16_t>(), bs,
-                                   d_h.as<uint32_t>(), d_o.as<uint32_t>(), d_c.as<uint32_t>(), 0, nullptr, s));
+                                   d_h.as<uint32_t>(), d_o.as<uint32_t>(), d_c.as<uint32_t>(), 0, nullptr, dbg_on ? d_d.as<uint32_t>() : nullptr, s));
     uint32_t cnt[2] = {0, 0};
     DBG_TRY(hipMemcpyAsync(cnt, d_c.p, sizeof cnt, hipMemcpyDeviceToHost, s));
     DBG_TRY(hipStreamSynchronize(s));
@@ -1515,6 +1556,23 @@ int vtx_debug_bands(vtx_ctx* c, const uint32_t* tasks, uint32_t n_tasks, uint32_
     if (cnt[0]) {
         DBG_TRY(hipMemcpy(hard.data(), d_h.p, (size_t)cnt[0] * 4, hipMemcpyDeviceToHost));
         DBG_TRY(hipMemcpy(bands.data(), d_b.p, bands.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    }
+    if (dbg_on) {
+        std::vector<uint32_t> dd((size_t)n_tasks * 64);
+        DBG_TRY(hipMemcpy(dd.data(), d_d.p, dd.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n_tasks; ++i) {
+            const uint32_t* o = dd.data() + (size_t)i * 64;
+            fprintf(stderr, "[sweep dbg] task %u: best dp %u x %u y %u, log %u, sections %u, cA %d cB %d, decline %u, m %u n %u\n  sections:", tasks[i],
+                    o[0] >> 16, (o[0] >> 8) & 0xff, o[0] & 0xff, o[1], o[2], (int)o[3], (int)o[4], o[5], o[6], o[7]);
+            for (uint32_t k = 0; k < o[2] && k < 12; ++k) fprintf(stderr, " (%u,%u,%u)", o[8 + k] >> 16, (o[8 + k] >> 8) & 0xff, o[8 + k] & 0xff);
+            fprintf(stderr, "\n  log:");
+            for (uint32_t k = 0; k < o[1] && k < 24; ++k) fprintf(stderr, " (%u,%u<-%04x)", o[20 + k] >> 24, (o[20 + k] >> 16) & 0xff, o[20 + k] & 0xffff);
+            fprintf(stderr, "\n  rmin:");
+            for (int k = 0; k < 10; ++k) fprintf(stderr, " %d", (int)o[44 + k]);
+            fprintf(stderr, "  rmax:");
+            for (int k = 0; k < 10; ++k) fprintf(stderr, " %d", (int)o[54 + k]);
+            fprintf(stderr, "\n");
+        }
     }
 #undef DBG_TRY
     // slots come out in any order, and a task may be listed more than once: every occurrence of a task gets the band of one of its slots

@@ -1864,11 +1864,12 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
     const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ fail_list, uint32_t* __restrict__ refine_rec, uint32_t refine_cap, uint32_t* __restrict__ counters,
-    uint32_t stats, uint32_t* __restrict__ tight_list, uint8_t* __restrict__ stage) {
+    uint32_t stats, uint32_t* __restrict__ tight_list, uint32_t* __restrict__ tight_pack, uint8_t* __restrict__ stage) {
     // tight_list != nullptr (round 4): a task whose off-diagonal matches are all harmless but whose bounds do not meet (or whose
     // generic set overflows) HAS a certificate — the chain is the closed form's, cert <= banded — so it leaves with
-    // score = cert as a PROVISIONAL score on tight_list (counters[15]) for the full-matrix check (sw_banded_kernel<.., true>:
-    // full == cert decides it), not on fail_list.  stage != nullptr: stage[task] = 1 for every task decided here (vtx_fetch_stage).
+    // its band (the (2w + 1)-squares along ONE diagonal stretch: tight_pack[i] = vtxf::band_pack) on tight_list (counters[15]):
+    // the band-masked DP scores it from that word, without band_sweep_kernel; score = cert meanwhile, a PROVISIONAL score
+    // (the optional full-matrix check sw_banded_kernel<.., 1> decides it where full == cert).  Not on fail_list.  stage != nullptr: stage[task] = 1 for every task decided here (vtx_fetch_stage).
     // refine_rec != nullptr: a task with main pieces only whose bounds do not meet leaves a 12-word record for band_refine_kernel
     // (counters[14]; REFINE_WORDS) instead of going to band_run_kernel's list: that kernel prices the stretches of >= 3 errors
     // within a few bases from the real neighbour diagonals and needs nothing else of what this one found.
@@ -1962,7 +1963,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         bool have_d = !live;
         int d = 0;
 #pragma unroll 1
-        for (int round = 0; round < 3; ++round) {
+        for (int round = 0; round < vtxf::N_SAMPLES / 2; ++round) {
             if (!__any(!have_d)) break;
             const int c_own = have_d ? vtxf::NO_DIAG : vtxf::cand_diag(x, vtxf::sample_row(2 * round + (tid & 1), m), tb);
             const int c_par = __shfl_xor(c_own, 1);
@@ -2086,7 +2087,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         if (again && pos >= refine_cap) again = false;              // (the record buffer is full: band_run_kernel takes it)
         if (again) {
             uint32_t* rec = refine_rec + (size_t)pos * REFINE_WORDS;
-            rec[0] = task; rec[1] = (uint32_t)fr.d;
+            rec[0] = task; rec[1] = vtxf::band_pack(fr);               // (the diagonal is its upper half)
             rec[2] = (uint32_t)fr.r | ((uint32_t)fr.cert << 4) | (aux << 16);
             rec[3] = fr.zc;
             for (int i = 0; i < vtxf::RM; ++i) rec[4 + i] = i < fr.r ? ln.at(i) : 0u;
@@ -2100,7 +2101,9 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         if (tid == leader) base = atomicAdd(&counters[15], (uint32_t)__popcll(tm));
         base = (uint32_t)__shfl((int)base, leader);
         if (tight) {
-            tight_list[base + (uint32_t)__popcll(tm & ((1ull << tid) - 1ull))] = task;
+            const uint32_t pos = base + (uint32_t)__popcll(tm & ((1ull << tid) - 1ull));
+            tight_list[pos] = task;
+            tight_pack[pos] = vtxf::band_pack(fr);
             *my_score = fr.cert;                                      // provisional: a lower bound of the banded score
         }
     }
@@ -2131,7 +2134,7 @@ __global__ __launch_bounds__(256) void band_refine_kernel(
     const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
     const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ fail_list, uint32_t* __restrict__ counters, uint32_t stats, uint32_t* __restrict__ tight_list,
-    uint8_t* __restrict__ stage, const uint32_t* __restrict__ n_dev) {
+    uint32_t* __restrict__ tight_pack, uint8_t* __restrict__ stage, const uint32_t* __restrict__ n_dev) {
     // tight_list != nullptr (round 4): an undecided record still has its certificate: provisional score + tight_list (counters[15])
     // instead of fail_list (see band_diag_kernel).  n_dev: the record count lives on the device (min(*n_dev, n_recs)).
     __shared__ uint32_t piece_mem_[4][vtxf::RM * 64];
@@ -2139,12 +2142,13 @@ __global__ __launch_bounds__(256) void band_refine_kernel(
     const int wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
     const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
     bool fail = false;
-    uint32_t task = 0;
+    uint32_t task = 0, pack = 0;
     if (slot < n_recs) {
         const uint4* rp = (const uint4*)(recs + (size_t)slot * REFINE_WORDS);
         const uint4 h = rp[0], p0 = rp[1], p1 = rp[2];
         task = h.x;
-        const int d = (int)h.y, r = (int)(h.z & 15u), cert = (int)((h.z >> 4) & 0xfffu), far_e = (int)(h.z >> 16);
+        const int d = (int)(h.y >> 16) - 256, r = (int)(h.z & 15u), cert = (int)((h.z >> 4) & 0xfffu), far_e = (int)(h.z >> 16);
+        pack = h.y;
         const uint32_t rid = task >> 1, hap = task & 1;
         const vtx_record rec = records[rid];
         const uint32_t my_locus = rec_locus[rid];
@@ -2166,7 +2170,9 @@ __global__ __launch_bounds__(256) void band_refine_kernel(
         if (tid == leader) base = atomicAdd(&counters[tight_list ? 15 : 12], (uint32_t)__popcll(fm));
         base = (uint32_t)__shfl((int)base, leader);
         if (fail) {
-            (tight_list ? tight_list : fail_list)[base + (uint32_t)__popcll(fm & ((1ull << tid) - 1ull))] = task;
+            const uint32_t pos = base + (uint32_t)__popcll(fm & ((1ull << tid) - 1ull));
+            (tight_list ? tight_list : fail_list)[pos] = task;
+            if (tight_list) tight_pack[pos] = pack;
             if (stats & 0xffu) atomicAdd(&counters[32 + vtxf::W_NOT_TIGHT], 1u);
         }
     }
@@ -2311,7 +2317,8 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
                                             const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score, int32_t* alt_score,
                                             uint32_t* fail_list, uint32_t* refine_rec, uint32_t refine_cap, uint32_t* counters,
                                             uint32_t tasks_per_locus, uint32_t gt_l0, uint32_t n_loci, uint8_t* gtables,
-                                            size_t gtables_bytes, int stats, uint32_t* tight_list, uint8_t* stage, hipStream_t s) {
+                                            size_t gtables_bytes, int stats, uint32_t* tight_list, uint32_t* tight_pack, uint8_t* stage,
+                                            hipStream_t s) {
     if (!n_tasks) return hipSuccess;
     const uint32_t n_heads = pick_heads(tasks_per_locus, true);
     const size_t tstride = band_table_stride(max_hap, n_heads);
@@ -2325,11 +2332,11 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     if (max_hap <= 255 && !force_wide)
         hipLaunchKernelGGL((band_diag_kernel<4, uint16_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
                            rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, stage);
+                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, tight_pack, stage);
     else
         hipLaunchKernelGGL((band_diag_kernel<4, uint32_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
                            rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, stage);
+                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, tight_pack, stage);
     return hipGetLastError();
 }
 
@@ -2338,13 +2345,14 @@ extern "C" hipError_t vtxk_launch_band_refine(const uint32_t* recs, uint32_t n_r
                                               const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                               uint32_t max_hap, int32_t* ref_score, int32_t* alt_score, uint32_t* fail_list,
                                               uint32_t* counters, uint32_t tasks_per_locus, uint32_t gt_l0, const uint8_t* gtables,
-                                              int stats, uint32_t* tight_list, uint8_t* stage, const uint32_t* n_dev, hipStream_t s) {
+                                              int stats, uint32_t* tight_list, uint32_t* tight_pack, uint8_t* stage, const uint32_t* n_dev,
+                                              hipStream_t s) {
     if (!n_recs) return hipSuccess;
     const uint32_t n_heads = pick_heads(tasks_per_locus, true);
     const size_t tstride = band_table_stride(max_hap, n_heads);
     hipLaunchKernelGGL(band_refine_kernel, dim3((n_recs + 255) / 256), dim3(256), 0, s, recs, n_recs, records, rec_locus, loci, read_arena,
                        max_hap, (uint32_t)tstride, n_heads, gtables, gt_l0, ref_score, alt_score, fail_list, counters, (uint32_t)stats,
-                       tight_list, stage, n_dev);
+                       tight_list, tight_pack, stage, n_dev);
     return hipGetLastError();
 }
 

@@ -277,9 +277,17 @@ struct Front {
     uint32_t why;           // W_OK: go on with the probes
     int d, r;               // main diagonal, main pieces
     int best_dp, cert;
+    int ca, cb;             // the chain's staircase: the cells (c - d, c), c = ca .. cb (lazy extensions included) — with every off-diagonal
+                            // match harmless this IS the reference's staircase, so the band is its (2w + 1)-squares (band_pack)
     uint32_t zc;            // nibble i: mismatching bases between main pieces i - 1 and i (capped at 15; nibble 0 unused)
     M192 need;              // rows to probe
 };
+
+// The band of a task whose chain lies on ONE diagonal, as one word: (d + 256) << 16 | ca << 8 | cb (haplotypes up to 255 bases).
+// Column j of the DP matrix is in band for j in [ca - W, cb + W]: rows [max(0, max(j - W, ca) - d - W), min(m + 1, min(j + W, cb) - d + W + 1))
+// (vtx_band.hip's closed form with rmin[c] = rmax[c] = c - d).  sw_banded_kernel<.., 2> expands it.
+// (with haplotypes above 255 bases the word still carries d — band_refine_kernel reads it there — and ca / cb are not used)
+VTXF_FN uint32_t band_pack(const Front& fr) { return ((uint32_t)(fr.d + 256) << 16) | (((uint32_t)fr.ca & 0xffu) << 8) | ((uint32_t)fr.cb & 0xffu); }
 
 // The read as 8-byte words in registers (RW words cover MAX_READ bases): loaded once per task — by the device with 16-byte
 // loads split between the two haplotype lanes of a record (read_words_pair in vtx_band.hip), by the host plainly.
@@ -344,9 +352,13 @@ template <class F> VTXF_FN void walk_bucket(const Tab& tb, uint64_t w8, uint32_t
 constexpr int NO_DIAG = -100000;
 // row of the t-th sample (t = 0 .. 5) of the main-diagonal search: middle rows first — the ends of a read hang over the padded
 // window more often than its middle
+// (t = 6 .. 11, round 4: six more rows between the first six — a clean read whose six samples all fell into the overhang, onto an
+// error or onto a repeated k-mer was 60 % of what band_diag_kernel left on the headline workload)
+constexpr int N_SAMPLES = 12;
 VTXF_FN int sample_row(int t, int m) {
     const int last = m - K;
-    return imin((int)((0x504132u >> (4 * t)) & 0xfu) * imax(1, last / 5), last);
+    if (t < 6) return imin((int)((0x504132u >> (4 * t)) & 0xfu) * imax(1, last / 5), last);
+    return imin((int)((0x619375u >> (4 * (t - 6))) & 0xfu) * last / 10 + (t == 11 ? 3 : 0), last);      // tenths 5, 7, 3, 9, 1, and 6 (+ 3 rows)
 }
 // candidate diagonal from one row: its k-mer sits alone in its bucket and matches it (then the haplotype holds it exactly once)
 VTXF_FN int cand_diag(const uint8_t* x, int row, const Tab& tb) {
@@ -372,11 +384,11 @@ template <class LN> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab&
 // one lane on its own: the six sample rows in turn; a candidate is kept if its mask has at least 20 matching bases
 template <class LN> VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln) {
     Front fr;
-    fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.zc = 0; fr.need = M192{0, 0, 0};
+    fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.ca = fr.cb = 0; fr.zc = 0; fr.need = M192{0, 0, 0};
     if (m < K || n < K || m > MAX_READ) { fr.why = W_SHAPE; return fr; }
     int prev = NO_DIAG;
     const ReadWords rw = read_words(x, m);
-    for (int t = 0; t < 6; ++t) {
+    for (int t = 0; t < N_SAMPLES; ++t) {
         const int dc = cand_diag(x, sample_row(t, m), tb);
         if (dc == NO_DIAG || dc == prev) continue;
         prev = dc;
@@ -392,7 +404,7 @@ template <class LN> VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, 
 template <class LN> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, int d, M192 M) {
     (void)x;
     Front fr;
-    fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.zc = 0; fr.need = M192{0, 0, 0};
+    fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.ca = fr.cb = 0; fr.zc = 0; fr.need = M192{0, 0, 0};
     fr.d = d;
 
     // ---- main pieces (runs of >= K matching bases, found between the zeros of M) and sdpkpp on the diagonal ----
@@ -441,6 +453,7 @@ template <class LN> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab&
         int re = best_last + 1, ce = re + d;                           // cell after the last k-mer: (b + K, b + K + d)
         const int d1 = imin(imin(m - re, n - ce), LAZY);
         re += d1; ce += d1;
+        fr.ca = fy - d0; fr.cb = ce;                                   // first / last anchor column of the staircase
         const int t1 = imin(imin(m - re, n - ce), W);
         const int hi = re + t1;
         int s = 0, best = 0, prev = lo - 1;

@@ -413,20 +413,26 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
 
 #define NEG_G PK(-16000)
 
-// FULL (round 4): the same kernel WITHOUT a band — every cell is in band, the mask arithmetic folds away (12 packed ops per
-// cell pair instead of 19) — used as a CHECK, not as a score: the tasks of `hard` carry a provisional score (the certificate
-// of band_diag_kernel / band_refine_kernel, a lower bound of the banded score: cert <= banded <= full); where the full-matrix
-// score EQUALS it the provisional score is the banded score and stays; the other tasks are appended to recheck_list
-// (recheck_count) for band_sweep_kernel + the masked DP.  n_dev != nullptr: the list length lives on the device
-// (min(*n_dev, n_hard) entries; the grid is sized for n_hard).
-template <int R, int GL, bool FULL>
+// MODE (round 4).  0: the band is per-column row ranges in `band` (band_sweep_kernel / band_expand_kernel wrote them).
+// 2: the band is ONE diagonal stretch widened by the (2w + 1)-squares, one word per listed task (packs[s] = vtxf::band_pack:
+//    (d + 256) << 16 | ca << 8 | cb): what band_diag_kernel / band_refine_kernel leave when every off-diagonal match is harmless —
+//    the chain, hence the staircase, IS that stretch — but the bounds do not meet; the ranges are expanded here, in LDS.
+// 1: the same kernel WITHOUT a band — every cell is in band, the mask arithmetic folds away (12 packed ops per cell pair
+//    instead of 19) — used as a CHECK, not as a score (experiment hook VTX_BAND_CHECK=1): the listed tasks carry a provisional
+//    score (the certificate, a lower bound of the banded score: cert <= banded <= full); where the full-matrix score EQUALS it
+//    the provisional score is the banded score and stays; the other tasks (and their packs) are appended to recheck_list /
+//    recheck_pack (recheck_count) for the masked DP.
+// n_dev != nullptr: the list length lives on the device (min(*n_dev, n_hard) entries; the grid is sized for n_hard).
+template <int R, int GL, int MODE>
 __global__ __launch_bounds__(256) void sw_banded_kernel(
     const uint32_t* __restrict__ hard, uint32_t n_hard, const uint32_t* __restrict__ n_dev,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus,
     const vtx_locus* __restrict__ loci, const uint8_t* __restrict__ read_arena,
     const uint8_t* __restrict__ hap_arena, const uint16_t* __restrict__ band, uint32_t band_stride,
     int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score, uint32_t lcols,
-    uint32_t* __restrict__ recheck_list, uint32_t* __restrict__ recheck_count, uint8_t* __restrict__ stage) {
+    uint32_t* __restrict__ recheck_list, uint32_t* __restrict__ recheck_count, uint8_t* __restrict__ stage,
+    const uint32_t* __restrict__ packs, uint32_t* __restrict__ recheck_pack) {
+    constexpr bool FULL = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (n_dev) { const uint32_t nd = *n_dev; n_hard = nd < n_hard ? nd : n_hard; }
     const int GROUPS_PER_BLOCK = (int)blockDim.x / GL;     // 256 threads, or fewer when three LDS arrays per record slot of a wide haplotype do not fit
@@ -442,7 +448,7 @@ __global__ __launch_bounds__(256) void sw_banded_kernel(
     if (2u * (blockIdx.x * (uint32_t)GROUPS_PER_BLOCK) >= n_hard) return;      // (whole workgroup: uniform)
 
     // the two tasks of this record slot
-    uint32_t task[2], m[2] = {0, 0}, n[2] = {0, 0}, roff[2] = {0, 0}, hoff[2] = {0, 0};
+    uint32_t task[2], m[2] = {0, 0}, n[2] = {0, 0}, roff[2] = {0, 0}, hoff[2] = {0, 0}, pk[2] = {0, 0};
     bool act[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -451,6 +457,7 @@ __global__ __launch_bounds__(256) void sw_banded_kernel(
         task[k] = 0;
         if (act[k]) {
             task[k] = hard[s];
+            if (MODE != 0 && packs) pk[k] = packs[s];
             const uint32_t rid = task[k] >> 1;
             const vtx_record rec = records[rid];
             const vtx_locus loc = loci[rec_locus[rid]];
@@ -477,8 +484,25 @@ __global__ __launch_bounds__(256) void sw_banded_kernel(
         const int j = (int)idx - PRE;
         uint32_t ca = HAP_PAD, cb = HAP_PAD, la = 0x7fff, lb = 0x7fff, ha = 0, hb = 0;
         if (j >= -1) {
-            if (act[0] && j < (int)n[0]) { if (j >= 0) ca = hap_arena[hoff[0] + j]; if (!FULL) { la = bandA[j + 1]; ha = bandA[band_stride + j + 1]; } }
-            if (act[1] && j < (int)n[1]) { if (j >= 0) cb = hap_arena[hoff[1] + j]; if (!FULL) { lb = bandB[j + 1]; hb = bandB[band_stride + j + 1]; } }
+            if (act[0] && j < (int)n[0]) { if (j >= 0) ca = hap_arena[hoff[0] + j]; if (MODE == 0) { la = bandA[j + 1]; ha = bandA[band_stride + j + 1]; } }
+            if (act[1] && j < (int)n[1]) { if (j >= 0) cb = hap_arena[hoff[1] + j]; if (MODE == 0) { lb = bandB[j + 1]; hb = bandB[band_stride + j + 1]; } }
+            if (MODE == 2) {
+                // column jj = j + 1 of the DP matrix; anchors (c - d, c), c = cA .. cB; the (2w + 1)-squares (W = 20, src/main.rs:34)
+                const int jj = j + 1;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (!act[k] || j >= (int)n[k]) continue;
+                    const int d = (int)(pk[k] >> 16) - 256, cA = (int)((pk[k] >> 8) & 0xffu), cB = (int)(pk[k] & 0xffu);
+                    uint32_t lv = 0x7fffu, hv = 0;
+                    if (jj >= cA - 20 && jj <= cB + 20) {
+                        const int c0 = jj - 20 > cA ? jj - 20 : cA, c1 = jj + 20 < cB ? jj + 20 : cB;
+                        const int l_ = c0 - d - 20, h_ = c1 - d + 21;
+                        lv = (uint32_t)(l_ > 0 ? l_ : 0);
+                        hv = (uint32_t)(h_ < (int)m[k] + 1 ? h_ : (int)m[k] + 1);
+                    }
+                    if (k == 0) { la = lv; ha = hv; } else { lb = lv; hb = hv; }
+                }
+            }
         }
         cols[idx] = ca | (cb << 16);
         if (!FULL) { los[idx] = la | (lb << 16); his[idx] = ha | (hb << 16); }
@@ -550,29 +574,33 @@ __global__ __launch_bounds__(256) void sw_banded_kernel(
             if (!act[k]) continue;
             const int32_t sc = (int32_t)(int16_t)((best >> (16 * k)) & 0xffffu);
             int32_t* dst = ((task[k] & 1) ? alt_score : ref_score) + (task[k] >> 1);
-            if (FULL) { if (*dst != sc) recheck_list[atomicAdd(recheck_count, 1u)] = task[k]; else if (stage) stage[task[k]] = 3; }
-            else *dst = sc;
+            if (FULL) {
+                if (*dst != sc) { const uint32_t pos = atomicAdd(recheck_count, 1u); recheck_list[pos] = task[k]; if (recheck_pack) recheck_pack[pos] = pk[k]; }
+                else if (stage) stage[task[k]] = 3;
+            } else {
+                *dst = sc;
+                if (MODE == 2 && stage) stage[task[k]] = 7;
+            }
         }
     }
 }
 
-static hipError_t launch_sw_pairs(bool full, int R, int GL, uint32_t n_hard, const uint32_t* hard, const uint32_t* n_dev,
+static hipError_t launch_sw_pairs(int mode, int R, int GL, uint32_t n_hard, const uint32_t* hard, const uint32_t* n_dev,
                                   const vtx_record* records, const uint32_t* rec_locus, const vtx_locus* loci,
                                   const uint8_t* read_arena, const uint8_t* hap_arena, const uint16_t* band,
                                   uint32_t band_stride, int32_t* ref_score, int32_t* alt_score, uint32_t max_hap_len,
-                                  uint32_t* recheck_list, uint32_t* recheck_count, uint8_t* stage, hipStream_t stream) {
+                                  uint32_t* recheck_list, uint32_t* recheck_count, uint8_t* stage, const uint32_t* packs,
+                                  uint32_t* recheck_pack, hipStream_t stream) {
     if (n_hard == 0) return hipSuccess;
     const uint32_t pairs = (n_hard + 1) / 2;
     const uint32_t lcols = ((GL + max_hap_len + GL + 8) + 3u) & ~3u;
-    const uint32_t arrays = full ? 1u : 3u;
     // 256 threads per workgroup unless the three LDS arrays per record slot do not fit (haplotypes above ~800 bases: round 3
     // found the launch failing there — no test had a hard task on a wide window): then 128 or 64
     uint32_t threads = 256;
     while (threads > 64 && (size_t)(threads / GL) * 3 * lcols * sizeof(uint32_t) > 150 * 1024) threads >>= 1;
     if (threads < (uint32_t)GL) threads = (uint32_t)GL;
     const uint32_t groups = threads / GL;
-    const size_t shmem = (size_t)groups * 3 * lcols * sizeof(uint32_t);      // (the FULL variant keeps the layout, it only skips two of the arrays)
-    (void)arrays;
+    const size_t shmem = (size_t)groups * 3 * lcols * sizeof(uint32_t);      // (the check variant keeps the layout, it only skips two of the arrays)
     if (shmem > 160 * 1024 - 512) return hipErrorInvalidValue;
     const dim3 grid((pairs + groups - 1) / groups), block(threads);
 #define CASE_F(r, gl, f)                                                                                  \
@@ -584,10 +612,10 @@ static hipError_t launch_sw_pairs(bool full, int R, int GL, uint32_t n_hard, con
         }                                                                                                 \
         hipLaunchKernelGGL((sw_banded_kernel<r, gl, f>), grid, block, shmem, stream, hard, n_hard, n_dev, records, \
                            rec_locus, loci, read_arena, hap_arena, band, band_stride, ref_score, alt_score, lcols, \
-                           recheck_list, recheck_count, stage);                                           \
+                           recheck_list, recheck_count, stage, packs, recheck_pack);                      \
         return hipGetLastError();                                                                         \
     }
-#define CASE(r, gl) if (R == r && GL == gl) { if (full) CASE_F(r, gl, true) else CASE_F(r, gl, false) }
+#define CASE(r, gl) if (R == r && GL == gl) { if (mode == 1) CASE_F(r, gl, 1) else if (mode == 2) CASE_F(r, gl, 2) else CASE_F(r, gl, 0) }
     CASE(2, 16) CASE(4, 16) CASE(6, 16) CASE(8, 16) CASE(10, 16) CASE(12, 16) CASE(16, 16) CASE(8, 64) CASE(16, 64)
 #undef CASE
 #undef CASE_F
@@ -599,8 +627,8 @@ extern "C" hipError_t vtxk_launch_sw_banded(int R, int GL, uint32_t n_hard, cons
                                             const uint8_t* read_arena, const uint8_t* hap_arena, const uint16_t* band,
                                             uint32_t band_stride, int32_t* ref_score, int32_t* alt_score,
                                             uint32_t max_hap_len, hipStream_t stream) {
-    return launch_sw_pairs(false, R, GL, n_hard, hard, nullptr, records, rec_locus, loci, read_arena, hap_arena, band, band_stride,
-                           ref_score, alt_score, max_hap_len, nullptr, nullptr, nullptr, stream);
+    return launch_sw_pairs(0, R, GL, n_hard, hard, nullptr, records, rec_locus, loci, read_arena, hap_arena, band, band_stride,
+                           ref_score, alt_score, max_hap_len, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 // the masked DP over a list whose length lives on the device (n_dev; n_cap bounds the grid)
 extern "C" hipError_t vtxk_launch_sw_banded_dev(int R, int GL, uint32_t n_cap, const uint32_t* hard, const uint32_t* n_dev,
@@ -608,17 +636,26 @@ extern "C" hipError_t vtxk_launch_sw_banded_dev(int R, int GL, uint32_t n_cap, c
                                                 const uint8_t* read_arena, const uint8_t* hap_arena, const uint16_t* band,
                                                 uint32_t band_stride, int32_t* ref_score, int32_t* alt_score,
                                                 uint32_t max_hap_len, hipStream_t stream) {
-    return launch_sw_pairs(false, R, GL, n_cap, hard, n_dev, records, rec_locus, loci, read_arena, hap_arena, band, band_stride,
-                           ref_score, alt_score, max_hap_len, nullptr, nullptr, nullptr, stream);
+    return launch_sw_pairs(0, R, GL, n_cap, hard, n_dev, records, rec_locus, loci, read_arena, hap_arena, band, band_stride,
+                           ref_score, alt_score, max_hap_len, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
-// full-matrix CHECK of provisional scores (see the kernel): tasks whose full score differs go to recheck_list
-extern "C" hipError_t vtxk_launch_sw_check(int R, int GL, uint32_t n_cap, const uint32_t* list, const uint32_t* n_dev,
+// the masked DP over tasks whose band is one diagonal stretch (packs[i] = vtxf::band_pack of list[i]); stage: VTX_STAGE_DIAG_DP
+extern "C" hipError_t vtxk_launch_sw_diag_band(int R, int GL, uint32_t n_cap, const uint32_t* list, const uint32_t* packs,
+                                               const uint32_t* n_dev, const vtx_record* records, const uint32_t* rec_locus,
+                                               const vtx_locus* loci, const uint8_t* read_arena, const uint8_t* hap_arena,
+                                               int32_t* ref_score, int32_t* alt_score, uint32_t max_hap_len, uint8_t* stage,
+                                               hipStream_t stream) {
+    return launch_sw_pairs(2, R, GL, n_cap, list, n_dev, records, rec_locus, loci, read_arena, hap_arena, nullptr, 0,
+                           ref_score, alt_score, max_hap_len, nullptr, nullptr, stage, packs, nullptr, stream);
+}
+// full-matrix CHECK of provisional scores (see the kernel): tasks whose full score differs go to recheck_list / recheck_pack
+extern "C" hipError_t vtxk_launch_sw_check(int R, int GL, uint32_t n_cap, const uint32_t* list, const uint32_t* packs, const uint32_t* n_dev,
                                            const vtx_record* records, const uint32_t* rec_locus, const vtx_locus* loci,
                                            const uint8_t* read_arena, const uint8_t* hap_arena, int32_t* ref_score,
-                                           int32_t* alt_score, uint32_t max_hap_len, uint32_t* recheck_list,
+                                           int32_t* alt_score, uint32_t max_hap_len, uint32_t* recheck_list, uint32_t* recheck_pack,
                                            uint32_t* recheck_count, uint8_t* stage, hipStream_t stream) {
-    return launch_sw_pairs(true, R, GL, n_cap, list, n_dev, records, rec_locus, loci, read_arena, hap_arena, nullptr, 0,
-                           ref_score, alt_score, max_hap_len, recheck_list, recheck_count, stage, stream);
+    return launch_sw_pairs(1, R, GL, n_cap, list, n_dev, records, rec_locus, loci, read_arena, hap_arena, nullptr, 0,
+                           ref_score, alt_score, max_hap_len, recheck_list, recheck_count, stage, packs, recheck_pack, stream);
 }
 
 __global__ void fill_i32_kernel(int32_t* __restrict__ p, uint32_t n, int32_t v) {

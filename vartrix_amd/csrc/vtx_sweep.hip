@@ -43,19 +43,24 @@ namespace {
 constexpr int K = VTX_REF_K, W = VTX_REF_W;
 static_assert(K == 6 && W == 20 && VTX_REF_MATCH == 1 && VTX_REF_GAP_OPEN == -5 && VTX_REF_GAP_EXTEND == -1,
               "band_sweep_kernel's sdpkpp is written for k = 6, match 1, gap -5 / -1 (src/main.rs:33-38, :899)");
-constexpr int LOGCAP = 128;          // sections a task may open (real sequence: p99 55, max 88; tandem repeats over 2 letters: 400+)
-constexpr int SECCAP = 12;           // sections of the best chain
+constexpr int SECCAP = 28;           // sections of the best chain (a 150-base read chains at most 25 six-mers end to end)
 constexpr int MAXLEN = 255;          // read / haplotype bases (one byte per coordinate in the packed words)
-// per-task LDS (32-bit words)
-constexpr int O_RING = 0;            // 8 rows x 256 dp bytes; after the sweep: rmin[256], rmax[256]
-constexpr int O_C = 512;             // C[ye], 256 words
-constexpr int O_BM = 768;            // block maxima of C, 8 columns each
-constexpr int O_PBM = 800;           // exclusive prefix maxima of BM
-constexpr int O_LOG = 832;           // LOGCAP section records: x << 24 | y << 16 | source (0xffff: none)
-constexpr int O_CODE = 960;          // read base codes, one byte per row (7: no base), 272 bytes
-constexpr int O_SEC = 1028;          // SECCAP sections: x0 << 16 | y0 << 8 | matches
-constexpr int O_MISC = 1040;         // [0] log entries, [1] maximum of every inserted value
-constexpr int TASK_W = 1044;         // = 4 (mod 32) x 5: the eight tasks of a wavefront start in eight different banks
+// per-task LDS (32-bit words).  LOGCAP = sections a task may open: 128 for the first pass (real sequence: p99 55; 4.1 KB per task,
+// four wavefronts per CU), 1024 for the second pass over what the first declined (satellites, tandem repeats over two letters:
+// hundreds of dominated pieces whose every match opens a section; 7.6 KB per task, two wavefronts per CU).
+template <int LOGCAP>
+struct Lay {
+    static constexpr int O_RING = 0;            // 8 rows x 256 dp bytes; after the sweep: rmin[256], rmax[256]
+    static constexpr int O_C = 512;             // C[ye], 256 words
+    static constexpr int O_BM = 768;            // block maxima of C, 8 columns each
+    static constexpr int O_PBM = 800;           // exclusive prefix maxima of BM
+    static constexpr int O_CODE = 832;          // read base codes, one NIBBLE per row (7: no base): 8 rows per word, 36 words
+    static constexpr int O_SEC = 900;           // SECCAP sections: x0 << 16 | y0 << 8 | matches
+    static constexpr int O_MISC = 928;          // [0] log entries
+    static constexpr int O_LOG = 948;           // LOGCAP section records: x << 24 | y << 16 | source (0xffff: none)
+    static constexpr int TASK_W = 948 + LOGCAP; // = 20 (mod 32) for both capacities: the eight tasks of a wavefront start in eight different banks
+    static_assert(TASK_W % 32 == 20 && TASK_W % 4 == 0, "bank spread / 16-byte alignment of the task slices");
+};
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -63,12 +68,23 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// DPP moves are never wrapped in a select: `cond ? dpp(x) : 0` compiles to an EXEC-masked DPP, and a source lane that EXEC
+// disables reads as 0 (the first version of the block-maximum scan lost lane 0's blocks that way).  Masks are ANDed in.
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp0(uint32_t v) {      // lanes without a source get 0
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 #define DPP_ROW_SHL(n) (0x100 + (n))
 #define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_QUAD_XOR1 0xB1           // quad_perm:[1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E           // quad_perm:[2,3,0,1]
+#define DPP_HALF_MIRROR 0x141        // row_half_mirror: lane i <-> 7 - i inside each group of eight
+// maximum over the eight lanes of a task (every lane active)
+__device__ __forceinline__ uint32_t group_max(uint32_t v) {
+    v = max(v, dpp0<DPP_QUAD_XOR1>(v));
+    v = max(v, dpp0<DPP_QUAD_XOR2>(v));
+    return max(v, dpp0<DPP_HALF_MIRROR>(v));
+}
 
 // A: 0, C: 1, G: 2, T: 3, N: 4, anything else: 7
 __device__ __forceinline__ uint32_t base_code(uint32_t b) {
@@ -86,24 +102,35 @@ __device__ __forceinline__ uint32_t base_code(uint32_t b) {
 // tasks[n_tasks]: task = 2 * record + haplotype.  Every task either gets band slot h = atomicAdd(counters[0]) (hard_list[h] =
 // task, lo at band + h * 2 * band_stride, hi at + band_stride) or, when declined, goes to overflow_list[atomicAdd(counters[1])].
 // stats != 0: counters[48 + reason] counts the declined tasks (1 bytes / lengths, 2 log full, 3 sections).
+// n_dev != nullptr: the list length lives on the device (min(*n_dev, n_tasks); the grid is sized for n_tasks).
+//
+// The sweep's fast path: nearly every lane has at most ONE match per row, and it continues the lane's match of the row before.  The
+// dp of a lane's first match of the last six rows rides in a register (one byte per row): the END event six rows later and the
+// continuation test of the next row read it there; whether (x - 1, y - 1) is a match at all is a bit of the previous row's mask.
+// The dp bytes in LDS are only READ for a lane's second and further matches of a row (repeats).
+template <int LOGCAP>
 __global__ __launch_bounds__(64) void band_sweep_kernel(
-    const uint32_t* __restrict__ tasks, uint32_t n_tasks,
+    const uint32_t* __restrict__ tasks, uint32_t n_tasks, const uint32_t* __restrict__ n_dev,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
     uint16_t* __restrict__ band, uint32_t band_stride, uint32_t* __restrict__ hard_list,
-    uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters, uint32_t stats, uint8_t* __restrict__ stage) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[8 * TASK_W];
+    uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters, uint32_t stats, uint8_t* __restrict__ stage,
+    uint32_t* __restrict__ dbg) {
+    typedef Lay<LOGCAP> L;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if (n_dev) { const uint32_t nd = *n_dev; n_tasks = nd < n_tasks ? nd : n_tasks; }
+    if (blockIdx.x * 8u >= n_tasks) return;
     const int lane = (int)threadIdx.x;
     const int g = lane >> 3, l = lane & 7;
-    uint32_t* T = lds + g * TASK_W;
-    uint8_t* ring = (uint8_t*)(T + O_RING);
-    uint32_t* Cw = T + O_C;
-    uint32_t* BM = T + O_BM;
-    uint32_t* PBM = T + O_PBM;
-    uint32_t* LOG = T + O_LOG;
-    uint8_t* codes = (uint8_t*)(T + O_CODE);
-    uint32_t* SEC = T + O_SEC;
-    uint32_t* MISC = T + O_MISC;
+    uint32_t* T = lds + g * L::TASK_W;
+    uint8_t* ring = (uint8_t*)(T + L::O_RING);
+    uint32_t* Cw = T + L::O_C;
+    uint32_t* BM = T + L::O_BM;
+    uint32_t* PBM = T + L::O_PBM;
+    uint32_t* LOG = T + L::O_LOG;
+    uint32_t* codes32 = T + L::O_CODE;
+    uint32_t* SEC = T + L::O_SEC;
+    uint32_t* MISC = T + L::O_MISC;
 
     const uint32_t slot = blockIdx.x * 8u + (uint32_t)g;
     const bool have = slot < n_tasks;
@@ -130,7 +157,7 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
         for (int i = 0; i < 8; ++i) c4[i] = z;
         *(uint4*)(BM + 4 * l) = z;
         *(uint4*)(PBM + 4 * l) = z;
-        if (l == 0) { MISC[0] = 0; MISC[1] = 0; }
+        if (l == 0) MISC[0] = 0;
     }
     uint32_t bad = 0;
     {
@@ -142,26 +169,22 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
             if (col0 + 16 * h < m) __builtin_memcpy(&v, read_arena + roff + col0 + 16 * h, 16);
             wds[4 * h] = v.x; wds[4 * h + 1] = v.y; wds[4 * h + 2] = v.z; wds[4 * h + 3] = v.w;
         }
-        uint32_t packed[8];
+        uint32_t packed[4] = {0, 0, 0, 0};                        // rows 32 l .. 32 l + 31, a nibble each
 #pragma unroll
         for (int wi = 0; wi < 8; ++wi) {
-            uint32_t pk = 0;
 #pragma unroll
             for (int bi = 0; bi < 4; ++bi) {
-                const int idx = col0 + 4 * wi + bi;
+                const int k = 4 * wi + bi;
                 uint32_t c = 7u;
-                if (idx < m) {
+                if (col0 + k < m) {
                     c = base_code((wds[wi] >> (8 * bi)) & 0xffu);
                     bad |= (c == 7u) ? 1u : 0u;
                 }
-                pk |= c << (8 * bi);
+                packed[k >> 3] |= c << (4 * (k & 7));
             }
-            packed[wi] = pk;
         }
-        uint4* cd = (uint4*)(codes + col0);
-        cd[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-        cd[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
-        if (l == 0) *(uint4*)(codes + 256) = make_uint4(0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u);
+        *(uint4*)(codes32 + 4 * l) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        if (l == 0) *(uint4*)(codes32 + 32) = make_uint4(0x77777777u, 0x77777777u, 0x77777777u, 0x77777777u);
     }
     uint32_t eq0 = 0, eq1 = 0, eq2 = 0, eq3 = 0, eq4 = 0;
     {
@@ -184,12 +207,13 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
         }
     }
     // a byte outside ACGTN anywhere in the task: declined (all eight lanes agree)
-    bad |= (uint32_t)__shfl_xor((int)bad, 1); bad |= (uint32_t)__shfl_xor((int)bad, 2); bad |= (uint32_t)__shfl_xor((int)bad, 4);
+    bad = group_max(bad);
     if (bad) { decline = 1u; eq0 = eq1 = eq2 = eq3 = eq4 = 0; }       // (no matches: the sweep idles for this task)
     wave_sync();
 
     // ---- the sweep ----
     const uint32_t nbmask = l == 7 ? 0u : 0xffffffffu;            // lane 7's upper neighbour belongs to the next task
+    const uint32_t ge1 = l >= 1 ? 0xffffffffu : 0u, ge2 = l >= 2 ? 0xffffffffu : 0u, ge4 = l >= 4 ? 0xffffffffu : 0u;
     int mmax = m;
     mmax = max(mmax, __shfl_xor(mmax, 8)); mmax = max(mmax, __shfl_xor(mmax, 16)); mmax = max(mmax, __shfl_xor(mmax, 32));
     const int tmax = __builtin_amdgcn_readfirstlane(mmax) + K;    // feed step t = 0 .. m + 5: row r = t - 5 reaches m
@@ -197,12 +221,26 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
     uint32_t m2a = 0, m2b = 0, m2c = 0, m2d = 0;                  // M2(t - 2) .. M2(t - 5)
     uint32_t h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0;      // M6(r - 1) .. M6(r - 6)
     uint32_t best = 0;
-    uint32_t code_next = codes[0];
+    uint64_t dq = 0;                                              // dp of this lane's FIRST match of rows r - 1 (bits 0-7) .. r - 6 (bits 40-47)
+    uint32_t pmax = 0;                                            // see the END phase
+    uint32_t code_blk = 0, code_blk_next = codes32[0];          // the codes of eight rows per word: one LDS read (and one wait) per eight rows
+#define LDS_DONE() __builtin_amdgcn_s_waitcnt(0xC07F)          /* s_waitcnt lgkmcnt(0) (gfx9 encoding: vmcnt / expcnt untouched) */
 #define SHR_WORDS(v, s) __builtin_amdgcn_alignbit(dpp0<DPP_ROW_SHL(1)>(v) & nbmask, (v), (s))
+    // one END event: the match that started at (r - 6, y) with dp enters C / BM; returns the inserted value
+#define END_EVENT(y, dp)                                                                              \
+    {                                                                                                 \
+        const uint32_t key_ = ((uint32_t)(dp) << 16) | ((uint32_t)(r - K) << 8) | (uint32_t)(y);      \
+        best = max(best, key_);                                                                       \
+        const uint32_t val_ = key_ + ((uint32_t)(r + K + (y)) << 16);   /* V = dp + xe + ye = dp + r + (y + 6) */ \
+        atomicMax(&Cw[(y) + K], val_);                                                                \
+        atomicMax(&BM[((y) + K) >> 3], val_);                                                         \
+        if ((((y) + K) >> 5) == l) ins_a = max(ins_a, val_); else ins_b = max(ins_b, val_);           \
+    }
+    const uint32_t ablate = stats >> 8;                           // (profiling aid, tools/ablate_sweep.sh; results are wrong by design)
 #pragma unroll 1
-    for (int t = 0; t < tmax; ++t) {
-        const uint32_t code = code_next;
-        code_next = codes[min(t + 1, 271)];
+    for (int t = 0; t < (ablate == 1 ? 0 : tmax); ++t) {
+        if ((t & 7) == 0) { code_blk = code_blk_next; code_blk_next = codes32[min((t >> 3) + 1, 35)]; }
+        const uint32_t code = (code_blk >> (4 * (t & 7))) & 7u;
         // M1(t): the Eq word of this row's base
         uint32_t m1 = (code & 1u) ? ((code & 2u) ? eq3 : eq1) : ((code & 2u) ? eq2 : eq0);
         m1 = (code & 4u) ? (code == 4u ? eq4 : 0u) : m1;
@@ -211,66 +249,88 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
         const uint32_t w_start = m4 & SHR_WORDS(m2n, 4);          // M6(t - 5)
         m1p = m1; m2d = m2c; m2c = m2b; m2b = m2a; m2a = m2n;
         const int r = t - (K - 1);
-        const uint32_t w_end = h6;
+        const uint32_t w_end = h6, w_prev = h1;                   // M6(r - 6), M6(r - 1)
         h6 = h5; h5 = h4; h4 = h3; h3 = h2; h2 = h1; h1 = w_start;
         if (r < 0) continue;                                      // (uniform)
-        // the dp bytes of row r live in ring slot r & 7 (last used by row r - 8): cleared even when the row has no match —
-        // row r + 1 looks its continuation partners up here
-        {
-            uint4* rc = (uint4*)(ring + ((r & 7) << 8) + col0);
-            rc[0] = make_uint4(0, 0, 0, 0); rc[1] = make_uint4(0, 0, 0, 0);
-        }
-        if (!__any((w_start | w_end) != 0u)) continue;
-        wave_sync();
-        // ---- END events of row r: matches that started at row r - 6 ----
-        {
+        if (ablate == 2) { best |= w_start | w_end; continue; }   // (profiling aid) the match pipeline only
+        // (the dp bytes of row r live in ring slot r & 7, last used by row r - 8.  Nothing clears them: whether a cell holds a match is
+        // a bit of that row's mask, the byte is only read where the bit is set)
+        if (!__any((w_start | w_end) != 0u)) { dq <<= 8; continue; }
+        // ---- END events of row r: matches that started at row r - 6.  The lane's first one has its dp in dq ----
+        if (__any(w_end != 0u)) {
+            uint32_t ins_a = 0, ins_b = 0;                        // inserted into this lane's own 32 columns / into the next lane's
             uint32_t w = w_end;
-            const uint8_t* rrow = ring + (((r - K) & 7) << 8);
-            while (__any(w != 0u)) {
-                const bool on = w != 0u;
-                const int b = on ? (int)__builtin_ctz(w) : 0;
-                w &= w - 1u;                                              // (0 stays 0)
-                const int y = col0 + b;
-                const uint32_t dp = on ? (uint32_t)rrow[y] : 0u;
-                if (on) {
-                    const uint32_t key = (dp << 16) | ((uint32_t)(r - K) << 8) | (uint32_t)y;
-                    best = max(best, key);
-                    const uint32_t val = key + ((uint32_t)(r + K + y) << 16);          // V = dp + xe + ye = dp + r + (y + 6); V << 16 | xq << 8 | yq
-                    const int ye = y + K;
-                    atomicMax(&Cw[ye], val);
-                    atomicMax(&BM[ye >> 3], val);
-                    atomicMax(&MISC[1], val);
+            if (w) {
+                const int y = col0 + (int)__builtin_ctz(w);
+                w &= w - 1u;
+                const uint32_t dp = (uint32_t)(dq >> 40) & 0xffu;
+                END_EVENT(y, dp)
+            }
+            if (__any(w != 0u)) {
+                wave_sync();
+                const uint8_t* rrow = ring + (((r - K) & 7) << 8);
+                while (__any(w != 0u)) {
+                    const bool on = w != 0u;
+                    const int y = col0 + (on ? (int)__builtin_ctz(w) : 0);
+                    w &= w - 1u;                                          // (0 stays 0)
+                    const uint32_t dp = on ? (uint32_t)rrow[y] : 0u;
+                    if (on) END_EVENT(y, dp)
                 }
             }
+            // pmax = the largest value inserted so far at an end column below 32 (l + 1): an upper bound of every prefix maximum
+            // this lane can ask for.  (A bound over the whole task — the first version — made every main-diagonal match after a
+            // chance match far to the RIGHT look up the prefix maximum for the next ~15 rows: 60 % of the kernel's time.)
+            uint32_t sc = max(ins_a, dpp0<DPP_ROW_SHR(1)>(ins_b) & ge1);
+            sc = max(sc, dpp0<DPP_ROW_SHR(1)>(sc) & ge1);
+            sc = max(sc, dpp0<DPP_ROW_SHR(2)>(sc) & ge2);
+            sc = max(sc, dpp0<DPP_ROW_SHR(4)>(sc) & ge4);
+            pmax = max(pmax, sc);
         }
         wave_sync();
+        if (ablate == 3) { dq <<= 8; continue; }                  // (profiling aid) ... + the END events
         // ---- START events of row r ----
-        {
+        uint32_t dv_first = 0;
+        if (__any(w_start != 0u)) {
+            // is (r - 1, y - 1) a match?  bit b of the previous row's mask shifted up by one column (bit 31 of the lane below comes in
+            // at bit 0); is it its lane's FIRST match of that row (then its dp rides in that lane's dq)?  the same with the lowest bits
+            const uint32_t left_prev = dpp0<DPP_ROW_SHR(1)>(w_prev) & ge1;
+            const uint32_t pshift = __builtin_amdgcn_alignbit(w_prev, left_prev, 31);
+            const uint32_t lowp = w_prev & (0u - w_prev);
+            const uint32_t fshift = __builtin_amdgcn_alignbit(lowp, dpp0<DPP_ROW_SHR(1)>(lowp) & ge1, 31);
+            const uint32_t own_dp = (uint32_t)dq & 0xffu;
+            const uint32_t left_dp = dpp0<DPP_ROW_SHR(1)>(own_dp) & ge1;
             uint32_t w = w_start;
             const uint8_t* prow = ring + (((r - 1) & 7) << 8);
             uint8_t* crow = ring + ((r & 7) << 8);
-            const uint32_t gmax = MISC[1];
             bool pbm_ready = false;
+            bool first = true;
             while (__any(w != 0u)) {
                 const bool on = w != 0u;
                 const int b = on ? (int)__builtin_ctz(w) : 0;
                 w &= w - 1u;
                 const int y = col0 + b;
-                const int dpc = (on && r > 0 && y > 0) ? (int)prow[y - 1] : 0;
-                // could a jump beat the continuation (or reach 6 where there is none)?  upper bound from the task's maximum
-                const int cand_ub = (int)(gmax >> 16) - (r + y) + 1;
-                const bool need_q = on && gmax != 0u && cand_ub > (dpc ? dpc + 1 : K - 1);
+                const bool exists = on && ((pshift >> b) & 1u);
+                int dpc = !exists ? 0 : (((fshift >> b) & 1u) ? (int)(b ? own_dp : left_dp) : -1);
+                if (__any(dpc < 0)) {
+                    wave_sync();
+                    if (dpc < 0) dpc = (int)prow[y - 1];
+                    LDS_DONE();        // the wait belongs INSIDE the rare branch: at the join the compiler would wait on every path — for the
+                }                      // END events' atomics the fast path has just issued (41 % of the kernel's wave cycles were such waits)
+                // could a jump beat the continuation (or reach 6 where there is none)?  upper bound from pmax
+                const int cand_ub = (int)(pmax >> 16) - (r + y) + 1;
+                const bool need_q = on && pmax != 0u && cand_ub > (dpc ? dpc + 1 : K - 1);
                 uint32_t q = 0;
                 if (__any(need_q)) {
                     if (!pbm_ready) {
                         // exclusive prefix maxima of the block maxima (BM cannot change during the START phase)
+                        wave_sync();
                         const uint4 bm = *(const uint4*)(BM + 4 * l);
                         const uint32_t p0 = bm.x, p1 = max(p0, bm.y), p2 = max(p1, bm.z), p3 = max(p2, bm.w);
                         uint32_t inc = p3;
-                        inc = max(inc, l >= 1 ? dpp0<DPP_ROW_SHR(1)>(inc) : 0u);
-                        inc = max(inc, l >= 2 ? dpp0<DPP_ROW_SHR(2)>(inc) : 0u);
-                        inc = max(inc, l >= 4 ? dpp0<DPP_ROW_SHR(4)>(inc) : 0u);
-                        const uint32_t exc = l >= 1 ? dpp0<DPP_ROW_SHR(1)>(inc) : 0u;
+                        inc = max(inc, dpp0<DPP_ROW_SHR(1)>(inc) & ge1);
+                        inc = max(inc, dpp0<DPP_ROW_SHR(2)>(inc) & ge2);
+                        inc = max(inc, dpp0<DPP_ROW_SHR(4)>(inc) & ge4);
+                        const uint32_t exc = dpp0<DPP_ROW_SHR(1)>(inc) & ge1;
                         *(uint4*)(PBM + 4 * l) = make_uint4(exc, max(exc, p0), max(exc, p1), max(exc, p2));
                         pbm_ready = true;
                         wave_sync();
@@ -284,6 +344,7 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
                         q = max(q, kk >= 4 ? c1.x : 0u); q = max(q, kk >= 5 ? c1.y : 0u); q = max(q, kk >= 6 ? c1.z : 0u);
                         q = max(q, kk >= 7 ? c1.w : 0u);
                     }
+                    LDS_DONE();
                 }
                 if (on) {
                     int dv = K;
@@ -295,23 +356,26 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
                     bool cont = false;
                     if (dpc && dpc + 1 >= dv) { dv = dpc + 1; cont = true; }
                     crow[y] = (uint8_t)dv;
+                    if (first) dv_first = (uint32_t)dv;
                     if (!cont) {
                         const uint32_t pos = atomicAdd(&MISC[0], 1u);
                         if (pos < (uint32_t)LOGCAP) LOG[pos] = ((uint32_t)r << 24) | ((uint32_t)y << 16) | src;
                     }
                 }
+                first = false;
             }
         }
+        dq = (dq << 8) | dv_first;
         wave_sync();
     }
 #undef SHR_WORDS
+#undef END_EVENT
+#undef LDS_DONE
     wave_sync();
-    best = max(best, (uint32_t)__shfl_xor((int)best, 1));
-    best = max(best, (uint32_t)__shfl_xor((int)best, 2));
-    best = max(best, (uint32_t)__shfl_xor((int)best, 4));
+    best = group_max(best);
     const uint32_t logn = MISC[0];
     if (!decline && logn > (uint32_t)LOGCAP) decline = 2u;
-    const bool seeded = best != 0u && !decline;
+    const bool seeded = best != 0u && !decline && ablate != 4;     // (ablate 4: profiling aid — the sweep without the chain walk and the band)
 
     // ---- the chain's sections, last first ----
     int nsec = 0;
@@ -320,21 +384,19 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
         bool walking = seeded;
         while (__any(walking)) {
             const int d = cy - cx;
-            uint32_t pick = 0;                                      // (x' + 1) << 8 | log index, maximum over the diagonal's entries with x' <= x
+            uint32_t pick = 0;                                      // (x' + 1) << 12 | log index, maximum over the diagonal's entries with x' <= x
             if (walking) {
                 for (uint32_t i = (uint32_t)l; i < logn; i += 8u) {
                     const uint32_t e = LOG[i];
                     const int ex = (int)(e >> 24), ey = (int)((e >> 16) & 0xffu);
-                    if (ey - ex == d && ex <= cx) pick = max(pick, ((uint32_t)(ex + 1) << 8) | i);
+                    if (ey - ex == d && ex <= cx) pick = max(pick, ((uint32_t)(ex + 1) << 12) | i);
                 }
             }
-            pick = max(pick, (uint32_t)__shfl_xor((int)pick, 1));
-            pick = max(pick, (uint32_t)__shfl_xor((int)pick, 2));
-            pick = max(pick, (uint32_t)__shfl_xor((int)pick, 4));
+            pick = group_max(pick);
             if (walking) {
                 if (pick == 0u || nsec >= SECCAP) { decline = pick == 0u ? 4u : 3u; walking = false; }
                 else {
-                    const uint32_t e = LOG[pick & 0xffu];
+                    const uint32_t e = LOG[pick & 0xfffu];
                     const int ex = (int)(e >> 24), ey = (int)((e >> 16) & 0xffu);
                     if (l == 0) SEC[nsec] = ((uint32_t)ex << 16) | ((uint32_t)ey << 8) | (uint32_t)(cx - ex + 1);
                     ++nsec;
@@ -347,7 +409,7 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
     }
     wave_sync();
     // ---- anchors -> first / last anchor row per column (the ring is dead: rmin / rmax take its place) ----
-    uint32_t* rmin = T + O_RING;
+    uint32_t* rmin = T + L::O_RING;
     uint32_t* rmax = rmin + 256;
     {
         uint4* a = (uint4*)(rmin + col0);
@@ -401,6 +463,13 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
         }
     }
     wave_sync();
+    if (dbg && have && l == 0) {                                   // (vtx_debug_bands with VTX_SWEEP_DBG=1: what the task's lanes agreed on)
+        uint32_t* o = dbg + (size_t)slot * 64;
+        o[0] = best; o[1] = logn; o[2] = (uint32_t)nsec; o[3] = (uint32_t)cA; o[4] = (uint32_t)cB; o[5] = decline; o[6] = (uint32_t)m; o[7] = (uint32_t)n;
+        for (int i = 0; i < 12; ++i) o[8 + i] = SEC[i];
+        for (int i = 0; i < 24; ++i) o[20 + i] = (uint32_t)i < logn ? LOG[i] : 0u;
+        for (int i = 0; i < 10; ++i) { o[44 + i] = rmin[i]; o[54 + i] = rmax[i]; }
+    }
     // ---- slots and ranges ----
     const bool emit = have && !decline;
     const uint64_t em = __ballot(emit && l == 0), dm = __ballot(have && decline && l == 0);
@@ -431,17 +500,33 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
         }
     } else if (have && l == 0) {
         overflow_list[obase + (uint32_t)__popcll(dm & below)] = task;
-        if (stats) atomicAdd(&counters[48 + min(decline, 7u)], 1u);
+        if (stats & 0xffu) atomicAdd(&counters[48 + min(decline, 7u)], 1u);
     }
 }
 
-extern "C" hipError_t vtxk_launch_band_sweep(const uint32_t* tasks, uint32_t n_tasks, const vtx_record* records,
+// tier 0: 128 sections per task (first pass); tier 1: 1024 (second pass over the first's log overflows)
+extern "C" hipError_t vtxk_launch_band_sweep(int tier, const uint32_t* tasks, uint32_t n_tasks, const uint32_t* n_dev,
+                                             const vtx_record* records,
                                              const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                              const uint8_t* hap_arena, uint16_t* band, uint32_t band_stride, uint32_t* hard_list,
-                                             uint32_t* overflow_list, uint32_t* counters, int stats, uint8_t* stage, hipStream_t s) {
+                                             uint32_t* overflow_list, uint32_t* counters, int stats, uint8_t* stage, uint32_t* dbg,
+                                             hipStream_t s) {
     if (!n_tasks) return hipSuccess;
-    hipLaunchKernelGGL(band_sweep_kernel, dim3((n_tasks + 7) / 8), dim3(64), 0, s, tasks, n_tasks, records, rec_locus, loci,
-                       read_arena, hap_arena, band, band_stride, hard_list, overflow_list, counters, (uint32_t)stats, stage);
+    static const uint32_t ablate = getenv("VTX_SWEEP_ABLATE") ? (uint32_t)atoi(getenv("VTX_SWEEP_ABLATE")) << 8 : 0u;
+#define LAUNCH_SWEEP(CAP)                                                                                          \
+    {                                                                                                              \
+        const size_t shmem = (size_t)8 * Lay<CAP>::TASK_W * sizeof(uint32_t);                                      \
+        if (shmem > 48 * 1024) {                                                                                   \
+            hipError_t e = hipFuncSetAttribute((const void*)band_sweep_kernel<CAP>,                               \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);           \
+            if (e != hipSuccess) return e;                                                                         \
+        }                                                                                                          \
+        hipLaunchKernelGGL(band_sweep_kernel<CAP>, dim3((n_tasks + 7) / 8), dim3(64), shmem, s, tasks, n_tasks, n_dev, records, \
+                           rec_locus, loci, read_arena, hap_arena, band, band_stride, hard_list, overflow_list, counters,      \
+                           (uint32_t)stats | ablate, stage, dbg);                                                  \
+    }
+    if (tier == 0) LAUNCH_SWEEP(128) else LAUNCH_SWEEP(1024)
+#undef LAUNCH_SWEEP
     return hipGetLastError();
 }
 // what the kernel holds: reads and haplotypes up to this many bases (longer ones are declined task by task; a batch whose
