@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/band_kat.json: known-answer vectors of the banded aligner AS THE ORACLE RESTATES IT (oracle/vtx_oracle.c),
+for a maintainer who holds bio 0.30.0's source (this repository does not: SURVEY.md §8c) to replay against the crate:
+
+    banded::Aligner::new(-5, -1, |a, b| if a == b { 1 } else { -5 }, 6, 20).local(read, hap).score     (src/main.rs:898-901)
+
+Every vector: read, haplotype, the banded score, the full-matrix score, and the band — per column j = 0 .. len(hap) of the DP matrix
+the row range [lo[j], hi[j]) (rows 0 .. len(read)), run-length encoded.  The pairs are ADVERSARIAL for the recollected details
+(include/vtx_band_semantics.h): chosen from the stress generators (tests/stress_batches.py) where the band matters — banded != full,
+chains over several diagonals, reads hanging over the window, repeats — plus a share of ordinary ones.  INTEGRATION.md holds the
+20-line Rust test that replays the file.  Deterministic: fixed seeds, no GPU.
+
+    python tools/make_band_kat.py            # rewrites tests/golden/band_kat.json
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import oracle           # noqa: E402
+import stress_batches as SB         # noqa: E402
+
+
+def rle(a):
+    out, i = [], 0
+    while i < len(a):
+        j = i
+        while j + 1 < len(a) and a[j + 1] == a[i]:
+            j += 1
+        out.append([int(a[i]), j - i + 1])
+        i = j + 1
+    return out
+
+
+def pairs(batch, limit):
+    hb, rb = batch.hap_arena.tobytes(), batch.read_arena.tobytes()
+    n = 0
+    for loc in batch.loci:
+        for ri in range(int(loc["rec_begin"]), int(loc["rec_begin"]) + int(loc["rec_count"])):
+            r = batch.records[ri]
+            x = rb[int(r["read_off"]):int(r["read_off"]) + int(r["read_len"])]
+            for off, ln in ((int(loc["ref_off"]), int(loc["ref_len"])), (int(loc["alt_off"]), int(loc["alt_len"]))):
+                if len(x) >= 6 and ln >= 6:
+                    yield x, hb[off:off + ln]
+                    n += 1
+                    if n >= limit:
+                        return
+
+
+def main():
+    vectors, seen = [], set()
+    sources = [("error models and indels", SB.synthetic_batches(per_model=1, n_loci=30, reads=12), 500, 10),
+               ("near repeats", SB.near_repeat_batches(trials=4), 400, 8),
+               ("loci from real sequence", SB.real_sequence_batches(trials=2), 600, 12),
+               ("real-read shapes", SB.real_shape_batches(trials=2), 600, 12),
+               ("tandem repeats", SB.repeat_rich_batches(trials=4, loci=12, reads=8, pad_range=(30, 120)), 200, 10)]
+    for kind, gen, per_batch, keep_plain in sources:
+        for label, batch, _nb in gen:
+            plain = 0
+            for x, y in pairs(batch, per_batch):
+                if (x, y) in seen:
+                    continue
+                b, f = oracle.sw_banded(x, y), oracle.sw_full(x, y)
+                mt = oracle.kmer_matches(x, y)
+                chain, _ = oracle.sdpkpp(mt) if len(mt) else ([], 0)
+                diags = {int(mt[p, 1]) - int(mt[p, 0]) for p in chain}
+                interesting = b != f or len(diags) > 1
+                if not interesting:
+                    if plain >= keep_plain:
+                        continue
+                    plain += 1
+                seen.add((x, y))
+                lo, hi, cells = oracle.band_create(x, y)
+                vectors.append({"kind": kind, "from": label, "read": x.decode("latin-1"), "hap": y.decode("latin-1"),
+                                "banded_score": int(b), "full_score": int(f), "band_cells": int(cells),
+                                "chain_diagonals": len(diags), "kmer_matches": int(len(mt)), "lo_rle": rle(lo), "hi_rle": rle(hi)})
+    # keep the file small: every vector where the band changes the score, then the others up to 320 in all
+    vectors.sort(key=lambda v: (v["banded_score"] == v["full_score"], v["chain_diagonals"] <= 1))
+    vectors = vectors[:320]
+    out = {"what": "known-answer vectors of banded::Aligner::new(-5, -1, score(1, -5), 6, 20).local(read, hap) as restated by oracle/vtx_oracle.c "
+                   "(reference call site src/main.rs:898-901); band = per column j of the DP matrix the row range [lo, hi), run-length encoded as [value, count]",
+           "k": 6, "w": 20, "scoring": {"match": 1, "mismatch": -5, "gap_open": -5, "gap_extend": -1},
+           "recollected_details": {"lazy_extension": "2 * k", "kmer_last_anchor": "k", "no_seed": "full matrix", "sdpkpp_ties": "larger match index"},
+           "generator": "tools/make_band_kat.py", "vectors": vectors}
+    path = os.path.join(ROOT, "tests", "golden", "band_kat.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, separators=(",", ":"))
+    ne = sum(v["banded_score"] != v["full_score"] for v in vectors)
+    print("%s: %d vectors, %d with banded != full, %d with a chain over several diagonals, %.0f KB" % (
+        path, len(vectors), ne, sum(v["chain_diagonals"] > 1 for v in vectors), os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

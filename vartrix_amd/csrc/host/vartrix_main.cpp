@@ -148,8 +148,14 @@ void run_shard(Shard* s, vtx_config cfg) {
             if (!s->rc) { s->rc = VTX_E_PEER; s->err = "another shard failed before the communicator was set up"; vtx_destroy(ctx); }
             return;
         }
-        if ((s->rc = vtx_comm_init(ctx, s->comm_id, s->rank, s->world))) {     // collective over the shard threads
-            s->err = vtx_strerror(ctx); vtx_destroy(ctx); return;
+        s->rc = vtx_comm_init(ctx, s->comm_id, s->rank, s->world);             // collective over the shard threads
+        if (s->rc) s->err = vtx_strerror(ctx);
+        // ... and every shard has joined it, or none goes on: a shard whose vtx_comm_init failed has no communicator to call
+        // vtx_gather_abort on — the others would wait for ever in vtx_gather_coo's all-gather (round-3 ADVICE)
+        if (!s->gate->meet(s->rc == 0)) {
+            if (!s->rc) { s->rc = VTX_E_PEER; s->err = "another shard failed to join the communicator"; }
+            vtx_destroy(ctx);
+            return;
         }
     } else if (s->rc) return;
     s->t_create = now_s() - t0; t0 = now_s();
@@ -171,6 +177,8 @@ void run_shard(Shard* s, vtx_config cfg) {
     if ((s->rc = vtx_run(ctx))) { s->err = vtx_strerror(ctx); if (s->comm_id) (void)vtx_gather_abort(ctx); vtx_destroy(ctx); return; }
     s->t_run = now_s() - t0; t0 = now_s();
     if (s->comm_id) {
+        // (no host gate here: a shard that failed after joining the communicator says so INSIDE the collective — vtx_gather_abort
+        // above takes part in the status round, every vtx_gather_coo returns VTX_E_PEER)
         // every shard's triplets to rank 0 over RCCL (rank order = row order); rank 0 copies the gathered matrix out
         vtx_coo dev{};
         if ((s->rc = vtx_gather_coo(ctx, 0, &dev))) { s->err = vtx_strerror(ctx); vtx_destroy(ctx); return; }
@@ -283,7 +291,13 @@ int main(int argc, char** argv) {
         struct stat st;
         if (stat(val["bam"].c_str(), &st) == 0 && (uint64_t)st.st_size > (4ull << 30)) stream_loci = 32768;
     } else {
-        stream_loci = (uint32_t)strtoul(val["stream-loci"].c_str(), nullptr, 10);
+        char* endp = nullptr;
+        const unsigned long v = strtoul(val["stream-loci"].c_str(), &endp, 10);
+        if (val["stream-loci"].empty() || *endp != '\0' || v > 0xffffffffull) {
+            fprintf(stderr, "error: --stream-loci takes a number of VCF records or `auto`, not `%s`\n", val["stream-loci"].c_str());
+            return 1;
+        }
+        stream_loci = (uint32_t)v;                            // (0: one range)
     }
     struct Packed { vtxh_pack* pk = nullptr; int rc = 0; std::string err; double secs = 0; bool last = false; };
     std::mutex q_mu;

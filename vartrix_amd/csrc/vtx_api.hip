@@ -1299,6 +1299,8 @@ int vtx_run(vtx_ctx* c) {
                         } else (void)hipGetLastError();
                     }
                 } else {
+                    // (the tables do not fit the buffer for this chunk: band_run_kernel alone, tables in LDS)
+                    if (getenv("VTX_DEBUG")) fprintf(stderr, "[vtx] band_diag_kernel not launched for tasks [%llu, +%u): %s\n", (unsigned long long)base, nt, hipGetErrorString(e));
                     (void)hipGetLastError();
                 }
             }

@@ -698,7 +698,11 @@ extern "C" hipError_t vtxk_launch_band_coop(int tier, const uint32_t* tasks, uin
 // active lanes per wavefront of band_kernel<false> for a list of n_tasks (the workspace holds 64 slabs per wavefront either way)
 extern "C" uint32_t vtxk_band_lanes(uint32_t n_tasks) {
     static const int forced = getenv("VTX_BAND_LANES") ? atoi(getenv("VTX_BAND_LANES")) : 0;       // experiment knob
-    if (forced) return (uint32_t)forced;
+    if (forced > 0) {                                         // a power of two in [4, 64]: anything else would leave tasks unscored
+        uint32_t lanes = 4;
+        while (lanes < 64 && lanes < (uint32_t)forced) lanes <<= 1;
+        return lanes;
+    }
     uint32_t lanes = 64;
     while (lanes > 4 && (n_tasks + lanes - 1) / lanes < 4096u) lanes >>= 1;        // >= 4096 wavefronts: 16 per CU
     return lanes;
