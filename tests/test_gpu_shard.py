@@ -126,3 +126,95 @@ def test_bench_native_gather_matches_plain_run():
     plain = _bench({}, args)
     nat = _bench({"VTX_FORCE_GATHER": "1", "VTX_NATIVE_GATHER": "1"}, args)
     assert plain["result"] == nat["result"] and nat["result"]["nnz"] > 10000
+
+
+# ---- vtx_gather_coo with world 2 and 4: ranks = processes on ONE device, RCCL's nine entry points replaced by the test transport
+#      (vartrix_amd/csrc/vtx_comm_test.hip, VTX_COMM_TEST_TRANSPORT).  What runs is the library's exchange as shipped: the status
+#      rounds, vtx_gather_plan, the grouped Send / Recv of the five arrays to their final offsets on rank 0, the f64 values
+#      recomputed there — with a real second (third, fourth) rank on the other side of every Recv.  RCCL itself and xGMI do not. ----
+_RANK_CODE = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+import numpy as np
+from vartrix_amd import lib, shard, synth
+from vartrix_amd.abi import default_config
+rank, world, scenario, tmp = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+mode, umi = ("alt_frac", 1) if scenario != "consensus" else ("consensus", 0)
+spec = synth.SynthSpec(n_loci=240, n_barcodes=300, reads_per_locus=24, use_umi=bool(umi), indel_frac=0.3, seed=17)
+whole = synth.make_batch(spec)
+parts = shard.partition_loci(whole, world)
+if scenario == "empty":                      # rank 1 holds no locus at all
+    parts = [(0, parts[1][1])] + [(parts[1][1], parts[1][1])] + parts[2:]
+lo, hi = parts[rank]
+mine = whole.slice_loci(lo, hi)
+idf = os.path.join(tmp, "id")
+if rank == 0:
+    ident = lib.comm_id()
+    open(idf + ".tmp", "wb").write(ident); os.rename(idf + ".tmp", idf)
+else:
+    t0 = time.time()
+    while not os.path.exists(idf):
+        assert time.time() - t0 < 60
+        time.sleep(0.01)
+    ident = open(idf, "rb").read()
+cfg = default_config(aligner="banded", scoring_mode=mode, use_umi=umi, n_barcodes=300)
+with lib.Context(cfg) as ctx:
+    ctx.comm_init(ident, rank, world)
+    ctx.submit(mine)
+    if scenario == "fail" and rank == world - 1:
+        ctx.gather_abort()                   # "my own work failed": the others must leave gather_coo with VTX_E_PEER
+        print("aborted"); sys.exit(0)
+    ctx.run()
+    try:
+        g = ctx.gather_coo(0)
+    except lib.VtxError as e:
+        print("error", e.status); sys.exit(0)
+    if rank == 0:
+        got = ctx.fetch_gathered()
+        np.savez(os.path.join(tmp, "gathered.npz"), **got)
+    print("ok", g["nnz"])
+''' % ROOT
+
+
+def _run_world(world, scenario, tmp):
+    env = dict(os.environ, VTX_COMM_TEST_TRANSPORT=str(tmp))
+    procs = [subprocess.Popen([sys.executable, "-c", _RANK_CODE, str(r), str(world), scenario, str(tmp)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, e[-3000:]
+        outs.append(o.strip().splitlines()[-1])
+    return outs
+
+
+@pytest.mark.parametrize("world,scenario", [(2, "consensus"), (2, "alt_frac"), (4, "alt_frac"), (4, "empty")])
+def test_gather_coo_between_processes_equals_the_unsharded_matrix(tmp_path, world, scenario):
+    import numpy as np
+    from vartrix_amd import lib, synth
+    from vartrix_amd.abi import default_config
+    outs = _run_world(world, scenario, tmp_path)
+    assert all(o.startswith("ok") for o in outs), outs
+    assert [int(o.split()[1]) for o in outs[1:]] == [0] * (world - 1)                  # nnz = 0 away from the destination
+    mode, umi = ("alt_frac", 1) if scenario != "consensus" else ("consensus", 0)
+    spec = synth.SynthSpec(n_loci=240, n_barcodes=300, reads_per_locus=24, use_umi=bool(umi), indel_frac=0.3, seed=17)
+    with lib.Context(default_config(aligner="banded", scoring_mode=mode, use_umi=umi, n_barcodes=300)) as ctx:
+        ctx.submit(synth.make_batch(spec))
+        ctx.run()
+        want = ctx.fetch_coo()
+    got = np.load(tmp_path / "gathered.npz")
+    assert int(outs[0].split()[1]) == len(want["row"]) > 1000
+    for k in want:
+        assert np.array_equal(got[k].view(np.uint8), want[k].view(np.uint8)), (world, scenario, k)
+
+
+def test_a_failing_rank_makes_every_gather_return_peer_error(tmp_path):
+    from vartrix_amd import abi
+    outs = _run_world(4, "fail", tmp_path)
+    assert outs[3] == "aborted"
+    assert outs[:3] == ["error %d" % abi.VTX_E_PEER] * 3, outs

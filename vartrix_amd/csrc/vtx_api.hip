@@ -311,6 +311,7 @@ int fetch_arrays(vtx_ctx* c, size_t n, const void* row, const void* col, const v
     return VTX_OK;
 }
 
+extern "C" void* vtxt_comm_test_table(void** fns);          // vtx_comm_test.hip
 // ---- RCCL, opened on first use ---------------------------------------------------------------------------------
 struct Rccl {
     void* lib = nullptr;
@@ -328,6 +329,17 @@ Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;          // vtx_comm_init is called from several threads at once (one context per GPU)
     std::call_once(once, [] {
+        if (getenv("VTX_COMM_TEST_TRANSPORT")) {
+            // TEST TRANSPORT (vtx_comm_test.hip): ranks = processes that may share one device, payloads over Unix sockets in that
+            // directory — the exchange's own logic with world > 1 on a one-GPU box.  Never set in production.
+            void* f[9];
+            r.lib = vtxt_comm_test_table(f);
+            r.GetUniqueId = (decltype(r.GetUniqueId))f[0]; r.CommInitRank = (decltype(r.CommInitRank))f[1];
+            r.CommDestroy = (decltype(r.CommDestroy))f[2]; r.AllGather = (decltype(r.AllGather))f[3];
+            r.Send = (decltype(r.Send))f[4]; r.Recv = (decltype(r.Recv))f[5]; r.GroupStart = (decltype(r.GroupStart))f[6];
+            r.GroupEnd = (decltype(r.GroupEnd))f[7]; r.GetErrorString = (decltype(r.GetErrorString))f[8];
+            return;
+        }
         for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
             r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
