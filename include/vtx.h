@@ -305,7 +305,7 @@ int vtx_last_timing(vtx_ctx* ctx, vtx_timing* out);
  *   rows 0 .. read_len) band_sweep_kernel builds for n_tasks tasks of the resident batch — lo / hi hold `stride` uint16 per
  *   task (stride >= longest haplotype + 1; empty column: lo 0x7fff, hi 0); status[i] = 0 band written, != 0 declined (the
  *   general kernel takes such a task in vtx_run).  Parity of the BAND, not only of the score it leads to.                   */
-#define VTX_STAGE_UNKNOWN 0        /* VTX_BAND_LEGACY path: band_run_kernel's / band_pending_kernel's certificate */
+#define VTX_STAGE_UNKNOWN 0        /* band_run_kernel's / band_pending_kernel's certificate (cert == ub over all pieces: chains over several diagonals) */
 #define VTX_STAGE_DIAG_CERT 1      /* band_diag_kernel: cert == ub */
 #define VTX_STAGE_REFINE_CERT 2    /* band_refine_kernel: cert == refined ub */
 #define VTX_STAGE_FULL_CHECK 3     /* full-matrix score == certificate (cert <= banded <= full); experiment hook VTX_BAND_CHECK only */

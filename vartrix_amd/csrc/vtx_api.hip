@@ -93,7 +93,7 @@ struct vtx_ctx {
     uint64_t g_nnz = 0;
     uint32_t* h_pin = nullptr;               // pinned words for counters read back asynchronously (a D2H copy into pageable
                                              // memory blocks the host until the stream reaches it)
-    hipEvent_t ev[10] = {};
+    hipEvent_t ev[12] = {};
     std::string err;
     bool submitted = false, ran = false;
     uint32_t n_loci = 0, n_records = 0, n_cell_groups = 0, n_umi_groups = 0, max_hap_len = 0;
@@ -106,7 +106,7 @@ struct vtx_ctx {
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
     bool band_long_lists = false;      // (performance feedback between runs: see vtx_run)
     DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail, d_fail_tmp, d_refine;   // banded flavour
-    DevBuf d_tight, d_tight_pack, d_dband, d_dband_pack, d_stage;                                                 // round 4: tasks with a provisional score (full-matrix check); stage bytes (vtx_fetch_stage)
+    DevBuf d_tight, d_tight_pack, d_dband, d_dband_pack, d_dense, d_stage;                                                 // round 4: tasks with a provisional score (full-matrix check); stage bytes (vtx_fetch_stage)
     bool stage_trace = false, poison = false;                                // test / audit hooks (vtx_set_debug)
     int32_t poison_value = 0;
     DevBuf d_redo, d_redo_cnt;                                               // LUT kernel: records with non-ACGTN bytes
@@ -569,7 +569,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_cnt, &c->d_redo, &c->d_redo_cnt, &c->d_bc_slots, &c->d_bc_hash, &c->d_bc_off, &c->d_bc_bytes,
                       &c->d_raw, &c->d_tags, &c->d_raw_locus, &c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2,
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
-                      &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp, &c->d_refine, &c->d_tight, &c->d_tight_pack, &c->d_dband, &c->d_dband_pack, &c->d_stage};
+                      &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp, &c->d_refine, &c->d_tight, &c->d_tight_pack, &c->d_dband, &c->d_dband_pack, &c->d_dense, &c->d_stage};
     for (DevBuf* b : bufs) b->release();
     c->d_slow_ws.release(); c->d_slow_retry.release();
     DevBuf* gb[] = {&c->d_g_cnt, &c->d_g_row, &c->d_g_col, &c->d_g_alt, &c->d_g_ref, &c->d_g_unk, &c->d_g_val, &c->d_g_refval};
@@ -644,12 +644,15 @@ static int band_reserve(vtx_ctx* c, BandPlan& p, bool quiet) {
     RES(d_poly, ((size_t)p.hard_cap + p.pend_cap) * p.poly_stride * sizeof(uint16_t));
     RES(d_band, (size_t)p.slots * 2 * p.band_stride * sizeof(uint16_t));
     RES(d_hard, ((size_t)p.hard_cap + p.pend_cap) * sizeof(uint32_t));
-    RES(d_over, 2 * (size_t)p.n_tasks * sizeof(uint32_t));      // second chance: what overflows again is appended behind the first list
+    // [0, n): band_run_kernel's overflows (second chance: what overflows again is appended behind the first list, [n, 2n)); round 4:
+    // [n, 2n) = what band_sweep_kernel's first pass declines, behind it what the second declines (at most as many), [n + nB, ..)
+    RES(d_over, 3 * (size_t)p.n_tasks * sizeof(uint32_t));
     RES(d_cnt, 64 * sizeof(uint32_t));
     if (p.gt_bytes) RES(d_fail, 2 * (size_t)p.chunk * sizeof(uint32_t));  // tasks band_diag_kernel leaves to band_run_kernel (as listed, then sorted)
     if (p.gt_bytes) RES(d_refine, (size_t)band_refine_cap(p.chunk) * vtxk_band_refine_words() * sizeof(uint32_t));   // records for band_refine_kernel
     if (p.gt_bytes) RES(d_tight, (size_t)p.chunk * sizeof(uint32_t));       // tasks with a certificate but no verdict ...
     if (p.gt_bytes) RES(d_tight_pack, (size_t)p.chunk * sizeof(uint32_t));  // ... and their bands (one diagonal stretch each: one word)
+    if (p.gt_bytes) RES(d_dense, 2 * (size_t)p.chunk * sizeof(uint32_t));   // tasks for band_sweep_kernel (repeats: as listed, then sorted)
 #undef RES
     return VTX_OK;
 }
@@ -1150,14 +1153,14 @@ int vtx_run(vtx_ctx* c) {
         // the band of every listed task (band_sweep_kernel, tier 0 / 1), one slice of band slots at a time, then the masked DP over
         // the slice (its length — the tasks the sweep did not decline — is read on the device: counters[0]; declined: counters[1])
         auto sweep_slices = [&](int tier, const uint32_t* list, uint32_t n, uint32_t* over_out, uint32_t* counters) -> int {
-            static const int sweep_stats = getenv("VTX_DEBUG") ? 1 : 0;
+            static const bool sweep_stats = getenv("VTX_DEBUG") != nullptr;
             for (uint32_t off = 0; off < n; off += slots) {
                 const uint32_t cnt_s = std::min(slots, n - off);
                 HIP_TRY(c, hipMemsetAsync(counters, 0, sizeof(uint32_t), s));
                 HIP_TRY(c, vtxk_launch_band_sweep(tier, list + off, cnt_s, nullptr, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                                   c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                                   c->d_band.as<uint16_t>(), band_stride, c->d_hard.as<uint32_t>(), over_out,
-                                                  counters, sweep_stats, stage, nullptr, s));
+                                                  counters, sweep_stats ? d_cnt + 56 : nullptr, stage, nullptr, s));
                 HIP_TRY(c, vtxk_launch_sw_banded_dev(kShapes[shape][0], kShapes[shape][1], cnt_s, c->d_hard.as<uint32_t>(), counters,
                                                      c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
                                                      c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_band.as<uint16_t>(), band_stride,
@@ -1167,15 +1170,15 @@ int vtx_run(vtx_ctx* c) {
             return VTX_OK;
         };
         uint32_t resweep_total = 0;
+        bool sweep_used = false;                    // some chunk took the round-4 path
         bool sweep_pending = false;                 // the events of a swept chunk have not been read yet
         auto collect_sweep_times = [&]() -> int {
             if (!sweep_pending) return VTX_OK;
             sweep_pending = false;
             HIP_TRY(c, hipEventSynchronize(c->ev[8]));
             float ms = 0;
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[7], c->ev[5])); check_ms += ms;
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[5], c->ev[8])); sweep_ms += ms;
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[6])); diag_ms += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[7], c->ev[9])); check_ms += ms;     // the one-diagonal bands' masked DP
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[9], c->ev[8])); sweep_ms += ms;     // band_sweep_kernel + its masked DP (the chunk's repeats)
             return VTX_OK;
         };
         for (uint64_t base = 0; base < n_tasks; base += chunk) {
@@ -1213,8 +1216,13 @@ int vtx_run(vtx_ctx* c) {
             const bool sweep_path = !legacy && c->max_hap_len <= vtxk_band_sweep_max_len() && c->max_hap_len > 0;
             uint32_t* tight_list = (sweep_path && !no_tight) ? c->d_tight.as<uint32_t>() : nullptr;
             uint32_t* tight_pack = tight_list ? c->d_tight_pack.as<uint32_t>() : nullptr;
+            // which of the tasks the certificate stages leave skip band_run_kernel (whose piece lists they would overflow) and take
+            // band_sweep_kernel at once: bit = vtxf::Why.  Default: W_MATCHES (4: more than 40 off-diagonal k-mer matches — repeats).
+            // VTX_BAND_DENSE_MASK: experiment knob (0x3be: everything but shape; 0: nothing — band_run_kernel sees every task first).
+            static const uint32_t dense_mask = getenv("VTX_BAND_DENSE_MASK") ? (uint32_t)strtoul(getenv("VTX_BAND_DENSE_MASK"), nullptr, 0) : (1u << 4);
+            uint32_t* dense_list = sweep_path ? c->d_dense.as<uint32_t>() : nullptr;
             if (gt_n && !no_diag) {
-                HIP_TRY(c, hipMemsetAsync(d_cnt + 12, 0, 4 * sizeof(uint32_t), s));   // [12] left, [14] refine records, [15] tasks with a provisional score
+                HIP_TRY(c, hipMemsetAsync(d_cnt + 12, 0, 4 * sizeof(uint32_t), s));   // [12] left for band_run_kernel, [13] for band_sweep_kernel, [14] refine records, [15] tasks with a one-diagonal band
                 // tasks with main pieces only whose bounds do not meet leave a record for band_refine_kernel
                 static const bool no_refine = getenv("VTX_BAND_NO_REFINE") != nullptr;        // experiment / test hook
                 const uint32_t refine_cap = band_refine_cap(chunk);
@@ -1223,9 +1231,10 @@ int vtx_run(vtx_ctx* c) {
                                                            c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                                            c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
                                                            c->d_fail.as<uint32_t>(), refine_list, refine_cap, d_cnt, tasks_per_locus, gt_l0, gt_n,
-                                                           c->d_gtables.as<uint8_t>(), gt_bytes, diag_stats, tight_list, tight_pack, stage, s);
+                                                           c->d_gtables.as<uint8_t>(), gt_bytes, diag_stats, tight_list, tight_pack, stage,
+                                                           dense_list, dense_mask, s);
                 if (e == hipSuccess && sweep_path) {
-                    diag = true; swept = true;
+                    diag = true; swept = true; sweep_used = true;
                     HIP_TRY(c, hipEventRecord(c->ev[6], s));
                     // band_refine_kernel over the records left for it, the full-matrix check over the tasks with a provisional
                     // score: both lists are counted on the device (grids sized for the lists' capacities: a workgroup beyond the
@@ -1266,19 +1275,37 @@ int vtx_run(vtx_ctx* c) {
                                                             c->d_alt.as<int32_t>(), c->max_hap_len, stage, s));
                         ++launches;
                     }
-                    HIP_TRY(c, hipEventRecord(c->ev[5], s));
+                    HIP_TRY(c, hipEventRecord(c->ev[9], s));
                     n_fail = c->h_pin[8];
+                    const uint32_t n_dense = std::min(c->h_pin[9], nt);
                     checked_total += n_tight;
-                    diag_total += nt; diag_left += n_fail;
-                    if (n_fail > 64) {                                  // by task: neighbours share their locus' haplotypes (and the hard list comes out in a fixed order)
+                    diag_total += nt; diag_left += (uint64_t)n_fail + n_dense;
+                    // repeats: band_sweep_kernel (the band of ANY task) + masked DP, sorted by task (neighbours share their locus'
+                    // haplotypes, and the hard list comes out in a fixed order); what it declines waits in d_over[n_tasks ..) for the
+                    // second pass after the last chunk
+                    if (n_dense) {
+                        const uint32_t* dl = dense_list;
+                        if (n_dense > 64) {
+                            const size_t tb = vtxk_sort_keys_u32_temp_bytes(n_dense);
+                            if (c->d_fail_tmp.reserve(tb) == hipSuccess) {
+                                HIP_TRY(c, vtxk_sort_keys_u32(dense_list, dense_list + nt, n_dense, c->d_fail_tmp.p, tb, s));
+                                dl = dense_list + nt;
+                            } else (void)hipGetLastError();
+                        }
+                        if (int rc = sweep_slices(0, dl, n_dense, c->d_over.as<uint32_t>() + n_tasks, d_cnt + 26)) return rc;
+                        swept_total += n_dense;
+                    }
+                    HIP_TRY(c, hipEventRecord(c->ev[8], s));
+                    sweep_pending = true;
+                    // the others: band_run_kernel (task-list mode) below — seeds, chain and the general certificate (a read against the
+                    // other allele of an indel lies on TWO diagonals: cert == ub decides nearly all of those without a DP cell)
+                    if (n_fail > 64) {
                         const size_t tb = vtxk_sort_keys_u32_temp_bytes(n_fail);
                         if (c->d_fail_tmp.reserve(tb) == hipSuccess) {
                             HIP_TRY(c, vtxk_sort_keys_u32(c->d_fail.as<uint32_t>(), c->d_fail.as<uint32_t>() + nt, n_fail, c->d_fail_tmp.p, tb, s));
                             fail_list = c->d_fail.as<uint32_t>() + nt;
                         } else (void)hipGetLastError();
                     }
-                    if (int rc = sweep_slices(0, fail_list, n_fail, c->d_over.as<uint32_t>(), d_cnt)) return rc;
-                    swept_total += n_fail;
                 } else if (e == hipSuccess) {
                     diag = true;
                     HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1316,28 +1343,7 @@ int vtx_run(vtx_ctx* c) {
                     (void)hipGetLastError();
                 }
             }
-            if (swept) {
-                HIP_TRY(c, hipEventRecord(c->ev[8], s));
-                sweep_pending = true;
-                if (base + chunk >= n_tasks) {                              // last chunk: what the sweep declined is complete
-                    HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
-                    HIP_TRY(c, hipStreamSynchronize(s));
-                    // what the first pass declined (log of 128 sections full: satellites) takes the second, 1024 sections; what that
-                    // declines too (bytes outside ACGTN, reads above 255 bases, still more sections) takes the general band kernel
-                    const uint32_t n1 = cnt[1];
-                    if (n1) {
-                        resweep_total = n1;
-                        if (int rc = sweep_slices(1, c->d_over.as<uint32_t>(), n1, c->d_over.as<uint32_t>() + n1, d_cnt + 2)) return rc;
-                        HIP_TRY(c, hipEventRecord(c->ev[8], s));
-                        HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
-                        HIP_TRY(c, hipStreamSynchronize(s));
-                    }
-                    if (int rc = collect_sweep_times()) return rc;
-                    cnt[1] = n1 ? cnt[3] : 0;                                       // tasks for the general kernel: d_over[n1, n1 + cnt[3])
-                    if (cnt[1]) { if (int rc = fallback_start(n1, n1 + cnt[1])) return rc; }
-                }
-                continue;
-            }
+            HIP_TRY(c, hipEventRecord(c->ev[10], s));
             if (!diag || n_fail)
                 HIP_TRY(c, vtxk_launch_band_run(diag ? n_fail : nt, diag ? 0u : (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                                  c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
@@ -1382,11 +1388,12 @@ int vtx_run(vtx_ctx* c) {
             over_before = cnt[1];
             {
                 float ms = 0;
-                HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
+                HIP_TRY(c, hipEventElapsedTime(&ms, swept ? c->ev[10] : c->ev[4], c->ev[5]));
                 band_run_ms += ms;
                 if (diag) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[6])); diag_ms += ms; }
+                if (int rc = collect_sweep_times()) return rc;
             }
-            if (base + chunk >= n_tasks && cnt[1])                     // last chunk: the overflow list is complete
+            if (!sweep_used && base + chunk >= n_tasks && cnt[1])      // last chunk: the overflow list is complete
                 if (int rc = fallback_start(0, cnt[1])) return rc;
             if (cnt[0] > hard_cap) {               // the excess went to the general kernel's list: slots in use = hard_cap
                 cnt[0] = hard_cap;
@@ -1406,6 +1413,29 @@ int vtx_run(vtx_ctx* c) {
             if (int rc = masked_dp(cnt[0], c->d_hard.as<uint32_t>(), c->d_poly.as<uint16_t>(), c->d_band.as<uint16_t>(), slots, s, VTX_STAGE_RUN_DP)) return rc;
             hard_total += cnt[0];
             ++launches;
+            if (sweep_used && base + chunk >= n_tasks) {
+                // last chunk.  What overflowed band_run_kernel's lists (d_over[0, nA)) takes band_sweep_kernel too; then everything
+                // its first pass declined — here and in the chunks' own sweeps: d_over[n_tasks, + nB), counted on the device — takes
+                // the second pass (1024 sections); what that declines as well (bytes outside ACGTN, reads above 255 bases, more
+                // sections still: d_over[n_tasks + nB, + nC)) takes the general band kernel.
+                uint32_t* over = c->d_over.as<uint32_t>();
+                const uint32_t nA = cnt[1];
+                if (nA) {
+                    if (int rc = sweep_slices(0, over, nA, over + n_tasks, d_cnt + 26)) return rc;
+                    swept_total += nA;
+                }
+                uint32_t nB = 0, nC = 0;
+                HIP_TRY(c, hipMemcpyAsync(&nB, d_cnt + 27, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipStreamSynchronize(s));
+                if (nB) {
+                    resweep_total = nB;
+                    if (int rc = sweep_slices(1, over + n_tasks, nB, over + n_tasks + nB, d_cnt + 28)) return rc;
+                    HIP_TRY(c, hipMemcpyAsync(&nC, d_cnt + 29, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipStreamSynchronize(s));
+                }
+                cnt[1] = nC;
+                if (nC) { if (int rc = fallback_start((uint32_t)n_tasks + nB, (uint32_t)n_tasks + nB + nC)) return rc; }
+            }
         }
         fast_overflow = cnt[1];
         if (getenv("VTX_DEBUG")) {
@@ -1561,7 +1591,7 @@ int vtx_debug_bands(vtx_ctx* c, const uint32_t* tasks, uint32_t n_tasks, uint32_
     const int dbg_tier = getenv("VTX_SWEEP_TIER") ? atoi(getenv("VTX_SWEEP_TIER")) : 0;      // (tests: the 1024-section variant)
     DBG_TRY(vtxk_launch_band_sweep(dbg_tier, d_t.as<uint32_t>(), n_tasks, nullptr, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                    c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), d_b.as<uint16_t>(), bs,
-                                   d_h.as<uint32_t>(), d_o.as<uint32_t>(), d_c.as<uint32_t>(), 0, nullptr, dbg_on ? d_d.as<uint32_t>() : nullptr, s));
+                                   d_h.as<uint32_t>(), d_o.as<uint32_t>(), d_c.as<uint32_t>(), nullptr, nullptr, dbg_on ? d_d.as<uint32_t>() : nullptr, s));
     uint32_t cnt[2] = {0, 0};
     DBG_TRY(hipMemcpyAsync(cnt, d_c.p, sizeof cnt, hipMemcpyDeviceToHost, s));
     DBG_TRY(hipStreamSynchronize(s));

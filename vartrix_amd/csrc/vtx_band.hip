@@ -1868,7 +1868,11 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
     const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ fail_list, uint32_t* __restrict__ refine_rec, uint32_t refine_cap, uint32_t* __restrict__ counters,
-    uint32_t stats, uint32_t* __restrict__ tight_list, uint32_t* __restrict__ tight_pack, uint8_t* __restrict__ stage) {
+    uint32_t stats, uint32_t* __restrict__ tight_list, uint32_t* __restrict__ tight_pack, uint8_t* __restrict__ stage,
+    uint32_t* __restrict__ dense_list, uint32_t dense_mask) {
+    // dense_list != nullptr (round 4): a task left for a reason in dense_mask (bit = vtxf::Why; by default W_MATCHES: more than 40
+    // off-diagonal k-mer matches — repeats) goes there (counters[13]): band_run_kernel's piece lists would overflow on it, it takes
+    // band_sweep_kernel directly.
     // tight_list != nullptr (round 4): a task whose off-diagonal matches are all harmless but whose bounds do not meet (or whose
     // generic set overflows) HAS a certificate — the chain is the closed form's, cert <= banded — so it leaves with
     // its band (the (2w + 1)-squares along ONE diagonal stretch: tight_pack[i] = vtxf::band_pack) on tight_list (counters[15]):
@@ -2070,7 +2074,28 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     //      tests over the wavefront like the probes — one queue entry per match, A | T << 8 left in the entry, a short recurrence per
     //      owner — was built and measured: 1.67 ms pooled against 1.7 ms per lane, 18.24 against 18.33 ms per step: not kept.) ----
     const int ns = (int)min(s_cnt[tid], (uint32_t)LaneT::SMAX + 1u);
-    if (live && ns > LaneT::SMAX) { live = false; fail = true; why = vtxf::W_MATCHES; }
+    bool spread = false;
+    if (live && ns > LaneT::SMAX) {
+        live = false; fail = true; why = vtxf::W_MATCHES;
+        // More off-diagonal matches than a lane holds.  Two very different tasks end here: a read against the OTHER allele of an
+        // indel (its second half lies on ONE other diagonal: band_run_kernel's two-piece case, decided by its certificate) and
+        // repeats (matches on many diagonals: band_run_kernel's piece lists overflow, band_sweep_kernel takes them).  Eight of the
+        // matches found so far tell them apart: no diagonal holds four of them -> spread.
+        if (dense_list) {
+            int dg[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const uint32_t w = (uint32_t)ln.s(5 * i); dg[i] = (int)(w & LaneT::YM) - (int)(w >> LaneT::XS); }
+            int mode = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int cnt = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cnt += dg[j] == dg[i] ? 1 : 0;
+                mode = max(mode, cnt);
+            }
+            spread = mode <= 3;
+        }
+    }
     if (live) vtxf::back_sort(ns, ln);
     if ((stats >> 8) == 7) { if (live && ns == 0x7fffffff) counters[40] = 1; return; }            // (profiling aid) ... + the sort
     if (live && !vtxf::back_harmless(fr, ns, ln)) { live = false; fail = true; why = vtxf::W_NOT_HARMLESS; }
@@ -2111,13 +2136,22 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             *my_score = fr.cert;                                      // provisional: a lower bound of the banded score
         }
     }
-    const uint64_t fm = __ballot(fail && !again && !tight);
+    const bool dense = fail && !again && !tight && dense_list != nullptr && ((dense_mask >> why) & 1u) && (why != vtxf::W_MATCHES || spread);
+    const uint64_t dm = __ballot(dense);
+    if (dm) {
+        uint32_t base = 0;
+        const int leader = __ffsll((long long)dm) - 1;
+        if (tid == leader) base = atomicAdd(&counters[13], (uint32_t)__popcll(dm));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (dense) dense_list[base + (uint32_t)__popcll(dm & ((1ull << tid) - 1ull))] = task;
+    }
+    const uint64_t fm = __ballot(fail && !again && !tight && !dense);
     if (fm) {
         uint32_t base = 0;
         const int leader = __ffsll((long long)fm) - 1;
         if (tid == leader) base = atomicAdd(&counters[12], (uint32_t)__popcll(fm));
         base = (uint32_t)__shfl((int)base, leader);
-        if (fail && !again && !tight) fail_list[base + (uint32_t)__popcll(fm & ((1ull << tid) - 1ull))] = task;
+        if (fail && !again && !tight && !dense) fail_list[base + (uint32_t)__popcll(fm & ((1ull << tid) - 1ull))] = task;
     }
     if (fail && !again && (stats & 0xffu)) atomicAdd(&counters[32 + why], 1u);
 }
@@ -2322,7 +2356,7 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
                                             uint32_t* fail_list, uint32_t* refine_rec, uint32_t refine_cap, uint32_t* counters,
                                             uint32_t tasks_per_locus, uint32_t gt_l0, uint32_t n_loci, uint8_t* gtables,
                                             size_t gtables_bytes, int stats, uint32_t* tight_list, uint32_t* tight_pack, uint8_t* stage,
-                                            hipStream_t s) {
+                                            uint32_t* dense_list, uint32_t dense_mask, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
     const uint32_t n_heads = pick_heads(tasks_per_locus, true);
     const size_t tstride = band_table_stride(max_hap, n_heads);
@@ -2336,11 +2370,11 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     if (max_hap <= 255 && !force_wide)
         hipLaunchKernelGGL((band_diag_kernel<4, uint16_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
                            rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, tight_pack, stage);
+                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, tight_pack, stage, dense_list, dense_mask);
     else
         hipLaunchKernelGGL((band_diag_kernel<4, uint32_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
                            rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, tight_pack, stage);
+                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, tight_pack, stage, dense_list, dense_mask);
     return hipGetLastError();
 }
 

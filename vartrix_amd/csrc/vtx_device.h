@@ -66,7 +66,8 @@ hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base, const vtx
                                  const vtx_locus* loci, const uint8_t* read_arena, const uint8_t* hap_arena, uint32_t max_hap,
                                  int32_t* ref_score, int32_t* alt_score, uint32_t* fail_list, uint32_t* refine_rec,
                                  uint32_t refine_cap, uint32_t* counters, uint32_t tasks_per_locus, uint32_t gt_l0, uint32_t n_loci,
-                                 uint8_t* gtables, size_t gtables_bytes, int stats, uint32_t* tight_list, uint32_t* tight_pack, uint8_t* stage, hipStream_t s);
+                                 uint8_t* gtables, size_t gtables_bytes, int stats, uint32_t* tight_list, uint32_t* tight_pack, uint8_t* stage,
+                                 uint32_t* dense_list, uint32_t dense_mask, hipStream_t s);
 uint32_t vtxk_band_refine_words(void);
 hipError_t vtxk_launch_band_refine(const uint32_t* recs, uint32_t n_recs, const vtx_record* records, const uint32_t* rec_locus,
                                    const vtx_locus* loci, const uint8_t* read_arena, uint32_t max_hap, int32_t* ref_score,
@@ -77,7 +78,7 @@ hipError_t vtxk_launch_band_refine(const uint32_t* recs, uint32_t n_recs, const 
 hipError_t vtxk_launch_band_sweep(int tier, const uint32_t* tasks, uint32_t n_tasks, const uint32_t* n_dev, const vtx_record* records,
                                   const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena, const uint8_t* hap_arena,
                                   uint16_t* band, uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list, uint32_t* counters,
-                                  int stats, uint8_t* stage, uint32_t* dbg, hipStream_t s);
+                                  uint32_t* stat_counters, uint8_t* stage, uint32_t* dbg, hipStream_t s);
 uint32_t vtxk_band_sweep_max_len(void);
 hipError_t vtxk_launch_sw_banded_dev(int R, int GL, uint32_t n_cap, const uint32_t* hard, const uint32_t* n_dev,
                                      const vtx_record* records, const uint32_t* rec_locus, const vtx_locus* loci,

@@ -101,7 +101,7 @@ __device__ __forceinline__ uint32_t base_code(uint32_t b) {
 
 // tasks[n_tasks]: task = 2 * record + haplotype.  Every task either gets band slot h = atomicAdd(counters[0]) (hard_list[h] =
 // task, lo at band + h * 2 * band_stride, hi at + band_stride) or, when declined, goes to overflow_list[atomicAdd(counters[1])].
-// stats != 0: counters[48 + reason] counts the declined tasks (1 bytes / lengths, 2 log full, 3 sections).
+// stat_counters != nullptr: stat_counters[reason] counts the declined tasks (1 bytes / lengths, 2 log full, 3 sections).
 // n_dev != nullptr: the list length lives on the device (min(*n_dev, n_tasks); the grid is sized for n_tasks).
 //
 // The sweep's fast path: nearly every lane has at most ONE match per row, and it continues the lane's match of the row before.  The
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
     uint16_t* __restrict__ band, uint32_t band_stride, uint32_t* __restrict__ hard_list,
-    uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters, uint32_t stats, uint8_t* __restrict__ stage,
-    uint32_t* __restrict__ dbg) {
+    uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters, uint32_t stats, uint32_t* __restrict__ stat_counters,
+    uint8_t* __restrict__ stage, uint32_t* __restrict__ dbg) {
     typedef Lay<LOGCAP> L;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (n_dev) { const uint32_t nd = *n_dev; n_tasks = nd < n_tasks ? nd : n_tasks; }
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
         }
     } else if (have && l == 0) {
         overflow_list[obase + (uint32_t)__popcll(dm & below)] = task;
-        if (stats & 0xffu) atomicAdd(&counters[48 + min(decline, 7u)], 1u);
+        if (stat_counters) atomicAdd(&stat_counters[min(decline, 7u)], 1u);
     }
 }
 
@@ -509,8 +509,8 @@ extern "C" hipError_t vtxk_launch_band_sweep(int tier, const uint32_t* tasks, ui
                                              const vtx_record* records,
                                              const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                              const uint8_t* hap_arena, uint16_t* band, uint32_t band_stride, uint32_t* hard_list,
-                                             uint32_t* overflow_list, uint32_t* counters, int stats, uint8_t* stage, uint32_t* dbg,
-                                             hipStream_t s) {
+                                             uint32_t* overflow_list, uint32_t* counters, uint32_t* stat_counters, uint8_t* stage,
+                                             uint32_t* dbg, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
     static const uint32_t ablate = getenv("VTX_SWEEP_ABLATE") ? (uint32_t)atoi(getenv("VTX_SWEEP_ABLATE")) << 8 : 0u;
 #define LAUNCH_SWEEP(CAP)                                                                                          \
@@ -523,7 +523,7 @@ extern "C" hipError_t vtxk_launch_band_sweep(int tier, const uint32_t* tasks, ui
         }                                                                                                          \
         hipLaunchKernelGGL(band_sweep_kernel<CAP>, dim3((n_tasks + 7) / 8), dim3(64), shmem, s, tasks, n_tasks, n_dev, records, \
                            rec_locus, loci, read_arena, hap_arena, band, band_stride, hard_list, overflow_list, counters,      \
-                           (uint32_t)stats | ablate, stage, dbg);                                                  \
+                           ablate, stat_counters, stage, dbg);                                                     \
     }
     if (tier == 0) LAUNCH_SWEEP(128) else LAUNCH_SWEEP(1024)
 #undef LAUNCH_SWEEP
