@@ -248,3 +248,40 @@ def test_config5_full_size_properties():
         rh = bytes(batch.hap_arena[loc["ref_off"]:loc["ref_off"] + loc["ref_len"]])
         ah = bytes(batch.hap_arena[loc["alt_off"]:loc["alt_off"] + loc["alt_len"]])
         assert (oracle.sw_banded(read, rh), oracle.sw_banded(read, ah)) == (int(ref[k]), int(alt[k])), k
+
+
+def test_config3_full_size_stage_audit():
+    """BASELINE.json configs[2] at full size, every alignment audited: the banded and the full flavour run on the
+    device, the stage byte of every one of the 48.6 M banded alignments is fetched, and
+      * every alignment whose banded score differs from its full-matrix score was decided by a DP stage — never by a certificate
+        (cert <= banded <= full: a certificate that equals the upper bound of the FULL score cannot coexist with banded < full);
+      * ALL of those alignments, ALL alignments the certificate stages did not decide, and a 1 % random sample of the records
+        are compared with the oracle (reference call site src/main.rs:898-901; the scores of Scores.ref_score / alt_score, :926-927)."""
+    from vartrix_amd import abi
+    from audit_util import assert_stage_invariant, oracle_scores_of, stage_report
+    spec = synth.config3()
+    batch = synth.make_batch(spec)
+    out = {}
+    for aligner in ("banded", "full"):
+        with lib.Context(default_config(aligner=aligner, scoring_mode="consensus", n_barcodes=spec.n_barcodes)) as ctx:
+            ctx.submit(batch)
+            if aligner == "banded":
+                ctx.set_stage_trace(True)
+                ctx.set_poison(-4242)
+            ctx.run()
+            out[aligner] = ctx.fetch_scores() + ((ctx.fetch_stage(),) if aligner == "banded" else ())
+    rb, ab, stage = out["banded"]
+    rf, af = out["full"]
+    assert not (rb == -4242).any() and not (ab == -4242).any()
+    differ = assert_stage_invariant(stage, (rb, ab), (rf, af), "config 3")
+    by_cert = np.isin(stage, (abi.STAGE_DIAG_CERT, abi.STAGE_REFINE_CERT, abi.STAGE_UNKNOWN))
+    print("config 3: %d alignments, banded != full on %d; stages %s" % (len(stage), int(differ.sum()), stage_report(stage)))
+    assert by_cert.mean() > 0.99                                                  # the headline's premise
+    rng = np.random.default_rng(7)
+    recs = np.unique(np.concatenate([np.nonzero(differ)[0] >> 1, np.nonzero(~by_cert)[0] >> 1,
+                                     rng.choice(batch.n_records, batch.n_records // 100, replace=False)]))
+    ids, oref, oalt = oracle_scores_of(batch, recs, "banded", spec.n_barcodes)
+    bad = np.nonzero((rb[ids] != oref) | (ab[ids] != oalt))[0]
+    assert bad.size == 0, "record %d: device (%d, %d) oracle (%d, %d), stages %s" % (
+        ids[bad[0]], rb[ids[bad[0]]], ab[ids[bad[0]]], oref[bad[0]], oalt[bad[0]], stage[2 * ids[bad[0]]:2 * ids[bad[0]] + 2])
+    print("config 3: %d records (%d alignments) compared with the oracle: all equal" % (len(ids), 2 * len(ids)))

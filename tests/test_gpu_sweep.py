@@ -50,7 +50,7 @@ def bands_vs_oracle(batch, nb, label, max_tasks=6000, tier=0):
             lo, hi, status = ctx.debug_bands(tasks, stride)
     finally:
         os.environ.pop("VTX_SWEEP_TIER", None)
-    log_cap = 1024 if tier else 128
+    log_cap = 1024 if tier else 256
     rec_locus = np.repeat(np.arange(batch.n_loci), batch.loci["rec_count"])
     hb, rb = batch.hap_arena.tobytes(), batch.read_arena.tobytes()
     declined = 0

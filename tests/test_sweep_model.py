@@ -16,7 +16,7 @@ from oracle import oracle
 import stress_batches as SB
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LOGCAP, SECCAP = 128, 28          # vtx_sweep.hip
+LOGCAP, SECCAP = 256, 28          # vtx_sweep.hip
 
 
 @pytest.fixture(scope="module")

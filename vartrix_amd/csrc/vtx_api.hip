@@ -1277,12 +1277,20 @@ int vtx_run(vtx_ctx* c) {
                     }
                     HIP_TRY(c, hipEventRecord(c->ev[9], s));
                     n_fail = c->h_pin[8];
-                    const uint32_t n_dense = std::min(c->h_pin[9], nt);
+                    uint32_t n_dense = std::min(c->h_pin[9], nt);
                     checked_total += n_tight;
                     diag_total += nt; diag_left += (uint64_t)n_fail + n_dense;
                     // repeats: band_sweep_kernel (the band of ANY task) + masked DP, sorted by task (neighbours share their locus'
                     // haplotypes, and the hard list comes out in a fixed order); what it declines waits in d_over[n_tasks ..) for the
                     // second pass after the last chunk
+                    // (a short list of the other tasks is not worth band_run_kernel's launch — a persistent grid: ~1 ms whatever the
+                    // count — and the two host round trips behind it: it joins the repeats, ~25 ns per task)
+                    static const uint32_t run_min = getenv("VTX_BAND_RUN_MIN") ? (uint32_t)strtoul(getenv("VTX_BAND_RUN_MIN"), nullptr, 10) : 65536u;
+                    if (n_fail && n_fail < run_min && (uint64_t)n_dense + n_fail <= nt) {
+                        HIP_TRY(c, hipMemcpyAsync(dense_list + n_dense, c->d_fail.as<uint32_t>(), (size_t)n_fail * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+                        n_dense += n_fail;
+                        n_fail = 0;
+                    }
                     if (n_dense) {
                         const uint32_t* dl = dense_list;
                         if (n_dense > 64) {
@@ -1295,10 +1303,6 @@ int vtx_run(vtx_ctx* c) {
                         if (int rc = sweep_slices(0, dl, n_dense, c->d_over.as<uint32_t>() + n_tasks, d_cnt + 26)) return rc;
                         swept_total += n_dense;
                     }
-                    HIP_TRY(c, hipEventRecord(c->ev[8], s));
-                    sweep_pending = true;
-                    // the others: band_run_kernel (task-list mode) below — seeds, chain and the general certificate (a read against the
-                    // other allele of an indel lies on TWO diagonals: cert == ub decides nearly all of those without a DP cell)
                     if (n_fail > 64) {
                         const size_t tb = vtxk_sort_keys_u32_temp_bytes(n_fail);
                         if (c->d_fail_tmp.reserve(tb) == hipSuccess) {
@@ -1306,6 +1310,10 @@ int vtx_run(vtx_ctx* c) {
                             fail_list = c->d_fail.as<uint32_t>() + nt;
                         } else (void)hipGetLastError();
                     }
+                    HIP_TRY(c, hipEventRecord(c->ev[8], s));
+                    sweep_pending = true;
+                    // the others: band_run_kernel (task-list mode) below — seeds, chain and the general certificate (a read against the
+                    // other allele of an indel lies on TWO diagonals: cert == ub decides nearly all of those without a DP cell)
                 } else if (e == hipSuccess) {
                     diag = true;
                     HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1354,8 +1362,13 @@ int vtx_run(vtx_ctx* c) {
                                                  tasks_per_locus, gt_l0, gt_n, gt_n ? c->d_gtables.as<uint8_t>() : nullptr, gt_bytes,
                                                  diag ? fail_list : nullptr, c->band_long_lists ? 1 : 0, s));
             HIP_TRY(c, hipEventRecord(c->ev[5], s));                  // (complete once the read-back below is: no synchronisation of its own)
-            HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
+            const bool run_skipped = swept && n_fail == 0;             // nothing went to band_run_kernel: its counters are what they were
+            if (run_skipped) {
+                cnt[0] = 0; cnt[11] = 0; cnt[1] = over_before;
+            } else {
+                HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipStreamSynchronize(s));
+            }
             // (task-list mode runs the 15-entry variant: nothing to give a second chance to)
             const bool short_lists = !diag && gt_n && vtxk_band_second_chance(tasks_per_locus, c->band_long_lists ? 1 : 0);
             if (short_lists && nt >= (1u << 20)) {
@@ -1388,10 +1401,12 @@ int vtx_run(vtx_ctx* c) {
             over_before = cnt[1];
             {
                 float ms = 0;
-                HIP_TRY(c, hipEventElapsedTime(&ms, swept ? c->ev[10] : c->ev[4], c->ev[5]));
-                band_run_ms += ms;
+                if (!run_skipped) {
+                    HIP_TRY(c, hipEventElapsedTime(&ms, swept ? c->ev[10] : c->ev[4], c->ev[5]));
+                    band_run_ms += ms;
+                    if (int rc = collect_sweep_times()) return rc;
+                }
                 if (diag) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[6])); diag_ms += ms; }
-                if (int rc = collect_sweep_times()) return rc;
             }
             if (!sweep_used && base + chunk >= n_tasks && cnt[1])      // last chunk: the overflow list is complete
                 if (int rc = fallback_start(0, cnt[1])) return rc;
@@ -1427,6 +1442,7 @@ int vtx_run(vtx_ctx* c) {
                 uint32_t nB = 0, nC = 0;
                 HIP_TRY(c, hipMemcpyAsync(&nB, d_cnt + 27, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                 HIP_TRY(c, hipStreamSynchronize(s));
+                if (int rc = collect_sweep_times()) return rc;
                 if (nB) {
                     resweep_total = nB;
                     if (int rc = sweep_slices(1, over + n_tasks, nB, over + n_tasks + nB, d_cnt + 28)) return rc;

@@ -45,9 +45,9 @@ static_assert(K == 6 && W == 20 && VTX_REF_MATCH == 1 && VTX_REF_GAP_OPEN == -5 
               "band_sweep_kernel's sdpkpp is written for k = 6, match 1, gap -5 / -1 (src/main.rs:33-38, :899)");
 constexpr int SECCAP = 28;           // sections of the best chain (a 150-base read chains at most 25 six-mers end to end)
 constexpr int MAXLEN = 255;          // read / haplotype bases (one byte per coordinate in the packed words)
-// per-task LDS (32-bit words).  LOGCAP = sections a task may open: 128 for the first pass (real sequence: p99 55; 4.1 KB per task,
+// per-task LDS (32-bit words).  LOGCAP = sections a task may open: 256 for the first pass (real sequence: p99 55; 4.8 KB per task,
 // four wavefronts per CU), 1024 for the second pass over what the first declined (satellites, tandem repeats over two letters:
-// hundreds of dominated pieces whose every match opens a section; 7.6 KB per task, two wavefronts per CU).
+// hundreds of dominated pieces whose every match opens a section; 7.9 KB per task, two wavefronts per CU).
 template <int LOGCAP>
 struct Lay {
     static constexpr int O_RING = 0;            // 8 rows x 256 dp bytes; after the sweep: rmin[256], rmax[256]
@@ -504,7 +504,8 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
     }
 }
 
-// tier 0: 128 sections per task (first pass); tier 1: 1024 (second pass over the first's log overflows)
+// tier 0: 256 sections per task (first pass: 4.8 KB of LDS per task, still four wavefronts per CU); tier 1: 1024 (second pass over
+// the first's log overflows: 7.9 KB per task, two wavefronts per CU)
 extern "C" hipError_t vtxk_launch_band_sweep(int tier, const uint32_t* tasks, uint32_t n_tasks, const uint32_t* n_dev,
                                              const vtx_record* records,
                                              const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
@@ -525,7 +526,7 @@ extern "C" hipError_t vtxk_launch_band_sweep(int tier, const uint32_t* tasks, ui
                            rec_locus, loci, read_arena, hap_arena, band, band_stride, hard_list, overflow_list, counters,      \
                            ablate, stat_counters, stage, dbg);                                                     \
     }
-    if (tier == 0) LAUNCH_SWEEP(128) else LAUNCH_SWEEP(1024)
+    if (tier == 0) LAUNCH_SWEEP(256) else LAUNCH_SWEEP(1024)
 #undef LAUNCH_SWEEP
     return hipGetLastError();
 }
