@@ -47,7 +47,7 @@ VALU_PEAK_TOPS = 39.3          # packed 16-bit VALU ops issue at 4 cycles / wave
                                # lanes/clk x 2.4 GHz (measured 38.7, profiles/r01_valu_peak_microbench.txt)
 OPS_PER_CELL_PAIR = 9          # packed VALU ops per DP cell pair of the LUT / duo DP kernels
 KERNEL_SOURCES = ("vartrix_amd/csrc/vtx_band.hip", "vartrix_amd/csrc/vtx_kernels.hip", "vartrix_amd/csrc/vtx_api.hip",
-                  "vartrix_amd/csrc/vtx_fast_core.h")
+                  "vartrix_amd/csrc/vtx_fast_core.h", "vartrix_amd/csrc/vtx_sweep.hip")
 SIMDS = 256 * 4                # per chip
 NOMINAL_GHZ = 2.4
 
@@ -408,7 +408,7 @@ def main():
                                            "rocprofv3 --pmc passes; the x2 is calibrated for this kernel's 8-byte scattered loads "
                                            "(profiles/r03_fetch_calibration.json: every request is a 128-byte line tallied at 64)",
                          "whole_sw_stage": {"kernels": ("sw_full_duo_kernel" if not banded else
-                                                        "band_tables + band_diag + band_refine + sw_banded<full> (check) + band_sweep + sw_banded kernels")
+                                                        "band_tables + band_diag + band_refine + band_run (+ pending) + band_sweep + sw_banded (band-masked DP) kernels")
                                             + " (%d launches)" % launches, "ms": sw_avg_ms,
                                             "achieved": alg_bytes / (sw_avg_ms * 1e-3) / 1e9},
                          "note": "integer mask / chain / bound work: neither HBM nor MFMA binds it (86 B per alignment); the HBM "

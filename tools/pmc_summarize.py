@@ -59,7 +59,7 @@ def main():
     import hashlib
     h = hashlib.sha256()
     for rel in ("vartrix_amd/csrc/vtx_band.hip", "vartrix_amd/csrc/vtx_kernels.hip", "vartrix_amd/csrc/vtx_api.hip",
-                "vartrix_amd/csrc/vtx_fast_core.h"):
+                "vartrix_amd/csrc/vtx_fast_core.h", "vartrix_amd/csrc/vtx_sweep.hip"):
         h.update(open(os.path.join(root, rel), "rb").read())
     digest = {"source_hash": h.hexdigest()[:16], "from": os.path.basename(dst),
               "method": "rocprofv3 --pmc, one counter group per pass (FETCH_SIZE and WRITE_SIZE in separate passes; read bytes = "

@@ -1027,10 +1027,16 @@ int vtx_run(vtx_ctx* c) {
     float band_run_ms = 0;
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
     if (c->cfg.aligner == VTX_ALIGNER_BANDED && nr) {
-        // Banded flavour.  Per chunk of tasks (task = 2*record + hap): band_run_kernel (seeds, chain, DP-free
-        // certificate: writes the score of every certified task) -> hard list -> expand -> band-masked DP writes
-        // the hard scores.  Tasks band_run_kernel cannot hold accumulate in ONE overflow list that the general
-        // band kernel processes after the last chunk (a launch of a handful of serial lanes costs ~2 ms).
+        // Banded flavour.  Per chunk of tasks (task = 2*record + hap), round 4 (the stages are described in vtx_band.hip's header):
+        // tables -> band_diag_kernel (+ band_refine_kernel): scores of the certified tasks, and three lists — tasks whose band is one
+        // diagonal stretch (masked DP straight from one word), repeats (band_sweep_kernel + masked DP), the others (band_run_kernel:
+        // seeds, chain, general certificate; its hard list -> expand -> masked DP).  What overflows band_run_kernel's lists joins the
+        // repeats after the last chunk; what band_sweep_kernel declines twice takes the general band kernel (side stream).
+        // Counters (d_cnt, 64 words, zeroed once per run unless noted): [0] hard / [1] overflow / [2..7] reasons / [10] / [11] pending of
+        // band_run_kernel (0 and 11 per chunk); [8], [9] general kernel; [12] tasks for band_run_kernel, [13] for band_sweep_kernel,
+        // [14] refine records, [15] one-diagonal bands (12..15 per chunk); [16..23] band_run_kernel's block counters; [24] full-matrix
+        // check; [26] / [27] hard (per slice) / declined of the sweep's first pass, [28] / [29] of its second; [32..47] reasons of
+        // band_diag_kernel; [56..63] reasons of band_sweep_kernel.
         BandPlan bp = band_plan(nr, c->n_loci, c->max_hap_len);
         if (int rc = band_reserve(c, bp, false)) return rc;
         const uint64_t n_tasks = bp.n_tasks;
@@ -1039,7 +1045,7 @@ int vtx_run(vtx_ctx* c) {
         const size_t gt_bytes = bp.gt_bytes;
         const bool gt_chunked = gt_bytes && bp.gt_loci < c->n_loci;
         uint32_t fast_overflow = 0;
-        uint32_t* d_cnt = c->d_cnt.as<uint32_t>();        // [0] hard, [1] overflow, [2..7] reasons; [8],[9] general kernel; [10] stats; [11] pending
+        uint32_t* d_cnt = c->d_cnt.as<uint32_t>();
         int shape = 0;
         while ((uint32_t)(kShapes[shape][0] * kShapes[shape][1]) < c->max_read_len) ++shape;
         // src == nullptr: the band slots already hold arrays (or the full-matrix marker), one slot per task

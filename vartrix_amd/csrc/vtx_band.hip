@@ -2,6 +2,15 @@
 // (bio 0.30.0 banded::Aligner::local as restated in oracle/vtx_oracle.c; reference call site
 // src/main.rs:899-901 with K = 6, W = 20, src/main.rs:33-34).
 //
+// The banded flavour's pipeline (vtx_api.hip: vtx_run), round 4:
+//   band_tables_kernel -> band_diag_kernel (+ band_refine_kernel): the certificate of a task whose alignment lives on ONE diagonal;
+//   what they leave: (a) with every off-diagonal match harmless but bounds apart: its band IS one diagonal stretch — the band-masked
+//   DP expands it from one word (sw_banded_kernel<.., 2>); (b) repeats (more than 40 off-diagonal matches spread over many
+//   diagonals): band_sweep_kernel (vtx_sweep.hip: the band of ANY task) + band-masked DP; (c) the others (a read against the other
+//   allele of an indel: two diagonals): band_run_kernel's general certificate below, its hard tasks to the masked DP, its list
+//   overflows to band_sweep_kernel; (d) what band_sweep_kernel declines (bytes outside ACGTN, more than 255 bases, more than
+//   1024 sections): band_coop_kernel / band_kernel, the literal general path.
+//
 //   band_run_kernel    one lane per (record, haplotype) task, k-mer tables of the haplotypes shared in LDS:
 //                      seeding (exact 6-mer matches as diagonal pieces), sdpkpp chaining over the pieces,
 //                      traceback to the anchor staircase, and the DP-FREE CERTIFICATE below.  Certified
