@@ -865,7 +865,8 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     // reads are not copied by the filter pass: it notes where each kept read's packed bases lie (the window's bytes stay
     // put until the parse is over) and the second pass decodes them straight into the global arena
     struct Decode { const unsigned char* sq; uint32_t l_seq; uint32_t off; };
-    struct WorkerOut { std::vector<Hit> hits; std::vector<Decode> dec; uint64_t reads_size = 0; std::string tags; vtxh_metrics m{}; std::string err; uint64_t rbase = 0; };
+    // (one per worker, written on every record: each on its own cache lines, or the workers fight over them)
+    struct alignas(128) WorkerOut { std::vector<Hit> hits; std::vector<Decode> dec; uint64_t reads_size = 0; std::string tags; vtxh_metrics m{}; std::string err; uint64_t rbase = 0; int32_t hint_tid = -1; size_t hint_hi = 0; };
     ByteBuf& reads = P->read_arena;
     auto process = [&](const unsigned char* r, uint32_t bs, WorkerOut& o, std::vector<uint32_t>& hits) -> bool {
         const int32_t tid = rdi32(r);
@@ -889,8 +890,20 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
         // loci of this contig with start < endpos && end > pos, in VCF-independent (start) order
         const auto& iv = by_tid[(size_t)tid];
         hits.clear();
-        size_t hi = (size_t)(std::lower_bound(iv.begin(), iv.end(), endpos,
-                                              [](const Interval& x, int64_t e) { return x.start < e; }) - iv.begin());
+        // hi = first interval with start >= endpos.  Records come in coordinate order, so the answer is almost always within
+        // a few intervals of the previous record's: walk from there, binary search only after a long hop.
+        size_t hi;
+        {
+            size_t h = o.hint_tid == tid ? std::min(o.hint_hi, iv.size()) : iv.size() + 1;
+            int steps = 0;
+            if (h <= iv.size()) {
+                while (h < iv.size() && iv[h].start < endpos && steps < 16) { ++h; ++steps; }
+                while (h > 0 && iv[h - 1].start >= endpos && steps < 16) { --h; ++steps; }
+            }
+            if (h > iv.size() || steps >= 16)
+                h = (size_t)(std::lower_bound(iv.begin(), iv.end(), endpos, [](const Interval& x, int64_t e) { return x.start < e; }) - iv.begin());
+            hi = h; o.hint_tid = tid; o.hint_hi = h;
+        }
         for (size_t k = hi; k-- > 0;) {
             if (iv[k].start + max_span[(size_t)tid] <= pos) break;
             if (iv[k].end > pos) hits.push_back(iv[k].locus);
@@ -942,7 +955,9 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     std::vector<size_t> rec_offs;
     // every window's worker outputs go to the global arrays at prefix offsets (thread order = BAM order), copied by the
     // workers themselves
-    std::vector<WorkerOut> outs((size_t)threads);
+    // a window is cut into more slices than workers and the workers take slices as they come (a worker that shares its core
+    // with the indexing thread, or was descheduled, does not hold the window up); slice order = BAM order
+    std::vector<WorkerOut> outs((size_t)threads * (threads > 1 ? 4 : 1));
     ByteBuf hit_store;                         // Hit[]: every surviving (read, locus) pair, BAM order, offsets into the global arenas
     size_t n_hits = 0;
     ByteBuf& tag_store = P->tag_arena;         // raw: barcode + UMI bytes for the device; cooked: UMI bytes until the ids are assigned
@@ -984,20 +999,28 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     std::vector<size_t> pend_offs;
     int parse_rc = VTX_OK;
     std::string parse_msg;
+    double t_index_s = 0, t_parse_s = 0, t_filter_s = 0;               // (VTXH_PROFILE: the serial record index against the parallel parse it overlaps)
     auto parse_pending = [&]() {
         const size_t nrec = pend_offs.size();
         if (!nrec) return;
+        const auto t_p0 = std::chrono::steady_clock::now();
+        struct Acc { double& d; std::chrono::steady_clock::time_point t0; ~Acc() { d += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } acc{t_parse_s, t_p0};
         const unsigned char* pend_base = pend_detached ? pend_store.data() : buf.data();
-        pool.run([&](size_t t) {
-            WorkerOut& o = outs[t];
-            o.hits.clear(); o.dec.clear(); o.reads_size = 0; o.tags.clear(); o.m = vtxh_metrics{}; o.err.clear();
+        const size_t n_slices = outs.size();
+        std::atomic<size_t> next_slice{0};
+        pool.run([&](size_t) {
             std::vector<uint32_t> hits;
-            for (size_t k = nrec * t / (size_t)threads, e = nrec * (t + 1) / (size_t)threads; k < e; ++k) {
-                const unsigned char* rp = pend_base + pend_offs[k];
-                if (!process(rp + 4, rd32(rp), o, hits)) { if (o.err.empty()) o.err = "one window of the BAM holds more than 4 GiB of read bases"; return; }
+            for (size_t c; (c = next_slice.fetch_add(1)) < n_slices;) {
+                WorkerOut& o = outs[c];
+                o.hits.clear(); o.dec.clear(); o.reads_size = 0; o.tags.clear(); o.m = vtxh_metrics{}; o.err.clear();
+                for (size_t k = nrec * c / n_slices, e = nrec * (c + 1) / n_slices; k < e; ++k) {
+                    const unsigned char* rp = pend_base + pend_offs[k];
+                    if (!process(rp + 4, rd32(rp), o, hits)) { if (o.err.empty()) o.err = "one window of the BAM holds more than 4 GiB of read bases"; break; }
+                }
             }
         });
-        std::vector<uint64_t> tbase((size_t)threads), hbase((size_t)threads);
+        t_filter_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_p0).count();
+        std::vector<uint64_t> tbase(n_slices), hbase(n_slices);
         uint64_t rtotal = reads.size(), ttotal = tag_store.size(), htotal = n_hits;
         for (size_t t = 0; t < outs.size(); ++t) {
             WorkerOut& o = outs[t];
@@ -1013,7 +1036,9 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
             !hit_store.grow((size_t)(htotal - n_hits) * sizeof(Hit))) { parse_rc = VTX_E_NOMEM; parse_msg = "out of memory growing the read arenas"; return; }
         n_hits = (size_t)htotal;
         Hit* all = (Hit*)hit_store.data();
-        pool.run([&](size_t t) {
+        next_slice = 0;
+        pool.run([&](size_t) {
+          for (size_t t; (t = next_slice.fetch_add(1)) < n_slices;) {
             const WorkerOut& o = outs[t];
             for (const Decode& d : o.dec) {                                                  // rec.seq().as_bytes() :896
                 unsigned char* dst = reads.data() + o.rbase + d.off;
@@ -1027,6 +1052,7 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
                 h.roff = o.rbase + h.rr.read_off; h.toff = tbase[t];
                 dst[k] = h;
             }
+          }
         });
         pend_offs.clear();
         pend_begin = SIZE_MAX; pend_detached = false;
@@ -1061,6 +1087,7 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
         if (refill_failed) return fail(VTX_E_INVAL, "%s: a BGZF block does not inflate (or out of memory)", a->bam);
         ph.mark("inflate");
         if (!pend_offs.empty()) parse_thread = std::thread(parse_pending);      // ... beside the indexing below
+        const auto t_idx0 = std::chrono::steady_clock::now();
         rec_offs.clear();
         size_t p = buf_pos;
         bool all_served = false;
@@ -1091,6 +1118,7 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
             __builtin_prefetch(buf.data() + p + 8 * (4 + (size_t)bs));      // records are of similar size: the chain is predictable
             __builtin_prefetch(buf.data() + p + 8 * (4 + (size_t)bs) + 64);
         }
+        t_index_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_idx0).count();
         if (!finish_parse()) return fail(parse_rc, "%s: %s", a->bam, parse_msg.c_str());
         const bool eof = next_block >= blocks.size();
         if (rec_offs.empty() && (all_served || jump_pending)) {
@@ -1113,6 +1141,7 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     }
     parse_pending();                                   // the last window
     if (parse_rc != VTX_OK) return fail(parse_rc, "%s: %s", a->bam, parse_msg.c_str());
+    if (getenv("VTXH_PROFILE")) fprintf(stderr, "[vtxh]   record index %.3f s (one thread), parse %.3f s (%d threads; filter pass %.3f s), side by side\n", t_index_s, t_parse_s, threads, t_filter_s);
     P->blocks_inflated = n_inflated; P->blocks_total = blocks.size(); P->index_jumps = n_jumps;
 
     // ---- group the hits by locus: stable counting sort (hits are in BAM order, so every locus keeps it); thread t owns the
