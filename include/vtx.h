@@ -304,7 +304,11 @@ int vtx_last_timing(vtx_ctx* ctx, vtx_timing* out);
  * vtx_debug_bands: the band (banded::Aligner's Band: per column of the DP matrix the row range [lo, hi), columns 0 .. hap_len,
  *   rows 0 .. read_len) band_sweep_kernel builds for n_tasks tasks of the resident batch — lo / hi hold `stride` uint16 per
  *   task (stride >= longest haplotype + 1; empty column: lo 0x7fff, hi 0); status[i] = 0 band written, != 0 declined (the
- *   general kernel takes such a task in vtx_run).  Parity of the BAND, not only of the score it leads to.                   */
+ *   general kernel takes such a task in vtx_run).  Parity of the BAND, not only of the score it leads to.
+ * vtx_debug_tables: the haplotype k-mer tables (the device form of the reference's per-haplotype hash index, bio 0.30.0
+ *   sparse::hash_kmers as called from banded::Aligner::local, src/main.rs:898-901) the last banded vtx_run left in global
+ *   memory: *bytes = their size (0: that run kept its tables in LDS), min(cap, *bytes) bytes are copied to dst (dst may be
+ *   null with cap 0).  Lets a test compare two ways of BUILDING the tables byte for byte (VTX_BAND_TABLES_V1).           */
 #define VTX_STAGE_UNKNOWN 0        /* band_run_kernel's / band_pending_kernel's certificate (cert == ub over all pieces: chains over several diagonals) */
 #define VTX_STAGE_DIAG_CERT 1      /* band_diag_kernel: cert == ub */
 #define VTX_STAGE_REFINE_CERT 2    /* band_refine_kernel: cert == refined ub */
@@ -321,6 +325,7 @@ int vtx_last_timing(vtx_ctx* ctx, vtx_timing* out);
 int vtx_set_debug(vtx_ctx* ctx, int key, int64_t value);
 int vtx_fetch_stage(vtx_ctx* ctx, uint8_t* stage);
 int vtx_debug_bands(vtx_ctx* ctx, const uint32_t* tasks, uint32_t n_tasks, uint32_t stride, uint16_t* lo, uint16_t* hi, uint8_t* status);
+int vtx_debug_tables(vtx_ctx* ctx, void* dst, uint64_t cap, uint64_t* bytes);
 
 /* Number of DP cells the last vtx_run evaluated (sum over records and both
  * haplotypes of rows x columns actually computed) — the roofline numerator.  */

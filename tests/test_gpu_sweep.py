@@ -213,3 +213,67 @@ def test_hooks_give_the_same_scores(hook):
             print(hook, on, p.stderr.strip().replace("\n", " | "))
             res.append(np.load(path))
     assert np.array_equal(res[0], res[1])
+
+
+def _tables_and_scores(batch, nb):
+    with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb)) as ctx:
+        ctx.submit(batch)
+        ctx.run()
+        return ctx.debug_tables(), ctx.fetch_scores()
+
+
+def _table_layout(max_hap, n_heads):
+    """vtx_fast_core.h: tab_bytes_off .. tab_stride."""
+    bytes_off = max_hap * 8 + n_heads * 2
+    fb_off = bytes_off + max_hap + 8
+    uq_off = (fb_off + max_hap + 8 + 3) & ~3
+    pb_off = uq_off + 4 * (6 + (max_hap + 31) // 32 + 8)
+    return bytes_off, fb_off, uq_off, pb_off, (pb_off + 512 + 15) & ~15
+
+
+def _defined_bytes(tables, batch, n_heads=1024):
+    """The bytes of the tables that MEAN something (entries of existing k-mers, head words, haplotype and flag bytes, the two
+    bitmaps), table by table; the gaps between them are whatever the LDS held."""
+    nl = batch.n_loci
+    stride = len(tables) // (2 * nl)
+    longest = int(max(batch.loci["ref_len"].max(), batch.loci["alt_len"].max()))
+    max_hap = next(m for m in range(longest, longest + 64) if _table_layout(m, n_heads)[4] == stride)
+    bytes_off, fb_off, uq_off, pb_off, _ = _table_layout(max_hap, n_heads)
+    out = []
+    for t in range(2 * nl):
+        tb = tables[t * stride:(t + 1) * stride]
+        hn = int(batch.loci["alt_len" if t & 1 else "ref_len"][t >> 1])
+        nk = max(hn - 5, 0)
+        out += [tb[:8 * nk], tb[max_hap * 8:bytes_off], tb[bytes_off:bytes_off + hn], tb[fb_off:fb_off + hn], tb[uq_off:pb_off + 512]]
+    return np.concatenate(out)
+
+
+def test_table_kernel_against_round3s():
+    """band_tables_kernel (a table per wavefront, the hash chains linked by all 64 lanes: rounds of 64 positions, ds_max per bucket
+    slot) must leave the bytes round 3's kernel left (VTX_BAND_TABLES_V1=1: a locus per wavefront, serial insertion) — on random
+    sequence (one trip per round), on repeats (a bucket with many k-mers inside one round: as many trips), on real sequence, on
+    haplotypes of one repeated unit."""
+    cases = list(SB.synthetic_batches(per_model=1, n_loci=120, reads=8))[:3]
+    cases += list(SB.repeat_rich_batches(trials=4, loci=60, reads=6, pad_range=(60, 120)))
+    cases += list(SB.real_sequence_batches(trials=1, n_loci=200, reads=6))
+    haps = [(b"A" * 201, b"A" * 100 + b"C" + b"A" * 100), (b"AC" * 100 + b"A", b"AC" * 50 + b"T" + b"AC" * 50),
+            (b"ACG" * 67, b"ACG" * 33 + b"T" + b"ACG" * 33), (b"ACGTN" * 5 + b"\x90" + b"ACGGT" * 20, b"ACGTTGCA" * 12)]
+    rds = [[(0, 0, h[0][20:170])] * 4 for h in haps]
+    cases.append(("haplotypes of one repeated unit, a byte above 0x7f", SB.manual_batch(haps, rds, 10), 10))
+    checked = 0
+    for label, batch, nb in cases:
+        os.environ.pop("VTX_BAND_TABLES_V1", None)
+        tp, sp = _tables_and_scores(batch, nb)
+        os.environ["VTX_BAND_TABLES_V1"] = "1"
+        try:
+            ts, ss = _tables_and_scores(batch, nb)
+        finally:
+            os.environ.pop("VTX_BAND_TABLES_V1", None)
+        assert len(tp) == len(ts)
+        if len(tp) == 0:
+            continue                                     # (this shape keeps its tables in LDS: nothing to compare)
+        dp, ds = _defined_bytes(tp, batch), _defined_bytes(ts, batch)
+        assert np.array_equal(dp, ds), "%s: tables differ (%d of %d defined bytes)" % (label, int((dp != ds).sum()), len(dp))
+        assert np.array_equal(sp[0], ss[0]) and np.array_equal(sp[1], ss[1]), label
+        checked += 1
+    assert checked >= 5

@@ -105,6 +105,7 @@ struct vtx_ctx {
     DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
     bool band_long_lists = false;      // (performance feedback between runs: see vtx_run)
+    uint64_t gt_used = 0;      // bytes of d_gtables the last banded run's table kernel wrote (vtx_debug_tables)
     DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail, d_fail_tmp, d_refine;   // banded flavour
     DevBuf d_tight, d_tight_pack, d_dband, d_dband_pack, d_dense, d_stage;                                                 // round 4: tasks with a provisional score (full-matrix check); stage bytes (vtx_fetch_stage)
     bool stage_trace = false, poison = false;                                // test / audit hooks (vtx_set_debug)
@@ -1204,6 +1205,7 @@ int vtx_run(vtx_ctx* c) {
                 gt_n = ends[1] - ends[0] + 1;
                 if (gt_n > bp.gt_loci) gt_n = 0;              // does not fit after all: tables in LDS for this chunk
             }
+            c->gt_used = (gt_n && bp.gt_loci) ? (uint64_t)gt_n * (gt_bytes / bp.gt_loci) : 0;     // (gt_bytes = gt_loci x bytes per locus)
             HIP_TRY(c, hipEventRecord(c->ev[4], s));
             // Stage 1 (tables in global memory): band_diag_kernel decides the tasks whose alignment lives on one diagonal
             // (vtx_fast_core.h) and lists the others; band_run_kernel then takes that LIST instead of the whole range.
@@ -1586,6 +1588,20 @@ int vtx_fetch_stage(vtx_ctx* c, uint8_t* stage) {
     if (c->n_records && !stage) return fail(c, VTX_E_INVAL, "vtx_fetch_stage: null output");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     if (c->n_records) HIP_TRY(c, hipMemcpy(stage, c->d_stage.p, 2 * (size_t)c->n_records, hipMemcpyDeviceToHost));
+    return VTX_OK;
+}
+
+int vtx_debug_tables(vtx_ctx* c, void* dst, uint64_t cap, uint64_t* bytes) {
+    if (!c || !bytes) return VTX_E_INVAL;
+    *bytes = 0;
+    if (!c->submitted) return fail(c, VTX_E_STATE, "vtx_debug_tables: no batch submitted");
+    if (cap && !dst) return fail(c, VTX_E_INVAL, "vtx_debug_tables: null destination");
+    *bytes = c->gt_used;
+    const size_t n = (size_t)std::min<uint64_t>(cap, c->gt_used);
+    if (!n) return VTX_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(dst, c->d_gtables.p, n, hipMemcpyDeviceToHost));
     return VTX_OK;
 }
 

@@ -1247,9 +1247,10 @@ __device__ __forceinline__ void build_tables(uint8_t* tables, uint32_t n_tab, ui
         __syncthreads();
 }
 
-// One workgroup (one wavefront) per locus of [l0, l0 + n_loci): both tables in LDS, then copied to
+// Round 3's table kernel, kept as the REFERENCE of band_tables_kernel (further down) under VTX_BAND_TABLES_V1=1: one workgroup
+// (one wavefront) per locus of [l0, l0 + n_loci): both tables in LDS (build_tables), then copied to
 // gtables[(locus - l0) * 2 * table_stride].
-__global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __restrict__ loci, uint32_t l0, uint32_t n_loci,
+__global__ __launch_bounds__(64) void band_tables_v1_kernel(const vtx_locus* __restrict__ loci, uint32_t l0, uint32_t n_loci,
                                                          const uint8_t* __restrict__ hap_arena, uint32_t max_hap,
                                                          uint32_t table_stride, uint32_t n_heads, uint8_t* __restrict__ gtables) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -1866,6 +1867,109 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// =============================================================================================
+// band_tables_kernel (round 4) — the k-mer tables of loci [l0, l0 + n_loci) in global memory, the same bytes build_tables leaves
+// (layout: vtx_fast_core.h, Tab), ONE TABLE per wavefront instead of a locus: half the LDS per wavefront (twice the tables in
+// flight per CU: the kernel is a chain of dependent LDS / global round trips per table, and the wavefronts in flight are what
+// hides them), and no phase that runs on two lanes:
+//   fill    one unaligned 8-byte load per position (bytes 0-5 = the k-mer) instead of six byte loads;
+//   link    build_tables inserts the positions one by one in descending order (so that every chain ascends): ~185 dependent LDS
+//           round trips on one lane.  Here: rounds of 64 consecutive positions, last round first; inside a round only k-mers of
+//           the SAME bucket have to keep their order, so on every trip the largest pending position of each bucket goes (ds_max of
+//           y + 1 on a slot; the slots are the 128 words of the still-empty presence bitmap; buckets that share a slot wait for
+//           each other, which costs a trip and changes nothing) and clears its slot.  Same insertion order, same chains;
+//   flags   uniqueness (chain walk), presence bit and — after one more fence — the head tags, all per position (build_tables
+//           walks the 1024 head words for the tags).
+// One wavefront per workgroup: its LDS instructions execute in program order, wave_sync() is all the ordering needed.
+// =============================================================================================
+__global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __restrict__ loci, uint32_t l0, uint32_t n_loci,
+                                                         const uint8_t* __restrict__ hap_arena, uint32_t max_hap,
+                                                         uint32_t table_stride, uint32_t n_heads, uint8_t* __restrict__ gtables) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint8_t* tb = (uint8_t*)smem;
+    const int tid = threadIdx.x;
+    uint2* ent = TB_ENT(tb);
+    uint16_t* head = TB_HEAD(tb);
+    uint8_t* bytes = TB_BYTES(tb);
+    uint8_t* fb = TB_FB(tb);
+    uint32_t* uq0 = TB_UQ(tb);
+    uint32_t* pb = TB_PB(tb);
+    const uint32_t hmask = n_heads - 1;
+    const uint32_t zero_words = vtxf::tab_uq_words(max_hap) + 128u;           // uq[] and, behind it, pb[128]
+    for (uint32_t t = blockIdx.x; t < 2u * n_loci; t += gridDim.x) {
+        const vtx_locus loc = loci[l0 + (t >> 1)];
+        const uint32_t hn = max(loc.ref_len, loc.alt_len) > max_hap ? 0u : ((t & 1) ? loc.alt_len : loc.ref_len);   // (a locus of the slow list: no table)
+        const uint8_t* hy = hap_arena + ((t & 1) ? loc.alt_off : loc.ref_off);
+        const int nk = hn >= (uint32_t)KMER ? (int)hn - KMER + 1 : 0;
+        wave_sync();                                                          // (the copy of the table before has read everything)
+        for (uint32_t i = tid; i < n_heads / 4; i += 64) ((uint2*)head)[i] = make_uint2(0xffffffffu, 0xffffffffu);   // CH_END x 4
+        for (uint32_t i = tid; i < zero_words; i += 64) uq0[i] = 0;
+        bool hib = false;
+        for (uint32_t y = tid; y < hn; y += 64) {
+            const uint64_t w = vtxf::ld8(hy + y);                             // (the arena is padded: bytes beyond the haplotype are never USED)
+            const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32) & 0xffffu;
+            bytes[y] = (uint8_t)lo;
+            fb[y] = (uint8_t)(lo & 0x7fu);
+            hib |= (lo & 0x80u) != 0;
+            if ((int)y < nk) ent[y] = make_uint2(lo, hi | (kw_hash(lo, hi, hmask) << 16));   // (the bucket rides in the next-pointer field until the link)
+        }
+        hib = __any(hib);
+        wave_sync();
+        for (int base = nk > 0 ? ((nk - 1) / 64) * 64 : -1; base >= 0; base -= 64) {
+            const int y = base + tid;
+            bool pend = y < nk;
+            const uint32_t ey = pend ? ent[y].y : 0u;
+            const uint32_t h = ey >> 16;
+            uint32_t* slot = pb + (h & 127u);
+            while (__any(pend)) {
+                if (pend) atomicMax(slot, (uint32_t)y + 1u);
+                wave_sync();
+                const bool win = pend && *slot == (uint32_t)y + 1u;
+                wave_sync();
+                if (win) {
+                    ent[y].y = (ey & 0xffffu) | ((uint32_t)head[h] << 16);
+                    head[h] = (uint16_t)y;
+                    *slot = 0;
+                    pend = false;
+                }
+                wave_sync();
+            }
+        }
+        // uniqueness flags (build_tables: a haplotype with a byte >= 0x80 gets none) and the presence bitmap
+        for (int y = tid; y < nk; y += 64) {
+            const uint2 k = ent[y];
+            const uint32_t klo = k.x, khi = k.y & 0xffffu;
+            if (!hib) {
+                uint32_t same = 0;
+                for (uint32_t e = head[kw_hash(klo, khi, hmask)]; e != CH_END; e = ent[e].y >> 16)
+                    same += (ent[e].x == klo && (ent[e].y & 0xffffu) == khi);
+                if (same == 1) {
+                    fb[y + KMER - 1] |= 0x80;                                 // only this lane touches that byte
+                    atomicOr(&uq0[vtxf::UQ_PAD_WORDS + ((uint32_t)y >> 5)], 1u << (y & 31));
+                }
+            }
+            const uint32_t code = vtxf::kw_code(klo, khi);
+            atomicOr(&pb[code >> 5], 1u << (code & 31u));
+        }
+        wave_sync();
+        // head tags: the first position of a chain writes its bucket's head word (a lane that reads a tagged word compares it
+        // with its own position, which is not the chain's first: no match either way)
+        for (int y = tid; y < nk; y += 64) {
+            const uint2 k = ent[y];
+            const uint32_t mix = vtxf::kw_mix(k.x, k.y & 0xffffu);
+            const uint32_t h = vtxf::kw_bucket(mix, hmask);
+            if (head[h] == (uint16_t)y) {
+                const uint32_t tag = (k.y >> 16) == CH_END ? vtxf::kw_tag(mix) : vtxf::HEAD_MULTI;
+                head[h] = (uint16_t)((uint32_t)y | (tag << 12));
+            }
+        }
+        wave_sync();
+        const uint4* src = (const uint4*)smem;
+        uint4* dst = (uint4*)(gtables + (size_t)t * table_stride);
+        for (uint32_t i = tid; i < table_stride / 16; i += 64) dst[i] = src[i];
+    }
+}
+
 #define REFINE_WORDS 12u       // record of band_refine_kernel: task, d, r | cert << 4 | far matches << 16, zc, RM piece words
 extern "C" uint32_t vtxk_band_refine_words(void) { return REFINE_WORDS; }
 // ST: type of an off-diagonal match entry — uint16_t (x << 8 | y: 40 entries per task in the same LDS) when every haplotype of
@@ -2232,6 +2336,18 @@ static uint32_t gt_max_tpl() {
     static const uint32_t v = getenv("VTX_BAND_GT_MAX_TPL") ? (uint32_t)atoi(getenv("VTX_BAND_GT_MAX_TPL")) : 0x7fffffffu;
     return v;
 }
+// the tables of n_loci loci in global memory: band_tables_kernel (a table per wavefront); VTX_BAND_TABLES_V1=1: round 3's kernel
+// (a locus per wavefront, serial chain insertion) — the reference the new one is compared with byte for byte (tests)
+static void launch_band_tables(const vtx_locus* loci, uint32_t gt_l0, uint32_t n_loci, const uint8_t* hap_arena, uint32_t max_hap,
+                               size_t tstride, uint32_t n_heads, uint8_t* gtables, hipStream_t s) {
+    if (getenv("VTX_BAND_TABLES_V1"))
+        hipLaunchKernelGGL(band_tables_v1_kernel, dim3(std::min(n_loci, 256u * 16u)), dim3(64), 2 * tstride, s, loci, gt_l0, n_loci,
+                           hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
+    else
+        hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(2u * n_loci, 256u * 32u)), dim3(64), tstride, s, loci, gt_l0, n_loci,
+                           hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
+}
+
 // buckets of a table's hash (power of two; experiment knob VTX_BAND_HEADS)
 static uint32_t pick_heads(uint32_t tasks_per_locus, bool global_tables) {
     if (getenv("VTX_BAND_HEADS")) return (uint32_t)atoi(getenv("VTX_BAND_HEADS"));
@@ -2329,8 +2445,7 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     if (shmem > 160 * 1024 - 256) return hipErrorInvalidValue;
     if (task_list && !global_tables) return hipErrorInvalidValue;    // (list mode reads the tables the first pass built)
     if (global_tables && !task_list)
-        hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(n_loci, 256u * 16u)), dim3(64), 2 * tstride, s, loci, gt_l0, n_loci,
-                           hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
+        launch_band_tables(loci, gt_l0, n_loci, hap_arena, max_hap, tstride, n_heads, gtables, s);
     const uint32_t ablate = (uint32_t)(getenv("VTX_BAND_ABLATE") ? atoi(getenv("VTX_BAND_ABLATE")) : 0);
     const uint32_t xcd_claim = ((tasks_per_locus >= 24 || getenv("VTX_BAND_XCD")) && !getenv("VTX_BAND_NO_XCD")) ? 1u : 0u;   // (measured: config 3 -3 %, 64 / 32 reads per locus -4.5 %, 16: -1 %, 4: +2 %)
 #define LAUNCH_RUN(NTV, GTV, WV, PV)                                                                                 \
@@ -2370,8 +2485,7 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     const uint32_t n_heads = pick_heads(tasks_per_locus, true);
     const size_t tstride = band_table_stride(max_hap, n_heads);
     if (!gtables || (size_t)n_loci * 2 * tstride > gtables_bytes) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(n_loci, 256u * 16u)), dim3(64), 2 * tstride, s, loci, gt_l0, n_loci,
-                       hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
+    launch_band_tables(loci, gt_l0, n_loci, hap_arena, max_hap, tstride, n_heads, gtables, s);
     const uint32_t n_blocks = (n_tasks + 255) / 256;
     const uint32_t st = (uint32_t)stats | (getenv("VTX_DIAG_ABLATE") ? (uint32_t)atoi(getenv("VTX_DIAG_ABLATE")) << 8 : 0u);
     // two-byte match entries (40 per task) whenever a haplotype position fits a byte; VTX_DIAG_WIDE=1 forces the four-byte variant (tests)

@@ -23,7 +23,7 @@ SYMBOLS = (
     "vtx_fetch_coo", "vtx_device_scores", "vtx_device_coo", "vtx_last_timing", "vtx_last_cells", "vtx_strerror",
     "vtx_status_name", "vtx_abi_sizes", "vtx_set_barcodes", "vtx_submit_raw", "vtx_fetch_records",
     "vtx_comm_id", "vtx_comm_init", "vtx_gather_coo", "vtx_fetch_gathered", "vtx_gather_abort", "vtx_gather_plan",
-    "vtx_set_debug", "vtx_fetch_stage", "vtx_debug_bands",
+    "vtx_set_debug", "vtx_fetch_stage", "vtx_debug_bands", "vtx_debug_tables",
 )
 
 
@@ -96,6 +96,8 @@ def load():
     L.vtx_set_debug.argtypes = [ctxp, C.c_int, C.c_int64]
     L.vtx_fetch_stage.restype = C.c_int
     L.vtx_fetch_stage.argtypes = [ctxp, C.c_void_p]
+    L.vtx_debug_tables.restype = C.c_int
+    L.vtx_debug_tables.argtypes = [ctxp, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.vtx_debug_bands.restype = C.c_int
     L.vtx_debug_bands.argtypes = [ctxp, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
@@ -282,6 +284,15 @@ class Context:
         status = np.zeros(len(t), np.uint8)
         self._check(self._L.vtx_debug_bands(self._h, t.ctypes.data, len(t), stride, lo.ctypes.data, hi.ctypes.data, status.ctypes.data))
         return lo, hi, status
+
+    def debug_tables(self) -> np.ndarray:
+        """The haplotype k-mer tables the last banded run left in global memory, as bytes (vtx_debug_tables); empty: tables in LDS."""
+        n = C.c_uint64(0)
+        self._check(self._L.vtx_debug_tables(self._h, None, 0, C.byref(n)))
+        out = np.zeros(int(n.value), np.uint8)
+        if n.value:
+            self._check(self._L.vtx_debug_tables(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out
 
     def timing(self) -> abi.VtxTiming:
         t = abi.VtxTiming()
