@@ -1179,13 +1179,19 @@ int vtx_run(vtx_ctx* c) {
         uint32_t resweep_total = 0;
         bool sweep_used = false;                    // some chunk took the round-4 path
         bool sweep_pending = false;                 // the events of a swept chunk have not been read yet
+        bool sweep_forked = false;                  // ... and that chunk ran its two branches side by side
+        uint32_t fork_nt = 0;
         auto collect_sweep_times = [&]() -> int {
             if (!sweep_pending) return VTX_OK;
             sweep_pending = false;
             HIP_TRY(c, hipEventSynchronize(c->ev[8]));
             float ms = 0;
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[7], c->ev[9])); check_ms += ms;     // the one-diagonal bands' masked DP
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[9], c->ev[8])); sweep_ms += ms;     // band_sweep_kernel + its masked DP (the chunk's repeats)
+            // ev[7] .. ev[9]: band_refine_kernel (forked only) + the one-diagonal bands' masked DP; then band_sweep_kernel + its masked
+            // DP (the chunk's repeats) — forked: ev[11] .. ev[8] on the main stream, BESIDE the first interval, not after it
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[7], c->ev[9])); check_ms += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, sweep_forked ? c->ev[11] : c->ev[9], c->ev[8])); sweep_ms += ms;
+            if (sweep_forked) checked_total += std::min(c->h_pin[12], fork_nt);          // (copied before ev[9], which ev[8] waited for)
+            sweep_forked = false;
             return VTX_OK;
         };
         for (uint64_t base = 0; base < n_tasks; base += chunk) {
@@ -1244,49 +1250,68 @@ int vtx_run(vtx_ctx* c) {
                 if (e == hipSuccess && sweep_path) {
                     diag = true; swept = true; sweep_used = true;
                     HIP_TRY(c, hipEventRecord(c->ev[6], s));
-                    // band_refine_kernel over the records left for it, the full-matrix check over the tasks with a provisional
-                    // score: both lists are counted on the device (grids sized for the lists' capacities: a workgroup beyond the
-                    // count returns at once) — no host round trip before the one that sizes the sweep
-                    if (refine_list)
+                    // What the stage left, in two branches that share nothing but the score arrays (disjoint tasks):
+                    //   side stream   band_refine_kernel over its records, then the masked DP over the one-diagonal bands (tight list:
+                    //                 band_diag_kernel's entries + what the refinement leaves; counted on the device, the grid is
+                    //                 sized for the bound known here);
+                    //   this stream   band_sweep_kernel + masked DP over the repeats and the short fail list (both final once
+                    //                 band_diag_kernel is done: with a tight list the refinement adds nothing to them).
+                    // At 16 reads per locus these are five latency-bound launches of 0.1 - 0.2 ms each: side by side 0.31 instead
+                    // of 0.55 ms.  One host round trip, right after band_diag_kernel.  (VTX_BAND_NO_TIGHT: the refinement's leftovers
+                    // go to the fail list, so everything stays in order on this stream.)
+                    static const bool no_fork = getenv("VTX_BAND_NO_FORK") != nullptr;          // experiment / test hook
+                    const bool fork = tight_list != nullptr && !no_fork;
+                    hipStream_t sb = fork ? s2 : s;                                             // the refine / one-diagonal branch
+                    if (!fork && refine_list)
                         HIP_TRY(c, vtxk_launch_band_refine(refine_list, std::min(refine_cap, nt), c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                                            c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
                                                            c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
                                                            tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, tight_list, tight_pack, stage, d_cnt + 14, s));
-                    HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));   // [12] fail, [14] refine, [15] tight
+                    HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));   // [12] fail, [13] dense, [14] refine, [15] tight
                     HIP_TRY(c, hipStreamSynchronize(s));
-                    const uint32_t n_refine = std::min(c->h_pin[10], refine_cap), n_tight = std::min(c->h_pin[11], nt);
+                    const uint32_t n_refine = std::min(c->h_pin[10], refine_cap);
+                    // (forked: the tight list still grows by what the refinement leaves — at most its records)
+                    const uint32_t n_tight = (uint32_t)std::min<uint64_t>((uint64_t)c->h_pin[11] + (fork && refine_list ? n_refine : 0u), nt);
                     refined_total += n_refine;
                     launches += 2;
-                    HIP_TRY(c, hipEventRecord(c->ev[7], s));
+                    if (fork) HIP_TRY(c, hipStreamWaitEvent(s2, c->ev[6], 0));
+                    HIP_TRY(c, hipEventRecord(c->ev[7], sb));
+                    if (fork && refine_list && n_refine)
+                        HIP_TRY(c, vtxk_launch_band_refine(refine_list, n_refine, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                           c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
+                                                           c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
+                                                           tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, tight_list, tight_pack, stage, d_cnt + 14, sb));
                     if (n_tight) {
                         // tasks with a certificate but no verdict: their band is one diagonal stretch (tight_pack): the masked DP
                         // expands it itself.  (VTX_BAND_CHECK=1: the full-matrix check first — full == cert decides a task, cert <=
                         // banded <= full; measured: 5.6 ns per task against 10 for the DP it saves on 20 - 30 % of noisy reads.)
                         const uint32_t* dp_list = tight_list;
                         const uint32_t* dp_pack = tight_pack;
-                        const uint32_t* dp_cnt = nullptr;
+                        const uint32_t* dp_cnt = fork ? d_cnt + 15 : nullptr;
                         if (use_check) {
                             HIP_TRY(c, c->d_dband.reserve((size_t)chunk * sizeof(uint32_t)));
                             HIP_TRY(c, c->d_dband_pack.reserve((size_t)chunk * sizeof(uint32_t)));
-                            HIP_TRY(c, hipMemsetAsync(d_cnt + 24, 0, sizeof(uint32_t), s));
-                            HIP_TRY(c, vtxk_launch_sw_check(kShapes[shape][0], kShapes[shape][1], n_tight, tight_list, tight_pack, nullptr,
+                            HIP_TRY(c, hipMemsetAsync(d_cnt + 24, 0, sizeof(uint32_t), sb));
+                            HIP_TRY(c, vtxk_launch_sw_check(kShapes[shape][0], kShapes[shape][1], n_tight, tight_list, tight_pack, dp_cnt,
                                                             c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
                                                             c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(),
                                                             c->d_alt.as<int32_t>(), c->max_hap_len, c->d_dband.as<uint32_t>(),
-                                                            c->d_dband_pack.as<uint32_t>(), d_cnt + 24, stage, s));
+                                                            c->d_dband_pack.as<uint32_t>(), d_cnt + 24, stage, sb));
                             dp_list = c->d_dband.as<uint32_t>(); dp_pack = c->d_dband_pack.as<uint32_t>(); dp_cnt = d_cnt + 24;
                             ++launches;
                         }
                         HIP_TRY(c, vtxk_launch_sw_diag_band(kShapes[shape][0], kShapes[shape][1], n_tight, dp_list, dp_pack, dp_cnt,
                                                             c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
                                                             c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(),
-                                                            c->d_alt.as<int32_t>(), c->max_hap_len, stage, s));
+                                                            c->d_alt.as<int32_t>(), c->max_hap_len, stage, sb));
                         ++launches;
                     }
-                    HIP_TRY(c, hipEventRecord(c->ev[9], s));
+                    if (fork) HIP_TRY(c, hipMemcpyAsync(c->h_pin + 12, d_cnt + 15, sizeof(uint32_t), hipMemcpyDeviceToHost, sb));   // the list's final length (read in collect_sweep_times)
+                    HIP_TRY(c, hipEventRecord(c->ev[9], sb));
+                    if (fork) HIP_TRY(c, hipEventRecord(c->ev[11], s));                          // (this stream's branch starts here)
                     n_fail = c->h_pin[8];
                     uint32_t n_dense = std::min(c->h_pin[9], nt);
-                    checked_total += n_tight;
+                    if (!fork) checked_total += n_tight;                                    // (forked: the exact count arrives with the events)
                     diag_total += nt; diag_left += (uint64_t)n_fail + n_dense;
                     // repeats: band_sweep_kernel (the band of ANY task) + masked DP, sorted by task (neighbours share their locus'
                     // haplotypes, and the hard list comes out in a fixed order); what it declines waits in d_over[n_tasks ..) for the
@@ -1318,8 +1343,9 @@ int vtx_run(vtx_ctx* c) {
                             fail_list = c->d_fail.as<uint32_t>() + nt;
                         } else (void)hipGetLastError();
                     }
+                    if (fork) HIP_TRY(c, hipStreamWaitEvent(s, c->ev[9], 0));                    // join: what follows reads every score
                     HIP_TRY(c, hipEventRecord(c->ev[8], s));
-                    sweep_pending = true;
+                    sweep_pending = true; sweep_forked = fork; fork_nt = nt;
                     // the others: band_run_kernel (task-list mode) below — seeds, chain and the general certificate (a read against the
                     // other allele of an indel lies on TWO diagonals: cert == ub decides nearly all of those without a DP cell)
                 } else if (e == hipSuccess) {
