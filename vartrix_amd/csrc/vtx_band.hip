@@ -2002,10 +2002,13 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     __shared__ uint16_t q_ent_[4][64 * QROWS];                 // pooled probes of one round: owner lane << 8 | row
     __shared__ uint32_t o_read_[4][64], o_tab_[4][64], s_cnt_[4][64];      // per owner lane: read offset, table offset, matches found
     __shared__ int32_t o_diag_[4][64];
+    constexpr int WALK_CAP = 224;                              // entries of the walk list (the survivors of pass 1, across rounds)
+    __shared__ uint16_t q_walk_[4][WALK_CAP];
     __shared__ uint32_t q_count_[4][2];
     const int wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
     uint32_t* lane_mem = lane_mem_[wv];
     uint16_t* q_ent = q_ent_[wv];
+    uint16_t* q_walk = q_walk_[wv];
     uint32_t *o_read = o_read_[wv], *o_tab = o_tab_[wv], *s_cnt = s_cnt_[wv], *q_count = q_count_[wv];
     int32_t* o_diag = o_diag_[wv];
     const uint32_t per_xcd = (n_blocks + 7) / 8;
@@ -2024,6 +2027,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     vtxf::Tab tb;
     tb.gt = gtables; tb.ent = tb.head = tb.bytes = tb.uq = tb.pb = 0; tb.hmask = n_heads - 1;
     s_cnt[tid] = 0;
+    o_read[tid] = 0;
     const uint8_t* x = read_arena;
     int m = 0, n = 0;
     if (have) {
@@ -2033,6 +2037,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         const vtx_locus loc = loci[my_locus];
         m = (int)rec.read_len; n = (int)(hap ? loc.alt_len : loc.ref_len);
         my_score = (hap ? alt_score : ref_score) + rid;
+        o_read[tid] = rec.read_off;                                      // (also where this lane drops out: its partner may probe the read)
         if (m == 0 || n == 0) {
             *my_score = 0;                                               // empty read / haplotype: score 0
             if (stage) stage[task] = 1;
@@ -2047,7 +2052,6 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             tb.uq = tb.ent + vtxf::tab_uq_off(max_hap, n_heads);
             tb.pb = tb.ent + vtxf::tab_pb_off(max_hap, n_heads);
             x = read_arena + rec.read_off;
-            o_read[tid] = rec.read_off;
             live = true;
         }
     }
@@ -2107,30 +2111,97 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             if (fr.why != vtxf::W_OK) { live = false; fail = true; why = fr.why; }
         }
     }
-    o_tab[tid] = tb.ent;
+    constexpr uint32_t NO_TAB = 0xffffffffu;
+    o_tab[tid] = tb.head ? tb.ent : NO_TAB;                     // (head offset 0: the lane never got as far as its table)
     o_diag[tid] = fr.d;
     // ---- pooled probes: the rows the lanes still have to look up differ a lot from lane to lane (a read that hangs over
     //      the padded window has up to 49 rows without a main-diagonal k-mer), so the wavefront's rows go through one queue
     //      and every lane probes for whoever owns the row.  Pass 1: the presence bitmap (one word of 512 bytes per
     //      haplotype) — most k-mers are not in the haplotype at all; the survivors are compacted in place.  Pass 2: bucket
     //      walk for the survivors; matches land in the owner's list. ----
-    vtxf::MIter need_it = vtxf::m_iter(live ? fr.need : vtxf::M192{0, 0, 0});
+    // The two lanes of a pair hold ONE read against the two haplotypes of its locus, and the rows they have to look up are nearly
+    // the same (they differ around the variant): the pair pools the UNION of its rows — even rows from the even lane, odd rows
+    // from the odd one — and an entry (pair, row) is probed in BOTH tables: one load of the read's bytes instead of two, half the
+    // entries, half the trips of dependent loads below.  (A row one of the two did not ask for has no off-diagonal match in that
+    // haplotype — that is why it was not asked for: looking it up finds nothing.)
+    vtxf::M192 nd = live ? fr.need : vtxf::M192{0, 0, 0};
+    {
+        const uint64_t par = (tid & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+        auto other = [&](uint64_t v) {
+            return (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)v, 1) | ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), 1) << 32);
+        };
+        nd.w0 = (nd.w0 | other(nd.w0)) & par; nd.w1 = (nd.w1 | other(nd.w1)) & par; nd.w2 = (nd.w2 | other(nd.w2)) & par;
+    }
+    vtxf::MIter need_it = vtxf::m_iter(nd);
     if ((stats >> 8) == 1) { if (live && fr.cert == 0x7fffffff) counters[40] = 1; return; }      // (profiling aid) front only
     const uint32_t pb_rel = vtxf::tab_pb_off(max_hap, n_heads), head_rel = max_hap * 8u;
+    // pass 2 over the first n_walk entries of the walk list (every lane calls it; 0xffff: a slot reserved by a lane that did not fit)
+    auto walk_list = [&](uint32_t n_walk) {
+        if ((stats >> 8) == 9) return;                                // (profiling aid) pass 1 without the bucket walks
+        // two entries per lane and trip: a walk is three DEPENDENT loads (the read's bytes, the head word of their bucket, the
+        // chain's first entry) — the two entries' loads go out together, level by level
+        constexpr int WPL = 2;
+        for (uint32_t i0 = 0; i0 < n_walk; i0 += 64 * WPL) {
+            uint32_t own[WPL], row[WPL], hh[WPL], raw[WPL], tent[WPL];
+            uint64_t w8[WPL], e0[WPL];
+            bool go[WPL];
+#pragma unroll
+            for (int u = 0; u < WPL; ++u) {
+                const uint32_t i = i0 + 64u * u + tid;
+                const uint32_t e = i < n_walk ? q_walk[i] : 0xffffu;
+                go[u] = e != 0xffffu;
+                own[u] = go[u] ? e >> 8 : 0u; row[u] = e & 0xffu;
+                w8[u] = vtxf::ld8(read_arena + o_read[own[u]] + row[u]);
+                tent[u] = o_tab[own[u]];
+                go[u] = go[u] && tent[u] != NO_TAB;
+                if (!go[u]) tent[u] = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < WPL; ++u) {
+                hh[u] = vtxf::kw_mix((uint32_t)w8[u], (uint32_t)(w8[u] >> 32) & 0xffffu);
+                raw[u] = vtxf::ld2(gtables + tent[u] + head_rel + 2u * vtxf::kw_bucket(hh[u], n_heads - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < WPL; ++u) {
+                const uint32_t tag = raw[u] >> 12;
+                go[u] = go[u] && raw[u] != vtxf::HEAD_END && (tag == vtxf::HEAD_MULTI || tag == vtxf::kw_tag(hh[u]));   // (else: the bucket's only k-mer is another one)
+                e0[u] = vtxf::ld8(gtables + tent[u] + 8u * (go[u] ? raw[u] & 0xfffu : 0u));
+            }
+#pragma unroll
+            for (int u = 0; u < WPL; ++u) {
+                if (!go[u]) continue;
+                const uint32_t lo = (uint32_t)w8[u], hi = (uint32_t)(w8[u] >> 32) & 0xffffu;
+                const int od = o_diag[own[u]];
+                uint32_t yc = raw[u] & 0xfffu;
+                uint64_t e = e0[u];
+                for (;;) {
+                    if ((uint32_t)e == lo && ((uint32_t)(e >> 32) & 0xffffu) == hi && (int)yc - (int)row[u] != od) {
+                        const uint32_t pos = atomicAdd(&s_cnt[own[u]], 1u);
+                        if (pos < (uint32_t)LaneT::SMAX) ((ST*)lane_mem)[pos * 64 + own[u]] = (ST)((row[u] << LaneT::XS) | yc);
+                    }
+                    yc = (uint32_t)(e >> 48);
+                    if (yc == vtxf::HEAD_END) break;
+                    e = vtxf::ld8(gtables + tent[u] + 8u * yc);
+                }
+            }
+        }
+    };
+    if (tid == 0) q_count[1] = 0;                                   // length of the walk list: it lives across the rounds
     for (;;) {
-        if (tid == 0) { q_count[0] = 0; q_count[1] = 0; }
+        if (tid == 0) q_count[0] = 0;
         wave_sync();
         const int cnt = min(QROWS, need_it.left);
         if (!__any(cnt > 0)) break;
         if (cnt > 0) {
             const uint32_t base = atomicAdd(&q_count[0], (uint32_t)cnt);
-            for (int t = 0; t < cnt; ++t) q_ent[base + t] = (uint16_t)(((uint32_t)tid << 8) | (uint32_t)vtxf::m_next(need_it));
+            for (int t = 0; t < cnt; ++t) q_ent[base + t] = (uint16_t)(((uint32_t)(tid >> 1) << 8) | (uint32_t)vtxf::m_next(need_it));
         }
         wave_sync();
+        if ((stats >> 8) == 8) continue;                              // (profiling aid) the rounds' queue fill only
         const uint32_t total = q_count[0];
         constexpr int EPL = 4;                                        // queue entries per lane and trip: their loads go out together
         for (uint32_t i0 = 0; i0 < total; i0 += 64 * EPL) {
-            uint32_t ent2[EPL], code[EPL], bits[EPL];
+            uint32_t ent2[EPL], code[EPL], bits_a[EPL], bits_b[EPL];
             uint64_t w8[EPL];
             bool on[EPL];
 #pragma unroll
@@ -2138,48 +2209,54 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
                 const uint32_t i = i0 + 64u * u + tid;
                 on[u] = i < total;
                 ent2[u] = q_ent[on[u] ? i : 0];
-                w8[u] = vtxf::ld8(read_arena + o_read[ent2[u] >> 8] + (ent2[u] & 0xffu));
+                w8[u] = vtxf::ld8(read_arena + o_read[(ent2[u] >> 8) * 2u] + (ent2[u] & 0xffu));
             }
 #pragma unroll
             for (int u = 0; u < EPL; ++u) {
                 code[u] = vtxf::kw_code((uint32_t)w8[u], (uint32_t)(w8[u] >> 32) & 0xffffu);
-                bits[u] = *(const uint32_t*)(gtables + o_tab[ent2[u] >> 8] + pb_rel + 4u * (code[u] >> 5));
+                const uint32_t ta = o_tab[(ent2[u] >> 8) * 2u], tb_ = o_tab[(ent2[u] >> 8) * 2u + 1u];   // (NO_TAB: a lane without a table)
+                bits_a[u] = ta == NO_TAB ? 0u : *(const uint32_t*)(gtables + ta + pb_rel + 4u * (code[u] >> 5));
+                bits_b[u] = tb_ == NO_TAB ? 0u : *(const uint32_t*)(gtables + tb_ + pb_rel + 4u * (code[u] >> 5));
             }
-            wave_sync();                                             // (every lane has read its entries: survivors may overwrite them)
+            // the survivors (5 % of the probes) join the walk list: one LDS add per lane that has any, no ballots.  The list is
+            // short (WALK_CAP entries — the LDS this kernel has left): a lane that does not fit marks what it reserved inside the
+            // list as empty, the list is walked and emptied, and the lane tries again.
+            uint32_t nh = 0;
+            bool hit_a[EPL], hit_b[EPL];
 #pragma unroll
             for (int u = 0; u < EPL; ++u) {
-                const bool hit = on[u] && ((bits[u] >> (code[u] & 31u)) & 1u);
-                const uint64_t hm = __ballot(hit);
-                if (hm) {
-                    uint32_t base = 0;
-                    const int leader = __ffsll((long long)hm) - 1;
-                    if (tid == leader) { base = q_count[1]; q_count[1] = base + (uint32_t)__popcll(hm); }
-                    base = (uint32_t)__shfl((int)base, leader);
-                    if (hit) q_ent[base + (uint32_t)__popcll(hm & ((1ull << tid) - 1ull))] = (uint16_t)ent2[u];
+                hit_a[u] = on[u] && ((bits_a[u] >> (code[u] & 31u)) & 1u);
+                hit_b[u] = on[u] && ((bits_b[u] >> (code[u] & 31u)) & 1u);
+                nh += (hit_a[u] ? 1u : 0u) + (hit_b[u] ? 1u : 0u);
+            }
+            bool todo = nh > 0;
+            for (;;) {
+                if (todo) {
+                    uint32_t pos = atomicAdd(&q_count[1], nh);
+                    if (pos + nh <= (uint32_t)WALK_CAP) {
+#pragma unroll
+                        for (int u = 0; u < EPL; ++u) {                 // (walk entries name the OWNER lane: pair * 2 + haplotype)
+                            const uint32_t e2 = ((ent2[u] >> 8) << 9) | (ent2[u] & 0xffu);
+                            if (hit_a[u]) q_walk[pos++] = (uint16_t)e2;
+                            if (hit_b[u]) q_walk[pos++] = (uint16_t)(e2 | 0x100u);
+                        }
+                        todo = false;
+                    } else {
+                        for (; pos < (uint32_t)WALK_CAP; ++pos) q_walk[pos] = 0xffffu;
+                    }
                 }
+                wave_sync();
+                const uint32_t wc = q_count[1];
+                if (wc <= (uint32_t)WALK_CAP) break;                   // (everybody fitted)
+                walk_list((uint32_t)WALK_CAP);
+                wave_sync();
+                if (tid == 0) q_count[1] = 0;
+                wave_sync();
             }
         }
-        wave_sync();
-        const uint32_t n_walk = q_count[1];
-        for (uint32_t i0 = 0; i0 < n_walk; i0 += 64) {
-            const uint32_t i = i0 + tid;
-            if (i >= n_walk) continue;
-            const uint32_t e = q_ent[i];
-            const uint32_t own = e >> 8, row = e & 0xffu;
-            const uint64_t w8 = vtxf::ld8(read_arena + o_read[own] + row);
-            const uint32_t hh = vtxf::kw_mix((uint32_t)w8, (uint32_t)(w8 >> 32) & 0xffffu);
-            vtxf::Tab to = tb;
-            to.ent = o_tab[own];
-            const uint32_t raw = vtxf::ld2(gtables + to.ent + head_rel + 2u * vtxf::kw_bucket(hh, n_heads - 1));
-            const int od = o_diag[own];
-            vtxf::walk_bucket(to, w8, hh, raw, [&](uint32_t yc) {
-                if ((int)yc - (int)row == od) return;
-                const uint32_t pos = atomicAdd(&s_cnt[own], 1u);
-                if (pos < (uint32_t)LaneT::SMAX) ((ST*)lane_mem)[pos * 64 + own] = (ST)((row << LaneT::XS) | yc);
-            });
-        }
-        wave_sync();
     }
+    walk_list(q_count[1]);
+    wave_sync();
     if ((stats >> 8) == 2) { if (live && s_cnt[tid] == 0x7fffffff) counters[40] = 1; return; }   // (profiling aid) front + probes
     uint32_t aux = 0xffffffffu;
     bool tight = false;
