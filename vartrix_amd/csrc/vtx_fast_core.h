@@ -300,21 +300,22 @@ VTXF_FN ReadWords read_words(const uint8_t* x, int m) {
 }
 
 // The match mask of diagonal d: bit i = (x[i] == y[i + d]), i in [max(0, -d), min(m, n - d)).
-// Eight 8-base words per mask word, their haplotype loads issued together (a loop of load - wait - compare steps is a chain of
-// 19 L2 round trips per task); words that do not overlap the haplotype load a clamped address and are masked.
+// Eight 8-base words per mask word, their haplotype bytes loaded together (a loop of load - wait - compare steps is a chain of
+// 19 L2 round trips per task) and SIXTEEN bytes per load: every lane has its own address, so what such a load costs the address
+// unit does not depend on its width — four loads per mask word instead of eight.  Words that do not overlap the haplotype are
+// masked, not skipped: their bytes lie inside the same table (the head words in front of bytes[], the flag bytes behind it),
+// readable and ignored.
+struct W16 { uint64_t a, b; };
+VTXF_FN W16 ld16(const uint8_t* p) { W16 v; __builtin_memcpy(&v, p, 16); return v; }
 template <int C> VTXF_FN uint64_t diag_mask_word(const ReadWords& rw, const uint8_t* yb, int d, int wa, int wb) {
-    uint64_t h[8];
+    W16 h[4];
 VTXF_UNROLL
-    for (int k = 0; k < 8; ++k) {
-        const int w = 8 * C + k;
-        const int wc = w < wa ? wa : (w >= wb ? wb - 1 : w);      // (wa < wb: the caller checked)
-        h[k] = ld8(yb + (8 * wc + d));
-    }
+    for (int k = 0; k < 4; ++k) h[k] = ld16(yb + (8 * (8 * C + 2 * k) + d));
     uint64_t out = 0;
 VTXF_UNROLL
     for (int k = 0; k < 8; ++k) {
         const int w = 8 * C + k;
-        const uint64_t e = (uint64_t)eq8(rw.w[w], h[k]) << (8 * k);
+        const uint64_t e = (uint64_t)eq8(rw.w[w], (k & 1) ? h[k >> 1].b : h[k >> 1].a) << (8 * k);
         out |= (w >= wa && w < wb) ? e : 0ull;
     }
     return out;
