@@ -104,6 +104,11 @@ int vtxh_write_mtx(const char* path, uint32_t n_rows, uint32_t n_cols, uint64_t 
                    const uint32_t* row, const uint32_t* col, const double* value);
 int vtxh_format_f64(double v, char* buf32);
 
+/* Test hook: the packer's own raw-DEFLATE decoder (vartrix_amd/csrc/host/vtx_inflate.h; the blocks htslib's bgzf_read hands
+ * to zlib behind src/main.rs:822-830) on one stream whose output size is known.  1: accepted, out holds out_len bytes; 0: the
+ * decoder declined (the packer then gives the block to zlib).  Nothing is written outside [out, out + out_len).               */
+int vtxh_test_inflate(const uint8_t* in, uint64_t in_len, uint8_t* out, uint64_t out_len);
+
 #ifdef __cplusplus
 }
 #endif

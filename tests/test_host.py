@@ -444,3 +444,102 @@ print("packed", ok, "refused", err)
     r = subprocess.run([sys.executable, "-c", code, vcfp, fap, bcp] + paths, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stderr[-400:])
     assert "packed" in r.stdout and int(r.stdout.split()[3]) > 0, r.stdout     # the truncations inside a record are refused
+
+
+# ---- the packer's own DEFLATE decoder (vtx_inflate.h) against zlib ----
+def _own_inflate(raw, n):
+    import ctypes as C
+    L = hostlib.load()
+    out = (C.c_uint8 * (n + 64))()
+    C.memset(C.addressof(out) + n, 0xAB, 64)
+    rc = L.vtxh_test_inflate(raw, len(raw), C.addressof(out), n)
+    assert bytes(out[n:n + 64]) == b"\xab" * 64, "the decoder wrote beyond its output"
+    return rc, bytes(out[:n])
+
+
+def test_own_inflate_equals_zlib_on_every_block_kind():
+    """Stored, fixed and dynamic blocks, literal-only and match-heavy data, every size from empty to a full BGZF block: accepted
+    and byte-identical; a wrong output size or a truncated stream is declined."""
+    import random
+    import zlib
+    rng = random.Random(1)
+    accepted = 0
+    for trial in range(60):
+        n = rng.choice([0, 1, 5, 100, 1000, 20000, 65280])
+        kind = trial % 5
+        if kind == 0:
+            data = bytes(rng.getrandbits(8) for _ in range(n))
+        elif kind == 1:
+            data = bytes(rng.choice(b"ACGT") for _ in range(n))
+        elif kind == 2:
+            data = (b"ACGTTGCA" * (n // 8 + 1))[:n]
+        elif kind == 3:
+            data = bytes(rng.choice(b"AB") for _ in range(n))
+        else:
+            data = bytes([rng.randrange(4)]) * n
+        for level in (0, 1, 6, 9):
+            for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strat)
+                raw = co.compress(data) + co.flush()
+                rc, out = _own_inflate(raw, len(data))
+                assert rc == 1 and out == data, (trial, level, strat, n)
+                accepted += 1
+                if data:
+                    assert _own_inflate(raw, len(data) - 1)[0] == 0
+                assert _own_inflate(raw, len(data) + 1)[0] == 0
+                if len(raw) > 2 and data:
+                    assert _own_inflate(raw[:len(raw) // 2], len(data))[0] == 0
+    assert accepted == 60 * 16
+
+
+def test_own_inflate_never_accepts_what_zlib_rejects():
+    """Bit flips in valid streams: the decoder either declines (the packer then asks zlib) or returns exactly what zlib returns."""
+    import random
+    import zlib
+    rng = random.Random(7)
+    accepted = declined = 0
+    for trial in range(1500):
+        n = rng.choice([50, 500, 5000, 30000])
+        data = bytes(rng.choice(b"ACGTN") for _ in range(n)) if trial % 2 else bytes(rng.getrandbits(8) & 0x3f for _ in range(n))
+        co = zlib.compressobj(rng.choice([1, 6, 9]), zlib.DEFLATED, -15)
+        raw = bytearray(co.compress(data) + co.flush())
+        for _ in range(rng.randint(1, 4)):
+            raw[rng.randrange(len(raw))] ^= 1 << rng.randrange(8)
+        raw = bytes(raw)
+        rc, out = _own_inflate(raw, n)
+        try:
+            d = zlib.decompressobj(-15)
+            z = d.decompress(raw) + d.flush()
+            zok = d.eof and len(z) == n
+        except zlib.error:
+            zok, z = False, None
+        if rc:
+            accepted += 1
+            assert zok and out == z, trial
+        else:
+            declined += 1
+    assert accepted > 100 and declined > 100
+
+
+def test_own_inflate_on_the_reference_bam_and_pack_equality(monkeypatch):
+    """Every BGZF block of the reference's test BAM through the decoder, and the whole pack with the decoder against the pack with
+    zlib only (VTXH_ZLIB_INFLATE=1)."""
+    import struct
+    import zlib
+    f = open(os.path.join(G, "test.bam"), "rb").read()
+    o = blocks = 0
+    while o + 18 <= len(f):
+        xlen = struct.unpack_from("<H", f, o + 10)[0]
+        bsize = struct.unpack_from("<H", f, o + 16)[0] + 1
+        raw = f[o + 12 + xlen:o + bsize - 8]
+        isize = struct.unpack_from("<I", f, o + bsize - 4)[0]
+        if isize:
+            rc, out = _own_inflate(raw, isize)
+            assert rc == 1 and out == zlib.decompress(raw, -15) and zlib.crc32(out) == struct.unpack_from("<I", f, o + bsize - 8)[0]
+            blocks += 1
+        o += bsize
+    assert blocks >= 1
+    a = hostlib.pack_files(**_inputs())
+    monkeypatch.setenv("VTXH_ZLIB_INFLATE", "1")
+    b = hostlib.pack_files(**_inputs())
+    assert same_batch(a[0], b[0]) and a[1:] == b[1:]

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "../../../include/vtx_host.h"
+#include "vtx_inflate.h"
 
 namespace {
 
@@ -221,8 +222,15 @@ bool index_bgzf(const MappedFile& file, std::vector<BgzfBlock>& blocks) {
     return o == file.size();
 }
 
+// the packer's own decoder first (vtx_inflate.h: one-shot, table driven, ~2.5 x zlib on BAM data); whatever it does not accept
+// — malformed or merely unusual — goes to zlib, which decides.  VTXH_ZLIB_INFLATE=1: zlib only (A/B timing, tests).
 bool inflate_block(const MappedFile& file, const BgzfBlock& b, unsigned char* dst) {
     if (b.isize == 0) return true;
+    const bool zlib_only = getenv("VTXH_ZLIB_INFLATE") != nullptr;      // (per block: a test switches it between two packs of one process)
+    if (!zlib_only) {
+        vtxinf::Tables T;
+        if (vtxinf::inflate_raw((const uint8_t*)file.data() + b.coff, b.clen, dst, b.isize, T)) return true;
+    }
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) return false;
@@ -1314,6 +1322,11 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     ph.mark("sort + pack");
     *out = P.release();
     return VTX_OK;
+}
+
+int vtxh_test_inflate(const uint8_t* in, uint64_t in_len, uint8_t* out, uint64_t out_len) {
+    vtxinf::Tables T;
+    return vtxinf::inflate_raw(in, (size_t)in_len, out, (size_t)out_len, T) ? 1 : 0;
 }
 
 }  // extern "C"

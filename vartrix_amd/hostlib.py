@@ -17,7 +17,7 @@ CLI_PATH = os.path.join(_HERE, "bin", "vartrix")
 SYMBOLS = ("vtxh_pack_files", "vtxh_free", "vtxh_last_error", "vtxh_get_batch", "vtxh_get_metrics", "vtxh_get_ingest_stats",
            "vtxh_num_variants", "vtxh_num_barcodes", "vtxh_variant_name", "vtxh_barcode", "vtxh_write_mtx",
            "vtxh_format_f64", "vtxh_pack_files_raw", "vtxh_get_raw_batch", "vtxh_get_barcode_table", "vtxh_num_batches",
-           "vtxh_get_batch_at", "vtxh_get_raw_batch_at", "vtxh_pack_files_range")
+           "vtxh_get_batch_at", "vtxh_get_raw_batch_at", "vtxh_pack_files_range", "vtxh_test_inflate")
 METRIC_NAMES = ("num_reads", "num_low_mapq", "num_non_primary", "num_duplicates", "num_not_cell_bc",
                 "num_not_useful", "num_non_umi", "num_invalid_recs", "num_multiallelic_recs")
 
@@ -54,6 +54,8 @@ def load():
         L.vtxh_num_batches.argtypes = [C.c_void_p]
         L.vtxh_get_batch_at.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.VtxBatch)]
         L.vtxh_get_raw_batch_at.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.VtxRawBatch)]
+        L.vtxh_test_inflate.restype = C.c_int
+        L.vtxh_test_inflate.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64]
         L.vtxh_free.argtypes = [C.c_void_p]
         L.vtxh_last_error.restype = C.c_char_p
         L.vtxh_get_batch.argtypes = [C.c_void_p, C.POINTER(abi.VtxBatch)]
