@@ -221,6 +221,21 @@ def main():
     t_sub = time.perf_counter()
     ctx.submit(batch)                                      # the steady-state hand-over of a batch: validation, H2D, work lists
     t_sub = time.perf_counter() - t_sub
+    # the same hand-over with the bases two per byte, as a BAM record holds them and as the drop-in CLI ships them (vtx_set_read_format:
+    # the device unpacks): half the bytes through the pinned buffers and over PCIe.  The conversion is not timed — the packer copies
+    # the nibbles out of the BAM, it never has the bytes.  The timed steps below run on the byte-submitted batch.
+    t_sub_nib = None
+    try:
+        nib = batch.to_nibbles()
+        ctx.submit(nib)
+        t_sub_nib = time.perf_counter()
+        ctx.submit(nib)
+        t_sub_nib = time.perf_counter() - t_sub_nib
+        del nib
+    except ValueError:
+        pass                                                   # (a generator that lays reads out at odd offsets)
+    if t_sub_nib is not None:
+        ctx.submit(batch)
 
     # Row gather.  Default: torch.distributed (RCCL) with shard.GatherPipeline — the gather of step k overlaps with the
     # kernels of step k + 1.  VTX_NATIVE_GATHER=1: the C-ABI's own exchange (vtx_gather_coo: grouped ncclSend / ncclRecv
@@ -420,7 +435,9 @@ def main():
                        "diag_left_tasks": int(ctx.timing().diag_left), "reduce_ms": float(np.mean(red_ms)), "submit_h2d_s": t_sub,
                        "generate_s": t_gen, "hard_tasks": int(ctx.timing().hard_tasks),
                        "overflow_tasks": int(ctx.timing().overflow_tasks),
-                       "pcie_inclusive_alignments_per_s": n_aln / (t_sub + elapsed / args.steps)},
+                       "pcie_inclusive_alignments_per_s": n_aln / (t_sub + elapsed / args.steps),
+                       "submit_h2d_nibbles_s": t_sub_nib,
+                       "pcie_inclusive_nibbles_alignments_per_s": (n_aln / (t_sub_nib + elapsed / args.steps)) if t_sub_nib else None},
         }
         if pmc_extra and pmc_extra.get("valu_instructions_per_launch") and dom_ms > 0:
             # VALU pipe occupancy of the dominant kernel.  VALU wave-instructions come from the PMC pass (same code, same workload);

@@ -186,6 +186,17 @@ void vtx_destroy(vtx_ctx* ctx);
  * stays resident until the next vtx_submit, so vtx_run may be repeated.      */
 int vtx_submit(vtx_ctx* ctx, const vtx_batch* batch);
 
+/* Format of the read arena of the batches submitted from now on (vtx_submit and vtx_submit_raw; sticky until set again):
+ *   VTX_READS_BYTES    one ASCII byte per base, what rec.seq().as_bytes() returns (src/main.rs:896) — the default;
+ *   VTX_READS_NIBBLES  two bases per byte as the BAM record holds them (high nibble first, "=ACMGRSVTWYHKDBN"): half the bytes to
+ *                      write on the host and to move over PCIe.  Offsets and lengths still count BASES of the unpacked arena:
+ *                      read i's packed bytes start at read_arena + read_off / 2, so every read_off must be even (a read of odd
+ *                      length is followed by one unused base), read_bytes is even and the packed arena holds read_bytes / 2
+ *                      bytes; the device unpacks it once per submit (unpack_nibbles_kernel) into the arena the kernels read. */
+#define VTX_READS_BYTES 0
+#define VTX_READS_NIBBLES 1
+int vtx_set_read_format(vtx_ctx* ctx, int format);
+
 /* ---- raw batches: barcode lookup, UMI grouping and the sort done on the device ----------------
  * A raw record is a read that passed the alignment-level filters of evaluate_alns
  * (mapq / flags / useful_alignment, src/main.rs:833-864) but whose cell barcode and UMI are

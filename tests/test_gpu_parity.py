@@ -606,3 +606,37 @@ np.save(OUT, np.concatenate([r, a, [hard]]))
         res[name] = np.load(path)
         os.remove(path)
     assert res["one"][-1] > 100 and np.array_equal(res["one"], res["many"])
+
+
+def test_nibble_read_arena_gives_the_same_result():
+    """vtx_set_read_format(VTX_READS_NIBBLES): the read arena arrives two bases per byte (what the packer copies out of a BAM
+    record, half the bytes over PCIe) and unpack_nibbles_kernel writes the arena every other kernel reads — scores and triplets
+    must be those of the byte submit, through vtx_submit and through vtx_submit_raw, and the next byte submit must work again."""
+    from vartrix_amd import abi
+    spec = synth.SynthSpec(n_loci=300, n_barcodes=200, reads_per_locus=24, indel_frac=0.2, sub_error=0.02, read_len_jitter=0, seed=77)
+    batch = synth.make_batch(spec)
+    nib = batch.to_nibbles()
+    assert nib.read_arena.size * 2 >= batch.read_arena.size
+    with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=200)) as ctx:
+        ctx.submit(batch); ctx.run()
+        want_scores, want = ctx.fetch_scores(), ctx.fetch_coo()
+        ctx.submit(nib); ctx.run()
+        got_scores, got = ctx.fetch_scores(), ctx.fetch_coo()
+        assert np.array_equal(want_scores[0], got_scores[0]) and np.array_equal(want_scores[1], got_scores[1])
+        for k in want:
+            assert np.array_equal(want[k], got[k]), k
+        ctx.submit(batch); ctx.run()                                   # (the format is per submit: back to bytes)
+        again = ctx.fetch_scores()
+        assert np.array_equal(want_scores[0], again[0]) and np.array_equal(want_scores[1], again[1])
+    # the raw path: tags as bytes, reads as nibbles
+    raw, barcodes = synth.make_raw(batch, 200, use_umi=False)
+    assert not (raw.records["read_off"] & 1).any()
+    raw_nib = abi.RawBatch(raw.loci, raw.records, raw.hap_arena, abi.pack_nibbles(raw.read_arena), raw.tag_arena, abi.READS_NIBBLES)
+    outs = []
+    for rb in (raw, raw_nib):
+        with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=200)) as ctx:
+            ctx.set_barcodes(barcodes)
+            ctx.submit_raw(rb); ctx.run()
+            outs.append(ctx.fetch_coo())
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k

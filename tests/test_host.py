@@ -543,3 +543,58 @@ def test_own_inflate_on_the_reference_bam_and_pack_equality(monkeypatch):
     monkeypatch.setenv("VTXH_ZLIB_INFLATE", "1")
     b = hostlib.pack_files(**_inputs())
     assert same_batch(a[0], b[0]) and a[1:] == b[1:]
+
+
+# ---- read arenas as the BAM holds bases: two per byte (vtxh_args.read_format = VTX_READS_NIBBLES) ----
+def _unpacked(b):
+    """A nibble batch with its arena expanded the way unpack_nibbles_kernel does on the device."""
+    from vartrix_amd import abi
+    if getattr(b, "read_format", 0) != abi.READS_NIBBLES:
+        return b
+    lut = np.frombuffer(b"=ACMGRSVTWYHKDBN", np.uint8)
+    out = np.empty(2 * b.read_arena.size, np.uint8)
+    out[0::2] = lut[b.read_arena >> 4]
+    out[1::2] = lut[b.read_arena & 15]
+    import copy
+    c = copy.copy(b)
+    c.read_arena, c.read_format = out, abi.READS_BYTES
+    return c
+
+
+@pytest.mark.parametrize("raw", [False, True])
+@pytest.mark.parametrize("umi", [False, True])
+def test_nibble_pack_holds_the_same_reads(tmp_path, monkeypatch, raw, umi):
+    """The packer can leave the bases two per byte (half the arena to write and to ship; the device unpacks).  Offsets and
+    lengths still count bases; every read starts at an even one.  Same records, same reads, same metrics as the byte pack —
+    over one window and many, one batch and many."""
+    from vartrix_amd import abi
+    bam = make_dna_bam(tmp_path, seed=11, n_reads=1500)
+    inputs = dict(vcf=os.path.join(G, "test_dna.vcf"), bam=bam, fasta=os.path.join(G, "test_dna.fa"),
+                  cell_barcodes=os.path.join(G, "dna_barcodes.tsv"))
+    for env in ({}, {"VTXH_CHUNK_BLOCKS": "1"}, {"VTXH_BATCH_BYTES": "9000"}):
+        for k in ("VTXH_CHUNK_BLOCKS", "VTXH_BATCH_BYTES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        want, m1, *_ = hostlib.pack_files(use_umi=umi, raw=raw, threads=3, all_batches=True, **inputs)
+        got, m2, *_ = hostlib.pack_files(use_umi=umi, raw=raw, threads=3, all_batches=True, nibbles=True, **inputs)
+        assert m1 == m2 and len(got) == len(want) and (len(got) > 3) == ("VTXH_BATCH_BYTES" in env)
+        for b in got:
+            assert b.read_format == abi.READS_NIBBLES
+            assert not (b.records["read_off"] & 1).any()
+            assert b.as_struct().read_bytes == 2 * b.read_arena.size
+            assert np.all(b.records["read_off"].astype(np.int64) + b.records["read_len"] <= 2 * b.read_arena.size)
+        assert _concat_batches([_unpacked(b) for b in got]) == _concat_batches(want)
+        assert sum(b.read_arena.size for b in got) <= sum(b.read_arena.size for b in want) // 2 + 2 * sum(b.n_records for b in want)
+
+
+def test_nibble_helpers_round_trip():
+    from vartrix_amd import abi, synth
+    b = synth.make_batch(synth.SynthSpec(n_loci=30, n_barcodes=10, reads_per_locus=6, seed=5))
+    n = b.to_nibbles()
+    assert n.read_format == abi.READS_NIBBLES and n.read_arena.size == (b.read_arena.size + 1) // 2
+    r = n.to_bytes()
+    assert np.array_equal(r.read_arena[:b.read_arena.size], b.read_arena)
+    s = n.slice_loci(7, 19)
+    t = b.slice_loci(7, 19)
+    assert np.array_equal(s.records, t.records) and np.array_equal(s.to_bytes().read_arena[:t.read_arena.size], t.read_arena)

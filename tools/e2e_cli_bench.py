@@ -200,7 +200,8 @@ def main():
         print("authored %d reads over %d loci in %.1f s (%.1f MB BAM)" % (n_reads, args.loci, time.time() - t0, os.path.getsize(bam) / 1e6), flush=True)
         texts = []
         runs = [(["--prep", "host"], "--prep host", args.threads), (["--prep", "device"], "--prep device", args.threads),
-                (["--prep", "device"], "--prep device (second run, page cache warm)", args.threads)]
+                (["--prep", "device"], "--prep device (second run, page cache warm)", args.threads),
+                (["--prep", "host", "--reads", "bytes"], "--prep host --reads bytes (one byte per base, as before round 4's nibbles)", args.threads)]
         for th in args.more_threads:
             runs.append((["--prep", "device"], "--prep device, --threads %d" % th, th))
         for extra, label, th in runs:
@@ -208,7 +209,7 @@ def main():
             import hashlib
             texts.append(hashlib.sha256(open(out, "rb").read()).hexdigest())
             print("  .mtx %.1f MB, sha256 %s" % (os.path.getsize(out) / 1e6, texts[-1][:16]), flush=True)
-        assert texts[0] == texts[1] == texts[2], "host-prepared and device-prepared outputs differ"
+        assert len(set(texts)) == 1, "host-prepared / device-prepared / byte-arena outputs differ"
         print("host-prepared and device-prepared .mtx are byte-identical")
         return
     rng = np.random.default_rng(7)

@@ -13,6 +13,7 @@ from dataclasses import dataclass
 import numpy as np
 
 VTX_ABI_VERSION = 4
+READS_BYTES, READS_NIBBLES = 0, 1          # vtx_set_read_format
 
 VTX_OK = 0
 VTX_E_INVAL = -1
@@ -168,6 +169,20 @@ class VtxRawStats(C.Structure):
     ]
 
 
+def pack_nibbles(arena: np.ndarray) -> np.ndarray:
+    """One ASCII byte per base -> two bases per byte, high nibble first, the BAM's code "=ACMGRSVTWYHKDBN" (SAM spec 4.2.3)."""
+    code = np.full(256, 255, np.uint8)
+    for k, ch in enumerate(b"=ACMGRSVTWYHKDBN"):
+        code[ch] = k
+    a = np.ascontiguousarray(arena, np.uint8)
+    if a.size & 1:
+        a = np.concatenate([a, np.frombuffer(b"=", np.uint8)])
+    c = code[a]
+    if (c == 255).any():
+        raise ValueError("pack_nibbles: a base outside =ACMGRSVTWYHKDBN")
+    return (c[0::2] << 4) | c[1::2]
+
+
 @dataclass
 class RawBatch:
     """Host-side raw batch — the payload of ``vtx_submit_raw``: reads that passed the alignment-level
@@ -177,6 +192,7 @@ class RawBatch:
     hap_arena: np.ndarray
     read_arena: np.ndarray
     tag_arena: np.ndarray
+    read_format: int = 0          # READS_BYTES | READS_NIBBLES (vtx_set_read_format): read_arena then holds two bases per byte
 
     def __post_init__(self):
         self.loci = np.ascontiguousarray(self.loci, dtype=LOCUS_DTYPE)
@@ -199,7 +215,7 @@ class RawBatch:
         return VtxRawBatch(
             loci=ptr(self.loci), n_loci=self.n_loci, records=ptr(self.records), n_records=self.n_records,
             hap_arena=ptr(self.hap_arena), hap_bytes=int(self.hap_arena.size),
-            read_arena=ptr(self.read_arena), read_bytes=int(self.read_arena.size),
+            read_arena=ptr(self.read_arena), read_bytes=int(self.read_arena.size) * (2 if self.read_format == READS_NIBBLES else 1),
             tag_arena=ptr(self.tag_arena), tag_bytes=int(self.tag_arena.size))
 
 
@@ -216,6 +232,7 @@ class PackedBatch:
     records: np.ndarray
     hap_arena: np.ndarray
     read_arena: np.ndarray
+    read_format: int = 0          # READS_BYTES | READS_NIBBLES (vtx_set_read_format): read_arena then holds two bases per byte
 
     def __post_init__(self):
         self.loci = np.ascontiguousarray(self.loci, dtype=LOCUS_DTYPE)
@@ -238,7 +255,26 @@ class PackedBatch:
             loci=ptr(self.loci), n_loci=self.n_loci,
             records=ptr(self.records), n_records=self.n_records,
             hap_arena=ptr(self.hap_arena), hap_bytes=int(self.hap_arena.size),
-            read_arena=ptr(self.read_arena), read_bytes=int(self.read_arena.size))
+            read_arena=ptr(self.read_arena), read_bytes=int(self.read_arena.size) * (2 if self.read_format == READS_NIBBLES else 1))
+
+    def to_nibbles(self) -> "PackedBatch":
+        """The same batch with its read arena as the BAM holds bases: two per byte, high nibble first (READS_NIBBLES).  Every
+        read must start at an even offset (the packer lays them out so; the synthetic generators do when read lengths are even)."""
+        if self.read_format == READS_NIBBLES:
+            return self
+        if self.n_records and (self.records["read_off"] & 1).any():
+            raise ValueError("to_nibbles: a read starts at an odd offset")
+        return PackedBatch(self.loci, self.records, self.hap_arena, pack_nibbles(self.read_arena), READS_NIBBLES)
+
+    def to_bytes(self) -> "PackedBatch":
+        """Inverse of to_nibbles (what unpack_nibbles_kernel writes on the device)."""
+        if self.read_format != READS_NIBBLES:
+            return self
+        lut = np.frombuffer(b"=ACMGRSVTWYHKDBN", np.uint8)
+        out = np.empty(2 * self.read_arena.size, np.uint8)
+        out[0::2] = lut[self.read_arena >> 4]
+        out[1::2] = lut[self.read_arena & 15]
+        return PackedBatch(self.loci, self.records, self.hap_arena, out, READS_BYTES)
 
     def slice_loci(self, lo: int, hi: int) -> "PackedBatch":
         """Contiguous sub-batch [lo, hi) of loci, re-based so it is self-contained.
@@ -249,7 +285,7 @@ class PackedBatch:
         """
         loci = self.loci[lo:hi].copy()
         if loci.shape[0] == 0:
-            return PackedBatch(loci, self.records[:0], self.hap_arena[:0], self.read_arena[:0])
+            return PackedBatch(loci, self.records[:0], self.hap_arena[:0], self.read_arena[:0], self.read_format)
         r0 = int(loci["rec_begin"][0])
         r1 = int(loci["rec_begin"][-1] + loci["rec_count"][-1])
         recs = self.records[r0:r1].copy()
@@ -264,7 +300,10 @@ class PackedBatch:
             a0 = int(recs["read_off"].min())
             a1 = int((recs["read_off"] + recs["read_len"]).max())
             recs["read_off"] -= a0
-            reads = self.read_arena[a0:a1].copy()
+            if self.read_format == READS_NIBBLES:                # (offsets are even: a0 is)
+                reads = self.read_arena[a0 // 2:(a1 + 1) // 2].copy()
+            else:
+                reads = self.read_arena[a0:a1].copy()
         else:
             reads = self.read_arena[:0]
-        return PackedBatch(loci, recs, haps, reads)
+        return PackedBatch(loci, recs, haps, reads, self.read_format)

@@ -68,7 +68,7 @@ const Opt kOpts[] = {
     {"primary-alignments", 0, true, nullptr}, {"no-duplicates", 0, true, nullptr}, {"umi", 0, true, nullptr},
     {"bam-tag", 0, false, "CB"}, {"valid-chars", 0, false, "ATGCatgc"},
     {"devices", 0, false, "1"}, {"aligner", 0, false, "banded"}, {"prep", 0, false, "host"},
-    {"stream-loci", 0, false, "auto"},
+    {"stream-loci", 0, false, "auto"}, {"reads", 0, false, "nibbles"},
 };
 
 void usage() {
@@ -82,7 +82,9 @@ void usage() {
             "  --prep host|device [host]  (device: barcode lookup, UMI grouping and the sort run on the GPU)\n"
             "  --stream-loci <INT>|auto [auto]  VCF records per streamed range (ingest of range k + 1 overlaps the device work on\n"
             "                               range k; host memory follows the range, not the BAM); 0 = the whole input at once;\n"
-            "                               auto = at once when the BAM is below 4 GiB (faster: one sweep), ranges of 32768 above\n");
+            "                               auto = at once when the BAM is below 4 GiB (faster: one sweep), ranges of 32768 above\n"
+            "  --reads nibbles|bytes [nibbles]  read bases on their way to the device: two per byte as the BAM holds them (the device\n"
+            "                               unpacks), or one ASCII byte per base\n");
 }
 
 // The shard threads of one batch meet here before each RCCL collective, carrying their status: if any shard has failed,
@@ -129,6 +131,7 @@ struct Shard {
     const uint8_t* comm_id = nullptr;
     int rank = 0, world = 1;
     ShardGate* gate = nullptr;
+    int read_format = VTX_READS_BYTES;          // of the pack's read arenas (vtxh_read_format)
 };
 
 double since(std::chrono::steady_clock::time_point t0) {
@@ -159,6 +162,7 @@ void run_shard(Shard* s, vtx_config cfg) {
         }
     } else if (s->rc) return;
     s->t_create = now_s() - t0; t0 = now_s();
+    if ((s->rc = vtx_set_read_format(ctx, s->read_format))) { s->err = vtx_strerror(ctx); if (s->comm_id) (void)vtx_gather_abort(ctx); vtx_destroy(ctx); return; }
     vtx_batch b{s->loci.data(), (uint32_t)s->loci.size(), s->records, s->n_records, s->haps,
                 s->hap_bytes, s->reads, s->read_bytes};
     vtx_coo coo{};
@@ -270,6 +274,8 @@ int main(int argc, char** argv) {
     ha.use_umi = present.count("umi");
     ha.bam_tag = val["bam-tag"].c_str(); ha.valid_chars = val["valid-chars"].c_str();
     ha.threads = std::max(1, atoi(val["threads"].c_str()));
+    if (val["reads"] != "nibbles" && val["reads"] != "bytes") { fprintf(stderr, "error: --reads takes nibbles or bytes, not `%s`\n", val["reads"].c_str()); return 1; }
+    ha.read_format = val["reads"] == "nibbles" ? VTX_READS_NIBBLES : VTX_READS_BYTES;
     const auto t_start = std::chrono::steady_clock::now();
     if (val["prep"] != "host" && val["prep"] != "device") {
         fprintf(stderr, "error: '%s' isn't a valid value for '--prep <prep>'\n", val["prep"].c_str());
@@ -424,7 +430,7 @@ int main(int argc, char** argv) {
                 }
                 for (auto& L : s.loci) L.rec_begin -= r0;
                 s.haps = full.hap_arena; s.hap_bytes = full.hap_bytes;       // arenas are shared read-only, offsets stay valid
-                s.reads = full.read_arena; s.read_bytes = full.read_bytes;
+                s.reads = full.read_arena; s.read_bytes = full.read_bytes; s.read_format = vtxh_read_format(pk);
             }
         }
         if (bi == 0)

@@ -443,6 +443,7 @@ struct vtxh_pack {
     RawArr<vtx_record> records;
     std::string hap_arena;
     ByteBuf read_arena;            // grown without zero-fill, filled by the sweep's workers
+    int read_format = VTX_READS_BYTES;   // VTX_READS_NIBBLES: two bases per byte, offsets / sizes below still count bases
     vtxh_metrics metrics{};
     uint32_t n_variants = 0;
     std::vector<std::string> barcodes, variant_names;
@@ -548,7 +549,8 @@ void vtxh_get_batch_at(const vtxh_pack* p, uint32_t i, vtx_batch* out) {
     out->loci = p->loci.data() + b.l0; out->n_loci = b.l1 - b.l0;
     out->records = p->records.data() + b.rec0; out->n_records = (uint32_t)(b.rec1 - b.rec0);
     out->hap_arena = (const uint8_t*)p->hap_arena.data(); out->hap_bytes = p->hap_arena.size();
-    out->read_arena = p->read_arena.data() + b.rbase; out->read_bytes = b.rbytes;
+    if (p->read_format == VTX_READS_NIBBLES) { out->read_arena = p->read_arena.data() + b.rbase / 2; out->read_bytes = (b.rbytes + 1) & ~(uint64_t)1; }   // (rbase is even: every read starts at an even base)
+    else { out->read_arena = p->read_arena.data() + b.rbase; out->read_bytes = b.rbytes; }
 }
 void vtxh_get_batch(const vtxh_pack* p, vtx_batch* out) { vtxh_get_batch_at(p, 0, out); }
 void vtxh_get_metrics(const vtxh_pack* p, vtxh_metrics* out) { *out = p->metrics; }
@@ -565,7 +567,8 @@ void vtxh_get_raw_batch_at(const vtxh_pack* p, uint32_t i, vtx_raw_batch* out) {
     out->loci = p->loci.data() + b.l0; out->n_loci = b.l1 - b.l0;
     out->records = p->raw_records.data() + b.rec0; out->n_records = (uint32_t)(b.rec1 - b.rec0);
     out->hap_arena = (const uint8_t*)p->hap_arena.data(); out->hap_bytes = p->hap_arena.size();
-    out->read_arena = p->read_arena.data() + b.rbase; out->read_bytes = b.rbytes;
+    if (p->read_format == VTX_READS_NIBBLES) { out->read_arena = p->read_arena.data() + b.rbase / 2; out->read_bytes = (b.rbytes + 1) & ~(uint64_t)1; }   // (rbase is even: every read starts at an even base)
+    else { out->read_arena = p->read_arena.data() + b.rbase; out->read_bytes = b.rbytes; }
     out->tag_arena = (const uint8_t*)p->tag_arena.data() + b.tbase; out->tag_bytes = b.tbytes;
 }
 void vtxh_get_raw_batch(const vtxh_pack* p, vtx_raw_batch* out) { vtxh_get_raw_batch_at(p, 0, out); }
@@ -869,13 +872,23 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     // outputs, and the outputs are merged in thread order — so every locus sees its reads in BAM order,
     // exactly like one sequential sweep.
     // rr offsets are relative to the worker's arenas; roff / toff: where those start in the global arenas (64-bit)
-    struct Hit { uint32_t locus, cell; vtx_raw_record rr; uint64_t roff, toff; };
+    // 32 bytes per surviving (read, locus) pair.  roff: the read's bases; toff: the record's first tag byte — raw mode the barcode,
+    // then (umi_len != VTX_TAG_MISSING) the UMI right behind it; cooked mode (bc_len 0) the UMI alone.  (Round 3 kept 48 bytes per
+    // pair AND a second copy sorted by locus: every byte of either is a page the process touches for the first time, and
+    // those pages — not the work on them — are what the packer's time is made of.)
+    struct Hit { uint32_t locus, cell, read_len; uint16_t bc_len, umi_len; uint64_t roff, toff; };
+    static_assert(sizeof(Hit) == 32, "compact hit");
     // reads are not copied by the filter pass: it notes where each kept read's packed bases lie (the window's bytes stay
     // put until the parse is over) and the second pass decodes them straight into the global arena
     struct Decode { const unsigned char* sq; uint32_t l_seq; uint32_t off; };
     // (one per worker, written on every record: each on its own cache lines, or the workers fight over them)
     struct alignas(128) WorkerOut { std::vector<Hit> hits; std::vector<Decode> dec; uint64_t reads_size = 0; std::string tags; vtxh_metrics m{}; std::string err; uint64_t rbase = 0; int32_t hint_tid = -1; size_t hint_hi = 0; };
     ByteBuf& reads = P->read_arena;
+    // a->read_format VTX_READS_NIBBLES: the arena keeps the BAM's two-bases-per-byte form (half the pages to touch here, half the
+    // bytes over PCIe; the device unpacks: vtx_set_read_format); reads_bases counts BASES either way
+    const bool nibbles = a->read_format == VTX_READS_NIBBLES;
+    P->read_format = nibbles ? VTX_READS_NIBBLES : VTX_READS_BYTES;
+    uint64_t reads_bases = 0;
     auto process = [&](const unsigned char* r, uint32_t bs, WorkerOut& o, std::vector<uint32_t>& hits) -> bool {
         const int32_t tid = rdi32(r);
         if (tid < 0 || (size_t)tid >= by_tid.size() || by_tid[(size_t)tid].empty()) return true;
@@ -953,10 +966,13 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
                 seq_ready = true;
                 rr.read_off = (uint32_t)o.reads_size;                           // one copy per read, shared by its loci
                 o.dec.push_back(Decode{sq, l_seq, rr.read_off});
-                o.reads_size += l_seq;
+                o.reads_size += nibbles ? ((uint64_t)l_seq + 1) & ~(uint64_t)1 : l_seq;     // (nibbles: every read starts at an even base)
             }
             rr.read_len = l_seq;
-            o.hits.push_back(Hit{li, cell, rr, 0, 0});
+            // (offsets relative to this slice's arenas until the slice is copied out; the UMI, when there is one, was appended right
+            //  behind the barcode — or alone, in cooked mode)
+            o.hits.push_back(Hit{li, cell, l_seq, raw ? rr.bc_len : (uint16_t)0, rr.umi_len, rr.read_off,
+                                 raw ? rr.bc_off : (rr.umi_len != VTX_TAG_MISSING ? rr.umi_off : 0u)});
         }
         return o.reads_size <= 0xffffffffull && o.tags.size() <= 0xffffffffull;
     };
@@ -1029,7 +1045,7 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
         });
         t_filter_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_p0).count();
         std::vector<uint64_t> tbase(n_slices), hbase(n_slices);
-        uint64_t rtotal = reads.size(), ttotal = tag_store.size(), htotal = n_hits;
+        uint64_t rtotal = reads_bases, ttotal = tag_store.size(), htotal = n_hits;
         for (size_t t = 0; t < outs.size(); ++t) {
             WorkerOut& o = outs[t];
             if (!o.err.empty()) { parse_rc = o.err[0] == 'm' ? VTX_E_INVAL : VTX_E_UNSUPPORTED; parse_msg = o.err; return; }
@@ -1040,15 +1056,19 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
             uint64_t* dst = &P->metrics.num_reads;
             for (int k = 0; k < 9; ++k) dst[k] += src[k];
         }
-        if (!reads.grow((size_t)(rtotal - reads.size())) || !tag_store.grow((size_t)(ttotal - tag_store.size())) ||
+        if (!reads.grow((size_t)((rtotal - reads_bases) / (nibbles ? 2 : 1))) || !tag_store.grow((size_t)(ttotal - tag_store.size())) ||
             !hit_store.grow((size_t)(htotal - n_hits) * sizeof(Hit))) { parse_rc = VTX_E_NOMEM; parse_msg = "out of memory growing the read arenas"; return; }
-        n_hits = (size_t)htotal;
+        n_hits = (size_t)htotal; reads_bases = rtotal;
         Hit* all = (Hit*)hit_store.data();
         next_slice = 0;
         pool.run([&](size_t) {
           for (size_t t; (t = next_slice.fetch_add(1)) < n_slices;) {
             const WorkerOut& o = outs[t];
             for (const Decode& d : o.dec) {                                                  // rec.seq().as_bytes() :896
+                if (nibbles) {                                                               // the record's own packed bases, as they are
+                    memcpy(reads.data() + (o.rbase + d.off) / 2, d.sq, ((size_t)d.l_seq + 1) / 2);
+                    continue;
+                }
                 unsigned char* dst = reads.data() + o.rbase + d.off;
                 for (uint32_t k = 0; k + 1 < d.l_seq; k += 2) memcpy(dst + k, &kNt16Pair[d.sq[k >> 1]], 2);
                 if (d.l_seq & 1) dst[d.l_seq - 1] = (unsigned char)kNt16[d.sq[d.l_seq >> 1] >> 4];
@@ -1057,7 +1077,7 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
             Hit* dst = all + hbase[t];
             for (size_t k = 0; k < o.hits.size(); ++k) {
                 Hit h = o.hits[k];
-                h.roff = o.rbase + h.rr.read_off; h.toff = tbase[t];
+                h.roff += o.rbase; h.toff += tbase[t];
                 dst[k] = h;
             }
           }
@@ -1157,9 +1177,12 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     const size_t nloc = loci.size();
     const Hit* all_hits = (const Hit*)hit_store.data();
     std::vector<uint64_t> l_begin(nloc + 1, 0);
-    ByteBuf sorted_store;
-    if (!sorted_store.grow(n_hits * sizeof(Hit))) return fail(VTX_E_NOMEM, "out of memory sorting the reads");
-    Hit* by_locus = (Hit*)sorted_store.data();
+    // (the sort moves 4-byte indices, not the hits: by_locus(j) is the j-th hit in (locus, BAM) order)
+    if (n_hits > 0xffffffffull) return fail(VTX_E_UNSUPPORTED, "more than 2^32 (read, locus) pairs in one pack: pack ranges of VCF rows");
+    ByteBuf order_store;
+    if (!order_store.grow(n_hits * sizeof(uint32_t))) return fail(VTX_E_NOMEM, "out of memory sorting the reads");
+    uint32_t* order = (uint32_t*)order_store.data();
+    auto by_locus = [&](uint64_t j) -> const Hit& { return all_hits[order[j]]; };
     {
         // thread t counts its slice over the locus range the slice touches (narrow in a sorted file); the cursors are
         // then handed out in thread order, so within a locus the slices land in BAM order
@@ -1202,10 +1225,9 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
         }
         pool.run([&](size_t t) {
             Slice& S = sl[t];
-            for (size_t k = S.k0; k < S.k1; ++k) by_locus[S.cur[all_hits[k].locus - S.lmin]++] = all_hits[k];
+            for (size_t k = S.k0; k < S.k1; ++k) order[S.cur[all_hits[k].locus - S.lmin]++] = (uint32_t)k;
         });
     }
-    hit_store.release();
     const size_t n_sorted = n_hits;
     // ---- batches: consecutive loci whose reads / tags span < 4 GiB (32-bit offsets relative to the batch window) ----
     uint64_t limit = 0xF0000000ull;
@@ -1229,12 +1251,11 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
             for (size_t l = nloc * t / (size_t)threads, e = nloc * (t + 1) / (size_t)threads; l < e; ++l) {
                 uint64_t a0 = UINT64_MAX, a1 = 0, b0 = UINT64_MAX, b1 = 0;
                 for (uint64_t j = l_begin[l]; j < l_begin[l + 1]; ++j) {
-                    const Hit& h = by_locus[j];
-                    a0 = std::min(a0, h.roff); a1 = std::max(a1, h.roff + h.rr.read_len);
+                    const Hit& h = by_locus(j);
+                    a0 = std::min(a0, h.roff); a1 = std::max(a1, h.roff + h.read_len);
                     if (need_tags) {
-                        b0 = std::min(b0, h.toff + h.rr.bc_off);
-                        b1 = std::max(b1, h.toff + h.rr.bc_off + h.rr.bc_len);
-                        if (h.rr.umi_len != VTX_TAG_MISSING) b1 = std::max(b1, h.toff + h.rr.umi_off + h.rr.umi_len);
+                        b0 = std::min(b0, h.toff);
+                        b1 = std::max(b1, h.toff + h.bc_len + (h.umi_len != VTX_TAG_MISSING ? h.umi_len : 0u));
                     }
                 }
                 ext[l] = Extent{a0, a1, b0, b1};
@@ -1275,11 +1296,14 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
             for (size_t l = nloc * t / (size_t)threads, e = nloc * (t + 1) / (size_t)threads; l < e; ++l) {
                 const vtxh_pack::Batch& B = P->batches[batch_of[l]];
                 for (uint64_t j = l_begin[l]; j < l_begin[l + 1]; ++j) {
-                    const Hit& h = by_locus[j];
-                    vtx_raw_record rr = h.rr;
+                    const Hit& h = by_locus(j);
+                    vtx_raw_record rr{};
                     rr.read_off = (uint32_t)(h.roff - B.rbase);
-                    rr.bc_off = (uint32_t)(h.toff + h.rr.bc_off - B.tbase);
-                    rr.umi_off = h.rr.umi_len != VTX_TAG_MISSING ? (uint32_t)(h.toff + h.rr.umi_off - B.tbase) : 0u;
+                    rr.read_len = h.read_len;
+                    rr.bc_off = (uint32_t)(h.toff - B.tbase);
+                    rr.bc_len = h.bc_len;
+                    rr.umi_off = h.umi_len != VTX_TAG_MISSING ? (uint32_t)(h.toff + h.bc_len - B.tbase) : 0u;
+                    rr.umi_len = h.umi_len;
                     P->raw_records[j] = rr;
                 }
             }
@@ -1301,10 +1325,10 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
                     const uint64_t rbase = P->batches[batch_of[ll]].rbase;
                     umi_ids.clear(); recs.clear();
                     for (uint64_t j = l_begin[ll]; j < l_begin[ll + 1]; ++j) {
-                        const Hit& h = by_locus[j];
+                        const Hit& h = by_locus(j);
                         uint32_t uid = 0;     // without --umi every read carries the same dummy UMI (:890-894)
-                        if (a->use_umi) uid = umi_ids.emplace(std::string((const char*)tag_store.data() + h.toff + h.rr.umi_off, h.rr.umi_len), (uint32_t)umi_ids.size()).first->second;
-                        recs.push_back(LocusBuild::Rec{h.cell, uid, h.roff - rbase, h.rr.read_len});
+                        if (a->use_umi) uid = umi_ids.emplace(std::string((const char*)tag_store.data() + h.toff + h.bc_len, h.umi_len), (uint32_t)umi_ids.size()).first->second;
+                        recs.push_back(LocusBuild::Rec{h.cell, uid, h.roff - rbase, h.read_len});
                     }
                     std::stable_sort(recs.begin(), recs.end(), [](const LocusBuild::Rec& x, const LocusBuild::Rec& y) {
                         return x.cell != y.cell ? x.cell < y.cell : x.umi < y.umi;
@@ -1323,6 +1347,8 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     *out = P.release();
     return VTX_OK;
 }
+
+int vtxh_read_format(const vtxh_pack* p) { return p ? p->read_format : VTX_READS_BYTES; }
 
 int vtxh_test_inflate(const uint8_t* in, uint64_t in_len, uint8_t* out, uint64_t out_len) {
     vtxinf::Tables T;

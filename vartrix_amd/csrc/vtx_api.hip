@@ -105,6 +105,8 @@ struct vtx_ctx {
     DevBuf d_cell_cnt, d_umi_cnt, d_keep, d_keep_scan, d_scan_tmp;
     DevBuf d_o_row, d_o_col, d_o_alt, d_o_ref, d_o_unk, d_o_val, d_o_refval;
     bool band_long_lists = false;      // (performance feedback between runs: see vtx_run)
+    int read_format = VTX_READS_BYTES;     // vtx_set_read_format
+    DevBuf d_read_packed;                  // VTX_READS_NIBBLES: the arena as uploaded, unpacked into d_read
     uint64_t gt_used = 0;      // bytes of d_gtables the last banded run's table kernel wrote (vtx_debug_tables)
     DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail, d_fail_tmp, d_refine;   // banded flavour
     DevBuf d_tight, d_tight_pack, d_dband, d_dband_pack, d_dense, d_stage;                                                 // round 4: tasks with a provisional score (full-matrix check); stage bytes (vtx_fetch_stage)
@@ -572,7 +574,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
                       &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp, &c->d_refine, &c->d_tight, &c->d_tight_pack, &c->d_dband, &c->d_dband_pack, &c->d_dense, &c->d_stage};
     for (DevBuf* b : bufs) b->release();
-    c->d_slow_ws.release(); c->d_slow_retry.release();
+    c->d_slow_ws.release(); c->d_slow_retry.release(); c->d_read_packed.release();
     DevBuf* gb[] = {&c->d_g_cnt, &c->d_g_row, &c->d_g_col, &c->d_g_alt, &c->d_g_ref, &c->d_g_unk, &c->d_g_val, &c->d_g_refval};
     for (DevBuf* b : gb) b->release();
     comm_release(c);
@@ -690,6 +692,9 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
     HIP_TRY(c, c->d_loci.reserve((size_t)nl * sizeof(vtx_locus)));
     HIP_TRY(c, c->d_hap.reserve(b->hap_bytes + 16));
     HIP_TRY(c, c->d_read.reserve(b->read_bytes + 16));
+    const bool nibbles = c->read_format == VTX_READS_NIBBLES;
+    if (nibbles && (b->read_bytes & 1)) return fail(c, VTX_E_INVAL, "vtx_submit: VTX_READS_NIBBLES needs an even read_bytes");
+    if (nibbles) HIP_TRY(c, c->d_read_packed.reserve(b->read_bytes / 2 + 16));
     if (int rc = reserve_record_buffers(c, nr)) return rc;
     HIP_TRY(c, c->d_seq.reserve(nr * u32));
     HIP_TRY(c, c->d_shape.reserve(nr + 16));
@@ -723,7 +728,10 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
     }
     HIP_TRY(c, hipMemcpyAsync(cnt, d_counters, 8 * u64, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(shape_cnt, d_shape_cnt, sizeof shape_cnt, hipMemcpyDeviceToHost, s));
-    if (int rc = upload(c, {{c->d_read.p, b->read_arena, (size_t)b->read_bytes}})) return rc;     // overlaps with the kernels above
+    if (nibbles) {
+        if (int rc = upload(c, {{c->d_read_packed.p, b->read_arena, (size_t)(b->read_bytes / 2)}})) return rc;
+        HIP_TRY(c, vtxk_unpack_nibbles(c->d_read_packed.as<uint8_t>(), b->read_bytes / 2, c->d_read.as<uint8_t>(), s));
+    } else if (int rc = upload(c, {{c->d_read.p, b->read_arena, (size_t)b->read_bytes}})) return rc;     // overlaps with the kernels above
     HIP_TRY(c, hipStreamSynchronize(s));
     if (cnt[6] != ~0ull) {
         const uint32_t r = (uint32_t)(cnt[6] >> 3), code = (uint32_t)(cnt[6] & 7);
@@ -827,6 +835,9 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     HIP_TRY(c, c->d_loci.reserve((size_t)nl * sizeof(vtx_locus)));
     HIP_TRY(c, c->d_hap.reserve(b->hap_bytes + 16));
     HIP_TRY(c, c->d_read.reserve(b->read_bytes + 16));
+    const bool nibbles = c->read_format == VTX_READS_NIBBLES;
+    if (nibbles && (b->read_bytes & 1)) return fail(c, VTX_E_INVAL, "vtx_submit_raw: VTX_READS_NIBBLES needs an even read_bytes");
+    if (nibbles) HIP_TRY(c, c->d_read_packed.reserve(b->read_bytes / 2 + 16));
     HIP_TRY(c, c->d_tags.reserve(b->tag_bytes + 16));
     HIP_TRY(c, c->d_raw.reserve((size_t)nr * sizeof(vtx_raw_record)));
     if (int rc = reserve_record_buffers(c, nr)) return rc;
@@ -852,7 +863,8 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
                             {c->d_raw.p, b->records, (size_t)nr * sizeof(vtx_raw_record)},
                             {c->d_hap.p, b->hap_arena, (size_t)b->hap_bytes},
                             {c->d_tags.p, b->tag_arena, (size_t)b->tag_bytes},
-                            {c->d_read.p, b->read_arena, (size_t)b->read_bytes}})) return rc;
+                            {nibbles ? c->d_read_packed.p : c->d_read.p, b->read_arena, (size_t)(nibbles ? b->read_bytes / 2 : b->read_bytes)}})) return rc;
+    if (nibbles) HIP_TRY(c, vtxk_unpack_nibbles(c->d_read_packed.as<uint8_t>(), b->read_bytes / 2, c->d_read.as<uint8_t>(), s));
 
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     const uint32_t cell_bits = bits_for(c->cfg.n_barcodes ? c->cfg.n_barcodes - 1 : 0);
@@ -1614,6 +1626,13 @@ int vtx_fetch_stage(vtx_ctx* c, uint8_t* stage) {
     if (c->n_records && !stage) return fail(c, VTX_E_INVAL, "vtx_fetch_stage: null output");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     if (c->n_records) HIP_TRY(c, hipMemcpy(stage, c->d_stage.p, 2 * (size_t)c->n_records, hipMemcpyDeviceToHost));
+    return VTX_OK;
+}
+
+int vtx_set_read_format(vtx_ctx* c, int format) {
+    if (!c) return VTX_E_INVAL;
+    if (format != VTX_READS_BYTES && format != VTX_READS_NIBBLES) return fail(c, VTX_E_INVAL, "vtx_set_read_format: unknown format %d", format);
+    c->read_format = format;
     return VTX_OK;
 }
 

@@ -171,6 +171,7 @@ hipError_t vtxk_prep_umi_ids(vtx_record* records, const uint32_t* umi_scan, uint
 hipError_t vtxk_prep_locus_ranges(vtx_locus* loci, const uint32_t* cnt, const uint32_t* cnt_scan, uint32_t n_loci, hipStream_t s);
 hipError_t vtxk_prep_lut_check(const uint32_t* work, uint32_t count, const uint32_t* rec_locus, uint32_t cap, uint32_t group,
                                uint32_t* flag, hipStream_t s);
+hipError_t vtxk_unpack_nibbles(const uint8_t* in, uint64_t n_in, uint8_t* out, hipStream_t s);
 hipError_t vtxk_prep_check(const vtx_record* records, uint32_t n, const uint32_t* rec_locus, const vtx_locus* loci,
                            uint64_t read_bytes, uint32_t max_read_len, uint32_t n_barcodes, uint32_t n_shapes, uint8_t* shape,
                            uint32_t* seq, uint32_t* shape_cnt, unsigned long long* counters, hipStream_t s);

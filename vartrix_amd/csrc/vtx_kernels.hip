@@ -373,6 +373,41 @@ extern "C" hipError_t vtxk_emit_coo(const uint32_t* cell_cnt, uint32_t n_grp, in
     return hipGetLastError();
 }
 
+// Read bases as the BAM holds them (two per byte, high nibble first; SAM spec 4.2.3: "=ACMGRSVTWYHKDBN") -> one byte per base,
+// what rec.seq().as_bytes() gives the reference (src/main.rs:896).  vtx_set_read_format(VTX_READS_NIBBLES): the host ships half
+// the bytes and this kernel writes the arena every other kernel reads.  16 input bytes -> 32 output bytes per thread.
+__global__ __launch_bounds__(256) void unpack_nibbles_kernel(const uint8_t* __restrict__ in, uint64_t n_in, uint8_t* __restrict__ out) {
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+    if (i >= n_in) return;
+    const uint64_t lut_lo = 0x565352474d43413dull, lut_hi = 0x4e42444b48595754ull;      // "=ACMGRSV", "TWYHKDBN" (little endian)
+    auto dec = [&](uint32_t nib) -> uint32_t { return (uint32_t)(((nib & 8u) ? lut_hi : lut_lo) >> (8u * (nib & 7u))) & 0xffu; };
+    if (i + 16 <= n_in) {
+        uint4 v;
+        __builtin_memcpy(&v, in + i, 16);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t o[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t b0 = (w[k] >> (16 * h)) & 0xffu, b1 = (w[k] >> (16 * h + 8)) & 0xffu;
+                o[2 * k + h] = dec(b0 >> 4) | (dec(b0 & 15u) << 8) | (dec(b1 >> 4) << 16) | (dec(b1 & 15u) << 24);
+            }
+        }
+        uint4 a = make_uint4(o[0], o[1], o[2], o[3]), b = make_uint4(o[4], o[5], o[6], o[7]);
+        __builtin_memcpy(out + 2 * i, &a, 16);
+        __builtin_memcpy(out + 2 * i + 16, &b, 16);
+    } else {
+        for (uint64_t j = i; j < n_in; ++j) { const uint32_t b0 = in[j]; out[2 * j] = (uint8_t)dec(b0 >> 4); out[2 * j + 1] = (uint8_t)dec(b0 & 15u); }
+    }
+}
+extern "C" hipError_t vtxk_unpack_nibbles(const uint8_t* in, uint64_t n_in, uint8_t* out, hipStream_t s) {
+    if (!n_in) return hipSuccess;
+    const uint64_t threads = (n_in + 15) / 16;
+    hipLaunchKernelGGL(unpack_nibbles_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, in, n_in, out);
+    return hipGetLastError();
+}
+
 // Matrix values of gathered triplets (vtx_gather_coo): the arithmetic of emit_coo_kernel on the three counts.
 __global__ void values_from_counts_kernel(const uint32_t* __restrict__ alt, const uint32_t* __restrict__ ref,
                                           const uint32_t* __restrict__ unk, uint32_t n, int mode,

@@ -17,7 +17,7 @@ CLI_PATH = os.path.join(_HERE, "bin", "vartrix")
 SYMBOLS = ("vtxh_pack_files", "vtxh_free", "vtxh_last_error", "vtxh_get_batch", "vtxh_get_metrics", "vtxh_get_ingest_stats",
            "vtxh_num_variants", "vtxh_num_barcodes", "vtxh_variant_name", "vtxh_barcode", "vtxh_write_mtx",
            "vtxh_format_f64", "vtxh_pack_files_raw", "vtxh_get_raw_batch", "vtxh_get_barcode_table", "vtxh_num_batches",
-           "vtxh_get_batch_at", "vtxh_get_raw_batch_at", "vtxh_pack_files_range", "vtxh_test_inflate")
+           "vtxh_get_batch_at", "vtxh_get_raw_batch_at", "vtxh_pack_files_range", "vtxh_test_inflate", "vtxh_read_format")
 METRIC_NAMES = ("num_reads", "num_low_mapq", "num_non_primary", "num_duplicates", "num_not_cell_bc",
                 "num_not_useful", "num_non_umi", "num_invalid_recs", "num_multiallelic_recs")
 
@@ -26,7 +26,7 @@ class VtxhArgs(C.Structure):
     _fields_ = [("vcf", C.c_char_p), ("bam", C.c_char_p), ("fasta", C.c_char_p), ("cell_barcodes", C.c_char_p),
                 ("padding", C.c_uint32), ("mapq", C.c_uint32), ("primary_only", C.c_int32),
                 ("no_duplicates", C.c_int32), ("use_umi", C.c_int32), ("bam_tag", C.c_char_p),
-                ("valid_chars", C.c_char_p), ("threads", C.c_int32)]
+                ("valid_chars", C.c_char_p), ("threads", C.c_int32), ("read_format", C.c_int32)]
 
 
 class VtxhMetrics(C.Structure):
@@ -56,6 +56,8 @@ def load():
         L.vtxh_get_raw_batch_at.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.VtxRawBatch)]
         L.vtxh_test_inflate.restype = C.c_int
         L.vtxh_test_inflate.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.vtxh_read_format.restype = C.c_int
+        L.vtxh_read_format.argtypes = [C.c_void_p]
         L.vtxh_free.argtypes = [C.c_void_p]
         L.vtxh_last_error.restype = C.c_char_p
         L.vtxh_get_batch.argtypes = [C.c_void_p, C.POINTER(abi.VtxBatch)]
@@ -86,14 +88,16 @@ class HostError(RuntimeError):
 
 
 def pack_files(vcf, bam, fasta, cell_barcodes, padding=100, mapq=0, primary_only=False, no_duplicates=False,
-               use_umi=False, bam_tag="CB", valid_chars="ATGCatgc", threads=1, raw=False, all_batches=False, rows=None):
+               use_umi=False, bam_tag="CB", valid_chars="ATGCatgc", threads=1, raw=False, all_batches=False, rows=None,
+               nibbles=False):
     """-> (PackedBatch, metrics dict, n_variants, barcodes list, variant names); with ``raw`` the batch is a
     RawBatch for ``Context.submit_raw`` (vtxh_pack_files_raw: tags as bytes, BAM order inside a locus).
     A pack whose reads span more than 4 GiB comes as several batches: ``all_batches`` returns the list of them
     (loci keep their global row; triplets of the batches are appended in order)."""
     L = load()
     args = VtxhArgs(vcf.encode(), bam.encode(), fasta.encode(), cell_barcodes.encode(), padding, mapq,
-                    int(primary_only), int(no_duplicates), int(use_umi), bam_tag.encode(), valid_chars.encode(), threads)
+                    int(primary_only), int(no_duplicates), int(use_umi), bam_tag.encode(), valid_chars.encode(), threads,
+                    abi.READS_NIBBLES if nibbles else abi.READS_BYTES)
     h = C.c_void_p()
     if rows is not None:      # streaming: VCF records [rows[0], rows[1]) only (vtxh_pack_files_range)
         rc = L.vtxh_pack_files_range(C.byref(args), int(raw), int(rows[0]), int(rows[1]), C.byref(h))
@@ -107,6 +111,8 @@ def pack_files(vcf, bam, fasta, cell_barcodes, padding=100, mapq=0, primary_only
                 return np.zeros(0, dt)
             return np.frombuffer(C.string_at(ptr, n * np.dtype(dt).itemsize), dtype=dt).copy()
         nb_batches = L.vtxh_num_batches(h)
+        fmt = int(L.vtxh_read_format(h))
+        rdiv = 2 if fmt == abi.READS_NIBBLES else 1
         if nb_batches != 1 and not all_batches:
             raise HostError("the pack has %d batches: call pack_files(..., all_batches=True)" % nb_batches)
         batches = []
@@ -115,13 +121,13 @@ def pack_files(vcf, bam, fasta, cell_barcodes, padding=100, mapq=0, primary_only
                 b = abi.VtxRawBatch()
                 L.vtxh_get_raw_batch_at(h, i, C.byref(b))
                 batches.append(abi.RawBatch(arr(b.loci, b.n_loci, abi.LOCUS_DTYPE), arr(b.records, b.n_records, abi.RAW_RECORD_DTYPE),
-                                            arr(b.hap_arena, b.hap_bytes, np.uint8), arr(b.read_arena, b.read_bytes, np.uint8),
-                                            arr(b.tag_arena, b.tag_bytes, np.uint8)))
+                                            arr(b.hap_arena, b.hap_bytes, np.uint8), arr(b.read_arena, b.read_bytes // rdiv, np.uint8),
+                                            arr(b.tag_arena, b.tag_bytes, np.uint8), fmt))
             else:
                 b = abi.VtxBatch()
                 L.vtxh_get_batch_at(h, i, C.byref(b))
                 batches.append(abi.PackedBatch(arr(b.loci, b.n_loci, abi.LOCUS_DTYPE), arr(b.records, b.n_records, abi.RECORD_DTYPE),
-                                               arr(b.hap_arena, b.hap_bytes, np.uint8), arr(b.read_arena, b.read_bytes, np.uint8)))
+                                               arr(b.hap_arena, b.hap_bytes, np.uint8), arr(b.read_arena, b.read_bytes // rdiv, np.uint8), fmt))
         batch = batches if all_batches else batches[0]
         m = VtxhMetrics()
         L.vtxh_get_metrics(h, C.byref(m))

@@ -23,7 +23,7 @@ SYMBOLS = (
     "vtx_fetch_coo", "vtx_device_scores", "vtx_device_coo", "vtx_last_timing", "vtx_last_cells", "vtx_strerror",
     "vtx_status_name", "vtx_abi_sizes", "vtx_set_barcodes", "vtx_submit_raw", "vtx_fetch_records",
     "vtx_comm_id", "vtx_comm_init", "vtx_gather_coo", "vtx_fetch_gathered", "vtx_gather_abort", "vtx_gather_plan",
-    "vtx_set_debug", "vtx_fetch_stage", "vtx_debug_bands", "vtx_debug_tables",
+    "vtx_set_debug", "vtx_fetch_stage", "vtx_debug_bands", "vtx_debug_tables", "vtx_set_read_format",
 )
 
 
@@ -96,6 +96,8 @@ def load():
     L.vtx_set_debug.argtypes = [ctxp, C.c_int, C.c_int64]
     L.vtx_fetch_stage.restype = C.c_int
     L.vtx_fetch_stage.argtypes = [ctxp, C.c_void_p]
+    L.vtx_set_read_format.restype = C.c_int
+    L.vtx_set_read_format.argtypes = [ctxp, C.c_int]
     L.vtx_debug_tables.restype = C.c_int
     L.vtx_debug_tables.argtypes = [ctxp, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.vtx_debug_bands.restype = C.c_int
@@ -165,7 +167,11 @@ class Context:
         except Exception:
             pass
 
+    def set_read_format(self, fmt: int):
+        self._check(self._L.vtx_set_read_format(self._h, int(fmt)))
+
     def submit(self, batch: abi.PackedBatch):
+        self.set_read_format(getattr(batch, "read_format", 0))
         st = batch.as_struct()
         self._check(self._L.vtx_submit(self._h, C.byref(st)))
         self.n_records = batch.n_records
@@ -181,6 +187,7 @@ class Context:
         self._check(self._L.vtx_set_barcodes(self._h, data.ctypes.data if data.size else None, offsets.ctypes.data, len(blobs)))
 
     def submit_raw(self, raw: abi.RawBatch) -> abi.VtxRawStats:
+        self.set_read_format(getattr(raw, "read_format", 0))
         st = raw.as_struct()
         stats = abi.VtxRawStats()
         self._check(self._L.vtx_submit_raw(self._h, C.byref(st), C.byref(stats)))
