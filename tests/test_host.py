@@ -598,3 +598,26 @@ def test_nibble_helpers_round_trip():
     s = n.slice_loci(7, 19)
     t = b.slice_loci(7, 19)
     assert np.array_equal(s.records, t.records) and np.array_equal(s.to_bytes().read_arena[:t.read_arena.size], t.read_arena)
+
+
+def test_own_inflate_on_long_huffman_codes():
+    """Geometrically distributed symbols: zlib's length-limited codes reach 15 bits, beyond the decoder's 11-bit primary table —
+    the subtable path."""
+    import random
+    import zlib
+    rng = random.Random(3)
+    for trial in range(6):
+        syms = list(range(256))
+        rng.shuffle(syms)
+        data = bytearray()
+        while len(data) < 60000:
+            k = 0
+            while k < 40 and rng.random() < 0.62:
+                k += 1
+            data.append(syms[k * 6 % 256 if k < 40 else rng.randrange(256)])
+        data = bytes(data)
+        for strat in (zlib.Z_HUFFMAN_ONLY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED):
+            co = zlib.compressobj(9, zlib.DEFLATED, -15, 9, strat)
+            raw = co.compress(data) + co.flush()
+            rc, out = _own_inflate(raw, len(data))
+            assert rc == 1 and out == data, (trial, strat)
