@@ -165,14 +165,15 @@ def author_fast(out_dir, V, R, B, Lr=150, seed=7, procs=32, chunk_loci=2000):
     return fa, os.path.join(out_dir, "v.vcf"), bam, os.path.join(out_dir, "bcs.tsv"), n_reads
 
 
-def run_cli_timed(out_dir, fa, vcf, bam, bcs, threads, extra, label):
+def run_cli_timed(out_dir, fa, vcf, bam, bcs, threads, extra, label, env=None):
     out = os.path.join(out_dir, "out.mtx")
     for f in (out, os.path.join(out_dir, "ref_matrix.mtx")):
         if os.path.exists(f):
             os.remove(f)
     t0 = time.time()
     r = subprocess.run([hostlib.CLI_PATH, "-v", vcf, "-b", bam, "-f", fa, "-c", bcs, "-o", out, "--threads", str(threads),
-                        "--log-level", "info"] + extra, cwd=out_dir, capture_output=True, text=True)
+                        "--log-level", "info"] + extra, cwd=out_dir, capture_output=True, text=True,
+                       env=dict(os.environ, **env) if env else None)
     wall = time.time() - t0
     assert r.returncode == 0, r.stdout + r.stderr
     keep = [ln for ln in r.stderr.splitlines() if any(k in ln for k in ("Ingest", "Device", "shard:", "Merge +", "Waited", "Total",
@@ -204,8 +205,12 @@ def main():
                 (["--prep", "host", "--reads", "bytes"], "--prep host --reads bytes (one byte per base, as before round 4's nibbles)", args.threads)]
         for th in args.more_threads:
             runs.append((["--prep", "device"], "--prep device, --threads %d" % th, th))
-        for extra, label, th in runs:
-            out = run_cli_timed(args.out, fa, vcf, bam, bcs, th, extra, label)
+        runs = [r + (None,) for r in runs]
+        if os.environ.get("E2E_TRY_HUGEPAGES"):
+            runs.append((["--prep", "host"], "--prep host, VTXH_HUGEPAGES=1 (transparent huge pages for the packer's arenas)", args.threads, {"VTXH_HUGEPAGES": "1"}))
+            runs.append((["--prep", "host"], "--prep host again (no huge pages)", args.threads, None))
+        for extra, label, th, env in runs:
+            out = run_cli_timed(args.out, fa, vcf, bam, bcs, th, extra, label, env)
             import hashlib
             texts.append(hashlib.sha256(open(out, "rb").read()).hexdigest())
             print("  .mtx %.1f MB, sha256 %s" % (os.path.getsize(out) / 1e6, texts[-1][:16]), flush=True)

@@ -190,6 +190,15 @@ struct ByteBuf {
             unsigned char* q = (unsigned char*)realloc(p, want);
             if (!q) return nullptr;
             p = q; cap = want;
+            // VTXH_HUGEPAGES=1 (experiment knob): ask for transparent huge pages for the big buffers.  Where the kernel has 2 MiB
+            // pages at hand this removes 511 of 512 first-touch faults; where it has to compact memory first it is several times
+            // SLOWER than 4 KiB faults (measured: 1.85 s against 0.71 s per GiB on the build container) — hence not the default.
+            static const bool huge = getenv("VTXH_HUGEPAGES") != nullptr;
+            if (huge && cap >= ((size_t)8 << 20)) {
+                const uintptr_t a0 = ((uintptr_t)p + ((size_t)2 << 20) - 1) & ~(uintptr_t)(((size_t)2 << 20) - 1);
+                const uintptr_t a1 = ((uintptr_t)p + cap) & ~(uintptr_t)(((size_t)2 << 20) - 1);
+                if (a1 > a0) (void)madvise((void*)a0, (size_t)(a1 - a0), MADV_HUGEPAGE);
+            }
         }
         unsigned char* r = p + len;
         len += add;
