@@ -621,3 +621,15 @@ def test_own_inflate_on_long_huffman_codes():
             raw = co.compress(data) + co.flush()
             rc, out = _own_inflate(raw, len(data))
             assert rc == 1 and out == data, (trial, strat)
+
+
+def test_packs_reuse_each_others_memory():
+    """The packer keeps released buffers of a megabyte and more and hands them out again (touched pages are what its time is made
+    of).  A buffer then arrives with another pack's bytes in it: with the threshold at 64 bytes every buffer of these small packs
+    is a reused one, and every result must still be what it is with fresh memory."""
+    import subprocess
+    env = dict(os.environ, VTXH_POOL_MIN="64")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "packer_equals or raw_packer or nibble_pack or splits_large or row_ranges or authored_indel"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -174,19 +174,70 @@ struct RawArr {
     size_t size() const { return n; }
 };
 
+// Buffers of a megabyte and more are kept when released and handed out again (a few, process-wide): their pages have been touched,
+// and touched pages are what the packer's time is made of — the pack of the NEXT range of a streamed run
+// (vtxh_pack_files_range) then writes into memory that costs nothing to write to.
+struct BufPool {
+    std::mutex m;
+    struct Item { unsigned char* p; size_t cap; };
+    std::vector<Item> items;
+    static constexpr size_t kKeep = 12;
+    size_t held = 0;                                          // bytes kept; bounded (VTXH_POOL_BYTES, default 8 GiB)
+    static size_t min_bytes() { static const size_t v = getenv("VTXH_POOL_MIN") ? (size_t)strtoull(getenv("VTXH_POOL_MIN"), nullptr, 10) : ((size_t)1 << 20); return v; }   // (tests: 64, so that small packs reuse each other's memory)
+    static size_t limit() { static const size_t v = getenv("VTXH_POOL_BYTES") ? (size_t)strtoull(getenv("VTXH_POOL_BYTES"), nullptr, 10) : ((size_t)8 << 30); return v; }
+    unsigned char* take(size_t want, size_t* cap) {
+        std::lock_guard<std::mutex> g(m);
+        size_t best = SIZE_MAX;
+        for (size_t i = 0; i < items.size(); ++i)
+            if (items[i].cap >= want && (best == SIZE_MAX || items[i].cap < items[best].cap)) best = i;
+        if (best == SIZE_MAX) return nullptr;
+        unsigned char* p = items[best].p; *cap = items[best].cap;
+        held -= items[best].cap;
+        items.erase(items.begin() + (long)best);
+        return p;
+    }
+    void give(unsigned char* p, size_t cap) {
+        if (!p) return;
+        if (cap < min_bytes() || getenv("VTXH_NO_BUFFER_POOL")) { free(p); return; }
+        std::lock_guard<std::mutex> g(m);
+        if (cap > limit()) { free(p); return; }
+        while (!items.empty() && (items.size() >= kKeep || held + cap > limit())) {      // make room: the smallest go first
+            size_t small = 0;
+            for (size_t i = 1; i < items.size(); ++i) if (items[i].cap < items[small].cap) small = i;
+            if (items.size() >= kKeep && items[small].cap >= cap) { free(p); return; }
+            held -= items[small].cap;
+            free(items[small].p); items.erase(items.begin() + (long)small);
+        }
+        items.push_back(Item{p, cap});
+        held += cap;
+    }
+};
+static BufPool g_buf_pool;
+
 struct ByteBuf {
     unsigned char* p = nullptr;
     size_t len = 0, cap = 0;
-    ~ByteBuf() { free(p); }
+    ~ByteBuf() { g_buf_pool.give(p, cap); }
     unsigned char* data() { return p; }
     const unsigned char* data() const { return p; }
     size_t size() const { return len; }
     void drop_prefix(size_t n) { if (n) { memmove(p, p + n, len - n); len -= n; } }
-    void release() { free(p); p = nullptr; len = cap = 0; }
+    void release() { g_buf_pool.give(p, cap); p = nullptr; len = cap = 0; }
     void swap_with(ByteBuf& o) { std::swap(p, o.p); std::swap(len, o.len); std::swap(cap, o.cap); }
     unsigned char* grow(size_t add) {      // returns the start of the new bytes; nullptr when out of memory
         if (len + add > cap || !p) {
             size_t want = std::max<size_t>(std::max(len + add, cap + cap / 2), 64);
+            if (want >= BufPool::min_bytes()) {
+                size_t pcap = 0;
+                if (unsigned char* q = g_buf_pool.take(len + add, &pcap)) {     // a kept buffer that holds what is needed now
+                    if (len) memcpy(q, p, len);
+                    g_buf_pool.give(p, cap);
+                    p = q; cap = pcap;
+                    unsigned char* r = p + len;
+                    len += add;
+                    return r;
+                }
+            }
             unsigned char* q = (unsigned char*)realloc(p, want);
             if (!q) return nullptr;
             p = q; cap = want;
