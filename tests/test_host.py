@@ -628,6 +628,7 @@ def test_packs_reuse_each_others_memory():
     of).  A buffer then arrives with another pack's bytes in it: with the threshold at 64 bytes every buffer of these small packs
     is a reused one, and every result must still be what it is with fresh memory."""
     import subprocess
+    import sys
     env = dict(os.environ, VTXH_POOL_MIN="64")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider",
                         "-k", "packer_equals or raw_packer or nibble_pack or splits_large or row_ranges or authored_indel"],
