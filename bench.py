@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--loci", type=int, default=None)
     ap.add_argument("--barcodes", type=int, default=None)
     ap.add_argument("--reads-per-locus", type=int, default=256)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--padding", type=int, default=100, help="bases of reference either side of the variant (src/main.rs:88): haplotypes of 2 x padding + 1")
     ap.add_argument("--depth-sigma", type=float, default=0.0,
                     help="> 0: reads per locus log-normal with this sigma and median --reads-per-locus (realistic depth mix)")
     ap.add_argument("--mode", default="consensus", choices=["consensus", "alt_frac", "coverage"])
@@ -169,6 +171,9 @@ def main():
     ap.add_argument("--sensitivity-steps", type=int, default=3)
     ap.add_argument("--no-other-aligner", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--sustain-seconds", type=float, default=1.0,
+                    help="after the K timed steps (the contract's measurement: value / ms_per_step), keep stepping until this much wall "
+                         "time has passed and report it as `sustained` (steps, seconds, value): a cross-check of a short timed region; 0: off")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -180,18 +185,29 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # Launch rehearsal on a one-GPU box (tests/test_gpu_shard.py): with VTX_COMM_TEST_TRANSPORT=<dir> and the developer library
+    # (VTX_LIB_VARIANT=dev) the ranks are processes that SHARE device 0, the library's exchange runs over the socket transport that
+    # stands in for RCCL there, and torch.distributed (barriers, the max over ranks) uses gloo — RCCL refuses two ranks on one GPU.
+    # Everything else — launcher plumbing, partitioning, vtx_comm_init / vtx_gather_coo per step, the JSON line — is the N-GPU path.
+    rehearsal = bool(os.environ.get("VTX_COMM_TEST_TRANSPORT")) and lib.DEFAULT_VARIANT == "dev"
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    force_gather = os.environ.get("VTX_FORCE_GATHER") == "1"     # exercise the RCCL path with one rank
+    ddev = torch.device("cpu") if rehearsal else device          # where torch.distributed's own tensors live
+    force_gather = os.environ.get("VTX_FORCE_GATHER") == "1"     # exercise the gather path with one rank
     use_gather = world > 1 or force_gather
     if use_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     workload = args.workload
     if workload == "auto":
-        workload = "custom" if (args.loci or args.barcodes or args.genome) else ("config3" if world == 1 else "config4")
+        workload = "custom" if (args.loci or args.barcodes or args.genome or args.read_len != 150 or args.padding != 100) else ("config3" if world == 1 else "config4")
     scaling = args.scaling
     if scaling == "auto":
         scaling = "strong"
@@ -200,8 +216,8 @@ def main():
     weak = scaling == "weak" and world > 1
 
     # ---- the workload: every rank generates the same batch (same seed) and keeps its range of loci ----
-    spec = synth.SynthSpec(n_loci=n_loci, n_barcodes=n_barcodes, reads_per_locus=args.reads_per_locus,
-                           use_umi=bool(args.umi), indel_frac=args.indel_frac, sub_error=args.sub_error,
+    spec = synth.SynthSpec(n_loci=n_loci, n_barcodes=n_barcodes, reads_per_locus=args.reads_per_locus, read_len=args.read_len,
+                           padding=args.padding, use_umi=bool(args.umi), indel_frac=args.indel_frac, sub_error=args.sub_error,
                            depth_sigma=args.depth_sigma, genome_fasta=args.genome, seed=20260926 + (rank if weak else 0))
     t_gen = time.perf_counter()
     whole = synth.make_batch(spec)
@@ -241,16 +257,19 @@ def main():
     if nib_attempted:
         ctx.submit(batch)                                      # the byte-submitted batch is what the timed steps run on
 
-    # Row gather.  Default: torch.distributed (RCCL) with shard.GatherPipeline — the gather of step k overlaps with the
-    # kernels of step k + 1.  VTX_NATIVE_GATHER=1: the C-ABI's own exchange (vtx_gather_coo: grouped ncclSend / ncclRecv
-    # of exact-size blocks behind the library, what a non-Python host would call); synchronous per step.
-    native = use_gather and os.environ.get("VTX_NATIVE_GATHER") == "1"
+    # Row gather.  Default: the PRODUCT's own exchange behind the C-ABI (vtx_comm_init / vtx_gather_coo: one ncclAllGather of
+    # (count, status), then grouped ncclSend / ncclRecv of exact-size blocks to their final offsets on rank 0 — what a Rust host would
+    # call in place of the merge loop, src/main.rs:284-291, :320-348); synchronous per step.  VTX_TORCH_GATHER=1: the alternative in
+    # Python, torch.distributed with shard.GatherPipeline (the gather of step k overlaps with the kernels of step k + 1).
+    native = use_gather and os.environ.get("VTX_TORCH_GATHER") != "1"
+    if rehearsal and not native:
+        raise SystemExit("bench.py: the launch rehearsal (VTX_COMM_TEST_TRANSPORT) runs the library's gather only")
     pipe = shard.GatherPipeline(cfg.scoring_mode) if (use_gather and not native) else None
     native_last = [None]
     if native:
-        ident = torch.zeros(lib.COMM_ID_BYTES, dtype=torch.uint8, device=device)
+        ident = torch.zeros(lib.COMM_ID_BYTES, dtype=torch.uint8, device=ddev)
         if rank == 0:
-            ident = torch.frombuffer(bytearray(lib.comm_id()), dtype=torch.uint8).to(device)
+            ident = torch.frombuffer(bytearray(lib.comm_id()), dtype=torch.uint8).to(ddev)
         dist.broadcast(ident, src=0)
         ctx.comm_init(bytes(ident.cpu().numpy().tobytes()), rank, world)
 
@@ -291,6 +310,21 @@ def main():
     drain()               # every step's gather has completed inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
+    # cross-check of a short timed region (the K steps above are the measurement): keep stepping until --sustain-seconds have passed
+    sustained = None
+    if args.sustain_seconds > 0 and elapsed < args.sustain_seconds:
+        more = int(min(10000, max(1, (args.sustain_seconds - elapsed) / max(elapsed / args.steps, 1e-6))))
+        if world > 1:                                      # every rank must take the same number of (collective) steps
+            mt = torch.tensor([more], dtype=torch.int64, device=ddev)
+            dist.all_reduce(mt, op=dist.ReduceOp.MAX)
+            more = int(mt.item())
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(more):
+            step()
+        drain()
+        fence()
+        sustained = {"steps": more, "seconds": time.perf_counter() - t1}
     n_aln = 2 * batch.n_records
     cells = ctx.cells()
     nnz = ctx.device_coo()["nnz"]
@@ -306,10 +340,12 @@ def main():
         summary = coo_summary(shard.device_coo_tensors(ctx, device))
 
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed, sustained["seconds"] if sustained else 0.0], dtype=torch.float64, device=ddev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        tot = torch.tensor([n_aln, cells, nnz], dtype=torch.int64, device=device)
+        elapsed = float(tt[0].item())
+        if sustained:
+            sustained["seconds"] = float(tt[1].item())
+        tot = torch.tensor([n_aln, cells, nnz], dtype=torch.int64, device=ddev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_aln, total_cells, total_nnz = (int(x) for x in tot.tolist())
     else:
@@ -347,7 +383,9 @@ def main():
     if rank == 0 and world == 1 and workload == "config3" and args.aligner == "banded" and not args.no_sensitivity:
         sensitivity = {}
         cases = [("real_sequence_loci", dict(genome_fasta=os.path.join(ROOT, "tests", "golden", "test_dna.fa"))),
-                 ("sub_error_3pct", dict(sub_error=0.03)), ("sub_error_8pct", dict(sub_error=0.08))]
+                 ("sub_error_3pct", dict(sub_error=0.03)), ("sub_error_8pct", dict(sub_error=0.08)),
+                 # shapes off the benchmark's (150-base reads, 201-base haplotypes): longer reads, a wider window
+                 ("reads_250bp", dict(read_len=250)), ("padding_150", dict(padding=150))]
         for name, kw in cases:
             if "genome_fasta" in kw and not os.path.exists(kw["genome_fasta"]):
                 continue
@@ -364,7 +402,7 @@ def main():
             torch.cuda.synchronize()
             dts = (time.perf_counter() - ts) / args.sensitivity_steps
             st = sctx.timing()
-            sensitivity[name] = {"workload": sspec.name, "alignments_per_step": 2 * sb.n_records, "steps": args.sensitivity_steps,
+            sensitivity[name] = {"workload": sspec.name + (", padding %d" % sspec.padding if sspec.padding != 100 else ""), "alignments_per_step": 2 * sb.n_records, "steps": args.sensitivity_steps,
                                  "ms_per_step": 1e3 * dts, "value": 2 * sb.n_records / dts, "unit": "read-alignments/s",
                                  "left_by_certificate_stages": int(st.diag_left), "full_matrix_checked": int(st.checked_tasks),
                                  "swept": int(st.swept_tasks), "masked_dp_tasks": int(st.hard_tasks), "declined_by_sweep": int(st.overflow_tasks),
@@ -418,6 +456,14 @@ def main():
                                     "one workload, contiguous locus ranges of equal record count per rank, COO rows "
                                     "gathered to rank 0 over RCCL") if world > 1 else "single GPU"},
             "result": summary,
+            "gather": (None if not use_gather else
+                       {"impl": "vtx_gather_coo (the library's exchange behind the C-ABI: ncclAllGather of (count, status) + grouped ncclSend / ncclRecv)"
+                                if native else "torch.distributed (shard.GatherPipeline: all_gather of counts + async gather)",
+                        "ranks": world, "transport": "socket test transport, ranks share one device (launch rehearsal)" if rehearsal else "RCCL",
+                        "per_step": True}),
+            "sustained": (None if sustained is None else
+                          dict(sustained, value=total_aln * sustained["steps"] / sustained["seconds"],
+                               ms_per_step=1e3 * sustained["seconds"] / sustained["steps"])),
             # dominant kernel; its duration is a hipEvent pair around its launch(es) on the context's stream, live in this run
             "roofline": {"bound": "hbm", "kernel": dom_label, "kernel_ms": dom_ms,
                          "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -61,6 +61,11 @@ typedef struct vtxh_pack vtxh_pack;
 int vtxh_pack_files(const vtxh_args* args, vtxh_pack** out);
 void vtxh_free(vtxh_pack* p);
 const char* vtxh_last_error(void);
+/* A freed pack's large buffers (>= 1 MiB) are kept for the next pack of the process — at most 12 buffers / 2 GiB; their pages have
+ * been touched, which is what a streamed run's next range gains from.  vtxh_trim() returns them to the allocator (a long-lived
+ * process that packed once calls it after vtxh_free).
+ * Limit: one pack holds at most 2^32 (read, locus) pairs (VTX_E_UNSUPPORTED beyond; pack ranges of VCF rows: vtxh_pack_files_range). */
+void vtxh_trim(void);
 
 /* Same ingest, but everything per-read that follows the alignment-level filters — barcode
  * dictionary lookup (:867-876), UB test (:879-888), UMI grouping (:1047-1057) and the sort by

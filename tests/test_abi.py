@@ -70,3 +70,32 @@ def test_no_cpu_fallback_without_device(L):
 def test_status_names(L):
     assert lib.status_name(0) == "VTX_OK"
     assert lib.status_name(abi.VTX_E_NODEVICE) == "VTX_E_NODEVICE"
+
+
+def test_production_library_has_no_experiment_hooks(L):
+    """libvtx.so as shipped reads ONE environment variable, VTX_DEBUG (stderr diagnostics).  Stage switches, ablations ("results
+    wrong by design"), buffer caps and the socket transport that stands in for RCCL are compiled into libvtx_dev.so only
+    (-DVTX_DEVTOOLS): a stray variable in a production environment cannot change a matrix."""
+    csrc = os.path.join(ROOT, "vartrix_amd", "csrc")
+    hooks = set()
+    for f in ("vtx_api.hip", "vtx_band.hip", "vtx_sweep.hip", "vtx_kernels.hip", "vtx_prep.hip", "vtx_comm_test.hip"):
+        src = open(os.path.join(csrc, f)).read()
+        hooks |= set(re.findall(r'VTX_DEV_ENV\("([A-Z0-9_]+)"\)', src))
+        # the only raw getenv of the library sources is VTX_DEBUG (the test transport, dev-only, reads its own directory variable)
+        assert set(re.findall(r'[^_]getenv\("([A-Z0-9_]+)"\)', src)) <= ({"VTX_DEBUG"} if f != "vtx_comm_test.hip" else {"VTX_COMM_TEST_TRANSPORT"}), f
+    assert len(hooks) >= 30 and {"VTX_DIAG_ABLATE", "VTX_SWEEP_ABLATE", "VTX_BAND_LEGACY", "VTX_COMM_TEST_TRANSPORT"} <= hooks
+
+    def present(path):
+        blob = open(path, "rb").read()
+        return {h for h in hooks if h.encode() in blob}
+    here = os.path.dirname(lib.lib_path(""))
+    assert present(os.path.join(here, "libvtx.so")) == set()
+    assert b"VTX_DEBUG" in open(os.path.join(here, "libvtx.so"), "rb").read()
+    assert present(os.path.join(here, "libvtx_dev.so")) == hooks
+    # the variants of the band-semantics tests are production builds with one constant changed: no hooks either
+    for v in ("lazy0",):
+        assert present(lib.lib_path(v)) == set(), v
+    # the developer library exports the same C-ABI
+    D = lib.load("dev")
+    for name in lib.SYMBOLS:
+        assert hasattr(D, name), name

@@ -169,13 +169,13 @@ def test_multi_batch_run_equals_single_batch(tmp_path, prep):
 
 
 def test_cli_row_gather_through_the_library(tmp_path):
-    """--devices N > 1 merges the shards with vtx_gather_coo (RCCL) instead of host-side concatenation; the hook forces
+    """--devices N > 1 merges the shards with vtx_gather_coo (RCCL) instead of host-side concatenation; `--gather library` takes
     that path with one device: same bytes as the plain run."""
     out1, out2 = str(tmp_path / "a.mtx"), str(tmp_path / "b.mtx")
     run_cli(base_args() + ["-o", out1, "-s", "alt_frac"], tmp_path)
     os.remove(tmp_path / "ref_matrix.mtx") if os.path.exists(tmp_path / "ref_matrix.mtx") else None
-    r = subprocess.run([hostlib.CLI_PATH] + base_args() + ["-o", out2, "-s", "alt_frac"], cwd=tmp_path, capture_output=True, text=True,
-                       timeout=300, env=dict(os.environ, VTX_CLI_FORCE_GATHER="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    r = subprocess.run([hostlib.CLI_PATH] + base_args() + ["-o", out2, "-s", "alt_frac", "--gather", "library"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert open(out1).read() == open(out2).read() == open(os.path.join(G, "test_frac.mtx")).read()
 

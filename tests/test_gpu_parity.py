@@ -252,7 +252,7 @@ np.save(sys.argv[1], np.stack([r, a]))
     outs = []
     for heads in ("256", "512", "2048"):
         out = str(tmp_path / (heads + ".npy"))
-        env = dict(os.environ, VTX_BAND_HEADS=heads)
+        env = dict(os.environ, VTX_LIB_VARIANT="dev", VTX_BAND_HEADS=heads)
         subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
         outs.append(np.load(out))
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
@@ -364,7 +364,7 @@ np.save(sys.argv[1], np.stack([r, a])); print("hard", t.hard_tasks, "overflow", 
     out = str(tmp_path / "capped.npy")
     # (VTX_BAND_HARD_CAP bounds the polyline / pending records of the round-3 path: VTX_BAND_LEGACY=1; the band slots bound both paths)
     extra = {hook: "3", "VTX_BAND_LEGACY": "1"} if hook == "VTX_BAND_HARD_CAP" else {hook: "3"}
-    r = subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, **extra), timeout=300,
+    r = subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, VTX_LIB_VARIANT="dev", **extra), timeout=300,
                        capture_output=True, text=True)
     got = np.load(out)
     spec = synth.SynthSpec(n_loci=150, n_barcodes=100, reads_per_locus=48, indel_frac=0.5, read_len_jitter=50, seed=15, sub_error=0.03)
@@ -405,7 +405,7 @@ np.save(sys.argv[1], np.stack([r, a]))
     for i, env in enumerate((dict(VTX_BAND_GT_MAX_TPL="0"), dict(VTX_BAND_GT_MAX_TPL="100000"), dict(VTX_BAND_GT_BYTES="400000"))):
         out = str(tmp_path / ("t%d.npy" % i))
         subprocess.run([sys.executable, "-c", code, out, str(reads_per_locus)], check=True,
-                       env=dict(os.environ, **env), timeout=300, capture_output=True, text=True)
+                       env=dict(os.environ, VTX_LIB_VARIANT="dev", **env), timeout=300, capture_output=True, text=True)
         got = np.load(out)
         assert np.array_equal(got[0], oref) and np.array_equal(got[1], oalt), env
 
@@ -556,7 +556,7 @@ np.save(OUT, np.concatenate(out))
     res = {}
     for kern in ("duo", "lut"):
         path = "/tmp/vtx_dp_%s_%d.npy" % (kern, os.getpid())
-        env = dict(os.environ, VTX_DP_KERNEL=kern, PYTHONPATH=root)
+        env = dict(os.environ, VTX_LIB_VARIANT="dev", VTX_DP_KERNEL=kern, PYTHONPATH=root)
         p = subprocess.run([sys.executable, "-c", code.replace("OUT", repr(path))], env=env, cwd=root, capture_output=True,
                            text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
@@ -600,7 +600,7 @@ np.save(OUT, np.concatenate([r, a, [hard]]))
     res = {}
     for name, env in (("one", {}), ("many", {"VTX_BAND_CHUNK": "3000"})):
         path = "/tmp/vtx_chunk_%s_%d.npy" % (name, os.getpid())
-        p = subprocess.run([sys.executable, "-c", code.replace("OUT", repr(path))], env=dict(os.environ, PYTHONPATH=root, **env),
+        p = subprocess.run([sys.executable, "-c", code.replace("OUT", repr(path))], env=dict(os.environ, VTX_LIB_VARIANT="dev", PYTHONPATH=root, **env),
                            cwd=root, capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
         res[name] = np.load(path)
@@ -640,3 +640,27 @@ def test_nibble_read_arena_gives_the_same_result():
             outs.append(ctx.fetch_coo())
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_nibble_arena_rejects_a_read_at_an_odd_base():
+    """include/vtx.h: with VTX_READS_NIBBLES every read starts at an even base.  A record that does not is an error of the caller
+    (it would be aligned shifted by one base): vtx_submit and vtx_submit_raw return VTX_E_INVAL and name it."""
+    from vartrix_amd import abi
+    spec = synth.SynthSpec(n_loci=20, n_barcodes=50, reads_per_locus=8, seed=3)
+    batch = synth.make_batch(spec)
+    nib = batch.to_nibbles()
+    recs = nib.records.copy()
+    recs["read_off"][5] += 1
+    bad = abi.PackedBatch(nib.loci, recs, nib.hap_arena, nib.read_arena, abi.READS_NIBBLES)
+    with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=50)) as ctx:
+        with pytest.raises(lib.VtxError) as e:
+            ctx.submit(bad)
+        assert e.value.status == abi.VTX_E_INVAL and "record 5" in str(e.value) and "odd" in str(e.value)
+        ctx.submit(nib); ctx.run()                       # the context is still usable
+        raw, barcodes = synth.make_raw(batch, 50, use_umi=False)
+        rr = raw.records.copy()
+        rr["read_off"][3] += 1
+        ctx.set_barcodes(barcodes)
+        with pytest.raises(lib.VtxError) as e:
+            ctx.submit_raw(abi.RawBatch(raw.loci, rr, raw.hap_arena, abi.pack_nibbles(raw.read_arena), raw.tag_arena, abi.READS_NIBBLES))
+        assert e.value.status == abi.VTX_E_INVAL and "odd" in str(e.value)

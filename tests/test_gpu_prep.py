@@ -112,7 +112,7 @@ assert st.hash_rounds == 3, st.hash_rounds
 assert prep.canonical_records(recs, begin, count) == prep.canonical_records(want.records, want.loci["rec_begin"], want.loci["rec_count"])
 print("ROUNDS", st.hash_rounds)
 """
-    env = dict(os.environ, VTX_PREP_WEAK_ROUNDS="2", PYTHONPATH=ROOT)
+    env = dict(os.environ, VTX_LIB_VARIANT="dev", VTX_PREP_WEAK_ROUNDS="2", PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "ROUNDS 3" in out.stdout

@@ -121,11 +121,41 @@ def test_native_rccl_gather_one_rank_equals_fetch_coo():
     assert r.returncode == 0 and "native-gather-one-rank-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_bench_native_gather_matches_plain_run():
+def test_bench_torch_gather_matches_plain_run():
+    """The alternative exchange in Python (VTX_TORCH_GATHER=1: shard.GatherPipeline over torch.distributed) gives the same matrix;
+    the default — asserted here too — is the library's own vtx_gather_coo."""
     args = ["--loci", "1500", "--barcodes", "5000", "--reads-per-locus", "64"]
     plain = _bench({}, args)
-    nat = _bench({"VTX_FORCE_GATHER": "1", "VTX_NATIVE_GATHER": "1"}, args)
-    assert plain["result"] == nat["result"] and nat["result"]["nnz"] > 10000
+    nat = _bench({"VTX_FORCE_GATHER": "1"}, args)
+    alt = _bench({"VTX_FORCE_GATHER": "1", "VTX_TORCH_GATHER": "1"}, args)
+    assert plain["result"] == nat["result"] == alt["result"] and nat["result"]["nnz"] > 10000
+    assert plain["gather"] is None
+    assert nat["gather"]["impl"].startswith("vtx_gather_coo") and nat["gather"]["transport"] == "RCCL" and nat["gather"]["ranks"] == 1
+    assert alt["gather"]["impl"].startswith("torch.distributed")
+
+
+def test_two_rank_launch_rehearsal_on_one_device(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` exactly as the driver launches the scaling bench,
+    on ONE device: the ranks share it, the library's exchange (vtx_comm_init, vtx_gather_coo in every step) runs over the test
+    transport of libvtx_dev.so, torch.distributed falls back to gloo for the barriers.  The line must parse, say n_gpus 2 and the
+    library's gather, and carry the matrix of the unsharded run."""
+    args = ["--loci", "4000", "--barcodes", "50000", "--reads-per-locus", "32"]
+    plain = _bench({}, args)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VTX_LIB_VARIANT="dev", VTX_COMM_TEST_TRANSPORT=str(tmp_path))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"] + args,
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "strong"
+    assert j["gather"]["impl"].startswith("vtx_gather_coo") and j["gather"]["ranks"] == 2
+    assert j["result"] == plain["result"] and j["result"]["nnz"] > 50000
+    assert j["config"]["alignments_per_step"] == plain["config"]["alignments_per_step"]
+    assert j["value"] > 0 and j["ms_per_step"] > 0 and j["sustained"]["steps"] >= 1
 
 
 # ---- vtx_gather_coo with world 2 and 4: ranks = processes on ONE device, RCCL's nine entry points replaced by the test transport
@@ -177,7 +207,7 @@ with lib.Context(cfg) as ctx:
 
 
 def _run_world(world, scenario, tmp):
-    env = dict(os.environ, VTX_COMM_TEST_TRANSPORT=str(tmp))
+    env = dict(os.environ, VTX_LIB_VARIANT="dev", VTX_COMM_TEST_TRANSPORT=str(tmp))   # (the test transport is in libvtx_dev.so only)
     procs = [subprocess.Popen([sys.executable, "-c", _RANK_CODE, str(r), str(world), scenario, str(tmp)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = []

@@ -143,7 +143,7 @@ np.save(sys.argv[1], np.concatenate(out))
     res = []
     with tempfile.TemporaryDirectory() as td:
         for wide in (0, 1):
-            env = dict(os.environ)
+            env = dict(os.environ, VTX_LIB_VARIANT="dev")            # (the hooks exist in libvtx_dev.so only)
             env.pop("VTX_DIAG_WIDE", None)
             if wide:
                 env["VTX_DIAG_WIDE"] = "1"
@@ -182,7 +182,7 @@ np.save(sys.argv[1], np.concatenate(out))
     res = []
     with tempfile.TemporaryDirectory() as td:
         for serial in (0, 1):
-            env = dict(os.environ, VTX_BAND_LEGACY="1")             # (the general kernels are the round-3 path; round 4's default only sends them what band_sweep_kernel declines)
+            env = dict(os.environ, VTX_LIB_VARIANT="dev", VTX_BAND_LEGACY="1")             # (the general kernels are the round-3 path; round 4's default only sends them what band_sweep_kernel declines)
             env.pop("VTX_BAND_NO_COOP", None)
             if serial:
                 env["VTX_BAND_NO_COOP"] = "1"
@@ -217,7 +217,7 @@ np.save(sys.argv[1], np.concatenate(out))
     res = []
     with tempfile.TemporaryDirectory() as td:
         for off in (0, 1):
-            env = dict(os.environ, VTX_BAND_LEGACY="1")             # (hard-task counts of the round-3 path; with the full-matrix check in front the refinement changes little)
+            env = dict(os.environ, VTX_LIB_VARIANT="dev", VTX_BAND_LEGACY="1")             # (hard-task counts of the round-3 path; with the full-matrix check in front the refinement changes little)
             env.pop("VTX_BAND_NO_REFINE", None)
             if off:
                 env["VTX_BAND_NO_REFINE"] = "1"
@@ -250,7 +250,7 @@ np.save(sys.argv[1], np.concatenate(out))
         for env_extra in ({}, {"VTX_BAND_NO_DIAG": "1"}):
             path = os.path.join(td, "s%d.npy" % len(res))
             r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=900,
-                               env=dict(os.environ, **env_extra))
+                               env=dict(os.environ, VTX_LIB_VARIANT="dev", **env_extra))
             assert r.returncode == 0, r.stderr[-3000:]
             res.append(np.load(path))
         assert np.array_equal(res[0], res[1])

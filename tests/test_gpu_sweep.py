@@ -45,7 +45,7 @@ def bands_vs_oracle(batch, nb, label, max_tasks=6000, tier=0):
     stride = int(max(batch.loci["ref_len"].max(), batch.loci["alt_len"].max())) + 1
     os.environ["VTX_SWEEP_TIER"] = str(tier)                       # (read at every vtx_debug_bands call)
     try:
-        with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb)) as ctx:
+        with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb), variant="dev" if tier else None) as ctx:
             ctx.submit(batch)
             lo, hi, status = ctx.debug_bands(tasks, stride)
     finally:
@@ -203,7 +203,7 @@ def test_hooks_give_the_same_scores(hook):
     res = []
     with tempfile.TemporaryDirectory() as td:
         for on in (0, 1):
-            env = dict(os.environ)
+            env = dict(os.environ, VTX_LIB_VARIANT="dev")           # (the hooks exist in libvtx_dev.so only)
             env.pop(hook, None)
             if on:
                 env[hook] = "5" if hook == "VTX_BAND_SLOTS" else "1"
@@ -215,8 +215,8 @@ def test_hooks_give_the_same_scores(hook):
     assert np.array_equal(res[0], res[1])
 
 
-def _tables_and_scores(batch, nb):
-    with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb)) as ctx:
+def _tables_and_scores(batch, nb, variant=None):
+    with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb), variant=variant) as ctx:
         ctx.submit(batch)
         ctx.run()
         return ctx.debug_tables(), ctx.fetch_scores()
@@ -263,10 +263,10 @@ def test_table_kernel_against_round3s():
     checked = 0
     for label, batch, nb in cases:
         os.environ.pop("VTX_BAND_TABLES_V1", None)
-        tp, sp = _tables_and_scores(batch, nb)
+        tp, sp = _tables_and_scores(batch, nb)                   # the production library
         os.environ["VTX_BAND_TABLES_V1"] = "1"
         try:
-            ts, ss = _tables_and_scores(batch, nb)
+            ts, ss = _tables_and_scores(batch, nb, variant="dev")   # round 3's kernel lives on in libvtx_dev.so
         finally:
             os.environ.pop("VTX_BAND_TABLES_V1", None)
         assert len(tp) == len(ts)

@@ -33,9 +33,24 @@ def same_batch(a, b):
 
 @pytest.fixture(scope="module", autouse=True)
 def built():
+    # the developer build of the host library and the CLI: this module's hooks (VTXH_BATCH_BYTES, VTXH_CHUNK_BLOCKS, VTXH_NO_INDEX,
+    # VTXH_ZLIB_INFLATE, VTXH_POOL_MIN) do not exist in the production library
+    hostlib.use_variant("dev")
     if not (os.path.exists(hostlib.LIB_PATH) and os.path.exists(hostlib.CLI_PATH)):
         import __graft_entry__
         __graft_entry__.build()
+    yield
+    hostlib.use_variant("dev" if os.environ.get("VTX_LIB_VARIANT") == "dev" else "")
+
+
+def test_production_host_library_has_no_test_hooks():
+    """libvtxhost.so / bin/vartrix as shipped: VTXH_PROFILE is the only environment variable they know."""
+    import re
+    here = os.path.dirname(hostlib.LIB_PATH)
+    for path in (os.path.join(here, "libvtxhost.so"), os.path.join(here, "bin", "vartrix")):
+        names = set(re.findall(rb"VTXH?_[A-Z][A-Z0-9_]{3,}", open(path, "rb").read()))
+        names = {n for n in names if not n.startswith((b"VTX_E_", b"VTX_OK"))}
+        assert names <= {b"VTXH_PROFILE"}, (path, names)
 
 
 def _inputs(bc="barcodes.tsv"):

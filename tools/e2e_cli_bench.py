@@ -205,13 +205,7 @@ def main():
                 (["--prep", "host", "--reads", "bytes"], "--prep host --reads bytes (one byte per base, as before round 4's nibbles)", args.threads)]
         for th in args.more_threads:
             runs.append((["--prep", "device"], "--prep device, --threads %d" % th, th))
-        runs = [] if os.environ.get("E2E_ONLY_EXTRA") else [r + (None,) for r in runs]
-        if os.environ.get("E2E_TRY_SPIN"):
-            for sp in os.environ["E2E_TRY_SPIN"].split(","):
-                runs.append((["--prep", "host"], "--prep host, VTXH_POOL_SPIN=%s" % sp, args.threads, {"VTXH_POOL_SPIN": sp}))
-        if os.environ.get("E2E_TRY_HUGEPAGES"):
-            runs.append((["--prep", "host"], "--prep host, VTXH_HUGEPAGES=1 (transparent huge pages for the packer's arenas)", args.threads, {"VTXH_HUGEPAGES": "1"}))
-            runs.append((["--prep", "host"], "--prep host again (no huge pages)", args.threads, None))
+        runs = [r + (None,) for r in runs]
         for extra, label, th, env in runs:
             out = run_cli_timed(args.out, fa, vcf, bam, bcs, th, extra, label, env)
             import hashlib

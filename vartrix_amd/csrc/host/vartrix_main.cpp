@@ -68,7 +68,7 @@ const Opt kOpts[] = {
     {"primary-alignments", 0, true, nullptr}, {"no-duplicates", 0, true, nullptr}, {"umi", 0, true, nullptr},
     {"bam-tag", 0, false, "CB"}, {"valid-chars", 0, false, "ATGCatgc"},
     {"devices", 0, false, "1"}, {"aligner", 0, false, "banded"}, {"prep", 0, false, "host"},
-    {"stream-loci", 0, false, "auto"}, {"reads", 0, false, "nibbles"},
+    {"stream-loci", 0, false, "auto"}, {"reads", 0, false, "nibbles"}, {"gather", 0, false, "auto"},
 };
 
 void usage() {
@@ -84,7 +84,9 @@ void usage() {
             "                               range k; host memory follows the range, not the BAM); 0 = the whole input at once;\n"
             "                               auto = at once when the BAM is below 4 GiB (faster: one sweep), ranges of 32768 above\n"
             "  --reads nibbles|bytes [nibbles]  read bases on their way to the device: two per byte as the BAM holds them (the device\n"
-            "                               unpacks), or one ASCII byte per base\n");
+            "                               unpacks), or one ASCII byte per base\n"
+            "  --gather auto|library [auto]  how the shards' rows meet: auto = through the library's RCCL gather when --devices > 1;\n"
+            "                               library = through it even with one device (the same bytes either way)\n");
 }
 
 // The shard threads of one batch meet here before each RCCL collective, carrying their status: if any shard has failed,
@@ -282,6 +284,10 @@ int main(int argc, char** argv) {
         return 1;
     }
     const bool raw = val["prep"] == "device";
+    if (val["gather"] != "auto" && val["gather"] != "library") {
+        fprintf(stderr, "error: '%s' isn't a valid value for '--gather <gather>'\n", val["gather"].c_str());
+        return 1;
+    }
     const int ndev = std::max(1, atoi(val["devices"].c_str()));
     std::vector<std::thread> warm;
     for (int d = 0; d < ndev; ++d) warm.emplace_back(warm_device, d);
@@ -440,7 +446,7 @@ int main(int argc, char** argv) {
         uint8_t comm_id[VTX_COMM_ID_BYTES];
         ShardGate gate;
         gate.world = ndev;
-        const bool use_comm = ndev > 1 || getenv("VTX_CLI_FORCE_GATHER");
+        const bool use_comm = ndev > 1 || val["gather"] == "library";
         if (use_comm) {
             if (int rc = vtx_comm_id(comm_id)) { printf("Vartrix error.\nError: %s: %s\n", vtx_status_name(rc), vtx_strerror(nullptr)); return 1; }
             for (int d = 0; d < ndev; ++d) { shards[(size_t)d].comm_id = comm_id; shards[(size_t)d].rank = d; shards[(size_t)d].world = ndev; shards[(size_t)d].gate = &gate; }

@@ -34,6 +34,15 @@
 #include "../../../include/vtx_host.h"
 #include "vtx_inflate.h"
 
+// Test hooks (window / batch sizes that force the many-window and many-batch paths, the zlib-only inflater, the buffer pool's
+// thresholds) exist only in libvtxhost_dev.so (-DVTX_DEVTOOLS; tests/ load it).  The production library reads one environment
+// variable, VTXH_PROFILE (phase timings on stderr; changes no result).
+#ifdef VTX_DEVTOOLS
+#define VTXH_DEV_ENV(name) getenv(name)
+#else
+#define VTXH_DEV_ENV(name) ((const char*)nullptr)
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -182,9 +191,14 @@ struct BufPool {
     struct Item { unsigned char* p; size_t cap; };
     std::vector<Item> items;
     static constexpr size_t kKeep = 12;
-    size_t held = 0;                                          // bytes kept; bounded (VTXH_POOL_BYTES, default 8 GiB)
-    static size_t min_bytes() { static const size_t v = getenv("VTXH_POOL_MIN") ? (size_t)strtoull(getenv("VTXH_POOL_MIN"), nullptr, 10) : ((size_t)1 << 20); return v; }   // (tests: 64, so that small packs reuse each other's memory)
-    static size_t limit() { static const size_t v = getenv("VTXH_POOL_BYTES") ? (size_t)strtoull(getenv("VTXH_POOL_BYTES"), nullptr, 10) : ((size_t)8 << 30); return v; }
+    size_t held = 0;                                          // bytes kept; bounded (2 GiB: two ranges of a streamed run; vtxh_trim() returns them)
+    static size_t min_bytes() { static const size_t v = VTXH_DEV_ENV("VTXH_POOL_MIN") ? (size_t)strtoull(VTXH_DEV_ENV("VTXH_POOL_MIN"), nullptr, 10) : ((size_t)1 << 20); return v; }   // (tests: 64, so that small packs reuse each other's memory)
+    static size_t limit() { static const size_t v = VTXH_DEV_ENV("VTXH_POOL_BYTES") ? (size_t)strtoull(VTXH_DEV_ENV("VTXH_POOL_BYTES"), nullptr, 10) : ((size_t)2 << 30); return v; }
+    void trim() {
+        std::lock_guard<std::mutex> g(m);
+        for (auto& it : items) free(it.p);
+        items.clear(); held = 0;
+    }
     unsigned char* take(size_t want, size_t* cap) {
         std::lock_guard<std::mutex> g(m);
         size_t best = SIZE_MAX;
@@ -198,7 +212,7 @@ struct BufPool {
     }
     void give(unsigned char* p, size_t cap) {
         if (!p) return;
-        if (cap < min_bytes() || getenv("VTXH_NO_BUFFER_POOL")) { free(p); return; }
+        if (cap < min_bytes() || VTXH_DEV_ENV("VTXH_NO_BUFFER_POOL")) { free(p); return; }
         std::lock_guard<std::mutex> g(m);
         if (cap > limit()) { free(p); return; }
         while (!items.empty() && (items.size() >= kKeep || held + cap > limit())) {      // make room: the smallest go first
@@ -229,7 +243,9 @@ struct ByteBuf {
             size_t want = std::max<size_t>(std::max(len + add, cap + cap / 2), 64);
             if (want >= BufPool::min_bytes()) {
                 size_t pcap = 0;
-                if (unsigned char* q = g_buf_pool.take(len + add, &pcap)) {     // a kept buffer that holds what is needed now
+                unsigned char* q = g_buf_pool.take(want, &pcap);                // a kept buffer with the geometric headroom (a buffer that
+                if (!q) q = g_buf_pool.take(len + add, &pcap);                  // grows step by step is not re-copied at every step), else one
+                if (q) {                                                        // that holds what is needed now
                     if (len) memcpy(q, p, len);
                     g_buf_pool.give(p, cap);
                     p = q; cap = pcap;
@@ -241,15 +257,6 @@ struct ByteBuf {
             unsigned char* q = (unsigned char*)realloc(p, want);
             if (!q) return nullptr;
             p = q; cap = want;
-            // VTXH_HUGEPAGES=1 (experiment knob): ask for transparent huge pages for the big buffers.  Where the kernel has 2 MiB
-            // pages at hand this removes 511 of 512 first-touch faults; where it has to compact memory first it is several times
-            // SLOWER than 4 KiB faults (measured: 1.85 s against 0.71 s per GiB on the build container) — hence not the default.
-            static const bool huge = getenv("VTXH_HUGEPAGES") != nullptr;
-            if (huge && cap >= ((size_t)8 << 20)) {
-                const uintptr_t a0 = ((uintptr_t)p + ((size_t)2 << 20) - 1) & ~(uintptr_t)(((size_t)2 << 20) - 1);
-                const uintptr_t a1 = ((uintptr_t)p + cap) & ~(uintptr_t)(((size_t)2 << 20) - 1);
-                if (a1 > a0) (void)madvise((void*)a0, (size_t)(a1 - a0), MADV_HUGEPAGE);
-            }
         }
         unsigned char* r = p + len;
         len += add;
@@ -286,7 +293,7 @@ bool index_bgzf(const MappedFile& file, std::vector<BgzfBlock>& blocks) {
 // — malformed or merely unusual — goes to zlib, which decides.  VTXH_ZLIB_INFLATE=1: zlib only (A/B timing, tests).
 bool inflate_block(const MappedFile& file, const BgzfBlock& b, unsigned char* dst) {
     if (b.isize == 0) return true;
-    const bool zlib_only = getenv("VTXH_ZLIB_INFLATE") != nullptr;      // (per block: a test switches it between two packs of one process)
+    const bool zlib_only = VTXH_DEV_ENV("VTXH_ZLIB_INFLATE") != nullptr;      // (per block: a test switches it between two packs of one process)
     if (!zlib_only) {
         vtxinf::Tables T;
         if (vtxinf::inflate_raw((const uint8_t*)file.data() + b.coff, b.clen, dst, b.isize, T)) return true;
@@ -424,11 +431,9 @@ bool useful_alignment(const unsigned char* cig, uint32_t n_ops, int64_t pos, int
 }
 
 // Minimal persistent worker pool: run(fn) executes fn(t) for t in [0, n) — t = 0 on the caller — and waits.
-// The sweep calls run() three or four times per window of blocks, a few milliseconds apart; a worker that went to sleep on the
-// condition variable in between needs a futex wake.  Waiters may SPIN before they sleep (VTXH_POOL_SPIN pause instructions) —
-// an experiment knob, off by default: on the build container 20 000 pauses made a pack 20 % faster, on the GPU boxes (16 CPUs of
-// quota for 18 threads) 2 000 made the ingest 20 % SLOWER (1.5 - 1.7 s -> 1.9 - 2.0 s, profiles/r04_e2e_cli_spin.log): the spinning
-// is paid from the same quota as the work.
+// The sweep calls run() three or four times per window of blocks, a few milliseconds apart; the workers sleep on a condition
+// variable in between (spinning before the sleep was measured in round 4 and is gone: on the GPU boxes' CPU quota it made the ingest
+// 20 % slower, profiles/r04_e2e_cli_spin.log).
 class Pool {
   public:
     explicit Pool(int n) : n_(n < 1 ? 1 : n) {
@@ -444,7 +449,6 @@ class Pool {
         { std::lock_guard<std::mutex> g(m_); fn_ = &fn; pending_.store(n_ - 1); gen_.fetch_add(1); }
         cv_.notify_all();
         fn(0);
-        for (int i = 0; i < kSpin && pending_.load(std::memory_order_acquire) != 0; ++i) cpu_relax();
         if (pending_.load(std::memory_order_acquire) != 0) {
             std::unique_lock<std::mutex> g(m_);
             done_.wait(g, [this] { return pending_.load() == 0; });
@@ -453,17 +457,10 @@ class Pool {
     }
 
   private:
-    const int kSpin = getenv("VTXH_POOL_SPIN") ? atoi(getenv("VTXH_POOL_SPIN")) : 0;
-    static void cpu_relax() {
-#if defined(__x86_64__) || defined(__i386__)
-        __builtin_ia32_pause();
-#endif
-    }
     void loop(int t) {
         uint64_t seen = 0;
         while (true) {
             const std::function<void(size_t)>* fn;
-            for (int i = 0; i < kSpin && gen_.load(std::memory_order_acquire) == seen; ++i) cpu_relax();
             {
                 std::unique_lock<std::mutex> g(m_);
                 cv_.wait(g, [&] { return gen_.load() != seen; });
@@ -616,6 +613,7 @@ int vtxh_write_mtx(const char* path, uint32_t n_rows, uint32_t n_cols, uint64_t 
 }
 
 void vtxh_free(vtxh_pack* p) { delete p; }
+void vtxh_trim(void) { g_buf_pool.trim(); }
 uint32_t vtxh_num_batches(const vtxh_pack* p) { return (uint32_t)p->batches.size(); }
 void vtxh_get_batch_at(const vtxh_pack* p, uint32_t i, vtx_batch* out) {
     memset(out, 0, sizeof *out);
@@ -791,7 +789,7 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     size_t buf_pos = 0, next_block = 0;
     size_t chunk_blocks = 512;            // blocks per inflate round; restarts small after an index-guided jump
     size_t max_chunk_blocks = 512;
-    if (const char* e = getenv("VTXH_CHUNK_BLOCKS")) chunk_blocks = max_chunk_blocks = std::max<size_t>(1, strtoull(e, nullptr, 10));   // tests: many windows
+    if (const char* e = VTXH_DEV_ENV("VTXH_CHUNK_BLOCKS")) chunk_blocks = max_chunk_blocks = std::max<size_t>(1, strtoull(e, nullptr, 10));   // tests: many windows
     size_t chunk_limit_block = SIZE_MAX;  // index-guided sweep: no read-ahead beyond the block the sweep would jump to anyway
     uint64_t n_inflated = 0, n_jumps = 0;
     // the window whose records are indexed but not parsed yet (the parse of window k runs beside the indexing of window
@@ -925,7 +923,7 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     bool use_index = false;
     {
         std::vector<std::vector<uint64_t>> lin;
-        if (!getenv("VTXH_NO_INDEX") && read_bai_linear(std::string(a->bam) + ".bai", bam_refs.size(), lin)) {
+        if (!VTXH_DEV_ENV("VTXH_NO_INDEX") && read_bai_linear(std::string(a->bam) + ".bai", bam_refs.size(), lin)) {
             use_index = true;
             for (size_t t = 0; t < by_tid.size(); ++t) {
                 const auto& iv = by_tid[t];
@@ -1306,7 +1304,7 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     const size_t n_sorted = n_hits;
     // ---- batches: consecutive loci whose reads / tags span < 4 GiB (32-bit offsets relative to the batch window) ----
     uint64_t limit = 0xF0000000ull;
-    if (const char* e = getenv("VTXH_BATCH_BYTES")) limit = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // tests
+    if (const char* e = VTXH_DEV_ENV("VTXH_BATCH_BYTES")) limit = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // tests
     const bool need_tags = raw;
     {
         vtxh_pack::Batch cur{0, 0, 0, 0, 0, 0, 0, 0};

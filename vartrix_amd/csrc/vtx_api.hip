@@ -314,7 +314,9 @@ int fetch_arrays(vtx_ctx* c, size_t n, const void* row, const void* col, const v
     return VTX_OK;
 }
 
-extern "C" void* vtxt_comm_test_table(void** fns);          // vtx_comm_test.hip
+#ifdef VTX_DEVTOOLS
+extern "C" void* vtxt_comm_test_table(void** fns);          // vtx_comm_test.hip (linked into libvtx_dev.so only)
+#endif
 // ---- RCCL, opened on first use ---------------------------------------------------------------------------------
 struct Rccl {
     void* lib = nullptr;
@@ -332,9 +334,10 @@ Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;          // vtx_comm_init is called from several threads at once (one context per GPU)
     std::call_once(once, [] {
-        if (getenv("VTX_COMM_TEST_TRANSPORT")) {
-            // TEST TRANSPORT (vtx_comm_test.hip): ranks = processes that may share one device, payloads over Unix sockets in that
-            // directory — the exchange's own logic with world > 1 on a one-GPU box.  Never set in production.
+#ifdef VTX_DEVTOOLS
+        if (VTX_DEV_ENV("VTX_COMM_TEST_TRANSPORT")) {
+            // TEST TRANSPORT (vtx_comm_test.hip, libvtx_dev.so only): ranks = processes that may share one device, payloads over Unix
+            // sockets in that directory — the exchange's own logic with world > 1 on a one-GPU box.  Not in the production library.
             void* f[9];
             r.lib = vtxt_comm_test_table(f);
             r.GetUniqueId = (decltype(r.GetUniqueId))f[0]; r.CommInitRank = (decltype(r.CommInitRank))f[1];
@@ -343,6 +346,7 @@ Rccl* rccl() {
             r.GroupEnd = (decltype(r.GroupEnd))f[7]; r.GetErrorString = (decltype(r.GetErrorString))f[8];
             return;
         }
+#endif
         for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
             r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
@@ -606,14 +610,14 @@ static BandPlan band_plan(uint32_t nr, uint32_t n_loci, uint32_t max_hap_len) {
     BandPlan p;
     p.n_tasks = 2ull * nr;
     uint64_t chunk_cap = 1u << 31;
-    if (getenv("VTX_BAND_CHUNK")) chunk_cap = std::max<uint64_t>(256, strtoull(getenv("VTX_BAND_CHUNK"), nullptr, 10));   // test hook
+    if (VTX_DEV_ENV("VTX_BAND_CHUNK")) chunk_cap = std::max<uint64_t>(256, strtoull(VTX_DEV_ENV("VTX_BAND_CHUNK"), nullptr, 10));   // test hook
     p.chunk = (uint32_t)std::min<uint64_t>(p.n_tasks, chunk_cap);
     p.band_stride = (max_hap_len + 2 + 7) & ~7u;
     p.hard_cap = (uint32_t)std::min<uint64_t>(p.chunk, p.chunk / 4 + (1u << 20));
     p.pend_cap = (uint32_t)std::min<uint64_t>(p.chunk, p.chunk / 8 + (1u << 20));
     p.slots = (uint32_t)std::min<uint64_t>(p.chunk, p.chunk / 16 + (1u << 20));
-    if (getenv("VTX_BAND_HARD_CAP")) p.hard_cap = p.pend_cap = p.slots = std::max(1u, (uint32_t)atoi(getenv("VTX_BAND_HARD_CAP")));   // test hook
-    if (getenv("VTX_BAND_SLOTS")) p.slots = std::max(1u, (uint32_t)atoi(getenv("VTX_BAND_SLOTS")));                                  // test hook
+    if (VTX_DEV_ENV("VTX_BAND_HARD_CAP")) p.hard_cap = p.pend_cap = p.slots = std::max(1u, (uint32_t)atoi(VTX_DEV_ENV("VTX_BAND_HARD_CAP")));   // test hook
+    if (VTX_DEV_ENV("VTX_BAND_SLOTS")) p.slots = std::max(1u, (uint32_t)atoi(VTX_DEV_ENV("VTX_BAND_SLOTS")));                                  // test hook
     p.poly_stride = vtxk_band_poly_stride();
     p.tasks_per_locus = (uint32_t)(p.n_tasks / std::max(n_loci, 1u));
     p.gt_bytes = vtxk_band_gtables_bytes(n_loci, max_hap_len, p.tasks_per_locus, &p.gt_loci);
@@ -649,7 +653,7 @@ static int band_reserve(vtx_ctx* c, BandPlan& p, bool quiet) {
     RES(d_hard, ((size_t)p.hard_cap + p.pend_cap) * sizeof(uint32_t));
     // [0, n): band_run_kernel's overflows (second chance: what overflows again is appended behind the first list, [n, 2n)); round 4:
     // [n, 2n) = what band_sweep_kernel's first pass declines, behind it what the second declines (at most as many), [n + nB, ..)
-    RES(d_over, 3 * (size_t)p.n_tasks * sizeof(uint32_t));
+    RES(d_over, 4 * (size_t)p.n_tasks * sizeof(uint32_t));   // [0, 2n): band_run_kernel's overflows and their second-chance appends; [2n, 4n): what band_sweep_kernel declines (its own region: the appends of an overflowing chunk cannot reach it)
     RES(d_cnt, 64 * sizeof(uint32_t));
     if (p.gt_bytes) RES(d_fail, 2 * (size_t)p.chunk * sizeof(uint32_t));  // tasks band_diag_kernel leaves to band_run_kernel (as listed, then sorted)
     if (p.gt_bytes) RES(d_refine, (size_t)band_refine_cap(p.chunk) * vtxk_band_refine_words() * sizeof(uint32_t));   // records for band_refine_kernel
@@ -720,7 +724,7 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
     if (nr) {
         HIP_TRY(c, vtxk_prep_rec_locus(c->d_loci.as<vtx_locus>(), nl, c->d_rec_locus.as<uint32_t>(), s));
         HIP_TRY(c, vtxk_prep_check(c->d_records.as<vtx_record>(), nr, c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
-                                   b->read_bytes, kMaxReadLen, c->cfg.n_barcodes, kNumShapes, c->d_shape.as<uint8_t>(),
+                                   b->read_bytes, kMaxReadLen | (nibbles ? 0x80000000u : 0u), c->cfg.n_barcodes, kNumShapes, c->d_shape.as<uint8_t>(),
                                    c->d_seq.as<uint32_t>(), d_shape_cnt, d_counters, s));
         // work lists per kernel shape: stable sort of the record numbers by shape
         HIP_TRY(c, vtxk_prep_sort_u8(c->d_shape.as<uint8_t>(), c->d_shape2.as<uint8_t>(), c->d_seq.as<uint32_t>(),
@@ -739,6 +743,7 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
         if (code == 1) return fail(c, VTX_E_INVAL, "vtx_submit: record %u: read outside read_arena", r);
         if (code == 2) return fail(c, VTX_E_UNSUPPORTED, "vtx_submit: record %u: read length %u above %u", r, R.read_len, kMaxReadLen);
         if (code == 3) return fail(c, VTX_E_INVAL, "vtx_submit: record %u: cell_index %u >= n_barcodes %u", r, R.cell_index, c->cfg.n_barcodes);
+        if (code == 5) return fail(c, VTX_E_INVAL, "vtx_submit: record %u: read_off %u is odd (VTX_READS_NIBBLES: every read starts at an even base)", r, R.read_off);
         return fail(c, VTX_E_INVAL, "vtx_submit: record %u: not sorted by (cell_index, umi_id) within its locus", r);
     }
     if (int rc = make_buckets(c, shape_cnt, max_hap, d_shape_cnt + 16)) return rc;
@@ -874,7 +879,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     unsigned long long cnt[8] = {0};
     uint32_t n_kept = 0, rounds = 0;
     // test hook: the first N rounds hash every UMI to 0, so that the collision check and the re-seed are exercised
-    const uint32_t weak_rounds = getenv("VTX_PREP_WEAK_ROUNDS") ? (uint32_t)atoi(getenv("VTX_PREP_WEAK_ROUNDS")) : 0;
+    const uint32_t weak_rounds = VTX_DEV_ENV("VTX_PREP_WEAK_ROUNDS") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_PREP_WEAK_ROUNDS")) : 0;
     if (nr) HIP_TRY(c, vtxk_prep_rec_locus(c->d_loci.as<vtx_locus>(), nl, c->d_raw_locus.as<uint32_t>(), s));
     for (uint64_t seed = 0x9e3779b97f4a7c15ull;; seed = seed * 0xd1342543de82ef95ull + 1) {
         ++rounds;
@@ -882,13 +887,13 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
         HIP_TRY(c, hipMemsetAsync(c->d_locus_cnt.p, 0, ((size_t)nl + 1) * u32, s));      // first record of each locus
         HIP_TRY(c, hipMemsetAsync(c->d_locus_scan.p, 0, ((size_t)nl + 1) * u32, s));     // one past its last record
         HIP_TRY(c, vtxk_prep_resolve(c->d_raw.as<vtx_raw_record>(), nr, c->d_raw_locus.as<uint32_t>(), c->d_tags.as<uint8_t>(),
-                                     b->tag_bytes, b->read_bytes, kMaxReadLen, c->d_bc_slots.as<uint32_t>(), c->bc_mask,
+                                     b->tag_bytes, b->read_bytes, kMaxReadLen | (nibbles ? 0x80000000u : 0u), c->d_bc_slots.as<uint32_t>(), c->bc_mask,
                                      c->d_bc_hash.as<uint64_t>(), c->d_bc_off.as<uint64_t>(), c->d_bc_bytes.as<uint8_t>(),
                                      use_umi, seed, rounds <= weak_rounds ? 0ull : ~0ull, cell_bits, nl, c->d_key_lc.as<uint64_t>(), c->d_key_umi.as<uint64_t>(),
                                      c->d_idx.as<uint32_t>(), d_counters, s));
         HIP_TRY(c, hipMemcpyAsync(cnt, d_counters, 3 * u64, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
-        if (cnt[2]) return fail(c, VTX_E_INVAL, "vtx_submit_raw: a record points outside its arena or is longer than %u bases", kMaxReadLen);
+        if (cnt[2]) return fail(c, VTX_E_INVAL, "vtx_submit_raw: a record points outside its arena, is longer than %u bases, or (VTX_READS_NIBBLES) starts at an odd base", kMaxReadLen);
         n_kept = nr - (uint32_t)cnt[0] - (uint32_t)cnt[1];
         // stable LSD order: UMI hash first, then (locus, cell); dropped records carry the largest key and end up last
         const uint32_t* perm = nullptr;
@@ -998,8 +1003,8 @@ int vtx_run(vtx_ctx* c) {
     if (any_lut) HIP_TRY(c, hipMemsetAsync(c->d_redo_cnt.p, 0, 16 * sizeof(uint32_t), s));
     for (size_t b = 0; full_dp && b < c->buckets.size(); ++b) {
         const Bucket& bk = c->buckets[b];
-        static const bool no_duo = getenv("VTX_DP_KERNEL") && !strcmp(getenv("VTX_DP_KERNEL"), "lut");
-        static const bool no_pair = getenv("VTX_DP_KERNEL") && !strcmp(getenv("VTX_DP_KERNEL"), "duo2");   // two-lookup prefix phase
+        static const bool no_duo = VTX_DEV_ENV("VTX_DP_KERNEL") && !strcmp(VTX_DEV_ENV("VTX_DP_KERNEL"), "lut");
+        static const bool no_pair = VTX_DEV_ENV("VTX_DP_KERNEL") && !strcmp(VTX_DEV_ENV("VTX_DP_KERNEL"), "duo2");   // two-lookup prefix phase
         const bool use_pair = bk.pair && !no_pair;
         if (bk.duo && !no_duo) {
             HIP_TRY(c, vtxk_launch_sw_full_duo(bk.R, bk.count, c->d_work.as<uint32_t>() + bk.offset, c->d_records.as<vtx_record>(),
@@ -1091,13 +1096,13 @@ int vtx_run(vtx_ctx* c) {
         // A few overflow tasks (shallow data: some hundreds per run) first try the in-LDS variant of the general kernel
         // with a slab for kLdsMatches k-mer matches: their ~2 ms of serial HBM latency were a third of a shallow step.
         const uint32_t kLdsMatches = 512;
-        static const uint32_t kLdsTasks = getenv("VTX_BAND_LDS_TASKS") ? (uint32_t)atoi(getenv("VTX_BAND_LDS_TASKS")) : 4096u;   // experiment knob
+        static const uint32_t kLdsTasks = VTX_DEV_ENV("VTX_BAND_LDS_TASKS") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_BAND_LDS_TASKS")) : 4096u;   // experiment knob
         auto fallback_launch = [&]() -> int {
             const uint64_t worst = (uint64_t)c->max_read_len * c->max_hap_len;
             if (fb.cap2 >= worst && fb.cap2 >= 512) return fail(c, VTX_E_STATE, "vtx_run: band kernel overflow with a worst-case slab");
             // first three rounds: the cooperative kernel, everything in LDS (band_coop_kernel: a wavefront per task, up to 512 matches,
             // then 1024, then 4096; reads up to 256 bases); what that cannot hold takes the serial kernel below
-            static const bool no_coop = getenv("VTX_BAND_NO_COOP") != nullptr;             // experiment / test hook
+            static const bool no_coop = VTX_DEV_ENV("VTX_BAND_NO_COOP") != nullptr;             // experiment / test hook
             const int tier = fb.cap2 < 512 ? 0 : (fb.cap2 == 512 ? 1 : (fb.cap2 == 1024 ? 2 : -1));
             const uint32_t tier_cap = tier == 0 ? 512u : (tier == 1 ? 1024u : 4096u);
             // (haplotypes up to 1000 bases: the kernel walks its Fenwick tree in ten unrolled steps, tn = n + 8 < 1024)
@@ -1114,7 +1119,7 @@ int vtx_run(vtx_ctx* c) {
                 ++launches;
                 return VTX_OK;
             }
-            const bool in_lds = fb.cap2 < 512 && fb.todo <= kLdsTasks && !getenv("VTX_BAND_NO_LDS_FALLBACK") &&
+            const bool in_lds = fb.cap2 < 512 && fb.todo <= kLdsTasks && !VTX_DEV_ENV("VTX_BAND_NO_LDS_FALLBACK") &&
                                 vtxk_band_lds_stride(kLdsMatches, c->max_hap_len, c->max_read_len) <= 160 * 1024 - 512;
             fb.cap2 = in_lds ? kLdsMatches : (uint32_t)std::max<uint64_t>(std::min<uint64_t>((uint64_t)fb.cap2 * 16, worst), 512);
             const size_t stride2 = vtxk_band_ws_stride(fb.cap2, c->max_hap_len);
@@ -1227,7 +1232,7 @@ int vtx_run(vtx_ctx* c) {
             HIP_TRY(c, hipEventRecord(c->ev[4], s));
             // Stage 1 (tables in global memory): band_diag_kernel decides the tasks whose alignment lives on one diagonal
             // (vtx_fast_core.h) and lists the others; band_run_kernel then takes that LIST instead of the whole range.
-            static const bool no_diag = getenv("VTX_BAND_NO_DIAG") != nullptr;          // experiment / test hook: stage 1 off
+            static const bool no_diag = VTX_DEV_ENV("VTX_BAND_NO_DIAG") != nullptr;          // experiment / test hook: stage 1 off
             static const int diag_stats = getenv("VTX_DEBUG") ? 1 : 0;
             bool diag = false, swept = false;
             uint32_t n_fail = 0;
@@ -1236,21 +1241,21 @@ int vtx_run(vtx_ctx* c) {
             // (full == cert decides it: cert <= banded <= full), (b) otherwise, or when the check fails: through band_sweep_kernel
             // (the band of ANY task, vtx_sweep.hip) and the masked DP.  VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending /
             // general path instead (kept for A/B tests; also what takes over when a haplotype of the batch exceeds 255 bases).
-            static const bool legacy = getenv("VTX_BAND_LEGACY") != nullptr;
-            static const bool no_tight = getenv("VTX_BAND_NO_TIGHT") != nullptr;          // test hook: tasks with a certificate go to the sweep like the others
-            static const bool use_check = getenv("VTX_BAND_CHECK") != nullptr;            // experiment hook: full-matrix check in front of their DP
+            static const bool legacy = VTX_DEV_ENV("VTX_BAND_LEGACY") != nullptr;
+            static const bool no_tight = VTX_DEV_ENV("VTX_BAND_NO_TIGHT") != nullptr;          // test hook: tasks with a certificate go to the sweep like the others
+            static const bool use_check = VTX_DEV_ENV("VTX_BAND_CHECK") != nullptr;            // experiment hook: full-matrix check in front of their DP
             const bool sweep_path = !legacy && c->max_hap_len <= vtxk_band_sweep_max_len() && c->max_hap_len > 0;
             uint32_t* tight_list = (sweep_path && !no_tight) ? c->d_tight.as<uint32_t>() : nullptr;
             uint32_t* tight_pack = tight_list ? c->d_tight_pack.as<uint32_t>() : nullptr;
             // which of the tasks the certificate stages leave skip band_run_kernel (whose piece lists they would overflow) and take
             // band_sweep_kernel at once: bit = vtxf::Why.  Default: W_MATCHES (4: more than 40 off-diagonal k-mer matches — repeats).
             // VTX_BAND_DENSE_MASK: experiment knob (0x3be: everything but shape; 0: nothing — band_run_kernel sees every task first).
-            static const uint32_t dense_mask = getenv("VTX_BAND_DENSE_MASK") ? (uint32_t)strtoul(getenv("VTX_BAND_DENSE_MASK"), nullptr, 0) : (1u << 4);
+            static const uint32_t dense_mask = VTX_DEV_ENV("VTX_BAND_DENSE_MASK") ? (uint32_t)strtoul(VTX_DEV_ENV("VTX_BAND_DENSE_MASK"), nullptr, 0) : (1u << 4);
             uint32_t* dense_list = sweep_path ? c->d_dense.as<uint32_t>() : nullptr;
             if (gt_n && !no_diag) {
                 HIP_TRY(c, hipMemsetAsync(d_cnt + 12, 0, 4 * sizeof(uint32_t), s));   // [12] left for band_run_kernel, [13] for band_sweep_kernel, [14] refine records, [15] tasks with a one-diagonal band
                 // tasks with main pieces only whose bounds do not meet leave a record for band_refine_kernel
-                static const bool no_refine = getenv("VTX_BAND_NO_REFINE") != nullptr;        // experiment / test hook
+                static const bool no_refine = VTX_DEV_ENV("VTX_BAND_NO_REFINE") != nullptr;        // experiment / test hook
                 const uint32_t refine_cap = band_refine_cap(chunk);
                 uint32_t* refine_list = no_refine ? nullptr : c->d_refine.as<uint32_t>();
                 const hipError_t e = vtxk_launch_band_diag(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
@@ -1271,7 +1276,7 @@ int vtx_run(vtx_ctx* c) {
                     // At 16 reads per locus these are five latency-bound launches of 0.1 - 0.2 ms each: side by side 0.31 instead
                     // of 0.55 ms.  One host round trip, right after band_diag_kernel.  (VTX_BAND_NO_TIGHT: the refinement's leftovers
                     // go to the fail list, so everything stays in order on this stream.)
-                    static const bool no_fork = getenv("VTX_BAND_NO_FORK") != nullptr;          // experiment / test hook
+                    static const bool no_fork = VTX_DEV_ENV("VTX_BAND_NO_FORK") != nullptr;          // experiment / test hook
                     const bool fork = tight_list != nullptr && !no_fork;
                     hipStream_t sb = fork ? s2 : s;                                             // the refine / one-diagonal branch
                     if (!fork && refine_list)
@@ -1326,11 +1331,11 @@ int vtx_run(vtx_ctx* c) {
                     if (!fork) checked_total += n_tight;                                    // (forked: the exact count arrives with the events)
                     diag_total += nt; diag_left += (uint64_t)n_fail + n_dense;
                     // repeats: band_sweep_kernel (the band of ANY task) + masked DP, sorted by task (neighbours share their locus'
-                    // haplotypes, and the hard list comes out in a fixed order); what it declines waits in d_over[n_tasks ..) for the
+                    // haplotypes, and the hard list comes out in a fixed order); what it declines waits in d_over[2 n_tasks ..) for the
                     // second pass after the last chunk
                     // (a short list of the other tasks is not worth band_run_kernel's launch — a persistent grid: ~1 ms whatever the
                     // count — and the two host round trips behind it: it joins the repeats, ~25 ns per task)
-                    static const uint32_t run_min = getenv("VTX_BAND_RUN_MIN") ? (uint32_t)strtoul(getenv("VTX_BAND_RUN_MIN"), nullptr, 10) : 65536u;
+                    static const uint32_t run_min = VTX_DEV_ENV("VTX_BAND_RUN_MIN") ? (uint32_t)strtoul(VTX_DEV_ENV("VTX_BAND_RUN_MIN"), nullptr, 10) : 65536u;
                     if (n_fail && n_fail < run_min && (uint64_t)n_dense + n_fail <= nt) {
                         HIP_TRY(c, hipMemcpyAsync(dense_list + n_dense, c->d_fail.as<uint32_t>(), (size_t)n_fail * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
                         n_dense += n_fail;
@@ -1345,7 +1350,7 @@ int vtx_run(vtx_ctx* c) {
                                 dl = dense_list + nt;
                             } else (void)hipGetLastError();
                         }
-                        if (int rc = sweep_slices(0, dl, n_dense, c->d_over.as<uint32_t>() + n_tasks, d_cnt + 26)) return rc;
+                        if (int rc = sweep_slices(0, dl, n_dense, c->d_over.as<uint32_t>() + 2 * n_tasks, d_cnt + 26)) return rc;
                         swept_total += n_dense;
                     }
                     if (n_fail > 64) {
@@ -1476,13 +1481,13 @@ int vtx_run(vtx_ctx* c) {
             ++launches;
             if (sweep_used && base + chunk >= n_tasks) {
                 // last chunk.  What overflowed band_run_kernel's lists (d_over[0, nA)) takes band_sweep_kernel too; then everything
-                // its first pass declined — here and in the chunks' own sweeps: d_over[n_tasks, + nB), counted on the device — takes
+                // its first pass declined — here and in the chunks' own sweeps: d_over[2 n_tasks, + nB), counted on the device — takes
                 // the second pass (1024 sections); what that declines as well (bytes outside ACGTN, reads above 255 bases, more
-                // sections still: d_over[n_tasks + nB, + nC)) takes the general band kernel.
+                // sections still: d_over[2 n_tasks + nB, + nC)) takes the general band kernel.
                 uint32_t* over = c->d_over.as<uint32_t>();
                 const uint32_t nA = cnt[1];
                 if (nA) {
-                    if (int rc = sweep_slices(0, over, nA, over + n_tasks, d_cnt + 26)) return rc;
+                    if (int rc = sweep_slices(0, over, nA, over + 2 * n_tasks, d_cnt + 26)) return rc;
                     swept_total += nA;
                 }
                 uint32_t nB = 0, nC = 0;
@@ -1491,12 +1496,12 @@ int vtx_run(vtx_ctx* c) {
                 if (int rc = collect_sweep_times()) return rc;
                 if (nB) {
                     resweep_total = nB;
-                    if (int rc = sweep_slices(1, over + n_tasks, nB, over + n_tasks + nB, d_cnt + 28)) return rc;
+                    if (int rc = sweep_slices(1, over + 2 * n_tasks, nB, over + 2 * n_tasks + nB, d_cnt + 28)) return rc;
                     HIP_TRY(c, hipMemcpyAsync(&nC, d_cnt + 29, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     HIP_TRY(c, hipStreamSynchronize(s));
                 }
                 cnt[1] = nC;
-                if (nC) { if (int rc = fallback_start((uint32_t)n_tasks + nB, (uint32_t)n_tasks + nB + nC)) return rc; }
+                if (nC) { if (int rc = fallback_start((uint32_t)(2 * n_tasks) + nB, (uint32_t)(2 * n_tasks) + nB + nC)) return rc; }
             }
         }
         fast_overflow = cnt[1];
@@ -1667,11 +1672,11 @@ int vtx_debug_bands(vtx_ctx* c, const uint32_t* tasks, uint32_t n_tasks, uint32_
 #define DBG_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return done(fail(c, VTX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_))); } while (0)
     DBG_TRY(d_t.reserve((size_t)n_tasks * 4)); DBG_TRY(d_h.reserve((size_t)n_tasks * 4)); DBG_TRY(d_o.reserve((size_t)n_tasks * 4));
     DBG_TRY(d_c.reserve(64 * 4)); DBG_TRY(d_b.reserve((size_t)n_tasks * 2 * bs * sizeof(uint16_t)));
-    const bool dbg_on = getenv("VTX_SWEEP_DBG") != nullptr;        // developer aid: the kernel's per-task intermediate state on stderr
+    const bool dbg_on = VTX_DEV_ENV("VTX_SWEEP_DBG") != nullptr;        // developer aid: the kernel's per-task intermediate state on stderr
     if (dbg_on) DBG_TRY(d_d.reserve((size_t)n_tasks * 64 * 4));
     DBG_TRY(hipMemcpyAsync(d_t.p, tasks, (size_t)n_tasks * 4, hipMemcpyHostToDevice, s));
     DBG_TRY(hipMemsetAsync(d_c.p, 0, 64 * 4, s));
-    const int dbg_tier = getenv("VTX_SWEEP_TIER") ? atoi(getenv("VTX_SWEEP_TIER")) : 0;      // (tests: the 1024-section variant)
+    const int dbg_tier = VTX_DEV_ENV("VTX_SWEEP_TIER") ? atoi(VTX_DEV_ENV("VTX_SWEEP_TIER")) : 0;      // (tests: the 1024-section variant)
     DBG_TRY(vtxk_launch_band_sweep(dbg_tier, d_t.as<uint32_t>(), n_tasks, nullptr, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                    c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), d_b.as<uint16_t>(), bs,
                                    d_h.as<uint32_t>(), d_o.as<uint32_t>(), d_c.as<uint32_t>(), nullptr, nullptr, dbg_on ? d_d.as<uint32_t>() : nullptr, s));

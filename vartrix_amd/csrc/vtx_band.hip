@@ -504,7 +504,7 @@ __global__ __launch_bounds__(64) void band_coop_kernel(
         }
     }
     wave_sync();                                                       // (y6 is dead: rmin / rmax may be written)
-    if (ablate == 1) { if (mt[0] == 0x7fffffffu) counters[2] = 1; return; }     // (profiling aid: phase A only; results are wrong)
+    if (VTX_ABLATE(ablate) == 1) { if (mt[0] == 0x7fffffffu) counters[2] = 1; return; }     // (profiling aid: phase A only; results are wrong)
     // ---- B: sdpkpp ----
     const int tn = n + KMER + 2;                                      // < 1024 (the host launches this kernel for haplotypes <= 1000 bases): tree paths of <= 10 nodes
     if (live) for (int i = l; i <= tn; i += G) tree[i] = 0;
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64) void band_coop_kernel(
     for (int d = 1; d < G; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)best, d, G); best = o > best ? o : best; }
     // (the reference starts `best` at (k, match 0): an END beats it iff (dp, index) > (k, 0) — dp >= k always, so the maximum
     //  over (dp, index) is the same entry)
-    if (ablate == 2) { if (best == 0x7fffffffu) counters[2] = 1; return; }      // (profiling aid: phases A + B)
+    if (VTX_ABLATE(ablate) == 2) { if (best == 0x7fffffffu) counters[2] = 1; return; }      // (profiling aid: phases A + B)
     // ---- traceback (one lane per task), the chain reversed in path[] ----
     if (live && l == 0) {
         uint32_t cur = best & 0xffffu, len = 0;
@@ -686,7 +686,7 @@ extern "C" hipError_t vtxk_launch_band_coop(int tier, const uint32_t* tasks, uin
                                             uint32_t* counters, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
     const uint32_t mc = tier == 0 ? 512u : (tier == 1 ? 1024u : 4096u), tpw = 1u;
-    static const uint32_t ablate = getenv("VTX_COOP_ABLATE") ? (uint32_t)atoi(getenv("VTX_COOP_ABLATE")) : 0u;     // profiling aid
+    static const uint32_t ablate = VTX_DEV_ENV("VTX_COOP_ABLATE") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_COOP_ABLATE")) : 0u;     // profiling aid
     const size_t task_bytes = vtxk_band_coop_lds(max_hap, mc), shmem = task_bytes * tpw;
     if (shmem > 64 * 1024) return hipErrorInvalidValue;
 #define LAUNCH_COOP(G, MC)                                                                                               \
@@ -706,7 +706,7 @@ extern "C" hipError_t vtxk_launch_band_coop(int tier, const uint32_t* tasks, uin
 
 // active lanes per wavefront of band_kernel<false> for a list of n_tasks (the workspace holds 64 slabs per wavefront either way)
 extern "C" uint32_t vtxk_band_lanes(uint32_t n_tasks) {
-    static const int forced = getenv("VTX_BAND_LANES") ? atoi(getenv("VTX_BAND_LANES")) : 0;       // experiment knob
+    static const int forced = VTX_DEV_ENV("VTX_BAND_LANES") ? atoi(VTX_DEV_ENV("VTX_BAND_LANES")) : 0;       // experiment knob
     if (forced > 0) {                                         // a power of two in [4, 64]: anything else would leave tasks unscored
         uint32_t lanes = 4;
         while (lanes < 64 && lanes < (uint32_t)forced) lanes <<= 1;
@@ -1380,8 +1380,8 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
             if constexpr (GT) return gtables[(size_t)(t_fb + i)]; else return fb[i];
         };
         if (m < KMER || n < KMER) { PUSH_FULL_MATRIX() continue; }    // no k-mer: Band::full_matrix
-        if (ablate == 1) continue;                           // (profiling aid) table build only
-        if (ablate == 2) {                                   // (profiling aid) probe loop only
+        if (VTX_ABLATE(ablate) == 1) continue;                           // (profiling aid) table build only
+        if (VTX_ABLATE(ablate) == 2) {                                   // (profiling aid) probe loop only
             uint32_t wl = (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
             uint32_t wh = (uint32_t)x[4] | ((uint32_t)x[5] << 8), cntm = 0;
             for (uint32_t xr = 0; xr + KMER <= m; ++xr) {
@@ -1526,7 +1526,7 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
         bool overflow = st.overflow;
         uint32_t why = st.why;
         if (!overflow && st.n_ent == 0 && st.best_v < 0) { PUSH_FULL_MATRIX() continue; }   // no k-mer match
-        if (ablate == 3) { if (st.n_ent == 0xffffu) counters[7] = st.n_ent; continue; }   // (profiling aid) phase 1 only
+        if (VTX_ABLATE(ablate) == 3) { if (st.n_ent == 0xffffu) counters[7] = st.n_ent; continue; }   // (profiling aid) phase 1 only
         // ================= phase 2: the rest of the chain DP =================
         if (!overflow) {
             uint32_t no_a = NONE_ID, no_b = NONE_ID;
@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
         // band_pending_kernel, which computes the same bound with a wavefront's lanes over up to 32 pieces.
         const bool pending = st.ub_ok && st.n_sp > 0;
         const int32_t ub = (st.ub_ok && !pending) ? run_ub<NT>(pm_a, pm_id, tid, st.n_ent) : INT32_MAX;
-        if (ablate == 4) { if (ub == -1) counters[7] = 1; continue; }   // (profiling aid) everything but the staircase walk
+        if (VTX_ABLATE(ablate) == 4) { if (ub == -1) counters[7] = 1; continue; }   // (profiling aid) everything but the staircase walk
         uint32_t verts[4 * SG + 6];
         uint32_t nv = 0;
         int32_t cert = 0;
@@ -2055,7 +2055,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             live = true;
         }
     }
-    if ((stats >> 8) == 4) { if (live && m == 0x7fffffff) counters[40] = 1; return; }           // (profiling aid) task set-up only
+    if (VTX_ABLATE(stats >> 8) == 4) { if (live && m == 0x7fffffff) counters[40] = 1; return; }           // (profiling aid) task set-up only
     // ---- the read, once: lanes 2i / 2i + 1 hold the two haplotypes of ONE record, so each loads half of its 8-byte words (16-byte
     //      loads) and the two swap halves — a quarter of the load instructions and of the L2 lines 8-byte loads per lane cost ----
     vtxf::ReadWords rw;
@@ -2105,7 +2105,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             if (vtxf::m_pop(M) < 20) have_d = false;
         }
         if (live && !have_d) { live = false; fail = true; why = vtxf::W_NO_DIAG; }
-        if ((stats >> 8) == 3) { if (live && d == 0x7fffffff) counters[40] = 1; return; }       // (profiling aid) up to the diagonal and its mask
+        if (VTX_ABLATE(stats >> 8) == 3) { if (live && d == 0x7fffffff) counters[40] = 1; return; }       // (profiling aid) up to the diagonal and its mask
         if (live) {
             fr = vtxf::front_rest(x, m, tb, n, ln, d, M);
             if (fr.why != vtxf::W_OK) { live = false; fail = true; why = fr.why; }
@@ -2133,11 +2133,11 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         nd.w0 = (nd.w0 | other(nd.w0)) & par; nd.w1 = (nd.w1 | other(nd.w1)) & par; nd.w2 = (nd.w2 | other(nd.w2)) & par;
     }
     vtxf::MIter need_it = vtxf::m_iter(nd);
-    if ((stats >> 8) == 1) { if (live && fr.cert == 0x7fffffff) counters[40] = 1; return; }      // (profiling aid) front only
+    if (VTX_ABLATE(stats >> 8) == 1) { if (live && fr.cert == 0x7fffffff) counters[40] = 1; return; }      // (profiling aid) front only
     const uint32_t pb_rel = vtxf::tab_pb_off(max_hap, n_heads), head_rel = max_hap * 8u;
     // pass 2 over the first n_walk entries of the walk list (every lane calls it; 0xffff: a slot reserved by a lane that did not fit)
     auto walk_list = [&](uint32_t n_walk) {
-        if ((stats >> 8) == 9) return;                                // (profiling aid) pass 1 without the bucket walks
+        if (VTX_ABLATE(stats >> 8) == 9) return;                                // (profiling aid) pass 1 without the bucket walks
         // two entries per lane and trip: a walk is three DEPENDENT loads (the read's bytes, the head word of their bucket, the
         // chain's first entry) — the two entries' loads go out together, level by level
         constexpr int WPL = 2;
@@ -2150,7 +2150,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
                 const uint32_t i = i0 + 64u * u + tid;
                 const uint32_t e = i < n_walk ? q_walk[i] : 0xffffu;
                 go[u] = e != 0xffffu;
-                own[u] = go[u] ? e >> 8 : 0u; row[u] = e & 0xffu;
+                own[u] = go[u] ? e >> 8 : 0u; row[u] = go[u] ? e & 0xffu : 0u;       // (an idle slot reads lane 0's first bytes: inside the arena whatever its padding)
                 w8[u] = vtxf::ld8(read_arena + o_read[own[u]] + row[u]);
                 tent[u] = o_tab[own[u]];
                 go[u] = go[u] && tent[u] != NO_TAB;
@@ -2197,7 +2197,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             for (int t = 0; t < cnt; ++t) q_ent[base + t] = (uint16_t)(((uint32_t)(tid >> 1) << 8) | (uint32_t)vtxf::m_next(need_it));
         }
         wave_sync();
-        if ((stats >> 8) == 8) continue;                              // (profiling aid) the rounds' queue fill only
+        if (VTX_ABLATE(stats >> 8) == 8) continue;                              // (profiling aid) the rounds' queue fill only
         const uint32_t total = q_count[0];
         constexpr int EPL = 4;                                        // queue entries per lane and trip: their loads go out together
         for (uint32_t i0 = 0; i0 < total; i0 += 64 * EPL) {
@@ -2257,7 +2257,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     }
     walk_list(q_count[1]);
     wave_sync();
-    if ((stats >> 8) == 2) { if (live && s_cnt[tid] == 0x7fffffff) counters[40] = 1; return; }   // (profiling aid) front + probes
+    if (VTX_ABLATE(stats >> 8) == 2) { if (live && s_cnt[tid] == 0x7fffffff) counters[40] = 1; return; }   // (profiling aid) front + probes
     uint32_t aux = 0xffffffffu;
     bool tight = false;
     // ---- the last phase, every lane for itself: sort, harmless tests, closure, run bound (vtx_fast_core.h).  (Pooling the harmless
@@ -2287,11 +2287,11 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         }
     }
     if (live) vtxf::back_sort(ns, ln);
-    if ((stats >> 8) == 7) { if (live && ns == 0x7fffffff) counters[40] = 1; return; }            // (profiling aid) ... + the sort
+    if (VTX_ABLATE(stats >> 8) == 7) { if (live && ns == 0x7fffffff) counters[40] = 1; return; }            // (profiling aid) ... + the sort
     if (live && !vtxf::back_harmless(fr, ns, ln)) { live = false; fail = true; why = vtxf::W_NOT_HARMLESS; }
     if (live) {
         const vtxf::Lane gl{(uint32_t*)q_ent + tid, 64};                 // (the queue is dead by now)
-        const int32_t sc = vtxf::back_rest(fr, ns, ln, gl, &why, (int)(stats >> 8), nullptr, &aux);
+        const int32_t sc = vtxf::back_rest(fr, ns, ln, gl, &why, (int)VTX_ABLATE(stats >> 8), nullptr, &aux);
         if (sc >= 0) { *my_score = sc; if (stage) stage[task] = 1; }
         else { fail = true; tight = tight_list != nullptr; }
     }
@@ -2410,14 +2410,14 @@ __global__ __launch_bounds__(256) void band_refine_kernel(
 // size); the per-lane scratch is sized from it.
 // tables in global memory below this many tasks per locus (experiment knob VTX_BAND_GT_MAX_TPL; 0: never)
 static uint32_t gt_max_tpl() {
-    static const uint32_t v = getenv("VTX_BAND_GT_MAX_TPL") ? (uint32_t)atoi(getenv("VTX_BAND_GT_MAX_TPL")) : 0x7fffffffu;
+    static const uint32_t v = VTX_DEV_ENV("VTX_BAND_GT_MAX_TPL") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_BAND_GT_MAX_TPL")) : 0x7fffffffu;
     return v;
 }
 // the tables of n_loci loci in global memory: band_tables_kernel (a table per wavefront); VTX_BAND_TABLES_V1=1: round 3's kernel
 // (a locus per wavefront, serial chain insertion) — the reference the new one is compared with byte for byte (tests)
 static void launch_band_tables(const vtx_locus* loci, uint32_t gt_l0, uint32_t n_loci, const uint8_t* hap_arena, uint32_t max_hap,
                                size_t tstride, uint32_t n_heads, uint8_t* gtables, hipStream_t s) {
-    if (getenv("VTX_BAND_TABLES_V1"))
+    if (VTX_DEV_ENV("VTX_BAND_TABLES_V1"))
         hipLaunchKernelGGL(band_tables_v1_kernel, dim3(std::min(n_loci, 256u * 16u)), dim3(64), 2 * tstride, s, loci, gt_l0, n_loci,
                            hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
     else
@@ -2427,7 +2427,7 @@ static void launch_band_tables(const vtx_locus* loci, uint32_t gt_l0, uint32_t n
 
 // buckets of a table's hash (power of two; experiment knob VTX_BAND_HEADS)
 static uint32_t pick_heads(uint32_t tasks_per_locus, bool global_tables) {
-    if (getenv("VTX_BAND_HEADS")) return (uint32_t)atoi(getenv("VTX_BAND_HEADS"));
+    if (VTX_DEV_ENV("VTX_BAND_HEADS")) return (uint32_t)atoi(VTX_DEV_ENV("VTX_BAND_HEADS"));
     if (global_tables) return 1024;          // no LDS to fit: short chains, and band_diag_kernel's bucket tags want single-entry buckets
     if (tasks_per_locus < 48) return 256;
     return 512;
@@ -2441,7 +2441,7 @@ extern "C" size_t vtxk_band_gtables_bytes(uint32_t n_loci, uint32_t max_hap, uin
     if (tasks_per_locus >= gt_max_tpl()) return 0;
     const size_t per_locus = 2 * band_table_stride(max_hap, pick_heads(tasks_per_locus, true));
     size_t cap = ((size_t)4 << 30) - 65536;
-    if (getenv("VTX_BAND_GT_BYTES")) cap = std::max<size_t>(per_locus, strtoull(getenv("VTX_BAND_GT_BYTES"), nullptr, 10));   // test hook
+    if (VTX_DEV_ENV("VTX_BAND_GT_BYTES")) cap = std::max<size_t>(per_locus, strtoull(VTX_DEV_ENV("VTX_BAND_GT_BYTES"), nullptr, 10));   // test hook
     const size_t hold = std::min<size_t>(n_loci, cap / per_locus);
     if (loci_cap) *loci_cap = (uint32_t)hold;
     return hold * per_locus;
@@ -2451,8 +2451,8 @@ extern "C" size_t vtxk_band_gtables_bytes(uint32_t n_loci, uint32_t max_hap, uin
 // chance in the 15-entry variant (task_list mode) before the general kernel
 extern "C" int vtxk_band_second_chance(uint32_t tasks_per_locus, int long_lists) {
     if (long_lists) return 0;
-    const uint32_t w6 = getenv("VTX_BAND_W6_MIN_TPL") ? (uint32_t)atoi(getenv("VTX_BAND_W6_MIN_TPL")) : 80u;
-    return tasks_per_locus >= w6 && tasks_per_locus < gt_max_tpl() && !getenv("VTX_BAND_NO_SECOND_CHANCE");
+    const uint32_t w6 = VTX_DEV_ENV("VTX_BAND_W6_MIN_TPL") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_BAND_W6_MIN_TPL")) : 80u;
+    return tasks_per_locus >= w6 && tasks_per_locus < gt_max_tpl() && !VTX_DEV_ENV("VTX_BAND_NO_SECOND_CHANCE");
 }
 
 // persistent grid of band_run_kernel<nt, ., wpe>: what the chip holds (wavefronts per SIMD x 4 SIMDs x 256 CUs)
@@ -2500,7 +2500,7 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     // only the lists — 6 x 12 for deeper loci (config 3: band_run 45.0 -> 39.9 ms; the shorter lists send 2.7x the
     // tasks to the general kernel, still -2.5 ms per step), 5 x 15 for shallower ones (16 reads per locus: 6.9 vs 7.7 ms),
     // 4 x 15 when the grid does not fill the chip anyway.
-    static const uint32_t w6_min_tpl = getenv("VTX_BAND_W6_MIN_TPL") ? (uint32_t)atoi(getenv("VTX_BAND_W6_MIN_TPL")) : 80u;   // experiment knob (crossover between 32 and 48 reads per locus)
+    static const uint32_t w6_min_tpl = VTX_DEV_ENV("VTX_BAND_W6_MIN_TPL") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_BAND_W6_MIN_TPL")) : 80u;   // experiment knob (crossover between 32 and 48 reads per locus)
     const int variant = !global_tables ? 0 : ((task_list || long_lists) ? (tasks_per_locus < 16 && !task_list ? 1 : 2) : (tasks_per_locus < 16 ? 1 : (tasks_per_locus < w6_min_tpl ? 2 : 3)));
     const uint32_t psv = variant == 3 ? 12u : (uint32_t)VTX_PS;
     const size_t lane_bytes = (size_t)(2 * psv) * nt * 4;
@@ -2523,8 +2523,8 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     if (task_list && !global_tables) return hipErrorInvalidValue;    // (list mode reads the tables the first pass built)
     if (global_tables && !task_list)
         launch_band_tables(loci, gt_l0, n_loci, hap_arena, max_hap, tstride, n_heads, gtables, s);
-    const uint32_t ablate = (uint32_t)(getenv("VTX_BAND_ABLATE") ? atoi(getenv("VTX_BAND_ABLATE")) : 0);
-    const uint32_t xcd_claim = ((tasks_per_locus >= 24 || getenv("VTX_BAND_XCD")) && !getenv("VTX_BAND_NO_XCD")) ? 1u : 0u;   // (measured: config 3 -3 %, 64 / 32 reads per locus -4.5 %, 16: -1 %, 4: +2 %)
+    const uint32_t ablate = (uint32_t)(VTX_DEV_ENV("VTX_BAND_ABLATE") ? atoi(VTX_DEV_ENV("VTX_BAND_ABLATE")) : 0);
+    const uint32_t xcd_claim = ((tasks_per_locus >= 24 || VTX_DEV_ENV("VTX_BAND_XCD")) && !VTX_DEV_ENV("VTX_BAND_NO_XCD")) ? 1u : 0u;   // (measured: config 3 -3 %, 64 / 32 reads per locus -4.5 %, 16: -1 %, 4: +2 %)
 #define LAUNCH_RUN(NTV, GTV, WV, PV)                                                                                 \
     {                                                                                                                \
         if (shmem > 48 * 1024) {                                                                                     \
@@ -2564,9 +2564,9 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     if (!gtables || (size_t)n_loci * 2 * tstride > gtables_bytes) return hipErrorInvalidValue;
     launch_band_tables(loci, gt_l0, n_loci, hap_arena, max_hap, tstride, n_heads, gtables, s);
     const uint32_t n_blocks = (n_tasks + 255) / 256;
-    const uint32_t st = (uint32_t)stats | (getenv("VTX_DIAG_ABLATE") ? (uint32_t)atoi(getenv("VTX_DIAG_ABLATE")) << 8 : 0u);
+    const uint32_t st = (uint32_t)stats | (VTX_DEV_ENV("VTX_DIAG_ABLATE") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_DIAG_ABLATE")) << 8 : 0u);
     // two-byte match entries (40 per task) whenever a haplotype position fits a byte; VTX_DIAG_WIDE=1 forces the four-byte variant (tests)
-    static const bool force_wide = getenv("VTX_DIAG_WIDE") != nullptr;
+    static const bool force_wide = VTX_DEV_ENV("VTX_DIAG_WIDE") != nullptr;
     if (max_hap <= 255 && !force_wide)
         hipLaunchKernelGGL((band_diag_kernel<4, uint16_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
                            rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,

@@ -7,6 +7,22 @@
 
 #include "../../include/vtx.h"
 
+// Experiment / test hooks.  The PRODUCTION library (libvtx.so) reads one environment variable, VTX_DEBUG (stderr diagnostics; changes
+// no result).  Every other knob — stage on/off switches, ablations ("results wrong by design"), buffer caps that force the overflow
+// paths, kernel variants, the socket transport that stands in for RCCL in tests — exists only in libvtx_dev.so, the same sources
+// compiled with -DVTX_DEVTOOLS (make dev; loaded by tests/ and tools/ through VTX_LIB_VARIANT=dev).  In the production build
+// VTX_DEV_ENV("...") is the constant nullptr: the branches fold away and the strings are not in the binary.
+#ifdef VTX_DEVTOOLS
+#include <cstdlib>
+#define VTX_DEV_ENV(name) getenv(name)
+#define VTX_DEVTOOLS_ON 1
+#else
+#define VTX_DEV_ENV(name) ((const char*)nullptr)
+#define VTX_DEVTOOLS_ON 0
+#endif
+// a kernel's profiling-ablation selector: the constant 0 in the production build (the early exits compile out of the hot bodies)
+#define VTX_ABLATE(x) (VTX_DEVTOOLS_ON ? (uint32_t)(x) : 0u)
+
 // 64-bit hash of a tag byte string (FNV-1a style over little-endian 8-byte words + fmix64), identical on the
 // host (barcode table build) and the device.  The words are read with memcpy: gfx950 global memory takes
 // unaligned dwordx2 loads, so a lane hashes an 18-byte barcode with 3 loads instead of 18.

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void prep_rec_locus_kernel(const vtx_locus* __
 // costs more than the rest of the kernel.
 __global__ __launch_bounds__(256) void prep_resolve_kernel(
     const vtx_raw_record* __restrict__ raw, uint32_t n, const uint32_t* __restrict__ rec_locus,
-    const uint8_t* __restrict__ tags, uint64_t tag_bytes, uint64_t read_bytes, uint32_t max_read_len,
+    const uint8_t* __restrict__ tags, uint64_t tag_bytes, uint64_t read_bytes, uint32_t max_read_len_fmt,
     const uint32_t* __restrict__ bc_slots, uint32_t bc_mask, const uint64_t* __restrict__ bc_hash,
     const uint64_t* __restrict__ bc_off, const uint8_t* __restrict__ bc_bytes,
     int use_umi, uint64_t seed, uint64_t hash_mask, uint32_t cell_bits, uint32_t n_loci,
@@ -46,13 +46,15 @@ __global__ __launch_bounds__(256) void prep_resolve_kernel(
     __shared__ uint32_t s_cnt[3];
     if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
     __syncthreads();
+    // bit 31 of the length limit: the reads arrive two bases per byte (VTX_READS_NIBBLES) — every read must start at an even base
+    const uint32_t max_read_len = max_read_len_fmt & 0x7fffffffu, odd_mask = max_read_len_fmt >> 31;
     uint32_t n_not_bc = 0, n_no_umi = 0, n_bad = 0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         uint64_t klc = (uint64_t)n_loci << cell_bits, ku = 0;
         const vtx_raw_record r = raw[i];
         const bool umi_missing = r.umi_len == VTX_TAG_MISSING;
         const bool bad = (uint64_t)r.bc_off + r.bc_len > tag_bytes || (uint64_t)r.read_off + r.read_len > read_bytes ||
-                         r.read_len > max_read_len || (use_umi && !umi_missing && (uint64_t)r.umi_off + r.umi_len > tag_bytes);
+                         r.read_len > max_read_len || (r.read_off & odd_mask) || (use_umi && !umi_missing && (uint64_t)r.umi_off + r.umi_len > tag_bytes);
         if (bad) ++n_bad;
         else {
             const uint8_t* b = tags + r.bc_off;
@@ -181,9 +183,10 @@ __global__ __launch_bounds__(256) void prep_locus_ranges_kernel(vtx_locus* __res
 // (record << 3 | code): 1 read outside the arena, 2 read too long, 3 cell_index >= n_barcodes, 4 order.
 __global__ __launch_bounds__(256) void prep_check_kernel(
     const vtx_record* __restrict__ records, uint32_t n, const uint32_t* __restrict__ rec_locus,
-    const vtx_locus* __restrict__ loci, uint64_t read_bytes, uint32_t max_read_len, uint32_t n_barcodes, uint32_t n_shapes,
+    const vtx_locus* __restrict__ loci, uint64_t read_bytes, uint32_t max_read_len_fmt, uint32_t n_barcodes, uint32_t n_shapes,
     uint8_t* __restrict__ shape, uint32_t* __restrict__ seq, uint32_t* __restrict__ shape_cnt,
     unsigned long long* __restrict__ counters) {
+    const uint32_t max_read_len = max_read_len_fmt & 0x7fffffffu, odd_mask = max_read_len_fmt >> 31;   // (bit 31: VTX_READS_NIBBLES, as in prep_resolve_kernel)
     __shared__ uint32_t s_shape[16];
     __shared__ unsigned long long s_cells, s_bad;
     __shared__ uint32_t s_maxlen;
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(256) void prep_check_kernel(
         if ((uint64_t)r.read_off + r.read_len > read_bytes) code = 1;
         else if (r.read_len > max_read_len) code = 2;
         else if (r.cell_index >= n_barcodes) code = 3;
+        else if (r.read_off & odd_mask) code = 5;
         else if (j > 0 && rec_locus[j - 1] == locus) {
             const vtx_record q = records[j - 1];
             if (q.cell_index > r.cell_index || (q.cell_index == r.cell_index && q.umi_id > r.umi_id)) code = 4;

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
         atomicMax(&BM[((y) + K) >> 3], val_);                                                         \
         if ((((y) + K) >> 5) == l) ins_a = max(ins_a, val_); else ins_b = max(ins_b, val_);           \
     }
-    const uint32_t ablate = stats >> 8;                           // (profiling aid, tools/ablate_sweep.sh; results are wrong by design)
+    const uint32_t ablate = VTX_ABLATE(stats >> 8);                           // (profiling aid, tools/ablate_sweep.sh; results are wrong by design)
 #pragma unroll 1
     for (int t = 0; t < (ablate == 1 ? 0 : tmax); ++t) {
         if ((t & 7) == 0) { code_blk = code_blk_next; code_blk_next = codes32[min((t >> 3) + 1, 35)]; }
@@ -513,7 +513,7 @@ extern "C" hipError_t vtxk_launch_band_sweep(int tier, const uint32_t* tasks, ui
                                              uint32_t* overflow_list, uint32_t* counters, uint32_t* stat_counters, uint8_t* stage,
                                              uint32_t* dbg, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
-    static const uint32_t ablate = getenv("VTX_SWEEP_ABLATE") ? (uint32_t)atoi(getenv("VTX_SWEEP_ABLATE")) << 8 : 0u;
+    static const uint32_t ablate = VTX_DEV_ENV("VTX_SWEEP_ABLATE") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_SWEEP_ABLATE")) << 8 : 0u;
 #define LAUNCH_SWEEP(CAP)                                                                                          \
     {                                                                                                              \
         const size_t shmem = (size_t)8 * Lay<CAP>::TASK_W * sizeof(uint32_t);                                      \

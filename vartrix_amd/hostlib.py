@@ -11,13 +11,29 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvtxhost.so")
-CLI_PATH = os.path.join(_HERE, "bin", "vartrix")
+# VTX_LIB_VARIANT=dev: the developer build of the same sources with the test hooks (VTXH_BATCH_BYTES, VTXH_CHUNK_BLOCKS, ...) compiled
+# in (make dev); the production library and CLI read VTXH_PROFILE only
+LIB_PATH = CLI_PATH = None
+
+
+def cli_path(variant="") -> str:
+    return os.path.join(_HERE, "bin", "vartrix" + ("_dev" if variant == "dev" else ""))
+
+
+def use_variant(variant=""):
+    """Select the production ("") or developer ("dev") build for the NEXT load() (tests/test_host.py switches to dev for its hooks)."""
+    global LIB_PATH, CLI_PATH, _lib
+    LIB_PATH = os.path.join(_HERE, "libvtxhost%s.so" % ("_dev" if variant == "dev" else ""))
+    CLI_PATH = cli_path(variant)
+    _lib = None
+
+
 
 SYMBOLS = ("vtxh_pack_files", "vtxh_free", "vtxh_last_error", "vtxh_get_batch", "vtxh_get_metrics", "vtxh_get_ingest_stats",
            "vtxh_num_variants", "vtxh_num_barcodes", "vtxh_variant_name", "vtxh_barcode", "vtxh_write_mtx",
            "vtxh_format_f64", "vtxh_pack_files_raw", "vtxh_get_raw_batch", "vtxh_get_barcode_table", "vtxh_num_batches",
-           "vtxh_get_batch_at", "vtxh_get_raw_batch_at", "vtxh_pack_files_range", "vtxh_test_inflate", "vtxh_read_format")
+           "vtxh_get_batch_at", "vtxh_get_raw_batch_at", "vtxh_pack_files_range", "vtxh_test_inflate", "vtxh_read_format",
+           "vtxh_trim")
 METRIC_NAMES = ("num_reads", "num_low_mapq", "num_non_primary", "num_duplicates", "num_not_cell_bc",
                 "num_not_useful", "num_non_umi", "num_invalid_recs", "num_multiallelic_recs")
 
@@ -34,6 +50,7 @@ class VtxhMetrics(C.Structure):
 
 
 _lib = None
+use_variant("dev" if os.environ.get("VTX_LIB_VARIANT") == "dev" else "")
 
 
 def load():

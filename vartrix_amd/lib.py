@@ -15,8 +15,20 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# VTX_LIB_VARIANT=lazy0 loads a build variant of the SAME sources (tests/test_gpu_variants.py); never set in production
-LIB_PATH = os.path.join(_HERE, "libvtx%s.so" % ("_" + os.environ["VTX_LIB_VARIANT"] if os.environ.get("VTX_LIB_VARIANT") else ""))
+# Build variants of the SAME sources (vartrix_amd/csrc/Makefile), never loaded in production:
+#   dev    -DVTX_DEVTOOLS: the experiment / test hooks (stage switches, ablations, buffer caps, the socket transport standing in for
+#          RCCL) exist only there; the production libvtx.so reads VTX_DEBUG and nothing else
+#   lazy0, anchor5, tie0   one recollected detail of the crate's band switched (tests/test_gpu_variants.py)
+# VTX_LIB_VARIANT=<name> makes a variant the process default; load(variant) / Context(cfg, variant=...) pick one explicitly.
+DEFAULT_VARIANT = os.environ.get("VTX_LIB_VARIANT", "")
+
+
+def lib_path(variant=None) -> str:
+    v = DEFAULT_VARIANT if variant is None else variant
+    return os.path.join(_HERE, "libvtx%s.so" % ("_" + v if v else ""))
+
+
+LIB_PATH = lib_path()
 
 SYMBOLS = (
     "vtx_config_default", "vtx_create", "vtx_destroy", "vtx_submit", "vtx_run", "vtx_fetch_scores",
@@ -33,18 +45,18 @@ class VtxError(RuntimeError):
         self.status = status
 
 
-_lib = None
+_libs = {}
 
 
-def load():
+def load(variant=None):
     """dlopen libvtx.so (built in-tree by ``__graft_entry__.build()``); raises if absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    path = lib_path(variant)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise ImportError("%s not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
-                          "(make -C vartrix_amd/csrc). There is no CPU fallback." % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+                          "(make -C vartrix_amd/csrc). There is no CPU fallback." % path)
+    L = C.CDLL(path)
     ctxp = C.c_void_p
     L.vtx_config_default.restype = None
     L.vtx_config_default.argtypes = [C.POINTER(abi.VtxConfig)]
@@ -102,7 +114,7 @@ def load():
     L.vtx_debug_tables.argtypes = [ctxp, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.vtx_debug_bands.restype = C.c_int
     L.vtx_debug_bands.argtypes = [ctxp, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
-    _lib = L
+    _libs[path] = L
     return L
 
 
@@ -137,8 +149,8 @@ def comm_id() -> bytes:
 class Context:
     """One vtx_ctx: bound to one GPU, holds one resident batch."""
 
-    def __init__(self, cfg: abi.VtxConfig):
-        self._L = load()
+    def __init__(self, cfg: abi.VtxConfig, variant=None):
+        self._L = load(variant)
         self._h = C.c_void_p()
         self.cfg = cfg
         rc = self._L.vtx_create(C.byref(cfg), C.byref(self._h))
