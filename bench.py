@@ -389,8 +389,9 @@ def main():
         for name, kw in cases:
             if "genome_fasta" in kw and not os.path.exists(kw["genome_fasta"]):
                 continue
-            sspec = synth.SynthSpec(n_loci=n_loci, n_barcodes=n_barcodes, reads_per_locus=args.reads_per_locus, seed=20260926,
-                                    **dict(dict(sub_error=args.sub_error), **kw))
+            # (250-base reads: 60 k loci — 256 x 250 bases x 100 k loci would pass the 4 GiB arena of one batch)
+            sspec = synth.SynthSpec(n_loci=min(n_loci, 60_000) if kw.get("read_len", 150) > 160 else n_loci, n_barcodes=n_barcodes,
+                                    reads_per_locus=args.reads_per_locus, seed=20260926, **dict(dict(sub_error=args.sub_error), **kw))
             sb = synth.make_batch(sspec)
             sctx = lib.Context(cfg)
             sctx.submit(sb)

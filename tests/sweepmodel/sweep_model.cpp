@@ -176,4 +176,155 @@ int vtxs_band(const uint8_t* x, int m, const uint8_t* y, int n, int log_cap, int
     return 0;
 }
 
+
+// ---- round 5: the sweep WITHOUT a dp ring (vtx_sweep.hip, band_sweep_kernel) --------------------------------------------------
+// dp along a run of continuing matches grows by exactly 1 per row, so dp(x, y) = x + 6 - o with ONE deficit o per SECTION (a run
+// that starts at a match which does not continue its diagonal, or at one where a jump beats the continuation).  The kernel keeps
+// per DIAGONAL d = y - x the latest section only: (o, x0 = its first row), 16 bits — no per-row / per-column dp bytes.  A
+// continuing match costs nothing at its START unless a jump could beat it; the END event of the match that started at row xs
+// reads dp = xs + 6 - o from its diagonal's entry.  The one case the latest section does not cover: a jump beats the continuation
+// at row r while matches of rows r - 5 .. r - 1 of the OLD section have not ended yet.  Their (end row, column, dp) go to a
+// stash — eight buckets by end row, STASH entries each — and enter the tree when their row comes; the END loop skips a match
+// whose row lies before its diagonal's x0.  status 5: a stash bucket is full (the general kernel takes the task).
+// stats: [0] log entries, [1] sections, [2] matches, [3] jump-beats-continuation events, [4] fullest stash bucket.
+int vtxs_band2(const uint8_t* x, int m, const uint8_t* y, int n, int log_cap, int sec_cap, int stash_cap, int32_t* lo, int32_t* hi,
+               int32_t* stats) {
+    if (stats) stats[0] = stats[1] = stats[2] = stats[3] = stats[4] = 0;
+    if (m > MAXLEN || n > MAXLEN) return 1;
+    std::vector<int> cx(m), cy(n);
+    for (int i = 0; i < m; ++i) if ((cx[i] = code_of(x[i])) < 0) return 1;
+    for (int j = 0; j < n; ++j) if ((cy[j] = code_of(y[j])) < 0) return 1;
+    Mask256 eq[5];
+    memset(eq, 0, sizeof eq);
+    for (int j = 0; j < n; ++j) eq[cy[j]].w[j >> 5] |= 1u << (j & 31);
+    const int rows_m = m - K + 1;
+    std::vector<Mask256> m6(std::max(rows_m, 0));
+    long total = 0;
+    for (int r = 0; r < rows_m; ++r) {
+        Mask256 a = eq[cx[r]];
+        for (int t = 1; t < K; ++t) a = band(a, shr(eq[cx[r + t]], t));
+        m6[r] = a;
+        for (int i = 0; i < 8; ++i) total += __builtin_popcount(a.w[i]);
+    }
+    if (stats) stats[2] = (int32_t)total;
+    for (int j = 0; j <= n; ++j) { lo[j] = m + 1; hi[j] = 0; }
+    if (total == 0) {
+        if (VTX_BAND_NO_SEED_FULL_MATRIX) for (int j = 0; j <= n; ++j) { lo[j] = 0; hi[j] = m + 1; }
+        return 0;
+    }
+    auto bit = [&](int r, int yy) { return r >= 0 && r < rows_m && yy >= 0 && yy < n && ((m6[r].w[yy >> 5] >> (yy & 31)) & 1u); };
+    struct Ent { uint8_t o, x0; };
+    Ent off[512];
+    memset(off, 0, sizeof off);
+    uint32_t tree[257];
+    memset(tree, 0, sizeof tree);
+    struct St { int y, dp; };
+    std::vector<St> stash[8];
+    std::vector<uint32_t> log;
+    uint32_t best = 0;
+    auto end_event = [&](int xs, int yy, uint32_t dp) {
+        const uint32_t V = dp + (uint32_t)(xs + K) + (uint32_t)(yy + K);
+        const uint32_t val = (V << 16) | ((uint32_t)xs << 8) | (uint32_t)yy;
+        for (int i = yy + K + 1; i <= 256; i += i & (-i)) tree[i] = std::max(tree[i], val);
+        best = std::max(best, (dp << 16) | ((uint32_t)xs << 8) | (uint32_t)yy);
+    };
+    for (int r = 0; r <= m; ++r) {
+        const int xs = r - K;
+        if (xs >= 0 && xs < rows_m) {
+            for (int yy = 0; yy < n; ++yy) {
+                if (!bit(xs, yy)) continue;
+                const Ent e = off[yy - xs + 256];
+                if (xs < (int)e.x0) continue;                  // a match of the diagonal's previous section: its END is in the stash
+                end_event(xs, yy, (uint32_t)(r - (int)e.o));   // dp = xs + 6 - o
+            }
+        }
+        for (const St& t : stash[r & 7]) end_event(xs, t.y, (uint32_t)t.dp);
+        stash[r & 7].clear();
+        if (r < rows_m) {
+            for (int yy = 0; yy < n; ++yy) {
+                if (!bit(r, yy)) continue;
+                uint32_t q = 0;
+                for (int i = yy + 1; i > 0; i -= i & (-i)) q = std::max(q, tree[i]);
+                const int cand = q ? (int)(q >> 16) - (r + yy) + 1 : 0;
+                const int d = yy - r + 256;
+                if (!bit(r - 1, yy - 1)) {                     // opens its diagonal's run: a section
+                    int dv = K;
+                    uint32_t src = 0xffffu;
+                    if (q && cand >= K) { dv = cand; src = q & 0xffffu; }
+                    off[d] = Ent{(uint8_t)(r + K - dv), (uint8_t)r};
+                    if ((int)log.size() >= log_cap) return 2;
+                    log.push_back(((uint32_t)r << 24) | ((uint32_t)yy << 16) | src);
+                } else {
+                    const Ent e = off[d];
+                    const int dpc = (r - 1) + K - (int)e.o;
+                    if (q && cand > dpc + 1) {                 // a jump beats the continuation (ties: the continuation)
+                        if (stats) ++stats[3];
+                        for (int xp = std::max((int)e.x0, r - (K - 1)); xp <= r - 1; ++xp) {   // matches of the old section still to end
+                            std::vector<St>& b = stash[(xp + K) & 7];
+                            if ((int)b.size() >= stash_cap) return 5;
+                            b.push_back(St{yy - (r - xp), xp + K - (int)e.o});
+                            if (stats) stats[4] = std::max(stats[4], (int32_t)b.size());
+                        }
+                        off[d] = Ent{(uint8_t)(r + K - cand), (uint8_t)r};
+                        if ((int)log.size() >= log_cap) return 2;
+                        log.push_back(((uint32_t)r << 24) | ((uint32_t)yy << 16) | (q & 0xffffu));
+                    }
+                }
+            }
+        }
+    }
+    if (stats) stats[0] = (int32_t)log.size();
+    struct Sec { int x0, y0, len; };
+    std::vector<Sec> secs;
+    int cxr = (int)((best >> 8) & 0xffu), cyr = (int)(best & 0xffu);
+    for (;;) {
+        const int d = cyr - cxr;
+        int found = -1, fx = -1;
+        for (size_t e = 0; e < log.size(); ++e) {
+            const int ex = (int)(log[e] >> 24), ey = (int)((log[e] >> 16) & 0xffu);
+            if (ey - ex == d && ex <= cxr && ex > fx) { fx = ex; found = (int)e; }
+        }
+        if (found < 0) return 4;
+        const int ex = (int)(log[found] >> 24), ey = (int)((log[found] >> 16) & 0xffu);
+        if ((int)secs.size() >= sec_cap) return 3;
+        secs.push_back(Sec{ex, ey, cxr - ex + 1});
+        const uint32_t src = log[found] & 0xffffu;
+        if (src == 0xffffu) break;
+        cxr = (int)(src >> 8); cyr = (int)(src & 0xffu);
+    }
+    std::reverse(secs.begin(), secs.end());
+    if (stats) stats[1] = (int32_t)secs.size();
+    std::vector<int> rmin(n + 2, 1 << 20), rmax(n + 2, -1);
+    auto anchor = [&](int r, int c) { rmin[c] = std::min(rmin[c], r); rmax[c] = std::max(rmax[c], r); };
+    const int lazy = VTX_BAND_LAZY_EXT(K), last = VTX_BAND_KMER_LAST_ANCHOR(K);
+    const int fx0 = secs.front().x0, fy0 = secs.front().y0;
+    const int d0 = std::min(std::min(fx0, fy0), lazy);
+    for (int t = 0; t <= d0; ++t) anchor(fx0 - d0 + t, fy0 - d0 + t);
+    const int cA = fy0 - d0;
+    int pr = -1, pc = -1;
+    for (size_t s2 = 0; s2 < secs.size(); ++s2) {
+        const Sec& S = secs[s2];
+        if (s2 > 0) {
+            const int dr = S.x0 - pr, dc = S.y0 - pc, dg = std::min(dr, dc);
+            for (int t = 0; t <= dg; ++t) anchor(pr + t, pc + t);
+            if (dr > dc) { for (int r = pr + dg; r <= S.x0; ++r) anchor(r, pc + dg); }
+            else { for (int c = pc + dg; c <= S.y0; ++c) anchor(pr + dg, c); }
+        }
+        const int span = S.len - 1 + last;
+        for (int t = 0; t <= span; ++t) anchor(S.x0 + t, S.y0 + t);
+        pr = S.x0 + S.len - 1 + K; pc = S.y0 + S.len - 1 + K;
+    }
+    const int lx = pr, ly = pc;
+    const int d1 = std::min(std::min(m - lx, n - ly), lazy);
+    for (int t = 0; t <= d1; ++t) anchor(lx + t, ly + t);
+    const int cB = ly + d1;
+    for (int j = 0; j <= n; ++j) {
+        if (j < cA - W || j > cB + W) continue;
+        const int c0 = std::max(j - W, cA), c1 = std::min(j + W, cB);
+        lo[j] = std::max(rmin[c0] - W, 0);
+        hi[j] = std::min(rmax[c1] + W + 1, m + 1);
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -33,24 +33,31 @@ def model_lib():
     L = C.CDLL(os.path.join(HERE, "sweepmodel", "libsweep_model.so"))
     L.vtxs_band.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.vtxs_band.restype = C.c_int
+    L.vtxs_band2.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.vtxs_band2.restype = C.c_int
     return L
 
 
-def bands_vs_oracle(batch, nb, label, max_tasks=6000, tier=0):
+def bands_vs_oracle(batch, nb, label, max_tasks=6000, tier=None):
     """Every task of the batch through vtx_debug_bands; the band of every accepted task equals the oracle's, and a task is declined
-    exactly when the CPU model of the kernel (same capacities) declines it."""
+    exactly when the CPU model of the kernel (same capacities) declines it.  tier None: band_sweep_kernel (round 5: the section
+    store per diagonal, 1 024 log entries in global memory, seven stash entries per END row — model vtxs_band2); tier 0 / 1: round 4's
+    kernel in libvtx_dev.so (VTX_SWEEP_V1=1; 256 / 1 024 log entries — model vtxs_band)."""
     M = model_lib()
     n_tasks = min(2 * batch.n_records, max_tasks)
     tasks = np.arange(n_tasks, dtype=np.uint32)
     stride = int(max(batch.loci["ref_len"].max(), batch.loci["alt_len"].max())) + 1
-    os.environ["VTX_SWEEP_TIER"] = str(tier)                       # (read at every vtx_debug_bands call)
+    if tier is not None:
+        os.environ["VTX_SWEEP_V1"] = "1"                           # (both read at every vtx_debug_bands call of libvtx_dev.so)
+        os.environ["VTX_SWEEP_TIER"] = str(tier)
     try:
-        with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb), variant="dev" if tier else None) as ctx:
+        with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb), variant=None if tier is None else "dev") as ctx:
             ctx.submit(batch)
             lo, hi, status = ctx.debug_bands(tasks, stride)
     finally:
         os.environ.pop("VTX_SWEEP_TIER", None)
-    log_cap = 1024 if tier else 256
+        os.environ.pop("VTX_SWEEP_V1", None)
+    log_cap = 1024 if tier != 0 else 256
     rec_locus = np.repeat(np.arange(batch.n_loci), batch.loci["rec_count"])
     hb, rb = batch.hap_arena.tobytes(), batch.read_arena.tobytes()
     declined = 0
@@ -62,7 +69,12 @@ def bands_vs_oracle(batch, nb, label, max_tasks=6000, tier=0):
         y = hb[off:off + ln]
         mlo = np.zeros(len(y) + 1, np.int32)
         mhi = np.zeros(len(y) + 1, np.int32)
-        rc = M.vtxs_band(x, len(x), y, len(y), log_cap, 28, mlo.ctypes.data, mhi.ctypes.data, None) if len(x) and len(y) else 0
+        if not len(x) or not len(y):
+            rc = 0
+        elif tier is None:
+            rc = M.vtxs_band2(x, len(x), y, len(y), log_cap, 28, 7, mlo.ctypes.data, mhi.ctypes.data, None)
+        else:
+            rc = M.vtxs_band(x, len(x), y, len(y), log_cap, 28, mlo.ctypes.data, mhi.ctypes.data, None)
         assert (status[t] != 0) == (rc != 0), "%s: task %d device status %d, model %d" % (label, t, status[t], rc)
         if status[t]:
             declined += 1
@@ -102,15 +114,17 @@ def test_bands_of_repeats_real_sequence_and_read_shapes():
     assert tot > 8000 and 0 < dec < 0.25 * tot
 
 
-def test_bands_of_the_second_pass():
-    """The 1024-section variant of the kernel (what the first pass declines with a full log) on tandem repeats: far fewer declined."""
-    tot = dec = 0
-    for label, batch, nb in SB.repeat_rich_batches(trials=4, loci=20, reads=12, pad_range=(30, 120)):
-        n, d = bands_vs_oracle(batch, nb, label, 800, tier=1)
-        tot += n
-        dec += d
-    print("second pass: %d tasks, %d declined" % (tot, dec))
-    assert tot > 1500 and dec < 0.05 * tot
+def test_bands_of_round4s_kernel():
+    """Round 4's kernel (libvtx_dev.so, VTX_SWEEP_V1=1: the A/B reference of the timing campaigns), both log capacities, on tandem
+    repeats: the same bands."""
+    for tier in (0, 1):
+        tot = dec = 0
+        for label, batch, nb in SB.repeat_rich_batches(trials=3, loci=20, reads=12, pad_range=(30, 120)):
+            n, d = bands_vs_oracle(batch, nb, label, 600, tier=tier)
+            tot += n
+            dec += d
+        print("round-4 kernel, tier %d: %d tasks, %d declined" % (tier, tot, dec))
+        assert tot > 1200 and (dec < 0.05 * tot if tier else dec > 0)
 
 
 def run_both(batch, nb, trace=True, poison=None, runs=1):
@@ -194,9 +208,9 @@ np.save(sys.argv[1], np.concatenate(out))
 ''' % (ROOT, HERE)
 
 
-@pytest.mark.parametrize("hook", ["VTX_BAND_LEGACY", "VTX_BAND_CHECK", "VTX_BAND_NO_TIGHT", "VTX_BAND_SLOTS"])
+@pytest.mark.parametrize("hook", ["VTX_BAND_LEGACY", "VTX_BAND_CHECK", "VTX_BAND_NO_TIGHT", "VTX_BAND_SLOTS", "VTX_SWEEP_V1"])
 def test_hooks_give_the_same_scores(hook):
-    """VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending / general kernels instead of the sweep; VTX_BAND_CHECK=1: the full-matrix
+    """VTX_SWEEP_V1=1: round 4's band_sweep_kernel (two passes) instead of round 5's; VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending / general kernels instead of the sweep; VTX_BAND_CHECK=1: the full-matrix
     check in front of the DP of the tasks that left with a certificate; VTX_BAND_NO_TIGHT=1: those tasks go to the sweep like the
     others (the sweep's band and the certificate's one-diagonal band must give the same scores); VTX_BAND_SLOTS=5: the sweep + masked
     DP in slices of five band slots.  Identical scores (separate processes: the hooks are read once)."""

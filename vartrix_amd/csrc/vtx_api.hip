@@ -109,6 +109,7 @@ struct vtx_ctx {
     DevBuf d_read_packed;                  // VTX_READS_NIBBLES: the arena as uploaded, unpacked into d_read
     uint64_t gt_used = 0;      // bytes of d_gtables the last banded run's table kernel wrote (vtx_debug_tables)
     DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail, d_fail_tmp, d_refine;   // banded flavour
+    DevBuf d_sweep_log;                                                      // band_sweep_kernel: the section logs of the resident workgroups (64 MB)
     DevBuf d_tight, d_tight_pack, d_dband, d_dband_pack, d_dense, d_stage;                                                 // round 4: tasks with a provisional score (full-matrix check); stage bytes (vtx_fetch_stage)
     bool stage_trace = false, poison = false;                                // test / audit hooks (vtx_set_debug)
     int32_t poison_value = 0;
@@ -576,7 +577,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_cnt, &c->d_redo, &c->d_redo_cnt, &c->d_bc_slots, &c->d_bc_hash, &c->d_bc_off, &c->d_bc_bytes,
                       &c->d_raw, &c->d_tags, &c->d_raw_locus, &c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2,
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
-                      &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp, &c->d_refine, &c->d_tight, &c->d_tight_pack, &c->d_dband, &c->d_dband_pack, &c->d_dense, &c->d_stage};
+                      &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp, &c->d_refine, &c->d_tight, &c->d_tight_pack, &c->d_dband, &c->d_dband_pack, &c->d_dense, &c->d_stage, &c->d_sweep_log};
     for (DevBuf* b : bufs) b->release();
     c->d_slow_ws.release(); c->d_slow_retry.release(); c->d_read_packed.release();
     DevBuf* gb[] = {&c->d_g_cnt, &c->d_g_row, &c->d_g_col, &c->d_g_alt, &c->d_g_ref, &c->d_g_unk, &c->d_g_val, &c->d_g_refval};
@@ -651,8 +652,6 @@ static int band_reserve(vtx_ctx* c, BandPlan& p, bool quiet) {
     RES(d_poly, ((size_t)p.hard_cap + p.pend_cap) * p.poly_stride * sizeof(uint16_t));
     RES(d_band, (size_t)p.slots * 2 * p.band_stride * sizeof(uint16_t));
     RES(d_hard, ((size_t)p.hard_cap + p.pend_cap) * sizeof(uint32_t));
-    // [0, n): band_run_kernel's overflows (second chance: what overflows again is appended behind the first list, [n, 2n)); round 4:
-    // [n, 2n) = what band_sweep_kernel's first pass declines, behind it what the second declines (at most as many), [n + nB, ..)
     RES(d_over, 4 * (size_t)p.n_tasks * sizeof(uint32_t));   // [0, 2n): band_run_kernel's overflows and their second-chance appends; [2n, 4n): what band_sweep_kernel declines (its own region: the appends of an overflowing chunk cannot reach it)
     RES(d_cnt, 64 * sizeof(uint32_t));
     if (p.gt_bytes) RES(d_fail, 2 * (size_t)p.chunk * sizeof(uint32_t));  // tasks band_diag_kernel leaves to band_run_kernel (as listed, then sorted)
@@ -660,6 +659,7 @@ static int band_reserve(vtx_ctx* c, BandPlan& p, bool quiet) {
     if (p.gt_bytes) RES(d_tight, (size_t)p.chunk * sizeof(uint32_t));       // tasks with a certificate but no verdict ...
     if (p.gt_bytes) RES(d_tight_pack, (size_t)p.chunk * sizeof(uint32_t));  // ... and their bands (one diagonal stretch each: one word)
     if (p.gt_bytes) RES(d_dense, 2 * (size_t)p.chunk * sizeof(uint32_t));   // tasks for band_sweep_kernel (repeats: as listed, then sorted)
+    if (p.gt_bytes) RES(d_sweep_log, vtxk_band_sweep_log_bytes());
 #undef RES
     return VTX_OK;
 }
@@ -1176,15 +1176,28 @@ int vtx_run(vtx_ctx* c) {
         float diag_ms = 0, check_ms = 0, sweep_ms = 0;
         // the band of every listed task (band_sweep_kernel, tier 0 / 1), one slice of band slots at a time, then the masked DP over
         // the slice (its length — the tasks the sweep did not decline — is read on the device: counters[0]; declined: counters[1])
+        // (libvtx_dev.so, VTX_SWEEP_V1=1: round 4's kernel instead — 256 sections per task, then a second pass with 1 024 over what the
+        // first declined; the A/B reference of tests/test_gpu_sweep.py and tools/gpu_campaign.sh)
+        static const bool sweep_v1 = VTX_DEV_ENV("VTX_SWEEP_V1") != nullptr;
         auto sweep_slices = [&](int tier, const uint32_t* list, uint32_t n, uint32_t* over_out, uint32_t* counters) -> int {
             static const bool sweep_stats = getenv("VTX_DEBUG") != nullptr;
+            HIP_TRY(c, c->d_sweep_log.reserve(vtxk_band_sweep_log_bytes()));
             for (uint32_t off = 0; off < n; off += slots) {
                 const uint32_t cnt_s = std::min(slots, n - off);
                 HIP_TRY(c, hipMemsetAsync(counters, 0, sizeof(uint32_t), s));
-                HIP_TRY(c, vtxk_launch_band_sweep(tier, list + off, cnt_s, nullptr, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+#ifdef VTX_DEVTOOLS
+                if (sweep_v1)
+                    HIP_TRY(c, vtxk_launch_band_sweep_v1(tier, list + off, cnt_s, nullptr, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                         c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                                         c->d_band.as<uint16_t>(), band_stride, c->d_hard.as<uint32_t>(), over_out,
+                                                         counters, sweep_stats ? d_cnt + 56 : nullptr, stage, nullptr, s));
+                else
+#endif
+                HIP_TRY(c, vtxk_launch_band_sweep(list + off, cnt_s, nullptr, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                                   c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
                                                   c->d_band.as<uint16_t>(), band_stride, c->d_hard.as<uint32_t>(), over_out,
-                                                  counters, sweep_stats ? d_cnt + 56 : nullptr, stage, nullptr, s));
+                                                  counters, sweep_stats ? d_cnt + 56 : nullptr, stage, nullptr, c->d_sweep_log.as<uint32_t>(), s));
+                (void)tier;
                 HIP_TRY(c, vtxk_launch_sw_banded_dev(kShapes[shape][0], kShapes[shape][1], cnt_s, c->d_hard.as<uint32_t>(), counters,
                                                      c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
                                                      c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_band.as<uint16_t>(), band_stride,
@@ -1481,9 +1494,8 @@ int vtx_run(vtx_ctx* c) {
             ++launches;
             if (sweep_used && base + chunk >= n_tasks) {
                 // last chunk.  What overflowed band_run_kernel's lists (d_over[0, nA)) takes band_sweep_kernel too; then everything
-                // its first pass declined — here and in the chunks' own sweeps: d_over[2 n_tasks, + nB), counted on the device — takes
-                // the second pass (1024 sections); what that declines as well (bytes outside ACGTN, reads above 255 bases, more
-                // sections still: d_over[2 n_tasks + nB, + nC)) takes the general band kernel.
+                // the sweep declined — here and in the chunks' own sweeps: d_over[2 n_tasks, + nB), counted on the device — takes the
+                // general band kernel (round 4's kernel, libvtx_dev.so: first its second pass, [2 n_tasks + nB, + nC) is what is left).
                 uint32_t* over = c->d_over.as<uint32_t>();
                 const uint32_t nA = cnt[1];
                 if (nA) {
@@ -1494,11 +1506,13 @@ int vtx_run(vtx_ctx* c) {
                 HIP_TRY(c, hipMemcpyAsync(&nB, d_cnt + 27, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                 HIP_TRY(c, hipStreamSynchronize(s));
                 if (int rc = collect_sweep_times()) return rc;
-                if (nB) {
+                if (nB && sweep_v1) {                       // (round 4's kernel only: its second pass with the larger log)
                     resweep_total = nB;
                     if (int rc = sweep_slices(1, over + 2 * n_tasks, nB, over + 2 * n_tasks + nB, d_cnt + 28)) return rc;
                     HIP_TRY(c, hipMemcpyAsync(&nC, d_cnt + 29, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     HIP_TRY(c, hipStreamSynchronize(s));
+                } else if (nB) {                            // what band_sweep_kernel declines (bytes outside ACGTN, > 255 bases, > 1 024 sections, a
+                    nC = nB; nB = 0;                        // full stash bucket) takes the general band kernel
                 }
                 cnt[1] = nC;
                 if (nC) { if (int rc = fallback_start((uint32_t)(2 * n_tasks) + nB, (uint32_t)(2 * n_tasks) + nB + nC)) return rc; }
@@ -1676,10 +1690,20 @@ int vtx_debug_bands(vtx_ctx* c, const uint32_t* tasks, uint32_t n_tasks, uint32_
     if (dbg_on) DBG_TRY(d_d.reserve((size_t)n_tasks * 64 * 4));
     DBG_TRY(hipMemcpyAsync(d_t.p, tasks, (size_t)n_tasks * 4, hipMemcpyHostToDevice, s));
     DBG_TRY(hipMemsetAsync(d_c.p, 0, 64 * 4, s));
-    const int dbg_tier = VTX_DEV_ENV("VTX_SWEEP_TIER") ? atoi(VTX_DEV_ENV("VTX_SWEEP_TIER")) : 0;      // (tests: the 1024-section variant)
-    DBG_TRY(vtxk_launch_band_sweep(dbg_tier, d_t.as<uint32_t>(), n_tasks, nullptr, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+    DBG_TRY(c->d_sweep_log.reserve(vtxk_band_sweep_log_bytes()));
+#ifdef VTX_DEVTOOLS
+    // (libvtx_dev.so: VTX_SWEEP_V1=1 asks round 4's kernel instead; VTX_SWEEP_TIER=1 its 1024-section variant)
+    if (VTX_DEV_ENV("VTX_SWEEP_V1"))
+        DBG_TRY(vtxk_launch_band_sweep_v1(VTX_DEV_ENV("VTX_SWEEP_TIER") ? atoi(VTX_DEV_ENV("VTX_SWEEP_TIER")) : 0, d_t.as<uint32_t>(), n_tasks, nullptr,
+                                          c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                          c->d_hap.as<uint8_t>(), d_b.as<uint16_t>(), bs, d_h.as<uint32_t>(), d_o.as<uint32_t>(), d_c.as<uint32_t>(), nullptr,
+                                          nullptr, dbg_on ? d_d.as<uint32_t>() : nullptr, s));
+    else
+#endif
+    DBG_TRY(vtxk_launch_band_sweep(d_t.as<uint32_t>(), n_tasks, nullptr, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                    c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), d_b.as<uint16_t>(), bs,
-                                   d_h.as<uint32_t>(), d_o.as<uint32_t>(), d_c.as<uint32_t>(), nullptr, nullptr, dbg_on ? d_d.as<uint32_t>() : nullptr, s));
+                                   d_h.as<uint32_t>(), d_o.as<uint32_t>(), d_c.as<uint32_t>(), nullptr, nullptr, dbg_on ? d_d.as<uint32_t>() : nullptr,
+                                   c->d_sweep_log.as<uint32_t>(), s));
     uint32_t cnt[2] = {0, 0};
     DBG_TRY(hipMemcpyAsync(cnt, d_c.p, sizeof cnt, hipMemcpyDeviceToHost, s));
     DBG_TRY(hipStreamSynchronize(s));

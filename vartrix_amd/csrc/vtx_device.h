@@ -90,11 +90,20 @@ hipError_t vtxk_launch_band_refine(const uint32_t* recs, uint32_t n_recs, const 
                                    int32_t* alt_score, uint32_t* fail_list, uint32_t* counters, uint32_t tasks_per_locus,
                                    uint32_t gt_l0, const uint8_t* gtables, int stats, uint32_t* tight_list, uint32_t* tight_pack,
                                    uint8_t* stage, const uint32_t* n_dev, hipStream_t s);
-// ---- round 4: the band for any task (vtx_sweep.hip), the masked DP over a device-counted list, the full-matrix check ----
-hipError_t vtxk_launch_band_sweep(int tier, const uint32_t* tasks, uint32_t n_tasks, const uint32_t* n_dev, const vtx_record* records,
+// ---- the band for any task (vtx_sweep.hip), the masked DP over a device-counted list, the full-matrix check ----
+hipError_t vtxk_launch_band_sweep(const uint32_t* tasks, uint32_t n_tasks, const uint32_t* n_dev, const vtx_record* records,
                                   const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena, const uint8_t* hap_arena,
                                   uint16_t* band, uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list, uint32_t* counters,
-                                  uint32_t* stat_counters, uint8_t* stage, uint32_t* dbg, hipStream_t s);
+                                  uint32_t* stat_counters, uint8_t* stage, uint32_t* dbg, uint32_t* glog, hipStream_t s);
+size_t vtxk_band_sweep_log_bytes(void);            // glog: the section logs of the resident workgroups
+uint32_t vtxk_band_sweep_grid(uint32_t n_tasks);
+#ifdef VTX_DEVTOOLS
+// round 4's kernel (vtx_sweep_v1.hip, libvtx_dev.so only: VTX_SWEEP_V1=1), the reference of the A/B tests
+hipError_t vtxk_launch_band_sweep_v1(int tier, const uint32_t* tasks, uint32_t n_tasks, const uint32_t* n_dev, const vtx_record* records,
+                                     const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena, const uint8_t* hap_arena,
+                                     uint16_t* band, uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list, uint32_t* counters,
+                                     uint32_t* stat_counters, uint8_t* stage, uint32_t* dbg, hipStream_t s);
+#endif
 uint32_t vtxk_band_sweep_max_len(void);
 hipError_t vtxk_launch_sw_banded_dev(int R, int GL, uint32_t n_cap, const uint32_t* hard, const uint32_t* n_dev,
                                      const vtx_record* records, const uint32_t* rec_locus, const vtx_locus* loci,

@@ -1,49 +1,39 @@
-// vtx_sweep.hip — band_sweep_kernel: the band of bio 0.30.0's banded aligner for ANY task, eight lanes per task
-// (the robust path behind band_diag_kernel / band_refine_kernel; round 5: no dp ring, 2.4 KB of LDS per task).
+// vtx_sweep_v1.hip — round 4's band_sweep_kernel (dp bytes of eight rows in LDS, 4.8 KB per task, one wavefront per SIMD), kept as
+// the REFERENCE the round-5 kernel (vtx_sweep.hip) is compared with: linked into libvtx_dev.so only, selected there with
+// VTX_SWEEP_V1=1 (tests/test_gpu_sweep.py: identical bands and scores; tools/gpu_campaign.sh: A/B timing).
 //
 // What is computed: Band::create of banded::Aligner::local(read, haplotype) as the reference calls it
 // (src/main.rs:898-901, K = 6, W = 20) — find_kmer_matches, sdpkpp, the anchor staircase with set_boundaries' lazy
 // extension, the (2w + 1)-squares — restated in oracle/vtx_oracle.c (vtxo_band_create).  The output is the per-column row
 // range [lo, hi) of every task, in the slot layout sw_banded_kernel reads; that kernel then scores the task exactly.
 //
+// Why a new kernel: the certificate stages decide a task only when its alignment lives on one diagonal.  On loci drawn
+// from real (repeat-rich) sequence 17-20 % of the tasks are left, and round 3 sent them through band_run_kernel (15-entry
+// piece lists per lane), then a wavefront-per-task general kernel (band_coop_kernel, ~70 ns per task) — 580 ms per step
+// against 18 ms on an iid genome.  This kernel has no lists to overflow and no per-match storage:
+//
 //   matches   Eq[c] = bit mask of the haplotype columns holding base c (five 256-bit masks; lane l of the task's eight
 //             lanes owns word l = columns 32 l .. 32 l + 31, in registers).  The 6-mer matches of read row x are
 //             M6(x) = AND_t Eq[x[x + t]] >> t — three funnel shifts per row over a sliding window (M2, M4, M6).
-//             Bytes outside ACGTN, reads / haplotypes above 255 bases: the task is declined (the general kernel of
-//             vtx_band.hip takes it).
-//   sdpkpp    rows ascending; END events of row x (matches that started at row x - 6) enter C[ye] (LDS, ds_max_u32) and an
-//             8-column block maximum with V << 16 | xq << 8 | yq (V = dp + xe + ye: the tuple order of the crate's max-tree);
-//             START events: dp = max(6, prefixmax(y).V - (x + y) + 1, dp(x - 1, y - 1) + 1), the continuation wins ties.
-//   sections  ROUND 5.  Along a run of continuing matches dp grows by exactly 1 per row: dp(x, y) = x + 6 - o with ONE deficit
-//             o per SECTION — a run that starts at a match which does not continue its diagonal, or at one where a jump beats the
-//             continuation.  Per DIAGONAL d = y - x the kernel keeps the latest section only, 16 bits (o, x0 = its first row):
-//             512 diagonals = 1 KB per task instead of round 4's 2 KB of dp bytes (eight rows x 256 columns), and — what the
-//             time was made of — a continuing match costs NOTHING at its START event (round 4: an LDS read of its partner's
-//             dp and a write of its own, one trip of a serial per-lane loop per match).  It is looked at only when a jump
-//             could beat it: lane-level test  pmax.V - 2x - 5 > G,  G = a lower bound of y - o over the lane's continuing
-//             matches (carried from row to row: + 1 per row, the lower lane's bound for the match that crosses in).
-//             The END event of the match that started at row xs reads dp = xs + 6 - o from its diagonal's entry.
-//   stash     the one case the latest section does not cover: a jump beats the continuation at row r while matches of rows
-//             r - 5 .. r - 1 of the OLD section have not ended.  Their (column, dp) go to a stash — eight buckets by end row,
-//             seven entries each — and enter C when their row comes; the END loop skips a match whose row lies before its
-//             diagonal's x0.  (Inside six rows a diagonal cannot break and resume, so x0 > xs means exactly this.)  A full
-//             bucket declines the task (tandem repeats over two letters; 0 of 4 000 real-sequence tasks).
-//   chain     a match that opens a section is logged (x, y, source) — in GLOBAL memory (a 4 KB slice per resident task, L2-
-//             resident; LDS holds none of it: round 4's 1 KB log and its second pass over the log overflows are gone).  From
-//             the best (dp, x, y): the section is the log entry of this diagonal with the largest x' <= x; go on from its source.
+//             Bytes outside ACGTN, reads / haplotypes above 255 bases: the task is declined (overflow list: the general
+//             kernel of vtx_band.hip takes it).
+//   sdpkpp    rows ascending.  END events of row x (matches that started at row x - 6): their value
+//             V << 16 | xq << 8 | yq (V = dp + xe + ye; the tuple order of the crate's max-tree, ties to the larger
+//             match index) enters C[ye] (LDS, ds_max_u32), an 8-column block maximum and a per-task maximum.  START events
+//             of row x: dp = max(6, prefixmax(y).V - (x + y) + 1, dp(x - 1, y - 1) + 1): the continuation wins ties, a jump
+//             needs >= 6 (oracle: `cand > dp || cand == dp && larger index`; every jump source has a smaller index than the
+//             continuation partner).  The prefix maximum is only looked up when the per-task maximum says a jump COULD beat
+//             the continuation.  dp is final at the start event (the partner's was), kept one byte per (row mod 8, column).
+//   chain     a match that does not continue its diagonal opens a section and is logged (x, y, source).  From the best
+//             (dp, x, y): the section is the log entry of this diagonal with the largest x' <= x; go on from its source.
 //   band      the staircase's anchors (lazy extension, sections, gaps) -> first / last anchor row per column (ds_min / ds_max)
 //             -> lo / hi in closed form (vtx_band.hip's header).
-// tests/sweepmodel/sweep_model.cpp (vtxs_band2) restates exactly this on the CPU; tests/test_sweep_model.py checks it against
-// the oracle; tests/test_gpu_sweep.py checks the device's bands column by column against both.
+// tests/sweepmodel/sweep_model.cpp restates exactly this on the CPU; tests/test_sweep_model.py checks it against the oracle.
 //
-// Machine mapping: one wavefront per workgroup = 8 tasks x 8 lanes, 612 words of LDS per task = 19.1 KB per wavefront: EIGHT
-// wavefronts per CU (two per SIMD; round 4: 38.5 KB, one per SIMD — nothing hid a wave's LDS / SALU latency).  A persistent
-// grid (a workgroup takes task groups blockIdx.x, + gridDim.x, ...) so that the log slices are per resident workgroup.
-// Integer / LDS work, no MFMA.
+// Machine mapping: one wavefront per workgroup = 8 tasks x 8 lanes, 4.1 KB of LDS per task.  Integer / LDS work, no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <algorithm>
 #include <cstdlib>
 
 #include "vtx_device.h"
@@ -56,18 +46,22 @@ static_assert(K == 6 && W == 20 && VTX_REF_MATCH == 1 && VTX_REF_GAP_OPEN == -5 
               "band_sweep_kernel's sdpkpp is written for k = 6, match 1, gap -5 / -1 (src/main.rs:33-38, :899)");
 constexpr int SECCAP = 28;           // sections of the best chain (a 150-base read chains at most 25 six-mers end to end)
 constexpr int MAXLEN = 255;          // read / haplotype bases (one byte per coordinate in the packed words)
-constexpr int LOGCAP = 1024;         // sections a task may open (global memory; real sequence: p99 55, satellites: hundreds)
-constexpr int STASH = 7;             // entries per stash bucket
-constexpr int GRID_MAX = 2048;       // resident workgroups: 256 CUs x 8
-constexpr int G_INF = 0x3fffffff;
-// per-task LDS (32-bit words)
-constexpr int O_OFF = 0;             // 512 diagonals x 16 bits: x0 << 8 | o; after the sweep: rmin[256]
-constexpr int O_C = 256;             // C[ye], 256 words; after the sweep: rmax[256]
-constexpr int O_BM = 512;            // block maxima of C, 8 columns each (32 words); after the sweep: the chain's sections
-constexpr int O_STASH = 544;         // 8 buckets x (count, 7 entries: y << 8 | dp)
-constexpr int O_MISC = 608;          // [0] log entries
-constexpr int TASK_W = 612;          // = 4 (mod 32): the eight tasks of a wavefront start in eight different banks; 16-byte aligned
-static_assert(TASK_W % 32 == 4 && TASK_W % 4 == 0 && O_MISC + 4 <= TASK_W && SECCAP <= 32, "LDS layout");
+// per-task LDS (32-bit words).  LOGCAP = sections a task may open: 256 for the first pass (real sequence: p99 55; 4.8 KB per task,
+// four wavefronts per CU), 1024 for the second pass over what the first declined (satellites, tandem repeats over two letters:
+// hundreds of dominated pieces whose every match opens a section; 7.9 KB per task, two wavefronts per CU).
+template <int LOGCAP>
+struct Lay {
+    static constexpr int O_RING = 0;            // 8 rows x 256 dp bytes; after the sweep: rmin[256], rmax[256]
+    static constexpr int O_C = 512;             // C[ye], 256 words
+    static constexpr int O_BM = 768;            // block maxima of C, 8 columns each
+    static constexpr int O_PBM = 800;           // exclusive prefix maxima of BM
+    static constexpr int O_CODE = 832;          // read base codes, one NIBBLE per row (7: no base): 8 rows per word, 36 words
+    static constexpr int O_SEC = 900;           // SECCAP sections: x0 << 16 | y0 << 8 | matches
+    static constexpr int O_MISC = 928;          // [0] log entries
+    static constexpr int O_LOG = 948;           // LOGCAP section records: x << 24 | y << 16 | source (0xffff: none)
+    static constexpr int TASK_W = 948 + LOGCAP; // = 20 (mod 32) for both capacities: the eight tasks of a wavefront start in eight different banks
+    static_assert(TASK_W % 32 == 20 && TASK_W % 4 == 0, "bank spread / 16-byte alignment of the task slices");
+};
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -76,7 +70,7 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // DPP moves are never wrapped in a select: `cond ? dpp(x) : 0` compiles to an EXEC-masked DPP, and a source lane that EXEC
-// disables reads as 0.  Masks are ANDed in.
+// disables reads as 0 (the first version of the block-maximum scan lost lane 0's blocks that way).  Masks are ANDed in.
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp0(uint32_t v) {      // lanes without a source get 0
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
@@ -108,37 +102,38 @@ __device__ __forceinline__ uint32_t base_code(uint32_t b) {
 
 // tasks[n_tasks]: task = 2 * record + haplotype.  Every task either gets band slot h = atomicAdd(counters[0]) (hard_list[h] =
 // task, lo at band + h * 2 * band_stride, hi at + band_stride) or, when declined, goes to overflow_list[atomicAdd(counters[1])].
-// stat_counters != nullptr: stat_counters[reason] counts the declined tasks (1 bytes / lengths, 2 log full, 3 sections, 5 stash).
+// stat_counters != nullptr: stat_counters[reason] counts the declined tasks (1 bytes / lengths, 2 log full, 3 sections).
 // n_dev != nullptr: the list length lives on the device (min(*n_dev, n_tasks); the grid is sized for n_tasks).
-// glog: gridDim.x * 8 * LOGCAP words (vtxk_band_sweep_log_bytes).
-__global__ __launch_bounds__(64) void band_sweep_kernel(
+//
+// The sweep's fast path: nearly every lane has at most ONE match per row, and it continues the lane's match of the row before.  The
+// dp of a lane's first match of the last six rows rides in a register (one byte per row): the END event six rows later and the
+// continuation test of the next row read it there; whether (x - 1, y - 1) is a match at all is a bit of the previous row's mask.
+// The dp bytes in LDS are only READ for a lane's second and further matches of a row (repeats).
+template <int LOGCAP>
+__global__ __launch_bounds__(64) void band_sweep_v1_kernel(
     const uint32_t* __restrict__ tasks, uint32_t n_tasks, const uint32_t* __restrict__ n_dev,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
     uint16_t* __restrict__ band, uint32_t band_stride, uint32_t* __restrict__ hard_list,
     uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ counters, uint32_t stats, uint32_t* __restrict__ stat_counters,
-    uint8_t* __restrict__ stage, uint32_t* __restrict__ dbg, uint32_t* __restrict__ glog) {
+    uint8_t* __restrict__ stage, uint32_t* __restrict__ dbg) {
+    typedef Lay<LOGCAP> L;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (n_dev) { const uint32_t nd = *n_dev; n_tasks = nd < n_tasks ? nd : n_tasks; }
+    if (blockIdx.x * 8u >= n_tasks) return;
     const int lane = (int)threadIdx.x;
     const int g = lane >> 3, l = lane & 7;
-    uint32_t* T = lds + g * TASK_W;
-    uint16_t* OFF = (uint16_t*)(T + O_OFF);
-    uint32_t* Cw = T + O_C;
-    uint32_t* BM = T + O_BM;
-    uint32_t* ST = T + O_STASH;
-    uint32_t* MISC = T + O_MISC;
-    uint32_t* SEC = T + O_BM;
-    uint32_t* LOG = glog + ((size_t)blockIdx.x * 8u + (uint32_t)g) * (size_t)LOGCAP;
-    const int col0 = 32 * l;
-    const uint32_t nbmask = l == 7 ? 0u : 0xffffffffu;            // lane 7's upper neighbour belongs to the next task
-    const uint32_t ge1 = l >= 1 ? 0xffffffffu : 0u, ge2 = l >= 2 ? 0xffffffffu : 0u, ge4 = l >= 4 ? 0xffffffffu : 0u;
-    const uint32_t ablate = VTX_ABLATE(stats >> 8);               // (profiling aid, libvtx_dev.so only; results are wrong by design)
+    uint32_t* T = lds + g * L::TASK_W;
+    uint8_t* ring = (uint8_t*)(T + L::O_RING);
+    uint32_t* Cw = T + L::O_C;
+    uint32_t* BM = T + L::O_BM;
+    uint32_t* PBM = T + L::O_PBM;
+    uint32_t* LOG = T + L::O_LOG;
+    uint32_t* codes32 = T + L::O_CODE;
+    uint32_t* SEC = T + L::O_SEC;
+    uint32_t* MISC = T + L::O_MISC;
 
-#pragma unroll 1
-    for (uint32_t grp = blockIdx.x; grp * 8u < n_tasks; grp += gridDim.x) {
-    wave_sync();                                                  // (the previous group's LDS reads are done)
-    const uint32_t slot = grp * 8u + (uint32_t)g;
+    const uint32_t slot = blockIdx.x * 8u + (uint32_t)g;
     const bool have = slot < n_tasks;
     uint32_t task = 0, roff = 0, hoff = 0;
     int m = 0, n = 0;
@@ -153,19 +148,19 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
     }
     uint32_t decline = (have && (m > MAXLEN || n > MAXLEN)) ? 1u : 0u;
     if (decline) { m = 0; n = 0; }
+    const int col0 = 32 * l;
 
-    // ---- set-up: zero C / BM / stash counts / log count; read codes and Eq words to registers ----
+    // ---- set-up: zero C / BM / counters, read codes to LDS, Eq words to registers ----
     {
         const uint4 z = make_uint4(0, 0, 0, 0);
         uint4* c4 = (uint4*)(Cw + col0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) c4[i] = z;
         *(uint4*)(BM + 4 * l) = z;
-        ST[8 * l] = 0;
+        *(uint4*)(PBM + 4 * l) = z;
         if (l == 0) MISC[0] = 0;
     }
     uint32_t bad = 0;
-    uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0;                  // codes of read rows 32 l .. 32 l + 31, a nibble each (7: no base)
     {
         // read bytes [32 l, 32 l + 32): two 16-byte loads (the arena is padded by 16 bytes)
         uint32_t wds[8];
@@ -175,7 +170,7 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
             if (col0 + 16 * h < m) __builtin_memcpy(&v, read_arena + roff + col0 + 16 * h, 16);
             wds[4 * h] = v.x; wds[4 * h + 1] = v.y; wds[4 * h + 2] = v.z; wds[4 * h + 3] = v.w;
         }
-        uint32_t packed[4] = {0, 0, 0, 0};
+        uint32_t packed[4] = {0, 0, 0, 0};                        // rows 32 l .. 32 l + 31, a nibble each
 #pragma unroll
         for (int wi = 0; wi < 8; ++wi) {
 #pragma unroll
@@ -189,7 +184,8 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
                 packed[k >> 3] |= c << (4 * (k & 7));
             }
         }
-        pk0 = packed[0]; pk1 = packed[1]; pk2 = packed[2]; pk3 = packed[3];
+        *(uint4*)(codes32 + 4 * l) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        if (l == 0) *(uint4*)(codes32 + 32) = make_uint4(0x77777777u, 0x77777777u, 0x77777777u, 0x77777777u);
     }
     uint32_t eq0 = 0, eq1 = 0, eq2 = 0, eq3 = 0, eq4 = 0;
     {
@@ -217,6 +213,8 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
     wave_sync();
 
     // ---- the sweep ----
+    const uint32_t nbmask = l == 7 ? 0u : 0xffffffffu;            // lane 7's upper neighbour belongs to the next task
+    const uint32_t ge1 = l >= 1 ? 0xffffffffu : 0u, ge2 = l >= 2 ? 0xffffffffu : 0u, ge4 = l >= 4 ? 0xffffffffu : 0u;
     int mmax = m;
     mmax = max(mmax, __shfl_xor(mmax, 8)); mmax = max(mmax, __shfl_xor(mmax, 16)); mmax = max(mmax, __shfl_xor(mmax, 32));
     const int tmax = __builtin_amdgcn_readfirstlane(mmax) + K;    // feed step t = 0 .. m + 5: row r = t - 5 reaches m
@@ -224,36 +222,25 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
     uint32_t m2a = 0, m2b = 0, m2c = 0, m2d = 0;                  // M2(t - 2) .. M2(t - 5)
     uint32_t h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0;      // M6(r - 1) .. M6(r - 6)
     uint32_t best = 0;
+    uint64_t dq = 0;                                              // dp of this lane's FIRST match of rows r - 1 (bits 0-7) .. r - 6 (bits 40-47)
     uint32_t pmax = 0;                                            // see the END phase
-    int G = G_INF;                                                // lower bound of y - o over this lane's matches of the previous row
-    int stash_until = -1;                                         // the task's stash may hold entries for END rows <= this
-    uint32_t stash_full = 0;
-    // the codes of eight rows per word, fetched from the lane that holds them (word j = rows 8 j .. 8 j + 7: register j & 3 of lane
-    // j >> 2; selected by VALUE with the uniform j — a select between the variables themselves sends them through scratch memory)
-#define FETCH_CODES(dst, jexpr)                                                                                  \
-    {                                                                                                            \
-        const int j_ = (jexpr);                                                                                  \
-        uint32_t mine_ = pk0;                                                                                    \
-        mine_ = (j_ & 3) == 1 ? pk1 : mine_; mine_ = (j_ & 3) == 2 ? pk2 : mine_; mine_ = (j_ & 3) == 3 ? pk3 : mine_;   \
-        const uint32_t v_ = (uint32_t)__shfl((int)mine_, (lane & ~7) | ((j_ >> 2) & 7));                          \
-        dst = j_ < 32 ? v_ : 0x77777777u;                                                                        \
-    }
-    uint32_t code_blk = 0, code_blk_next;
-    FETCH_CODES(code_blk_next, 0)
+    uint32_t code_blk = 0, code_blk_next = codes32[0];          // the codes of eight rows per word: one LDS read (and one wait) per eight rows
 #define LDS_DONE() __builtin_amdgcn_s_waitcnt(0xC07F)          /* s_waitcnt lgkmcnt(0) (gfx9 encoding: vmcnt / expcnt untouched) */
 #define SHR_WORDS(v, s) __builtin_amdgcn_alignbit(dpp0<DPP_ROW_SHL(1)>(v) & nbmask, (v), (s))
-    // one END event: the match that started at (r - 6, y) with dp enters C / BM; val_ = the inserted value
-#define END_EVENT(y, dp, val_)                                                                        \
+    // one END event: the match that started at (r - 6, y) with dp enters C / BM; returns the inserted value
+#define END_EVENT(y, dp)                                                                              \
     {                                                                                                 \
         const uint32_t key_ = ((uint32_t)(dp) << 16) | ((uint32_t)(r - K) << 8) | (uint32_t)(y);      \
         best = max(best, key_);                                                                       \
-        val_ = key_ + ((uint32_t)(r + K + (y)) << 16);   /* V = dp + xe + ye = dp + r + (y + 6) */     \
+        const uint32_t val_ = key_ + ((uint32_t)(r + K + (y)) << 16);   /* V = dp + xe + ye = dp + r + (y + 6) */ \
         atomicMax(&Cw[(y) + K], val_);                                                                \
         atomicMax(&BM[((y) + K) >> 3], val_);                                                         \
+        if ((((y) + K) >> 5) == l) ins_a = max(ins_a, val_); else ins_b = max(ins_b, val_);           \
     }
+    const uint32_t ablate = VTX_ABLATE(stats >> 8);                           // (profiling aid, tools/ablate_sweep.sh; results are wrong by design)
 #pragma unroll 1
     for (int t = 0; t < (ablate == 1 ? 0 : tmax); ++t) {
-        if ((t & 7) == 0) { code_blk = code_blk_next; FETCH_CODES(code_blk_next, (t >> 3) + 1) }
+        if ((t & 7) == 0) { code_blk = code_blk_next; code_blk_next = codes32[min((t >> 3) + 1, 35)]; }
         const uint32_t code = (code_blk >> (4 * (t & 7))) & 7u;
         // M1(t): the Eq word of this row's base
         uint32_t m1 = (code & 1u) ? ((code & 2u) ? eq3 : eq1) : ((code & 2u) ? eq2 : eq0);
@@ -267,86 +254,77 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
         h6 = h5; h5 = h4; h4 = h3; h3 = h2; h2 = h1; h1 = w_start;
         if (r < 0) continue;                                      // (uniform)
         if (ablate == 2) { best |= w_start | w_end; continue; }   // (profiling aid) the match pipeline only
-        const bool drain = r <= stash_until;
-        if (!__any((w_start | w_end) != 0u || drain)) { G = G_INF; continue; }
-        // ---- END events of row r: matches that started at row xs = r - 6; dp = xs + 6 - o of their diagonal's section ----
+        // (the dp bytes of row r live in ring slot r & 7, last used by row r - 8.  Nothing clears them: whether a cell holds a match is
+        // a bit of that row's mask, the byte is only read where the bit is set)
+        if (!__any((w_start | w_end) != 0u)) { dq <<= 8; continue; }
+        // ---- END events of row r: matches that started at row r - 6.  The lane's first one has its dp in dq ----
         if (__any(w_end != 0u)) {
             uint32_t ins_a = 0, ins_b = 0;                        // inserted into this lane's own 32 columns / into the next lane's
             uint32_t w = w_end;
-            const int xs = r - K;
-            while (__any(w != 0u)) {
-                const bool on = w != 0u;
-                const int y = col0 + (on ? (int)__builtin_ctz(w) : 0);
-                w &= w - 1u;                                      // (0 stays 0)
-                const uint32_t e = OFF[y - xs + 256];             // x0 << 8 | o
-                if (on && xs >= (int)(e >> 8)) {                  // (x0 > xs: a match of the diagonal's previous section — its END is in the stash)
-                    const uint32_t dp = (uint32_t)r - (e & 0xffu);
-                    uint32_t val;
-                    END_EVENT(y, dp, val)
-                    if (((y + K) >> 5) == l) ins_a = max(ins_a, val); else ins_b = max(ins_b, val);
+            if (w) {
+                const int y = col0 + (int)__builtin_ctz(w);
+                w &= w - 1u;
+                const uint32_t dp = (uint32_t)(dq >> 40) & 0xffu;
+                END_EVENT(y, dp)
+            }
+            if (__any(w != 0u)) {
+                wave_sync();
+                const uint8_t* rrow = ring + (((r - K) & 7) << 8);
+                while (__any(w != 0u)) {
+                    const bool on = w != 0u;
+                    const int y = col0 + (on ? (int)__builtin_ctz(w) : 0);
+                    w &= w - 1u;                                          // (0 stays 0)
+                    const uint32_t dp = on ? (uint32_t)rrow[y] : 0u;
+                    if (on) END_EVENT(y, dp)
                 }
             }
             // pmax = the largest value inserted so far at an end column below 32 (l + 1): an upper bound of every prefix maximum
-            // this lane can ask for
+            // this lane can ask for.  (A bound over the whole task — the first version — made every main-diagonal match after a
+            // chance match far to the RIGHT look up the prefix maximum for the next ~15 rows: 60 % of the kernel's time.)
             uint32_t sc = max(ins_a, dpp0<DPP_ROW_SHR(1)>(ins_b) & ge1);
             sc = max(sc, dpp0<DPP_ROW_SHR(1)>(sc) & ge1);
             sc = max(sc, dpp0<DPP_ROW_SHR(2)>(sc) & ge2);
             sc = max(sc, dpp0<DPP_ROW_SHR(4)>(sc) & ge4);
             pmax = max(pmax, sc);
         }
-        if (__any(drain)) {                                       // stashed END events of this row (rare: a jump beat a continuation)
-            wave_sync();
-            const uint32_t* bk = ST + 8 * (r & 7);
-            const uint32_t cnt = drain ? min(bk[0], (uint32_t)STASH) : 0u;     // (a bucket that overflowed has counted on: the task is declined below)
-            uint32_t val = 0;
-            if ((uint32_t)l < cnt) {
-                const uint32_t e = bk[1 + l];
-                const int y = (int)(e >> 8);
-                END_EVENT(y, e & 0xffu, val)
-            }
-            pmax = max(pmax, group_max(val));                     // (whoever inserted it: every lane's bound takes it)
-            wave_sync();
-            if (drain && l == 0) ST[8 * (r & 7)] = 0;
-        }
         wave_sync();
-        if (ablate == 3) { G = G_INF; continue; }                 // (profiling aid) ... + the END events
+        if (ablate == 3) { dq <<= 8; continue; }                  // (profiling aid) ... + the END events
         // ---- START events of row r ----
-        int Gn = G_INF;
+        uint32_t dv_first = 0;
         if (__any(w_start != 0u)) {
-            // is (r - 1, y - 1) a match?  bit b of the previous row's mask shifted up by one column (bit 31 of the lane below comes in at bit 0)
+            // is (r - 1, y - 1) a match?  bit b of the previous row's mask shifted up by one column (bit 31 of the lane below comes in
+            // at bit 0); is it its lane's FIRST match of that row (then its dp rides in that lane's dq)?  the same with the lowest bits
             const uint32_t left_prev = dpp0<DPP_ROW_SHR(1)>(w_prev) & ge1;
             const uint32_t pshift = __builtin_amdgcn_alignbit(w_prev, left_prev, 31);
-            const uint32_t w_cont = w_start & pshift, w_new = w_start & ~pshift;
-            // continuing matches: could a jump beat one of them?  y - o of a continuing match = its partner's + 1
-            const int Glow = (int)(dpp0<DPP_ROW_SHR(1)>((uint32_t)G) & ge1) | (int)(~ge1 & (uint32_t)G_INF);
-            int Gc = (w_cont & ~1u) ? G + 1 : G_INF;
-            Gc = (w_cont & 1u) ? min(Gc, Glow + 1) : Gc;
-            const int thr = (int)(pmax >> 16) - 2 * r - 5;        // a jump from q beats the continuation iff q.V - 2 r - 5 > y - o
-            const bool chk = w_cont != 0u && pmax != 0u && thr > Gc;
-            uint32_t todo = w_new | (chk ? w_cont : 0u);
-            Gn = chk ? G_INF : Gc;                                // (a lane that looks at its continuing matches gets the exact minimum back)
+            const uint32_t lowp = w_prev & (0u - w_prev);
+            const uint32_t fshift = __builtin_amdgcn_alignbit(lowp, dpp0<DPP_ROW_SHR(1)>(lowp) & ge1, 31);
+            const uint32_t own_dp = (uint32_t)dq & 0xffu;
+            const uint32_t left_dp = dpp0<DPP_ROW_SHR(1)>(own_dp) & ge1;
+            uint32_t w = w_start;
+            const uint8_t* prow = ring + (((r - 1) & 7) << 8);
+            uint8_t* crow = ring + ((r & 7) << 8);
             bool pbm_ready = false;
-            uint32_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0;          // exclusive prefix maxima of the block maxima at this lane's four blocks
-            bool jumped = false;
-            while (__any(todo != 0u)) {
-                const bool on = todo != 0u;
-                const int b = on ? (int)__builtin_ctz(todo) : 0;
-                todo &= todo - 1u;
+            bool first = true;
+            while (__any(w != 0u)) {
+                const bool on = w != 0u;
+                const int b = on ? (int)__builtin_ctz(w) : 0;
+                w &= w - 1u;
                 const int y = col0 + b;
-                const bool is_new = (w_new >> b) & 1u;
-                const int di = y - r + 256;
-                uint32_t eo = 0;
-                if (__any(on && !is_new)) {
-                    eo = OFF[di];
-                    LDS_DONE();
-                }
-                const int o_old = (int)(eo & 0xffu), x0_old = (int)(eo >> 8);
-                int gy = y - o_old;
-                const bool need_q = on && pmax != 0u && (is_new ? ((int)(pmax >> 16) - (r + y) + 1 >= K) : (thr > gy));
+                const bool exists = on && ((pshift >> b) & 1u);
+                int dpc = !exists ? 0 : (((fshift >> b) & 1u) ? (int)(b ? own_dp : left_dp) : -1);
+                if (__any(dpc < 0)) {
+                    wave_sync();
+                    if (dpc < 0) dpc = (int)prow[y - 1];
+                    LDS_DONE();        // the wait belongs INSIDE the rare branch: at the join the compiler would wait on every path — for the
+                }                      // END events' atomics the fast path has just issued (41 % of the kernel's wave cycles were such waits)
+                // could a jump beat the continuation (or reach 6 where there is none)?  upper bound from pmax
+                const int cand_ub = (int)(pmax >> 16) - (r + y) + 1;
+                const bool need_q = on && pmax != 0u && cand_ub > (dpc ? dpc + 1 : K - 1);
                 uint32_t q = 0;
                 if (__any(need_q)) {
                     if (!pbm_ready) {
                         // exclusive prefix maxima of the block maxima (BM cannot change during the START phase)
+                        wave_sync();
                         const uint4 bm = *(const uint4*)(BM + 4 * l);
                         const uint32_t p0 = bm.x, p1 = max(p0, bm.y), p2 = max(p1, bm.z), p3 = max(p2, bm.w);
                         uint32_t inc = p3;
@@ -354,12 +332,13 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
                         inc = max(inc, dpp0<DPP_ROW_SHR(2)>(inc) & ge2);
                         inc = max(inc, dpp0<DPP_ROW_SHR(4)>(inc) & ge4);
                         const uint32_t exc = dpp0<DPP_ROW_SHR(1)>(inc) & ge1;
-                        pb0 = exc; pb1 = max(exc, p0); pb2 = max(exc, p1); pb3 = max(exc, p2);
+                        *(uint4*)(PBM + 4 * l) = make_uint4(exc, max(exc, p0), max(exc, p1), max(exc, p2));
                         pbm_ready = true;
+                        wave_sync();
                     }
                     if (need_q) {
-                        const int blk = y >> 3, kk = y & 7, bi = blk & 3;
-                        q = (bi & 2) ? ((bi & 1) ? pb3 : pb2) : ((bi & 1) ? pb1 : pb0);
+                        const int blk = y >> 3, kk = y & 7;
+                        q = PBM[blk];
                         const uint4 c0 = *(const uint4*)(Cw + 8 * blk), c1 = *(const uint4*)(Cw + 8 * blk + 4);
                         q = max(q, c0.x);
                         q = max(q, kk >= 1 ? c0.y : 0u); q = max(q, kk >= 2 ? c0.z : 0u); q = max(q, kk >= 3 ? c0.w : 0u);
@@ -369,63 +348,37 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
                     LDS_DONE();
                 }
                 if (on) {
-                    const int cand = q ? (int)(q >> 16) - (r + y) + 1 : 0;
-                    bool open = false;
                     int dv = K;
                     uint32_t src = 0xffffu;
-                    if (is_new) {
-                        open = true;
+                    if (q) {
+                        const int cand = (int)(q >> 16) - (r + y) + 1;
                         if (cand >= K) { dv = cand; src = q & 0xffffu; }
-                    } else if (q && (int)(q >> 16) - 2 * r - 5 > gy) {
-                        // a jump beats the continuation: the old section's matches of rows r - 5 .. r - 1 have not ended yet
-                        open = true; dv = cand; src = q & 0xffffu; jumped = true;
-                        for (int xp = max(x0_old, r - (K - 1)); xp <= r - 1; ++xp) {
-                            uint32_t* bk = ST + 8 * ((xp + K) & 7);
-                            const uint32_t pos = atomicAdd(&bk[0], 1u);
-                            if (pos < (uint32_t)STASH) bk[1 + pos] = ((uint32_t)(y - (r - xp)) << 8) | (uint32_t)(xp + K - o_old);
-                            else stash_full = 1u;
-                        }
                     }
-                    if (open) {
-                        const int o_new = r + K - dv;
-                        OFF[di] = (uint16_t)(((uint32_t)r << 8) | (uint32_t)o_new);
-                        gy = y - o_new;
+                    bool cont = false;
+                    if (dpc && dpc + 1 >= dv) { dv = dpc + 1; cont = true; }
+                    crow[y] = (uint8_t)dv;
+                    if (first) dv_first = (uint32_t)dv;
+                    if (!cont) {
                         const uint32_t pos = atomicAdd(&MISC[0], 1u);
                         if (pos < (uint32_t)LOGCAP) LOG[pos] = ((uint32_t)r << 24) | ((uint32_t)y << 16) | src;
                     }
-                    Gn = min(Gn, gy);
                 }
+                first = false;
             }
-            if (__any(jumped)) stash_until = max(stash_until, (int)group_max(jumped ? (uint32_t)(r + K - 1) : 0u));
         }
-        G = w_start ? Gn : G_INF;
+        dq = (dq << 8) | dv_first;
         wave_sync();
     }
 #undef SHR_WORDS
 #undef END_EVENT
 #undef LDS_DONE
-#undef FETCH_CODES
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");            // the log lives in global memory: written by any lane, read by all eight
     wave_sync();
     best = group_max(best);
-    stash_full = group_max(stash_full);
     const uint32_t logn = MISC[0];
     if (!decline && logn > (uint32_t)LOGCAP) decline = 2u;
-    if (!decline && stash_full) decline = 5u;
     const bool seeded = best != 0u && !decline && ablate != 4;     // (ablate 4: profiling aid — the sweep without the chain walk and the band)
-    auto log_at = [&](uint32_t i) -> uint32_t { return __hip_atomic_load(&LOG[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 
     // ---- the chain's sections, last first ----
-    // (the first 32 log entries — all of them for 85 % of the tasks on real sequence — ride in registers, four per lane, loaded once:
-    // a walk over them is one global round trip for the task, not one per section)
-    uint32_t lg0, lg1, lg2, lg3;
-    {
-        const uint32_t nl = seeded ? min(logn, (uint32_t)LOGCAP) : 0u;
-        lg0 = (uint32_t)l < nl ? log_at((uint32_t)l) : 0u;
-        lg1 = (uint32_t)l + 8u < nl ? log_at((uint32_t)l + 8u) : 0u;
-        lg2 = (uint32_t)l + 16u < nl ? log_at((uint32_t)l + 16u) : 0u;
-        lg3 = (uint32_t)l + 24u < nl ? log_at((uint32_t)l + 24u) : 0u;
-    }
     int nsec = 0;
     {
         int cx = (int)((best >> 8) & 0xffu), cy = (int)(best & 0xffu);
@@ -434,22 +387,17 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
             const int d = cy - cx;
             uint32_t pick = 0;                                      // (x' + 1) << 12 | log index, maximum over the diagonal's entries with x' <= x
             if (walking) {
-                auto look = [&](uint32_t e, uint32_t i) {
+                for (uint32_t i = (uint32_t)l; i < logn; i += 8u) {
+                    const uint32_t e = LOG[i];
                     const int ex = (int)(e >> 24), ey = (int)((e >> 16) & 0xffu);
-                    if (i < logn && ey - ex == d && ex <= cx) pick = max(pick, ((uint32_t)(ex + 1) << 12) | i);
-                };
-                look(lg0, (uint32_t)l); look(lg1, (uint32_t)l + 8u); look(lg2, (uint32_t)l + 16u); look(lg3, (uint32_t)l + 24u);
-                for (uint32_t i = (uint32_t)l + 32u; i < logn; i += 8u) look(log_at(i), i);
+                    if (ey - ex == d && ex <= cx) pick = max(pick, ((uint32_t)(ex + 1) << 12) | i);
+                }
             }
             pick = group_max(pick);
-            // the picked entry: from its owner's registers (index < 32) or from memory
-            const uint32_t pidx = pick & 0xfffu;
-            const uint32_t psel = (pidx & 16u) ? ((pidx & 8u) ? lg3 : lg2) : ((pidx & 8u) ? lg1 : lg0);
-            const uint32_t preg = (uint32_t)__shfl((int)psel, (lane & ~7) | (int)(pidx & 7u));
             if (walking) {
                 if (pick == 0u || nsec >= SECCAP) { decline = pick == 0u ? 4u : 3u; walking = false; }
                 else {
-                    const uint32_t e = pidx < 32u ? preg : log_at(pidx);
+                    const uint32_t e = LOG[pick & 0xfffu];
                     const int ex = (int)(e >> 24), ey = (int)((e >> 16) & 0xffu);
                     if (l == 0) SEC[nsec] = ((uint32_t)ex << 16) | ((uint32_t)ey << 8) | (uint32_t)(cx - ex + 1);
                     ++nsec;
@@ -461,9 +409,9 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
         }
     }
     wave_sync();
-    // ---- anchors -> first / last anchor row per column (the section store and C are dead: rmin / rmax take their place) ----
-    uint32_t* rmin = T + O_OFF;
-    uint32_t* rmax = T + O_C;
+    // ---- anchors -> first / last anchor row per column (the ring is dead: rmin / rmax take its place) ----
+    uint32_t* rmin = T + L::O_RING;
+    uint32_t* rmax = rmin + 256;
     {
         uint4* a = (uint4*)(rmin + col0);
         uint4* b4 = (uint4*)(rmax + col0);
@@ -520,7 +468,7 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
         uint32_t* o = dbg + (size_t)slot * 64;
         o[0] = best; o[1] = logn; o[2] = (uint32_t)nsec; o[3] = (uint32_t)cA; o[4] = (uint32_t)cB; o[5] = decline; o[6] = (uint32_t)m; o[7] = (uint32_t)n;
         for (int i = 0; i < 12; ++i) o[8 + i] = SEC[i];
-        for (int i = 0; i < 24; ++i) o[20 + i] = (uint32_t)i < logn && i < LOGCAP ? log_at((uint32_t)i) : 0u;
+        for (int i = 0; i < 24; ++i) o[20 + i] = (uint32_t)i < logn ? LOG[i] : 0u;
         for (int i = 0; i < 10; ++i) { o[44 + i] = rmin[i]; o[54 + i] = rmax[i]; }
     }
     // ---- slots and ranges ----
@@ -555,27 +503,31 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
         overflow_list[obase + (uint32_t)__popcll(dm & below)] = task;
         if (stat_counters) atomicAdd(&stat_counters[min(decline, 7u)], 1u);
     }
-    }   // task groups
 }
 
-extern "C" uint32_t vtxk_band_sweep_grid(uint32_t n_tasks) { return (uint32_t)std::min<uint64_t>(((uint64_t)n_tasks + 7) / 8, (uint64_t)GRID_MAX); }
-// the log slices of the largest grid (one buffer for the life of the context)
-extern "C" size_t vtxk_band_sweep_log_bytes(void) { return (size_t)GRID_MAX * 8 * LOGCAP * sizeof(uint32_t); }
-
-extern "C" hipError_t vtxk_launch_band_sweep(const uint32_t* tasks, uint32_t n_tasks, const uint32_t* n_dev,
+// tier 0: 256 sections per task (first pass: 4.8 KB of LDS per task, still four wavefronts per CU); tier 1: 1024 (second pass over
+// the first's log overflows: 7.9 KB per task, two wavefronts per CU)
+extern "C" hipError_t vtxk_launch_band_sweep_v1(int tier, const uint32_t* tasks, uint32_t n_tasks, const uint32_t* n_dev,
                                              const vtx_record* records,
                                              const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
                                              const uint8_t* hap_arena, uint16_t* band, uint32_t band_stride, uint32_t* hard_list,
                                              uint32_t* overflow_list, uint32_t* counters, uint32_t* stat_counters, uint8_t* stage,
-                                             uint32_t* dbg, uint32_t* glog, hipStream_t s) {
+                                             uint32_t* dbg, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
     static const uint32_t ablate = VTX_DEV_ENV("VTX_SWEEP_ABLATE") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_SWEEP_ABLATE")) << 8 : 0u;
-    const size_t shmem = (size_t)8 * TASK_W * sizeof(uint32_t);
-    hipLaunchKernelGGL(band_sweep_kernel, dim3(vtxk_band_sweep_grid(n_tasks)), dim3(64), shmem, s, tasks, n_tasks, n_dev, records,
-                       rec_locus, loci, read_arena, hap_arena, band, band_stride, hard_list, overflow_list, counters,
-                       ablate, stat_counters, stage, dbg, glog);
+#define LAUNCH_SWEEP(CAP)                                                                                          \
+    {                                                                                                              \
+        const size_t shmem = (size_t)8 * Lay<CAP>::TASK_W * sizeof(uint32_t);                                      \
+        if (shmem > 48 * 1024) {                                                                                   \
+            hipError_t e = hipFuncSetAttribute((const void*)band_sweep_v1_kernel<CAP>,                               \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);           \
+            if (e != hipSuccess) return e;                                                                         \
+        }                                                                                                          \
+        hipLaunchKernelGGL(band_sweep_v1_kernel<CAP>, dim3((n_tasks + 7) / 8), dim3(64), shmem, s, tasks, n_tasks, n_dev, records, \
+                           rec_locus, loci, read_arena, hap_arena, band, band_stride, hard_list, overflow_list, counters,      \
+                           ablate, stat_counters, stage, dbg);                                                     \
+    }
+    if (tier == 0) LAUNCH_SWEEP(256) else LAUNCH_SWEEP(1024)
+#undef LAUNCH_SWEEP
     return hipGetLastError();
 }
-// what the kernel holds: reads and haplotypes up to this many bases (longer ones are declined task by task; a batch whose
-// haplotypes are all longer should not be sent here at all)
-extern "C" uint32_t vtxk_band_sweep_max_len(void) { return (uint32_t)MAXLEN; }
