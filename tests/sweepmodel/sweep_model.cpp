@@ -185,8 +185,15 @@ int vtxs_band(const uint8_t* x, int m, const uint8_t* y, int n, int log_cap, int
 // reads dp = xs + 6 - o from its diagonal's entry.  The one case the latest section does not cover: a jump beats the continuation
 // at row r while matches of rows r - 5 .. r - 1 of the OLD section have not ended yet.  Their (end row, column, dp) go to a
 // stash — eight buckets by end row, STASH entries each — and enter the tree when their row comes; the END loop skips a match
-// whose row lies before its diagonal's x0.  status 5: a stash bucket is full (the general kernel takes the task).
+// whose row lies before its diagonal's x0.  status 5: a stash bucket is full (the general kernel takes the task); status 2: one of
+// the eight lanes (32 columns each) opened more than log_cap / 8 sections.
 // stats: [0] log entries, [1] sections, [2] matches, [3] jump-beats-continuation events, [4] fullest stash bucket.
+// vtxs_band2_lanes (same algorithm, 12 stats): additionally what the kernel's EIGHT LANES would do row by row — [5] START trips (sum
+// over rows of the largest per-lane count of matches the lane has to look at: new sections + the continuing matches of a lane whose
+// bound pmax.V - 2x - 5 > G fails), [6] END trips (largest per-lane count of ending matches), [7] prefix-maximum queries, [8] rows
+// with any START trip, [9] continuing matches looked at, [10] of those: in a lane with NO new section (pure filter failures).
+static int g_lane_stats = 0;
+static int g_row_start[272], g_row_end[272];             // per row: the trips of the last vtxs_band2_lanes call (START, END)
 int vtxs_band2(const uint8_t* x, int m, const uint8_t* y, int n, int log_cap, int sec_cap, int stash_cap, int32_t* lo, int32_t* hi,
                int32_t* stats) {
     if (stats) stats[0] = stats[1] = stats[2] = stats[3] = stats[4] = 0;
@@ -213,6 +220,11 @@ int vtxs_band2(const uint8_t* x, int m, const uint8_t* y, int n, int log_cap, in
         return 0;
     }
     auto bit = [&](int r, int yy) { return r >= 0 && r < rows_m && yy >= 0 && yy < n && ((m6[r].w[yy >> 5] >> (yy & 31)) & 1u); };
+    const bool lane_stats = g_lane_stats && stats;
+    if (lane_stats) for (int i = 5; i < 12; ++i) stats[i] = 0;
+    uint32_t pmax_l[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // largest V inserted at an end column below 32 (l + 1)
+    int G_l[8];
+    for (int l = 0; l < 8; ++l) G_l[l] = 0x3fffffff;
     struct Ent { uint8_t o, x0; };
     Ent off[512];
     memset(off, 0, sizeof off);
@@ -221,15 +233,23 @@ int vtxs_band2(const uint8_t* x, int m, const uint8_t* y, int n, int log_cap, in
     struct St { int y, dp; };
     std::vector<St> stash[8];
     std::vector<uint32_t> log;
+    int lane_log[8] = {0, 0, 0, 0, 0, 0, 0, 0};           // the kernel's lane l logs the sections that open in columns 32 l .. 32 l + 31: log_cap / 8 each
     uint32_t best = 0;
     auto end_event = [&](int xs, int yy, uint32_t dp) {
         const uint32_t V = dp + (uint32_t)(xs + K) + (uint32_t)(yy + K);
         const uint32_t val = (V << 16) | ((uint32_t)xs << 8) | (uint32_t)yy;
         for (int i = yy + K + 1; i <= 256; i += i & (-i)) tree[i] = std::max(tree[i], val);
         best = std::max(best, (dp << 16) | ((uint32_t)xs << 8) | (uint32_t)yy);
+        for (int l = std::min((yy + K) >> 5, 7); l < 8; ++l) pmax_l[l] = std::max(pmax_l[l], val);
     };
     for (int r = 0; r <= m; ++r) {
         const int xs = r - K;
+        if (lane_stats && xs >= 0 && xs < rows_m) {
+            int mx = 0;
+            for (int l = 0; l < 8; ++l) mx = std::max(mx, __builtin_popcount(m6[xs].w[l]));
+            stats[6] += mx;
+            g_row_end[r] = mx;
+        }
         if (xs >= 0 && xs < rows_m) {
             for (int yy = 0; yy < n; ++yy) {
                 if (!bit(xs, yy)) continue;
@@ -240,6 +260,43 @@ int vtxs_band2(const uint8_t* x, int m, const uint8_t* y, int n, int log_cap, in
         }
         for (const St& t : stash[r & 7]) end_event(xs, t.y, (uint32_t)t.dp);
         stash[r & 7].clear();
+        if (lane_stats && r < rows_m) {
+            // what the eight lanes do (vtx_sweep.hip): per lane the new sections, plus ALL its continuing matches when the lane-level
+            // bound fails; G = the bound carried from the previous row
+            int trips = 0, Gn[8];
+            for (int l = 0; l < 8; ++l) {
+                int Gc = 0x3fffffff, n_new = 0, n_cont = 0, gmin_all = 0x3fffffff, nq = 0;
+                const int thr = (int)(pmax_l[l] >> 16) - 2 * r - 5;
+                for (int b = 0; b < 32; ++b) {
+                    const int yy = 32 * l + b;
+                    if (!bit(r, yy)) continue;
+                    if (bit(r - 1, yy - 1)) {
+                        ++n_cont;
+                        Gc = std::min(Gc, (b ? G_l[l] : (l ? G_l[l - 1] : 0x3fffffff)) + 1);
+                    } else ++n_new;
+                }
+                const bool chk = n_cont && pmax_l[l] && thr > Gc;
+                for (int b = 0; b < 32; ++b) {
+                    const int yy = 32 * l + b;
+                    if (!bit(r, yy)) continue;
+                    if (bit(r - 1, yy - 1)) {
+                        const int gy = yy - (int)off[yy - r + 256].o;
+                        if (chk && thr > gy) ++nq;
+                        gmin_all = std::min(gmin_all, gy);       // (a jump that wins raises it: ignored here, the bound only gets looser)
+                    } else if (pmax_l[l] && (int)(pmax_l[l] >> 16) - (r + yy) + 1 >= K) ++nq;
+                }
+                const int todo = n_new + (chk ? n_cont : 0);
+                trips = std::max(trips, todo);
+                stats[7] += nq;
+                if (chk) { stats[9] += n_cont; if (!n_new) stats[10] += n_cont; }
+                Gn[l] = chk ? gmin_all : Gc;                      // new sections' own values join below (after their dv is known): approximated by the continuing ones
+                if (!(n_new + n_cont)) Gn[l] = 0x3fffffff;
+            }
+            for (int l = 0; l < 8; ++l) G_l[l] = Gn[l];
+            stats[5] += trips;
+            g_row_start[r] = trips;
+            if (trips) ++stats[8];
+        }
         if (r < rows_m) {
             for (int yy = 0; yy < n; ++yy) {
                 if (!bit(r, yy)) continue;
@@ -252,7 +309,8 @@ int vtxs_band2(const uint8_t* x, int m, const uint8_t* y, int n, int log_cap, in
                     uint32_t src = 0xffffu;
                     if (q && cand >= K) { dv = cand; src = q & 0xffffu; }
                     off[d] = Ent{(uint8_t)(r + K - dv), (uint8_t)r};
-                    if ((int)log.size() >= log_cap) return 2;
+                    if (lane_stats) G_l[yy >> 5] = std::min(G_l[yy >> 5], yy - (r + K - dv));
+                    if (++lane_log[yy >> 5] > log_cap / 8) return 2;
                     log.push_back(((uint32_t)r << 24) | ((uint32_t)yy << 16) | src);
                 } else {
                     const Ent e = off[d];
@@ -266,7 +324,7 @@ int vtxs_band2(const uint8_t* x, int m, const uint8_t* y, int n, int log_cap, in
                             if (stats) stats[4] = std::max(stats[4], (int32_t)b.size());
                         }
                         off[d] = Ent{(uint8_t)(r + K - cand), (uint8_t)r};
-                        if ((int)log.size() >= log_cap) return 2;
+                        if (++lane_log[yy >> 5] > log_cap / 8) return 2;
                         log.push_back(((uint32_t)r << 24) | ((uint32_t)yy << 16) | (q & 0xffffu));
                     }
                 }
@@ -326,5 +384,16 @@ int vtxs_band2(const uint8_t* x, int m, const uint8_t* y, int n, int log_cap, in
     }
     return 0;
 }
+
+int vtxs_band2_lanes(const uint8_t* x, int m, const uint8_t* y, int n, int log_cap, int sec_cap, int stash_cap, int32_t* lo, int32_t* hi,
+                      int32_t* stats12) {
+    g_lane_stats = 1;
+    memset(g_row_start, 0, sizeof g_row_start); memset(g_row_end, 0, sizeof g_row_end);
+    const int rc = vtxs_band2(x, m, y, n, log_cap, sec_cap, stash_cap, lo, hi, stats12);
+    g_lane_stats = 0;
+    return rc;
+}
+
+void vtxs_last_rows(int32_t* start272, int32_t* end272) { memcpy(start272, g_row_start, sizeof g_row_start); memcpy(end272, g_row_end, sizeof g_row_end); }
 
 }  // extern "C"

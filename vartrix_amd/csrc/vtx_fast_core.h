@@ -85,7 +85,10 @@ static_assert(K == 6 && W == 20 && VTX_REF_MATCH == 1 && VTX_REF_MISMATCH == -5 
 constexpr int LAZY = VTX_BAND_LAZY_EXT(6);
 constexpr int MAX_READ = 192;   // mask capacity
 constexpr int RM = 8;           // main-diagonal pieces
-constexpr int S_WORDS = 20;     // LDS words per lane for the off-diagonal k-mer matches: 40 two-byte entries (haplotypes <= 255 bases) or 20 four-byte ones
+#ifndef VTXF_S_WORDS
+#define VTXF_S_WORDS 20
+#endif
+constexpr int S_WORDS = VTXF_S_WORDS;     // LDS words per lane for the off-diagonal k-mer matches: 40 two-byte entries (haplotypes <= 255 bases) or 20 four-byte ones
 constexpr int GM = 6;           // off-diagonal pieces admitted to the generic set
 constexpr int LANE_WORDS = S_WORDS + RM;   // per-lane scratch: off-diagonal matches, main pieces (+ GM words for back(): generic off-diagonal pieces)
 constexpr int DMAX = 120;       // diagonal offsets of generic pieces are stored in a signed byte

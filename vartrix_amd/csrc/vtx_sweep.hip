@@ -56,16 +56,20 @@ static_assert(K == 6 && W == 20 && VTX_REF_MATCH == 1 && VTX_REF_GAP_OPEN == -5 
               "band_sweep_kernel's sdpkpp is written for k = 6, match 1, gap -5 / -1 (src/main.rs:33-38, :899)");
 constexpr int SECCAP = 28;           // sections of the best chain (a 150-base read chains at most 25 six-mers end to end)
 constexpr int MAXLEN = 255;          // read / haplotype bases (one byte per coordinate in the packed words)
-constexpr int LOGCAP = 1024;         // sections a task may open (global memory; real sequence: p99 55, satellites: hundreds)
+constexpr int LOGCAP = 1024;         // sections a task may open (global memory), 128 per lane: lane l logs the sections that open in its
+                                     // columns at entries l, l + 8, l + 16, ... with a counter of its own — no atomic, no wait (real
+                                     // sequence: p99 55 per task; satellites: hundreds)
 constexpr int STASH = 7;             // entries per stash bucket
-constexpr int GRID_MAX = 2048;       // resident workgroups: 256 CUs x 8
+constexpr int GRID_MAX = 1536;       // workgroups of the persistent grid: 256 CUs x 6.  Eight fit a CU's LDS (tools/residency_census.hip), but the
+                                     // kernel saturates before: 100 k real-sequence loci take 998 / 525 / 284 / 195 / 208 ms with 256 / 512 / 1 024 /
+                                     // 1 536 / 2 048 workgroups (profiles/r05_sweep_grid.txt) — and 6 x 19.1 KB leave LDS for other kernels' workgroups
 constexpr int G_INF = 0x3fffffff;
 // per-task LDS (32-bit words)
 constexpr int O_OFF = 0;             // 512 diagonals x 16 bits: x0 << 8 | o; after the sweep: rmin[256]
 constexpr int O_C = 256;             // C[ye], 256 words; after the sweep: rmax[256]
 constexpr int O_BM = 512;            // block maxima of C, 8 columns each (32 words); after the sweep: the chain's sections
 constexpr int O_STASH = 544;         // 8 buckets x (count, 7 entries: y << 8 | dp)
-constexpr int O_MISC = 608;          // [0] log entries
+constexpr int O_MISC = 608;          // (spare)
 constexpr int TASK_W = 612;          // = 4 (mod 32): the eight tasks of a wavefront start in eight different banks; 16-byte aligned
 static_assert(TASK_W % 32 == 4 && TASK_W % 4 == 0 && O_MISC + 4 <= TASK_W && SECCAP <= 32, "LDS layout");
 
@@ -127,7 +131,6 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
     uint32_t* Cw = T + O_C;
     uint32_t* BM = T + O_BM;
     uint32_t* ST = T + O_STASH;
-    uint32_t* MISC = T + O_MISC;
     uint32_t* SEC = T + O_BM;
     uint32_t* LOG = glog + ((size_t)blockIdx.x * 8u + (uint32_t)g) * (size_t)LOGCAP;
     const int col0 = 32 * l;
@@ -162,7 +165,6 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
         for (int i = 0; i < 8; ++i) c4[i] = z;
         *(uint4*)(BM + 4 * l) = z;
         ST[8 * l] = 0;
-        if (l == 0) MISC[0] = 0;
     }
     uint32_t bad = 0;
     uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0;                  // codes of read rows 32 l .. 32 l + 31, a nibble each (7: no base)
@@ -228,6 +230,9 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
     int G = G_INF;                                                // lower bound of y - o over this lane's matches of the previous row
     int stash_until = -1;                                         // the task's stash may hold entries for END rows <= this
     uint32_t stash_full = 0;
+    uint32_t nlog = 0;                                            // sections this lane has logged: entry k at LOG[8 k + l]
+    uint32_t lg0 = 0, lg1 = 0, lg2 = 0, lg3 = 0;                  // ... the first four stay in registers as well (the chain walk reads them there)
+    uint32_t pre_e = 0xff00u;                                     // OFF entry of this lane's first END event of the NEXT row, requested a row ahead
     // the codes of eight rows per word, fetched from the lane that holds them (word j = rows 8 j .. 8 j + 7: register j & 3 of lane
     // j >> 2; selected by VALUE with the uniform j — a select between the variables themselves sends them through scratch memory)
 #define FETCH_CODES(dst, jexpr)                                                                                  \
@@ -268,17 +273,24 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
         if (r < 0) continue;                                      // (uniform)
         if (ablate == 2) { best |= w_start | w_end; continue; }   // (profiling aid) the match pipeline only
         const bool drain = r <= stash_until;
-        if (!__any((w_start | w_end) != 0u || drain)) { G = G_INF; continue; }
+        // the OFF entry of this lane's first END event of the NEXT row (h6 = M6(r - 5) after the shift above), requested a row ahead
+#define PREFETCH_END() pre_e = OFF[col0 + (h6 ? (int)__builtin_ctz(h6) : 0) - (r + 1 - K) + 256]
+        if (!__any((w_start | w_end) != 0u || drain)) { G = G_INF; PREFETCH_END(); continue; }
         // ---- END events of row r: matches that started at row xs = r - 6; dp = xs + 6 - o of their diagonal's section ----
         if (__any(w_end != 0u)) {
             uint32_t ins_a = 0, ins_b = 0;                        // inserted into this lane's own 32 columns / into the next lane's
             uint32_t w = w_end;
             const int xs = r - K;
+            bool first = true;
             while (__any(w != 0u)) {
                 const bool on = w != 0u;
                 const int y = col0 + (on ? (int)__builtin_ctz(w) : 0);
                 w &= w - 1u;                                      // (0 stays 0)
-                const uint32_t e = OFF[y - xs + 256];             // x0 << 8 | o
+                // x0 << 8 | o of the match's diagonal.  The lane's first match: requested at the end of the previous row (an entry
+                // rewritten since — a jump beat the continuation in that row's START phase — carries x0 = r - 1 > xs: the old entry
+                // then inserts what the stash inserts again, the same value twice)
+                const uint32_t e = first ? pre_e : (uint32_t)OFF[y - xs + 256];
+                first = false;
                 if (on && xs >= (int)(e >> 8)) {                  // (x0 > xs: a match of the diagonal's previous section — its END is in the stash)
                     const uint32_t dp = (uint32_t)r - (e & 0xffu);
                     uint32_t val;
@@ -309,7 +321,7 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
             if (drain && l == 0) ST[8 * (r & 7)] = 0;
         }
         wave_sync();
-        if (ablate == 3) { G = G_INF; continue; }                 // (profiling aid) ... + the END events
+        if (ablate == 3) { G = G_INF; PREFETCH_END(); continue; } // (profiling aid) ... + the END events
         // ---- START events of row r ----
         int Gn = G_INF;
         if (__any(w_start != 0u)) {
@@ -325,9 +337,12 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
             const bool chk = w_cont != 0u && pmax != 0u && thr > Gc;
             uint32_t todo = w_new | (chk ? w_cont : 0u);
             Gn = chk ? G_INF : Gc;                                // (a lane that looks at its continuing matches gets the exact minimum back)
+            // the exclusive prefix maxima of the block maxima at this lane's four blocks (BM cannot change during the START phase):
+            // once per row, requested together with the first trip's reads
             bool pbm_ready = false;
-            uint32_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0;          // exclusive prefix maxima of the block maxima at this lane's four blocks
+            uint32_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0;
             bool jumped = false;
+            const bool qrow = __any(todo != 0u && pmax != 0u);        // somebody may have to ask for a prefix maximum in this row
             while (__any(todo != 0u)) {
                 const bool on = todo != 0u;
                 const int b = on ? (int)__builtin_ctz(todo) : 0;
@@ -335,38 +350,35 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
                 const int y = col0 + b;
                 const bool is_new = (w_new >> b) & 1u;
                 const int di = y - r + 256;
-                uint32_t eo = 0;
-                if (__any(on && !is_new)) {
-                    eo = OFF[di];
-                    LDS_DONE();
+                // ONE round trip to the LDS per trip: the diagonal's entry, the match's block of C, (first trip) the block maxima
+                const uint32_t eo = OFF[di];
+                const int blk = y >> 3, kk = y & 7, bi = blk & 3;
+                uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, bm = c0;
+                if (qrow) {
+                    c0 = *(const uint4*)(Cw + 8 * blk); c1 = *(const uint4*)(Cw + 8 * blk + 4);
+                    if (!pbm_ready) bm = *(const uint4*)(BM + 4 * l);
+                }
+                LDS_DONE();
+                if (qrow && !pbm_ready) {
+                    const uint32_t p0 = bm.x, p1 = max(p0, bm.y), p2 = max(p1, bm.z), p3 = max(p2, bm.w);
+                    uint32_t inc = p3;
+                    inc = max(inc, dpp0<DPP_ROW_SHR(1)>(inc) & ge1);
+                    inc = max(inc, dpp0<DPP_ROW_SHR(2)>(inc) & ge2);
+                    inc = max(inc, dpp0<DPP_ROW_SHR(4)>(inc) & ge4);
+                    const uint32_t exc = dpp0<DPP_ROW_SHR(1)>(inc) & ge1;
+                    pb0 = exc; pb1 = max(exc, p0); pb2 = max(exc, p1); pb3 = max(exc, p2);
+                    pbm_ready = true;
                 }
                 const int o_old = (int)(eo & 0xffu), x0_old = (int)(eo >> 8);
                 int gy = y - o_old;
                 const bool need_q = on && pmax != 0u && (is_new ? ((int)(pmax >> 16) - (r + y) + 1 >= K) : (thr > gy));
                 uint32_t q = 0;
-                if (__any(need_q)) {
-                    if (!pbm_ready) {
-                        // exclusive prefix maxima of the block maxima (BM cannot change during the START phase)
-                        const uint4 bm = *(const uint4*)(BM + 4 * l);
-                        const uint32_t p0 = bm.x, p1 = max(p0, bm.y), p2 = max(p1, bm.z), p3 = max(p2, bm.w);
-                        uint32_t inc = p3;
-                        inc = max(inc, dpp0<DPP_ROW_SHR(1)>(inc) & ge1);
-                        inc = max(inc, dpp0<DPP_ROW_SHR(2)>(inc) & ge2);
-                        inc = max(inc, dpp0<DPP_ROW_SHR(4)>(inc) & ge4);
-                        const uint32_t exc = dpp0<DPP_ROW_SHR(1)>(inc) & ge1;
-                        pb0 = exc; pb1 = max(exc, p0); pb2 = max(exc, p1); pb3 = max(exc, p2);
-                        pbm_ready = true;
-                    }
-                    if (need_q) {
-                        const int blk = y >> 3, kk = y & 7, bi = blk & 3;
-                        q = (bi & 2) ? ((bi & 1) ? pb3 : pb2) : ((bi & 1) ? pb1 : pb0);
-                        const uint4 c0 = *(const uint4*)(Cw + 8 * blk), c1 = *(const uint4*)(Cw + 8 * blk + 4);
-                        q = max(q, c0.x);
-                        q = max(q, kk >= 1 ? c0.y : 0u); q = max(q, kk >= 2 ? c0.z : 0u); q = max(q, kk >= 3 ? c0.w : 0u);
-                        q = max(q, kk >= 4 ? c1.x : 0u); q = max(q, kk >= 5 ? c1.y : 0u); q = max(q, kk >= 6 ? c1.z : 0u);
-                        q = max(q, kk >= 7 ? c1.w : 0u);
-                    }
-                    LDS_DONE();
+                if (need_q) {
+                    q = (bi & 2) ? ((bi & 1) ? pb3 : pb2) : ((bi & 1) ? pb1 : pb0);
+                    q = max(q, c0.x);
+                    q = max(q, kk >= 1 ? c0.y : 0u); q = max(q, kk >= 2 ? c0.z : 0u); q = max(q, kk >= 3 ? c0.w : 0u);
+                    q = max(q, kk >= 4 ? c1.x : 0u); q = max(q, kk >= 5 ? c1.y : 0u); q = max(q, kk >= 6 ? c1.z : 0u);
+                    q = max(q, kk >= 7 ? c1.w : 0u);
                 }
                 if (on) {
                     const int cand = q ? (int)(q >> 16) - (r + y) + 1 : 0;
@@ -390,8 +402,10 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
                         const int o_new = r + K - dv;
                         OFF[di] = (uint16_t)(((uint32_t)r << 8) | (uint32_t)o_new);
                         gy = y - o_new;
-                        const uint32_t pos = atomicAdd(&MISC[0], 1u);
-                        if (pos < (uint32_t)LOGCAP) LOG[pos] = ((uint32_t)r << 24) | ((uint32_t)y << 16) | src;
+                        const uint32_t ent = ((uint32_t)r << 24) | ((uint32_t)y << 16) | src;
+                        if (nlog < (uint32_t)(LOGCAP / 8)) LOG[8u * nlog + (uint32_t)l] = ent;
+                        lg0 = nlog == 0u ? ent : lg0; lg1 = nlog == 1u ? ent : lg1; lg2 = nlog == 2u ? ent : lg2; lg3 = nlog == 3u ? ent : lg3;
+                        ++nlog;
                     }
                     Gn = min(Gn, gy);
                 }
@@ -399,33 +413,27 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
             if (__any(jumped)) stash_until = max(stash_until, (int)group_max(jumped ? (uint32_t)(r + K - 1) : 0u));
         }
         G = w_start ? Gn : G_INF;
+        PREFETCH_END();                                          // (the wait is the barrier's)
         wave_sync();
     }
 #undef SHR_WORDS
 #undef END_EVENT
 #undef LDS_DONE
 #undef FETCH_CODES
+#undef PREFETCH_END
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");            // the log lives in global memory: written by any lane, read by all eight
     wave_sync();
     best = group_max(best);
     stash_full = group_max(stash_full);
-    const uint32_t logn = MISC[0];
-    if (!decline && logn > (uint32_t)LOGCAP) decline = 2u;
+    const uint32_t nlog_max = group_max(nlog);
+    if (!decline && nlog_max > (uint32_t)(LOGCAP / 8)) decline = 2u;
     if (!decline && stash_full) decline = 5u;
     const bool seeded = best != 0u && !decline && ablate != 4;     // (ablate 4: profiling aid — the sweep without the chain walk and the band)
     auto log_at = [&](uint32_t i) -> uint32_t { return __hip_atomic_load(&LOG[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 
     // ---- the chain's sections, last first ----
-    // (the first 32 log entries — all of them for 85 % of the tasks on real sequence — ride in registers, four per lane, loaded once:
-    // a walk over them is one global round trip for the task, not one per section)
-    uint32_t lg0, lg1, lg2, lg3;
-    {
-        const uint32_t nl = seeded ? min(logn, (uint32_t)LOGCAP) : 0u;
-        lg0 = (uint32_t)l < nl ? log_at((uint32_t)l) : 0u;
-        lg1 = (uint32_t)l + 8u < nl ? log_at((uint32_t)l + 8u) : 0u;
-        lg2 = (uint32_t)l + 16u < nl ? log_at((uint32_t)l + 16u) : 0u;
-        lg3 = (uint32_t)l + 24u < nl ? log_at((uint32_t)l + 24u) : 0u;
-    }
+    // (log entry i = 8 k + l is lane l's k-th; every lane scans its own — the first four from its registers: a walk over a task
+    // whose lanes logged four sections or fewer each touches no memory at all)
     int nsec = 0;
     {
         int cx = (int)((best >> 8) & 0xffu), cy = (int)(best & 0xffu);
@@ -434,12 +442,12 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
             const int d = cy - cx;
             uint32_t pick = 0;                                      // (x' + 1) << 12 | log index, maximum over the diagonal's entries with x' <= x
             if (walking) {
-                auto look = [&](uint32_t e, uint32_t i) {
+                auto look = [&](uint32_t e, uint32_t k) {
                     const int ex = (int)(e >> 24), ey = (int)((e >> 16) & 0xffu);
-                    if (i < logn && ey - ex == d && ex <= cx) pick = max(pick, ((uint32_t)(ex + 1) << 12) | i);
+                    if (k < nlog && ey - ex == d && ex <= cx) pick = max(pick, ((uint32_t)(ex + 1) << 12) | (8u * k + (uint32_t)l));
                 };
-                look(lg0, (uint32_t)l); look(lg1, (uint32_t)l + 8u); look(lg2, (uint32_t)l + 16u); look(lg3, (uint32_t)l + 24u);
-                for (uint32_t i = (uint32_t)l + 32u; i < logn; i += 8u) look(log_at(i), i);
+                look(lg0, 0u); look(lg1, 1u); look(lg2, 2u); look(lg3, 3u);
+                for (uint32_t k = 4u; k < nlog; ++k) look(log_at(8u * k + (uint32_t)l), k);
             }
             pick = group_max(pick);
             // the picked entry: from its owner's registers (index < 32) or from memory
@@ -518,9 +526,9 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
     wave_sync();
     if (dbg && have && l == 0) {                                   // (vtx_debug_bands with VTX_SWEEP_DBG=1: what the task's lanes agreed on)
         uint32_t* o = dbg + (size_t)slot * 64;
-        o[0] = best; o[1] = logn; o[2] = (uint32_t)nsec; o[3] = (uint32_t)cA; o[4] = (uint32_t)cB; o[5] = decline; o[6] = (uint32_t)m; o[7] = (uint32_t)n;
+        o[0] = best; o[1] = nlog_max; o[2] = (uint32_t)nsec; o[3] = (uint32_t)cA; o[4] = (uint32_t)cB; o[5] = decline; o[6] = (uint32_t)m; o[7] = (uint32_t)n;
         for (int i = 0; i < 12; ++i) o[8 + i] = SEC[i];
-        for (int i = 0; i < 24; ++i) o[20 + i] = (uint32_t)i < logn && i < LOGCAP ? log_at((uint32_t)i) : 0u;
+        for (int i = 0; i < 24; ++i) o[20 + i] = log_at((uint32_t)i);       // (entry 8 k + lane: slots a lane did not write hold an earlier task's)
         for (int i = 0; i < 10; ++i) { o[44 + i] = rmin[i]; o[54 + i] = rmax[i]; }
     }
     // ---- slots and ranges ----
@@ -558,7 +566,10 @@ __global__ __launch_bounds__(64) void band_sweep_kernel(
     }   // task groups
 }
 
-extern "C" uint32_t vtxk_band_sweep_grid(uint32_t n_tasks) { return (uint32_t)std::min<uint64_t>(((uint64_t)n_tasks + 7) / 8, (uint64_t)GRID_MAX); }
+extern "C" uint32_t vtxk_band_sweep_grid(uint32_t n_tasks) {
+    static const uint32_t cap = VTX_DEV_ENV("VTX_SWEEP_GRID") ? (uint32_t)std::min(std::max(atoi(VTX_DEV_ENV("VTX_SWEEP_GRID")), 1), GRID_MAX) : (uint32_t)GRID_MAX;   // experiment knob (libvtx_dev.so)
+    return (uint32_t)std::min<uint64_t>(((uint64_t)n_tasks + 7) / 8, (uint64_t)cap);
+}
 // the log slices of the largest grid (one buffer for the life of the context)
 extern "C" size_t vtxk_band_sweep_log_bytes(void) { return (size_t)GRID_MAX * 8 * LOGCAP * sizeof(uint32_t); }
 
