@@ -93,7 +93,7 @@ def test_production_library_has_no_experiment_hooks(L):
     assert b"VTX_DEBUG" in open(os.path.join(here, "libvtx.so"), "rb").read()
     assert present(os.path.join(here, "libvtx_dev.so")) == hooks
     # the variants of the band-semantics tests are production builds with one constant changed: no hooks either
-    for v in ("lazy0",):
+    for v in ("lazy0", "anchor5", "noseed0"):
         assert present(lib.lib_path(v)) == set(), v
     # the developer library exports the same C-ABI
     D = lib.load("dev")

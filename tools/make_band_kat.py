@@ -12,6 +12,7 @@ chains over several diagonals, reads hanging over the window, repeats — plus a
 
     python tools/make_band_kat.py            # rewrites tests/golden/band_kat.json
 """
+import ctypes as C
 import json
 import os
 import sys
@@ -51,6 +52,49 @@ def pairs(batch, limit):
                         return
 
 
+# The four recollected details and the alternative each is switched to (oracle/vtx_oracle.c: vtxo_set_variant).  A vector
+# DISCRIMINATES a detail when the oracle run with that alternative gives another banded score ("score") or another band ("band"):
+# a maintainer replaying the file against the crate who sees exactly the vectors tagged with one detail fail knows which
+# constant of include/vtx_band_semantics.h to change, and to what.
+EDGE = 0x7fffffff
+ALTERNATIVES = [("lazy_extension", "0", 0, 0), ("lazy_extension", "k", 0, 6), ("lazy_extension", "to the matrix edge", 0, EDGE),
+                ("kmer_last_anchor", "k - 1", 1, 5), ("no_seed", "empty band", 2, 0), ("sdpkpp_ties", "smaller match index", 3, 0)]
+
+
+def discriminates(x, y, b0, lo0, hi0):
+    L = oracle.lib()
+    L.vtxo_set_variant.argtypes = [C.c_int, C.c_int]
+    out = []
+    for detail, alt, which, value in ALTERNATIVES:
+        L.vtxo_set_variant(which, value)
+        try:
+            b = oracle.sw_banded(x, y)
+            lo, hi, _ = oracle.band_create(x, y)
+        finally:
+            L.vtxo_set_variant(which, -1)
+        band_moved = not (np.array_equal(lo, lo0) and np.array_equal(hi, hi0))
+        if b != b0 or band_moved:
+            out.append({"detail": detail, "alternative": alt, "banded_score_then": int(b), "band_changes": bool(band_moved)})
+    return out
+
+
+def no_seed_pairs(n, seed=11):
+    """Reads that share no 6-mer with their haplotype (bio: Band::full_matrix): every fifth base of a window of the haplotype
+    replaced, so that the full-matrix alignment still scores (runs of four matches) and an EMPTY band would not."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        hap = bytes(rng.choice(list(b"ACGT"), int(rng.integers(60, 200))).tolist())
+        a = int(rng.integers(0, len(hap) - 40))
+        read = bytearray(hap[a:a + int(rng.integers(30, min(120, len(hap) - a)))])
+        for i in range(int(rng.integers(0, 5)), len(read), 5):
+            read[i] = (b"ACGT".replace(bytes([read[i]]), b""))[int(rng.integers(0, 3))]
+        read = bytes(read)
+        if len(oracle.kmer_matches(read, hap)) == 0 and oracle.sw_full(read, hap) > 0:
+            out.append((read, hap))
+    return out
+
+
 def main():
     vectors, seen = [], set()
     sources = [("error models and indels", SB.synthetic_batches(per_model=1, n_loci=30, reads=12), 500, 10),
@@ -81,10 +125,31 @@ def main():
     # keep the file small: every vector where the band changes the score, then the others up to 320 in all
     vectors.sort(key=lambda v: (v["banded_score"] == v["full_score"], v["chain_diagonals"] <= 1))
     vectors = vectors[:320]
+    # pairs without any common 6-mer: the only vectors that can tell "whole matrix" from "empty band"
+    for x, y in no_seed_pairs(16):
+        lo, hi, cells = oracle.band_create(x, y)
+        vectors.append({"kind": "no common 6-mer", "from": "tools/make_band_kat.py: no_seed_pairs", "read": x.decode("latin-1"), "hap": y.decode("latin-1"),
+                        "banded_score": int(oracle.sw_banded(x, y)), "full_score": int(oracle.sw_full(x, y)), "band_cells": int(cells),
+                        "chain_diagonals": 0, "kmer_matches": 0, "lo_rle": rle(lo), "hi_rle": rle(hi)})
+    per_detail = {}
+    for v in vectors:
+        x, y = v["read"].encode("latin-1"), v["hap"].encode("latin-1")
+        v["discriminates"] = discriminates(x, y, v["banded_score"], np.concatenate([np.full(c, a) for a, c in v["lo_rle"]]),
+                                           np.concatenate([np.full(c, a) for a, c in v["hi_rle"]]))
+        for d in v["discriminates"]:
+            e = per_detail.setdefault("%s -> %s" % (d["detail"], d["alternative"]), {"score": 0, "band": 0})
+            e["score"] += d["banded_score_then"] != v["banded_score"]
+            e["band"] += d["band_changes"]
     out = {"what": "known-answer vectors of banded::Aligner::new(-5, -1, score(1, -5), 6, 20).local(read, hap) as restated by oracle/vtx_oracle.c "
                    "(reference call site src/main.rs:898-901); band = per column j of the DP matrix the row range [lo, hi), run-length encoded as [value, count]",
            "k": 6, "w": 20, "scoring": {"match": 1, "mismatch": -5, "gap_open": -5, "gap_extend": -1},
            "recollected_details": {"lazy_extension": "2 * k", "kmer_last_anchor": "k", "no_seed": "full matrix", "sdpkpp_ties": "larger match index"},
+           "discriminating_vectors": per_detail,
+           "how_to_read_a_failure": "every vector carries `discriminates`: the recollected details whose ALTERNATIVE would change its banded score "
+                                    "(banded_score_then) or its band.  If the crate disagrees with banded_score exactly on the vectors that list "
+                                    "one detail, and agrees with their banded_score_then, that detail's constant in include/vtx_band_semantics.h "
+                                    "takes the alternative.  kmer_last_anchor -> k - 1 changes no band at all (the cell after a chained k-mer's "
+                                    "last base is anchored by add_gap's origin or by the next k-mer either way): it cannot be told apart and does not matter",
            "generator": "tools/make_band_kat.py", "vectors": vectors}
     path = os.path.join(ROOT, "tests", "golden", "band_kat.json")
     with open(path, "w") as fh:
@@ -92,6 +157,8 @@ def main():
     ne = sum(v["banded_score"] != v["full_score"] for v in vectors)
     print("%s: %d vectors, %d with banded != full, %d with a chain over several diagonals, %.0f KB" % (
         path, len(vectors), ne, sum(v["chain_diagonals"] > 1 for v in vectors), os.path.getsize(path) / 1024))
+    for k, e in sorted(per_detail.items()):
+        print("  %-44s score changes on %3d vectors, band on %3d" % (k, e["score"], e["band"]))
 
 
 if __name__ == "__main__":

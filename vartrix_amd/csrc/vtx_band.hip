@@ -1818,8 +1818,8 @@ __global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __rest
     const vtx_locus loc = loci[rec_locus[task >> 1]];
     const int m = (int)rec.read_len, n = (int)((task & 1) ? loc.alt_len : loc.ref_len);
     const int rows = m + 1;
-    if (whole) {                                             // Band::full_matrix
-        for (int j = l; j <= n; j += 16) { lo[j] = 0; hi[j] = (uint16_t)rows; }
+    if (whole) {                                             // no k-mer match: Band::full_matrix (the alternative of include/vtx_band_semantics.h: an empty band)
+        for (int j = l; j <= n; j += 16) { lo[j] = VTX_BAND_NO_SEED_FULL_MATRIX ? 0 : 0x7fff; hi[j] = VTX_BAND_NO_SEED_FULL_MATRIX ? (uint16_t)rows : 0; }
         return;
     }
     const uint32_t* v = sv[grp];
