@@ -11,8 +11,13 @@
  *                                 0 (no extension) and VTX_BAND_EXT_TO_EDGE (to the matrix corner).
  *   VTX_BAND_KMER_LAST_ANCHOR(k)  Band::add_kmer: the anchors of a chained k-mer are the cells (r + d, c + d) for
  *                                 d = 0 .. VTX_BAND_KMER_LAST_ANCHOR(k).  Recollection: inclusive of k (k + 1 cells, the
- *                                 cell after the k-mer's last base).
+ *                                 cell after the k-mer's last base).  The alternative k - 1 changes NO band: that cell is
+ *                                 the origin of add_gap / of set_boundaries' extension either way (tests/test_band_kat.py;
+ *                                 libvtx_anchor5.so gives the production scores) — kept as a constant for completeness.
  *   VTX_BAND_NO_SEED_FULL_MATRIX  no exact k-mer match at all: the whole matrix is in band.  Recollection: 1.
+ * (A fourth recollection, the tie rule of sdpkpp — the larger match index wins — is not a constant: it is the order of the
+ * packed words the kernels maximise; oracle/vtx_oracle.c has the switch VTXO_VAR_TIE, tests/golden/band_kat.json 28 vectors
+ * whose score tells the two rules apart.)
  *
  * The call site these implement is src/main.rs:898-901, `banded::Aligner::new(-5, -1, score, 6, 20)`.
  */
@@ -21,7 +26,7 @@
 
 #define VTX_BAND_EXT_TO_EDGE 0x7fffffff
 /* (every constant may be overridden on the compiler command line: `make -C vartrix_amd/csrc variants` builds
- * libvtx_lazy0.so with -D'VTX_BAND_LAZY_EXT(k)=0', and tests/test_gpu_variants.py checks that the device then follows the
+ * libvtx_lazy0.so with -D'VTX_BAND_LAZY_EXT(k)=0' (and libvtx_anchor5.so, libvtx_noseed0.so), and tests/test_gpu_variants.py checks that the device then follows the
  * oracle run with the same override — a maintainer correcting one of these edits this header and nothing else) */
 #ifndef VTX_BAND_LAZY_EXT
 #define VTX_BAND_LAZY_EXT(k) (2 * (k))

@@ -264,7 +264,10 @@ __device__ int band_task(const uint8_t* x, int m, const uint8_t* y, int n, band_
         for (int i = 0; i < dc; ++i) STEP_RIGHT()
         // the k-mer itself (add_kmer, or add_entry for a continued k-mer: same cells)
         const int32_t nx = sc.dpp[p];
-        int steps = VTX_BAND_KMER_LAST_ANCHOR(KMER);      // add_kmer: anchors d = 0 .. k
+        // add_kmer anchors the cells d = 0 .. VTX_BAND_KMER_LAST_ANCHOR(k); the cell d = k is an anchor either way (add_gap's origin /
+        // set_boundaries' extension start from it: oracle/vtx_oracle.c), so the walkers of this file always go on to d = k: the constant
+        // cannot move a band (tests/test_band_kat.py::test_last_anchor_alternative_never_moves_a_band; libvtx_anchor5.so agrees)
+        int steps = KMER;
         if (nx >= 0) {
             const int qx = (int)(sc.mt[nx] >> 16), qy = (int)(sc.mt[nx] & 0xffff);
             if (qx == px + 1 && qy == py + 1) steps = 1;     // next match continues: advance one cell only
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(64) void band_coop_kernel(
     int lx, ly;                                                        // cell behind the last chained k-mer
     {
         const uint32_t w = link(L - 1);
-        lx = (int)(w >> 16) + VTX_BAND_KMER_LAST_ANCHOR(KMER); ly = (int)(w & 0xffffu) + VTX_BAND_KMER_LAST_ANCHOR(KMER);
+        lx = (int)(w >> 16) + KMER; ly = (int)(w & 0xffffu) + KMER;
     }
     const int d1 = min(min(m - lx, n - ly), (int)VTX_BAND_LAZY_EXT(KMER));
     const int cB = ly + d1;
@@ -629,13 +632,13 @@ __global__ __launch_bounds__(64) void band_coop_kernel(
         else {
             const uint32_t q = link(t - 1);
             const int qx = (int)(q >> 16), qy = (int)(q & 0xffffu);
-            const int sq = (px == qx + 1 && py == qy + 1) ? 1 : VTX_BAND_KMER_LAST_ANCHOR(KMER);
+            const int sq = (px == qx + 1 && py == qy + 1) ? 1 : KMER;
             ax = qx + sq; ay = qy + sq;
         }
         const int dr = px - ax, dc = py - ay, dg = min(dr, dc);
         for (int i = 1; i <= dg; ++i) { rmin[ay + i] = (uint32_t)(ax + i); rmax[ay + i] = (uint32_t)(ax + i); }
         for (int c = ay + dg + 1; c <= py; ++c) { rmin[c] = (uint32_t)px; rmax[c] = (uint32_t)px; }       // horizontal remainder (dc > dr)
-        int st = VTX_BAND_KMER_LAST_ANCHOR(KMER);
+        int st = KMER;
         if (t + 1 < L) { const uint32_t nx = link(t + 1); if ((int)(nx >> 16) == px + 1 && (int)(nx & 0xffffu) == py + 1) st = 1; }
         for (int i = 1; i <= st; ++i) { rmin[py + i] = (uint32_t)(px + i); rmax[py + i] = (uint32_t)(px + i); }
     }
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(64) void band_coop_kernel(
         else {
             const uint32_t q = link(t - 1);
             const int qx = (int)(q >> 16), qy = (int)(q & 0xffffu);
-            const int sq = (px == qx + 1 && py == qy + 1) ? 1 : VTX_BAND_KMER_LAST_ANCHOR(KMER);
+            const int sq = (px == qx + 1 && py == qy + 1) ? 1 : KMER;
             ax = qx + sq; ay = qy + sq;
         }
         const int dr = px - ax, dc = py - ay;
@@ -861,7 +864,7 @@ __device__ int band_finish(const uint32_t* mylog, uint32_t ls, uint32_t lg_n, ui
             for (int i = 0; i < dc; ++i) { ++c; walk_gap(w, 2); }
             if (dc > 0) EMIT();
             // the segment's k-mer cells: len + K - 1 diagonal steps, every one an exact match
-            const int run = (int)seg_len[sgi] - 1 + VTX_BAND_KMER_LAST_ANCHOR(KMER);
+            const int run = (int)seg_len[sgi] - 1 + KMER;
             const int32_t v = (w.s > w.gap ? w.s : w.gap) + 1;      // s >= 0, so v >= 1
             w.s = v + (run - 1); w.gap = -100000; w.dir = 0;
             if (w.s > w.best) w.best = w.s;
