@@ -27,7 +27,7 @@ wl_args() {
     e1) echo "--sub-error 0.01 --loci 100000";; e3) echo "--sub-error 0.03 --loci 100000";; e8) echo "--sub-error 0.08 --loci 100000";;
     c5) echo "--indel-frac 0.3 --umi 1 --mode alt_frac --loci 100000";;
     d128|d64|d32|d16|d4) echo "--reads-per-locus ${1#d}";; ln8) echo "--reads-per-locus 8 --depth-sigma 1.0";;
-    r250) echo "--read-len 250 --loci 100000";; p150) echo "--padding 150 --loci 100000";; c4) echo "--workload config4";;
+    r250) echo "--read-len 250 --loci 60000";; p150) echo "--padding 150 --loci 100000";; c4) echo "--workload config4";;
     *) echo "unknown workload $1" >&2; exit 2;;
   esac
 }
