@@ -649,3 +649,16 @@ def test_packs_reuse_each_others_memory():
                         "-k", "packer_equals or raw_packer or nibble_pack or splits_large or row_ranges or authored_indel"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_trim_returns_the_kept_buffers():
+    """vtxh_trim(): the buffers a freed pack leaves in the process-wide pool (touched pages for the next pack of a streamed run) go
+    back to the allocator; packing afterwards still works and gives the same batch."""
+    import ctypes as C
+    L = hostlib.load()
+    L.vtxh_trim.restype = None
+    a, m1, *_ = hostlib.pack_files(**_inputs())
+    L.vtxh_trim()
+    L.vtxh_trim()                                   # (idempotent)
+    b, m2, *_ = hostlib.pack_files(**_inputs())
+    assert m1 == m2 and same_batch(a, b)
