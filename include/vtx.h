@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define VTX_ABI_VERSION 4
+#define VTX_ABI_VERSION 5
 
 typedef enum vtx_status {
     VTX_OK = 0,
@@ -168,8 +168,11 @@ typedef struct vtx_timing {
     float sweep_ms;        /* band_sweep_kernel + band-masked DP over what is left (part of band_ms)                 */
     uint32_t checked_tasks; /* alignments that left the certificate stages WITH a certificate: one-diagonal band + masked DP */
     uint32_t swept_tasks;  /* alignments handed to band_sweep_kernel                                                 */
-    uint32_t resweep_tasks; /* ... of which its first pass declined (more than 128 sections): second pass, 1024 sections; what
-                              that declines too (overflow_tasks) takes the general band kernel                               */
+    uint32_t resweep_tasks; /* (round 4's sweep kernel, developer build only: tasks of its second pass)                     */
+    uint32_t diag2_tasks;  /* alignments the second single-diagonal stage looked at (band_diag2_kernel: what the first left with
+                              more off-diagonal matches than its list holds) ...                                              */
+    uint32_t diag2_scored; /* ... of which it decided outright (cert == ub); the rest of them is in checked_tasks (one-diagonal
+                              band) or swept_tasks                                                                            */
 } vtx_timing;
 
 typedef struct vtx_ctx vtx_ctx;

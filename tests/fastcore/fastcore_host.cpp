@@ -185,4 +185,63 @@ int vtxt_fastcore_batch(const vtx_batch* b, uint32_t n_heads, int32_t* score, ui
     }
     return 0;
 }
+
+// ---- the SECOND stage (vtxf::fast_task2: band_diag2_kernel's per-task logic) ----
+// one read against one haplotype: returns the verdict (vtxf::T2Verdict), *score (T2_SCORE: the score; T2_TIGHT: the certificate),
+// *pack (T2_TIGHT: vtxf::band_pack) and *why
+int vtxt_task2(const uint8_t* x, int m, const uint8_t* y, int n, int32_t* score, uint32_t* pack, uint32_t* why) {
+    using namespace vtxf;
+    const uint32_t max_hap = (uint32_t)std::max(n, 8), n_heads = 1024;
+    std::vector<uint8_t> gt(tab_stride(max_hap, n_heads) + 64);
+    build_table(gt.data(), y, (uint32_t)n, max_hap, n_heads);
+    Tab tb;
+    tb.gt = gt.data(); tb.ent = 0; tb.head = max_hap * 8; tb.bytes = tab_bytes_off(max_hap, n_heads);
+    tb.uq = tab_uq_off(max_hap, n_heads); tb.pb = tab_pb_off(max_hap, n_heads); tb.hmask = n_heads - 1;
+    std::vector<uint8_t> xb((size_t)m + 16, 0);
+    memcpy(xb.data(), x, (size_t)m);
+    uint32_t lane[S2_WORDS + RM], generic[GM];
+    uint8_t ub[LaneS2::SMAX];
+    const LaneS2 ln{lane + S2_WORDS, 1, (uint16_t*)lane, 1, ub, 1};
+    const Result2 r = n <= 255 ? fast_task2(xb.data(), m, tb, n, ln, Lane{generic, 1}) : Result2{T2_SWEEP, -1, 0u, W_SHAPE};
+    *score = r.score; *pack = r.pack; *why = r.why;
+    return (int)r.verdict;
+}
+// every task of a packed batch: verdict[t], score[t], pack[t] (t = 2 * record + hap); haplotypes above 255 bases: T2_SWEEP
+int vtxt_fastcore2_batch(const vtx_batch* b, uint32_t n_heads, uint8_t* verdict, int32_t* score, uint32_t* pack, uint32_t* why) {
+    using namespace vtxf;
+    uint32_t max_hap = 8;
+    for (uint32_t l = 0; l < b->n_loci; ++l) max_hap = std::max(max_hap, std::max(b->loci[l].ref_len, b->loci[l].alt_len));
+    const uint32_t stride = tab_stride(max_hap, n_heads);
+    std::vector<uint8_t> gt((size_t)2 * stride + 64);
+    std::vector<uint8_t> readbuf;
+    uint32_t lane[S2_WORDS + RM], generic[GM];
+    uint8_t ub[LaneS2::SMAX];
+    for (uint32_t l = 0; l < b->n_loci; ++l) {
+        const vtx_locus& L = b->loci[l];
+        build_table(gt.data(), b->hap_arena + L.ref_off, L.ref_len, max_hap, n_heads);
+        build_table(gt.data() + stride, b->hap_arena + L.alt_off, L.alt_len, max_hap, n_heads);
+        for (uint32_t r = L.rec_begin; r < L.rec_begin + L.rec_count; ++r) {
+            const vtx_record& R = b->records[r];
+            readbuf.assign(R.read_len + 16, 0);
+            memcpy(readbuf.data(), b->read_arena + R.read_off, R.read_len);
+            for (int h = 0; h < 2; ++h) {
+                Tab tb;
+                tb.gt = gt.data();
+                tb.ent = (uint32_t)h * stride;
+                tb.head = tb.ent + max_hap * 8;
+                tb.bytes = tb.ent + tab_bytes_off(max_hap, n_heads);
+                tb.uq = tb.ent + tab_uq_off(max_hap, n_heads);
+                tb.pb = tb.ent + tab_pb_off(max_hap, n_heads);
+                tb.hmask = n_heads - 1;
+                const LaneS2 ln{lane + S2_WORDS, 1, (uint16_t*)lane, 1, ub, 1};
+                const int n = (int)(h ? L.alt_len : L.ref_len);
+                const Result2 res = max_hap <= 255 ? fast_task2(readbuf.data(), (int)R.read_len, tb, n, ln, Lane{generic, 1})
+                                                   : Result2{T2_SWEEP, -1, 0u, W_SHAPE};
+                const size_t t = 2 * (size_t)r + h;
+                verdict[t] = (uint8_t)res.verdict; score[t] = res.score; pack[t] = res.pack; why[t] = res.why;
+            }
+        }
+    }
+    return 0;
+}
 }

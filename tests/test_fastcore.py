@@ -386,3 +386,64 @@ def test_edge_shapes(core):
         [(0, 0, g[1600:1750]), (1, 0, g[1620:1700] + b"ACGTACGTAC" + g[1700:1760]), (2, 0, g[1400:1550])],
     ]
     check(core, SB.manual_batch(haps, reads, 8), 8, "edge shapes")
+
+
+# ---- the second stage (vtxf::fast_task2 = band_diag2_kernel's per-task logic): 120 list entries and the harmless bound from the
+#      matches that can really precede a match ----
+def _band_from_pack(pk, m, n):
+    dd, ca, cb = (pk >> 16) - 256, (pk >> 8) & 0xff, pk & 0xff
+    lo = np.full(n + 1, m + 1, np.int64)
+    hi = np.zeros(n + 1, np.int64)
+    for j in range(n + 1):
+        if ca - 20 <= j <= cb + 20:
+            lo[j] = max(0, max(j - 20, ca) - dd - 20)
+            hi[j] = min(m + 1, min(j + 20, cb) - dd + 21)
+    return lo, hi
+
+
+def _check_second_stage(core, batch, nb, label, band_checks=400):
+    """Every task of the batch through fast_task2: a SCORE verdict is the oracle's banded score; a TIGHT verdict promises that the
+    reference's band is the one diagonal stretch of band_pack — checked column by column against the oracle's Band::create on a
+    sample, and the masked DP over that band (oracle.sw_ranges) gives the oracle's score on every one."""
+    core.vtxt_fastcore2_batch.argtypes = [C.POINTER(VtxBatch), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    st = batch.as_struct()
+    n = 2 * batch.n_records
+    verdict, score, pack, why = np.zeros(n, np.uint8), np.zeros(n, np.int32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    assert core.vtxt_fastcore2_batch(C.byref(st), 1024, verdict.ctypes.data, score.ctypes.data, pack.ctypes.data, why.ctypes.data) == 0
+    r, a = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=nb), threads=8)
+    want = np.empty(n, np.int32)
+    want[0::2], want[1::2] = r, a
+    dec = verdict == 0
+    bad = np.nonzero(dec & (score != want))[0]
+    assert bad.size == 0, "%s: task %d scored %d, oracle %d" % (label, bad[0], score[bad[0]], want[bad[0]])
+    tight = np.nonzero(verdict == 1)[0]
+    assert np.all(score[tight] <= want[tight]), label                  # the certificate is a lower bound of the banded score
+    rec_locus = np.repeat(np.arange(batch.n_loci), batch.loci["rec_count"])
+    hb, rb = batch.hap_arena.tobytes(), batch.read_arena.tobytes()
+    rng = np.random.default_rng(1)
+    for t in (tight if len(tight) <= band_checks else rng.choice(tight, band_checks, replace=False)):
+        rec, loc = batch.records[t >> 1], batch.loci[rec_locus[t >> 1]]
+        x = rb[int(rec["read_off"]):int(rec["read_off"]) + int(rec["read_len"])]
+        off, ln = (int(loc["alt_off"]), int(loc["alt_len"])) if t & 1 else (int(loc["ref_off"]), int(loc["ref_len"]))
+        y = hb[off:off + ln]
+        lo, hi = _band_from_pack(int(pack[t]), len(x), len(y))
+        olo, ohi, _ = oracle.band_create(x, y)
+        empty = ohi <= olo
+        assert np.array_equal(lo[~empty], olo[~empty]) and np.array_equal(hi[~empty], ohi[~empty]) and not hi[empty].any(), (label, int(t))
+    return float(dec.mean()), float((verdict == 1).mean()), float((verdict == 2).mean())
+
+
+def test_second_stage_on_real_sequence_repeats_and_noise(core):
+    tot = {}
+    cases = [("real sequence", synth.make_batch(synth.SynthSpec(n_loci=300, n_barcodes=500, reads_per_locus=12, seed=3,
+                                                                genome_fasta=os.path.join(HERE, "golden", "test_dna.fa"))), 500)]
+    cases += list(SB.real_sequence_batches(trials=1)) + list(SB.near_repeat_batches(trials=3)) + list(SB.real_shape_batches(trials=1))
+    cases += list(SB.repeat_rich_batches(trials=3, loci=16, reads=10, pad_range=(60, 120)))
+    cases += [(lbl, b, nb) for lbl, b, nb in SB.synthetic_batches(per_model=1, n_loci=24, reads=12)]
+    for label, batch, nb in cases:
+        if max(int(batch.loci["ref_len"].max()), int(batch.loci["alt_len"].max())) > 255:
+            continue
+        tot[label] = _check_second_stage(core, batch, nb, label)
+    d, t, s = tot["real sequence"]
+    print("second stage, real sequence: decided %.1f %%, one-diagonal band %.1f %%, left to the sweep %.1f %%" % (100 * d, 100 * t, 100 * s))
+    assert s < 0.05 and d > 0.80, tot["real sequence"]           # (the first stage alone leaves 15 % of these tasks)

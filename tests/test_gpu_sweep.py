@@ -208,9 +208,10 @@ np.save(sys.argv[1], np.concatenate(out))
 ''' % (ROOT, HERE)
 
 
-@pytest.mark.parametrize("hook", ["VTX_BAND_LEGACY", "VTX_BAND_CHECK", "VTX_BAND_NO_TIGHT", "VTX_BAND_SLOTS", "VTX_SWEEP_V1"])
+@pytest.mark.parametrize("hook", ["VTX_BAND_LEGACY", "VTX_BAND_CHECK", "VTX_BAND_NO_TIGHT", "VTX_BAND_SLOTS", "VTX_SWEEP_V1", "VTX_BAND_DIAG2_MIN"])
 def test_hooks_give_the_same_scores(hook):
-    """VTX_SWEEP_V1=1: round 4's band_sweep_kernel (two passes) instead of round 5's; VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending / general kernels instead of the sweep; VTX_BAND_CHECK=1: the full-matrix
+    """VTX_BAND_DIAG2_MIN=1: the second single-diagonal stage (band_diag2_kernel) on every list, however short — by default lists
+    below 200 k tasks skip it, i.e. every batch of this test suite but the full-size ones; VTX_SWEEP_V1=1: round 4's band_sweep_kernel (two passes) instead of round 5's; VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending / general kernels instead of the sweep; VTX_BAND_CHECK=1: the full-matrix
     check in front of the DP of the tasks that left with a certificate; VTX_BAND_NO_TIGHT=1: those tasks go to the sweep like the
     others (the sweep's band and the certificate's one-diagonal band must give the same scores); VTX_BAND_SLOTS=5: the sweep + masked
     DP in slices of five band slots.  Identical scores (separate processes: the hooks are read once)."""
@@ -220,7 +221,7 @@ def test_hooks_give_the_same_scores(hook):
             env = dict(os.environ, VTX_LIB_VARIANT="dev")           # (the hooks exist in libvtx_dev.so only)
             env.pop(hook, None)
             if on:
-                env[hook] = "5" if hook == "VTX_BAND_SLOTS" else "1"
+                env[hook] = "5" if hook == "VTX_BAND_SLOTS" else "1"           # (VTX_BAND_DIAG2_MIN=1: every list)
             path = os.path.join(td, "h%d.npy" % on)
             p = subprocess.run([sys.executable, "-c", CODE, path], env=env, capture_output=True, text=True, timeout=1200)
             assert p.returncode == 0, p.stderr[-3000:]
@@ -291,3 +292,47 @@ def test_table_kernel_against_round3s():
         assert np.array_equal(sp[0], ss[0]) and np.array_equal(sp[1], ss[1]), label
         checked += 1
     assert checked >= 5
+
+
+CODE2 = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import stress_batches as SB
+from oracle import oracle
+from vartrix_amd import abi, lib, synth
+from vartrix_amd.abi import default_config
+from audit_util import assert_stage_invariant
+batches = list(SB.real_sequence_batches(trials=2)) + list(SB.repeat_rich_batches(trials=3, loci=30, reads=16, pad_range=(60, 120)))
+batches += list(SB.near_repeat_batches(trials=2)) + list(SB.real_shape_batches(trials=1))
+batches += [("real sequence, deep", synth.make_batch(synth.SynthSpec(n_loci=400, n_barcodes=500, reads_per_locus=48, seed=4,
+             genome_fasta=os.path.join(%r, "tests", "golden", "test_dna.fa"))), 500)]
+looked = scored = 0
+for label, batch, nb in batches:
+    out = {}
+    for aligner in ("banded", "full"):
+        with lib.Context(default_config(aligner=aligner, scoring_mode="coverage", n_barcodes=nb)) as ctx:
+            ctx.submit(batch)
+            if aligner == "banded":
+                ctx.set_stage_trace(True); ctx.set_poison(-999)
+            ctx.run()
+            out[aligner] = ctx.fetch_scores() + ((ctx.fetch_stage(), ctx.timing()) if aligner == "banded" else ())
+    rb, ab, stage, t = out["banded"]
+    assert_stage_invariant(stage, (rb, ab), out["full"], label)
+    oref, oalt = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=nb), threads=os.cpu_count() or 8)
+    bad = np.nonzero((rb != oref) | (ab != oalt))[0]
+    assert bad.size == 0, (label, int(bad[0]), int(rb[bad[0]]), int(oref[bad[0]]), int(ab[bad[0]]), int(oalt[bad[0]]), stage[2 * bad[0]:2 * bad[0] + 2].tolist())
+    looked += t.diag2_tasks; scored += t.diag2_scored
+    print(label, "second stage looked at", t.diag2_tasks, "scored", t.diag2_scored, "one-diagonal bands", t.checked_tasks, "swept", t.swept_tasks, file=sys.stderr)
+assert looked > 3000 and scored > 300, (looked, scored)
+print("second-stage-ok", looked, scored)
+''' % (ROOT, HERE, ROOT)
+
+
+def test_second_stage_against_the_oracle():
+    """band_diag2_kernel forced on every list (libvtx_dev.so, VTX_BAND_DIAG2_MIN=1) on real-sequence loci, tandem repeats, near repeats
+    and real-read shapes: every score is the oracle's, banded != full only on DP stages, no score is left unwritten (poisoned
+    arrays), and the stage really takes tasks (thousands looked at, hundreds scored outright)."""
+    p = subprocess.run([sys.executable, "-c", CODE2], env=dict(os.environ, VTX_LIB_VARIANT="dev", VTX_BAND_DIAG2_MIN="1"),
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0 and "second-stage-ok" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+    print(p.stderr.strip().replace("\n", " | "))

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-VTX_ABI_VERSION = 4
+VTX_ABI_VERSION = 5
 READS_BYTES, READS_NIBBLES = 0, 1          # vtx_set_read_format
 
 VTX_OK = 0
@@ -125,6 +125,8 @@ class VtxTiming(C.Structure):
         ("checked_tasks", C.c_uint32),
         ("swept_tasks", C.c_uint32),
         ("resweep_tasks", C.c_uint32),
+        ("diag2_tasks", C.c_uint32),
+        ("diag2_scored", C.c_uint32),
     ]
 
 

@@ -109,6 +109,7 @@ struct vtx_ctx {
     DevBuf d_read_packed;                  // VTX_READS_NIBBLES: the arena as uploaded, unpacked into d_read
     uint64_t gt_used = 0;      // bytes of d_gtables the last banded run's table kernel wrote (vtx_debug_tables)
     DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail, d_fail_tmp, d_refine;   // banded flavour
+    DevBuf d_tight2, d_tight2_pack;                                          // band_diag2_kernel: tasks whose band is one diagonal stretch after all
     DevBuf d_sweep_log;                                                      // band_sweep_kernel: the section logs of the resident workgroups (64 MB)
     DevBuf d_tight, d_tight_pack, d_dband, d_dband_pack, d_dense, d_stage;                                                 // round 4: tasks with a provisional score (full-matrix check); stage bytes (vtx_fetch_stage)
     bool stage_trace = false, poison = false;                                // test / audit hooks (vtx_set_debug)
@@ -577,7 +578,7 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_cnt, &c->d_redo, &c->d_redo_cnt, &c->d_bc_slots, &c->d_bc_hash, &c->d_bc_off, &c->d_bc_bytes,
                       &c->d_raw, &c->d_tags, &c->d_raw_locus, &c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2,
                       &c->d_idx, &c->d_idx2, &c->d_shape, &c->d_shape2, &c->d_seq, &c->d_locus_cnt, &c->d_locus_scan,
-                      &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp, &c->d_refine, &c->d_tight, &c->d_tight_pack, &c->d_dband, &c->d_dband_pack, &c->d_dense, &c->d_stage, &c->d_sweep_log};
+                      &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp, &c->d_refine, &c->d_tight, &c->d_tight_pack, &c->d_dband, &c->d_dband_pack, &c->d_dense, &c->d_stage, &c->d_sweep_log, &c->d_tight2, &c->d_tight2_pack};
     for (DevBuf* b : bufs) b->release();
     c->d_slow_ws.release(); c->d_slow_retry.release(); c->d_read_packed.release();
     DevBuf* gb[] = {&c->d_g_cnt, &c->d_g_row, &c->d_g_col, &c->d_g_alt, &c->d_g_ref, &c->d_g_unk, &c->d_g_val, &c->d_g_refval};
@@ -660,6 +661,8 @@ static int band_reserve(vtx_ctx* c, BandPlan& p, bool quiet) {
     if (p.gt_bytes) RES(d_tight_pack, (size_t)p.chunk * sizeof(uint32_t));  // ... and their bands (one diagonal stretch each: one word)
     if (p.gt_bytes) RES(d_dense, 2 * (size_t)p.chunk * sizeof(uint32_t));   // tasks for band_sweep_kernel (repeats: as listed, then sorted)
     if (p.gt_bytes) RES(d_sweep_log, vtxk_band_sweep_log_bytes());
+    if (p.gt_bytes) RES(d_tight2, (size_t)p.chunk * sizeof(uint32_t));      // second stage: one-diagonal bands ...
+    if (p.gt_bytes) RES(d_tight2_pack, (size_t)p.chunk * sizeof(uint32_t)); // ... one word each
 #undef RES
     return VTX_OK;
 }
@@ -1172,7 +1175,7 @@ int vtx_run(vtx_ctx* c) {
         HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 64 * sizeof(uint32_t), s));
         uint32_t cnt[12] = {0};
         uint32_t pending_total = 0, over_before = 0;
-        uint64_t diag_total = 0, diag_left = 0, refined_total = 0, checked_total = 0, swept_total = 0;
+        uint64_t diag_total = 0, diag_left = 0, refined_total = 0, checked_total = 0, swept_total = 0, diag2_total = 0, diag2_scored = 0, tight2_total = 0;
         float diag_ms = 0, check_ms = 0, sweep_ms = 0;
         // the band of every listed task (band_sweep_kernel, tier 0 / 1), one slice of band slots at a time, then the masked DP over
         // the slice (its length — the tasks the sweep did not decline — is read on the device: counters[0]; declined: counters[1])
@@ -1363,8 +1366,43 @@ int vtx_run(vtx_ctx* c) {
                                 dl = dense_list + nt;
                             } else (void)hipGetLastError();
                         }
-                        if (int rc = sweep_slices(0, dl, n_dense, c->d_over.as<uint32_t>() + 2 * n_tasks, d_cnt + 26)) return rc;
-                        swept_total += n_dense;
+                        // Second stage (round 5): the same single-diagonal logic with a list of 120 entries and the harmless bound from
+                        // the matches that can really precede a match (band_diag2_kernel).  It scores most of these tasks or proves
+                        // that their band is one diagonal stretch (masked DP, no sweep); what it leaves takes the sweep.  One host
+                        // round trip for the two counts.  (libvtx_dev.so: VTX_BAND_NO_DIAG2=1 sends everything to the sweep, as round 4 did.)
+                        // A short list skips it: one lane per task, a few hundred dependent loads each — below ~4 k wavefronts the
+                        // kernel is a latency chain that the sweep + its DP beat (headline: 48 k tasks, 0.6 ms against 0.35 saved).
+                        static const bool no_diag2 = VTX_DEV_ENV("VTX_BAND_NO_DIAG2") != nullptr;
+                        static const uint32_t diag2_min = VTX_DEV_ENV("VTX_BAND_DIAG2_MIN") ? (uint32_t)strtoul(VTX_DEV_ENV("VTX_BAND_DIAG2_MIN"), nullptr, 10) : 200000u;
+                        const uint32_t* sl = dl;
+                        uint32_t n_sweep = n_dense;
+                        if (!no_diag2 && n_dense >= diag2_min) {
+                            uint32_t* sweep2 = (dl == dense_list) ? dense_list + nt : dense_list;          // (the half of d_dense the list is not in)
+                            HIP_TRY(c, hipMemsetAsync(d_cnt + 30, 0, 2 * sizeof(uint32_t), s));
+                            HIP_TRY(c, vtxk_launch_band_diag2(dl, n_dense, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                              c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
+                                                              c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), tasks_per_locus, gt_l0,
+                                                              c->d_gtables.as<uint8_t>(), sweep2, c->d_tight2.as<uint32_t>(),
+                                                              c->d_tight2_pack.as<uint32_t>(), d_cnt + 30, stage, s));
+                            HIP_TRY(c, hipMemcpyAsync(c->h_pin + 14, d_cnt + 30, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                            HIP_TRY(c, hipStreamSynchronize(s));
+                            n_sweep = std::min(c->h_pin[14], n_dense);
+                            const uint32_t n_tight2 = std::min(c->h_pin[15], n_dense - n_sweep);
+                            sl = sweep2;
+                            ++launches;
+                            diag2_total += n_dense; diag2_scored += n_dense - n_sweep - n_tight2;
+                            if (n_tight2) {
+                                HIP_TRY(c, vtxk_launch_sw_diag_band(kShapes[shape][0], kShapes[shape][1], n_tight2, c->d_tight2.as<uint32_t>(),
+                                                                    c->d_tight2_pack.as<uint32_t>(), nullptr, c->d_records.as<vtx_record>(),
+                                                                    c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                                                    c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
+                                                                    c->max_hap_len, stage, s));
+                                ++launches;
+                                tight2_total += n_tight2;
+                            }
+                        }
+                        if (n_sweep) { if (int rc = sweep_slices(0, sl, n_sweep, c->d_over.as<uint32_t>() + 2 * n_tasks, d_cnt + 26)) return rc; }
+                        swept_total += n_sweep;
                     }
                     if (n_fail > 64) {
                         const size_t tb = vtxk_sort_keys_u32_temp_bytes(n_fail);
@@ -1532,6 +1570,10 @@ int vtx_run(vtx_ctx* c) {
         c->timing.checked_tasks = (uint32_t)std::min<uint64_t>(checked_total, 0xffffffffull);
         c->timing.swept_tasks = (uint32_t)std::min<uint64_t>(swept_total, 0xffffffffull);
         c->timing.resweep_tasks = resweep_total;
+        c->timing.diag2_tasks = (uint32_t)std::min<uint64_t>(diag2_total, 0xffffffffull);
+        c->timing.diag2_scored = (uint32_t)std::min<uint64_t>(diag2_scored, 0xffffffffull);
+        checked_total += tight2_total;                     // (one-diagonal bands of the second stage: the same masked DP)
+        c->timing.checked_tasks = (uint32_t)std::min<uint64_t>(checked_total, 0xffffffffull);
         if (swept_total) hard_total += (uint32_t)std::min<uint64_t>(swept_total - std::min<uint64_t>(swept_total, fast_overflow), 0xffffffffull);
         hard_total += (uint32_t)std::min<uint64_t>(checked_total, 0xffffffffull);      // (tasks with a certificate: masked DP over their diagonal band; with VTX_BAND_CHECK an upper bound)
         if (getenv("VTX_DEBUG") && diag_total) {
@@ -1542,6 +1584,10 @@ int vtx_run(vtx_ctx* c) {
                     (unsigned long long)diag_left, (unsigned long long)diag_total, 100.0 * (double)diag_left / (double)diag_total, (double)diag_ms,
                     why[1], why[2], why[3], why[4], why[5], why[7], why[8], why[9]);
         }
+        if (getenv("VTX_DEBUG") && diag2_total)
+            fprintf(stderr, "[vtx] band_diag2_kernel: %llu tasks looked at, %llu scored, %llu left with a one-diagonal band, %llu to band_sweep_kernel\n",
+                    (unsigned long long)diag2_total, (unsigned long long)diag2_scored, (unsigned long long)tight2_total,
+                    (unsigned long long)(diag2_total - diag2_scored - tight2_total));
         if (getenv("VTX_DEBUG")) fprintf(stderr, "[vtx] banded: %llu tasks, %u overflowed band_run_kernel, %u bounded by the pending kernel, %u hard\n", (unsigned long long)n_tasks, fast_overflow, pending_total, hard_total);
     }
     if (c->slow_cnt) {

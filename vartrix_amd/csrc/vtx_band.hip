@@ -2597,6 +2597,81 @@ extern "C" hipError_t vtxk_launch_band_refine(const uint32_t* recs, uint32_t n_r
     return hipGetLastError();
 }
 
+// ---- the SECOND stage (round 5): band_diag2_kernel ------------------------------------------------------------------------------
+// What band_diag_kernel leaves because a task's off-diagonal matches do not fit its 40-entry list (W_MATCHES: loci in repeat-rich
+// sequence; 14 % of the real-sequence workload) used to take band_sweep_kernel + the masked DP, 38 ns per task.  Most of these tasks
+// still have their alignment on ONE diagonal: with a list of 120 entries and the harmless test bounding a match's dp from the matches
+// that can really precede it (vtx_fast_core.h: back_harmless, LN::TIGHT) the same per-task logic decides 60 % of them outright and
+// proves for another 25 % that every off-diagonal match is harmless — the reference's chain lies on the main diagonal, the band is
+// one diagonal stretch (band_pack), and the masked DP needs no sweep.  One lane per task, the plain per-lane form of the logic
+// (vtxf::fast_task2: its own probes, no pooling): 7 M tasks, not 49 M.  Per lane 104 words of LDS (60 list, 8 pieces, 30 bound bytes,
+// 6 generic pieces): 26.6 KB per wavefront.
+// Output: T2_SCORE -> the score (stage 1); T2_TIGHT -> tight_list / tight_pack at counters[1] (provisional score = the certificate);
+// T2_SWEEP -> sweep_list at counters[0].
+constexpr int D2_LANE_WORDS = vtxf::S2_WORDS + vtxf::RM + vtxf::LaneS2::SMAX / 4 + vtxf::GM;
+__global__ __launch_bounds__(64) void band_diag2_kernel(
+    const uint32_t* __restrict__ tasks, uint32_t n_tasks,
+    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
+    const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
+    const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
+    uint32_t* __restrict__ sweep_list, uint32_t* __restrict__ tight_list, uint32_t* __restrict__ tight_pack,
+    uint32_t* __restrict__ counters, uint8_t* __restrict__ stage) {
+    __shared__ uint32_t mem[D2_LANE_WORDS * 64];
+    const int tid = (int)threadIdx.x;
+    const uint32_t slot = blockIdx.x * 64u + (uint32_t)tid;
+    uint32_t verdict = 3u, task = 0, pack = 0;
+    if (slot < n_tasks) {
+        task = tasks[slot];
+        const uint32_t rid = task >> 1, hap = task & 1u;
+        const vtx_record rec = records[rid];
+        const uint32_t my_locus = rec_locus[rid];
+        const vtx_locus loc = loci[my_locus];
+        const int m = (int)rec.read_len, n = (int)(hap ? loc.alt_len : loc.ref_len);
+        vtxf::Tab tb;
+        tb.gt = gtables; tb.hmask = n_heads - 1;
+        tb.ent = (uint32_t)(((size_t)(my_locus - gt_l0) * 2 + hap) * table_stride);
+        tb.head = tb.ent + max_hap * 8u;
+        tb.bytes = tb.ent + vtxf::tab_bytes_off(max_hap, n_heads);
+        tb.uq = tb.ent + vtxf::tab_uq_off(max_hap, n_heads);
+        tb.pb = tb.ent + vtxf::tab_pb_off(max_hap, n_heads);
+        // lane scratch, the 64 lanes interleaved: list (two-byte entries), pieces, bound bytes, generic pieces
+        uint32_t* base = mem + tid;
+        const vtxf::LaneS2 ln{base + vtxf::S2_WORDS * 64, 64, (uint16_t*)mem + tid, 64,
+                              (uint8_t*)(mem + (vtxf::S2_WORDS + vtxf::RM) * 64) + tid, 64};
+        const vtxf::Lane gl{base + (vtxf::S2_WORDS + vtxf::RM + vtxf::LaneS2::SMAX / 4) * 64, 64};
+        const vtxf::Result2 r = vtxf::fast_task2(read_arena + rec.read_off, m, tb, n, ln, gl);
+        verdict = r.verdict; pack = r.pack;
+        if (verdict != vtxf::T2_SWEEP) (hap ? alt_score : ref_score)[rid] = r.score;     // final (T2_SCORE) or provisional: the certificate
+        if (verdict == vtxf::T2_SCORE && stage) stage[task] = 1;
+    }
+    const uint64_t sm = __ballot(verdict == vtxf::T2_SWEEP), tm = __ballot(verdict == vtxf::T2_TIGHT);
+    uint32_t sbase = 0, tbase = 0;
+    if (tid == 0) {
+        if (sm) sbase = atomicAdd(&counters[0], (uint32_t)__popcll(sm));
+        if (tm) tbase = atomicAdd(&counters[1], (uint32_t)__popcll(tm));
+    }
+    sbase = (uint32_t)__shfl((int)sbase, 0); tbase = (uint32_t)__shfl((int)tbase, 0);
+    const uint64_t below = (1ull << tid) - 1ull;
+    if (verdict == vtxf::T2_SWEEP) sweep_list[sbase + (uint32_t)__popcll(sm & below)] = task;
+    else if (verdict == vtxf::T2_TIGHT) { const uint32_t pos = tbase + (uint32_t)__popcll(tm & below); tight_list[pos] = task; tight_pack[pos] = pack; }
+}
+
+// band_diag2_kernel over a task list (the tables are the ones vtxk_launch_band_diag built for the chunk); counters[0] / [1]: sweep / tight
+extern "C" hipError_t vtxk_launch_band_diag2(const uint32_t* tasks, uint32_t n_tasks, const vtx_record* records, const uint32_t* rec_locus,
+                                             const vtx_locus* loci, const uint8_t* read_arena, uint32_t max_hap, int32_t* ref_score,
+                                             int32_t* alt_score, uint32_t tasks_per_locus, uint32_t gt_l0, const uint8_t* gtables,
+                                             uint32_t* sweep_list, uint32_t* tight_list, uint32_t* tight_pack, uint32_t* counters,
+                                             uint8_t* stage, hipStream_t s) {
+    if (!n_tasks) return hipSuccess;
+    if (max_hap > 255) return hipErrorInvalidValue;                  // (two-byte list entries)
+    const uint32_t n_heads = pick_heads(tasks_per_locus, true);
+    const size_t tstride = band_table_stride(max_hap, n_heads);
+    hipLaunchKernelGGL(band_diag2_kernel, dim3((n_tasks + 63) / 64), dim3(64), 0, s, tasks, n_tasks, records, rec_locus, loci, read_arena,
+                       max_hap, (uint32_t)tstride, n_heads, gtables, gt_l0, ref_score, alt_score, sweep_list, tight_list, tight_pack,
+                       counters, stage);
+    return hipGetLastError();
+}
+
 extern "C" uint32_t vtxk_band_poly_stride(void) { return (2 + 2 * (4 * SG + 6) + 7) & ~7u; }   // u16 per polyline record
 
 extern "C" hipError_t vtxk_launch_band_expand(const uint32_t* hard_list, uint32_t n_hard, const vtx_record* records,

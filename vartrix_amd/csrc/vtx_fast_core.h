@@ -265,15 +265,36 @@ struct Lane {
     uint32_t* base; int stride;
     VTXF_MEM uint32_t& at(int i) const { return base[i * stride]; }
 };
-template <class ST> struct LaneS {
+template <class ST, int SW = S_WORDS> struct LaneS {
     typedef ST SType;
     uint32_t* base; int stride;
     ST* sb; int sstride;
     static constexpr int XS = sizeof(ST) == 2 ? 8 : 16;
-    static constexpr int SMAX = S_WORDS * 4 / (int)sizeof(ST);
+    static constexpr int SMAX = SW * 4 / (int)sizeof(ST);
     static constexpr uint32_t YM = (1u << XS) - 1u, ONE = (1u << XS) | 1u;
+    static constexpr bool TIGHT = false;
     VTXF_MEM uint32_t& at(int i) const { return base[i * stride]; }
     VTXF_MEM ST& s(int k) const { return sb[k * sstride]; }
+};
+// The lane of the SECOND stage (band_diag2_kernel, round 5): two-byte entries, S2_WORDS words of them, and a byte per entry for the
+// dp bound of the harmless test (u(k)): with it the bound of an off-diagonal match comes from the matches that can really precede it
+// (back_harmless), not from every earlier one.
+#ifndef VTXF_S2_WORDS
+#define VTXF_S2_WORDS 60
+#endif
+constexpr int S2_WORDS = VTXF_S2_WORDS;   // 120 entries (back_rest's closure is only asked for <= 64 of them: its bit set and byte counters)
+struct LaneS2 {
+    typedef uint16_t SType;
+    uint32_t* base; int stride;
+    uint16_t* sb; int sstride;
+    uint8_t* ub; int ustride;
+    static constexpr int XS = 8;
+    static constexpr int SMAX = S2_WORDS * 2;
+    static constexpr uint32_t YM = 0xffu, ONE = 0x101u;
+    static constexpr bool TIGHT = true;
+    VTXF_MEM uint32_t& at(int i) const { return base[i * stride]; }
+    VTXF_MEM uint16_t& s(int k) const { return sb[k * sstride]; }
+    VTXF_MEM uint8_t& u(int k) const { return ub[k * ustride]; }
 };
 
 struct Front {
@@ -600,13 +621,39 @@ template <class LN> VTXF_FN void back_sort(int ns, const LN& ln) {
         ln.s(j + 1) = (typename LN::SType)v;
     }
 }
+// The dp bound of an off-diagonal match s (harmless_step): max(6, A from the main matches that end before it, 1 + the bound of a
+// match it can be reached from).  First stage: "a match it can be reached from" = every earlier match of the (x, y) order — one
+// running maximum, no storage, and a bound that grows by one per match: 80 chance matches of a repeat-rich window make the last
+// ones look dangerous whatever they are.  Second stage (LN::TIGHT, a byte per match): only the matches that have ENDED when s
+// starts (x' + K <= x; sdpkpp jumps to a match from matches that end at or before its start — the y condition is dropped: a
+// superset) and its diagonal continuation partner (x - 1, y - 1).  A jump adds at most 1 (gap 0), the continuation exactly 1.
 template <class LN> VTXF_FN bool back_harmless(const Front& fr, int ns, const LN& ln) {
-    int runmax = 0;
-    for (int k = 0; k < ns; ++k) {
-        const uint32_t w = ln.s(k);
-        if (!harmless_step(harmless_item(ln, fr.r, fr.d, fr.best_dp, (int)(w >> LN::XS), (int)(w & LN::YM)), runmax)) return false;
+    if constexpr (LN::TIGHT) {
+        int ended = 0, j = 0;                              // max bound over the matches with x' + K <= x of the current one
+        for (int k = 0; k < ns; ++k) {
+            const uint32_t w = ln.s(k);
+            const int sx = (int)(w >> LN::XS), sy = (int)(w & LN::YM);
+            while (j < k && (int)((uint32_t)ln.s(j) >> LN::XS) + K <= sx) { ended = imax(ended, (int)ln.u(j)); ++j; }
+            const uint32_t at = harmless_item(ln, fr.r, fr.d, fr.best_dp, sx, sy);
+            int dp = imax(K, (int)(at & 0xffu));
+            if (ended) dp = imax(dp, ended + 1);
+            for (int i = k - 1; i >= 0; --i) {             // the partner (sx - 1, sy - 1): among the matches of the previous row
+                const uint32_t wi = ln.s(i);
+                if ((int)(wi >> LN::XS) < sx - 1) break;
+                if (wi + LN::ONE == w) { dp = imax(dp, (int)ln.u(i) + 1); break; }
+            }
+            if (!(dp < (int)(at >> 8))) return false;
+            ln.u(k) = (uint8_t)imin(dp, 255);
+        }
+        return true;
+    } else {
+        int runmax = 0;
+        for (int k = 0; k < ns; ++k) {
+            const uint32_t w = ln.s(k);
+            if (!harmless_step(harmless_item(ln, fr.r, fr.d, fr.best_dp, (int)(w >> LN::XS), (int)(w & LN::YM)), runmax)) return false;
+        }
+        return true;
     }
-    return true;
 }
 template <class LN> VTXF_FN int32_t back_rest(const Front& fr, int ns, const LN& ln, const Lane& gl, uint32_t* why, int ablate,
                                               const Refine* rf, uint32_t* aux);
@@ -761,6 +808,26 @@ template <class LN> VTXF_FN Result fast_task(const uint8_t* x, int m, const Tab&
     const Refine rf{x, tb.gt + tb.bytes, m, n};
     const int32_t sc = back(fr, ns, ln, gl, &why, 0, refine ? &rf : nullptr);
     return Result{sc, why};
+}
+
+// The SECOND stage on one lane (band_diag2_kernel; host test): a task the first stage left because its off-diagonal matches did not
+// fit the lane's list (or did not pass its coarse harmless test).  Verdict: T2_SCORE — cert == ub, the score; T2_TIGHT — every
+// off-diagonal match is harmless, so the reference's chain lies on the main diagonal and the band is band_pack(fr)'s one diagonal
+// stretch (masked DP, no sweep); T2_SWEEP — neither (more matches than the list holds, no diagonal, a match that may matter).
+enum T2Verdict : uint32_t { T2_SCORE = 0, T2_TIGHT = 1, T2_SWEEP = 2 };
+struct Result2 { uint32_t verdict; int32_t score; uint32_t pack; uint32_t why; };
+VTXF_FN Result2 fast_task2(const uint8_t* x, int m, const Tab& tb, int n, const LaneS2& ln, const Lane& gl) {
+    const Front fr = front(x, m, tb, n, ln);
+    if (fr.why != W_OK) return Result2{T2_SWEEP, -1, 0u, fr.why};
+    const int ns = probe_rows(x, tb, fr, ln);
+    if (ns > LaneS2::SMAX) return Result2{T2_SWEEP, -1, 0u, W_MATCHES};
+    back_sort(ns, ln);
+    if (!back_harmless(fr, ns, ln)) return Result2{T2_SWEEP, -1, 0u, W_NOT_HARMLESS};
+    uint32_t why = W_GENERIC;
+    int32_t sc = -1;
+    if (ns <= 64) sc = back_rest(fr, ns, ln, gl, &why, 0, nullptr, nullptr);      // (the closure's bit set holds 64 matches)
+    if (sc >= 0) return Result2{T2_SCORE, sc, 0u, W_OK};
+    return Result2{T2_TIGHT, fr.cert, band_pack(fr), why};
 }
 
 }  // namespace vtxf
