@@ -244,4 +244,28 @@ int vtxt_fastcore2_batch(const vtx_batch* b, uint32_t n_heads, uint8_t* verdict,
     }
     return 0;
 }
+
+// the streaming harmless test against the list version on one read / haplotype (both with the second stage's bounds): returns
+// list_verdict | stream_verdict << 8 | 0x10000 when the list held every match (0xffffffff: front declined); verdicts: 1 harmless, 0 not, 2: -1
+uint32_t vtxt_harmless_stream_vs_list(const uint8_t* x, int m, const uint8_t* y, int n) {
+    using namespace vtxf;
+    const uint32_t max_hap = (uint32_t)std::max(n, 8), n_heads = 1024;
+    std::vector<uint8_t> gt(tab_stride(max_hap, n_heads) + 64);
+    build_table(gt.data(), y, (uint32_t)n, max_hap, n_heads);
+    Tab tb;
+    tb.gt = gt.data(); tb.ent = 0; tb.head = max_hap * 8; tb.bytes = tab_bytes_off(max_hap, n_heads);
+    tb.uq = tab_uq_off(max_hap, n_heads); tb.pb = tab_pb_off(max_hap, n_heads); tb.hmask = n_heads - 1;
+    std::vector<uint8_t> xb((size_t)m + 16, 0);
+    memcpy(xb.data(), x, (size_t)m);
+    uint32_t lane[S2_WORDS + RM];
+    uint8_t ub[LaneS2::SMAX];
+    const LaneS2 ln{lane + S2_WORDS, 1, (uint16_t*)lane, 1, ub, 1};
+    const Front fr = front(xb.data(), m, tb, n, ln);
+    if (fr.why != W_OK) return 0xffffffffu;
+    const int ns = probe_rows(xb.data(), tb, fr, ln);
+    uint32_t lv = 3;
+    if (ns <= LaneS2::SMAX) { back_sort(ns, ln); lv = back_harmless(fr, ns, ln) ? 1u : 0u; }
+    const int sv = probe_harmless_stream(xb.data(), tb, fr, ln);
+    return lv | ((uint32_t)(sv < 0 ? 2 : sv) << 8) | (ns <= LaneS2::SMAX ? 0x10000u : 0u);
+}
 }

@@ -447,3 +447,26 @@ def test_second_stage_on_real_sequence_repeats_and_noise(core):
     d, t, s = tot["real sequence"]
     print("second stage, real sequence: decided %.1f %%, one-diagonal band %.1f %%, left to the sweep %.1f %%" % (100 * d, 100 * t, 100 * s))
     assert s < 0.05 and d > 0.80, tot["real sequence"]           # (the first stage alone leaves 15 % of these tasks)
+
+
+def test_streaming_harmless_test_equals_the_list_version(core):
+    """probe_harmless_stream (a window of the last six rows, for tasks whose matches do not fit the list) must give the verdict of
+    back_harmless over the whole list wherever the list holds every match."""
+    core.vtxt_harmless_stream_vs_list.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    core.vtxt_harmless_stream_vs_list.restype = C.c_uint32
+    from test_sweep_model import tasks_of
+    n = yes = no = 0
+    gens = (SB.real_sequence_batches(trials=1), SB.repeat_rich_batches(trials=3, loci=12, reads=8, pad_range=(60, 120)),
+            SB.near_repeat_batches(trials=2), SB.synthetic_batches(per_model=1, n_loci=12, reads=8))
+    for gen in gens:
+        for label, batch, _nb in gen:
+            if max(int(batch.loci["ref_len"].max()), int(batch.loci["alt_len"].max())) > 255:
+                continue
+            for x, y in tasks_of(batch, 300):
+                r = core.vtxt_harmless_stream_vs_list(x, len(x), y, len(y))
+                if r == 0xffffffff or not (r & 0x10000):
+                    continue
+                lv, sv = r & 0xff, (r >> 8) & 0xff
+                assert sv != 2 and lv == sv, (label, lv, sv, x, y)
+                n += 1; yes += lv; no += 1 - lv
+    assert n > 1500 and yes > 1000 and no > 50, (n, yes, no)

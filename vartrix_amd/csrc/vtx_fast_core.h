@@ -810,6 +810,59 @@ template <class LN> VTXF_FN Result fast_task(const uint8_t* x, int m, const Tab&
     return Result{sc, why};
 }
 
+// The harmless test WITHOUT the list (second stage, tasks with more off-diagonal matches than the list holds): the probes deliver
+// the matches in (x, y) order, and the bound of a match needs only (a) the running maximum over the matches that have ended
+// (x' + K <= x) and (b) its partner in the previous row — so a WINDOW of the matches of the last six rows is all that has to be
+// kept: they are folded into the running maximum as their rows fall K behind.  Same bounds, same verdict as back_harmless with
+// LN::TIGHT on a list that holds everything (tests/test_fastcore.py checks the two against each other).  Returns 1: every match
+// harmless; 0: one is not; -1: more than SMAX matches inside six rows.
+VTXF_FN int probe_harmless_stream(const uint8_t* x, const Tab& tb, const Front& fr, const LaneS2& ln) {
+    constexpr int SM = LaneS2::SMAX;
+    const uint8_t* head = tb.gt + tb.head;
+    const uint32_t* pb = (const uint32_t*)(tb.gt + tb.pb);
+    M192 need = fr.need;
+    int h = 0, cnt = 0, ended = 0, verdict = 1;             // the window: entries h .. h + cnt - 1 (mod SM) of ln.s / ln.u
+    while (m_any(need) && verdict == 1) {
+        int row[4];
+        uint64_t w8[4];
+        uint32_t code[4], bits[4];
+        for (int t = 0; t < 4; ++t) row[t] = m_pop_lowest(need);
+        for (int t = 0; t < 4; ++t) w8[t] = ld8(x + (row[t] < 192 ? row[t] : 0));
+        for (int t = 0; t < 4; ++t) {
+            code[t] = kw_code((uint32_t)w8[t], (uint32_t)(w8[t] >> 32) & 0xffffu);
+            bits[t] = pb[code[t] >> 5];
+        }
+        for (int t = 0; t < 4 && verdict == 1; ++t) {
+            if (row[t] >= 192 || !((bits[t] >> (code[t] & 31u)) & 1u)) continue;       // not a k-mer of this haplotype
+            const int sx = row[t];
+            while (cnt && (int)((uint32_t)ln.s(h) >> 8) + K <= sx) {                   // matches that have ended by this row
+                ended = imax(ended, (int)ln.u(h));
+                h = h + 1 == SM ? 0 : h + 1; --cnt;
+            }
+            const uint32_t hh = kw_mix((uint32_t)w8[t], (uint32_t)(w8[t] >> 32) & 0xffffu);
+            walk_bucket(tb, w8[t], hh, ld2(head + 2u * kw_bucket(hh, tb.hmask)), [&](uint32_t yc) {
+                if ((int)yc - sx == fr.d || verdict != 1) return;
+                const uint32_t w = ((uint32_t)sx << 8) | yc;
+                const uint32_t at = harmless_item(ln, fr.r, fr.d, fr.best_dp, sx, (int)yc);
+                int dp = imax(K, (int)(at & 0xffu));
+                if (ended) dp = imax(dp, ended + 1);
+                for (int i = cnt - 1; i >= 0; --i) {                                  // the partner (sx - 1, yc - 1): newest entries first
+                    int k = h + i; k = k >= SM ? k - SM : k;
+                    const uint32_t wi = ln.s(k);
+                    if ((int)(wi >> 8) < sx - 1) break;
+                    if (wi + 0x101u == w) { dp = imax(dp, (int)ln.u(k) + 1); break; }
+                }
+                if (!(dp < (int)(at >> 8))) { verdict = 0; return; }
+                if (cnt == SM) { verdict = -1; return; }
+                int k = h + cnt; k = k >= SM ? k - SM : k;
+                ln.s(k) = (uint16_t)w; ln.u(k) = (uint8_t)imin(dp, 255);
+                ++cnt;
+            });
+        }
+    }
+    return verdict;
+}
+
 // The SECOND stage on one lane (band_diag2_kernel; host test): a task the first stage left because its off-diagonal matches did not
 // fit the lane's list (or did not pass its coarse harmless test).  Verdict: T2_SCORE — cert == ub, the score; T2_TIGHT — every
 // off-diagonal match is harmless, so the reference's chain lies on the main diagonal and the band is band_pack(fr)'s one diagonal
@@ -820,7 +873,12 @@ VTXF_FN Result2 fast_task2(const uint8_t* x, int m, const Tab& tb, int n, const 
     const Front fr = front(x, m, tb, n, ln);
     if (fr.why != W_OK) return Result2{T2_SWEEP, -1, 0u, fr.why};
     const int ns = probe_rows(x, tb, fr, ln);
-    if (ns > LaneS2::SMAX) return Result2{T2_SWEEP, -1, 0u, W_MATCHES};
+    if (ns > LaneS2::SMAX) {
+        // more matches than the list holds: the harmless test alone, over a window of the last six rows (the probes run again)
+        const int v = probe_harmless_stream(x, tb, fr, ln);
+        if (v == 1) return Result2{T2_TIGHT, fr.cert, band_pack(fr), W_MATCHES};
+        return Result2{T2_SWEEP, -1, 0u, v == 0 ? W_NOT_HARMLESS : W_MATCHES};
+    }
     back_sort(ns, ln);
     if (!back_harmless(fr, ns, ln)) return Result2{T2_SWEEP, -1, 0u, W_NOT_HARMLESS};
     uint32_t why = W_GENERIC;
