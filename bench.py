@@ -406,7 +406,7 @@ def main():
             sensitivity[name] = {"workload": sspec.name + (", padding %d" % sspec.padding if sspec.padding != 100 else ""), "alignments_per_step": 2 * sb.n_records, "steps": args.sensitivity_steps,
                                  "ms_per_step": 1e3 * dts, "value": 2 * sb.n_records / dts, "unit": "read-alignments/s",
                                  "left_by_certificate_stages": int(st.diag_left), "full_matrix_checked": int(st.checked_tasks),
-                                 "second_stage": int(st.diag2_tasks), "second_stage_scored": int(st.diag2_scored),
+                                 "second_stage": int(st.diag2_tasks), "second_stage_scored": int(st.diag2_scored), "second_stage_streamed": int(st.diag2_streamed),
                                  "swept": int(st.swept_tasks), "masked_dp_tasks": int(st.hard_tasks), "declined_by_sweep": int(st.overflow_tasks),
                                  "diag_ms": float(st.diag_ms), "check_ms": float(st.check_ms), "sweep_and_dp_ms": float(st.sweep_ms)}
             sctx.close()
@@ -484,7 +484,7 @@ def main():
                        "band_run_kernel_ms": max(run_avg_ms - diag_avg_ms, 0.0), "band_diag_ms": diag_avg_ms,
                        "full_matrix_check_ms": float(np.mean(check_ms)), "sweep_and_masked_dp_ms": float(np.mean(sweep_ms)),
                        "checked_tasks": int(ctx.timing().checked_tasks), "swept_tasks": int(ctx.timing().swept_tasks),
-                       "second_stage_tasks": int(ctx.timing().diag2_tasks), "second_stage_scored": int(ctx.timing().diag2_scored),
+                       "second_stage_tasks": int(ctx.timing().diag2_tasks), "second_stage_scored": int(ctx.timing().diag2_scored), "second_stage_streamed": int(ctx.timing().diag2_streamed),
                        "diag_left_tasks": int(ctx.timing().diag_left), "reduce_ms": float(np.mean(red_ms)), "submit_h2d_s": t_sub,
                        "generate_s": t_gen, "hard_tasks": int(ctx.timing().hard_tasks),
                        "overflow_tasks": int(ctx.timing().overflow_tasks),

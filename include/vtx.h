@@ -173,6 +173,7 @@ typedef struct vtx_timing {
                               more off-diagonal matches than its list holds) ...                                              */
     uint32_t diag2_scored; /* ... of which it decided outright (cert == ub); the rest of them is in checked_tasks (one-diagonal
                               band) or swept_tasks                                                                            */
+    uint32_t diag2_streamed; /* ... and how many exceeded its list and took band_stream_kernel (the harmless test over a window)       */
 } vtx_timing;
 
 typedef struct vtx_ctx vtx_ctx;

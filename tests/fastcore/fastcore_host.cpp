@@ -247,7 +247,7 @@ int vtxt_fastcore2_batch(const vtx_batch* b, uint32_t n_heads, uint8_t* verdict,
 
 // the streaming harmless test against the list version on one read / haplotype (both with the second stage's bounds): returns
 // list_verdict | stream_verdict << 8 | 0x10000 when the list held every match (0xffffffff: front declined); verdicts: 1 harmless, 0 not, 2: -1
-uint32_t vtxt_harmless_stream_vs_list(const uint8_t* x, int m, const uint8_t* y, int n) {
+uint32_t vtxt_harmless_stream_vs_list(const uint8_t* x, int m, const uint8_t* y, int n, int win) {
     using namespace vtxf;
     const uint32_t max_hap = (uint32_t)std::max(n, 8), n_heads = 1024;
     std::vector<uint8_t> gt(tab_stride(max_hap, n_heads) + 64);
@@ -265,7 +265,7 @@ uint32_t vtxt_harmless_stream_vs_list(const uint8_t* x, int m, const uint8_t* y,
     const int ns = probe_rows(xb.data(), tb, fr, ln);
     uint32_t lv = 3;
     if (ns <= LaneS2::SMAX) { back_sort(ns, ln); lv = back_harmless(fr, ns, ln) ? 1u : 0u; }
-    const int sv = probe_harmless_stream(xb.data(), tb, fr, ln);
+    const int sv = probe_harmless_stream(xb.data(), tb, fr, ln, win > 0 ? win : LaneS2::SMAX / 2);
     return lv | ((uint32_t)(sv < 0 ? 2 : sv) << 8) | (ns <= LaneS2::SMAX ? 0x10000u : 0u);
 }
 }

@@ -452,7 +452,7 @@ def test_second_stage_on_real_sequence_repeats_and_noise(core):
 def test_streaming_harmless_test_equals_the_list_version(core):
     """probe_harmless_stream (a window of the last six rows, for tasks whose matches do not fit the list) must give the verdict of
     back_harmless over the whole list wherever the list holds every match."""
-    core.vtxt_harmless_stream_vs_list.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    core.vtxt_harmless_stream_vs_list.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int]
     core.vtxt_harmless_stream_vs_list.restype = C.c_uint32
     from test_sweep_model import tasks_of
     n = yes = no = 0
@@ -463,7 +463,7 @@ def test_streaming_harmless_test_equals_the_list_version(core):
             if max(int(batch.loci["ref_len"].max()), int(batch.loci["alt_len"].max())) > 255:
                 continue
             for x, y in tasks_of(batch, 300):
-                r = core.vtxt_harmless_stream_vs_list(x, len(x), y, len(y))
+                r = core.vtxt_harmless_stream_vs_list(x, len(x), y, len(y), 0)
                 if r == 0xffffffff or not (r & 0x10000):
                     continue
                 lv, sv = r & 0xff, (r >> 8) & 0xff

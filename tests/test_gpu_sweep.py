@@ -306,7 +306,7 @@ batches = list(SB.real_sequence_batches(trials=2)) + list(SB.repeat_rich_batches
 batches += list(SB.near_repeat_batches(trials=2)) + list(SB.real_shape_batches(trials=1))
 batches += [("real sequence, deep", synth.make_batch(synth.SynthSpec(n_loci=400, n_barcodes=500, reads_per_locus=48, seed=4,
              genome_fasta=os.path.join(%r, "tests", "golden", "test_dna.fa"))), 500)]
-looked = scored = 0
+looked = scored = streamed = 0
 for label, batch, nb in batches:
     out = {}
     for aligner in ("banded", "full"):
@@ -321,18 +321,34 @@ for label, batch, nb in batches:
     oref, oalt = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=nb), threads=os.cpu_count() or 8)
     bad = np.nonzero((rb != oref) | (ab != oalt))[0]
     assert bad.size == 0, (label, int(bad[0]), int(rb[bad[0]]), int(oref[bad[0]]), int(ab[bad[0]]), int(oalt[bad[0]]), stage[2 * bad[0]:2 * bad[0] + 2].tolist())
-    looked += t.diag2_tasks; scored += t.diag2_scored
-    print(label, "second stage looked at", t.diag2_tasks, "scored", t.diag2_scored, "one-diagonal bands", t.checked_tasks, "swept", t.swept_tasks, file=sys.stderr)
+    looked += t.diag2_tasks; scored += t.diag2_scored; streamed += t.diag2_streamed
+    print(label, "second stage looked at", t.diag2_tasks, "scored", t.diag2_scored, "streamed", t.diag2_streamed, "one-diagonal bands", t.checked_tasks, "swept", t.swept_tasks, file=sys.stderr)
+    np.save(os.path.join(sys.argv[1], "s%%d.npy" %% len(os.listdir(sys.argv[1]))), np.concatenate([rb, ab]))
 assert looked > 3000 and scored > 300, (looked, scored)
-print("second-stage-ok", looked, scored)
+if not os.environ.get("VTX_BAND_NO_STREAM"):
+    assert streamed > 300, streamed
+else:
+    assert streamed == 0
+print("second-stage-ok", looked, scored, streamed)
 ''' % (ROOT, HERE, ROOT)
 
 
 def test_second_stage_against_the_oracle():
     """band_diag2_kernel forced on every list (libvtx_dev.so, VTX_BAND_DIAG2_MIN=1) on real-sequence loci, tandem repeats, near repeats
     and real-read shapes: every score is the oracle's, banded != full only on DP stages, no score is left unwritten (poisoned
-    arrays), and the stage really takes tasks (thousands looked at, hundreds scored outright)."""
-    p = subprocess.run([sys.executable, "-c", CODE2], env=dict(os.environ, VTX_LIB_VARIANT="dev", VTX_BAND_DIAG2_MIN="1"),
-                       capture_output=True, text=True, timeout=1500)
-    assert p.returncode == 0 and "second-stage-ok" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
-    print(p.stderr.strip().replace("\n", " | "))
+    arrays), and the stage really takes tasks (thousands looked at, hundreds scored outright, hundreds through band_stream_kernel).
+    A second run with VTX_BAND_NO_STREAM=1 (what exceeds the list goes to the sweep, as before band_stream_kernel existed): the same."""
+    with tempfile.TemporaryDirectory() as td:
+        for no_stream in (0, 1):
+            env = dict(os.environ, VTX_LIB_VARIANT="dev", VTX_BAND_DIAG2_MIN="1")
+            env.pop("VTX_BAND_NO_STREAM", None)
+            if no_stream:
+                env["VTX_BAND_NO_STREAM"] = "1"
+            d = os.path.join(td, str(no_stream)); os.mkdir(d)
+            p = subprocess.run([sys.executable, "-c", CODE2, d], env=env, capture_output=True, text=True, timeout=1500)
+            assert p.returncode == 0 and "second-stage-ok" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+            print(p.stderr.strip().replace("\n", " | "))
+        files = sorted(os.listdir(os.path.join(td, "0")))
+        assert files and files == sorted(os.listdir(os.path.join(td, "1")))
+        for f in files:
+            assert np.array_equal(np.load(os.path.join(td, "0", f)), np.load(os.path.join(td, "1", f))), f

@@ -61,8 +61,8 @@ def main():
         print("  MISMATCHES device vs oracle: %d%s" % (int(bad.sum()), "" if not bad.any() else
               "  by stage %s, first at task %d: device %d oracle %d" % (stage_report(stage[bad]), int(np.nonzero(bad)[0][0]),
                                                                         int(b[bad][0]), int(o[bad][0]))))
-        print("  left by the first certificate stage %d, second stage looked at %d (scored %d), one-diagonal bands %d, swept %d, general kernel %d" % (
-            t.diag_left, t.diag2_tasks, t.diag2_scored, t.checked_tasks, t.swept_tasks, t.overflow_tasks), flush=True)
+        print("  left by the first certificate stage %d, second stage looked at %d (scored %d, %d through band_stream_kernel), one-diagonal bands %d, swept %d, general kernel %d" % (
+            t.diag_left, t.diag2_tasks, t.diag2_scored, t.diag2_streamed, t.checked_tasks, t.swept_tasks, t.overflow_tasks), flush=True)
         assert not bad.any()
 
 

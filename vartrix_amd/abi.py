@@ -127,6 +127,7 @@ class VtxTiming(C.Structure):
         ("resweep_tasks", C.c_uint32),
         ("diag2_tasks", C.c_uint32),
         ("diag2_scored", C.c_uint32),
+        ("diag2_streamed", C.c_uint32),
     ]
 
 

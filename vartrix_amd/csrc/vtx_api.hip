@@ -110,7 +110,7 @@ struct vtx_ctx {
     uint64_t gt_used = 0;      // bytes of d_gtables the last banded run's table kernel wrote (vtx_debug_tables)
     DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail, d_fail_tmp, d_refine;   // banded flavour
     DevBuf d_tight2, d_tight2_pack;                                          // band_diag2_kernel: tasks whose band is one diagonal stretch after all
-    DevBuf d_recheck2, d_recheck2_pack;                                      // ... of which the full-matrix check did not settle (full != certificate)
+    DevBuf d_recheck2, d_recheck2_pack;                                      // ... of which the full-matrix check did not settle (full != certificate); d_recheck2 first holds band_stream_kernel's task list
     DevBuf d_sweep_log;                                                      // band_sweep_kernel: the section logs of the resident workgroups (64 MB)
     DevBuf d_tight, d_tight_pack, d_dband, d_dband_pack, d_dense, d_stage;                                                 // round 4: tasks with a provisional score (full-matrix check); stage bytes (vtx_fetch_stage)
     bool stage_trace = false, poison = false;                                // test / audit hooks (vtx_set_debug)
@@ -1178,7 +1178,7 @@ int vtx_run(vtx_ctx* c) {
         HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 64 * sizeof(uint32_t), s));
         uint32_t cnt[12] = {0};
         uint32_t pending_total = 0, over_before = 0;
-        uint64_t diag_total = 0, diag_left = 0, refined_total = 0, checked_total = 0, swept_total = 0, diag2_total = 0, diag2_scored = 0, tight2_total = 0;
+        uint64_t diag_total = 0, diag_left = 0, refined_total = 0, checked_total = 0, swept_total = 0, diag2_total = 0, diag2_scored = 0, tight2_total = 0, stream_total = 0;
         float diag_ms = 0, check_ms = 0, sweep_ms = 0;
         // the band of every listed task (band_sweep_kernel, tier 0 / 1), one slice of band slots at a time, then the masked DP over
         // the slice (its length — the tasks the sweep did not decline — is read on the device: counters[0]; declined: counters[1])
@@ -1381,14 +1381,20 @@ int vtx_run(vtx_ctx* c) {
                         uint32_t n_sweep = n_dense;
                         if (!no_diag2 && n_dense >= diag2_min) {
                             uint32_t* sweep2 = (dl == dense_list) ? dense_list + nt : dense_list;          // (the half of d_dense the list is not in)
+                            // (libvtx_dev.so: VTX_BAND_NO_STREAM=1 — what exceeds the second stage's list goes to the sweep)
+                            static const bool no_stream = VTX_DEV_ENV("VTX_BAND_NO_STREAM") != nullptr;
                             HIP_TRY(c, hipMemsetAsync(d_cnt + 30, 0, 2 * sizeof(uint32_t), s));
+                            HIP_TRY(c, hipMemsetAsync(d_cnt + 48, 0, sizeof(uint32_t), s));
                             HIP_TRY(c, vtxk_launch_band_diag2(dl, n_dense, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
                                                               c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
                                                               c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), tasks_per_locus, gt_l0,
                                                               c->d_gtables.as<uint8_t>(), sweep2, c->d_tight2.as<uint32_t>(),
-                                                              c->d_tight2_pack.as<uint32_t>(), d_cnt + 30, stage, s));
+                                                              c->d_tight2_pack.as<uint32_t>(), d_cnt + 30,
+                                                              no_stream ? nullptr : c->d_recheck2.as<uint32_t>(), d_cnt + 48, stage, s));
                             HIP_TRY(c, hipMemcpyAsync(c->h_pin + 14, d_cnt + 30, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                            HIP_TRY(c, hipMemcpyAsync(c->h_pin + 16, d_cnt + 48, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                             HIP_TRY(c, hipStreamSynchronize(s));
+                            stream_total += std::min(c->h_pin[16], n_dense);
                             n_sweep = std::min(c->h_pin[14], n_dense);
                             const uint32_t n_tight2 = std::min(c->h_pin[15], n_dense - n_sweep);
                             sl = sweep2;
@@ -1585,6 +1591,7 @@ int vtx_run(vtx_ctx* c) {
         c->timing.resweep_tasks = resweep_total;
         c->timing.diag2_tasks = (uint32_t)std::min<uint64_t>(diag2_total, 0xffffffffull);
         c->timing.diag2_scored = (uint32_t)std::min<uint64_t>(diag2_scored, 0xffffffffull);
+        c->timing.diag2_streamed = (uint32_t)std::min<uint64_t>(stream_total, 0xffffffffull);
         checked_total += tight2_total;                     // (one-diagonal bands of the second stage: the same masked DP)
         c->timing.checked_tasks = (uint32_t)std::min<uint64_t>(checked_total, 0xffffffffull);
         if (swept_total) hard_total += (uint32_t)std::min<uint64_t>(swept_total - std::min<uint64_t>(swept_total, fast_overflow), 0xffffffffull);
@@ -1598,9 +1605,9 @@ int vtx_run(vtx_ctx* c) {
                     why[1], why[2], why[3], why[4], why[5], why[7], why[8], why[9]);
         }
         if (getenv("VTX_DEBUG") && diag2_total)
-            fprintf(stderr, "[vtx] band_diag2_kernel: %llu tasks looked at, %llu scored, %llu left with a one-diagonal band, %llu to band_sweep_kernel\n",
+            fprintf(stderr, "[vtx] band_diag2_kernel: %llu tasks looked at, %llu scored, %llu left with a one-diagonal band, %llu to band_sweep_kernel (%llu through band_stream_kernel)\n",
                     (unsigned long long)diag2_total, (unsigned long long)diag2_scored, (unsigned long long)tight2_total,
-                    (unsigned long long)(diag2_total - diag2_scored - tight2_total));
+                    (unsigned long long)(diag2_total - diag2_scored - tight2_total), (unsigned long long)stream_total);
         if (getenv("VTX_DEBUG")) fprintf(stderr, "[vtx] banded: %llu tasks, %u overflowed band_run_kernel, %u bounded by the pending kernel, %u hard\n", (unsigned long long)n_tasks, fast_overflow, pending_total, hard_total);
     }
     if (c->slow_cnt) {

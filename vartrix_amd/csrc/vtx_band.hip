@@ -2607,7 +2607,7 @@ extern "C" hipError_t vtxk_launch_band_refine(const uint32_t* recs, uint32_t n_r
 // (vtxf::fast_task2: its own probes, no pooling): 7 M tasks, not 49 M.  Per lane 104 words of LDS (60 list, 8 pieces, 30 bound bytes,
 // 6 generic pieces): 26.6 KB per wavefront.
 // Output: T2_SCORE -> the score (stage 1); T2_TIGHT -> tight_list / tight_pack at counters[1] (provisional score = the certificate);
-// T2_SWEEP -> sweep_list at counters[0].
+// T2_SWEEP -> sweep_list at counters[0]; T2_STREAM (more than 120 matches) -> stream_list at *stream_cnt: band_stream_kernel.
 constexpr int D2_LANE_WORDS = vtxf::S2_WORDS + vtxf::RM + vtxf::LaneS2::SMAX / 4 + vtxf::GM;
 __global__ __launch_bounds__(64) void band_diag2_kernel(
     const uint32_t* __restrict__ tasks, uint32_t n_tasks,
@@ -2615,7 +2615,7 @@ __global__ __launch_bounds__(64) void band_diag2_kernel(
     const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
     const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ sweep_list, uint32_t* __restrict__ tight_list, uint32_t* __restrict__ tight_pack,
-    uint32_t* __restrict__ counters, uint8_t* __restrict__ stage) {
+    uint32_t* __restrict__ stream_list, uint32_t* __restrict__ stream_cnt, uint32_t* __restrict__ counters, uint8_t* __restrict__ stage) {
     __shared__ uint32_t mem[D2_LANE_WORDS * 64];
     const int tid = (int)threadIdx.x;
     const uint32_t slot = blockIdx.x * 64u + (uint32_t)tid;
@@ -2639,10 +2639,63 @@ __global__ __launch_bounds__(64) void band_diag2_kernel(
         const vtxf::LaneS2 ln{base + vtxf::S2_WORDS * 64, 64, (uint16_t*)mem + tid, 64,
                               (uint8_t*)(mem + (vtxf::S2_WORDS + vtxf::RM) * 64) + tid, 64};
         const vtxf::Lane gl{base + (vtxf::S2_WORDS + vtxf::RM + vtxf::LaneS2::SMAX / 4) * 64, 64};
-        const vtxf::Result2 r = vtxf::fast_task2(read_arena + rec.read_off, m, tb, n, ln, gl);
+        vtxf::Result2 r = vtxf::fast_task2_list(read_arena + rec.read_off, m, tb, n, ln, gl);
+        if (r.verdict == vtxf::T2_STREAM && !stream_list) r.verdict = vtxf::T2_SWEEP;
         verdict = r.verdict; pack = r.pack;
-        if (verdict != vtxf::T2_SWEEP) (hap ? alt_score : ref_score)[rid] = r.score;     // final (T2_SCORE) or provisional: the certificate
+        if (verdict <= vtxf::T2_TIGHT) (hap ? alt_score : ref_score)[rid] = r.score;     // final (T2_SCORE) or provisional: the certificate
         if (verdict == vtxf::T2_SCORE && stage) stage[task] = 1;
+    }
+    const uint64_t sm = __ballot(verdict == vtxf::T2_SWEEP), tm = __ballot(verdict == vtxf::T2_TIGHT), rm = __ballot(verdict == vtxf::T2_STREAM);
+    uint32_t sbase = 0, tbase = 0, rbase = 0;
+    if (tid == 0) {
+        if (sm) sbase = atomicAdd(&counters[0], (uint32_t)__popcll(sm));
+        if (tm) tbase = atomicAdd(&counters[1], (uint32_t)__popcll(tm));
+        if (rm) rbase = atomicAdd(stream_cnt, (uint32_t)__popcll(rm));
+    }
+    sbase = (uint32_t)__shfl((int)sbase, 0); tbase = (uint32_t)__shfl((int)tbase, 0); rbase = (uint32_t)__shfl((int)rbase, 0);
+    const uint64_t below = (1ull << tid) - 1ull;
+    if (verdict == vtxf::T2_SWEEP) sweep_list[sbase + (uint32_t)__popcll(sm & below)] = task;
+    else if (verdict == vtxf::T2_TIGHT) { const uint32_t pos = tbase + (uint32_t)__popcll(tm & below); tight_list[pos] = task; tight_pack[pos] = pack; }
+    else if (verdict == vtxf::T2_STREAM) stream_list[rbase + (uint32_t)__popcll(rm & below)] = task;
+}
+
+// band_stream_kernel: the tasks band_diag2_kernel's list could not hold (heavy repeats: hundreds of off-diagonal matches).  Whether
+// every one of them is harmless does not need the list: vtxf::probe_harmless_stream keeps the matches of two rows and a running
+// maximum.  One lane per task; per lane 40 words of LDS (64 window entries, 8 pieces): 10 KB per wavefront, so that the dependent
+// loads of the bucket walks overlap across many wavefronts.  T2_TIGHT -> tight_list / tight_pack at counters[1] (after
+// band_diag2_kernel's entries), T2_SWEEP -> sweep_list at counters[0].  *n_dev tasks (a device count: no host round trip between the two).
+constexpr int ST_LANE_WORDS = vtxf::WIN_WORDS + vtxf::RM;
+__global__ __launch_bounds__(64) void band_stream_kernel(
+    const uint32_t* __restrict__ tasks, const uint32_t* __restrict__ n_dev,
+    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
+    const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
+    const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
+    uint32_t* __restrict__ sweep_list, uint32_t* __restrict__ tight_list, uint32_t* __restrict__ tight_pack,
+    uint32_t* __restrict__ counters) {
+    __shared__ uint32_t mem[ST_LANE_WORDS * 64];
+    const int tid = (int)threadIdx.x;
+    const uint32_t slot = blockIdx.x * 64u + (uint32_t)tid;
+    const uint32_t n_tasks = *n_dev;
+    if (blockIdx.x * 64u >= n_tasks) return;
+    uint32_t verdict = 3u, task = 0, pack = 0;
+    if (slot < n_tasks) {
+        task = tasks[slot];
+        const uint32_t rid = task >> 1, hap = task & 1u;
+        const vtx_record rec = records[rid];
+        const uint32_t my_locus = rec_locus[rid];
+        const vtx_locus loc = loci[my_locus];
+        const int m = (int)rec.read_len, n = (int)(hap ? loc.alt_len : loc.ref_len);
+        vtxf::Tab tb;
+        tb.gt = gtables; tb.hmask = n_heads - 1;
+        tb.ent = (uint32_t)(((size_t)(my_locus - gt_l0) * 2 + hap) * table_stride);
+        tb.head = tb.ent + max_hap * 8u;
+        tb.bytes = tb.ent + vtxf::tab_bytes_off(max_hap, n_heads);
+        tb.uq = tb.ent + vtxf::tab_uq_off(max_hap, n_heads);
+        tb.pb = tb.ent + vtxf::tab_pb_off(max_hap, n_heads);
+        const vtxf::LaneW wl{mem + vtxf::WIN_WORDS * 64 + tid, 64, (uint16_t*)mem + tid, 64, nullptr, 0};      // window entries, pieces
+        const vtxf::Result2 r = vtxf::fast_task2_stream(read_arena + rec.read_off, m, tb, n, wl);
+        verdict = r.verdict; pack = r.pack;
+        if (verdict == vtxf::T2_TIGHT) (hap ? alt_score : ref_score)[rid] = r.score;     // provisional: the certificate
     }
     const uint64_t sm = __ballot(verdict == vtxf::T2_SWEEP), tm = __ballot(verdict == vtxf::T2_TIGHT);
     uint32_t sbase = 0, tbase = 0;
@@ -2656,19 +2709,26 @@ __global__ __launch_bounds__(64) void band_diag2_kernel(
     else if (verdict == vtxf::T2_TIGHT) { const uint32_t pos = tbase + (uint32_t)__popcll(tm & below); tight_list[pos] = task; tight_pack[pos] = pack; }
 }
 
-// band_diag2_kernel over a task list (the tables are the ones vtxk_launch_band_diag built for the chunk); counters[0] / [1]: sweep / tight
+// band_diag2_kernel (+ band_stream_kernel when stream_list != nullptr) over a task list (the tables are the ones vtxk_launch_band_diag
+// built for the chunk); counters[0] / [1]: sweep / tight; *stream_cnt: the tasks that went through band_stream_kernel
 extern "C" hipError_t vtxk_launch_band_diag2(const uint32_t* tasks, uint32_t n_tasks, const vtx_record* records, const uint32_t* rec_locus,
                                              const vtx_locus* loci, const uint8_t* read_arena, uint32_t max_hap, int32_t* ref_score,
                                              int32_t* alt_score, uint32_t tasks_per_locus, uint32_t gt_l0, const uint8_t* gtables,
                                              uint32_t* sweep_list, uint32_t* tight_list, uint32_t* tight_pack, uint32_t* counters,
-                                             uint8_t* stage, hipStream_t s) {
+                                             uint32_t* stream_list, uint32_t* stream_cnt, uint8_t* stage, hipStream_t s) {
     if (!n_tasks) return hipSuccess;
     if (max_hap > 255) return hipErrorInvalidValue;                  // (two-byte list entries)
     const uint32_t n_heads = pick_heads(tasks_per_locus, true);
     const size_t tstride = band_table_stride(max_hap, n_heads);
     hipLaunchKernelGGL(band_diag2_kernel, dim3((n_tasks + 63) / 64), dim3(64), 0, s, tasks, n_tasks, records, rec_locus, loci, read_arena,
                        max_hap, (uint32_t)tstride, n_heads, gtables, gt_l0, ref_score, alt_score, sweep_list, tight_list, tight_pack,
-                       counters, stage);
+                       stream_list, stream_cnt, counters, stage);
+    if (stream_list) {
+        // (*stream_cnt <= n_tasks tasks: workgroups past the count leave at once)
+        hipLaunchKernelGGL(band_stream_kernel, dim3((n_tasks + 63) / 64), dim3(64), 0, s, stream_list, stream_cnt, records, rec_locus, loci,
+                           read_arena, max_hap, (uint32_t)tstride, n_heads, gtables, gt_l0, ref_score, alt_score, sweep_list, tight_list,
+                           tight_pack, counters);
+    }
     return hipGetLastError();
 }
 

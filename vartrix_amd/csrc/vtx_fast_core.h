@@ -283,19 +283,25 @@ template <class ST, int SW = S_WORDS> struct LaneS {
 #define VTXF_S2_WORDS 60
 #endif
 constexpr int S2_WORDS = VTXF_S2_WORDS;   // 120 entries (back_rest's closure is only asked for <= 64 of them: its bit set and byte counters)
-struct LaneS2 {
+template <int W> struct LaneS2T {
     typedef uint16_t SType;
     uint32_t* base; int stride;
     uint16_t* sb; int sstride;
     uint8_t* ub; int ustride;
     static constexpr int XS = 8;
-    static constexpr int SMAX = S2_WORDS * 2;
+    static constexpr int SMAX = W * 2;
     static constexpr uint32_t YM = 0xffu, ONE = 0x101u;
     static constexpr bool TIGHT = true;
     VTXF_MEM uint32_t& at(int i) const { return base[i * stride]; }
     VTXF_MEM uint16_t& s(int k) const { return sb[k * sstride]; }
     VTXF_MEM uint8_t& u(int k) const { return ub[k * ustride]; }
 };
+typedef LaneS2T<S2_WORDS> LaneS2;
+#ifndef VTXF_WIN_WORDS
+#define VTXF_WIN_WORDS 32
+#endif
+constexpr int WIN_WORDS = VTXF_WIN_WORDS;  // band_stream_kernel's window: 64 entries
+typedef LaneS2T<WIN_WORDS> LaneW;
 
 struct Front {
     uint32_t why;           // W_OK: go on with the probes
@@ -810,54 +816,64 @@ template <class LN> VTXF_FN Result fast_task(const uint8_t* x, int m, const Tab&
     return Result{sc, why};
 }
 
-// The harmless test WITHOUT the list (second stage, tasks with more off-diagonal matches than the list holds): the probes deliver
-// the matches in (x, y) order, and the bound of a match needs only (a) the running maximum over the matches that have ended
-// (x' + K <= x) and (b) its partner in the previous row — so a WINDOW of the matches of the last six rows is all that has to be
-// kept: they are folded into the running maximum as their rows fall K behind.  Same bounds, same verdict as back_harmless with
-// LN::TIGHT on a list that holds everything (tests/test_fastcore.py checks the two against each other).  Returns 1: every match
-// harmless; 0: one is not; -1: more than SMAX matches inside six rows.
-VTXF_FN int probe_harmless_stream(const uint8_t* x, const Tab& tb, const Front& fr, const LaneS2& ln) {
-    constexpr int SM = LaneS2::SMAX;
+// The harmless test WITHOUT the list (band_stream_kernel: tasks with more off-diagonal matches than the second stage's list holds).
+// The probes deliver the matches row by row, and the bound of a match needs only (a) the maximum over the matches that have ended
+// (x' + K <= x): a running maximum, fed from the maxima of the last rows (a byte per row, eight rows in one 64-bit word) as they fall
+// K behind, and (b) its partner in the previous row: the (y, bound) pairs of TWO rows are all that is kept (ln.s: y | bound << 8,
+// two halves of SMAX / 2 entries that swap roles).  Same bounds, same verdict as back_harmless with LN::TIGHT on a list that holds
+// everything (tests/test_fastcore.py checks the two against each other).  Returns 1: every match harmless; 0: one is not;
+// -1: a row with more than `cap` matches.
+template <class LN> VTXF_FN int probe_harmless_stream(const uint8_t* x, const Tab& tb, const Front& fr, const LN& ln, int cap = LN::SMAX / 2) {
+    constexpr int HALF = LN::SMAX / 2;
     const uint8_t* head = tb.gt + tb.head;
     const uint32_t* pb = (const uint32_t*)(tb.gt + tb.pb);
     M192 need = fr.need;
-    int h = 0, cnt = 0, ended = 0, verdict = 1;             // the window: entries h .. h + cnt - 1 (mod SM) of ln.s / ln.u
+    uint64_t rowmax = 0;                  // byte r & 7: the largest bound among the matches of row r, for the rows that have not ended yet
+    int folded = -1;                      // rows <= folded are in `ended`
+    int ended = 0, verdict = 1;
+    int cur = 0, cn = 0, pn = 0, crow = -2;     // the current row's entries: ln.s(cur * HALF + i), i < cn; the previous row's: the other half, pn
     while (m_any(need) && verdict == 1) {
         int row[4];
         uint64_t w8[4];
-        uint32_t code[4], bits[4];
+        uint32_t code[4], bits[4], raw[4];
         for (int t = 0; t < 4; ++t) row[t] = m_pop_lowest(need);
         for (int t = 0; t < 4; ++t) w8[t] = ld8(x + (row[t] < 192 ? row[t] : 0));
         for (int t = 0; t < 4; ++t) {
             code[t] = kw_code((uint32_t)w8[t], (uint32_t)(w8[t] >> 32) & 0xffffu);
             bits[t] = pb[code[t] >> 5];
+            raw[t] = ld2(head + 2u * kw_bucket(kw_mix((uint32_t)w8[t], (uint32_t)(w8[t] >> 32) & 0xffffu), tb.hmask));
         }
         for (int t = 0; t < 4 && verdict == 1; ++t) {
             if (row[t] >= 192 || !((bits[t] >> (code[t] & 31u)) & 1u)) continue;       // not a k-mer of this haplotype
             const int sx = row[t];
-            while (cnt && (int)((uint32_t)ln.s(h) >> 8) + K <= sx) {                   // matches that have ended by this row
-                ended = imax(ended, (int)ln.u(h));
-                h = h + 1 == SM ? 0 : h + 1; --cnt;
+            for (int r = imax(folded + 1, sx - K - 7); r <= sx - K; ++r) {             // rows that have ended by this one
+                const int sh = 8 * (r & 7);
+                ended = imax(ended, (int)((rowmax >> sh) & 0xffu));
+                rowmax &= ~(0xffull << sh);
             }
+            folded = imax(folded, sx - K);
+            if (sx == crow + 1) { cur ^= 1; pn = cn; } else pn = 0;                    // (a row without matches leaves cn = 0)
+            cn = 0; crow = sx;
+            const int cb = cur * HALF, pbase = (cur ^ 1) * HALF;
+            int rmax = 0;
             const uint32_t hh = kw_mix((uint32_t)w8[t], (uint32_t)(w8[t] >> 32) & 0xffffu);
-            walk_bucket(tb, w8[t], hh, ld2(head + 2u * kw_bucket(hh, tb.hmask)), [&](uint32_t yc) {
+            walk_bucket(tb, w8[t], hh, raw[t], [&](uint32_t yc) {
                 if ((int)yc - sx == fr.d || verdict != 1) return;
-                const uint32_t w = ((uint32_t)sx << 8) | yc;
                 const uint32_t at = harmless_item(ln, fr.r, fr.d, fr.best_dp, sx, (int)yc);
                 int dp = imax(K, (int)(at & 0xffu));
                 if (ended) dp = imax(dp, ended + 1);
-                for (int i = cnt - 1; i >= 0; --i) {                                  // the partner (sx - 1, yc - 1): newest entries first
-                    int k = h + i; k = k >= SM ? k - SM : k;
-                    const uint32_t wi = ln.s(k);
-                    if ((int)(wi >> 8) < sx - 1) break;
-                    if (wi + 0x101u == w) { dp = imax(dp, (int)ln.u(k) + 1); break; }
+                for (int i = 0; i < pn; ++i) {                                         // the partner (sx - 1, yc - 1)
+                    const uint32_t wi = ln.s(pbase + i);
+                    if ((wi & 0xffu) + 1u == yc) { dp = imax(dp, (int)(wi >> 8) + 1); break; }
                 }
                 if (!(dp < (int)(at >> 8))) { verdict = 0; return; }
-                if (cnt == SM) { verdict = -1; return; }
-                int k = h + cnt; k = k >= SM ? k - SM : k;
-                ln.s(k) = (uint16_t)w; ln.u(k) = (uint8_t)imin(dp, 255);
-                ++cnt;
+                if (cn == cap) { verdict = -1; return; }
+                dp = imin(dp, 255);
+                ln.s(cb + cn) = (uint16_t)(yc | ((uint32_t)dp << 8));
+                ++cn;
+                rmax = imax(rmax, dp);
             });
+            rowmax |= (uint64_t)rmax << (8 * (sx & 7));
         }
     }
     return verdict;
@@ -866,19 +882,15 @@ VTXF_FN int probe_harmless_stream(const uint8_t* x, const Tab& tb, const Front& 
 // The SECOND stage on one lane (band_diag2_kernel; host test): a task the first stage left because its off-diagonal matches did not
 // fit the lane's list (or did not pass its coarse harmless test).  Verdict: T2_SCORE — cert == ub, the score; T2_TIGHT — every
 // off-diagonal match is harmless, so the reference's chain lies on the main diagonal and the band is band_pack(fr)'s one diagonal
-// stretch (masked DP, no sweep); T2_SWEEP — neither (more matches than the list holds, no diagonal, a match that may matter).
-enum T2Verdict : uint32_t { T2_SCORE = 0, T2_TIGHT = 1, T2_SWEEP = 2 };
+// stretch (masked DP, no sweep); T2_SWEEP — neither (no diagonal, a match that may matter); T2_STREAM — more matches than the list
+// holds: fast_task2_stream (band_stream_kernel) runs the harmless test alone over a two-row window.
+enum T2Verdict : uint32_t { T2_SCORE = 0, T2_TIGHT = 1, T2_SWEEP = 2, T2_STREAM = 3 };
 struct Result2 { uint32_t verdict; int32_t score; uint32_t pack; uint32_t why; };
-VTXF_FN Result2 fast_task2(const uint8_t* x, int m, const Tab& tb, int n, const LaneS2& ln, const Lane& gl) {
+VTXF_FN Result2 fast_task2_list(const uint8_t* x, int m, const Tab& tb, int n, const LaneS2& ln, const Lane& gl) {
     const Front fr = front(x, m, tb, n, ln);
     if (fr.why != W_OK) return Result2{T2_SWEEP, -1, 0u, fr.why};
     const int ns = probe_rows(x, tb, fr, ln);
-    if (ns > LaneS2::SMAX) {
-        // more matches than the list holds: the harmless test alone, over a window of the last six rows (the probes run again)
-        const int v = probe_harmless_stream(x, tb, fr, ln);
-        if (v == 1) return Result2{T2_TIGHT, fr.cert, band_pack(fr), W_MATCHES};
-        return Result2{T2_SWEEP, -1, 0u, v == 0 ? W_NOT_HARMLESS : W_MATCHES};
-    }
+    if (ns > LaneS2::SMAX) return Result2{T2_STREAM, -1, 0u, W_MATCHES};
     back_sort(ns, ln);
     if (!back_harmless(fr, ns, ln)) return Result2{T2_SWEEP, -1, 0u, W_NOT_HARMLESS};
     uint32_t why = W_GENERIC;
@@ -886,6 +898,21 @@ VTXF_FN Result2 fast_task2(const uint8_t* x, int m, const Tab& tb, int n, const 
     if (ns <= 64) sc = back_rest(fr, ns, ln, gl, &why, 0, nullptr, nullptr);      // (the closure's bit set holds 64 matches)
     if (sc >= 0) return Result2{T2_SCORE, sc, 0u, W_OK};
     return Result2{T2_TIGHT, fr.cert, band_pack(fr), why};
+}
+// ... and what follows for T2_STREAM: front again (the same pieces, diagonal and certificate), then the probes with the harmless
+// test on the fly.  T2_TIGHT or T2_SWEEP (a match that may matter, or a row with more matches than half the window).
+template <class LN> VTXF_FN Result2 fast_task2_stream(const uint8_t* x, int m, const Tab& tb, int n, const LN& wl) {
+    const Front fr = front(x, m, tb, n, wl);
+    if (fr.why != W_OK) return Result2{T2_SWEEP, -1, 0u, fr.why};                 // (the second stage's front accepted this task)
+    const int v = probe_harmless_stream(x, tb, fr, wl);
+    if (v == 1) return Result2{T2_TIGHT, fr.cert, band_pack(fr), W_MATCHES};
+    return Result2{T2_SWEEP, -1, 0u, v == 0 ? W_NOT_HARMLESS : W_MATCHES};
+}
+// both, one after the other (host tests; the device runs them as two kernels)
+VTXF_FN Result2 fast_task2(const uint8_t* x, int m, const Tab& tb, int n, const LaneS2& ln, const Lane& gl) {
+    const Result2 r = fast_task2_list(x, m, tb, n, ln, gl);
+    if (r.verdict != T2_STREAM) return r;
+    return fast_task2_stream(x, m, tb, n, LaneW{ln.base, ln.stride, ln.sb, ln.sstride, ln.ub, ln.ustride});
 }
 
 }  // namespace vtxf
