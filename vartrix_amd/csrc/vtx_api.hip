@@ -1369,7 +1369,7 @@ int vtx_run(vtx_ctx* c) {
                                 dl = dense_list + nt;
                             } else (void)hipGetLastError();
                         }
-                        // Second stage (round 5): the same single-diagonal logic with a list of 120 entries and the harmless bound from
+                        // Second stage (round 5): the same single-diagonal logic with a list of 64 entries and the harmless bound from
                         // the matches that can really precede a match (band_diag2_kernel).  It scores most of these tasks or proves
                         // that their band is one diagonal stretch (masked DP, no sweep); what it leaves takes the sweep.  One host
                         // round trip for the two counts.  (libvtx_dev.so: VTX_BAND_NO_DIAG2=1 sends everything to the sweep, as round 4 did.)

@@ -2600,14 +2600,14 @@ extern "C" hipError_t vtxk_launch_band_refine(const uint32_t* recs, uint32_t n_r
 // ---- the SECOND stage (round 5): band_diag2_kernel ------------------------------------------------------------------------------
 // What band_diag_kernel leaves because a task's off-diagonal matches do not fit its 40-entry list (W_MATCHES: loci in repeat-rich
 // sequence; 14 % of the real-sequence workload) used to take band_sweep_kernel + the masked DP, 38 ns per task.  Most of these tasks
-// still have their alignment on ONE diagonal: with a list of 120 entries and the harmless test bounding a match's dp from the matches
-// that can really precede it (vtx_fast_core.h: back_harmless, LN::TIGHT) the same per-task logic decides 60 % of them outright and
-// proves for another 25 % that every off-diagonal match is harmless — the reference's chain lies on the main diagonal, the band is
+// still have their alignment on ONE diagonal: with a list of 64 entries and the harmless test bounding a match's dp from the matches
+// that can really precede it (vtx_fast_core.h: back_harmless, LN::TIGHT) the same per-task logic decides 21 % of them outright and
+// proves for another 62 % (band_stream_kernel included) that every off-diagonal match is harmless — the reference's chain lies on the main diagonal, the band is
 // one diagonal stretch (band_pack), and the masked DP needs no sweep.  One lane per task, the plain per-lane form of the logic
-// (vtxf::fast_task2: its own probes, no pooling): 7 M tasks, not 49 M.  Per lane 104 words of LDS (60 list, 8 pieces, 30 bound bytes,
-// 6 generic pieces): 26.6 KB per wavefront.
+// (vtxf::fast_task2: its own probes, no pooling): 7 M tasks, not 49 M.  Per lane 62 words of LDS (32 list, 8 pieces, 16 bound bytes,
+// 6 generic pieces): 15.9 KB per wavefront.
 // Output: T2_SCORE -> the score (stage 1); T2_TIGHT -> tight_list / tight_pack at counters[1] (provisional score = the certificate);
-// T2_SWEEP -> sweep_list at counters[0]; T2_STREAM (more than 120 matches) -> stream_list at *stream_cnt: band_stream_kernel.
+// T2_SWEEP -> sweep_list at counters[0]; T2_STREAM (more than 64 matches) -> stream_list at *stream_cnt: band_stream_kernel.
 constexpr int D2_LANE_WORDS = vtxf::S2_WORDS + vtxf::RM + vtxf::LaneS2::SMAX / 4 + vtxf::GM;
 __global__ __launch_bounds__(64) void band_diag2_kernel(
     const uint32_t* __restrict__ tasks, uint32_t n_tasks,
@@ -2665,7 +2665,10 @@ __global__ __launch_bounds__(64) void band_diag2_kernel(
 // loads of the bucket walks overlap across many wavefronts.  T2_TIGHT -> tight_list / tight_pack at counters[1] (after
 // band_diag2_kernel's entries), T2_SWEEP -> sweep_list at counters[0].  *n_dev tasks (a device count: no host round trip between the two).
 constexpr int ST_LANE_WORDS = vtxf::WIN_WORDS + vtxf::RM;
-__global__ __launch_bounds__(64) void band_stream_kernel(
+#ifndef VTX_STREAM_WAVES
+#define VTX_STREAM_WAVES 4       // 128 VGPRs (17 words spilled): four wavefronts per SIMD overlap more bucket walks than three without spills (-3 ms of 175)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VTX_STREAM_WAVES, VTX_STREAM_WAVES))) void band_stream_kernel(
     const uint32_t* __restrict__ tasks, const uint32_t* __restrict__ n_dev,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,

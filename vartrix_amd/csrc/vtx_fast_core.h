@@ -280,9 +280,11 @@ template <class ST, int SW = S_WORDS> struct LaneS {
 // dp bound of the harmless test (u(k)): with it the bound of an off-diagonal match comes from the matches that can really precede it
 // (back_harmless), not from every earlier one.
 #ifndef VTXF_S2_WORDS
-#define VTXF_S2_WORDS 60
+#define VTXF_S2_WORDS 32
 #endif
-constexpr int S2_WORDS = VTXF_S2_WORDS;   // 120 entries (back_rest's closure is only asked for <= 64 of them: its bit set and byte counters)
+constexpr int S2_WORDS = VTXF_S2_WORDS;   // 64 entries: what back_rest's closure holds (a bit set, byte counters).  (With 120 the list also
+                                           // settled the harmless test of tasks with 65 .. 120 matches; band_stream_kernel does that for any number,
+                                           // and the smaller list lets ten wavefronts per CU overlap their loads instead of six: -4 ms of 178.)
 template <int W> struct LaneS2T {
     typedef uint16_t SType;
     uint32_t* base; int stride;
