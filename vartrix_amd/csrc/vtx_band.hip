@@ -2619,7 +2619,7 @@ __global__ __launch_bounds__(64) void band_diag2_kernel(
     __shared__ uint32_t mem[D2_LANE_WORDS * 64];
     const int tid = (int)threadIdx.x;
     const uint32_t slot = blockIdx.x * 64u + (uint32_t)tid;
-    uint32_t verdict = 3u, task = 0, pack = 0;
+    uint32_t verdict = 0xffu, task = 0, pack = 0;          // (a lane without a task: no list)
     if (slot < n_tasks) {
         task = tasks[slot];
         const uint32_t rid = task >> 1, hap = task & 1u;
@@ -2680,7 +2680,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VTX_STREAM_W
     const uint32_t slot = blockIdx.x * 64u + (uint32_t)tid;
     const uint32_t n_tasks = *n_dev;
     if (blockIdx.x * 64u >= n_tasks) return;
-    uint32_t verdict = 3u, task = 0, pack = 0;
+    uint32_t verdict = 0xffu, task = 0, pack = 0;          // (a lane without a task: no list)
     if (slot < n_tasks) {
         task = tasks[slot];
         const uint32_t rid = task >> 1, hap = task & 1u;
