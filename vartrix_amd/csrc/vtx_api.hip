@@ -110,7 +110,7 @@ struct vtx_ctx {
     uint64_t gt_used = 0;      // bytes of d_gtables the last banded run's table kernel wrote (vtx_debug_tables)
     DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail, d_fail_tmp, d_refine;   // banded flavour
     DevBuf d_tight2, d_tight2_pack;                                          // band_diag2_kernel: tasks whose band is one diagonal stretch after all
-    DevBuf d_recheck2, d_recheck2_pack;                                      // ... of which the full-matrix check did not settle (full != certificate); d_recheck2 first holds band_stream_kernel's task list
+    DevBuf d_recheck2, d_recheck2_pack;                                      // ... of which the full-matrix check did not settle (full != certificate); first they hold band_stream_kernel's task list and diagonals
     DevBuf d_sweep_log;                                                      // band_sweep_kernel: the section logs of the resident workgroups (64 MB)
     DevBuf d_tight, d_tight_pack, d_dband, d_dband_pack, d_dense, d_stage;                                                 // round 4: tasks with a provisional score (full-matrix check); stage bytes (vtx_fetch_stage)
     bool stage_trace = false, poison = false;                                // test / audit hooks (vtx_set_debug)
@@ -1213,6 +1213,60 @@ int vtx_run(vtx_ctx* c) {
             return VTX_OK;
         };
         uint32_t resweep_total = 0;
+        // Second stage (round 5): the same single-diagonal logic with a list of 64 entries and the harmless bound from
+        // the matches that can really precede a match (band_diag2_kernel), the harmless test alone over a two-row window for what
+        // exceeds the list (band_stream_kernel).  They score most of these tasks or prove that their band is one diagonal stretch
+        // (full-matrix check, masked DP for what it does not settle; no sweep); what they leave — out[0, *n_out) — takes the sweep.
+        // One host round trip for the counts.  (libvtx_dev.so: VTX_BAND_NO_DIAG2=1 sends everything to the sweep, as round 4 did;
+        // VTX_BAND_NO_STREAM=1 — what exceeds the second stage's list goes to the sweep.)
+        // A short list skips it: one lane per task, a few hundred dependent loads each — below ~4 k wavefronts the
+        // kernels are a latency chain that the sweep + its DP beat (headline: 48 k tasks, 0.6 ms against 0.35 saved).
+        // The tables of the tasks' loci have to be resident (gt_l0: first locus of the table buffer).
+        auto second_stage_on = [&](uint32_t n) -> bool {
+            static const bool no_diag2 = VTX_DEV_ENV("VTX_BAND_NO_DIAG2") != nullptr;
+            static const uint32_t diag2_min = VTX_DEV_ENV("VTX_BAND_DIAG2_MIN") ? (uint32_t)strtoul(VTX_DEV_ENV("VTX_BAND_DIAG2_MIN"), nullptr, 10) : 200000u;
+            return !no_diag2 && n >= diag2_min && c->max_hap_len <= 255;
+        };
+        auto second_stage = [&](const uint32_t* list, uint32_t n, uint32_t gt_l0, uint32_t* out, uint32_t* n_out) -> int {
+            static const bool no_stream = VTX_DEV_ENV("VTX_BAND_NO_STREAM") != nullptr;
+            HIP_TRY(c, hipMemsetAsync(d_cnt + 30, 0, 2 * sizeof(uint32_t), s));
+            HIP_TRY(c, hipMemsetAsync(d_cnt + 48, 0, sizeof(uint32_t), s));
+            HIP_TRY(c, vtxk_launch_band_diag2(list, n, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                              c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
+                                              c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), bp.tasks_per_locus, gt_l0,
+                                              c->d_gtables.as<uint8_t>(), out, c->d_tight2.as<uint32_t>(),
+                                              c->d_tight2_pack.as<uint32_t>(), d_cnt + 30,
+                                              no_stream ? nullptr : c->d_recheck2.as<uint32_t>(), c->d_recheck2_pack.as<uint32_t>(), d_cnt + 48, stage, s));
+            HIP_TRY(c, hipMemcpyAsync(c->h_pin + 14, d_cnt + 30, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(c->h_pin + 16, d_cnt + 48, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            stream_total += std::min(c->h_pin[16], n);
+            const uint32_t n_sweep = std::min(c->h_pin[14], n);
+            const uint32_t n_tight2 = std::min(c->h_pin[15], n - n_sweep);
+            ++launches;
+            diag2_total += n; diag2_scored += n - n_sweep - n_tight2;
+            if (n_tight2) {
+                // These tasks hold a certificate (a lower bound of the banded score) and sit in repeat-rich sequence on
+                // clean reads: the full-matrix score equals it for practically all of them (4 223 of 4 223 in the CPU
+                // sample), and cert <= banded <= full then decides the task for 5.9 ns where the masked DP takes 10.
+                // What the check does not settle takes the masked DP over its one-diagonal band (count on the device).
+                HIP_TRY(c, hipMemsetAsync(d_cnt + 25, 0, sizeof(uint32_t), s));
+                HIP_TRY(c, vtxk_launch_sw_check(kShapes[shape][0], kShapes[shape][1], n_tight2, c->d_tight2.as<uint32_t>(),
+                                                c->d_tight2_pack.as<uint32_t>(), nullptr, c->d_records.as<vtx_record>(),
+                                                c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                                c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len,
+                                                c->d_recheck2.as<uint32_t>(), c->d_recheck2_pack.as<uint32_t>(), d_cnt + 25, stage, s));
+                HIP_TRY(c, vtxk_launch_sw_diag_band(kShapes[shape][0], kShapes[shape][1], n_tight2, c->d_recheck2.as<uint32_t>(),
+                                                    c->d_recheck2_pack.as<uint32_t>(), d_cnt + 25, c->d_records.as<vtx_record>(),
+                                                    c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                                    c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
+                                                    c->max_hap_len, stage, s));
+                launches += 2;
+                tight2_total += n_tight2;
+            }
+            *n_out = n_sweep;
+            return 0;
+        };
         bool sweep_used = false;                    // some chunk took the round-4 path
         bool sweep_pending = false;                 // the events of a swept chunk have not been read yet
         bool sweep_forked = false;                  // ... and that chunk ran its two branches side by side
@@ -1369,56 +1423,13 @@ int vtx_run(vtx_ctx* c) {
                                 dl = dense_list + nt;
                             } else (void)hipGetLastError();
                         }
-                        // Second stage (round 5): the same single-diagonal logic with a list of 64 entries and the harmless bound from
-                        // the matches that can really precede a match (band_diag2_kernel).  It scores most of these tasks or proves
-                        // that their band is one diagonal stretch (masked DP, no sweep); what it leaves takes the sweep.  One host
-                        // round trip for the two counts.  (libvtx_dev.so: VTX_BAND_NO_DIAG2=1 sends everything to the sweep, as round 4 did.)
-                        // A short list skips it: one lane per task, a few hundred dependent loads each — below ~4 k wavefronts the
-                        // kernel is a latency chain that the sweep + its DP beat (headline: 48 k tasks, 0.6 ms against 0.35 saved).
-                        static const bool no_diag2 = VTX_DEV_ENV("VTX_BAND_NO_DIAG2") != nullptr;
-                        static const uint32_t diag2_min = VTX_DEV_ENV("VTX_BAND_DIAG2_MIN") ? (uint32_t)strtoul(VTX_DEV_ENV("VTX_BAND_DIAG2_MIN"), nullptr, 10) : 200000u;
+                        // Second stage (round 5): band_diag2_kernel + band_stream_kernel + the full-matrix check (second_stage above)
                         const uint32_t* sl = dl;
                         uint32_t n_sweep = n_dense;
-                        if (!no_diag2 && n_dense >= diag2_min) {
+                        if (second_stage_on(n_dense)) {
                             uint32_t* sweep2 = (dl == dense_list) ? dense_list + nt : dense_list;          // (the half of d_dense the list is not in)
-                            // (libvtx_dev.so: VTX_BAND_NO_STREAM=1 — what exceeds the second stage's list goes to the sweep)
-                            static const bool no_stream = VTX_DEV_ENV("VTX_BAND_NO_STREAM") != nullptr;
-                            HIP_TRY(c, hipMemsetAsync(d_cnt + 30, 0, 2 * sizeof(uint32_t), s));
-                            HIP_TRY(c, hipMemsetAsync(d_cnt + 48, 0, sizeof(uint32_t), s));
-                            HIP_TRY(c, vtxk_launch_band_diag2(dl, n_dense, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                                              c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
-                                                              c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), tasks_per_locus, gt_l0,
-                                                              c->d_gtables.as<uint8_t>(), sweep2, c->d_tight2.as<uint32_t>(),
-                                                              c->d_tight2_pack.as<uint32_t>(), d_cnt + 30,
-                                                              no_stream ? nullptr : c->d_recheck2.as<uint32_t>(), d_cnt + 48, stage, s));
-                            HIP_TRY(c, hipMemcpyAsync(c->h_pin + 14, d_cnt + 30, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                            HIP_TRY(c, hipMemcpyAsync(c->h_pin + 16, d_cnt + 48, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                            HIP_TRY(c, hipStreamSynchronize(s));
-                            stream_total += std::min(c->h_pin[16], n_dense);
-                            n_sweep = std::min(c->h_pin[14], n_dense);
-                            const uint32_t n_tight2 = std::min(c->h_pin[15], n_dense - n_sweep);
+                            if (int rc = second_stage(dl, n_dense, gt_l0, sweep2, &n_sweep)) return rc;
                             sl = sweep2;
-                            ++launches;
-                            diag2_total += n_dense; diag2_scored += n_dense - n_sweep - n_tight2;
-                            if (n_tight2) {
-                                // These tasks hold a certificate (a lower bound of the banded score) and sit in repeat-rich sequence on
-                                // clean reads: the full-matrix score equals it for practically all of them (2 941 of 2 941 in the CPU
-                                // sample), and cert <= banded <= full then decides the task for 5.6 ns where the masked DP takes 10.
-                                // What the check does not settle takes the masked DP over its one-diagonal band (count on the device).
-                                HIP_TRY(c, hipMemsetAsync(d_cnt + 25, 0, sizeof(uint32_t), s));
-                                HIP_TRY(c, vtxk_launch_sw_check(kShapes[shape][0], kShapes[shape][1], n_tight2, c->d_tight2.as<uint32_t>(),
-                                                                c->d_tight2_pack.as<uint32_t>(), nullptr, c->d_records.as<vtx_record>(),
-                                                                c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
-                                                                c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len,
-                                                                c->d_recheck2.as<uint32_t>(), c->d_recheck2_pack.as<uint32_t>(), d_cnt + 25, stage, s));
-                                HIP_TRY(c, vtxk_launch_sw_diag_band(kShapes[shape][0], kShapes[shape][1], n_tight2, c->d_recheck2.as<uint32_t>(),
-                                                                    c->d_recheck2_pack.as<uint32_t>(), d_cnt + 25, c->d_records.as<vtx_record>(),
-                                                                    c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
-                                                                    c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
-                                                                    c->max_hap_len, stage, s));
-                                launches += 2;
-                                tight2_total += n_tight2;
-                            }
                         }
                         if (n_sweep) { if (int rc = sweep_slices(0, sl, n_sweep, c->d_over.as<uint32_t>() + 2 * n_tasks, d_cnt + 26)) return rc; }
                         swept_total += n_sweep;
@@ -1556,8 +1567,17 @@ int vtx_run(vtx_ctx* c) {
                 uint32_t* over = c->d_over.as<uint32_t>();
                 const uint32_t nA = cnt[1];
                 if (nA) {
-                    if (int rc = sweep_slices(0, over, nA, over + 2 * n_tasks, d_cnt + 26)) return rc;
-                    swept_total += nA;
+                    // (these tasks left band_diag_kernel for another reason than their number of matches, and then overflowed
+                    // band_run_kernel's piece lists: repeats as well — on real-sequence loci 0.9 M tasks.  The second stage first, when
+                    // the tables of every locus are still resident.)
+                    const uint32_t* sl = over;
+                    uint32_t n_sweep = nA;
+                    if (second_stage_on(nA) && gt_bytes && !gt_chunked && nA <= chunk && c->d_dense.cap >= (size_t)nA * sizeof(uint32_t)) {
+                        if (int rc = second_stage(over, nA, 0, c->d_dense.as<uint32_t>(), &n_sweep)) return rc;
+                        sl = c->d_dense.as<uint32_t>();
+                    }
+                    if (n_sweep) { if (int rc = sweep_slices(0, sl, n_sweep, over + 2 * n_tasks, d_cnt + 26)) return rc; }
+                    swept_total += n_sweep;
                 }
                 uint32_t nB = 0, nC = 0;
                 HIP_TRY(c, hipMemcpyAsync(&nB, d_cnt + 27, sizeof(uint32_t), hipMemcpyDeviceToHost, s));

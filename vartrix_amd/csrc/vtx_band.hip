@@ -2607,7 +2607,7 @@ extern "C" hipError_t vtxk_launch_band_refine(const uint32_t* recs, uint32_t n_r
 // (vtxf::fast_task2: its own probes, no pooling): 7 M tasks, not 49 M.  Per lane 62 words of LDS (32 list, 8 pieces, 16 bound bytes,
 // 6 generic pieces): 15.9 KB per wavefront.
 // Output: T2_SCORE -> the score (stage 1); T2_TIGHT -> tight_list / tight_pack at counters[1] (provisional score = the certificate);
-// T2_SWEEP -> sweep_list at counters[0]; T2_STREAM (more than 64 matches) -> stream_list at *stream_cnt: band_stream_kernel.
+// T2_SWEEP -> sweep_list at counters[0]; T2_STREAM (more than 64 matches) -> stream_list / stream_diag (the diagonal) at *stream_cnt: band_stream_kernel.
 constexpr int D2_LANE_WORDS = vtxf::S2_WORDS + vtxf::RM + vtxf::LaneS2::SMAX / 4 + vtxf::GM;
 __global__ __launch_bounds__(64) void band_diag2_kernel(
     const uint32_t* __restrict__ tasks, uint32_t n_tasks,
@@ -2615,7 +2615,8 @@ __global__ __launch_bounds__(64) void band_diag2_kernel(
     const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
     const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ sweep_list, uint32_t* __restrict__ tight_list, uint32_t* __restrict__ tight_pack,
-    uint32_t* __restrict__ stream_list, uint32_t* __restrict__ stream_cnt, uint32_t* __restrict__ counters, uint8_t* __restrict__ stage) {
+    uint32_t* __restrict__ stream_list, uint32_t* __restrict__ stream_diag, uint32_t* __restrict__ stream_cnt,
+    uint32_t* __restrict__ counters, uint8_t* __restrict__ stage) {
     __shared__ uint32_t mem[D2_LANE_WORDS * 64];
     const int tid = (int)threadIdx.x;
     const uint32_t slot = blockIdx.x * 64u + (uint32_t)tid;
@@ -2656,7 +2657,7 @@ __global__ __launch_bounds__(64) void band_diag2_kernel(
     const uint64_t below = (1ull << tid) - 1ull;
     if (verdict == vtxf::T2_SWEEP) sweep_list[sbase + (uint32_t)__popcll(sm & below)] = task;
     else if (verdict == vtxf::T2_TIGHT) { const uint32_t pos = tbase + (uint32_t)__popcll(tm & below); tight_list[pos] = task; tight_pack[pos] = pack; }
-    else if (verdict == vtxf::T2_STREAM) stream_list[rbase + (uint32_t)__popcll(rm & below)] = task;
+    else if (verdict == vtxf::T2_STREAM) { const uint32_t pos = rbase + (uint32_t)__popcll(rm & below); stream_list[pos] = task; stream_diag[pos] = pack; }
 }
 
 // band_stream_kernel: the tasks band_diag2_kernel's list could not hold (heavy repeats: hundreds of off-diagonal matches).  Whether
@@ -2669,7 +2670,7 @@ constexpr int ST_LANE_WORDS = vtxf::WIN_WORDS + vtxf::RM;
 #define VTX_STREAM_WAVES 4       // 128 VGPRs (17 words spilled): four wavefronts per SIMD overlap more bucket walks than three without spills (-3 ms of 175)
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VTX_STREAM_WAVES, VTX_STREAM_WAVES))) void band_stream_kernel(
-    const uint32_t* __restrict__ tasks, const uint32_t* __restrict__ n_dev,
+    const uint32_t* __restrict__ tasks, const uint32_t* __restrict__ task_diag, const uint32_t* __restrict__ n_dev,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, uint32_t max_hap, uint32_t table_stride, uint32_t n_heads,
     const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
@@ -2696,7 +2697,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VTX_STREAM_W
         tb.uq = tb.ent + vtxf::tab_uq_off(max_hap, n_heads);
         tb.pb = tb.ent + vtxf::tab_pb_off(max_hap, n_heads);
         const vtxf::LaneW wl{mem + vtxf::WIN_WORDS * 64 + tid, 64, (uint16_t*)mem + tid, 64, nullptr, 0};      // window entries, pieces
-        const vtxf::Result2 r = vtxf::fast_task2_stream(read_arena + rec.read_off, m, tb, n, wl);
+        const vtxf::Result2 r = vtxf::fast_task2_stream(read_arena + rec.read_off, m, tb, n, wl, (int)task_diag[slot]);
         verdict = r.verdict; pack = r.pack;
         if (verdict == vtxf::T2_TIGHT) (hap ? alt_score : ref_score)[rid] = r.score;     // provisional: the certificate
     }
@@ -2718,17 +2719,18 @@ extern "C" hipError_t vtxk_launch_band_diag2(const uint32_t* tasks, uint32_t n_t
                                              const vtx_locus* loci, const uint8_t* read_arena, uint32_t max_hap, int32_t* ref_score,
                                              int32_t* alt_score, uint32_t tasks_per_locus, uint32_t gt_l0, const uint8_t* gtables,
                                              uint32_t* sweep_list, uint32_t* tight_list, uint32_t* tight_pack, uint32_t* counters,
-                                             uint32_t* stream_list, uint32_t* stream_cnt, uint8_t* stage, hipStream_t s) {
+                                             uint32_t* stream_list, uint32_t* stream_diag, uint32_t* stream_cnt, uint8_t* stage,
+                                             hipStream_t s) {
     if (!n_tasks) return hipSuccess;
     if (max_hap > 255) return hipErrorInvalidValue;                  // (two-byte list entries)
     const uint32_t n_heads = pick_heads(tasks_per_locus, true);
     const size_t tstride = band_table_stride(max_hap, n_heads);
     hipLaunchKernelGGL(band_diag2_kernel, dim3((n_tasks + 63) / 64), dim3(64), 0, s, tasks, n_tasks, records, rec_locus, loci, read_arena,
                        max_hap, (uint32_t)tstride, n_heads, gtables, gt_l0, ref_score, alt_score, sweep_list, tight_list, tight_pack,
-                       stream_list, stream_cnt, counters, stage);
+                       stream_list, stream_diag, stream_cnt, counters, stage);
     if (stream_list) {
         // (*stream_cnt <= n_tasks tasks: workgroups past the count leave at once)
-        hipLaunchKernelGGL(band_stream_kernel, dim3((n_tasks + 63) / 64), dim3(64), 0, s, stream_list, stream_cnt, records, rec_locus, loci,
+        hipLaunchKernelGGL(band_stream_kernel, dim3((n_tasks + 63) / 64), dim3(64), 0, s, stream_list, stream_diag, stream_cnt, records, rec_locus, loci,
                            read_arena, max_hap, (uint32_t)tstride, n_heads, gtables, gt_l0, ref_score, alt_score, sweep_list, tight_list,
                            tight_pack, counters);
     }

@@ -96,7 +96,7 @@ hipError_t vtxk_launch_band_diag2(const uint32_t* tasks, uint32_t n_tasks, const
                                   const vtx_locus* loci, const uint8_t* read_arena, uint32_t max_hap, int32_t* ref_score,
                                   int32_t* alt_score, uint32_t tasks_per_locus, uint32_t gt_l0, const uint8_t* gtables,
                                   uint32_t* sweep_list, uint32_t* tight_list, uint32_t* tight_pack, uint32_t* counters,
-                                  uint32_t* stream_list, uint32_t* stream_cnt, uint8_t* stage, hipStream_t s);
+                                  uint32_t* stream_list, uint32_t* stream_diag, uint32_t* stream_cnt, uint8_t* stage, hipStream_t s);
 // ---- the band for any task (vtx_sweep.hip), the masked DP over a device-counted list, the full-matrix check ----
 hipError_t vtxk_launch_band_sweep(const uint32_t* tasks, uint32_t n_tasks, const uint32_t* n_dev, const vtx_record* records,
                                   const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena, const uint8_t* hap_arena,

@@ -892,7 +892,7 @@ VTXF_FN Result2 fast_task2_list(const uint8_t* x, int m, const Tab& tb, int n, c
     const Front fr = front(x, m, tb, n, ln);
     if (fr.why != W_OK) return Result2{T2_SWEEP, -1, 0u, fr.why};
     const int ns = probe_rows(x, tb, fr, ln);
-    if (ns > LaneS2::SMAX) return Result2{T2_STREAM, -1, 0u, W_MATCHES};
+    if (ns > LaneS2::SMAX) return Result2{T2_STREAM, -1, (uint32_t)fr.d, W_MATCHES};          // (pack: the diagonal, for fast_task2_stream)
     back_sort(ns, ln);
     if (!back_harmless(fr, ns, ln)) return Result2{T2_SWEEP, -1, 0u, W_NOT_HARMLESS};
     uint32_t why = W_GENERIC;
@@ -901,11 +901,13 @@ VTXF_FN Result2 fast_task2_list(const uint8_t* x, int m, const Tab& tb, int n, c
     if (sc >= 0) return Result2{T2_SCORE, sc, 0u, W_OK};
     return Result2{T2_TIGHT, fr.cert, band_pack(fr), why};
 }
-// ... and what follows for T2_STREAM: front again (the same pieces, diagonal and certificate), then the probes with the harmless
-// test on the fly.  T2_TIGHT or T2_SWEEP (a match that may matter, or a row with more matches than half the window).
-template <class LN> VTXF_FN Result2 fast_task2_stream(const uint8_t* x, int m, const Tab& tb, int n, const LN& wl) {
-    const Front fr = front(x, m, tb, n, wl);
-    if (fr.why != W_OK) return Result2{T2_SWEEP, -1, 0u, fr.why};                 // (the second stage's front accepted this task)
+// ... and what follows for T2_STREAM: front again on the diagonal d the list stage found (the same pieces and certificate, without
+// the search for the diagonal), then the probes with the harmless test on the fly.  T2_TIGHT or T2_SWEEP (a match that may matter,
+// or a row with more matches than half the window).
+template <class LN> VTXF_FN Result2 fast_task2_stream(const uint8_t* x, int m, const Tab& tb, int n, const LN& wl, int d) {
+    if (m < K || n < K || m > MAX_READ || d < -(m - K) || d > n - K) return Result2{T2_SWEEP, -1, 0u, W_SHAPE};   // (not what the list stage hands over)
+    const Front fr = front_rest(x, m, tb, n, wl, d, diag_mask(read_words(x, m), m, tb, n, d));
+    if (fr.why != W_OK) return Result2{T2_SWEEP, -1, 0u, fr.why};                 // (the list stage's front accepted this task)
     const int v = probe_harmless_stream(x, tb, fr, wl);
     if (v == 1) return Result2{T2_TIGHT, fr.cert, band_pack(fr), W_MATCHES};
     return Result2{T2_SWEEP, -1, 0u, v == 0 ? W_NOT_HARMLESS : W_MATCHES};
@@ -914,7 +916,7 @@ template <class LN> VTXF_FN Result2 fast_task2_stream(const uint8_t* x, int m, c
 VTXF_FN Result2 fast_task2(const uint8_t* x, int m, const Tab& tb, int n, const LaneS2& ln, const Lane& gl) {
     const Result2 r = fast_task2_list(x, m, tb, n, ln, gl);
     if (r.verdict != T2_STREAM) return r;
-    return fast_task2_stream(x, m, tb, n, LaneW{ln.base, ln.stride, ln.sb, ln.sstride, ln.ub, ln.ustride});
+    return fast_task2_stream(x, m, tb, n, LaneW{ln.base, ln.stride, ln.sb, ln.sstride, ln.ub, ln.ustride}, (int)r.pack);
 }
 
 }  // namespace vtxf
