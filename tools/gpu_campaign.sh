@@ -77,11 +77,13 @@ case $CMD in
       f=$(find /tmp/abl_$a -name "*kernel_stats.csv" | head -1); echo "== $KNOB=$a" | tee -a $OUT/ablate.txt; kstats "$f" 4 | head -6 | tee -a $OUT/ablate.txt
     done;;
   final)
+    # the counters first: bench.py's line carries roofline.traffic only from a profiles/pmc_traffic.json of the sources it runs
+    bash tools/pmc_collect.sh /tmp/pmc --no-sensitivity --sustain-seconds 0 > $OUT/pmc_collect.log 2>&1
+    python tools/pmc_summarize.py /tmp/pmc $OUT/pmc_counters.json 24320920 $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1
+    [ -s $OUT/pmc_traffic.json ] && cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
     python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench default rc=$?"
     bash $0 stats $OUT head genome e3 e8 c5 d16 d4 e1 r250 p150
     bash $0 lines $OUT d128 d64 d32 d16 d4 ln8 c4
-    bash tools/pmc_collect.sh /tmp/pmc --no-sensitivity --sustain-seconds 0 > $OUT/pmc_collect.log 2>&1
-    python tools/pmc_summarize.py /tmp/pmc $OUT/pmc_counters.json 24320920 $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1
     echo done;;
   *) echo "unknown command $CMD" >&2; exit 2;;
 esac

@@ -2667,7 +2667,7 @@ __global__ __launch_bounds__(64) void band_diag2_kernel(
 // band_diag2_kernel's entries), T2_SWEEP -> sweep_list at counters[0].  *n_dev tasks (a device count: no host round trip between the two).
 constexpr int ST_LANE_WORDS = vtxf::WIN_WORDS + vtxf::RM;
 #ifndef VTX_STREAM_WAVES
-#define VTX_STREAM_WAVES 4       // 128 VGPRs (17 words spilled): four wavefronts per SIMD overlap more bucket walks than three without spills (-3 ms of 175)
+#define VTX_STREAM_WAVES 4       // four wavefronts per SIMD (108 VGPRs; the LDS allows as many): what overlaps the bucket walks
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VTX_STREAM_WAVES, VTX_STREAM_WAVES))) void band_stream_kernel(
     const uint32_t* __restrict__ tasks, const uint32_t* __restrict__ task_diag, const uint32_t* __restrict__ n_dev,
