@@ -806,11 +806,20 @@ template <class LN> VTXF_FN int32_t back_rest(const Front& fr, int ns, const LN&
     return fr.cert;
 }
 
+// A read that matches the haplotype base for base on its diagonal needs nothing else: cert == m (every base of the read a one of the
+// mask, in band).  The FULL score is at most m (a local alignment scores at most +1 per read base), so full = m; and the banded score
+// is m whatever the off-diagonal matches are: sdpkpp's dp of a match never exceeds x + K (dp = K at a chain's first match, + 1 per row
+// at best: a jump over dx + dy > 0 bases loses dx + dy), so the best chain has dp = m, and only a chain of m - K + 1 continuing
+// matches from row 0 on ONE diagonal reaches it — this diagonal or, by the tie rule, another one that is just as perfect; its
+// staircase spans the whole read, the band holds that diagonal from end to end, and the DP scores m on it.  No probes, no bounds.
+VTXF_FN bool whole_read(const Front& fr, int m) { return fr.why == W_OK && fr.cert == m; }
+
 struct Result { int32_t score; uint32_t why; };
 // all three phases on one lane (host test; device variant without pooled probes)
 template <class LN> VTXF_FN Result fast_task(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, const Lane& gl, bool refine) {
     const Front fr = front(x, m, tb, n, ln);
     if (fr.why != W_OK) return Result{-1, fr.why};
+    if (whole_read(fr, m)) return Result{m, W_OK};
     const int ns = probe_rows(x, tb, fr, ln);
     uint32_t why = W_OK;
     const Refine rf{x, tb.gt + tb.bytes, m, n};
@@ -891,6 +900,7 @@ struct Result2 { uint32_t verdict; int32_t score; uint32_t pack; uint32_t why; }
 VTXF_FN Result2 fast_task2_list(const uint8_t* x, int m, const Tab& tb, int n, const LaneS2& ln, const Lane& gl) {
     const Front fr = front(x, m, tb, n, ln);
     if (fr.why != W_OK) return Result2{T2_SWEEP, -1, 0u, fr.why};
+    if (whole_read(fr, m)) return Result2{T2_SCORE, m, 0u, W_OK};                 // (band_diag_kernel decides these itself: a list of band_run_kernel's overflows may hold one)
     const int ns = probe_rows(x, tb, fr, ln);
     if (ns > LaneS2::SMAX) return Result2{T2_STREAM, -1, (uint32_t)fr.d, W_MATCHES};          // (pack: the diagonal, for fast_task2_stream)
     back_sort(ns, ln);
