@@ -470,3 +470,38 @@ def test_streaming_harmless_test_equals_the_list_version(core):
                 assert sv != 2 and lv == sv, (label, lv, sv, x, y)
                 n += 1; yes += lv; no += 1 - lv
     assert n > 1500 and yes > 1000 and no > 50, (n, yes, no)
+
+
+def test_whole_read_is_decided_whatever_else_matches(core):
+    """vtxf::whole_read: a read that matches its haplotype base for base on one diagonal is scored m without a probe — also where the
+    same read fits several diagonals just as perfectly (tandem repeats, a duplicated segment: the tie rule picks the reference's
+    chain), where hundreds of off-diagonal matches surround it, and where it ends at the haplotype's edge.  Every such task has to
+    be decided, with the oracle's banded score (= m = the full-matrix score)."""
+    rng = np.random.default_rng(77)
+    g = bytes(rng.choice(list(b"ACGT"), 4000).tolist())
+    haps, reads = [], []
+    for unit_len in (2, 3, 7, 13, 23, 41):
+        unit = bytes(rng.choice(list(b"ACGT"), unit_len).tolist())
+        hap = (unit * (220 // unit_len + 2))[:220]
+        alt = hap[:110] + bytes([hap[110] ^ 6]) + hap[111:]
+        haps.append((hap, alt))
+        reads.append([(c, 0, hap[o:o + ln]) for c, (o, ln) in enumerate([(0, 150), (3, 150), (40, 120), (70, 150), (100, 60), (214, 6), (0, 192)])])
+    seg = g[100:250]
+    haps.append((g[0:40] + seg + g[300:305] + seg[:50], g[0:40] + seg + b"T" + g[300:305] + seg[:50]))      # a duplicated segment
+    reads.append([(0, 0, seg), (1, 0, seg[:50]), (2, 0, seg[10:140]), (3, 0, (g[0:40] + seg)[20:170])])
+    haps.append((g[1000:1201], g[1000:1100] + b"A" + g[1101:1201]))                                         # plain sequence, reads at the edges
+    reads.append([(0, 0, g[1000:1150]), (1, 0, g[1051:1201]), (2, 0, g[1000:1192]), (3, 0, g[1100:1106])])
+    batch = SB.manual_batch(haps, reads, 8)
+    sc, why = run_core(core, batch)
+    r, a = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=8), threads=8)
+    rf, af = oracle.batch_scores(batch, default_config(aligner="full", n_barcodes=8), threads=8)
+    want = np.empty(2 * batch.n_records, np.int32); want[0::2], want[1::2] = r, a
+    full = np.empty(2 * batch.n_records, np.int32); full[0::2], full[1::2] = rf, af
+    lens = np.repeat(batch.records["read_len"].astype(np.int32), 2)
+    decided = sc >= 0
+    assert np.all(sc[decided] == want[decided])
+    whole = full == lens                                     # the full-matrix score is the read's length: the read fits somewhere base for base
+    assert whole.sum() >= 45 and np.all(want[whole] == lens[whole])
+    # (a whole read the stage does not decide found no diagonal: every 6-mer of a short-unit repeat is repeated, no sampled row gives a
+    # candidate — those go on to band_sweep_kernel)
+    assert decided[whole].sum() >= 8 and set(why[whole & ~decided].tolist()) <= {2}, {WHY[k]: int(v) for k, v in zip(*np.unique(why[whole], return_counts=True))}
