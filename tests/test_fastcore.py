@@ -388,7 +388,7 @@ def test_edge_shapes(core):
     check(core, SB.manual_batch(haps, reads, 8), 8, "edge shapes")
 
 
-# ---- the second stage (vtxf::fast_task2 = band_diag2_kernel's per-task logic): 120 list entries and the harmless bound from the
+# ---- the second stage (vtxf::fast_task2 = band_diag2_kernel + band_stream_kernel per task): 64 list entries, the harmless bound from the
 #      matches that can really precede a match ----
 def _band_from_pack(pk, m, n):
     dd, ca, cb = (pk >> 16) - 256, (pk >> 8) & 0xff, pk & 0xff
