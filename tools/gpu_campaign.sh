@@ -9,6 +9,9 @@
 #                                                           VTX_DIAG_ABLATE / VTX_SWEEP_ABLATE / VTX_BAND_ABLATE / VTX_COOP_ABLATE — these exist
 #                                                           in libvtx_dev.so only (the script sets VTX_LIB_VARIANT=dev); scores are wrong by
 #                                                           design for values != 0, only the kernel times are read
+#   bash tools/gpu_campaign.sh variants OUTDIR WORKLOAD LIB...   the same workload on several builds of the library, one line each: LIB is
+#                                                           prod (libvtx.so) or a VTX_LIB_VARIANT name (dev, lazy0, ..., or an experimental
+#                                                           libvtx_<name>.so built by hand: how S2_WORDS / the stream kernel's occupancy were chosen)
 #   bash tools/gpu_campaign.sh final   OUTDIR               the round's closing set: default bench line, stats of every workload, the depth
 #                                                           ladder, config 4 on one GPU, the PMC passes (tools/pmc_collect.sh)
 #
@@ -75,6 +78,14 @@ case $CMD in
       rm -rf /tmp/abl_$a
       env $KNOB=$a rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abl_$a -o a -- $BENCH "$@" > $OUT/abl_$a.json 2> $OUT/abl_$a.err
       f=$(find /tmp/abl_$a -name "*kernel_stats.csv" | head -1); echo "== $KNOB=$a" | tee -a $OUT/ablate.txt; kstats "$f" 4 | head -6 | tee -a $OUT/ablate.txt
+    done;;
+  variants)
+    W=$1; shift
+    A=$(wl_args $W) || exit 2
+    for v in "$@"; do
+      if [ "$v" = prod ]; then unset VTX_LIB_VARIANT; else export VTX_LIB_VARIANT=$v; fi
+      $BENCH $A 2> $OUT/var_$v.err | tail -1 > $OUT/var_$v.json
+      echo "== $W on $v"; show_line $OUT/var_$v.json
     done;;
   final)
     # the counters first: bench.py's line carries roofline.traffic only from a profiles/pmc_traffic.json of the sources it runs
