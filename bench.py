@@ -264,14 +264,33 @@ def main():
     native = use_gather and os.environ.get("VTX_TORCH_GATHER") != "1"
     if rehearsal and not native:
         raise SystemExit("bench.py: the launch rehearsal (VTX_COMM_TEST_TRANSPORT) runs the library's gather only")
-    pipe = shard.GatherPipeline(cfg.scoring_mode) if (use_gather and not native) else None
     native_last = [None]
+    native_error = None
     if native:
-        ident = torch.zeros(lib.COMM_ID_BYTES, dtype=torch.uint8, device=ddev)
-        if rank == 0:
-            ident = torch.frombuffer(bytearray(lib.comm_id()), dtype=torch.uint8).to(ddev)
-        dist.broadcast(ident, src=0)
-        ctx.comm_init(bytes(ident.cpu().numpy().tobytes()), rank, world)
+        # If the library's communicator cannot be set up on this node (it has never run between two devices: no such node was available
+        # to this project), every rank falls back to the torch.distributed gather TOGETHER and the line says so — a scaling run that
+        # reports the alternative path beats one that reports nothing.  (An error inside a later vtx_gather_coo still ends the run.)
+        ok = 1
+        try:
+            ident = torch.zeros(lib.COMM_ID_BYTES, dtype=torch.uint8, device=ddev)
+            if rank == 0:
+                ident = torch.frombuffer(bytearray(lib.comm_id()), dtype=torch.uint8).to(ddev)
+            dist.broadcast(ident, src=0)
+            if os.environ.get("VTX_BENCH_TEST_COMM_FAIL") == "1":      # (tests/test_gpu_shard.py: the fallback below)
+                raise RuntimeError("VTX_BENCH_TEST_COMM_FAIL")
+            ctx.comm_init(bytes(ident.cpu().numpy().tobytes()), rank, world)
+        except Exception as e:                                 # (a SystemExit of the rehearsal check above is not caught here)
+            ok, native_error = 0, "%s: %s" % (type(e).__name__, e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=ddev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if rehearsal:
+                raise SystemExit("bench.py: vtx_comm_init failed in the launch rehearsal: %s" % native_error)
+            native = False
+            native_error = native_error or "vtx_comm_init failed on another rank"
+            if rank == 0:
+                print("bench: vtx_comm_init failed (%s): falling back to the torch.distributed gather" % native_error, file=sys.stderr)
+    pipe = shard.GatherPipeline(cfg.scoring_mode) if (use_gather and not native) else None
 
     def step():
         ctx.run()
@@ -461,6 +480,7 @@ def main():
             "gather": (None if not use_gather else
                        {"impl": "vtx_gather_coo (the library's exchange behind the C-ABI: ncclAllGather of (count, status) + grouped ncclSend / ncclRecv)"
                                 if native else "torch.distributed (shard.GatherPipeline: all_gather of counts + async gather)",
+                        "fallback_from_vtx_gather_coo": native_error,
                         "ranks": world, "transport": "socket test transport, ranks share one device (launch rehearsal)" if rehearsal else "RCCL",
                         "per_step": True}),
             "sustained": (None if sustained is None else

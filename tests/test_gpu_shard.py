@@ -131,7 +131,11 @@ def test_bench_torch_gather_matches_plain_run():
     assert plain["result"] == nat["result"] == alt["result"] and nat["result"]["nnz"] > 10000
     assert plain["gather"] is None
     assert nat["gather"]["impl"].startswith("vtx_gather_coo") and nat["gather"]["transport"] == "RCCL" and nat["gather"]["ranks"] == 1
-    assert alt["gather"]["impl"].startswith("torch.distributed")
+    assert alt["gather"]["impl"].startswith("torch.distributed") and alt["gather"]["fallback_from_vtx_gather_coo"] is None
+    # a communicator that cannot be set up: every rank falls back to the torch.distributed gather together, and the line says so
+    fb = _bench({"VTX_FORCE_GATHER": "1", "VTX_BENCH_TEST_COMM_FAIL": "1"}, args)
+    assert fb["result"] == plain["result"] and fb["gather"]["impl"].startswith("torch.distributed")
+    assert "VTX_BENCH_TEST_COMM_FAIL" in fb["gather"]["fallback_from_vtx_gather_coo"]
 
 
 def test_two_rank_launch_rehearsal_on_one_device(tmp_path):
