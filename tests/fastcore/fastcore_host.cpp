@@ -10,6 +10,7 @@
 
 #include "../../include/vtx.h"
 #include "../../vartrix_amd/csrc/vtx_fast_core.h"
+#include "../../vartrix_amd/csrc/vtx_band_trim.h"
 
 namespace {
 // serial restatement of build_tables (vtx_band.hip): same layout, same chain order (ascending y), same flags
@@ -267,5 +268,56 @@ uint32_t vtxt_harmless_stream_vs_list(const uint8_t* x, int m, const uint8_t* y,
     if (ns <= LaneS2::SMAX) { back_sort(ns, ln); lv = back_harmless(fr, ns, ln) ? 1u : 0u; }
     const int sv = probe_harmless_stream(xb.data(), tb, fr, ln, win > 0 ? win : LaneS2::SMAX / 2);
     return lv | ((uint32_t)(sv < 0 ? 2 : sv) << 8) | (ns <= LaneS2::SMAX ? 0x10000u : 0u);
+}
+
+// vtxt_fastcore_batch with the band-trimmed bound behind it (vtx_band_trim.h; refinement on): score[t] (-1: undecided), why[t], and
+// trimmed[t] = 1 where the trimmed bound decided the task (its score is the BANDED score, which may be below the full-matrix one)
+int vtxt_fastcore_trim_batch(const vtx_batch* b, uint32_t n_heads, int32_t* score, uint32_t* why, uint8_t* trimmed) {
+    using namespace vtxf;
+    uint32_t max_hap = 8;
+    for (uint32_t l = 0; l < b->n_loci; ++l) max_hap = std::max(max_hap, std::max(b->loci[l].ref_len, b->loci[l].alt_len));
+    if (max_hap > 255) return -1;
+    const uint32_t stride = tab_stride(max_hap, n_heads);
+    std::vector<uint8_t> gt((size_t)2 * stride + 64);
+    std::vector<uint8_t> readbuf;
+    uint32_t lane[LANE_WORDS], generic[GM];
+    for (uint32_t l = 0; l < b->n_loci; ++l) {
+        const vtx_locus& L = b->loci[l];
+        build_table(gt.data(), b->hap_arena + L.ref_off, L.ref_len, max_hap, n_heads);
+        build_table(gt.data() + stride, b->hap_arena + L.alt_off, L.alt_len, max_hap, n_heads);
+        for (uint32_t r = L.rec_begin; r < L.rec_begin + L.rec_count; ++r) {
+            const vtx_record& R = b->records[r];
+            readbuf.assign(R.read_len + 16, 0);
+            memcpy(readbuf.data(), b->read_arena + R.read_off, R.read_len);
+            for (int h = 0; h < 2; ++h) {
+                Tab tb;
+                tb.gt = gt.data();
+                tb.ent = (uint32_t)h * stride;
+                tb.head = tb.ent + max_hap * 8;
+                tb.bytes = tb.ent + tab_bytes_off(max_hap, n_heads);
+                tb.uq = tb.ent + tab_uq_off(max_hap, n_heads);
+                tb.pb = tb.ent + tab_pb_off(max_hap, n_heads);
+                tb.hmask = n_heads - 1;
+                const size_t t = 2 * (size_t)r + h;
+                const int m = (int)R.read_len, n = (int)(h ? L.alt_len : L.ref_len);
+                const LaneS<uint16_t> ln{lane + S_WORDS, 1, (uint16_t*)lane, 1};
+                const uint8_t* x = readbuf.data();
+                trimmed[t] = 0;
+                const Front fr = front(x, m, tb, n, ln);
+                if (fr.why != W_OK) { score[t] = -1; why[t] = fr.why; continue; }
+                if (whole_read(fr, m)) { score[t] = m; why[t] = W_OK; continue; }
+                const int ns = probe_rows(x, tb, fr, ln);
+                uint32_t w = W_OK, aux = 0xffffffffu;
+                const Refine rf{x, tb.gt + tb.bytes, m, n};
+                int32_t sc = back(fr, ns, ln, Lane{generic, 1}, &w, 0, &rf, &aux);
+                if (sc < 0 && w == W_NOT_TIGHT && aux != 0xffffffffu) {
+                    sc = band_trim_verdict(fr, m, ln, aux, &rf);
+                    if (sc >= 0) { w = W_OK; trimmed[t] = 1; }
+                }
+                score[t] = sc; why[t] = w;
+            }
+        }
+    }
+    return 0;
 }
 }

@@ -505,3 +505,43 @@ def test_whole_read_is_decided_whatever_else_matches(core):
     # (a whole read the stage does not decide found no diagonal: every 6-mer of a short-unit repeat is repeated, no sampled row gives a
     # candidate — those go on to band_sweep_kernel)
     assert decided[whole].sum() >= 8 and set(why[whole & ~decided].tolist()) <= {2}, {WHY[k]: int(v) for k, v in zip(*np.unique(why[whole], return_counts=True))}
+
+
+def test_band_trimmed_bound_decides_the_banded_score(core):
+    """vtx_band_trim.h (not in any kernel yet): the run bound over the main pieces trimmed to the one-diagonal band bounds the
+    BANDED score.  Behind the corridor refinement, on substitution-error models, indels, real-read shapes, repeats and real sequence:
+    every score it decides is the oracle's banded score — also (and mostly) where banded < full, which the bound of the full score can
+    never decide — and it decides a third to a half of what the refinement leaves on noisy reads."""
+    core.vtxt_fastcore_trim_batch.argtypes = [C.POINTER(VtxBatch), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    core.vtxt_fastcore_trim_batch.restype = C.c_int
+    cases = [("sub %.3f" % e, synth.make_batch(synth.SynthSpec(n_loci=250, n_barcodes=500, reads_per_locus=24, sub_error=e, seed=300 + i)), 500)
+             for i, e in enumerate((0.01, 0.03, 0.08, 0.08, 0.15))]
+    cases += list(SB.synthetic_batches(per_model=1, n_loci=40, reads=16))
+    cases += list(SB.real_shape_batches(trials=1)) + list(SB.real_sequence_batches(trials=1))
+    cases += list(SB.repeat_rich_batches(trials=2, loci=12, reads=8, pad_range=(60, 120))) + list(SB.near_repeat_batches(trials=1))
+    n_trim = n_below = 0
+    left = {}
+    for label, batch, nb in cases:
+        if max(int(batch.loci["ref_len"].max()), int(batch.loci["alt_len"].max())) > 255:
+            continue
+        st = batch.as_struct()
+        n = 2 * batch.n_records
+        sc, why, tr = np.zeros(n, np.int32), np.zeros(n, np.uint32), np.zeros(n, np.uint8)
+        assert core.vtxt_fastcore_trim_batch(C.byref(st), 1024, sc.ctypes.data, why.ctypes.data, tr.ctypes.data) == 0
+        s0, w0 = run_core(core, batch, 1024 | (1 << 30))                       # the same logic without the trimmed bound
+        r, a = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=nb), threads=8)
+        rf, af = oracle.batch_scores(batch, default_config(aligner="full", n_barcodes=nb), threads=8)
+        want, full = np.empty(n, np.int32), np.empty(n, np.int32)
+        want[0::2], want[1::2] = r, a
+        full[0::2], full[1::2] = rf, af
+        dec = sc >= 0
+        bad = np.nonzero(dec & (sc != want))[0]
+        assert bad.size == 0, "%s: task %d scored %d, oracle %d (trimmed %d)" % (label, bad[0], sc[bad[0]], want[bad[0]], tr[bad[0]])
+        assert np.array_equal(sc[tr == 0], s0[tr == 0]) and np.all(s0[tr == 1] < 0) and np.all(w0[tr == 1] == 8)   # it only adds verdicts
+        n_trim += int((tr == 1).sum())
+        n_below += int(((tr == 1) & (want < full)).sum())
+        if label.startswith("sub 0.08"):
+            left[label + str(len(left))] = (int((w0 == 8).sum()), int((why == 8).sum()))
+    assert n_trim > 2000 and n_below > 1500, (n_trim, n_below)
+    for before, after in left.values():
+        assert after < 0.6 * before, left
