@@ -25,6 +25,18 @@
 //
 // Measured (host, refinement on): decides 58 % (8 % errors) and 53 % (3 %) of what the refinement leaves, every decided score the
 // oracle's banded score (tests).  Projected on the device: the one-diagonal DP of 8 % errors 151 -> ~65 ms per step.
+//
+// Where it goes on the device (not applied): band_refine_kernel already holds everything in its record — band_pack (d, ca, cb), the
+// certificate, the far matches, the pieces and the mismatch nibbles.  Behind its `ub == cert` test, for batches whose haplotypes
+// have <= 255 bases (ca / cb are bytes of the pack):
+//     else {
+//         const int lo = max(0, ca - vtxf::W - 1 - d), hi = min((int)rec.read_len - 1, cb + vtxf::W - 1 - d);
+//         const int ubb = max(max(vtxf::K - 1, far_e > 0 ? far_e + 5 : 0), vtxf::main_pieces_ub_band(pl, r, h.w, d, &rf, lo, hi));
+//         if (ubb == cert) { if (stage) stage[task] = VTX_STAGE_BAND_CERT; }      // a stage of its own: banded < full is allowed here
+//         else fail = true;
+//     }
+// plus the stage code in include/vtx.h / abi.py (tests/audit_util.py: "banded != full => a DP stage or this one"), the parity suite,
+// tools/full_audit.py and the counters again.
 #ifndef VTX_BAND_TRIM_H
 #define VTX_BAND_TRIM_H
 #include "vtx_fast_core.h"
