@@ -58,3 +58,27 @@ for label, b, nb in (list(SB.real_shape_batches(trials=3)) + list(SB.real_sequen
     tot += run(label, b, nb)
 print("stress (error rates 2 - 20 %%, read lengths 60 - 190, paddings 20 - 100, indel loci, real-read shapes, real sequence, repeats): "
       "%d tasks, %d decided by the trimmed bound, every decided score the oracle's banded score" % (tot[0], tot[5]))
+
+# The same under the alternative of the one recollected detail that moves bands (include/vtx_band_semantics.h: the lazy extension
+# recompiled to 0, the oracle run with the same override): the trimmed rows follow band_pack, whatever built it.
+import tempfile
+with tempfile.TemporaryDirectory() as td:
+    so = os.path.join(td, "libfastcore_lazy0.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DVTX_BAND_LAZY_EXT(k)=0", "-o", so, "tests/fastcore/fastcore_host.cpp"])
+    L = C.CDLL(so)
+    L.vtxt_fastcore_trim_batch.argtypes = [C.POINTER(VtxBatch), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.vtxt_fastcore_batch.argtypes = [C.POINTER(VtxBatch), C.c_uint32, C.c_void_p, C.c_void_p]
+    O = oracle.lib(); O.vtxo_set_variant.argtypes = [C.c_int, C.c_int]
+    O.vtxo_set_variant(0, 0)
+    THREADS = 1                          # (the oracle's variant switches are process globals: single-threaded use)
+    try:
+        tot = np.zeros(7, np.int64)
+        seed = 500
+        for err in (0.03, 0.08, 0.12):
+            for rl, pad in ((150, 100), (100, 40)):
+                seed += 1
+                tot += run("lazy0 err %g" % err, synth.make_batch(synth.SynthSpec(n_loci=120, n_barcodes=500, reads_per_locus=12, sub_error=err,
+                                                                                    read_len=rl, padding=pad, seed=seed)), 500)
+    finally:
+        O.vtxo_set_variant(0, -1)
+    print("lazy extension 0 (harness and oracle): %d tasks, %d decided by the trimmed bound, every decided score the oracle's banded score" % (tot[0], tot[5]))
