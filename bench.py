@@ -270,17 +270,30 @@ def main():
         # If the library's communicator cannot be set up on this node (it has never run between two devices: no such node was available
         # to this project), every rank falls back to the torch.distributed gather TOGETHER and the line says so — a scaling run that
         # reports the alternative path beats one that reports nothing.  (An error inside a later vtx_gather_coo still ends the run.)
+        # Every rank runs the same sequence of collectives whatever fails where: broadcast(id + ok byte), then all_reduce(MIN).  Rank 0's
+        # vtx_comm_id failure (librccl cannot be opened, ...) travels as an all-zero id with ok byte 0 — it must not skip the broadcast
+        # the other ranks are blocked in.
         ok = 1
-        try:
-            ident = torch.zeros(lib.COMM_ID_BYTES, dtype=torch.uint8, device=ddev)
-            if rank == 0:
-                ident = torch.frombuffer(bytearray(lib.comm_id()), dtype=torch.uint8).to(ddev)
-            dist.broadcast(ident, src=0)
-            if os.environ.get("VTX_BENCH_TEST_COMM_FAIL") == "1":      # (tests/test_gpu_shard.py: the fallback below)
-                raise RuntimeError("VTX_BENCH_TEST_COMM_FAIL")
-            ctx.comm_init(bytes(ident.cpu().numpy().tobytes()), rank, world)
-        except Exception as e:                                 # (a SystemExit of the rehearsal check above is not caught here)
-            ok, native_error = 0, "%s: %s" % (type(e).__name__, e)
+        ident = torch.zeros(lib.COMM_ID_BYTES + 1, dtype=torch.uint8)
+        if rank == 0:
+            try:
+                ident[:lib.COMM_ID_BYTES] = torch.frombuffer(bytearray(lib.comm_id()), dtype=torch.uint8)
+                ident[lib.COMM_ID_BYTES] = 1
+            except Exception as e:
+                ok, native_error = 0, "%s: %s" % (type(e).__name__, e)
+        ident = ident.to(ddev)
+        dist.broadcast(ident, src=0)
+        ident = ident.cpu()
+        if int(ident[lib.COMM_ID_BYTES]) != 1:
+            if ok:
+                ok, native_error = 0, "vtx_comm_id failed on rank 0"
+        else:
+            try:
+                if os.environ.get("VTX_BENCH_TEST_COMM_FAIL") == "1":      # (tests/test_gpu_shard.py: the fallback below)
+                    raise RuntimeError("VTX_BENCH_TEST_COMM_FAIL")
+                ctx.comm_init(bytes(ident[:lib.COMM_ID_BYTES].numpy().tobytes()), rank, world)
+            except Exception as e:                             # (a SystemExit of the rehearsal check above is not caught here)
+                ok, native_error = 0, "%s: %s" % (type(e).__name__, e)
         flag = torch.tensor([ok], dtype=torch.int32, device=ddev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
@@ -331,12 +344,15 @@ def main():
     elapsed = time.perf_counter() - t0
     # cross-check of a short timed region (the K steps above are the measurement): keep stepping until --sustain-seconds have passed
     sustained = None
-    if args.sustain_seconds > 0 and elapsed < args.sustain_seconds:
-        more = int(min(10000, max(1, (args.sustain_seconds - elapsed) / max(elapsed / args.steps, 1e-6))))
-        if world > 1:                                      # every rank must take the same number of (collective) steps
-            mt = torch.tensor([more], dtype=torch.int64, device=ddev)
-            dist.all_reduce(mt, op=dist.ReduceOp.MAX)
-            more = int(mt.item())
+    # (the decision and the step count are agreed over the ranks BEFORE anybody branches: a rank near the threshold must not skip
+    #  the collectives the others enter)
+    elapsed_all = elapsed
+    if world > 1:
+        et = torch.tensor([elapsed], dtype=torch.float64, device=ddev)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        elapsed_all = float(et.item())
+    if args.sustain_seconds > 0 and elapsed_all < args.sustain_seconds:
+        more = int(min(10000, max(1, (args.sustain_seconds - elapsed_all) / max(elapsed_all / args.steps, 1e-6))))
         fence()
         t1 = time.perf_counter()
         for _ in range(more):

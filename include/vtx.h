@@ -334,6 +334,8 @@ int vtx_last_timing(vtx_ctx* ctx, vtx_timing* out);
 #define VTX_STAGE_DIAG_DP 7        /* the certificate stages' one-diagonal band (every off-diagonal match harmless) + band-masked DP */
 #define VTX_STAGE_SLOW 8           /* slow_align_kernel (records beyond the fast kernels' limits): exact DP */
 #define VTX_STAGE_FULL_DP 9        /* full flavour: the full-matrix DP */
+#define VTX_STAGE_BAND_CERT 10     /* band_refine_kernel: cert == the run bound over the pieces trimmed to the one-diagonal band — a bound of the BANDED
+                                      score (vtx_band_trim.h): like the DP stages, this one may decide a task whose banded score is below the full one */
 #define VTX_DEBUG_STAGE_TRACE 1
 #define VTX_DEBUG_POISON_SCORES 2
 #define VTX_DEBUG_POISON_VALUE 3

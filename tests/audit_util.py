@@ -33,7 +33,8 @@ def stage_report(stage):
 
 def assert_stage_invariant(stage, banded, full, label=""):
     """banded = (ref, alt) of the banded flavour, full = of the full flavour, stage = vtx_fetch_stage of the banded run.
-    cert <= banded <= full: an alignment whose two scores differ must have been decided by a DP stage."""
+    cert <= banded <= full: an alignment whose two scores differ must have been decided by a DP stage or by the
+    band-restricted certificate (abi.BANDED_STAGES)."""
     b = np.empty(2 * len(banded[0]), np.int32)
     f = np.empty_like(b)
     b[0::2], b[1::2] = banded
@@ -42,7 +43,7 @@ def assert_stage_invariant(stage, banded, full, label=""):
     known = np.isin(stage, list(abi.STAGE_NAMES))
     assert np.all(known), "%s: unknown stage byte %d" % (label, int(stage[~known][0]))
     differ = b != f
-    by_cert = differ & ~np.isin(stage, abi.DP_STAGES)
+    by_cert = differ & ~np.isin(stage, abi.BANDED_STAGES)
     assert not by_cert.any(), "%s: task %d has banded %d != full %d but was decided by stage %d" % (
         label, int(np.nonzero(by_cert)[0][0]), int(b[by_cert][0]), int(f[by_cert][0]), int(stage[by_cert][0]))
     return differ

@@ -6,7 +6,7 @@
 The banded flavour runs on the device with the stage trace on and the score arrays poisoned; oracle.batch_scores (the restated
 reference CPU path: bio 0.30.0's banded::Aligner::local per read and haplotype, src/main.rs:898-901) scores the whole batch on the
 host's cores; every one of the 2 x records scores is compared, and the mismatches — none are expected — are broken down by the
-stage that decided them.  The full flavour runs too: banded != full must imply a DP stage."""
+stage that decided them.  The full flavour runs too: banded != full must imply a DP stage or the band-restricted certificate."""
 import os
 import sys
 import time
@@ -56,7 +56,7 @@ def main():
         bad = b != o
         print("%s: %s" % (name, spec.name))
         print("  %d alignments on the device (second run of the context, scores poisoned before it); decided by %s" % (len(b), stage_report(stage)))
-        print("  banded != full on %d alignments, every one decided by a DP stage" % int(differ.sum()))
+        print("  banded != full on %d alignments, every one decided by a DP stage or the band-restricted certificate" % int(differ.sum()))
         print("  oracle: all %d alignments in %.0f s on %d threads (%.3g alignments/s)" % (len(o), dt, threads, len(o) / dt))
         print("  MISMATCHES device vs oracle: %d%s" % (int(bad.sum()), "" if not bad.any() else
               "  by stage %s, first at task %d: device %d oracle %d" % (stage_report(stage[bad]), int(np.nonzero(bad)[0][0]),

@@ -56,6 +56,7 @@
 
 #include "vtx_device.h"
 #include "vtx_fast_core.h"
+#include "vtx_band_trim.h"
 #include "../../include/vtx_band_semantics.h"
 
 #define KMER 6
@@ -2398,8 +2399,18 @@ __global__ __launch_bounds__(256) void band_refine_kernel(
         const vtxf::Refine rf{read_arena + rec.read_off, yb, (int)rec.read_len, (int)(hap ? loc.alt_len : loc.ref_len)};
         const int ub = max(max(vtxf::K - 1, far_e > 0 ? far_e + 5 : 0), vtxf::main_pieces_ub(pl, r, h.w, d, &rf));
         (hap ? alt_score : ref_score)[rid] = cert;                     // final when ub == cert, provisional otherwise
-        if (ub == cert) { if (stage) stage[task] = 2; }
-        else fail = true;
+        if (ub == cert) { if (stage) stage[task] = VTX_STAGE_REFINE_CERT; }
+        else if (tight_list) {
+            // Round 6 (vtx_band_trim.h): the same bound over the pieces TRIMMED to the rows whose main-diagonal cell lies in the band
+            // bounds the BANDED score (a path inside the band touches in-band cells only).  Where the band cuts end pieces off
+            // (banded < full: half of what the refinement leaves on noisy reads) no bound of the full score can meet the certificate;
+            // this one does.  A tight list means every haplotype has <= 255 bases: ca / cb are the bytes of the pack.
+            const int ca = (int)((h.y >> 8) & 0xffu), cb = (int)(h.y & 0xffu);
+            const int lo = max(0, ca - vtxf::W - 1 - d), hi = min((int)rec.read_len - 1, cb + vtxf::W - 1 - d);
+            const int ubb = max(max(vtxf::K - 1, far_e > 0 ? far_e + 5 : 0), vtxf::main_pieces_ub_band(pl, r, h.w, d, &rf, lo, hi));
+            if (ubb == cert) { if (stage) stage[task] = VTX_STAGE_BAND_CERT; }      // a stage of its own: banded < full is allowed here
+            else fail = true;
+        } else fail = true;
     }
     const uint64_t fm = __ballot(fail);
     if (fm) {

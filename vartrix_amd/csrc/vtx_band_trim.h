@@ -1,8 +1,8 @@
 // vtx_band_trim.h — the run bound of a one-diagonal task restricted to its BAND: an upper bound of the BANDED score, not of the full one.
 //
-// STATUS (round 5): per-task logic + host harness + tests (tests/fastcore, tests/test_fastcore.py::test_band_trimmed_bound_*); NOT
-// included by any kernel yet — the round's GPU minutes were spent when the measurement below was made, and the kernels of record
-// stay the ones the counters and audits under profiles/ were taken on.  Include after vtx_fast_core.h.
+// STATUS: included by vtx_band.hip; band_refine_kernel runs it behind its `ub == cert` test (round 6; stage VTX_STAGE_BAND_CERT).
+// Host harness and tests: tests/fastcore, tests/test_fastcore.py::test_band_trimmed_bound_*, tools/band_trim_stress.py
+// (profiles/r05_band_trim_cpu.txt: 2.0 M tasks against the oracle).
 //
 // Why.  On noisy reads (3 % / 8 % substitution errors) the tasks that leave band_diag_kernel / band_refine_kernel WITH a certificate
 // have cert == banded for 95 % — and banded < full for 27 % / 51 %: sdpkpp drops short end pieces (a jump over D bases costs 2 D), the
@@ -26,17 +26,9 @@
 // Measured (host, refinement on): decides 58 % (8 % errors) and 53 % (3 %) of what the refinement leaves, every decided score the
 // oracle's banded score (tests).  Projected on the device: the one-diagonal DP of 8 % errors 151 -> ~65 ms per step.
 //
-// Where it goes on the device (not applied): band_refine_kernel already holds everything in its record — band_pack (d, ca, cb), the
-// certificate, the far matches, the pieces and the mismatch nibbles.  Behind its `ub == cert` test, for batches whose haplotypes
-// have <= 255 bases (ca / cb are bytes of the pack):
-//     else {
-//         const int lo = max(0, ca - vtxf::W - 1 - d), hi = min((int)rec.read_len - 1, cb + vtxf::W - 1 - d);
-//         const int ubb = max(max(vtxf::K - 1, far_e > 0 ? far_e + 5 : 0), vtxf::main_pieces_ub_band(pl, r, h.w, d, &rf, lo, hi));
-//         if (ubb == cert) { if (stage) stage[task] = VTX_STAGE_BAND_CERT; }      // a stage of its own: banded < full is allowed here
-//         else fail = true;
-//     }
-// plus the stage code in include/vtx.h / abi.py (tests/audit_util.py: "banded != full => a DP stage or this one"), the parity suite,
-// tools/full_audit.py and the counters again.
+// On the device: band_refine_kernel holds everything in its record — band_pack (d, ca, cb), the certificate, the far matches, the
+// pieces and the mismatch nibbles — and calls main_pieces_ub_band for batches whose haplotypes have <= 255 bases (ca / cb are bytes
+// of the pack).  tests/audit_util.py: "banded != full => a DP stage or this one".
 #ifndef VTX_BAND_TRIM_H
 #define VTX_BAND_TRIM_H
 #include "vtx_fast_core.h"
