@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define VTX_ABI_VERSION 5
+#define VTX_ABI_VERSION 6
 
 typedef enum vtx_status {
     VTX_OK = 0,
@@ -255,6 +255,80 @@ int vtx_submit_raw(vtx_ctx* ctx, const vtx_raw_batch* batch, vtx_raw_stats* stat
  * (rec_begin, rec_count) pairs).  Buffers are caller-allocated; n_records = stats.kept.           */
 int vtx_fetch_records(vtx_ctx* ctx, vtx_record* records, uint32_t* rec_begin, uint32_t* rec_count);
 
+/* ---- vtx_submit_bam: the ingest itself on the device (round 6) -------------------------------------------------------------
+ * Replaces, for one contiguous stretch of a coordinate-sorted BAM, what the reference does per locus on the CPU before the
+ * aligner: `bam.fetch(tid, start, end)` + `bam.records()` (src/main.rs:822-830; rust-htslib -> htslib bgzf_read -> zlib below
+ * them), the read filters in their order with the Metrics counters (:831-864: num_reads, mapq, primary, duplicates,
+ * useful_alignment :790-806), the barcode / UB tags as bytes (:737-757) and rec.seq() (:896); then, as after vtx_submit_raw, the
+ * in-list test, the UB test, the UMI grouping and the sort by cell.  The host hands over the FILE BYTES and an index of them:
+ *   blocks     consecutive BGZF blocks (payload offset / size, ISIZE) — a header walk, no inflate;
+ *   seeds      ascending offsets into the inflated stream of those blocks at which a BAM record starts: the first record to look at
+ *              and whatever record starts the .bai's linear index names (SAM spec 5.2: one per 16 kb window with alignments).
+ *              Record boundaries are a serial block_size chain; the seeds cut it into independent pieces.  A chain that does not
+ *              land exactly on the next seed (index and file disagree) is an error, not a guess;
+ *   end_upos   records starting at or beyond this offset are not looked at (a record start, or the end of the stream);
+ *   intervals  the loci as the fetch sees them, per contig sorted by start (Locus {chrom, start, end}, src/main.rs:619-623);
+ *   loci / hap_arena   as in vtx_raw_batch; rec_begin / rec_count are ignored (the device fills them).
+ * The same resident state afterwards as after vtx_submit_raw (vtx_run / vtx_fetch_* unchanged); stats carries the Metrics
+ * counters the filters produce.  VTX_E_UNSUPPORTED (with the reason in vtx_strerror) when the device declines — a block its
+ * inflater does not accept, reads above one batch's 4 GiB arena: the caller then packs on the host (libvtxhost), where zlib and the
+ * multi-batch logic live.  Nothing is read from the file but [blocks[0].coff, blocks[n - 1].coff + clen).                         */
+typedef struct vtx_bgzf_block {
+    uint64_t coff;       /* file offset of the block's raw-DEFLATE payload (behind the gzip header and its extra field) */
+    uint32_t clen;       /* payload bytes (BSIZE + 1 - header - 8)                                                      */
+    uint32_t isize;      /* ISIZE: bytes it inflates to (<= 65536)                                                      */
+} vtx_bgzf_block;
+
+typedef struct vtx_bam_interval {
+    int32_t start, end;  /* [start, end) on its contig, 0-based */
+    uint32_t locus;      /* index into vtx_bam_ingest.loci      */
+    uint32_t reserved;
+} vtx_bam_interval;
+
+typedef struct vtx_bam_ingest {
+    const uint8_t* file;                 /* the BAM file's bytes (e.g. a read-only mapping) */
+    uint64_t file_bytes;
+    const vtx_bgzf_block* blocks;
+    uint32_t n_blocks;
+    uint32_t n_ref;                      /* contigs of the BAM header */
+    const uint64_t* seeds;
+    uint32_t n_seeds;
+    uint32_t n_intervals;
+    uint64_t end_upos;
+    const vtx_bam_interval* intervals;   /* contig t owns [tid_begin[t], tid_begin[t + 1]) */
+    const uint32_t* tid_begin;           /* n_ref + 1 entries */
+    const int32_t* tid_max_span;         /* n_ref entries: the longest end - start among the contig's intervals */
+    const vtx_locus* loci;
+    uint32_t n_loci;
+    uint32_t min_mapq;                   /* --mapq (src/main.rs:112-116)            */
+    int32_t primary_only;                /* --primary-alignments (:117-119)         */
+    int32_t no_duplicates;               /* --no-duplicates (:120-122)              */
+    const uint8_t* hap_arena;
+    uint64_t hap_bytes;
+    char bam_tag[2];                     /* --bam-tag, default "CB" (:126-129)      */
+    char reserved[6];
+} vtx_bam_ingest;
+
+typedef struct vtx_ingest_stats {
+    uint64_t num_reads, num_low_mapq, num_non_primary, num_duplicates, num_not_useful;   /* Metrics, src/main.rs:449-459 */
+    uint64_t num_no_barcode_tag;         /* reads without a usable barcode tag (part of num_not_cell_bc; raw.num_not_cell_bc has the rest) */
+    uint64_t bam_records, raw_records;   /* BAM records looked at; (read, locus) pairs handed to the preparation */
+    uint64_t compressed_bytes, inflated_bytes;
+    vtx_raw_stats raw;
+    float h2d_ms, inflate_ms, index_ms, filter_ms;   /* host wall time of the upload; device time of the inflate, the record chains, the filter passes */
+} vtx_ingest_stats;
+
+int vtx_submit_bam(vtx_ctx* ctx, const vtx_bam_ingest* ingest, vtx_ingest_stats* stats);
+
+/* Test / audit hook: intermediate arrays of the last vtx_submit_bam.  *bytes = the array's size, min(cap, *bytes) bytes go to dst. */
+#define VTX_INGEST_INFLATED 0        /* the inflated stream of the submitted blocks                           */
+#define VTX_INGEST_RECORD_OFFSETS 1  /* uint64 per BAM record: where its block_size word lies in that stream */
+#define VTX_INGEST_RAW_RECORDS 2     /* vtx_raw_record per surviving (read, locus) pair, BAM order            */
+#define VTX_INGEST_RAW_LOCUS 3       /* uint32 per pair: its locus                                            */
+#define VTX_INGEST_TAGS 4            /* the tag arena those records point into                                */
+#define VTX_INGEST_READS_PACKED 5    /* the read arena, two bases per byte                                    */
+int vtx_debug_ingest(vtx_ctx* ctx, int what, void* dst, uint64_t cap, uint64_t* bytes);
+
 /* Run the hot path on the resident batch: Smith-Waterman of every record
  * against both haplotypes (src/main.rs:898-901), per-read call
  * (evaluate_scores :1019-1030), UMI collapse (parse_scores :1041-1109) and the
@@ -353,9 +427,9 @@ const char* vtx_strerror(const vtx_ctx* ctx);
 const char* vtx_status_name(int status);
 
 /* sizeof() of {vtx_config, vtx_locus, vtx_record, vtx_batch, vtx_coo,
- * vtx_timing, vtx_raw_record, vtx_raw_batch, vtx_raw_stats} as compiled into
- * the library, for binding self-checks.
- * Writes min(n, 9) entries; returns VTX_ABI_VERSION.                         */
+ * vtx_timing, vtx_raw_record, vtx_raw_batch, vtx_raw_stats, vtx_bgzf_block, vtx_bam_interval,
+ * vtx_bam_ingest, vtx_ingest_stats} as compiled into the library, for binding self-checks.
+ * Writes min(n, 13) entries; returns VTX_ABI_VERSION.                        */
 int vtx_abi_sizes(uint32_t* out, uint32_t n);
 
 #ifdef __cplusplus

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from vartrix_amd import synth
+from vartrix_amd import abi, synth
 from vartrix_amd.abi import VtxBatch, default_config
 
 import stress_batches as SB
@@ -49,6 +49,14 @@ def check(L, batch, n_barcodes, label, n_heads=1024):
     bad = np.nonzero(decided & (sc != want))[0]
     assert bad.size == 0, "%s: task %d scored %d, oracle %d" % (label, bad[0], sc[bad[0]], want[bad[0]])
     assert np.all((why == 0) == decided)
+    # cert == ub decides a task, and ub bounds the FULL-matrix score: a decided score is the full score too (cert <= banded <= full <= ub).
+    # (Round 6: the refined join was priced above what an excursion over a far piece costs — ub 36 < full 37 on a task whose banded
+    #  score happened to be 36 as well; comparing with the banded score alone never saw it.)
+    rf_, af_ = oracle.batch_scores(batch, default_config(aligner="full", n_barcodes=n_barcodes), threads=8)
+    full = np.empty(2 * batch.n_records, np.int32)
+    full[0::2], full[1::2] = rf_, af_
+    bad = np.nonzero(decided & (sc != full))[0]
+    assert bad.size == 0, "%s: task %d decided at %d by a bound of the full score, which is %d" % (label, bad[0], sc[bad[0]], full[bad[0]])
     return float(decided.mean()), {WHY[k]: int(v) for k, v in zip(*np.unique(why, return_counts=True))}
 
 
@@ -102,6 +110,30 @@ def test_corridor_refinement_is_exact_and_decides_more(core):
     assert dec[(0.03, 150, 1)] > dec[(0.03, 150, 0)] + 0.02, dec
     for label, batch, nb in list(SB.near_repeat_batches(trials=4)) + list(SB.repeat_rich_batches(trials=3)):
         check(core, batch, nb, label, 1024 | (1 << 30))
+
+
+def test_refined_join_stays_below_an_excursion_over_a_far_piece(core):
+    """Round 6, found by the first full audit of the 8 percent workload (tools/full_audit.py e8, task 25 715 285): seven errors within
+    16 bases between two main runs, and a 7-base exact run four diagonals out.  The excursion D4 - 7 matches - I4 joins the runs for 12;
+    join_gap3(16) = 13 assumed no run above 5 bases outside the corridor, so the refined bound said 36 where the full-matrix score is
+    37 (the banded score is 36: the band cuts the read's start off — the output was right by accident).  join_gap3_far prices the
+    excursion with the task's far k-mer matches: the task must be left undecided (or decided at the full score)."""
+    read = b'AGTGTCATGCTCAGAGCTTTCGTTACAGACAAGTCGCTCGCCCCGTCATGTGTTGGTGACTTGTTCAATAAGGGCCCGCGACAGTGCGTATCTTCACAGGTAGGGCCACTCGATTGGCTTGTCAAATTGTACCCACGCGGTTGGAGTTCT'
+    ref = b'CGAGTGCGCTGCATGACGACTAGATCAACATCACCGAACAACAAAATGTCTCACATCATGGCGTGGGCACTATGATCCGGACAGTGTCACGCTCAGAGCTCCCGTTAGACACAGACAGCTCGCCCCGTCAAGTATTGGTGACTTGTTCAATAACGGCCCGCGACGGTGCGTATCTTCTCGGGTAGGGGCATTCTGTTGGCT'
+    alt = b'CGAGTGCGCTGCATGACGACTAGATCAACATCACCGAACAACAAAATGTCTCACATCATGGCGTGGGCACTATGATCCGGACAGTGTCACGCTCAGAGCTTCCGTTAGACACAGACAGCTCGCCCCGTCAAGTATTGGTGACTTGTTCAATAACGGCCCGCGACGGTGCGTATCTTCTCGGGTAGGGGCATTCTGTTGGCT'
+    loci = np.zeros(1, abi.LOCUS_DTYPE)
+    loci["rec_count"] = 1
+    loci["ref_len"], loci["alt_off"], loci["alt_len"] = len(ref), len(ref), len(alt)
+    recs = np.zeros(1, abi.RECORD_DTYPE)
+    recs["read_len"] = len(read)
+    batch = abi.PackedBatch(loci, recs, np.frombuffer(ref + alt, np.uint8).copy(), np.frombuffer(read + bytes(16), np.uint8).copy())
+    rf_, af_ = oracle.batch_scores(batch, default_config(aligner="full", n_barcodes=4), threads=1)
+    rb_, ab_ = oracle.batch_scores(batch, default_config(aligner="banded", n_barcodes=4), threads=1)
+    assert (int(rf_[0]), int(af_[0]), int(rb_[0]), int(ab_[0])) == (36, 37, 36, 36)
+    for flags in (1024, 1024 | (1 << 30)):
+        sc, why = run_core(core, batch, flags)
+        assert sc[1] in (-1, 37), (flags, sc, why)
+        assert sc[0] in (-1, 36), (flags, sc, why)
 
 
 def test_mask_pieces_and_mismatch_counts_of_a_diagonal(core):

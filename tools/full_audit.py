@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off full audit: EVERY alignment of a full-size workload, device against the oracle.
 
-    python tools/full_audit.py [config3|real|e3] ...      (GPU box; ~2.5 min of 16 CPU threads per workload)
+    python tools/full_audit.py [config3|real|e3|e8] ...      (GPU box; ~2.5 min of 16 CPU threads per workload)
 
 The banded flavour runs on the device with the stage trace on and the score arrays poisoned; oracle.batch_scores (the restated
 reference CPU path: bio 0.30.0's banded::Aligner::local per read and haplotype, src/main.rs:898-901) scores the whole batch on the
@@ -25,6 +25,7 @@ WORKLOADS = {
     "config3": dict(),
     "real": dict(genome_fasta=os.path.join(ROOT, "tests", "golden", "test_dna.fa")),
     "e3": dict(sub_error=0.03),
+    "e8": dict(sub_error=0.08),
 }
 
 

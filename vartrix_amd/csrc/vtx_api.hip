@@ -15,12 +15,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <new>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "vtx_device.h"
+#include "vtx_ingest.h"
 #include "../../include/vtx_band_semantics.h"
 
 extern "C" hipError_t vtxk_inclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, void* temp,
@@ -122,6 +124,11 @@ struct vtx_ctx {
     bool bc_ready = false;
     DevBuf d_raw, d_tags, d_raw_locus, d_key_lc, d_key_lc2, d_key_umi, d_key_umi2, d_idx, d_idx2, d_shape, d_shape2, d_seq,
         d_locus_cnt, d_locus_scan, d_prep_cnt, d_sort_tmp;
+    // device-side BAM ingest (vtx_submit_bam, vtx_ingest.hip): compressed range, inflated stream, record offsets, per-record counts / scans
+    DevBuf d_bam_comp, d_bam_data, d_bam_blocks, d_bam_seeds, d_bam_seed_cnt, d_bam_seed_scan, d_bam_iv, d_bam_cnt, d_bam_rec, d_bam_nhit,
+        d_bam_rsz, d_bam_tsz, d_bam_hscan, d_bam_rscan, d_bam_tscan, d_bam_info;
+    uint32_t bam_n_rec = 0, bam_n_raw = 0;
+    uint64_t bam_utotal = 0, bam_read_bases = 0, bam_tag_bytes = 0;
     uint32_t max_read_len = 0, fast_overflow = 0;
     uint32_t slow_off = 0, slow_cnt = 0, max_hap_all = 0, max_read_all = 0;   // records of the slow list (d_work[slow_off ..])
     DevBuf d_slow_ws, d_slow_retry;
@@ -502,10 +509,12 @@ void vtx_config_default(vtx_config* cfg) {
 }
 
 int vtx_abi_sizes(uint32_t* out, uint32_t n) {
-    const uint32_t s[9] = {(uint32_t)sizeof(vtx_config), (uint32_t)sizeof(vtx_locus), (uint32_t)sizeof(vtx_record),
-                           (uint32_t)sizeof(vtx_batch), (uint32_t)sizeof(vtx_coo), (uint32_t)sizeof(vtx_timing),
-                           (uint32_t)sizeof(vtx_raw_record), (uint32_t)sizeof(vtx_raw_batch), (uint32_t)sizeof(vtx_raw_stats)};
-    for (uint32_t i = 0; i < n && i < 9; ++i) out[i] = s[i];
+    const uint32_t s[13] = {(uint32_t)sizeof(vtx_config), (uint32_t)sizeof(vtx_locus), (uint32_t)sizeof(vtx_record),
+                            (uint32_t)sizeof(vtx_batch), (uint32_t)sizeof(vtx_coo), (uint32_t)sizeof(vtx_timing),
+                            (uint32_t)sizeof(vtx_raw_record), (uint32_t)sizeof(vtx_raw_batch), (uint32_t)sizeof(vtx_raw_stats),
+                            (uint32_t)sizeof(vtx_bgzf_block), (uint32_t)sizeof(vtx_bam_interval), (uint32_t)sizeof(vtx_bam_ingest),
+                            (uint32_t)sizeof(vtx_ingest_stats)};
+    for (uint32_t i = 0; i < n && i < 13; ++i) out[i] = s[i];
     return VTX_ABI_VERSION;
 }
 
@@ -582,6 +591,9 @@ void vtx_destroy(vtx_ctx* c) {
                       &c->d_prep_cnt, &c->d_sort_tmp, &c->d_fail, &c->d_fail_tmp, &c->d_refine, &c->d_tight, &c->d_tight_pack, &c->d_dband, &c->d_dband_pack, &c->d_dense, &c->d_stage, &c->d_sweep_log, &c->d_tight2, &c->d_tight2_pack, &c->d_recheck2, &c->d_recheck2_pack};
     for (DevBuf* b : bufs) b->release();
     c->d_slow_ws.release(); c->d_slow_retry.release(); c->d_read_packed.release();
+    DevBuf* ib[] = {&c->d_bam_comp, &c->d_bam_data, &c->d_bam_blocks, &c->d_bam_seeds, &c->d_bam_seed_cnt, &c->d_bam_seed_scan, &c->d_bam_iv, &c->d_bam_cnt,
+                    &c->d_bam_rec, &c->d_bam_nhit, &c->d_bam_rsz, &c->d_bam_tsz, &c->d_bam_hscan, &c->d_bam_rscan, &c->d_bam_tscan, &c->d_bam_info};
+    for (DevBuf* b : ib) b->release();
     DevBuf* gb[] = {&c->d_g_cnt, &c->d_g_row, &c->d_g_col, &c->d_g_alt, &c->d_g_ref, &c->d_g_unk, &c->d_g_val, &c->d_g_refval};
     for (DevBuf* b : gb) b->release();
     comm_release(c);
@@ -812,44 +824,15 @@ int vtx_set_barcodes(vtx_ctx* c, const uint8_t* bytes, const uint64_t* offsets, 
     return VTX_OK;
 }
 
-int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
-    if (!c) return VTX_E_INVAL;
-    if (!b) return fail(c, VTX_E_INVAL, "vtx_submit_raw: null batch");
-    c->submitted = false; c->ran = false;
-    if (!c->bc_ready) return fail(c, VTX_E_STATE, "vtx_submit_raw: no barcode list (vtx_set_barcodes)");
-    const uint32_t nl = b->n_loci, nr = b->n_records;
-    if ((nl && !b->loci) || (nr && !b->records) || (b->hap_bytes && !b->hap_arena) || (b->read_bytes && !b->read_arena) ||
-        (b->tag_bytes && !b->tag_arena))
-        return fail(c, VTX_E_INVAL, "vtx_submit_raw: null array with non-zero count");
-    if (b->hap_bytes > 0xffffffffull || b->read_bytes > 0xffffffffull || b->tag_bytes > 0xffffffffull)
-        return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_raw: arenas above 4 GiB need more than one batch");
-    // loci: host validation is O(loci); everything per record happens on the device
-    uint32_t next_rec = 0, max_hap = 0, max_hap_all = 0;
-    for (uint32_t l = 0; l < nl; ++l) {
-        const vtx_locus& L = b->loci[l];
-        if (L.rec_begin != next_rec) return fail(c, VTX_E_INVAL, "vtx_submit_raw: locus %u: records not contiguous (rec_begin %u, expected %u)", l, L.rec_begin, next_rec);
-        if ((uint64_t)L.rec_begin + L.rec_count > nr) return fail(c, VTX_E_INVAL, "vtx_submit_raw: locus %u: record range exceeds n_records", l);
-        if ((uint64_t)L.ref_off + L.ref_len > b->hap_bytes || (uint64_t)L.alt_off + L.alt_len > b->hap_bytes)
-            return fail(c, VTX_E_INVAL, "vtx_submit_raw: locus %u: haplotype outside hap_arena", l);
-        if (L.ref_len > kMaxHapLen || L.alt_len > kMaxHapLen)
-            return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_raw: locus %u: haplotype longer than %u", l, kMaxHapLen);
-        const uint32_t hl = std::max(L.ref_len, L.alt_len);
-        max_hap_all = std::max(max_hap_all, hl);
-        if (hl <= kFastHapLen) max_hap = std::max(max_hap, hl);
-        next_rec = L.rec_begin + L.rec_count;
-    }
-    if (next_rec != nr) return fail(c, VTX_E_INVAL, "vtx_submit_raw: %u records not covered by any locus", nr - next_rec);
-
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    hipStream_t s = c->stream;
+// ---- raw batches: what vtx_submit_raw and vtx_submit_bam share ----
+// device buffers of a raw batch of nr records over nl loci (the arenas: d_read / d_read_packed, d_tags; the records: d_raw, d_raw_locus)
+static int raw_reserve(vtx_ctx* c, uint32_t nl, uint32_t nr, uint64_t hap_bytes, uint64_t read_bytes, uint64_t tag_bytes, bool nibbles) {
     const size_t u32 = sizeof(uint32_t), u64 = sizeof(uint64_t);
     HIP_TRY(c, c->d_loci.reserve((size_t)nl * sizeof(vtx_locus)));
-    HIP_TRY(c, c->d_hap.reserve(b->hap_bytes + 16));
-    HIP_TRY(c, c->d_read.reserve(b->read_bytes + 16));
-    const bool nibbles = c->read_format == VTX_READS_NIBBLES;
-    if (nibbles && (b->read_bytes & 1)) return fail(c, VTX_E_INVAL, "vtx_submit_raw: VTX_READS_NIBBLES needs an even read_bytes");
-    if (nibbles) HIP_TRY(c, c->d_read_packed.reserve(b->read_bytes / 2 + 16));
-    HIP_TRY(c, c->d_tags.reserve(b->tag_bytes + 16));
+    HIP_TRY(c, c->d_hap.reserve(hap_bytes + 16));
+    HIP_TRY(c, c->d_read.reserve(read_bytes + 16));
+    if (nibbles) HIP_TRY(c, c->d_read_packed.reserve(read_bytes / 2 + 16));
+    HIP_TRY(c, c->d_tags.reserve(tag_bytes + 16));
     HIP_TRY(c, c->d_raw.reserve((size_t)nr * sizeof(vtx_raw_record)));
     if (int rc = reserve_record_buffers(c, nr)) return rc;
     DevBuf* k64[] = {&c->d_key_lc, &c->d_key_lc2, &c->d_key_umi, &c->d_key_umi2};
@@ -863,43 +846,47 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     HIP_TRY(c, c->d_prep_cnt.reserve(8 * u64 + 64 * u32));
     const size_t sort_tmp = vtxk_prep_sort_temp_bytes(nr);
     HIP_TRY(c, c->d_sort_tmp.reserve(std::max(sort_tmp, vtxk_scan_temp_bytes(std::max(nr, nl)))));
-    unsigned long long* d_counters = c->d_prep_cnt.as<unsigned long long>();
-    uint32_t* d_shape_cnt = (uint32_t*)(d_counters + 8);
-    uint32_t* d_lut_flag = d_shape_cnt + 16;
     uint32_t caps[kNumShapes];
     for (int i = 0; i < kNumShapes; ++i) caps[i] = (uint32_t)(kShapes[i][0] * kShapes[i][1]);
     HIP_TRY(c, vtxk_prep_set_shapes(caps, kNumShapes, kFastReadLen, kFastHapLen));
+    return VTX_OK;
+}
 
-    if (int rc = upload(c, {{c->d_loci.p, b->loci, (size_t)nl * sizeof(vtx_locus)},
-                            {c->d_raw.p, b->records, (size_t)nr * sizeof(vtx_raw_record)},
-                            {c->d_hap.p, b->hap_arena, (size_t)b->hap_bytes},
-                            {c->d_tags.p, b->tag_arena, (size_t)b->tag_bytes},
-                            {nibbles ? c->d_read_packed.p : c->d_read.p, b->read_arena, (size_t)(nibbles ? b->read_bytes / 2 : b->read_bytes)}})) return rc;
-    if (nibbles) HIP_TRY(c, vtxk_unpack_nibbles(c->d_read_packed.as<uint8_t>(), b->read_bytes / 2, c->d_read.as<uint8_t>(), s));
-
+// Barcode lookup, UB test, UMI grouping and the sort by (locus, cell, UMI) of the nr raw records resident in d_raw / d_tags (their
+// bases in d_read), then the work lists and the group structure: the state vtx_submit leaves.  locus_from_loci: d_raw_locus is derived
+// from the loci's record ranges (vtx_submit_raw: records grouped by locus); otherwise the caller filled it (vtx_submit_bam: records in
+// BAM order, a locus per record — the sort's key does not care).
+static int raw_prepare(vtx_ctx* c, uint32_t nl, uint32_t nr, uint64_t read_bytes, uint64_t tag_bytes, bool nibbles, uint32_t max_hap,
+                       uint32_t max_hap_all, bool locus_from_loci, vtx_raw_stats* stats) {
+    hipStream_t s = c->stream;
+    const size_t u32 = sizeof(uint32_t), u64 = sizeof(uint64_t);
+    const size_t sort_tmp = vtxk_prep_sort_temp_bytes(nr);
+    unsigned long long* d_counters = c->d_prep_cnt.as<unsigned long long>();
+    uint32_t* d_shape_cnt = (uint32_t*)(d_counters + 8);
+    uint32_t* d_lut_flag = d_shape_cnt + 16;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     const uint32_t cell_bits = bits_for(c->cfg.n_barcodes ? c->cfg.n_barcodes - 1 : 0);
     const int end_bit = (int)(cell_bits + bits_for(nl));
-    if (end_bit > 64) return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_raw: loci x barcodes exceed a 64-bit sort key");
+    if (end_bit > 64) return fail(c, VTX_E_UNSUPPORTED, "raw batch: loci x barcodes exceed a 64-bit sort key");
     const int use_umi = c->cfg.use_umi ? 1 : 0;
     unsigned long long cnt[8] = {0};
     uint32_t n_kept = 0, rounds = 0;
     // test hook: the first N rounds hash every UMI to 0, so that the collision check and the re-seed are exercised
     const uint32_t weak_rounds = VTX_DEV_ENV("VTX_PREP_WEAK_ROUNDS") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_PREP_WEAK_ROUNDS")) : 0;
-    if (nr) HIP_TRY(c, vtxk_prep_rec_locus(c->d_loci.as<vtx_locus>(), nl, c->d_raw_locus.as<uint32_t>(), s));
+    if (nr && locus_from_loci) HIP_TRY(c, vtxk_prep_rec_locus(c->d_loci.as<vtx_locus>(), nl, c->d_raw_locus.as<uint32_t>(), s));
     for (uint64_t seed = 0x9e3779b97f4a7c15ull;; seed = seed * 0xd1342543de82ef95ull + 1) {
         ++rounds;
         HIP_TRY(c, hipMemsetAsync(c->d_prep_cnt.p, 0, 8 * u64 + 64 * u32, s));
         HIP_TRY(c, hipMemsetAsync(c->d_locus_cnt.p, 0, ((size_t)nl + 1) * u32, s));      // first record of each locus
         HIP_TRY(c, hipMemsetAsync(c->d_locus_scan.p, 0, ((size_t)nl + 1) * u32, s));     // one past its last record
         HIP_TRY(c, vtxk_prep_resolve(c->d_raw.as<vtx_raw_record>(), nr, c->d_raw_locus.as<uint32_t>(), c->d_tags.as<uint8_t>(),
-                                     b->tag_bytes, b->read_bytes, kMaxReadLen | (nibbles ? 0x80000000u : 0u), c->d_bc_slots.as<uint32_t>(), c->bc_mask,
+                                     tag_bytes, read_bytes, kMaxReadLen | (nibbles ? 0x80000000u : 0u), c->d_bc_slots.as<uint32_t>(), c->bc_mask,
                                      c->d_bc_hash.as<uint64_t>(), c->d_bc_off.as<uint64_t>(), c->d_bc_bytes.as<uint8_t>(),
                                      use_umi, seed, rounds <= weak_rounds ? 0ull : ~0ull, cell_bits, nl, c->d_key_lc.as<uint64_t>(), c->d_key_umi.as<uint64_t>(),
                                      c->d_idx.as<uint32_t>(), d_counters, s));
         HIP_TRY(c, hipMemcpyAsync(cnt, d_counters, 3 * u64, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
-        if (cnt[2]) return fail(c, VTX_E_INVAL, "vtx_submit_raw: a record points outside its arena, is longer than %u bases, or (VTX_READS_NIBBLES) starts at an odd base", kMaxReadLen);
+        if (cnt[2]) return fail(c, VTX_E_INVAL, "raw batch: a record points outside its arena, is longer than %u bases, or (VTX_READS_NIBBLES) starts at an odd base", kMaxReadLen);
         n_kept = nr - (uint32_t)cnt[0] - (uint32_t)cnt[1];
         // stable LSD order: UMI hash first, then (locus, cell); dropped records carry the largest key and end up last
         const uint32_t* perm = nullptr;
@@ -924,7 +911,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
         HIP_TRY(c, hipMemcpyAsync(cnt, d_counters, 8 * u64, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         if (!cnt[4]) break;                  // no UMI hash collision inside a (locus, cell) group
-        if (rounds == 8) return fail(c, VTX_E_STATE, "vtx_submit_raw: UMI hash collisions with 8 different seeds");
+        if (rounds == 8) return fail(c, VTX_E_STATE, "raw batch: UMI hash collisions with 8 different seeds");
     }
     const size_t scan_tmp = vtxk_scan_temp_bytes(std::max(nr, nl));
     // dense UMI group numbers; per-locus record ranges of the kept, sorted records
@@ -962,6 +949,233 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     if (stats) {
         stats->num_not_cell_bc = cnt[0]; stats->num_non_umi = cnt[1]; stats->kept = n_kept; stats->prep_ms = ms;
         stats->hash_rounds = rounds;
+    }
+    return VTX_OK;
+}
+
+// loci of a raw batch, host side: haplotypes inside the arena and within the limits; *max_hap: the longest one the fast kernels take
+static int check_loci_haps(vtx_ctx* c, const char* who, const vtx_locus* loci, uint32_t nl, uint64_t hap_bytes, uint32_t* max_hap, uint32_t* max_hap_all) {
+    *max_hap = *max_hap_all = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+        const vtx_locus& L = loci[l];
+        if ((uint64_t)L.ref_off + L.ref_len > hap_bytes || (uint64_t)L.alt_off + L.alt_len > hap_bytes)
+            return fail(c, VTX_E_INVAL, "%s: locus %u: haplotype outside hap_arena", who, l);
+        if (L.ref_len > kMaxHapLen || L.alt_len > kMaxHapLen)
+            return fail(c, VTX_E_UNSUPPORTED, "%s: locus %u: haplotype longer than %u", who, l, kMaxHapLen);
+        const uint32_t hl = std::max(L.ref_len, L.alt_len);
+        *max_hap_all = std::max(*max_hap_all, hl);
+        if (hl <= kFastHapLen) *max_hap = std::max(*max_hap, hl);
+    }
+    return VTX_OK;
+}
+
+int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
+    if (!c) return VTX_E_INVAL;
+    if (!b) return fail(c, VTX_E_INVAL, "vtx_submit_raw: null batch");
+    c->submitted = false; c->ran = false;
+    if (!c->bc_ready) return fail(c, VTX_E_STATE, "vtx_submit_raw: no barcode list (vtx_set_barcodes)");
+    const uint32_t nl = b->n_loci, nr = b->n_records;
+    if ((nl && !b->loci) || (nr && !b->records) || (b->hap_bytes && !b->hap_arena) || (b->read_bytes && !b->read_arena) ||
+        (b->tag_bytes && !b->tag_arena))
+        return fail(c, VTX_E_INVAL, "vtx_submit_raw: null array with non-zero count");
+    if (b->hap_bytes > 0xffffffffull || b->read_bytes > 0xffffffffull || b->tag_bytes > 0xffffffffull)
+        return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_raw: arenas above 4 GiB need more than one batch");
+    // loci: host validation is O(loci); everything per record happens on the device
+    uint32_t next_rec = 0, max_hap = 0, max_hap_all = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+        const vtx_locus& L = b->loci[l];
+        if (L.rec_begin != next_rec) return fail(c, VTX_E_INVAL, "vtx_submit_raw: locus %u: records not contiguous (rec_begin %u, expected %u)", l, L.rec_begin, next_rec);
+        if ((uint64_t)L.rec_begin + L.rec_count > nr) return fail(c, VTX_E_INVAL, "vtx_submit_raw: locus %u: record range exceeds n_records", l);
+        next_rec = L.rec_begin + L.rec_count;
+    }
+    if (next_rec != nr) return fail(c, VTX_E_INVAL, "vtx_submit_raw: %u records not covered by any locus", nr - next_rec);
+    if (int rc = check_loci_haps(c, "vtx_submit_raw", b->loci, nl, b->hap_bytes, &max_hap, &max_hap_all)) return rc;
+
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    const bool nibbles = c->read_format == VTX_READS_NIBBLES;
+    if (nibbles && (b->read_bytes & 1)) return fail(c, VTX_E_INVAL, "vtx_submit_raw: VTX_READS_NIBBLES needs an even read_bytes");
+    if (int rc = raw_reserve(c, nl, nr, b->hap_bytes, b->read_bytes, b->tag_bytes, nibbles)) return rc;
+    if (int rc = upload(c, {{c->d_loci.p, b->loci, (size_t)nl * sizeof(vtx_locus)},
+                            {c->d_raw.p, b->records, (size_t)nr * sizeof(vtx_raw_record)},
+                            {c->d_hap.p, b->hap_arena, (size_t)b->hap_bytes},
+                            {c->d_tags.p, b->tag_arena, (size_t)b->tag_bytes},
+                            {nibbles ? c->d_read_packed.p : c->d_read.p, b->read_arena, (size_t)(nibbles ? b->read_bytes / 2 : b->read_bytes)}})) return rc;
+    if (nibbles) HIP_TRY(c, vtxk_unpack_nibbles(c->d_read_packed.as<uint8_t>(), b->read_bytes / 2, c->d_read.as<uint8_t>(), s));
+    return raw_prepare(c, nl, nr, b->read_bytes, b->tag_bytes, nibbles, max_hap, max_hap_all, true, stats);
+}
+
+// ---- vtx_submit_bam: the ingest itself on the device (vtx_ingest.hip) ----
+int vtx_submit_bam(vtx_ctx* c, const vtx_bam_ingest* g, vtx_ingest_stats* st) {
+    if (!c) return VTX_E_INVAL;
+    if (!g) return fail(c, VTX_E_INVAL, "vtx_submit_bam: null argument");
+    c->submitted = false; c->ran = false;
+    if (st) memset(st, 0, sizeof *st);
+    if (!c->bc_ready) return fail(c, VTX_E_STATE, "vtx_submit_bam: no barcode list (vtx_set_barcodes)");
+    const uint32_t nl = g->n_loci, nb = g->n_blocks;
+    if ((nb && (!g->blocks || !g->file)) || (nl && !g->loci) || (g->hap_bytes && !g->hap_arena) || (g->n_seeds && !g->seeds) ||
+        (g->n_intervals && !g->intervals) || !g->tid_begin || (g->n_ref && !g->tid_max_span))
+        return fail(c, VTX_E_INVAL, "vtx_submit_bam: null array with non-zero count");
+    if (g->hap_bytes > 0xffffffffull) return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_bam: hap arena above 4 GiB");
+    uint32_t max_hap = 0, max_hap_all = 0;
+    if (int rc = check_loci_haps(c, "vtx_submit_bam", g->loci, nl, g->hap_bytes, &max_hap, &max_hap_all)) return rc;
+    if (g->tid_begin[0] != 0 || g->tid_begin[g->n_ref] != g->n_intervals) return fail(c, VTX_E_INVAL, "vtx_submit_bam: tid_begin does not cover the intervals");
+    for (uint32_t t = 0; t < g->n_ref; ++t) {
+        if (g->tid_begin[t] > g->tid_begin[t + 1]) return fail(c, VTX_E_INVAL, "vtx_submit_bam: tid_begin not ascending at %u", t);
+        for (uint32_t k = g->tid_begin[t]; k < g->tid_begin[t + 1]; ++k) {
+            const vtx_bam_interval& I = g->intervals[k];
+            if (I.locus >= nl || I.end < I.start || (k > g->tid_begin[t] && g->intervals[k - 1].start > I.start) || (int64_t)I.end - I.start > g->tid_max_span[t])
+                return fail(c, VTX_E_INVAL, "vtx_submit_bam: interval %u: bad locus / order / span", k);
+        }
+    }
+    // blocks: consecutive in the file; the compressed range [lo, hi) travels as it is
+    std::vector<vtxg_block> blocks(nb);
+    uint64_t lo = nb ? g->blocks[0].coff : 0, hi = lo, utotal = 0;
+    for (uint32_t i = 0; i < nb; ++i) {
+        const vtx_bgzf_block& B = g->blocks[i];
+        if (B.coff < hi || B.coff + B.clen > g->file_bytes || B.isize > 65536u)
+            return fail(c, VTX_E_INVAL, "vtx_submit_bam: block %u: out of order, outside the file or above 64 KiB", i);
+        blocks[i] = vtxg_block{B.coff - lo, utotal, B.clen, B.isize};
+        hi = B.coff + B.clen;
+        utotal += B.isize;
+    }
+    const uint64_t end_upos = std::min<uint64_t>(g->end_upos, utotal);
+    for (uint32_t i = 0; i < g->n_seeds; ++i)
+        if (g->seeds[i] >= end_upos || (i && g->seeds[i] <= g->seeds[i - 1])) return fail(c, VTX_E_INVAL, "vtx_submit_bam: seed %u: not ascending or beyond the end", i);
+
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    const size_t u32 = sizeof(uint32_t), u64 = sizeof(uint64_t);
+    const uint32_t ns = g->n_seeds, ni = g->n_intervals, nref = g->n_ref;
+    HIP_TRY(c, c->d_bam_comp.reserve((size_t)(hi - lo) + 64));
+    HIP_TRY(c, c->d_bam_data.reserve((size_t)utotal + 64));
+    HIP_TRY(c, c->d_bam_blocks.reserve((size_t)nb * sizeof(vtxg_block)));
+    HIP_TRY(c, c->d_bam_seeds.reserve((size_t)ns * u64));
+    HIP_TRY(c, c->d_bam_seed_cnt.reserve((size_t)ns * u32 + 16));
+    HIP_TRY(c, c->d_bam_seed_scan.reserve((size_t)ns * u32 + 16));
+    HIP_TRY(c, c->d_bam_iv.reserve((size_t)ni * 3 * u32 + ((size_t)nref + 1) * u32 + (size_t)nref * u32 + 64));
+    HIP_TRY(c, c->d_bam_cnt.reserve(VTXG_N_COUNTERS * u64 + 4 * u32));
+    HIP_TRY(c, c->d_scan_tmp.reserve(vtxk_scan_temp_bytes(std::max(ns, 1u))));
+    // intervals as arrays: start[ni], end[ni], locus[ni], tid_begin[nref + 1], tid_span[nref]
+    std::vector<uint32_t> ivh((size_t)ni * 3 + nref + 1 + nref);
+    for (uint32_t k = 0; k < ni; ++k) { ivh[k] = (uint32_t)g->intervals[k].start; ivh[ni + k] = (uint32_t)g->intervals[k].end; ivh[2 * (size_t)ni + k] = g->intervals[k].locus; }
+    for (uint32_t t = 0; t <= nref; ++t) ivh[3 * (size_t)ni + t] = g->tid_begin[t];
+    for (uint32_t t = 0; t < nref; ++t) ivh[3 * (size_t)ni + nref + 1 + t] = (uint32_t)g->tid_max_span[t];
+    const int32_t* d_iv_start = c->d_bam_iv.as<int32_t>();
+    const int32_t* d_iv_end = d_iv_start + ni;
+    const uint32_t* d_iv_locus = (const uint32_t*)(d_iv_end + ni);
+    const uint32_t* d_tid_begin = d_iv_locus + ni;
+    const int32_t* d_tid_span = (const int32_t*)(d_tid_begin + nref + 1);
+    unsigned long long* d_counters = c->d_bam_cnt.as<unsigned long long>();
+    uint32_t* d_err = (uint32_t*)(d_counters + VTXG_N_COUNTERS);
+    HIP_TRY(c, c->d_hap.reserve(g->hap_bytes + 16));
+    HIP_TRY(c, c->d_loci.reserve((size_t)nl * sizeof(vtx_locus)));
+
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t) { return (float)(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count()); };
+    HIP_TRY(c, hipMemsetAsync(d_counters, 0, VTXG_N_COUNTERS * u64 + 4 * u32, s));
+    HIP_TRY(c, hipMemsetAsync(d_err + 1, 0xff, u32, s));
+    if (int rc = upload(c, {{c->d_bam_comp.p, g->file + lo, (size_t)(hi - lo)},
+                            {c->d_bam_blocks.p, blocks.data(), (size_t)nb * sizeof(vtxg_block)},
+                            {c->d_bam_seeds.p, g->seeds, (size_t)ns * u64},
+                            {c->d_bam_iv.p, ivh.data(), ivh.size() * u32},
+                            {c->d_loci.p, g->loci, (size_t)nl * sizeof(vtx_locus)},
+                            {c->d_hap.p, g->hap_arena, (size_t)g->hap_bytes}})) return rc;
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const float h2d_ms = since(t0);
+    // ---- inflate, record boundaries ----
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    HIP_TRY(c, vtxg_inflate(c->d_bam_comp.as<uint8_t>(), c->d_bam_blocks.as<vtxg_block>(), nb, c->d_bam_data.as<uint8_t>(), d_err, s));
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    uint32_t n_rec = 0;
+    if (ns) {
+        HIP_TRY(c, vtxg_chain(c->d_bam_data.as<uint8_t>(), utotal, c->d_bam_seeds.as<uint64_t>(), ns, end_upos, c->d_bam_seed_cnt.as<uint32_t>(), nullptr, nullptr, d_err, s));
+        HIP_TRY(c, vtxk_inclusive_scan_u32(c->d_bam_seed_cnt.as<uint32_t>(), c->d_bam_seed_scan.as<uint32_t>(), ns, c->d_scan_tmp.p, vtxk_scan_temp_bytes(ns), s));
+        HIP_TRY(c, hipMemcpyAsync(&n_rec, c->d_bam_seed_scan.as<uint32_t>() + (ns - 1), u32, hipMemcpyDeviceToHost, s));
+    }
+    uint32_t err[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(err, d_err, 2 * u32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    auto ingest_error = [&](uint32_t e0, uint32_t e1) -> int {
+        if (e0 & 0x1ffu) return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_bam: BGZF block %u does not inflate on the device (status bits 0x%x): the host packer decides", e1, e0 & 0x1ffu);
+        if (e0 & VTXG_ERR_CHAIN) return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_bam: a record chain does not end on the index's next record start (index and file disagree, or a malformed record)");
+        return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_bam: malformed BAM record");
+    };
+    if (err[0]) return ingest_error(err[0], err[1]);
+    if ((uint64_t)n_rec > 0xfffffff0ull) return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_bam: more than 2^32 BAM records in one ingest");
+    HIP_TRY(c, c->d_bam_rec.reserve((size_t)n_rec * u64 + 16));
+    DevBuf* per_rec[] = {&c->d_bam_nhit, &c->d_bam_rsz, &c->d_bam_tsz, &c->d_bam_hscan, &c->d_bam_rscan, &c->d_bam_tscan};
+    for (DevBuf* d : per_rec) HIP_TRY(c, d->reserve((size_t)n_rec * u32 + 16));
+    HIP_TRY(c, c->d_bam_info.reserve((size_t)n_rec * sizeof(vtxg_recinfo) + 16));
+    HIP_TRY(c, c->d_scan_tmp.reserve(vtxk_scan_temp_bytes(std::max(n_rec, 1u))));
+    if (ns) HIP_TRY(c, vtxg_chain(c->d_bam_data.as<uint8_t>(), utotal, c->d_bam_seeds.as<uint64_t>(), ns, end_upos, c->d_bam_seed_cnt.as<uint32_t>(),
+                                   c->d_bam_seed_scan.as<uint32_t>(), c->d_bam_rec.as<uint64_t>(), d_err, s));
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    // ---- fetch + filters per (read, locus) pair: counts, then offsets, then the raw records ----
+    const vtxg_filter f{nref, g->min_mapq, g->primary_only ? 1u : 0u, g->no_duplicates ? 1u : 0u, (uint32_t)(uint8_t)g->bam_tag[0] | ((uint32_t)(uint8_t)g->bam_tag[1] << 8)};
+    HIP_TRY(c, vtxg_scan(0, c->d_bam_data.as<uint8_t>(), c->d_bam_rec.as<uint64_t>(), n_rec, f, d_iv_start, d_iv_end, d_iv_locus, d_tid_begin, d_tid_span,
+                         c->d_bam_nhit.as<uint32_t>(), c->d_bam_rsz.as<uint32_t>(), c->d_bam_tsz.as<uint32_t>(), c->d_bam_info.as<vtxg_recinfo>(),
+                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_counters, d_err, s));
+    unsigned long long cnt[VTXG_N_COUNTERS] = {0};
+    HIP_TRY(c, hipMemcpyAsync(cnt, d_counters, sizeof cnt, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(err, d_err, 2 * u32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (err[0]) return ingest_error(err[0], err[1]);
+    const uint64_t read_bases = cnt[6], tag_bytes = cnt[7], n_pairs = cnt[8];
+    if (read_bases > 0xF0000000ull || tag_bytes > 0xF0000000ull || n_pairs > 0x7fffffffull)
+        return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_bam: the reads of this range need more than one batch (%llu bases, %llu tag bytes, %llu pairs): pack ranges of loci",
+                    (unsigned long long)read_bases, (unsigned long long)tag_bytes, (unsigned long long)n_pairs);
+    const uint32_t nr = (uint32_t)n_pairs;
+    if (int rc = raw_reserve(c, nl, nr, g->hap_bytes, read_bases, tag_bytes, true)) return rc;
+    if (n_rec) {
+        const size_t tb = vtxk_scan_temp_bytes(n_rec);
+        HIP_TRY(c, vtxk_inclusive_scan_u32(c->d_bam_nhit.as<uint32_t>(), c->d_bam_hscan.as<uint32_t>(), n_rec, c->d_scan_tmp.p, tb, s));
+        HIP_TRY(c, vtxk_inclusive_scan_u32(c->d_bam_rsz.as<uint32_t>(), c->d_bam_rscan.as<uint32_t>(), n_rec, c->d_scan_tmp.p, tb, s));
+        HIP_TRY(c, vtxk_inclusive_scan_u32(c->d_bam_tsz.as<uint32_t>(), c->d_bam_tscan.as<uint32_t>(), n_rec, c->d_scan_tmp.p, tb, s));
+        HIP_TRY(c, vtxg_scan(1, c->d_bam_data.as<uint8_t>(), c->d_bam_rec.as<uint64_t>(), n_rec, f, d_iv_start, d_iv_end, d_iv_locus, d_tid_begin, d_tid_span,
+                             c->d_bam_nhit.as<uint32_t>(), c->d_bam_rsz.as<uint32_t>(), c->d_bam_tsz.as<uint32_t>(), c->d_bam_info.as<vtxg_recinfo>(),
+                             c->d_bam_hscan.as<uint32_t>(), c->d_bam_rscan.as<uint32_t>(), c->d_bam_tscan.as<uint32_t>(), c->d_raw.as<vtx_raw_record>(),
+                             c->d_raw_locus.as<uint32_t>(), c->d_tags.as<uint8_t>(), c->d_read_packed.as<uint8_t>(), d_counters, d_err, s));
+    }
+    HIP_TRY(c, vtxk_unpack_nibbles(c->d_read_packed.as<uint8_t>(), read_bases / 2, c->d_read.as<uint8_t>(), s));
+    HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    float inflate_ms = 0, index_ms = 0, filter_ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&inflate_ms, c->ev[0], c->ev[1]));
+    HIP_TRY(c, hipEventElapsedTime(&index_ms, c->ev[1], c->ev[2]));
+    HIP_TRY(c, hipEventElapsedTime(&filter_ms, c->ev[2], c->ev[3]));
+    c->bam_n_rec = n_rec; c->bam_n_raw = nr; c->bam_utotal = utotal; c->bam_read_bases = read_bases; c->bam_tag_bytes = tag_bytes;
+    vtx_raw_stats rs{};
+    if (int rc = raw_prepare(c, nl, nr, read_bases, tag_bytes, true, max_hap, max_hap_all, false, &rs)) return rc;
+    if (st) {
+        st->num_reads = cnt[0]; st->num_low_mapq = cnt[1]; st->num_non_primary = cnt[2]; st->num_duplicates = cnt[3];
+        st->num_not_useful = cnt[4]; st->num_no_barcode_tag = cnt[5];
+        st->bam_records = n_rec; st->raw_records = nr; st->inflated_bytes = utotal; st->compressed_bytes = hi - lo;
+        st->raw = rs; st->h2d_ms = h2d_ms; st->inflate_ms = inflate_ms; st->index_ms = index_ms; st->filter_ms = filter_ms;
+    }
+    return VTX_OK;
+}
+
+// Test / audit hook: the ingest's intermediate arrays of the last vtx_submit_bam (what: VTX_INGEST_*).  *bytes = the array's size;
+// min(cap, *bytes) bytes are copied to dst.
+int vtx_debug_ingest(vtx_ctx* c, int what, void* dst, uint64_t cap, uint64_t* bytes) {
+    if (!c || !bytes) return VTX_E_INVAL;
+    const void* src = nullptr;
+    uint64_t n = 0;
+    switch (what) {
+    case VTX_INGEST_INFLATED: src = c->d_bam_data.p; n = c->bam_utotal; break;
+    case VTX_INGEST_RECORD_OFFSETS: src = c->d_bam_rec.p; n = (uint64_t)c->bam_n_rec * 8; break;
+    case VTX_INGEST_RAW_RECORDS: src = c->d_raw.p; n = (uint64_t)c->bam_n_raw * sizeof(vtx_raw_record); break;
+    case VTX_INGEST_RAW_LOCUS: src = c->d_raw_locus.p; n = (uint64_t)c->bam_n_raw * 4; break;
+    case VTX_INGEST_TAGS: src = c->d_tags.p; n = c->bam_tag_bytes; break;
+    case VTX_INGEST_READS_PACKED: src = c->d_read_packed.p; n = c->bam_read_bases / 2; break;
+    default: return fail(c, VTX_E_INVAL, "vtx_debug_ingest: unknown array %d", what);
+    }
+    *bytes = n;
+    const uint64_t k = std::min(cap, n);
+    if (k && dst) {
+        HIP_TRY(c, hipSetDevice(c->cfg.device));
+        HIP_TRY(c, hipMemcpy(dst, src, (size_t)k, hipMemcpyDeviceToHost));
     }
     return VTX_OK;
 }

@@ -2397,7 +2397,7 @@ __global__ __launch_bounds__(256) void band_refine_kernel(
         pl.at(4) = p1.x; pl.at(5) = p1.y; pl.at(6) = p1.z; pl.at(7) = p1.w;
         const uint8_t* yb = gtables + ((size_t)(my_locus - gt_l0) * 2 + hap) * table_stride + vtxf::tab_bytes_off(max_hap, n_heads);
         const vtxf::Refine rf{read_arena + rec.read_off, yb, (int)rec.read_len, (int)(hap ? loc.alt_len : loc.ref_len)};
-        const int ub = max(max(vtxf::K - 1, far_e > 0 ? far_e + 5 : 0), vtxf::main_pieces_ub(pl, r, h.w, d, &rf));
+        const int ub = max(max(vtxf::K - 1, far_e > 0 ? far_e + 5 : 0), vtxf::main_pieces_ub(pl, r, h.w, d, &rf, far_e));
         (hap ? alt_score : ref_score)[rid] = cert;                     // final when ub == cert, provisional otherwise
         if (ub == cert) { if (stage) stage[task] = VTX_STAGE_REFINE_CERT; }
         else if (tight_list) {
@@ -2407,7 +2407,7 @@ __global__ __launch_bounds__(256) void band_refine_kernel(
             // this one does.  A tight list means every haplotype has <= 255 bases: ca / cb are the bytes of the pack.
             const int ca = (int)((h.y >> 8) & 0xffu), cb = (int)(h.y & 0xffu);
             const int lo = max(0, ca - vtxf::W - 1 - d), hi = min((int)rec.read_len - 1, cb + vtxf::W - 1 - d);
-            const int ubb = max(max(vtxf::K - 1, far_e > 0 ? far_e + 5 : 0), vtxf::main_pieces_ub_band(pl, r, h.w, d, &rf, lo, hi));
+            const int ubb = max(max(vtxf::K - 1, far_e > 0 ? far_e + 5 : 0), vtxf::main_pieces_ub_band(pl, r, h.w, d, &rf, lo, hi, far_e));
             if (ubb == cert) { if (stage) stage[task] = VTX_STAGE_BAND_CERT; }      // a stage of its own: banded < full is allowed here
             else fail = true;
         } else fail = true;

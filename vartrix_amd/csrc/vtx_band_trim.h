@@ -43,7 +43,7 @@ VTXF_FN void band_rows(const Front& fr, int m, int& lo, int& hi) {
 
 // main_pieces_ub (vtx_fast_core.h) over the pieces trimmed to rows [lo, hi]: pieces outside do not exist, a piece cut at its low
 // end has no predecessor (everything before it is out of band), a piece cut at its high end is nobody's predecessor.
-template <class PL> VTXF_FN int main_pieces_ub_band(const PL& pl, int r, uint32_t zc, int d, const Refine* rf, int lo, int hi) {
+template <class PL> VTXF_FN int main_pieces_ub_band(const PL& pl, int r, uint32_t zc, int d, const Refine* rf, int lo, int hi, int far_e) {
     int ub = 0;
     for (int p = 0; p < r; ++p) {
         const uint32_t wp = pl.at(p);
@@ -64,7 +64,7 @@ template <class PL> VTXF_FN int main_pieces_ub_band(const PL& pl, int r, uint32_
                 if (rf && D > 0 && J < 6 * e - D && e < 15) {
                     const int mu = imax(0, 6 * e - D - 8);
                     const int inside = corridor_cost(rf->x, rf->m, rf->yb, rf->n, ql0, d, D, imin(mu, lq - 1), imin(mu, lp - 1));
-                    J = imin(6 * e - D, imin(inside, join_gap3(D)));
+                    J = imin(6 * e - D, imin(inside, join_gap3_far(D, far_e)));
                 }
                 g = imax(g, lq + gq - J);
             }
@@ -81,7 +81,7 @@ template <class LN> VTXF_FN int32_t band_trim_verdict(const Front& fr, int m, co
     int lo, hi;
     band_rows(fr, m, lo, hi);
     int ub = imax(K - 1, far_e > 0 ? (int)far_e + 5 : 0);
-    ub = imax(ub, main_pieces_ub_band(ln, fr.r, fr.zc, fr.d, rf, lo, hi));
+    ub = imax(ub, main_pieces_ub_band(ln, fr.r, fr.zc, fr.d, rf, lo, hi, (int)far_e));
     return ub == fr.cert ? fr.cert : -1;
 }
 

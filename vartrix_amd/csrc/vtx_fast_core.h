@@ -219,6 +219,23 @@ VTXF_FN int join_gap3(int D) {                    // J_gap for G >= 3, D >= 3 (a
     const uint32_t hi = 0x1200u;                  // D = 19 .. 22
     return 11 + (int)(D <= 18 ? (lo >> (4 * (D - 3))) & 15u : (hi >> (4 * (D - 19))) & 15u);
 }
+// join_gap3 assumes what J_gap assumes: between the two runs every exact-match run on ANY diagonal has <= 5 bases (a longer one would
+// be a piece).  A task with main pieces only still has its FAR off-diagonal pieces (far_e k-mer matches in all), and an excursion may
+// run over them: a far piece of E matches is a run of 5 + E bases.  Shortening every such run to 5 bases turns the excursion into one
+// of the model over D - t bases (t <= far_e bases removed, gaps untouched) that scores t less, so the excursion costs at least
+// min over t <= far_e of join_gap3(D - t) - t; and by the far-piece lemma (header; condition (*) holds for these tasks) any join through
+// far pieces costs >= 11.  Round 6: found by the first full audit of the 8 % workload — the plain join_gap3 priced a join at 13 that a
+// 7-base run four diagonals out made for 12 (ub 36 < full 37; the banded score happened to be 36 too).
+VTXF_FN int join_gap3_far(int D, int far_e) {
+    int j = join_gap3(D);
+    if (far_e > 0) {
+        VTXF_UNROLL
+        for (int t = 1; t <= 5; ++t)                   // (join_gap3 <= 16: beyond t = 5 the floor of 11 is reached anyway)
+            if (t <= far_e && D - t >= 3) j = imin(j, join_gap3(D - t) - t);
+        j = imax(j, 11);
+    }
+    return j;
+}
 // x, yb: the read and the haplotype bytes; (xb, xb + d): the first run's last base; cells are prefix cells (i, j) = i read
 // bases and j haplotype bases consumed, diagonal index k = j - i - d + CORR
 VTXF_FN int corridor_cost(const uint8_t* x, int m, const uint8_t* yb, int n, int xb, int d, int D, int mu_a, int mu_b) {
@@ -563,7 +580,7 @@ struct Refine { const uint8_t* x; const uint8_t* yb; int m, n; };
 // The run bound over main pieces only (pl.at(i), i < r: first base | last base << 8 | . | G << 24, in base order; zc: mismatching
 // bases between consecutive pieces, a nibble each): all on one diagonal — a predecessor always lies before its successor, so one
 // pass over the ordered pairs q < p settles every G (no back edges), and every join is a same-diagonal join.
-template <class PL> VTXF_FN int main_pieces_ub(const PL& pl, int r, uint32_t zc, int d, const Refine* rf) {
+template <class PL> VTXF_FN int main_pieces_ub(const PL& pl, int r, uint32_t zc, int d, const Refine* rf, int far_e) {
     int ub = 0;
     for (int p = 0; p < r; ++p) {
         const uint32_t wp = pl.at(p);
@@ -580,7 +597,7 @@ template <class PL> VTXF_FN int main_pieces_ub(const PL& pl, int r, uint32_t zc,
                 // (e is exact below the nibbles' cap; the whole of q may be given up to its first base, p to its last)
                 const int mu = imax(0, 6 * e - D - 8);
                 const int inside = corridor_cost(rf->x, rf->m, rf->yb, rf->n, xq + lq - 1, d, D, imin(mu, lq - 1), imin(mu, lp - 1));
-                J = imin(6 * e - D, imin(inside, join_gap3(D)));
+                J = imin(6 * e - D, imin(inside, join_gap3_far(D, far_e)));
             }
             g = imax(g, lq + gq - J);
         }
@@ -755,7 +772,7 @@ template <class LN> VTXF_FN int32_t back_rest(const Front& fr, int ns, const LN&
         for (int i = 0; i < n_all; ++i) word(i) &= 0x00ffffffu;
         bool changed = n_all > 1;
         if (ng == 0) {
-            ub = imax(ub, main_pieces_ub(ln, r, fr.zc, d, rf));
+            ub = imax(ub, main_pieces_ub(ln, r, fr.zc, d, rf, far_e));
             changed = false;
         }
         uint64_t zpre = 0;                                  // byte i: mismatching bases between main pieces 0 and i

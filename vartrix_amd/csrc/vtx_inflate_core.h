@@ -26,9 +26,11 @@
 
 #ifdef __HIPCC__
 #define VTXI_FN __device__ __forceinline__
+#define VTXI_MEM __device__ __forceinline__
 #define VTXI_UNROLL _Pragma("unroll")
 #else
 #define VTXI_FN static inline
+#define VTXI_MEM inline
 #define VTXI_UNROLL
 #endif
 
@@ -38,13 +40,14 @@ namespace vtxi {
 struct Scratch {
     uint16_t* p;
     int stride;
-    VTXI_FN uint16_t& at(int i) const { return p[i * stride]; }
+    VTXI_MEM uint16_t& at(int i) const { return p[i * stride]; }
 };
 constexpr int SYM_LL = 0;      // 288: literal / length symbols sorted by (code length, symbol)
 constexpr int SYM_D = 288;     // 32: distance symbols, likewise
 constexpr int SYM_CL = 320;    // 20: code-length symbols, likewise
-constexpr int CUR = 340;       // 16: per-length counters / cursors while a table is built
-constexpr int WORDS = 356;
+constexpr int CUR = 340;       // 16: per-length counters / cursors while a table is built (code-length code, literal / length table)
+constexpr int CUR_D = 356;     // 16: the same for the distance table (both tables of a dynamic block are counted in one pass)
+constexpr int WORDS = 372;
 
 enum Status : uint32_t { ST_OK = 0, ST_BAD_TYPE = 1, ST_BAD_STORED = 2, ST_BAD_CODE = 3, ST_BAD_SYMBOL = 4, ST_BAD_DIST = 5,
                          ST_OVERRUN = 6, ST_SHORT = 7, ST_INPUT = 8 };
@@ -81,17 +84,17 @@ VTXI_FN void decode(const Code& c, uint32_t bits, uint32_t& idx, uint32_t& len) 
     idx = ((sel >> 4) & 0xfffu) + ((rev - (sel >> 16)) >> (15u - len));
 }
 
-// The code of the lengths counted in sc.at(CUR + 1 .. CUR + 15); leaves the cursors (index of each length's first symbol) there.
+// The code of the lengths counted in sc.at(cur + 1 .. cur + 15); leaves the cursors (index of each length's first symbol) there.
 // Returns 0: complete code; 1: incomplete (the caller decides: only a distance table with one code may be); 2: over-subscribed.
-VTXI_FN int make_code(Code& c, const Scratch& sc, int max_len) {
+VTXI_FN int make_code(Code& c, const Scratch& sc, int cur, int max_len) {
     uint32_t first = 0, offs = 0;
     int left = 1;
     bool over = false;
     VTXI_UNROLL
     for (int l = 1; l <= 15; ++l) {
-        const uint32_t cnt = l <= max_len ? sc.at(CUR + l) : 0u;
+        const uint32_t cnt = l <= max_len ? sc.at(cur + l) : 0u;
         c.p[l - 1] = ((first << (15 - l)) << 16) | (offs << 4) | (uint32_t)l;
-        if (l <= max_len) sc.at(CUR + l) = (uint16_t)offs;
+        if (l <= max_len) sc.at(cur + l) = (uint16_t)offs;
         left = left * 2 - (int)cnt;
         over |= left < 0;
         if (left < 0) left = 0;
@@ -107,16 +110,16 @@ struct Bits {
     uint32_t ip;             // next byte to load
     uint32_t cnt;            // valid bits in buf
     uint64_t buf;
-    VTXI_FN void refill() {  // >= 33 valid bits afterwards (the input may be exhausted: the bits beyond are whatever follows, and
+    VTXI_MEM void refill() {  // >= 33 valid bits afterwards (the input may be exhausted: the bits beyond are whatever follows, and
         if (cnt <= 32) {     // `consumed() > in_len * 8` is checked where a block ends)
             buf |= (uint64_t)ld4(in + ip) << cnt;
             ip += 4; cnt += 32;
         }
     }
-    VTXI_FN uint32_t peek15() const { return (uint32_t)buf & 0x7fffu; }
-    VTXI_FN uint32_t take(uint32_t n) { const uint32_t v = (uint32_t)buf & ((1u << n) - 1u); buf >>= n; cnt -= n; return v; }
-    VTXI_FN void drop(uint32_t n) { buf >>= n; cnt -= n; }
-    VTXI_FN uint64_t consumed() const { return (uint64_t)ip * 8 - cnt; }
+    VTXI_MEM uint32_t peek15() const { return (uint32_t)buf & 0x7fffu; }
+    VTXI_MEM uint32_t take(uint32_t n) { const uint32_t v = (uint32_t)buf & ((1u << n) - 1u); buf >>= n; cnt -= n; return v; }
+    VTXI_MEM void drop(uint32_t n) { buf >>= n; cnt -= n; }
+    VTXI_MEM uint64_t consumed() const { return (uint64_t)ip * 8 - cnt; }
 };
 
 constexpr uint32_t S_HEADER = 0, S_SYM = 1, S_COPY = 2, S_STORED = 3, S_DONE = 4;
@@ -237,14 +240,14 @@ VTXI_FN uint32_t inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out,
                 // fixed code (RFC 1951 3.2.6): 7 bits 256..279, 8 bits 0..143 and 280..287, 9 bits 144..255; 32 distance codes of 5 bits
                 for (int l = 1; l <= 15; ++l) sc.at(CUR + l) = 0;
                 sc.at(CUR + 7) = 24; sc.at(CUR + 8) = 152; sc.at(CUR + 9) = 112;
-                (void)make_code(ll, sc, 15);
+                (void)make_code(ll, sc, CUR, 15);
                 for (int i = 0; i < 24; ++i) sc.at(SYM_LL + i) = (uint16_t)(256 + i);
                 for (int i = 0; i < 144; ++i) sc.at(SYM_LL + 24 + i) = (uint16_t)i;
                 for (int i = 0; i < 8; ++i) sc.at(SYM_LL + 168 + i) = (uint16_t)(280 + i);
                 for (int i = 0; i < 112; ++i) sc.at(SYM_LL + 176 + i) = (uint16_t)(144 + i);
                 for (int l = 1; l <= 15; ++l) sc.at(CUR + l) = 0;
                 sc.at(CUR + 5) = 32;
-                (void)make_code(dc, sc, 15);
+                (void)make_code(dc, sc, CUR, 15);
                 for (int i = 0; i < 32; ++i) sc.at(SYM_D + i) = (uint16_t)i;
                 st = S_SYM;
             } else {
@@ -258,106 +261,63 @@ VTXI_FN uint32_t inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out,
                         b.refill();
                         const uint32_t v = b.take(3);
                         // order: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 (5 bits each, packed in two words)
-                        const uint32_t s = i < 12 ? (uint32_t)((0x0a53121c4a307250ull >> (5 * i)) & 31u)           // 16 17 18 0 8 7 9 6 10 5 11 4
-                                                  : (uint32_t)((0x0000003c1704d8ccull >> (5 * (i - 12))) & 31u);   // 12 3 13 2 14 1 15
+                        const uint32_t s = i < 12 ? (uint32_t)((0x022caa324e804a30ull >> (5 * i)) & 31u)           // 16 17 18 0 8 7 9 6 10 5 11 4
+                                                  : (uint32_t)((0x00000003c2e1346cull >> (5 * (i - 12))) & 31u);   // 12 3 13 2 14 1 15
                         cl |= (uint64_t)v << (3 * s);
                     }
-                    for (int l = 1; l <= 7; ++l) sc.at(CUR + l) = 0;
+                    for (int l = 0; l <= 7; ++l) sc.at(CUR + l) = 0;
                     for (int s = 0; s < 19; ++s) { const int l = (int)((cl >> (3 * s)) & 7u); if (l) sc.at(CUR + l) = (uint16_t)(sc.at(CUR + l) + 1); }
                     Code cc;
-                    const int vc = make_code(cc, sc, 7);
+                    const int vc = make_code(cc, sc, CUR, 7);
                     if (vc != 0) { err = ST_BAD_CODE; st = S_DONE; }
                     else {
                         for (int s = 0; s < 19; ++s) {
                             const int l = (int)((cl >> (3 * s)) & 7u);
                             if (l) { const int k = sc.at(CUR + l); sc.at(CUR + l) = (uint16_t)(k + 1); sc.at(SYM_CL + k) = (uint16_t)s; }
                         }
-                        // pass 1: count the lengths of both tables; pass 2 (same bits again): place the symbols
+                        // pass 0: count the lengths of both tables; pass 1 (the same bits again): place the symbols at their cursors
                         const Bits mark = b;
                         const uint32_t total = nll + nd;
-                        bool bad = false;
-                        bool has_eob = false;
+                        bool bad = false, has_eob = false;
                         uint32_t d_used = 0, d_one_len = 0;
+                        for (int l = 0; l <= 15; ++l) { sc.at(CUR + l) = 0; sc.at(CUR_D + l) = 0; }
                         for (int pass = 0; pass < 2 && !bad; ++pass) {
-                            if (pass == 1) {
-                                // cursors of both tables from the counts: literal / length in CUR + 1 .. 15 (make_code), distances kept in
-                                // registers-free form: a second make_code needs the same slots, so the distance cursors live in SYM_CL + 20 ..
-                                // (the code-length symbols are still needed: they stay below)
-                                b = mark;
-                            }
-                            // (counts / cursors: literal-length table in CUR + 1 .. 15; the distance table's in the low 16 words of SYM_D's
-                            //  neighbour is not available — use the upper half of CUR instead: not enough room.  So: two sub-passes per table.)
-                            uint32_t i = 0, prev = 0;
-                            if (pass == 0) { for (int l = 0; l <= 15; ++l) sc.at(CUR + l) = 0; }
-                            // Table selection by symbol number: i < nll -> literal / length table, else distance table.  The two tables
-                            // share the CUR slots by running the WHOLE length stream once per (pass, table): 4 decodes of ~300 symbols.
-                            // (A block header is ~1 % of a block's symbols; the 3 extra decodes cost less than 32 more bytes of LDS per
-                            //  lane would in occupancy.)
-                            (void)i; (void)prev;
-                            for (int table = 0; table < 2 && !bad; ++table) {
-                                b = mark;
-                                if (pass == 0) { for (int l = 0; l <= 15; ++l) sc.at(CUR + l) = 0; }
-                                else {
-                                    // counts of this table once more (they were overwritten by the other table's): recount, then cursors
-                                    for (int l = 0; l <= 15; ++l) sc.at(CUR + l) = 0;
-                                    uint32_t k = 0, pv = 0;
-                                    Bits r = mark;
-                                    while (k < total) {
-                                        r.refill();
-                                        uint32_t ci, cn;
-                                        decode(cc, r.peek15(), ci, cn);
-                                        r.drop(cn);
-                                        const uint32_t cs = sc.at(SYM_CL + (int)ci);
-                                        uint32_t rep = 1, val = cs;
-                                        if (cs == 16) { val = pv; rep = 3 + r.take(2); }
-                                        else if (cs == 17) { val = 0; rep = 3 + r.take(3); }
-                                        else if (cs == 18) { val = 0; rep = 11 + r.take(7); }
-                                        for (uint32_t t = 0; t < rep; ++t, ++k) {
-                                            const bool mine = table == 0 ? k < nll : k >= nll;
-                                            if (mine && val) sc.at(CUR + (int)val) = (uint16_t)(sc.at(CUR + (int)val) + 1);
-                                        }
-                                        pv = val;
-                                    }
-                                    Code tmp;
-                                    (void)make_code(tmp, sc, 15);        // counts -> cursors
-                                    if (table == 0) ll = tmp; else dc = tmp;
-                                }
-                                uint32_t k = 0, pv = 0;
-                                while (k < total) {
-                                    b.refill();
-                                    uint32_t ci, cn;
-                                    decode(cc, b.peek15(), ci, cn);
-                                    if (ci >= cc.n) { bad = true; break; }
-                                    b.drop(cn);
-                                    const uint32_t cs = sc.at(SYM_CL + (int)ci);
-                                    uint32_t rep = 1, val = cs;
-                                    if (cs == 16) { if (k == 0) { bad = true; break; } val = pv; rep = 3 + b.take(2); }
-                                    else if (cs == 17) { val = 0; rep = 3 + b.take(3); }
-                                    else if (cs == 18) { val = 0; rep = 11 + b.take(7); }
-                                    if (k + rep > total) { bad = true; break; }
-                                    for (uint32_t t = 0; t < rep; ++t, ++k) {
-                                        const bool mine = table == 0 ? k < nll : k >= nll;
-                                        if (!mine || !val) continue;
+                            b = mark;
+                            uint32_t k = 0, pv = 0;
+                            while (k < total) {
+                                b.refill();
+                                uint32_t ci, cn;
+                                decode(cc, b.peek15(), ci, cn);
+                                if (ci >= cc.n) { bad = true; break; }
+                                b.drop(cn);
+                                const uint32_t cs = sc.at(SYM_CL + (int)ci);
+                                uint32_t rep = 1, val = cs;
+                                if (cs == 16) { if (k == 0) { bad = true; break; } val = pv; rep = 3 + b.take(2); }
+                                else if (cs == 17) { val = 0; rep = 3 + b.take(3); }
+                                else if (cs == 18) { val = 0; rep = 11 + b.take(7); }
+                                if (k + rep > total) { bad = true; break; }
+                                if (val) {
+                                    for (uint32_t t = 0; t < rep; ++t) {
+                                        const uint32_t sy = k + t;
+                                        const int cur = (sy < nll ? CUR : CUR_D) + (int)val;
+                                        const int slot = sc.at(cur);
+                                        sc.at(cur) = (uint16_t)(slot + 1);
                                         if (pass == 0) {
-                                            sc.at(CUR + (int)val) = (uint16_t)(sc.at(CUR + (int)val) + 1);
-                                            if (table == 0 && k == 256) has_eob = true;
-                                            if (table == 1) { ++d_used; d_one_len = val; }
-                                        } else {
-                                            const int slot = sc.at(CUR + (int)val);
-                                            sc.at(CUR + (int)val) = (uint16_t)(slot + 1);
-                                            sc.at((table == 0 ? SYM_LL : SYM_D) + slot) = (uint16_t)(table == 0 ? k : k - nll);
-                                        }
+                                            if (sy == 256) has_eob = true;
+                                            if (sy >= nll) { ++d_used; d_one_len = val; }
+                                        } else sc.at((sy < nll ? SYM_LL : SYM_D) + slot) = (uint16_t)(sy < nll ? sy : sy - nll);
                                     }
-                                    pv = val;
                                 }
-                                if (bad) break;
-                                if (pass == 0) {
-                                    Code tmp;
-                                    const int v = make_code(tmp, sc, 15);
-                                    if (table == 0) { if (v != 0 || !has_eob) bad = true; }
-                                    else if (v == 2) bad = true;
-                                    else if (v == 1 && !(d_used == 0 || (d_used == 1 && d_one_len == 1))) bad = true;   // RFC 1951 3.2.7
-                                }
+                                k += rep;
+                                pv = val;
+                            }
+                            if (bad) break;
+                            if (pass == 0) {
+                                const int v0 = make_code(ll, sc, CUR, 15);
+                                const int v1 = make_code(dc, sc, CUR_D, 15);
+                                if (v0 != 0 || !has_eob) bad = true;
+                                else if (v1 == 2) bad = true;
+                                else if (v1 == 1 && !(d_used == 0 || (d_used == 1 && d_one_len == 1))) bad = true;   // RFC 1951 3.2.7
                             }
                         }
                         if (bad) { err = ST_BAD_CODE; st = S_DONE; }
