@@ -328,6 +328,11 @@ int vtx_submit_bam(vtx_ctx* ctx, const vtx_bam_ingest* ingest, vtx_ingest_stats*
 #define VTX_INGEST_TAGS 4            /* the tag arena those records point into                                */
 #define VTX_INGEST_READS_PACKED 5    /* the read arena, two bases per byte                                    */
 int vtx_debug_ingest(vtx_ctx* ctx, int what, void* dst, uint64_t cap, uint64_t* bytes);
+/* Test hook: the device's BGZF inflater on arbitrary raw-DEFLATE payloads (block i = file[coff .. coff + clen), expected to inflate
+ * to isize bytes): status[i] = 0 accepted, its bytes at out + (sum of the isizes before it); else the decoder's reason.  The product
+ * path (vtx_submit_bam) treats any non-zero status as "the host packer decides".                                              */
+int vtx_debug_inflate(vtx_ctx* ctx, const uint8_t* file, uint64_t file_bytes, const vtx_bgzf_block* blocks, uint32_t n_blocks,
+                      uint8_t* out, uint64_t out_cap, uint32_t* status);
 
 /* Run the hot path on the resident batch: Smith-Waterman of every record
  * against both haplotypes (src/main.rs:898-901), per-read call

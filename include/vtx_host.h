@@ -85,6 +85,17 @@ void vtxh_get_barcode_table(const vtxh_pack* p, const uint8_t** bytes, const uin
  * holds one locus' reads at a time (src/main.rs:822-830) — and pack range k + 1 while the device works on range k.           */
 int vtxh_pack_files_range(const vtxh_args* args, int raw, uint32_t row_begin, uint32_t row_end, vtxh_pack** out);
 
+/* Device-side ingest (vtx_submit_bam in vtx.h): the PLAN is everything vtxh_pack_files does before it touches a read — barcodes, VCF
+ * rows [row_begin, row_end), haplotypes, loci — plus an index of the BAM for the device: the BGZF blocks that can hold reads of those
+ * loci (a header walk; the file stays mapped, nothing but its header is inflated), the record starts the .bai's linear index names
+ * inside them, and the offset of the first record that lies beyond the last locus.  vtxh_get_ingest fills the struct vtx_submit_bam
+ * takes (pointers valid until vtxh_free); VTX_E_UNSUPPORTED — no usable .bai, loci so sparse that an index-guided sweep inflates far
+ * less, an index that does not match the file — means: pack on the host (vtxh_pack_files_range), as before.  The returned pack
+ * carries the loci, names, barcode table and the two VCF-level Metrics like any raw pack; it has no batches.                    */
+int vtxh_plan_ingest(const vtxh_args* args, uint32_t row_begin, uint32_t row_end, vtxh_pack** out);
+int vtxh_get_ingest(const vtxh_pack* p, vtx_bam_ingest* out);
+int vtxh_is_plan(const vtxh_pack* p);
+
 /* A pack holds one or more BATCHES: consecutive loci whose reads span less than 4 GiB of the arenas, so that the
  * 32-bit offsets of vtx.h hold relative to the batch (the reference has no such limit: it streams per locus).
  * Loci keep their global `row`; feed the batches to vtx_submit / vtx_submit_raw one after the other (or to different

@@ -31,11 +31,13 @@ def test_exports_every_declared_symbol(L):
 
 
 def test_struct_sizes_match(L):
-    out = (C.c_uint32 * 9)()
-    assert L.vtx_abi_sizes(out, 9) == abi.VTX_ABI_VERSION
+    out = (C.c_uint32 * 13)()
+    assert L.vtx_abi_sizes(out, 13) == abi.VTX_ABI_VERSION
     assert list(out) == [C.sizeof(abi.VtxConfig), abi.LOCUS_DTYPE.itemsize, abi.RECORD_DTYPE.itemsize,
                          C.sizeof(abi.VtxBatch), C.sizeof(abi.VtxCoo), C.sizeof(abi.VtxTiming),
-                         abi.RAW_RECORD_DTYPE.itemsize, C.sizeof(abi.VtxRawBatch), C.sizeof(abi.VtxRawStats)]
+                         abi.RAW_RECORD_DTYPE.itemsize, C.sizeof(abi.VtxRawBatch), C.sizeof(abi.VtxRawStats),
+                         abi.BGZF_BLOCK_DTYPE.itemsize, abi.BAM_INTERVAL_DTYPE.itemsize, C.sizeof(abi.VtxBamIngest),
+                         C.sizeof(abi.VtxIngestStats)]
 
 
 def test_config_default_is_reference_constants(L):

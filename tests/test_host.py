@@ -104,7 +104,7 @@ def test_validate_inputs_unknown_contig(tmp_path):
         hostlib.pack_files(str(vcf), os.path.join(G, "test.bam"), os.path.join(G, "test.fa"), os.path.join(G, "barcodes.tsv"))
 
 
-def make_dna_bam(tmp_path, seed=1, n_reads=600):
+def make_dna_bam(tmp_path, seed=1, n_reads=600, block=20000):
     """Author a coordinate-sorted BAM over test_dna.fa covering the loci of test_dna.vcf (SNV, INS,
     DEL, one multi-allelic record) with assorted CIGARs, flags, tags and soft clips."""
     from oracle import bamwriter
@@ -159,7 +159,7 @@ def make_dna_bam(tmp_path, seed=1, n_reads=600):
         recs.append((start, bamwriter.record(0, start, "r%04d" % k, seq, cigar, flag=flag, mapq=mapq, tags=tags)))
     recs.sort(key=lambda t: t[0])
     bam = str(tmp_path / "dna.bam")
-    bamwriter.write_bam(bam, [("1", len(fa))], [r for _, r in recs], block=20000)
+    bamwriter.write_bam(bam, [("1", len(fa))], [r for _, r in recs], block=block)
     return bam
 
 

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-VTX_ABI_VERSION = 5
+VTX_ABI_VERSION = 6
 READS_BYTES, READS_NIBBLES = 0, 1          # vtx_set_read_format
 
 VTX_OK = 0
@@ -174,6 +174,33 @@ class VtxRawStats(C.Structure):
         ("prep_ms", C.c_float),
         ("hash_rounds", C.c_uint32),
     ]
+
+
+# ---- vtx_submit_bam (device-side ingest) ----
+BGZF_BLOCK_DTYPE = np.dtype([("coff", "<u8"), ("clen", "<u4"), ("isize", "<u4")])
+BAM_INTERVAL_DTYPE = np.dtype([("start", "<i4"), ("end", "<i4"), ("locus", "<u4"), ("reserved", "<u4")])
+assert BGZF_BLOCK_DTYPE.itemsize == 16 and BAM_INTERVAL_DTYPE.itemsize == 16
+INGEST_INFLATED, INGEST_RECORD_OFFSETS, INGEST_RAW_RECORDS, INGEST_RAW_LOCUS, INGEST_TAGS, INGEST_READS_PACKED = range(6)
+
+
+class VtxBamIngest(C.Structure):
+    _fields_ = [
+        ("file", C.c_void_p), ("file_bytes", C.c_uint64),
+        ("blocks", C.c_void_p), ("n_blocks", C.c_uint32), ("n_ref", C.c_uint32),
+        ("seeds", C.c_void_p), ("n_seeds", C.c_uint32), ("n_intervals", C.c_uint32),
+        ("end_upos", C.c_uint64),
+        ("intervals", C.c_void_p), ("tid_begin", C.c_void_p), ("tid_max_span", C.c_void_p),
+        ("loci", C.c_void_p), ("n_loci", C.c_uint32), ("min_mapq", C.c_uint32),
+        ("primary_only", C.c_int32), ("no_duplicates", C.c_int32),
+        ("hap_arena", C.c_void_p), ("hap_bytes", C.c_uint64),
+        ("bam_tag", C.c_char * 2), ("reserved", C.c_char * 6),
+    ]
+
+
+class VtxIngestStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("num_reads", "num_low_mapq", "num_non_primary", "num_duplicates", "num_not_useful",
+                                          "num_no_barcode_tag", "bam_records", "raw_records", "compressed_bytes", "inflated_bytes")] + \
+               [("raw", VtxRawStats)] + [(n, C.c_float) for n in ("h2d_ms", "inflate_ms", "index_ms", "filter_ms")]
 
 
 def pack_nibbles(arena: np.ndarray) -> np.ndarray:

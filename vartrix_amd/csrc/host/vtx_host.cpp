@@ -528,6 +528,19 @@ struct vtxh_pack {
     // of vtx.h hold relative to the batch's window.  Loci / records of all batches sit back to back in the arrays above.
     struct Batch { uint32_t l0, l1; uint64_t rec0, rec1, rbase, rbytes, tbase, tbytes; };
     std::vector<Batch> batches;
+    // plan of a device-side ingest (vtxh_plan_ingest): the file stays mapped, the index of its blocks / record starts / loci below
+    bool is_plan = false, planned = false;
+    std::string plan_reason;
+    std::unique_ptr<MappedFile> bam_map;
+    std::vector<vtx_bgzf_block> pl_blocks;
+    std::vector<uint64_t> pl_seeds;
+    uint64_t pl_end = 0;
+    std::vector<vtx_bam_interval> pl_iv;
+    std::vector<uint32_t> pl_tid_begin;
+    std::vector<int32_t> pl_span;
+    uint32_t pl_mapq = 0;
+    int32_t pl_primary = 0, pl_nodup = 0;
+    char pl_tag[2] = {'C', 'B'};
 };
 
 extern "C" {
@@ -649,17 +662,40 @@ void vtxh_get_barcode_table(const vtxh_pack* p, const uint8_t** bytes, const uin
     *bytes = (const uint8_t*)p->bc_bytes.data(); *offsets = p->bc_offsets.data(); *n = (uint32_t)p->barcodes.size();
 }
 
-static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t row_end, vtxh_pack** out);
+static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t row_end, vtxh_pack** out, bool plan = false);
 int vtxh_pack_files(const vtxh_args* a, vtxh_pack** out) { return pack_impl(a, false, 0, 0xffffffffu, out); }
 int vtxh_pack_files_raw(const vtxh_args* a, vtxh_pack** out) { return pack_impl(a, true, 0, 0xffffffffu, out); }
 int vtxh_pack_files_range(const vtxh_args* a, int raw, uint32_t row_begin, uint32_t row_end, vtxh_pack** out) {
     if (row_begin > row_end) return fail(VTX_E_INVAL, "vtxh_pack_files_range: row_begin > row_end");
     return pack_impl(a, raw != 0, row_begin, row_end, out);
 }
+int vtxh_plan_ingest(const vtxh_args* a, uint32_t row_begin, uint32_t row_end, vtxh_pack** out) {
+    if (row_begin > row_end) return fail(VTX_E_INVAL, "vtxh_plan_ingest: row_begin > row_end");
+    return pack_impl(a, true, row_begin, row_end, out, true);
+}
+int vtxh_get_ingest(const vtxh_pack* p, vtx_bam_ingest* out) {
+    if (!p || !out) return fail(VTX_E_INVAL, "vtxh_get_ingest: null argument");
+    memset(out, 0, sizeof *out);
+    if (!p->is_plan) return fail(VTX_E_STATE, "vtxh_get_ingest: not a plan (vtxh_plan_ingest)");
+    if (!p->planned) return fail(VTX_E_UNSUPPORTED, "no device-side ingest for this input: %s", p->plan_reason.c_str());
+    out->file = p->bam_map->data(); out->file_bytes = p->bam_map->size();
+    out->blocks = p->pl_blocks.data(); out->n_blocks = (uint32_t)p->pl_blocks.size();
+    out->n_ref = (uint32_t)p->pl_span.size();
+    out->seeds = p->pl_seeds.data(); out->n_seeds = (uint32_t)p->pl_seeds.size();
+    out->n_intervals = (uint32_t)p->pl_iv.size();
+    out->end_upos = p->pl_end;
+    out->intervals = p->pl_iv.data(); out->tid_begin = p->pl_tid_begin.data(); out->tid_max_span = p->pl_span.data();
+    out->loci = p->loci.data(); out->n_loci = (uint32_t)p->loci.size();
+    out->min_mapq = p->pl_mapq; out->primary_only = p->pl_primary; out->no_duplicates = p->pl_nodup;
+    out->hap_arena = (const uint8_t*)p->hap_arena.data(); out->hap_bytes = p->hap_arena.size();
+    out->bam_tag[0] = p->pl_tag[0]; out->bam_tag[1] = p->pl_tag[1];
+    return VTX_OK;
+}
+int vtxh_is_plan(const vtxh_pack* p) { return p && p->is_plan ? 1 : 0; }
 
 // VCF records [row_begin, row_end) only: the other records keep their matrix rows (n_variants, names) but get no haplotypes, no
 // loci and no reads, and are not counted in the metrics — the packs of consecutive ranges add up to the pack of the whole file.
-static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t row_end, vtxh_pack** out) {
+static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t row_end, vtxh_pack** out, bool plan) {
     if (!a || !out || !a->vcf || !a->bam || !a->fasta || !a->cell_barcodes) return fail(VTX_E_INVAL, "vtxh_pack_files: null argument");
     *out = nullptr;
     const std::string bam_tag = a->bam_tag ? a->bam_tag : "CB";
@@ -777,7 +813,8 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
 
     ph.mark("fasta index");
     // ---- BAM: header ----
-    MappedFile bam_file;
+    std::unique_ptr<MappedFile> bam_holder(new MappedFile());      // (a plan keeps the mapping: vtx_submit_bam reads the file's bytes)
+    MappedFile& bam_file = *bam_holder;
     if (!bam_file.open(a->bam)) return fail(VTX_E_INVAL, "error opening bam file: %s", a->bam);
     if (ends_with(a->bam, ".cram")) return fail(VTX_E_UNSUPPORTED, "CRAM input is not supported");
     std::vector<BgzfBlock> blocks;
@@ -790,6 +827,8 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     size_t chunk_blocks = 512;            // blocks per inflate round; restarts small after an index-guided jump
     size_t max_chunk_blocks = 512;
     if (const char* e = VTXH_DEV_ENV("VTXH_CHUNK_BLOCKS")) chunk_blocks = max_chunk_blocks = std::max<size_t>(1, strtoull(e, nullptr, 10));   // tests: many windows
+    if (plan) chunk_blocks = max_chunk_blocks = 2;      // a plan inflates the header's blocks only
+    uint64_t buf_origin = 0;              // offset of buf[0] in the inflated stream of the whole file
     size_t chunk_limit_block = SIZE_MAX;  // index-guided sweep: no read-ahead beyond the block the sweep would jump to anyway
     uint64_t n_inflated = 0, n_jumps = 0;
     // the window whose records are indexed but not parsed yet (the parse of window k runs beside the indexing of window
@@ -816,7 +855,7 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
                 buf_pos = 0;
                 pend_detached = true;
             } else if (buf_pos) {
-                buf.drop_prefix(buf_pos); buf_pos = 0;
+                buf.drop_prefix(buf_pos); buf_origin += buf_pos; buf_pos = 0;
             }
             std::vector<size_t> off(chunk + 1, 0);
             for (size_t k = 0; k < chunk; ++k) off[k + 1] = off[k] + blocks[next_block + k].isize;
@@ -921,8 +960,8 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     struct Target { int32_t tid; int64_t start, end; uint64_t voff; };
     std::vector<Target> targets;
     bool use_index = false;
+    std::vector<std::vector<uint64_t>> lin;
     {
-        std::vector<std::vector<uint64_t>> lin;
         if (!VTXH_DEV_ENV("VTXH_NO_INDEX") && read_bai_linear(std::string(a->bam) + ".bai", bam_refs.size(), lin)) {
             use_index = true;
             for (size_t t = 0; t < by_tid.size(); ++t) {
@@ -938,6 +977,129 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
                 }
             }
         }
+    }
+    if (plan) {
+        // ---- the plan of a device-side ingest (vtx_submit_bam): the loci, the BGZF blocks that can hold their reads, the record starts
+        //      the index names inside them, and where to stop.  No read is touched here. ----
+        P->is_plan = true;
+        P->pl_mapq = a->mapq; P->pl_primary = a->primary_only; P->pl_nodup = a->no_duplicates;
+        P->pl_tag[0] = bam_tag[0]; P->pl_tag[1] = bam_tag[1];
+        for (size_t l = 0; l < loci.size(); ++l) {
+            const LocusBuild& L = loci[l];
+            vtx_locus o{};
+            o.row = L.row;
+            o.ref_off = (uint32_t)P->hap_arena.size(); o.ref_len = (uint32_t)L.ref_hap.size();
+            P->hap_arena += L.ref_hap;
+            o.alt_off = (uint32_t)P->hap_arena.size(); o.alt_len = (uint32_t)L.alt_hap.size();
+            P->hap_arena += L.alt_hap;
+            P->loci.push_back(o);
+        }
+        if (P->hap_arena.size() > 0xffffffffull) return fail(VTX_E_UNSUPPORTED, "haplotype arena above 4 GiB: split the VCF");
+        P->blocks_total = blocks.size();
+        auto done = [&](const char* why) { if (why) P->plan_reason = why; else P->planned = true; P->bam_map = std::move(bam_holder); *out = P.release(); return VTX_OK; };
+        P->pl_tid_begin.assign(bam_refs.size() + 1, 0);
+        P->pl_span.assign(bam_refs.size(), 1);
+        for (size_t t = 0; t < by_tid.size(); ++t) {
+            P->pl_tid_begin[t] = (uint32_t)P->pl_iv.size();
+            for (const Interval& x : by_tid[t]) {
+                if (x.start > INT32_MAX || x.end > INT32_MAX) return done("a locus beyond 2^31 on its contig");
+                P->pl_iv.push_back(vtx_bam_interval{(int32_t)x.start, (int32_t)x.end, x.locus, 0});
+            }
+            if (max_span[t] > INT32_MAX) return done("a locus longer than 2^31");
+            P->pl_span[t] = (int32_t)max_span[t];
+        }
+        P->pl_tid_begin[bam_refs.size()] = (uint32_t)P->pl_iv.size();
+        if (!use_index) return done("no usable .bai next to the BAM (the record starts come from its linear index)");
+        if (targets.empty()) return done(nullptr);                   // no locus can have reads: nothing to inflate
+        std::vector<uint64_t> ustart(blocks.size() + 1, 0);
+        for (size_t b = 0; b < blocks.size(); ++b) ustart[b + 1] = ustart[b] + blocks[b].isize;
+        auto blk_of = [&](uint64_t voff) -> size_t {                  // the block that starts at voff's compressed offset (blocks.size(): none)
+            const size_t co = (size_t)(voff >> 16);
+            size_t lo = 0, hi = blocks.size();
+            while (lo < hi) { const size_t mid = (lo + hi) / 2; if (blocks[mid].start < co) lo = mid + 1; else hi = mid; }
+            return lo < blocks.size() && blocks[lo].start == co ? lo : blocks.size();
+        };
+        auto upos_of = [&](uint64_t voff, uint64_t* up) -> bool {
+            const size_t b = blk_of(voff);
+            if (b == blocks.size() || (voff & 0xffff) > blocks[b].isize) return false;
+            *up = ustart[b] + (voff & 0xffff);
+            return true;
+        };
+        auto record_at = [&](uint64_t voff, int32_t* rt, int64_t* rp) -> bool {      // (tid, pos) of the record that starts at voff
+            size_t b = blk_of(voff);
+            if (b == blocks.size()) return false;
+            const size_t within = (size_t)(voff & 0xffff);
+            std::vector<unsigned char> tmp;
+            while (tmp.size() < within + 12 && b < blocks.size()) {
+                const size_t o = tmp.size();
+                tmp.resize(o + blocks[b].isize + 8);
+                if (!inflate_block(bam_file, blocks[b], tmp.data() + o)) return false;
+                tmp.resize(o + blocks[b].isize);
+                ++b;
+            }
+            if (tmp.size() < within + 12) return false;
+            *rt = rdi32(tmp.data() + within + 4); *rp = rdi32(tmp.data() + within + 8);
+            return true;
+        };
+        const uint64_t first_rec = buf_origin + buf_pos;             // where the header ends
+        uint64_t start_upos = first_rec, start_voff = 0;
+        if (targets[0].voff) {
+            start_voff = targets[0].voff;
+            if (!upos_of(start_voff, &start_upos)) return done("the .bai names an offset that is not in the BAM");
+            if (start_upos < first_rec) return done("the .bai names an offset inside the BAM header");
+        }
+        // where to stop: the first indexed record at or beyond the end of the last contig's last locus (coordinate-sorted file:
+        // nothing later can overlap a locus), else the first record of a later contig, else the end of the file
+        const int32_t tl = targets.back().tid;
+        int64_t seg_end = 0;
+        for (const Target& t : targets) if (t.tid == tl) seg_end = std::max(seg_end, t.end);
+        uint64_t end_upos = ustart[blocks.size()];
+        bool found_end = false;
+        {
+            const auto& li = lin[(size_t)tl];
+            uint64_t prev = 0;
+            int probes = 0;
+            for (size_t w = (size_t)(seg_end >> 14); w < li.size() && !found_end; ++w) {
+                const uint64_t v = li[w];
+                if (!v || v == prev || v <= start_voff) continue;
+                prev = v;
+                int32_t rt; int64_t rp;
+                if (!record_at(v, &rt, &rp)) return done("the .bai names an offset that is not a record of the BAM");
+                if (rt < 0 || rt > tl || (rt == tl && rp >= seg_end)) {
+                    if (!upos_of(v, &end_upos)) return done("the .bai names an offset that is not in the BAM");
+                    found_end = true;
+                }
+                if (++probes > 64) break;                            // (a pile-up of long records over the locus: sweep to the next contig)
+            }
+            for (size_t t = (size_t)tl + 1; t < lin.size() && !found_end; ++t)
+                for (const uint64_t v : lin[t])
+                    if (v) { if (!upos_of(v, &end_upos)) return done("the .bai names an offset that is not in the BAM"); found_end = true; break; }
+        }
+        if (end_upos <= start_upos) return done(nullptr);            // nothing between: no reads
+        // blocks [b0, b1) hold [start_upos, end_upos)
+        const size_t b0 = (size_t)(std::upper_bound(ustart.begin(), ustart.end(), start_upos) - ustart.begin()) - 1;
+        const size_t b1 = (size_t)(std::lower_bound(ustart.begin(), ustart.end(), end_upos) - ustart.begin());
+        // sparse loci far apart: the host's index-guided sweep inflates a few blocks per locus; one contiguous range would inflate
+        // everything between the first and the last
+        if (ustart[b1] - ustart[b0] > ((uint64_t)64 << 20) && (ustart[b1] - ustart[b0]) >> 20 > targets.size())       // (> 1 MiB of BAM per locus)
+            return done("sparse loci (an index-guided sweep on the host inflates less)");
+        if (ustart[b1] - ustart[b0] > ((uint64_t)48 << 30)) return done("more than 48 GiB of inflated BAM in one range: stream ranges of loci");
+        for (size_t b = b0; b < b1; ++b) P->pl_blocks.push_back(vtx_bgzf_block{(uint64_t)blocks[b].coff, blocks[b].clen, blocks[b].isize});
+        const uint64_t base = ustart[b0];
+        P->pl_seeds.push_back(start_upos - base);
+        for (size_t t = (size_t)targets[0].tid; t <= (size_t)tl; ++t)
+            for (const uint64_t v : lin[t]) {
+                if (!v) continue;
+                uint64_t up;
+                if (!upos_of(v, &up)) return done("the .bai names an offset that is not in the BAM");
+                if (up > start_upos && up < end_upos) P->pl_seeds.push_back(up - base);
+            }
+        std::sort(P->pl_seeds.begin(), P->pl_seeds.end());
+        P->pl_seeds.erase(std::unique(P->pl_seeds.begin(), P->pl_seeds.end()), P->pl_seeds.end());
+        P->pl_end = end_upos - base;
+        P->blocks_inflated = b1 - b0;
+        ph.mark("plan");
+        return done(nullptr);
     }
     // ---- sweep the BAM (fetch + filters of evaluate_alns, :822-895) ----
     // Per window of inflated blocks: record boundaries are indexed sequentially (a hop per record), the

@@ -1085,7 +1085,7 @@ int vtx_submit_bam(vtx_ctx* c, const vtx_bam_ingest* g, vtx_ingest_stats* st) {
     const float h2d_ms = since(t0);
     // ---- inflate, record boundaries ----
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    HIP_TRY(c, vtxg_inflate(c->d_bam_comp.as<uint8_t>(), c->d_bam_blocks.as<vtxg_block>(), nb, c->d_bam_data.as<uint8_t>(), d_err, s));
+    HIP_TRY(c, vtxg_inflate(c->d_bam_comp.as<uint8_t>(), c->d_bam_blocks.as<vtxg_block>(), nb, c->d_bam_data.as<uint8_t>(), d_err, nullptr, s));
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     uint32_t n_rec = 0;
     if (ns) {
@@ -1153,6 +1153,38 @@ int vtx_submit_bam(vtx_ctx* c, const vtx_bam_ingest* g, vtx_ingest_stats* st) {
         st->bam_records = n_rec; st->raw_records = nr; st->inflated_bytes = utotal; st->compressed_bytes = hi - lo;
         st->raw = rs; st->h2d_ms = h2d_ms; st->inflate_ms = inflate_ms; st->index_ms = index_ms; st->filter_ms = filter_ms;
     }
+    return VTX_OK;
+}
+
+// Test hook: bgzf_inflate_kernel on arbitrary raw-DEFLATE payloads — block i is file[blocks[i].coff .. + clen) and must inflate to
+// exactly blocks[i].isize bytes; status[i] = 0 when the device's decoder accepted it (its bytes at out + the sum of the isizes before
+// it), else a vtxi::Status.  Blocks need not be ordered or disjoint (the tests feed truncated copies of one stream).
+int vtx_debug_inflate(vtx_ctx* c, const uint8_t* file, uint64_t file_bytes, const vtx_bgzf_block* blk, uint32_t n, uint8_t* out, uint64_t out_cap, uint32_t* status) {
+    if (!c || (n && (!blk || !status)) || (file_bytes && !file)) return VTX_E_INVAL;
+    std::vector<vtxg_block> blocks(n);
+    uint64_t utotal = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (blk[i].coff + blk[i].clen > file_bytes || blk[i].isize > 65536u) return fail(c, VTX_E_INVAL, "vtx_debug_inflate: block %u outside the input or above 64 KiB", i);
+        blocks[i] = vtxg_block{blk[i].coff, utotal, blk[i].clen, blk[i].isize};
+        utotal += blk[i].isize;
+    }
+    if (utotal > out_cap) return fail(c, VTX_E_INVAL, "vtx_debug_inflate: output buffer too small");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, c->d_bam_comp.reserve((size_t)file_bytes + 64));
+    HIP_TRY(c, c->d_bam_data.reserve((size_t)utotal + 64));
+    HIP_TRY(c, c->d_bam_blocks.reserve((size_t)n * sizeof(vtxg_block) + 16));
+    HIP_TRY(c, c->d_bam_cnt.reserve(VTXG_N_COUNTERS * sizeof(uint64_t) + 4 * sizeof(uint32_t)));
+    HIP_TRY(c, c->d_bam_seed_cnt.reserve((size_t)n * sizeof(uint32_t) + 16));
+    uint32_t* d_err = (uint32_t*)(c->d_bam_cnt.as<unsigned long long>() + VTXG_N_COUNTERS);
+    HIP_TRY(c, hipMemsetAsync(d_err, 0, 4 * sizeof(uint32_t), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_bam_data.p, 0xEE, (size_t)utotal + 64, s));
+    if (file_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_bam_comp.p, file, (size_t)file_bytes, hipMemcpyHostToDevice, s));
+    if (n) HIP_TRY(c, hipMemcpyAsync(c->d_bam_blocks.p, blocks.data(), (size_t)n * sizeof(vtxg_block), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, vtxg_inflate(c->d_bam_comp.as<uint8_t>(), c->d_bam_blocks.as<vtxg_block>(), n, c->d_bam_data.as<uint8_t>(), d_err, c->d_bam_seed_cnt.as<uint32_t>(), s));
+    if (n) HIP_TRY(c, hipMemcpyAsync(status, c->d_bam_seed_cnt.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (utotal && out) HIP_TRY(c, hipMemcpyAsync(out, c->d_bam_data.p, (size_t)utotal, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
     return VTX_OK;
 }
 

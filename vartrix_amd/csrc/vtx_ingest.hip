@@ -33,7 +33,8 @@ namespace {
 // 49 152 lanes resident on 256 CUs — a 0.9 GB BAM has ~45 000 blocks: one pass).
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const vtxg_block* __restrict__ blocks,
-                                                          uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ err) {
+                                                          uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ err,
+                                                          uint32_t* __restrict__ status) {
     __shared__ uint16_t scratch[vtxi::WORDS * 64];
     const vtxi::Scratch sc{scratch + threadIdx.x, 64};
     for (uint32_t b = blockIdx.x * 64 + threadIdx.x; b < n_blocks; b += gridDim.x * 64) {
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
         uint32_t st = vtxi::ST_OK;
         if (B.isize) st = vtxi::inflate_block(comp + B.coff, B.clen, out + B.uoff, B.isize, sc, nullptr);
         if (st != vtxi::ST_OK) { atomicMin(&err[1], b); atomicOr(&err[0], 1u << st); }
+        if (status) status[b] = st;                         // (vtx_debug_inflate: the verdict per block)
     }
 }
 
@@ -319,10 +321,10 @@ __global__ __launch_bounds__(256) void bam_scan_kernel(const uint8_t* __restrict
 
 extern "C" {
 
-hipError_t vtxg_inflate(const uint8_t* comp, const vtxg_block* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* err, hipStream_t s) {
+hipError_t vtxg_inflate(const uint8_t* comp, const vtxg_block* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* err, uint32_t* status, hipStream_t s) {
     if (!n_blocks) return hipSuccess;
     const uint32_t wgs = std::min<uint32_t>((n_blocks + 63) / 64, 256u * 3u);
-    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(wgs), dim3(64), 0, s, comp, blocks, n_blocks, out, err);
+    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(wgs), dim3(64), 0, s, comp, blocks, n_blocks, out, err, status);
     return hipGetLastError();
 }
 

@@ -33,7 +33,7 @@ SYMBOLS = ("vtxh_pack_files", "vtxh_free", "vtxh_last_error", "vtxh_get_batch", 
            "vtxh_num_variants", "vtxh_num_barcodes", "vtxh_variant_name", "vtxh_barcode", "vtxh_write_mtx",
            "vtxh_format_f64", "vtxh_pack_files_raw", "vtxh_get_raw_batch", "vtxh_get_barcode_table", "vtxh_num_batches",
            "vtxh_get_batch_at", "vtxh_get_raw_batch_at", "vtxh_pack_files_range", "vtxh_test_inflate", "vtxh_read_format",
-           "vtxh_trim")
+           "vtxh_trim", "vtxh_plan_ingest", "vtxh_get_ingest", "vtxh_is_plan")
 METRIC_NAMES = ("num_reads", "num_low_mapq", "num_non_primary", "num_duplicates", "num_not_cell_bc",
                 "num_not_useful", "num_non_umi", "num_invalid_recs", "num_multiallelic_recs")
 
@@ -91,6 +91,12 @@ def load():
         L.vtxh_write_mtx.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vtxh_format_f64.restype = C.c_int
         L.vtxh_format_f64.argtypes = [C.c_double, C.c_char_p]
+        L.vtxh_plan_ingest.restype = C.c_int
+        L.vtxh_plan_ingest.argtypes = [C.POINTER(VtxhArgs), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.vtxh_get_ingest.restype = C.c_int
+        L.vtxh_get_ingest.argtypes = [C.c_void_p, C.POINTER(abi.VtxBamIngest)]
+        L.vtxh_is_plan.restype = C.c_int
+        L.vtxh_is_plan.argtypes = [C.c_void_p]
         L.vtxh_get_ingest_stats.restype = None
         L.vtxh_get_ingest_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 3)]
         _lib = L
@@ -159,6 +165,72 @@ def pack_files(vcf, bam, fasta, cell_barcodes, padding=100, mapq=0, primary_only
     finally:
         L.vtxh_free(h)
     return batch, metrics, nv, barcodes, variants
+
+
+class IngestPlan:
+    """The plan of a device-side ingest (vtxh_plan_ingest): ``ingest`` is the struct ``Context.submit_bam`` takes (its pointers live as
+    long as this object), ``reason`` says why there is none.  Also the loci, the VCF-level metrics, the barcode list and the names."""
+
+    def __init__(self, h, L):
+        self._h, self._L = h, L
+        self.ingest = abi.VtxBamIngest()
+        rc = L.vtxh_get_ingest(h, C.byref(self.ingest))
+        self.reason = None if rc == 0 else L.vtxh_last_error().decode()
+        if rc != 0:
+            self.ingest = None
+        m = VtxhMetrics()
+        L.vtxh_get_metrics(h, C.byref(m))
+        self.metrics = {n: int(getattr(m, n)) for n in METRIC_NAMES}
+        self.n_variants, nb = L.vtxh_num_variants(h), L.vtxh_num_barcodes(h)
+        self.barcodes = [L.vtxh_barcode(h, j) for j in range(nb)]
+        self.variants = [L.vtxh_variant_name(h, i).decode() for i in range(self.n_variants)]
+        st = (C.c_uint64 * 3)()
+        L.vtxh_get_ingest_stats(h, C.byref(st))
+        self.blocks_planned, self.blocks_total = int(st[0]), int(st[1])
+
+    @property
+    def n_loci(self):
+        return int(self.ingest.n_loci) if self.ingest is not None else 0
+
+    def arrays(self):
+        """numpy copies of the plan's arrays (tests)."""
+        g = self.ingest
+
+        def arr(ptr, n, dt):
+            return np.frombuffer(C.string_at(ptr, n * np.dtype(dt).itemsize), dtype=dt).copy() if n else np.zeros(0, dt)
+        return dict(blocks=arr(g.blocks, g.n_blocks, abi.BGZF_BLOCK_DTYPE), seeds=arr(g.seeds, g.n_seeds, np.uint64),
+                    intervals=arr(g.intervals, g.n_intervals, abi.BAM_INTERVAL_DTYPE), tid_begin=arr(g.tid_begin, g.n_ref + 1, np.uint32),
+                    tid_max_span=arr(g.tid_max_span, g.n_ref, np.int32), loci=arr(g.loci, g.n_loci, abi.LOCUS_DTYPE),
+                    hap_arena=arr(g.hap_arena, g.hap_bytes, np.uint8), end_upos=int(g.end_upos))
+
+    def close(self):
+        if self._h:
+            self._L.vtxh_free(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def plan_ingest(vcf, bam, fasta, cell_barcodes, padding=100, mapq=0, primary_only=False, no_duplicates=False, use_umi=False,
+                bam_tag="CB", valid_chars="ATGCatgc", threads=1, rows=None) -> IngestPlan:
+    L = load()
+    args = VtxhArgs(vcf.encode(), bam.encode(), fasta.encode(), cell_barcodes.encode(), padding, mapq, int(primary_only),
+                    int(no_duplicates), int(use_umi), bam_tag.encode(), valid_chars.encode(), threads, abi.READS_NIBBLES)
+    h = C.c_void_p()
+    r0, r1 = (0, 0xFFFFFFFF) if rows is None else (int(rows[0]), int(rows[1]))
+    if L.vtxh_plan_ingest(C.byref(args), r0, r1, C.byref(h)) != 0:
+        raise HostError(L.vtxh_last_error().decode())
+    return IngestPlan(h, L)
 
 
 def write_mtx(path, n_rows, n_cols, row, col, value):

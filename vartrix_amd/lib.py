@@ -36,6 +36,7 @@ SYMBOLS = (
     "vtx_status_name", "vtx_abi_sizes", "vtx_set_barcodes", "vtx_submit_raw", "vtx_fetch_records",
     "vtx_comm_id", "vtx_comm_init", "vtx_gather_coo", "vtx_fetch_gathered", "vtx_gather_abort", "vtx_gather_plan",
     "vtx_set_debug", "vtx_fetch_stage", "vtx_debug_bands", "vtx_debug_tables", "vtx_set_read_format",
+    "vtx_submit_bam", "vtx_debug_ingest", "vtx_debug_inflate",
 )
 
 
@@ -114,6 +115,12 @@ def load(variant=None):
     L.vtx_debug_tables.argtypes = [ctxp, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.vtx_debug_bands.restype = C.c_int
     L.vtx_debug_bands.argtypes = [ctxp, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.vtx_submit_bam.restype = C.c_int
+    L.vtx_submit_bam.argtypes = [ctxp, C.POINTER(abi.VtxBamIngest), C.POINTER(abi.VtxIngestStats)]
+    L.vtx_debug_inflate.restype = C.c_int
+    L.vtx_debug_inflate.argtypes = [ctxp, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.vtx_debug_ingest.restype = C.c_int
+    L.vtx_debug_ingest.argtypes = [ctxp, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     _libs[path] = L
     return L
 
@@ -206,6 +213,35 @@ class Context:
         self.n_records = int(stats.kept)
         self._n_loci = raw.n_loci
         return stats
+
+    def submit_bam(self, ingest: abi.VtxBamIngest, n_loci: int) -> abi.VtxIngestStats:
+        """Device-side ingest of a BAM range (vtx_submit_bam): ``ingest`` comes from ``hostlib.plan_ingest`` (or is built by hand in the
+        tests); the barcode list must be set.  Afterwards the context is in the state ``submit_raw`` leaves."""
+        stats = abi.VtxIngestStats()
+        self._check(self._L.vtx_submit_bam(self._h, C.byref(ingest), C.byref(stats)))
+        self.n_records = int(stats.raw.kept)
+        self._n_loci = n_loci
+        return stats
+
+    def debug_inflate(self, data: bytes, blocks):
+        """bgzf_inflate_kernel on raw-DEFLATE payloads: blocks = [(offset, clen, isize)] into ``data``.  -> (status array, [bytes per block])"""
+        blk = np.array(blocks, dtype=abi.BGZF_BLOCK_DTYPE) if len(blocks) else np.zeros(0, abi.BGZF_BLOCK_DTYPE)
+        total = int(blk["isize"].sum())
+        out = np.zeros(total + 64, np.uint8)
+        status = np.zeros(max(len(blk), 1), np.uint32)
+        self._check(self._L.vtx_debug_inflate(self._h, data, len(data), blk.ctypes.data if len(blk) else None, len(blk),
+                                              out.ctypes.data, total, status.ctypes.data))
+        offs = np.concatenate([[0], np.cumsum(blk["isize"])]).astype(np.int64)
+        return status[:len(blk)], [bytes(out[offs[i]:offs[i + 1]]) for i in range(len(blk))]
+
+    def debug_ingest(self, what: int, dtype=np.uint8) -> np.ndarray:
+        """An intermediate array of the last submit_bam (abi.INGEST_*)."""
+        n = C.c_uint64(0)
+        self._check(self._L.vtx_debug_ingest(self._h, what, None, 0, C.byref(n)))
+        out = np.zeros(int(n.value), np.uint8)
+        if n.value:
+            self._check(self._L.vtx_debug_ingest(self._h, what, out.ctypes.data, n.value, C.byref(n)))
+        return out.view(dtype)
 
     def fetch_records(self):
         """Resolved, sorted records of the resident batch + per-locus (rec_begin, rec_count)."""
