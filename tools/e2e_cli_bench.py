@@ -177,7 +177,7 @@ def run_cli_timed(out_dir, fa, vcf, bam, bcs, threads, extra, label, env=None):
     wall = time.time() - t0
     assert r.returncode == 0, r.stdout + r.stderr
     keep = [ln for ln in r.stderr.splitlines() if any(k in ln for k in ("Ingest", "Device", "shard:", "Merge +", "Waited", "Total",
-                                                                       "[vtxh]", "alignments evaluated", "device preparation"))]
+                                                                       "[vtxh]", "alignments evaluated", "device preparation", "device ingest", "Plan of", "packing on the host"))]
     print("%s: CLI wall time %.2f s\n  %s" % (label, wall, "\n  ".join(keep)), flush=True)
     return out
 
@@ -200,9 +200,10 @@ def main():
         fa, vcf, bam, bcs, n_reads = author_fast(args.out, args.loci, args.reads, args.barcodes, procs=args.procs)
         print("authored %d reads over %d loci in %.1f s (%.1f MB BAM)" % (n_reads, args.loci, time.time() - t0, os.path.getsize(bam) / 1e6), flush=True)
         texts = []
-        runs = [(["--prep", "host"], "--prep host", args.threads), (["--prep", "device"], "--prep device", args.threads),
-                (["--prep", "device"], "--prep device (second run, page cache warm)", args.threads),
-                (["--prep", "host", "--reads", "bytes"], "--prep host --reads bytes (one byte per base, as before round 4's nibbles)", args.threads)]
+        runs = [(["--ingest", "device"], "--ingest device (BGZF inflate, record split, filters on the GPU)", args.threads),
+                (["--ingest", "device"], "--ingest device (second run, page cache warm)", args.threads),
+                (["--ingest", "host", "--prep", "device"], "--ingest host --prep device", args.threads),
+                (["--ingest", "host", "--prep", "host"], "--ingest host --prep host", args.threads)]
         for th in args.more_threads:
             runs.append((["--prep", "device"], "--prep device, --threads %d" % th, th))
         runs = [r + (None,) for r in runs]
@@ -211,8 +212,8 @@ def main():
             import hashlib
             texts.append(hashlib.sha256(open(out, "rb").read()).hexdigest())
             print("  .mtx %.1f MB, sha256 %s" % (os.path.getsize(out) / 1e6, texts[-1][:16]), flush=True)
-        assert len(set(texts)) == 1, "host-prepared / device-prepared / byte-arena outputs differ"
-        print("host-prepared and device-prepared .mtx are byte-identical")
+        assert len(set(texts)) == 1, "device-ingested / host-packed outputs differ"
+        print("device-ingested, host-packed + device-prepared and host-prepared .mtx are byte-identical")
         return
     rng = np.random.default_rng(7)
     V, R, B, Lr = args.loci, args.reads, args.barcodes, 150

@@ -68,7 +68,7 @@ const Opt kOpts[] = {
     {"primary-alignments", 0, true, nullptr}, {"no-duplicates", 0, true, nullptr}, {"umi", 0, true, nullptr},
     {"bam-tag", 0, false, "CB"}, {"valid-chars", 0, false, "ATGCatgc"},
     {"devices", 0, false, "1"}, {"aligner", 0, false, "banded"}, {"prep", 0, false, "host"},
-    {"stream-loci", 0, false, "auto"}, {"reads", 0, false, "nibbles"}, {"gather", 0, false, "auto"},
+    {"stream-loci", 0, false, "auto"}, {"reads", 0, false, "nibbles"}, {"gather", 0, false, "auto"}, {"ingest", 0, false, "auto"},
 };
 
 void usage() {
@@ -79,6 +79,9 @@ void usage() {
             "  --ref-matrix <FILE> [ref_matrix.mtx]   --log-level info|debug|error [error]   --threads <INT> [1]\n"
             "  --mapq <INT> [0]   --primary-alignments   --no-duplicates   --umi   --bam-tag <TAG> [CB]\n"
             "  --valid-chars <CHARS> [ATGCatgc]   --devices <INT> [1]   --aligner banded|full [banded]\n"
+            "  --ingest auto|device|host [auto]  where the BAM is read: device = BGZF inflate, record split, read filters and tag lookups on the\n"
+            "                               GPU (vtx_submit_bam; needs the .bai; implies --prep device for that range); host = the packer\n"
+            "                               threads of libvtxhost; auto = device with one GPU when the input allows it, else host\n"
             "  --prep host|device [host]  (device: barcode lookup, UMI grouping and the sort run on the GPU)\n"
             "  --stream-loci <INT>|auto [auto]  VCF records per streamed range (ingest of range k + 1 overlaps the device work on\n"
             "                               range k; host memory follows the range, not the BAM); 0 = the whole input at once;\n"
@@ -134,6 +137,10 @@ struct Shard {
     int rank = 0, world = 1;
     ShardGate* gate = nullptr;
     int read_format = VTX_READS_BYTES;          // of the pack's read arenas (vtxh_read_format)
+    // --ingest device: the range's reads never exist on the host — the device gets the file's bytes and the plan (vtx_submit_bam)
+    const vtx_bam_ingest* ingest = nullptr;
+    vtx_ingest_stats istats{};
+    bool declined = false;                      // vtx_submit_bam said VTX_E_UNSUPPORTED: the caller packs this range on the host
 };
 
 double since(std::chrono::steady_clock::time_point t0) {
@@ -168,7 +175,15 @@ void run_shard(Shard* s, vtx_config cfg) {
     vtx_batch b{s->loci.data(), (uint32_t)s->loci.size(), s->records, s->n_records, s->haps,
                 s->hap_bytes, s->reads, s->read_bytes};
     vtx_coo coo{};
-    if (s->raw) {
+    if (s->ingest) {
+        if ((s->rc = vtx_set_barcodes(ctx, s->bc_bytes, s->bc_offsets, s->n_bcs)) || (s->rc = vtx_submit_bam(ctx, s->ingest, &s->istats))) {
+            s->err = vtx_strerror(ctx);
+            s->declined = s->rc == VTX_E_UNSUPPORTED;
+            vtx_destroy(ctx);
+            return;
+        }
+        s->stats = s->istats.raw;
+    } else if (s->raw) {
         vtx_raw_batch rb{s->loci.data(), (uint32_t)s->loci.size(), s->raw_records, s->n_records,
                          s->haps, s->hap_bytes, s->reads, s->read_bytes, s->tags, s->tag_bytes};
         if ((s->rc = vtx_set_barcodes(ctx, s->bc_bytes, s->bc_offsets, s->n_bcs)) || (s->rc = vtx_submit_raw(ctx, &rb, &s->stats))) {
@@ -178,7 +193,7 @@ void run_shard(Shard* s, vtx_config cfg) {
             return;
         }
     }
-    if (!s->raw && (s->rc = vtx_submit(ctx, &b))) { s->err = vtx_strerror(ctx); if (s->comm_id) (void)vtx_gather_abort(ctx); vtx_destroy(ctx); return; }
+    if (!s->raw && !s->ingest && (s->rc = vtx_submit(ctx, &b))) { s->err = vtx_strerror(ctx); if (s->comm_id) (void)vtx_gather_abort(ctx); vtx_destroy(ctx); return; }
     s->t_submit = now_s() - t0; t0 = now_s();
     if ((s->rc = vtx_run(ctx))) { s->err = vtx_strerror(ctx); if (s->comm_id) (void)vtx_gather_abort(ctx); vtx_destroy(ctx); return; }
     s->t_run = now_s() - t0; t0 = now_s();
@@ -289,6 +304,14 @@ int main(int argc, char** argv) {
         return 1;
     }
     const int ndev = std::max(1, atoi(val["devices"].c_str()));
+    if (val["ingest"] != "auto" && val["ingest"] != "device" && val["ingest"] != "host") {
+        fprintf(stderr, "error: '%s' isn't a valid value for '--ingest <ingest>'\n", val["ingest"].c_str());
+        return 1;
+    }
+    if (val["ingest"] == "device" && ndev > 1) { fprintf(stderr, "error: --ingest device runs on one GPU (use --ingest host with --devices %d)\n", ndev); return 1; }
+    // the plan of a device-side ingest instead of a pack: with one GPU, unless the host was asked for
+    const bool try_device_ingest = val["ingest"] != "host" && ndev == 1 && val["gather"] != "library";
+    const bool must_device_ingest = val["ingest"] == "device";
     std::vector<std::thread> warm;
     for (int d = 0; d < ndev; ++d) warm.emplace_back(warm_device, d);
     struct JoinAll { std::vector<std::thread>& v; ~JoinAll() { for (auto& t : v) if (t.joinable()) t.join(); } } join_warm{warm};
@@ -311,7 +334,7 @@ int main(int argc, char** argv) {
         }
         stream_loci = (uint32_t)v;                            // (0: one range)
     }
-    struct Packed { vtxh_pack* pk = nullptr; int rc = 0; std::string err; double secs = 0; bool last = false; };
+    struct Packed { vtxh_pack* pk = nullptr; int rc = 0; std::string err; double secs = 0; bool last = false; uint32_t begin = 0, end = 0; std::string why_host; };
     std::mutex q_mu;
     std::condition_variable q_cv;
     std::vector<Packed> q;                 // at most one packed range waiting (plus the one being consumed)
@@ -322,8 +345,18 @@ int main(int argc, char** argv) {
             Packed pc;
             const auto t0 = std::chrono::steady_clock::now();
             const uint32_t end = stream_loci ? (begin + stream_loci < begin ? 0xffffffffu : begin + stream_loci) : 0xffffffffu;
-            pc.rc = vtxh_pack_files_range(&ha, raw ? 1 : 0, begin, end, &pc.pk);
-            if (pc.rc) pc.err = vtxh_last_error();
+            pc.begin = begin; pc.end = end;
+            if (try_device_ingest) {
+                pc.rc = vtxh_plan_ingest(&ha, begin, end, &pc.pk);
+                vtx_bam_ingest probe;
+                if (!pc.rc && vtxh_get_ingest(pc.pk, &probe) != VTX_OK) {        // no plan for this input: pack on the host (here, beside the device)
+                    pc.why_host = vtxh_last_error();
+                    vtxh_free(pc.pk); pc.pk = nullptr;
+                    if (must_device_ingest) { pc.rc = VTX_E_UNSUPPORTED; pc.err = pc.why_host; }
+                    else pc.rc = vtxh_pack_files_range(&ha, raw ? 1 : 0, begin, end, &pc.pk);
+                }
+            } else pc.rc = vtxh_pack_files_range(&ha, raw ? 1 : 0, begin, end, &pc.pk);
+            if (pc.rc && pc.err.empty()) pc.err = vtxh_last_error();
             else n_total = vtxh_num_variants(pc.pk);
             pc.secs = since(t0);
             pc.last = pc.rc != 0 || end >= n_total;
@@ -394,8 +427,50 @@ int main(int argc, char** argv) {
     Packed cur = std::move(first);
     for (uint32_t range_idx = 0;; ++range_idx) {
     pk = cur.pk;
-    if (raw) vtxh_get_barcode_table(pk, &bc_bytes, &bc_offsets, &bc_n);
-    const uint32_t n_batches = vtxh_num_batches(pk);
+    if (!cur.why_host.empty()) LOG_INFO("Range %u: %s — packing on the host", range_idx, cur.why_host.c_str());
+    if (vtxh_is_plan(pk)) {
+        // ---- --ingest device: the BAM's bytes and the plan go to the device; the reads never exist on the host ----
+        vtx_bam_ingest g;
+        (void)vtxh_get_ingest(pk, &g);
+        vtxh_get_barcode_table(pk, &bc_bytes, &bc_offsets, &bc_n);
+        Shard s;
+        s.ingest = &g; s.bc_bytes = bc_bytes; s.bc_offsets = bc_offsets; s.n_bcs = bc_n; s.raw = true;
+        s.keep_ctx = range_idx == 0 && cur.last;
+        const auto t_shard = std::chrono::steady_clock::now();
+        LOG_INFO("Plan of range %u: %.3f s (%u loci, %u BGZF blocks, %u record-start seeds from the .bai); ingest on the device", range_idx, cur.secs,
+                 g.n_loci, g.n_blocks, g.n_seeds);
+        run_shard(&s, cfg);
+        if (s.rc && s.declined && !must_device_ingest) {
+            LOG_INFO("Range %u: the device declined (%s) — packing on the host", range_idx, s.err.c_str());
+            vtxh_pack* hp = nullptr;
+            const auto t_hp = std::chrono::steady_clock::now();
+            if (vtxh_pack_files_range(&ha, raw ? 1 : 0, cur.begin, cur.end, &hp)) { printf("Vartrix error.\nError: %s\n", vtxh_last_error()); return 1; }
+            vtxh_free(pk);
+            pk = cur.pk = hp;
+            cur.secs += since(t_hp);
+        } else {
+            if (s.rc) { printf("Vartrix error.\nError: %s: %s\n", vtx_status_name(s.rc), s.err.c_str()); return 1; }
+            t_device += since(t_shard);
+            const vtx_ingest_stats& is = s.istats;
+            LOG_INFO("  device ingest: %llu BAM records, %llu (read, locus) pairs; upload %.1f ms (%.1f MB compressed), inflate %.1f ms (%.1f MB), record index %.1f ms, filters %.1f ms",
+                     (unsigned long long)is.bam_records, (unsigned long long)is.raw_records, (double)is.h2d_ms, is.compressed_bytes / 1e6, (double)is.inflate_ms,
+                     is.inflated_bytes / 1e6, (double)is.index_ms, (double)is.filter_ms);
+            LOG_INFO("  shard: create %.3f s, submit (upload + ingest + device preparation) %.3f s, run %.3f s, fetch %.3f s", s.t_create, s.t_submit, s.t_run, s.t_fetch);
+            LOG_INFO("  device preparation: %llu reads kept, %.3f ms, %u hash round(s)", (unsigned long long)s.stats.kept, (double)s.stats.prep_ms, s.stats.hash_rounds);
+            if (s.keep_ctx) { out_nnz = s.kept.nnz; out_row = s.kept.row; out_col = s.kept.col; out_v = s.kept.value; out_rv = s.kept.ref_value; }
+            row.insert(row.end(), s.row.begin(), s.row.end());
+            col.insert(col.end(), s.col.begin(), s.col.end());
+            v.insert(v.end(), s.val.begin(), s.val.end());
+            rv.insert(rv.end(), s.refval.begin(), s.refval.end());
+            m.num_reads += is.num_reads; m.num_low_mapq += is.num_low_mapq; m.num_non_primary += is.num_non_primary;
+            m.num_duplicates += is.num_duplicates; m.num_not_useful += is.num_not_useful; m.num_not_cell_bc += is.num_no_barcode_tag;
+            raw_total.num_not_cell_bc += s.stats.num_not_cell_bc; raw_total.num_non_umi += s.stats.num_non_umi; raw_total.kept += s.stats.kept;
+        }
+    }
+    const bool range_raw = raw && !vtxh_is_plan(pk);             // (a plan that ran has no batches: the loop below is empty)
+    if (raw && !vtxh_is_plan(pk)) vtxh_get_barcode_table(pk, &bc_bytes, &bc_offsets, &bc_n);
+    (void)range_raw;
+    const uint32_t n_batches = vtxh_is_plan(pk) ? 0u : vtxh_num_batches(pk);
     for (uint32_t bi = 0; bi < n_batches; ++bi) {
         vtx_batch full{};
         vtx_raw_batch full_raw{};
