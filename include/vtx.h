@@ -353,6 +353,14 @@ int vtx_fetch_coo(vtx_ctx* ctx, vtx_coo* out);
  * keep results on the GPU, e.g. an RCCL gather).  int32[n_records] each.     */
 int vtx_device_scores(vtx_ctx* ctx, const int32_t** d_ref, const int32_t** d_alt);
 
+/* sprs::io::write_matrix_market of the last vtx_run's triplets (src/main.rs:381-389: three header lines, then "row+1 col+1 value"
+ * per triplet in insertion order) — formatted on the device and streamed into `path` by the copy workers; the triplets never become
+ * host arrays.  which: 0 = `value` (the matrix), 1 = `ref_value` (coverage mode's ref matrix, :385-389).  Integral values only
+ * (consensus 1 / 2 / 3, coverage counts: Rust's `{}` of such an f64 is its digits); alt_frac's fractions / NaN return
+ * VTX_E_UNSUPPORTED and leave nothing at `path` — format those on the host (vtx_fetch_coo + vtxh_write_mtx: shortest round-trip
+ * digits).  *sum (optional): the sum of the values written (the reference's "sum of 0" warning, :410-415).                      */
+int vtx_write_mtx(vtx_ctx* ctx, const char* path, uint32_t n_rows, uint32_t n_cols, int which, double* sum);
+
 /* Device pointers of the last vtx_run's triplets (same layout as vtx_coo, all
  * arrays resident in HBM) — the payload of the multi-GPU row gather.          */
 int vtx_device_coo(vtx_ctx* ctx, vtx_coo* out);
@@ -378,6 +386,8 @@ int vtx_comm_id(uint8_t id[VTX_COMM_ID_BYTES]);
 int vtx_comm_init(vtx_ctx* ctx, const uint8_t id[VTX_COMM_ID_BYTES], int rank, int world);
 int vtx_gather_coo(vtx_ctx* ctx, int dst, vtx_coo* out);
 int vtx_fetch_gathered(vtx_ctx* ctx, vtx_coo* out);
+/* The number of ranks the communicator itself reports (ncclCommCount) — a cross-check of the launcher's world size. */
+int vtx_comm_ranks(vtx_ctx* ctx, int* ranks);
 /* A rank whose own work failed after vtx_comm_init (vtx_submit / vtx_run error) calls this INSTEAD of vtx_gather_coo: it takes
  * part in the status round, and every other rank's vtx_gather_coo returns VTX_E_PEER instead of waiting for ever.          */
 int vtx_gather_abort(vtx_ctx* ctx);

@@ -90,7 +90,13 @@ def test_coverage_mode_without_ref_matrix_flag_writes_the_default_ref_matrix(tmp
     assert os.path.exists(out2) and not os.path.exists(tmp_path / "ref_matrix.mtx")
 
 
-@pytest.mark.parametrize("prep", ["host", "device"])
+# where the reads are prepared: "host" = the packer threads do everything (--ingest host --prep host); "device" = the packer reads the
+# BAM, the device does barcode lookup / UMI grouping / sort (--ingest host --prep device); "ingest" = the device reads the BAM itself
+# (--ingest device: BGZF inflate, record split, filters, tags — vtx_submit_bam; no fallback: a declined range is an error)
+PATHS = {"host": ["--ingest", "host", "--prep", "host"], "device": ["--ingest", "host", "--prep", "device"], "ingest": ["--ingest", "device"]}
+
+
+@pytest.mark.parametrize("prep", ["host", "device", "ingest"])
 @pytest.mark.parametrize("aligner", ["banded", "full"])
 @pytest.mark.parametrize("mode", ["consensus", "alt_frac", "coverage"])
 @pytest.mark.parametrize("umi", [False, True])
@@ -102,8 +108,9 @@ def test_authored_indel_bam_end_to_end(tmp_path, mode, umi, aligner, prep):
     vcfp, fap, bcp = (os.path.join(G, n) for n in ("test_dna.vcf", "test_dna.fa", "dna_barcodes.tsv"))
     out, ref = str(tmp_path / "out.mtx"), str(tmp_path / "ref.mtx")
     args = ["-v", vcfp, "-b", bam, "-f", fap, "-c", bcp, "-o", out, "-s", mode, "--ref-matrix", ref, "--threads", "4",
-            "--aligner", aligner, "--prep", prep, "--log-level", "info"]
+            "--aligner", aligner, "--log-level", "info"] + PATHS[prep]
     r = run_cli(args + (["--umi"] if umi else []), tmp_path)
+    assert ("ingest on the device" in r.stderr) == (prep == "ingest")
     bcs = refpipe.load_barcodes(bcp)
     vcf = refpipe.read_vcf(vcfp)
     batch, wm = refpipe.pack(vcf, refpipe.read_fasta(fap), refpipe.read_bam(bam), bcs, refpipe.Args(use_umi=umi))
@@ -137,13 +144,32 @@ def test_authored_indel_bam_end_to_end(tmp_path, mode, umi, aligner, prep):
 def test_reference_fixtures_with_device_prep(tmp_path, umi):
     """The reference's coverage fixtures (src/main.rs:1266-1339) with barcode lookup / UMI grouping / sort on the GPU."""
     out, ref = str(tmp_path / "out.mtx"), str(tmp_path / "ref.mtx")
-    run_cli(base_args() + ["-o", out, "-s", "coverage", "--ref-matrix", ref, "--prep", "device"] + (["--umi"] if umi else []), tmp_path)
+    run_cli(base_args() + ["-o", out, "-s", "coverage", "--ref-matrix", ref, "--prep", "device", "--ingest", "host"] + (["--umi"] if umi else []), tmp_path)
     sfx = "_umi" if umi else ""
     assert csr(out) == csr(os.path.join(G, "test_coverage%s.mtx" % sfx))         # the reference compares CSR (:1296-1299)
     assert csr(ref) == csr(os.path.join(G, "test_coverage_ref%s.mtx" % sfx))
     out2 = str(tmp_path / "c.mtx")
-    run_cli(base_args() + ["-o", out2, "--prep", "device", "--devices", "1"], tmp_path)
+    run_cli(base_args() + ["-o", out2, "--prep", "device", "--devices", "1", "--ingest", "host"], tmp_path)
     assert open(out2).read() == open(os.path.join(G, "test_consensus.mtx")).read()
+
+
+@pytest.mark.parametrize("umi", [False, True])
+def test_reference_fixtures_with_device_ingest(tmp_path, umi):
+    """The reference's fixtures (src/main.rs:1208-1339) with the BAM read ON THE DEVICE (--ingest device: vtx_submit_bam — BGZF inflate,
+    record split, filters, tags; the default with one GPU, forced here so that a silent fallback to the host packer would fail)."""
+    out, ref = str(tmp_path / "out.mtx"), str(tmp_path / "ref.mtx")
+    r = run_cli(base_args() + ["-o", out, "-s", "coverage", "--ref-matrix", ref, "--ingest", "device", "--log-level", "info"] + (["--umi"] if umi else []), tmp_path)
+    assert "ingest on the device" in r.stderr and "packing on the host" not in r.stderr
+    sfx = "_umi" if umi else ""
+    assert csr(out) == csr(os.path.join(G, "test_coverage%s.mtx" % sfx))
+    assert csr(ref) == csr(os.path.join(G, "test_coverage_ref%s.mtx" % sfx))
+    if not umi:
+        for mode, fixture in (("consensus", "test_consensus.mtx"), ("alt_frac", "test_frac.mtx")):
+            o2 = str(tmp_path / (mode + ".mtx"))
+            if os.path.exists(ref):
+                os.remove(ref)
+            run_cli(base_args() + ["-o", o2, "-s", mode, "--ref-matrix", ref, "--ingest", "device"], tmp_path)
+            assert open(o2).read() == open(os.path.join(G, fixture)).read()
 
 
 @pytest.mark.parametrize("prep", ["host", "device"])
@@ -156,7 +182,7 @@ def test_multi_batch_run_equals_single_batch(tmp_path, prep):
     outs = {}
     for name, env in (("one", {}), ("many", {"VTXH_BATCH_BYTES": "12000"})):
         out = str(tmp_path / (name + ".mtx"))
-        args = ["-v", vcfp, "-b", bam, "-f", fap, "-c", bcp, "-o", out, "-s", "alt_frac", "--umi", "--threads", "3", "--prep", prep,
+        args = ["-v", vcfp, "-b", bam, "-f", fap, "-c", bcp, "-o", out, "-s", "alt_frac", "--umi", "--threads", "3", "--prep", prep, "--ingest", "host",
                 "--log-level", "info", "--ref-matrix", str(tmp_path / (name + "_ref.mtx")), "--stream-loci", "0"]
         # (the tiny batch limit is a hook of the developer build: bin/vartrix_dev, libvtxhost_dev.so; the single-batch run is the product)
         r = subprocess.run([hostlib.cli_path("dev") if env else hostlib.CLI_PATH] + args, cwd=tmp_path, capture_output=True, text=True,
@@ -181,7 +207,7 @@ def test_cli_row_gather_through_the_library(tmp_path):
     assert open(out1).read() == open(out2).read() == open(os.path.join(G, "test_frac.mtx")).read()
 
 
-@pytest.mark.parametrize("prep", ["host", "device"])
+@pytest.mark.parametrize("prep", ["host", "device", "ingest"])
 def test_streamed_ranges_give_the_same_files_and_counters(tmp_path, prep):
     """--stream-loci: the VCF taken in ranges of 7 records (7 ranges for test_dna.vcf, packed by a producer thread while the
     device works on the range before) writes byte-identical matrices and logs the same nine counters as the whole input at once
@@ -194,12 +220,12 @@ def test_streamed_ranges_give_the_same_files_and_counters(tmp_path, prep):
     for name, sl in (("whole", "0"), ("ranges", "7"), ("single", "1")):
         out, ref, ov = (str(tmp_path / ("%s_%s" % (name, n))) for n in ("out.mtx", "ref.mtx", "vars.txt"))
         r = run_cli(["-v", vcfp, "-b", bam, "-f", fap, "-c", bcp, "-o", out, "-s", "coverage", "--ref-matrix", ref, "--umi",
-                     "--threads", "4", "--prep", prep, "--log-level", "info", "--stream-loci", sl, "--out-variants", ov], tmp_path)
+                     "--threads", "4", "--log-level", "info", "--stream-loci", sl, "--out-variants", ov] + PATHS[prep], tmp_path)
         log = r.stdout + r.stderr
         counters = re.findall(r"Number of [^:]+: (\d+)", log)
         assert len(counters) == 9
         outs[name] = (open(out).read(), open(ref).read(), open(ov).read(), counters)
-        n_ranges = len(re.findall(r"pack of range \d+", log))
+        n_ranges = len(re.findall(r"(?:pack|Plan) of range \d+", log))
         assert n_ranges == {"whole": 1, "ranges": 7, "single": 46}[name]
     assert outs["whole"] == outs["ranges"] == outs["single"]
     assert len(outs["whole"][0]) > 500

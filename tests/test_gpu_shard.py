@@ -156,10 +156,34 @@ def test_two_rank_launch_rehearsal_on_one_device(tmp_path):
     assert len(lines) == 1, r.stdout[-3000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "strong"
-    assert j["gather"]["impl"].startswith("vtx_gather_coo") and j["gather"]["ranks"] == 2
+    assert j["gather"]["impl"].startswith("vtx_gather_coo") and j["gather"]["ranks"] == 2 and j["gather"]["rccl_ranks"] == 2
     assert j["result"] == plain["result"] and j["result"]["nnz"] > 50000
     assert j["config"]["alignments_per_step"] == plain["config"]["alignments_per_step"]
     assert j["value"] > 0 and j["ms_per_step"] > 0 and j["sustained"]["steps"] >= 1
+
+
+def test_eight_rank_launch_rehearsal_on_one_device(tmp_path):
+    """The driver's 8-GPU command — `torchrun --nproc-per-node 8 bench.py --gpus 8` — on ONE device over the test transport (round 6:
+    8 is what the scaling run launches; 2 and 4 were the rehearsed worlds).  Eight contexts share the device (a reduced config 4:
+    50 000 barcodes, sharded by partition_loci), every step ends in the library's gather with seven senders, the communicator
+    reports 8 ranks, and the gathered matrix equals the unsharded run's."""
+    args = ["--loci", "6000", "--barcodes", "50000", "--reads-per-locus", "24", "--no-sensitivity", "--no-cpu-baseline", "--no-other-aligner"]
+    plain = _bench({}, args)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VTX_LIB_VARIANT="dev", VTX_COMM_TEST_TRANSPORT=str(tmp_path))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", "29647", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--sustain-seconds", "0"] + args,
+                       capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["steps"] == 2 and j["scaling"] == "strong"
+    assert j["gather"]["impl"].startswith("vtx_gather_coo") and j["gather"]["ranks"] == 8 and j["gather"]["rccl_ranks"] == 8
+    assert j["result"] == plain["result"] and j["result"]["nnz"] > 50000
+    assert j["config"]["alignments_per_step"] == plain["config"]["alignments_per_step"]
 
 
 # ---- vtx_gather_coo with world 2 and 4: ranks = processes on ONE device, RCCL's nine entry points replaced by the test transport

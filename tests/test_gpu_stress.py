@@ -225,7 +225,9 @@ np.save(sys.argv[1], np.concatenate(out))
             subprocess.check_call([sys.executable, "-c", code, path], env=env)
             res.append(np.load(path))
     assert np.array_equal(res[0][:-1], res[1][:-1])
-    assert res[0][-1] < 0.8 * res[1][-1], (res[0][-1], res[1][-1])
+    # (round 6: the refined join is capped by what an excursion over far pieces costs — join_gap3_far, a soundness fix — so the
+    #  refinement decides fewer tasks than round 5's did: 19 % fewer hard tasks on this mix instead of 25 %)
+    assert res[0][-1] < 0.9 * res[1][-1], (res[0][-1], res[1][-1])
 
 
 def test_single_diagonal_stage_on_and_off_give_the_same_scores():

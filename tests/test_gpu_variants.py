@@ -49,9 +49,9 @@ print("variant-ok", moved)
 
 
 # variant, oracle hook (vtxo_set_variant which / value), must the override move scores?
-@pytest.mark.parametrize("variant,which,value,must_move", [("lazy0", 0, 0, 1), ("anchor5", 1, 5, 0), ("noseed0", 2, 0, 1)])
+@pytest.mark.parametrize("variant,which,value,must_move", [("lazy0", 0, 0, 1), ("lazy40", 0, 40, 1), ("anchor5", 1, 5, 0), ("noseed0", 2, 0, 1)])
 def test_device_follows_the_header_when_a_recollected_detail_is_recompiled(variant, which, value, must_move):
-    """libvtx_lazy0.so / libvtx_anchor5.so / libvtx_noseed0.so: the production sources with ONE constant of
+    """libvtx_lazy0.so / libvtx_lazy40.so (round 6: 2 w, the other plausible reading of set_boundaries) / libvtx_anchor5.so / libvtx_noseed0.so: the production sources with ONE constant of
     include/vtx_band_semantics.h at its alternative.  Each must reproduce the oracle run with the same override on test.bam's real
     reads, on the known-answer vectors and on the stress batches.  (anchor5 moves nothing — tests/test_band_kat.py shows why — and the
     device agrees; the fourth detail, sdpkpp's tie rule, is the order of the packed words the kernels maximise, not a constant:

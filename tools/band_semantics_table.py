@@ -3,7 +3,7 @@ VTXO_VAR_*): alignments whose banded score changes and per-read calls that chang
   (a) every read of the reference's test/test.bam that reaches the aligner with the barcode list ignored (576 real reads),
   (b) a config-5-shaped synthetic batch (30 % indel loci <= 20 bp, UMIs),
   (c) real-read shapes (soft clips, adapters, spliced reads; tests/stress_batches.py).
-CPU only (the oracle).  Writes profiles/r03_band_semantics_sensitivity.json and prints a markdown table.
+CPU only (the oracle).  Writes profiles/r06_band_semantics_sensitivity.json and prints a markdown table.
     python tools/band_semantics_table.py
 """
 import ctypes as C
@@ -28,6 +28,7 @@ VARIANTS = [  # (label, which, value)
     ("default (the recollection)", None, None),
     ("lazy extension 0 instead of 2k", 0, 0),
     ("lazy extension k instead of 2k", 0, 6),
+    ("lazy extension 2w = 40 instead of 2k", 0, 40),
     ("lazy extension to the matrix edge", 0, EDGE),
     ("add_kmer anchors 0..k-1 instead of 0..k", 1, 5),
     ("no k-mer match: empty band instead of the whole matrix", 2, 0),
@@ -78,7 +79,7 @@ def workloads(small=False):
 
 if __name__ == "__main__":
     rows = table(workloads())
-    out = os.path.join(ROOT, "profiles", "r03_band_semantics_sensitivity.json")
+    out = os.path.join(ROOT, "profiles", "r06_band_semantics_sensitivity.json")
     json.dump({"method": "oracle (CPU) with one recollected detail switched at a time: tools/band_semantics_table.py", "rows": rows}, open(out, "w"), indent=1)
     print("| workload | variant | alignments | changed vs default | calls changed | != full matrix | calls != full |")
     print("|---|---|---|---|---|---|---|")

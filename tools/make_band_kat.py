@@ -57,7 +57,7 @@ def pairs(batch, limit):
 # a maintainer replaying the file against the crate who sees exactly the vectors tagged with one detail fail knows which
 # constant of include/vtx_band_semantics.h to change, and to what.
 EDGE = 0x7fffffff
-ALTERNATIVES = [("lazy_extension", "0", 0, 0), ("lazy_extension", "k", 0, 6), ("lazy_extension", "to the matrix edge", 0, EDGE),
+ALTERNATIVES = [("lazy_extension", "0", 0, 0), ("lazy_extension", "k", 0, 6), ("lazy_extension", "2 * w", 0, 40), ("lazy_extension", "to the matrix edge", 0, EDGE),
                 ("kmer_last_anchor", "k - 1", 1, 5), ("no_seed", "empty band", 2, 0), ("sdpkpp_ties", "smaller match index", 3, 0)]
 
 

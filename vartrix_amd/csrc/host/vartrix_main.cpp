@@ -129,6 +129,8 @@ struct Shard {
     // a run of one batch on one shard writes the matrices straight from the context's arrays (ctx kept until exit)
     bool keep_ctx = false;
     vtx_coo kept{};
+    vtx_ctx* ctx_kept = nullptr;                // keep_ctx with defer_fetch: the triplets stay on the device — vtx_write_mtx formats them there
+    bool defer_fetch = false;
     std::string err;
     int rc = 0;
     double t_create = 0, t_submit = 0, t_run = 0, t_fetch = 0;
@@ -178,7 +180,7 @@ void run_shard(Shard* s, vtx_config cfg) {
     if (s->ingest) {
         if ((s->rc = vtx_set_barcodes(ctx, s->bc_bytes, s->bc_offsets, s->n_bcs)) || (s->rc = vtx_submit_bam(ctx, s->ingest, &s->istats))) {
             s->err = vtx_strerror(ctx);
-            s->declined = s->rc == VTX_E_UNSUPPORTED;
+            s->declined = s->rc == VTX_E_UNSUPPORTED || s->rc == VTX_E_NOMEM;      // (the inflated stream did not fit the device: the host packer needs far less of it)
             vtx_destroy(ctx);
             return;
         }
@@ -205,8 +207,9 @@ void run_shard(Shard* s, vtx_config cfg) {
         if ((s->rc = vtx_gather_coo(ctx, 0, &dev))) { s->err = vtx_strerror(ctx); vtx_destroy(ctx); return; }
         if (s->rank != 0) { s->t_fetch = now_s() - t0; vtx_destroy(ctx); return; }
         if ((s->rc = vtx_fetch_gathered(ctx, &coo))) { s->err = vtx_strerror(ctx); vtx_destroy(ctx); return; }
-    } else if ((s->rc = vtx_fetch_coo(ctx, &coo))) { s->err = vtx_strerror(ctx); vtx_destroy(ctx); return; }
-    if (s->keep_ctx) { s->kept = coo; s->t_fetch = now_s() - t0; return; }
+    } else if (s->keep_ctx && s->defer_fetch) { s->ctx_kept = ctx; return; }
+    else if ((s->rc = vtx_fetch_coo(ctx, &coo))) { s->err = vtx_strerror(ctx); vtx_destroy(ctx); return; }
+    if (s->keep_ctx) { s->kept = coo; s->ctx_kept = ctx; s->t_fetch = now_s() - t0; return; }
     s->row.assign(coo.row, coo.row + coo.nnz);
     s->col.assign(coo.col, coo.col + coo.nnz);
     s->val.assign(coo.value, coo.value + coo.nnz);
@@ -421,6 +424,7 @@ int main(int argc, char** argv) {
     const uint32_t *out_row = nullptr, *out_col = nullptr;
     const double *out_v = nullptr, *out_rv = nullptr;
     std::vector<double> v, rv;
+    vtx_ctx* kept_ctx = nullptr;                           // one range, one batch, one device: the matrix is written from the device (vtx_write_mtx)
     vtx_raw_stats raw_total{};
     vtxh_metrics m{};
     double t_device = 0;
@@ -436,6 +440,7 @@ int main(int argc, char** argv) {
         Shard s;
         s.ingest = &g; s.bc_bytes = bc_bytes; s.bc_offsets = bc_offsets; s.n_bcs = bc_n; s.raw = true;
         s.keep_ctx = range_idx == 0 && cur.last;
+        s.defer_fetch = s.keep_ctx && mode != "alt_frac";
         const auto t_shard = std::chrono::steady_clock::now();
         LOG_INFO("Plan of range %u: %.3f s (%u loci, %u BGZF blocks, %u record-start seeds from the .bai); ingest on the device", range_idx, cur.secs,
                  g.n_loci, g.n_blocks, g.n_seeds);
@@ -457,7 +462,8 @@ int main(int argc, char** argv) {
                      is.inflated_bytes / 1e6, (double)is.index_ms, (double)is.filter_ms);
             LOG_INFO("  shard: create %.3f s, submit (upload + ingest + device preparation) %.3f s, run %.3f s, fetch %.3f s", s.t_create, s.t_submit, s.t_run, s.t_fetch);
             LOG_INFO("  device preparation: %llu reads kept, %.3f ms, %u hash round(s)", (unsigned long long)s.stats.kept, (double)s.stats.prep_ms, s.stats.hash_rounds);
-            if (s.keep_ctx) { out_nnz = s.kept.nnz; out_row = s.kept.row; out_col = s.kept.col; out_v = s.kept.value; out_rv = s.kept.ref_value; }
+            if (s.keep_ctx && s.ctx_kept && s.defer_fetch) kept_ctx = s.ctx_kept;
+            else if (s.keep_ctx) { out_nnz = s.kept.nnz; out_row = s.kept.row; out_col = s.kept.col; out_v = s.kept.value; out_rv = s.kept.ref_value; }
             row.insert(row.end(), s.row.begin(), s.row.end());
             col.insert(col.end(), s.col.begin(), s.col.end());
             v.insert(v.end(), s.val.begin(), s.val.end());
@@ -501,6 +507,7 @@ int main(int argc, char** argv) {
                 const uint32_t r1 = s.loci.empty() ? 0 : s.loci.back().rec_begin + s.loci.back().rec_count;
                 s.n_records = r1 - r0;
                 s.keep_ctx = n_batches == 1 && ndev == 1 && range_idx == 0 && cur.last;
+                s.defer_fetch = s.keep_ctx && mode != "alt_frac" && val["gather"] != "library";
                 if (raw) {
                     s.raw = true;
                     s.raw_records = full_raw.records + r0;
@@ -541,7 +548,8 @@ int main(int argc, char** argv) {
         for (auto& s : shards) {
             LOG_INFO("  batch %u shard: create %.3f s, submit (H2D%s) %.3f s, run %.3f s, fetch %.3f s", bi, s.t_create,
                      s.raw ? " + device preparation" : "", s.t_submit, s.t_run, s.t_fetch);
-            if (s.keep_ctx) { out_nnz = s.kept.nnz; out_row = s.kept.row; out_col = s.kept.col; out_v = s.kept.value; out_rv = s.kept.ref_value; }
+            if (s.keep_ctx && s.ctx_kept && s.defer_fetch) kept_ctx = s.ctx_kept;
+            else if (s.keep_ctx) { out_nnz = s.kept.nnz; out_row = s.kept.row; out_col = s.kept.col; out_v = s.kept.value; out_rv = s.kept.ref_value; }
             row.insert(row.end(), s.row.begin(), s.row.end());       // shard (= row) order: the triplet order of the merge loop :320-348
             col.insert(col.end(), s.col.begin(), s.col.end());
             v.insert(v.end(), s.val.begin(), s.val.end());
@@ -584,6 +592,22 @@ int main(int argc, char** argv) {
     LOG_INFO("Number of VCF records skipped due to having invalid characters in the alternative haplotype: %llu", (unsigned long long)m.num_invalid_recs);
     LOG_INFO("Number of VCF records skipped due to being multi-allelic: %llu", (unsigned long long)m.num_multiallelic_recs);
 
+    double sum = 0;
+    bool written = false;
+    if (kept_ctx) {
+        // the matrix straight from the device: Matrix-Market text formatted there, streamed into the file by the copy workers
+        double s0 = 0;
+        int rc = vtx_write_mtx(kept_ctx, out_matrix.c_str(), n_vars, n_bcs, 0, &s0);
+        if (rc == VTX_OK && mode == "coverage") rc = vtx_write_mtx(kept_ctx, ref_matrix.c_str(), n_vars, n_bcs, 1, nullptr);    // :385-389 (see below)
+        if (rc == VTX_OK) { written = true; sum = s0; }
+        else if (rc != VTX_E_UNSUPPORTED) { printf("Vartrix error.\nError: Error writing out-matrix\nInfo: caused by %s\n", vtx_strerror(kept_ctx)); return 1; }
+        else {
+            vtx_coo coo{};
+            if (vtx_fetch_coo(kept_ctx, &coo)) { printf("Vartrix error.\nError: %s\n", vtx_strerror(kept_ctx)); return 1; }
+            out_nnz = coo.nnz; out_row = coo.row; out_col = coo.col; out_v = coo.value; out_rv = coo.ref_value;
+        }
+    }
+    if (!written) {
     if (!out_row) { out_nnz = row.size(); out_row = row.data(); out_col = col.data(); out_v = v.data(); out_rv = rv.data(); }
     if (vtxh_write_mtx(out_matrix.c_str(), n_vars, n_bcs, out_nnz, out_row, out_col, out_v) != 0) {
         printf("Vartrix error.\nError: Error writing out-matrix\nInfo: caused by %s\n", vtxh_last_error());
@@ -596,6 +620,8 @@ int main(int argc, char** argv) {
             printf("Vartrix error.\nError: Error writing ref-matrix\nInfo: caused by %s\n", vtxh_last_error());
             return 1;
         }
+    }
+    for (uint64_t k = 0; k < out_nnz; ++k) sum += out_v[k];
     }
     if (present.count("out-variants")) {                                                                                     // :391-398
         validate_output_path(val["out-variants"]);
@@ -612,8 +638,6 @@ int main(int argc, char** argv) {
         fclose(f);
     }
     LOG_INFO("Merge + output files: %.3f s", since(t_out));
-    double sum = 0;
-    for (uint64_t k = 0; k < out_nnz; ++k) sum += out_v[k];
     if (sum == 0.0) LOG_ERROR("The resulting matrix has a sum of 0. Did you use the --umi flag on data without UMIs?");       // :410-415
     LOG_INFO("Total since launch: %.3f s", since(t_main));
     // every output file is closed: skip the teardown of a GB of host arrays and of the HIP runtime (~0.1 s)

@@ -1097,6 +1097,12 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
         std::sort(P->pl_seeds.begin(), P->pl_seeds.end());
         P->pl_seeds.erase(std::unique(P->pl_seeds.begin(), P->pl_seeds.end()), P->pl_seeds.end());
         P->pl_end = end_upos - base;
+        // a record chain between two seeds is walked by ONE lane: a pile-up of hundreds of MB inside one 16 kb window (amplicon data)
+        // would serialise the device — the host's sweep indexes records at memory speed
+        for (size_t i = 0; i < P->pl_seeds.size(); ++i) {
+            const uint64_t stop = i + 1 < P->pl_seeds.size() ? P->pl_seeds[i + 1] : P->pl_end;
+            if (stop - P->pl_seeds[i] > ((uint64_t)256 << 20)) { P->pl_blocks.clear(); P->pl_seeds.clear(); return done("more than 256 MiB of BAM between two indexed record starts"); }
+        }
         P->blocks_inflated = b1 - b0;
         ph.mark("plan");
         return done(nullptr);

@@ -7,6 +7,8 @@
 #include <hipcub/hipcub.hpp>
 #include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed on first use (vtx_comm_*)
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <mutex>
@@ -306,6 +308,64 @@ int download(vtx_ctx* c, const std::vector<UploadJob>& jobs) {     // dst = host
     return VTX_OK;
 }
 
+// Device bytes straight into a file: the copy workers pwrite() their pinned buffers at the chunk's file offset — one host copy (pinned
+// buffer -> page cache), spread over the workers, instead of two (pinned -> caller's array -> page cache).
+int download_to_fd(vtx_ctx* c, int fd, uint64_t file_off, const void* d_src, size_t bytes) {
+    if (!bytes) return VTX_OK;
+    if (int rc = upload_init(c)) return rc;
+    const size_t n_chunks = (bytes + vtx_ctx::kUpChunk - 1) / vtx_ctx::kUpChunk;
+    std::atomic<size_t> next{0};
+    std::atomic<int> err{(int)hipSuccess};
+    std::atomic<bool> io_err{false};
+    const int device = c->cfg.device;
+    auto worker = [&](int w) {
+        if (hipSetDevice(device) != hipSuccess) { err = (int)hipErrorInvalidDevice; return; }
+        size_t held[vtx_ctx::kUpSlots];
+        bool used[vtx_ctx::kUpSlots] = {};
+        auto drain = [&](int slot) -> hipError_t {
+            if (!used[slot]) return hipSuccess;
+            used[slot] = false;
+            const hipError_t e = hipEventSynchronize(c->up_ev[w][slot]);
+            if (e != hipSuccess) return e;
+            const size_t o = held[slot] * vtx_ctx::kUpChunk, n = std::min(vtx_ctx::kUpChunk, bytes - o);
+            const char* p = (const char*)c->up_pin[w][slot];
+            size_t done = 0;
+            while (done < n) {
+                const ssize_t k = pwrite(fd, p + done, n - done, (off_t)(file_off + o + done));
+                if (k <= 0) { io_err = true; break; }
+                done += (size_t)k;
+            }
+            return hipSuccess;
+        };
+        int slot = 0;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            hipError_t e = drain(slot);
+            if (e == hipSuccess && i < n_chunks && err.load() == (int)hipSuccess && !io_err.load()) {
+                const size_t o = i * vtx_ctx::kUpChunk, n = std::min(vtx_ctx::kUpChunk, bytes - o);
+                e = hipMemcpyAsync(c->up_pin[w][slot], (const char*)d_src + o, n, hipMemcpyDeviceToHost, c->up_stream[w]);
+                if (e == hipSuccess) e = hipEventRecord(c->up_ev[w][slot], c->up_stream[w]);
+                if (e == hipSuccess) { used[slot] = true; held[slot] = i; }
+            } else {
+                for (int k = 1; k < vtx_ctx::kUpSlots && e == hipSuccess; ++k) e = drain((slot + k) % vtx_ctx::kUpSlots);
+                if (e != hipSuccess) err = (int)e;
+                break;
+            }
+            if (e != hipSuccess) { err = (int)e; break; }
+            slot = (slot + 1) % vtx_ctx::kUpSlots;
+        }
+        (void)hipStreamSynchronize(c->up_stream[w]);
+    };
+    const int nw = (int)std::min<size_t>(vtx_ctx::kUpWorkers, n_chunks);
+    std::vector<std::thread> th;
+    for (int w = 1; w < nw; ++w) th.emplace_back(worker, w);
+    worker(0);
+    for (auto& t : th) t.join();
+    if (err.load() != (int)hipSuccess) return fail(c, VTX_E_HIP, "download: %s", hipGetErrorString((hipError_t)err.load()));
+    if (io_err.load()) return fail(c, VTX_E_INVAL, "error writing the output file");
+    return VTX_OK;
+}
+
 // the seven triplet arrays of n entries, device -> host
 int fetch_arrays(vtx_ctx* c, size_t n, const void* row, const void* col, const void* alt, const void* ref, const void* unk,
                  const void* val, const void* refval, vtx_coo* out) {
@@ -339,6 +399,7 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
 };
 Rccl* rccl() {
     static Rccl r;
@@ -348,12 +409,12 @@ Rccl* rccl() {
         if (VTX_DEV_ENV("VTX_COMM_TEST_TRANSPORT")) {
             // TEST TRANSPORT (vtx_comm_test.hip, libvtx_dev.so only): ranks = processes that may share one device, payloads over Unix
             // sockets in that directory — the exchange's own logic with world > 1 on a one-GPU box.  Not in the production library.
-            void* f[9];
+            void* f[10];
             r.lib = vtxt_comm_test_table(f);
             r.GetUniqueId = (decltype(r.GetUniqueId))f[0]; r.CommInitRank = (decltype(r.CommInitRank))f[1];
             r.CommDestroy = (decltype(r.CommDestroy))f[2]; r.AllGather = (decltype(r.AllGather))f[3];
             r.Send = (decltype(r.Send))f[4]; r.Recv = (decltype(r.Recv))f[5]; r.GroupStart = (decltype(r.GroupStart))f[6];
-            r.GroupEnd = (decltype(r.GroupEnd))f[7]; r.GetErrorString = (decltype(r.GetErrorString))f[8];
+            r.GroupEnd = (decltype(r.GroupEnd))f[7]; r.GetErrorString = (decltype(r.GetErrorString))f[8]; r.CommCount = (decltype(r.CommCount))f[9];
             return;
         }
 #endif
@@ -364,7 +425,7 @@ Rccl* rccl() {
         if (r.lib) {
 #define VTX_SYM(f) r.f = (decltype(r.f))dlsym(r.lib, "nccl" #f)
             VTX_SYM(GetUniqueId); VTX_SYM(CommInitRank); VTX_SYM(CommDestroy); VTX_SYM(AllGather); VTX_SYM(Send); VTX_SYM(Recv);
-            VTX_SYM(GroupStart); VTX_SYM(GroupEnd); VTX_SYM(GetErrorString);
+            VTX_SYM(GroupStart); VTX_SYM(GroupEnd); VTX_SYM(GetErrorString); VTX_SYM(CommCount);
 #undef VTX_SYM
             if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.Send || !r.Recv || !r.GroupStart ||
                 !r.GroupEnd || !r.GetErrorString) { dlclose(r.lib); r.lib = nullptr; }
@@ -2094,6 +2155,65 @@ int vtx_fetch_coo(vtx_ctx* c, vtx_coo* out) {
     return fetch_arrays(c, c->nnz, c->d_o_row.p, c->d_o_col.p, c->d_o_alt.p, c->d_o_ref.p, c->d_o_unk.p, c->d_o_val.p, c->d_o_refval.p, out);
 }
 
+// sprs::io::write_matrix_market of the last vtx_run's triplets (src/main.rs:381-389: three header lines, then "row+1 col+1 value"
+// in insertion order), formatted ON THE DEVICE and streamed into the file by the copy workers: the triplets never become host arrays.
+// which: 0 = `value` (the matrix), 1 = `ref_value` (coverage mode's ref matrix).  Only for integral values — consensus 1 / 2 / 3,
+// coverage counts — whose Rust `{}` text is their digits; alt_frac's fractions / NaN need shortest-round-trip digits: VTX_E_UNSUPPORTED,
+// nothing is left at `path`, the caller formats on the host (vtx_fetch_coo + vtxh_write_mtx).  *sum (optional) = the sum of the values
+// (the reference's "matrix has a sum of 0" warning, :410-415).
+int vtx_write_mtx(vtx_ctx* c, const char* path, uint32_t n_rows, uint32_t n_cols, int which, double* sum) {
+    if (!c) return VTX_E_INVAL;
+    if (!path || (which != 0 && which != 1)) return fail(c, VTX_E_INVAL, "vtx_write_mtx: bad argument");
+    if (!c->ran) return fail(c, VTX_E_STATE, "vtx_write_mtx: no completed vtx_run");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    const uint64_t nnz = c->nnz;
+    const uint32_t* d_row = c->d_o_row.as<uint32_t>();
+    const uint32_t* d_col = c->d_o_col.as<uint32_t>();
+    const double* d_val = which ? c->d_o_refval.as<double>() : c->d_o_val.as<double>();
+    const uint32_t kSlab = 48u << 20;                     // lines per pass: <= 33 bytes each, 32-bit text offsets
+    HIP_TRY(c, c->d_bam_cnt.reserve(VTXG_N_COUNTERS * sizeof(uint64_t) + 4 * sizeof(uint32_t)));
+    double* d_sum = (double*)c->d_bam_cnt.p;
+    uint32_t* d_flag = (uint32_t*)(c->d_bam_cnt.as<unsigned long long>() + VTXG_N_COUNTERS);
+    HIP_TRY(c, hipMemsetAsync(c->d_bam_cnt.p, 0, VTXG_N_COUNTERS * sizeof(uint64_t) + 4 * sizeof(uint32_t), s));
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return fail(c, VTX_E_INVAL, "cannot open %s for writing", path);
+    auto bail = [&](int rc) { close(fd); unlink(path); return rc; };
+    char head[160];
+    const int hl = snprintf(head, sizeof head, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%u %u %llu\n", n_rows, n_cols,
+                            (unsigned long long)nnz);
+    if (pwrite(fd, head, (size_t)hl, 0) != hl) return bail(fail(c, VTX_E_INVAL, "error writing %s", path));
+    uint64_t file_off = (uint64_t)hl;
+    for (uint64_t base = 0; base < nnz; base += kSlab) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(kSlab, nnz - base);
+        if (hipError_t e = c->d_bam_nhit.reserve((size_t)n * sizeof(uint32_t) + 16)) return bail(fail(c, VTX_E_NOMEM, "vtx_write_mtx: %s", hipGetErrorString(e)));
+        if (hipError_t e = c->d_bam_hscan.reserve((size_t)n * sizeof(uint32_t) + 16)) return bail(fail(c, VTX_E_NOMEM, "vtx_write_mtx: %s", hipGetErrorString(e)));
+        if (hipError_t e = c->d_scan_tmp.reserve(vtxk_scan_temp_bytes(n))) return bail(fail(c, VTX_E_NOMEM, "vtx_write_mtx: %s", hipGetErrorString(e)));
+        uint32_t* d_len = c->d_bam_nhit.as<uint32_t>();
+        uint32_t* d_end = c->d_bam_hscan.as<uint32_t>();
+        hipError_t e = vtxg_mtx_len(d_row + base, d_col + base, d_val + base, n, d_len, d_sum, d_flag, s);
+        if (e == hipSuccess) e = vtxk_inclusive_scan_u32(d_len, d_end, n, c->d_scan_tmp.p, vtxk_scan_temp_bytes(n), s);
+        uint32_t total = 0, flag = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, d_end + (n - 1), sizeof total, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return bail(fail(c, VTX_E_HIP, "vtx_write_mtx: %s", hipGetErrorString(e)));
+        if (flag) return bail(fail(c, VTX_E_UNSUPPORTED, "vtx_write_mtx: a value that is not a non-negative integer (alt_frac): format on the host (vtx_fetch_coo + vtxh_write_mtx)"));
+        if ((e = c->d_bam_data.reserve((size_t)total + 64)) != hipSuccess) return bail(fail(c, VTX_E_NOMEM, "vtx_write_mtx: %s", hipGetErrorString(e)));
+        e = vtxg_mtx_text(d_row + base, d_col + base, d_val + base, n, d_end, c->d_bam_data.as<uint8_t>(), s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return bail(fail(c, VTX_E_HIP, "vtx_write_mtx: %s", hipGetErrorString(e)));
+        if (int rc = download_to_fd(c, fd, file_off, c->d_bam_data.p, total)) return bail(rc);
+        file_off += total;
+    }
+    if (sum) {
+        *sum = 0.0;
+        if (nnz) HIP_TRY(c, hipMemcpy(sum, d_sum, sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (close(fd) != 0) { unlink(path); return fail(c, VTX_E_INVAL, "error writing %s", path); }
+    return VTX_OK;
+}
+
 int vtx_device_coo(vtx_ctx* c, vtx_coo* out) {
     if (!c) return VTX_E_INVAL;
     if (!out) return fail(c, VTX_E_INVAL, "vtx_device_coo: null output");
@@ -2125,6 +2245,15 @@ int vtx_comm_init(vtx_ctx* c, const uint8_t id[VTX_COMM_ID_BYTES], int rank, int
     memcpy(u.internal, id, VTX_COMM_ID_BYTES);
     NCCL_TRY(c, rccl()->CommInitRank(&c->comm, world, u, rank));
     c->comm_rank = rank; c->comm_world = world;
+    return VTX_OK;
+}
+
+// How many ranks the communicator itself reports (ncclCommCount): what bench.py's line quotes next to the launcher's world size.
+int vtx_comm_ranks(vtx_ctx* c, int* ranks) {
+    if (!c || !ranks) return VTX_E_INVAL;
+    if (!c->comm) return fail(c, VTX_E_STATE, "vtx_comm_ranks: no communicator (vtx_comm_init)");
+    if (!rccl() || !rccl()->CommCount) return fail(c, VTX_E_UNSUPPORTED, "vtx_comm_ranks: ncclCommCount not available");
+    NCCL_TRY(c, rccl()->CommCount(c->comm, ranks));
     return VTX_OK;
 }
 

@@ -1251,6 +1251,7 @@ __device__ __forceinline__ void build_tables(uint8_t* tables, uint32_t n_tab, ui
         __syncthreads();
 }
 
+#ifdef VTX_DEVTOOLS        // (developer build only: the production library carries one table kernel)
 // Round 3's table kernel, kept as the REFERENCE of band_tables_kernel (further down) under VTX_BAND_TABLES_V1=1: one workgroup
 // (one wavefront) per locus of [l0, l0 + n_loci): both tables in LDS (build_tables), then copied to
 // gtables[(locus - l0) * 2 * table_stride].
@@ -1267,6 +1268,7 @@ __global__ __launch_bounds__(64) void band_tables_v1_kernel(const vtx_locus* __r
         for (uint32_t i = tid; i < 2 * table_stride / 16; i += 64) dst[i] = src[i];
     }
 }
+#endif
 
 template <int NT, bool GT, int WPE, int PSV>
 __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
@@ -2438,11 +2440,14 @@ static uint32_t gt_max_tpl() {
 // (a locus per wavefront, serial chain insertion) — the reference the new one is compared with byte for byte (tests)
 static void launch_band_tables(const vtx_locus* loci, uint32_t gt_l0, uint32_t n_loci, const uint8_t* hap_arena, uint32_t max_hap,
                                size_t tstride, uint32_t n_heads, uint8_t* gtables, hipStream_t s) {
-    if (VTX_DEV_ENV("VTX_BAND_TABLES_V1"))
+#ifdef VTX_DEVTOOLS
+    if (VTX_DEV_ENV("VTX_BAND_TABLES_V1")) {
         hipLaunchKernelGGL(band_tables_v1_kernel, dim3(std::min(n_loci, 256u * 16u)), dim3(64), 2 * tstride, s, loci, gt_l0, n_loci,
                            hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
-    else
-        hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(2u * n_loci, 256u * 32u)), dim3(64), tstride, s, loci, gt_l0, n_loci,
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(2u * n_loci, 256u * 32u)), dim3(64), tstride, s, loci, gt_l0, n_loci,
                            hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
 }
 

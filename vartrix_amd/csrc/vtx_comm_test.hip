@@ -214,10 +214,17 @@ const char* t_error_string(ncclResult_t r) {
 
 }  // namespace
 
-// fills the nine entry points (vtx_api.hip: Rccl) with the test transport; returns a non-null cookie for Rccl::lib
+ncclResult_t t_comm_count(const ncclComm_t comm, int* count) {
+    if (!comm || !count) return ncclInvalidArgument;
+    *count = ((const TestComm*)comm)->world;
+    return ncclSuccess;
+}
+
+// fills the ten entry points (vtx_api.hip: Rccl) with the test transport; returns a non-null cookie for Rccl::lib
 extern "C" void* vtxt_comm_test_table(void** fns) {
     fns[0] = (void*)t_get_unique_id; fns[1] = (void*)t_comm_init_rank; fns[2] = (void*)t_comm_destroy; fns[3] = (void*)t_all_gather;
     fns[4] = (void*)t_send; fns[5] = (void*)t_recv; fns[6] = (void*)t_group; fns[7] = (void*)t_group; fns[8] = (void*)t_error_string;
+    fns[9] = (void*)t_comm_count;
     static int cookie;
     return &cookie;
 }

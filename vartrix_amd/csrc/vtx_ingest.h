@@ -30,5 +30,9 @@ hipError_t vtxg_scan(int emit, const uint8_t* data, const uint64_t* rec_upos, ui
                      uint32_t* n_hit, uint32_t* read_sz, uint32_t* tag_sz, vtxg_recinfo* info, const uint32_t* hit_scan,
                      const uint32_t* read_scan, const uint32_t* tag_scan, vtx_raw_record* raw, uint32_t* raw_locus, uint8_t* tags,
                      uint8_t* reads_packed, unsigned long long* counters, uint32_t* err, hipStream_t s);
+// Matrix-Market lines of n triplets with integral values: byte length per line (0 + flag when a value is not a non-negative integer
+// below 2^32), sum of the values; then the text at the inclusive scan `end` of the lengths
+hipError_t vtxg_mtx_len(const uint32_t* row, const uint32_t* col, const double* val, uint32_t n, uint32_t* len, double* sum, uint32_t* flag, hipStream_t s);
+hipError_t vtxg_mtx_text(const uint32_t* row, const uint32_t* col, const double* val, uint32_t n, const uint32_t* end, uint8_t* text, hipStream_t s);
 }
 #endif

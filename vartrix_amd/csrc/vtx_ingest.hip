@@ -317,6 +317,48 @@ __global__ __launch_bounds__(256) void bam_scan_kernel(const uint8_t* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Matrix-Market text of resident triplets (sprs::io::write_matrix_market, src/main.rs:381-389): "row+1 col+1 value\n" per triplet,
+// Rust `{}` of an f64 that holds a non-negative integer = its decimal digits (consensus 1 / 2 / 3, coverage counts).  Any other
+// value (alt_frac's fractions, NaN) sets the flag: the host formatter (shortest round-trip digits, vtxh_write_mtx) takes over.
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ndigits(uint32_t v) {
+    return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u : v < 10000000u ? 7u
+         : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
+}
+__device__ __forceinline__ uint8_t* put_u32(uint8_t* p, uint32_t v, uint32_t nd) {      // nd = ndigits(v); returns the end
+    for (uint32_t i = nd; i-- > 0;) { p[i] = (uint8_t)('0' + v % 10u); v /= 10u; }
+    return p + nd;
+}
+__global__ __launch_bounds__(256) void mtx_len_kernel(const uint32_t* __restrict__ row, const uint32_t* __restrict__ col,
+                                                      const double* __restrict__ val, uint32_t n, uint32_t* __restrict__ len,
+                                                      double* __restrict__ sum, uint32_t* __restrict__ flag) {
+    __shared__ double s_sum[4];
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    double v = 0.0;
+    if (k < n) {
+        v = val[k];
+        const bool integral = v >= 0.0 && v < 4294967296.0 && v == (double)(uint32_t)v;      // (false for NaN)
+        if (!integral) { atomicOr(flag, 1u); v = 0.0; len[k] = 0; }
+        else len[k] = ndigits(row[k] + 1u) + ndigits(col[k] + 1u) + ndigits((uint32_t)v) + 3u;
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { const double t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]; if (t != 0.0) atomicAdd(sum, t); }
+}
+__global__ __launch_bounds__(256) void mtx_text_kernel(const uint32_t* __restrict__ row, const uint32_t* __restrict__ col,
+                                                       const double* __restrict__ val, uint32_t n, const uint32_t* __restrict__ end,
+                                                       uint8_t* __restrict__ text) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t r = row[k] + 1u, c = col[k] + 1u, v = (uint32_t)val[k];
+    uint8_t* p = text + (k ? end[k - 1] : 0u);
+    p = put_u32(p, r, ndigits(r)); *p++ = ' ';
+    p = put_u32(p, c, ndigits(c)); *p++ = ' ';
+    p = put_u32(p, v, ndigits(v)); *p = '\n';
+}
+
 }  // namespace
 
 extern "C" {
@@ -348,6 +390,17 @@ hipError_t vtxg_scan(int emit, const uint8_t* data, const uint64_t* rec_upos, ui
     else
         hipLaunchKernelGGL(bam_scan_kernel<false>, dim3(wgs), dim3(256), 0, s, data, rec_upos, n_rec, f, iv_start, iv_end, iv_locus, tid_begin,
                            tid_span, n_hit, read_sz, tag_sz, info, hit_scan, read_scan, tag_scan, raw, raw_locus, tags, reads_packed, counters, err);
+    return hipGetLastError();
+}
+
+hipError_t vtxg_mtx_len(const uint32_t* row, const uint32_t* col, const double* val, uint32_t n, uint32_t* len, double* sum, uint32_t* flag, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(mtx_len_kernel, dim3((n + 255) / 256), dim3(256), 0, s, row, col, val, n, len, sum, flag);
+    return hipGetLastError();
+}
+hipError_t vtxg_mtx_text(const uint32_t* row, const uint32_t* col, const double* val, uint32_t n, const uint32_t* end, uint8_t* text, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(mtx_text_kernel, dim3((n + 255) / 256), dim3(256), 0, s, row, col, val, n, end, text);
     return hipGetLastError();
 }
 

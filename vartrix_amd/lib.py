@@ -36,7 +36,7 @@ SYMBOLS = (
     "vtx_status_name", "vtx_abi_sizes", "vtx_set_barcodes", "vtx_submit_raw", "vtx_fetch_records",
     "vtx_comm_id", "vtx_comm_init", "vtx_gather_coo", "vtx_fetch_gathered", "vtx_gather_abort", "vtx_gather_plan",
     "vtx_set_debug", "vtx_fetch_stage", "vtx_debug_bands", "vtx_debug_tables", "vtx_set_read_format",
-    "vtx_submit_bam", "vtx_debug_ingest", "vtx_debug_inflate",
+    "vtx_submit_bam", "vtx_debug_ingest", "vtx_debug_inflate", "vtx_comm_ranks", "vtx_write_mtx",
 )
 
 
@@ -117,6 +117,10 @@ def load(variant=None):
     L.vtx_debug_bands.argtypes = [ctxp, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.vtx_submit_bam.restype = C.c_int
     L.vtx_submit_bam.argtypes = [ctxp, C.POINTER(abi.VtxBamIngest), C.POINTER(abi.VtxIngestStats)]
+    L.vtx_write_mtx.restype = C.c_int
+    L.vtx_write_mtx.argtypes = [ctxp, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
+    L.vtx_comm_ranks.restype = C.c_int
+    L.vtx_comm_ranks.argtypes = [ctxp, C.POINTER(C.c_int)]
     L.vtx_debug_inflate.restype = C.c_int
     L.vtx_debug_inflate.argtypes = [ctxp, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
     L.vtx_debug_ingest.restype = C.c_int
@@ -289,6 +293,18 @@ class Context:
         """Join the RCCL communicator of the sharded run (collective; vtx_comm_init)."""
         assert len(ident) == COMM_ID_BYTES
         self._check(self._L.vtx_comm_init(self._h, C.c_char_p(ident), rank, world))
+
+    def write_mtx(self, path: str, n_rows: int, n_cols: int, which: int = 0) -> float:
+        """The last run's triplets as Matrix-Market text, formatted on the device and streamed into ``path``; returns the sum of the
+        values.  Raises VTX_E_UNSUPPORTED for non-integral values (alt_frac): use fetch_coo + hostlib.write_mtx."""
+        s = C.c_double(0.0)
+        self._check(self._L.vtx_write_mtx(self._h, path.encode(), n_rows, n_cols, which, C.byref(s)))
+        return float(s.value)
+
+    def comm_ranks(self) -> int:
+        n = C.c_int(0)
+        self._check(self._L.vtx_comm_ranks(self._h, C.byref(n)))
+        return int(n.value)
 
     def gather_coo(self, dst: int = 0) -> dict:
         """Collective: every rank's triplets to rank ``dst`` over RCCL (vtx_gather_coo).  Returns the device addresses of
