@@ -8,6 +8,8 @@
 // pool here (it never affected results in the reference either, :279-291).
 // New, optional: --devices N (shard loci over N GPUs), --aligner banded|full (default banded = the
 // reference's banded::Aligner, src/main.rs:899; full = unbanded Smith-Waterman).
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -129,6 +131,7 @@ struct Shard {
     // a run of one batch on one shard writes the matrices straight from the context's arrays (ctx kept until exit)
     bool keep_ctx = false;
     vtx_coo kept{};
+    vtx_ctx* ctx_pre = nullptr;                 // a context created at launch (its vtx_prefetch_file is bringing the BAM's bytes): used instead of vtx_create
     vtx_ctx* ctx_kept = nullptr;                // keep_ctx with defer_fetch: the triplets stay on the device — vtx_write_mtx formats them there
     bool defer_fetch = false;
     std::string err;
@@ -152,10 +155,12 @@ double since(std::chrono::steady_clock::time_point t0) {
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 void run_shard(Shard* s, vtx_config cfg) {
-    vtx_ctx* ctx = nullptr;
+    vtx_ctx* ctx = s->ctx_pre;
     double t0 = now_s();
-    s->rc = vtx_create(&cfg, &ctx);
-    if (s->rc) s->err = vtx_strerror(nullptr);
+    if (!ctx) {
+        s->rc = vtx_create(&cfg, &ctx);
+        if (s->rc) s->err = vtx_strerror(nullptr);
+    }
     if (s->comm_id) {
         // every shard has a context, or none joins the communicator
         if (!s->gate->meet(s->rc == 0)) {
@@ -315,8 +320,41 @@ int main(int argc, char** argv) {
     // the plan of a device-side ingest instead of a pack: with one GPU, unless the host was asked for
     const bool try_device_ingest = val["ingest"] != "host" && ndev == 1 && val["gather"] != "library";
     const bool must_device_ingest = val["ingest"] == "device";
+    vtx_config cfg;
+    vtx_config_default(&cfg);
+    if (val["aligner"] != "banded" && val["aligner"] != "full") {
+        fprintf(stderr, "error: '%s' isn't a valid value for '--aligner <aligner>'\n", val["aligner"].c_str());
+        return 1;
+    }
+    cfg.aligner = val["aligner"] == "banded" ? VTX_ALIGNER_BANDED : VTX_ALIGNER_FULL;
+    cfg.scoring_mode = mode == "consensus" ? VTX_MODE_CONSENSUS : (mode == "alt_frac" ? VTX_MODE_ALT_FRAC : VTX_MODE_COVERAGE);
+    cfg.use_umi = ha.use_umi;
+    cfg.n_barcodes = 0;                                    // (known once the barcode file is read: vtx_set_barcodes fills it in)
+    // ---- device ingest of the whole input at once: the context is created NOW and the BAM's bytes start travelling to the device
+    //      (vtx_prefetch_file) while this thread still reads the VCF, builds the haplotypes and walks the BGZF headers ----
+    bool whole_input_at_once = false;
+    {
+        struct stat st;
+        whole_input_at_once = (val["stream-loci"] == "0" || (val["stream-loci"] == "auto" && stat(val["bam"].c_str(), &st) == 0 && (uint64_t)st.st_size <= (4ull << 30)));
+    }
+    vtx_ctx* early_ctx = nullptr;
+    const uint8_t* early_map = nullptr;
+    std::thread early;
+    if (try_device_ingest && whole_input_at_once)
+        early = std::thread([&, cfg0 = cfg] {
+            if (vtx_create(&cfg0, &early_ctx) != VTX_OK) { early_ctx = nullptr; return; }
+            const int fd = open(val["bam"].c_str(), O_RDONLY);
+            struct stat st;
+            if (fd < 0 || fstat(fd, &st) != 0 || st.st_size <= 0) { if (fd >= 0) close(fd); return; }
+            void* mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            close(fd);
+            if (mp == MAP_FAILED) return;
+            early_map = (const uint8_t*)mp;                // (stays mapped until the process leaves)
+            (void)vtx_prefetch_file(early_ctx, early_map, 0, (uint64_t)st.st_size);      // best effort: vtx_submit_bam uploads itself otherwise
+        });
+    struct EarlyJoin { std::thread& t; ~EarlyJoin() { if (t.joinable()) t.join(); } } early_join{early};
     std::vector<std::thread> warm;
-    for (int d = 0; d < ndev; ++d) warm.emplace_back(warm_device, d);
+    for (int d = (early.joinable() ? 1 : 0); d < ndev; ++d) warm.emplace_back(warm_device, d);
     struct JoinAll { std::vector<std::thread>& v; ~JoinAll() { for (auto& t : v) if (t.joinable()) t.join(); } } join_warm{warm};
     // ---- streaming: the VCF records are taken in ranges of --stream-loci rows.  A producer thread packs range k + 1 (BGZF
     //      inflate, filters, haplotypes: the host-bound 70 % of a run) while this thread drives the device through range k and
@@ -403,15 +441,6 @@ int main(int argc, char** argv) {
 
     // ---- the hot path: every batch of the pack (one unless the reads span > 4 GiB) is sharded over --devices GPUs
     //      (contiguous row ranges by record count); triplets are appended in batch order = row order ----
-    vtx_config cfg;
-    vtx_config_default(&cfg);
-    if (val["aligner"] != "banded" && val["aligner"] != "full") {
-        fprintf(stderr, "error: '%s' isn't a valid value for '--aligner <aligner>'\n", val["aligner"].c_str());
-        return 1;
-    }
-    cfg.aligner = val["aligner"] == "banded" ? VTX_ALIGNER_BANDED : VTX_ALIGNER_FULL;
-    cfg.scoring_mode = mode == "consensus" ? VTX_MODE_CONSENSUS : (mode == "alt_frac" ? VTX_MODE_ALT_FRAC : VTX_MODE_COVERAGE);
-    cfg.use_umi = ha.use_umi;
     cfg.n_barcodes = n_bcs;
     const uint8_t* bc_bytes = nullptr;
     const uint64_t* bc_offsets = nullptr;
@@ -441,6 +470,8 @@ int main(int argc, char** argv) {
         s.ingest = &g; s.bc_bytes = bc_bytes; s.bc_offsets = bc_offsets; s.n_bcs = bc_n; s.raw = true;
         s.keep_ctx = range_idx == 0 && cur.last;
         s.defer_fetch = s.keep_ctx && mode != "alt_frac";
+        if (early.joinable()) early.join();
+        if (early_ctx) { s.ctx_pre = early_ctx; early_ctx = nullptr; }
         const auto t_shard = std::chrono::steady_clock::now();
         LOG_INFO("Plan of range %u: %.3f s (%u loci, %u BGZF blocks, %u record-start seeds from the .bai); ingest on the device", range_idx, cur.secs,
                  g.n_loci, g.n_blocks, g.n_seeds);
@@ -472,6 +503,10 @@ int main(int argc, char** argv) {
             m.num_duplicates += is.num_duplicates; m.num_not_useful += is.num_not_useful; m.num_not_cell_bc += is.num_no_barcode_tag;
             raw_total.num_not_cell_bc += s.stats.num_not_cell_bc; raw_total.num_non_umi += s.stats.num_non_umi; raw_total.kept += s.stats.kept;
         }
+    }
+    if (!vtxh_is_plan(pk) || vtxh_num_batches(pk)) {         // the host packed this range: the early context (and the bytes it prefetched) go
+        if (early.joinable()) early.join();
+        if (early_ctx) { vtx_destroy(early_ctx); early_ctx = nullptr; }
     }
     const bool range_raw = raw && !vtxh_is_plan(pk);             // (a plan that ran has no batches: the loop below is empty)
     if (raw && !vtxh_is_plan(pk)) vtxh_get_barcode_table(pk, &bc_bytes, &bc_offsets, &bc_n);

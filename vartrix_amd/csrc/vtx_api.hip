@@ -129,6 +129,11 @@ struct vtx_ctx {
     // device-side BAM ingest (vtx_submit_bam, vtx_ingest.hip): compressed range, inflated stream, record offsets, per-record counts / scans
     DevBuf d_bam_comp, d_bam_data, d_bam_blocks, d_bam_seeds, d_bam_seed_cnt, d_bam_seed_scan, d_bam_iv, d_bam_cnt, d_bam_rec, d_bam_nhit,
         d_bam_rsz, d_bam_tsz, d_bam_hscan, d_bam_rscan, d_bam_tscan, d_bam_info;
+    // vtx_prefetch_file: bytes [pf_off, pf_off + pf_n) of the BAM on their way into d_bam_comp (a library thread drives the copy workers)
+    std::thread pf_thread;
+    uint64_t pf_off = 0, pf_n = 0;
+    int pf_rc = 0;
+    bool pf_valid = false;
     uint32_t bam_n_rec = 0, bam_n_raw = 0;
     uint64_t bam_utotal = 0, bam_read_bases = 0, bam_tag_bytes = 0;
     uint32_t max_read_len = 0, fast_overflow = 0;
@@ -639,6 +644,7 @@ int vtx_create(const vtx_config* cfg, vtx_ctx** out) {
 
 void vtx_destroy(vtx_ctx* c) {
     if (!c) return;
+    if (c->pf_thread.joinable()) c->pf_thread.join();
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->d_loci, &c->d_records, &c->d_rec_locus, &c->d_hap, &c->d_read, &c->d_work, &c->d_ref,
@@ -844,6 +850,7 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
 int vtx_set_barcodes(vtx_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint32_t n) {
     if (!c) return VTX_E_INVAL;
     if (!offsets || (n && !bytes && offsets[n] > offsets[0])) return fail(c, VTX_E_INVAL, "vtx_set_barcodes: null argument");
+    if (c->cfg.n_barcodes == 0) c->cfg.n_barcodes = n;          // a context created before the list was read (cfg.n_barcodes 0) takes its width from it
     if (n != c->cfg.n_barcodes) return fail(c, VTX_E_INVAL, "vtx_set_barcodes: %u barcodes, cfg.n_barcodes is %u", n, c->cfg.n_barcodes);
     c->bc_ready = false;
     for (uint32_t j = 0; j < n; ++j) {
@@ -1066,6 +1073,24 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     return raw_prepare(c, nl, nr, b->read_bytes, b->tag_bytes, nibbles, max_hap, max_hap_all, true, stats);
 }
 
+// ---- vtx_prefetch_file: the BAM's bytes start travelling before anybody knows which of them matter ----
+int vtx_prefetch_file(vtx_ctx* c, const uint8_t* bytes, uint64_t file_off, uint64_t n) {
+    if (!c) return VTX_E_INVAL;
+    if (n && !bytes) return fail(c, VTX_E_INVAL, "vtx_prefetch_file: null argument");
+    if (c->pf_thread.joinable()) c->pf_thread.join();
+    c->pf_valid = false;
+    if (!n) return VTX_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, c->d_bam_comp.reserve((size_t)n + 64));
+    c->pf_off = file_off; c->pf_n = n; c->pf_rc = VTX_OK; c->pf_valid = true;
+    void* dst = c->d_bam_comp.p;
+    c->pf_thread = std::thread([c, dst, bytes, n] {
+        if (hipSetDevice(c->cfg.device) != hipSuccess) { c->pf_rc = VTX_E_HIP; return; }
+        c->pf_rc = upload(c, {{dst, bytes, (size_t)n}});
+    });
+    return VTX_OK;
+}
+
 // ---- vtx_submit_bam: the ingest itself on the device (vtx_ingest.hip) ----
 int vtx_submit_bam(vtx_ctx* c, const vtx_bam_ingest* g, vtx_ingest_stats* st) {
     if (!c) return VTX_E_INVAL;
@@ -1108,7 +1133,11 @@ int vtx_submit_bam(vtx_ctx* c, const vtx_bam_ingest* g, vtx_ingest_stats* st) {
     hipStream_t s = c->stream;
     const size_t u32 = sizeof(uint32_t), u64 = sizeof(uint64_t);
     const uint32_t ns = g->n_seeds, ni = g->n_intervals, nref = g->n_ref;
-    HIP_TRY(c, c->d_bam_comp.reserve((size_t)(hi - lo) + 64));
+    // bytes a vtx_prefetch_file already brought (or is still bringing) to the device?
+    if (c->pf_thread.joinable()) c->pf_thread.join();
+    const bool prefetched = c->pf_valid && c->pf_rc == VTX_OK && nb && c->pf_off <= lo && hi <= c->pf_off + c->pf_n;
+    if (prefetched) { const uint64_t shift = lo - c->pf_off; for (auto& B : blocks) B.coff += shift; }
+    else { c->pf_valid = false; HIP_TRY(c, c->d_bam_comp.reserve((size_t)(hi - lo) + 64)); }
     HIP_TRY(c, c->d_bam_data.reserve((size_t)utotal + 64));
     HIP_TRY(c, c->d_bam_blocks.reserve((size_t)nb * sizeof(vtxg_block)));
     HIP_TRY(c, c->d_bam_seeds.reserve((size_t)ns * u64));
@@ -1136,7 +1165,7 @@ int vtx_submit_bam(vtx_ctx* c, const vtx_bam_ingest* g, vtx_ingest_stats* st) {
     auto since = [&](std::chrono::steady_clock::time_point t) { return (float)(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count()); };
     HIP_TRY(c, hipMemsetAsync(d_counters, 0, VTXG_N_COUNTERS * u64 + 4 * u32, s));
     HIP_TRY(c, hipMemsetAsync(d_err + 1, 0xff, u32, s));
-    if (int rc = upload(c, {{c->d_bam_comp.p, g->file + lo, (size_t)(hi - lo)},
+    if (int rc = upload(c, {{c->d_bam_comp.p, g->file + lo, prefetched ? (size_t)0 : (size_t)(hi - lo)},
                             {c->d_bam_blocks.p, blocks.data(), (size_t)nb * sizeof(vtxg_block)},
                             {c->d_bam_seeds.p, g->seeds, (size_t)ns * u64},
                             {c->d_bam_iv.p, ivh.data(), ivh.size() * u32},
@@ -1232,6 +1261,8 @@ int vtx_debug_inflate(vtx_ctx* c, const uint8_t* file, uint64_t file_bytes, cons
     if (utotal > out_cap) return fail(c, VTX_E_INVAL, "vtx_debug_inflate: output buffer too small");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
+    if (c->pf_thread.joinable()) c->pf_thread.join();
+    c->pf_valid = false;
     HIP_TRY(c, c->d_bam_comp.reserve((size_t)file_bytes + 64));
     HIP_TRY(c, c->d_bam_data.reserve((size_t)utotal + 64));
     HIP_TRY(c, c->d_bam_blocks.reserve((size_t)n * sizeof(vtxg_block) + 16));

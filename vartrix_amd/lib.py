@@ -36,7 +36,7 @@ SYMBOLS = (
     "vtx_status_name", "vtx_abi_sizes", "vtx_set_barcodes", "vtx_submit_raw", "vtx_fetch_records",
     "vtx_comm_id", "vtx_comm_init", "vtx_gather_coo", "vtx_fetch_gathered", "vtx_gather_abort", "vtx_gather_plan",
     "vtx_set_debug", "vtx_fetch_stage", "vtx_debug_bands", "vtx_debug_tables", "vtx_set_read_format",
-    "vtx_submit_bam", "vtx_debug_ingest", "vtx_debug_inflate", "vtx_comm_ranks", "vtx_write_mtx",
+    "vtx_submit_bam", "vtx_debug_ingest", "vtx_debug_inflate", "vtx_comm_ranks", "vtx_write_mtx", "vtx_prefetch_file",
 )
 
 
@@ -117,6 +117,8 @@ def load(variant=None):
     L.vtx_debug_bands.argtypes = [ctxp, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.vtx_submit_bam.restype = C.c_int
     L.vtx_submit_bam.argtypes = [ctxp, C.POINTER(abi.VtxBamIngest), C.POINTER(abi.VtxIngestStats)]
+    L.vtx_prefetch_file.restype = C.c_int
+    L.vtx_prefetch_file.argtypes = [ctxp, C.c_void_p, C.c_uint64, C.c_uint64]
     L.vtx_write_mtx.restype = C.c_int
     L.vtx_write_mtx.argtypes = [ctxp, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
     L.vtx_comm_ranks.restype = C.c_int
@@ -217,6 +219,10 @@ class Context:
         self.n_records = int(stats.kept)
         self._n_loci = raw.n_loci
         return stats
+
+    def prefetch_file(self, addr: int, file_off: int, n: int):
+        """Start uploading n bytes at host address ``addr`` (= byte file_off of the BAM) for a later submit_bam."""
+        self._check(self._L.vtx_prefetch_file(self._h, addr, file_off, n))
 
     def submit_bam(self, ingest: abi.VtxBamIngest, n_loci: int) -> abi.VtxIngestStats:
         """Device-side ingest of a BAM range (vtx_submit_bam): ``ingest`` comes from ``hostlib.plan_ingest`` (or is built by hand in the
