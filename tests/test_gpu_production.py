@@ -45,3 +45,37 @@ def test_production_library_ignores_every_experiment_knob(tmp_path):
     env.pop("VTX_LIB_VARIANT", None)
     r = subprocess.run([sys.executable, "-c", _CODE], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "production-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_CODE2 = r'''
+import sys, os
+sys.path.insert(0, %r)
+import numpy as np
+from oracle import oracle
+from vartrix_amd import lib, synth
+from vartrix_amd.abi import default_config
+assert lib.lib_path().endswith("libvtx.so")
+spec = synth.SynthSpec(n_loci=15000, n_barcodes=5000, reads_per_locus=256, seed=20260926, genome_fasta=os.path.join(%r, "tests", "golden", "test_dna.fa"))
+batch = synth.make_batch(spec)
+cfg = default_config(aligner="banded", scoring_mode="consensus", n_barcodes=spec.n_barcodes)
+with lib.Context(cfg) as ctx:
+    ctx.submit(batch); ctx.run()
+    ref, alt = ctx.fetch_scores()
+    t = ctx.timing()
+assert t.diag2_tasks >= 700000 and t.swept_tasks > 0 and t.diag2_scored > 0, (t.diag2_tasks, t.swept_tasks, t.diag2_scored)
+oref, oalt = oracle.batch_scores(batch, cfg, threads=os.cpu_count() or 8)
+bad = np.nonzero((ref != oref) | (alt != oalt))[0]
+assert bad.size == 0, (int(bad[0]), int(ref[bad[0]]), int(oref[bad[0]]), int(alt[bad[0]]), int(oalt[bad[0]]))
+print("production-second-stage-ok", int(t.diag2_tasks), int(t.diag2_streamed), int(t.swept_tasks))
+''' % (ROOT, ROOT)
+
+
+def test_production_library_second_stage_on_its_own_threshold():
+    """ADVICE round 5: the second single-diagonal stage (band_diag2_kernel, band_stream_kernel, the full-matrix check, the one-diagonal
+    DP behind it) runs in libvtx.so only on lists above its threshold (700 000 tasks since round 6) — the other GPU tests reach it
+    through libvtx_dev.so with the threshold forced to 1.  Here the PRODUCTION library on 15 000 loci drawn from real sequence
+    (7.3 M alignments, 1 M of them repeat tasks): the stage runs on its own, and every score is the oracle's."""
+    env = dict(os.environ)
+    env.pop("VTX_LIB_VARIANT", None)
+    r = subprocess.run([sys.executable, "-c", _CODE2], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0 and "production-second-stage-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

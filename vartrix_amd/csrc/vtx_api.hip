@@ -1557,12 +1557,14 @@ int vtx_run(vtx_ctx* c) {
         // (full-matrix check, masked DP for what it does not settle; no sweep); what they leave — out[0, *n_out) — takes the sweep.
         // One host round trip for the counts.  (libvtx_dev.so: VTX_BAND_NO_DIAG2=1 sends everything to the sweep, as round 4 did;
         // VTX_BAND_NO_STREAM=1 — what exceeds the second stage's list goes to the sweep.)
-        // A short list skips it: one lane per task, a few hundred dependent loads each — below ~4 k wavefronts the
-        // kernels are a latency chain that the sweep + its DP beat (headline: 48 k tasks, 0.6 ms against 0.35 saved).
+        // A short list skips it: one lane per task, a few hundred dependent loads each — the kernels are latency chains with a fixed
+        // cost of several milliseconds that the sweep + its DP beat below ~0.65 M tasks.  Measured in round 6 on loci from real sequence
+        // (profiles/r06_second_stage_threshold.txt; stage on / off): 33 k tasks 7.9 / 3.4 ms per step, 145 k 12.8 / 8.6, 319 k 28.9 / 19.9,
+        // 638 k 36.8 / 36.0, 1.28 M 52.2 / 64.3 — round 5's threshold of 200 k made mid-size batches a third slower.
         // The tables of the tasks' loci have to be resident (gt_l0: first locus of the table buffer).
         auto second_stage_on = [&](uint32_t n) -> bool {
             static const bool no_diag2 = VTX_DEV_ENV("VTX_BAND_NO_DIAG2") != nullptr;
-            static const uint32_t diag2_min = VTX_DEV_ENV("VTX_BAND_DIAG2_MIN") ? (uint32_t)strtoul(VTX_DEV_ENV("VTX_BAND_DIAG2_MIN"), nullptr, 10) : 200000u;
+            static const uint32_t diag2_min = VTX_DEV_ENV("VTX_BAND_DIAG2_MIN") ? (uint32_t)strtoul(VTX_DEV_ENV("VTX_BAND_DIAG2_MIN"), nullptr, 10) : 700000u;
             return !no_diag2 && n >= diag2_min && c->max_hap_len <= 255;
         };
         auto second_stage = [&](const uint32_t* list, uint32_t n, uint32_t gt_l0, uint32_t* out, uint32_t* n_out) -> int {
