@@ -229,3 +229,49 @@ def test_streamed_ranges_give_the_same_files_and_counters(tmp_path, prep):
         assert n_ranges == {"whole": 1, "ranges": 7, "single": 46}[name]
     assert outs["whole"] == outs["ranges"] == outs["single"]
     assert len(outs["whole"][0]) > 500
+
+
+def test_ingest_auto_falls_back_and_device_insists(tmp_path):
+    """--ingest auto (the default): an input the device path cannot take — here a BAM whose .bai carries no linear index (the record
+    starts the device needs come from it) — is packed on the host, says so, and gives the same bytes; --ingest device refuses it.
+    A BAM with a damaged BGZF block: the device's inflater declines the block, the host packer takes over and zlib rejects it too —
+    the run fails with the packer's message whichever path was asked for."""
+    import shutil
+    from oracle import bamwriter
+    from tests.test_host import make_dna_bam
+    bam = make_dna_bam(tmp_path, seed=6, n_reads=1200)
+    vcfp, fap, bcp = (os.path.join(G, n) for n in ("test_dna.vcf", "test_dna.fa", "dna_barcodes.tsv"))
+    base = ["-v", vcfp, "-f", fap, "-c", bcp, "--log-level", "info", "-s", "coverage"]
+    want = str(tmp_path / "want.mtx")
+    r = run_cli(base + ["-b", bam, "-o", want, "--ref-matrix", str(tmp_path / "want_ref.mtx"), "--ingest", "device"], tmp_path)
+    assert "ingest on the device" in r.stderr
+    # (a) an index without a linear part
+    noidx = str(tmp_path / "noidx.bam")
+    shutil.copy(bam, noidx)
+    open(noidx + ".bai", "wb").write(b"BAI\x01" + (0).to_bytes(4, "little"))
+    out = str(tmp_path / "a.mtx")
+    r = run_cli(base + ["-b", noidx, "-o", out, "--ref-matrix", str(tmp_path / "a_ref.mtx")], tmp_path)
+    assert "packing on the host" in r.stderr and "ingest on the device" not in r.stderr
+    assert open(out).read() == open(want).read() and open(tmp_path / "a_ref.mtx").read() == open(tmp_path / "want_ref.mtx").read()
+    r = subprocess.run([hostlib.CLI_PATH] + base + ["-b", noidx, "-o", str(tmp_path / "b.mtx"), "--ref-matrix", str(tmp_path / "b_ref.mtx"), "--ingest", "device"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and ".bai" in r.stdout + r.stderr and not os.path.exists(tmp_path / "b.mtx")
+    # (b) a damaged block in the middle of the file
+    data = bytearray(open(bam, "rb").read())
+    o, offs = 0, []
+    while o + 18 <= len(data):
+        offs.append(o)
+        o += int.from_bytes(data[o + 16:o + 18], "little") + 1
+    mid = offs[len(offs) // 2]
+    for k in range(40, 60):
+        data[mid + k] ^= 0x5a
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(data))
+    shutil.copy(bam + ".bai", bad + ".bai")
+    for flags in ([], ["--ingest", "host"]):
+        r = subprocess.run([hostlib.CLI_PATH] + base + ["-b", bad, "-o", str(tmp_path / "c.mtx"), "--ref-matrix", str(tmp_path / "c_ref.mtx")] + flags,
+                           cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "does not inflate" in r.stdout + r.stderr, r.stdout + r.stderr
+        assert not os.path.exists(tmp_path / "c.mtx")
+        if not flags:
+            assert "the device declined" in r.stderr

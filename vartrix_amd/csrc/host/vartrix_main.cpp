@@ -352,6 +352,9 @@ int main(int argc, char** argv) {
             early_map = (const uint8_t*)mp;                // (stays mapped until the process leaves)
             (void)vtx_prefetch_file(early_ctx, early_map, 0, (uint64_t)st.st_size);      // best effort: vtx_submit_bam uploads itself otherwise
         });
+    // (an error return from main must not leave the library's prefetch thread copying while the HIP runtime is torn down: the context
+    //  that nobody took over is destroyed — after the early thread has been joined: destructors run in reverse order)
+    struct EarlyCtx { vtx_ctx*& c; ~EarlyCtx() { if (c) { vtx_destroy(c); c = nullptr; } } } early_ctx_guard{early_ctx};
     struct EarlyJoin { std::thread& t; ~EarlyJoin() { if (t.joinable()) t.join(); } } early_join{early};
     std::vector<std::thread> warm;
     for (int d = (early.joinable() ? 1 : 0); d < ndev; ++d) warm.emplace_back(warm_device, d);
@@ -397,7 +400,7 @@ int main(int argc, char** argv) {
                     else pc.rc = vtxh_pack_files_range(&ha, raw ? 1 : 0, begin, end, &pc.pk);
                 }
             } else pc.rc = vtxh_pack_files_range(&ha, raw ? 1 : 0, begin, end, &pc.pk);
-            if (pc.rc && pc.err.empty()) pc.err = vtxh_last_error();
+            if (pc.rc) { if (pc.err.empty()) pc.err = vtxh_last_error(); }
             else n_total = vtxh_num_variants(pc.pk);
             pc.secs = since(t0);
             pc.last = pc.rc != 0 || end >= n_total;

@@ -882,7 +882,8 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
         }
         return buf.size() - buf_pos >= need;
     };
-    if (!refill(12) || memcmp(buf.data() + buf_pos, "BAM\1", 4) != 0) return fail(VTX_E_INVAL, "%s: bad BAM magic", a->bam);
+    if (!refill(12) && refill_failed) return fail(VTX_E_INVAL, "%s: a BGZF block does not inflate (or out of memory)", a->bam);
+    if (buf.size() - buf_pos < 12 || memcmp(buf.data() + buf_pos, "BAM\1", 4) != 0) return fail(VTX_E_INVAL, "%s: bad BAM magic", a->bam);
     uint32_t l_text = rd32(buf.data() + buf_pos + 4);
     if (!refill(12 + (size_t)l_text)) return fail(VTX_E_INVAL, "%s: truncated BAM header", a->bam);
     buf_pos += 8 + l_text;
