@@ -501,7 +501,8 @@ struct Phases {
 struct LocusBuild {
     uint32_t row;
     int64_t start, end;
-    std::string ref_hap, alt_hap;
+    uint64_t ref_off = 0, alt_off = 0;          // into the pack's haplotype arena
+    uint32_t ref_len = 0, alt_len = 0;
     struct Rec { uint32_t cell, umi; uint64_t read_off; uint32_t read_len; };
 };
 
@@ -513,7 +514,7 @@ struct vtxh_pack {
     uint64_t blocks_inflated = 0, blocks_total = 0, index_jumps = 0;      // ingest statistics (vtxh_get_ingest_stats)
     std::vector<vtx_locus> loci;
     RawArr<vtx_record> records;
-    std::string hap_arena;
+    ByteBuf hap_arena;             // REF then ALT haplotype of every locus, in locus order (written by the workers: no zero-fill, no serial append)
     ByteBuf read_arena;            // grown without zero-fill, filled by the sweep's workers
     int read_format = VTX_READS_BYTES;   // VTX_READS_NIBBLES: two bases per byte, offsets / sizes below still count bases
     vtxh_metrics metrics{};
@@ -922,13 +923,20 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
         std::vector<LocusBuild> built(vcf.size());
         std::vector<uint8_t> verdict(vcf.size(), 0);            // 0 locus, 1 multi-allelic, 2 invalid characters, 3 outside this range of rows
         std::vector<int32_t> tid_i(vcf.size(), 0);
+        // every worker appends the haplotypes of ITS records (a contiguous range of the VCF) to a buffer of its own — REF then ALT per
+        // valid locus, the arena's layout — and the buffers are then copied behind each other: the arena's pages are touched by all
+        // workers at once instead of by one thread appending 200 000 strings (the pages, not the bytes, are what this costs)
+        struct HapOut { ByteBuf bytes; };
+        std::vector<HapOut> hout((size_t)threads);
         pool.run([&](size_t t) {
-            std::string left, right;
+            std::string left, right, refh;
+            ByteBuf& out = hout[t].bytes;
             for (size_t i = vcf.size() * t / (size_t)threads, e = vcf.size() * (t + 1) / (size_t)threads; i < e; ++i) {
                 const VcfRec& v = vcf[i];
                 if (i < row_begin || i >= row_end) { verdict[i] = 3; continue; }
                 if (v.alleles.size() > 2) { verdict[i] = 1; continue; }                                // :646-653
-                const std::string alt = v.alleles.size() == 2 ? v.alleles[1] : std::string();          // :656-659
+                static const std::string no_alt;
+                const std::string& alt = v.alleles.size() == 2 ? v.alleles[1] : no_alt;                // :656-659
                 const FaiEntry& fe = fa.seqs[fa.by_name.find(v.chrom)->second];
                 const int64_t start = v.pos, end = v.pos + (int64_t)v.alleles[0].size();
                 const int64_t pad = a->padding;
@@ -939,14 +947,38 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
                 const int64_t re = std::min<int64_t>(end + pad, (int64_t)fe.len);
                 fa.fetch_upper(fe, (uint64_t)ls, (uint64_t)std::min<int64_t>(start, (int64_t)fe.len), left);
                 fa.fetch_upper(fe, (uint64_t)end, (uint64_t)re, right);
-                L.alt_hap = left + alt + right;
                 int64_t rs = (int64_t)((int32_t)start - (int32_t)pad);       // i32 casts, :944
                 if (rs < 0) rs = 0;
-                fa.fetch_upper(fe, (uint64_t)rs, (uint64_t)re, L.ref_hap);
-                for (unsigned char c : L.alt_hap) if (!valid[c]) { verdict[i] = 2; break; }             // :675-684
+                fa.fetch_upper(fe, (uint64_t)rs, (uint64_t)re, refh);
+                bool ok = true;                                                                         // :675-684: the whole ALT haplotype
+                for (unsigned char c : left) ok &= valid[c];
+                for (unsigned char c : alt) ok &= valid[c];
+                for (unsigned char c : right) ok &= valid[c];
+                if (!ok) { verdict[i] = 2; continue; }
                 tid_i[i] = tid_of.find(v.chrom)->second;
+                L.ref_len = (uint32_t)refh.size(); L.alt_len = (uint32_t)(left.size() + alt.size() + right.size());
+                L.ref_off = out.size();                                      // (relative to this worker's buffer until the copy below)
+                unsigned char* d = out.grow(refh.size() + L.alt_len);
+                if (!d) { verdict[i] = 4; continue; }
+                memcpy(d, refh.data(), refh.size()); d += refh.size();
+                L.alt_off = L.ref_off + refh.size();
+                memcpy(d, left.data(), left.size()); d += left.size();
+                memcpy(d, alt.data(), alt.size()); d += alt.size();
+                memcpy(d, right.data(), right.size());
             }
         });
+        for (size_t i = 0; i < vcf.size(); ++i) if (verdict[i] == 4) return fail(VTX_E_NOMEM, "out of memory building the haplotypes");
+        {
+            std::vector<uint64_t> hbase((size_t)threads + 1, 0);
+            for (int t = 0; t < threads; ++t) hbase[(size_t)t + 1] = hbase[(size_t)t] + hout[(size_t)t].bytes.size();
+            if (hbase[(size_t)threads] > 0xffffffffull) return fail(VTX_E_UNSUPPORTED, "haplotype arena above 4 GiB: split the VCF");
+            if (hbase[(size_t)threads] && !P->hap_arena.grow((size_t)hbase[(size_t)threads])) return fail(VTX_E_NOMEM, "out of memory building the haplotypes");
+            pool.run([&](size_t t) {
+                if (hout[t].bytes.size()) memcpy(P->hap_arena.data() + hbase[t], hout[t].bytes.data(), hout[t].bytes.size());
+                for (size_t i = vcf.size() * t / (size_t)threads, e = vcf.size() * (t + 1) / (size_t)threads; i < e; ++i)
+                    if (verdict[i] == 0) { built[i].ref_off += hbase[t]; built[i].alt_off += hbase[t]; }
+            });
+        }
         for (size_t i = 0; i < vcf.size(); ++i) {
             if (verdict[i] == 1) { ++P->metrics.num_multiallelic_recs; continue; }
             if (verdict[i] == 2) { ++P->metrics.num_invalid_recs; continue; }
@@ -998,13 +1030,10 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
             const LocusBuild& L = loci[l];
             vtx_locus o{};
             o.row = L.row;
-            o.ref_off = (uint32_t)P->hap_arena.size(); o.ref_len = (uint32_t)L.ref_hap.size();
-            P->hap_arena += L.ref_hap;
-            o.alt_off = (uint32_t)P->hap_arena.size(); o.alt_len = (uint32_t)L.alt_hap.size();
-            P->hap_arena += L.alt_hap;
+            o.ref_off = (uint32_t)L.ref_off; o.ref_len = L.ref_len;
+            o.alt_off = (uint32_t)L.alt_off; o.alt_len = L.alt_len;
             P->loci.push_back(o);
         }
-        if (P->hap_arena.size() > 0xffffffffull) return fail(VTX_E_UNSUPPORTED, "haplotype arena above 4 GiB: split the VCF");
         P->blocks_total = blocks.size();
         auto done = [&](const char* why) { if (why) P->plan_reason = why; else P->planned = true; P->bam_map = std::move(bam_holder); *out = P.release(); return VTX_OK; };
         P->pl_tid_begin.assign(bam_refs.size() + 1, 0);
@@ -1528,13 +1557,10 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
         const LocusBuild& L = loci[l];
         vtx_locus o{};
         o.row = L.row; o.rec_count = (uint32_t)(l_begin[l + 1] - l_begin[l]);
-        o.ref_off = (uint32_t)P->hap_arena.size(); o.ref_len = (uint32_t)L.ref_hap.size();
-        P->hap_arena += L.ref_hap;
-        o.alt_off = (uint32_t)P->hap_arena.size(); o.alt_len = (uint32_t)L.alt_hap.size();
-        P->hap_arena += L.alt_hap;
+        o.ref_off = (uint32_t)L.ref_off; o.ref_len = L.ref_len;
+        o.alt_off = (uint32_t)L.alt_off; o.alt_len = L.alt_len;
         P->loci.push_back(o);
     }
-    if (P->hap_arena.size() > 0xffffffffull) return fail(VTX_E_UNSUPPORTED, "haplotype arena above 4 GiB: split the VCF");
     std::vector<uint32_t> batch_of(nloc, 0);
     for (size_t b = 0; b < P->batches.size(); ++b)
         for (uint32_t l = P->batches[b].l0; l < P->batches[b].l1; ++l) {
