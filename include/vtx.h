@@ -316,14 +316,16 @@ typedef struct vtx_ingest_stats {
     uint64_t compressed_bytes, inflated_bytes;
     vtx_raw_stats raw;
     float h2d_ms, inflate_ms, index_ms, filter_ms;   /* host wall time of the upload; device time of the inflate, the record chains, the filter passes */
+    float prefetch_ms, prefetch_wait_ms;             /* vtx_prefetch_file: how long its copy took; how long vtx_submit_bam waited for it (0: not used) */
 } vtx_ingest_stats;
 
-/* Optional, before vtx_submit_bam: start moving the file's bytes [file_off, file_off + n) (`bytes` points at the first of them) to
- * the device NOW — while the host still parses the VCF and walks the BGZF headers.  Returns at once; library threads drive the copy.
- * A later vtx_submit_bam whose blocks lie inside the range uses the bytes (it waits for the copy first), any other uploads its own.
- * `bytes` must stay readable until that vtx_submit_bam (or vtx_destroy) returns.  A context may be created for this before the
- * barcode list is known: cfg.n_barcodes = 0 means "taken from the first vtx_set_barcodes".                                       */
-int vtx_prefetch_file(vtx_ctx* ctx, const uint8_t* bytes, uint64_t file_off, uint64_t n);
+/* Optional, before vtx_submit_bam: start moving bytes [file_off, file_off + n) of the file at `path` (n = 0: to its end) to the device
+ * NOW — while the host still parses the VCF and walks the BGZF headers.  Returns at once; library threads copy the file (through a
+ * read-only mapping of their own) into their pinned buffers and push them.  A later
+ * vtx_submit_bam whose blocks lie inside the range uses the bytes (it waits for the copy first), any other uploads its own.  A
+ * context may be created for this before the barcode list is known: cfg.n_barcodes = 0 means "taken from the first
+ * vtx_set_barcodes".                                                                                                              */
+int vtx_prefetch_file(vtx_ctx* ctx, const char* path, uint64_t file_off, uint64_t n);
 int vtx_submit_bam(vtx_ctx* ctx, const vtx_bam_ingest* ingest, vtx_ingest_stats* stats);
 
 /* Test / audit hook: intermediate arrays of the last vtx_submit_bam.  *bytes = the array's size, min(cap, *bytes) bytes go to dst. */

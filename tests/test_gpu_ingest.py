@@ -276,7 +276,7 @@ def test_prefetched_bytes_give_the_same_ingest():
         for pf in (None, (0, f.size), (f.size // 2, f.size - f.size // 2)):
             with lib.Context(default_config(n_barcodes=0 if pf else len(plan.barcodes))) as ctx:
                 if pf:
-                    ctx.prefetch_file(f.ctypes.data + pf[0], pf[0], pf[1])
+                    ctx.prefetch_file(inputs["bam"], pf[0], pf[1])
                 ctx.set_barcodes(plan.barcodes)
                 st = ctx.submit_bam(plan.ingest, plan.n_loci)
                 ctx.run()

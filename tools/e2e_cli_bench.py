@@ -202,6 +202,8 @@ def main():
         texts = []
         runs = [(["--ingest", "device"], "--ingest device (BGZF inflate, record split, filters on the GPU)", args.threads),
                 (["--ingest", "device"], "--ingest device (second run, page cache warm)", args.threads),
+                (["--ingest", "device"], "--ingest device (third run)", args.threads),
+                (["--ingest", "device"], "--ingest device (fourth run)", args.threads),
                 (["--ingest", "host", "--prep", "device"], "--ingest host --prep device", args.threads),
                 (["--ingest", "host", "--prep", "host"], "--ingest host --prep host", args.threads)]
         for th in args.more_threads:

@@ -200,7 +200,7 @@ class VtxBamIngest(C.Structure):
 class VtxIngestStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("num_reads", "num_low_mapq", "num_non_primary", "num_duplicates", "num_not_useful",
                                           "num_no_barcode_tag", "bam_records", "raw_records", "compressed_bytes", "inflated_bytes")] + \
-               [("raw", VtxRawStats)] + [(n, C.c_float) for n in ("h2d_ms", "inflate_ms", "index_ms", "filter_ms")]
+               [("raw", VtxRawStats)] + [(n, C.c_float) for n in ("h2d_ms", "inflate_ms", "index_ms", "filter_ms", "prefetch_ms", "prefetch_wait_ms")]
 
 
 def pack_nibbles(arena: np.ndarray) -> np.ndarray:

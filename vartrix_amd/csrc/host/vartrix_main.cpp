@@ -338,19 +338,11 @@ int main(int argc, char** argv) {
         whole_input_at_once = (val["stream-loci"] == "0" || (val["stream-loci"] == "auto" && stat(val["bam"].c_str(), &st) == 0 && (uint64_t)st.st_size <= (4ull << 30)));
     }
     vtx_ctx* early_ctx = nullptr;
-    const uint8_t* early_map = nullptr;
     std::thread early;
     if (try_device_ingest && whole_input_at_once)
         early = std::thread([&, cfg0 = cfg] {
             if (vtx_create(&cfg0, &early_ctx) != VTX_OK) { early_ctx = nullptr; return; }
-            const int fd = open(val["bam"].c_str(), O_RDONLY);
-            struct stat st;
-            if (fd < 0 || fstat(fd, &st) != 0 || st.st_size <= 0) { if (fd >= 0) close(fd); return; }
-            void* mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-            close(fd);
-            if (mp == MAP_FAILED) return;
-            early_map = (const uint8_t*)mp;                // (stays mapped until the process leaves)
-            (void)vtx_prefetch_file(early_ctx, early_map, 0, (uint64_t)st.st_size);      // best effort: vtx_submit_bam uploads itself otherwise
+            (void)vtx_prefetch_file(early_ctx, val["bam"].c_str(), 0, 0);      // best effort: vtx_submit_bam uploads itself otherwise
         });
     // (an error return from main must not leave the library's prefetch thread copying while the HIP runtime is torn down: the context
     //  that nobody took over is destroyed — after the early thread has been joined: destructors run in reverse order)
@@ -491,9 +483,9 @@ int main(int argc, char** argv) {
             if (s.rc) { printf("Vartrix error.\nError: %s: %s\n", vtx_status_name(s.rc), s.err.c_str()); return 1; }
             t_device += since(t_shard);
             const vtx_ingest_stats& is = s.istats;
-            LOG_INFO("  device ingest: %llu BAM records, %llu (read, locus) pairs; upload %.1f ms (%.1f MB compressed), inflate %.1f ms (%.1f MB), record index %.1f ms, filters %.1f ms",
-                     (unsigned long long)is.bam_records, (unsigned long long)is.raw_records, (double)is.h2d_ms, is.compressed_bytes / 1e6, (double)is.inflate_ms,
-                     is.inflated_bytes / 1e6, (double)is.index_ms, (double)is.filter_ms);
+            LOG_INFO("  device ingest: %llu BAM records, %llu (read, locus) pairs; upload %.1f ms (%.1f MB compressed; prefetch %.1f ms, waited %.1f ms for it), inflate %.1f ms (%.1f MB), record index %.1f ms, filters %.1f ms",
+                     (unsigned long long)is.bam_records, (unsigned long long)is.raw_records, (double)is.h2d_ms, is.compressed_bytes / 1e6, (double)is.prefetch_ms,
+                     (double)is.prefetch_wait_ms, (double)is.inflate_ms, is.inflated_bytes / 1e6, (double)is.index_ms, (double)is.filter_ms);
             LOG_INFO("  shard: create %.3f s, submit (upload + ingest + device preparation) %.3f s, run %.3f s, fetch %.3f s", s.t_create, s.t_submit, s.t_run, s.t_fetch);
             LOG_INFO("  device preparation: %llu reads kept, %.3f ms, %u hash round(s)", (unsigned long long)s.stats.kept, (double)s.stats.prep_ms, s.stats.hash_rounds);
             if (s.keep_ctx && s.ctx_kept && s.defer_fetch) kept_ctx = s.ctx_kept;

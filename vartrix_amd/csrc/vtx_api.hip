@@ -8,6 +8,8 @@
 #include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed on first use (vtx_comm_*)
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -18,6 +20,7 @@
 #include <cstring>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <new>
 #include <string>
 #include <thread>
@@ -133,6 +136,9 @@ struct vtx_ctx {
     std::thread pf_thread;
     uint64_t pf_off = 0, pf_n = 0;
     int pf_rc = 0;
+    void* pf_map = nullptr;           // the mapping the prefetch reads from (unmapped by the next prefetch / vtx_destroy)
+    size_t pf_map_bytes = 0;
+    float pf_ms = 0;                  // how long the prefetch's copy took
     bool pf_valid = false;
     uint32_t bam_n_rec = 0, bam_n_raw = 0;
     uint64_t bam_utotal = 0, bam_read_bases = 0, bam_tag_bytes = 0;
@@ -645,6 +651,7 @@ int vtx_create(const vtx_config* cfg, vtx_ctx** out) {
 void vtx_destroy(vtx_ctx* c) {
     if (!c) return;
     if (c->pf_thread.joinable()) c->pf_thread.join();
+    if (c->pf_map) { munmap(c->pf_map, c->pf_map_bytes); c->pf_map = nullptr; }
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->d_loci, &c->d_records, &c->d_rec_locus, &c->d_hap, &c->d_read, &c->d_work, &c->d_ref,
@@ -1074,19 +1081,34 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
 }
 
 // ---- vtx_prefetch_file: the BAM's bytes start travelling before anybody knows which of them matter ----
-int vtx_prefetch_file(vtx_ctx* c, const uint8_t* bytes, uint64_t file_off, uint64_t n) {
+int vtx_prefetch_file(vtx_ctx* c, const char* path, uint64_t file_off, uint64_t n) {
     if (!c) return VTX_E_INVAL;
-    if (n && !bytes) return fail(c, VTX_E_INVAL, "vtx_prefetch_file: null argument");
+    if (!path) return fail(c, VTX_E_INVAL, "vtx_prefetch_file: null argument");
     if (c->pf_thread.joinable()) c->pf_thread.join();
     c->pf_valid = false;
-    if (!n) return VTX_OK;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    HIP_TRY(c, c->d_bam_comp.reserve((size_t)n + 64));
+    if (c->pf_map) { munmap(c->pf_map, c->pf_map_bytes); c->pf_map = nullptr; }
+    const int fd = open(path, O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) { if (fd >= 0) close(fd); return fail(c, VTX_E_INVAL, "vtx_prefetch_file: cannot open %s", path); }
+    if (file_off > (uint64_t)st.st_size) file_off = (uint64_t)st.st_size;
+    if (n == 0 || file_off + n > (uint64_t)st.st_size) n = (uint64_t)st.st_size - file_off;
+    if (!n) { close(fd); return VTX_OK; }
+    if (hipSetDevice(c->cfg.device) != hipSuccess || c->d_bam_comp.reserve((size_t)n + 64) != hipSuccess) { close(fd); return fail(c, VTX_E_NOMEM, "vtx_prefetch_file: no device memory for %llu bytes", (unsigned long long)n); }
+    // the copy workers read the file through a mapping of their own (measured against pread() into the pinned buffers at config-3 scale:
+    // the same 80 - 200 ms beside the host's planning threads, and the mapping showed no multi-second outliers)
+    const uint64_t map_off = file_off & ~(uint64_t)4095;
+    void* mp = mmap(nullptr, (size_t)(file_off - map_off + n), PROT_READ, MAP_PRIVATE, fd, (off_t)map_off);
+    close(fd);
+    if (mp == MAP_FAILED) return fail(c, VTX_E_INVAL, "vtx_prefetch_file: cannot map %s", path);
+    c->pf_map = mp; c->pf_map_bytes = (size_t)(file_off - map_off + n);
     c->pf_off = file_off; c->pf_n = n; c->pf_rc = VTX_OK; c->pf_valid = true;
     void* dst = c->d_bam_comp.p;
-    c->pf_thread = std::thread([c, dst, bytes, n] {
+    const uint8_t* src = (const uint8_t*)mp + (file_off - map_off);
+    c->pf_thread = std::thread([c, dst, src, n] {
         if (hipSetDevice(c->cfg.device) != hipSuccess) { c->pf_rc = VTX_E_HIP; return; }
-        c->pf_rc = upload(c, {{dst, bytes, (size_t)n}});
+        const auto t0 = std::chrono::steady_clock::now();
+        c->pf_rc = upload(c, {{dst, src, (size_t)n}});
+        c->pf_ms = (float)(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     });
     return VTX_OK;
 }
@@ -1134,7 +1156,12 @@ int vtx_submit_bam(vtx_ctx* c, const vtx_bam_ingest* g, vtx_ingest_stats* st) {
     const size_t u32 = sizeof(uint32_t), u64 = sizeof(uint64_t);
     const uint32_t ns = g->n_seeds, ni = g->n_intervals, nref = g->n_ref;
     // bytes a vtx_prefetch_file already brought (or is still bringing) to the device?
+    // (Tried in round 6: inflating the blocks of a 128 MB segment as soon as it has landed, on streams of their own.  Every launch of
+    //  the latency-bound inflate kernel takes its full ~35 ms whatever the block count, and the copies still in flight queued behind
+    //  the kernels: inflate 94 -> 250 ms, the copy 0.09 -> 1.4 s.  The copy is waited for as a whole.)
+    const auto t_pf = std::chrono::steady_clock::now();
     if (c->pf_thread.joinable()) c->pf_thread.join();
+    const float pf_wait_ms = (float)(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pf).count());
     const bool prefetched = c->pf_valid && c->pf_rc == VTX_OK && nb && c->pf_off <= lo && hi <= c->pf_off + c->pf_n;
     if (prefetched) { const uint64_t shift = lo - c->pf_off; for (auto& B : blocks) B.coff += shift; }
     else { c->pf_valid = false; HIP_TRY(c, c->d_bam_comp.reserve((size_t)(hi - lo) + 64)); }
@@ -1175,7 +1202,7 @@ int vtx_submit_bam(vtx_ctx* c, const vtx_bam_ingest* g, vtx_ingest_stats* st) {
     const float h2d_ms = since(t0);
     // ---- inflate, record boundaries ----
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    HIP_TRY(c, vtxg_inflate(c->d_bam_comp.as<uint8_t>(), c->d_bam_blocks.as<vtxg_block>(), nb, c->d_bam_data.as<uint8_t>(), d_err, nullptr, s));
+    HIP_TRY(c, vtxg_inflate(c->d_bam_comp.as<uint8_t>(), c->d_bam_blocks.as<vtxg_block>(), nb, c->d_bam_data.as<uint8_t>(), d_err, nullptr, 0, s));
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     uint32_t n_rec = 0;
     if (ns) {
@@ -1242,6 +1269,7 @@ int vtx_submit_bam(vtx_ctx* c, const vtx_bam_ingest* g, vtx_ingest_stats* st) {
         st->num_not_useful = cnt[4]; st->num_no_barcode_tag = cnt[5];
         st->bam_records = n_rec; st->raw_records = nr; st->inflated_bytes = utotal; st->compressed_bytes = hi - lo;
         st->raw = rs; st->h2d_ms = h2d_ms; st->inflate_ms = inflate_ms; st->index_ms = index_ms; st->filter_ms = filter_ms;
+        st->prefetch_ms = prefetched ? c->pf_ms : 0.f; st->prefetch_wait_ms = prefetched ? pf_wait_ms : 0.f;
     }
     return VTX_OK;
 }
@@ -1273,7 +1301,7 @@ int vtx_debug_inflate(vtx_ctx* c, const uint8_t* file, uint64_t file_bytes, cons
     HIP_TRY(c, hipMemsetAsync(c->d_bam_data.p, 0xEE, (size_t)utotal + 64, s));
     if (file_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_bam_comp.p, file, (size_t)file_bytes, hipMemcpyHostToDevice, s));
     if (n) HIP_TRY(c, hipMemcpyAsync(c->d_bam_blocks.p, blocks.data(), (size_t)n * sizeof(vtxg_block), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, vtxg_inflate(c->d_bam_comp.as<uint8_t>(), c->d_bam_blocks.as<vtxg_block>(), n, c->d_bam_data.as<uint8_t>(), d_err, c->d_bam_seed_cnt.as<uint32_t>(), s));
+    HIP_TRY(c, vtxg_inflate(c->d_bam_comp.as<uint8_t>(), c->d_bam_blocks.as<vtxg_block>(), n, c->d_bam_data.as<uint8_t>(), d_err, c->d_bam_seed_cnt.as<uint32_t>(), 0, s));
     if (n) HIP_TRY(c, hipMemcpyAsync(status, c->d_bam_seed_cnt.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (utotal && out) HIP_TRY(c, hipMemcpyAsync(out, c->d_bam_data.p, (size_t)utotal, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));

@@ -22,7 +22,7 @@ struct vtxg_recinfo { uint32_t bc_rel, umi_rel, lens; };
 #define VTXG_ERR_RECORD (1u << 17)     // a record whose fields run past its block_size
 
 extern "C" {
-hipError_t vtxg_inflate(const uint8_t* comp, const vtxg_block* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* err, uint32_t* status, hipStream_t s);
+hipError_t vtxg_inflate(const uint8_t* comp, const vtxg_block* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* err, uint32_t* status, uint32_t b_base, hipStream_t s);
 hipError_t vtxg_chain(const uint8_t* data, uint64_t total, const uint64_t* seeds, uint32_t n_seeds, uint64_t end_upos, uint32_t* cnt,
                       const uint32_t* off, uint64_t* rec_upos, uint32_t* err, hipStream_t s);
 hipError_t vtxg_scan(int emit, const uint8_t* data, const uint64_t* rec_upos, uint32_t n_rec, vtxg_filter f, const int32_t* iv_start,

@@ -34,14 +34,14 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const vtxg_block* __restrict__ blocks,
                                                           uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ err,
-                                                          uint32_t* __restrict__ status) {
+                                                          uint32_t* __restrict__ status, uint32_t b_base) {
     __shared__ uint16_t scratch[vtxi::WORDS * 64];
     const vtxi::Scratch sc{scratch + threadIdx.x, 64};
     for (uint32_t b = blockIdx.x * 64 + threadIdx.x; b < n_blocks; b += gridDim.x * 64) {
         const vtxg_block B = blocks[b];
         uint32_t st = vtxi::ST_OK;
         if (B.isize) st = vtxi::inflate_block(comp + B.coff, B.clen, out + B.uoff, B.isize, sc, nullptr);
-        if (st != vtxi::ST_OK) { atomicMin(&err[1], b); atomicOr(&err[0], 1u << st); }
+        if (st != vtxi::ST_OK) { atomicMin(&err[1], b_base + b); atomicOr(&err[0], 1u << st); }     // (b_base: the launch covers blocks [b_base, b_base + n_blocks) of the ingest)
         if (status) status[b] = st;                         // (vtx_debug_inflate: the verdict per block)
     }
 }
@@ -363,10 +363,10 @@ __global__ __launch_bounds__(256) void mtx_text_kernel(const uint32_t* __restric
 
 extern "C" {
 
-hipError_t vtxg_inflate(const uint8_t* comp, const vtxg_block* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* err, uint32_t* status, hipStream_t s) {
+hipError_t vtxg_inflate(const uint8_t* comp, const vtxg_block* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* err, uint32_t* status, uint32_t b_base, hipStream_t s) {
     if (!n_blocks) return hipSuccess;
     const uint32_t wgs = std::min<uint32_t>((n_blocks + 63) / 64, 256u * 3u);
-    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(wgs), dim3(64), 0, s, comp, blocks, n_blocks, out, err, status);
+    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(wgs), dim3(64), 0, s, comp, blocks, n_blocks, out, err, status, b_base);
     return hipGetLastError();
 }
 

@@ -118,7 +118,7 @@ def load(variant=None):
     L.vtx_submit_bam.restype = C.c_int
     L.vtx_submit_bam.argtypes = [ctxp, C.POINTER(abi.VtxBamIngest), C.POINTER(abi.VtxIngestStats)]
     L.vtx_prefetch_file.restype = C.c_int
-    L.vtx_prefetch_file.argtypes = [ctxp, C.c_void_p, C.c_uint64, C.c_uint64]
+    L.vtx_prefetch_file.argtypes = [ctxp, C.c_char_p, C.c_uint64, C.c_uint64]
     L.vtx_write_mtx.restype = C.c_int
     L.vtx_write_mtx.argtypes = [ctxp, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
     L.vtx_comm_ranks.restype = C.c_int
@@ -220,9 +220,9 @@ class Context:
         self._n_loci = raw.n_loci
         return stats
 
-    def prefetch_file(self, addr: int, file_off: int, n: int):
-        """Start uploading n bytes at host address ``addr`` (= byte file_off of the BAM) for a later submit_bam."""
-        self._check(self._L.vtx_prefetch_file(self._h, addr, file_off, n))
+    def prefetch_file(self, path: str, file_off: int = 0, n: int = 0):
+        """Start uploading bytes [file_off, file_off + n) of the file (n = 0: to its end) for a later submit_bam."""
+        self._check(self._L.vtx_prefetch_file(self._h, path.encode(), file_off, n))
 
     def submit_bam(self, ingest: abi.VtxBamIngest, n_loci: int) -> abi.VtxIngestStats:
         """Device-side ingest of a BAM range (vtx_submit_bam): ``ingest`` comes from ``hostlib.plan_ingest`` (or is built by hand in the
