@@ -14,8 +14,10 @@ uint32_t vtxt_inflate(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t
     std::vector<uint8_t> padded((size_t)in_len + 16, 0xa5);
     if (in_len) memcpy(padded.data(), in, in_len);
     if (stride < 1) stride = 1;
-    std::vector<uint16_t> scratch((size_t)vtxi::WORDS * stride, 0xdead);
-    const vtxi::Scratch sc{scratch.data(), stride};
+    std::vector<uint8_t> sb((size_t)vtxi::BYTES * stride, 0xde);
+    std::vector<uint32_t> sh((size_t)vtxi::HI_WORDS * stride, 0xdeadbeefu);
+    std::vector<uint16_t> scn((size_t)vtxi::CNT_WORDS * stride, 0xdead);
+    const vtxi::Scratch sc{sb.data(), sh.data(), scn.data(), stride};
     return vtxi::inflate_block(padded.data(), in_len, out, out_len, sc, trips);
 }
 

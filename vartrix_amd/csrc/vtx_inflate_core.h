@@ -10,7 +10,8 @@
 // Huffman decoding without lookup tables (there is no room for 64 lanes' tables in LDS): the canonical code of a table lives in 15
 // registers, word j = (left-justified first code of length j + 1) << 16 | (index of that length's first symbol) << 4 | (j + 1).  The
 // words ascend, so "the last word <= the next 15 input bits (bit-reversed, left-justified)" is a chain of 14 compare + select pairs;
-// the symbol is one 16-bit read of the lane's symbol list sorted by (length, symbol) — 288 + 32 entries in LDS, 712 bytes per lane.
+// the symbol is one byte read (plus a bit for the ninth bit of a literal / length symbol) of the lane's symbol list sorted by
+// (length, symbol) — 288 + 32 entries in LDS, 444 bytes per lane with the counters.
 // The code lengths of a dynamic block are decoded TWICE (count per length, then place the symbols) instead of being stored.
 //
 // Strictness: what zlib would reject is rejected (over-subscribed or incomplete codes except the one-code distance table of RFC 1951
@@ -36,18 +37,24 @@
 
 namespace vtxi {
 
-// per-lane scratch of 16-bit words at a stride (LDS: word i of lane l at [i * 64 + l])
+// Per-lane scratch at a stride (LDS: element i of lane l at [i * 64 + l]): the symbol lists as BYTES — a literal / length symbol's
+// ninth bit in a bit array beside them — and 16-bit counters.  444 bytes per lane (round 6, first cut: 744 as 16-bit words): 28.4 KB per
+// wavefront, FIVE wavefronts per CU instead of three — the kernel is a latency chain per block, the lanes in flight are its throughput.
 struct Scratch {
-    uint16_t* p;
+    uint8_t* b;        // [0, 288) literal / length symbols sorted by (code length, symbol), low byte; [288, 320) distance symbols; [320, 340) code-length symbols
+    uint32_t* hi;      // 9 words: bit i = bit 8 of literal / length symbol i
+    uint16_t* c;       // 32: per-length counters / cursors while a table is built (16 literal / length or code-length, 16 distance)
     int stride;
-    VTXI_MEM uint16_t& at(int i) const { return p[i * stride]; }
+    VTXI_MEM uint32_t ll(uint32_t i) const { return (uint32_t)b[i * stride] | (((hi[(i >> 5) * stride] >> (i & 31u)) & 1u) << 8); }
+    VTXI_MEM void set_ll(uint32_t i, uint32_t v) const { b[i * stride] = (uint8_t)v; if (v >> 8) hi[(i >> 5) * stride] |= 1u << (i & 31u); }
+    VTXI_MEM void clear_hi() const { for (int w = 0; w < 9; ++w) hi[w * stride] = 0; }
+    VTXI_MEM uint8_t& d(uint32_t i) const { return b[(288 + i) * stride]; }
+    VTXI_MEM uint8_t& cl(uint32_t i) const { return b[(320 + i) * stride]; }
+    VTXI_MEM uint16_t& at(int i) const { return c[i * stride]; }      // counters: CUR + l, CUR_D + l
 };
-constexpr int SYM_LL = 0;      // 288: literal / length symbols sorted by (code length, symbol)
-constexpr int SYM_D = 288;     // 32: distance symbols, likewise
-constexpr int SYM_CL = 320;    // 20: code-length symbols, likewise
-constexpr int CUR = 340;       // 16: per-length counters / cursors while a table is built (code-length code, literal / length table)
-constexpr int CUR_D = 356;     // 16: the same for the distance table (both tables of a dynamic block are counted in one pass)
-constexpr int WORDS = 372;
+constexpr int CUR = 0;         // 16: per-length counters / cursors (code-length code, literal / length table)
+constexpr int CUR_D = 16;      // 16: the same for the distance table (both tables of a dynamic block are counted in one pass)
+constexpr int BYTES = 344, HI_WORDS = 9, CNT_WORDS = 32;           // per lane: 344 + 36 + 64 = 444 bytes
 
 enum Status : uint32_t { ST_OK = 0, ST_BAD_TYPE = 1, ST_BAD_STORED = 2, ST_BAD_CODE = 3, ST_BAD_SYMBOL = 4, ST_BAD_DIST = 5,
                          ST_OVERRUN = 6, ST_SHORT = 7, ST_INPUT = 8 };
@@ -137,7 +144,7 @@ VTXI_FN uint32_t dist_base_extra(uint32_t s) {           // 0..29
     return (1 + ((2 + (s & 1)) << e)) | (e << 16);
 }
 
-// Inflates in[0 .. in_len) into out[0 .. out_len); returns a Status.  sc: WORDS words of scratch private to this lane.
+// Inflates in[0 .. in_len) into out[0 .. out_len); returns a Status.  sc: scratch private to this lane.
 // trips (optional statistics): state-machine trips taken.
 VTXI_FN uint32_t inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, const Scratch& sc, uint32_t* trips) {
     Bits b{in, 0u, 0u, 0ull};
@@ -174,7 +181,7 @@ VTXI_FN uint32_t inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out,
             if (idx >= ll.n) { err = ST_BAD_CODE; st = S_DONE; }
             else {
                 b.drop(len);
-                const uint32_t sym = sc.at(SYM_LL + (int)idx);
+                const uint32_t sym = sc.ll(idx);
                 if (sym < 256) {
                     if (op >= out_len) { err = ST_OVERRUN; st = S_DONE; }
                     else out[op++] = (uint8_t)sym;
@@ -191,7 +198,7 @@ VTXI_FN uint32_t inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out,
                     if (didx >= dc.n) { err = ST_BAD_CODE; st = S_DONE; }
                     else {
                         b.drop(dlen);
-                        const uint32_t dsym = sc.at(SYM_D + (int)didx);
+                        const uint32_t dsym = sc.d(didx);
                         if (dsym > 29) { err = ST_BAD_SYMBOL; st = S_DONE; }
                         else {
                             const uint32_t db = dist_base_extra(dsym);
@@ -241,14 +248,15 @@ VTXI_FN uint32_t inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out,
                 for (int l = 1; l <= 15; ++l) sc.at(CUR + l) = 0;
                 sc.at(CUR + 7) = 24; sc.at(CUR + 8) = 152; sc.at(CUR + 9) = 112;
                 (void)make_code(ll, sc, CUR, 15);
-                for (int i = 0; i < 24; ++i) sc.at(SYM_LL + i) = (uint16_t)(256 + i);
-                for (int i = 0; i < 144; ++i) sc.at(SYM_LL + 24 + i) = (uint16_t)i;
-                for (int i = 0; i < 8; ++i) sc.at(SYM_LL + 168 + i) = (uint16_t)(280 + i);
-                for (int i = 0; i < 112; ++i) sc.at(SYM_LL + 176 + i) = (uint16_t)(144 + i);
+                sc.clear_hi();
+                for (uint32_t i = 0; i < 24; ++i) sc.set_ll(i, 256 + i);
+                for (uint32_t i = 0; i < 144; ++i) sc.set_ll(24 + i, i);
+                for (uint32_t i = 0; i < 8; ++i) sc.set_ll(168 + i, 280 + i);
+                for (uint32_t i = 0; i < 112; ++i) sc.set_ll(176 + i, 144 + i);
                 for (int l = 1; l <= 15; ++l) sc.at(CUR + l) = 0;
                 sc.at(CUR + 5) = 32;
                 (void)make_code(dc, sc, CUR, 15);
-                for (int i = 0; i < 32; ++i) sc.at(SYM_D + i) = (uint16_t)i;
+                for (uint32_t i = 0; i < 32; ++i) sc.d(i) = (uint8_t)i;
                 st = S_SYM;
             } else {
                 b.refill();
@@ -273,7 +281,7 @@ VTXI_FN uint32_t inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out,
                     else {
                         for (int s = 0; s < 19; ++s) {
                             const int l = (int)((cl >> (3 * s)) & 7u);
-                            if (l) { const int k = sc.at(CUR + l); sc.at(CUR + l) = (uint16_t)(k + 1); sc.at(SYM_CL + k) = (uint16_t)s; }
+                            if (l) { const int k = sc.at(CUR + l); sc.at(CUR + l) = (uint16_t)(k + 1); sc.cl((uint32_t)k) = (uint8_t)s; }
                         }
                         // pass 0: count the lengths of both tables; pass 1 (the same bits again): place the symbols at their cursors
                         const Bits mark = b;
@@ -283,6 +291,7 @@ VTXI_FN uint32_t inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out,
                         for (int l = 0; l <= 15; ++l) { sc.at(CUR + l) = 0; sc.at(CUR_D + l) = 0; }
                         for (int pass = 0; pass < 2 && !bad; ++pass) {
                             b = mark;
+                            if (pass == 1) sc.clear_hi();
                             uint32_t k = 0, pv = 0;
                             while (k < total) {
                                 b.refill();
@@ -290,7 +299,7 @@ VTXI_FN uint32_t inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out,
                                 decode(cc, b.peek15(), ci, cn);
                                 if (ci >= cc.n) { bad = true; break; }
                                 b.drop(cn);
-                                const uint32_t cs = sc.at(SYM_CL + (int)ci);
+                                const uint32_t cs = sc.cl(ci);
                                 uint32_t rep = 1, val = cs;
                                 if (cs == 16) { if (k == 0) { bad = true; break; } val = pv; rep = 3 + b.take(2); }
                                 else if (cs == 17) { val = 0; rep = 3 + b.take(3); }
@@ -305,7 +314,8 @@ VTXI_FN uint32_t inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out,
                                         if (pass == 0) {
                                             if (sy == 256) has_eob = true;
                                             if (sy >= nll) { ++d_used; d_one_len = val; }
-                                        } else sc.at((sy < nll ? SYM_LL : SYM_D) + slot) = (uint16_t)(sy < nll ? sy : sy - nll);
+                                        } else if (sy < nll) sc.set_ll((uint32_t)slot, sy);
+                                        else sc.d((uint32_t)slot) = (uint8_t)(sy - nll);
                                     }
                                 }
                                 k += rep;

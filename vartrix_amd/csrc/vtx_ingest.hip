@@ -29,14 +29,16 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// BGZF inflate: one lane per block.  LDS: WORDS 16-bit words per lane, lane-interleaved (47.6 KB per wavefront: three per CU =
-// 49 152 lanes resident on 256 CUs — a 0.9 GB BAM has ~45 000 blocks: one pass).
+// BGZF inflate: one lane per block.  LDS: 444 bytes per lane, lane-interleaved (28.4 KB per wavefront: five per CU = 81 920 lanes
+// resident on 256 CUs; the first cut kept 16-bit symbols: 47.6 KB, three per CU).
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const vtxg_block* __restrict__ blocks,
                                                           uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ err,
                                                           uint32_t* __restrict__ status, uint32_t b_base) {
-    __shared__ uint16_t scratch[vtxi::WORDS * 64];
-    const vtxi::Scratch sc{scratch + threadIdx.x, 64};
+    __shared__ uint8_t s_bytes[vtxi::BYTES * 64];
+    __shared__ uint32_t s_hi[vtxi::HI_WORDS * 64];
+    __shared__ uint16_t s_cnt[vtxi::CNT_WORDS * 64];
+    const vtxi::Scratch sc{s_bytes + threadIdx.x, s_hi + threadIdx.x, s_cnt + threadIdx.x, 64};
     for (uint32_t b = blockIdx.x * 64 + threadIdx.x; b < n_blocks; b += gridDim.x * 64) {
         const vtxg_block B = blocks[b];
         uint32_t st = vtxi::ST_OK;
@@ -365,7 +367,7 @@ extern "C" {
 
 hipError_t vtxg_inflate(const uint8_t* comp, const vtxg_block* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* err, uint32_t* status, uint32_t b_base, hipStream_t s) {
     if (!n_blocks) return hipSuccess;
-    const uint32_t wgs = std::min<uint32_t>((n_blocks + 63) / 64, 256u * 3u);
+    const uint32_t wgs = std::min<uint32_t>((n_blocks + 63) / 64, 256u * 5u);
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(wgs), dim3(64), 0, s, comp, blocks, n_blocks, out, err, status, b_base);
     return hipGetLastError();
 }
