@@ -179,7 +179,13 @@ def run_cli_timed(out_dir, fa, vcf, bam, bcs, threads, extra, label, env=None):
     keep = [ln for ln in r.stderr.splitlines() if any(k in ln for k in ("Ingest", "Device", "shard:", "Merge +", "Waited", "Total",
                                                                        "[vtxh]", "alignments evaluated", "device preparation", "device ingest", "Plan of", "packing on the host"))]
     print("%s: CLI wall time %.2f s\n  %s" % (label, wall, "\n  ".join(keep)), flush=True)
+    import re
+    m = re.search(r"Total since launch: ([\d.]+) s", r.stderr)
+    run_cli_timed.totals.append((label, float(m.group(1)) if m else None, wall))
     return out
+
+
+run_cli_timed.totals = []
 
 
 def main():
@@ -215,6 +221,19 @@ def main():
             texts.append(hashlib.sha256(open(out, "rb").read()).hexdigest())
             print("  .mtx %.1f MB, sha256 %s" % (os.path.getsize(out) / 1e6, texts[-1][:16]), flush=True)
         assert len(set(texts)) == 1, "device-ingested / host-packed outputs differ"
+        import json
+        n_aln = 2 * n_reads
+        dev = sorted(t for lab, t, _ in run_cli_timed.totals if lab.startswith("--ingest device") and t)
+        host = sorted(t for lab, t, _ in run_cli_timed.totals if lab.startswith("--ingest host") and t)
+        summary = {"what": "drop-in CLI from main() to exit on authored files at config-3 scale (tools/e2e_cli_bench.py --fast)",
+                   "loci": args.loci, "reads": n_reads, "alignments": n_aln, "bam_bytes": os.path.getsize(bam), "mtx_sha256_16": texts[0][:16],
+                   "ingest_device_s": dev, "ingest_host_s": host,
+                   "ingest_device_median_s": dev[len(dev) // 2] if dev else None,
+                   "alignments_per_s_end_to_end_median": n_aln / dev[len(dev) // 2] if dev else None,
+                   "alignments_per_s_end_to_end_host_packer_best": n_aln / host[0] if host else None}
+        with open(os.path.join(args.out, "e2e_summary.json"), "w") as fh:
+            json.dump(summary, fh, indent=1)
+        print("summary: " + json.dumps(summary))
         print("device-ingested, host-packed + device-prepared and host-prepared .mtx are byte-identical")
         return
     rng = np.random.default_rng(7)

@@ -13,7 +13,7 @@
 #                                                           prod (libvtx.so) or a VTX_LIB_VARIANT name (dev, lazy0, ..., or an experimental
 #                                                           libvtx_<name>.so built by hand: how S2_WORDS / the stream kernel's occupancy were chosen)
 #   bash tools/gpu_campaign.sh final   OUTDIR               the round's closing set: default bench line, stats of every workload, the depth
-#                                                           ladder, config 4 on one GPU, the PMC passes (tools/pmc_collect.sh)
+#                                                           ladder, config 4 on one GPU, the PMC passes (tools/pmc_collect.sh), the CLI end to end
 #
 # WORKLOAD names: head (config 3, the headline) | genome (loci from tests/golden/test_dna.fa) | e1 e3 e8 (1 / 3 / 8 % substitution errors) |
 #   c5 (config-5 shape: 30 % indel loci, UMIs, alt_frac) | d128 d64 d32 d16 d4 (reads per locus) | ln8 (log-normal depth, median 8) |
@@ -95,6 +95,10 @@ case $CMD in
     python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench default rc=$?"
     bash $0 stats $OUT head genome e3 e8 c5 d16 d4 e1 r250 p150
     bash $0 lines $OUT d128 d64 d32 d16 d4 ln8 c4
+    # end to end through the drop-in CLI at config-3 scale (device ingest against the host packer), and the kernels of one such run
+    VTXH_PROFILE=1 python tools/e2e_cli_bench.py --fast --loci 100000 --reads 256 --barcodes 10000 --out /tmp/e2e > $OUT/e2e_cli_config3.log 2>&1; echo "e2e rc=$?"
+    cp /tmp/e2e/e2e_summary.json $OUT/e2e_summary.json 2>/dev/null
+    bash tools/e2e_profile.sh $OUT/e2e_prof > $OUT/e2e_profile.txt 2>&1; tail -14 $OUT/e2e_profile.txt
     echo done;;
   *) echo "unknown command $CMD" >&2; exit 2;;
 esac
