@@ -13,9 +13,9 @@
  *   write_variants :1166-1179, write_barcodes :1181-1195.
  * Library code replaced: rust-htslib/htslib (BGZF, BAM, text VCF), rust-bio
  * fasta::IndexedReader, flate2, sprs — re-implemented on zlib only.
- * Not supported (fails loudly): CRAM, BCF, CSI-only semantics are not needed
- * (the BAM is swept once in coordinate order instead of one index seek per
- * locus; the index file must still exist, like check_inputs_exist :513-541).
+ * Inputs: text VCF (plain or gzip) and BCF2 (by content, like bcf::Reader::from_path :220); BAM with a .bai or a .csi (:520-529;
+ * the window table the sweep and the device's plan use is the .bai's linear index or is rebuilt from the .csi's leaf bins);
+ * FASTA + .fai.  Not supported (fails loudly): CRAM.
  *
  * Pure CPU code, no GPU needed: `tests/test_host.py` checks it against the
  * Python restatement on the reference's own fixtures.

@@ -81,7 +81,8 @@ def _ref_span(rec: bytes):
 
 def write_bam(path: str, refs: list, records: list, block: int = 60000, index: str = "linear"):
     """refs = [(name, length)], records = output of record() in coordinate order.
-    index: "linear" writes a .bai whose LINEAR index is real (smallest virtual offset of an alignment overlapping each
+    index: "csi" writes a .csi instead (CSI v1, min_shift 14, depth 5: every record filed under its smallest containing bin, every
+    bin with its chunks and its loffset — no linear index, as htslib writes it); "linear" writes a .bai whose LINEAR index is real (smallest virtual offset of an alignment overlapping each
     16 kb window, gaps filled with the previous value like htslib does) and whose bin index is empty — enough for the
     packer's index-guided skipping; "fake" writes the magic with zero references (the packer then sweeps everything)."""
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
@@ -96,6 +97,9 @@ def write_bam(path: str, refs: list, records: list, block: int = 60000, index: s
             coffs.append(fh.tell())
             fh.write(_bgzf_block(data[o:o + block]))
         fh.write(_bgzf_block(b""))          # EOF marker
+    if index == "csi":
+        _write_csi(path + ".csi", refs, records, hdr, coffs, block)
+        return
     with open(path + ".bai", "wb") as fh:
         if index != "linear":
             fh.write(b"BAI\x01" + struct.pack("<i", 0))
@@ -119,3 +123,92 @@ def write_bam(path: str, refs: list, records: list, block: int = 60000, index: s
                     l[i] = l[i - 1]
             out += struct.pack("<i", 0) + struct.pack("<i", len(l)) + b"".join(struct.pack("<Q", v) for v in l)
         fh.write(out)
+
+
+def _reg2bin(beg, end, min_shift=14, depth=5):
+    """CSI spec 5.1.1: the smallest bin that contains [beg, end)."""
+    end -= 1
+    s, t = min_shift, ((1 << depth * 3) - 1) // 7
+    level = depth
+    while level > 0:
+        if beg >> s == end >> s:
+            return t + (beg >> s)
+        s += 3
+        t -= 1 << ((level - 1) * 3)
+        level -= 1
+    return 0
+
+
+def _write_csi(path, refs, records, hdr, coffs, block, min_shift=14, depth=5):
+    """A real CSI: per reference the bins that hold records, each with loffset (smallest virtual offset of a record that overlaps
+    the bin's interval) and one chunk [first record's offset, end of its last record)."""
+    bins = [dict() for _ in refs]          # bin -> [chunk_beg, chunk_end]
+    spans = [[] for _ in refs]             # (pos, end, voff) for the loffsets
+    u = len(hdr)
+    for rec in records:
+        tid, pos, end = _ref_span(rec)
+        voff = (coffs[u // block] << 16) | (u % block)
+        u2 = u + len(rec)
+        vend = (coffs[u2 // block] << 16) | (u2 % block) if u2 // block < len(coffs) else ((coffs[-1] + 1) << 16)
+        if 0 <= tid < len(refs):
+            b = _reg2bin(max(pos, 0), max(end, pos + 1), min_shift, depth)
+            c = bins[tid].setdefault(b, [voff, vend])
+            c[1] = vend
+            spans[tid].append((max(pos, 0), max(end, pos + 1), voff))
+        u = u2
+    out = b"CSI\x01" + struct.pack("<iii", min_shift, depth, 0) + struct.pack("<i", len(refs))
+    for t in range(len(refs)):
+        out += struct.pack("<i", len(bins[t]))
+        for b in sorted(bins[t]):
+            # the bin's interval
+            level, first = depth, ((1 << depth * 3) - 1) // 7
+            while level > 0 and b < first:
+                level -= 1
+                first = ((1 << level * 3) - 1) // 7
+            span = 1 << (min_shift + 3 * (depth - level))
+            lo, hi = (b - first) * span, (b - first + 1) * span
+            loff = min(v for p0, p1, v in spans[t] if p0 < hi and p1 > lo)
+            out += struct.pack("<IQi", b, loff, 1) + struct.pack("<QQ", *bins[t][b])
+    with open(path, "wb") as fh:
+        for o in range(0, len(out), 60000):
+            fh.write(_bgzf_block(out[o:o + 60000]))
+        fh.write(_bgzf_block(b""))
+
+
+def vcf_to_bcf(vcf_path, bcf_path):
+    """A text VCF as BCF2 (BGZF): the header text verbatim, every record with CHROM as the index of its ##contig line, 0-based POS,
+    the ID and the alleles as typed strings; no INFO, no FORMAT.  Enough for what the reference reads (src/main.rs:220-234)."""
+    lines = open(vcf_path).read().splitlines()
+    header = [ln for ln in lines if ln.startswith("#")]
+    contigs = []
+    for ln in header:
+        if ln.startswith("##contig=<"):
+            contigs.append(ln.split("ID=", 1)[1].split(",")[0].split(">")[0])
+    text = ("\n".join(header) + "\n").encode() + b"\x00"
+    out = bytearray(b"BCF\x02\x02" + struct.pack("<I", len(text)) + text)
+
+    def typed_str(b):
+        if len(b) < 15:
+            return bytes([(len(b) << 4) | 7]) + b
+        if len(b) < 128:
+            return bytes([0xF7, 0x11, len(b)]) + b
+        return bytes([0xF7, 0x12]) + struct.pack("<H", len(b)) + b
+    for ln in lines:
+        if not ln or ln.startswith("#"):
+            continue
+        f = ln.split("\t")
+        chrom, pos, vid, ref, alt = f[0], int(f[1]) - 1, f[2], f[3], f[4]
+        if chrom not in contigs:
+            contigs.append(chrom)
+        alleles = [ref] + ([] if alt == "." else alt.split(","))
+        shared = struct.pack("<iiif", contigs.index(chrom), pos, len(ref), float("nan"))
+        shared += struct.pack("<II", (len(alleles) << 16) | 0, 0)
+        shared += typed_str(b"" if vid == "." else vid.encode())
+        for a in alleles:
+            shared += typed_str(a.encode())
+        shared += bytes([0x00])                                   # FILTER: an empty typed vector
+        out += struct.pack("<II", len(shared), 0) + shared
+    with open(bcf_path, "wb") as fh:
+        for o in range(0, len(out), 60000):
+            fh.write(_bgzf_block(bytes(out[o:o + 60000])))
+        fh.write(_bgzf_block(b""))

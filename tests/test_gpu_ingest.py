@@ -225,10 +225,12 @@ def test_authored_bam_with_every_filter(tmp_path, opts):
     assert (st.raw_records > 0) == ("bam_tag" not in opts)          # (no read carries a CR tag: every pair ends at num_not_cell_bc)
 
 
-def test_many_blocks_many_seeds(tmp_path):
-    """Small BGZF blocks (records cross block boundaries all the time) and a seed per 16 kb window."""
+@pytest.mark.parametrize("index", ["linear", "csi"])
+def test_many_blocks_many_seeds(tmp_path, index):
+    """Small BGZF blocks (records cross block boundaries all the time) and a seed per 16 kb window — from a .bai's linear index, or
+    from a .csi's leaf bins (round 6: src/main.rs:520-529 accepts either index)."""
     from test_host import make_dna_bam
-    bam = make_dna_bam(tmp_path, seed=5, n_reads=6000, block=3000)
+    bam = make_dna_bam(tmp_path, seed=5, n_reads=6000, block=3000, index=index)
     inputs = dict(vcf=os.path.join(G, "test_dna.vcf"), bam=bam, fasta=os.path.join(G, "test_dna.fa"),
                   cell_barcodes=os.path.join(G, "dna_barcodes.tsv"))
     ingest_and_compare(inputs, pack_kw=dict(use_umi=True))

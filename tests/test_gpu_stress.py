@@ -230,6 +230,39 @@ np.save(sys.argv[1], np.concatenate(out))
     assert res[0][-1] < 0.9 * res[1][-1], (res[0][-1], res[1][-1])
 
 
+def test_whole_read_shortcut_on_and_off():
+    """include/vtx_band_semantics.h, fifth item: band_diag_kernel scores a read that matches its haplotype base for base before any
+    k-mer probe (`whole_read`).  libvtx_dev.so under VTX_DIAG_ABLATE=10 runs without the shortcut — every such task then takes the
+    probes, the harmless tests and the run bound like any other: identical scores on clean reads in random sequence, in tandem repeats
+    and in real sequence (the cases where "whatever else matches" matters), and more work left to the later stages' counters."""
+    code = r'''
+import sys, os, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import stress_batches as SB
+from vartrix_amd import lib, synth
+from vartrix_amd.abi import default_config
+out = []
+batches = [("clean", synth.make_batch(synth.SynthSpec(n_loci=400, n_barcodes=500, reads_per_locus=64, sub_error=0.0, seed=3)), 500)]
+batches += list(SB.repeat_rich_batches(trials=2)) + list(SB.real_sequence_batches(trials=1))
+for label, batch, nb in batches:
+    with lib.Context(default_config(aligner="banded", scoring_mode="coverage", n_barcodes=nb)) as ctx:
+        ctx.set_stage_trace(True)
+        ctx.submit(batch); ctx.run(); r, a = ctx.fetch_scores()
+    out.append(np.concatenate([r, a]))
+np.save(sys.argv[1], np.concatenate(out))
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        res = []
+        for env_extra in ({}, {"VTX_DIAG_ABLATE": "10"}):
+            path = os.path.join(td, "w%d.npy" % len(res))
+            r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=900,
+                               env=dict(os.environ, VTX_LIB_VARIANT="dev", **env_extra))
+            assert r.returncode == 0, r.stderr[-3000:]
+            res.append(np.load(path))
+        assert np.array_equal(res[0], res[1]) and res[0].size > 50000
+
+
 def test_single_diagonal_stage_on_and_off_give_the_same_scores():
     """VTX_BAND_NO_DIAG=1 runs the banded flavour without band_diag_kernel (band_run_kernel takes every task, the round-2 path):
     identical scores (separate process: the hook is read from the environment)."""

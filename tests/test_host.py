@@ -104,7 +104,7 @@ def test_validate_inputs_unknown_contig(tmp_path):
         hostlib.pack_files(str(vcf), os.path.join(G, "test.bam"), os.path.join(G, "test.fa"), os.path.join(G, "barcodes.tsv"))
 
 
-def make_dna_bam(tmp_path, seed=1, n_reads=600, block=20000):
+def make_dna_bam(tmp_path, seed=1, n_reads=600, block=20000, index="linear"):
     """Author a coordinate-sorted BAM over test_dna.fa covering the loci of test_dna.vcf (SNV, INS,
     DEL, one multi-allelic record) with assorted CIGARs, flags, tags and soft clips."""
     from oracle import bamwriter
@@ -159,7 +159,7 @@ def make_dna_bam(tmp_path, seed=1, n_reads=600, block=20000):
         recs.append((start, bamwriter.record(0, start, "r%04d" % k, seq, cigar, flag=flag, mapq=mapq, tags=tags)))
     recs.sort(key=lambda t: t[0])
     bam = str(tmp_path / "dna.bam")
-    bamwriter.write_bam(bam, [("1", len(fa))], [r for _, r in recs], block=block)
+    bamwriter.write_bam(bam, [("1", len(fa))], [r for _, r in recs], block=block, index=index)
     return bam
 
 
@@ -347,8 +347,10 @@ def test_packs_of_row_ranges_add_up_to_the_whole_pack(tmp_path, raw):
     assert sum(bb.n_records for bb in b) < 0.5 * whole[0].n_records
 
 
-def test_index_guided_skipping_on_a_sparse_vcf(tmp_path, monkeypatch):
-    """A few loci over a BAM that covers the whole contig: with the .bai the packer inflates only the stretches that can
+@pytest.mark.parametrize("index", ["linear", "csi"])
+def test_index_guided_skipping_on_a_sparse_vcf(tmp_path, monkeypatch, index):
+    """A few loci over a BAM that covers the whole contig: with the .bai — or, round 6, a .csi (src/main.rs:520-529 accepts either:
+    the window table is rebuilt from the leaf bins' loffsets) — the packer inflates only the stretches that can
     hold their reads (the reference does an indexed fetch per locus, src/main.rs:822-826) — and packs exactly what the
     full sweep packs.  Reads with long reference skips (spliced, N) start far before the locus they overlap: the linear
     index accounts for them."""
@@ -385,10 +387,13 @@ def test_index_guided_skipping_on_a_sparse_vcf(tmp_path, monkeypatch):
                                               tags=[("CB", "Z", bcs[3]), ("UB", "Z", "USP")])))
     recs.sort(key=lambda t: t[0])
     bam = str(tmp_path / "wide.bam")
-    bamwriter.write_bam(bam, [("1", len(fa))], [r for _, r in recs], block=4000)
+    bamwriter.write_bam(bam, [("1", len(fa))], [r for _, r in recs], block=4000, index=index)
+    assert os.path.exists(bam + (".csi" if index == "csi" else ".bai")) and not os.path.exists(bam + (".bai" if index == "csi" else ".csi"))
     fap, bcp = os.path.join(G, "test_dna.fa"), os.path.join(G, "dna_barcodes.tsv")
     got, gm, nv, _, _ = hostlib.pack_files(str(vcf), bam, fap, bcp, threads=3, use_umi=True)
     st = dict(hostlib.last_ingest_stats)
+    with hostlib.plan_ingest(str(vcf), bam, fap, bcp, use_umi=True) as plan:      # (the device's plan takes its record starts from the same table)
+        assert plan.reason is None or "sparse" in plan.reason
     monkeypatch.setenv("VTXH_NO_INDEX", "1")
     full, fm, _, _, _ = hostlib.pack_files(str(vcf), bam, fap, bcp, threads=3, use_umi=True)
     st_full = dict(hostlib.last_ingest_stats)
@@ -402,6 +407,53 @@ def test_index_guided_skipping_on_a_sparse_vcf(tmp_path, monkeypatch):
     # (each far locus drags in the 30 kb its spliced read spans, and a restart over-reads up to ~100 of these tiny 4 kB
     # blocks: a third of the file stays untouched here; with 64 kB blocks and a 50 GB BAM it is nearly all of it)
     assert st["index_jumps"] >= 2 and st["blocks_inflated"] < 0.7 * st["blocks_total"], st
+
+
+@pytest.mark.parametrize("fixture", ["test", "test_dna"])
+def test_bcf_input_equals_vcf(tmp_path, fixture):
+    """bcf::Reader::from_path (src/main.rs:220) reads BCF as well as text VCF; so does the packer since round 6 (by content: "BCF\\2\\2"
+    behind the BGZF layer).  The reference's two VCFs converted by the test's own BCF writer (oracle/bamwriter.py: vcf_to_bcf — typed
+    strings of every length class, a multi-allelic record, IDs): the same pack, the same names, the same skipped-record counters."""
+    from oracle import bamwriter
+    vcfp = os.path.join(G, fixture + ".vcf")
+    bcfp = str(tmp_path / (fixture + ".bcf"))
+    bamwriter.vcf_to_bcf(vcfp, bcfp)
+    if fixture == "test":
+        rest = dict(bam=os.path.join(G, "test.bam"), fasta=os.path.join(G, "test.fa"), cell_barcodes=os.path.join(G, "barcodes.tsv"))
+    else:
+        rest = dict(bam=make_dna_bam(tmp_path, seed=2, n_reads=800), fasta=os.path.join(G, "test_dna.fa"), cell_barcodes=os.path.join(G, "dna_barcodes.tsv"))
+    a = hostlib.pack_files(vcf=vcfp, threads=2, use_umi=True, **rest)
+    b = hostlib.pack_files(vcf=bcfp, threads=2, use_umi=True, **rest)
+    assert same_batch(a[0], b[0]) and a[1:] == b[1:]
+    assert a[2] == (4 if fixture == "test" else 46) and (fixture == "test" or a[1]["num_multiallelic_recs"] == 1)
+    # a long allele (> 127 bytes: the 16-bit length class of a typed string) and a truncated file
+    long_vcf = str(tmp_path / "long.vcf")
+    fa = refpipe.read_fasta(os.path.join(G, "test_dna.fa"))["1"].upper()
+
+    def clean(p):                                                       # first position >= p whose +-130 window is pure ACGT
+        while any(c not in b"ACGT" for c in fa[p - 130:p + 131]):
+            p += 50
+        return p
+    p1 = clean(60000)
+    p2 = clean(p1 + 2000)
+    with open(long_vcf, "w") as fh:
+        fh.write("##fileformat=VCFv4.2\n##contig=<ID=1,length=%d>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n" % len(fa))
+        fh.write("1\t%d\trs1\t%s\t%s\t.\t.\t.\n" % (p1 + 1, fa[p1:p1 + 1].decode(), fa[p1:p1 + 1].decode() + "ACGT" * 40))
+        fh.write("1\t%d\t.\t%s\t%s\t.\t.\t.\n" % (p2 + 1, fa[p2:p2 + 20].decode(), fa[p2:p2 + 1].decode()))
+    long_bcf = str(tmp_path / "long.bcf")
+    bamwriter.vcf_to_bcf(long_vcf, long_bcf)
+    dna = dict(bam=make_dna_bam(tmp_path, seed=2, n_reads=300), fasta=os.path.join(G, "test_dna.fa"), cell_barcodes=os.path.join(G, "dna_barcodes.tsv"))
+    a = hostlib.pack_files(vcf=long_vcf, **dna)
+    b = hostlib.pack_files(vcf=long_bcf, **dna)
+    assert same_batch(a[0], b[0]) and a[1:] == b[1:] and a[0].loci["alt_len"][0] == 100 + 161 + 100
+    import gzip
+    raw = gzip.open(long_bcf, "rb").read()
+    cut = str(tmp_path / "cut.bcf")
+    with gzip.open(cut, "wb") as fh:
+        fh.write(raw[:-7])
+    with pytest.raises(hostlib.HostError) as ei:
+        hostlib.pack_files(vcf=cut, **dna)
+    assert "BCF" in str(ei.value)
 
 
 def test_packer_survives_corrupted_bam(tmp_path):

@@ -156,6 +156,92 @@ struct Fasta {
 // ---- VCF (text, optionally gz) -------------------------------------------------
 struct VcfRec { std::string chrom; int64_t pos; std::vector<std::string> alleles; };
 
+// BCF2 (the binary VCF htslib reads behind bcf::Reader, src/main.rs:220): "BCF\2\2", l_text, the VCF header text, then records
+// {l_shared, l_indiv, CHROM i32, POS i32 (0-based), rlen, QUAL, n_info | n_allele << 16, n_fmt | n_sample << 24, ID, alleles ...}
+// with typed values (descriptor byte: size << 4 | type; size 15: the real size follows as a typed integer; type 7: characters).
+// Only what the reference uses is read: rid -> contig name (header dictionary: IDX= if present, else order of appearance), pos,
+// the alleles (record.alleles(), :229-233).  `data` is the inflated file.
+bool parse_bcf(const std::string& data, std::vector<VcfRec>& out, std::string& msg) {
+    const unsigned char* p = (const unsigned char*)data.data();
+    const size_t n = data.size();
+    auto u32at = [&](size_t o) { return (uint32_t)p[o] | ((uint32_t)p[o + 1] << 8) | ((uint32_t)p[o + 2] << 16) | ((uint32_t)p[o + 3] << 24); };
+    if (n < 9 || p[4] != 2) { msg = "unsupported BCF version"; return false; }
+    const uint32_t l_text = u32at(5);
+    if ((size_t)9 + l_text > n) { msg = "truncated BCF header"; return false; }
+    // contig dictionary
+    std::vector<std::string> contigs;
+    {
+        const std::string text(data, 9, l_text);
+        size_t seen = 0;
+        for (auto& line : split_lines(text)) {
+            if (line.compare(0, 10, "##contig=<") != 0) continue;
+            std::string id;
+            long idx = -1;
+            size_t i = 10;
+            while (i < line.size() && line[i] != '>') {
+                size_t e = line.find_first_of(",>", i), q = line.find('=', i);
+                if (q != std::string::npos && q < e) {
+                    size_t vb = q + 1;
+                    if (vb < line.size() && line[vb] == '"') { const size_t qe = line.find('"', vb + 1); if (qe != std::string::npos) e = line.find_first_of(",>", qe); }
+                    if (e == std::string::npos) e = line.size();
+                    const std::string key(line, i, q - i), val(line, vb, e - vb);
+                    if (key == "ID") id = val;
+                    else if (key == "IDX") idx = atol(val.c_str());
+                }
+                if (e == std::string::npos) break;
+                i = e + 1;
+            }
+            const size_t at = idx >= 0 ? (size_t)idx : seen;
+            if (contigs.size() <= at) contigs.resize(at + 1);
+            contigs[at] = id;
+            ++seen;
+        }
+    }
+    size_t o = 9 + (size_t)l_text;
+    // typed string at o -> [ptr, len); advances o.  false: malformed
+    auto typed_len = [&](size_t& q, uint32_t& len, uint32_t& type) -> bool {
+        if (q >= n) return false;
+        const uint32_t d = p[q++];
+        type = d & 15u; len = d >> 4;
+        if (len == 15) {                                       // the length is a typed integer of its own
+            if (q >= n) return false;
+            const uint32_t d2 = p[q++], t2 = d2 & 15u;
+            if ((d2 >> 4) != 1) return false;
+            if (t2 == 1) { if (q + 1 > n) return false; len = p[q]; q += 1; }
+            else if (t2 == 2) { if (q + 2 > n) return false; len = (uint32_t)p[q] | ((uint32_t)p[q + 1] << 8); q += 2; }
+            else if (t2 == 3) { if (q + 4 > n) return false; len = u32at(q); q += 4; }
+            else return false;
+        }
+        return true;
+    };
+    while (o + 8 <= n) {
+        const uint32_t l_shared = u32at(o), l_indiv = u32at(o + 4);
+        const size_t body = o + 8;
+        if (body + (size_t)l_shared + l_indiv > n || l_shared < 24) { msg = "truncated BCF record"; return false; }
+        const int32_t rid = (int32_t)u32at(body), pos = (int32_t)u32at(body + 4);
+        const uint32_t n_allele = u32at(body + 16) >> 16;
+        if (rid < 0 || (size_t)rid >= contigs.size() || contigs[(size_t)rid].empty()) { msg = "BCF record on a contig the header does not define"; return false; }
+        size_t q = body + 24;
+        const size_t end = body + l_shared;
+        uint32_t len, type;
+        if (!typed_len(q, len, type) || (len && type != 7) || q + len > end) { msg = "malformed BCF record (ID)"; return false; }
+        q += len;
+        VcfRec r;
+        r.chrom = contigs[(size_t)rid];
+        r.pos = pos;
+        for (uint32_t k = 0; k < n_allele; ++k) {
+            if (!typed_len(q, len, type) || (len && type != 7) || q + len > end) { msg = "malformed BCF record (alleles)"; return false; }
+            r.alleles.emplace_back((const char*)p + q, len);
+            q += len;
+        }
+        if (r.alleles.empty()) { msg = "BCF record without a REF allele"; return false; }
+        out.push_back(std::move(r));
+        o = body + (size_t)l_shared + l_indiv;
+    }
+    if (o != n) { msg = "trailing bytes behind the last BCF record"; return false; }
+    return true;
+}
+
 // ---- BAM ------------------------------------------------------------------------
 const char kNt16[] = "=ACMGRSVTWYHKDBN";
 struct Nt16Pairs {                    // byte of two 4-bit codes -> its two letters
@@ -340,6 +426,65 @@ bool read_bai_linear(const std::string& path, size_t n_ref_expected, std::vector
             any |= v != 0;
         }
     }
+    return any;
+}
+
+// The same table from a .csi (CSI v1, htslib: BGZF-compressed; bins of min_shift + 3 * level bits, `depth` levels): no linear index,
+// but every bin carries loffset — the smallest virtual offset of a record overlapping the bin.  The window table is rebuilt from the
+// LEAF bins (one per 2^min_shift bases: exactly a linear-index entry); a window whose leaf bin is absent takes its nearest present
+// ancestor's loffset (records that span a leaf boundary are filed further up; an ancestor's loffset is at or before anything that
+// overlaps the window: conservative), else 0 = "not recorded" like an empty .bai slot.  *shift = min_shift (the window size).
+bool read_csi_linear(const std::string& path, size_t n_ref_expected, std::vector<std::vector<uint64_t>>& lin, int* shift) {
+    std::string d;
+    if (!read_gz(path, d) || d.size() < 16 || memcmp(d.data(), "CSI\1", 4) != 0) return false;
+    const unsigned char* p = (const unsigned char*)d.data();
+    size_t o = 4;
+    auto u32 = [&](uint32_t& v) { if (o + 4 > d.size()) return false; v = p[o] | (p[o + 1] << 8) | (p[o + 2] << 16) | ((uint32_t)p[o + 3] << 24); o += 4; return true; };
+    auto u64 = [&](uint64_t& v) { if (o + 8 > d.size()) return false; v = 0; for (int k = 7; k >= 0; --k) v = (v << 8) | p[o + (size_t)k]; o += 8; return true; };
+    uint32_t min_shift, depth, l_aux, n_ref;
+    if (!u32(min_shift) || !u32(depth) || !u32(l_aux) || o + l_aux > d.size()) return false;
+    o += l_aux;
+    if (!u32(n_ref) || n_ref != n_ref_expected || min_shift < 8 || min_shift > 29 || depth > 9) return false;
+    auto first_of = [](uint32_t level) -> uint64_t { return (((uint64_t)1 << (3 * level)) - 1) / 7; };
+    const uint64_t leaf0 = first_of(depth), n_leaf = (uint64_t)1 << (3 * depth);
+    lin.assign(n_ref, {});
+    bool any = false;
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        uint32_t n_bin;
+        if (!u32(n_bin)) return false;
+        std::unordered_map<uint32_t, uint64_t> loff;
+        uint64_t max_leaf = 0;
+        bool has = false;
+        for (uint32_t b = 0; b < n_bin; ++b) {
+            uint32_t bin, n_chunk;
+            uint64_t lo;
+            if (!u32(bin) || !u64(lo) || !u32(n_chunk) || o + 16ull * n_chunk > d.size()) return false;
+            uint64_t last_end_window = 0;
+            if (bin < leaf0 + n_leaf) {                         // (the pseudo-bin of the metadata lies beyond the last level)
+                loff[bin] = lo;
+                // the last window this bin can touch: its level's span
+                uint32_t level = depth;
+                while (level > 0 && bin < first_of(level)) --level;
+                const uint64_t idx = bin - first_of(level), span = (uint64_t)1 << (3 * (depth - level));
+                last_end_window = idx * span + span - 1;
+                if (n_chunk) { has = true; max_leaf = std::max(max_leaf, last_end_window); }
+            }
+            o += 16ull * n_chunk;
+        }
+        if (!has) continue;
+        lin[r].assign((size_t)std::min<uint64_t>(max_leaf + 1, n_leaf), 0);
+        for (size_t w = 0; w < lin[r].size(); ++w) {
+            uint64_t bin = leaf0 + w;
+            for (uint32_t level = depth;; --level) {
+                auto it = loff.find((uint32_t)bin);
+                if (it != loff.end() && it->second) { lin[r][w] = it->second; break; }
+                if (level == 0) break;
+                bin = first_of(level - 1) + ((bin - first_of(level)) >> 3);      // the parent
+            }
+            any |= lin[r][w] != 0;
+        }
+    }
+    *shift = (int)min_shift;
     return any;
 }
 
@@ -770,8 +915,14 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     {
         std::string data;
         std::string path = a->vcf;
-        if (ends_with(path, ".bcf")) return fail(VTX_E_UNSUPPORTED, "BCF input is not supported; use text VCF (optionally .gz)");
         if (!read_gz(path, data)) return fail(VTX_E_INVAL, "error opening vcf file %s", path.c_str());
+        // bcf::Reader::from_path (src/main.rs:220) reads BCF as well as VCF — by content, not by extension
+        if (data.size() >= 9 && memcmp(data.data(), "BCF\2", 4) == 0) {
+            std::string msg;
+            if (!parse_bcf(data, vcf, msg)) return fail(VTX_E_INVAL, "%s: %s", path.c_str(), msg.c_str());
+            for (const VcfRec& r : vcf) P->variant_names.push_back(r.chrom + "_" + std::to_string(r.pos));
+            data.clear();
+        }
         for (auto& line : split_lines(data)) {
             if (line.empty() || line[0] == '#') continue;
             std::vector<std::string> f;
@@ -1002,16 +1153,19 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
     struct Target { int32_t tid; int64_t start, end; uint64_t voff; };
     std::vector<Target> targets;
     bool use_index = false;
+    int lin_shift = 14;                   // bases per window of the table below, as a shift (.bai: 16 kb; .csi: its min_shift)
     std::vector<std::vector<uint64_t>> lin;
     {
-        if (!VTXH_DEV_ENV("VTXH_NO_INDEX") && read_bai_linear(std::string(a->bam) + ".bai", bam_refs.size(), lin)) {
+        // the .bai's linear index, or the same table rebuilt from a .csi's leaf bins (src/main.rs:520-529 accepts either)
+        if (!VTXH_DEV_ENV("VTXH_NO_INDEX") && (read_bai_linear(std::string(a->bam) + ".bai", bam_refs.size(), lin) ||
+                                                read_csi_linear(std::string(a->bam) + ".csi", bam_refs.size(), lin, &lin_shift))) {
             use_index = true;
             for (size_t t = 0; t < by_tid.size(); ++t) {
                 const auto& iv = by_tid[t];
                 const auto& li = lin[t];
                 for (const Interval& x : iv) {
                     if (li.empty()) continue;                                  // no alignment on this contig
-                    size_t w = (size_t)(x.start >> 14);
+                    size_t w = (size_t)(x.start >> lin_shift);
                     if (w >= li.size()) continue;                              // nothing overlaps this window or any later one
                     uint64_t v = 0;
                     for (size_t k = w + 1; k-- > 0 && !v;) v = li[k];          // 0 = "not recorded": fall back to an earlier window
@@ -1048,7 +1202,7 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
             P->pl_span[t] = (int32_t)max_span[t];
         }
         P->pl_tid_begin[bam_refs.size()] = (uint32_t)P->pl_iv.size();
-        if (!use_index) return done("no usable .bai next to the BAM (the record starts come from its linear index)");
+        if (!use_index) return done("no usable .bai / .csi next to the BAM (the record starts come from the index)");
         if (targets.empty()) return done(nullptr);                   // no locus can have reads: nothing to inflate
         std::vector<uint64_t> ustart(blocks.size() + 1, 0);
         for (size_t b = 0; b < blocks.size(); ++b) ustart[b + 1] = ustart[b] + blocks[b].isize;
@@ -1098,7 +1252,7 @@ static int pack_impl(const vtxh_args* a, bool raw, uint32_t row_begin, uint32_t 
             const auto& li = lin[(size_t)tl];
             uint64_t prev = 0;
             int probes = 0;
-            for (size_t w = (size_t)(seg_end >> 14); w < li.size() && !found_end; ++w) {
+            for (size_t w = (size_t)(seg_end >> lin_shift); w < li.size() && !found_end; ++w) {
                 const uint64_t v = li[w];
                 if (!v || v == prev || v <= start_voff) continue;
                 prev = v;

@@ -118,7 +118,7 @@ struct vtx_ctx {
     DevBuf d_band_ws, d_band_ws2, d_band, d_poly, d_gtables, d_hard, d_over, d_over2, d_pend, d_pend_buf, d_cnt, d_band2, d_hard2, d_fail, d_fail_tmp, d_refine;   // banded flavour
     DevBuf d_tight2, d_tight2_pack;                                          // band_diag2_kernel: tasks whose band is one diagonal stretch after all
     DevBuf d_recheck2, d_recheck2_pack;                                      // ... of which the full-matrix check did not settle (full != certificate); first they hold band_stream_kernel's task list and diagonals
-    DevBuf d_sweep_log;                                                      // band_sweep_kernel: the section logs of the resident workgroups (64 MB)
+    DevBuf d_sweep_log;                                                      // band_sweep_kernel: the section logs of the resident workgroups (48 MB: 1 536 x 8 x 1 024 words)
     DevBuf d_tight, d_tight_pack, d_dband, d_dband_pack, d_dense, d_stage;                                                 // round 4: tasks with a provisional score (full-matrix check); stage bytes (vtx_fetch_stage)
     bool stage_trace = false, poison = false;                                // test / audit hooks (vtx_set_debug)
     int32_t poison_value = 0;

@@ -2115,7 +2115,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         if (live) {
             fr = vtxf::front_rest(x, m, tb, n, ln, d, M);
             if (fr.why != vtxf::W_OK) { live = false; fail = true; why = fr.why; }
-            else if (vtxf::whole_read(fr, m)) {
+            else if (VTX_ABLATE(stats >> 8) != 10 && vtxf::whole_read(fr, m)) {      // (developer build, VTX_DIAG_ABLATE=10: the shortcut off — the A/B switch of include/vtx_band_semantics.h's fifth item; results stay right)
                 // the read matches base for base: full <= m = cert, and the reference's chain is a perfect diagonal whatever else
                 // matches (vtx_fast_core.h: whole_read) — decided here, before any probe: a fifth of the tasks of a clean workload
                 *my_score = m;

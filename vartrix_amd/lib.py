@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # Build variants of the SAME sources (vartrix_amd/csrc/Makefile), never loaded in production:
 #   dev    -DVTX_DEVTOOLS: the experiment / test hooks (stage switches, ablations, buffer caps, the socket transport standing in for
 #          RCCL) exist only there; the production libvtx.so reads VTX_DEBUG and nothing else
-#   lazy0, anchor5, tie0   one recollected detail of the crate's band switched (tests/test_gpu_variants.py)
+#   lazy0, lazy40, anchor5, noseed0   one recollected detail of the crate's band switched (tests/test_gpu_variants.py)
 # VTX_LIB_VARIANT=<name> makes a variant the process default; load(variant) / Context(cfg, variant=...) pick one explicitly.
 DEFAULT_VARIANT = os.environ.get("VTX_LIB_VARIANT", "")
 
