@@ -311,6 +311,16 @@ int vtxt_fastcore_trim_batch(const vtx_batch* b, uint32_t n_heads, int32_t* scor
                 const Refine rf{x, tb.gt + tb.bytes, m, n};
                 int32_t sc = back(fr, ns, ln, Lane{generic, 1}, &w, 0, &rf, &aux);
                 if (sc < 0 && w == W_NOT_TIGHT && aux != 0xffffffffu) {
+                    // the kernel's fused pass (main_pieces_ub_both) must give what the two separate passes give
+                    uint32_t copy[LANE_WORDS];
+                    memcpy(copy, lane, sizeof copy);
+                    const LaneS<uint16_t> ln2{copy + S_WORDS, 1, (uint16_t*)copy, 1};
+                    int lo, hi, ubb2 = 0;
+                    band_rows(fr, m, lo, hi);
+                    const int ubf2 = main_pieces_ub_both(ln2, fr.r, fr.zc, fr.d, &rf, (int)aux, lo, hi, &ubb2);
+                    const int ubf1 = main_pieces_ub(ln, fr.r, fr.zc, fr.d, &rf, (int)aux);
+                    const int ubb1 = main_pieces_ub_band(ln, fr.r, fr.zc, fr.d, &rf, lo, hi, (int)aux);
+                    if (ubf1 != ubf2 || ubb1 != ubb2) return -2;
                     sc = band_trim_verdict(fr, m, ln, aux, &rf);
                     if (sc >= 0) { w = W_OK; trimmed[t] = 1; }
                 }

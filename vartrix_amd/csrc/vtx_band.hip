@@ -2399,20 +2399,24 @@ __global__ __launch_bounds__(256) void band_refine_kernel(
         pl.at(4) = p1.x; pl.at(5) = p1.y; pl.at(6) = p1.z; pl.at(7) = p1.w;
         const uint8_t* yb = gtables + ((size_t)(my_locus - gt_l0) * 2 + hap) * table_stride + vtxf::tab_bytes_off(max_hap, n_heads);
         const vtxf::Refine rf{read_arena + rec.read_off, yb, (int)rec.read_len, (int)(hap ? loc.alt_len : loc.ref_len)};
-        const int ub = max(max(vtxf::K - 1, far_e > 0 ? far_e + 5 : 0), vtxf::main_pieces_ub(pl, r, h.w, d, &rf, far_e));
-        (hap ? alt_score : ref_score)[rid] = cert;                     // final when ub == cert, provisional otherwise
-        if (ub == cert) { if (stage) stage[task] = VTX_STAGE_REFINE_CERT; }
-        else if (tight_list) {
-            // Round 6 (vtx_band_trim.h): the same bound over the pieces TRIMMED to the rows whose main-diagonal cell lies in the band
-            // bounds the BANDED score (a path inside the band touches in-band cells only).  Where the band cuts end pieces off
-            // (banded < full: half of what the refinement leaves on noisy reads) no bound of the full score can meet the certificate;
-            // this one does.  A tight list means every haplotype has <= 255 bases: ca / cb are the bytes of the pack.
+        // Round 6 (vtx_band_trim.h): next to the refined bound of the FULL score, the same bound over the pieces TRIMMED to the rows whose
+        // main-diagonal cell lies in the band — a bound of the BANDED score (a path inside the band touches in-band cells only).  Where
+        // the band cuts end pieces off (banded < full: half of what the refinement leaves on noisy reads) no bound of the full score can
+        // meet the certificate; this one does.  Both in one pass: the corridor DPs of the joins are shared.  A tight list means every
+        // haplotype has <= 255 bases: ca / cb are the bytes of the pack.
+        const int base_ub = max(vtxf::K - 1, far_e > 0 ? far_e + 5 : 0);
+        int ub, ubb = -1;
+        if (tight_list) {
             const int ca = (int)((h.y >> 8) & 0xffu), cb = (int)(h.y & 0xffu);
             const int lo = max(0, ca - vtxf::W - 1 - d), hi = min((int)rec.read_len - 1, cb + vtxf::W - 1 - d);
-            const int ubb = max(max(vtxf::K - 1, far_e > 0 ? far_e + 5 : 0), vtxf::main_pieces_ub_band(pl, r, h.w, d, &rf, lo, hi, far_e));
-            if (ubb == cert) { if (stage) stage[task] = VTX_STAGE_BAND_CERT; }      // a stage of its own: banded < full is allowed here
-            else fail = true;
-        } else fail = true;
+            int band_part = 0;
+            ub = max(base_ub, vtxf::main_pieces_ub_both(pl, r, h.w, d, &rf, far_e, lo, hi, &band_part));
+            ubb = max(base_ub, band_part);
+        } else ub = max(base_ub, vtxf::main_pieces_ub(pl, r, h.w, d, &rf, far_e));
+        (hap ? alt_score : ref_score)[rid] = cert;                     // final when a bound meets it, provisional otherwise
+        if (ub == cert) { if (stage) stage[task] = VTX_STAGE_REFINE_CERT; }
+        else if (ubb == cert) { if (stage) stage[task] = VTX_STAGE_BAND_CERT; }      // a stage of its own: banded < full is allowed here
+        else fail = true;
     }
     const uint64_t fm = __ballot(fail);
     if (fm) {

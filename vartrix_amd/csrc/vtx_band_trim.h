@@ -75,6 +75,56 @@ template <class PL> VTXF_FN int main_pieces_ub_band(const PL& pl, int r, uint32_
     return ub;
 }
 
+// Both bounds in ONE pass over the ordered pairs (band_refine_kernel, round 6): the refined bound of the full score (main_pieces_ub) and
+// the bound of the banded score (main_pieces_ub_band) price the same joins — the corridor DP of a join, which is where the time goes,
+// is run once and only repeated for the (at most two) pieces the band actually cuts, where the bases a run may give up differ.
+// G of the full bound in the top byte of a piece word as before, G of the band bound in bits 16 - 23 (the refine record has no use for
+// the dp byte kept there).  Returns the full bound, *ub_band the other.
+template <class PL> VTXF_FN int main_pieces_ub_both(const PL& pl, int r, uint32_t zc, int d, const Refine* rf, int far_e, int lo, int hi, int* ub_band) {
+    int ub = 0, ubb = 0;
+    for (int p = 0; p < r; ++p) {
+        const uint32_t wp = pl.at(p);
+        const int xp0 = (int)(wp & 0xffu), xl0 = (int)((wp >> 8) & 0xffu), lp0 = xl0 - xp0 + 1;
+        const int xpb = imax(xp0, lo), xlb = imin(xl0, hi), lpb = xlb - xpb + 1;
+        const bool in_band = xlb >= xpb, cut_lo = xpb != xp0;
+        int g = 0, gb = 0, e = 0;
+        bool band_open = in_band && !cut_lo;                             // (a piece cut at its low end has no in-band predecessor)
+        for (int q = p - 1; q >= 0; --q) {
+            const uint32_t wq = pl.at(q);
+            const int xq0 = (int)(wq & 0xffu), ql0 = (int)((wq >> 8) & 0xffu), lq0 = ql0 - xq0 + 1;
+            const int gq = (int)(wq >> 24), gqb = (int)((wq >> 16) & 0xffu);
+            const int D = xp0 - (ql0 + 1);
+            e += (int)((zc >> (4 * (q + 1))) & 15u);
+            const int Js = D == 0 ? 0 : join_same(D, e);
+            const bool refine = rf && D > 0 && Js < 6 * e - D && e < 15;
+            const int mu = imax(0, 6 * e - D - 8);
+            int J = Js;
+            if (refine) {
+                const int inside = corridor_cost(rf->x, rf->m, rf->yb, rf->n, ql0, d, D, imin(mu, lq0 - 1), imin(mu, lp0 - 1));
+                J = imin(6 * e - D, imin(inside, join_gap3_far(D, far_e)));
+            }
+            g = imax(g, lq0 + gq - J);
+            if (band_open) {
+                if (ql0 < lo) band_open = false;                         // q and everything before it: out of band
+                else {
+                    const int lqb = ql0 - imax(xq0, lo) + 1;
+                    int Jb = J;
+                    if (refine && (imin(mu, lqb - 1) != imin(mu, lq0 - 1) || imin(mu, lpb - 1) != imin(mu, lp0 - 1))) {
+                        const int inside = corridor_cost(rf->x, rf->m, rf->yb, rf->n, ql0, d, D, imin(mu, lqb - 1), imin(mu, lpb - 1));
+                        Jb = imin(6 * e - D, imin(inside, join_gap3_far(D, far_e)));
+                    }
+                    gb = imax(gb, lqb + gqb - Jb);
+                }
+            }
+        }
+        pl.at(p) = (wp & 0x0000ffffu) | ((uint32_t)(in_band ? gb : 0) << 16) | ((uint32_t)g << 24);
+        ub = imax(ub, lp0 + g);
+        if (in_band) ubb = imax(ubb, lpb + gb);
+    }
+    *ub_band = ubb;
+    return ub;
+}
+
 // After back_rest left a task W_NOT_TIGHT with main pieces only (aux = its far k-mer matches): the bound of the BANDED score.
 // Returns the score (= the certificate) or -1.
 template <class LN> VTXF_FN int32_t band_trim_verdict(const Front& fr, int m, const LN& ln, uint32_t far_e, const Refine* rf) {
