@@ -1624,19 +1624,15 @@ int vtx_run(vtx_ctx* c) {
                                                 c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
                                                 c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len,
                                                 c->d_recheck2.as<uint32_t>(), c->d_recheck2_pack.as<uint32_t>(), d_cnt + 25, stage, s));
-                // How many did the check leave?  A few hundred of millions — and a masked-DP grid sized for the bound (n_tight2) is 130 000
-                // workgroups that start, read the count and leave: 13 ms of dispatch per list on the real-sequence workload, a sixth of
-                // its step (round 6: found in the kernel table — sw_banded_kernel<.., 2> three times 13.2 ms for 0.5 M tasks).  One more
-                // host round trip instead: the stream holds nothing else behind the check at this point.
-                HIP_TRY(c, hipMemcpyAsync(c->h_pin + 20, d_cnt + 25, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                HIP_TRY(c, hipStreamSynchronize(s));
-                const uint32_t n_recheck = std::min(c->h_pin[20], n_tight2);
-                if (n_recheck)
-                    HIP_TRY(c, vtxk_launch_sw_diag_band(kShapes[shape][0], kShapes[shape][1], n_recheck, c->d_recheck2.as<uint32_t>(),
-                                                        c->d_recheck2_pack.as<uint32_t>(), nullptr, c->d_records.as<vtx_record>(),
-                                                        c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
-                                                        c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
-                                                        c->max_hap_len, stage, s));
+                HIP_TRY(c, vtxk_launch_sw_diag_band(kShapes[shape][0], kShapes[shape][1], n_tight2, c->d_recheck2.as<uint32_t>(),
+                                                    c->d_recheck2_pack.as<uint32_t>(), d_cnt + 25, c->d_records.as<vtx_record>(),
+                                                    c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                                    c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
+                                                    c->max_hap_len, stage, s));
+                // (its grid is sized for n_tight2 although a few hundred tasks remain: the workgroups past the device count leave at once —
+                //  measured in round 6 with an exact-size launch behind a host round trip: no difference.  The 3 x 13 ms of
+                //  sw_banded_kernel<.., 2> in the real-sequence kernel table are ONE launch of 39 ms — the first stage's 0.5 M one-diagonal
+                //  bands on the side stream, stretched by the kernels it runs beside — and two of microseconds.)
                 launches += 2;
                 tight2_total += n_tight2;
             }
