@@ -22,7 +22,8 @@
  * A consequence that rests on the same recollections (round-5 ADVICE): the `whole_read` shortcut of band_diag_kernel / band_diag2_kernel
  * (vtx_fast_core.h) — a read that matches its haplotype base for base on one diagonal is scored m before any k-mer probe — assumes
  * sdpkpp's rules as recalled (a jump always costs gap_open + gap_extend per base, a match's dp never exceeds x + K) and the band's
- * end event at + k.  It agrees with oracle/vtx_oracle.c on every test; should the crate's sdpkpp differ, libvtx_dev.so runs without
+ * end event at + k.  It agrees with oracle/vtx_oracle.c on every test (tests/golden/band_kat.json carries 24 such vectors, `whole_read`:
+ * the Rust replay of INTEGRATION.md section 5 prints what the crate gives on them); should the crate's sdpkpp differ, libvtx_dev.so runs without
  * the shortcut under VTX_DIAG_ABLATE=10 (tests/test_gpu_stress.py::test_whole_read_shortcut_on_and_off) for an A/B comparison.
  *
  * The call site these implement is src/main.rs:898-901, `banded::Aligner::new(-5, -1, score, 6, 20)`.

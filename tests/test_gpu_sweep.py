@@ -324,6 +324,12 @@ for label, batch, nb in batches:
     looked += t.diag2_tasks; scored += t.diag2_scored; streamed += t.diag2_streamed
     print(label, "second stage looked at", t.diag2_tasks, "scored", t.diag2_scored, "streamed", t.diag2_streamed, "one-diagonal bands", t.checked_tasks, "swept", t.swept_tasks, file=sys.stderr)
     np.save(os.path.join(sys.argv[1], "s%%d.npy" %% len(os.listdir(sys.argv[1]))), np.concatenate([rb, ab]))
+if os.environ.get("VTXT_OVERFLOW_PATH"):
+    # (nothing reached the stage from band_diag_kernel's repeat list — VTX_BAND_DENSE_MASK=0 keeps it empty: every task it looked at came
+    # from band_run_kernel's overflow list, the last-chunk call)
+    assert looked > 300, looked
+    print("second-stage-ok", looked, scored, streamed)
+    sys.exit(0)
 assert looked > 3000 and scored > 300, (looked, scored)
 if not os.environ.get("VTX_BAND_NO_STREAM"):
     assert streamed > 300, streamed
@@ -352,3 +358,17 @@ def test_second_stage_against_the_oracle():
         assert files and files == sorted(os.listdir(os.path.join(td, "1")))
         for f in files:
             assert np.array_equal(np.load(os.path.join(td, "0", f)), np.load(os.path.join(td, "1", f))), f
+
+
+def test_second_stage_on_the_overflow_list_of_band_run_kernel():
+    """Round-5 ADVICE: the LAST-CHUNK call of the second stage — on what overflowed band_run_kernel's piece lists (vtx_run: `nA`, tables
+    of every locus still resident, d_dense reused as its output) — had no test of its own: small batches never send anything to
+    band_run_kernel (a short fail list joins the repeats).  libvtx_dev.so with VTX_BAND_RUN_MIN=1 (band_run_kernel takes every list)
+    and VTX_BAND_DENSE_MASK=0 (band_diag_kernel sends it the repeats too) makes its lists overflow on repeat-rich loci; with
+    VTX_BAND_DIAG2_MIN=1 the overflow list then takes the second stage.  Every score against the oracle, stage invariant, poison."""
+    with tempfile.TemporaryDirectory() as td:
+        env = dict(os.environ, VTX_LIB_VARIANT="dev", VTX_BAND_DIAG2_MIN="1", VTX_BAND_RUN_MIN="1", VTX_BAND_DENSE_MASK="0",
+                   VTXT_OVERFLOW_PATH="1")
+        p = subprocess.run([sys.executable, "-c", CODE2, td], env=env, capture_output=True, text=True, timeout=1500)
+        assert p.returncode == 0 and "second-stage-ok" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+        print(p.stderr.strip().replace("\n", " | "))

@@ -95,6 +95,26 @@ def no_seed_pairs(n, seed=11):
     return out
 
 
+def whole_read_pairs(n, seed=29):
+    """Reads that match their haplotype base for base on one diagonal — in random sequence, inside tandem repeats (the read then matches
+    on SEVERAL diagonals) and hanging against either end of the window.  The device scores such a task len(read) before any k-mer
+    probe (`whole_read`, vtx_fast_core.h); that rests on sdpkpp as recalled (include/vtx_band_semantics.h, last paragraph)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        kind = len(out) % 3
+        if kind == 1:                                            # a tandem repeat in the middle of the window
+            unit = bytes(rng.choice(list(b"ACGT"), int(rng.integers(2, 13))).tolist())
+            core = (unit * 40)[:int(rng.integers(30, 120))]
+            hap = bytes(rng.choice(list(b"ACGT"), int(rng.integers(20, 80))).tolist()) + core + bytes(rng.choice(list(b"ACGT"), int(rng.integers(20, 80))).tolist())
+        else:
+            hap = bytes(rng.choice(list(b"ACGT"), int(rng.integers(80, 230))).tolist())
+        m = int(rng.integers(20, min(150, len(hap)) + 1))
+        a = 0 if kind == 2 and len(out) % 2 == 0 else (len(hap) - m if kind == 2 else int(rng.integers(0, len(hap) - m + 1)))
+        out.append((hap[a:a + m], hap))
+    return out
+
+
 def main():
     vectors, seen = [], set()
     sources = [("error models and indels", SB.synthetic_batches(per_model=1, n_loci=30, reads=12), 500, 10),
@@ -131,6 +151,19 @@ def main():
         vectors.append({"kind": "no common 6-mer", "from": "tools/make_band_kat.py: no_seed_pairs", "read": x.decode("latin-1"), "hap": y.decode("latin-1"),
                         "banded_score": int(oracle.sw_banded(x, y)), "full_score": int(oracle.sw_full(x, y)), "band_cells": int(cells),
                         "chain_diagonals": 0, "kmer_matches": 0, "lo_rle": rle(lo), "hi_rle": rle(hi)})
+    for x, y in whole_read_pairs(24):
+        lo, hi, cells = oracle.band_create(x, y)
+        mt = oracle.kmer_matches(x, y)
+        chain, _ = oracle.sdpkpp(mt) if len(mt) else ([], 0)
+        vectors.append({"kind": "whole read", "from": "tools/make_band_kat.py: whole_read_pairs", "read": x.decode("latin-1"), "hap": y.decode("latin-1"),
+                        "banded_score": int(oracle.sw_banded(x, y)), "full_score": int(oracle.sw_full(x, y)), "band_cells": int(cells),
+                        "chain_diagonals": len({int(mt[p, 1]) - int(mt[p, 0]) for p in chain}), "kmer_matches": int(len(mt)),
+                        "lo_rle": rle(lo), "hi_rle": rle(hi)})
+    n_whole = 0
+    for v in vectors:                                            # (any vector of the file, not only the ones made for it)
+        v["whole_read"] = v["read"] in v["hap"]
+        n_whole += v["whole_read"]
+        assert not v["whole_read"] or v["banded_score"] == len(v["read"]) == v["full_score"], v["read"]
     per_detail = {}
     for v in vectors:
         x, y = v["read"].encode("latin-1"), v["hap"].encode("latin-1")
@@ -145,6 +178,11 @@ def main():
            "k": 6, "w": 20, "scoring": {"match": 1, "mismatch": -5, "gap_open": -5, "gap_extend": -1},
            "recollected_details": {"lazy_extension": "2 * k", "kmer_last_anchor": "k", "no_seed": "full matrix", "sdpkpp_ties": "larger match index"},
            "discriminating_vectors": per_detail,
+           "whole_read": "%d vectors carry whole_read = true: the read occurs in the haplotype base for base.  The device scores such a task len(read) "
+                         "before any k-mer probe (vtx_fast_core.h: whole_read); the argument rests on sdpkpp as recalled (a jump always costs gap_open "
+                         "+ gap_extend per base, a match's dp never exceeds x + k) and on the band's end event at + k — include/vtx_band_semantics.h, "
+                         "last paragraph.  If the crate gives another score on exactly these vectors, rebuild with the shortcut off (libvtx_dev.so, "
+                         "VTX_DIAG_ABLATE=10) and compare" % n_whole,
            "how_to_read_a_failure": "every vector carries `discriminates`: the recollected details whose ALTERNATIVE would change its banded score "
                                     "(banded_score_then) or its band.  If the crate disagrees with banded_score exactly on the vectors that list "
                                     "one detail, and agrees with their banded_score_then, that detail's constant in include/vtx_band_semantics.h "

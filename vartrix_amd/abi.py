@@ -310,6 +310,30 @@ class PackedBatch:
         out[1::2] = lut[self.read_arena & 15]
         return PackedBatch(self.loci, self.records, self.hap_arena, out, READS_BYTES)
 
+    @staticmethod
+    def concat(parts) -> "PackedBatch":
+        """The loci of several self-contained batches one after the other (rows renumbered 0, 1, ...): how tests put ONE unusual
+        locus into the middle of an ordinary batch.  Byte-per-base arenas only."""
+        parts = [p for p in parts if p.n_loci]
+        assert all(p.read_format == READS_BYTES for p in parts)
+        loci, recs = [], []
+        r0 = h0 = a0 = 0
+        for p in parts:
+            l, r = p.loci.copy(), p.records.copy()
+            l["rec_begin"] += r0
+            l["ref_off"] += h0
+            l["alt_off"] += h0
+            r["read_off"] += a0
+            loci.append(l)
+            recs.append(r)
+            r0 += p.n_records
+            h0 += int(p.hap_arena.size)
+            a0 += int(p.read_arena.size)
+        out = PackedBatch(np.concatenate(loci), np.concatenate(recs), np.concatenate([p.hap_arena for p in parts]),
+                          np.concatenate([p.read_arena for p in parts]))
+        out.loci["row"] = np.arange(out.n_loci, dtype=np.uint32)
+        return out
+
     def slice_loci(self, lo: int, hi: int) -> "PackedBatch":
         """Contiguous sub-batch [lo, hi) of loci, re-based so it is self-contained.
 

@@ -144,6 +144,9 @@ struct vtx_ctx {
     uint64_t bam_utotal = 0, bam_read_bases = 0, bam_tag_bytes = 0;
     uint32_t max_read_len = 0, fast_overflow = 0;
     uint32_t slow_off = 0, slow_cnt = 0, max_hap_all = 0, max_read_all = 0;   // records of the slow list (d_work[slow_off ..])
+    // a batch that mixes haplotypes of <= 255 bases with longer ones (note_long_loci; vtx_run's two banded passes): the longest haplotype
+    // among the former, how many loci the latter are, the first and the last of them
+    uint32_t hap_short_max = 0, n_long_loci = 0, long_first = 0, long_last = 0;
     DevBuf d_slow_ws, d_slow_retry;
     // host -> device feed: pinned staging buffers + one stream per copy worker (see upload())
     static constexpr int kUpWorkers = 6, kUpSlots = 2;
@@ -680,6 +683,20 @@ void vtx_destroy(vtx_ctx* c) {
     delete c;
 }
 
+// Which loci of the batch have a haplotype above 255 bases (and within the fast kernels' limit)?  One of them used to put the WHOLE batch
+// on round 3's path (four-byte match entries, no sweep, no second stage); vtx_run now scores them in a pass of their own (round 6).
+static void note_long_loci(vtx_ctx* c, const vtx_locus* loci, uint32_t nl) {
+    c->hap_short_max = c->n_long_loci = c->long_first = c->long_last = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+        const uint32_t hl = std::max(loci[l].ref_len, loci[l].alt_len);
+        if (hl <= 255) c->hap_short_max = std::max(c->hap_short_max, hl);
+        else if (hl <= kFastHapLen) {
+            if (!c->n_long_loci++) c->long_first = l;
+            c->long_last = l;
+        }
+    }
+}
+
 // ---- buffers of the banded stage -------------------------------------------------------------------------------
 // One launch covers every task unless a test hook asks for chunks.  The scratch of band_run_kernel belongs to its
 // RESIDENT lanes (persistent workgroups).  Hard tasks leave band_run_kernel / band_pending_kernel as compact staircase
@@ -782,6 +799,7 @@ int vtx_submit(vtx_ctx* c, const vtx_batch* b) {
         next_rec = L.rec_begin + L.rec_count;
     }
     if (next_rec != nr) return fail(c, VTX_E_INVAL, "vtx_submit: %u records not covered by any locus", nr - next_rec);
+    note_long_loci(c, b->loci, nl);
 
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const size_t u32 = sizeof(uint32_t), u64 = sizeof(uint64_t);
@@ -1065,6 +1083,7 @@ int vtx_submit_raw(vtx_ctx* c, const vtx_raw_batch* b, vtx_raw_stats* stats) {
     }
     if (next_rec != nr) return fail(c, VTX_E_INVAL, "vtx_submit_raw: %u records not covered by any locus", nr - next_rec);
     if (int rc = check_loci_haps(c, "vtx_submit_raw", b->loci, nl, b->hap_bytes, &max_hap, &max_hap_all)) return rc;
+    note_long_loci(c, b->loci, nl);
 
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
@@ -1127,6 +1146,7 @@ int vtx_submit_bam(vtx_ctx* c, const vtx_bam_ingest* g, vtx_ingest_stats* st) {
     if (g->hap_bytes > 0xffffffffull) return fail(c, VTX_E_UNSUPPORTED, "vtx_submit_bam: hap arena above 4 GiB");
     uint32_t max_hap = 0, max_hap_all = 0;
     if (int rc = check_loci_haps(c, "vtx_submit_bam", g->loci, nl, g->hap_bytes, &max_hap, &max_hap_all)) return rc;
+    note_long_loci(c, g->loci, nl);
     if (g->tid_begin[0] != 0 || g->tid_begin[g->n_ref] != g->n_intervals) return fail(c, VTX_E_INVAL, "vtx_submit_bam: tid_begin does not cover the intervals");
     for (uint32_t t = 0; t < g->n_ref; ++t) {
         if (g->tid_begin[t] > g->tid_begin[t + 1]) return fail(c, VTX_E_INVAL, "vtx_submit_bam: tid_begin not ascending at %u", t);
@@ -1417,590 +1437,619 @@ int vtx_run(vtx_ctx* c) {
     float band_run_ms = 0;
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
     if (c->cfg.aligner == VTX_ALIGNER_BANDED && nr) {
-        // Banded flavour.  Per chunk of tasks (task = 2*record + hap), round 4 (the stages are described in vtx_band.hip's header):
-        // tables -> band_diag_kernel (+ band_refine_kernel): scores of the certified tasks, and three lists — tasks whose band is one
-        // diagonal stretch (masked DP straight from one word), repeats (band_sweep_kernel + masked DP), the others (band_run_kernel:
-        // seeds, chain, general certificate; its hard list -> expand -> masked DP).  What overflows band_run_kernel's lists joins the
-        // repeats after the last chunk; what band_sweep_kernel declines twice takes the general band kernel (side stream).
-        // Counters (d_cnt, 64 words, zeroed once per run unless noted): [0] hard / [1] overflow / [2..7] reasons / [10] / [11] pending of
-        // band_run_kernel (0 and 11 per chunk); [8], [9] general kernel; [12] tasks for band_run_kernel, [13] for band_sweep_kernel,
-        // [14] refine records, [15] one-diagonal bands (12..15 per chunk); [16..23] band_run_kernel's block counters; [24] full-matrix
-        // check; [26] / [27] hard (per slice) / declined of the sweep's first pass, [28] / [29] of its second; [32..47] reasons of
-        // band_diag_kernel; [56..63] reasons of band_sweep_kernel.
-        BandPlan bp = band_plan(nr, c->n_loci, c->max_hap_len);
-        if (int rc = band_reserve(c, bp, false)) return rc;
-        const uint64_t n_tasks = bp.n_tasks;
-        const uint32_t chunk = bp.chunk, band_stride = bp.band_stride, hard_cap = bp.hard_cap, pend_cap = bp.pend_cap;
-        const uint32_t slots = bp.slots, poly_stride = bp.poly_stride, tasks_per_locus = bp.tasks_per_locus;
-        const size_t gt_bytes = bp.gt_bytes;
-        const bool gt_chunked = gt_bytes && bp.gt_loci < c->n_loci;
-        uint32_t fast_overflow = 0;
-        uint32_t* d_cnt = c->d_cnt.as<uint32_t>();
-        int shape = 0;
-        while ((uint32_t)(kShapes[shape][0] * kShapes[shape][1]) < c->max_read_len) ++shape;
-        // src == nullptr: the band slots already hold arrays (or the full-matrix marker), one slot per task
-        auto masked_dp = [&](uint32_t n_hard, uint32_t* hard, const uint16_t* src, uint16_t* band, uint32_t n_slots, hipStream_t st, uint8_t code) -> int {
-            if (stage) HIP_TRY(c, vtxk_mark_stage(hard, n_hard, nullptr, code, stage, st));
-            for (uint32_t off = 0; off < n_hard; off += n_slots) {
-                const uint32_t cnt_s = std::min(n_slots, n_hard - off);
-                HIP_TRY(c, vtxk_launch_band_expand(hard + off, cnt_s, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                                   c->d_loci.as<vtx_locus>(), src ? src + (size_t)off * poly_stride : band,
-                                                   src ? poly_stride : 2 * band_stride, band, band_stride, st));
-                HIP_TRY(c, vtxk_launch_sw_banded(kShapes[shape][0], kShapes[shape][1], cnt_s, hard + off, c->d_records.as<vtx_record>(),
-                                                 c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
-                                                 c->d_hap.as<uint8_t>(), band, band_stride, c->d_ref.as<int32_t>(),
-                                                 c->d_alt.as<int32_t>(), c->max_hap_len, st));
-                launches += 2;
+        // One pass of the banded stages over tasks [t_begin, t_end) whose locus has its longer haplotype in (mh_min, mh] (the others
+        // are left alone); chunk_tables: the tables are built per chunk for the loci the chunk spans, whatever the buffer would hold.
+        auto band_pass = [&](const uint32_t mh, const uint32_t mh_min, const uint64_t t_begin, const uint64_t t_end, const bool chunk_tables) -> int {
+            // Banded flavour.  Per chunk of tasks (task = 2*record + hap), round 4 (the stages are described in vtx_band.hip's header):
+            // tables -> band_diag_kernel (+ band_refine_kernel): scores of the certified tasks, and three lists — tasks whose band is one
+            // diagonal stretch (masked DP straight from one word), repeats (band_sweep_kernel + masked DP), the others (band_run_kernel:
+            // seeds, chain, general certificate; its hard list -> expand -> masked DP).  What overflows band_run_kernel's lists joins the
+            // repeats after the last chunk; what band_sweep_kernel declines twice takes the general band kernel (side stream).
+            // Counters (d_cnt, 64 words, zeroed once per run unless noted): [0] hard / [1] overflow / [2..7] reasons / [10] / [11] pending of
+            // band_run_kernel (0 and 11 per chunk); [8], [9] general kernel; [12] tasks for band_run_kernel, [13] for band_sweep_kernel,
+            // [14] refine records, [15] one-diagonal bands (12..15 per chunk); [16..23] band_run_kernel's block counters; [24] full-matrix
+            // check; [26] / [27] hard (per slice) / declined of the sweep's first pass, [28] / [29] of its second; [32..47] reasons of
+            // band_diag_kernel; [56..63] reasons of band_sweep_kernel.
+            BandPlan bp = band_plan(nr, c->n_loci, mh);
+            if (int rc = band_reserve(c, bp, false)) return rc;
+            const uint64_t n_tasks = bp.n_tasks;
+            const uint32_t chunk = bp.chunk, band_stride = bp.band_stride, hard_cap = bp.hard_cap, pend_cap = bp.pend_cap;
+            const uint32_t slots = bp.slots, poly_stride = bp.poly_stride, tasks_per_locus = bp.tasks_per_locus;
+            const size_t gt_bytes = bp.gt_bytes;
+            const bool gt_chunked = gt_bytes && (bp.gt_loci < c->n_loci || chunk_tables);
+            uint32_t fast_overflow = 0;
+            uint32_t* d_cnt = c->d_cnt.as<uint32_t>();
+            int shape = 0;
+            while ((uint32_t)(kShapes[shape][0] * kShapes[shape][1]) < c->max_read_len) ++shape;
+            // src == nullptr: the band slots already hold arrays (or the full-matrix marker), one slot per task
+            auto masked_dp = [&](uint32_t n_hard, uint32_t* hard, const uint16_t* src, uint16_t* band, uint32_t n_slots, hipStream_t st, uint8_t code) -> int {
+                if (stage) HIP_TRY(c, vtxk_mark_stage(hard, n_hard, nullptr, code, stage, st));
+                for (uint32_t off = 0; off < n_hard; off += n_slots) {
+                    const uint32_t cnt_s = std::min(n_slots, n_hard - off);
+                    HIP_TRY(c, vtxk_launch_band_expand(hard + off, cnt_s, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                       c->d_loci.as<vtx_locus>(), src ? src + (size_t)off * poly_stride : band,
+                                                       src ? poly_stride : 2 * band_stride, band, band_stride, st));
+                    HIP_TRY(c, vtxk_launch_sw_banded(kShapes[shape][0], kShapes[shape][1], cnt_s, hard + off, c->d_records.as<vtx_record>(),
+                                                     c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                                     c->d_hap.as<uint8_t>(), band, band_stride, c->d_ref.as<int32_t>(),
+                                                     c->d_alt.as<int32_t>(), mh, st));
+                    launches += 2;
+                }
+                return VTX_OK;
+            };
+            // The general band kernel (tasks band_run_kernel could not hold) is a handful of serial lanes: ~4.5 ms of latency
+            // for 0.1 % of config 3.  It runs on a side stream, with its own hard list, beside the pending kernel and the
+            // masked DP of the last chunk.  Started once the overflow list is complete; finished (host loop: slabs grow
+            // until every task fits) after the main path's launches are queued.
+            if (!c->stream2) {
+                HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+                HIP_TRY(c, hipEventCreateWithFlags(&c->ev2, hipEventDisableTiming));
+                HIP_TRY(c, hipHostMalloc((void**)&c->h_pin, 64 * sizeof(uint32_t), hipHostMallocDefault));
             }
-            return VTX_OK;
-        };
-        // The general band kernel (tasks band_run_kernel could not hold) is a handful of serial lanes: ~4.5 ms of latency
-        // for 0.1 % of config 3.  It runs on a side stream, with its own hard list, beside the pending kernel and the
-        // masked DP of the last chunk.  Started once the overflow list is complete; finished (host loop: slabs grow
-        // until every task fits) after the main path's launches are queued.
-        if (!c->stream2) {
-            HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->ev2, hipEventDisableTiming));
-            HIP_TRY(c, hipHostMalloc((void**)&c->h_pin, 64 * sizeof(uint32_t), hipHostMallocDefault));
-        }
-        hipStream_t s2 = c->stream2;
-        struct { uint32_t n_over = 0, cap2 = 0, todo = 0, off = 0, total = 0; const uint32_t* tasks = nullptr; bool active = false; uint32_t gcnt[2] = {0, 0}; } fb;
-        // A few overflow tasks (shallow data: some hundreds per run) first try the in-LDS variant of the general kernel
-        // with a slab for kLdsMatches k-mer matches: their ~2 ms of serial HBM latency were a third of a shallow step.
-        const uint32_t kLdsMatches = 512;
-        static const uint32_t kLdsTasks = VTX_DEV_ENV("VTX_BAND_LDS_TASKS") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_BAND_LDS_TASKS")) : 4096u;   // experiment knob
-        auto fallback_launch = [&]() -> int {
-            const uint64_t worst = (uint64_t)c->max_read_len * c->max_hap_len;
-            if (fb.cap2 >= worst && fb.cap2 >= 512) return fail(c, VTX_E_STATE, "vtx_run: band kernel overflow with a worst-case slab");
-            // first three rounds: the cooperative kernel, everything in LDS (band_coop_kernel: a wavefront per task, up to 512 matches,
-            // then 1024, then 4096; reads up to 256 bases); what that cannot hold takes the serial kernel below
-            static const bool no_coop = VTX_DEV_ENV("VTX_BAND_NO_COOP") != nullptr;             // experiment / test hook
-            const int tier = fb.cap2 < 512 ? 0 : (fb.cap2 == 512 ? 1 : (fb.cap2 == 1024 ? 2 : -1));
-            const uint32_t tier_cap = tier == 0 ? 512u : (tier == 1 ? 1024u : 4096u);
-            // (haplotypes up to 1000 bases: the kernel walks its Fenwick tree in ten unrolled steps, tn = n + 8 < 1024)
-            if (tier >= 0 && !no_coop && c->max_read_len <= 256 && c->max_hap_len <= 1000 &&
-                vtxk_band_coop_lds(c->max_hap_len, tier_cap) <= 64u * 1024) {
-                fb.cap2 = tier_cap;
+            hipStream_t s2 = c->stream2;
+            struct { uint32_t n_over = 0, cap2 = 0, todo = 0, off = 0, total = 0; const uint32_t* tasks = nullptr; bool active = false; uint32_t gcnt[2] = {0, 0}; } fb;
+            // A few overflow tasks (shallow data: some hundreds per run) first try the in-LDS variant of the general kernel
+            // with a slab for kLdsMatches k-mer matches: their ~2 ms of serial HBM latency were a third of a shallow step.
+            const uint32_t kLdsMatches = 512;
+            static const uint32_t kLdsTasks = VTX_DEV_ENV("VTX_BAND_LDS_TASKS") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_BAND_LDS_TASKS")) : 4096u;   // experiment knob
+            auto fallback_launch = [&]() -> int {
+                const uint64_t worst = (uint64_t)c->max_read_len * mh;
+                if (fb.cap2 >= worst && fb.cap2 >= 512) return fail(c, VTX_E_STATE, "vtx_run: band kernel overflow with a worst-case slab");
+                // first three rounds: the cooperative kernel, everything in LDS (band_coop_kernel: a wavefront per task, up to 512 matches,
+                // then 1024, then 4096; reads up to 256 bases); what that cannot hold takes the serial kernel below
+                static const bool no_coop = VTX_DEV_ENV("VTX_BAND_NO_COOP") != nullptr;             // experiment / test hook
+                const int tier = fb.cap2 < 512 ? 0 : (fb.cap2 == 512 ? 1 : (fb.cap2 == 1024 ? 2 : -1));
+                const uint32_t tier_cap = tier == 0 ? 512u : (tier == 1 ? 1024u : 4096u);
+                // (haplotypes up to 1000 bases: the kernel walks its Fenwick tree in ten unrolled steps, tn = n + 8 < 1024)
+                if (tier >= 0 && !no_coop && c->max_read_len <= 256 && mh <= 1000 &&
+                    vtxk_band_coop_lds(mh, tier_cap) <= 64u * 1024) {
+                    fb.cap2 = tier_cap;
+                    HIP_TRY(c, hipMemsetAsync(d_cnt + 9, 0, sizeof(uint32_t), s2));
+                    uint32_t* other = c->d_over2.as<uint32_t>() + ((fb.tasks == c->d_over2.as<uint32_t>()) ? fb.n_over : 0);
+                    HIP_TRY(c, vtxk_launch_band_coop(tier, fb.tasks, fb.todo, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                     c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), mh,
+                                                     c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_band2.as<uint16_t>(), band_stride,
+                                                     c->d_hard2.as<uint32_t>(), other, d_cnt + 8, s2));
+                    HIP_TRY(c, hipMemcpyAsync(c->h_pin, d_cnt + 8, sizeof fb.gcnt, hipMemcpyDeviceToHost, s2));
+                    ++launches;
+                    return VTX_OK;
+                }
+                const bool in_lds = fb.cap2 < 512 && fb.todo <= kLdsTasks && !VTX_DEV_ENV("VTX_BAND_NO_LDS_FALLBACK") &&
+                                    vtxk_band_lds_stride(kLdsMatches, mh, c->max_read_len) <= 160 * 1024 - 512;
+                fb.cap2 = in_lds ? kLdsMatches : (uint32_t)std::max<uint64_t>(std::min<uint64_t>((uint64_t)fb.cap2 * 16, worst), 512);
+                const size_t stride2 = vtxk_band_ws_stride(fb.cap2, mh);
+                if (!in_lds) {                                                  // whole wavefronts: the 64 slabs are interleaved, vtxk_band_lanes() of them in use
+                    const size_t lanes = vtxk_band_lanes(fb.todo);
+                    HIP_TRY(c, c->d_band_ws2.reserve(lanes < 64 ? (size_t)fb.todo * stride2 : ((size_t)fb.todo + 63) / 64 * 64 * stride2));   // (sparse lanes: a contiguous slab per task)
+                }
                 HIP_TRY(c, hipMemsetAsync(d_cnt + 9, 0, sizeof(uint32_t), s2));
                 uint32_t* other = c->d_over2.as<uint32_t>() + ((fb.tasks == c->d_over2.as<uint32_t>()) ? fb.n_over : 0);
-                HIP_TRY(c, vtxk_launch_band_coop(tier, fb.tasks, fb.todo, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                                 c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->max_hap_len,
-                                                 c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_band2.as<uint16_t>(), band_stride,
-                                                 c->d_hard2.as<uint32_t>(), other, d_cnt + 8, s2));
-                HIP_TRY(c, hipMemcpyAsync(c->h_pin, d_cnt + 8, sizeof fb.gcnt, hipMemcpyDeviceToHost, s2));
+                HIP_TRY(c, vtxk_launch_band(fb.tasks, fb.todo, 0, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                            c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                            c->d_band_ws2.as<uint8_t>(), stride2, fb.cap2, mh, c->d_ref.as<int32_t>(),
+                                            c->d_alt.as<int32_t>(), c->d_band2.as<uint16_t>(), band_stride, c->d_hard2.as<uint32_t>(),
+                                            other, d_cnt + 8, in_lds ? 1 : 0, c->max_read_len, s2));
+                HIP_TRY(c, hipMemcpyAsync(c->h_pin, d_cnt + 8, sizeof fb.gcnt, hipMemcpyDeviceToHost, s2));   // pinned: does not block
                 ++launches;
                 return VTX_OK;
-            }
-            const bool in_lds = fb.cap2 < 512 && fb.todo <= kLdsTasks && !VTX_DEV_ENV("VTX_BAND_NO_LDS_FALLBACK") &&
-                                vtxk_band_lds_stride(kLdsMatches, c->max_hap_len, c->max_read_len) <= 160 * 1024 - 512;
-            fb.cap2 = in_lds ? kLdsMatches : (uint32_t)std::max<uint64_t>(std::min<uint64_t>((uint64_t)fb.cap2 * 16, worst), 512);
-            const size_t stride2 = vtxk_band_ws_stride(fb.cap2, c->max_hap_len);
-            if (!in_lds) {                                                  // whole wavefronts: the 64 slabs are interleaved, vtxk_band_lanes() of them in use
-                const size_t lanes = vtxk_band_lanes(fb.todo);
-                HIP_TRY(c, c->d_band_ws2.reserve(lanes < 64 ? (size_t)fb.todo * stride2 : ((size_t)fb.todo + 63) / 64 * 64 * stride2));   // (sparse lanes: a contiguous slab per task)
-            }
-            HIP_TRY(c, hipMemsetAsync(d_cnt + 9, 0, sizeof(uint32_t), s2));
-            uint32_t* other = c->d_over2.as<uint32_t>() + ((fb.tasks == c->d_over2.as<uint32_t>()) ? fb.n_over : 0);
-            HIP_TRY(c, vtxk_launch_band(fb.tasks, fb.todo, 0, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                        c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
-                                        c->d_band_ws2.as<uint8_t>(), stride2, fb.cap2, c->max_hap_len, c->d_ref.as<int32_t>(),
-                                        c->d_alt.as<int32_t>(), c->d_band2.as<uint16_t>(), band_stride, c->d_hard2.as<uint32_t>(),
-                                        other, d_cnt + 8, in_lds ? 1 : 0, c->max_read_len, s2));
-            HIP_TRY(c, hipMemcpyAsync(c->h_pin, d_cnt + 8, sizeof fb.gcnt, hipMemcpyDeviceToHost, s2));   // pinned: does not block
-            ++launches;
-            return VTX_OK;
-        };
-        auto fallback_start = [&](uint32_t off, uint32_t total) -> int {   // the overflow list d_over[0, total) is complete and visible
-            const uint32_t n_over = std::min(std::max(slots, 1024u), total - off);   // slices (bounds d_band2)
-            fb.off = off; fb.total = total;
-            fb.n_over = n_over; fb.todo = n_over; fb.cap2 = 512 / 16; fb.tasks = c->d_over.as<uint32_t>() + off; fb.active = true;
-            HIP_TRY(c, c->d_over2.reserve(2 * (size_t)n_over * sizeof(uint32_t)));
-            HIP_TRY(c, c->d_hard2.reserve((size_t)n_over * sizeof(uint32_t)));
-            HIP_TRY(c, c->d_band2.reserve((size_t)n_over * 2 * band_stride * sizeof(uint16_t)));
-            HIP_TRY(c, hipMemsetAsync(d_cnt + 8, 0, 2 * sizeof(uint32_t), s2));
-            return fallback_launch();
-        };
-        auto fallback_finish = [&]() -> int {
-            if (!fb.active) return VTX_OK;
-            for (;;) {
+            };
+            auto fallback_start = [&](uint32_t off, uint32_t total) -> int {   // the overflow list d_over[0, total) is complete and visible
+                const uint32_t n_over = std::min(std::max(slots, 1024u), total - off);   // slices (bounds d_band2)
+                fb.off = off; fb.total = total;
+                fb.n_over = n_over; fb.todo = n_over; fb.cap2 = 512 / 16; fb.tasks = c->d_over.as<uint32_t>() + off; fb.active = true;
+                HIP_TRY(c, c->d_over2.reserve(2 * (size_t)n_over * sizeof(uint32_t)));
+                HIP_TRY(c, c->d_hard2.reserve((size_t)n_over * sizeof(uint32_t)));
+                HIP_TRY(c, c->d_band2.reserve((size_t)n_over * 2 * band_stride * sizeof(uint16_t)));
+                HIP_TRY(c, hipMemsetAsync(d_cnt + 8, 0, 2 * sizeof(uint32_t), s2));
+                return fallback_launch();
+            };
+            auto fallback_finish = [&]() -> int {
+                if (!fb.active) return VTX_OK;
                 for (;;) {
-                    HIP_TRY(c, hipStreamSynchronize(s2));
-                    fb.gcnt[0] = c->h_pin[0]; fb.gcnt[1] = c->h_pin[1];
-                    // tasks that still do not fit were written to the other half of d_over2: rerun them with a larger slab
-                    fb.tasks = c->d_over2.as<uint32_t>() + ((fb.tasks == c->d_over2.as<uint32_t>()) ? fb.n_over : 0);
-                    fb.todo = fb.gcnt[1];
-                    if (!fb.todo) break;
-                    if (int rc = fallback_launch()) return rc;
+                    for (;;) {
+                        HIP_TRY(c, hipStreamSynchronize(s2));
+                        fb.gcnt[0] = c->h_pin[0]; fb.gcnt[1] = c->h_pin[1];
+                        // tasks that still do not fit were written to the other half of d_over2: rerun them with a larger slab
+                        fb.tasks = c->d_over2.as<uint32_t>() + ((fb.tasks == c->d_over2.as<uint32_t>()) ? fb.n_over : 0);
+                        fb.todo = fb.gcnt[1];
+                        if (!fb.todo) break;
+                        if (int rc = fallback_launch()) return rc;
+                    }
+                    if (int rc = masked_dp(fb.gcnt[0], c->d_hard2.as<uint32_t>(), nullptr, c->d_band2.as<uint16_t>(), std::max(fb.gcnt[0], 1u), s2, VTX_STAGE_GENERAL_DP)) return rc;
+                    hard_total += fb.gcnt[0];
+                    if (fb.off + fb.n_over >= fb.total) break;
+                    if (int rc = fallback_start(fb.off + fb.n_over, fb.total)) return rc;      // next slice (same stream: in order)
                 }
-                if (int rc = masked_dp(fb.gcnt[0], c->d_hard2.as<uint32_t>(), nullptr, c->d_band2.as<uint16_t>(), std::max(fb.gcnt[0], 1u), s2, VTX_STAGE_GENERAL_DP)) return rc;
-                hard_total += fb.gcnt[0];
-                if (fb.off + fb.n_over >= fb.total) break;
-                if (int rc = fallback_start(fb.off + fb.n_over, fb.total)) return rc;      // next slice (same stream: in order)
-            }
-            HIP_TRY(c, hipEventRecord(c->ev2, s2));
-            HIP_TRY(c, hipStreamWaitEvent(s, c->ev2, 0));             // the reduction kernels read every score
-            return VTX_OK;
-        };
-        HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 64 * sizeof(uint32_t), s));
-        uint32_t cnt[12] = {0};
-        uint32_t pending_total = 0, over_before = 0;
-        uint64_t diag_total = 0, diag_left = 0, refined_total = 0, checked_total = 0, swept_total = 0, diag2_total = 0, diag2_scored = 0, tight2_total = 0, stream_total = 0;
-        float diag_ms = 0, check_ms = 0, sweep_ms = 0;
-        // the band of every listed task (band_sweep_kernel, tier 0 / 1), one slice of band slots at a time, then the masked DP over
-        // the slice (its length — the tasks the sweep did not decline — is read on the device: counters[0]; declined: counters[1])
-        // (libvtx_dev.so, VTX_SWEEP_V1=1: round 4's kernel instead — 256 sections per task, then a second pass with 1 024 over what the
-        // first declined; the A/B reference of tests/test_gpu_sweep.py and tools/gpu_campaign.sh)
-        static const bool sweep_v1 = VTX_DEV_ENV("VTX_SWEEP_V1") != nullptr;
-        auto sweep_slices = [&](int tier, const uint32_t* list, uint32_t n, uint32_t* over_out, uint32_t* counters) -> int {
-            static const bool sweep_stats = getenv("VTX_DEBUG") != nullptr;
-            HIP_TRY(c, c->d_sweep_log.reserve(vtxk_band_sweep_log_bytes()));
-            for (uint32_t off = 0; off < n; off += slots) {
-                const uint32_t cnt_s = std::min(slots, n - off);
-                HIP_TRY(c, hipMemsetAsync(counters, 0, sizeof(uint32_t), s));
-#ifdef VTX_DEVTOOLS
-                if (sweep_v1)
-                    HIP_TRY(c, vtxk_launch_band_sweep_v1(tier, list + off, cnt_s, nullptr, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                                         c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
-                                                         c->d_band.as<uint16_t>(), band_stride, c->d_hard.as<uint32_t>(), over_out,
-                                                         counters, sweep_stats ? d_cnt + 56 : nullptr, stage, nullptr, s));
-                else
-#endif
-                HIP_TRY(c, vtxk_launch_band_sweep(list + off, cnt_s, nullptr, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                                  c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
-                                                  c->d_band.as<uint16_t>(), band_stride, c->d_hard.as<uint32_t>(), over_out,
-                                                  counters, sweep_stats ? d_cnt + 56 : nullptr, stage, nullptr, c->d_sweep_log.as<uint32_t>(), s));
-                (void)tier;
-                HIP_TRY(c, vtxk_launch_sw_banded_dev(kShapes[shape][0], kShapes[shape][1], cnt_s, c->d_hard.as<uint32_t>(), counters,
-                                                     c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
-                                                     c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_band.as<uint16_t>(), band_stride,
-                                                     c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len, s));
-                launches += 2;
-            }
-            return VTX_OK;
-        };
-        uint32_t resweep_total = 0;
-        // Second stage (round 5): the same single-diagonal logic with a list of 64 entries and the harmless bound from
-        // the matches that can really precede a match (band_diag2_kernel), the harmless test alone over a two-row window for what
-        // exceeds the list (band_stream_kernel).  They score most of these tasks or prove that their band is one diagonal stretch
-        // (full-matrix check, masked DP for what it does not settle; no sweep); what they leave — out[0, *n_out) — takes the sweep.
-        // One host round trip for the counts.  (libvtx_dev.so: VTX_BAND_NO_DIAG2=1 sends everything to the sweep, as round 4 did;
-        // VTX_BAND_NO_STREAM=1 — what exceeds the second stage's list goes to the sweep.)
-        // A short list skips it: one lane per task, a few hundred dependent loads each — the kernels are latency chains with a fixed
-        // cost of several milliseconds that the sweep + its DP beat below ~0.65 M tasks.  Measured in round 6 on loci from real sequence
-        // (profiles/r06_second_stage_threshold.txt; stage on / off): 33 k tasks 7.9 / 3.4 ms per step, 145 k 12.8 / 8.6, 319 k 28.9 / 19.9,
-        // 638 k 36.8 / 36.0, 1.28 M 52.2 / 64.3 — round 5's threshold of 200 k made mid-size batches a third slower.
-        // The tables of the tasks' loci have to be resident (gt_l0: first locus of the table buffer).
-        auto second_stage_on = [&](uint32_t n) -> bool {
-            static const bool no_diag2 = VTX_DEV_ENV("VTX_BAND_NO_DIAG2") != nullptr;
-            static const uint32_t diag2_min = VTX_DEV_ENV("VTX_BAND_DIAG2_MIN") ? (uint32_t)strtoul(VTX_DEV_ENV("VTX_BAND_DIAG2_MIN"), nullptr, 10) : 700000u;
-            return !no_diag2 && n >= diag2_min && c->max_hap_len <= 255;
-        };
-        auto second_stage = [&](const uint32_t* list, uint32_t n, uint32_t gt_l0, uint32_t* out, uint32_t* n_out) -> int {
-            static const bool no_stream = VTX_DEV_ENV("VTX_BAND_NO_STREAM") != nullptr;
-            HIP_TRY(c, hipMemsetAsync(d_cnt + 30, 0, 2 * sizeof(uint32_t), s));
-            HIP_TRY(c, hipMemsetAsync(d_cnt + 48, 0, sizeof(uint32_t), s));
-            HIP_TRY(c, vtxk_launch_band_diag2(list, n, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                              c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
-                                              c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), bp.tasks_per_locus, gt_l0,
-                                              c->d_gtables.as<uint8_t>(), out, c->d_tight2.as<uint32_t>(),
-                                              c->d_tight2_pack.as<uint32_t>(), d_cnt + 30,
-                                              no_stream ? nullptr : c->d_recheck2.as<uint32_t>(), c->d_recheck2_pack.as<uint32_t>(), d_cnt + 48, stage, s));
-            HIP_TRY(c, hipMemcpyAsync(c->h_pin + 14, d_cnt + 30, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipMemcpyAsync(c->h_pin + 16, d_cnt + 48, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
-            stream_total += std::min(c->h_pin[16], n);
-            const uint32_t n_sweep = std::min(c->h_pin[14], n);
-            const uint32_t n_tight2 = std::min(c->h_pin[15], n - n_sweep);
-            ++launches;
-            diag2_total += n; diag2_scored += n - n_sweep - n_tight2;
-            if (n_tight2) {
-                // These tasks hold a certificate (a lower bound of the banded score) and sit in repeat-rich sequence on
-                // clean reads: the full-matrix score equals it for practically all of them (4 223 of 4 223 in the CPU
-                // sample), and cert <= banded <= full then decides the task for 5.9 ns where the masked DP takes 10.
-                // What the check does not settle takes the masked DP over its one-diagonal band (count on the device).
-                HIP_TRY(c, hipMemsetAsync(d_cnt + 25, 0, sizeof(uint32_t), s));
-                HIP_TRY(c, vtxk_launch_sw_check(kShapes[shape][0], kShapes[shape][1], n_tight2, c->d_tight2.as<uint32_t>(),
-                                                c->d_tight2_pack.as<uint32_t>(), nullptr, c->d_records.as<vtx_record>(),
-                                                c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
-                                                c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->max_hap_len,
-                                                c->d_recheck2.as<uint32_t>(), c->d_recheck2_pack.as<uint32_t>(), d_cnt + 25, stage, s));
-                HIP_TRY(c, vtxk_launch_sw_diag_band(kShapes[shape][0], kShapes[shape][1], n_tight2, c->d_recheck2.as<uint32_t>(),
-                                                    c->d_recheck2_pack.as<uint32_t>(), d_cnt + 25, c->d_records.as<vtx_record>(),
-                                                    c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
-                                                    c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
-                                                    c->max_hap_len, stage, s));
-                // (its grid is sized for n_tight2 although a few hundred tasks remain: the workgroups past the device count leave at once —
-                //  measured in round 6 with an exact-size launch behind a host round trip: no difference.  The 3 x 13 ms of
-                //  sw_banded_kernel<.., 2> in the real-sequence kernel table are ONE launch of 39 ms — the first stage's 0.5 M one-diagonal
-                //  bands on the side stream, stretched by the kernels it runs beside — and two of microseconds.)
-                launches += 2;
-                tight2_total += n_tight2;
-            }
-            *n_out = n_sweep;
-            return 0;
-        };
-        bool sweep_used = false;                    // some chunk took the round-4 path
-        bool sweep_pending = false;                 // the events of a swept chunk have not been read yet
-        bool sweep_forked = false;                  // ... and that chunk ran its two branches side by side
-        uint32_t fork_nt = 0;
-        auto collect_sweep_times = [&]() -> int {
-            if (!sweep_pending) return VTX_OK;
-            sweep_pending = false;
-            HIP_TRY(c, hipEventSynchronize(c->ev[8]));
-            float ms = 0;
-            // ev[7] .. ev[9]: band_refine_kernel (forked only) + the one-diagonal bands' masked DP; then band_sweep_kernel + its masked
-            // DP (the chunk's repeats) — forked: ev[11] .. ev[8] on the main stream, BESIDE the first interval, not after it
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[7], c->ev[9])); check_ms += ms;
-            HIP_TRY(c, hipEventElapsedTime(&ms, sweep_forked ? c->ev[11] : c->ev[9], c->ev[8])); sweep_ms += ms;
-            if (sweep_forked) checked_total += std::min(c->h_pin[12], fork_nt);          // (copied before ev[9], which ev[8] waited for)
-            sweep_forked = false;
-            return VTX_OK;
-        };
-        for (uint64_t base = 0; base < n_tasks; base += chunk) {
-            const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, n_tasks - base);
-            if (int rc = collect_sweep_times()) return rc;                              // (a chunk re-records the events)
-            HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), s));                 // hard count of this chunk
-            HIP_TRY(c, hipMemsetAsync(d_cnt + 11, 0, sizeof(uint32_t), s));            // pending count of this chunk
-            HIP_TRY(c, hipMemsetAsync(d_cnt + 16, 0, 8 * sizeof(uint32_t), s));        // block counters (one per XCD)
-            // the loci of this range of tasks (tables in global memory are built per range)
-            uint32_t gt_l0 = 0, gt_n = gt_bytes ? c->n_loci : 0;
-            if (gt_chunked) {
-                uint32_t ends[2];
-                HIP_TRY(c, hipMemcpyAsync(&ends[0], c->d_rec_locus.as<uint32_t>() + base / 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                HIP_TRY(c, hipMemcpyAsync(&ends[1], c->d_rec_locus.as<uint32_t>() + (base + nt - 1) / 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                HIP_TRY(c, hipStreamSynchronize(s));
-                gt_l0 = ends[0];
-                gt_n = ends[1] - ends[0] + 1;
-                if (gt_n > bp.gt_loci) gt_n = 0;              // does not fit after all: tables in LDS for this chunk
-            }
-            c->gt_used = (gt_n && bp.gt_loci) ? (uint64_t)gt_n * (gt_bytes / bp.gt_loci) : 0;     // (gt_bytes = gt_loci x bytes per locus)
-            HIP_TRY(c, hipEventRecord(c->ev[4], s));
-            // Stage 1 (tables in global memory): band_diag_kernel decides the tasks whose alignment lives on one diagonal
-            // (vtx_fast_core.h) and lists the others; band_run_kernel then takes that LIST instead of the whole range.
-            static const bool no_diag = VTX_DEV_ENV("VTX_BAND_NO_DIAG") != nullptr;          // experiment / test hook: stage 1 off
-            static const int diag_stats = getenv("VTX_DEBUG") ? 1 : 0;
-            bool diag = false, swept = false;
-            uint32_t n_fail = 0;
-            const uint32_t* fail_list = c->d_fail.as<uint32_t>();
-            // Round 4: what band_diag_kernel / band_refine_kernel leave goes (a) with a certificate: through the full-matrix CHECK
-            // (full == cert decides it: cert <= banded <= full), (b) otherwise, or when the check fails: through band_sweep_kernel
-            // (the band of ANY task, vtx_sweep.hip) and the masked DP.  VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending /
-            // general path instead (kept for A/B tests; also what takes over when a haplotype of the batch exceeds 255 bases).
-            static const bool legacy = VTX_DEV_ENV("VTX_BAND_LEGACY") != nullptr;
-            static const bool no_tight = VTX_DEV_ENV("VTX_BAND_NO_TIGHT") != nullptr;          // test hook: tasks with a certificate go to the sweep like the others
-            static const bool use_check = VTX_DEV_ENV("VTX_BAND_CHECK") != nullptr;            // experiment hook: full-matrix check in front of their DP
-            const bool sweep_path = !legacy && c->max_hap_len <= vtxk_band_sweep_max_len() && c->max_hap_len > 0;
-            uint32_t* tight_list = (sweep_path && !no_tight) ? c->d_tight.as<uint32_t>() : nullptr;
-            uint32_t* tight_pack = tight_list ? c->d_tight_pack.as<uint32_t>() : nullptr;
-            // which of the tasks the certificate stages leave skip band_run_kernel (whose piece lists they would overflow) and take
-            // band_sweep_kernel at once: bit = vtxf::Why.  Default: W_MATCHES (4: more than 40 off-diagonal k-mer matches — repeats).
-            // VTX_BAND_DENSE_MASK: experiment knob (0x3be: everything but shape; 0: nothing — band_run_kernel sees every task first).
-            static const uint32_t dense_mask = VTX_DEV_ENV("VTX_BAND_DENSE_MASK") ? (uint32_t)strtoul(VTX_DEV_ENV("VTX_BAND_DENSE_MASK"), nullptr, 0) : (1u << 4);
-            uint32_t* dense_list = sweep_path ? c->d_dense.as<uint32_t>() : nullptr;
-            if (gt_n && !no_diag) {
-                HIP_TRY(c, hipMemsetAsync(d_cnt + 12, 0, 4 * sizeof(uint32_t), s));   // [12] left for band_run_kernel, [13] for band_sweep_kernel, [14] refine records, [15] tasks with a one-diagonal band
-                // tasks with main pieces only whose bounds do not meet leave a record for band_refine_kernel
-                static const bool no_refine = VTX_DEV_ENV("VTX_BAND_NO_REFINE") != nullptr;        // experiment / test hook
-                const uint32_t refine_cap = band_refine_cap(chunk);
-                uint32_t* refine_list = no_refine ? nullptr : c->d_refine.as<uint32_t>();
-                const hipError_t e = vtxk_launch_band_diag(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                                           c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
-                                                           c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
-                                                           c->d_fail.as<uint32_t>(), refine_list, refine_cap, d_cnt, tasks_per_locus, gt_l0, gt_n,
-                                                           c->d_gtables.as<uint8_t>(), gt_bytes, diag_stats, tight_list, tight_pack, stage,
-                                                           dense_list, dense_mask, s);
-                if (e == hipSuccess && sweep_path) {
-                    diag = true; swept = true; sweep_used = true;
-                    HIP_TRY(c, hipEventRecord(c->ev[6], s));
-                    // What the stage left, in two branches that share nothing but the score arrays (disjoint tasks):
-                    //   side stream   band_refine_kernel over its records, then the masked DP over the one-diagonal bands (tight list:
-                    //                 band_diag_kernel's entries + what the refinement leaves; counted on the device, the grid is
-                    //                 sized for the bound known here);
-                    //   this stream   band_sweep_kernel + masked DP over the repeats and the short fail list (both final once
-                    //                 band_diag_kernel is done: with a tight list the refinement adds nothing to them).
-                    // At 16 reads per locus these are five latency-bound launches of 0.1 - 0.2 ms each: side by side 0.31 instead
-                    // of 0.55 ms.  One host round trip, right after band_diag_kernel.  (VTX_BAND_NO_TIGHT: the refinement's leftovers
-                    // go to the fail list, so everything stays in order on this stream.)
-                    static const bool no_fork = VTX_DEV_ENV("VTX_BAND_NO_FORK") != nullptr;          // experiment / test hook
-                    const bool fork = tight_list != nullptr && !no_fork;
-                    hipStream_t sb = fork ? s2 : s;                                             // the refine / one-diagonal branch
-                    if (!fork && refine_list)
-                        HIP_TRY(c, vtxk_launch_band_refine(refine_list, std::min(refine_cap, nt), c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                                           c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
-                                                           c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
-                                                           tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, tight_list, tight_pack, stage, d_cnt + 14, s));
-                    HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));   // [12] fail, [13] dense, [14] refine, [15] tight
-                    HIP_TRY(c, hipStreamSynchronize(s));
-                    const uint32_t n_refine = std::min(c->h_pin[10], refine_cap);
-                    // (forked: the tight list still grows by what the refinement leaves — at most its records)
-                    const uint32_t n_tight = (uint32_t)std::min<uint64_t>((uint64_t)c->h_pin[11] + (fork && refine_list ? n_refine : 0u), nt);
-                    refined_total += n_refine;
+                HIP_TRY(c, hipEventRecord(c->ev2, s2));
+                HIP_TRY(c, hipStreamWaitEvent(s, c->ev2, 0));             // the reduction kernels read every score
+                return VTX_OK;
+            };
+            HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 64 * sizeof(uint32_t), s));
+            uint32_t cnt[12] = {0};
+            uint32_t pending_total = 0, over_before = 0;
+            uint64_t diag_total = 0, diag_left = 0, refined_total = 0, checked_total = 0, swept_total = 0, diag2_total = 0, diag2_scored = 0, tight2_total = 0, stream_total = 0;
+            float diag_ms = 0, check_ms = 0, sweep_ms = 0;
+            // the band of every listed task (band_sweep_kernel, tier 0 / 1), one slice of band slots at a time, then the masked DP over
+            // the slice (its length — the tasks the sweep did not decline — is read on the device: counters[0]; declined: counters[1])
+            // (libvtx_dev.so, VTX_SWEEP_V1=1: round 4's kernel instead — 256 sections per task, then a second pass with 1 024 over what the
+            // first declined; the A/B reference of tests/test_gpu_sweep.py and tools/gpu_campaign.sh)
+            static const bool sweep_v1 = VTX_DEV_ENV("VTX_SWEEP_V1") != nullptr;
+            auto sweep_slices = [&](int tier, const uint32_t* list, uint32_t n, uint32_t* over_out, uint32_t* counters) -> int {
+                static const bool sweep_stats = getenv("VTX_DEBUG") != nullptr;
+                HIP_TRY(c, c->d_sweep_log.reserve(vtxk_band_sweep_log_bytes()));
+                for (uint32_t off = 0; off < n; off += slots) {
+                    const uint32_t cnt_s = std::min(slots, n - off);
+                    HIP_TRY(c, hipMemsetAsync(counters, 0, sizeof(uint32_t), s));
+    #ifdef VTX_DEVTOOLS
+                    if (sweep_v1)
+                        HIP_TRY(c, vtxk_launch_band_sweep_v1(tier, list + off, cnt_s, nullptr, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                             c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                                             c->d_band.as<uint16_t>(), band_stride, c->d_hard.as<uint32_t>(), over_out,
+                                                             counters, sweep_stats ? d_cnt + 56 : nullptr, stage, nullptr, s));
+                    else
+    #endif
+                    HIP_TRY(c, vtxk_launch_band_sweep(list + off, cnt_s, nullptr, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                      c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                                      c->d_band.as<uint16_t>(), band_stride, c->d_hard.as<uint32_t>(), over_out,
+                                                      counters, sweep_stats ? d_cnt + 56 : nullptr, stage, nullptr, c->d_sweep_log.as<uint32_t>(), s));
+                    (void)tier;
+                    HIP_TRY(c, vtxk_launch_sw_banded_dev(kShapes[shape][0], kShapes[shape][1], cnt_s, c->d_hard.as<uint32_t>(), counters,
+                                                         c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
+                                                         c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_band.as<uint16_t>(), band_stride,
+                                                         c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), mh, s));
                     launches += 2;
-                    if (fork) HIP_TRY(c, hipStreamWaitEvent(s2, c->ev[6], 0));
-                    HIP_TRY(c, hipEventRecord(c->ev[7], sb));
-                    if (fork && refine_list && n_refine)
-                        HIP_TRY(c, vtxk_launch_band_refine(refine_list, n_refine, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                                           c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
-                                                           c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
-                                                           tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, tight_list, tight_pack, stage, d_cnt + 14, sb));
-                    if (n_tight) {
-                        // tasks with a certificate but no verdict: their band is one diagonal stretch (tight_pack): the masked DP
-                        // expands it itself.  (VTX_BAND_CHECK=1: the full-matrix check first — full == cert decides a task, cert <=
-                        // banded <= full; measured: 5.6 ns per task against 10 for the DP it saves on 20 - 30 % of noisy reads.)
-                        const uint32_t* dp_list = tight_list;
-                        const uint32_t* dp_pack = tight_pack;
-                        const uint32_t* dp_cnt = fork ? d_cnt + 15 : nullptr;
-                        if (use_check) {
-                            HIP_TRY(c, c->d_dband.reserve((size_t)chunk * sizeof(uint32_t)));
-                            HIP_TRY(c, c->d_dband_pack.reserve((size_t)chunk * sizeof(uint32_t)));
-                            HIP_TRY(c, hipMemsetAsync(d_cnt + 24, 0, sizeof(uint32_t), sb));
-                            HIP_TRY(c, vtxk_launch_sw_check(kShapes[shape][0], kShapes[shape][1], n_tight, tight_list, tight_pack, dp_cnt,
-                                                            c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
-                                                            c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(),
-                                                            c->d_alt.as<int32_t>(), c->max_hap_len, c->d_dband.as<uint32_t>(),
-                                                            c->d_dband_pack.as<uint32_t>(), d_cnt + 24, stage, sb));
-                            dp_list = c->d_dband.as<uint32_t>(); dp_pack = c->d_dband_pack.as<uint32_t>(); dp_cnt = d_cnt + 24;
+                }
+                return VTX_OK;
+            };
+            uint32_t resweep_total = 0;
+            // Second stage (round 5): the same single-diagonal logic with a list of 64 entries and the harmless bound from
+            // the matches that can really precede a match (band_diag2_kernel), the harmless test alone over a two-row window for what
+            // exceeds the list (band_stream_kernel).  They score most of these tasks or prove that their band is one diagonal stretch
+            // (full-matrix check, masked DP for what it does not settle; no sweep); what they leave — out[0, *n_out) — takes the sweep.
+            // One host round trip for the counts.  (libvtx_dev.so: VTX_BAND_NO_DIAG2=1 sends everything to the sweep, as round 4 did;
+            // VTX_BAND_NO_STREAM=1 — what exceeds the second stage's list goes to the sweep.)
+            // A short list skips it: one lane per task, a few hundred dependent loads each — the kernels are latency chains with a fixed
+            // cost of several milliseconds that the sweep + its DP beat below ~0.65 M tasks.  Measured in round 6 on loci from real sequence
+            // (profiles/r06_second_stage_threshold.txt; stage on / off): 33 k tasks 7.9 / 3.4 ms per step, 145 k 12.8 / 8.6, 319 k 28.9 / 19.9,
+            // 638 k 36.8 / 36.0, 1.28 M 52.2 / 64.3 — round 5's threshold of 200 k made mid-size batches a third slower.
+            // The tables of the tasks' loci have to be resident (gt_l0: first locus of the table buffer).
+            auto second_stage_on = [&](uint32_t n) -> bool {
+                static const bool no_diag2 = VTX_DEV_ENV("VTX_BAND_NO_DIAG2") != nullptr;
+                static const uint32_t diag2_min = VTX_DEV_ENV("VTX_BAND_DIAG2_MIN") ? (uint32_t)strtoul(VTX_DEV_ENV("VTX_BAND_DIAG2_MIN"), nullptr, 10) : 700000u;
+                return !no_diag2 && n >= diag2_min && mh <= 255;
+            };
+            auto second_stage = [&](const uint32_t* list, uint32_t n, uint32_t gt_l0, uint32_t* out, uint32_t* n_out) -> int {
+                static const bool no_stream = VTX_DEV_ENV("VTX_BAND_NO_STREAM") != nullptr;
+                HIP_TRY(c, hipMemsetAsync(d_cnt + 30, 0, 2 * sizeof(uint32_t), s));
+                HIP_TRY(c, hipMemsetAsync(d_cnt + 48, 0, sizeof(uint32_t), s));
+                HIP_TRY(c, vtxk_launch_band_diag2(list, n, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                  c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), mh,
+                                                  c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), bp.tasks_per_locus, gt_l0,
+                                                  c->d_gtables.as<uint8_t>(), out, c->d_tight2.as<uint32_t>(),
+                                                  c->d_tight2_pack.as<uint32_t>(), d_cnt + 30,
+                                                  no_stream ? nullptr : c->d_recheck2.as<uint32_t>(), c->d_recheck2_pack.as<uint32_t>(), d_cnt + 48, stage, s));
+                HIP_TRY(c, hipMemcpyAsync(c->h_pin + 14, d_cnt + 30, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipMemcpyAsync(c->h_pin + 16, d_cnt + 48, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipStreamSynchronize(s));
+                stream_total += std::min(c->h_pin[16], n);
+                const uint32_t n_sweep = std::min(c->h_pin[14], n);
+                const uint32_t n_tight2 = std::min(c->h_pin[15], n - n_sweep);
+                ++launches;
+                diag2_total += n; diag2_scored += n - n_sweep - n_tight2;
+                if (n_tight2) {
+                    // These tasks hold a certificate (a lower bound of the banded score) and sit in repeat-rich sequence on
+                    // clean reads: the full-matrix score equals it for practically all of them (4 223 of 4 223 in the CPU
+                    // sample), and cert <= banded <= full then decides the task for 5.9 ns where the masked DP takes 10.
+                    // What the check does not settle takes the masked DP over its one-diagonal band (count on the device).
+                    HIP_TRY(c, hipMemsetAsync(d_cnt + 25, 0, sizeof(uint32_t), s));
+                    HIP_TRY(c, vtxk_launch_sw_check(kShapes[shape][0], kShapes[shape][1], n_tight2, c->d_tight2.as<uint32_t>(),
+                                                    c->d_tight2_pack.as<uint32_t>(), nullptr, c->d_records.as<vtx_record>(),
+                                                    c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                                    c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), mh,
+                                                    c->d_recheck2.as<uint32_t>(), c->d_recheck2_pack.as<uint32_t>(), d_cnt + 25, stage, s));
+                    HIP_TRY(c, vtxk_launch_sw_diag_band(kShapes[shape][0], kShapes[shape][1], n_tight2, c->d_recheck2.as<uint32_t>(),
+                                                        c->d_recheck2_pack.as<uint32_t>(), d_cnt + 25, c->d_records.as<vtx_record>(),
+                                                        c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(),
+                                                        c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
+                                                        mh, stage, s));
+                    // (its grid is sized for n_tight2 although a few hundred tasks remain: the workgroups past the device count leave at once —
+                    //  measured in round 6 with an exact-size launch behind a host round trip: no difference.  The 3 x 13 ms of
+                    //  sw_banded_kernel<.., 2> in the real-sequence kernel table are ONE launch of 39 ms — the first stage's 0.5 M one-diagonal
+                    //  bands on the side stream, stretched by the kernels it runs beside — and two of microseconds.)
+                    launches += 2;
+                    tight2_total += n_tight2;
+                }
+                *n_out = n_sweep;
+                return 0;
+            };
+            bool sweep_used = false;                    // some chunk took the round-4 path
+            bool sweep_pending = false;                 // the events of a swept chunk have not been read yet
+            bool sweep_forked = false;                  // ... and that chunk ran its two branches side by side
+            uint32_t fork_nt = 0;
+            auto collect_sweep_times = [&]() -> int {
+                if (!sweep_pending) return VTX_OK;
+                sweep_pending = false;
+                HIP_TRY(c, hipEventSynchronize(c->ev[8]));
+                float ms = 0;
+                // ev[7] .. ev[9]: band_refine_kernel (forked only) + the one-diagonal bands' masked DP; then band_sweep_kernel + its masked
+                // DP (the chunk's repeats) — forked: ev[11] .. ev[8] on the main stream, BESIDE the first interval, not after it
+                HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[7], c->ev[9])); check_ms += ms;
+                HIP_TRY(c, hipEventElapsedTime(&ms, sweep_forked ? c->ev[11] : c->ev[9], c->ev[8])); sweep_ms += ms;
+                if (sweep_forked) checked_total += std::min(c->h_pin[12], fork_nt);          // (copied before ev[9], which ev[8] waited for)
+                sweep_forked = false;
+                return VTX_OK;
+            };
+            for (uint64_t base = t_begin; base < t_end; base += chunk) {
+                const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, t_end - base);
+                if (int rc = collect_sweep_times()) return rc;                              // (a chunk re-records the events)
+                HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), s));                 // hard count of this chunk
+                HIP_TRY(c, hipMemsetAsync(d_cnt + 11, 0, sizeof(uint32_t), s));            // pending count of this chunk
+                HIP_TRY(c, hipMemsetAsync(d_cnt + 16, 0, 8 * sizeof(uint32_t), s));        // block counters (one per XCD)
+                // the loci of this range of tasks (tables in global memory are built per range)
+                uint32_t gt_l0 = 0, gt_n = gt_bytes ? c->n_loci : 0;
+                if (gt_chunked) {
+                    uint32_t ends[2];
+                    HIP_TRY(c, hipMemcpyAsync(&ends[0], c->d_rec_locus.as<uint32_t>() + base / 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipMemcpyAsync(&ends[1], c->d_rec_locus.as<uint32_t>() + (base + nt - 1) / 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipStreamSynchronize(s));
+                    gt_l0 = ends[0];
+                    gt_n = ends[1] - ends[0] + 1;
+                    if (gt_n > bp.gt_loci) gt_n = 0;              // does not fit after all: tables in LDS for this chunk
+                }
+                c->gt_used = (gt_n && bp.gt_loci) ? (uint64_t)gt_n * (gt_bytes / bp.gt_loci) : 0;     // (gt_bytes = gt_loci x bytes per locus)
+                HIP_TRY(c, hipEventRecord(c->ev[4], s));
+                // Stage 1 (tables in global memory): band_diag_kernel decides the tasks whose alignment lives on one diagonal
+                // (vtx_fast_core.h) and lists the others; band_run_kernel then takes that LIST instead of the whole range.
+                static const bool no_diag = VTX_DEV_ENV("VTX_BAND_NO_DIAG") != nullptr;          // experiment / test hook: stage 1 off
+                static const int diag_stats = getenv("VTX_DEBUG") ? 1 : 0;
+                bool diag = false, swept = false;
+                uint32_t n_fail = 0;
+                const uint32_t* fail_list = c->d_fail.as<uint32_t>();
+                // Round 4: what band_diag_kernel / band_refine_kernel leave goes (a) with a certificate: through the full-matrix CHECK
+                // (full == cert decides it: cert <= banded <= full), (b) otherwise, or when the check fails: through band_sweep_kernel
+                // (the band of ANY task, vtx_sweep.hip) and the masked DP.  VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending /
+                // general path instead (kept for A/B tests; also what takes over when a haplotype of the batch exceeds 255 bases).
+                static const bool legacy = VTX_DEV_ENV("VTX_BAND_LEGACY") != nullptr;
+                static const bool no_tight = VTX_DEV_ENV("VTX_BAND_NO_TIGHT") != nullptr;          // test hook: tasks with a certificate go to the sweep like the others
+                static const bool use_check = VTX_DEV_ENV("VTX_BAND_CHECK") != nullptr;            // experiment hook: full-matrix check in front of their DP
+                const bool sweep_path = !legacy && mh <= vtxk_band_sweep_max_len() && mh > 0;
+                uint32_t* tight_list = (sweep_path && !no_tight) ? c->d_tight.as<uint32_t>() : nullptr;
+                uint32_t* tight_pack = tight_list ? c->d_tight_pack.as<uint32_t>() : nullptr;
+                // which of the tasks the certificate stages leave skip band_run_kernel (whose piece lists they would overflow) and take
+                // band_sweep_kernel at once: bit = vtxf::Why.  Default: W_MATCHES (4: more than 40 off-diagonal k-mer matches — repeats).
+                // VTX_BAND_DENSE_MASK: experiment knob (0x3be: everything but shape; 0: nothing — band_run_kernel sees every task first).
+                static const uint32_t dense_mask = VTX_DEV_ENV("VTX_BAND_DENSE_MASK") ? (uint32_t)strtoul(VTX_DEV_ENV("VTX_BAND_DENSE_MASK"), nullptr, 0) : (1u << 4);
+                uint32_t* dense_list = sweep_path ? c->d_dense.as<uint32_t>() : nullptr;
+                if (gt_n && !no_diag) {
+                    HIP_TRY(c, hipMemsetAsync(d_cnt + 12, 0, 4 * sizeof(uint32_t), s));   // [12] left for band_run_kernel, [13] for band_sweep_kernel, [14] refine records, [15] tasks with a one-diagonal band
+                    // tasks with main pieces only whose bounds do not meet leave a record for band_refine_kernel
+                    static const bool no_refine = VTX_DEV_ENV("VTX_BAND_NO_REFINE") != nullptr;        // experiment / test hook
+                    const uint32_t refine_cap = band_refine_cap(chunk);
+                    uint32_t* refine_list = no_refine ? nullptr : c->d_refine.as<uint32_t>();
+                    const hipError_t e = vtxk_launch_band_diag(nt, (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                               c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                                               mh, mh_min, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
+                                                               c->d_fail.as<uint32_t>(), refine_list, refine_cap, d_cnt, tasks_per_locus, gt_l0, gt_n,
+                                                               c->d_gtables.as<uint8_t>(), gt_bytes, diag_stats, tight_list, tight_pack, stage,
+                                                               dense_list, dense_mask, s);
+                    if (e == hipSuccess && sweep_path) {
+                        diag = true; swept = true; sweep_used = true;
+                        HIP_TRY(c, hipEventRecord(c->ev[6], s));
+                        // What the stage left, in two branches that share nothing but the score arrays (disjoint tasks):
+                        //   side stream   band_refine_kernel over its records, then the masked DP over the one-diagonal bands (tight list:
+                        //                 band_diag_kernel's entries + what the refinement leaves; counted on the device, the grid is
+                        //                 sized for the bound known here);
+                        //   this stream   band_sweep_kernel + masked DP over the repeats and the short fail list (both final once
+                        //                 band_diag_kernel is done: with a tight list the refinement adds nothing to them).
+                        // At 16 reads per locus these are five latency-bound launches of 0.1 - 0.2 ms each: side by side 0.31 instead
+                        // of 0.55 ms.  One host round trip, right after band_diag_kernel.  (VTX_BAND_NO_TIGHT: the refinement's leftovers
+                        // go to the fail list, so everything stays in order on this stream.)
+                        static const bool no_fork = VTX_DEV_ENV("VTX_BAND_NO_FORK") != nullptr;          // experiment / test hook
+                        const bool fork = tight_list != nullptr && !no_fork;
+                        hipStream_t sb = fork ? s2 : s;                                             // the refine / one-diagonal branch
+                        if (!fork && refine_list)
+                            HIP_TRY(c, vtxk_launch_band_refine(refine_list, std::min(refine_cap, nt), c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                               c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), mh,
+                                                               c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
+                                                               tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, tight_list, tight_pack, stage, d_cnt + 14, s));
+                        HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));   // [12] fail, [13] dense, [14] refine, [15] tight
+                        HIP_TRY(c, hipStreamSynchronize(s));
+                        const uint32_t n_refine = std::min(c->h_pin[10], refine_cap);
+                        // (forked: the tight list still grows by what the refinement leaves — at most its records)
+                        const uint32_t n_tight = (uint32_t)std::min<uint64_t>((uint64_t)c->h_pin[11] + (fork && refine_list ? n_refine : 0u), nt);
+                        refined_total += n_refine;
+                        launches += 2;
+                        if (fork) HIP_TRY(c, hipStreamWaitEvent(s2, c->ev[6], 0));
+                        HIP_TRY(c, hipEventRecord(c->ev[7], sb));
+                        if (fork && refine_list && n_refine)
+                            HIP_TRY(c, vtxk_launch_band_refine(refine_list, n_refine, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                               c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), mh,
+                                                               c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
+                                                               tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, tight_list, tight_pack, stage, d_cnt + 14, sb));
+                        if (n_tight) {
+                            // tasks with a certificate but no verdict: their band is one diagonal stretch (tight_pack): the masked DP
+                            // expands it itself.  (VTX_BAND_CHECK=1: the full-matrix check first — full == cert decides a task, cert <=
+                            // banded <= full; measured: 5.6 ns per task against 10 for the DP it saves on 20 - 30 % of noisy reads.)
+                            const uint32_t* dp_list = tight_list;
+                            const uint32_t* dp_pack = tight_pack;
+                            const uint32_t* dp_cnt = fork ? d_cnt + 15 : nullptr;
+                            if (use_check) {
+                                HIP_TRY(c, c->d_dband.reserve((size_t)chunk * sizeof(uint32_t)));
+                                HIP_TRY(c, c->d_dband_pack.reserve((size_t)chunk * sizeof(uint32_t)));
+                                HIP_TRY(c, hipMemsetAsync(d_cnt + 24, 0, sizeof(uint32_t), sb));
+                                HIP_TRY(c, vtxk_launch_sw_check(kShapes[shape][0], kShapes[shape][1], n_tight, tight_list, tight_pack, dp_cnt,
+                                                                c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
+                                                                c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(),
+                                                                c->d_alt.as<int32_t>(), mh, c->d_dband.as<uint32_t>(),
+                                                                c->d_dband_pack.as<uint32_t>(), d_cnt + 24, stage, sb));
+                                dp_list = c->d_dband.as<uint32_t>(); dp_pack = c->d_dband_pack.as<uint32_t>(); dp_cnt = d_cnt + 24;
+                                ++launches;
+                            }
+                            HIP_TRY(c, vtxk_launch_sw_diag_band(kShapes[shape][0], kShapes[shape][1], n_tight, dp_list, dp_pack, dp_cnt,
+                                                                c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
+                                                                c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(),
+                                                                c->d_alt.as<int32_t>(), mh, stage, sb));
                             ++launches;
                         }
-                        HIP_TRY(c, vtxk_launch_sw_diag_band(kShapes[shape][0], kShapes[shape][1], n_tight, dp_list, dp_pack, dp_cnt,
-                                                            c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(), c->d_loci.as<vtx_locus>(),
-                                                            c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(), c->d_ref.as<int32_t>(),
-                                                            c->d_alt.as<int32_t>(), c->max_hap_len, stage, sb));
-                        ++launches;
-                    }
-                    if (fork) HIP_TRY(c, hipMemcpyAsync(c->h_pin + 12, d_cnt + 15, sizeof(uint32_t), hipMemcpyDeviceToHost, sb));   // the list's final length (read in collect_sweep_times)
-                    HIP_TRY(c, hipEventRecord(c->ev[9], sb));
-                    if (fork) HIP_TRY(c, hipEventRecord(c->ev[11], s));                          // (this stream's branch starts here)
-                    n_fail = c->h_pin[8];
-                    uint32_t n_dense = std::min(c->h_pin[9], nt);
-                    if (!fork) checked_total += n_tight;                                    // (forked: the exact count arrives with the events)
-                    diag_total += nt; diag_left += (uint64_t)n_fail + n_dense;
-                    // repeats: band_sweep_kernel (the band of ANY task) + masked DP, sorted by task (neighbours share their locus'
-                    // haplotypes, and the hard list comes out in a fixed order); what it declines waits in d_over[2 n_tasks ..) for the
-                    // second pass after the last chunk
-                    // (a short list of the other tasks is not worth band_run_kernel's launch — a persistent grid: ~1 ms whatever the
-                    // count — and the two host round trips behind it: it joins the repeats, ~25 ns per task)
-                    static const uint32_t run_min = VTX_DEV_ENV("VTX_BAND_RUN_MIN") ? (uint32_t)strtoul(VTX_DEV_ENV("VTX_BAND_RUN_MIN"), nullptr, 10) : 65536u;
-                    if (n_fail && n_fail < run_min && (uint64_t)n_dense + n_fail <= nt) {
-                        HIP_TRY(c, hipMemcpyAsync(dense_list + n_dense, c->d_fail.as<uint32_t>(), (size_t)n_fail * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-                        n_dense += n_fail;
-                        n_fail = 0;
-                    }
-                    if (n_dense) {
-                        const uint32_t* dl = dense_list;
-                        if (n_dense > 64) {
-                            const size_t tb = vtxk_sort_keys_u32_temp_bytes(n_dense);
+                        if (fork) HIP_TRY(c, hipMemcpyAsync(c->h_pin + 12, d_cnt + 15, sizeof(uint32_t), hipMemcpyDeviceToHost, sb));   // the list's final length (read in collect_sweep_times)
+                        HIP_TRY(c, hipEventRecord(c->ev[9], sb));
+                        if (fork) HIP_TRY(c, hipEventRecord(c->ev[11], s));                          // (this stream's branch starts here)
+                        n_fail = c->h_pin[8];
+                        uint32_t n_dense = std::min(c->h_pin[9], nt);
+                        if (!fork) checked_total += n_tight;                                    // (forked: the exact count arrives with the events)
+                        diag_total += nt; diag_left += (uint64_t)n_fail + n_dense;
+                        // repeats: band_sweep_kernel (the band of ANY task) + masked DP, sorted by task (neighbours share their locus'
+                        // haplotypes, and the hard list comes out in a fixed order); what it declines waits in d_over[2 n_tasks ..) for the
+                        // second pass after the last chunk
+                        // (a short list of the other tasks is not worth band_run_kernel's launch — a persistent grid: ~1 ms whatever the
+                        // count — and the two host round trips behind it: it joins the repeats, ~25 ns per task)
+                        static const uint32_t run_min = VTX_DEV_ENV("VTX_BAND_RUN_MIN") ? (uint32_t)strtoul(VTX_DEV_ENV("VTX_BAND_RUN_MIN"), nullptr, 10) : 65536u;
+                        if (n_fail && n_fail < run_min && (uint64_t)n_dense + n_fail <= nt) {
+                            HIP_TRY(c, hipMemcpyAsync(dense_list + n_dense, c->d_fail.as<uint32_t>(), (size_t)n_fail * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+                            n_dense += n_fail;
+                            n_fail = 0;
+                        }
+                        if (n_dense) {
+                            const uint32_t* dl = dense_list;
+                            if (n_dense > 64) {
+                                const size_t tb = vtxk_sort_keys_u32_temp_bytes(n_dense);
+                                if (c->d_fail_tmp.reserve(tb) == hipSuccess) {
+                                    HIP_TRY(c, vtxk_sort_keys_u32(dense_list, dense_list + nt, n_dense, c->d_fail_tmp.p, tb, s));
+                                    dl = dense_list + nt;
+                                } else (void)hipGetLastError();
+                            }
+                            // Second stage (round 5): band_diag2_kernel + band_stream_kernel + the full-matrix check (second_stage above)
+                            const uint32_t* sl = dl;
+                            uint32_t n_sweep = n_dense;
+                            if (second_stage_on(n_dense)) {
+                                uint32_t* sweep2 = (dl == dense_list) ? dense_list + nt : dense_list;          // (the half of d_dense the list is not in)
+                                if (int rc = second_stage(dl, n_dense, gt_l0, sweep2, &n_sweep)) return rc;
+                                sl = sweep2;
+                            }
+                            if (n_sweep) { if (int rc = sweep_slices(0, sl, n_sweep, c->d_over.as<uint32_t>() + 2 * n_tasks, d_cnt + 26)) return rc; }
+                            swept_total += n_sweep;
+                        }
+                        if (n_fail > 64) {
+                            const size_t tb = vtxk_sort_keys_u32_temp_bytes(n_fail);
                             if (c->d_fail_tmp.reserve(tb) == hipSuccess) {
-                                HIP_TRY(c, vtxk_sort_keys_u32(dense_list, dense_list + nt, n_dense, c->d_fail_tmp.p, tb, s));
-                                dl = dense_list + nt;
+                                HIP_TRY(c, vtxk_sort_keys_u32(c->d_fail.as<uint32_t>(), c->d_fail.as<uint32_t>() + nt, n_fail, c->d_fail_tmp.p, tb, s));
+                                fail_list = c->d_fail.as<uint32_t>() + nt;
                             } else (void)hipGetLastError();
                         }
-                        // Second stage (round 5): band_diag2_kernel + band_stream_kernel + the full-matrix check (second_stage above)
-                        const uint32_t* sl = dl;
-                        uint32_t n_sweep = n_dense;
-                        if (second_stage_on(n_dense)) {
-                            uint32_t* sweep2 = (dl == dense_list) ? dense_list + nt : dense_list;          // (the half of d_dense the list is not in)
-                            if (int rc = second_stage(dl, n_dense, gt_l0, sweep2, &n_sweep)) return rc;
-                            sl = sweep2;
-                        }
-                        if (n_sweep) { if (int rc = sweep_slices(0, sl, n_sweep, c->d_over.as<uint32_t>() + 2 * n_tasks, d_cnt + 26)) return rc; }
-                        swept_total += n_sweep;
-                    }
-                    if (n_fail > 64) {
-                        const size_t tb = vtxk_sort_keys_u32_temp_bytes(n_fail);
-                        if (c->d_fail_tmp.reserve(tb) == hipSuccess) {
-                            HIP_TRY(c, vtxk_sort_keys_u32(c->d_fail.as<uint32_t>(), c->d_fail.as<uint32_t>() + nt, n_fail, c->d_fail_tmp.p, tb, s));
-                            fail_list = c->d_fail.as<uint32_t>() + nt;
-                        } else (void)hipGetLastError();
-                    }
-                    if (fork) HIP_TRY(c, hipStreamWaitEvent(s, c->ev[9], 0));                    // join: what follows reads every score
-                    HIP_TRY(c, hipEventRecord(c->ev[8], s));
-                    sweep_pending = true; sweep_forked = fork; fork_nt = nt;
-                    // the others: band_run_kernel (task-list mode) below — seeds, chain and the general certificate (a read against the
-                    // other allele of an indel lies on TWO diagonals: cert == ub decides nearly all of those without a DP cell)
-                } else if (e == hipSuccess) {
-                    diag = true;
-                    HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                    HIP_TRY(c, hipMemcpyAsync(c->h_pin + 9, d_cnt + 14, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                    HIP_TRY(c, hipEventRecord(c->ev[6], s));
-                    HIP_TRY(c, hipStreamSynchronize(s));
-                    n_fail = c->h_pin[8];
-                    const uint32_t n_refine = std::min(c->h_pin[9], refine_cap);
-                    if (n_refine) {
-                        HIP_TRY(c, vtxk_launch_band_refine(refine_list, n_refine, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                                           c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->max_hap_len,
-                                                           c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
-                                                           tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, nullptr, nullptr, stage, nullptr, s));
+                        if (fork) HIP_TRY(c, hipStreamWaitEvent(s, c->ev[9], 0));                    // join: what follows reads every score
+                        HIP_TRY(c, hipEventRecord(c->ev[8], s));
+                        sweep_pending = true; sweep_forked = fork; fork_nt = nt;
+                        // the others: band_run_kernel (task-list mode) below — seeds, chain and the general certificate (a read against the
+                        // other allele of an indel lies on TWO diagonals: cert == ub decides nearly all of those without a DP cell)
+                    } else if (e == hipSuccess) {
+                        diag = true;
                         HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                        HIP_TRY(c, hipMemcpyAsync(c->h_pin + 9, d_cnt + 14, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                        HIP_TRY(c, hipEventRecord(c->ev[6], s));
                         HIP_TRY(c, hipStreamSynchronize(s));
                         n_fail = c->h_pin[8];
-                        refined_total += n_refine;
+                        const uint32_t n_refine = std::min(c->h_pin[9], refine_cap);
+                        if (n_refine) {
+                            HIP_TRY(c, vtxk_launch_band_refine(refine_list, n_refine, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                               c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), mh,
+                                                               c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
+                                                               tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, nullptr, nullptr, stage, nullptr, s));
+                            HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                            HIP_TRY(c, hipStreamSynchronize(s));
+                            n_fail = c->h_pin[8];
+                            refined_total += n_refine;
+                            ++launches;
+                        }
+                        diag_total += nt; diag_left += n_fail;
                         ++launches;
+                        if (n_fail > 64) {
+                            // the list comes out in the order the wavefronts finished: eight XCD ranges interleaved.  Sorted by task, the
+                            // 64 tasks of a band_run_kernel wavefront share their loci's tables and reads again (12.7 -> GB of L2 misses
+                            // for 2 % of the tasks otherwise)
+                            const size_t tb = vtxk_sort_keys_u32_temp_bytes(n_fail);
+                            if (c->d_fail_tmp.reserve(tb) == hipSuccess) {
+                                HIP_TRY(c, vtxk_sort_keys_u32(c->d_fail.as<uint32_t>(), c->d_fail.as<uint32_t>() + nt, n_fail, c->d_fail_tmp.p, tb, s));
+                                fail_list = c->d_fail.as<uint32_t>() + nt;
+                            } else (void)hipGetLastError();
+                        }
+                    } else {
+                        // (the tables do not fit the buffer for this chunk: band_run_kernel alone, tables in LDS)
+                        if (getenv("VTX_DEBUG")) fprintf(stderr, "[vtx] band_diag_kernel not launched for tasks [%llu, +%u): %s\n", (unsigned long long)base, nt, hipGetErrorString(e));
+                        (void)hipGetLastError();
                     }
-                    diag_total += nt; diag_left += n_fail;
-                    ++launches;
-                    if (n_fail > 64) {
-                        // the list comes out in the order the wavefronts finished: eight XCD ranges interleaved.  Sorted by task, the
-                        // 64 tasks of a band_run_kernel wavefront share their loci's tables and reads again (12.7 -> GB of L2 misses
-                        // for 2 % of the tasks otherwise)
-                        const size_t tb = vtxk_sort_keys_u32_temp_bytes(n_fail);
-                        if (c->d_fail_tmp.reserve(tb) == hipSuccess) {
-                            HIP_TRY(c, vtxk_sort_keys_u32(c->d_fail.as<uint32_t>(), c->d_fail.as<uint32_t>() + nt, n_fail, c->d_fail_tmp.p, tb, s));
-                            fail_list = c->d_fail.as<uint32_t>() + nt;
-                        } else (void)hipGetLastError();
-                    }
+                }
+                HIP_TRY(c, hipEventRecord(c->ev[10], s));
+                if (!diag || n_fail)
+                    HIP_TRY(c, vtxk_launch_band_run(diag ? n_fail : nt, diag ? 0u : (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                     c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                                     mh, mh_min, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
+                                                     c->d_band_ws.as<uint32_t>(), c->d_poly.as<uint16_t>(), poly_stride / 2,
+                                                     c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
+                                                     c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt,
+                                                     tasks_per_locus, gt_l0, gt_n, gt_n ? c->d_gtables.as<uint8_t>() : nullptr, gt_bytes,
+                                                     diag ? fail_list : nullptr, c->band_long_lists ? 1 : 0, s));
+                HIP_TRY(c, hipEventRecord(c->ev[5], s));                  // (complete once the read-back below is: no synchronisation of its own)
+                const bool run_skipped = swept && n_fail == 0;             // nothing went to band_run_kernel: its counters are what they were
+                if (run_skipped) {
+                    cnt[0] = 0; cnt[11] = 0; cnt[1] = over_before;
                 } else {
-                    // (the tables do not fit the buffer for this chunk: band_run_kernel alone, tables in LDS)
-                    if (getenv("VTX_DEBUG")) fprintf(stderr, "[vtx] band_diag_kernel not launched for tasks [%llu, +%u): %s\n", (unsigned long long)base, nt, hipGetErrorString(e));
-                    (void)hipGetLastError();
-                }
-            }
-            HIP_TRY(c, hipEventRecord(c->ev[10], s));
-            if (!diag || n_fail)
-                HIP_TRY(c, vtxk_launch_band_run(diag ? n_fail : nt, diag ? 0u : (uint32_t)base, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                                 c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
-                                                 c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
-                                                 c->d_band_ws.as<uint32_t>(), c->d_poly.as<uint16_t>(), poly_stride / 2,
-                                                 c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
-                                                 c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt,
-                                                 tasks_per_locus, gt_l0, gt_n, gt_n ? c->d_gtables.as<uint8_t>() : nullptr, gt_bytes,
-                                                 diag ? fail_list : nullptr, c->band_long_lists ? 1 : 0, s));
-            HIP_TRY(c, hipEventRecord(c->ev[5], s));                  // (complete once the read-back below is: no synchronisation of its own)
-            const bool run_skipped = swept && n_fail == 0;             // nothing went to band_run_kernel: its counters are what they were
-            if (run_skipped) {
-                cnt[0] = 0; cnt[11] = 0; cnt[1] = over_before;
-            } else {
-                HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
-                HIP_TRY(c, hipStreamSynchronize(s));
-            }
-            // (task-list mode runs the 15-entry variant: nothing to give a second chance to)
-            const bool short_lists = !diag && gt_n && vtxk_band_second_chance(tasks_per_locus, c->band_long_lists ? 1 : 0);
-            if (short_lists && nt >= (1u << 20)) {
-                // feedback for the next run of this context: many overflows of the 12-entry lists (noisy reads: 3.3 % of the
-                // tasks at 3 % substitution errors, 0.2 % at 0.5 %) make the 15-entry variant the better first pass
-                if ((uint64_t)(cnt[1] - over_before) * 50 > nt) c->band_long_lists = true;
-            }
-            if (short_lists && cnt[1] > over_before) {
-                // The six-wavefront variant keeps 12-entry lists: the tasks that overflowed them ([a0, a1) of the overflow
-                // list) get a second chance in the 15-entry variant before the general kernel — what overflows again is
-                // appended behind a1 and then moved down to a0.
-                const uint32_t a0 = over_before, a1 = cnt[1];
-                HIP_TRY(c, hipMemsetAsync(d_cnt + 16, 0, 8 * sizeof(uint32_t), s));
-                HIP_TRY(c, vtxk_launch_band_run(a1 - a0, 0, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                                 c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
-                                                 c->max_hap_len, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
-                                                 c->d_band_ws.as<uint32_t>(), c->d_poly.as<uint16_t>(), poly_stride / 2,
-                                                 c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
-                                                 c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt, tasks_per_locus, gt_l0,
-                                                 gt_n, c->d_gtables.as<uint8_t>(), gt_bytes, c->d_over.as<uint32_t>() + a0, 0, s));
-                HIP_TRY(c, hipEventRecord(c->ev[5], s));
-                HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
-                HIP_TRY(c, hipStreamSynchronize(s));
-                const uint32_t again = cnt[1] - a1;          // <= a1 - a0: source and destination do not overlap
-                if (again) HIP_TRY(c, hipMemcpyAsync(c->d_over.as<uint32_t>() + a0, c->d_over.as<uint32_t>() + a1, (size_t)again * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-                cnt[1] = a0 + again;
-                HIP_TRY(c, hipMemcpyAsync(d_cnt + 1, cnt + 1, sizeof(uint32_t), hipMemcpyHostToDevice, s));
-                ++launches;
-            }
-            over_before = cnt[1];
-            {
-                float ms = 0;
-                if (!run_skipped) {
-                    HIP_TRY(c, hipEventElapsedTime(&ms, swept ? c->ev[10] : c->ev[4], c->ev[5]));
-                    band_run_ms += ms;
-                    if (int rc = collect_sweep_times()) return rc;
-                }
-                if (diag) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[6])); diag_ms += ms; }
-            }
-            if (!sweep_used && base + chunk >= n_tasks && cnt[1])      // last chunk: the overflow list is complete
-                if (int rc = fallback_start(0, cnt[1])) return rc;
-            if (cnt[0] > hard_cap) {               // the excess went to the general kernel's list: slots in use = hard_cap
-                cnt[0] = hard_cap;
-                HIP_TRY(c, hipMemcpyAsync(d_cnt, cnt, sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            }
-            cnt[11] = std::min(cnt[11], pend_cap);
-            if (cnt[11]) {
-                // tasks whose piece list overflowed its LDS slots: the same certificate, from their pending records
-                HIP_TRY(c, vtxk_launch_band_pending(c->d_pend.as<uint32_t>(), cnt[11], c->d_pend_buf.as<uint32_t>(),
-                                                    c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_poly.as<uint16_t>(),
-                                                    poly_stride / 2, c->d_hard.as<uint32_t>(), d_cnt, s));
-                HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                HIP_TRY(c, hipStreamSynchronize(s));
-                pending_total += cnt[11];
-                ++launches;
-            }
-            if (int rc = masked_dp(cnt[0], c->d_hard.as<uint32_t>(), c->d_poly.as<uint16_t>(), c->d_band.as<uint16_t>(), slots, s, VTX_STAGE_RUN_DP)) return rc;
-            hard_total += cnt[0];
-            ++launches;
-            if (sweep_used && base + chunk >= n_tasks) {
-                // last chunk.  What overflowed band_run_kernel's lists (d_over[0, nA)) takes band_sweep_kernel too; then everything
-                // the sweep declined — here and in the chunks' own sweeps: d_over[2 n_tasks, + nB), counted on the device — takes the
-                // general band kernel (round 4's kernel, libvtx_dev.so: first its second pass, [2 n_tasks + nB, + nC) is what is left).
-                uint32_t* over = c->d_over.as<uint32_t>();
-                const uint32_t nA = cnt[1];
-                if (nA) {
-                    // (these tasks left band_diag_kernel for another reason than their number of matches, and then overflowed
-                    // band_run_kernel's piece lists: repeats as well — on real-sequence loci 0.9 M tasks.  The second stage first, when
-                    // the tables of every locus are still resident.)
-                    const uint32_t* sl = over;
-                    uint32_t n_sweep = nA;
-                    if (second_stage_on(nA) && gt_bytes && !gt_chunked && nA <= chunk && c->d_dense.cap >= (size_t)nA * sizeof(uint32_t)) {
-                        if (int rc = second_stage(over, nA, 0, c->d_dense.as<uint32_t>(), &n_sweep)) return rc;
-                        sl = c->d_dense.as<uint32_t>();
-                    }
-                    if (n_sweep) { if (int rc = sweep_slices(0, sl, n_sweep, over + 2 * n_tasks, d_cnt + 26)) return rc; }
-                    swept_total += n_sweep;
-                }
-                uint32_t nB = 0, nC = 0;
-                HIP_TRY(c, hipMemcpyAsync(&nB, d_cnt + 27, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                HIP_TRY(c, hipStreamSynchronize(s));
-                if (int rc = collect_sweep_times()) return rc;
-                if (nB && sweep_v1) {                       // (round 4's kernel only: its second pass with the larger log)
-                    resweep_total = nB;
-                    if (int rc = sweep_slices(1, over + 2 * n_tasks, nB, over + 2 * n_tasks + nB, d_cnt + 28)) return rc;
-                    HIP_TRY(c, hipMemcpyAsync(&nC, d_cnt + 29, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
                     HIP_TRY(c, hipStreamSynchronize(s));
-                } else if (nB) {                            // what band_sweep_kernel declines (bytes outside ACGTN, > 255 bases, > 1 024 sections, a
-                    nC = nB; nB = 0;                        // full stash bucket) takes the general band kernel
                 }
-                cnt[1] = nC;
-                if (nC) { if (int rc = fallback_start((uint32_t)(2 * n_tasks) + nB, (uint32_t)(2 * n_tasks) + nB + nC)) return rc; }
+                // (task-list mode runs the 15-entry variant: nothing to give a second chance to)
+                const bool short_lists = !diag && gt_n && vtxk_band_second_chance(tasks_per_locus, c->band_long_lists ? 1 : 0);
+                if (short_lists && nt >= (1u << 20)) {
+                    // feedback for the next run of this context: many overflows of the 12-entry lists (noisy reads: 3.3 % of the
+                    // tasks at 3 % substitution errors, 0.2 % at 0.5 %) make the 15-entry variant the better first pass
+                    if ((uint64_t)(cnt[1] - over_before) * 50 > nt) c->band_long_lists = true;
+                }
+                if (short_lists && cnt[1] > over_before) {
+                    // The six-wavefront variant keeps 12-entry lists: the tasks that overflowed them ([a0, a1) of the overflow
+                    // list) get a second chance in the 15-entry variant before the general kernel — what overflows again is
+                    // appended behind a1 and then moved down to a0.
+                    const uint32_t a0 = over_before, a1 = cnt[1];
+                    HIP_TRY(c, hipMemsetAsync(d_cnt + 16, 0, 8 * sizeof(uint32_t), s));
+                    HIP_TRY(c, vtxk_launch_band_run(a1 - a0, 0, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                     c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                                     mh, mh_min, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
+                                                     c->d_band_ws.as<uint32_t>(), c->d_poly.as<uint16_t>(), poly_stride / 2,
+                                                     c->d_hard.as<uint32_t>(), c->d_over.as<uint32_t>(), c->d_pend.as<uint32_t>(),
+                                                     c->d_pend_buf.as<uint32_t>(), hard_cap, pend_cap, d_cnt, tasks_per_locus, gt_l0,
+                                                     gt_n, c->d_gtables.as<uint8_t>(), gt_bytes, c->d_over.as<uint32_t>() + a0, 0, s));
+                    HIP_TRY(c, hipEventRecord(c->ev[5], s));
+                    HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipStreamSynchronize(s));
+                    const uint32_t again = cnt[1] - a1;          // <= a1 - a0: source and destination do not overlap
+                    if (again) HIP_TRY(c, hipMemcpyAsync(c->d_over.as<uint32_t>() + a0, c->d_over.as<uint32_t>() + a1, (size_t)again * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+                    cnt[1] = a0 + again;
+                    HIP_TRY(c, hipMemcpyAsync(d_cnt + 1, cnt + 1, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+                    ++launches;
+                }
+                over_before = cnt[1];
+                {
+                    float ms = 0;
+                    if (!run_skipped) {
+                        HIP_TRY(c, hipEventElapsedTime(&ms, swept ? c->ev[10] : c->ev[4], c->ev[5]));
+                        band_run_ms += ms;
+                        if (int rc = collect_sweep_times()) return rc;
+                    }
+                    if (diag) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[6])); diag_ms += ms; }
+                }
+                if (!sweep_used && base + chunk >= t_end && cnt[1])      // last chunk: the overflow list is complete
+                    if (int rc = fallback_start(0, cnt[1])) return rc;
+                if (cnt[0] > hard_cap) {               // the excess went to the general kernel's list: slots in use = hard_cap
+                    cnt[0] = hard_cap;
+                    HIP_TRY(c, hipMemcpyAsync(d_cnt, cnt, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+                }
+                cnt[11] = std::min(cnt[11], pend_cap);
+                if (cnt[11]) {
+                    // tasks whose piece list overflowed its LDS slots: the same certificate, from their pending records
+                    HIP_TRY(c, vtxk_launch_band_pending(c->d_pend.as<uint32_t>(), cnt[11], c->d_pend_buf.as<uint32_t>(),
+                                                        c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_poly.as<uint16_t>(),
+                                                        poly_stride / 2, c->d_hard.as<uint32_t>(), d_cnt, s));
+                    HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipStreamSynchronize(s));
+                    pending_total += cnt[11];
+                    ++launches;
+                }
+                if (int rc = masked_dp(cnt[0], c->d_hard.as<uint32_t>(), c->d_poly.as<uint16_t>(), c->d_band.as<uint16_t>(), slots, s, VTX_STAGE_RUN_DP)) return rc;
+                hard_total += cnt[0];
+                ++launches;
+                if (sweep_used && base + chunk >= t_end) {
+                    // last chunk.  What overflowed band_run_kernel's lists (d_over[0, nA)) takes band_sweep_kernel too; then everything
+                    // the sweep declined — here and in the chunks' own sweeps: d_over[2 n_tasks, + nB), counted on the device — takes the
+                    // general band kernel (round 4's kernel, libvtx_dev.so: first its second pass, [2 n_tasks + nB, + nC) is what is left).
+                    uint32_t* over = c->d_over.as<uint32_t>();
+                    const uint32_t nA = cnt[1];
+                    if (nA) {
+                        // (these tasks left band_diag_kernel for another reason than their number of matches, and then overflowed
+                        // band_run_kernel's piece lists: repeats as well — on real-sequence loci 0.9 M tasks.  The second stage first, when
+                        // the tables of every locus are still resident.)
+                        const uint32_t* sl = over;
+                        uint32_t n_sweep = nA;
+                        if (second_stage_on(nA) && gt_bytes && !gt_chunked && nA <= chunk && c->d_dense.cap >= (size_t)nA * sizeof(uint32_t)) {
+                            if (int rc = second_stage(over, nA, 0, c->d_dense.as<uint32_t>(), &n_sweep)) return rc;
+                            sl = c->d_dense.as<uint32_t>();
+                        }
+                        if (n_sweep) { if (int rc = sweep_slices(0, sl, n_sweep, over + 2 * n_tasks, d_cnt + 26)) return rc; }
+                        swept_total += n_sweep;
+                    }
+                    uint32_t nB = 0, nC = 0;
+                    HIP_TRY(c, hipMemcpyAsync(&nB, d_cnt + 27, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipStreamSynchronize(s));
+                    if (int rc = collect_sweep_times()) return rc;
+                    if (nB && sweep_v1) {                       // (round 4's kernel only: its second pass with the larger log)
+                        resweep_total = nB;
+                        if (int rc = sweep_slices(1, over + 2 * n_tasks, nB, over + 2 * n_tasks + nB, d_cnt + 28)) return rc;
+                        HIP_TRY(c, hipMemcpyAsync(&nC, d_cnt + 29, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                        HIP_TRY(c, hipStreamSynchronize(s));
+                    } else if (nB) {                            // what band_sweep_kernel declines (bytes outside ACGTN, > 255 bases, > 1 024 sections, a
+                        nC = nB; nB = 0;                        // full stash bucket) takes the general band kernel
+                    }
+                    cnt[1] = nC;
+                    if (nC) { if (int rc = fallback_start((uint32_t)(2 * n_tasks) + nB, (uint32_t)(2 * n_tasks) + nB + nC)) return rc; }
+                }
             }
+            fast_overflow = cnt[1];
+            if (getenv("VTX_DEBUG")) {
+                uint32_t why[11];
+                HIP_TRY(c, hipMemcpy(why, d_cnt, sizeof why, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[vtx] band_run_kernel: %u tasks hard only because pieces were dropped from a full list\n", why[10]);
+                fprintf(stderr, "[vtx] band_run_kernel overflow reasons: bound=%u parked-full=%u log-full=%u other=%u traceback=%u\n", why[3], why[4], why[5], why[6], why[7]);
+            }
+            if (int rc = fallback_finish()) return rc;
+            c->fast_overflow += fast_overflow;
+            c->timing.diag_ms += diag_ms; c->timing.diag_left += (uint32_t)std::min<uint64_t>(diag_left, 0xffffffffull);
+            c->timing.check_ms += check_ms; c->timing.sweep_ms += sweep_ms;
+            c->timing.swept_tasks += (uint32_t)std::min<uint64_t>(swept_total, 0xffffffffull);
+            c->timing.resweep_tasks += resweep_total;
+            c->timing.diag2_tasks += (uint32_t)std::min<uint64_t>(diag2_total, 0xffffffffull);
+            c->timing.diag2_scored += (uint32_t)std::min<uint64_t>(diag2_scored, 0xffffffffull);
+            c->timing.diag2_streamed += (uint32_t)std::min<uint64_t>(stream_total, 0xffffffffull);
+            checked_total += tight2_total;                     // (one-diagonal bands of the second stage: the same masked DP)
+            c->timing.checked_tasks += (uint32_t)std::min<uint64_t>(checked_total, 0xffffffffull);
+            if (swept_total) hard_total += (uint32_t)std::min<uint64_t>(swept_total - std::min<uint64_t>(swept_total, fast_overflow), 0xffffffffull);
+            hard_total += (uint32_t)std::min<uint64_t>(checked_total, 0xffffffffull);      // (tasks with a certificate: masked DP over their diagonal band; with VTX_BAND_CHECK an upper bound)
+            if (getenv("VTX_DEBUG") && diag_total) {
+                uint32_t why[16];
+                HIP_TRY(c, hipMemcpy(why, d_cnt + 32, sizeof why, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[vtx] band_refine_kernel: %llu tasks listed\n", (unsigned long long)refined_total);
+                fprintf(stderr, "[vtx] band_diag_kernel: %llu of %llu tasks left to band_run_kernel (%.2f %%), %.2f ms: shape=%u no-diagonal=%u pieces=%u matches=%u not-harmless=%u generic=%u not-tight=%u no-main=%u\n",
+                        (unsigned long long)diag_left, (unsigned long long)diag_total, 100.0 * (double)diag_left / (double)diag_total, (double)diag_ms,
+                        why[1], why[2], why[3], why[4], why[5], why[7], why[8], why[9]);
+            }
+            if (getenv("VTX_DEBUG") && diag2_total)
+                fprintf(stderr, "[vtx] band_diag2_kernel: %llu tasks looked at, %llu scored, %llu left with a one-diagonal band, %llu to band_sweep_kernel (%llu through band_stream_kernel)\n",
+                        (unsigned long long)diag2_total, (unsigned long long)diag2_scored, (unsigned long long)tight2_total,
+                        (unsigned long long)(diag2_total - diag2_scored - tight2_total), (unsigned long long)stream_total);
+            if (getenv("VTX_DEBUG")) fprintf(stderr, "[vtx] banded: %llu tasks, %u overflowed band_run_kernel, %u bounded by the pending kernel, %u hard\n", (unsigned long long)n_tasks, fast_overflow, pending_total, hard_total);
+            return VTX_OK;
+        };
+        c->fast_overflow = 0;
+        c->timing.diag_ms = c->timing.check_ms = c->timing.sweep_ms = 0;
+        c->timing.diag_left = c->timing.checked_tasks = c->timing.swept_tasks = c->timing.resweep_tasks = 0;
+        c->timing.diag2_tasks = c->timing.diag2_scored = c->timing.diag2_streamed = 0;
+        // Shape per task (round 6).  A haplotype above 255 bases (a long deletion or insertion, a larger --padding) does not fit the
+        // two-byte match entries of band_diag_kernel<., uint16_t> nor band_sweep_kernel's 256 columns; ONE such locus used to put the
+        // whole batch on round 3's path (config 3: 18.9 instead of 15.9 ms; repeat-rich loci lose the sweep and the second stage, 2x).
+        // When they are few, two passes: every locus up to 255 bases as if the others were not there, then the stretch of tasks from
+        // the first to the last long locus with round 3's kernels, the short loci skipped (measured, config 3 + 1 long locus: 16.45 ms;
+        // + 20 spread over the batch: 17.6 ms — the second pass walks the whole stretch: 0.6 ms of skipping, 1 ms of launches).
+        // (Many long loci — a batch at --padding 150 — : one pass as before; two would walk the batch twice for nothing.)
+        static const bool no_split = VTX_DEV_ENV("VTX_BAND_NO_SPLIT") != nullptr;          // test hook: the single pass of rounds 3 - 5
+        const bool split = !no_split && c->max_hap_len > 255 && c->hap_short_max > 0 && c->n_long_loci > 0 &&
+                           (uint64_t)c->n_long_loci * 8 <= c->n_loci;
+        if (!split) {
+            if (int rc = band_pass(c->max_hap_len, 0, 0, 2ull * nr, false)) return rc;
+        } else {
+            if (int rc = band_pass(c->hap_short_max, 0, 0, 2ull * nr, false)) return rc;
+            vtx_locus ends[2];
+            HIP_TRY(c, hipMemcpyAsync(&ends[0], c->d_loci.as<vtx_locus>() + c->long_first, sizeof(vtx_locus), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(&ends[1], c->d_loci.as<vtx_locus>() + c->long_last, sizeof(vtx_locus), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            const uint64_t t0 = 2ull * std::min(ends[0].rec_begin, nr), t1 = 2ull * std::min<uint64_t>((uint64_t)ends[1].rec_begin + ends[1].rec_count, nr);
+            if (t1 > t0) { if (int rc = band_pass(c->max_hap_len, 255, t0, t1, true)) return rc; }
         }
-        fast_overflow = cnt[1];
-        if (getenv("VTX_DEBUG")) {
-            uint32_t why[11];
-            HIP_TRY(c, hipMemcpy(why, d_cnt, sizeof why, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[vtx] band_run_kernel: %u tasks hard only because pieces were dropped from a full list\n", why[10]);
-            fprintf(stderr, "[vtx] band_run_kernel overflow reasons: bound=%u parked-full=%u log-full=%u other=%u traceback=%u\n", why[3], why[4], why[5], why[6], why[7]);
-        }
-        if (int rc = fallback_finish()) return rc;
-        c->fast_overflow = fast_overflow;
-        c->timing.diag_ms = diag_ms; c->timing.diag_left = (uint32_t)std::min<uint64_t>(diag_left, 0xffffffffull);
-        c->timing.check_ms = check_ms; c->timing.sweep_ms = sweep_ms;
-        c->timing.checked_tasks = (uint32_t)std::min<uint64_t>(checked_total, 0xffffffffull);
-        c->timing.swept_tasks = (uint32_t)std::min<uint64_t>(swept_total, 0xffffffffull);
-        c->timing.resweep_tasks = resweep_total;
-        c->timing.diag2_tasks = (uint32_t)std::min<uint64_t>(diag2_total, 0xffffffffull);
-        c->timing.diag2_scored = (uint32_t)std::min<uint64_t>(diag2_scored, 0xffffffffull);
-        c->timing.diag2_streamed = (uint32_t)std::min<uint64_t>(stream_total, 0xffffffffull);
-        checked_total += tight2_total;                     // (one-diagonal bands of the second stage: the same masked DP)
-        c->timing.checked_tasks = (uint32_t)std::min<uint64_t>(checked_total, 0xffffffffull);
-        if (swept_total) hard_total += (uint32_t)std::min<uint64_t>(swept_total - std::min<uint64_t>(swept_total, fast_overflow), 0xffffffffull);
-        hard_total += (uint32_t)std::min<uint64_t>(checked_total, 0xffffffffull);      // (tasks with a certificate: masked DP over their diagonal band; with VTX_BAND_CHECK an upper bound)
-        if (getenv("VTX_DEBUG") && diag_total) {
-            uint32_t why[16];
-            HIP_TRY(c, hipMemcpy(why, d_cnt + 32, sizeof why, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[vtx] band_refine_kernel: %llu tasks listed\n", (unsigned long long)refined_total);
-            fprintf(stderr, "[vtx] band_diag_kernel: %llu of %llu tasks left to band_run_kernel (%.2f %%), %.2f ms: shape=%u no-diagonal=%u pieces=%u matches=%u not-harmless=%u generic=%u not-tight=%u no-main=%u\n",
-                    (unsigned long long)diag_left, (unsigned long long)diag_total, 100.0 * (double)diag_left / (double)diag_total, (double)diag_ms,
-                    why[1], why[2], why[3], why[4], why[5], why[7], why[8], why[9]);
-        }
-        if (getenv("VTX_DEBUG") && diag2_total)
-            fprintf(stderr, "[vtx] band_diag2_kernel: %llu tasks looked at, %llu scored, %llu left with a one-diagonal band, %llu to band_sweep_kernel (%llu through band_stream_kernel)\n",
-                    (unsigned long long)diag2_total, (unsigned long long)diag2_scored, (unsigned long long)tight2_total,
-                    (unsigned long long)(diag2_total - diag2_scored - tight2_total), (unsigned long long)stream_total);
-        if (getenv("VTX_DEBUG")) fprintf(stderr, "[vtx] banded: %llu tasks, %u overflowed band_run_kernel, %u bounded by the pending kernel, %u hard\n", (unsigned long long)n_tasks, fast_overflow, pending_total, hard_total);
     }
     if (c->slow_cnt) {
         // records beyond the fast kernels' limits: exact slow path, both flavours (slabs grow until every chain fits)

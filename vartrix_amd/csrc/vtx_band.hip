@@ -1275,7 +1275,7 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
     uint32_t n_tasks, uint32_t task_base,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
     const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
-    uint32_t max_hap, uint32_t tables_per_pass, uint32_t table_stride,
+    uint32_t max_hap, uint32_t min_hap, uint32_t tables_per_pass, uint32_t table_stride,
     int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ logbuf, uint16_t* __restrict__ band, uint32_t band_stride,
     uint32_t* __restrict__ hard_list, uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ pending_list,
@@ -1351,7 +1351,9 @@ __global__ __launch_bounds__(NT, WPE) void band_run_kernel(
     bool done = !have;
     if (have && (m == 0 || n == 0)) { *my_score = 0; done = true; }     // empty read / haplotype: score 0
     // reads / haplotypes beyond what these tables and lists hold are scored by slow_align_kernel (the host lists them)
-    if (have && (m > VTX_FAST_READ_LEN || max(loci[my_locus].ref_len, loci[my_locus].alt_len) > max_hap)) done = true;
+    // (min_hap: the pass over the batch's long-haplotype loci — vtx_run's second pass — leaves the loci the first pass scored alone)
+    if (have && (m > VTX_FAST_READ_LEN || max(loci[my_locus].ref_len, loci[my_locus].alt_len) > max_hap ||
+                 max(loci[my_locus].ref_len, loci[my_locus].alt_len) <= min_hap)) done = true;
     // a task without any k-mer match has the whole matrix in band (Band::full_matrix): hard list, marker slot
     // (hard slots beyond the capacity of the band buffer go to the general kernel's list, which makes them hard in slices)
 #define PUSH_FULL_MATRIX() { const uint32_t h_ = atomicAdd(&counters[0], 1u);                                    \
@@ -1889,7 +1891,7 @@ __device__ __forceinline__ void wave_sync() {
 // One wavefront per workgroup: its LDS instructions execute in program order, wave_sync() is all the ordering needed.
 // =============================================================================================
 __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __restrict__ loci, uint32_t l0, uint32_t n_loci,
-                                                         const uint8_t* __restrict__ hap_arena, uint32_t max_hap,
+                                                         const uint8_t* __restrict__ hap_arena, uint32_t max_hap, uint32_t min_hap,
                                                          uint32_t table_stride, uint32_t n_heads, uint8_t* __restrict__ gtables) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint8_t* tb = (uint8_t*)smem;
@@ -1904,6 +1906,7 @@ __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __rest
     const uint32_t zero_words = vtxf::tab_uq_words(max_hap) + 128u;           // uq[] and, behind it, pb[128]
     for (uint32_t t = blockIdx.x; t < 2u * n_loci; t += gridDim.x) {
         const vtx_locus loc = loci[l0 + (t >> 1)];
+        if (max(loc.ref_len, loc.alt_len) <= min_hap) continue;               // (a locus of the other pass: its table is never read; wave-uniform)
         const uint32_t hn = max(loc.ref_len, loc.alt_len) > max_hap ? 0u : ((t & 1) ? loc.alt_len : loc.ref_len);   // (a locus of the slow list: no table)
         const uint8_t* hy = hap_arena + ((t & 1) ? loc.alt_off : loc.ref_off);
         const int nk = hn >= (uint32_t)KMER ? (int)hn - KMER + 1 : 0;
@@ -1988,7 +1991,9 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     const uint8_t* __restrict__ gtables, uint32_t gt_l0, int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score,
     uint32_t* __restrict__ fail_list, uint32_t* __restrict__ refine_rec, uint32_t refine_cap, uint32_t* __restrict__ counters,
     uint32_t stats, uint32_t* __restrict__ tight_list, uint32_t* __restrict__ tight_pack, uint8_t* __restrict__ stage,
-    uint32_t* __restrict__ dense_list, uint32_t dense_mask) {
+    uint32_t* __restrict__ dense_list, uint32_t dense_mask, uint32_t min_hap) {
+    // min_hap: tasks of loci whose longer haplotype has <= min_hap bases are left alone (vtx_run's second pass over a batch that mixes
+    // haplotypes of <= 255 bases with a few longer ones: the first pass, with two-byte entries and the sweep behind it, scored them).
     // dense_list != nullptr (round 4): a task left for a reason in dense_mask (bit = vtxf::Why; by default W_MATCHES: more than 40
     // off-diagonal k-mer matches — repeats) goes there (counters[13]): band_run_kernel's piece lists would overflow on it, it takes
     // band_sweep_kernel directly.
@@ -2047,8 +2052,8 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         if (m == 0 || n == 0) {
             *my_score = 0;                                               // empty read / haplotype: score 0
             if (stage) stage[task] = 1;
-        } else if ((uint32_t)m > VTX_FAST_READ_LEN || max(loc.ref_len, loc.alt_len) > max_hap) {
-            // beyond the fast kernels: slow_align_kernel scores it (the host lists these records)
+        } else if ((uint32_t)m > VTX_FAST_READ_LEN || max(loc.ref_len, loc.alt_len) > max_hap || max(loc.ref_len, loc.alt_len) <= min_hap) {
+            // beyond the fast kernels: slow_align_kernel scores it (the host lists these records); or a locus of the other pass
         } else if (m < vtxf::K || n < vtxf::K || m > vtxf::MAX_READ) {
             fail = true; why = vtxf::W_SHAPE;
         } else {
@@ -2442,7 +2447,7 @@ static uint32_t gt_max_tpl() {
 }
 // the tables of n_loci loci in global memory: band_tables_kernel (a table per wavefront); VTX_BAND_TABLES_V1=1: round 3's kernel
 // (a locus per wavefront, serial chain insertion) — the reference the new one is compared with byte for byte (tests)
-static void launch_band_tables(const vtx_locus* loci, uint32_t gt_l0, uint32_t n_loci, const uint8_t* hap_arena, uint32_t max_hap,
+static void launch_band_tables(const vtx_locus* loci, uint32_t gt_l0, uint32_t n_loci, const uint8_t* hap_arena, uint32_t max_hap, uint32_t min_hap,
                                size_t tstride, uint32_t n_heads, uint8_t* gtables, hipStream_t s) {
 #ifdef VTX_DEVTOOLS
     if (VTX_DEV_ENV("VTX_BAND_TABLES_V1")) {
@@ -2452,7 +2457,7 @@ static void launch_band_tables(const vtx_locus* loci, uint32_t gt_l0, uint32_t n
     }
 #endif
     hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(2u * n_loci, 256u * 32u)), dim3(64), tstride, s, loci, gt_l0, n_loci,
-                           hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
+                           hap_arena, max_hap, min_hap, (uint32_t)tstride, n_heads, gtables);
 }
 
 // buckets of a table's hash (power of two; experiment knob VTX_BAND_HEADS)
@@ -2491,7 +2496,7 @@ extern "C" uint32_t vtxk_band_run_lanes(void) { return 256u * 256u * (uint32_t)s
 
 extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
                                            const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
-                                           const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score,
+                                           const uint8_t* hap_arena, uint32_t max_hap, uint32_t min_hap, int32_t* ref_score,
                                            int32_t* alt_score, uint32_t* logbuf, uint16_t* band,
                                            uint32_t band_stride, uint32_t* hard_list, uint32_t* overflow_list,
                                            uint32_t* pending_list, uint32_t* pend_buf, uint32_t hard_cap, uint32_t pend_cap,
@@ -2552,7 +2557,7 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     if (shmem > 160 * 1024 - 256) return hipErrorInvalidValue;
     if (task_list && !global_tables) return hipErrorInvalidValue;    // (list mode reads the tables the first pass built)
     if (global_tables && !task_list)
-        launch_band_tables(loci, gt_l0, n_loci, hap_arena, max_hap, tstride, n_heads, gtables, s);
+        launch_band_tables(loci, gt_l0, n_loci, hap_arena, max_hap, min_hap, tstride, n_heads, gtables, s);
     const uint32_t ablate = (uint32_t)(VTX_DEV_ENV("VTX_BAND_ABLATE") ? atoi(VTX_DEV_ENV("VTX_BAND_ABLATE")) : 0);
     const uint32_t xcd_claim = ((tasks_per_locus >= 24 || VTX_DEV_ENV("VTX_BAND_XCD")) && !VTX_DEV_ENV("VTX_BAND_NO_XCD")) ? 1u : 0u;   // (measured: config 3 -3 %, 64 / 32 reads per locus -4.5 %, 16: -1 %, 4: +2 %)
 #define LAUNCH_RUN(NTV, GTV, WV, PV)                                                                                 \
@@ -2565,7 +2570,7 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
         hipLaunchKernelGGL((band_run_kernel<NTV, GTV, WV, PV>),                                                      \
                            dim3(std::min((n_tasks + NTV - 1) / NTV, vtxk_band_run_grid(NTV, WV))),                    \
                            dim3(NTV), shmem, s, n_tasks,                                                             \
-                           task_base, records, rec_locus, loci, read_arena, hap_arena, max_hap, tables,              \
+                           task_base, records, rec_locus, loci, read_arena, hap_arena, max_hap, min_hap, tables,     \
                            (uint32_t)tstride, ref_score, alt_score, logbuf, band, band_stride, hard_list,            \
                            overflow_list, pending_list, pend_buf, hard_cap, pend_cap, counters, ablate, n_heads,     \
                            (const uint8_t*)gtables, gt_l0, task_list ? 0u : xcd_claim, task_list);                   \
@@ -2583,7 +2588,7 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
 // tables do not fit the buffer (the caller then runs band_run_kernel alone, which falls back to tables in LDS).
 extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
                                             const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
-                                            const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score, int32_t* alt_score,
+                                            const uint8_t* hap_arena, uint32_t max_hap, uint32_t min_hap, int32_t* ref_score, int32_t* alt_score,
                                             uint32_t* fail_list, uint32_t* refine_rec, uint32_t refine_cap, uint32_t* counters,
                                             uint32_t tasks_per_locus, uint32_t gt_l0, uint32_t n_loci, uint8_t* gtables,
                                             size_t gtables_bytes, int stats, uint32_t* tight_list, uint32_t* tight_pack, uint8_t* stage,
@@ -2592,7 +2597,7 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     const uint32_t n_heads = pick_heads(tasks_per_locus, true);
     const size_t tstride = band_table_stride(max_hap, n_heads);
     if (!gtables || (size_t)n_loci * 2 * tstride > gtables_bytes) return hipErrorInvalidValue;
-    launch_band_tables(loci, gt_l0, n_loci, hap_arena, max_hap, tstride, n_heads, gtables, s);
+    launch_band_tables(loci, gt_l0, n_loci, hap_arena, max_hap, min_hap, tstride, n_heads, gtables, s);
     const uint32_t n_blocks = (n_tasks + 255) / 256;
     const uint32_t st = (uint32_t)stats | (VTX_DEV_ENV("VTX_DIAG_ABLATE") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_DIAG_ABLATE")) << 8 : 0u);
     // two-byte match entries (40 per task) whenever a haplotype position fits a byte; VTX_DIAG_WIDE=1 forces the four-byte variant (tests)
@@ -2600,11 +2605,11 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     if (max_hap <= 255 && !force_wide)
         hipLaunchKernelGGL((band_diag_kernel<4, uint16_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
                            rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, tight_pack, stage, dense_list, dense_mask);
+                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, tight_pack, stage, dense_list, dense_mask, min_hap);
     else
         hipLaunchKernelGGL((band_diag_kernel<4, uint32_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
                            rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, tight_pack, stage, dense_list, dense_mask);
+                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, tight_pack, stage, dense_list, dense_mask, min_hap);
     return hipGetLastError();
 }
 

@@ -72,14 +72,14 @@ hipError_t vtxk_launch_band(const uint32_t* tasks, uint32_t n_tasks, uint32_t ta
                             hipStream_t s);
 hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base, const vtx_record* records,
                                 const uint32_t* rec_locus, const vtx_locus* loci, const uint8_t* read_arena,
-                                const uint8_t* hap_arena, uint32_t max_hap, int32_t* ref_score,
+                                const uint8_t* hap_arena, uint32_t max_hap, uint32_t min_hap, int32_t* ref_score,
                                 int32_t* alt_score, uint32_t* logbuf, uint16_t* band, uint32_t band_stride,
                                 uint32_t* hard_list, uint32_t* overflow_list, uint32_t* pending_list, uint32_t* pend_buf,
                                 uint32_t hard_cap, uint32_t pend_cap, uint32_t* counters, uint32_t tasks_per_locus,
                                 uint32_t gt_l0, uint32_t n_loci, uint8_t* gtables, size_t gtables_bytes, const uint32_t* task_list,
                                 int long_lists, hipStream_t s);
 hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base, const vtx_record* records, const uint32_t* rec_locus,
-                                 const vtx_locus* loci, const uint8_t* read_arena, const uint8_t* hap_arena, uint32_t max_hap,
+                                 const vtx_locus* loci, const uint8_t* read_arena, const uint8_t* hap_arena, uint32_t max_hap, uint32_t min_hap,
                                  int32_t* ref_score, int32_t* alt_score, uint32_t* fail_list, uint32_t* refine_rec,
                                  uint32_t refine_cap, uint32_t* counters, uint32_t tasks_per_locus, uint32_t gt_l0, uint32_t n_loci,
                                  uint8_t* gtables, size_t gtables_bytes, int stats, uint32_t* tight_list, uint32_t* tight_pack, uint8_t* stage,
