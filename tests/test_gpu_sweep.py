@@ -277,6 +277,9 @@ def test_table_kernel_against_round3s():
     cases.append(("haplotypes of one repeated unit, a byte above 0x7f", SB.manual_batch(haps, rds, 10), 10))
     checked = 0
     for label, batch, nb in cases:
+        hl = np.maximum(batch.loci["ref_len"], batch.loci["alt_len"])
+        if (hl > 255).any() and (hl <= 255).any() and int((hl > 255).sum()) * 8 <= batch.n_loci:
+            continue                                     # (vtx_run scores such a batch in two passes, tests/test_gpu_shape.py: the buffer holds the second pass' few tables)
         os.environ.pop("VTX_BAND_TABLES_V1", None)
         tp, sp = _tables_and_scores(batch, nb)                   # the production library
         os.environ["VTX_BAND_TABLES_V1"] = "1"
