@@ -58,7 +58,7 @@ int vtxt_corridor_cost(const uint8_t* x, int m, const uint8_t* y, int n, int xb,
     return vtxf::corridor_cost(x, m, y, n, xb, d, D, mu_a, mu_b);
 }
 // diag_mask (the match mask of one diagonal) and the pieces / mismatch nibbles front_rest() derives from it, for a single read and
-// haplotype: out[0..2] = mask words, out[3] = number of main pieces, out[4] = zc, out[5] = certificate
+// haplotype: out[0..2] (and out[14]) = mask words, out[3] = number of main pieces, out[4] = zc, out[5] = certificate
 int vtxt_front_of_diagonal(const uint8_t* x, int m, const uint8_t* y, int n, int d, uint64_t* out) {
     using namespace vtxf;
     const uint32_t max_hap = (uint32_t)std::max(n, 8), n_heads = 1024;
@@ -70,8 +70,8 @@ int vtxt_front_of_diagonal(const uint8_t* x, int m, const uint8_t* y, int n, int
     std::vector<uint8_t> xb((size_t)m + 16, 0);
     memcpy(xb.data(), x, (size_t)m);
     const ReadWords rw = read_words(xb.data(), m);
-    const M192 M = diag_mask(rw, m, tb, n, d);
-    out[0] = M.w0; out[1] = M.w1; out[2] = M.w2;
+    const M192 M = diag_mask(rw, xb.data(), m, tb, n, d);
+    out[0] = M.w[0]; out[1] = M.w[1]; out[2] = M.w[2]; out[14] = NW > 3 ? M.w[NW - 1] : 0;     // (out[6 .. 13]: the pieces)
     uint32_t lane[LANE_WORDS];
     const LaneS<uint32_t> ln{lane + S_WORDS, 1, lane, 1};
     const Front fr = front_rest(xb.data(), m, tb, n, ln, d, M);
@@ -79,7 +79,7 @@ int vtxt_front_of_diagonal(const uint8_t* x, int m, const uint8_t* y, int n, int
     for (int i = 0; i < RM; ++i) out[6 + i] = i < fr.r ? lane[S_WORDS + i] : 0;
     return 0;
 }
-// The probe phase for a single read and haplotype on diagonal d: out[0..2] = the rows front_rest() wants probed, then the
+// The probe phase for a single read and haplotype on diagonal d: need_out[0..3] = the rows front_rest() wants probed, then the
 // off-diagonal matches probe_rows() finds (x << 16 | y, up to cap); returns their number (-1: front_rest declined)
 int vtxt_probe_of_diagonal(const uint8_t* x, int m, const uint8_t* y, int n, int d, uint64_t* need_out, uint32_t* s_out, int cap) {
     using namespace vtxf;
@@ -92,20 +92,20 @@ int vtxt_probe_of_diagonal(const uint8_t* x, int m, const uint8_t* y, int n, int
     std::vector<uint8_t> xb((size_t)m + 16, 0);
     memcpy(xb.data(), x, (size_t)m);
     const ReadWords rw = read_words(xb.data(), m);
-    const M192 M = diag_mask(rw, m, tb, n, d);
+    const M192 M = diag_mask(rw, xb.data(), m, tb, n, d);
     uint32_t lane[LANE_WORDS];
     const LaneS<uint32_t> ln{lane + S_WORDS, 1, lane, 1};
     const Front fr = front_rest(xb.data(), m, tb, n, ln, d, M);
     if (fr.why != W_OK) return -1;
-    need_out[0] = fr.need.w0; need_out[1] = fr.need.w1; need_out[2] = fr.need.w2;
+    for (int k = 0; k < 4; ++k) need_out[k] = k < NW ? fr.need.w[k < NW ? k : 0] : 0;
     // probe_rows() stops counting above the lane's capacity: probe the rows in slices so that every match is seen
     int total = 0;
     M192 need = fr.need;
     while (m_any(need)) {
         Front one = fr;
-        one.need = M192{0, 0, 0};
+        one.need = m_zero();
         const int row = m_pop_lowest(need);
-        if (row < 64) one.need.w0 = 1ull << row; else if (row < 128) one.need.w1 = 1ull << (row - 64); else one.need.w2 = 1ull << (row - 128);
+        one.need.w[row >> 6] = 1ull << (row & 63);
         const int ns = probe_rows(xb.data(), tb, one, ln);
         if (ns > LaneS<uint32_t>::SMAX) return -2;                    // more matches in ONE row than a lane holds
         for (int k = 0; k < ns && total < cap; ++k) s_out[total++] = lane[k];

@@ -102,8 +102,8 @@ def test_corridor_refinement_is_exact_and_decides_more(core):
     oracle's, and at 3 % substitution errors clearly more tasks are decided."""
     dec = {}
     for err in (0.01, 0.03, 0.08):
-        for rl, pad in ((150, 100), (100, 60)):
-            batch = synth.make_batch(synth.SynthSpec(n_loci=120, n_barcodes=500, reads_per_locus=48, sub_error=err, read_len=rl, padding=pad, seed=77))
+        for rl, pad in ((150, 100), (100, 60), (250, 100), (200, 120)):            # (above 192 bases: the fourth mask word, round 6)
+            batch = synth.make_batch(synth.SynthSpec(n_loci=120 if rl <= 150 else 40, n_barcodes=500, reads_per_locus=48, sub_error=err, read_len=rl, padding=pad, seed=77))
             for rf in (0, 1):
                 frac, why = check(core, batch, 500, "err %g len %d, refine %d" % (err, rl, rf), 1024 | (rf << 30))
                 dec[(err, rl, rf)] = frac
@@ -139,7 +139,7 @@ def test_refined_join_stays_below_an_excursion_over_a_far_piece(core):
 def test_mask_pieces_and_mismatch_counts_of_a_diagonal(core):
     """diag_mask and front_rest AS COMPILED from vtx_fast_core.h on single (read, haplotype, diagonal) triples against the
     definitions: bit i of the mask = (x[i] == y[i + d]) where both exist; the main pieces = the runs of >= 6 ones, in order;
-    nibble i of zc = the zeros between piece i - 1 and piece i (capped at 15).  Reads up to 192 bases, diagonals from far left of
+    nibble i of zc = the zeros between piece i - 1 and piece i (capped at 15).  Reads up to 256 bases (four mask words since round 6), diagonals from far left of
     the haplotype to far right of it, bytes above 0x7f, lower case, N."""
     core.vtxt_front_of_diagonal.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
     rng = np.random.default_rng(99)
@@ -149,7 +149,7 @@ def test_mask_pieces_and_mismatch_counts_of_a_diagonal(core):
         n = int(rng.integers(8, 256))
         alpha = [b"ACGT", b"ACGTN", b"AC", bytes([65, 67, 71, 84, 0x80, 0xff, 97, 110])][trial % 4]
         y = bytes(rng.choice(list(alpha), n).tolist())
-        m = int(rng.integers(6, 193))
+        m = int(rng.integers(6, 257))
         d = int(rng.integers(-m + 1, n))
         x = bytearray(rng.choice(list(alpha), m).tolist())
         for i in range(m):                                     # mostly the haplotype's own bases on that diagonal
@@ -160,7 +160,7 @@ def test_mask_pieces_and_mismatch_counts_of_a_diagonal(core):
         for i in range(m):
             if 0 <= i + d < n and x[i] == y[i + d]:
                 want |= 1 << i
-        have = int(out[0]) | (int(out[1]) << 64) | (int(out[2]) << 128)
+        have = int(out[0]) | (int(out[1]) << 64) | (int(out[2]) << 128) | (int(out[14]) << 192)
         assert have == want, (trial, m, n, d)
         # pieces and nibbles from the definition (front_rest declines above RM pieces or without any: skip those)
         lo, hi = max(0, -d), min(m, n - d)
@@ -196,7 +196,7 @@ def test_probe_phase_finds_every_off_diagonal_match(core):
     exactly the off-diagonal matches of those rows — on iid, two-letter, tandem-repeat and poly-A haplotypes."""
     core.vtxt_probe_of_diagonal.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     rng = np.random.default_rng(123)
-    need = np.zeros(3, np.uint64)
+    need = np.zeros(4, np.uint64)
     sbuf = np.zeros(20000, np.uint32)
     n_matches = n_done = 0
     for trial in range(600):
@@ -215,7 +215,7 @@ def test_probe_phase_finds_every_off_diagonal_match(core):
             a0 = int(rng.integers(10, n - 40))
             yb[a0:a0 + 25] = b"A" * 25
             y = bytes(yb)
-        m = int(rng.integers(30, 160))
+        m = int(rng.integers(30, 160)) if trial % 3 else int(rng.integers(160, 257))
         d = int(rng.integers(-20, max(n - m + 20, -19)))
         x = bytearray(rng.choice(list(b"ACGT"), m).tolist())
         for i in range(m):
@@ -225,7 +225,7 @@ def test_probe_phase_finds_every_off_diagonal_match(core):
         got = core.vtxt_probe_of_diagonal(x, m, y, n, d, need.ctypes.data, sbuf.ctypes.data, len(sbuf))
         if got < 0:
             continue
-        nmask = int(need[0]) | (int(need[1]) << 64) | (int(need[2]) << 128)
+        nmask = int(need[0]) | (int(need[1]) << 64) | (int(need[2]) << 128) | (int(need[3]) << 192)
         mt = oracle.kmer_matches(x, y)
         off = {(int(a), int(b)) for a, b in mt if int(b) - int(a) != d}
         for (a, b) in off:
@@ -403,19 +403,22 @@ def test_real_read_shapes(core):
 
 
 def test_edge_shapes(core):
-    """Reads at the capacity edge (192 bases), beyond it, shorter than a k-mer; haplotypes shorter than the read; lower-case and
-    N bytes; identical haplotypes; a read that is a pure repeat."""
+    """Reads at the capacity edge (256 bases; 192 until round 6), beyond it, shorter than a k-mer; haplotypes shorter than the read;
+    lower-case and N bytes; identical haplotypes; a read that is a pure repeat."""
     rng = np.random.default_rng(5)
     g = bytes(rng.choice(list(b"ACGT"), 3000).tolist())
     haps = [(g[100:301], g[100:200] + b"T" + g[201:301]), (g[500:520], g[500:510] + g[512:520]),
             (g[800:1001], g[800:900] + b"n" + g[901:1001]), (b"AC" * 100, b"AC" * 50 + b"G" + b"AC" * 50),
-            (g[1500:1900], g[1500:1700] + b"ACGTACGTAC" + g[1700:1900])]
+            (g[1500:1900], g[1500:1700] + b"ACGTACGTAC" + g[1700:1900]),
+            (g[2100:2355], g[2100:2227] + b"T" + g[2228:2355])]
     reads = [
         [(0, 0, g[80:272]), (1, 0, g[60:253]), (2, 0, g[150:155]), (3, 0, g[150:156]), (4, 0, g[100:292]), (5, 0, b"")],
         [(0, 0, g[480:560]), (1, 0, g[500:520]), (2, 0, g[505:511])],
         [(0, 0, g[820:970]), (1, 0, g[820:900] + b"n" + g[901:970]), (2, 0, g[820:900] + b"N" + g[901:970])],
         [(0, 0, b"AC" * 75), (1, 0, b"CA" * 60), (2, 0, b"AC" * 40 + b"G" + b"AC" * 30)],
         [(0, 0, g[1600:1750]), (1, 0, g[1620:1700] + b"ACGTACGTAC" + g[1700:1760]), (2, 0, g[1400:1550])],
+        [(0, 0, g[2100:2355]), (1, 0, g[2050:2306]), (2, 0, g[2050:2307]), (3, 0, g[2090:2283]), (4, 0, g[2200:2450]),
+         (5, 0, g[2100:2200] + b"A" + g[2201:2300] + b"C" + g[2301:2355])],
     ]
     check(core, SB.manual_batch(haps, reads, 8), 8, "edge shapes")
 

@@ -118,3 +118,55 @@ def test_many_long_haplotypes_keep_the_single_pass():
     ids, oref, oalt = oracle_scores_of(batch, np.arange(batch.n_records), "banded", 5000)
     assert np.array_equal(r[ids], oref) and np.array_equal(a[ids], oalt)
     assert not np.isin(stage, (abi.STAGE_SWEEP_DP, abi.STAGE_BAND_CERT)).any()            # (the sweep path was not taken)
+
+
+@pytest.mark.parametrize("read_len", [250, 200, 256])
+def test_reads_above_192_bases_stay_in_the_first_stage(read_len):
+    """A fourth mask word (round 6): band_diag_kernel takes reads up to 256 bases (192 before: longer ones all went to band_run_kernel).
+    250-base reads at padding 100 hang over the window on both sides; at padding 150 (haplotypes above 255 bases) the batch is round
+    3's anyway.  Every alignment against the oracle."""
+    from audit_util import oracle_scores_of, stage_report
+    spec = synth.SynthSpec(n_loci=300, n_barcodes=2000, reads_per_locus=48, read_len=read_len, padding=100, seed=31 + read_len)
+    batch = synth.make_batch(spec)
+    r, a, stage, t = run_banded(batch, 2000)
+    assert not (r == -4242).any() and not (a == -4242).any()
+    round3 = np.isin(stage, ROUND3_STAGES)
+    print("%d-base reads: %d alignments, round-3 path %.2f %%; stages %s" % (read_len, len(stage), 100 * round3.mean(), stage_report(stage)))
+    assert round3.mean() < 0.02
+    ids, oref, oalt = oracle_scores_of(batch, np.arange(batch.n_records), "banded", 2000)
+    bad = np.nonzero((r[ids] != oref) | (a[ids] != oalt))[0]
+    assert bad.size == 0, "record %d: device (%d, %d) oracle (%d, %d)" % (ids[bad[0]], r[ids[bad[0]]], a[ids[bad[0]]], oref[bad[0]], oalt[bad[0]])
+
+
+def test_read_lengths_around_the_mask_edges():
+    """Reads of 186 .. 262 bases (every length) with errors, in one batch of mixed lengths: 192 / 193 (the third word's edge), 255 / 256
+    (the capacity), 257 and more (declined by the first stage: band_run_kernel), against haplotypes of 201 .. 255 bases."""
+    from audit_util import oracle_scores_of
+    rng = np.random.default_rng(77)
+    g = bytes(rng.choice(list(b"ACGT"), 40_000).tolist())
+    haps, reads = [], []
+    import stress_batches as SB
+    for l in range(60):
+        p0 = 500 + 600 * l
+        pad = int(rng.integers(100, 128))
+        alt_base = b"ACGT".replace(g[p0:p0 + 1], b"")[int(rng.integers(0, 3)):][:1]
+        haps.append((g[p0 - pad:p0 + pad + 1], g[p0 - pad:p0] + alt_base + g[p0 + 1:p0 + pad + 1]))
+        rs = []
+        for c, ln in enumerate(range(186, 263)):
+            s = p0 - int(rng.integers(0, ln))
+            x = bytearray(g[s:s + ln])
+            if rng.random() < 0.5:
+                x[p0 - s] = alt_base[0]
+            for e in np.nonzero(rng.random(ln) < 0.01)[0]:
+                x[e] = b"ACGT"[int(rng.integers(0, 4))]
+            rs.append((c, 0, bytes(x)))
+        reads.append(rs)
+    batch = SB.manual_batch(haps, reads, 100)
+    r, a, stage, t = run_banded(batch, 100)
+    ids, oref, oalt = oracle_scores_of(batch, np.arange(batch.n_records), "banded", 100)
+    bad = np.nonzero((r[ids] != oref) | (a[ids] != oalt))[0]
+    assert bad.size == 0, "record %d (length %d): device (%d, %d) oracle (%d, %d)" % (
+        ids[bad[0]], batch.records["read_len"][ids[bad[0]]], r[ids[bad[0]]], a[ids[bad[0]]], oref[bad[0]], oalt[bad[0]])
+    lens = np.repeat(batch.records["read_len"], 2)
+    first = np.isin(stage, (abi.STAGE_DIAG_CERT, abi.STAGE_REFINE_CERT, abi.STAGE_BAND_CERT, abi.STAGE_DIAG_DP))
+    assert first[lens <= 256].mean() > 0.9 and not first[lens > 256].any()

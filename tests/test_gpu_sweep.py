@@ -242,7 +242,7 @@ def _table_layout(max_hap, n_heads):
     bytes_off = max_hap * 8 + n_heads * 2
     fb_off = bytes_off + max_hap + 8
     uq_off = (fb_off + max_hap + 8 + 3) & ~3
-    pb_off = uq_off + 4 * (6 + (max_hap + 31) // 32 + 8)
+    pb_off = uq_off + 4 * (8 + (max_hap + 31) // 32 + 8)
     return bytes_off, fb_off, uq_off, pb_off, (pb_off + 512 + 15) & ~15
 
 

@@ -2030,9 +2030,10 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     const uint32_t task = task_base + slot;
     bool fail = false, live = false, whole = false;
     uint32_t why = 0;
-    int32_t* my_score = nullptr;
+    // (where a task's score goes is recomputed at each of the four stores: a pointer held across the kernel is two registers of 128)
+    auto my_score = [&]() -> int32_t* { return ((task & 1u) ? alt_score : ref_score) + (task >> 1); };
     vtxf::Front fr;
-    fr.why = vtxf::W_SHAPE; fr.d = 0; fr.need = vtxf::M192{0, 0, 0};
+    fr.why = vtxf::W_SHAPE; fr.d = 0; fr.need = vtxf::m_zero();
     typedef vtxf::LaneS<ST> LaneT;
     const LaneT ln{lane_mem + vtxf::S_WORDS * 64 + tid, 64, (ST*)lane_mem + tid, 64};
     vtxf::Tab tb;
@@ -2047,10 +2048,9 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         const uint32_t my_locus = rec_locus[rid];
         const vtx_locus loc = loci[my_locus];
         m = (int)rec.read_len; n = (int)(hap ? loc.alt_len : loc.ref_len);
-        my_score = (hap ? alt_score : ref_score) + rid;
         o_read[tid] = rec.read_off;                                      // (also where this lane drops out: its partner may probe the read)
         if (m == 0 || n == 0) {
-            *my_score = 0;                                               // empty read / haplotype: score 0
+            *my_score() = 0;                                             // empty read / haplotype: score 0
             if (stage) stage[task] = 1;
         } else if ((uint32_t)m > VTX_FAST_READ_LEN || max(loc.ref_len, loc.alt_len) > max_hap || max(loc.ref_len, loc.alt_len) <= min_hap) {
             // beyond the fast kernels: slow_align_kernel scores it (the host lists these records); or a locus of the other pass
@@ -2071,23 +2071,24 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     //      loads) and the two swap halves — a quarter of the load instructions and of the L2 lines 8-byte loads per lane cost ----
     vtxf::ReadWords rw;
     {
-        static_assert(vtxf::RW == 24, "12 words per lane of a pair");
+        constexpr int HW = vtxf::RW / 2;                               // words per lane of a pair (12; 16 with four mask words)
+        static_assert(vtxf::RW % 4 == 0, "16-byte loads");
         const int half = tid & 1;
-        uint64_t mine[12];
+        uint64_t mine[HW];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {                                  // words [12 half + 2k, + 2): bytes [96 half + 16 k, + 16)
-            const int off = 96 * half + 16 * k;
+        for (int k = 0; k < HW / 2; ++k) {                             // words [HW half + 2k, + 2): bytes [8 HW half + 16 k, + 16)
+            const int off = 8 * HW * half + 16 * k;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (live && off < m) __builtin_memcpy(&v, x + off, 16);    // (the arena is padded by 16 bytes)
             mine[2 * k] = (uint64_t)v.x | ((uint64_t)v.y << 32);
             mine[2 * k + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
         }
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
+        for (int k = 0; k < HW; ++k) {
             const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mine[k], 1), hi = (uint32_t)__shfl_xor((int)(uint32_t)(mine[k] >> 32), 1);
             const uint64_t theirs = (uint64_t)lo | ((uint64_t)hi << 32);
             rw.w[k] = half ? theirs : mine[k];
-            rw.w[12 + k] = half ? mine[k] : theirs;
+            rw.w[HW + k] = half ? mine[k] : theirs;
         }
     }
     // ---- the main diagonal.  Lanes 2i / 2i + 1 hold the two haplotypes of one record: each looks ONE sample row up in its own
@@ -2110,9 +2111,9 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
                 if (vtxf::verify_diag(x, m, tb, n, dc)) { d = dc; have_d = true; }
             }
         }
-        vtxf::M192 M{0, 0, 0};
+        vtxf::M192 M = vtxf::m_zero();
         if (live && have_d) {
-            M = vtxf::diag_mask(rw, m, tb, n, d);
+            M = vtxf::diag_mask(rw, x, m, tb, n, d);
             if (vtxf::m_pop(M) < 20) have_d = false;
         }
         if (live && !have_d) { live = false; fail = true; why = vtxf::W_NO_DIAG; }
@@ -2123,7 +2124,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             else if (VTX_ABLATE(stats >> 8) != 10 && vtxf::whole_read(fr, m)) {      // (developer build, VTX_DIAG_ABLATE=10: the shortcut off — the A/B switch of include/vtx_band_semantics.h's fifth item; results stay right)
                 // the read matches base for base: full <= m = cert, and the reference's chain is a perfect diagonal whatever else
                 // matches (vtx_fast_core.h: whole_read) — decided here, before any probe: a fifth of the tasks of a clean workload
-                *my_score = m;
+                *my_score() = m;
                 if (stage) stage[task] = 1;
                 live = false; whole = true;
             }
@@ -2142,13 +2143,14 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     // from the odd one — and an entry (pair, row) is probed in BOTH tables: one load of the read's bytes instead of two, half the
     // entries, half the trips of dependent loads below.  (A row one of the two did not ask for has no off-diagonal match in that
     // haplotype — that is why it was not asked for: looking it up finds nothing.)
-    vtxf::M192 nd = live ? fr.need : vtxf::M192{0, 0, 0};
+    vtxf::M192 nd = live ? fr.need : vtxf::m_zero();
     {
         const uint64_t par = (tid & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
         auto other = [&](uint64_t v) {
             return (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)v, 1) | ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), 1) << 32);
         };
-        nd.w0 = (nd.w0 | other(nd.w0)) & par; nd.w1 = (nd.w1 | other(nd.w1)) & par; nd.w2 = (nd.w2 | other(nd.w2)) & par;
+#pragma unroll
+        for (int k = 0; k < vtxf::NW; ++k) nd.w[k] = (nd.w[k] | other(nd.w[k])) & par;
     }
     vtxf::MIter need_it = vtxf::m_iter(nd);
     if (VTX_ABLATE(stats >> 8) == 1) { if (live && fr.cert == 0x7fffffff) counters[40] = 1; return; }      // (profiling aid) front only
@@ -2208,7 +2210,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     for (;;) {
         if (tid == 0) q_count[0] = 0;
         wave_sync();
-        const int cnt = min(QROWS, need_it.left);
+        const int cnt = min(QROWS, need_it.left());
         if (!__any(cnt > 0)) break;
         if (cnt > 0) {
             const uint32_t base = atomicAdd(&q_count[0], (uint32_t)cnt);
@@ -2310,7 +2312,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     if (live) {
         const vtxf::Lane gl{(uint32_t*)q_ent + tid, 64};                 // (the queue is dead by now)
         const int32_t sc = vtxf::back_rest(fr, ns, ln, gl, &why, (int)VTX_ABLATE(stats >> 8), nullptr, &aux);
-        if (sc >= 0) { *my_score = sc; if (stage) stage[task] = 1; }
+        if (sc >= 0) { *my_score() = sc; if (stage) stage[task] = 1; }
         else { fail = true; tight = tight_list != nullptr; }
     }
     bool again = fail && why == vtxf::W_NOT_TIGHT && refine_rec != nullptr && aux != 0xffffffffu;
@@ -2341,7 +2343,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             const uint32_t pos = base + (uint32_t)__popcll(tm & ((1ull << tid) - 1ull));
             tight_list[pos] = task;
             tight_pack[pos] = vtxf::band_pack(fr);
-            *my_score = fr.cert;                                      // provisional: a lower bound of the banded score
+            *my_score() = fr.cert;                                    // provisional: a lower bound of the banded score
         }
     }
     const bool dense = fail && !again && !tight && dense_list != nullptr && ((dense_mask >> why) & 1u) && (why != vtxf::W_MATCHES || spread);

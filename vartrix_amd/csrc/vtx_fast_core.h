@@ -50,7 +50,7 @@
 //          (Round 3 first used the special case "every far piece >= T = max(ns, 5) diagonals out": with the 20-40 chance
 //          matches of real sequence T made everything generic.)
 //
-// Capacities: reads up to 192 bases (3 mask words), RM main pieces, SM off-diagonal matches, GM generic off-diagonal
+// Capacities: reads up to 64 * NW bases (NW mask words: 256 since round 6, 192 before), RM main pieces, SM off-diagonal matches, GM generic off-diagonal
 // pieces; tasks beyond them are not wrong, they are band_run_kernel's.
 //
 // Three phases, so that the device can do the middle one cooperatively (a wavefront's probes pooled over its lanes):
@@ -83,7 +83,12 @@ constexpr int W = VTX_REF_W;
 static_assert(K == 6 && W == 20 && VTX_REF_MATCH == 1 && VTX_REF_MISMATCH == -5 && VTX_REF_GAP_OPEN == -5 && VTX_REF_GAP_EXTEND == -1,
               "the closed forms below (piece dp, join_same, the far-piece lemma, the +1 / -5 scan) are derived for the reference's scoring only");
 constexpr int LAZY = VTX_BAND_LAZY_EXT(6);
-constexpr int MAX_READ = 192;   // mask capacity
+#ifndef VTXF_NW
+#define VTXF_NW 4
+#endif
+constexpr int NW = VTXF_NW;     // 64-bit words of a diagonal's match mask (3: rounds 3 - 5; the A/B build of tools/gpu_campaign.sh)
+static_assert(NW == 3 || NW == 4, "rows, columns and piece ends are bytes: 256 bases at most");
+constexpr int MAX_READ = 64 * NW;   // mask capacity
 constexpr int RM = 8;           // main-diagonal pieces
 #ifndef VTXF_S_WORDS
 #define VTXF_S_WORDS 20
@@ -92,7 +97,7 @@ constexpr int S_WORDS = VTXF_S_WORDS;     // LDS words per lane for the off-diag
 constexpr int GM = 6;           // off-diagonal pieces admitted to the generic set
 constexpr int LANE_WORDS = S_WORDS + RM;   // per-lane scratch: off-diagonal matches, main pieces (+ GM words for back(): generic off-diagonal pieces)
 constexpr int DMAX = 120;       // diagonal offsets of generic pieces are stored in a signed byte
-constexpr uint32_t UQ_PAD_WORDS = 6;      // zero words in front of a table's unique-k-mer bit array (a negative diagonal reads them)
+constexpr uint32_t UQ_PAD_WORDS = 8;      // zero words in front of a table's unique-k-mer bit array (a negative diagonal reads them: 2 * NW at most)
 constexpr uint32_t HEAD_END = 0xffffu;    // empty bucket / end of a chain
 constexpr uint32_t HEAD_MULTI = 15u;      // tag of a bucket with more than one entry
 
@@ -137,49 +142,72 @@ VTXF_FN int imin(int a, int b) { return a < b ? a : b; }
 VTXF_FN int imax(int a, int b) { return a > b ? a : b; }
 VTXF_FN int iabs(int a) { return a < 0 ? -a : a; }
 
-// ---- 192-bit masks: three 64-bit words, always indexed with compile-time constants ----
-struct M192 { uint64_t w0, w1, w2; };
+// ---- masks of MAX_READ bits: NW 64-bit words, always indexed with compile-time constants (the loops below unroll) ----
+struct M192 { uint64_t w[NW]; };           // (the name is round 3's: 192 bits then)
 VTXF_FN int ctz64(uint64_t v) { return __builtin_ctzll(v); }
-VTXF_FN M192 m_and(M192 a, M192 b) { return M192{a.w0 & b.w0, a.w1 & b.w1, a.w2 & b.w2}; }
-VTXF_FN M192 m_andn(M192 a, M192 b) { return M192{a.w0 & ~b.w0, a.w1 & ~b.w1, a.w2 & ~b.w2}; }
-VTXF_FN bool m_any(M192 a) { return (a.w0 | a.w1 | a.w2) != 0; }
-VTXF_FN int m_pop(M192 a) { return __builtin_popcountll(a.w0) + __builtin_popcountll(a.w1) + __builtin_popcountll(a.w2); }
+VTXF_FN M192 m_zero() { M192 r; VTXF_UNROLL for (int k = 0; k < NW; ++k) r.w[k] = 0; return r; }
+VTXF_FN M192 m_and(M192 a, M192 b) { M192 r; VTXF_UNROLL for (int k = 0; k < NW; ++k) r.w[k] = a.w[k] & b.w[k]; return r; }
+VTXF_FN M192 m_andn(M192 a, M192 b) { M192 r; VTXF_UNROLL for (int k = 0; k < NW; ++k) r.w[k] = a.w[k] & ~b.w[k]; return r; }
+VTXF_FN bool m_any(M192 a) { uint64_t v = 0; VTXF_UNROLL for (int k = 0; k < NW; ++k) v |= a.w[k]; return v != 0; }
+VTXF_FN int m_pop(M192 a) { int c = 0; VTXF_UNROLL for (int k = 0; k < NW; ++k) c += __builtin_popcountll(a.w[k]); return c; }
 template <int S> VTXF_FN M192 m_shr(M192 a) {      // 0 < S < 64
-    return M192{(a.w0 >> S) | (a.w1 << (64 - S)), (a.w1 >> S) | (a.w2 << (64 - S)), a.w2 >> S};
+    M192 r;
+    VTXF_UNROLL
+    for (int k = 0; k < NW; ++k) r.w[k] = (a.w[k] >> S) | (k + 1 < NW ? a.w[k + 1 < NW ? k + 1 : k] << (64 - S) : 0ull);
+    return r;
 }
 VTXF_FN uint64_t ones_below(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull)); }
 VTXF_FN M192 m_range(int lo, int hi) {             // bits [lo, hi)
-    return M192{ones_below(hi) & ~ones_below(lo), ones_below(hi - 64) & ~ones_below(lo - 64), ones_below(hi - 128) & ~ones_below(lo - 128)};
-}
-// lowest set bit: its index (192: none), cleared in a
-VTXF_FN int m_pop_lowest(M192& a) {
-    const bool z0 = a.w0 == 0, z1 = z0 && a.w1 == 0;
-    const uint64_t cur = z1 ? a.w2 : (z0 ? a.w1 : a.w0);
-    if (cur == 0) return 192;
-    const int r = (z1 ? 128 : (z0 ? 64 : 0)) + ctz64(cur);
-    const uint64_t nxt = cur & (cur - 1);
-    a.w0 = z0 ? a.w0 : nxt; a.w1 = (z0 && !z1) ? nxt : a.w1; a.w2 = z1 ? nxt : a.w2;
+    M192 r;
+    VTXF_UNROLL
+    for (int k = 0; k < NW; ++k) r.w[k] = ones_below(hi - 64 * k) & ~ones_below(lo - 64 * k);
     return r;
 }
-// the set bits of a mask in ascending order, one per call: the words shift down as they run empty (twice in a mask's life), so a
-// call is one count-trailing-zeros and one clear on ONE word — m_pop_lowest selects among three words on every call
+// lowest set bit: its index (MAX_READ: none), cleared in a
+VTXF_FN int m_pop_lowest(M192& a) {
+    uint64_t cur = a.w[NW - 1];
+    int idx = NW - 1;
+    VTXF_UNROLL
+    for (int k = NW - 2; k >= 0; --k) if (a.w[k] != 0) { cur = a.w[k]; idx = k; }
+    if (cur == 0) return MAX_READ;
+    const int r = 64 * idx + ctz64(cur);
+    const uint64_t nxt = cur & (cur - 1);
+    VTXF_UNROLL
+    for (int k = 0; k < NW; ++k) a.w[k] = idx == k ? nxt : a.w[k];
+    return r;
+}
+// the set bits of a mask in ascending order, one per call: the words shift down as they run empty (NW - 1 times in a mask's life), so a
+// call is one count-trailing-zeros and one clear on ONE word — m_pop_lowest selects among the words on every call
 struct MIter {
-    uint64_t cur, n1, n2;
-    int base, left;
+    uint64_t cur, nx[NW - 1];
+    int st;                                  // bits still to deliver | base << 16 (one register: band_diag_kernel has none to spare)
+    VTXF_MEM int left() const { return st & 0xffff; }
 };
-VTXF_FN MIter m_iter(M192 a) { return MIter{a.w0, a.w1, a.w2, 0, m_pop(a)}; }
-VTXF_FN int m_next(MIter& it) {              // precondition: it.left > 0
-    while (it.cur == 0) { it.cur = it.n1; it.n1 = it.n2; it.n2 = 0; it.base += 64; }
-    const int r = it.base + ctz64(it.cur);
+VTXF_FN MIter m_iter(M192 a) {
+    MIter it;
+    it.cur = a.w[0];
+    VTXF_UNROLL
+    for (int k = 1; k < NW; ++k) it.nx[k - 1] = a.w[k];
+    it.st = m_pop(a);
+    return it;
+}
+VTXF_FN int m_next(MIter& it) {              // precondition: it.left() > 0
+    while (it.cur == 0) {
+        it.cur = it.nx[0];
+        VTXF_UNROLL
+        for (int k = 0; k + 2 < NW; ++k) it.nx[k] = it.nx[k + 1];
+        it.nx[NW - 2] = 0; it.st += 64 << 16;
+    }
+    const int r = (it.st >> 16) + ctz64(it.cur);
     it.cur &= it.cur - 1;
-    --it.left;
+    --it.st;
     return r;
 }
 // f(position) for every set bit, ascending
 template <class F> VTXF_FN void m_for_each(M192 a, F f) {
-    for (uint64_t v = a.w0; v; v &= v - 1) f(ctz64(v));
-    for (uint64_t v = a.w1; v; v &= v - 1) f(64 + ctz64(v));
-    for (uint64_t v = a.w2; v; v &= v - 1) f(128 + ctz64(v));
+    VTXF_UNROLL
+    for (int k = 0; k < NW; ++k)
+        for (uint64_t v = a.w[k]; v; v &= v - 1) f(64 * k + ctz64(v));
 }
 
 // 8 byte-equality flags of two 8-byte words as 8 bits
@@ -338,13 +366,15 @@ struct Front {
 // (with haplotypes above 255 bases the word still carries d — band_refine_kernel reads it there — and ca / cb are not used)
 VTXF_FN uint32_t band_pack(const Front& fr) { return ((uint32_t)(fr.d + 256) << 16) | (((uint32_t)fr.ca & 0xffu) << 8) | ((uint32_t)fr.cb & 0xffu); }
 
-// The read as 8-byte words in registers (RW words cover MAX_READ bases): loaded once per task — by the device with 16-byte
-// loads split between the two haplotype lanes of a record (read_words_pair in vtx_band.hip), by the host plainly.
-constexpr int RW = MAX_READ / 8;
+// The read's first 192 bases as 8-byte words in registers (RW words): loaded once per task — by the device with 16-byte
+// loads split between the two haplotype lanes of a record (read_words_pair in vtx_band.hip), by the host plainly.  (The bases of a
+// fourth mask word — reads above 192 bases — are loaded where they are compared: eight more words in registers would not fit
+// band_diag_kernel's 128 without spills.)
+constexpr int RW = 192 / 8;
 struct ReadWords { uint64_t w[RW]; };
 VTXF_FN ReadWords read_words(const uint8_t* x, int m) {
     ReadWords r;
-    for (int k = 0; k < RW; ++k) r.w[k] = 8 * k < m ? ld8(x + 8 * k) : 0ull;
+    for (int k = 0; k < RW; ++k) r.w[k] = 8 * k < m ? ld8(x + 8 * k) : 0ull;       // (a read's bytes are followed by >= 8 readable ones)
     return r;
 }
 
@@ -356,7 +386,7 @@ VTXF_FN ReadWords read_words(const uint8_t* x, int m) {
 // readable and ignored.
 struct W16 { uint64_t a, b; };
 VTXF_FN W16 ld16(const uint8_t* p) { W16 v; __builtin_memcpy(&v, p, 16); return v; }
-template <int C> VTXF_FN uint64_t diag_mask_word(const ReadWords& rw, const uint8_t* yb, int d, int wa, int wb) {
+template <int C> VTXF_FN uint64_t diag_mask_word(const ReadWords& rw, const uint8_t* x, const uint8_t* yb, int d, int wa, int wb) {
     W16 h[4];
 VTXF_UNROLL
     for (int k = 0; k < 4; ++k) h[k] = ld16(yb + (8 * (8 * C + 2 * k) + d));
@@ -364,21 +394,23 @@ VTXF_UNROLL
 VTXF_UNROLL
     for (int k = 0; k < 8; ++k) {
         const int w = 8 * C + k;
-        const uint64_t e = (uint64_t)eq8(rw.w[w], (k & 1) ? h[k >> 1].b : h[k >> 1].a) << (8 * k);
+        const uint64_t xw = w < RW ? rw.w[w < RW ? w : 0] : ld8(x + 8 * (w >= wa && w < wb ? w : 0));        // (compile-time choice: C is)
+        const uint64_t e = (uint64_t)eq8(xw, (k & 1) ? h[k >> 1].b : h[k >> 1].a) << (8 * k);
         out |= (w >= wa && w < wb) ? e : 0ull;
     }
     return out;
 }
-VTXF_FN M192 diag_mask(const ReadWords& rw, int m, const Tab& tb, int n, int d) {
+VTXF_FN M192 diag_mask(const ReadWords& rw, const uint8_t* x, int m, const Tab& tb, int n, int d) {
     const uint8_t* yb = tb.gt + tb.bytes;
     // only the 8-base words that overlap the haplotype: the 8-byte loads stay within 7 bytes of bytes[0, n)
     const int wa = d < 0 ? (-d) >> 3 : 0;
     const int wb = imin((m + 7) >> 3, (n - d + 7) >> 3);
-    if (wa >= wb) return M192{0, 0, 0};
+    if (wa >= wb) return m_zero();
     M192 M;
-    M.w0 = diag_mask_word<0>(rw, yb, d, wa, wb);
-    M.w1 = wb > 8 ? diag_mask_word<1>(rw, yb, d, wa, wb) : 0ull;
-    M.w2 = wb > 16 ? diag_mask_word<2>(rw, yb, d, wa, wb) : 0ull;
+    M.w[0] = diag_mask_word<0>(rw, x, yb, d, wa, wb);
+    M.w[1] = wb > 8 ? diag_mask_word<1>(rw, x, yb, d, wa, wb) : 0ull;
+    M.w[2] = wb > 16 ? diag_mask_word<2>(rw, x, yb, d, wa, wb) : 0ull;
+    if constexpr (NW > 3) M.w[NW - 1] = wb > 24 ? diag_mask_word<NW - 1>(rw, x, yb, d, wa, wb) : 0ull;
     return m_and(M, m_range(imax(0, -d), imin(m, n - d)));
 }
 
@@ -434,7 +466,7 @@ template <class LN> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab&
 // one lane on its own: the six sample rows in turn; a candidate is kept if its mask has at least 20 matching bases
 template <class LN> VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln) {
     Front fr;
-    fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.ca = fr.cb = 0; fr.zc = 0; fr.need = M192{0, 0, 0};
+    fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.ca = fr.cb = 0; fr.zc = 0; fr.need = m_zero();
     if (m < K || n < K || m > MAX_READ) { fr.why = W_SHAPE; return fr; }
     int prev = NO_DIAG;
     const ReadWords rw = read_words(x, m);
@@ -443,7 +475,7 @@ template <class LN> VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, 
         if (dc == NO_DIAG || dc == prev) continue;
         prev = dc;
         if (!verify_diag(x, m, tb, n, dc)) continue;
-        const M192 Mc = diag_mask(rw, m, tb, n, dc);
+        const M192 Mc = diag_mask(rw, x, m, tb, n, dc);
         if (m_pop(Mc) >= 20) return front_rest(x, m, tb, n, ln, dc, Mc);
     }
     fr.why = W_NO_DIAG;
@@ -454,7 +486,7 @@ template <class LN> VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, 
 template <class LN> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, int d, M192 M) {
     (void)x;
     Front fr;
-    fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.ca = fr.cb = 0; fr.zc = 0; fr.need = M192{0, 0, 0};
+    fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.ca = fr.cb = 0; fr.zc = 0; fr.need = m_zero();
     fr.d = d;
 
     // ---- main pieces (runs of >= K matching bases, found between the zeros of M) and sdpkpp on the diagonal ----
@@ -522,19 +554,22 @@ template <class LN> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab&
         const M192 A = m_and(M, m_shr<1>(M));
         const M192 B = m_and(A, m_shr<2>(A));
         const M192 I6 = m_and(B, m_shr<4>(A));              // bit i: bases i .. i + 5 all match
-        // unique-k-mer bits of haplotype positions [d, d + 192): the array carries 192 zero bits in front
+        // unique-k-mer bits of haplotype positions [d, d + MAX_READ): the array carries 32 * UQ_PAD_WORDS zero bits in front
+        static_assert(32 * (int)UQ_PAD_WORDS >= MAX_READ, "d >= -(m - K)");
         const uint32_t* uq = (const uint32_t*)(tb.gt + tb.uq);
         const uint32_t bo = (uint32_t)(d + 32 * (int)UQ_PAD_WORDS);
         const uint32_t wi = bo >> 5, sh = bo & 31u;
-        uint32_t q[7];
-        for (int k = 0; k < 7; ++k) q[k] = uq[wi + k];
-        uint64_t u[3];
-        for (int k = 0; k < 3; ++k) {
+        uint32_t q[2 * NW + 1];
+        VTXF_UNROLL
+        for (int k = 0; k < 2 * NW + 1; ++k) q[k] = (NW > 3 && 32 * (k - 1) >= m) ? 0u : uq[wi + k];     // (a 150-base read stops after six words)
+        M192 U;
+        VTXF_UNROLL
+        for (int k = 0; k < NW; ++k) {
             const uint32_t a = (uint32_t)((((uint64_t)q[2 * k + 1] << 32) | q[2 * k]) >> sh);
             const uint32_t b = (uint32_t)((((uint64_t)q[2 * k + 2] << 32) | q[2 * k + 1]) >> sh);
-            u[k] = ((uint64_t)b << 32) | a;
+            U.w[k] = ((uint64_t)b << 32) | a;
         }
-        fr.need = m_andn(m_range(0, m - K + 1), m_and(I6, M192{u[0], u[1], u[2]}));
+        fr.need = m_andn(m_range(0, m - K + 1), m_and(I6, U));
     }
     return fr;
 }
@@ -553,13 +588,13 @@ template <class LN> VTXF_FN int probe_rows(const uint8_t* x, const Tab& tb, cons
         uint64_t w8[4];
         uint32_t code[4], bits[4];
         for (int t = 0; t < 4; ++t) row[t] = m_pop_lowest(need);
-        for (int t = 0; t < 4; ++t) w8[t] = ld8(x + (row[t] < 192 ? row[t] : 0));
+        for (int t = 0; t < 4; ++t) w8[t] = ld8(x + (row[t] < MAX_READ ? row[t] : 0));
         for (int t = 0; t < 4; ++t) {
             code[t] = kw_code((uint32_t)w8[t], (uint32_t)(w8[t] >> 32) & 0xffffu);
             bits[t] = pb[code[t] >> 5];
         }
         for (int t = 0; t < 4; ++t) {
-            if (row[t] >= 192 || !((bits[t] >> (code[t] & 31u)) & 1u)) continue;       // not a k-mer of this haplotype
+            if (row[t] >= MAX_READ || !((bits[t] >> (code[t] & 31u)) & 1u)) continue;       // not a k-mer of this haplotype
             const uint32_t hh = kw_mix((uint32_t)w8[t], (uint32_t)(w8[t] >> 32) & 0xffffu);
             walk_bucket(tb, w8[t], hh, ld2(head + 2u * kw_bucket(hh, tb.hmask)), [&](uint32_t yc) {
                 if ((int)yc - row[t] == fr.d) return;
@@ -865,14 +900,14 @@ template <class LN> VTXF_FN int probe_harmless_stream(const uint8_t* x, const Ta
         uint64_t w8[4];
         uint32_t code[4], bits[4], raw[4];
         for (int t = 0; t < 4; ++t) row[t] = m_pop_lowest(need);
-        for (int t = 0; t < 4; ++t) w8[t] = ld8(x + (row[t] < 192 ? row[t] : 0));
+        for (int t = 0; t < 4; ++t) w8[t] = ld8(x + (row[t] < MAX_READ ? row[t] : 0));
         for (int t = 0; t < 4; ++t) {
             code[t] = kw_code((uint32_t)w8[t], (uint32_t)(w8[t] >> 32) & 0xffffu);
             bits[t] = pb[code[t] >> 5];
             raw[t] = ld2(head + 2u * kw_bucket(kw_mix((uint32_t)w8[t], (uint32_t)(w8[t] >> 32) & 0xffffu), tb.hmask));
         }
         for (int t = 0; t < 4 && verdict == 1; ++t) {
-            if (row[t] >= 192 || !((bits[t] >> (code[t] & 31u)) & 1u)) continue;       // not a k-mer of this haplotype
+            if (row[t] >= MAX_READ || !((bits[t] >> (code[t] & 31u)) & 1u)) continue;       // not a k-mer of this haplotype
             const int sx = row[t];
             for (int r = imax(folded + 1, sx - K - 7); r <= sx - K; ++r) {             // rows that have ended by this one
                 const int sh = 8 * (r & 7);
@@ -933,7 +968,7 @@ VTXF_FN Result2 fast_task2_list(const uint8_t* x, int m, const Tab& tb, int n, c
 // or a row with more matches than half the window).
 template <class LN> VTXF_FN Result2 fast_task2_stream(const uint8_t* x, int m, const Tab& tb, int n, const LN& wl, int d) {
     if (m < K || n < K || m > MAX_READ || d < -(m - K) || d > n - K) return Result2{T2_SWEEP, -1, 0u, W_SHAPE};   // (not what the list stage hands over)
-    const Front fr = front_rest(x, m, tb, n, wl, d, diag_mask(read_words(x, m), m, tb, n, d));
+    const Front fr = front_rest(x, m, tb, n, wl, d, diag_mask(read_words(x, m), x, m, tb, n, d));
     if (fr.why != W_OK) return Result2{T2_SWEEP, -1, 0u, fr.why};                 // (the list stage's front accepted this task)
     const int v = probe_harmless_stream(x, tb, fr, wl);
     if (v == 1) return Result2{T2_TIGHT, fr.cert, band_pack(fr), W_MATCHES};
