@@ -433,6 +433,9 @@ int vtx_last_timing(vtx_ctx* ctx, vtx_timing* out);
 #define VTX_STAGE_FULL_DP 9        /* full flavour: the full-matrix DP */
 #define VTX_STAGE_BAND_CERT 10     /* band_refine_kernel: cert == the run bound over the pieces trimmed to the one-diagonal band — a bound of the BANDED
                                       score (vtx_band_trim.h): like the DP stages, this one may decide a task whose banded score is below the full one */
+#define VTX_STAGE_CORRIDOR_CERT 11 /* band_corridor_kernel (round 6): an exact DP over the cells of the one-diagonal band within 8 diagonals of the main one,
+                                      with edges that bound every way around them; decided when the maximum needs none of those edges.  A bound of
+                                      the BANDED score as well */
 #define VTX_DEBUG_STAGE_TRACE 1
 #define VTX_DEBUG_POISON_SCORES 2
 #define VTX_DEBUG_POISON_VALUE 3

@@ -145,7 +145,8 @@ uint32_t vtxt_last_band_pack(void) { return g_last_pack; }
 int vtxt_fastcore_batch(const vtx_batch* b, uint32_t n_heads, int32_t* score, uint32_t* why) {
     const bool force_wide = (n_heads >> 31) != 0;
     const bool refine = ((n_heads >> 30) & 1u) != 0;          // bit 30: the corridor refinement of band_refine_kernel
-    n_heads &= 0x3fffffffu;
+    const bool corridor = ((n_heads >> 29) & 1u) != 0;        // bit 29: the corridor certificate of band_corridor_kernel (round 6) behind the run bound
+    n_heads &= 0x1fffffffu;
     using namespace vtxf;
     uint32_t max_hap = 8;
     for (uint32_t l = 0; l < b->n_loci; ++l) max_hap = std::max(max_hap, std::max(b->loci[l].ref_len, b->loci[l].alt_len));
@@ -172,7 +173,26 @@ int vtxt_fastcore_batch(const vtx_batch* b, uint32_t n_heads, int32_t* score, ui
                 tb.pb = tb.ent + tab_pb_off(max_hap, n_heads);
                 tb.hmask = n_heads - 1;
                 Result res;
-                if (narrow) {
+                if (narrow && corridor) {
+                    // what band_diag_kernel + band_corridor_kernel do with a task: the three phases, and for a task that leaves them with a
+                    // certificate and harmless matches only (the kernel's tight list) the corridor bound over its one-diagonal band
+                    const LaneS<uint16_t> ln{lane + S_WORDS, 1, (uint16_t*)lane, 1};
+                    const int m = (int)R.read_len, n = (int)(h ? L.alt_len : L.ref_len);
+                    const Front fr = front(readbuf.data(), m, tb, n, ln);
+                    res = Result{-1, fr.why};
+                    if (fr.why == W_OK && whole_read(fr, m)) res = Result{m, W_OK};
+                    else if (fr.why == W_OK) {
+                        const int ns = probe_rows(readbuf.data(), tb, fr, ln);
+                        uint32_t wy = W_OK;
+                        const int32_t sc = back(fr, ns, ln, Lane{generic, 1}, &wy, 0, nullptr);
+                        res = Result{sc, wy};
+                        if (sc < 0 && (wy == W_NOT_TIGHT || wy == W_GENERIC)) {
+                            const M192 far = far_rows(fr.d, ns, ln);
+                            const int cs = corridor_bound(readbuf.data(), m, tb.gt + tb.bytes, n, fr.d, fr.ca, fr.cb, far);
+                            if (cs >= 0) res = Result{cs, W_OK};
+                        }
+                    }
+                } else if (narrow) {
                     const LaneS<uint16_t> ln{lane + S_WORDS, 1, (uint16_t*)lane, 1};
                     res = fast_task(readbuf.data(), (int)R.read_len, tb, (int)(h ? L.alt_len : L.ref_len), ln, Lane{generic, 1}, refine);
                 } else {

@@ -52,6 +52,8 @@ def check(L, batch, n_barcodes, label, n_heads=1024):
     # cert == ub decides a task, and ub bounds the FULL-matrix score: a decided score is the full score too (cert <= banded <= full <= ub).
     # (Round 6: the refined join was priced above what an excursion over a far piece costs — ub 36 < full 37 on a task whose banded
     #  score happened to be 36 as well; comparing with the banded score alone never saw it.)
+    if n_heads & (1 << 29):                  # (the corridor certificate bounds the BANDED score: it decides tasks with banded < full too)
+        return float(decided.mean()), {WHY[k]: int(v) for k, v in zip(*np.unique(why, return_counts=True))}
     rf_, af_ = oracle.batch_scores(batch, default_config(aligner="full", n_barcodes=n_barcodes), threads=8)
     full = np.empty(2 * batch.n_records, np.int32)
     full[0::2], full[1::2] = rf_, af_

@@ -133,14 +133,14 @@ class VtxTiming(C.Structure):
 
 # vtx_fetch_stage: which stage decided an alignment's score (include/vtx.h)
 STAGE_UNKNOWN, STAGE_DIAG_CERT, STAGE_REFINE_CERT, STAGE_FULL_CHECK, STAGE_SWEEP_DP, STAGE_GENERAL_DP, STAGE_RUN_DP = range(7)
-STAGE_DIAG_DP, STAGE_SLOW, STAGE_FULL_DP, STAGE_BAND_CERT = 7, 8, 9, 10
+STAGE_DIAG_DP, STAGE_SLOW, STAGE_FULL_DP, STAGE_BAND_CERT, STAGE_CORRIDOR_CERT = 7, 8, 9, 10, 11
 STAGE_NAMES = {0: "band_run certificate", 1: "diag certificate", 2: "refine certificate", 3: "full-matrix check", 4: "sweep + masked DP",
                5: "general kernel + masked DP", 6: "band_run + masked DP", 7: "diagonal band + masked DP", 8: "slow path", 9: "full DP",
-               10: "band-restricted certificate"}
+               10: "band-restricted certificate", 11: "corridor certificate"}
 DP_STAGES = (STAGE_SWEEP_DP, STAGE_GENERAL_DP, STAGE_RUN_DP, STAGE_DIAG_DP, STAGE_SLOW, STAGE_FULL_DP)
 # stages that may decide an alignment whose banded score is BELOW the full-matrix one: the DPs, and the certificate against the
-# bound of the banded score (vtx_band_trim.h)
-BANDED_STAGES = DP_STAGES + (STAGE_BAND_CERT,)
+# bounds of the banded score (vtx_band_trim.h; the corridor certificate of vtx_fast_core.h)
+BANDED_STAGES = DP_STAGES + (STAGE_BAND_CERT, STAGE_CORRIDOR_CERT)
 DEBUG_STAGE_TRACE, DEBUG_POISON_SCORES, DEBUG_POISON_VALUE = 1, 2, 3
 
 

@@ -705,7 +705,9 @@ static void note_long_loci(vtx_ctx* c, const vtx_locus* loci, uint32_t nl) {
 // the general kernel's list.  gt_bytes: the k-mer tables of every locus in global memory (0: tables in LDS).
 // records band_diag_kernel may leave for band_refine_kernel per chunk of tasks (a quarter of the tasks: 22 % are listed at 8 %
 // substitution errors; what does not fit goes to band_run_kernel as before)
-static uint32_t band_refine_cap(uint32_t chunk) { return std::max(65536u, chunk / 4); }
+// (round 6: with a tight list EVERY task that leaves band_diag_kernel with a certificate leaves a record, for band_corridor_kernel: 24 - 30 %
+// of the tasks at 8 % errors (39 % measured: 19.1 M of 48.6 M) — half; a task that does not fit takes the masked DP over its band, as all of them did before)
+static uint32_t band_refine_cap(uint32_t chunk) { return std::max(65536u, chunk / 2); }
 struct BandPlan {
     uint64_t n_tasks = 0;
     uint32_t chunk = 0, band_stride = 0, hard_cap = 0, pend_cap = 0, slots = 0, poly_stride = 0, tasks_per_locus = 0;
@@ -1747,11 +1749,21 @@ int vtx_run(vtx_ctx* c) {
                         static const bool no_fork = VTX_DEV_ENV("VTX_BAND_NO_FORK") != nullptr;          // experiment / test hook
                         const bool fork = tight_list != nullptr && !no_fork;
                         hipStream_t sb = fork ? s2 : s;                                             // the refine / one-diagonal branch
-                        if (!fork && refine_list)
-                            HIP_TRY(c, vtxk_launch_band_refine(refine_list, std::min(refine_cap, nt), c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                                               c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), mh,
-                                                               c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
-                                                               tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, tight_list, tight_pack, stage, d_cnt + 14, s));
+                        // the records band_diag_kernel left: with a tight list (round 6) every task that holds a certificate and a one-diagonal
+                        // band, for band_corridor_kernel; else (VTX_BAND_NO_TIGHT, libvtx_dev.so's VTX_BAND_NO_CORRIDOR) round 3's, for band_refine_kernel
+                        static const bool no_corridor = VTX_DEV_ENV("VTX_BAND_NO_CORRIDOR") != nullptr;
+                        auto second_look = [&](uint32_t n_rec, hipStream_t st) -> hipError_t {
+                            if (tight_list && !no_corridor)
+                                return vtxk_launch_band_corridor(refine_list, n_rec, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                                 c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), c->d_hap.as<uint8_t>(),
+                                                                 c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), d_cnt, diag_stats, tight_list, tight_pack,
+                                                                 stage, d_cnt + 14, st);
+                            return vtxk_launch_band_refine(refine_list, n_rec, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
+                                                           c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), mh,
+                                                           c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
+                                                           tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, tight_list, tight_pack, stage, d_cnt + 14, st);
+                        };
+                        if (!fork && refine_list) HIP_TRY(c, second_look(std::min(refine_cap, nt), s));
                         HIP_TRY(c, hipMemcpyAsync(c->h_pin + 8, d_cnt + 12, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));   // [12] fail, [13] dense, [14] refine, [15] tight
                         HIP_TRY(c, hipStreamSynchronize(s));
                         const uint32_t n_refine = std::min(c->h_pin[10], refine_cap);
@@ -1761,11 +1773,7 @@ int vtx_run(vtx_ctx* c) {
                         launches += 2;
                         if (fork) HIP_TRY(c, hipStreamWaitEvent(s2, c->ev[6], 0));
                         HIP_TRY(c, hipEventRecord(c->ev[7], sb));
-                        if (fork && refine_list && n_refine)
-                            HIP_TRY(c, vtxk_launch_band_refine(refine_list, n_refine, c->d_records.as<vtx_record>(), c->d_rec_locus.as<uint32_t>(),
-                                                               c->d_loci.as<vtx_locus>(), c->d_read.as<uint8_t>(), mh,
-                                                               c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(), c->d_fail.as<uint32_t>(), d_cnt,
-                                                               tasks_per_locus, gt_l0, c->d_gtables.as<uint8_t>(), diag_stats, tight_list, tight_pack, stage, d_cnt + 14, sb));
+                        if (fork && refine_list && n_refine) HIP_TRY(c, second_look(n_refine, sb));
                         if (n_tight) {
                             // tasks with a certificate but no verdict: their band is one diagonal stretch (tight_pack): the masked DP
                             // expands it itself.  (VTX_BAND_CHECK=1: the full-matrix check first — full == cert decides a task, cert <=

@@ -2315,7 +2315,13 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         if (sc >= 0) { *my_score() = sc; if (stage) stage[task] = 1; }
         else { fail = true; tight = tight_list != nullptr; }
     }
-    bool again = fail && why == vtxf::W_NOT_TIGHT && refine_rec != nullptr && aux != 0xffffffffu;
+    // Round 6, the sweep path (a tight list): EVERY task that leaves the last phase with its certificate — harmless matches only, bounds
+    // apart or the generic set full — leaves a record for band_corridor_kernel (the task, its one-diagonal band, the rows of its
+    // matches far out: vtx_fast_core.h, "the corridor certificate") instead of taking the masked DP; what that kernel does not decide
+    // goes on to the tight list.  (stats bit 16 — libvtx_dev.so, VTX_BAND_NO_CORRIDOR=1 — and batches with haplotypes above 255 bases:
+    // round 3's records for band_refine_kernel, main pieces only.)
+    const bool corr_mode = tight_list != nullptr && refine_rec != nullptr && !(stats & 0x10000u);
+    bool again = corr_mode ? (fail && tight) : (fail && why == vtxf::W_NOT_TIGHT && refine_rec != nullptr && aux != 0xffffffffu);
     const uint64_t am = __ballot(again);
     if (am) {
         uint32_t base = 0;
@@ -2324,7 +2330,15 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         base = (uint32_t)__shfl((int)base, leader);
         const uint32_t pos = base + (uint32_t)__popcll(am & ((1ull << tid) - 1ull));
         if (again && pos >= refine_cap) again = false;              // (the record buffer is full: band_run_kernel takes it)
-        if (again) {
+        if (again && corr_mode) {
+            static_assert(REFINE_WORDS >= 4 + 2 * vtxf::NW, "the far rows fit the record");
+            const vtxf::M192 far = vtxf::far_rows(fr.d, ns, ln);
+            uint32_t* rec = refine_rec + (size_t)pos * REFINE_WORDS;
+            rec[0] = task; rec[1] = vtxf::band_pack(fr);
+            rec[2] = (uint32_t)fr.cert; rec[3] = 0;
+#pragma unroll
+            for (int i = 0; i < vtxf::NW; ++i) { rec[4 + 2 * i] = (uint32_t)far.w[i]; rec[5 + 2 * i] = (uint32_t)(far.w[i] >> 32); }
+        } else if (again) {
             uint32_t* rec = refine_rec + (size_t)pos * REFINE_WORDS;
             rec[0] = task; rec[1] = vtxf::band_pack(fr);               // (the diagonal is its upper half)
             rec[2] = (uint32_t)fr.r | ((uint32_t)fr.cert << 4) | (aux << 16);
@@ -2438,6 +2452,69 @@ __global__ __launch_bounds__(256) void band_refine_kernel(
             if (stats & 0xffu) atomicAdd(&counters[32 + vtxf::W_NOT_TIGHT], 1u);
         }
     }
+}
+
+// =============================================================================================
+// band_corridor_kernel (round 6) — the tasks band_diag_kernel leaves WITH a certificate and a one-diagonal band (every off-diagonal
+// match harmless; bounds apart): one lane per record runs the corridor certificate (vtx_fast_core.h: corridor_bound — an exact
+// affine-gap DP over the cells of the band within CC = 8 diagonals of the main one, 17 values per row in registers, plus "excursion"
+// edges that bound whatever a path of the band can do outside the corridor; a maximum reached without an excursion edge IS the banded
+// score).  ~45 k lane-instructions per task where the masked DP over the whole band (sw_banded_kernel<., ., 2>) spends 2 600 wave-
+// instructions per task, and it decides 99.7 % of these tasks at 8 % substitution errors: the masked DP, 115 ms of that workload's
+// step, and band_refine_kernel (36 ms) are replaced by this kernel.  What it does not decide keeps its certificate as a provisional
+// score and goes on to the tight list (masked DP), as before.
+// =============================================================================================
+__global__ __launch_bounds__(256) void band_corridor_kernel(
+    const uint32_t* __restrict__ recs, uint32_t n_recs,
+    const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
+    const uint8_t* __restrict__ read_arena, const uint8_t* __restrict__ hap_arena,
+    int32_t* __restrict__ ref_score, int32_t* __restrict__ alt_score, uint32_t* __restrict__ counters, uint32_t stats,
+    uint32_t* __restrict__ tight_list, uint32_t* __restrict__ tight_pack, uint8_t* __restrict__ stage, const uint32_t* __restrict__ n_dev) {
+    if (n_dev) { const uint32_t nd = *n_dev; n_recs = nd < n_recs ? nd : n_recs; }
+    const int tid = threadIdx.x & 63;
+    const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
+    bool fail = false;
+    uint32_t task = 0, pack = 0;
+    if (slot < n_recs) {
+        const uint4* rp = (const uint4*)(recs + (size_t)slot * REFINE_WORDS);
+        const uint4 h = rp[0], p0 = rp[1], p1 = rp[2];
+        task = h.x; pack = h.y;
+        const int d = (int)(pack >> 16) - 256, ca = (int)((pack >> 8) & 0xffu), cb = (int)(pack & 0xffu), cert = (int)h.z;
+        vtxf::M192 far = vtxf::m_zero();
+        far.w[0] = (uint64_t)p0.x | ((uint64_t)p0.y << 32); far.w[1] = (uint64_t)p0.z | ((uint64_t)p0.w << 32);
+        far.w[2] = (uint64_t)p1.x | ((uint64_t)p1.y << 32);
+        if constexpr (vtxf::NW > 3) far.w[vtxf::NW - 1] = (uint64_t)p1.z | ((uint64_t)p1.w << 32);
+        const uint32_t rid = task >> 1, hap = task & 1;
+        const vtx_record rec = records[rid];
+        const vtx_locus loc = loci[rec_locus[rid]];
+        const int sc = vtxf::corridor_bound(read_arena + rec.read_off, (int)rec.read_len, hap_arena + (hap ? loc.alt_off : loc.ref_off),
+                                            (int)(hap ? loc.alt_len : loc.ref_len), d, ca, cb, far);
+        (hap ? alt_score : ref_score)[rid] = sc >= 0 ? sc : cert;     // final, or the certificate as a provisional score
+        if (sc >= 0) { if (stage) stage[task] = VTX_STAGE_CORRIDOR_CERT; }
+        else fail = true;
+    }
+    const uint64_t fm = __ballot(fail);
+    if (fm) {
+        uint32_t base = 0;
+        const int leader = __ffsll((long long)fm) - 1;
+        if (tid == leader) base = atomicAdd(&counters[15], (uint32_t)__popcll(fm));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (fail) {
+            const uint32_t pos = base + (uint32_t)__popcll(fm & ((1ull << tid) - 1ull));
+            tight_list[pos] = task;
+            tight_pack[pos] = pack;
+            if (stats & 0xffu) atomicAdd(&counters[32 + vtxf::W_NOT_TIGHT], 1u);
+        }
+    }
+}
+extern "C" hipError_t vtxk_launch_band_corridor(const uint32_t* recs, uint32_t n_recs, const vtx_record* records, const uint32_t* rec_locus,
+                                                const vtx_locus* loci, const uint8_t* read_arena, const uint8_t* hap_arena,
+                                                int32_t* ref_score, int32_t* alt_score, uint32_t* counters, int stats,
+                                                uint32_t* tight_list, uint32_t* tight_pack, uint8_t* stage, const uint32_t* n_dev, hipStream_t s) {
+    if (!n_recs) return hipSuccess;
+    hipLaunchKernelGGL(band_corridor_kernel, dim3((n_recs + 255) / 256), dim3(256), 0, s, recs, n_recs, records, rec_locus, loci, read_arena,
+                       hap_arena, ref_score, alt_score, counters, (uint32_t)stats, tight_list, tight_pack, stage, n_dev);
+    return hipGetLastError();
 }
 
 // Resident workgroups of band_run_kernel (an upper bound: 256 CUs x the most workgroups a CU can hold for that block
@@ -2601,7 +2678,8 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     if (!gtables || (size_t)n_loci * 2 * tstride > gtables_bytes) return hipErrorInvalidValue;
     launch_band_tables(loci, gt_l0, n_loci, hap_arena, max_hap, min_hap, tstride, n_heads, gtables, s);
     const uint32_t n_blocks = (n_tasks + 255) / 256;
-    const uint32_t st = (uint32_t)stats | (VTX_DEV_ENV("VTX_DIAG_ABLATE") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_DIAG_ABLATE")) << 8 : 0u);
+    const uint32_t st = (uint32_t)stats | (VTX_DEV_ENV("VTX_DIAG_ABLATE") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_DIAG_ABLATE")) << 8 : 0u) |
+                        (VTX_DEV_ENV("VTX_BAND_NO_CORRIDOR") ? 0x10000u : 0u);          // (A/B hook: round 5's records for band_refine_kernel)
     // two-byte match entries (40 per task) whenever a haplotype position fits a byte; VTX_DIAG_WIDE=1 forces the four-byte variant (tests)
     static const bool force_wide = VTX_DEV_ENV("VTX_DIAG_WIDE") != nullptr;
     if (max_hap <= 255 && !force_wide)

@@ -858,6 +858,127 @@ template <class LN> VTXF_FN int32_t back_rest(const Front& fr, int ns, const LN&
     return fr.cert;
 }
 
+// ======== the corridor certificate (round 6; band_corridor_kernel; proof below, brute-force check in tests/test_fastcore.py) ========
+// For a task whose off-diagonal matches are all harmless the reference's chain is the main diagonal's stretch and its band B the
+// (2w + 1)-squares along it (band_pack: rows [ca - d - w, cb - d + w], columns [ca - w, cb + w]).  The run bound prices every join by
+// a closed form; on noisy reads (clusters of errors, a few chance matches far out) it stops meeting the certificate for a fifth of
+// the tasks although the banded score IS the certificate's.  This bound looks at the cells themselves, but only at those that matter:
+//
+//   K = the cells of B within CC diagonals of d (the corridor).  An exact affine-gap DP over K (one lane, 2 CC + 1 values per row)
+//   gives the best alignment that stays in K — a LOWER bound of the banded score.  It becomes an UPPER bound with one more kind of
+//   edge, the excursion: whatever a path of B does outside K is replaced by "leave K, come back later".
+//
+//   Claim.  Let P be any local alignment path inside B.  Cut it at its H-cells (cells where it is not inside a gap).  A maximal
+//   stretch of H-cells outside K (a) is entered and left by gaps (a diagonal step keeps the diagonal) that cost at least
+//   5 + (CC + 1 - |delta|) when they start / end at a K-cell of diagonal offset delta — the gap has to reach offset CC + 1 —, and
+//   (b) scores at most 5 + E - g, E = the k-mer matches it covers, g = its gaps: its g + 1 gap-free pieces are runs of matching bases
+//   separated by mismatches, a run of 5 + e bases covers e k-mer matches, so a piece of t runs scores <= 5 t + e - 5 (t - 1) = 5 + e,
+//   and every gap between two pieces costs >= 6.  (c) The k-mer matches it covers are OFF-DIAGONAL matches more than CC diagonals out
+//   (the list band_diag_kernel holds, complete for these tasks), each read row belongs to at most one of its diagonal steps, and all
+//   of them start at rows between the row it left K and the row it comes back: E <= the number of rows in that range with such a
+//   match (far bit).  Hence, with X_i = the best score a path can have while it is outside K having consumed i read bases:
+//       X_i = max(5, X_(i-1) + far(i - 1), max over the K-cells (i, delta) of H(i, delta) - exit(delta) + 5)
+//       H(i, delta) = max(0, diagonal, gap from the left, gap from above — all inside K —, X_(i-1) - exit(delta))
+//   bounds every path of B from above (X_(i-1), not X_i, for the re-entry: a way out and back within one row is a single gap inside K,
+//   which the DP has; a path that STARTS outside K is the 5 in X's maximum, one that ENDS outside is X itself):
+//   banded <= U = max(max H, max X).  Rows of B are intervals in every column and vice versa, so a gap between two K-cells runs
+//   through K-cells only: the DP misses no path of B that keeps its H-cells in K.
+//
+//   Exactness.  Every value carries one more bit, "no excursion edge on the way here" (value = 2 score + clean: adding even numbers
+//   keeps it, a maximum prefers the clean one of two equal scores, everything that comes through X is not clean).  If U is reached by
+//   a clean value, a path inside K — inside B — scores U: banded >= U, so banded = U.  (Every cell of an optimal clean path holds
+//   exactly that path's partial score — a larger value there would continue to more than U — and so its clean bit survives.)
+//   Otherwise the task keeps its band and takes the masked DP.  Measured on the CPU (tests/test_fastcore.py): it decides 99.7 % of the
+//   tasks the run bound leaves at 8 % substitution errors, all of them at 3 %.
+constexpr int CC = 8;                      // half-width of the corridor (5: decides 95 % where 8 decides 99.7 %)
+constexpr int CW = 2 * CC + 1;
+static_assert(CC <= W, "the corridor lies inside the band's squares");
+// rows that hold an off-diagonal k-mer match more than CC diagonals from the main one (ln.s(0 .. ns): the task's complete list)
+template <class LN> VTXF_FN M192 far_rows(int d, int ns, const LN& ln) {
+    M192 f = m_zero();
+    for (int k = 0; k < ns; ++k) {
+        const uint32_t w = ln.s(k);
+        const int sx = (int)(w >> LN::XS), sy = (int)(w & LN::YM);
+        if (iabs(sy - sx - d) <= CC) continue;
+        const uint64_t bit = 1ull << (sx & 63);
+        VTXF_UNROLL
+        for (int q = 0; q < NW; ++q) f.w[q] |= (sx >> 6) == q ? bit : 0ull;
+    }
+    return f;
+}
+// The banded score of the task (>= 0) when the bound above is exact, -1 otherwise.  x / yb: read and haplotype bytes (8 readable bytes
+// behind each), d / ca / cb: band_pack's fields, far: far_rows().
+VTXF_FN int corridor_bound(const uint8_t* x, int m, const uint8_t* yb, int n, int d, int ca, int cb, const M192& far) {
+    constexpr int NEGV = -(1 << 20);       // (a value no real one reaches: 300 steps of -12 do not bring it near an overflow)
+    const int r0 = imax(0, ca - d - W), r1 = imin(m, cb - d + W);
+    const int j0 = imax(0, ca - W), j1 = imin(n, cb + W);
+    if (r0 > r1 || j0 > j1) return -1;
+    int Hp[CW], Fp[CW];
+    VTXF_UNROLL
+    for (int k = 0; k < CW; ++k) { Hp[k] = NEGV; Fp[k] = NEGV; }
+    // the haplotype bytes of the row's cells: cell k of prefix row i compares x[i - 1] with y[i + d - CC + k - 1]; 24 bytes in three
+    // words, byte 0 = cell 0, shifted by one byte per row (the new byte: cell CW - 1 of the next row)
+    uint64_t yw[3] = {0, 0, 0};
+    {
+        const int p0 = r0 + d - CC - 1;
+        for (int k = 0; k < CW; ++k) {
+            const int p = p0 + k;
+            const uint64_t b = (p >= 0 && p < n) ? yb[p] : 0xffull;
+            yw[k >> 3] |= b << (8 * (k & 7));
+        }
+    }
+    int X = 5, best = 1;
+    uint64_t xw = 0;
+    for (int i = r0; i <= r1; ++i) {
+        // ---- the row's constants: the read base, the far bit of the row before, which cells exist ----
+        const int ri = i - 1;                                             // read index of this row's base
+        if (ri >= 0 && (i == r0 || (ri & 7) == 0)) xw = ld8(x + (ri & ~7));
+        const uint32_t xc = ri >= 0 ? (uint32_t)(xw >> (8 * (ri & 7))) & 0xffu : 0x100u;
+        uint32_t fbit = 0;
+        if (ri >= 0) {
+            uint64_t fwd = far.w[0];
+            VTXF_UNROLL
+            for (int q = 1; q < NW; ++q) fwd = (ri >> 6) == q ? far.w[q] : fwd;
+            fbit = (uint32_t)(fwd >> (ri & 63)) & 1u;
+        }
+        const int X2 = 2 * X;                                             // (what an excursion is worth when this row is entered)
+        int Xn = imax(5, X + (int)fbit);
+        const int jb = i + d - CC;                                        // column of cell 0
+        const int klo = imax(0, j0 - jb), khi = imin(CW - 1, j1 - jb);
+        const uint32_t vm = klo > khi ? 0u : ((2u << khi) - 1u) & ~((1u << klo) - 1u);
+        int Hc[CW], Fc[CW];
+        int E = NEGV, rowx = NEGV;
+        VTXF_UNROLL
+        for (int k = 0; k < CW; ++k) {
+            constexpr int dummy = 0; (void)dummy;
+            const int exitc = 5 + CC + 1 - (k < CC ? CC - k : k - CC);    // the gap to the nearest cell outside the corridor
+            const uint32_t yk = (uint32_t)(yw[k >> 3] >> (8 * (k & 7))) & 0xffu;
+            int h = imax(1, X2 - 2 * exitc);                              // a fresh start (clean) or the way back from an excursion (not clean)
+            h = imax(h, Hp[k] + (yk == xc ? 2 : -10));
+            int f = NEGV;
+            if (k + 1 < CW) { f = imax(Fp[k + 1 < CW ? k + 1 : k] - 2, Hp[k + 1 < CW ? k + 1 : k] - 12); h = imax(h, f); }
+            if (k >= 1) { E = imax(E - 2, Hc[k >= 1 ? k - 1 : 0] - 12); h = imax(h, E); }
+            const bool valid = (vm >> k) & 1u;
+            h = valid ? h : NEGV; f = valid ? f : NEGV; E = valid ? E : NEGV;
+            Hc[k] = h; Fc[k] = f;
+            best = imax(best, h);
+            rowx = imax(rowx, h - 2 * exitc);
+        }
+        Xn = imax(Xn, (rowx >> 1) + 5);
+        VTXF_UNROLL
+        for (int k = 0; k < CW; ++k) { Hp[k] = Hc[k]; Fp[k] = Fc[k]; }
+        X = Xn;
+        // ---- the window moves on by one column ----
+        const int pn = i + 1 + d - CC - 1 + (CW - 1);                     // haplotype byte of cell CW - 1 of the next row
+        const uint64_t nb = (pn >= 0 && pn < n) ? yb[pn] : 0xffull;
+        yw[0] = (yw[0] >> 8) | (yw[1] << 56);
+        yw[1] = (yw[1] >> 8) | (yw[2] << 56);
+        yw[2] = (yw[2] >> 8) | (nb << (8 * ((CW - 1) & 7)));
+    }
+    if (2 * X >= best || !(best & 1)) return -1;                         // (an excursion that never comes back, or one on the way to the maximum)
+    return best >> 1;
+}
+
 // A read that matches the haplotype base for base on its diagonal needs nothing else: cert == m (every base of the read a one of the
 // mask, in band).  The FULL score is at most m (a local alignment scores at most +1 per read base), so full = m; and the banded score
 // is m whatever the off-diagonal matches are: sdpkpp's dp of a match never exceeds x + K (dp = K at a chain's first match, + 1 per row
