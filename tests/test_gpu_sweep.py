@@ -208,13 +208,17 @@ np.save(sys.argv[1], np.concatenate(out))
 ''' % (ROOT, HERE)
 
 
-@pytest.mark.parametrize("hook", ["VTX_BAND_LEGACY", "VTX_BAND_CHECK", "VTX_BAND_NO_TIGHT", "VTX_BAND_SLOTS", "VTX_SWEEP_V1", "VTX_BAND_DIAG2_MIN"])
+@pytest.mark.parametrize("hook", ["VTX_BAND_LEGACY", "VTX_BAND_CHECK", "VTX_BAND_NO_TIGHT", "VTX_BAND_SLOTS", "VTX_SWEEP_V1", "VTX_BAND_DIAG2_MIN",
+                                  "VTX_BAND_NO_CORRIDOR", "VTX_DIAG_FOUR_WORDS"])
 def test_hooks_give_the_same_scores(hook):
     """VTX_BAND_DIAG2_MIN=1: the second single-diagonal stage (band_diag2_kernel) on every list, however short — by default lists
     below 700 k tasks skip it, i.e. every batch of this test suite but the full-size ones; VTX_SWEEP_V1=1: round 4's band_sweep_kernel (two passes) instead of round 5's; VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending / general kernels instead of the sweep; VTX_BAND_CHECK=1: the full-matrix
     check in front of the DP of the tasks that left with a certificate; VTX_BAND_NO_TIGHT=1: those tasks go to the sweep like the
     others (the sweep's band and the certificate's one-diagonal band must give the same scores); VTX_BAND_SLOTS=5: the sweep + masked
-    DP in slices of five band slots.  Identical scores (separate processes: the hooks are read once)."""
+    DP in slices of five band slots; VTX_BAND_NO_CORRIDOR=1 (round 6): round 5's routing of the tasks that hold a certificate —
+    band_refine_kernel for the ones with main pieces only, the masked DP for the rest — instead of band_corridor_kernel;
+    VTX_DIAG_FOUR_WORDS=1: band_diag_kernel's build for reads up to 256 bases on these batches of short reads (it is chosen by the
+    batch's longest read).  Identical scores (separate processes: the hooks are read once)."""
     res = []
     with tempfile.TemporaryDirectory() as td:
         for on in (0, 1):

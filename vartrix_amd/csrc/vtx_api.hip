@@ -1733,7 +1733,7 @@ int vtx_run(vtx_ctx* c) {
                                                                mh, mh_min, c->d_ref.as<int32_t>(), c->d_alt.as<int32_t>(),
                                                                c->d_fail.as<uint32_t>(), refine_list, refine_cap, d_cnt, tasks_per_locus, gt_l0, gt_n,
                                                                c->d_gtables.as<uint8_t>(), gt_bytes, diag_stats, tight_list, tight_pack, stage,
-                                                               dense_list, dense_mask, s);
+                                                               dense_list, dense_mask, c->max_read_len, s);
                     if (e == hipSuccess && sweep_path) {
                         diag = true; swept = true; sweep_used = true;
                         HIP_TRY(c, hipEventRecord(c->ev[6], s));

@@ -1983,7 +1983,8 @@ __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __rest
 extern "C" uint32_t vtxk_band_refine_words(void) { return REFINE_WORDS; }
 // ST: type of an off-diagonal match entry — uint16_t (x << 8 | y: 40 entries per task in the same LDS) when every haplotype of
 // the batch has <= 255 bases, else uint32_t (20 entries).
-template <int WPE, class ST>
+// A: mask words in use — 3 when no read of the batch exceeds 192 bases (the instruction count of rounds 3 - 5), else vtxf::NW = 4.
+template <int WPE, class ST, int A>
 __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     uint32_t n_tasks, uint32_t task_base, uint32_t n_blocks,
     const vtx_record* __restrict__ records, const uint32_t* __restrict__ rec_locus, const vtx_locus* __restrict__ loci,
@@ -2054,7 +2055,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             if (stage) stage[task] = 1;
         } else if ((uint32_t)m > VTX_FAST_READ_LEN || max(loc.ref_len, loc.alt_len) > max_hap || max(loc.ref_len, loc.alt_len) <= min_hap) {
             // beyond the fast kernels: slow_align_kernel scores it (the host lists these records); or a locus of the other pass
-        } else if (m < vtxf::K || n < vtxf::K || m > vtxf::MAX_READ) {
+        } else if (m < vtxf::K || n < vtxf::K || m > 64 * A) {
             fail = true; why = vtxf::W_SHAPE;
         } else {
             tb.ent = (uint32_t)(((size_t)(my_locus - gt_l0) * 2 + hap) * table_stride);
@@ -2113,13 +2114,13 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         }
         vtxf::M192 M = vtxf::m_zero();
         if (live && have_d) {
-            M = vtxf::diag_mask(rw, x, m, tb, n, d);
+            M = vtxf::diag_mask<A>(rw, x, m, tb, n, d);
             if (vtxf::m_pop(M) < 20) have_d = false;
         }
         if (live && !have_d) { live = false; fail = true; why = vtxf::W_NO_DIAG; }
         if (VTX_ABLATE(stats >> 8) == 3) { if (live && d == 0x7fffffff) counters[40] = 1; return; }       // (profiling aid) up to the diagonal and its mask
         if (live) {
-            fr = vtxf::front_rest(x, m, tb, n, ln, d, M);
+            fr = vtxf::front_rest<LaneT, A>(x, m, tb, n, ln, d, M);
             if (fr.why != vtxf::W_OK) { live = false; fail = true; why = fr.why; }
             else if (VTX_ABLATE(stats >> 8) != 10 && vtxf::whole_read(fr, m)) {      // (developer build, VTX_DIAG_ABLATE=10: the shortcut off — the A/B switch of include/vtx_band_semantics.h's fifth item; results stay right)
                 // the read matches base for base: full <= m = cert, and the reference's chain is a perfect diagonal whatever else
@@ -2150,7 +2151,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             return (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)v, 1) | ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), 1) << 32);
         };
 #pragma unroll
-        for (int k = 0; k < vtxf::NW; ++k) nd.w[k] = (nd.w[k] | other(nd.w[k])) & par;
+        for (int k = 0; k < A; ++k) nd.w[k] = (nd.w[k] | other(nd.w[k])) & par;
     }
     vtxf::MIter need_it = vtxf::m_iter(nd);
     if (VTX_ABLATE(stats >> 8) == 1) { if (live && fr.cert == 0x7fffffff) counters[40] = 1; return; }      // (profiling aid) front only
@@ -2671,7 +2672,8 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
                                             uint32_t* fail_list, uint32_t* refine_rec, uint32_t refine_cap, uint32_t* counters,
                                             uint32_t tasks_per_locus, uint32_t gt_l0, uint32_t n_loci, uint8_t* gtables,
                                             size_t gtables_bytes, int stats, uint32_t* tight_list, uint32_t* tight_pack, uint8_t* stage,
-                                            uint32_t* dense_list, uint32_t dense_mask, hipStream_t s) {
+                                            uint32_t* dense_list, uint32_t dense_mask, uint32_t max_read, hipStream_t s) {
+    // max_read: the longest read of the batch (the fast kernels' records) — up to 192 bases the kernel is built with three mask words
     if (!n_tasks) return hipSuccess;
     const uint32_t n_heads = pick_heads(tasks_per_locus, true);
     const size_t tstride = band_table_stride(max_hap, n_heads);
@@ -2682,14 +2684,15 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
                         (VTX_DEV_ENV("VTX_BAND_NO_CORRIDOR") ? 0x10000u : 0u);          // (A/B hook: round 5's records for band_refine_kernel)
     // two-byte match entries (40 per task) whenever a haplotype position fits a byte; VTX_DIAG_WIDE=1 forces the four-byte variant (tests)
     static const bool force_wide = VTX_DEV_ENV("VTX_DIAG_WIDE") != nullptr;
-    if (max_hap <= 255 && !force_wide)
-        hipLaunchKernelGGL((band_diag_kernel<4, uint16_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
-                           rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, tight_pack, stage, dense_list, dense_mask, min_hap);
-    else
-        hipLaunchKernelGGL((band_diag_kernel<4, uint32_t>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records,
-                           rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,
-                           alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, tight_pack, stage, dense_list, dense_mask, min_hap);
+    static const bool force_four = VTX_DEV_ENV("VTX_DIAG_FOUR_WORDS") != nullptr;      // (tests: the four-word build on short reads)
+#define LAUNCH_DIAG(STV, AV)                                                                                                             \
+    hipLaunchKernelGGL((band_diag_kernel<4, STV, AV>), dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, n_tasks, task_base, n_blocks, records, \
+                       rec_locus, loci, read_arena, max_hap, (uint32_t)tstride, n_heads, (const uint8_t*)gtables, gt_l0, ref_score,        \
+                       alt_score, fail_list, refine_rec, refine_cap, counters, st, tight_list, tight_pack, stage, dense_list, dense_mask, min_hap)
+    const bool three = max_read <= 192 && !force_four && vtxf::NW >= 3;
+    if (max_hap <= 255 && !force_wide) { if (three) LAUNCH_DIAG(uint16_t, 3); else LAUNCH_DIAG(uint16_t, vtxf::NW); }
+    else { if (three) LAUNCH_DIAG(uint32_t, 3); else LAUNCH_DIAG(uint32_t, vtxf::NW); }
+#undef LAUNCH_DIAG
     return hipGetLastError();
 }
 

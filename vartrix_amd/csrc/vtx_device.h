@@ -83,7 +83,7 @@ hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base, const vtx
                                  int32_t* ref_score, int32_t* alt_score, uint32_t* fail_list, uint32_t* refine_rec,
                                  uint32_t refine_cap, uint32_t* counters, uint32_t tasks_per_locus, uint32_t gt_l0, uint32_t n_loci,
                                  uint8_t* gtables, size_t gtables_bytes, int stats, uint32_t* tight_list, uint32_t* tight_pack, uint8_t* stage,
-                                 uint32_t* dense_list, uint32_t dense_mask, hipStream_t s);
+                                 uint32_t* dense_list, uint32_t dense_mask, uint32_t max_read, hipStream_t s);
 uint32_t vtxk_band_refine_words(void);
 hipError_t vtxk_launch_band_corridor(const uint32_t* recs, uint32_t n_recs, const vtx_record* records, const uint32_t* rec_locus,
                                      const vtx_locus* loci, const uint8_t* read_arena, const uint8_t* hap_arena, int32_t* ref_score,

@@ -157,10 +157,12 @@ template <int S> VTXF_FN M192 m_shr(M192 a) {      // 0 < S < 64
     return r;
 }
 VTXF_FN uint64_t ones_below(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull)); }
-VTXF_FN M192 m_range(int lo, int hi) {             // bits [lo, hi)
+// (A: the words that can hold a one — band_diag_kernel is built for reads up to 192 bases as well, A = 3: everything derived from a
+//  mask whose last word is the constant 0 costs nothing there, and the headline workload keeps round 5's instruction count)
+template <int A = NW> VTXF_FN M192 m_range(int lo, int hi) {             // bits [lo, hi)
     M192 r;
     VTXF_UNROLL
-    for (int k = 0; k < NW; ++k) r.w[k] = ones_below(hi - 64 * k) & ~ones_below(lo - 64 * k);
+    for (int k = 0; k < NW; ++k) r.w[k] = k < A ? ones_below(hi - 64 * k) & ~ones_below(lo - 64 * k) : 0ull;
     return r;
 }
 // lowest set bit: its index (MAX_READ: none), cleared in a
@@ -400,7 +402,7 @@ VTXF_UNROLL
     }
     return out;
 }
-VTXF_FN M192 diag_mask(const ReadWords& rw, const uint8_t* x, int m, const Tab& tb, int n, int d) {
+template <int A = NW> VTXF_FN M192 diag_mask(const ReadWords& rw, const uint8_t* x, int m, const Tab& tb, int n, int d) {
     const uint8_t* yb = tb.gt + tb.bytes;
     // only the 8-base words that overlap the haplotype: the 8-byte loads stay within 7 bytes of bytes[0, n)
     const int wa = d < 0 ? (-d) >> 3 : 0;
@@ -410,8 +412,8 @@ VTXF_FN M192 diag_mask(const ReadWords& rw, const uint8_t* x, int m, const Tab& 
     M.w[0] = diag_mask_word<0>(rw, x, yb, d, wa, wb);
     M.w[1] = wb > 8 ? diag_mask_word<1>(rw, x, yb, d, wa, wb) : 0ull;
     M.w[2] = wb > 16 ? diag_mask_word<2>(rw, x, yb, d, wa, wb) : 0ull;
-    if constexpr (NW > 3) M.w[NW - 1] = wb > 24 ? diag_mask_word<NW - 1>(rw, x, yb, d, wa, wb) : 0ull;
-    return m_and(M, m_range(imax(0, -d), imin(m, n - d)));
+    if constexpr (NW > 3) M.w[NW - 1] = (A > 3 && wb > 24) ? diag_mask_word<NW - 1>(rw, x, yb, d, wa, wb) : 0ull;
+    return m_and(M, m_range<A>(imax(0, -d), imin(m, n - d)));
 }
 
 // One bucket lookup for the k-mer in w8's low 6 bytes: f(y) for every position of the haplotype that holds it.
@@ -461,7 +463,7 @@ VTXF_FN bool verify_diag(const uint8_t* x, int m, const Tab& tb, int n, int dc) 
     const int p = vlo + ((vhi - vlo - 8) >> 1);
     return __builtin_popcount(eq8(ld8(x + p), ld8(tb.gt + tb.bytes + (p + dc)))) >= 6;
 }
-template <class LN> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, int d, M192 M);
+template <class LN, int A = NW> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, int d, M192 M);
 
 // one lane on its own: the six sample rows in turn; a candidate is kept if its mask has at least 20 matching bases
 template <class LN> VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln) {
@@ -483,7 +485,7 @@ template <class LN> VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, 
 }
 
 // everything of phase 1 behind the choice of the diagonal d (M = diag_mask(d))
-template <class LN> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, int d, M192 M) {
+template <class LN, int A> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, int d, M192 M) {
     (void)x;
     Front fr;
     fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.ca = fr.cb = 0; fr.zc = 0; fr.need = m_zero();
@@ -519,7 +521,7 @@ template <class LN> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab&
             ln.at(r) = (uint32_t)u | ((uint32_t)v << 8) | ((uint32_t)dpf << 16);
             ++r;
         };
-        m_for_each(m_andn(m_range(vlo, vhi), M), [&](int z) { piece(prev + 1, z - 1); prev = z; ++nz; });
+        m_for_each(m_andn(m_range<A>(vlo, vhi), M), [&](int z) { piece(prev + 1, z - 1); prev = z; ++nz; });
         piece(prev + 1, vhi - 1);
     }
     if (too_many) { fr.why = W_PIECES; return fr; }
@@ -539,7 +541,7 @@ template <class LN> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab&
         const int t1 = imin(imin(m - re, n - ce), W);
         const int hi = re + t1;
         int s = 0, best = 0, prev = lo - 1;
-        m_for_each(m_andn(m_range(lo, hi), M), [&](int z) {
+        m_for_each(m_andn(m_range<A>(lo, hi), M), [&](int z) {
             s += z - prev - 1;
             best = imax(best, s);
             s = imax(0, s - 5);
@@ -551,9 +553,9 @@ template <class LN> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab&
 
     // ---- rows that may hold an off-diagonal match: all but those whose main-diagonal k-mer is intact and unique ----
     {
-        const M192 A = m_and(M, m_shr<1>(M));
-        const M192 B = m_and(A, m_shr<2>(A));
-        const M192 I6 = m_and(B, m_shr<4>(A));              // bit i: bases i .. i + 5 all match
+        const M192 P2 = m_and(M, m_shr<1>(M));
+        const M192 P4 = m_and(P2, m_shr<2>(P2));
+        const M192 I6 = m_and(P4, m_shr<4>(P2));            // bit i: bases i .. i + 5 all match
         // unique-k-mer bits of haplotype positions [d, d + MAX_READ): the array carries 32 * UQ_PAD_WORDS zero bits in front
         static_assert(32 * (int)UQ_PAD_WORDS >= MAX_READ, "d >= -(m - K)");
         const uint32_t* uq = (const uint32_t*)(tb.gt + tb.uq);
@@ -561,15 +563,15 @@ template <class LN> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab&
         const uint32_t wi = bo >> 5, sh = bo & 31u;
         uint32_t q[2 * NW + 1];
         VTXF_UNROLL
-        for (int k = 0; k < 2 * NW + 1; ++k) q[k] = (NW > 3 && 32 * (k - 1) >= m) ? 0u : uq[wi + k];     // (a 150-base read stops after six words)
+        for (int k = 0; k < 2 * NW + 1; ++k) q[k] = k < 2 * A + 1 ? uq[wi + k] : 0u;
         M192 U;
         VTXF_UNROLL
         for (int k = 0; k < NW; ++k) {
             const uint32_t a = (uint32_t)((((uint64_t)q[2 * k + 1] << 32) | q[2 * k]) >> sh);
-            const uint32_t b = (uint32_t)((((uint64_t)q[2 * k + 2] << 32) | q[2 * k + 1]) >> sh);
-            U.w[k] = ((uint64_t)b << 32) | a;
+            const uint32_t b = (uint32_t)((((uint64_t)q[2 * k + 2 < 2 * NW + 1 ? 2 * k + 2 : 0] << 32) | q[2 * k + 1]) >> sh);
+            U.w[k] = k < A ? ((uint64_t)b << 32) | a : 0ull;
         }
-        fr.need = m_andn(m_range(0, m - K + 1), m_and(I6, U));
+        fr.need = m_andn(m_range<A>(0, m - K + 1), m_and(I6, U));
     }
     return fr;
 }
