@@ -46,6 +46,20 @@ void build_table(uint8_t* tb, const uint8_t* hy, uint32_t hn, uint32_t max_hap, 
         for (uint32_t z = 0; z + 6 <= hn; ++z) same += memcmp(hy + y, hy + z, 6) == 0;
         if (same == 1) { uq[y >> 5] |= 1u << (y & 31); fb[y + 5] |= 0x80; }
     }
+    // the twin list (vtx_fast_core.h: tab_tw_off): pairs (y, y') of positions with the same k-mer, in (y, y') order
+    uint8_t* tw = tb + tab_tw_off(max_hap, n_heads);
+    bool hib = false;
+    for (uint32_t y = 0; y < hn; ++y) hib |= (hy[y] & 0x80) != 0;
+    uint32_t cnt = 0;
+    bool ok = !hib && hn <= 256;
+    for (uint32_t y = 0; ok && y + 6 <= hn; ++y)
+        for (uint32_t z = 0; ok && z + 6 <= hn; ++z)
+            if (z != y && memcmp(hy + y, hy + z, 6) == 0) {
+                if (cnt == TW_MAX) { ok = false; break; }
+                tw[8 + 2 * cnt] = (uint8_t)y; tw[9 + 2 * cnt] = (uint8_t)z; ++cnt;
+            }
+    if (!ok) memset(tw, 0, TW_BYTES);
+    tw[0] = ok ? (uint8_t)cnt : (uint8_t)TW_NONE;
 }
 }  // namespace
 
@@ -112,6 +126,33 @@ int vtxt_probe_of_diagonal(const uint8_t* x, int m, const uint8_t* y, int n, int
     }
     return total;
 }
+// The off-diagonal matches of a read against a haplotype, found the two ways band_diag_kernel knows: every row that is not (intact and
+// unique) probed (s_a), or the twin list + probes of the rows that are not intact (s_b); both sorted.  Returns na | nb << 16
+// (0xffffffff: front declined; 0xfffffffe: the haplotype has no twin list; an entry count of 0xffff: more than cap)
+uint32_t vtxt_twin_vs_probe(const uint8_t* x, int m, const uint8_t* y, int n, uint32_t* s_a, uint32_t* s_b, int cap) {
+    using namespace vtxf;
+    const uint32_t max_hap = (uint32_t)std::max(n, 8), n_heads = 1024;
+    std::vector<uint8_t> gt(tab_stride(max_hap, n_heads) + 64);
+    build_table(gt.data(), y, (uint32_t)n, max_hap, n_heads);
+    Tab tb;
+    tb.gt = gt.data(); tb.ent = 0; tb.head = max_hap * 8; tb.bytes = tab_bytes_off(max_hap, n_heads);
+    tb.uq = tab_uq_off(max_hap, n_heads); tb.pb = tab_pb_off(max_hap, n_heads); tb.hmask = n_heads - 1;
+    if (!tab_has_twins(tb)) return 0xfffffffeu;
+    std::vector<uint8_t> xb((size_t)m + 16, 0);
+    memcpy(xb.data(), x, (size_t)m);
+    uint32_t la[LANE_WORDS], lb[LANE_WORDS];
+    const LaneS<uint16_t> lna{la + S_WORDS, 1, (uint16_t*)la, 1}, lnb{lb + S_WORDS, 1, (uint16_t*)lb, 1};
+    const Front fa = front(xb.data(), m, tb, n, lna, false), fb = front(xb.data(), m, tb, n, lnb, true);
+    if (fa.why != W_OK || fb.why != W_OK) return 0xffffffffu;
+    if (fa.d != fb.d || fa.cert != fb.cert || fa.r != fb.r) return 0xfffffffdu;
+    int na = probe_rows(xb.data(), tb, fa, lna);
+    int nb = probe_rows(xb.data(), tb, fb, lnb, twin_matches(tb, fb, m, lnb));
+    if (na <= LaneS<uint16_t>::SMAX) back_sort(na, lna);
+    if (nb <= LaneS<uint16_t>::SMAX) back_sort(nb, lnb);
+    for (int k = 0; k < std::min(std::min(na, cap), (int)LaneS<uint16_t>::SMAX); ++k) s_a[k] = lna.s(k);
+    for (int k = 0; k < std::min(std::min(nb, cap), (int)LaneS<uint16_t>::SMAX); ++k) s_b[k] = lnb.s(k);
+    return (uint32_t)(na > LaneS<uint16_t>::SMAX ? 0xffff : na) | ((uint32_t)(nb > LaneS<uint16_t>::SMAX ? 0xffff : nb) << 16);
+}
 static uint32_t g_last_pack = 0;
 // The harmless verdict for a single read and haplotype: 1 = every off-diagonal match is harmless (then the reference's chain lies on
 // the main diagonal *d_out), 0 = not, -1 = the logic declined before that (no diagonal, capacities)
@@ -146,7 +187,8 @@ int vtxt_fastcore_batch(const vtx_batch* b, uint32_t n_heads, int32_t* score, ui
     const bool force_wide = (n_heads >> 31) != 0;
     const bool refine = ((n_heads >> 30) & 1u) != 0;          // bit 30: the corridor refinement of band_refine_kernel
     const bool corridor = ((n_heads >> 29) & 1u) != 0;        // bit 29: the corridor certificate of band_corridor_kernel (round 6) behind the run bound
-    n_heads &= 0x1fffffffu;
+    const bool twins = ((n_heads >> 28) & 1u) != 0;           // bit 28 (with bit 29): the twin list instead of probes of the rows with an intact k-mer, as band_diag_kernel does
+    n_heads &= 0x0fffffffu;
     using namespace vtxf;
     uint32_t max_hap = 8;
     for (uint32_t l = 0; l < b->n_loci; ++l) max_hap = std::max(max_hap, std::max(b->loci[l].ref_len, b->loci[l].alt_len));
@@ -178,11 +220,12 @@ int vtxt_fastcore_batch(const vtx_batch* b, uint32_t n_heads, int32_t* score, ui
                     // certificate and harmless matches only (the kernel's tight list) the corridor bound over its one-diagonal band
                     const LaneS<uint16_t> ln{lane + S_WORDS, 1, (uint16_t*)lane, 1};
                     const int m = (int)R.read_len, n = (int)(h ? L.alt_len : L.ref_len);
-                    const Front fr = front(readbuf.data(), m, tb, n, ln);
+                    const bool tw = twins && tab_has_twins(tb);
+                    const Front fr = front(readbuf.data(), m, tb, n, ln, tw);
                     res = Result{-1, fr.why};
                     if (fr.why == W_OK && whole_read(fr, m)) res = Result{m, W_OK};
                     else if (fr.why == W_OK) {
-                        const int ns = probe_rows(readbuf.data(), tb, fr, ln);
+                        const int ns = probe_rows(readbuf.data(), tb, fr, ln, tw ? twin_matches(tb, fr, m, ln) : 0);
                         uint32_t wy = W_OK;
                         const int32_t sc = back(fr, ns, ln, Lane{generic, 1}, &wy, 0, nullptr);
                         res = Result{sc, wy};

@@ -582,3 +582,78 @@ def test_band_trimmed_bound_decides_the_banded_score(core):
     assert n_trim > 2000 and n_below > 1500, (n_trim, n_below)
     for before, after in left.values():
         assert after < 0.6 * before, left
+
+
+def test_twin_list_gives_the_matches_the_probes_gave(core):
+    """Round 6, the haplotype's twin list (vtx_fast_core.h: Tab tw[], twin_matches): band_diag_kernel takes the off-diagonal matches of
+    the rows whose main-diagonal k-mer is intact from the list and probes only the other rows.  Single (read, haplotype) pairs, AS
+    COMPILED: the match set equals the one the probes of every row that is not (intact and unique) give — on iid sequence, a
+    two-letter alphabet, tandem repeats next to iid sequence, a planted duplication, reads with errors, overhangs and indels; and
+    against the oracle's list of k-mer matches."""
+    core.vtxt_twin_vs_probe.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    core.vtxt_twin_vs_probe.restype = C.c_uint32
+    rng = np.random.default_rng(77)
+    sa, sb = np.zeros(64, np.uint32), np.zeros(64, np.uint32)
+    n_done = n_twin_matches = n_nolist = 0
+    for trial in range(1500):
+        kind = trial % 5
+        n = int(rng.integers(60, 256))
+        yb = bytearray(rng.choice(list(b"ACGT"), n).tolist())
+        if kind == 1:
+            yb = bytearray(rng.choice(list(b"AC"), n).tolist())
+        elif kind == 2:
+            unit = [b"AC", b"AAT", b"CAG", b"ACACAT"][int(rng.integers(0, 4))]
+            reps = unit * int(rng.integers(3, 9))
+            a0 = int(rng.integers(0, n - len(reps)))
+            yb[a0:a0 + len(reps)] = reps
+        elif kind == 3:
+            ln = int(rng.integers(7, 20))
+            a0, b0 = int(rng.integers(0, n - ln)), int(rng.integers(0, n - ln))
+            yb[b0:b0 + ln] = yb[a0:a0 + ln]
+        elif kind == 4 and trial % 10 == 4:
+            yb[int(rng.integers(0, n))] = ord("N")
+        y = bytes(yb)
+        m = int(rng.integers(40, 160)) if trial % 3 else int(rng.integers(160, 257))
+        d = int(rng.integers(-40, max(n - m + 40, -39)))
+        x = bytearray(rng.choice(list(b"ACGT"), m).tolist())
+        err = [0.0, 0.005, 0.03, 0.08][trial % 4]
+        for i in range(m):
+            if 0 <= i + d < n and rng.random() >= err:
+                x[i] = y[i + d]
+        if trial % 7 == 0 and m > 80:                      # a deletion in the read: its second half lies on another diagonal
+            cut = int(rng.integers(30, m - 30))
+            x = x[:cut] + x[cut + 3:]
+            m = len(x)
+        x = bytes(x)
+        got = core.vtxt_twin_vs_probe(x, m, y, n, sa.ctypes.data, sb.ctypes.data, 64)
+        if got == 0xfffffffe:
+            n_nolist += 1
+            continue
+        if got == 0xffffffff:
+            continue
+        assert got != 0xfffffffd, trial
+        na, nb = got & 0xffff, got >> 16
+        assert na == nb, (trial, na, nb)
+        if na == 0xffff:
+            continue
+        assert np.array_equal(sa[:na], sb[:nb]), (trial, sa[:na].tolist(), sb[:nb].tolist())
+        n_done += 1
+        n_twin_matches += na
+    assert n_done > 700 and n_twin_matches > 3000 and n_nolist > 50, (n_done, n_twin_matches, n_nolist)
+
+
+def test_twin_list_mode_decides_what_the_probes_decided(core):
+    """Whole batches through the three phases + the corridor certificate with (bit 28) and without the twin list: the same verdicts and
+    scores, task for task (the list changes where the matches come from, not what they are), and exact against the oracle."""
+    cases = list(SB.synthetic_batches(per_model=1, n_loci=60, reads=24)) + list(SB.real_sequence_batches(trials=1))
+    cases += list(SB.near_repeat_batches(trials=2)) + list(SB.repeat_rich_batches(trials=2))
+    tot = 0
+    for label, batch, nb in cases:
+        if int(max(batch.loci["ref_len"].max(), batch.loci["alt_len"].max())) > 255:
+            continue
+        s0, w0 = run_core(core, batch, 1024 | (1 << 29))
+        s1, w1 = run_core(core, batch, 1024 | (1 << 29) | (1 << 28))
+        assert np.array_equal(s0, s1) and np.array_equal(w0, w1), (label, int(np.nonzero((s0 != s1) | (w0 != w1))[0][0]))
+        tot += len(s0)
+    check(core, cases[0][1], cases[0][2], cases[0][0], 1024 | (1 << 29) | (1 << 28))
+    assert tot > 30000, tot

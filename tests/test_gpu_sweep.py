@@ -209,7 +209,7 @@ np.save(sys.argv[1], np.concatenate(out))
 
 
 @pytest.mark.parametrize("hook", ["VTX_BAND_LEGACY", "VTX_BAND_CHECK", "VTX_BAND_NO_TIGHT", "VTX_BAND_SLOTS", "VTX_SWEEP_V1", "VTX_BAND_DIAG2_MIN",
-                                  "VTX_BAND_NO_CORRIDOR", "VTX_DIAG_FOUR_WORDS"])
+                                  "VTX_BAND_NO_CORRIDOR", "VTX_DIAG_FOUR_WORDS", "VTX_DIAG_NO_TWINS"])
 def test_hooks_give_the_same_scores(hook):
     """VTX_BAND_DIAG2_MIN=1: the second single-diagonal stage (band_diag2_kernel) on every list, however short — by default lists
     below 700 k tasks skip it, i.e. every batch of this test suite but the full-size ones; VTX_SWEEP_V1=1: round 4's band_sweep_kernel (two passes) instead of round 5's; VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending / general kernels instead of the sweep; VTX_BAND_CHECK=1: the full-matrix
@@ -218,7 +218,8 @@ def test_hooks_give_the_same_scores(hook):
     DP in slices of five band slots; VTX_BAND_NO_CORRIDOR=1 (round 6): round 5's routing of the tasks that hold a certificate —
     band_refine_kernel for the ones with main pieces only, the masked DP for the rest — instead of band_corridor_kernel;
     VTX_DIAG_FOUR_WORDS=1: band_diag_kernel's build for reads up to 256 bases on these batches of short reads (it is chosen by the
-    batch's longest read).  Identical scores (separate processes: the hooks are read once)."""
+    batch's longest read); VTX_DIAG_NO_TWINS=1: band_diag_kernel probes every row that is not intact and unique instead of taking the
+    matches of the intact rows from the haplotype's twin list.  Identical scores (separate processes: the hooks are read once)."""
     res = []
     with tempfile.TemporaryDirectory() as td:
         for on in (0, 1):
@@ -247,7 +248,7 @@ def _table_layout(max_hap, n_heads):
     fb_off = bytes_off + max_hap + 8
     uq_off = (fb_off + max_hap + 8 + 3) & ~3
     pb_off = uq_off + 4 * (8 + (max_hap + 31) // 32 + 8)
-    return bytes_off, fb_off, uq_off, pb_off, (pb_off + 512 + 15) & ~15
+    return bytes_off, fb_off, uq_off, pb_off, (pb_off + 512 + 128 + 15) & ~15        # (tw[128] behind pb[]: the twin list, round 6)
 
 
 def _defined_bytes(tables, batch, n_heads=1024):
@@ -264,6 +265,8 @@ def _defined_bytes(tables, batch, n_heads=1024):
         hn = int(batch.loci["alt_len" if t & 1 else "ref_len"][t >> 1])
         nk = max(hn - 5, 0)
         out += [tb[:8 * nk], tb[max_hap * 8:bytes_off], tb[bytes_off:bytes_off + hn], tb[fb_off:fb_off + hn], tb[uq_off:pb_off + 512]]
+        tw = tb[pb_off + 512:pb_off + 640]
+        out += [tw[:1], tw[8:8 + 2 * (0 if tw[0] == 0xff else int(tw[0]))]]          # the twin list: its length, its pairs
     return np.concatenate(out)
 
 

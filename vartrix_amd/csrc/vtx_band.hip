@@ -805,6 +805,55 @@ static size_t band_table_stride(uint32_t max_hap, uint32_t n_heads) { return vtx
 #define TB_FB(tb) (TB_BYTES(tb) + max_hap + 8)
 #define TB_UQ(tb) ((uint32_t*)((tb) + vtxf::tab_uq_off(max_hap, n_heads)))
 #define TB_PB(tb) ((uint32_t*)((tb) + vtxf::tab_pb_off(max_hap, n_heads)))
+#define TB_TW(tb) ((uint8_t*)((tb) + vtxf::tab_tw_off(max_hap, n_heads)))
+
+// LDS exchanged between the lanes of ONE wavefront (its instructions reach the LDS in program order): a compiler-level
+// fence is all the ordering it needs
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The twin list of a finished table in LDS (vtx_fast_core.h: Tab tw[]; round 6), by ONE wavefront (lane = tid): the pairs (y, y'),
+// y != y', of positions with the same k-mer in (y, y') order — rounds of 64 positions, a prefix sum of the twin counts per round, the
+// chains ascend so every position writes its twins in order.  hib: the haplotype holds a byte >= 0x80 (no uniqueness flags, no list).
+// The tw area was zeroed with the bitmaps; the head words carry their tags already.
+__device__ __forceinline__ void build_twins_wave(uint8_t* tb, uint32_t hn, bool hib, uint32_t max_hap, uint32_t n_heads, int tid) {
+    const uint2* ent = TB_ENT(tb);
+    const uint16_t* head = TB_HEAD(tb);
+    const uint32_t* uq = TB_UQ(tb) + vtxf::UQ_PAD_WORDS;
+    uint8_t* tw = TB_TW(tb);
+    const int nk = hn >= (uint32_t)KMER ? (int)hn - KMER + 1 : 0;
+    bool ok = !hib && hn <= 256u;
+    uint32_t total = 0;
+    for (int base = 0; base < nk && ok; base += 64) {
+        const int y = base + tid;
+        uint32_t c = 0, first = CH_END;
+        uint2 k = make_uint2(0, 0);
+        if (y < nk && !((uq[y >> 5] >> (y & 31)) & 1u)) {
+            k = ent[y];
+            first = head_pos(head[kw_hash(k.x, k.y & 0xffffu, n_heads - 1)]);
+            for (uint32_t e = first; e != CH_END; e = ent[e].y >> 16) c += (ent[e].x == k.x && ((ent[e].y ^ k.y) & 0xffffu) == 0);
+            c -= 1u;                                                      // (the position itself)
+        }
+        uint32_t inc = c;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, sft); if (tid >= sft) inc += t; }
+        uint32_t off = total + inc - c;
+        total += (uint32_t)__shfl((int)inc, 63);
+        if (total > vtxf::TW_MAX) { ok = false; break; }                  // (wave-uniform)
+        if (c)
+            for (uint32_t e = first; e != CH_END; e = ent[e].y >> 16)
+                if (e != (uint32_t)y && ent[e].x == k.x && ((ent[e].y ^ k.y) & 0xffffu) == 0) {
+                    tw[8 + 2 * off] = (uint8_t)y; tw[9 + 2 * off] = (uint8_t)e; ++off;
+                }
+    }
+    wave_sync();
+    if (!ok) for (uint32_t i = tid; i < vtxf::TW_BYTES / 4; i += 64) ((uint32_t*)tw)[i] = 0;
+    wave_sync();
+    if (tid == 0) tw[0] = ok ? (uint8_t)total : (uint8_t)vtxf::TW_NONE;
+}
 
 // Tail of band_run_kernel: traceback through the jump log (chain = a few diagonal segments), walk of
 // the anchor staircase (its local score = the lower bound `cert`), polyline for hard tasks.
@@ -1173,7 +1222,7 @@ __device__ __forceinline__ void build_tables(uint8_t* tables, uint32_t n_tab, ui
             }
             for (uint32_t i = tid; i < n_heads; i += NT) head[i] = CH_END;
             uint32_t* uq = TB_UQ(tb);
-            for (uint32_t i = tid; i < vtxf::tab_uq_words(max_hap) + 128u; i += NT) uq[i] = 0;     // uq[] and, behind it, pb[128]
+            for (uint32_t i = tid; i < vtxf::tab_uq_words(max_hap) + 128u + vtxf::TW_BYTES / 4; i += NT) uq[i] = 0;     // uq[] and, behind it, pb[128] and tw[]
         }
         __syncthreads();
         if ((uint32_t)tid < n_tab) {     // one lane per table: sequential head insertion, descending y => ascending chains
@@ -1263,6 +1312,12 @@ __global__ __launch_bounds__(64) void band_tables_v1_kernel(const vtx_locus* __r
     const int tid = threadIdx.x;
     for (uint32_t l = blockIdx.x; l < n_loci; l += gridDim.x) {
         build_tables<64>((uint8_t*)smem, 2, l0 + l, loci, hap_arena, max_hap, table_stride, n_heads, tid, s_hibyte);
+        for (uint32_t t = 0; t < 2; ++t) {
+            const vtx_locus loc = loci[l0 + l];
+            const uint32_t hn = max(loc.ref_len, loc.alt_len) > max_hap ? 0u : (t ? loc.alt_len : loc.ref_len);
+            build_twins_wave((uint8_t*)smem + (size_t)t * table_stride, hn, ((s_hibyte >> t) & 1u) != 0, max_hap, n_heads, tid);
+        }
+        wave_sync();
         const uint4* src = (const uint4*)smem;
         uint4* dst = (uint4*)(gtables + (size_t)l * 2 * table_stride);
         for (uint32_t i = tid; i < 2 * table_stride / 16; i += 64) dst[i] = src[i];
@@ -1867,13 +1922,6 @@ __global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __rest
 // and reads meet in one L2.
 // counters[12] = tasks left to band_run_kernel; counters[32 + why] = reasons (stats != 0).
 // =============================================================================================
-// LDS exchanged between the lanes of ONE wavefront (its instructions reach the LDS in program order): a compiler-level
-// fence is all the ordering it needs
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // =============================================================================================
 // band_tables_kernel (round 4) — the k-mer tables of loci [l0, l0 + n_loci) in global memory, the same bytes build_tables leaves
@@ -1903,7 +1951,7 @@ __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __rest
     uint32_t* uq0 = TB_UQ(tb);
     uint32_t* pb = TB_PB(tb);
     const uint32_t hmask = n_heads - 1;
-    const uint32_t zero_words = vtxf::tab_uq_words(max_hap) + 128u;           // uq[] and, behind it, pb[128]
+    const uint32_t zero_words = vtxf::tab_uq_words(max_hap) + 128u + vtxf::TW_BYTES / 4;   // uq[] and, behind it, pb[128] and tw[]
     for (uint32_t t = blockIdx.x; t < 2u * n_loci; t += gridDim.x) {
         const vtx_locus loc = loci[l0 + (t >> 1)];
         if (max(loc.ref_len, loc.alt_len) <= min_hap) continue;               // (a locus of the other pass: its table is never read; wave-uniform)
@@ -1973,6 +2021,8 @@ __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __rest
             }
         }
         wave_sync();
+        build_twins_wave(tb, hn, hib, max_hap, n_heads, tid);
+        wave_sync();
         const uint4* src = (const uint4*)smem;
         uint4* dst = (uint4*)(gtables + (size_t)t * table_stride);
         for (uint32_t i = tid; i < table_stride / 16; i += 64) dst[i] = src[i];
@@ -2029,7 +2079,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     const uint32_t slot = blk * 256 + threadIdx.x;
     const bool have = slot < n_tasks;
     const uint32_t task = task_base + slot;
-    bool fail = false, live = false, whole = false;
+    bool fail = false, live = false, whole = false, twins = false;
     uint32_t why = 0;
     // (where a task's score goes is recomputed at each of the four stores: a pointer held across the kernel is two registers of 128)
     auto my_score = [&]() -> int32_t* { return ((task & 1u) ? alt_score : ref_score) + (task >> 1); };
@@ -2120,7 +2170,10 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         if (live && !have_d) { live = false; fail = true; why = vtxf::W_NO_DIAG; }
         if (VTX_ABLATE(stats >> 8) == 3) { if (live && d == 0x7fffffff) counters[40] = 1; return; }       // (profiling aid) up to the diagonal and its mask
         if (live) {
-            fr = vtxf::front_rest<LaneT, A>(x, m, tb, n, ln, d, M);
+            // (round 6) a haplotype with a twin list (two-byte entries only: positions are bytes there): the matches of the rows whose
+            // main-diagonal k-mer is intact come from the list, the probes below look at the other rows only
+            if constexpr (sizeof(ST) == 2) twins = !(stats & 0x20000u) && vtxf::tab_has_twins(tb);
+            fr = vtxf::front_rest<LaneT, A>(x, m, tb, n, ln, d, M, twins);
             if (fr.why != vtxf::W_OK) { live = false; fail = true; why = fr.why; }
             else if (VTX_ABLATE(stats >> 8) != 10 && vtxf::whole_read(fr, m)) {      // (developer build, VTX_DIAG_ABLATE=10: the shortcut off — the A/B switch of include/vtx_band_semantics.h's fifth item; results stay right)
                 // the read matches base for base: full <= m = cert, and the reference's chain is a perfect diagonal whatever else
@@ -2129,11 +2182,14 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
                 if (stage) stage[task] = 1;
                 live = false; whole = true;
             }
+            if (live && twins) s_cnt[tid] = (uint32_t)vtxf::twin_matches(tb, fr, m, ln);
         }
     }
     constexpr uint32_t NO_TAB = 0xffffffffu;
-    o_tab[tid] = tb.head && !whole ? tb.ent : NO_TAB;           // (head offset 0: the lane never got as far as its table; a whole read: nobody needs to probe for it)
-    o_diag[tid] = fr.d;
+    // (bit 0 — table offsets are multiples of 16: the lane took its twin list, so a row ANOTHER lane asked for may be one whose matches
+    //  it holds already; the walks below drop those)
+    o_tab[tid] = tb.head && !whole ? (tb.ent | (twins ? 1u : 0u)) : NO_TAB;     // (head offset 0: the lane never got as far as its table; a whole read: nobody needs to probe for it)
+    o_diag[tid] = (int32_t)(((uint32_t)fr.d & 0xffffu) | ((uint32_t)n << 16));     // the diagonal and the haplotype's length
     // ---- pooled probes: the rows the lanes still have to look up differ a lot from lane to lane (a read that hangs over
     //      the padded window has up to 49 rows without a main-diagonal k-mer), so the wavefront's rows go through one queue
     //      and every lane probes for whoever owns the row.  Pass 1: the presence bitmap (one word of 512 bytes per
@@ -2155,7 +2211,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     }
     vtxf::MIter need_it = vtxf::m_iter(nd);
     if (VTX_ABLATE(stats >> 8) == 1) { if (live && fr.cert == 0x7fffffff) counters[40] = 1; return; }      // (profiling aid) front only
-    const uint32_t pb_rel = vtxf::tab_pb_off(max_hap, n_heads), head_rel = max_hap * 8u;
+    const uint32_t pb_rel = vtxf::tab_pb_off(max_hap, n_heads), head_rel = max_hap * 8u, bytes_rel = vtxf::tab_bytes_off(max_hap, n_heads);
     // pass 2 over the first n_walk entries of the walk list (every lane calls it; 0xffff: a slot reserved by a lane that did not fit)
     auto walk_list = [&](uint32_t n_walk) {
         if (VTX_ABLATE(stats >> 8) == 9) return;                                // (profiling aid) pass 1 without the bucket walks
@@ -2164,8 +2220,9 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         constexpr int WPL = 2;
         for (uint32_t i0 = 0; i0 < n_walk; i0 += 64 * WPL) {
             uint32_t own[WPL], row[WPL], hh[WPL], raw[WPL], tent[WPL];
-            uint64_t w8[WPL], e0[WPL];
-            bool go[WPL];
+            uint64_t w8[WPL], e0[WPL], ym8[WPL];
+            bool go[WPL], chk[WPL];
+            int od[WPL];
 #pragma unroll
             for (int u = 0; u < WPL; ++u) {
                 const uint32_t i = i0 + 64u * u + tid;
@@ -2176,6 +2233,14 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
                 tent[u] = o_tab[own[u]];
                 go[u] = go[u] && tent[u] != NO_TAB;
                 if (!go[u]) tent[u] = 0;
+                // a lane that took its twin list did not ask for the rows whose main-diagonal k-mer is intact — its pair's other lane
+                // may have: the row's matches are in its list already.  Intact = the haplotype's six bytes at (row, row + d) are the read's.
+                const uint32_t dn = (uint32_t)o_diag[own[u]];
+                od[u] = (int)(int16_t)(uint16_t)dn;
+                const int ym = (int)row[u] + od[u];
+                chk[u] = go[u] && (tent[u] & 1u) && ym >= 0 && ym + vtxf::K <= (int)(dn >> 16);
+                tent[u] &= ~1u;
+                ym8[u] = vtxf::ld8(gtables + tent[u] + bytes_rel + (uint32_t)(chk[u] ? ym : 0));
             }
 #pragma unroll
             for (int u = 0; u < WPL; ++u) {
@@ -2186,17 +2251,17 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             for (int u = 0; u < WPL; ++u) {
                 const uint32_t tag = raw[u] >> 12;
                 go[u] = go[u] && raw[u] != vtxf::HEAD_END && (tag == vtxf::HEAD_MULTI || tag == vtxf::kw_tag(hh[u]));   // (else: the bucket's only k-mer is another one)
+                if (chk[u] && ((ym8[u] ^ w8[u]) & 0xffffffffffffull) == 0) go[u] = false;
                 e0[u] = vtxf::ld8(gtables + tent[u] + 8u * (go[u] ? raw[u] & 0xfffu : 0u));
             }
 #pragma unroll
             for (int u = 0; u < WPL; ++u) {
                 if (!go[u]) continue;
                 const uint32_t lo = (uint32_t)w8[u], hi = (uint32_t)(w8[u] >> 32) & 0xffffu;
-                const int od = o_diag[own[u]];
                 uint32_t yc = raw[u] & 0xfffu;
                 uint64_t e = e0[u];
                 for (;;) {
-                    if ((uint32_t)e == lo && ((uint32_t)(e >> 32) & 0xffffu) == hi && (int)yc - (int)row[u] != od) {
+                    if ((uint32_t)e == lo && ((uint32_t)(e >> 32) & 0xffffu) == hi && (int)yc - (int)row[u] != od[u]) {
                         const uint32_t pos = atomicAdd(&s_cnt[own[u]], 1u);
                         if (pos < (uint32_t)LaneT::SMAX) ((ST*)lane_mem)[pos * 64 + own[u]] = (ST)((row[u] << LaneT::XS) | yc);
                     }
@@ -2236,8 +2301,8 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             for (int u = 0; u < EPL; ++u) {
                 code[u] = vtxf::kw_code((uint32_t)w8[u], (uint32_t)(w8[u] >> 32) & 0xffffu);
                 const uint32_t ta = o_tab[(ent2[u] >> 8) * 2u], tb_ = o_tab[(ent2[u] >> 8) * 2u + 1u];   // (NO_TAB: a lane without a table)
-                bits_a[u] = ta == NO_TAB ? 0u : *(const uint32_t*)(gtables + ta + pb_rel + 4u * (code[u] >> 5));
-                bits_b[u] = tb_ == NO_TAB ? 0u : *(const uint32_t*)(gtables + tb_ + pb_rel + 4u * (code[u] >> 5));
+                bits_a[u] = ta == NO_TAB ? 0u : *(const uint32_t*)(gtables + (ta & ~1u) + pb_rel + 4u * (code[u] >> 5));
+                bits_b[u] = tb_ == NO_TAB ? 0u : *(const uint32_t*)(gtables + (tb_ & ~1u) + pb_rel + 4u * (code[u] >> 5));
             }
             // the survivors (5 % of the probes) join the walk list: one LDS add per lane that has any, no ballots.  The list is
             // short (WALK_CAP entries — the LDS this kernel has left): a lane that does not fit marks what it reserved inside the
@@ -2681,7 +2746,8 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     launch_band_tables(loci, gt_l0, n_loci, hap_arena, max_hap, min_hap, tstride, n_heads, gtables, s);
     const uint32_t n_blocks = (n_tasks + 255) / 256;
     const uint32_t st = (uint32_t)stats | (VTX_DEV_ENV("VTX_DIAG_ABLATE") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_DIAG_ABLATE")) << 8 : 0u) |
-                        (VTX_DEV_ENV("VTX_BAND_NO_CORRIDOR") ? 0x10000u : 0u);          // (A/B hook: round 5's records for band_refine_kernel)
+                        (VTX_DEV_ENV("VTX_BAND_NO_CORRIDOR") ? 0x10000u : 0u) |         // (A/B hook: round 5's records for band_refine_kernel)
+                        (VTX_DEV_ENV("VTX_DIAG_NO_TWINS") ? 0x20000u : 0u);             // (A/B hook: every row that is not intact and unique is probed, the twin lists unused)
     // two-byte match entries (40 per task) whenever a haplotype position fits a byte; VTX_DIAG_WIDE=1 forces the four-byte variant (tests)
     static const bool force_wide = VTX_DEV_ENV("VTX_DIAG_WIDE") != nullptr;
     static const bool force_four = VTX_DEV_ENV("VTX_DIAG_FOUR_WORDS") != nullptr;      // (tests: the four-word build on short reads)

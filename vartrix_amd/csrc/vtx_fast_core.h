@@ -121,7 +121,14 @@ VTXF_HD uint32_t tab_fb_off(uint32_t max_hap, uint32_t n_heads) { return tab_byt
 VTXF_HD uint32_t tab_uq_off(uint32_t max_hap, uint32_t n_heads) { return (tab_fb_off(max_hap, n_heads) + max_hap + 8u + 3u) & ~3u; }
 VTXF_HD uint32_t tab_uq_words(uint32_t max_hap) { return UQ_PAD_WORDS + (max_hap + 31u) / 32u + 8u; }
 VTXF_HD uint32_t tab_pb_off(uint32_t max_hap, uint32_t n_heads) { return tab_uq_off(max_hap, n_heads) + 4u * tab_uq_words(max_hap); }
-VTXF_HD uint32_t tab_stride(uint32_t max_hap, uint32_t n_heads) { return (tab_pb_off(max_hap, n_heads) + 512u + 15u) & ~15u; }
+// tw[TW_BYTES] behind pb[] (round 6): the haplotype's TWIN LIST — byte 0 = its length (TW_NONE: no list — more than TW_MAX pairs, a
+// byte >= 0x80 in the haplotype, or a haplotype above 256 bases), from byte 8 on the pairs (y, y'), y != y', of positions that hold
+// the same k-mer, in (y, y') order.  A read row whose main-diagonal k-mer is intact has, as off-diagonal matches, exactly the twins
+// of its haplotype position: band_diag_kernel takes them from this list (twin_matches) and probes only the rows whose k-mer is NOT
+// intact — on the headline workload 5 of the 28 rows a task probed, and 82 % of the bucket walks, were of this kind.
+constexpr uint32_t TW_MAX = 60, TW_BYTES = 128, TW_NONE = 0xffu;
+VTXF_HD uint32_t tab_tw_off(uint32_t max_hap, uint32_t n_heads) { return tab_pb_off(max_hap, n_heads) + 512u; }
+VTXF_HD uint32_t tab_stride(uint32_t max_hap, uint32_t n_heads) { return (tab_tw_off(max_hap, n_heads) + TW_BYTES + 15u) & ~15u; }
 // 12-bit code of a k-mer, two bits per byte ((b >> 1) & 3: A 0, C 1, T 2, G 3; any other byte lands on one of them — equal
 // bytes always give equal codes, which is all a presence filter needs)
 VTXF_HD uint32_t kw_code(uint32_t lo, uint32_t hi) {
@@ -463,10 +470,10 @@ VTXF_FN bool verify_diag(const uint8_t* x, int m, const Tab& tb, int n, int dc) 
     const int p = vlo + ((vhi - vlo - 8) >> 1);
     return __builtin_popcount(eq8(ld8(x + p), ld8(tb.gt + tb.bytes + (p + dc)))) >= 6;
 }
-template <class LN, int A = NW> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, int d, M192 M);
+template <class LN, int A = NW> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, int d, M192 M, bool tw = false);
 
 // one lane on its own: the six sample rows in turn; a candidate is kept if its mask has at least 20 matching bases
-template <class LN> VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln) {
+template <class LN> VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, bool tw = false) {
     Front fr;
     fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.ca = fr.cb = 0; fr.zc = 0; fr.need = m_zero();
     if (m < K || n < K || m > MAX_READ) { fr.why = W_SHAPE; return fr; }
@@ -478,14 +485,16 @@ template <class LN> VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, 
         prev = dc;
         if (!verify_diag(x, m, tb, n, dc)) continue;
         const M192 Mc = diag_mask(rw, x, m, tb, n, dc);
-        if (m_pop(Mc) >= 20) return front_rest(x, m, tb, n, ln, dc, Mc);
+        if (m_pop(Mc) >= 20) return front_rest(x, m, tb, n, ln, dc, Mc, tw);
     }
     fr.why = W_NO_DIAG;
     return fr;
 }
 
 // everything of phase 1 behind the choice of the diagonal d (M = diag_mask(d))
-template <class LN, int A> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, int d, M192 M) {
+// tw: the caller takes the off-diagonal matches of the rows with an intact main-diagonal k-mer from the haplotype's twin list
+// (twin_matches): fr.need = the rows whose k-mer is not intact, whether the haplotype's k-mer there is unique or not
+template <class LN, int A> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, int d, M192 M, bool tw) {
     (void)x;
     Front fr;
     fr.why = W_OK; fr.d = 0; fr.r = 0; fr.best_dp = 0; fr.cert = 0; fr.ca = fr.cb = 0; fr.zc = 0; fr.need = m_zero();
@@ -563,28 +572,54 @@ template <class LN, int A> VTXF_FN Front front_rest(const uint8_t* x, int m, con
         const uint32_t wi = bo >> 5, sh = bo & 31u;
         uint32_t q[2 * NW + 1];
         VTXF_UNROLL
-        for (int k = 0; k < 2 * NW + 1; ++k) q[k] = k < 2 * A + 1 ? uq[wi + k] : 0u;
+        for (int k = 0; k < 2 * NW + 1; ++k) q[k] = (k < 2 * A + 1 && !tw) ? uq[wi + k] : 0u;
         M192 U;
         VTXF_UNROLL
         for (int k = 0; k < NW; ++k) {
             const uint32_t a = (uint32_t)((((uint64_t)q[2 * k + 1] << 32) | q[2 * k]) >> sh);
             const uint32_t b = (uint32_t)((((uint64_t)q[2 * k + 2 < 2 * NW + 1 ? 2 * k + 2 : 0] << 32) | q[2 * k + 1]) >> sh);
-            U.w[k] = k < A ? ((uint64_t)b << 32) | a : 0ull;
+            U.w[k] = k < A ? (tw ? ~0ull : ((uint64_t)b << 32) | a) : 0ull;
         }
         fr.need = m_andn(m_range<A>(0, m - K + 1), m_and(I6, U));
     }
     return fr;
 }
 
+// ---- the twin list (Tab: tw[]): the off-diagonal matches of the rows whose main-diagonal k-mer is intact — a row i of [0, m - K]
+//      that front_rest(.., tw = true) did NOT put into fr.need — are (i, y') for the twins y' of haplotype position i + d.  Appended
+//      to ln[0 ..) in (x, y) order (the list's own); returns their number (entries beyond the lane's capacity are counted, not stored).
+//      Precondition: the list exists (tw[0] != TW_NONE). ----
+VTXF_FN bool tab_has_twins(const Tab& tb) { return tb.gt[tb.pb + 512u] != TW_NONE; }
+template <class LN> VTXF_FN int twin_matches(const Tab& tb, const Front& fr, int m, const LN& ln) {
+    const uint8_t* tw = tb.gt + tb.pb + 512u;
+    const int cnt = (int)tw[0];
+    int ns = 0;
+    for (int i0 = 0; i0 < cnt; i0 += 4) {
+        const uint64_t w = ld8(tw + 8 + 2 * i0);
+VTXF_UNROLL
+        for (int j = 0; j < 4; ++j) {
+            const int y = (int)((w >> (16 * j)) & 0xffu), y2 = (int)((w >> (16 * j + 8)) & 0xffu);
+            const int row = y - fr.d;
+            if (i0 + j >= cnt || row < 0 || row > m - K) continue;
+            const uint64_t nw = row < 64 ? fr.need.w[0] : (row < 128 ? fr.need.w[1] : (NW > 3 && row >= 192 ? fr.need.w[NW - 1] : fr.need.w[2]));
+            if ((nw >> (row & 63)) & 1ull) continue;                         // the row's k-mer is not intact: it is probed
+            if (ns < LN::SMAX) ln.s(ns) = (typename LN::SType)(((uint32_t)row << LN::XS) | (uint32_t)y2);
+            ++ns;
+        }
+    }
+    return ns;
+}
+
 // ---- phase 2, one lane on its own: the rows of fr.need four at a time (their loads go out together); a row whose k-mer is not
 //      in the haplotype's presence bitmap is done after one word.  Returns the number of off-diagonal matches appended to
 //      ln[0 ..), or SM + 1 when there are more than SM. ----
-template <class LN> VTXF_FN int probe_rows(const uint8_t* x, const Tab& tb, const Front& fr, const LN& ln) {
+template <class LN> VTXF_FN int probe_rows(const uint8_t* x, const Tab& tb, const Front& fr, const LN& ln, int ns0 = 0) {
     constexpr int SM = LN::SMAX;
     const uint8_t* head = tb.gt + tb.head;
     const uint32_t* pb = (const uint32_t*)(tb.gt + tb.pb);
     M192 need = fr.need;
-    int ns = 0;
+    int ns = ns0;                                  // (matches the lane holds already: twin_matches)
+    if (ns > SM) return SM + 1;
     while (m_any(need)) {
         int row[4];
         uint64_t w8[4];
