@@ -209,7 +209,7 @@ np.save(sys.argv[1], np.concatenate(out))
 
 
 @pytest.mark.parametrize("hook", ["VTX_BAND_LEGACY", "VTX_BAND_CHECK", "VTX_BAND_NO_TIGHT", "VTX_BAND_SLOTS", "VTX_SWEEP_V1", "VTX_BAND_DIAG2_MIN",
-                                  "VTX_BAND_NO_CORRIDOR", "VTX_DIAG_FOUR_WORDS", "VTX_DIAG_NO_TWINS"])
+                                  "VTX_BAND_NO_CORRIDOR", "VTX_DIAG_FOUR_WORDS", "VTX_DIAG_NO_TWINS", "VTX_DIAG_NO_T3"])
 def test_hooks_give_the_same_scores(hook):
     """VTX_BAND_DIAG2_MIN=1: the second single-diagonal stage (band_diag2_kernel) on every list, however short — by default lists
     below 700 k tasks skip it, i.e. every batch of this test suite but the full-size ones; VTX_SWEEP_V1=1: round 4's band_sweep_kernel (two passes) instead of round 5's; VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending / general kernels instead of the sweep; VTX_BAND_CHECK=1: the full-matrix
@@ -219,7 +219,8 @@ def test_hooks_give_the_same_scores(hook):
     band_refine_kernel for the ones with main pieces only, the masked DP for the rest — instead of band_corridor_kernel;
     VTX_DIAG_FOUR_WORDS=1: band_diag_kernel's build for reads up to 256 bases on these batches of short reads (it is chosen by the
     batch's longest read); VTX_DIAG_NO_TWINS=1: band_diag_kernel probes every row that is not intact and unique instead of taking the
-    matches of the intact rows from the haplotype's twin list.  Identical scores (separate processes: the hooks are read once)."""
+    matches of the intact rows from the haplotype's twin list; VTX_DIAG_NO_T3=1: its pooled probes take a queue entry and a presence-bitmap
+    word per row instead of blocks of three rows and the tables' three-row sets.  Identical scores (separate processes: the hooks are read once)."""
     res = []
     with tempfile.TemporaryDirectory() as td:
         for on in (0, 1):
@@ -248,7 +249,7 @@ def _table_layout(max_hap, n_heads):
     fb_off = bytes_off + max_hap + 8
     uq_off = (fb_off + max_hap + 8 + 3) & ~3
     pb_off = uq_off + 4 * (8 + (max_hap + 31) // 32 + 8)
-    return bytes_off, fb_off, uq_off, pb_off, (pb_off + 512 + 128 + 15) & ~15        # (tw[128] behind pb[]: the twin list, round 6)
+    return bytes_off, fb_off, uq_off, pb_off, (pb_off + 512 + 128 + 2048 + 15) & ~15        # (round 6: tw[128], the twin list, and t3[2048], the three-row sets, behind pb[])
 
 
 def _defined_bytes(tables, batch, n_heads=1024):
@@ -267,7 +268,23 @@ def _defined_bytes(tables, batch, n_heads=1024):
         out += [tb[:8 * nk], tb[max_hap * 8:bytes_off], tb[bytes_off:bytes_off + hn], tb[fb_off:fb_off + hn], tb[uq_off:pb_off + 512]]
         tw = tb[pb_off + 512:pb_off + 640]
         out += [tw[:1], tw[8:8 + 2 * (0 if tw[0] == 0xff else int(tw[0]))]]          # the twin list: its length, its pairs
+        out += [tb[pb_off + 640:pb_off + 640 + 2048]]                                 # the three-row sets
     return np.concatenate(out)
+
+
+def _expected_t3_and_twins(hap):
+    """vtx_fast_core.h, Tab: t3[] (three 16-bit sets per 8-bit code of four bases) and the twin list of one haplotype, from its bytes."""
+    code = [(b >> 1) & 3 for b in hap]
+    t3 = np.zeros(512, np.uint32)
+    nk = max(len(hap) - 5, 0)
+    for y in range(nk):
+        c = sum(code[y + i] << (2 * i) for i in range(6))
+        t3[2 * (c >> 4)] |= np.uint32(1 << (c & 15))
+        t3[2 * ((c >> 2) & 0xff)] |= np.uint32(1 << (16 + ((c & 3) | ((c >> 10) << 2))))
+        t3[2 * (c & 0xff) + 1] |= np.uint32(1 << (c >> 8))
+    pairs = [(y, z) for y in range(nk) for z in range(nk) if z != y and hap[y:y + 6] == hap[z:z + 6]]
+    ok = len(pairs) <= 60 and len(hap) <= 256 and max(hap, default=0) < 0x80
+    return t3, (pairs if ok else None)
 
 
 def test_table_kernel_against_round3s():
@@ -300,6 +317,22 @@ def test_table_kernel_against_round3s():
         dp, ds = _defined_bytes(tp, batch), _defined_bytes(ts, batch)
         assert np.array_equal(dp, ds), "%s: tables differ (%d of %d defined bytes)" % (label, int((dp != ds).sum()), len(dp))
         assert np.array_equal(sp[0], ss[0]) and np.array_equal(sp[1], ss[1]), label
+        # round 6's arrays against a plain restatement (a few tables per batch)
+        stride = len(tp) // (2 * batch.n_loci)
+        longest = int(max(batch.loci["ref_len"].max(), batch.loci["alt_len"].max()))
+        max_hap = next(m for m in range(longest, longest + 64) if _table_layout(m, 1024)[4] == stride)
+        pb_off = _table_layout(max_hap, 1024)[3]
+        for t in list(range(0, 2 * batch.n_loci, max(1, batch.n_loci // 4)))[:8]:
+            L = batch.loci[t >> 1]
+            off, hn = (int(L["alt_off"]), int(L["alt_len"])) if t & 1 else (int(L["ref_off"]), int(L["ref_len"]))
+            t3, pairs = _expected_t3_and_twins(bytes(batch.hap_arena[off:off + hn]))
+            tb = tp[t * stride:(t + 1) * stride]
+            assert np.array_equal(tb[pb_off + 640:pb_off + 640 + 2048].view(np.uint32), t3), (label, t)
+            tw = tb[pb_off + 512:pb_off + 640]
+            if pairs is None:
+                assert tw[0] == 0xff, (label, t)
+            else:
+                assert tw[0] == len(pairs) and [(int(tw[8 + 2 * i]), int(tw[9 + 2 * i])) for i in range(len(pairs))] == pairs, (label, t)
         checked += 1
     assert checked >= 5
 

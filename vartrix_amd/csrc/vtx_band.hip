@@ -798,7 +798,10 @@ __device__ __forceinline__ uint32_t kw_hash(uint32_t lo, uint32_t hi, uint32_t h
 // fb[y] = (byte y & 0x7f) | 0x80 if the k-mer that ENDS at y is unique in the haplotype (continuation shortcut).
 // ... and uq[] (vtx_fast_core.h: tab_uq_off): one bit per position, set if the k-mer STARTING there is unique, behind
 // UQ_PAD_WORDS zero words (band_diag_kernel reads 192 bits of it at the bit offset of its diagonal).
-static size_t band_table_stride(uint32_t max_hap, uint32_t n_heads) { return vtxf::tab_stride(max_hap, n_heads); }
+// (in_lds: a table band_run_kernel builds for itself in LDS ends behind pb[] — the twin list and the three-row sets are band_diag_kernel's)
+static size_t band_table_stride(uint32_t max_hap, uint32_t n_heads, bool in_lds = false) {
+    return in_lds ? vtxf::tab_stride_lds(max_hap, n_heads) : vtxf::tab_stride(max_hap, n_heads);
+}
 #define TB_ENT(tb) ((uint2*)(tb))
 #define TB_HEAD(tb) ((uint16_t*)((tb) + (size_t)max_hap * 8))
 #define TB_BYTES(tb) ((uint8_t*)(TB_HEAD(tb) + n_heads))
@@ -806,6 +809,7 @@ static size_t band_table_stride(uint32_t max_hap, uint32_t n_heads) { return vtx
 #define TB_UQ(tb) ((uint32_t*)((tb) + vtxf::tab_uq_off(max_hap, n_heads)))
 #define TB_PB(tb) ((uint32_t*)((tb) + vtxf::tab_pb_off(max_hap, n_heads)))
 #define TB_TW(tb) ((uint8_t*)((tb) + vtxf::tab_tw_off(max_hap, n_heads)))
+#define TB_T3(tb) ((uint32_t*)((tb) + vtxf::tab_t3_off(max_hap, n_heads)))
 
 // LDS exchanged between the lanes of ONE wavefront (its instructions reach the LDS in program order): a compiler-level
 // fence is all the ordering it needs
@@ -813,6 +817,20 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifdef VTX_DEVTOOLS        // (behind round 3's table kernel, the reference of band_tables_kernel — which builds both inside its flag loop)
+// The three-row presence sets of a table in LDS (vtx_fast_core.h: Tab t3[]; round 6), by one wavefront; t3[] was zeroed with the bitmaps.
+__device__ __forceinline__ void build_t3_wave(uint8_t* tb, uint32_t hn, uint32_t max_hap, uint32_t n_heads, int tid) {
+    const uint2* ent = TB_ENT(tb);
+    uint32_t* t3 = TB_T3(tb);
+    const int nk = hn >= (uint32_t)KMER ? (int)hn - KMER + 1 : 0;
+    for (int y = tid; y < nk && vtxf::T3_BYTES != 0; y += 64) {
+        const uint32_t c = vtxf::kw_code(ent[y].x, ent[y].y & 0xffffu);
+        atomicOr(&t3[vtxf::t3_word_a(c)], 1u << vtxf::t3_bit_a(c));
+        atomicOr(&t3[vtxf::t3_word_b(c)], 1u << vtxf::t3_bit_b(c));
+        atomicOr(&t3[vtxf::t3_word_c(c)], 1u << vtxf::t3_bit_c(c));
+    }
 }
 
 // The twin list of a finished table in LDS (vtx_fast_core.h: Tab tw[]; round 6), by ONE wavefront (lane = tid): the pairs (y, y'),
@@ -854,6 +872,7 @@ __device__ __forceinline__ void build_twins_wave(uint8_t* tb, uint32_t hn, bool 
     wave_sync();
     if (tid == 0) tw[0] = ok ? (uint8_t)total : (uint8_t)vtxf::TW_NONE;
 }
+#endif
 
 // Tail of band_run_kernel: traceback through the jump log (chain = a few diagonal segments), walk of
 // the anchor staircase (its local score = the lower bound `cert`), polyline for hard tasks.
@@ -1222,7 +1241,7 @@ __device__ __forceinline__ void build_tables(uint8_t* tables, uint32_t n_tab, ui
             }
             for (uint32_t i = tid; i < n_heads; i += NT) head[i] = CH_END;
             uint32_t* uq = TB_UQ(tb);
-            for (uint32_t i = tid; i < vtxf::tab_uq_words(max_hap) + 128u + vtxf::TW_BYTES / 4; i += NT) uq[i] = 0;     // uq[] and, behind it, pb[128] and tw[]
+            for (uint32_t i = tid; i < (table_stride - vtxf::tab_uq_off(max_hap, n_heads)) / 4; i += NT) uq[i] = 0;     // uq[] and, behind it, pb[128] (and tw[], t3[] of a table that goes to global memory)
         }
         __syncthreads();
         if ((uint32_t)tid < n_tab) {     // one lane per table: sequential head insertion, descending y => ascending chains
@@ -1316,6 +1335,7 @@ __global__ __launch_bounds__(64) void band_tables_v1_kernel(const vtx_locus* __r
             const vtx_locus loc = loci[l0 + l];
             const uint32_t hn = max(loc.ref_len, loc.alt_len) > max_hap ? 0u : (t ? loc.alt_len : loc.ref_len);
             build_twins_wave((uint8_t*)smem + (size_t)t * table_stride, hn, ((s_hibyte >> t) & 1u) != 0, max_hap, n_heads, tid);
+            build_t3_wave((uint8_t*)smem + (size_t)t * table_stride, hn, max_hap, n_heads, tid);
         }
         wave_sync();
         const uint4* src = (const uint4*)smem;
@@ -1951,7 +1971,7 @@ __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __rest
     uint32_t* uq0 = TB_UQ(tb);
     uint32_t* pb = TB_PB(tb);
     const uint32_t hmask = n_heads - 1;
-    const uint32_t zero_words = vtxf::tab_uq_words(max_hap) + 128u + vtxf::TW_BYTES / 4;   // uq[] and, behind it, pb[128] and tw[]
+    const uint32_t zero_words = (table_stride - vtxf::tab_uq_off(max_hap, n_heads)) / 4;   // uq[] and, behind it, pb[128], tw[] and t3[]
     for (uint32_t t = blockIdx.x; t < 2u * n_loci; t += gridDim.x) {
         const vtx_locus loc = loci[l0 + (t >> 1)];
         if (max(loc.ref_len, loc.alt_len) <= min_hap) continue;               // (a locus of the other pass: its table is never read; wave-uniform)
@@ -1960,7 +1980,7 @@ __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __rest
         const int nk = hn >= (uint32_t)KMER ? (int)hn - KMER + 1 : 0;
         wave_sync();                                                          // (the copy of the table before has read everything)
         for (uint32_t i = tid; i < n_heads / 4; i += 64) ((uint2*)head)[i] = make_uint2(0xffffffffu, 0xffffffffu);   // CH_END x 4
-        for (uint32_t i = tid; i < zero_words; i += 64) uq0[i] = 0;
+        for (uint32_t i = tid; i < zero_words; i += 64) uq0[i] = 0;      // (uq[] starts at a multiple of 4 only: no wider stores)
         bool hib = false;
         for (uint32_t y = tid; y < hn; y += 64) {
             const uint64_t w = vtxf::ld8(hy + y);                             // (the arena is padded: bytes beyond the haplotype are never USED)
@@ -1992,23 +2012,65 @@ __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __rest
                 wave_sync();
             }
         }
-        // uniqueness flags (build_tables: a haplotype with a byte >= 0x80 gets none) and the presence bitmap
-        for (int y = tid; y < nk; y += 64) {
-            const uint2 k = ent[y];
-            const uint32_t klo = k.x, khi = k.y & 0xffffu;
-            if (!hib) {
-                uint32_t same = 0;
-                for (uint32_t e = head[kw_hash(klo, khi, hmask)]; e != CH_END; e = ent[e].y >> 16)
-                    same += (ent[e].x == klo && (ent[e].y & 0xffffu) == khi);
-                if (same == 1) {
-                    fb[y + KMER - 1] |= 0x80;                                 // only this lane touches that byte
-                    atomicOr(&uq0[vtxf::UQ_PAD_WORDS + ((uint32_t)y >> 5)], 1u << (y & 31));
+        // uniqueness flags (build_tables: a haplotype with a byte >= 0x80 gets none), the presence bitmap, and (round 6) the three-row
+        // sets and the twin list — the pairs (y, y') of positions with the same k-mer in (y, y') order: rounds of 64 positions, the
+        // twins of a position counted by the walk that decides its uniqueness, a prefix sum per round, the chains ascend (the same
+        // list build_twins_wave leaves behind round 3's kernel)
+        uint8_t* tw = TB_TW(tb);
+        uint32_t* t3 = TB_T3(tb);
+        bool tw_ok = !hib && hn <= 256u;
+        uint32_t tw_total = 0;
+        for (int base = 0; base < nk; base += 64) {
+            const int y = base + tid;
+            uint32_t c = 0, first = CH_END, klo = 0, khi = 0;
+            if (y < nk) {
+                const uint2 k = ent[y];
+                klo = k.x; khi = k.y & 0xffffu;
+                if (!hib) {
+                    uint32_t same = 0;
+                    first = head[kw_hash(klo, khi, hmask)];
+                    for (uint32_t e = first; e != CH_END; e = ent[e].y >> 16)
+                        same += (ent[e].x == klo && (ent[e].y & 0xffffu) == khi);
+                    if (same == 1) {
+                        fb[y + KMER - 1] |= 0x80;                                 // only this lane touches that byte
+                        atomicOr(&uq0[vtxf::UQ_PAD_WORDS + ((uint32_t)y >> 5)], 1u << (y & 31));
+                    }
+                    c = same - 1u;
+                }
+                const uint32_t code = vtxf::kw_code(klo, khi);
+                atomicOr(&pb[code >> 5], 1u << (code & 31u));
+                if constexpr (vtxf::T3_BYTES != 0) {
+                    atomicOr(&t3[vtxf::t3_word_a(code)], 1u << vtxf::t3_bit_a(code));
+                    atomicOr(&t3[vtxf::t3_word_b(code)], 1u << vtxf::t3_bit_b(code));
+                    atomicOr(&t3[vtxf::t3_word_c(code)], 1u << vtxf::t3_bit_c(code));
                 }
             }
-            const uint32_t code = vtxf::kw_code(klo, khi);
-            atomicOr(&pb[code >> 5], 1u << (code & 31u));
+            const uint64_t nz = __ballot(c > 0);
+            if (tw_ok && nz) {                                                    // (wave-uniform)
+                uint32_t off, sum;
+                if (__any(c > 1)) {
+                    uint32_t inc = c;
+#pragma unroll
+                    for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, sft); if (tid >= sft) inc += v; }
+                    off = tw_total + inc - c;
+                    sum = (uint32_t)__shfl((int)inc, 63);
+                } else {
+                    off = tw_total + (uint32_t)__popcll(nz & ((1ull << tid) - 1ull));
+                    sum = (uint32_t)__popcll(nz);
+                }
+                tw_total += sum;
+                if (tw_total > vtxf::TW_MAX) tw_ok = false;
+                else if (c)
+                    for (uint32_t e = first; e != CH_END; e = ent[e].y >> 16)
+                        if (e != (uint32_t)y && ent[e].x == klo && (ent[e].y & 0xffffu) == khi) {
+                            tw[8 + 2 * off] = (uint8_t)y; tw[9 + 2 * off] = (uint8_t)e; ++off;
+                        }
+            }
         }
         wave_sync();
+        if (!tw_ok) for (uint32_t i = tid; i < vtxf::TW_BYTES / 4; i += 64) ((uint32_t*)tw)[i] = 0;
+        wave_sync();
+        if (tid == 0) tw[0] = tw_ok ? (uint8_t)tw_total : (uint8_t)vtxf::TW_NONE;
         // head tags: the first position of a chain writes its bucket's head word (a lane that reads a tagged word compares it
         // with its own position, which is not the chain's first: no match either way)
         for (int y = tid; y < nk; y += 64) {
@@ -2021,14 +2083,24 @@ __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __rest
             }
         }
         wave_sync();
-        build_twins_wave(tb, hn, hib, max_hap, n_heads, tid);
-        wave_sync();
         const uint4* src = (const uint4*)smem;
         uint4* dst = (uint4*)(gtables + (size_t)t * table_stride);
         for (uint32_t i = tid; i < table_stride / 16; i += 64) dst[i] = src[i];
     }
 }
 
+// (developer build, VTX_DIAG_PHASES=1) where a wavefront of band_diag_kernel spends its cycles: s_memtime between the phases, summed
+// over the wavefronts — phase i in g_diag_phase[i], the wavefronts in [15] (vtxk_diag_phases reads and clears them; tools/diag_phases.py)
+// (256 copies, one per workgroup number mod 256: 760 k wavefronts adding to twelve words made the kernel six times slower)
+__device__ unsigned long long g_diag_phase[256][16];
+extern "C" hipError_t vtxk_diag_phases(unsigned long long* out) {
+    static unsigned long long h[256][16];
+    hipError_t e = hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag_phase), sizeof h);
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < 16; ++i) { out[i] = 0; for (int k = 0; k < 256; ++k) out[i] += h[k][i]; }
+    memset(h, 0, sizeof h);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_phase), h, sizeof h);
+}
 #define REFINE_WORDS 12u       // record of band_refine_kernel: task, d, r | cert << 4 | far matches << 16, zc, RM piece words
 extern "C" uint32_t vtxk_band_refine_words(void) { return REFINE_WORDS; }
 // ST: type of an off-diagonal match entry — uint16_t (x << 8 | y: 40 entries per task in the same LDS) when every haplotype of
@@ -2068,6 +2140,15 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     __shared__ uint16_t q_walk_[4][WALK_CAP];
     __shared__ uint32_t q_count_[4][2];
     const int wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
+    const bool ph_on = VTX_DEVTOOLS_ON && (stats & 0x80000u);
+    unsigned long long ph_t = ph_on ? __builtin_readcyclecounter() : 0ull;
+    auto PH = [&](int i) {
+        if (VTX_DEVTOOLS_ON && ph_on) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            if (tid == 0) atomicAdd(&g_diag_phase[blockIdx.x & 255u][i], now - ph_t);
+            ph_t = now;
+        }
+    };
     uint32_t* lane_mem = lane_mem_[wv];
     uint16_t* q_ent = q_ent_[wv];
     uint16_t* q_walk = q_walk_[wv];
@@ -2120,6 +2201,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     if (VTX_ABLATE(stats >> 8) == 4) { if (live && m == 0x7fffffff) counters[40] = 1; return; }           // (profiling aid) task set-up only
     // ---- the read, once: lanes 2i / 2i + 1 hold the two haplotypes of ONE record, so each loads half of its 8-byte words (16-byte
     //      loads) and the two swap halves — a quarter of the load instructions and of the L2 lines 8-byte loads per lane cost ----
+    PH(0);                                                              // task set-up
     vtxf::ReadWords rw;
     {
         constexpr int HW = vtxf::RW / 2;                               // words per lane of a pair (12; 16 with four mask words)
@@ -2150,6 +2232,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         // candidate inside the rounds ran the expensive part up to six times per wavefront for a handful of lanes
         bool have_d = !live;
         int d = 0;
+        PH(1);                                                          // the read's words
 #pragma unroll 1
         for (int round = 0; round < vtxf::N_SAMPLES / 2; ++round) {
             if (!__any(!have_d)) break;
@@ -2162,12 +2245,14 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
                 if (vtxf::verify_diag(x, m, tb, n, dc)) { d = dc; have_d = true; }
             }
         }
+        PH(2);                                                          // the search for the diagonal
         vtxf::M192 M = vtxf::m_zero();
         if (live && have_d) {
             M = vtxf::diag_mask<A>(rw, x, m, tb, n, d);
             if (vtxf::m_pop(M) < 20) have_d = false;
         }
         if (live && !have_d) { live = false; fail = true; why = vtxf::W_NO_DIAG; }
+        PH(3);                                                          // the mask
         if (VTX_ABLATE(stats >> 8) == 3) { if (live && d == 0x7fffffff) counters[40] = 1; return; }       // (profiling aid) up to the diagonal and its mask
         if (live) {
             // (round 6) a haplotype with a twin list (two-byte entries only: positions are bytes there): the matches of the rows whose
@@ -2185,6 +2270,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             if (live && twins) s_cnt[tid] = (uint32_t)vtxf::twin_matches(tb, fr, m, ln);
         }
     }
+    PH(4);                                                              // pieces, chain, certificate, rows, twins
     constexpr uint32_t NO_TAB = 0xffffffffu;
     // (bit 0 — table offsets are multiples of 16: the lane took its twin list, so a row ANOTHER lane asked for may be one whose matches
     //  it holds already; the walks below drop those)
@@ -2200,18 +2286,42 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     // from the odd one — and an entry (pair, row) is probed in BOTH tables: one load of the read's bytes instead of two, half the
     // entries, half the trips of dependent loads below.  (A row one of the two did not ask for has no off-diagonal match in that
     // haplotype — that is why it was not asked for: looking it up finds nothing.)
-    vtxf::M192 nd = live ? fr.need : vtxf::m_zero();
+    // Round 6, blocks of three rows: the rows a task asks for come in runs (the bases that hang over the haplotype's window, the six
+    // rows around an error), and eight read bases hold three consecutive k-mers — the table's t3[] answers "is it in the haplotype" for
+    // all three with one 8-byte load (vtx_fast_core.h).  The rows are cut into blocks that END at rows e = m - K (mod 3) (so no block
+    // reaches beyond the read's last k-mer; the first may start before row 0: those rows are skipped); a queue entry is
+    // pair << 11 | the block's three membership bits << 8 | e, the block ends below half the read go to the even lane, the others to
+    // the odd one.  (libvtx_dev.so, VTX_DIAG_NO_T3=1: a queue entry per row, even rows from the even lane, and pb[] — rounds 3 - 5.)
+    const bool t3_mode = vtxf::T3_BYTES != 0 && (VTX_DEVTOOLS_ON ? !(stats & 0x40000u) : true);
+    vtxf::M192 nrows = live ? fr.need : vtxf::m_zero();             // (t3_mode: the pair's rows, kept for the membership bits)
+    vtxf::M192 nd;
     {
-        const uint64_t par = (tid & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
         auto other = [&](uint64_t v) {
             return (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)v, 1) | ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), 1) << 32);
         };
 #pragma unroll
-        for (int k = 0; k < A; ++k) nd.w[k] = (nd.w[k] | other(nd.w[k])) & par;
+        for (int k = 0; k < A; ++k) nrows.w[k] |= other(nrows.w[k]);
+        if (t3_mode) {
+            const vtxf::M192 s1 = vtxf::m_shl<1>(nrows), s2 = vtxf::m_shl<2>(nrows);
+            const uint32_t t = (uint32_t)(m + 3 * 86 - vtxf::K) % 3u;                       // (m >= 0)
+            const vtxf::M192 half = (tid & 1) ? vtxf::m_range<A>(m >> 1, 64 * A) : vtxf::m_range<A>(0, m >> 1);
+#pragma unroll
+            for (int k = 0; k < vtxf::NW; ++k) {
+                // rows 64 k + b with (64 k + b) % 3 == t: 64 = 1 (mod 3), so b % 3 == (t - k) % 3
+                const uint32_t j = (t + 3u - (uint32_t)(k % 3)) % 3u;
+                const uint64_t pat = j == 0 ? 0x9249249249249249ull : (j == 1 ? 0x2492492492492492ull : 0x4924924924924924ull);
+                nd.w[k] = k < A ? (nrows.w[k] | s1.w[k] | s2.w[k]) & pat & half.w[k] : 0ull;
+            }
+        } else {
+            const uint64_t par = (tid & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+#pragma unroll
+            for (int k = 0; k < vtxf::NW; ++k) nd.w[k] = k < A ? nrows.w[k] & par : 0ull;
+        }
     }
     vtxf::MIter need_it = vtxf::m_iter(nd);
     if (VTX_ABLATE(stats >> 8) == 1) { if (live && fr.cert == 0x7fffffff) counters[40] = 1; return; }      // (profiling aid) front only
     const uint32_t pb_rel = vtxf::tab_pb_off(max_hap, n_heads), head_rel = max_hap * 8u, bytes_rel = vtxf::tab_bytes_off(max_hap, n_heads);
+    const uint32_t t3_rel = vtxf::tab_t3_off(max_hap, n_heads);
     // pass 2 over the first n_walk entries of the walk list (every lane calls it; 0xffff: a slot reserved by a lane that did not fit)
     auto walk_list = [&](uint32_t n_walk) {
         if (VTX_ABLATE(stats >> 8) == 9) return;                                // (profiling aid) pass 1 without the bucket walks
@@ -2280,12 +2390,86 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         if (!__any(cnt > 0)) break;
         if (cnt > 0) {
             const uint32_t base = atomicAdd(&q_count[0], (uint32_t)cnt);
-            for (int t = 0; t < cnt; ++t) q_ent[base + t] = (uint16_t)(((uint32_t)(tid >> 1) << 8) | (uint32_t)vtxf::m_next(need_it));
+            if (t3_mode) {
+                for (int t = 0; t < cnt; ++t) {
+                    const int e = vtxf::m_next(need_it), s0 = e - 2;
+                    // the pair's rows s0 .. e as three bits (rows below 0 are no rows)
+                    const int kk = s0 >> 6, b = s0 & 63;                                      // (s0 < 0: kk = -1)
+                    const uint64_t wl = kk <= 0 ? nrows.w[0] : (kk == 1 ? nrows.w[1] : (A > 3 && kk == 3 ? nrows.w[vtxf::NW - 1] : nrows.w[2]));
+                    const uint64_t wh = kk <= 0 ? nrows.w[1] : (kk == 1 ? nrows.w[2] : (A > 3 && kk == 2 ? nrows.w[vtxf::NW - 1] : 0ull));
+                    const uint32_t m3 = s0 < 0 ? ((uint32_t)nrows.w[0] << (uint32_t)(-s0)) & 7u
+                                               : (uint32_t)((wl >> b) | (b > 61 ? wh << (64 - b) : 0ull)) & 7u;
+                    q_ent[base + t] = (uint16_t)(((uint32_t)(tid >> 1) << 11) | (m3 << 8) | (uint32_t)e);
+                }
+            } else {
+                for (int t = 0; t < cnt; ++t) q_ent[base + t] = (uint16_t)(((uint32_t)(tid >> 1) << 8) | (uint32_t)vtxf::m_next(need_it));
+            }
         }
         wave_sync();
+        PH(5);                                                          // queue fill
         if (VTX_ABLATE(stats >> 8) == 8) continue;                              // (profiling aid) the rounds' queue fill only
         const uint32_t total = q_count[0];
         constexpr int EPL = 4;                                        // queue entries per lane and trip: their loads go out together
+        if (t3_mode) {
+          constexpr int EPL = A > 3 ? 2 : 4;                          // (the four-word build has no registers for four: a spilled dword costs every launch its scratch set-up)
+          for (uint32_t i0 = 0; i0 < total; i0 += 64 * EPL) {
+            uint32_t ent2[EPL], c16[EPL];
+            uint64_t w8[EPL], ea[EPL], eb[EPL];
+            bool on[EPL];
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const uint32_t i = i0 + 64u * u + tid;
+                on[u] = i < total;
+                ent2[u] = q_ent[on[u] ? i : 0];
+                const int s0 = (int)(ent2[u] & 0xffu) - 2;              // the block's first row (below 0: the read's first bytes, shifted)
+                const uint64_t raw8 = vtxf::ld8(read_arena + o_read[(ent2[u] >> 11) * 2u] + (uint32_t)max(s0, 0));
+                w8[u] = s0 < 0 ? raw8 << (8 * -s0) : raw8;
+            }
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                c16[u] = vtxf::kw_code8(w8[u]);
+                const uint32_t ta = o_tab[(ent2[u] >> 11) * 2u], tb_ = o_tab[(ent2[u] >> 11) * 2u + 1u];   // (NO_TAB: a lane without a table)
+                const uint32_t so = t3_rel + 8u * ((c16[u] >> 4) & 0xffu);
+                ea[u] = ta == NO_TAB ? 0ull : vtxf::ld8(gtables + (ta & ~1u) + so);
+                eb[u] = tb_ == NO_TAB ? 0ull : vtxf::ld8(gtables + (tb_ & ~1u) + so);
+            }
+            uint32_t nh = 0, hits[EPL];                                 // hits: bits 0-2 rows of the block in the even lane's haplotype, 3-5 in the odd lane's
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const uint32_t b0 = c16[u] & 15u, b1 = 16u + (((c16[u] >> 2) & 3u) | (((c16[u] >> 12) & 3u) << 2)), b2 = 32u + (c16[u] >> 12);
+                const uint32_t ha = ((uint32_t)(ea[u] >> b0) & 1u) | (((uint32_t)(ea[u] >> b1) & 1u) << 1) | (((uint32_t)(ea[u] >> b2) & 1u) << 2);
+                const uint32_t hb = ((uint32_t)(eb[u] >> b0) & 1u) | (((uint32_t)(eb[u] >> b1) & 1u) << 1) | (((uint32_t)(eb[u] >> b2) & 1u) << 2);
+                const uint32_t m3 = on[u] ? (ent2[u] >> 8) & 7u : 0u;
+                hits[u] = (ha & m3) | ((hb & m3) << 3);
+                nh += (uint32_t)__builtin_popcount(hits[u]);
+            }
+            bool todo = nh > 0;
+            for (;;) {
+                if (todo) {
+                    uint32_t pos = atomicAdd(&q_count[1], nh);
+                    if (pos + nh <= (uint32_t)WALK_CAP) {
+#pragma unroll
+                        for (int u = 0; u < EPL; ++u) {                 // (walk entries name the OWNER lane: pair * 2 + haplotype)
+                            const uint32_t pr9 = (ent2[u] >> 11) << 9, e = ent2[u] & 0xffu;
+#pragma unroll
+                            for (int j = 0; j < 6; ++j)                  // (a row that hit is a row of the block's membership bits: e + j % 3 >= 2)
+                                if ((hits[u] >> j) & 1u) q_walk[pos++] = (uint16_t)(pr9 | (j >= 3 ? 0x100u : 0u) | (e + (uint32_t)(j % 3) - 2u));
+                        }
+                        todo = false;
+                    } else {
+                        for (; pos < (uint32_t)WALK_CAP; ++pos) q_walk[pos] = 0xffffu;
+                    }
+                }
+                wave_sync();
+                const uint32_t wc = q_count[1];
+                if (wc <= (uint32_t)WALK_CAP) break;                   // (everybody fitted)
+                walk_list((uint32_t)WALK_CAP);
+                wave_sync();
+                if (tid == 0) q_count[1] = 0;
+                wave_sync();
+            }
+          }
+        } else
         for (uint32_t i0 = 0; i0 < total; i0 += 64 * EPL) {
             uint32_t ent2[EPL], code[EPL], bits_a[EPL], bits_b[EPL];
             uint64_t w8[EPL];
@@ -2340,9 +2524,12 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
                 wave_sync();
             }
         }
+        PH(6);                                                          // pass 1 (and the walks of a full walk list)
     }
+    PH(5);
     walk_list(q_count[1]);
     wave_sync();
+    PH(7);                                                              // the walks
     if (VTX_ABLATE(stats >> 8) == 2) { if (live && s_cnt[tid] == 0x7fffffff) counters[40] = 1; return; }   // (profiling aid) front + probes
     uint32_t aux = 0xffffffffu;
     bool tight = false;
@@ -2373,8 +2560,10 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         }
     }
     if (live) vtxf::back_sort(ns, ln);
+    PH(8);                                                              // sort
     if (VTX_ABLATE(stats >> 8) == 7) { if (live && ns == 0x7fffffff) counters[40] = 1; return; }            // (profiling aid) ... + the sort
     if (live && !vtxf::back_harmless(fr, ns, ln)) { live = false; fail = true; why = vtxf::W_NOT_HARMLESS; }
+    PH(9);                                                              // harmless tests
     if (live) {
         const vtxf::Lane gl{(uint32_t*)q_ent + tid, 64};                 // (the queue is dead by now)
         const int32_t sc = vtxf::back_rest(fr, ns, ln, gl, &why, (int)VTX_ABLATE(stats >> 8), nullptr, &aux);
@@ -2386,6 +2575,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     // matches far out: vtx_fast_core.h, "the corridor certificate") instead of taking the masked DP; what that kernel does not decide
     // goes on to the tight list.  (stats bit 16 — libvtx_dev.so, VTX_BAND_NO_CORRIDOR=1 — and batches with haplotypes above 255 bases:
     // round 3's records for band_refine_kernel, main pieces only.)
+    PH(10);                                                             // closure, run bound
     const bool corr_mode = tight_list != nullptr && refine_rec != nullptr && !(stats & 0x10000u);
     bool again = corr_mode ? (fail && tight) : (fail && why == vtxf::W_NOT_TIGHT && refine_rec != nullptr && aux != 0xffffffffu);
     const uint64_t am = __ballot(again);
@@ -2444,6 +2634,8 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         if (fail && !again && !tight && !dense) fail_list[base + (uint32_t)__popcll(fm & ((1ull << tid) - 1ull))] = task;
     }
     if (fail && !again && (stats & 0xffu)) atomicAdd(&counters[32 + why], 1u);
+    PH(11);                                                             // lists
+    if (VTX_DEVTOOLS_ON && ph_on && tid == 0) atomicAdd(&g_diag_phase[blockIdx.x & 255u][15], 1ull);
 }
 
 // =============================================================================================
@@ -2667,10 +2859,10 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     // arrays, four workgroups per CU), one-wavefront workgroups with up to 32 tables below 64 tasks per locus.
     const bool want_global = tasks_per_locus < gt_max_tpl() && gtables;
     uint32_t n_heads = pick_heads(tasks_per_locus, want_global);
-    size_t tstride = band_table_stride(max_hap, n_heads);
+    size_t tstride = band_table_stride(max_hap, n_heads, !want_global);
     if (want_global && (size_t)n_loci * 2 * tstride > gtables_bytes) {       // the buffer is too small: tables in LDS
         n_heads = pick_heads(tasks_per_locus, false);
-        tstride = band_table_stride(max_hap, n_heads);
+        tstride = band_table_stride(max_hap, n_heads, true);
     }
     const bool global_tables = want_global && (size_t)n_loci * 2 * tstride <= gtables_bytes;
     const bool wave_wg = global_tables || tasks_per_locus < 64;
@@ -2747,7 +2939,9 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     const uint32_t n_blocks = (n_tasks + 255) / 256;
     const uint32_t st = (uint32_t)stats | (VTX_DEV_ENV("VTX_DIAG_ABLATE") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_DIAG_ABLATE")) << 8 : 0u) |
                         (VTX_DEV_ENV("VTX_BAND_NO_CORRIDOR") ? 0x10000u : 0u) |         // (A/B hook: round 5's records for band_refine_kernel)
-                        (VTX_DEV_ENV("VTX_DIAG_NO_TWINS") ? 0x20000u : 0u);             // (A/B hook: every row that is not intact and unique is probed, the twin lists unused)
+                        (VTX_DEV_ENV("VTX_DIAG_NO_TWINS") ? 0x20000u : 0u) |            // (A/B hook: every row that is not intact and unique is probed, the twin lists unused)
+                        (VTX_DEV_ENV("VTX_DIAG_PHASES") ? 0x80000u : 0u) |
+                        (VTX_DEV_ENV("VTX_DIAG_NO_T3") ? 0x40000u : 0u);                // (A/B hook: a queue entry and a presence-bitmap word per row instead of t3[] and blocks of three rows)
     // two-byte match entries (40 per task) whenever a haplotype position fits a byte; VTX_DIAG_WIDE=1 forces the four-byte variant (tests)
     static const bool force_wide = VTX_DEV_ENV("VTX_DIAG_WIDE") != nullptr;
     static const bool force_four = VTX_DEV_ENV("VTX_DIAG_FOUR_WORDS") != nullptr;      // (tests: the four-word build on short reads)

@@ -128,7 +128,34 @@ VTXF_HD uint32_t tab_pb_off(uint32_t max_hap, uint32_t n_heads) { return tab_uq_
 // intact — on the headline workload 5 of the 28 rows a task probed, and 82 % of the bucket walks, were of this kind.
 constexpr uint32_t TW_MAX = 60, TW_BYTES = 128, TW_NONE = 0xffu;
 VTXF_HD uint32_t tab_tw_off(uint32_t max_hap, uint32_t n_heads) { return tab_pb_off(max_hap, n_heads) + 512u; }
-VTXF_HD uint32_t tab_stride(uint32_t max_hap, uint32_t n_heads) { return (tab_tw_off(max_hap, n_heads) + TW_BYTES + 15u) & ~15u; }
+// t3[256] behind tw[] (round 6), 8 bytes each: the presence of THREE consecutive read k-mers in one load.  Eight read bases
+// b0 .. b7 hold the k-mers of rows r, r + 1, r + 2, which share the four bases b2 .. b5: entry S = their 8-bit code (kw_code's two
+// bits per base) carries three 16-bit sets — bits 0-15: the (b0, b1) in front of S that exist in the haplotype as a k-mer b0 b1 S,
+// bits 16-31: the (b1, b6) around S, bits 32-47: the (b6, b7) behind it.  band_diag_kernel's pooled probes test a block of three rows
+// with one 8-byte load per haplotype instead of one 4-byte load per row (the rows a task probes come in runs: the bases that hang over
+// the haplotype's window, the six rows around an error).  Like pb[], a filter: bytes outside ACGT alias, the walk compares the bytes.
+#ifndef VTXF_T3
+#define VTXF_T3 1          // (0: tables without t3[], a queue entry per row — the A/B build libvtx_not3.so of tools/gpu_campaign.sh variants)
+#endif
+constexpr uint32_t T3_BYTES = VTXF_T3 ? 2048 : 0;
+VTXF_HD uint32_t tab_t3_off(uint32_t max_hap, uint32_t n_heads) { return tab_tw_off(max_hap, n_heads) + TW_BYTES; }
+VTXF_HD uint32_t tab_stride(uint32_t max_hap, uint32_t n_heads) { return (tab_t3_off(max_hap, n_heads) + T3_BYTES + 15u) & ~15u; }
+// (a table in LDS — band_run_kernel without a global table buffer — ends behind pb[]: only band_diag_kernel reads tw[] and t3[])
+VTXF_HD uint32_t tab_stride_lds(uint32_t max_hap, uint32_t n_heads) { return (tab_tw_off(max_hap, n_heads) + 15u) & ~15u; }
+// where k-mer code c (kw_code) sits in t3: word index (entry S, 2 words each: sets 0 | 1 << 16, set 2) and bit, for its three roles
+VTXF_HD uint32_t t3_word_a(uint32_t c) { return 2u * (c >> 4); }
+VTXF_HD uint32_t t3_bit_a(uint32_t c) { return c & 15u; }
+VTXF_HD uint32_t t3_word_b(uint32_t c) { return 2u * ((c >> 2) & 0xffu); }
+VTXF_HD uint32_t t3_bit_b(uint32_t c) { return 16u + ((c & 3u) | ((c >> 10) << 2)); }
+VTXF_HD uint32_t t3_word_c(uint32_t c) { return 2u * (c & 0xffu) + 1u; }
+VTXF_HD uint32_t t3_bit_c(uint32_t c) { return c >> 8; }
+// 16-bit code of eight bases (two bits per byte, like kw_code): base i at bits 2 i
+VTXF_HD uint32_t kw_code8(uint64_t w8) {
+    uint32_t a = ((uint32_t)w8 >> 1) & 0x03030303u, b = ((uint32_t)(w8 >> 32) >> 1) & 0x03030303u;
+    a |= a >> 6; a = (a | (a >> 12)) & 0xffu;
+    b |= b >> 6; b = (b | (b >> 12)) & 0xffu;
+    return a | (b << 8);
+}
 // 12-bit code of a k-mer, two bits per byte ((b >> 1) & 3: A 0, C 1, T 2, G 3; any other byte lands on one of them — equal
 // bytes always give equal codes, which is all a presence filter needs)
 VTXF_HD uint32_t kw_code(uint32_t lo, uint32_t hi) {
@@ -161,6 +188,12 @@ template <int S> VTXF_FN M192 m_shr(M192 a) {      // 0 < S < 64
     M192 r;
     VTXF_UNROLL
     for (int k = 0; k < NW; ++k) r.w[k] = (a.w[k] >> S) | (k + 1 < NW ? a.w[k + 1 < NW ? k + 1 : k] << (64 - S) : 0ull);
+    return r;
+}
+template <int S> VTXF_FN M192 m_shl(M192 a) {      // 0 < S < 64; bits shifted beyond the mask are lost
+    M192 r;
+    VTXF_UNROLL
+    for (int k = 0; k < NW; ++k) r.w[k] = (a.w[k] << S) | (k > 0 ? a.w[k > 0 ? k - 1 : 0] >> (64 - S) : 0ull);
     return r;
 }
 VTXF_FN uint64_t ones_below(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull)); }
