@@ -2166,7 +2166,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     auto my_score = [&]() -> int32_t* { return ((task & 1u) ? alt_score : ref_score) + (task >> 1); };
     vtxf::Front fr;
     fr.why = vtxf::W_SHAPE; fr.d = 0; fr.need = vtxf::m_zero();
-    typedef vtxf::LaneS<ST> LaneT;
+    typedef vtxf::LaneS<ST, vtxf::S_WORDS, (A <= 3)> LaneT;
     const LaneT ln{lane_mem + vtxf::S_WORDS * 64 + tid, 64, (ST*)lane_mem + tid, 64};
     vtxf::Tab tb;
     tb.gt = gtables; tb.ent = tb.head = tb.bytes = tb.uq = tb.pb = 0; tb.hmask = n_heads - 1;
@@ -2196,9 +2196,13 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             tb.pb = tb.ent + vtxf::tab_pb_off(max_hap, n_heads);
             x = read_arena + rec.read_off;
             live = true;
+            // (round 6) a haplotype with a twin list (two-byte entries only: positions are bytes there): the matches of the rows whose
+            // main-diagonal k-mer is intact come from the list, the probes look at the other rows only.  (Asked here: the byte is on
+            // its way while the read's words and the diagonal are.)
+            if constexpr (sizeof(ST) == 2) twins = !(stats & 0x20000u) && vtxf::tab_has_twins(tb);
         }
     }
-    if (VTX_ABLATE(stats >> 8) == 4) { if (live && m == 0x7fffffff) counters[40] = 1; return; }           // (profiling aid) task set-up only
+    if (VTX_ABLATE((stats >> 8) & 0xffu) == 4) { if (live && m == 0x7fffffff) counters[40] = 1; return; }           // (profiling aid) task set-up only
     // ---- the read, once: lanes 2i / 2i + 1 hold the two haplotypes of ONE record, so each loads half of its 8-byte words (16-byte
     //      loads) and the two swap halves — a quarter of the load instructions and of the L2 lines 8-byte loads per lane cost ----
     PH(0);                                                              // task set-up
@@ -2233,6 +2237,8 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         bool have_d = !live;
         int d = 0;
         PH(1);                                                          // the read's words
+        // (two sample rows per lane and trip — the loads of the two lookups going out together — was measured: 11.9 k -> 13.7 k cycles
+        //  of a wavefront's 131 k in this phase; not kept)
 #pragma unroll 1
         for (int round = 0; round < vtxf::N_SAMPLES / 2; ++round) {
             if (!__any(!have_d)) break;
@@ -2253,21 +2259,19 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         }
         if (live && !have_d) { live = false; fail = true; why = vtxf::W_NO_DIAG; }
         PH(3);                                                          // the mask
-        if (VTX_ABLATE(stats >> 8) == 3) { if (live && d == 0x7fffffff) counters[40] = 1; return; }       // (profiling aid) up to the diagonal and its mask
+        if (VTX_ABLATE((stats >> 8) & 0xffu) == 3) { if (live && d == 0x7fffffff) counters[40] = 1; return; }       // (profiling aid) up to the diagonal and its mask
         if (live) {
-            // (round 6) a haplotype with a twin list (two-byte entries only: positions are bytes there): the matches of the rows whose
-            // main-diagonal k-mer is intact come from the list, the probes below look at the other rows only
-            if constexpr (sizeof(ST) == 2) twins = !(stats & 0x20000u) && vtxf::tab_has_twins(tb);
             fr = vtxf::front_rest<LaneT, A>(x, m, tb, n, ln, d, M, twins);
             if (fr.why != vtxf::W_OK) { live = false; fail = true; why = fr.why; }
-            else if (VTX_ABLATE(stats >> 8) != 10 && vtxf::whole_read(fr, m)) {      // (developer build, VTX_DIAG_ABLATE=10: the shortcut off — the A/B switch of include/vtx_band_semantics.h's fifth item; results stay right)
+            else if (VTX_ABLATE((stats >> 8) & 0xffu) != 10 && vtxf::whole_read(fr, m)) {      // (developer build, VTX_DIAG_ABLATE=10: the shortcut off — the A/B switch of include/vtx_band_semantics.h's fifth item; results stay right)
                 // the read matches base for base: full <= m = cert, and the reference's chain is a perfect diagonal whatever else
                 // matches (vtx_fast_core.h: whole_read) — decided here, before any probe: a fifth of the tasks of a clean workload
                 *my_score() = m;
                 if (stage) stage[task] = 1;
                 live = false; whole = true;
             }
-            if (live && twins) s_cnt[tid] = (uint32_t)vtxf::twin_matches(tb, fr, m, ln);
+            // (the upper half: how many of the lane's matches are the list's — in order already, the sort starts behind them)
+            if (live && twins) s_cnt[tid] = (uint32_t)vtxf::twin_matches(tb, fr, m, ln) * 0x10001u;
         }
     }
     PH(4);                                                              // pieces, chain, certificate, rows, twins
@@ -2319,12 +2323,12 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         }
     }
     vtxf::MIter need_it = vtxf::m_iter(nd);
-    if (VTX_ABLATE(stats >> 8) == 1) { if (live && fr.cert == 0x7fffffff) counters[40] = 1; return; }      // (profiling aid) front only
+    if (VTX_ABLATE((stats >> 8) & 0xffu) == 1) { if (live && fr.cert == 0x7fffffff) counters[40] = 1; return; }      // (profiling aid) front only
     const uint32_t pb_rel = vtxf::tab_pb_off(max_hap, n_heads), head_rel = max_hap * 8u, bytes_rel = vtxf::tab_bytes_off(max_hap, n_heads);
     const uint32_t t3_rel = vtxf::tab_t3_off(max_hap, n_heads);
     // pass 2 over the first n_walk entries of the walk list (every lane calls it; 0xffff: a slot reserved by a lane that did not fit)
     auto walk_list = [&](uint32_t n_walk) {
-        if (VTX_ABLATE(stats >> 8) == 9) return;                                // (profiling aid) pass 1 without the bucket walks
+        if (VTX_ABLATE((stats >> 8) & 0xffu) == 9) return;                                // (profiling aid) pass 1 without the bucket walks
         // two entries per lane and trip: a walk is three DEPENDENT loads (the read's bytes, the head word of their bucket, the
         // chain's first entry) — the two entries' loads go out together, level by level
         constexpr int WPL = 2;
@@ -2372,7 +2376,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
                 uint64_t e = e0[u];
                 for (;;) {
                     if ((uint32_t)e == lo && ((uint32_t)(e >> 32) & 0xffffu) == hi && (int)yc - (int)row[u] != od[u]) {
-                        const uint32_t pos = atomicAdd(&s_cnt[own[u]], 1u);
+                        const uint32_t pos = atomicAdd(&s_cnt[own[u]], 1u) & 0xffffu;
                         if (pos < (uint32_t)LaneT::SMAX) ((ST*)lane_mem)[pos * 64 + own[u]] = (ST)((row[u] << LaneT::XS) | yc);
                     }
                     yc = (uint32_t)(e >> 48);
@@ -2407,7 +2411,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         }
         wave_sync();
         PH(5);                                                          // queue fill
-        if (VTX_ABLATE(stats >> 8) == 8) continue;                              // (profiling aid) the rounds' queue fill only
+        if (VTX_ABLATE((stats >> 8) & 0xffu) == 8) continue;                              // (profiling aid) the rounds' queue fill only
         const uint32_t total = q_count[0];
         constexpr int EPL = 4;                                        // queue entries per lane and trip: their loads go out together
         if (t3_mode) {
@@ -2530,13 +2534,13 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     walk_list(q_count[1]);
     wave_sync();
     PH(7);                                                              // the walks
-    if (VTX_ABLATE(stats >> 8) == 2) { if (live && s_cnt[tid] == 0x7fffffff) counters[40] = 1; return; }   // (profiling aid) front + probes
+    if (VTX_ABLATE((stats >> 8) & 0xffu) == 2) { if (live && s_cnt[tid] == 0x7fffffffu) counters[40] = 1; return; }   // (profiling aid) front + probes
     uint32_t aux = 0xffffffffu;
     bool tight = false;
     // ---- the last phase, every lane for itself: sort, harmless tests, closure, run bound (vtx_fast_core.h).  (Pooling the harmless
     //      tests over the wavefront like the probes — one queue entry per match, A | T << 8 left in the entry, a short recurrence per
     //      owner — was built and measured: 1.67 ms pooled against 1.7 ms per lane, 18.24 against 18.33 ms per step: not kept.) ----
-    const int ns = (int)min(s_cnt[tid], (uint32_t)LaneT::SMAX + 1u);
+    const int ns = (int)min(s_cnt[tid] & 0xffffu, (uint32_t)LaneT::SMAX + 1u);
     bool spread = false;
     if (live && ns > LaneT::SMAX) {
         live = false; fail = true; why = vtxf::W_MATCHES;
@@ -2559,14 +2563,14 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             spread = mode <= 3;
         }
     }
-    if (live) vtxf::back_sort(ns, ln);
+    if (live) vtxf::back_sort(ns, ln, (int)(s_cnt[tid] >> 16));
     PH(8);                                                              // sort
-    if (VTX_ABLATE(stats >> 8) == 7) { if (live && ns == 0x7fffffff) counters[40] = 1; return; }            // (profiling aid) ... + the sort
+    if (VTX_ABLATE((stats >> 8) & 0xffu) == 7) { if (live && ns == 0x7fffffff) counters[40] = 1; return; }            // (profiling aid) ... + the sort
     if (live && !vtxf::back_harmless(fr, ns, ln)) { live = false; fail = true; why = vtxf::W_NOT_HARMLESS; }
     PH(9);                                                              // harmless tests
     if (live) {
         const vtxf::Lane gl{(uint32_t*)q_ent + tid, 64};                 // (the queue is dead by now)
-        const int32_t sc = vtxf::back_rest(fr, ns, ln, gl, &why, (int)VTX_ABLATE(stats >> 8), nullptr, &aux);
+        const int32_t sc = vtxf::back_rest(fr, ns, ln, gl, &why, (int)VTX_ABLATE((stats >> 8) & 0xffu), nullptr, &aux);
         if (sc >= 0) { *my_score() = sc; if (stage) stage[task] = 1; }
         else { fail = true; tight = tight_list != nullptr; }
     }

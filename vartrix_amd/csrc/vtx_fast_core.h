@@ -352,8 +352,11 @@ struct Lane {
     uint32_t* base; int stride;
     VTXF_MEM uint32_t& at(int i) const { return base[i * stride]; }
 };
-template <class ST, int SW = S_WORDS> struct LaneS {
+// (UB4: back_rest runs the main-only run bound on piece words held in registers — not in band_diag_kernel's four-word build, which
+//  has no register to spare: a spilled dword costs every launch its scratch set-up)
+template <class ST, int SW = S_WORDS, bool UB4_ = true> struct LaneS {
     typedef ST SType;
+    static constexpr bool UB4 = UB4_;
     uint32_t* base; int stride;
     ST* sb; int sstride;
     static constexpr int XS = sizeof(ST) == 2 ? 8 : 16;
@@ -381,6 +384,7 @@ template <int W> struct LaneS2T {
     static constexpr int SMAX = W * 2;
     static constexpr uint32_t YM = 0xffu, ONE = 0x101u;
     static constexpr bool TIGHT = true;
+    static constexpr bool UB4 = true;
     VTXF_MEM uint32_t& at(int i) const { return base[i * stride]; }
     VTXF_MEM uint16_t& s(int k) const { return sb[k * sstride]; }
     VTXF_MEM uint8_t& u(int k) const { return ub[k * ustride]; }
@@ -484,16 +488,16 @@ VTXF_FN int sample_row(int t, int m) {
     if (t < 6) return imin((int)((0x504132u >> (4 * t)) & 0xfu) * imax(1, last / 5), last);
     return imin((int)((0x619375u >> (4 * (t - 6))) & 0xfu) * last / 10 + (t == 11 ? 3 : 0), last);      // tenths 5, 7, 3, 9, 1, and 6 (+ 3 rows)
 }
-// candidate diagonal from one row: its k-mer sits alone in its bucket and matches it (then the haplotype holds it exactly once)
+// candidate diagonal from one row: its k-mer's bucket holds ONE k-mer with its four tag bits — most likely the k-mer itself, and then
+// the haplotype holds it exactly once.  (Until round 6 the bucket's entry was loaded and compared: one more dependent load per
+// round of the search.  A candidate is only ever a candidate — verify_diag looks at eight bases of its diagonal, the mask must hold
+// twenty matching ones — so a bucket whose k-mer merely shares the tag costs a wasted check, nothing else.)
 VTXF_FN int cand_diag(const uint8_t* x, int row, const Tab& tb) {
     const uint64_t w8 = ld8(x + row);
     const uint32_t hh = kw_mix((uint32_t)w8, (uint32_t)(w8 >> 32) & 0xffffu);
     const uint32_t raw = ld2(tb.gt + tb.head + 2u * kw_bucket(hh, tb.hmask));
     if (raw == HEAD_END || (raw >> 12) != kw_tag(hh)) return NO_DIAG;
-    const uint32_t yc = raw & 0xfffu;
-    const uint64_t e = ld8(tb.gt + tb.ent + 8u * yc);
-    if ((uint32_t)e != (uint32_t)w8 || ((uint32_t)(e >> 32) & 0xffffu) != ((uint32_t)(w8 >> 32) & 0xffffu)) return NO_DIAG;
-    return (int)yc - row;
+    return (int)(raw & 0xfffu) - row;
 }
 // cheap check of a candidate diagonal before its whole mask is computed: 8 bases in the middle of the overlap, at least 6 of
 // them equal (a chance k-mer match elsewhere in the haplotype passes with probability ~1e-3)
@@ -625,10 +629,8 @@ template <class LN, int A> VTXF_FN Front front_rest(const uint8_t* x, int m, con
 VTXF_FN bool tab_has_twins(const Tab& tb) { return tb.gt[tb.pb + 512u] != TW_NONE; }
 template <class LN> VTXF_FN int twin_matches(const Tab& tb, const Front& fr, int m, const LN& ln) {
     const uint8_t* tw = tb.gt + tb.pb + 512u;
-    const int cnt = (int)tw[0];
     int ns = 0;
-    for (int i0 = 0; i0 < cnt; i0 += 4) {
-        const uint64_t w = ld8(tw + 8 + 2 * i0);
+    auto four = [&](uint64_t w, int i0, int cnt) {                            // pairs i0 .. i0 + 3 of the list
 VTXF_UNROLL
         for (int j = 0; j < 4; ++j) {
             const int y = (int)((w >> (16 * j)) & 0xffu), y2 = (int)((w >> (16 * j + 8)) & 0xffu);
@@ -639,7 +641,16 @@ VTXF_UNROLL
             if (ns < LN::SMAX) ln.s(ns) = (typename LN::SType)(((uint32_t)row << LN::XS) | (uint32_t)y2);
             ++ns;
         }
-    }
+    };
+    // the length and the first twelve pairs in two loads that go out together (the usual haplotype has about ten pairs)
+    W16 h0, h1;
+    __builtin_memcpy(&h0, tw, 16);
+    __builtin_memcpy(&h1, tw + 16, 16);
+    const int cnt = (int)(h0.a & 0xffu);
+    four(h0.b, 0, cnt);
+    four(h1.a, 4, cnt);
+    four(h1.b, 8, cnt);
+    for (int i0 = 12; i0 < cnt; i0 += 4) four(ld8(tw + 8 + 2 * i0), i0, cnt);
     return ns;
 }
 
@@ -711,6 +722,29 @@ template <class PL> VTXF_FN int main_pieces_ub(const PL& pl, int r, uint32_t zc,
     }
     return ub;
 }
+// the same for up to four pieces held in registers, without the refinement (band_diag_kernel's usual task: no LDS round trips)
+VTXF_FN int main_pieces_ub4(uint32_t (&pw4)[4], int r, uint32_t zc) {
+    int ub = 0;
+    VTXF_UNROLL
+    for (int p = 0; p < 4; ++p) {
+        if (p >= r) continue;
+        const uint32_t wp = pw4[p];
+        const int xp = (int)(wp & 0xffu), lp = (int)((wp >> 8) & 0xffu) - xp + 1;
+        int g = 0, e = 0;
+        VTXF_UNROLL
+        for (int q = p - 1; q >= 0; --q) {
+            const uint32_t wq = pw4[q];
+            const int xq = (int)(wq & 0xffu), lq = (int)((wq >> 8) & 0xffu) - xq + 1, gq = (int)(wq >> 24);
+            const int D = xp - (xq + lq);
+            e += (int)((zc >> (4 * (q + 1))) & 15u);
+            const int J = D == 0 ? 0 : join_same(D, e);
+            g = imax(g, lq + gq - J);
+        }
+        pw4[p] = (wp & 0x00ffffffu) | ((uint32_t)g << 24);
+        ub = imax(ub, lp + g);
+    }
+    return ub;
+}
 // aux (optional): when the verdict is W_NOT_TIGHT with main pieces only, the number of far matches (the refinement needs nothing
 // else of the off-diagonal matches); 0xffffffff otherwise
 // ---- the harmless test in two parts, so that the device can pool the first over a wavefront (band_diag_kernel) ----
@@ -737,14 +771,35 @@ template <class PL> VTXF_FN uint32_t harmless_item(const PL& pl, int r, int d, i
     const int T = imin(imax(imin(best_dp, minH - q - 2 * K - 1), 0), 255);
     return (uint32_t)A | ((uint32_t)T << 8);
 }
+// the same against up to four main pieces held in registers (a piece word of 0 is no piece: it ends before it starts) — the usual task
+// has one to three, and the per-match loop over the lane's LDS words was a chain of dependent round trips
+VTXF_FN uint32_t harmless_item4(const uint32_t (&pw4)[4], int d, int best_dp, int sx, int sy) {
+    const int q = sx + sy - d;
+    const int lim = imin(sx, sy - d) - K;
+    int bv = -1000000, minH = 1000000;
+    VTXF_UNROLL
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t pw = pw4[i];
+        const int pu = (int)(pw & 0xffu), pv = (int)((pw >> 8) & 0xffu), dpf = (int)((pw >> 16) & 0xffu);
+        const int lm1 = pv - 5 - pu;
+        const int t = imin(lim - pu, lm1);
+        if (t >= 0) bv = imax(bv, dpf + t + 2 * (pu + t + K));
+        const int t0 = imax(0, imax(sx + K - pu, sy + K - d - pu));
+        if (t0 <= lm1) minH = imin(minH, dpf + 3 * t0 + 2 * pu);
+    }
+    const int A = bv > -1000000 ? imin(imax(bv - q + 1, 0), 255) : 0;
+    const int T = imin(imax(imin(best_dp, minH - q - 2 * K - 1), 0), 255);
+    return (uint32_t)A | ((uint32_t)T << 8);
+}
 VTXF_FN bool harmless_step(uint32_t at, int& runmax) {
     const int dp = imax(imax(K, runmax + 1), (int)(at & 0xffu));
     runmax = imax(runmax, dp);
     return dp < (int)(at >> 8);
 }
 // (x, y) order of the off-diagonal matches (a lane probing its own rows produces it; pooled probes arrive in any order)
-template <class LN> VTXF_FN void back_sort(int ns, const LN& ln) {
-    for (int k = 1; k < ns; ++k) {
+// (first: the leading entries that are in order already — the twin list's, which twin_matches appends in (x, y) order)
+template <class LN> VTXF_FN void back_sort(int ns, const LN& ln, int first = 0) {
+    for (int k = imax(first, 1); k < ns; ++k) {
         const uint32_t v = ln.s(k);
         int j = k - 1;
         while (j >= 0 && ln.s(j) > v) { ln.s(j + 1) = ln.s(j); --j; }
@@ -778,6 +833,23 @@ template <class LN> VTXF_FN bool back_harmless(const Front& fr, int ns, const LN
         return true;
     } else {
         int runmax = 0;
+        if (fr.r <= 4) {
+            uint32_t pw4[4];
+            VTXF_UNROLL
+            for (int i = 0; i < 4; ++i) pw4[i] = i < fr.r ? (ln.at(i) & 0x00ffffffu) : 0u;
+            // four matches per trip: their words are loaded together, the items are independent, only the steps are a chain
+            for (int k0 = 0; k0 < ns; k0 += 4) {
+                uint32_t w4[4], at[4];
+                VTXF_UNROLL
+                for (int j = 0; j < 4; ++j) w4[j] = ln.s(imin(k0 + j, ns - 1));
+                VTXF_UNROLL
+                for (int j = 0; j < 4; ++j) at[j] = harmless_item4(pw4, fr.d, fr.best_dp, (int)(w4[j] >> LN::XS), (int)(w4[j] & LN::YM));
+                VTXF_UNROLL
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + j < ns && !harmless_step(at[j], runmax)) return false;
+            }
+            return true;
+        }
         for (int k = 0; k < ns; ++k) {
             const uint32_t w = ln.s(k);
             if (!harmless_step(harmless_item(ln, fr.r, fr.d, fr.best_dp, (int)(w >> LN::XS), (int)(w & LN::YM)), runmax)) return false;
@@ -818,15 +890,22 @@ template <class LN> VTXF_FN int32_t back_rest(const Front& fr, int ns, const LN&
             // cumulative counters, one byte each: D <= 5, 7, 11, 15, 23, 31, 39 (a match at D >= 40 > ns can never be in the way)
             uint64_t cum = 0;
             int near_k = -1, near_d = 1 << 20;
-            for (int k = 0; k < nc; ++k) {
-                if ((used >> k) & 1ull) continue;
-                const uint32_t w = ln.s(k);
-                const int delta = (int)(w & YM) - (int)(w >> XS) - d;
-                const int D = delta > hull_hi ? delta - hull_hi : (delta < hull_lo ? hull_lo - delta : 0);
-                if (D < near_d) { near_d = D; near_k = k; }
-                if (D < 40) {
-                    const int bin = (D >= 6) + (D >= 8) + (D >= 12) + (D >= 16) + (D >= 24) + (D >= 32);
-                    cum += 0x0001010101010101ull << (8 * bin);
+            for (int k0 = 0; k0 < nc; k0 += 4) {               // (four words per trip, loaded together)
+                uint32_t w4[4];
+                VTXF_UNROLL
+                for (int j = 0; j < 4; ++j) w4[j] = ln.s(imin(k0 + j, nc - 1));
+                VTXF_UNROLL
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + j;
+                    if (k >= nc || ((used >> k) & 1ull)) continue;
+                    const uint32_t w = w4[j];
+                    const int delta = (int)(w & YM) - (int)(w >> XS) - d;
+                    const int D = delta > hull_hi ? delta - hull_hi : (delta < hull_lo ? hull_lo - delta : 0);
+                    if (D < near_d) { near_d = D; near_k = k; }
+                    if (D < 40) {
+                        const int bin = (D >= 6) + (D >= 8) + (D >= 12) + (D >= 16) + (D >= 24) + (D >= 32);
+                        cum += 0x0001010101010101ull << (8 * bin);
+                    }
                 }
             }
             if (near_k < 0) break;                                        // nothing is far
@@ -877,7 +956,16 @@ template <class LN> VTXF_FN int32_t back_rest(const Front& fr, int ns, const LN&
         for (int i = 0; i < n_all; ++i) word(i) &= 0x00ffffffu;
         bool changed = n_all > 1;
         if (ng == 0) {
-            ub = imax(ub, main_pieces_ub(ln, r, fr.zc, d, rf, far_e));
+            if (LN::UB4 && r <= 4 && !rf) {
+                uint32_t pw4[4];
+                VTXF_UNROLL
+                for (int i = 0; i < 4; ++i) pw4[i] = i < r ? ln.at(i) : 0u;
+                ub = imax(ub, main_pieces_ub4(pw4, r, fr.zc));
+                VTXF_UNROLL
+                for (int i = 0; i < 4; ++i) if (i < r) ln.at(i) = pw4[i];
+            } else {
+                ub = imax(ub, main_pieces_ub(ln, r, fr.zc, d, rf, far_e));
+            }
             changed = false;
         }
         uint64_t zpre = 0;                                  // byte i: mismatching bases between main pieces 0 and i
@@ -893,9 +981,15 @@ template <class LN> VTXF_FN int32_t back_rest(const Front& fr, int ns, const LN&
                 decode(p, wp, xp, yp, lp);
                 const int g0 = (int)(wp >> 24);
                 int g = g0;
-                for (int q = 0; q < n_all; ++q) {
-                    if (q == p) continue;
-                    const uint32_t wq = word(q);
+                for (int q0 = 0; q0 < n_all; q0 += 4) {          // (four piece words per trip, loaded together: an LDS round trip per PAIR was most of this loop)
+                  uint32_t wq4[4];
+                  VTXF_UNROLL
+                  for (int j = 0; j < 4; ++j) wq4[j] = word(imin(q0 + j, n_all - 1));
+                  VTXF_UNROLL
+                  for (int j = 0; j < 4; ++j) {
+                    const int q = q0 + j;
+                    if (q >= n_all || q == p) continue;
+                    const uint32_t wq = wq4[j];
                     int xq, yq, lq;
                     decode(q, wq, xq, yq, lq);
                     const int gq = (int)(wq >> 24);
@@ -911,6 +1005,7 @@ template <class LN> VTXF_FN int32_t back_rest(const Front& fr, int ns, const LN&
                         J = D == 0 ? 0 : (p < r && q < r ? join_same(D, (int)((zpre >> (8 * p)) & 0xffu) - (int)((zpre >> (8 * q)) & 0xffu)) : join_free(D));
                     }
                     g = imax(g, t + 1 + gq - J - s);
+                  }
                 }
                 if (g != g0) { word(p) = (wp & 0x00ffffffu) | ((uint32_t)g << 24); changed = true; }
             }
