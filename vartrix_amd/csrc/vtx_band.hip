@@ -2294,8 +2294,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     // rows around an error), and eight read bases hold three consecutive k-mers — the table's t3[] answers "is it in the haplotype" for
     // all three with one 8-byte load (vtx_fast_core.h).  The rows are cut into blocks that END at rows e = m - K (mod 3) (so no block
     // reaches beyond the read's last k-mer; the first may start before row 0: those rows are skipped); a queue entry is
-    // pair << 11 | the block's three membership bits << 8 | e, the block ends below half the read go to the even lane, the others to
-    // the odd one.  (libvtx_dev.so, VTX_DIAG_NO_T3=1: a queue entry per row, even rows from the even lane, and pb[] — rounds 3 - 5.)
+    // pair << 11 | the block's three membership bits << 8 | e, the blocks go to the pair's two lanes in turn.  (libvtx_dev.so, VTX_DIAG_NO_T3=1: a queue entry per row, even rows from the even lane, and pb[] — rounds 3 - 5.)
     const bool t3_mode = vtxf::T3_BYTES != 0 && (VTX_DEVTOOLS_ON ? !(stats & 0x40000u) : true);
     vtxf::M192 nrows = live ? fr.need : vtxf::m_zero();             // (t3_mode: the pair's rows, kept for the membership bits)
     vtxf::M192 nd;
@@ -2307,14 +2306,16 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         for (int k = 0; k < A; ++k) nrows.w[k] |= other(nrows.w[k]);
         if (t3_mode) {
             const vtxf::M192 s1 = vtxf::m_shl<1>(nrows), s2 = vtxf::m_shl<2>(nrows);
-            const uint32_t t = (uint32_t)(m + 3 * 86 - vtxf::K) % 3u;                       // (m >= 0)
-            const vtxf::M192 half = (tid & 1) ? vtxf::m_range<A>(m >> 1, 64 * A) : vtxf::m_range<A>(0, m >> 1);
+            // the blocks alternate between the pair's lanes (a read hangs over the window on ONE side as a rule: the halves of the read
+            // gave one lane all of that run, and a second round of the queue for it alone): block ends e = t (mod 6) to the even lane,
+            // e = t + 3 (mod 6) to the odd one, t = m - K
+            const uint32_t t = ((uint32_t)(m + 6 * 43 - vtxf::K) + ((tid & 1) ? 3u : 0u)) % 6u;       // (m >= 0)
 #pragma unroll
             for (int k = 0; k < vtxf::NW; ++k) {
-                // rows 64 k + b with (64 k + b) % 3 == t: 64 = 1 (mod 3), so b % 3 == (t - k) % 3
-                const uint32_t j = (t + 3u - (uint32_t)(k % 3)) % 3u;
-                const uint64_t pat = j == 0 ? 0x9249249249249249ull : (j == 1 ? 0x2492492492492492ull : 0x4924924924924924ull);
-                nd.w[k] = k < A ? (nrows.w[k] | s1.w[k] | s2.w[k]) & pat & half.w[k] : 0ull;
+                // rows 64 k + b with (64 k + b) % 6 == t: 64 = 4 (mod 6), so b % 6 == (t - 4 k) % 6
+                const uint32_t j = (t + 24u - 4u * (uint32_t)k) % 6u;
+                const uint64_t pat = 0x1041041041041041ull << j;
+                nd.w[k] = k < A ? (nrows.w[k] | s1.w[k] | s2.w[k]) & pat : 0ull;
             }
         } else {
             const uint64_t par = (tid & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
