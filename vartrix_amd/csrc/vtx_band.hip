@@ -2012,6 +2012,8 @@ __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __rest
                 wave_sync();
             }
         }
+        // (t3[] built on its own in the LDS the entries take afterwards and copied out first — 2 KB less LDS per wavefront, 30 tables in
+        //  flight per CU instead of 22 — was measured: 0.68 against 0.69 ms.  The kernel's time is the bytes it writes now: 1.44 GB.)
         // uniqueness flags (build_tables: a haplotype with a byte >= 0x80 gets none), the presence bitmap, and (round 6) the three-row
         // sets and the twin list — the pairs (y, y') of positions with the same k-mer in (y, y') order: rounds of 64 positions, the
         // twins of a position counted by the walk that decides its uniqueness, a prefix sum per round, the chains ascend (the same
@@ -2261,6 +2263,8 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         PH(3);                                                          // the mask
         if (VTX_ABLATE((stats >> 8) & 0xffu) == 3) { if (live && d == 0x7fffffff) counters[40] = 1; return; }       // (profiling aid) up to the diagonal and its mask
         if (live) {
+            vtxf::TwinHead th;
+            if (twins) th = vtxf::twin_head(tb);
             fr = vtxf::front_rest<LaneT, A>(x, m, tb, n, ln, d, M, twins);
             if (fr.why != vtxf::W_OK) { live = false; fail = true; why = fr.why; }
             else if (VTX_ABLATE((stats >> 8) & 0xffu) != 10 && vtxf::whole_read(fr, m)) {      // (developer build, VTX_DIAG_ABLATE=10: the shortcut off — the A/B switch of include/vtx_band_semantics.h's fifth item; results stay right)
@@ -2271,7 +2275,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
                 live = false; whole = true;
             }
             // (the upper half: how many of the lane's matches are the list's — in order already, the sort starts behind them)
-            if (live && twins) s_cnt[tid] = (uint32_t)vtxf::twin_matches(tb, fr, m, ln) * 0x10001u;
+            if (live && twins) s_cnt[tid] = (uint32_t)vtxf::twin_matches(tb, fr, m, ln, th) * 0x10001u;
         }
     }
     PH(4);                                                              // pieces, chain, certificate, rows, twins
@@ -2416,7 +2420,7 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
         const uint32_t total = q_count[0];
         constexpr int EPL = 4;                                        // queue entries per lane and trip: their loads go out together
         if (t3_mode) {
-          constexpr int EPL = A > 3 ? 2 : 4;                          // (the four-word build has no registers for four: a spilled dword costs every launch its scratch set-up)
+          constexpr int EPL = A > 3 ? 2 : 6;                          // (the four-word build has no registers for four: a spilled dword costs every launch its scratch set-up)
           for (uint32_t i0 = 0; i0 < total; i0 += 64 * EPL) {
             uint32_t ent2[EPL], c16[EPL];
             uint64_t w8[EPL], ea[EPL], eb[EPL];

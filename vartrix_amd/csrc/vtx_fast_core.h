@@ -627,7 +627,16 @@ template <class LN, int A> VTXF_FN Front front_rest(const uint8_t* x, int m, con
 //      to ln[0 ..) in (x, y) order (the list's own); returns their number (entries beyond the lane's capacity are counted, not stored).
 //      Precondition: the list exists (tw[0] != TW_NONE). ----
 VTXF_FN bool tab_has_twins(const Tab& tb) { return tb.gt[tb.pb + 512u] != TW_NONE; }
-template <class LN> VTXF_FN int twin_matches(const Tab& tb, const Front& fr, int m, const LN& ln) {
+// (the list's first 32 bytes — its length and twelve pairs: band_diag_kernel asks for them before front_rest, they arrive under it)
+struct TwinHead { W16 h0, h1; };
+VTXF_FN TwinHead twin_head(const Tab& tb) {
+    TwinHead t;
+    const uint8_t* tw = tb.gt + tb.pb + 512u;
+    __builtin_memcpy(&t.h0, tw, 16);
+    __builtin_memcpy(&t.h1, tw + 16, 16);
+    return t;
+}
+template <class LN> VTXF_FN int twin_matches(const Tab& tb, const Front& fr, int m, const LN& ln, const TwinHead& th) {
     const uint8_t* tw = tb.gt + tb.pb + 512u;
     int ns = 0;
     auto four = [&](uint64_t w, int i0, int cnt) {                            // pairs i0 .. i0 + 3 of the list
@@ -642,17 +651,15 @@ VTXF_UNROLL
             ++ns;
         }
     };
-    // the length and the first twelve pairs in two loads that go out together (the usual haplotype has about ten pairs)
-    W16 h0, h1;
-    __builtin_memcpy(&h0, tw, 16);
-    __builtin_memcpy(&h1, tw + 16, 16);
-    const int cnt = (int)(h0.a & 0xffu);
-    four(h0.b, 0, cnt);
-    four(h1.a, 4, cnt);
-    four(h1.b, 8, cnt);
+    // (the usual haplotype has about ten pairs)
+    const int cnt = (int)(th.h0.a & 0xffu);
+    four(th.h0.b, 0, cnt);
+    four(th.h1.a, 4, cnt);
+    four(th.h1.b, 8, cnt);
     for (int i0 = 12; i0 < cnt; i0 += 4) four(ld8(tw + 8 + 2 * i0), i0, cnt);
     return ns;
 }
+template <class LN> VTXF_FN int twin_matches(const Tab& tb, const Front& fr, int m, const LN& ln) { return twin_matches(tb, fr, m, ln, twin_head(tb)); }
 
 // ---- phase 2, one lane on its own: the rows of fr.need four at a time (their loads go out together); a row whose k-mer is not
 //      in the haplotype's presence bitmap is done after one word.  Returns the number of off-diagonal matches appended to
