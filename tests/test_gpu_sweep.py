@@ -209,7 +209,7 @@ np.save(sys.argv[1], np.concatenate(out))
 
 
 @pytest.mark.parametrize("hook", ["VTX_BAND_LEGACY", "VTX_BAND_CHECK", "VTX_BAND_NO_TIGHT", "VTX_BAND_SLOTS", "VTX_SWEEP_V1", "VTX_BAND_DIAG2_MIN",
-                                  "VTX_BAND_NO_CORRIDOR", "VTX_DIAG_FOUR_WORDS", "VTX_DIAG_NO_TWINS", "VTX_DIAG_NO_T3"])
+                                  "VTX_BAND_NO_CORRIDOR", "VTX_DIAG_FOUR_WORDS", "VTX_DIAG_NO_TWINS", "VTX_DIAG_T3", "VTX_DIAG_NO_T3"])
 def test_hooks_give_the_same_scores(hook):
     """VTX_BAND_DIAG2_MIN=1: the second single-diagonal stage (band_diag2_kernel) on every list, however short — by default lists
     below 700 k tasks skip it, i.e. every batch of this test suite but the full-size ones; VTX_SWEEP_V1=1: round 4's band_sweep_kernel (two passes) instead of round 5's; VTX_BAND_LEGACY=1: round 3's band_run_kernel / pending / general kernels instead of the sweep; VTX_BAND_CHECK=1: the full-matrix
@@ -219,8 +219,9 @@ def test_hooks_give_the_same_scores(hook):
     band_refine_kernel for the ones with main pieces only, the masked DP for the rest — instead of band_corridor_kernel;
     VTX_DIAG_FOUR_WORDS=1: band_diag_kernel's build for reads up to 256 bases on these batches of short reads (it is chosen by the
     batch's longest read); VTX_DIAG_NO_TWINS=1: band_diag_kernel probes every row that is not intact and unique instead of taking the
-    matches of the intact rows from the haplotype's twin list; VTX_DIAG_NO_T3=1: its pooled probes take a queue entry and a presence-bitmap
-    word per row instead of blocks of three rows and the tables' three-row sets.  Identical scores (separate processes: the hooks are read once)."""
+    matches of the intact rows from the haplotype's twin list; VTX_DIAG_T3=1: its pooled probes take blocks of three rows and the tables'
+    three-row sets whatever the depth, VTX_DIAG_NO_T3=1: never (by default from 16 tasks per locus: vtx_band.hip, band_use_t3) instead of a queue
+    entry and a presence-bitmap word per row.  Identical scores (separate processes: the hooks are read once)."""
     res = []
     with tempfile.TemporaryDirectory() as td:
         for on in (0, 1):
@@ -268,8 +269,14 @@ def _defined_bytes(tables, batch, n_heads=1024):
         out += [tb[:8 * nk], tb[max_hap * 8:bytes_off], tb[bytes_off:bytes_off + hn], tb[fb_off:fb_off + hn], tb[uq_off:pb_off + 512]]
         tw = tb[pb_off + 512:pb_off + 640]
         out += [tw[:1], tw[8:8 + 2 * (0 if tw[0] == 0xff else int(tw[0]))]]          # the twin list: its length, its pairs
-        out += [tb[pb_off + 640:pb_off + 640 + 2048]]                                 # the three-row sets
+        if _uses_t3(batch):
+            out += [tb[pb_off + 640:pb_off + 640 + 2048]]                             # the three-row sets
     return np.concatenate(out)
+
+
+def _uses_t3(batch):
+    """vtx_band.hip, band_use_t3: t3[] is built for batches of at least 16 tasks (8 reads) per locus on average."""
+    return (2 * batch.n_records) // max(batch.n_loci, 1) >= 16
 
 
 def _expected_t3_and_twins(hap):
@@ -299,7 +306,8 @@ def test_table_kernel_against_round3s():
             (b"ACG" * 67, b"ACG" * 33 + b"T" + b"ACG" * 33), (b"ACGTN" * 5 + b"\x90" + b"ACGGT" * 20, b"ACGTTGCA" * 12)]
     rds = [[(0, 0, h[0][20:170])] * 4 for h in haps]
     cases.append(("haplotypes of one repeated unit, a byte above 0x7f", SB.manual_batch(haps, rds, 10), 10))
-    checked = 0
+    cases.append(("twelve reads per locus (t3[] on)", synth.make_batch(synth.SynthSpec(n_loci=80, n_barcodes=100, reads_per_locus=12, seed=11)), 100))
+    checked = with_t3 = 0
     for label, batch, nb in cases:
         hl = np.maximum(batch.loci["ref_len"], batch.loci["alt_len"])
         if (hl > 255).any() and (hl <= 255).any() and int((hl > 255).sum()) * 8 <= batch.n_loci:
@@ -327,14 +335,16 @@ def test_table_kernel_against_round3s():
             off, hn = (int(L["alt_off"]), int(L["alt_len"])) if t & 1 else (int(L["ref_off"]), int(L["ref_len"]))
             t3, pairs = _expected_t3_and_twins(bytes(batch.hap_arena[off:off + hn]))
             tb = tp[t * stride:(t + 1) * stride]
-            assert np.array_equal(tb[pb_off + 640:pb_off + 640 + 2048].view(np.uint32), t3), (label, t)
+            if _uses_t3(batch):
+                assert np.array_equal(tb[pb_off + 640:pb_off + 640 + 2048].view(np.uint32), t3), (label, t)
+                with_t3 += 1
             tw = tb[pb_off + 512:pb_off + 640]
             if pairs is None:
                 assert tw[0] == 0xff, (label, t)
             else:
                 assert tw[0] == len(pairs) and [(int(tw[8 + 2 * i]), int(tw[9 + 2 * i])) for i in range(len(pairs))] == pairs, (label, t)
         checked += 1
-    assert checked >= 5
+    assert checked >= 5 and with_t3 >= 4, (checked, with_t3)
 
 
 CODE2 = r'''

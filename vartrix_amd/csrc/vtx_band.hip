@@ -1325,7 +1325,7 @@ __device__ __forceinline__ void build_tables(uint8_t* tables, uint32_t n_tab, ui
 // gtables[(locus - l0) * 2 * table_stride].
 __global__ __launch_bounds__(64) void band_tables_v1_kernel(const vtx_locus* __restrict__ loci, uint32_t l0, uint32_t n_loci,
                                                          const uint8_t* __restrict__ hap_arena, uint32_t max_hap,
-                                                         uint32_t table_stride, uint32_t n_heads, uint8_t* __restrict__ gtables) {
+                                                         uint32_t table_stride, uint32_t n_heads, uint8_t* __restrict__ gtables, uint32_t with_t3) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t s_hibyte;
     const int tid = threadIdx.x;
@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(64) void band_tables_v1_kernel(const vtx_locus* __r
             const vtx_locus loc = loci[l0 + l];
             const uint32_t hn = max(loc.ref_len, loc.alt_len) > max_hap ? 0u : (t ? loc.alt_len : loc.ref_len);
             build_twins_wave((uint8_t*)smem + (size_t)t * table_stride, hn, ((s_hibyte >> t) & 1u) != 0, max_hap, n_heads, tid);
-            build_t3_wave((uint8_t*)smem + (size_t)t * table_stride, hn, max_hap, n_heads, tid);
+            if (with_t3) build_t3_wave((uint8_t*)smem + (size_t)t * table_stride, hn, max_hap, n_heads, tid);
         }
         wave_sync();
         const uint4* src = (const uint4*)smem;
@@ -1960,7 +1960,9 @@ __global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __rest
 // =============================================================================================
 __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __restrict__ loci, uint32_t l0, uint32_t n_loci,
                                                          const uint8_t* __restrict__ hap_arena, uint32_t max_hap, uint32_t min_hap,
-                                                         uint32_t table_stride, uint32_t n_heads, uint8_t* __restrict__ gtables) {
+                                                         uint32_t table_stride, uint32_t n_heads, uint8_t* __restrict__ gtables, uint32_t with_t3) {
+    // with_t3 == 0: t3[] is neither built nor written (band_diag_kernel will not read it: vtxk_launch_band_diag decides per batch) —
+    // the kernel's time is the bytes it writes, and t3[] is 2 KB of a table's 7
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint8_t* tb = (uint8_t*)smem;
     const int tid = threadIdx.x;
@@ -1971,7 +1973,8 @@ __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __rest
     uint32_t* uq0 = TB_UQ(tb);
     uint32_t* pb = TB_PB(tb);
     const uint32_t hmask = n_heads - 1;
-    const uint32_t zero_words = (table_stride - vtxf::tab_uq_off(max_hap, n_heads)) / 4;   // uq[] and, behind it, pb[128], tw[] and t3[]
+    const uint32_t used_bytes = with_t3 ? table_stride : ((vtxf::tab_t3_off(max_hap, n_heads) + 15u) & ~15u);
+    const uint32_t zero_words = (used_bytes - vtxf::tab_uq_off(max_hap, n_heads)) / 4;     // uq[] and, behind it, pb[128], tw[] and t3[]
     for (uint32_t t = blockIdx.x; t < 2u * n_loci; t += gridDim.x) {
         const vtx_locus loc = loci[l0 + (t >> 1)];
         if (max(loc.ref_len, loc.alt_len) <= min_hap) continue;               // (a locus of the other pass: its table is never read; wave-uniform)
@@ -2041,7 +2044,7 @@ __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __rest
                 }
                 const uint32_t code = vtxf::kw_code(klo, khi);
                 atomicOr(&pb[code >> 5], 1u << (code & 31u));
-                if constexpr (vtxf::T3_BYTES != 0) {
+                if (vtxf::T3_BYTES != 0 && with_t3) {
                     atomicOr(&t3[vtxf::t3_word_a(code)], 1u << vtxf::t3_bit_a(code));
                     atomicOr(&t3[vtxf::t3_word_b(code)], 1u << vtxf::t3_bit_b(code));
                     atomicOr(&t3[vtxf::t3_word_c(code)], 1u << vtxf::t3_bit_c(code));
@@ -2087,7 +2090,7 @@ __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __rest
         wave_sync();
         const uint4* src = (const uint4*)smem;
         uint4* dst = (uint4*)(gtables + (size_t)t * table_stride);
-        for (uint32_t i = tid; i < table_stride / 16; i += 64) dst[i] = src[i];
+        for (uint32_t i = tid; i < used_bytes / 16; i += 64) dst[i] = src[i];
     }
 }
 
@@ -2298,8 +2301,8 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
     // rows around an error), and eight read bases hold three consecutive k-mers — the table's t3[] answers "is it in the haplotype" for
     // all three with one 8-byte load (vtx_fast_core.h).  The rows are cut into blocks that END at rows e = m - K (mod 3) (so no block
     // reaches beyond the read's last k-mer; the first may start before row 0: those rows are skipped); a queue entry is
-    // pair << 11 | the block's three membership bits << 8 | e, the blocks go to the pair's two lanes in turn.  (libvtx_dev.so, VTX_DIAG_NO_T3=1: a queue entry per row, even rows from the even lane, and pb[] — rounds 3 - 5.)
-    const bool t3_mode = vtxf::T3_BYTES != 0 && (VTX_DEVTOOLS_ON ? !(stats & 0x40000u) : true);
+    // pair << 11 | the block's three membership bits << 8 | e, the blocks go to the pair's two lanes in turn.  (Off for shallow batches — band_use_t3 —: a queue entry per row, even rows from the even lane, and pb[] — rounds 3 - 5.)
+    const bool t3_mode = vtxf::T3_BYTES != 0 && !(stats & 0x40000u);                // (per batch: vtxk_launch_band_diag, band_use_t3)
     vtxf::M192 nrows = live ? fr.need : vtxf::m_zero();             // (t3_mode: the pair's rows, kept for the membership bits)
     vtxf::M192 nd;
     {
@@ -2794,16 +2797,25 @@ static uint32_t gt_max_tpl() {
 // the tables of n_loci loci in global memory: band_tables_kernel (a table per wavefront); VTX_BAND_TABLES_V1=1: round 3's kernel
 // (a locus per wavefront, serial chain insertion) — the reference the new one is compared with byte for byte (tests)
 static void launch_band_tables(const vtx_locus* loci, uint32_t gt_l0, uint32_t n_loci, const uint8_t* hap_arena, uint32_t max_hap, uint32_t min_hap,
-                               size_t tstride, uint32_t n_heads, uint8_t* gtables, hipStream_t s) {
+                               size_t tstride, uint32_t n_heads, uint8_t* gtables, bool with_t3, hipStream_t s) {
 #ifdef VTX_DEVTOOLS
     if (VTX_DEV_ENV("VTX_BAND_TABLES_V1")) {
         hipLaunchKernelGGL(band_tables_v1_kernel, dim3(std::min(n_loci, 256u * 16u)), dim3(64), 2 * tstride, s, loci, gt_l0, n_loci,
-                           hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables);
+                           hap_arena, max_hap, (uint32_t)tstride, n_heads, gtables, with_t3 ? 1u : 0u);
         return;
     }
 #endif
     hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(2u * n_loci, 256u * 32u)), dim3(64), tstride, s, loci, gt_l0, n_loci,
-                           hap_arena, max_hap, min_hap, (uint32_t)tstride, n_heads, gtables);
+                           hap_arena, max_hap, min_hap, (uint32_t)tstride, n_heads, gtables, with_t3 ? 1u : 0u);
+}
+// Blocks of three rows and t3[] (vtx_fast_core.h): 2 KB more to write per table, whatever the depth.  Headline 14.67 ms per step without
+// them, 13.61 with (the blocks halve the queue's entries and balance them over a pair's lanes: one round instead of two); 250-base
+// reads 16.9 -> 15.7; at four reads per locus, where the tables are a third of the step, 1.57 ms without against 1.67 with, level at
+// sixteen.  Per batch: on from 16 tasks per locus.  (libvtx_dev.so: VTX_DIAG_T3=1 / VTX_DIAG_NO_T3=1 force it on / off.)
+static bool band_use_t3(uint32_t tasks_per_locus) {
+    if (vtxf::T3_BYTES == 0 || VTX_DEV_ENV("VTX_DIAG_NO_T3")) return false;
+    if (VTX_DEV_ENV("VTX_DIAG_T3")) return true;
+    return tasks_per_locus >= 16;
 }
 
 // buckets of a table's hash (power of two; experiment knob VTX_BAND_HEADS)
@@ -2903,7 +2915,7 @@ extern "C" hipError_t vtxk_launch_band_run(uint32_t n_tasks, uint32_t task_base,
     if (shmem > 160 * 1024 - 256) return hipErrorInvalidValue;
     if (task_list && !global_tables) return hipErrorInvalidValue;    // (list mode reads the tables the first pass built)
     if (global_tables && !task_list)
-        launch_band_tables(loci, gt_l0, n_loci, hap_arena, max_hap, min_hap, tstride, n_heads, gtables, s);
+        launch_band_tables(loci, gt_l0, n_loci, hap_arena, max_hap, min_hap, tstride, n_heads, gtables, false, s);
     const uint32_t ablate = (uint32_t)(VTX_DEV_ENV("VTX_BAND_ABLATE") ? atoi(VTX_DEV_ENV("VTX_BAND_ABLATE")) : 0);
     const uint32_t xcd_claim = ((tasks_per_locus >= 24 || VTX_DEV_ENV("VTX_BAND_XCD")) && !VTX_DEV_ENV("VTX_BAND_NO_XCD")) ? 1u : 0u;   // (measured: config 3 -3 %, 64 / 32 reads per locus -4.5 %, 16: -1 %, 4: +2 %)
 #define LAUNCH_RUN(NTV, GTV, WV, PV)                                                                                 \
@@ -2944,13 +2956,14 @@ extern "C" hipError_t vtxk_launch_band_diag(uint32_t n_tasks, uint32_t task_base
     const uint32_t n_heads = pick_heads(tasks_per_locus, true);
     const size_t tstride = band_table_stride(max_hap, n_heads);
     if (!gtables || (size_t)n_loci * 2 * tstride > gtables_bytes) return hipErrorInvalidValue;
-    launch_band_tables(loci, gt_l0, n_loci, hap_arena, max_hap, min_hap, tstride, n_heads, gtables, s);
+    const bool use_t3 = band_use_t3(tasks_per_locus);
+    launch_band_tables(loci, gt_l0, n_loci, hap_arena, max_hap, min_hap, tstride, n_heads, gtables, use_t3, s);
     const uint32_t n_blocks = (n_tasks + 255) / 256;
     const uint32_t st = (uint32_t)stats | (VTX_DEV_ENV("VTX_DIAG_ABLATE") ? (uint32_t)atoi(VTX_DEV_ENV("VTX_DIAG_ABLATE")) << 8 : 0u) |
                         (VTX_DEV_ENV("VTX_BAND_NO_CORRIDOR") ? 0x10000u : 0u) |         // (A/B hook: round 5's records for band_refine_kernel)
                         (VTX_DEV_ENV("VTX_DIAG_NO_TWINS") ? 0x20000u : 0u) |            // (A/B hook: every row that is not intact and unique is probed, the twin lists unused)
                         (VTX_DEV_ENV("VTX_DIAG_PHASES") ? 0x80000u : 0u) |
-                        (VTX_DEV_ENV("VTX_DIAG_NO_T3") ? 0x40000u : 0u);                // (A/B hook: a queue entry and a presence-bitmap word per row instead of t3[] and blocks of three rows)
+                        (use_t3 ? 0u : 0x40000u);                                       // (a queue entry and a presence-bitmap word per row instead of t3[] and blocks of three rows)
     // two-byte match entries (40 per task) whenever a haplotype position fits a byte; VTX_DIAG_WIDE=1 forces the four-byte variant (tests)
     static const bool force_wide = VTX_DEV_ENV("VTX_DIAG_WIDE") != nullptr;
     static const bool force_four = VTX_DEV_ENV("VTX_DIAG_FOUR_WORDS") != nullptr;      // (tests: the four-word build on short reads)
