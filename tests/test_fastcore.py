@@ -541,9 +541,7 @@ def test_whole_read_is_decided_whatever_else_matches(core):
     assert whole.sum() >= 45 and np.all(want[whole] == lens[whole])
     # (a whole read the stage does not decide found no diagonal: every 6-mer of a short-unit repeat is repeated, no sampled row gives a
     # candidate — those go on to band_sweep_kernel)
-    # (round 6: the first entry of a bucket with several k-mers is a candidate too — in a short-unit repeat it names a diagonal one or more
-    # units off, where the read matches for a stretch only: the task then leaves with more matches than a lane holds)
-    assert decided[whole].sum() >= 8 and set(why[whole & ~decided].tolist()) <= {2, 4}, {WHY[k]: int(v) for k, v in zip(*np.unique(why[whole], return_counts=True))}
+    assert decided[whole].sum() >= 8 and set(why[whole & ~decided].tolist()) <= {2}, {WHY[k]: int(v) for k, v in zip(*np.unique(why[whole], return_counts=True))}
 
 
 def test_band_trimmed_bound_decides_the_banded_score(core):
