@@ -2251,9 +2251,9 @@ __global__ __launch_bounds__(256, WPE) void band_diag_kernel(
             const int c_par = __shfl_xor(c_own, 1);
 #pragma unroll 1
             for (int u = 0; u < 2; ++u) {
-                const int ce = u ? c_par : c_own, dc = ce >> 1;              // (cand_diag: diagonal * 2 + weak)
-                if (have_d || ce == vtxf::NO_DIAG || dc < -(m - vtxf::K) || dc > n - vtxf::K) continue;
-                if (vtxf::verify_diag(x, m, tb, n, dc, (ce & 1) != 0)) { d = dc; have_d = true; }
+                const int dc = u ? c_par : c_own;
+                if (have_d || dc == vtxf::NO_DIAG || dc < -(m - vtxf::K) || dc > n - vtxf::K) continue;
+                if (vtxf::verify_diag(x, m, tb, n, dc)) { d = dc; have_d = true; }
             }
         }
         PH(2);                                                          // the search for the diagonal

@@ -496,22 +496,16 @@ VTXF_FN int cand_diag(const uint8_t* x, int row, const Tab& tb) {
     const uint64_t w8 = ld8(x + row);
     const uint32_t hh = kw_mix((uint32_t)w8, (uint32_t)(w8 >> 32) & 0xffffu);
     const uint32_t raw = ld2(tb.gt + tb.head + 2u * kw_bucket(hh, tb.hmask));
-    // (a bucket with several k-mers: its first entry is a candidate too — right half of the time when there are two, and a wrong one
-    //  costs the eight-base check; with single-entry buckets only, 4 % of the pairs needed a second round of the search and with
-    //  them 80 % of the wavefronts)
-    // Returns the diagonal * 2 + weak (weak: from a bucket with several k-mers — verify_diag then asks for all eight bases: a random
-    // diagonal passes six of eight once in 240 times, and its mask holds a quarter of the read's bases, more than the twenty asked for).
-    const uint32_t tag = raw >> 12;
-    if (raw == HEAD_END || (tag != HEAD_MULTI && tag != kw_tag(hh))) return NO_DIAG;
-    return (((int)(raw & 0xfffu) - row) << 1) | (tag == HEAD_MULTI ? 1 : 0);
+    if (raw == HEAD_END || (raw >> 12) != kw_tag(hh)) return NO_DIAG;
+    return (int)(raw & 0xfffu) - row;
 }
 // cheap check of a candidate diagonal before its whole mask is computed: 8 bases in the middle of the overlap, at least 6 of
 // them equal (a chance k-mer match elsewhere in the haplotype passes with probability ~1e-3)
-VTXF_FN bool verify_diag(const uint8_t* x, int m, const Tab& tb, int n, int dc, bool weak = false) {
+VTXF_FN bool verify_diag(const uint8_t* x, int m, const Tab& tb, int n, int dc) {
     const int vlo = imax(0, -dc), vhi = imin(m, n - dc);
     if (vhi - vlo < 20) return false;                     // (the mask must hold >= 20 matching bases anyway)
     const int p = vlo + ((vhi - vlo - 8) >> 1);
-    return __builtin_popcount(eq8(ld8(x + p), ld8(tb.gt + tb.bytes + (p + dc)))) >= (weak ? 8 : 6);
+    return __builtin_popcount(eq8(ld8(x + p), ld8(tb.gt + tb.bytes + (p + dc)))) >= 6;
 }
 template <class LN, int A = NW> VTXF_FN Front front_rest(const uint8_t* x, int m, const Tab& tb, int n, const LN& ln, int d, M192 M, bool tw = false);
 
@@ -523,11 +517,10 @@ template <class LN> VTXF_FN Front front(const uint8_t* x, int m, const Tab& tb, 
     int prev = NO_DIAG;
     const ReadWords rw = read_words(x, m);
     for (int t = 0; t < N_SAMPLES; ++t) {
-        const int ce = cand_diag(x, sample_row(t, m), tb);
-        if (ce == NO_DIAG || ce == prev) continue;
-        prev = ce;
-        const int dc = ce >> 1;
-        if (dc < -(m - K) || dc > n - K || !verify_diag(x, m, tb, n, dc, (ce & 1) != 0)) continue;
+        const int dc = cand_diag(x, sample_row(t, m), tb);
+        if (dc == NO_DIAG || dc == prev) continue;
+        prev = dc;
+        if (!verify_diag(x, m, tb, n, dc)) continue;
         const M192 Mc = diag_mask(rw, x, m, tb, n, dc);
         if (m_pop(Mc) >= 20) return front_rest(x, m, tb, n, ln, dc, Mc, tw);
     }
