@@ -199,6 +199,9 @@ def main():
     ap.add_argument("--barcodes", type=int, default=2000)
     ap.add_argument("--out", default="/tmp/vtx_e2e")
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--gap-seconds", type=float, default=3.0, help="pause in front of every timed CLI run: a process that starts while the driver "
+                    "still clears the ~20 GB of device memory the run before it released waits for that inside its first allocations "
+                    "(round 6: submit 0.25 s or 1.2 - 1.7 s, alternating, on back-to-back runs; the timed quantity is one run on an idle device)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     if args.fast:
@@ -215,7 +218,9 @@ def main():
         for th in args.more_threads:
             runs.append((["--prep", "device"], "--prep device, --threads %d" % th, th))
         runs = [r + (None,) for r in runs]
+        print("(%.1f s pause in front of every run: --gap-seconds)" % args.gap_seconds, flush=True)
         for extra, label, th, env in runs:
+            time.sleep(args.gap_seconds)
             out = run_cli_timed(args.out, fa, vcf, bam, bcs, th, extra, label, env)
             import hashlib
             texts.append(hashlib.sha256(open(out, "rb").read()).hexdigest())
