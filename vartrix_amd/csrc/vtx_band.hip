@@ -1961,8 +1961,9 @@ __global__ __launch_bounds__(256) void band_expand_kernel(const uint32_t* __rest
 __global__ __launch_bounds__(64) void band_tables_kernel(const vtx_locus* __restrict__ loci, uint32_t l0, uint32_t n_loci,
                                                          const uint8_t* __restrict__ hap_arena, uint32_t max_hap, uint32_t min_hap,
                                                          uint32_t table_stride, uint32_t n_heads, uint8_t* __restrict__ gtables, uint32_t with_t3) {
-    // with_t3 == 0: t3[] is neither built nor written (band_diag_kernel will not read it: vtxk_launch_band_diag decides per batch) —
-    // the kernel's time is the bytes it writes, and t3[] is 2 KB of a table's 7
+    // with_t3 == 0: t3[] is neither built nor written, and the launch leaves its 2 KB out of the workgroup's LDS (band_diag_kernel will not
+    // read it: vtxk_launch_band_diag decides per batch, band_use_t3) — the kernel's time is the bytes it writes and the tables in flight per
+    // CU.  (The twin lists stay: at four reads per locus they cost the table kernel 0.04 ms and save band_diag_kernel 0.1.)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint8_t* tb = (uint8_t*)smem;
     const int tid = threadIdx.x;
@@ -2805,7 +2806,8 @@ static void launch_band_tables(const vtx_locus* loci, uint32_t gt_l0, uint32_t n
         return;
     }
 #endif
-    hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(2u * n_loci, 256u * 32u)), dim3(64), tstride, s, loci, gt_l0, n_loci,
+    const size_t lds = with_t3 ? tstride : (size_t)((vtxf::tab_t3_off(max_hap, n_heads) + 15u) & ~15u);     // (the kernel's used_bytes)
+    hipLaunchKernelGGL(band_tables_kernel, dim3(std::min(2u * n_loci, 256u * 32u)), dim3(64), lds, s, loci, gt_l0, n_loci,
                            hap_arena, max_hap, min_hap, (uint32_t)tstride, n_heads, gtables, with_t3 ? 1u : 0u);
 }
 // Blocks of three rows and t3[] (vtx_fast_core.h): 2 KB more to write per table, whatever the depth.  Headline 14.67 ms per step without
